@@ -1,0 +1,153 @@
+"""ctypes binding of the C ABI in include/drm_hip.h (csrc/libdrm_hip.so).
+
+PyTorch is plumbing here: it owns the HBM buffers and the HIP stream; the
+kernels are launched on ``torch.cuda.current_stream()`` through plain pointers.
+``import torch`` must precede loading the library so that both share the HIP
+runtime that is already mapped into the process.
+
+There is no fallback: a missing library or a non-HIP tensor raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from .flatten import WalkProgram
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
+ABI_VERSION = 1
+
+RNEA_GRAVITY, RNEA_DAMPING = 1, 2
+
+
+class DrmWalk(ctypes.Structure):
+    """Mirror of ``struct drm_walk`` (include/drm_hip.h)."""
+    _fields_ = [("ops_f", ctypes.c_void_p), ("ops_i", ctypes.c_void_p),
+                ("n_ops", ctypes.c_int32), ("capacity", ctypes.c_int32),
+                ("n_dofs", ctypes.c_int32), ("n_slots", ctypes.c_int32),
+                ("dof_mask", ctypes.c_uint64)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea")
+
+
+def load_library(path: str = None):
+    """Load csrc/libdrm_hip.so (once) and declare the prototypes.  Raises NativeLibraryError if absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = path or os.environ.get("DRM_HIP_LIBRARY", LIB_PATH)
+        if not os.path.exists(path):
+            raise NativeLibraryError(
+                "native HIP library not found at %s — build it with `python __graft_entry__.py build` "
+                "(or `make -C differentiable-robot-model_amd/csrc`); there is no CPU fallback" % path)
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as err:
+            raise NativeLibraryError("cannot load %s: %s" % (path, err))
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        wp = ctypes.POINTER(DrmWalk)
+        lib.drm_abi_version.restype = ctypes.c_int
+        lib.drm_abi_version.argtypes = []
+        lib.drm_last_error.restype = ctypes.c_char_p
+        lib.drm_last_error.argtypes = []
+        lib.drm_fk.restype = ctypes.c_int
+        lib.drm_fk.argtypes = [wp, vp, i64, i32, vp, vp, vp]
+        lib.drm_fk_jacobian.restype = ctypes.c_int
+        lib.drm_fk_jacobian.argtypes = [wp, vp, i64, vp, vp, vp, vp, vp]
+        lib.drm_rnea.restype = ctypes.c_int
+        lib.drm_rnea.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
+        if lib.drm_abi_version() != ABI_VERSION:
+            raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
+        _lib = lib
+        return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = load_library().drm_last_error()
+        raise RuntimeError("drm_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+
+def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError("%s must be a tensor on a HIP device (got %s)" % (name, getattr(t, "device", type(t))))
+    if t.ndim != 2 or t.shape[1] != cols:
+        raise ValueError("%s must be [B, %d], got %s" % (name, cols, tuple(t.shape)))
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_dofs: int) -> DrmWalk:
+    rows = prog.capacity + 1
+    assert ops_f.is_cuda and ops_f.dtype == torch.float32 and ops_f.is_contiguous() and ops_f.shape[0] == rows
+    assert ops_i.is_cuda and ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[0] == rows
+    return DrmWalk(ops_f.data_ptr(), ops_i.data_ptr(), prog.n_ops, prog.capacity, n_dofs, prog.n_slots,
+                   prog.dof_mask)
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    B = q.shape[0]
+    pos = torch.empty(B, n_targets, 3, device=q.device, dtype=torch.float32)
+    quat = torch.empty(B, n_targets, 4, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return pos, quat
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_fk(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
+                          _stream(q.device)))
+    return pos, quat
+
+
+def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    B = q.shape[0]
+    pos = torch.empty(B, 3, device=q.device, dtype=torch.float32)
+    quat = torch.empty(B, 4, device=q.device, dtype=torch.float32)
+    lin = torch.empty(B, 3, n_dofs, device=q.device, dtype=torch.float32)
+    ang = torch.empty(B, 3, n_dofs, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return pos, quat, lin, ang
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_fk_jacobian(ctypes.byref(walk), q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(),
+                                   lin.data_ptr(), ang.data_ptr(), _stream(q.device)))
+    return pos, quat, lin, ang
+
+
+def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    qd = _dev_f32(qd, "qd", n_dofs)
+    qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+    B = q.shape[0]
+    if qd.shape[0] != B or (qdd is not None and qdd.shape[0] != B):
+        raise ValueError("q / qd / qdd batch sizes differ")
+    tau = torch.empty(B, n_dofs, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return tau
+    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(),
+                            qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
+                            _stream(q.device)))
+    return tau

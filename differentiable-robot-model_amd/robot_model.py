@@ -1,0 +1,383 @@
+"""Drop-in ``DifferentiableRobotModel`` for the FK / Jacobian / RNEA path on MI355X.
+
+Keeps the reference's Python method surface (reference
+``differentiable_robot_model/robot_model.py:87-790``): same constructor, same
+method names / argument meaning / return shapes, the ``tensor_check`` batching
+rules (robot_model.py:25-84), ``AssertionError`` / ``AttributeError`` /
+``KeyError`` behaviour, and the learnable-parameter mechanism
+(robot_model.py:669-713).  Underneath, the reference's per-link Python loops
+over tiny torch ops are replaced by:
+
+  host (this file + flatten.py)   URDF -> RobotSpec -> depth-first walk tables, once;
+  device (csrc/drm_kernels.hip)   one fused hand-written HIP kernel per API call,
+                                  reached through the C ABI of include/drm_hip.h.
+
+There is NO CPU compute path: the compute methods raise if the model does not
+live on a HIP device or if the native library is missing.
+"""
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import backend
+from .flatten import (OPF_DAMP, OPF_F, OPF_IO, OPF_MASS, OPF_MCOM, OPF_STRIDE, OPF_T, RobotSpec, WalkProgram,
+                      build_robot_spec, build_walk)
+from .rigid_body import DifferentiableRigidBody
+from .urdf_utils import URDFRobotModel
+
+robot_description_folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robot_data")
+
+
+def tensor_check(function):
+    """Input normalisation shared by all public compute methods.
+
+    Behaviour of the reference decorator of the same name (robot_model.py:25-84):
+    every ``torch.Tensor`` argument must be on the model's device type, have
+    ndim 1 or 2 and share one batch shape; 1-D inputs are promoted to ``[1, n]``
+    and Tensor / tuple results are stripped back (dict results pass through).
+    """
+
+    @dataclass
+    class BatchInfo:
+        shape: torch.Size = torch.Size([])
+        init: bool = False
+
+    def preprocess(arg, obj, info):
+        if type(arg) is torch.Tensor:
+            assert arg.device.type == obj._device.type, f"Input argument of different device as module: {arg}"
+            assert arg.ndim in [1, 2], "Input tensors must have ndim of 1 or 2."
+            if info.init:
+                assert info.shape == arg.shape[:-1], "Batch size mismatch between input tensors."
+            else:
+                info.init = True
+                info.shape = arg.shape[:-1]
+            if len(info.shape) == 0:
+                return arg.unsqueeze(0)
+        return arg
+
+    def postprocess(arg, info):
+        if type(arg) is torch.Tensor and info.init and len(info.shape) == 0:
+            return arg[0, ...]
+        return arg
+
+    def wrapper(self, *args, **kwargs):
+        info = BatchInfo()
+        p_args = [preprocess(a, self, info) for a in args]
+        p_kwargs = {k: preprocess(v, self, info) for k, v in kwargs.items()}
+        ret = function(self, *p_args, **p_kwargs)
+        if type(ret) is torch.Tensor:
+            return postprocess(ret, info)
+        if type(ret) is tuple:
+            return tuple(postprocess(r, info) for r in ret)
+        return ret
+
+    wrapper.__name__ = getattr(function, "__name__", "wrapper")
+    wrapper.__doc__ = function.__doc__
+    return wrapper
+
+
+@dataclass
+class _DeviceWalk:
+    program: WalkProgram
+    ops_i: torch.Tensor                 # int32 [cap+1, 8] on the model device
+    link_index: torch.Tensor            # int64 [n_ops] on the model device (gather index into the link table)
+    static_ops_f: Optional[torch.Tensor] = None
+
+
+class DifferentiableRobotModel(torch.nn.Module):
+    """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
+
+    def __init__(self, urdf_path: str, name="", device=None):
+        super().__init__()
+        self.name = name
+        if device is None:
+            # the reference defaults to CPU (robot_model.py:100-104); this engine only computes on a HIP
+            # device, so pick it when there is one
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self._device = torch.device(device)
+        if self._device.type == "cuda" and self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+
+        self._urdf_model = URDFRobotModel(urdf_path=urdf_path, device=self._device)
+        self._bodies = torch.nn.ModuleList()
+        self._n_dofs = 0
+        self._controlled_joints = []
+        self._name_to_idx_map = dict()
+
+        body_params, parent_names = [], []
+        # the joint is folded into its child link, as in the reference (robot_model.py:107-131)
+        for i, link in enumerate(self._urdf_model.robot.links):
+            params = self._urdf_model.get_body_parameters_from_urdf(i, link)
+            body = DifferentiableRigidBody(rigid_body_params=params, device=self._device)
+            if params["joint_type"] != "fixed":
+                body.joint_idx = self._n_dofs
+                self._n_dofs += 1
+                self._controlled_joints.append(i)
+            self._bodies.append(body)
+            self._name_to_idx_map[body.name] = i
+            body_params.append(params)
+            parent_names.append(None if i == 0 else self._urdf_model.get_name_of_parent_body(link.name))
+        for i, body in enumerate(self._bodies):
+            if i == 0:
+                continue
+            parent = self._bodies[self._name_to_idx_map[parent_names[i]]]
+            body.set_parent(parent)
+            parent.add_child(body)
+
+        self._spec: RobotSpec = build_robot_spec(body_params, parent_names)
+        self._learnable = set()          # {(link_idx, parameter_name)}
+        self._walks: Dict[tuple, _DeviceWalk] = {}
+        self._static_table: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ constants
+    def _link_table(self) -> torch.Tensor:
+        """[L, OPF_STRIDE] float32 table of per-link constants on the model device.
+
+        Built with torch ops from the bodies' parameter callables, so gradients
+        reach learnable parametrisations.  The arithmetic mirrors the reference:
+        R_fixed = (Rz(yaw) @ Ry(pitch)) @ Rx(roll)  (rigid_body.py:138-143, spatial_vector_algebra.py:14-53),
+        mcom = com * mass, I_o = I_c + mass * S(com) S(com)^T  (spatial_vector_algebra.py:321-327).
+        """
+        dev = self._device
+        L = len(self._bodies)
+        cat = lambda ts, shape: torch.stack([t.reshape(shape).to(dev) for t in ts])
+        rpy = cat([b.rot_angles() for b in self._bodies], (3,))
+        trans = cat([b.trans() for b in self._bodies], (3,))
+        mass = cat([b.inertia.mass() for b in self._bodies], (1,))
+        com = cat([b.inertia.com() for b in self._bodies], (3,))
+        inertia = cat([b.inertia.inertia_mat() for b in self._bodies], (3, 3))
+        zero1 = torch.zeros(1, device=dev)
+        damping = cat([b.joint_damping() if b.joint_damping() is not None else zero1 for b in self._bodies], (1,))
+
+        c, s = torch.cos(rpy), torch.sin(rpy)
+        one, zero = torch.ones(L, device=dev), torch.zeros(L, device=dev)
+        mat = lambda rows: torch.stack([torch.stack(r, dim=-1) for r in rows], dim=-2)
+        Rx = mat([[one, zero, zero], [zero, c[:, 0], -s[:, 0]], [zero, s[:, 0], c[:, 0]]])
+        Ry = mat([[c[:, 1], zero, s[:, 1]], [zero, one, zero], [-s[:, 1], zero, c[:, 1]]])
+        Rz = mat([[c[:, 2], -s[:, 2], zero], [s[:, 2], c[:, 2], zero], [zero, zero, one]])
+        F = (Rz @ Ry) @ Rx
+        S = mat([[zero, -com[:, 2], com[:, 1]], [com[:, 2], zero, -com[:, 0]], [-com[:, 1], com[:, 0], zero]])
+        Io = inertia + mass.reshape(L, 1, 1) * (S @ S.transpose(-2, -1))
+        mcom = com * mass
+        table = torch.cat([F.reshape(L, 9), trans, mass, mcom, Io.reshape(L, 9), damping,
+                           torch.zeros(L, OPF_STRIDE - 26, device=dev)], dim=1)
+        return table.to(torch.float32)
+
+    def _get_walk(self, key, targets=None, whole_tree=False) -> _DeviceWalk:
+        dw = self._walks.get(key)
+        if dw is None:
+            prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree)
+            dw = _DeviceWalk(
+                program=prog,
+                ops_i=torch.from_numpy(prog.ops_i).to(self._device).contiguous(),
+                link_index=torch.from_numpy(prog.links.astype("int64")).to(self._device),
+            )
+            self._walks[key] = dw
+        return dw
+
+    def _ops_f(self, dw: _DeviceWalk) -> torch.Tensor:
+        """[cap+1, OPF_STRIDE] constants gathered in walk order (cached while nothing is learnable)."""
+        if not self._learnable and dw.static_ops_f is not None:
+            return dw.static_ops_f
+        if self._learnable:
+            table = self._link_table()
+        else:
+            if self._static_table is None:
+                with torch.no_grad():
+                    self._static_table = self._link_table()
+            table = self._static_table
+        rows = dw.program.capacity + 1
+        pad = torch.zeros(rows - dw.program.n_ops, OPF_STRIDE, device=self._device)
+        ops_f = torch.cat([table.index_select(0, dw.link_index), pad], dim=0).contiguous()
+        if not self._learnable:
+            dw.static_ops_f = ops_f
+        return ops_f
+
+    def _require_device(self):
+        if self._device.type != "cuda":
+            raise RuntimeError(
+                "differentiable-robot-model_amd has no CPU compute path: construct the model with "
+                "device='cuda' on an MI355X (model device is %s)" % self._device)
+
+    # ------------------------------------------------------------------ FK
+    def _fk_targets(self, q: torch.Tensor, link_idxs: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pos [B,T,3], quat [B,T,4] of the given links (root targets filled with the identity pose)."""
+        self._require_device()
+        B = q.shape[0]
+        non_root = [i for i in link_idxs if i != 0]
+        pos = torch.zeros(B, len(link_idxs), 3, device=self._device)
+        quat = torch.zeros(B, len(link_idxs), 4, device=self._device)
+        quat[..., 3] = 1.0
+        if non_root:
+            dw = self._get_walk(("fk", tuple(non_root)), targets=non_root)
+            ops_f = self._ops_f(dw)
+            p, r = backend.fk(dw.program, ops_f, dw.ops_i, q, len(non_root), self._n_dofs)
+            if len(non_root) == len(link_idxs):
+                return p, r
+            cols = [k for k, i in enumerate(link_idxs) if i != 0]
+            pos[:, cols] = p
+            quat[:, cols] = r
+        return pos, quat
+
+    @tensor_check
+    def compute_forward_kinematics_all_links(self, q: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+        """{link_name: (pos [B,3], quat_xyzw [B,4])} for every link (robot_model.py:197-221)."""
+        assert q.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        idxs = list(range(len(self._bodies)))
+        pos, quat = self._fk_targets(q, idxs)
+        return {self._bodies[i].name: (pos[:, k], quat[:, k]) for k, i in enumerate(idxs)}
+
+    @tensor_check
+    def compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False
+                                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(pos [B,3], quat_xyzw [B,4]) of ``link_name`` (robot_model.py:223-248).
+
+        ``recursive`` selects between two implementations in the reference that return the same
+        pose on a fresh model; both map to the same kernel here.
+        """
+        assert q.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        idx = self._name_to_idx_map[link_name]
+        pos, quat = self._fk_targets(q, [idx])
+        return pos[:, 0], quat[:, 0]
+
+    # ------------------------------------------------------------------ Jacobian
+    @tensor_check
+    def compute_endeffector_jacobian(self, q: torch.Tensor, link_name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(lin_jac [B,3,n], ang_jac [B,3,n]) at the link origin, world frame (robot_model.py:626-667)."""
+        assert len(q.shape) == 2
+        assert q.shape[1] == self._n_dofs
+        _, _, lin, ang = self.compute_fk_and_jacobian(q, link_name)
+        return lin, ang
+
+    @tensor_check
+    def compute_fk_and_jacobian(self, q: torch.Tensor, link_name: str
+                                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(pos, quat, lin_jac, ang_jac) from ONE fused kernel launch.
+
+        The reference's ``compute_endeffector_jacobian`` runs the full FK first and throws the pose
+        away (robot_model.py:641); this returns it instead.
+        """
+        assert q.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        self._require_device()
+        idx = self._name_to_idx_map[link_name]
+        dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
+        ops_f = self._ops_f(dw)
+        return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+
+    # ------------------------------------------------------------------ inverse dynamics
+    @tensor_check
+    def compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,
+                                 include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
+                                 ) -> torch.Tensor:
+        """tau [B,n] achieving ``qdd_des`` (RNEA, robot_model.py:305-375)."""
+        assert q.ndim == 2
+        assert qd.ndim == 2
+        assert qdd_des.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        assert qd.shape[1] == self._n_dofs
+        assert qdd_des.shape[1] == self._n_dofs
+        self._require_device()
+        dw = self._get_walk(("tree",), whole_tree=True)
+        ops_f = self._ops_f(dw)
+        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd_des, bool(include_gravity), bool(use_damping),
+                            self._n_dofs)
+
+    @tensor_check
+    def compute_non_linear_effects(self, q: torch.Tensor, qd: torch.Tensor, include_gravity: Optional[bool] = True,
+                                   use_damping: Optional[bool] = True) -> torch.Tensor:
+        """Coriolis + centrifugal + gravity + damping torques = RNEA with qdd = 0 (robot_model.py:377-400)."""
+        assert q.ndim == 2 and qd.ndim == 2
+        assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs
+        self._require_device()
+        dw = self._get_walk(("tree",), whole_tree=True)
+        ops_f = self._ops_f(dw)
+        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, None, bool(include_gravity), bool(use_damping),
+                            self._n_dofs)
+
+    # ------------------------------------------------------------------ learnable parameters
+    def _get_parent_object_of_param(self, link_name: str, parameter_name: str):
+        body_idx = self._name_to_idx_map[link_name]
+        if parameter_name in ["trans", "rot_angles", "joint_damping"]:
+            return self._bodies[body_idx]
+        if parameter_name in ["mass", "inertia_mat", "com"]:
+            return self._bodies[body_idx].inertia
+        raise AttributeError(
+            "Invalid parameter name. Accepted parameter names are: "
+            "trans, rot_angles, joint_damping, mass, inertia_mat, com")
+
+    def make_link_param_learnable(self, link_name: str, parameter_name: str, parametrization: torch.nn.Module):
+        """Replace a URDF constant by a learnable module under the same attribute (robot_model.py:682-689)."""
+        parent_object = self._get_parent_object_of_param(link_name, parameter_name)
+        parent_object.__delattr__(parameter_name)
+        parent_object.add_module(parameter_name, parametrization.to(self._device))
+        self._learnable.add((self._name_to_idx_map[link_name], parameter_name))
+
+    def _learnable_module(self, link_name: str, parameter_name: str):
+        parent_object = self._get_parent_object_of_param(link_name, parameter_name)
+        module = getattr(parent_object, parameter_name)
+        assert isinstance(module, torch.nn.Module), f"{parameter_name} of {link_name} is not a learnable module."
+        return module
+
+    def freeze_learnable_link_param(self, link_name: str, parameter_name: str):
+        for param in self._learnable_module(link_name, parameter_name).parameters():
+            param.requires_grad = False
+
+    def unfreeze_learnable_link_param(self, link_name: str, parameter_name: str):
+        for param in self._learnable_module(link_name, parameter_name).parameters():
+            param.requires_grad = True
+
+    # ------------------------------------------------------------------ introspection
+    def get_joint_limits(self) -> List[Dict[str, float]]:
+        return [self._bodies[idx].get_joint_limits() for idx in self._controlled_joints]
+
+    def get_link_names(self) -> List[str]:
+        return [body.name for body in self._bodies]
+
+    def print_link_names(self) -> None:
+        for body in self._bodies:
+            print(body.name)
+
+    def print_learnable_params(self) -> None:
+        for name, param in self.named_parameters():
+            print(f"{name}: {param}")
+
+
+def _robot_path(rel):
+    return os.path.join(robot_description_folder, rel)
+
+
+class DifferentiableKUKAiiwa(DifferentiableRobotModel):
+    def __init__(self, device=None):
+        self.urdf_path = _robot_path("iiwa7.urdf")
+        self.learnable_rigid_body_config = None
+        self.name = "differentiable_kuka_iiwa"
+        super().__init__(self.urdf_path, self.name, device=device)
+
+
+class DifferentiableFrankaPanda(DifferentiableRobotModel):
+    def __init__(self, device=None):
+        self.urdf_path = _robot_path("panda_no_gripper.urdf")
+        self.learnable_rigid_body_config = None
+        self.name = "differentiable_franka_panda"
+        super().__init__(self.urdf_path, self.name, device=device)
+
+
+class DifferentiableTwoLinkRobot(DifferentiableRobotModel):
+    def __init__(self, device=None):
+        self.urdf_path = _robot_path("2link_robot.urdf")
+        self.learnable_rigid_body_config = None
+        self.name = "diff_2d_robot"
+        super().__init__(self.urdf_path, self.name, device=device)
+
+
+class DifferentiableTrifingerEdu(DifferentiableRobotModel):
+    def __init__(self, device=None):
+        self.urdf_path = _robot_path("trifinger_edu.urdf")
+        self.learnable_rigid_body_config = None
+        self.name = "trifinger_edu"
+        super().__init__(self.urdf_path, self.name, device=device)

@@ -1,0 +1,132 @@
+/*
+ * drm_hip.h — C ABI of the MI355X (gfx950) batched FK / Jacobian / RNEA engine.
+ *
+ * The reference (facebookresearch/differentiable-robot-model @ v1) has no FFI:
+ * its boundary for this path is the Python method surface of
+ * `DifferentiableRobotModel` (reference differentiable_robot_model/robot_model.py:87-754).
+ * Each entry point below is what a binding for one of those methods calls;
+ * the reference interface it replaces is cited per function.  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns 0 on
+ *     success or a negative DRM_ERR_* code, drm_last_error() (thread-local)
+ *     explains it.
+ *   - all data pointers are DEVICE pointers to contiguous row-major float32 /
+ *     int32 arrays owned by the caller (torch owns them in the Python host);
+ *     the library never allocates, frees, copies or synchronises.
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call is an
+ *     asynchronous launch on that stream and is re-entrant.
+ *   - one wavefront (64 lanes) owns a tile of 64 consecutive samples; a lane
+ *     owns one sample and walks the robot's flattened tree serially.
+ *
+ * The robot is handed over as a *walk*: the depth-first list of links a kernel
+ * has to visit (flattened on the host once per robot / target set, see
+ * differentiable-robot-model_amd/flatten.py) with their constants gathered in
+ * walk order, so every per-link constant is a wave-uniform scalar load.
+ */
+#ifndef DRM_HIP_H
+#define DRM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRM_ABI_VERSION 1
+
+/* ---- layout of one op (= one link) of a walk ---------------------------- */
+#define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
+#define DRM_OPF_F 0       /* [9] R_fixed = Rz(yaw)Ry(pitch)Rx(roll), row-major (rigid_body.py:138-143) */
+#define DRM_OPF_T 9       /* [3] joint origin xyz ("trans", rigid_body.py:48)                   */
+#define DRM_OPF_MASS 12   /* [1] link mass                                                     */
+#define DRM_OPF_MCOM 13   /* [3] mass * com                (spatial_vector_algebra.py:323)      */
+#define DRM_OPF_IO 16     /* [9] I_c + m S(c)S(c)^T        (spatial_vector_algebra.py:324-327)  */
+#define DRM_OPF_DAMP 25   /* [1] joint damping             (robot_model.py:368-373)             */
+
+#define DRM_OPI_STRIDE 8  /* int32 per op in ops_i                                             */
+#define DRM_OPI_DOF 0     /* DoF column driven by this link's joint, -1 = fixed joint          */
+#define DRM_OPI_AXIS 1    /* 0/1/2: joint rotates about local x/y/z (rigid_body.py:149-154)    */
+#define DRM_OPI_SIGN 2    /* +1/-1 = sign of the axis entry, 0 for fixed joints                */
+#define DRM_OPI_SRC 3     /* parent state: DRM_SRC_PREV, DRM_SRC_ROOT, or a save-slot index    */
+#define DRM_OPI_SAVE 4    /* save-slot this op's state is copied to (branch point), -1 = none  */
+#define DRM_OPI_OUT 5     /* output slot (target index) this op's pose is written to, -1 = none */
+#define DRM_OPI_LINK 6    /* link index in URDF <link> order (informational)                   */
+#define DRM_OPI_FLAGS 7   /* DRM_FLAG_*                                                        */
+
+#define DRM_SRC_PREV (-1) /* parent = previous op of the walk                                  */
+#define DRM_SRC_ROOT (-2) /* parent = the fixed root link (identity pose, zero velocity)       */
+#define DRM_FLAG_CHILD_IS_NEXT 1 /* op k+1 is a child of op k                                  */
+#define DRM_MAX_SLOTS 4   /* save slots compiled into the kernels                              */
+#define DRM_MAX_OPS 64    /* largest compiled walk capacity                                    */
+#define DRM_MAX_DOFS 64   /* largest supported number of DoF columns                           */
+
+/* flags of drm_rnea */
+#define DRM_RNEA_GRAVITY 1 /* base acceleration (0,0,+9.81)   (robot_model.py:344-350)         */
+#define DRM_RNEA_DAMPING 2 /* tau += damping * qd             (robot_model.py:368-373)         */
+
+/* error codes */
+#define DRM_OK 0
+#define DRM_ERR_INVALID (-1)     /* bad argument (NULL pointer, negative size, capacity ...)   */
+#define DRM_ERR_UNSUPPORTED (-2) /* walk larger than any compiled kernel                       */
+#define DRM_ERR_LAUNCH (-3)      /* HIP reported a launch error                                */
+
+/*
+ * A walk, as produced by flatten.build_walk().  ops_f / ops_i hold
+ * (capacity + 1) rows: n_ops valid ones, the rest padding the kernels may
+ * load but never use.
+ */
+typedef struct drm_walk {
+    const float *ops_f;   /* device [capacity + 1, DRM_OPF_STRIDE]                           */
+    const int32_t *ops_i; /* device [capacity + 1, DRM_OPI_STRIDE]                           */
+    int32_t n_ops;        /* links visited                                                   */
+    int32_t capacity;     /* 8, 16, 32 or 64: selects the compiled kernel                    */
+    int32_t n_dofs;       /* n = row width of q / qd / qdd / tau and Jacobian column count   */
+    int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS)                              */
+    uint64_t dof_mask;    /* bit d set <=> DoF d is driven by an op of this walk             */
+} drm_walk;
+
+int drm_abi_version(void);
+const char *drm_last_error(void);
+
+/*
+ * Forward kinematics of T target links.
+ * Replaces DifferentiableRobotModel.compute_forward_kinematics (robot_model.py:223-248:
+ * update_kinematic_state 139-195 + CoordinateTransform.get_quaternion
+ * spatial_vector_algebra.py:108-136) and, with T = all links,
+ * compute_forward_kinematics_all_links (robot_model.py:197-221).
+ *   q    [B, n]      joint angles
+ *   pos  [B, T, 3]   world position of each target link frame
+ *   quat [B, T, 4]   world orientation, xyzw
+ * Target t is the op whose DRM_OPI_OUT == t.
+ */
+int drm_fk(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets,
+           float *pos, float *quat, void *stream);
+
+/*
+ * FK + geometric Jacobian of ONE target link; the walk is the root->link chain
+ * and its last op is the target.
+ * Replaces DifferentiableRobotModel.compute_endeffector_jacobian (robot_model.py:626-667),
+ * which itself runs compute_forward_kinematics first (robot_model.py:641).
+ *   pos [B,3], quat [B,4] (either may be NULL), lin_jac / ang_jac [B, 3, n];
+ *   columns of DoFs that are not on the chain are written as zeros.
+ */
+int drm_fk_jacobian(const drm_walk *walk, const float *q, int64_t B,
+                    float *pos, float *quat, float *lin_jac, float *ang_jac, void *stream);
+
+/*
+ * Recursive Newton-Euler inverse dynamics over the whole tree.
+ * Replaces DifferentiableRobotModel.compute_inverse_dynamics (robot_model.py:305-375:
+ * update_kinematic_state + update_joint_acc rigid_body.py:159-165 +
+ * iterative_newton_euler robot_model.py:250-303).  With qdd = NULL the joint
+ * accelerations are zero: compute_non_linear_effects (robot_model.py:377-400).
+ *   q, qd, qdd [B, n]  ->  tau [B, n];  flags = DRM_RNEA_GRAVITY | DRM_RNEA_DAMPING
+ */
+int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B,
+             int32_t flags, float *tau, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRM_HIP_H */
