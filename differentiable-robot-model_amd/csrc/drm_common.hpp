@@ -1,0 +1,207 @@
+// drm_common.hpp — device-side tile I/O and host-side launch helpers shared by the kernels.
+//
+// Execution model:
+//   * one wavefront (64 lanes) owns a tile of 64 consecutive samples, one lane per sample;
+//     waves never talk to each other (no __syncthreads), so the block size is only a
+//     packing choice;
+//   * the API hands over row-major [B, n] / [B, 3, n] tensors (one ROW per sample), the
+//     lanes want one COLUMN element per lane.  Every tensor therefore crosses HBM exactly
+//     once with fully coalesced 16-byte accesses and is transposed through a wave-private
+//     LDS tile whose row stride is forced odd (S | 1), which makes both the row-per-lane
+//     accesses and the linear copy bank-conflict free;
+//   * everything derived from the wave index is made provably wave-uniform
+//     (readfirstlane) so tile bases live in SGPRs and per-lane offsets are 32-bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/drm_hip.h"
+
+namespace drm {
+
+constexpr int WAVE = 64;
+constexpr int MAX_WAVES_PER_BLOCK = 4;
+constexpr int MAX_LDS_BYTES = 160 * 1024;
+
+// Ordering point between LDS writes of some lanes and LDS reads of other lanes of the SAME
+// wave: the LDS executes a wave's instructions in order, so only the compiler must be kept
+// from reordering.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// keep a just-loaded value materialised HERE: stops the compiler from sinking the load into the
+// predicated block that consumes it (which would serialise load -> wait -> store per iteration)
+__device__ __forceinline__ void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+// Touch the first `LINES` 64-byte lines of every op of the walk table with scalar loads issued
+// back to back, so the (cold) misses overlap in ONE latency round instead of one per op.
+// Split in two so the kernel can put the q tile's global loads between issue and wait.
+template <int N>
+struct WarmRegs {
+    float x[N];
+};
+template <int CAP, int LINES>
+__device__ __forceinline__ void warm_walk_issue(const float *__restrict__ ops_f, WarmRegs<CAP * LINES> &w) {
+#pragma unroll
+    for (int i = 0; i < CAP * LINES; ++i) w.x[i] = ops_f[(i / LINES) * DRM_OPF_STRIDE + (i % LINES) * 16];
+}
+template <int N>
+__device__ __forceinline__ void warm_walk_wait(const WarmRegs<N> &w) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"s"(w.x[i]));
+}
+
+__host__ __device__ constexpr int pad_odd(int S) { return S | 1; }
+__host__ __device__ constexpr int round4(int x) { return (x + 3) & ~3; }
+// ceil(2^32 / S): floor(w / S) == umulhi(w, magic) for w * S < 2^32
+inline uint32_t div_magic(int S) {
+    return (S >= 2) ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)S - 1) / (uint64_t)S) : 0u;
+}
+
+// A [rows, S] row-major float tile (rows <= 64) in HBM <-> wave-private LDS with row stride
+// Sp = S | 1: word w of the tile lives at LDS word  w + (S even ? w / S : 0).
+__device__ __forceinline__ unsigned lds_word(unsigned w, bool padded, uint32_t magic) {
+    return padded ? w + __umulhi(w, magic) : w;
+}
+
+// ---- HBM -> LDS --------------------------------------------------------------------
+// fast: the tile is full (64 rows), S is odd (the LDS image is linear) and g is 16-byte
+// aligned -> float4 per lane.  S_CT > 0 fixes S at compile time (all loads are issued
+// before the first LDS write).
+template <int S_CT>
+__device__ __forceinline__ void tile_load(const float *__restrict__ g, int rows, int S_rt, uint32_t magic, float *lds,
+                                          unsigned lane, bool fast) {
+    const int S = S_CT ? S_CT : S_rt;
+    if (fast) {
+        const char *gb = reinterpret_cast<const char *>(g); // uniform base + 32-bit byte offset per lane
+        float4 *l4 = reinterpret_cast<float4 *>(lds);
+        const unsigned nvec = 16u * (unsigned)S;
+        if constexpr (S_CT > 0) {
+            // branch-free: every lane loads in every iteration (index clamped into the tile), so all
+            // loads are in flight before the first LDS write; only the LDS write is predicated
+            constexpr unsigned IT = (16u * S_CT + 63u) / 64u;
+            float4 v[IT];
+#pragma unroll
+            for (unsigned it = 0; it < IT; ++it) {
+                const unsigned i = lane + 64u * it;
+                v[it] = *reinterpret_cast<const float4 *>(gb + (i < nvec ? i : nvec - 1u) * 16u);
+            }
+#pragma unroll
+            for (unsigned it = 0; it < IT; ++it) pin(v[it]);
+#pragma unroll
+            for (unsigned it = 0; it < IT; ++it) {
+                const unsigned i = lane + 64u * it;
+                if ((it + 1u) * 64u <= nvec || i < nvec) l4[i] = v[it];
+            }
+        } else {
+#pragma unroll 2
+            for (unsigned i = lane; i < nvec; i += 64u) l4[i] = *reinterpret_cast<const float4 *>(gb + i * 16u);
+        }
+    } else {
+        const unsigned total = (unsigned)(rows * S);
+        const bool padded = !(S & 1);
+#pragma unroll 4
+        for (unsigned w = lane; w < total; w += 64u) lds[lds_word(w, padded, magic)] = g[w];
+    }
+}
+
+// ---- LDS -> HBM, same conventions ---------------------------------------------------
+template <int S_CT>
+__device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int S_rt, uint32_t magic, const float *lds,
+                                           unsigned lane, bool fast) {
+    const int S = S_CT ? S_CT : S_rt;
+    if (fast) {
+        char *gb = reinterpret_cast<char *>(g);
+        const float4 *l4 = reinterpret_cast<const float4 *>(lds);
+        const unsigned nvec = 16u * (unsigned)S;
+        if constexpr (S_CT > 0) {
+            constexpr unsigned IT = (16u * S_CT + 63u) / 64u;
+            float4 v[IT];
+#pragma unroll
+            for (unsigned it = 0; it < IT; ++it) {
+                const unsigned i = lane + 64u * it;
+                v[it] = l4[i < nvec ? i : nvec - 1u];
+            }
+#pragma unroll
+            for (unsigned it = 0; it < IT; ++it) {
+                const unsigned i = lane + 64u * it;
+                if ((it + 1u) * 64u <= nvec || i < nvec) *reinterpret_cast<float4 *>(gb + i * 16u) = v[it];
+            }
+        } else {
+#pragma unroll 2
+            for (unsigned i = lane; i < nvec; i += 64u) *reinterpret_cast<float4 *>(gb + i * 16u) = l4[i];
+        }
+    } else {
+        const unsigned total = (unsigned)(rows * S);
+        const bool padded = !(S & 1);
+#pragma unroll 4
+        for (unsigned w = lane; w < total; w += 64u) g[w] = lds[lds_word(w, padded, magic)];
+    }
+}
+
+struct WaveCtx {
+    unsigned lane;
+    int rows;    // valid samples of this tile (wave-uniform)
+    int64_t b0;  // first sample of this tile  (wave-uniform)
+    float *lds;  // wave-private LDS           (wave-uniform)
+    bool full;   // rows == 64
+};
+
+__device__ __forceinline__ bool wave_begin(int64_t B, int lds_floats_per_wave, float *smem, WaveCtx &cx) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    cx.lane = threadIdx.x & 63u;
+    const int64_t tile = (int64_t)blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    cx.b0 = tile * WAVE;
+    if (cx.b0 >= B) return false;
+    const int64_t left = B - cx.b0;
+    cx.rows = left < WAVE ? (int)left : WAVE;
+    cx.full = cx.rows == WAVE;
+    cx.lds = smem + wave * lds_floats_per_wave;
+    return true;
+}
+
+// alignment bits handed over by the launcher (bit set = pointer is 16-byte aligned)
+enum : uint32_t { AL_Q = 1, AL_QD = 2, AL_QDD = 4, AL_POS = 8, AL_QUAT = 16, AL_LIN = 32, AL_ANG = 64, AL_TAU = 128 };
+
+// ---- host side ----------------------------------------------------------------------
+int fail(int code, const char *fmt, const char *a = "", long b = 0, long c = 0);
+int check_walk(const drm_walk *w);
+int launched();
+
+static inline uint32_t al16(const void *p, uint32_t bit) { return (p && (((uintptr_t)p) & 15u) == 0) ? bit : 0u; }
+
+struct Geometry {
+    dim3 grid, block;
+    size_t lds_bytes;
+    int lds_per_wave; // floats
+};
+
+// waves per block: as many as fit a 64 KiB LDS budget (<= 4); one wave per 64 samples.
+int make_geometry(int64_t B, int lds_floats_per_wave, Geometry &g);
+
+template <class K>
+static int ensure_lds(K kernel, size_t bytes) {
+    if (bytes > (size_t)64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    return DRM_OK;
+}
+
+#define DRM_DISPATCH_CAP(cap, CALL)                  \
+    switch (cap) {                                   \
+    case 4: { constexpr int C = 4; CALL; } break;    \
+    case 8: { constexpr int C = 8; CALL; } break;    \
+    case 12: { constexpr int C = 12; CALL; } break;  \
+    case 16: { constexpr int C = 16; CALL; } break;  \
+    case 24: { constexpr int C = 24; CALL; } break;  \
+    default: { constexpr int C = 32; CALL; } break;  \
+    }
+
+} // namespace drm

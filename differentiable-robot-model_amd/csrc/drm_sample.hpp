@@ -2,10 +2,13 @@
 //
 // One lane of a wavefront owns one sample and runs these functions with the
 // walk's constants (ops_f / ops_i, include/drm_hip.h) as wave-uniform scalar
-// operands.  Every loop over ops is fully unrolled against the compile-time
-// capacity CAP and guarded by the (uniform) `k < n_ops`, so per-op state lives
-// in registers with compile-time indices and the only run-time-indexed
-// accesses are LDS reads/writes done by the accessor functors.
+// operands.  Walks are identity-padded to a compile-time capacity CAP and run
+// as STRAIGHT-LINE code: every loop over ops is fully unrolled, per-op state
+// (joint axes, origins, body forces) lives in registers with static indices,
+// and the only wave-uniform branches left are the rare ones (fixed joint,
+// branch point, target link).  Every joint rotates about its local z axis —
+// the host folds x / y axes into exact permutations of the constants
+// (flatten.py "axis canonicalisation").
 //
 // The arithmetic restates, per sample, what the reference spreads over
 // rigid_body.py:130-165, spatial_vector_algebra.py:14-136,175-338 and
@@ -32,13 +35,37 @@
 
 namespace drm {
 
+// ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.
+#define DRM_OPI(field, k) opi[(field) * CAP + (k)]
+
+// sin / cos of a joint angle, branch-free.  Argument reduction k = rint(x 2/pi),
+// r = x - k pi/2 is done in fp64 (two constants), which keeps r exact to fp32
+// rounding for |x| < ~1e9 without a slow path; the kernels then use degree-9/10
+// minimax polynomials on [-pi/4, pi/4] (coefficients of the classic fdlibm float
+// kernels) — max error ~1 ulp, i.e. the same class as torch.sin/cos on the CPU
+// (spatial_vector_algebra.py:14-53 evaluates them in fp32).
 DRM_HD void sincos_f(float x, float &s, float &c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincosf(x, &s, &c);
-#else
-    s = sinf(x);
-    c = cosf(x);
-#endif
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);   // 2/pi
+    double rd = fma(-kd, 1.57079632679489655800e+00, xd);    // pi/2 hi
+    rd = fma(-kd, 6.12323399573676603587e-17, rd);           // pi/2 lo
+    const float r = (float)rd;
+    const int q = (int)kd;
+    const float z = r * r;
+    float ps = fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f);
+    ps = fmaf(z, ps, 8.3333337680e-03f);
+    ps = fmaf(z, ps, -1.6666667163e-01f);
+    const float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f);
+    pc = fmaf(z, pc, -1.3888889225e-03f);
+    pc = fmaf(z, pc, 4.1666667908e-02f);
+    pc = fmaf(z, pc, -0.5f);
+    const float cr = fmaf(z, pc, 1.0f);
+    const bool swap = q & 1;
+    const float s0 = swap ? cr : sr;
+    const float c0 = swap ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 DRM_HD float rsqrt_f(float x) {
@@ -68,43 +95,60 @@ DRM_HD void matT_vec(const float *M, const float *x, float *y) {
     for (int c = 0; c < 3; ++c) y[c] = M[0 * 3 + c] * x[0] + M[1 * 3 + c] * x[1] + M[2 * 3 + c] * x[2];
 }
 
-// J = F * Rot_axis(theta), c = cos(theta), s = sin(theta) with theta = sign*q
-// (rigid_body.py:146-156, spatial_vector_algebra.py:14-53).  For a fixed joint
-// c = 1, s = 0 and J == F exactly.
-DRM_HD void joint_rot(const float *F, int axis, float c, float s, float *J) {
-    if (axis == 2) {
+// J = F * Rot_z(theta), c = cos(theta), s = sin(theta), theta = sign * q
+// (rigid_body.py:146-156, spatial_vector_algebra.py:42-53).  c = 1, s = 0 gives J == F exactly.
+DRM_HD void joint_rot_z(const float *__restrict__ F, float c, float s, float *J) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            J[r * 3 + 0] = F[r * 3 + 0] * c + F[r * 3 + 1] * s;
-            J[r * 3 + 1] = F[r * 3 + 1] * c - F[r * 3 + 0] * s;
-            J[r * 3 + 2] = F[r * 3 + 2];
-        }
-    } else if (axis == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            J[r * 3 + 0] = F[r * 3 + 0];
-            J[r * 3 + 1] = F[r * 3 + 1] * c + F[r * 3 + 2] * s;
-            J[r * 3 + 2] = F[r * 3 + 2] * c - F[r * 3 + 1] * s;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            J[r * 3 + 0] = F[r * 3 + 0] * c - F[r * 3 + 2] * s;
-            J[r * 3 + 1] = F[r * 3 + 1];
-            J[r * 3 + 2] = F[r * 3 + 0] * s + F[r * 3 + 2] * c;
-        }
+    for (int r = 0; r < 3; ++r) {
+        J[r * 3 + 0] = F[r * 3 + 0] * c + F[r * 3 + 1] * s;
+        J[r * 3 + 1] = F[r * 3 + 1] * c - F[r * 3 + 0] * s;
+        J[r * 3 + 2] = F[r * 3 + 2];
     }
 }
 
+struct Pose {
+    float R[9];
+    float p[3];
+};
+
 // world pose of a link from its parent's: R = Rp J, p = Rp t + pp
 // (robot_model.py:186, spatial_vector_algebra.py:98-103)
-DRM_HD void compose(const float *Rp, const float *pp, const float *J, const float *t, float *R, float *p) {
+DRM_HD void compose(const Pose &par, const float *J, const float *__restrict__ t, Pose &out) {
+    Pose tmp;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            R[r * 3 + c] = Rp[r * 3 + 0] * J[0 * 3 + c] + Rp[r * 3 + 1] * J[1 * 3 + c] + Rp[r * 3 + 2] * J[2 * 3 + c];
-        p[r] = Rp[r * 3 + 0] * t[0] + Rp[r * 3 + 1] * t[1] + Rp[r * 3 + 2] * t[2] + pp[r];
+            tmp.R[r * 3 + c] =
+                par.R[r * 3 + 0] * J[0 * 3 + c] + par.R[r * 3 + 1] * J[1 * 3 + c] + par.R[r * 3 + 2] * J[2 * 3 + c];
+        tmp.p[r] = par.R[r * 3 + 0] * t[0] + par.R[r * 3 + 1] * t[1] + par.R[r * 3 + 2] * t[2] + par.p[r];
+    }
+    out = tmp;
+}
+
+// child of the root link: the root pose is the identity, so R = J and p = t exactly
+DRM_HD void compose_root(const float *J, const float *__restrict__ t, Pose &out) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.R[i] = J[i];
+    out.p[0] = t[0]; out.p[1] = t[1]; out.p[2] = t[2];
+}
+
+DRM_HD void pose_identity(Pose &P) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    P.p[0] = P.p[1] = P.p[2] = 0.0f;
+}
+
+// undo the axis canonicalisation of a stored frame: R[:, pi(c)] = R~[:, c]
+// perm = 2: identity; 0: joint about x, pi = (1,2,0); 1: joint about y, pi = (2,0,1)
+DRM_HD void unpermute(int perm, float *R) {
+    if (perm != 2) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float a = R[r * 3 + 0], b = R[r * 3 + 1], c = R[r * 3 + 2];
+            if (perm == 0) { R[r * 3 + 1] = a; R[r * 3 + 2] = b; R[r * 3 + 0] = c; }
+            else           { R[r * 3 + 2] = a; R[r * 3 + 0] = b; R[r * 3 + 1] = c; }
+        }
     }
 }
 
@@ -143,123 +187,84 @@ DRM_HD void quat_xyzw(const float *R, float *q) {
     q[3] = w * scale;
 }
 
-struct Pose {
-    float R[9];
-    float p[3];
-};
-
-DRM_HD void pose_identity(Pose &P) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) P.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-    P.p[0] = P.p[1] = P.p[2] = 0.0f;
-}
-
-// cos / sigma*sin of every op's joint angle, computed up front so the
-// transcendental work is off the serial pose chain.
+// cos / sign*sin of every op's joint angle, computed up front so the transcendental work is
+// off the serial pose chain.  Branch-free on purpose (one basic block lets the compiler issue
+// every scalar load of the walk tables early): fixed joints and padding read DoF 0 and are
+// masked to c = 1, s = 0 (sign = 0).
 template <int CAP, class QF>
-DRM_HD void joint_trig(const int32_t *__restrict__ opi, int n_ops, QF qf, float *cs, float *sn) {
+DRM_HD void joint_trig(const int (&dof)[CAP], const int (&sign)[CAP], QF qf, float *cs, float *sn) {
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
-        cs[k] = 1.0f;
-        sn[k] = 0.0f;
-        if (k < n_ops) {
-            const int d = opi[k * DRM_OPI_STRIDE + DRM_OPI_DOF];
-            if (d >= 0) {
-                float s_, c_;
-                sincos_f(qf(d), s_, c_);
-                cs[k] = c_;
-                sn[k] = s_ * (float)opi[k * DRM_OPI_STRIDE + DRM_OPI_SIGN];
-            }
-        }
+        float c_, s_;
+        sincos_f(qf(dof[k] < 0 ? 0 : dof[k]), s_, c_);
+        cs[k] = dof[k] < 0 ? 1.0f : c_;
+        sn[k] = s_ * (float)sign[k];
     }
 }
 
-// One FK step of op k: world pose of the op's link from the parent pose `par`
-// (ignored when src == DRM_SRC_ROOT: the root pose is the identity, so R = J, p = t).
-DRM_HD void fk_step(const float *__restrict__ F, const float *__restrict__ t, int dof, int axis, int src, float c,
-                    float s, const Pose &par, Pose &out) {
-    float J[9];
-    if (dof >= 0) {
-        joint_rot(F, axis, c, s, J);
-    } else {
+// one field of the (field-major) int table for all ops: a single wide scalar load
+template <int CAP>
+DRM_HD void load_field(const int32_t *__restrict__ opi, int field, int (&out)[CAP]) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) J[i] = F[i];
-    }
-    if (src == DRM_SRC_ROOT) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) out.R[i] = J[i];
-        out.p[0] = t[0]; out.p[1] = t[1]; out.p[2] = t[2];
-    } else {
-        Pose tmp;
-        compose(par.R, par.p, J, t, tmp.R, tmp.p);
-        out = tmp;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Multi-target FK walk (robot_model.py:139-195 poses only, 223-248).
-//   qf(d)              -> joint angle of DoF d for this sample
-//   emit(t, Pose)      -> called once per target slot t
-// ---------------------------------------------------------------------------
-template <int CAP, class QF, class EMIT>
-DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int n_ops, QF qf, EMIT emit) {
-    float cs[CAP], sn[CAP];
-    joint_trig<CAP>(opi, n_ops, qf, cs, sn);
-    Pose cur, s0, s1, s2, s3;
-    pose_identity(cur);
-    s0 = cur; s1 = cur; s2 = cur; s3 = cur;
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-        if (k < n_ops) {
-            const int32_t *oi = opi + k * DRM_OPI_STRIDE;
-            const float *of = opf + k * DRM_OPF_STRIDE;
-            const int src = oi[DRM_OPI_SRC], save = oi[DRM_OPI_SAVE], out = oi[DRM_OPI_OUT];
-            Pose par = cur;
-            if (src == 0) par = s0;
-            else if (src == 1) par = s1;
-            else if (src == 2) par = s2;
-            else if (src == 3) par = s3;
-            fk_step(of + DRM_OPF_F, of + DRM_OPF_T, oi[DRM_OPI_DOF], oi[DRM_OPI_AXIS], src, cs[k], sn[k], par, cur);
-            if (save == 0) s0 = cur;
-            else if (save == 1) s1 = cur;
-            else if (save == 2) s2 = cur;
-            else if (save == 3) s3 = cur;
-            if (out >= 0) emit(out, cur);
-        }
-    }
+    for (int k = 0; k < CAP; ++k) out[k] = opi[field * CAP + k];
 }
 
 // ---------------------------------------------------------------------------
 // FK + geometric Jacobian along one chain (robot_model.py:626-667).
-// After the call: ee = pose of the last op (the target link), and for every
-// op k that drives a DoF: z[k] = R_k * (sign e_axis) (world joint axis),
-// pj[k] = p_k (world joint origin).  Column d = dof(k) of the Jacobian is
-// (z[k] x (ee.p - pj[k]), z[k]).
+// The walk is a chain: op 0 hangs off the root, op k off op k-1.  After the
+// call `ee` is the (canonical) pose of the last op, and for every op k:
+// z[k] = sign * R_k e_z (world joint axis), pj[k] = p_k (world joint origin).
+// Column d = dof(k) of the Jacobian is (z[k] x (ee.p - pj[k]), z[k]).
 // ---------------------------------------------------------------------------
 template <int CAP, class QF>
-DRM_HD void fk_chain(const float *__restrict__ opf, const int32_t *__restrict__ opi, int n_ops, QF qf, Pose &ee,
+DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], const int (&sign)[CAP], QF qf, Pose &ee,
                      float (&z)[CAP][3], float (&pj)[CAP][3]) {
     float cs[CAP], sn[CAP];
-    joint_trig<CAP>(opi, n_ops, qf, cs, sn);
-    pose_identity(ee);
+    joint_trig<CAP>(dof, sign, qf, cs, sn);
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
-        z[k][0] = z[k][1] = z[k][2] = 0.0f;
-        pj[k][0] = pj[k][1] = pj[k][2] = 0.0f;
-        if (k < n_ops) {
-            const int32_t *oi = opi + k * DRM_OPI_STRIDE;
-            const float *of = opf + k * DRM_OPF_STRIDE;
-            const int dof = oi[DRM_OPI_DOF], axis = oi[DRM_OPI_AXIS];
-            fk_step(of + DRM_OPF_F, of + DRM_OPF_T, dof, axis, k == 0 ? DRM_SRC_ROOT : DRM_SRC_PREV, cs[k], sn[k], ee,
-                    ee);
-            if (dof >= 0) {
-                const float sg = (float)oi[DRM_OPI_SIGN];
-                const float c0 = axis == 0 ? ee.R[0] : (axis == 1 ? ee.R[1] : ee.R[2]);
-                const float c1 = axis == 0 ? ee.R[3] : (axis == 1 ? ee.R[4] : ee.R[5]);
-                const float c2 = axis == 0 ? ee.R[6] : (axis == 1 ? ee.R[7] : ee.R[8]);
-                z[k][0] = c0 * sg; z[k][1] = c1 * sg; z[k][2] = c2 * sg;
-                pj[k][0] = ee.p[0]; pj[k][1] = ee.p[1]; pj[k][2] = ee.p[2];
-            }
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        float J[9];
+        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+        if (k == 0) compose_root(J, of + DRM_OPF_T, ee);
+        else compose(ee, J, of + DRM_OPF_T, ee);
+        const float sg = (float)sign[k];
+        z[k][0] = ee.R[2] * sg; z[k][1] = ee.R[5] * sg; z[k][2] = ee.R[8] * sg;
+        pj[k][0] = ee.p[0]; pj[k][1] = ee.p[1]; pj[k][2] = ee.p[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Multi-target FK walk over a (possibly branching) tree (robot_model.py:139-195
+// poses only, 223-248).
+//   qf(d)                  -> joint angle of DoF d for this sample
+//   slot_save(s, Pose) / slot_load(s, Pose&)   -> branch-point poses (kept in LDS by the kernel)
+//   emit(t, Pose)          -> called once per target slot t with the TRUE (un-permuted) pose
+// ---------------------------------------------------------------------------
+template <int CAP, class QF, class SAVE, class LOAD, class EMIT>
+DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, SAVE slot_save,
+                    LOAD slot_load, EMIT emit) {
+    int dof[CAP], sign[CAP];
+    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+    load_field<CAP>(opi, DRM_OPI_SIGN, sign);
+    float cs[CAP], sn[CAP];
+    joint_trig<CAP>(dof, sign, qf, cs, sn);
+    Pose cur;
+    pose_identity(cur);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
+        float J[9];
+        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+        if (src >= 0) slot_load(src, cur);
+        if (src == DRM_SRC_ROOT) compose_root(J, of + DRM_OPF_T, cur);
+        else compose(cur, J, of + DRM_OPF_T, cur);
+        if (save >= 0) slot_save(save, cur);
+        if (out >= 0) {
+            Pose P = cur;
+            unpermute(DRM_OPI(DRM_OPI_PERM, k), P.R);
+            emit(out, P);
         }
     }
 }
@@ -269,6 +274,7 @@ DRM_HD void fk_chain(const float *__restrict__ opf, const int32_t *__restrict__ 
 // coordinates at the link origin, as in the reference.
 //   qf(d, q, qd, qdd)   -> joint state of DoF d
 //   tau_out(d, value)   -> torque of DoF d
+//   motion / force slots: branch-point state, kept in LDS by the kernel
 // ---------------------------------------------------------------------------
 struct Motion {
     float w[3];  // angular velocity
@@ -277,160 +283,119 @@ struct Motion {
     float a[3];  // linear acceleration
 };
 
+struct Force {
+    float l[3]; // linear
+    float a[3]; // angular
+};
+
 DRM_HD void motion_root(Motion &M, float g) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) M.w[i] = M.v[i] = M.al[i] = M.a[i] = 0.0f;
     M.a[2] = g; // robot_model.py:344-350: gravity enters as a base acceleration (0,0,+9.81)
 }
 
-template <int CAP, class QF, class TAU>
-DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int n_ops, int flags, QF qf,
-                      TAU tau_out) {
+template <int CAP, class QF, class TAU, class MSAVE, class MLOAD, class FADD, class FTAKE>
+DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int flags, QF qf, TAU tau_out,
+                      MSAVE motion_save, MLOAD motion_load, FADD force_add, FTAKE force_take) {
     float cs[CAP], sn[CAP];
-    float fl[CAP][3], fa[CAP][3];
-    Motion cur, s0, s1, s2, s3, root;
-    motion_root(root, (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f);
-    cur = root; s0 = root; s1 = root; s2 = root; s3 = root;
+    Force f[CAP];
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    Motion cur;
+    motion_root(cur, g);
 
     // ---- forward sweep: velocities, accelerations, body forces -------------
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
-        cs[k] = 1.0f; sn[k] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) fl[k][i] = fa[k][i] = 0.0f;
-        if (k < n_ops) {
-            const int32_t *oi = opi + k * DRM_OPI_STRIDE;
-            const float *of = opf + k * DRM_OPF_STRIDE;
-            const int dof = oi[DRM_OPI_DOF], axis = oi[DRM_OPI_AXIS], src = oi[DRM_OPI_SRC], save = oi[DRM_OPI_SAVE];
-            const float sg = (float)oi[DRM_OPI_SIGN];
-            float q = 0.0f, qd = 0.0f, qdd = 0.0f;
-            float J[9];
-            if (dof >= 0) {
-                qf(dof, q, qd, qdd);
-                float s_, c_;
-                sincos_f(q, s_, c_);
-                cs[k] = c_;
-                sn[k] = s_ * sg;
-                joint_rot(of + DRM_OPF_F, axis, cs[k], sn[k], J);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) J[i] = of[DRM_OPF_F + i];
-            }
-            Motion P = cur;
-            if (src == DRM_SRC_ROOT) P = root;
-            else if (src == 0) P = s0;
-            else if (src == 1) P = s1;
-            else if (src == 2) P = s2;
-            else if (src == 3) P = s3;
-            const float *t = of + DRM_OPF_T;
-            // joint velocity / acceleration along the joint axis (rigid_body.py:133-136, 159-165)
-            const float wj = sg * qd, aj = sg * qdd;
-            float jv[3] = {axis == 0 ? wj : 0.0f, axis == 1 ? wj : 0.0f, axis == 2 ? wj : 0.0f};
-            float ja[3] = {axis == 0 ? aj : 0.0f, axis == 1 ? aj : 0.0f, axis == 2 ? aj : 0.0f};
-            // velocity (robot_model.py:189-193): w = J^T w_p + jv ; v = J^T (v_p + w_p x t)
-            float tmp[3], x[3];
-            Motion N;
-            matT_vec(J, P.w, N.w);
-            cross3(P.w, t, x);
-            tmp[0] = P.v[0] + x[0]; tmp[1] = P.v[1] + x[1]; tmp[2] = P.v[2] + x[2];
-            matT_vec(J, tmp, N.v);
-            N.w[0] += jv[0]; N.w[1] += jv[1]; N.w[2] += jv[2];
-            // acceleration (robot_model.py:269-277): al = J^T al_p + ja + w x jv ; a = J^T (a_p + al_p x t) + v x jv
-            matT_vec(J, P.al, N.al);
-            cross3(P.al, t, x);
-            tmp[0] = P.a[0] + x[0]; tmp[1] = P.a[1] + x[1]; tmp[2] = P.a[2] + x[2];
-            matT_vec(J, tmp, N.a);
-            cross3(N.w, jv, x);
-            N.al[0] += ja[0] + x[0]; N.al[1] += ja[1] + x[1]; N.al[2] += ja[2] + x[2];
-            cross3(N.v, jv, x);
-            N.a[0] += x[0]; N.a[1] += x[1]; N.a[2] += x[2];
-            cur = N;
-            if (save == 0) s0 = cur;
-            else if (save == 1) s1 = cur;
-            else if (save == 2) s2 = cur;
-            else if (save == 3) s3 = cur;
-            // body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
-            const float m = of[DRM_OPF_MASS];
-            const float *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
-            float hl[3], ha[3], gl[3], ga[3], y[3];
-            cross3(mc, N.w, x);
-            hl[0] = m * N.v[0] - x[0]; hl[1] = m * N.v[1] - x[1]; hl[2] = m * N.v[2] - x[2];
-            mat_vec(Io, N.w, y);
-            cross3(mc, N.v, x);
-            ha[0] = y[0] + x[0]; ha[1] = y[1] + x[1]; ha[2] = y[2] + x[2];
-            cross3(mc, N.al, x);
-            gl[0] = m * N.a[0] - x[0]; gl[1] = m * N.a[1] - x[1]; gl[2] = m * N.a[2] - x[2];
-            mat_vec(Io, N.al, y);
-            cross3(mc, N.a, x);
-            ga[0] = y[0] + x[0]; ga[1] = y[1] + x[1]; ga[2] = y[2] + x[2];
-            cross3(N.w, hl, x);
-            fl[k][0] = gl[0] + x[0]; fl[k][1] = gl[1] + x[1]; fl[k][2] = gl[2] + x[2];
-            cross3(N.w, ha, x);
-            cross3(N.v, hl, y);
-            fa[k][0] = ga[0] + (x[0] + y[0]); fa[k][1] = ga[1] + (x[1] + y[1]); fa[k][2] = ga[2] + (x[2] + y[2]);
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int dof = DRM_OPI(DRM_OPI_DOF, k), src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        float c_ = 1.0f, s_ = 0.0f, wj = 0.0f, aj = 0.0f;
+        if (dof >= 0) {
+            const float sg = (float)DRM_OPI(DRM_OPI_SIGN, k);
+            float q, qd, qdd;
+            qf(dof, q, qd, qdd);
+            sincos_f(q, s_, c_);
+            s_ *= sg;
+            wj = sg * qd;   // joint velocity / acceleration along the joint axis
+            aj = sg * qdd;  // (rigid_body.py:133-136, 159-165)
         }
+        cs[k] = c_;
+        sn[k] = s_;
+        float J[9];
+        joint_rot_z(of + DRM_OPF_F, c_, s_, J);
+        if (src == DRM_SRC_ROOT) motion_root(cur, g);
+        if (src >= 0) motion_load(src, cur);
+        const float *t = of + DRM_OPF_T;
+        // velocity (robot_model.py:189-193): w = J^T w_p + wj e_z ; v = J^T (v_p + w_p x t)
+        float tmp[3], x[3];
+        Motion N;
+        matT_vec(J, cur.w, N.w);
+        cross3(cur.w, t, x);
+        tmp[0] = cur.v[0] + x[0]; tmp[1] = cur.v[1] + x[1]; tmp[2] = cur.v[2] + x[2];
+        matT_vec(J, tmp, N.v);
+        N.w[2] += wj;
+        // acceleration (robot_model.py:269-277): al = J^T al_p + aj e_z + w x (wj e_z) ; a = J^T (a_p + al_p x t) + v x (wj e_z)
+        matT_vec(J, cur.al, N.al);
+        cross3(cur.al, t, x);
+        tmp[0] = cur.a[0] + x[0]; tmp[1] = cur.a[1] + x[1]; tmp[2] = cur.a[2] + x[2];
+        matT_vec(J, tmp, N.a);
+        N.al[0] += N.w[1] * wj; N.al[1] -= N.w[0] * wj; N.al[2] += aj;
+        N.a[0] += N.v[1] * wj;  N.a[1] -= N.v[0] * wj;
+        cur = N;
+        if (save >= 0) motion_save(save, cur);
+        // body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
+        const float m = of[DRM_OPF_MASS];
+        const float *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
+        float hl[3], ha[3], gl[3], ga[3], y[3];
+        cross3(mc, N.w, x);
+        hl[0] = m * N.v[0] - x[0]; hl[1] = m * N.v[1] - x[1]; hl[2] = m * N.v[2] - x[2];
+        mat_vec(Io, N.w, y);
+        cross3(mc, N.v, x);
+        ha[0] = y[0] + x[0]; ha[1] = y[1] + x[1]; ha[2] = y[2] + x[2];
+        cross3(mc, N.al, x);
+        gl[0] = m * N.a[0] - x[0]; gl[1] = m * N.a[1] - x[1]; gl[2] = m * N.a[2] - x[2];
+        mat_vec(Io, N.al, y);
+        cross3(mc, N.a, x);
+        ga[0] = y[0] + x[0]; ga[1] = y[1] + x[1]; ga[2] = y[2] + x[2];
+        cross3(N.w, hl, x);
+        f[k].l[0] = gl[0] + x[0]; f[k].l[1] = gl[1] + x[1]; f[k].l[2] = gl[2] + x[2];
+        cross3(N.w, ha, x);
+        cross3(N.v, hl, y);
+        f[k].a[0] = ga[0] + (x[0] + y[0]); f[k].a[1] = ga[1] + (x[1] + y[1]); f[k].a[2] = ga[2] + (x[2] + y[2]);
     }
 
     // ---- backward sweep: accumulate forces towards the root ----------------
-    float cl[3] = {0, 0, 0}, ca[3] = {0, 0, 0};
-    float l0[3] = {0, 0, 0}, a0[3] = {0, 0, 0}, l1[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
-    float l2[3] = {0, 0, 0}, a2[3] = {0, 0, 0}, l3[3] = {0, 0, 0}, a3[3] = {0, 0, 0};
+    Force carry = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
-        if (k < n_ops) {
-            const int32_t *oi = opi + k * DRM_OPI_STRIDE;
-            const float *of = opf + k * DRM_OPF_STRIDE;
-            const int dof = oi[DRM_OPI_DOF], axis = oi[DRM_OPI_AXIS], src = oi[DRM_OPI_SRC], save = oi[DRM_OPI_SAVE];
-            float tl[3] = {fl[k][0], fl[k][1], fl[k][2]}, ta[3] = {fa[k][0], fa[k][1], fa[k][2]};
-            if (oi[DRM_OPI_FLAGS] & DRM_FLAG_CHILD_IS_NEXT) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int dof = DRM_OPI(DRM_OPI_DOF, k), src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        Force tot = f[k];
+        if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { tl[i] += cl[i]; ta[i] += ca[i]; }
-            }
-#define DRM_TAKE_SLOT(L_, A_)                                                  \
-    {                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                        \
-            tl[i] += L_[i]; ta[i] += A_[i]; L_[i] = 0.0f; A_[i] = 0.0f;        \
-        }                                                                      \
-    }
-            if (save == 0) DRM_TAKE_SLOT(l0, a0)
-            else if (save == 1) DRM_TAKE_SLOT(l1, a1)
-            else if (save == 2) DRM_TAKE_SLOT(l2, a2)
-            else if (save == 3) DRM_TAKE_SLOT(l3, a3)
-#undef DRM_TAKE_SLOT
-            float J[9];
-            if (dof >= 0) {
-                // tau = sign * f.ang[axis] (+ damping * qd)   (robot_model.py:353-373)
+            for (int i = 0; i < 3; ++i) { tot.l[i] += carry.l[i]; tot.a[i] += carry.a[i]; }
+        }
+        if (save >= 0) force_take(save, tot); // += children that hang off this branch point, slot reset to 0
+        if (dof >= 0) {
+            // tau = sign * f.ang[axis] (+ damping * qd)   (robot_model.py:353-373)
+            float tau = (float)DRM_OPI(DRM_OPI_SIGN, k) * tot.a[2];
+            if (flags & DRM_RNEA_DAMPING) {
                 float q, qd, qdd;
                 qf(dof, q, qd, qdd);
-                float tau = (float)oi[DRM_OPI_SIGN] * (axis == 0 ? ta[0] : (axis == 1 ? ta[1] : ta[2]));
-                if (flags & DRM_RNEA_DAMPING) tau += of[DRM_OPF_DAMP] * qd;
-                tau_out(dof, tau);
-                joint_rot(of + DRM_OPF_F, axis, cs[k], sn[k], J);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) J[i] = of[DRM_OPF_F + i];
+                tau += of[DRM_OPF_DAMP] * qd;
             }
-            if (src != DRM_SRC_ROOT) {
-                // force.transform(joint_pose) (spatial_vector_algebra.py:281-291): lin = J f ; ang = t x (J f) + J n
-                float gl[3], ga[3], x[3];
-                mat_vec(J, tl, gl);
-                mat_vec(J, ta, ga);
-                cross3(of + DRM_OPF_T, gl, x);
-                ga[0] += x[0]; ga[1] += x[1]; ga[2] += x[2];
-                if (src == DRM_SRC_PREV) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { cl[i] = gl[i]; ca[i] = ga[i]; }
-                }
-#define DRM_ADD_SLOT(L_, A_)                                                   \
-    {                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) { L_[i] += gl[i]; A_[i] += ga[i]; } \
-    }
-                else if (src == 0) DRM_ADD_SLOT(l0, a0)
-                else if (src == 1) DRM_ADD_SLOT(l1, a1)
-                else if (src == 2) DRM_ADD_SLOT(l2, a2)
-                else if (src == 3) DRM_ADD_SLOT(l3, a3)
-#undef DRM_ADD_SLOT
-            }
+            tau_out(dof, tau);
+        }
+        if (src != DRM_SRC_ROOT) {
+            // force.transform(joint_pose) (spatial_vector_algebra.py:281-291): lin = J f ; ang = t x (J f) + J n
+            float J[9], x[3];
+            joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+            Force up;
+            mat_vec(J, tot.l, up.l);
+            mat_vec(J, tot.a, up.a);
+            cross3(of + DRM_OPF_T, up.l, x);
+            up.a[0] += x[0]; up.a[1] += x[1]; up.a[2] += x[2];
+            if (src >= 0) force_add(src, up);
+            else carry = up;
         }
     }
 }

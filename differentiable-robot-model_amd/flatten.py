@@ -10,18 +10,31 @@ tree is flattened ONCE at model construction:
   WalkProgram    a depth-first "walk program" over the sub-tree a kernel needs
                  (the root->target chain for FK/Jacobian, the union of chains
                  for multi-target FK, the whole tree for RNEA).  Every op is one
-                 link; its parent pose comes either from the previous op
+                 link; its parent state comes from the previous op
                  (``SRC_PREV``), from the identity root (``SRC_ROOT``) or from a
-                 numbered save slot written by an earlier branch-point op.  All
-                 of that is wave-uniform data the kernel reads through scalar
-                 loads, so one compiled kernel serves every robot.
+                 numbered save slot written by an earlier branch-point op.  The
+                 walk is padded with identity ops up to a compiled capacity so
+                 the kernels run it as straight-line code.
+
+Axis canonicalisation (exact, no rounding): the reference rotates a joint about
+its local x, y or z axis (rigid_body.py:149-154).  With the cyclic permutation
+matrix P_a (P_a e_z = e_a) one has Rot_a(q) = P_a Rot_z(q) P_a^T, so storing each
+link frame with permuted columns, R~_i = R_i P_i, turns every joint into a
+rotation about local z:   R~_i = R~_p (P_p^T F_i P_i) Rot_z(s q),   p_i = R~_p (P_p^T t_i) + p_p.
+Permuting rows/columns of the constants is a pure re-indexing, so the kernels
+compute bit-identical products without any per-axis branch; body-frame
+quantities (com, inertia) are re-indexed the same way, and a target link's
+columns are un-permuted when its pose is emitted.
 
 Device layout of one op (see include/drm_hip.h, DRM_OPF_* / DRM_OPI_*):
   ops_f[k, 0:32] float32: F(9) t(3) mass(1) mcom(3) Io(9) damping(1) pad(6)
-  ops_i[k, 0:8 ] int32  : dof axis sign src save out link flags
+  ops_i[0:8, k ] int32  : dof perm sign src save out link flags   (FIELD-MAJOR on the device:
+                          one scalar load fetches one field of many ops)
+``gather`` maps every ops_f entry to a flat index of the [L+1, 32] link table
+(row L = the identity op), so the device table is ONE differentiable gather.
 """
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -29,12 +42,16 @@ import numpy as np
 OPF_STRIDE = 32
 OPF_F, OPF_T, OPF_MASS, OPF_MCOM, OPF_IO, OPF_DAMP = 0, 9, 12, 13, 16, 25
 OPI_STRIDE = 8
-OPI_DOF, OPI_AXIS, OPI_SIGN, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
+OPI_DOF, OPI_PERM, OPI_SIGN, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
 FLAG_CHILD_IS_NEXT = 1               # op k+1 is a child of op k (RNEA backward carry)
-MAX_SLOTS = 4                        # save slots compiled into the kernels
-MAX_OPS = 64                         # largest compiled capacity (ops per walk)
+MAX_SLOTS = 4                        # save slots available to a walk
+CAPACITIES = (4, 8, 12, 16, 24, 32)  # compiled walk capacities
+MAX_OPS = CAPACITIES[-1]
 MAX_DOFS = 64                        # DoF columns addressable by one walk
+
+# _PERM[a][c] = index pi_a(c) with P_a e_c = e_{pi_a(c)};  (M P_a)[:, c] = M[:, pi_a(c)]
+_PERM = {0: (1, 2, 0), 1: (2, 0, 1), 2: (0, 1, 2)}
 
 
 class UnsupportedRobotError(ValueError):
@@ -49,7 +66,7 @@ class RobotSpec:
     axis_idx: np.ndarray          # int32 [L], 0/1/2 (2 for fixed joints, like rb.py:149-154's fall-through)
     axis_sign: np.ndarray         # int32 [L], +1/-1 (0 for fixed joints)
     controlled: List[int]         # link index of each DoF column (= reference _controlled_joints)
-    # float32 snapshots of the URDF constants (used when nothing is learnable, and by the oracle)
+    # float32 snapshots of the URDF constants (used by the oracle and by tests)
     rpy: np.ndarray               # [L,3]
     trans: np.ndarray             # [L,3]
     axis: np.ndarray              # [L,3]
@@ -75,6 +92,12 @@ class RobotSpec:
             chain.append(i)
             i = int(self.parent[i])
         return chain[::-1]
+
+    def perm_of(self, link: int):
+        """Column permutation of the stored frame of ``link`` (identity for fixed joints / root)."""
+        if link <= 0 or self.dof[link] < 0:
+            return _PERM[2]
+        return _PERM[int(self.axis_idx[link])]
 
 
 def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optional[str]]) -> RobotSpec:
@@ -132,8 +155,10 @@ def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optiona
 
 @dataclass
 class WalkProgram:
-    links: np.ndarray        # int32 [nops]  link index of every op
-    ops_i: np.ndarray        # int32 [nops_padded, OPI_STRIDE]
+    links: np.ndarray        # int32 [n_ops]  link index of every op
+    ops_i: np.ndarray        # int32 [capacity, OPI_STRIDE]   (identity-padded, op-major: host-side view)
+    ops_i_dev: np.ndarray    # int32 [OPI_STRIDE, capacity]   field-major copy = the device layout
+    gather: np.ndarray       # int64 [capacity, OPF_STRIDE]   flat indices into the [L+1, OPF_STRIDE] link table
     n_ops: int
     n_slots: int
     capacity: int            # compiled kernel capacity that fits n_ops
@@ -141,14 +166,30 @@ class WalkProgram:
     dof_mask: int            # bit d set <=> DoF d is driven by some op of this walk
 
 
-_CAPACITIES = (8, 16, 32, 64)
-
-
 def _capacity_for(n_ops: int) -> int:
-    for c in _CAPACITIES:
+    for c in CAPACITIES:
         if n_ops <= c:
             return c
-    raise UnsupportedRobotError("walk of %d links exceeds the largest compiled capacity %d" % (n_ops, _CAPACITIES[-1]))
+    raise UnsupportedRobotError(
+        "walk of %d links exceeds the largest compiled capacity %d" % (n_ops, CAPACITIES[-1]))
+
+
+def _gather_row(spec: RobotSpec, link: int) -> np.ndarray:
+    """Flat link-table indices of one op's constants, with the axis canonicalisation applied."""
+    base = link * OPF_STRIDE
+    pp = spec.perm_of(int(spec.parent[link]))   # rows of F / t follow the parent's stored frame
+    pi = spec.perm_of(link)                     # columns of F and body-frame quantities follow this link's
+    row = np.empty(OPF_STRIDE, np.int64)
+    for r in range(3):
+        for c in range(3):
+            row[OPF_F + r * 3 + c] = base + OPF_F + pp[r] * 3 + pi[c]
+            row[OPF_IO + r * 3 + c] = base + OPF_IO + pi[r] * 3 + pi[c]
+        row[OPF_T + r] = base + OPF_T + pp[r]
+        row[OPF_MCOM + r] = base + OPF_MCOM + pi[r]
+    row[OPF_MASS] = base + OPF_MASS
+    for k in range(OPF_DAMP, OPF_STRIDE):
+        row[k] = base + k
+    return row
 
 
 def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False) -> WalkProgram:
@@ -163,13 +204,11 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
             needed[i] = True
     out_of = {}
     for slot, t in enumerate(tlist):
-        out_of.setdefault(t, []).append(slot)
-    for t, slots in out_of.items():
-        if len(slots) > 1:
+        if t in out_of:
             raise ValueError("duplicate target link %s" % spec.link_names[t])
+        out_of[t] = slot
 
-    ops = []      # rows of ops_i
-    links = []
+    ops, links = [], []
     free_slots = list(range(MAX_SLOTS))[::-1]
     max_used = 0
 
@@ -184,8 +223,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
             save = free_slots.pop()
             max_used = max(max_used, MAX_SLOTS - len(free_slots))
         flags = FLAG_CHILD_IS_NEXT if kids else 0
-        out = out_of[i][0] if i in out_of else -1
-        ops.append([int(spec.dof[i]), int(spec.axis_idx[i]), int(spec.axis_sign[i]), src, save, out, i, flags])
+        perm = int(spec.axis_idx[i]) if spec.dof[i] >= 0 else 2
+        ops.append([int(spec.dof[i]), perm, int(spec.axis_sign[i]), src, save, out_of.get(i, -1), i, flags])
         links.append(i)
         for n, c in enumerate(kids):
             visit(c, SRC_PREV if n == 0 else save)
@@ -199,18 +238,35 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
             visit(c, SRC_ROOT)
     # a target that IS the root has no op: handled by the caller (identity pose)
     n_ops = len(ops)
+    if spec.n_dofs > MAX_DOFS:
+        raise UnsupportedRobotError("%d DoFs exceed the supported maximum %d" % (spec.n_dofs, MAX_DOFS))
     cap = _capacity_for(max(n_ops, 1))
-    ops_i = np.zeros((cap + 1, OPI_STRIDE), np.int32)
+    # identity padding: fixed joint, F = I, t = 0, mass-less, chained to the previous op
+    ops_i = np.zeros((cap, OPI_STRIDE), np.int32)
     ops_i[:, OPI_DOF] = -1
-    ops_i[:, OPI_SRC] = SRC_ROOT
+    ops_i[:, OPI_PERM] = 2
+    ops_i[:, OPI_SRC] = SRC_PREV
     ops_i[:, OPI_SAVE] = -1
     ops_i[:, OPI_OUT] = -1
+    ops_i[:, OPI_LINK] = -1
+    ident = L * OPF_STRIDE + np.arange(OPF_STRIDE, dtype=np.int64)
+    gather = np.tile(ident, (cap, 1))
     if n_ops:
         ops_i[:n_ops] = np.asarray(ops, np.int32)
+        for k, link in enumerate(links):
+            gather[k] = _gather_row(spec, link)
+    else:
+        ops_i[0, OPI_SRC] = SRC_ROOT
     mask = 0
     for row in ops:
         if row[OPI_DOF] >= 0:
             mask |= 1 << row[OPI_DOF]
-    if spec.n_dofs > MAX_DOFS:
-        raise UnsupportedRobotError("%d DoFs exceed the supported maximum %d" % (spec.n_dofs, MAX_DOFS))
-    return WalkProgram(np.asarray(links, np.int32), ops_i, n_ops, max_used, cap, tlist, mask)
+    return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, n_ops, max_used,
+                       cap, tlist, mask)
+
+
+def identity_table_row() -> np.ndarray:
+    """Row L of the link table: the constants of an identity (padding) op."""
+    row = np.zeros(OPF_STRIDE, np.float32)
+    row[OPF_F + 0] = row[OPF_F + 4] = row[OPF_F + 8] = 1.0
+    return row

@@ -22,8 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import backend
-from .flatten import (OPF_DAMP, OPF_F, OPF_IO, OPF_MASS, OPF_MCOM, OPF_STRIDE, OPF_T, RobotSpec, WalkProgram,
-                      build_robot_spec, build_walk)
+from .flatten import OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, identity_table_row
 from .rigid_body import DifferentiableRigidBody
 from .urdf_utils import URDFRobotModel
 
@@ -81,8 +80,8 @@ def tensor_check(function):
 @dataclass
 class _DeviceWalk:
     program: WalkProgram
-    ops_i: torch.Tensor                 # int32 [cap+1, 8] on the model device
-    link_index: torch.Tensor            # int64 [n_ops] on the model device (gather index into the link table)
+    ops_i: torch.Tensor                 # int32 [8, cap] (field-major) on the model device
+    gather: torch.Tensor                # int64 [cap * 32] flat indices into the [L+1, 32] link table
     static_ops_f: Optional[torch.Tensor] = None
 
 
@@ -133,7 +132,8 @@ class DifferentiableRobotModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ constants
     def _link_table(self) -> torch.Tensor:
-        """[L, OPF_STRIDE] float32 table of per-link constants on the model device.
+        """[L + 1, OPF_STRIDE] float32 table of per-link constants on the model device
+        (row L = the identity op used to pad walks).
 
         Built with torch ops from the bodies' parameter callables, so gradients
         reach learnable parametrisations.  The arithmetic mirrors the reference:
@@ -163,7 +163,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         mcom = com * mass
         table = torch.cat([F.reshape(L, 9), trans, mass, mcom, Io.reshape(L, 9), damping,
                            torch.zeros(L, OPF_STRIDE - 26, device=dev)], dim=1)
-        return table.to(torch.float32)
+        ident = torch.from_numpy(identity_table_row()).to(dev).reshape(1, OPF_STRIDE)
+        return torch.cat([table.to(torch.float32), ident], dim=0)
 
     def _get_walk(self, key, targets=None, whole_tree=False) -> _DeviceWalk:
         dw = self._walks.get(key)
@@ -171,14 +172,15 @@ class DifferentiableRobotModel(torch.nn.Module):
             prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree)
             dw = _DeviceWalk(
                 program=prog,
-                ops_i=torch.from_numpy(prog.ops_i).to(self._device).contiguous(),
-                link_index=torch.from_numpy(prog.links.astype("int64")).to(self._device),
+                ops_i=torch.from_numpy(prog.ops_i_dev).to(self._device).contiguous(),
+                gather=torch.from_numpy(prog.gather.reshape(-1)).to(self._device),
             )
             self._walks[key] = dw
         return dw
 
     def _ops_f(self, dw: _DeviceWalk) -> torch.Tensor:
-        """[cap+1, OPF_STRIDE] constants gathered in walk order (cached while nothing is learnable)."""
+        """[cap, OPF_STRIDE] constants gathered (and axis-canonicalised) in walk order; ONE differentiable
+        gather from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
         if self._learnable:
@@ -188,9 +190,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 with torch.no_grad():
                     self._static_table = self._link_table()
             table = self._static_table
-        rows = dw.program.capacity + 1
-        pad = torch.zeros(rows - dw.program.n_ops, OPF_STRIDE, device=self._device)
-        ops_f = torch.cat([table.index_select(0, dw.link_index), pad], dim=0).contiguous()
+        ops_f = table.reshape(-1).index_select(0, dw.gather).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
         return ops_f

@@ -45,9 +45,12 @@ extern "C" {
 #define DRM_OPF_IO 16     /* [9] I_c + m S(c)S(c)^T        (spatial_vector_algebra.py:324-327)  */
 #define DRM_OPF_DAMP 25   /* [1] joint damping             (robot_model.py:368-373)             */
 
-#define DRM_OPI_STRIDE 8  /* int32 per op in ops_i                                             */
+#define DRM_OPI_STRIDE 8  /* int32 fields per op; ops_i is FIELD-MAJOR: ops_i[field * capacity + k] */
 #define DRM_OPI_DOF 0     /* DoF column driven by this link's joint, -1 = fixed joint          */
-#define DRM_OPI_AXIS 1    /* 0/1/2: joint rotates about local x/y/z (rigid_body.py:149-154)    */
+#define DRM_OPI_PERM 1    /* axis canonicalisation of this link's stored frame: 2 = none (joint about z or
+                             fixed), 0 = joint about local x, 1 = about local y (rigid_body.py:149-154);
+                             the kernels rotate every joint about z of the permuted frame and undo
+                             the column permutation when a target pose is emitted                */
 #define DRM_OPI_SIGN 2    /* +1/-1 = sign of the axis entry, 0 for fixed joints                */
 #define DRM_OPI_SRC 3     /* parent state: DRM_SRC_PREV, DRM_SRC_ROOT, or a save-slot index    */
 #define DRM_OPI_SAVE 4    /* save-slot this op's state is copied to (branch point), -1 = none  */
@@ -58,8 +61,8 @@ extern "C" {
 #define DRM_SRC_PREV (-1) /* parent = previous op of the walk                                  */
 #define DRM_SRC_ROOT (-2) /* parent = the fixed root link (identity pose, zero velocity)       */
 #define DRM_FLAG_CHILD_IS_NEXT 1 /* op k+1 is a child of op k                                  */
-#define DRM_MAX_SLOTS 4   /* save slots compiled into the kernels                              */
-#define DRM_MAX_OPS 64    /* largest compiled walk capacity                                    */
+#define DRM_MAX_SLOTS 4   /* save slots a walk may use (kept in LDS)                           */
+#define DRM_MAX_OPS 32    /* largest compiled walk capacity (4, 8, 12, 16, 24, 32)             */
 #define DRM_MAX_DOFS 64   /* largest supported number of DoF columns                           */
 
 /* flags of drm_rnea */
@@ -73,18 +76,20 @@ extern "C" {
 #define DRM_ERR_LAUNCH (-3)      /* HIP reported a launch error                                */
 
 /*
- * A walk, as produced by flatten.build_walk().  ops_f / ops_i hold
- * (capacity + 1) rows: n_ops valid ones, the rest padding the kernels may
- * load but never use.
+ * A walk, as produced by flatten.build_walk().  ops_f / ops_i hold `capacity`
+ * rows: n_ops real ones followed by identity padding (fixed joint, F = I,
+ * t = 0, mass 0, DRM_SRC_PREV), so the kernels run the walk as straight-line code.
  */
 typedef struct drm_walk {
-    const float *ops_f;   /* device [capacity + 1, DRM_OPF_STRIDE]                           */
-    const int32_t *ops_i; /* device [capacity + 1, DRM_OPI_STRIDE]                           */
+    const float *ops_f;   /* device [capacity, DRM_OPF_STRIDE]                               */
+    const int32_t *ops_i; /* device [DRM_OPI_STRIDE, capacity]  (field-major)                */
     int32_t n_ops;        /* links visited                                                   */
-    int32_t capacity;     /* 8, 16, 32 or 64: selects the compiled kernel                    */
+    int32_t capacity;     /* 4, 8, 12, 16, 24 or 32: selects the compiled kernel             */
     int32_t n_dofs;       /* n = row width of q / qd / qdd / tau and Jacobian column count   */
     int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS)                              */
     uint64_t dof_mask;    /* bit d set <=> DoF d is driven by an op of this walk             */
+    int32_t target_perm;  /* drm_fk_jacobian: DRM_OPI_PERM of the target (last real) op      */
+    int32_t reserved;
 } drm_walk;
 
 int drm_abi_version(void);

@@ -1,0 +1,78 @@
+"""Shared test helpers (robot list, model construction, sampling, tolerances)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import torch
+
+import differentiable_robot_model_amd as drm
+from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel, robot_description_folder
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# the reference's test matrix (reference tests/test_kinematics_dynamics.py:19-52): (robot, test links)
+REFERENCE_TEST_MATRIX = [
+    ("fetch_arm_no_gripper_small_damping", ["virtual_ee_link"]),
+    ("2link_robot", ["endEffector"]),
+    ("iiwa7", ["iiwa_link_ee"]),
+    ("panda_no_gripper", ["panda_virtual_ee_link"]),
+    ("allegro_left_small_damping", ["link_11.0_tip", "link_7.0_tip", "link_3.0_tip", "link_15.0_tip"]),
+    ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"]),
+    ("jaco_clean", ["j2n6s300_link_ee"]),
+]
+EXTRA_ROBOTS = [
+    ("allegro_left", ["link_3.0_tip", "link_15.0_tip"]),
+    ("fetch_arm_no_gripper", ["virtual_ee_link"]),
+    ("iiwa7_allegro", ["link_3.0_tip", "link_15.0_tip"]),
+    ("panda", ["panda_hand", "panda_rightfinger"]),
+    ("jaco", ["j2n6s300_end_effector"]),
+]
+GOLDEN_ROBOTS = REFERENCE_TEST_MATRIX + EXTRA_ROBOTS
+ALL_ROBOTS = sorted(f[:-5] for f in os.listdir(robot_description_folder) if f.endswith(".urdf"))
+# batch shapes of the reference's tests (test_kinematics_dynamics.py:54-61)
+REFERENCE_BATCH_SHAPES = [tuple(), (1,), (3,), (6,), (7,)]
+
+# fp32 tolerances of the path: the reference's own fp32 noise floor is ~2e-7
+TOL_POS = dict(atol=2e-6, rtol=0)       # metres
+TOL_QUAT = dict(atol=2e-6, rtol=0)
+TOL_JAC = dict(atol=2e-6, rtol=0)
+TOL_TAU = dict(atol=2e-5, rtol=2e-5)    # N m
+
+
+def urdf_path(name):
+    return os.path.join(robot_description_folder, name + ".urdf")
+
+
+def load_model(name, device="cpu"):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return DifferentiableRobotModel(urdf_path(name), device=device)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, "golden_%s.npz" % name), allow_pickle=False)
+
+
+def sample_states(model, B, seed=0, vel=1.0, acc=2.0):
+    """q ~ U(lower, upper), qd ~ U(+-vel), qdd ~ U(+-acc) as float32 numpy arrays."""
+    lim = model.get_joint_limits()
+    lo = np.asarray([j["lower"] for j in lim]); hi = np.asarray([j["upper"] for j in lim])
+    rng = np.random.default_rng(seed)
+    n = len(lim)
+    q = (lo + (hi - lo) * rng.random((B, n))).astype(np.float32)
+    qd = ((rng.random((B, n)) * 2 - 1) * vel).astype(np.float32)
+    qdd = ((rng.random((B, n)) * 2 - 1) * acc).astype(np.float32)
+    return q, qd, qdd
+
+
+def quat_close(a, b, atol):
+    """Quaternions agree, allowing the global sign flip that fp32 rounding can trigger at the
+    branch boundaries of the reference's algorithm (spatial_vector_algebra.py:117-128)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    sgn = np.sign((a * b).sum(-1, keepdims=True))
+    sgn[sgn == 0] = 1.0
+    return np.abs(a * sgn - b).max() <= atol, int((sgn < 0).sum())
+
+
+def max_err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())

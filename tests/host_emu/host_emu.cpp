@@ -17,14 +17,17 @@ template <int CAP>
 void fk_t(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float *quat) {
     const int n = w->n_dofs;
     for (int64_t b = 0; b < B; ++b) {
+        Pose slots[DRM_MAX_SLOTS];
         auto qf = [&](int d) { return q[b * n + d]; };
+        auto save = [&](int s, const Pose &P) { slots[s] = P; };
+        auto load = [&](int s, Pose &P) { P = slots[s]; };
         auto emit = [&](int t, const Pose &P) {
             float qt[4];
             quat_xyzw(P.R, qt);
             for (int i = 0; i < 3; ++i) pos[(b * T + t) * 3 + i] = P.p[i];
             for (int i = 0; i < 4; ++i) quat[(b * T + t) * 4 + i] = qt[i];
         };
-        fk_walk<CAP>(w->ops_f, w->ops_i, w->n_ops, qf, emit);
+        fk_walk<CAP>(w->ops_f, w->ops_i, qf, save, load, emit);
     }
 }
 
@@ -35,12 +38,20 @@ void jac_t(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat
         auto qf = [&](int d) { return q[b * n + d]; };
         Pose ee;
         float z[CAP][3], pj[CAP][3];
-        fk_chain<CAP>(w->ops_f, w->ops_i, w->n_ops, qf, ee, z, pj);
+        int dof[CAP], sign[CAP];
+        load_field<CAP>(w->ops_i, DRM_OPI_DOF, dof);
+        load_field<CAP>(w->ops_i, DRM_OPI_SIGN, sign);
+        fk_chain<CAP>(w->ops_f, dof, sign, qf, ee, z, pj);
         if (pos) for (int i = 0; i < 3; ++i) pos[b * 3 + i] = ee.p[i];
-        if (quat) quat_xyzw(ee.R, quat + b * 4);
+        if (quat) {
+            float Ru[9];
+            for (int i = 0; i < 9; ++i) Ru[i] = ee.R[i];
+            unpermute(w->target_perm, Ru);
+            quat_xyzw(Ru, quat + b * 4);
+        }
         for (int i = 0; i < 3 * n; ++i) { lin[b * 3 * n + i] = 0.f; ang[b * 3 * n + i] = 0.f; }
-        for (int k = 0; k < w->n_ops; ++k) {
-            const int d = w->ops_i[k * DRM_OPI_STRIDE + DRM_OPI_DOF];
+        for (int k = 0; k < CAP; ++k) {
+            const int d = w->ops_i[DRM_OPI_DOF * CAP + k];
             if (d < 0) continue;
             float dp[3] = {ee.p[0] - pj[k][0], ee.p[1] - pj[k][1], ee.p[2] - pj[k][2]}, c[3];
             cross3(z[k], dp, c);
@@ -53,11 +64,19 @@ template <int CAP>
 void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
     const int n = w->n_dofs;
     for (int64_t b = 0; b < B; ++b) {
+        Motion ms[DRM_MAX_SLOTS];
+        Force fs[DRM_MAX_SLOTS] = {};
         auto qf = [&](int d, float &a, float &v, float &acc) {
             a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f;
         };
         auto out = [&](int d, float v) { tau[b * n + d] = v; };
-        rnea_walk<CAP>(w->ops_f, w->ops_i, w->n_ops, flags, qf, out);
+        auto msave = [&](int s, const Motion &M) { ms[s] = M; };
+        auto mload = [&](int s, Motion &M) { M = ms[s]; };
+        auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) { fs[s].l[i] += F.l[i]; fs[s].a[i] += F.a[i]; } };
+        auto ftake = [&](int s, Force &F) {
+            for (int i = 0; i < 3; ++i) { F.l[i] += fs[s].l[i]; F.a[i] += fs[s].a[i]; fs[s].l[i] = 0.f; fs[s].a[i] = 0.f; }
+        };
+        rnea_walk<CAP>(w->ops_f, w->ops_i, flags, qf, out, msave, mload, fadd, ftake);
     }
 }
 
@@ -65,10 +84,12 @@ void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd
 
 #define DISPATCH(FN, ...)                        \
     switch (w->capacity) {                       \
+    case 4: FN<4>(__VA_ARGS__); break;           \
     case 8: FN<8>(__VA_ARGS__); break;           \
+    case 12: FN<12>(__VA_ARGS__); break;         \
     case 16: FN<16>(__VA_ARGS__); break;         \
+    case 24: FN<24>(__VA_ARGS__); break;         \
     case 32: FN<32>(__VA_ARGS__); break;         \
-    case 64: FN<64>(__VA_ARGS__); break;         \
     default: return -2;                          \
     }
 

@@ -1,0 +1,113 @@
+"""Kernel arithmetic + walk encoding on the CPU (not gpu): csrc/drm_sample.hpp compiled with g++
+(tests/host_emu/host_emu.cpp) against the fp64 oracle, for every shipped robot.
+
+This covers what can be checked without a GPU: the per-sample math of the HIP kernels, the axis
+canonicalisation, the depth-first walk programs (slots, padding) and the constant tables.  The
+tile I/O and launches are covered by the `-m gpu` tests.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from differentiable_robot_model_amd.backend import DrmWalk
+from differentiable_robot_model_amd.flatten import OPI_PERM, build_walk
+from helpers import ALL_ROBOTS, load_model, max_err, quat_close, sample_states
+from oracle import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    src = os.path.join(HERE, "host_emu", "host_emu.cpp")
+    lib = os.path.join(HERE, "host_emu", "libdrm_host_emu.so")
+    hdr = os.path.join(HERE, "..", "differentiable-robot-model_amd", "csrc", "drm_sample.hpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-mfma",
+                               "-o", lib, src])
+    return ctypes.CDLL(lib)
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def host_walk(model, prog):
+    table = model._link_table().detach().cpu().numpy().reshape(-1)
+    ops_f = np.ascontiguousarray(table[prog.gather.reshape(-1)].reshape(prog.capacity, 32), np.float32)
+    perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
+    walk = DrmWalk(ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, prog.n_ops, prog.capacity, model._n_dofs,
+                   prog.n_slots, prog.dof_mask, perm, 0)
+    return walk, ops_f
+
+
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+def test_fk_all_links(emu, robot):
+    m = load_model(robot)
+    L, n, B = len(m._bodies), m._n_dofs, 33
+    q, _, _ = sample_states(m, B, seed=1)
+    targets = list(range(1, L))
+    prog = build_walk(m._spec, targets=targets)
+    walk, keep = host_walk(m, prog)
+    pos = np.zeros((B, len(targets), 3), np.float32); quat = np.zeros((B, len(targets), 4), np.float32)
+    assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), len(targets), _ptr(pos), _ptr(quat)) == 0
+    op, oq = Oracle(m._spec).fk(q.astype(np.float64), targets, np.float64)
+    assert max_err(pos, op) < 1e-6
+    ok, flips = quat_close(quat, oq, 1e-6)
+    assert ok and flips == 0
+
+
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+def test_jacobian_every_link(emu, robot):
+    m = load_model(robot)
+    L, n, B = len(m._bodies), m._n_dofs, 17
+    q, _, _ = sample_states(m, B, seed=2)
+    orc = Oracle(m._spec)
+    for link in range(0, L):
+        prog = build_walk(m._spec, targets=[link] if link else [])
+        walk, keep = host_walk(m, prog)
+        pos = np.zeros((B, 3), np.float32); quat = np.zeros((B, 4), np.float32)
+        lin = np.full((B, 3, n), np.nan, np.float32); ang = np.full((B, 3, n), np.nan, np.float32)
+        assert emu.emu_fk_jacobian(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(pos), _ptr(quat),
+                                   _ptr(lin), _ptr(ang)) == 0
+        op, oq, ol, oa = orc.fk_jacobian(q.astype(np.float64), link, np.float64)
+        assert max_err(pos, op) < 1e-6 and max_err(lin, ol) < 1e-6 and max_err(ang, oa) < 1e-6, (robot, link)
+        ok, _ = quat_close(quat, oq, 1e-6)
+        assert ok, (robot, link)
+
+
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_rnea(emu, robot, flags):
+    m = load_model(robot)
+    n, B = m._n_dofs, 29
+    q, qd, qdd = sample_states(m, B, seed=3)
+    prog = build_walk(m._spec, whole_tree=True)
+    walk, keep = host_walk(m, prog)
+    tau = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau)) == 0
+    ot = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau, ot, atol=2e-5, rtol=2e-5), (robot, np.abs(tau - ot).max())
+    # qdd = NULL == zero joint accelerations (compute_non_linear_effects)
+    tau0 = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), None, ctypes.c_int64(B), flags, _ptr(tau0)) == 0
+    o0 = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), np.zeros_like(q, np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
+
+
+def test_sincos_large_arguments(emu):
+    """The kernels' branch-free sincos keeps fp32 accuracy far outside any joint range."""
+    m = load_model("2link_robot")
+    prog = build_walk(m._spec, targets=[3])
+    walk, keep = host_walk(m, prog)
+    q = np.array([[1e4, -3e5], [123456.7, 1e6], [-7e6, 2.5e7], [0.0, -0.0], [np.pi, -np.pi / 2]], np.float32)
+    B = q.shape[0]
+    pos = np.zeros((B, 1, 3), np.float32); quat = np.zeros((B, 1, 4), np.float32)
+    assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(pos), _ptr(quat)) == 0
+    op, oq = Oracle(m._spec).fk(q.astype(np.float64), [3], np.float64)
+    assert max_err(pos, op) < 2e-6
