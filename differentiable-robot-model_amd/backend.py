@@ -152,3 +152,37 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
                             _stream(q.device)))
     return tau
+
+
+class FkJacobianPlan(object):
+    """A prepared drm_fk_jacobian launch on fixed buffers (no per-call allocation or argument marshalling).
+
+    Used by bench.py and by callers that evaluate the same batch shape repeatedly (MPC loops); works
+    under HIP graph capture because it only enqueues one kernel on the current stream.
+    """
+
+    def __init__(self, prog: WalkProgram, ops_f, ops_i, q, n_dofs: int, want_pose: bool = True):
+        self._lib = load_library()
+        self.q = _dev_f32(q, "q", n_dofs)
+        B = self.q.shape[0]
+        dev = self.q.device
+        self.pos = torch.empty(B, 3, device=dev) if want_pose else None
+        self.quat = torch.empty(B, 4, device=dev) if want_pose else None
+        self.lin = torch.empty(B, 3, n_dofs, device=dev)
+        self.ang = torch.empty(B, 3, n_dofs, device=dev)
+        self._keep = (ops_f, ops_i)
+        self._walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+        self._args = (ctypes.byref(self._walk), self.q.data_ptr(), B,
+                      self.pos.data_ptr() if want_pose else None, self.quat.data_ptr() if want_pose else None,
+                      self.lin.data_ptr(), self.ang.data_ptr())
+        self.batch = B
+        self.device = dev
+
+    def launch(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self._lib.drm_fk_jacobian(*self._args, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            _check(rc)
+
+    def outputs(self):
+        return self.pos, self.quat, self.lin, self.ang

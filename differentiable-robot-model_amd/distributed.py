@@ -1,0 +1,58 @@
+"""Batch sharding over the GPUs of one node (one process per GPU, torch.distributed).
+
+Every sample of the FK / Jacobian / RNEA path is independent and the per-robot
+constants are < 4 KB, so the path shards trivially: rank r owns the contiguous
+rows [lo_r, hi_r) of the batch, the walk tables are replicated, and NO collective
+is needed during compute.  The only exchange the path can have is the optional
+gather of the outputs (an MPC / particle batch that has to be re-assembled on
+every rank or on rank 0); it is a single `all_gather_into_tensor` per output —
+RCCL over xGMI with backend "nccl" on ROCm, gloo on CPU (tests).
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range [lo, hi) of `rank`; the first (batch % world) ranks get one extra row."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, extra = divmod(int(batch), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rows(t: torch.Tensor, world_size: int, rank: int) -> torch.Tensor:
+    """The rows of a [B, ...] tensor that `rank` owns (a view, no copy)."""
+    lo, hi = shard_bounds(t.shape[0], world_size, rank)
+    return t[lo:hi]
+
+
+def all_gather_rows(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
+    """Re-assemble a [B, ...] tensor from per-rank row shards produced with `shard_bounds`.
+
+    Equal shards use one `all_gather_into_tensor`; ragged shards (B % world != 0) are padded by
+    one row to the largest shard first.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_bounds(batch, world, r)[1] - shard_bounds(batch, world, r)[0] for r in range(world)]
+    if local.shape[0] != sizes[rank]:
+        raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], sizes[rank]))
+    most = max(sizes)
+    tail = tuple(local.shape[1:])
+    send = local.contiguous()
+    if send.shape[0] < most:
+        pad = torch.zeros((most - send.shape[0],) + tail, dtype=local.dtype, device=local.device)
+        send = torch.cat([send, pad], dim=0)
+    out = torch.empty((world * most,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    if min(sizes) == most:
+        return out
+    out = out.reshape((world, most) + tail)
+    return torch.cat([out[r, :sizes[r]] for r in range(world)], dim=0)
+
+
+def gather_outputs(outputs: Sequence[torch.Tensor], batch: int, group=None) -> List[torch.Tensor]:
+    return [all_gather_rows(t, batch, group) for t in outputs]

@@ -269,6 +269,16 @@ class DifferentiableRobotModel(torch.nn.Module):
         ops_f = self._ops_f(dw)
         return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
+    def plan_fk_and_jacobian(self, q: torch.Tensor, link_name: str, want_pose: bool = True
+                             ) -> "backend.FkJacobianPlan":
+        """Prepared (allocation-free, graph-capturable) FK+Jacobian launch on fixed buffers."""
+        self._require_device()
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
+        idx = self._name_to_idx_map[link_name]
+        dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
+        return backend.FkJacobianPlan(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs, want_pose)
+
     # ------------------------------------------------------------------ inverse dynamics
     @tensor_check
     def compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,

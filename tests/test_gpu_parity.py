@@ -1,0 +1,244 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the public API -> ctypes -> C ABI, against
+  * the fp64 oracle on seeded inputs (every shipped robot, ragged / tiny / multi-tile batches),
+  * the committed golden fixtures of the reference (its test matrix and batch shapes),
+  * size-independent properties at BASELINE.json's full sizes (65 536 and 2^20).
+Tolerances (fp32 path; the reference's own fp32 noise floor is ~2e-7): helpers.TOL_*.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (ALL_ROBOTS, GOLDEN_ROBOTS, REFERENCE_BATCH_SHAPES, REFERENCE_TEST_MATRIX, TOL_JAC, TOL_POS,
+                     TOL_QUAT, TOL_TAU, load_golden, load_model, max_err, quat_close, sample_states)
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_library():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from differentiable_robot_model_amd import backend
+    lib = backend.load_library()            # raises if the in-tree .so is missing: no silent fallback
+    assert backend.LIB_PATH.endswith("csrc/libdrm_hip.so") and lib.drm_abi_version() == 1
+
+
+# ------------------------------------------------------------------ vs the fp64 oracle
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 257])
+def test_fk_jacobian_rnea_vs_oracle(robot, B):
+    m = load_model(robot, "cuda")
+    orc = Oracle(m._spec)
+    L = len(m._bodies)
+    q, qd, qdd = sample_states(m, B, seed=100 + B)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    # all-links FK (branching walks, save slots, target un-permutation)
+    poses = m.compute_forward_kinematics_all_links(dev(q))
+    op, oq = orc.fk(q64, list(range(L)), np.float64)
+    for i, body in enumerate(m._bodies):
+        p, r = poses[body.name]
+        assert max_err(host(p), op[:, i]) <= TOL_POS["atol"], (robot, body.name)
+        ok, _ = quat_close(host(r), oq[:, i], TOL_QUAT["atol"])
+        assert ok, (robot, body.name)
+    # FK + Jacobian of a few links (first moving link, a middle one, the last one)
+    for link in sorted({1, L // 2, L - 1}):
+        name = m._bodies[link].name
+        pos, quat, lin, ang = m.compute_fk_and_jacobian(dev(q), name)
+        rp, rq, rl, ra = orc.fk_jacobian(q64, link, np.float64)
+        assert max_err(host(pos), rp) <= TOL_POS["atol"]
+        assert max_err(host(lin), rl) <= TOL_JAC["atol"] and max_err(host(ang), ra) <= TOL_JAC["atol"]
+        ok, _ = quat_close(host(quat), rq, TOL_QUAT["atol"])
+        assert ok
+        lin2, ang2 = m.compute_endeffector_jacobian(dev(q), name)
+        assert torch.equal(lin2, lin) and torch.equal(ang2, ang)
+    # RNEA, all flag combinations + the qdd = 0 entry point
+    for grav in (False, True):
+        for damp in (False, True):
+            tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+            ref = orc.rnea(q64, qd64, qdd64, grav, damp, np.float64)
+            assert np.allclose(host(tau), ref, **TOL_TAU), (robot, grav, damp, np.abs(host(tau) - ref).max())
+    nle = m.compute_non_linear_effects(dev(q), dev(qd))
+    assert np.allclose(host(nle), orc.rnea(q64, qd64, np.zeros_like(q64), True, True, np.float64), **TOL_TAU)
+
+
+# ------------------------------------------------------------------ vs the reference's golden fixtures
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+@pytest.mark.parametrize("tag", ["slow", "fast"])
+def test_against_reference_golden(robot, links, tag):
+    g = load_golden(robot)
+    m = load_model(robot, "cuda")
+    q, qd, qdd = (dev(g[tag + k]) for k in ("_q", "_qd", "_qdd"))
+    for link in links:
+        for recursive in (False, True):
+            pos, quat = m.compute_forward_kinematics(q, link, recursive=recursive)
+            assert max_err(host(pos), g["%s_pos_%s" % (tag, link)]) <= TOL_POS["atol"]
+            ok, _ = quat_close(host(quat), g["%s_quat_%s" % (tag, link)], TOL_QUAT["atol"])
+            assert ok
+        lin, ang = m.compute_endeffector_jacobian(q, link)
+        assert max_err(host(lin), g["%s_lin_%s" % (tag, link)]) <= TOL_JAC["atol"]
+        assert max_err(host(ang), g["%s_ang_%s" % (tag, link)]) <= TOL_JAC["atol"]
+    for grav in (0, 1):
+        for damp in (0, 1):
+            tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=bool(grav), use_damping=bool(damp))
+            assert np.allclose(host(tau), g["%s_tau_g%d_d%d" % (tag, grav, damp)], **TOL_TAU)
+
+
+@pytest.mark.parametrize("robot,links", REFERENCE_TEST_MATRIX)
+@pytest.mark.parametrize("shape", REFERENCE_BATCH_SHAPES)
+def test_reference_batch_shapes(robot, links, shape):
+    """The reference's batch shapes (), (1,), (3,), (6,), (7,) (test_kinematics_dynamics.py:54-61)."""
+    g = load_golden(robot)
+    m = load_model(robot, "cuda")
+    n = m._n_dofs
+    rows = shape[0] if shape else 1
+    sl = (lambda a: a[0]) if not shape else (lambda a: a[:rows])
+    q, qd, qdd = (dev(sl(g["slow" + k])) for k in ("_q", "_qd", "_qdd"))
+    link = links[0]
+    pos, quat = m.compute_forward_kinematics(q, link)
+    lin, ang = m.compute_endeffector_jacobian(q, link)
+    tau = m.compute_inverse_dynamics(q, qd, qdd)
+    assert tuple(pos.shape) == shape + (3,) and tuple(quat.shape) == shape + (4,)
+    assert tuple(lin.shape) == shape + (3, n) and tuple(ang.shape) == shape + (3, n) and tuple(tau.shape) == shape + (n,)
+    assert max_err(host(pos), sl(g["slow_pos_" + link])) <= TOL_POS["atol"]
+    assert max_err(host(lin), sl(g["slow_lin_" + link])) <= TOL_JAC["atol"]
+    assert np.allclose(host(tau), sl(g["slow_tau_g1_d1"]), **TOL_TAU)
+    if not shape:
+        assert max_err(host(pos), g["slow_pos_unbatched"]) <= TOL_POS["atol"]
+    allp = m.compute_forward_kinematics_all_links(q)     # dict results keep the batch dim
+    assert tuple(allp[link][0].shape) == (rows, 3)
+
+
+# ------------------------------------------------------------------ edge cases of the boundary
+def test_unaligned_and_noncontiguous_inputs():
+    m = load_model("panda_no_gripper", "cuda")
+    orc = Oracle(m._spec)
+    q, qd, qdd = sample_states(m, 130, seed=3)
+    big = dev(np.concatenate([np.zeros((1, 7), np.float32), q]))
+    view = big[1:]                                    # contiguous but only 4-byte aligned
+    assert view.data_ptr() % 16 != 0
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(view, "panda_virtual_ee_link")
+    rp, rq, rl, ra = orc.fk_jacobian(q.astype(np.float64), 8, np.float64)
+    assert max_err(host(pos), rp) <= TOL_POS["atol"] and max_err(host(lin), rl) <= TOL_JAC["atol"]
+    wide = dev(np.concatenate([q, q], axis=1))[:, :7]  # non-contiguous rows
+    assert not wide.is_contiguous()
+    tau = m.compute_inverse_dynamics(wide, dev(qd), dev(qdd))
+    assert np.allclose(host(tau), orc.rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64),
+                                           True, True, np.float64), **TOL_TAU)
+    pos64, _ = m.compute_forward_kinematics(dev(q).double(), "panda_virtual_ee_link")  # dtype is normalised
+    assert pos64.dtype == torch.float32 and max_err(host(pos64), rp) <= TOL_POS["atol"]
+
+
+def test_errors_on_gpu_model():
+    m = load_model("panda_no_gripper", "cuda")
+    with pytest.raises(AssertionError):                # CPU tensor into a GPU model (robot_model.py:38-40)
+        m.compute_forward_kinematics(torch.zeros(2, 7), "panda_virtual_ee_link")
+    with pytest.raises(AssertionError):
+        m.compute_endeffector_jacobian(torch.zeros(2, 6).cuda(), "panda_virtual_ee_link")
+    with pytest.raises(KeyError):
+        m.compute_forward_kinematics(torch.zeros(2, 7).cuda(), "nope")
+    empty = m.compute_inverse_dynamics(torch.zeros(0, 7).cuda(), torch.zeros(0, 7).cuda(), torch.zeros(0, 7).cuda())
+    assert tuple(empty.shape) == (0, 7)
+    root_pos, root_quat = m.compute_forward_kinematics(torch.rand(5, 7).cuda(), "panda_link0")  # the root link
+    assert torch.equal(root_pos, torch.zeros(5, 3).cuda()) and torch.equal(root_quat[:, 3], torch.ones(5).cuda())
+    lin, ang = m.compute_endeffector_jacobian(torch.rand(5, 7).cuda(), "panda_link0")
+    assert not lin.any() and not ang.any()
+
+
+def test_plan_and_hipgraph_replay_match_direct_call():
+    m = load_model("panda_no_gripper", "cuda")
+    q, _, _ = sample_states(m, 4096, seed=9)
+    qd = dev(q)
+    ref = m.compute_fk_and_jacobian(qd, "panda_virtual_ee_link")
+    plan = m.plan_fk_and_jacobian(qd, "panda_virtual_ee_link")
+    plan.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref))
+    for t in plan.outputs():
+        t.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.launch()
+    for t in plan.outputs():
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref))
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+@pytest.mark.parametrize("B", [65536, 1 << 20])
+def test_full_size_properties(B):
+    m = load_model("panda_no_gripper", "cuda")
+    ee = "panda_virtual_ee_link"
+    lim = m.get_joint_limits()
+    lo = torch.tensor([j["lower"] for j in lim]).cuda(); hi = torch.tensor([j["upper"] for j in lim]).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    q = lo + (hi - lo) * torch.rand(B, 7, device="cuda", generator=gen)
+    qd = torch.rand(B, 7, device="cuda", generator=gen) * 2 - 1
+    a1 = torch.rand(B, 7, device="cuda", generator=gen) * 4 - 2
+    a2 = torch.rand(B, 7, device="cuda", generator=gen) * 4 - 2
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(q, ee)
+    # determinism: a second launch is bit-identical
+    pos2, quat2, lin2, ang2 = m.compute_fk_and_jacobian(q, ee)
+    assert torch.equal(pos, pos2) and torch.equal(quat, quat2) and torch.equal(lin, lin2) and torch.equal(ang, ang2)
+    # unit quaternions and unit joint axes; last joint's own column of lin_jac: z x (p_e - p_7) with p_e - p_7 || z
+    assert (quat.norm(dim=1) - 1).abs().max() < 1e-5
+    assert (ang.norm(dim=1) - 1).abs().max() < 1e-5
+    assert lin[:, :, 6].abs().max() < 1e-5
+    # joint 1 of the Panda turns about the world z axis through the origin: shifting q1 by d rotates the pose
+    d = 0.37
+    qs = q.clone(); qs[:, 0] += d
+    pos_s, _, lin_s, _ = m.compute_fk_and_jacobian(qs, ee)
+    c, s = np.cos(d), np.sin(d)
+    rot = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32).cuda()
+    assert (pos_s - pos @ rot.T).abs().max() < 5e-6
+    assert (lin_s - torch.einsum("ij,bjk->bik", rot, lin)).abs().max() < 5e-6
+    # column 0 of the linear Jacobian is d pos / d q1 = z x pos
+    assert (lin[:, 0, 0] + pos[:, 1]).abs().max() < 5e-6 and (lin[:, 1, 0] - pos[:, 0]).abs().max() < 5e-6
+    # RNEA is affine in qdd: tau(a1 + a2) - tau(0) = (tau(a1) - tau(0)) + (tau(a2) - tau(0))
+    t0 = m.compute_non_linear_effects(q, qd)
+    t1 = m.compute_inverse_dynamics(q, qd, a1); t2 = m.compute_inverse_dynamics(q, qd, a2)
+    t12 = m.compute_inverse_dynamics(q, qd, a1 + a2)
+    scale = 1 + t12.abs().max().item()
+    assert ((t12 - t0) - ((t1 - t0) + (t2 - t0))).abs().max() / scale < 2e-5
+    # shard consistency: rows computed in two halves equal the single launch (what multi-GPU sharding relies on)
+    half = B // 2
+    pa = m.compute_fk_and_jacobian(q[:half].contiguous(), ee); pb = m.compute_fk_and_jacobian(q[half:].contiguous(), ee)
+    assert torch.equal(torch.cat([pa[2], pb[2]]), lin) and torch.equal(torch.cat([pa[0], pb[0]]), pos)
+    # spot-check 2048 random rows against the oracle
+    idx = torch.randperm(B, generator=torch.Generator().manual_seed(1))[:2048]
+    orc = Oracle(m._spec)
+    rp, rq, rl, ra = orc.fk_jacobian(host(q[idx.cuda()]).astype(np.float64), 8, np.float64)
+    assert max_err(host(pos[idx.cuda()]), rp) <= TOL_POS["atol"] and max_err(host(lin[idx.cuda()]), rl) <= TOL_JAC["atol"]
+    rt = orc.rnea(host(q[idx.cuda()]).astype(np.float64), host(qd[idx.cuda()]).astype(np.float64),
+                  host(a1[idx.cuda()]).astype(np.float64), True, True, np.float64)
+    assert np.allclose(host(t1[idx.cuda()]), rt, **TOL_TAU)
+
+
+def test_allegro_fingertips_full_batch():
+    """Config 4: Allegro 16-DoF branching tree, batch 65 536, FK to the four fingertips."""
+    m = load_model("allegro_left", "cuda")
+    tips = ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]
+    idx = [m._name_to_idx_map[t] for t in tips]
+    q, _, _ = sample_states(m, 65536, seed=4)
+    pos, quat = m._fk_targets(dev(q), idx)
+    assert tuple(pos.shape) == (65536, 4, 3) and tuple(quat.shape) == (65536, 4, 4)
+    sel = np.random.default_rng(0).choice(65536, 1024, replace=False)
+    rp, rq = Oracle(m._spec).fk(q[sel].astype(np.float64), idx, np.float64)
+    assert max_err(host(pos)[sel], rp) <= TOL_POS["atol"]
+    ok, _ = quat_close(host(quat)[sel], rq, TOL_QUAT["atol"])
+    assert ok
+    # a finger's tip does not move when another finger's joints move
+    q2 = q.copy(); q2[:, 4:8] += 0.3
+    pos2, _ = m._fk_targets(dev(q2), idx)
+    moved = (host(pos2) - host(pos)).reshape(65536, 4, 3)
+    still = [t for t in range(4) if np.abs(moved[:, t]).max() == 0.0]
+    assert len(still) == 3

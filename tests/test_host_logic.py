@@ -1,0 +1,190 @@
+"""Host-side logic (not gpu): URDF ingest, constant tables, walk programs, tensor_check, learnable-parameter
+plumbing, error behaviour, and the C-ABI library's exported symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from differentiable_robot_model_amd import backend
+from differentiable_robot_model_amd.flatten import (CAPACITIES, OPF_F, OPF_IO, OPF_MCOM, OPF_T, OPI_DOF, OPI_OUT, OPI_SAVE,
+                                                    OPI_SRC, SRC_PREV, SRC_ROOT, UnsupportedRobotError, build_walk)
+from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel
+from differentiable_robot_model_amd.urdf_utils import parse_urdf
+from helpers import ALL_ROBOTS, GOLDEN_ROBOTS, load_golden, load_model, urdf_path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ URDF ingest == reference's loader
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+def test_urdf_parameters_bit_identical_to_reference(robot, links):
+    g = load_golden(robot)
+    m = load_model(robot)
+    assert [b.name for b in m._bodies] == list(g["link_names"])
+    assert m._controlled_joints == list(g["controlled_joints"])
+    assert list(m._spec.parent) == list(g["parent"])
+    s = m._spec
+    for mine, ref in ((s.rpy, "rot_angles"), (s.trans, "trans"), (s.axis, "joint_axis"), (s.damping, "joint_damping"),
+                      (s.mass, "mass"), (s.com, "com"), (s.inertia, "inertia_mat")):
+        assert np.array_equal(mine, g[ref]), ref
+    lim = m.get_joint_limits()
+    for k in ("lower", "upper", "velocity", "effort"):
+        assert [j[k] for j in lim] == list(g["limit_" + k])
+    # R_fixed of the constant table == the reference's (z_rot(yaw) @ y_rot(pitch)) @ x_rot(roll), bit for bit
+    table = m._link_table().numpy()
+    assert np.array_equal(table[:-1, OPF_F:OPF_F + 9], g["R_fixed"])
+    assert np.array_equal(table[:-1, OPF_T:OPF_T + 3], g["trans"])
+
+
+def test_missing_inertial_and_dynamics_defaults():
+    m = load_model("2link_robot")     # root link "base" has no <inertial> (urdf_utils.py:114-124)
+    assert float(m._bodies[0].inertia.mass()) == 1.0
+    assert torch.equal(m._bodies[0].inertia.inertia_mat()[0], torch.eye(3))
+    p = load_model("panda_no_gripper")  # joints without <dynamics>: damping 0 (urdf_utils.py:65-72)
+    assert all(float(b.joint_damping()) == 0.0 for b in p._bodies[1:])
+    assert p._bodies[0].joint_damping() is None
+
+
+def test_lenient_xml_and_bad_robots(tmp_path):
+    bad = tmp_path / "unbound.urdf"
+    bad.write_text('<robot name="r"><link name="a"/><gazebo><sensor:camera name="c"/></gazebo></robot>')
+    assert parse_urdf(str(bad)).links[0].name == "a"
+    skew = tmp_path / "skew.urdf"
+    skew.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="revolute"><parent link="a"/>'
+                    '<child link="b"/><axis xyz="0 0.7071 0.7071"/><limit lower="-1" upper="1" effort="1" velocity="1"/>'
+                    '</joint></robot>')
+    with pytest.raises(UnsupportedRobotError):
+        DifferentiableRobotModel(str(skew), device="cpu")
+    order = tmp_path / "order.urdf"
+    order.write_text('<robot name="r"><link name="a"/><link name="c"/><link name="b"/>'
+                     '<joint name="j1" type="fixed"><parent link="a"/><child link="b"/></joint>'
+                     '<joint name="j2" type="fixed"><parent link="b"/><child link="c"/></joint></robot>')
+    with pytest.raises(UnsupportedRobotError):
+        DifferentiableRobotModel(str(order), device="cpu")
+
+
+# ------------------------------------------------------------------ walk programs
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+def test_walk_program_invariants(robot):
+    m = load_model(robot)
+    spec = m._spec
+    L = spec.n_links
+    prog = build_walk(spec, whole_tree=True)
+    assert prog.n_ops == L - 1 and prog.capacity in CAPACITIES and prog.capacity >= prog.n_ops
+    assert sorted(prog.links.tolist()) == list(range(1, L))
+    assert prog.dof_mask == (1 << spec.n_dofs) - 1
+    saved = {}
+    for k in range(prog.n_ops):
+        link = int(prog.links[k]); src = int(prog.ops_i[k, OPI_SRC]); par = int(spec.parent[link])
+        if src == SRC_ROOT:
+            assert par == 0
+        elif src == SRC_PREV:
+            assert k > 0 and int(prog.links[k - 1]) == par
+        else:
+            assert saved[src] == par          # the slot currently holds the parent's state
+        if prog.ops_i[k, OPI_SAVE] >= 0:
+            saved[int(prog.ops_i[k, OPI_SAVE])] = link
+        assert int(prog.ops_i[k, OPI_DOF]) == int(spec.dof[link])
+    assert np.all(prog.ops_i[prog.n_ops:, OPI_DOF] == -1) and np.all(prog.ops_i[prog.n_ops:, OPI_SRC] == SRC_PREV)
+    assert np.array_equal(prog.ops_i_dev, prog.ops_i.T)
+    # chain walk of the deepest link: exactly its ancestors, in order, outputs on the last op
+    deepest = max(range(L), key=lambda i: len(spec.chain_to(i)))
+    chain = build_walk(spec, targets=[deepest])
+    assert chain.links.tolist() == spec.chain_to(deepest) and chain.n_slots == 0
+    assert int(chain.ops_i[chain.n_ops - 1, OPI_OUT]) == 0
+
+
+def test_axis_canonicalisation_is_a_pure_reindexing():
+    m = load_model("allegro_left")   # has x, y and -z joints
+    spec = m._spec
+    assert set(int(a) for a in spec.axis_idx[spec.dof >= 0]) == {0, 1, 2}
+    prog = build_walk(spec, whole_tree=True)
+    table = m._link_table().numpy().reshape(-1)
+    ops_f = table[prog.gather.reshape(-1)].reshape(prog.capacity, 32)
+    for k in range(prog.n_ops):
+        link = int(prog.links[k])
+        raw = table[link * 32:(link + 1) * 32]
+        for a, b in ((OPF_F, 9), (OPF_T, 3), (OPF_MCOM, 3), (OPF_IO, 9)):
+            assert sorted(ops_f[k, a:a + b].tolist()) == sorted(raw[a:a + b].tolist())
+    ident = ops_f[prog.n_ops:]
+    assert np.array_equal(ident[:, :9], np.tile(np.eye(3, dtype=np.float32).reshape(-1), (len(ident), 1)))
+    assert np.all(ident[:, 9:] == 0)
+
+
+def test_capacity_limit():
+    m = load_model("panda_no_gripper")
+    assert build_walk(m._spec, targets=[8]).capacity == 8
+    assert build_walk(m._spec, targets=[2]).capacity == 4
+
+
+# ------------------------------------------------------------------ API behaviour without a GPU
+def test_cpu_model_has_no_compute_path():
+    m = load_model("panda_no_gripper", device="cpu")
+    q = torch.zeros(3, 7)
+    for call in (lambda: m.compute_forward_kinematics(q, "panda_virtual_ee_link"),
+                 lambda: m.compute_endeffector_jacobian(q, "panda_virtual_ee_link"),
+                 lambda: m.compute_inverse_dynamics(q, q, q)):
+        with pytest.raises(RuntimeError, match="no CPU compute path"):
+            call()
+
+
+def test_tensor_check_and_errors():
+    m = load_model("panda_no_gripper", device="cpu")
+    with pytest.raises(AssertionError):                       # ndim must be 1 or 2 (robot_model.py:42-43)
+        m.compute_forward_kinematics(torch.zeros(2, 3, 7), "panda_virtual_ee_link")
+    with pytest.raises(AssertionError):                       # batch mismatch (robot_model.py:45-48)
+        m.compute_inverse_dynamics(torch.zeros(3, 7), torch.zeros(4, 7), torch.zeros(3, 7))
+    with pytest.raises(AssertionError):                       # wrong DoF count (robot_model.py:151-154)
+        m.compute_inverse_dynamics(torch.zeros(3, 6), torch.zeros(3, 6), torch.zeros(3, 6))
+    with pytest.raises(KeyError):                             # unknown link
+        m.compute_forward_kinematics(torch.zeros(3, 7), "no_such_link")
+    with pytest.raises(AttributeError):                       # robot_model.py:676-679
+        m.make_link_param_learnable("panda_link1", "colour", torch.nn.Identity())
+    assert m.get_link_names()[0] == "panda_link0" and len(m.get_joint_limits()) == 7
+
+
+def test_learnable_parameters_reach_the_constant_table():
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
+    torch.manual_seed(0)
+    m = load_model("iiwa7", device="cpu")
+    before = m._link_table().clone()
+    m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(dim1=1, dim2=3))
+    m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(dim1=1, dim2=3))
+    names = [n for n, _ in m.named_parameters()]
+    assert len(names) == 2 and all("_bodies.1." in n for n in names)
+    table = m._link_table()
+    assert table.requires_grad and not torch.equal(table[1], before[1]) and torch.equal(table[2:], before[2:])
+    table[:, :12].sum().backward()
+    grads = [p.grad for p in m.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    m.freeze_learnable_link_param("iiwa_link_1", "trans")
+    assert sum(p.requires_grad for p in m.parameters()) == 1
+    m.unfreeze_learnable_link_param("iiwa_link_1", "trans")
+    assert sum(p.requires_grad for p in m.parameters()) == 2
+    assert "_bodies.1.trans.param" in m.state_dict()
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "drm_hip.h")).read()
+    declared = set(re.findall(r"\b(drm_[a-z_]+)\s*\(", header))
+    assert declared == set(backend.EXPORTS), declared ^ set(backend.EXPORTS)
+    assert os.path.exists(backend.LIB_PATH), "run `python __graft_entry__.py build` first"
+    lib = ctypes.CDLL(backend.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.drm_abi_version() == backend.ABI_VERSION == int(re.search(r"#define DRM_ABI_VERSION (\d+)", header).group(1))
+
+
+def test_abi_argument_errors_need_no_gpu():
+    lib = backend.load_library()
+    assert lib.drm_fk_jacobian(None, None, 1, None, None, None, None, None) == -1
+    assert b"NULL" in lib.drm_last_error()
+    w = backend.DrmWalk(1, 1, 9, 8, 7, 0, 0, 2, 0)   # n_ops > capacity
+    assert lib.drm_rnea(ctypes.byref(w), None, None, None, 1, 0, None, None) == -1
+    w = backend.DrmWalk(1, 1, 8, 10, 7, 0, 0, 2, 0)  # unsupported capacity
+    assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -2
+    assert ctypes.sizeof(backend.DrmWalk) == 48
