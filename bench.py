@@ -67,7 +67,7 @@ def cpu_baseline(spec, link_idx, q_host, seconds):
     t0 = time.perf_counter()
     orc.fk_jacobian(q, link_idx, np.float32)
     one = time.perf_counter() - t0
-    reps = max(1, min(200, int(seconds / max(one, 1e-6))))
+    reps = max(1, min(20000, int(seconds / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.fk_jacobian(q, link_idx, np.float32)
@@ -76,6 +76,21 @@ def cpu_baseline(spec, link_idx, q_host, seconds):
     return {"value": evals / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d passes over the same %d-sample batch (%.1f s of CPU work), fp32 C restatement of the "
                       "reference algorithm (oracle/drm_oracle.c), OpenMP over samples" % (reps, q.shape[0], dt)}
+
+
+def recorded_traffic(batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), if this
+    batch size was profiled; PMC counters cannot be collected from inside the timed run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)["per_batch"].get(str(batch))
+            if rec:
+                return rec["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def main():
@@ -167,6 +182,7 @@ def main():
         bytes_per_eval = 4 * (n + 7 + 6 * n)        # q in; pos, quat, lin_jac, ang_jac out
         launch_s = dev_time / K                     # average duration of one launch, HIP events on the launch stream
         achieved = bytes_per_eval * B / launch_s / 1e9
+        traffic, traffic_src = recorded_traffic(B) if args.robot == "panda_no_gripper" else (None, None)
         line = {
             "metric": "FK+Jacobian evals/sec, Panda 7-DoF, batch=65 536 @1/2/4/8 MI355X",
             "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -179,7 +195,9 @@ def main():
                        "launch": "hipGraph of K launches" if graph is not None else "eager launches",
                        "gather": bool(gathered is not None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_eval * B,
                          "kernel": "drm::fk_jacobian_kernel<8, 7>", "bytes_per_eval": bytes_per_eval,
                          "launch_us": launch_s * 1e6,
                          "note": "algorithmic bytes / average launch duration (HIP events over the timed region, "
