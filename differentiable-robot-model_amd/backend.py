@@ -37,7 +37,8 @@ class NativeLibraryError(RuntimeError):
 _lib = None
 _lock = threading.Lock()
 
-EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea")
+EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
+           "drm_fk_backward_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -67,6 +68,10 @@ def load_library(path: str = None):
         lib.drm_fk_jacobian.argtypes = [wp, vp, i64, vp, vp, vp, vp, vp]
         lib.drm_rnea.restype = ctypes.c_int
         lib.drm_rnea.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
+        lib.drm_fk_backward.restype = ctypes.c_int
+        lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp]
+        lib.drm_fk_backward_scratch_floats.restype = i64
+        lib.drm_fk_backward_scratch_floats.argtypes = [i64, i32]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         _lib = lib
@@ -152,6 +157,30 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
                             _stream(q.device)))
     return tau
+
+
+def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_dofs: int, param_mask: int,
+                want_grad_q: bool):
+    """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for a loss gradient on the target positions."""
+    lib = load_library()
+    if not prog.slots_unique:
+        raise RuntimeError("backward FK needs a walk whose branch points own their save slots (more than %d "
+                           "branch points in this tree)" % prog.n_slots)
+    q = _dev_f32(q, "q", n_dofs)
+    B = q.shape[0]
+    grad_pos = _dev_f32(grad_pos.reshape(B, n_targets * 3), "grad_pos", n_targets * 3)
+    dev = q.device
+    grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
+    grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
+    if grad_q is None and grad_ops is None:
+        return None, None
+    scratch = torch.empty(max(1, lib.drm_fk_backward_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(dev):
+        _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
+                                   ctypes.c_uint32(param_mask), grad_q.data_ptr() if want_grad_q else None,
+                                   grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
+    return grad_q, grad_ops
 
 
 class FkJacobianPlan(object):

@@ -1,0 +1,223 @@
+// drm_fk_backward.hip — K5: reverse-mode derivative of the multi-target FK (positions) with respect to the joint
+// angles and the per-link constants R_fixed / trans.
+//
+// Replaces what torch autograd does for the reference when a loss on compute_forward_kinematics' position is
+// back-propagated (robot_model.py:139-195, 223-248 with learnable link parameters robot_model.py:669-713;
+// examples/learn_kinematics_of_iiwa.py:25-61, examples/run_kinematic_trajectory_opt.py): there, one backward node
+// per tiny torch op of the per-link Python loop; here, one adjoint sweep per sample (drm_sample.hpp
+// fk_backward_walk) that recomputes the FK instead of saving per-link poses, plus a fixed-order reduction of the
+// per-link constant gradients over the batch.
+//
+// Per sample: in q[n], grad_pos[T,3]; out grad_q[n] (optional).                 n = 7, T = 1: 28 + 12 + 28 = 68 B
+// Per launch: out grad_ops_f[cap, 32] (dL/dF at +0..8, dL/dt at +9..11 of every op selected by param_mask, zeros
+//             elsewhere), reduced DETERMINISTICALLY: each wave strides over tiles and keeps one running sum per
+//             (op, field) in a lane of an accumulator register, writes one row of `partials`, and a second tiny
+//             kernel adds the rows in a fixed order.
+// LDS per wave: [ q : 64 (n|1) ][ grad_pos : 64 (3T|1) ][ grad_q : 64 (n|1) ][ pose slots : n_slots*12*64 ]
+//               [ adjoint slots : n_slots*12*64 ]
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+constexpr int BWD_FIELDS = 12;          // dF (9) + dt (3) per op
+constexpr int BWD_MAX_WAVES = 2048;     // 256 CUs x 4 SIMDs x 2: rows of `partials`
+
+// Sum over the 64 lanes of a wave, result valid in lane 63: DPP row shifts, then row broadcasts (fixed order).
+// Lanes that are shifted in from outside a row or masked off receive `old` = 0, i.e. they add nothing.
+#define DRM_DPP_ADD(v, ctrl, row_mask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    DRM_DPP_ADD(v, 0x111, 0xf); // row_shr:1
+    DRM_DPP_ADD(v, 0x112, 0xf); // row_shr:2
+    DRM_DPP_ADD(v, 0x114, 0xf); // row_shr:4
+    DRM_DPP_ADD(v, 0x118, 0xf); // row_shr:8   -> lane 15 of every row holds the row's sum
+    DRM_DPP_ADD(v, 0x142, 0xa); // row_bcast:15 into rows 1 and 3
+    DRM_DPP_ADD(v, 0x143, 0xc); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+#undef DRM_DPP_ADD
+
+template <int CAP>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    fk_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int T,
+                       const float *__restrict__ q, const float *__restrict__ gpos, int64_t B, float *__restrict__ gq,
+                       uint32_t param_mask, float *__restrict__ partials, uint32_t magic_q, uint32_t magic_g,
+                       int lds_per_wave, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NV = CAP * BWD_FIELDS, NACC = (NV + WAVE - 1) / WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t wave_id = (int64_t)blockIdx.x * wpb + wave_in_block;
+    const int64_t n_waves = (int64_t)gridDim.x * wpb;
+    const int64_t n_tiles = (B + WAVE - 1) / WAVE;
+
+    const int Sq = pad_odd(n), Sg = pad_odd(3 * T);
+    float *lq = smem + wave_in_block * lds_per_wave;
+    float *lg = lq + round4(WAVE * Sq);
+    float *lgq = lg + round4(WAVE * Sg);
+    float *lps = lgq + round4(WAVE * Sq);       // pose slots    [slot][12][64]
+    float *las = lps + n_slots * (12 * WAVE);   // adjoint slots [slot][12][64]
+
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t b0 = tile * WAVE;
+        const int64_t left = B - b0;
+        const int rows = left < WAVE ? (int)left : WAVE;
+        const bool full = rows == WAVE;
+        const bool live = (int)lane < rows;
+        wave_lds_sync(); // the previous tile's LDS reads are done before this tile overwrites
+        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, full && (n & 1) && (align & AL_Q));
+        tile_load<0>(gpos + b0 * 3 * T, rows, 3 * T, magic_g, lg, lane, full && ((3 * T) & 1) && (align & AL_POS));
+        for (int s = 0; s < n_slots * 12; ++s) las[s * WAVE + lane] = 0.0f;
+        wave_lds_sync();
+
+        const float *qrow = lq + lane * Sq;
+        const float *grow = lg + lane * Sg;
+        float *gqrow = lgq + lane * Sq;
+        if (gq)
+            for (int d = 0; d < n; ++d) gqrow[d] = 0.0f; // DoFs that are not on any target's chain
+        auto qf = [&](int d) -> float { return qrow[d]; };
+        auto grad_in = [&](int t, float *G) {
+            G[0] += grow[t * 3 + 0]; G[1] += grow[t * 3 + 1]; G[2] += grow[t * 3 + 2];
+        };
+        auto pose_save = [&](int s, const Pose &P) {
+            float *b = lps + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) b[i * WAVE] = P.R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[(9 + i) * WAVE] = P.p[i];
+        };
+        auto pose_load = [&](int s, Pose &P) {
+            const float *b = lps + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) P.R[i] = b[i * WAVE];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.p[i] = b[(9 + i) * WAVE];
+        };
+        auto adj_add = [&](int s, const Adjoint &A) {
+            float *b = las + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[i * WAVE] += A.G[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) b[(3 + i) * WAVE] += A.M[i];
+        };
+        auto adj_take = [&](int s, Adjoint &A) {
+            const float *b = las + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) A.G[i] += b[i * WAVE];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A.M[i] += b[(3 + i) * WAVE];
+        };
+        auto gq_out = [&](int d, float v) { gqrow[d] = v; };
+        float add[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
+        auto param_out = [&](int k, const float *dF, const float *dt) {
+#pragma unroll
+            for (int j = 0; j < BWD_FIELDS; ++j) {
+                const float mine = live ? (j < 9 ? dF[j] : dt[j - 9]) : 0.0f; // lanes past a partial tile hold garbage
+                const float total = wave_sum_lane63(mine);
+                const int idx = k * BWD_FIELDS + j;
+                const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
+                if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s; // lane idx%64 of accumulator idx/64 owns (k, j)
+            }
+        };
+        fk_backward_walk<CAP>(ops_f, ops_i, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
+                              adj_take, gq_out, param_out);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += add[a];
+        if (gq) {
+            wave_lds_sync();
+            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, full && (n & 1) && (align & AL_TAU));
+        }
+    }
+    // one row of partial sums per wave (zeros for waves that had no tile)
+    float *prow = partials + wave_id * NV;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        const int idx = a * WAVE + (int)lane;
+        if (idx < NV) prow[idx] = acc[a];
+    }
+}
+
+// grad_ops_f[k, j] = sum over the partial rows, fixed order: lane l adds rows l, l+64, ... then the wave adds lanes.
+__global__ void __launch_bounds__(WAVE)
+    fk_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f) {
+    const int k = blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    const int NV = cap * BWD_FIELDS;
+    if (lane < DRM_OPF_STRIDE - BWD_FIELDS) grad_ops_f[k * DRM_OPF_STRIDE + BWD_FIELDS + lane] = 0.0f;
+    for (int j = 0; j < BWD_FIELDS; ++j) {
+        float s = 0.0f;
+        for (int r = (int)lane; r < n_rows; r += WAVE) s += partials[(int64_t)r * NV + k * BWD_FIELDS + j];
+        s = wave_sum_lane63(s);
+        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + j] = s;
+    }
+}
+
+static int backward_waves(int64_t B, int wpb) {
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    int64_t waves = tiles < BWD_MAX_WAVES ? tiles : BWD_MAX_WAVES;
+    waves = (waves + wpb - 1) / wpb * wpb;
+    return (int)(waves < 1 ? wpb : waves);
+}
+
+} // namespace drm
+
+using namespace drm;
+
+extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
+    if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS) return 0;
+    // rows: waves of the launch rounded up to a full block of MAX_WAVES_PER_BLOCK
+    return (int64_t)backward_waves(B, MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS;
+}
+
+extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
+                               uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !grad_pos) return fail(DRM_ERR_INVALID, "q / grad_pos must not be NULL");
+    if (B < 0 || n_targets < 1) return fail(DRM_ERR_INVALID, "negative batch or no targets");
+    if (n_targets > w->n_ops) return fail(DRM_ERR_INVALID, "more targets than ops in the walk");
+    if ((param_mask != 0) != (grad_ops_f != nullptr))
+        return fail(DRM_ERR_INVALID, "grad_ops_f must be given exactly when param_mask selects ops");
+    if (!grad_q && !grad_ops_f) return fail(DRM_ERR_INVALID, "nothing to compute: grad_q and grad_ops_f are both NULL");
+    if (!scratch) return fail(DRM_ERR_INVALID, "scratch must not be NULL (drm_fk_backward_scratch_floats)");
+    if (w->capacity < 32 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
+    const int n = w->n_dofs, T = n_targets, cap = w->capacity;
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        if (grad_ops_f) {
+            hipError_t e = hipMemsetAsync(grad_ops_f, 0, sizeof(float) * cap * DRM_OPF_STRIDE, s);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return DRM_OK;
+    }
+    Geometry g;
+    rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE, g);
+    if (rc) return rc;
+    const int wpb = (int)(g.block.x / WAVE);
+    const int waves = backward_waves(B, wpb);
+    g.grid = dim3((unsigned)(waves / wpb));
+    const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU);
+    DRM_DISPATCH_CAP(cap, {
+        rc = ensure_lds(fk_backward_kernel<C>, g.lds_bytes);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fk_backward_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
+                           (int)w->n_slots, T, q, grad_pos, B, grad_q, param_mask, scratch, div_magic(n),
+                           div_magic(3 * T), g.lds_per_wave, align);
+    })
+    rc = launched();
+    if (rc) return rc;
+    if (grad_ops_f) {
+        hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, scratch, waves, cap,
+                           grad_ops_f);
+        rc = launched();
+    }
+    return rc;
+}

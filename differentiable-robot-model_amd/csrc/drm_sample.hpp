@@ -270,6 +270,119 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
 }
 
 // ---------------------------------------------------------------------------
+// Reverse-mode derivative of the multi-target FK walk with respect to the joint
+// angles and the per-link constants F (R_fixed) and t (trans), for a loss that
+// depends on the target POSITIONS (the reference's quaternion is not
+// differentiable, spatial_vector_algebra.py:108-136).  This is what torch
+// autograd produces for the reference's robot_model.py:139-195 + 223-248 with
+// learnable `trans` / `rot_angles` (robot_model.py:669-713,
+// examples/learn_kinematics_of_iiwa.py:25-61), restated as one adjoint sweep:
+//
+//   for every op k (reverse order), with r = p_d - p_k over the targets d below k,
+//     G_k = sum g_d                 (dL/dp_k, world frame)
+//     M_k = sum g_d r^T             (first moment of the target gradients about p_k)
+//     dL/dt_k = R_p^T G_k           dL/dF_k = (R_p^T M_k) (R_p F_k)
+//     dL/dq_k = sign_k z_k . N_k,   z_k = R_k e_z,  N_k = sum r x g_d  (antisymmetric part of M_k)
+//   and (G, M) move to the parent as  G_p += G_k,  M_p += M_k + G_k (p_k - p_p)^T.
+//
+//   grad_in(t, G)          adds the loss gradient of target slot t to G[3]
+//   pose_save / pose_load  branch-point poses (LDS); slots must be unique per branch point
+//   adj_add / adj_take     branch-point adjoints (LDS), take = read-and-add
+//   gq_out(d, v)           dL/dq of DoF d
+//   param_out(k, dF, dt)   per-sample dL/dF (9), dL/dt (3) of op k, only for ops in param_mask
+// ---------------------------------------------------------------------------
+struct Adjoint {
+    float G[3];
+    float M[9];
+};
+
+template <int CAP, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG>
+DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, uint32_t param_mask,
+                             bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
+                             ATAKE adj_take, GQ gq_out, PG param_out) {
+    int dof[CAP], sign[CAP];
+    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+    load_field<CAP>(opi, DRM_OPI_SIGN, sign);
+    float cs[CAP], sn[CAP];
+    joint_trig<CAP>(dof, sign, qf, cs, sn);
+    // ---- forward: world pose of every op, kept for the adjoint sweep -------
+    Pose P[CAP];
+    Pose cur;
+    pose_identity(cur);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        float J[9];
+        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+        if (src >= 0) pose_load(src, cur);
+        if (src == DRM_SRC_ROOT) compose_root(J, of + DRM_OPF_T, cur);
+        else compose(cur, J, of + DRM_OPF_T, cur);
+        if (save >= 0) pose_save(save, cur);
+        P[k] = cur;
+    }
+    // ---- adjoint sweep -------------------------------------------------------
+    Adjoint carry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) carry.G[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) carry.M[i] = 0.0f;
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
+        Adjoint tot;
+        if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
+            tot = carry;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.G[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tot.M[i] = 0.0f;
+        }
+        if (out >= 0) grad_in(out, tot.G);
+        if (save >= 0) adj_take(save, tot);
+        Pose par;
+        if (src >= 0) pose_load(src, par);
+        else if (src == DRM_SRC_ROOT || k == 0) pose_identity(par);
+        else par = P[k > 0 ? k - 1 : 0];
+        if (want_gq && dof[k] >= 0) {
+            const float Nx = tot.M[7] - tot.M[5], Ny = tot.M[2] - tot.M[6], Nz = tot.M[3] - tot.M[1];
+            gq_out(dof[k], (float)sign[k] * (P[k].R[2] * Nx + P[k].R[5] * Ny + P[k].R[8] * Nz));
+        }
+        if ((param_mask >> k) & 1u) {
+            float dt[3], A[9], Bm[9], dF[9];
+            matT_vec(par.R, tot.G, dt);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    A[r * 3 + c] = par.R[0 * 3 + r] * tot.M[0 * 3 + c] + par.R[1 * 3 + r] * tot.M[1 * 3 + c] +
+                                   par.R[2 * 3 + r] * tot.M[2 * 3 + c];
+                    Bm[r * 3 + c] = par.R[r * 3 + 0] * of[DRM_OPF_F + 0 * 3 + c] +
+                                    par.R[r * 3 + 1] * of[DRM_OPF_F + 1 * 3 + c] +
+                                    par.R[r * 3 + 2] * of[DRM_OPF_F + 2 * 3 + c];
+                }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    dF[r * 3 + c] = A[r * 3 + 0] * Bm[0 * 3 + c] + A[r * 3 + 1] * Bm[1 * 3 + c] + A[r * 3 + 2] * Bm[2 * 3 + c];
+            param_out(k, dF, dt);
+        }
+        if (src != DRM_SRC_ROOT) {
+            const float r[3] = {P[k].p[0] - par.p[0], P[k].p[1] - par.p[1], P[k].p[2] - par.p[2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tot.M[i * 3 + j] += tot.G[i] * r[j];
+            if (src >= 0) adj_add(src, tot);
+            else carry = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // RNEA over the whole tree (robot_model.py:250-375).  Body-frame Pluecker
 // coordinates at the link origin, as in the reference.
 //   qf(d, q, qd, qdd)   -> joint state of DoF d

@@ -164,6 +164,7 @@ class WalkProgram:
     capacity: int            # compiled kernel capacity that fits n_ops
     targets: List[int]       # link index per output slot
     dof_mask: int            # bit d set <=> DoF d is driven by some op of this walk
+    slots_unique: bool = True  # every branch point owns its slot for the whole walk (needed by the backward walk)
 
 
 def _capacity_for(n_ops: int) -> int:
@@ -209,19 +210,26 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
         out_of[t] = slot
 
     ops, links = [], []
-    free_slots = list(range(MAX_SLOTS))[::-1]
+    # slots are handed out fresh while there are any (so that a slot keeps its branch point's state for the
+    # whole walk, which the backward walk relies on) and only recycled once all MAX_SLOTS have been used
+    free_slots = []
     max_used = 0
+    unique = True
 
     def visit(i, src):
-        nonlocal max_used
+        nonlocal max_used, unique
         kids = [c for c in spec.children[i] if needed[c]]
         save = -1
         if len(kids) > 1:
-            if not free_slots:
+            if max_used < MAX_SLOTS:
+                save = max_used
+                max_used += 1
+            elif free_slots:
+                save = free_slots.pop()
+                unique = False
+            else:
                 raise UnsupportedRobotError(
                     "tree needs more than %d nested branch points; not supported by the compiled kernels" % MAX_SLOTS)
-            save = free_slots.pop()
-            max_used = max(max_used, MAX_SLOTS - len(free_slots))
         flags = FLAG_CHILD_IS_NEXT if kids else 0
         perm = int(spec.axis_idx[i]) if spec.dof[i] >= 0 else 2
         ops.append([int(spec.dof[i]), perm, int(spec.axis_sign[i]), src, save, out_of.get(i, -1), i, flags])
@@ -262,7 +270,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
         if row[OPI_DOF] >= 0:
             mask |= 1 << row[OPI_DOF]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, n_ops, max_used,
-                       cap, tlist, mask)
+                       cap, tlist, mask, unique)
 
 
 def identity_table_row() -> np.ndarray:

@@ -85,6 +85,35 @@ class _DeviceWalk:
     static_ops_f: Optional[torch.Tensor] = None
 
 
+class _FkPositions(torch.autograd.Function):
+    """FK of the walk's targets with a hand-written backward (csrc/drm_fk_backward.hip).
+
+    Differentiable: positions with respect to q and to the walk's constant table (and through its gather, to
+    learnable ``trans`` / ``rot_angles`` parametrisations).  The quaternion output carries no gradient, as in
+    the reference (spatial_vector_algebra.py:108-136 builds it outside autograd).
+    """
+
+    @staticmethod
+    def forward(ctx, q, ops_f, dw, n_targets, n_dofs, param_mask):
+        pos, quat = backend.fk(dw.program, ops_f, dw.ops_i, q, n_targets, n_dofs)
+        ctx.save_for_backward(q, ops_f)
+        ctx.dw, ctx.n_targets, ctx.n_dofs, ctx.param_mask = dw, n_targets, n_dofs, param_mask
+        ctx.mark_non_differentiable(quat)
+        return pos, quat
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_pos, _grad_quat):
+        q, ops_f = ctx.saved_tensors
+        want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dw = ctx.dw
+        grad_q, grad_ops = backend.fk_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, ctx.n_targets, ctx.n_dofs,
+                                               ctx.param_mask if want_p else 0, want_q)
+        if grad_q is not None:
+            grad_q = grad_q.to(q.dtype).reshape(q.shape)
+        return grad_q, grad_ops, None, None, None, None
+
+
 class DifferentiableRobotModel(torch.nn.Module):
     """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
 
@@ -195,6 +224,27 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw.static_ops_f = ops_f
         return ops_f
 
+    def _kinematic_param_mask(self, dw: _DeviceWalk) -> int:
+        """bit k set <=> op k's R_fixed / trans come from a learnable parametrisation (needs a constant gradient)."""
+        links = {link for link, pname in self._learnable if pname in ("trans", "rot_angles")}
+        mask = 0
+        for k, link in enumerate(dw.program.links):
+            if int(link) in links:
+                mask |= 1 << k
+        return mask
+
+    def _refuse_autograd(self, what: str, *tensors):
+        """The kernels behind ``what`` have no backward yet: refuse loudly rather than return silently detached
+        results where the reference would have propagated gradients."""
+        if not torch.is_grad_enabled():
+            return
+        live = any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+        live = live or (bool(self._learnable) and any(p.requires_grad for p in self.parameters()))
+        if live:
+            raise NotImplementedError(
+                "%s has no backward kernel yet: call it under torch.no_grad() (gradients are implemented for the "
+                "position output of compute_forward_kinematics[_all_links])" % what)
+
     def _require_device(self):
         if self._device.type != "cuda":
             raise RuntimeError(
@@ -213,7 +263,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         if non_root:
             dw = self._get_walk(("fk", tuple(non_root)), targets=non_root)
             ops_f = self._ops_f(dw)
-            p, r = backend.fk(dw.program, ops_f, dw.ops_i, q, len(non_root), self._n_dofs)
+            if torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
+                p, r = _FkPositions.apply(q, ops_f, dw, len(non_root), self._n_dofs, self._kinematic_param_mask(dw))
+            else:
+                p, r = backend.fk(dw.program, ops_f, dw.ops_i, q, len(non_root), self._n_dofs)
             if len(non_root) == len(link_idxs):
                 return p, r
             cols = [k for k, i in enumerate(link_idxs) if i != 0]
@@ -264,6 +317,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         self._require_device()
+        self._refuse_autograd("compute_endeffector_jacobian / compute_fk_and_jacobian", q)
         idx = self._name_to_idx_map[link_name]
         dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
         ops_f = self._ops_f(dw)
@@ -292,6 +346,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert qd.shape[1] == self._n_dofs
         assert qdd_des.shape[1] == self._n_dofs
         self._require_device()
+        self._refuse_autograd("compute_inverse_dynamics", q, qd, qdd_des)
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
         return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd_des, bool(include_gravity), bool(use_damping),
@@ -304,6 +359,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2 and qd.ndim == 2
         assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs
         self._require_device()
+        self._refuse_autograd("compute_non_linear_effects", q, qd)
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
         return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, None, bool(include_gravity), bool(use_damping),

@@ -131,6 +131,24 @@ int drm_fk_jacobian(const drm_walk *walk, const float *q, int64_t B,
 int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B,
              int32_t flags, float *tau, void *stream);
 
+/*
+ * Reverse-mode derivative of drm_fk's POSITIONS: what torch autograd computes in the reference when a loss on
+ * compute_forward_kinematics' position is back-propagated to q and to learnable `trans` / `rot_angles`
+ * (robot_model.py:139-195, 223-248, 669-713; examples/learn_kinematics_of_iiwa.py:25-61).  The quaternion has
+ * no gradient in the reference (spatial_vector_algebra.py:108-136) and none here.
+ *   q          [B, n]        joint angles of the forward call
+ *   grad_pos   [B, T, 3]     dL/dpos of every target
+ *   param_mask               bit k set: produce the constant gradient of op k (its link is learnable)
+ *   grad_q     [B, n]        dL/dq, or NULL
+ *   grad_ops_f [capacity, DRM_OPF_STRIDE]  dL/dF at +DRM_OPF_F (9), dL/dt at +DRM_OPF_T (3), summed over the
+ *                            batch in a fixed order (deterministic); zeros elsewhere.  NULL iff param_mask == 0.
+ *   scratch    drm_fk_backward_scratch_floats(B, capacity) floats, owned by the caller
+ * The walk must give every branch point its own save slot (flatten.WalkProgram.slots_unique).
+ */
+int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity);
+int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
+                    uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,7 @@ def quat_close(a, b, atol):
 
 def max_err(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def load_golden_grad():
+    return np.load(os.path.join(GOLDEN_DIR, "golden_grad.npz"), allow_pickle=False)

@@ -80,6 +80,40 @@ void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd
     }
 }
 
+// reverse-mode FK: per-sample adjoint sweep, constant gradients summed over the batch in double
+template <int CAP>
+void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, uint32_t mask, float *gq, float *gops) {
+    const int n = w->n_dofs;
+    static thread_local double sum[CAP * 12];
+    for (int i = 0; i < CAP * 12; ++i) sum[i] = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        Pose ps[DRM_MAX_SLOTS];
+        Adjoint as[DRM_MAX_SLOTS] = {};
+        if (gq) for (int d = 0; d < n; ++d) gq[b * n + d] = 0.f;
+        auto qf = [&](int d) { return q[b * n + d]; };
+        auto gin = [&](int t, float *G) { for (int i = 0; i < 3; ++i) G[i] += gpos[(b * T + t) * 3 + i]; };
+        auto psave = [&](int s, const Pose &P) { ps[s] = P; };
+        auto pload = [&](int s, Pose &P) { P = ps[s]; };
+        auto aadd = [&](int s, const Adjoint &A) {
+            for (int i = 0; i < 3; ++i) as[s].G[i] += A.G[i];
+            for (int i = 0; i < 9; ++i) as[s].M[i] += A.M[i];
+        };
+        auto atake = [&](int s, Adjoint &A) {
+            for (int i = 0; i < 3; ++i) A.G[i] += as[s].G[i];
+            for (int i = 0; i < 9; ++i) A.M[i] += as[s].M[i];
+        };
+        auto gqo = [&](int d, float v) { gq[b * n + d] = v; };
+        auto pout = [&](int k, const float *dF, const float *dt) {
+            for (int j = 0; j < 9; ++j) sum[k * 12 + j] += dF[j];
+            for (int j = 0; j < 3; ++j) sum[k * 12 + 9 + j] += dt[j];
+        };
+        fk_backward_walk<CAP>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout);
+    }
+    if (gops)
+        for (int k = 0; k < CAP; ++k)
+            for (int j = 0; j < DRM_OPF_STRIDE; ++j) gops[k * DRM_OPF_STRIDE + j] = j < 12 ? (float)sum[k * 12 + j] : 0.f;
+}
+
 } // namespace
 
 #define DISPATCH(FN, ...)                        \
@@ -100,6 +134,11 @@ int emu_fk(const drm_walk *w, const float *q, int64_t B, int32_t T, float *pos, 
 }
 int emu_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
     DISPATCH(jac_t, w, q, B, pos, quat, lin, ang)
+    return 0;
+}
+int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,
+                    float *gops) {
+    DISPATCH(fkb_t, w, q, B, T, gpos, mask, gq, gops)
     return 0;
 }
 int emu_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {

@@ -1,0 +1,224 @@
+"""FK backward (K5, csrc/drm_fk_backward.hip + drm_sample.hpp::fk_backward_walk).
+
+CPU part (not gpu): the per-sample adjoint sweep compiled with g++ (tests/host_emu) against
+  * gradients recorded from the UNMODIFIED reference through torch autograd (tests/golden/golden_grad.npz,
+    made by tests/golden/make_golden_grad.py; mirrors examples/learn_kinematics_of_iiwa.py:25-61),
+  * central differences of the fp64 oracle.
+GPU part (-m gpu): the real kernels through the public API + torch.autograd, same fixtures, plus BASELINE
+config 5 (iiwa, batch 16 384) against the host emulation and determinism of the batch reduction.
+Tolerance: gradients rtol 1e-3 of the largest entry (observed ~1e-5).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from differentiable_robot_model_amd.flatten import build_walk
+from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
+from helpers import load_golden_grad, load_model, sample_states
+from oracle import Oracle
+from test_host_emu import _ptr, emu, host_walk  # noqa: F401  (emu is a fixture)
+
+CASES = ["iiwa7", "panda_no_gripper", "allegro_left", "trifinger_edu"]
+GRAD_RTOL = 1e-3
+
+
+def close(a, b, rtol=GRAD_RTOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-12)
+
+
+def learnable_model(g, case, device="cpu"):
+    m = load_model(case, device)
+    for link in g[case + "/learnable"]:
+        for pname in ("trans", "rot_angles"):
+            init = torch.from_numpy(g["%s/init/%s/%s" % (case, link, pname)].copy())
+            m.make_link_param_learnable(str(link), pname, UnconstrainedTensor(dim1=1, dim2=3, init_tensor=init))
+    return m
+
+
+def emu_loss_and_grads(emu, m, q, targets, wants):
+    """Forward + backward through the host emulation and torch autograd of the constant table (CPU)."""
+    idx = [m._name_to_idx_map[t] for t in targets]
+    prog = build_walk(m._spec, targets=idx)
+    assert prog.slots_unique
+    table = m._link_table()
+    ops_f_t = table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))].reshape(prog.capacity, 32)
+    ops_f = np.ascontiguousarray(ops_f_t.detach().numpy(), np.float32)
+    walk, _keep = host_walk(m, prog)
+    walk.ops_f = ops_f.ctypes.data
+    B, T, n = q.shape[0], len(idx), m._n_dofs
+    pos = np.zeros((B, T, 3), np.float32); quat = np.zeros((B, T, 4), np.float32)
+    assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(pos), _ptr(quat)) == 0
+    want = np.stack(wants, axis=1)
+    loss = sum(((pos[:, t] - want[:, t]) ** 2).mean() for t in range(T))
+    gpos = np.ascontiguousarray(2.0 * (pos - want) / (B * 3), np.float32)
+    gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    mask = m._kinematic_param_mask(type("W", (), {"program": prog})())
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(mask),
+                               _ptr(gq), _ptr(gops)) == 0
+    m.zero_grad()
+    ops_f_t.backward(torch.from_numpy(gops))
+    return loss, pos, gq, gops, mask
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_emu_backward_vs_reference_autograd(emu, case):
+    g = load_golden_grad()
+    m = learnable_model(g, case)
+    targets = [str(t) for t in g[case + "/targets"]]
+    q = np.ascontiguousarray(g[case + "/q"])
+    wants = [g["%s/want/%s" % (case, t)] for t in targets]
+    loss, pos, gq, gops, mask = emu_loss_and_grads(emu, m, q, targets, wants)
+    assert abs(loss - float(g[case + "/loss"])) < 1e-6
+    for t_i, t in enumerate(targets):
+        assert np.abs(pos[:, t_i] - g["%s/pos/%s" % (case, t)]).max() < 2e-6
+    assert close(gq, g[case + "/grad_q"]), np.abs(gq - g[case + "/grad_q"]).max()
+    for link in g[case + "/learnable"]:
+        body = m._bodies[m._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            got = getattr(body, pname).param.grad.numpy()
+            ref = g["%s/grad/%s/%s" % (case, link, pname)]
+            assert close(got, ref), (case, link, pname, got, ref)
+    # ops outside the mask (and the padding) get exactly zero constant gradient
+    for k in range(gops.shape[0]):
+        if not (mask >> k) & 1:
+            assert not gops[k].any()
+
+
+@pytest.mark.parametrize("robot", ["iiwa7", "allegro_left", "trifinger_edu", "panda", "jaco_clean"])
+def test_emu_grad_q_vs_oracle_central_differences(emu, robot):
+    m = load_model(robot)
+    n, B = m._n_dofs, 5
+    L = len(m._bodies)
+    leaves = [i for i in range(1, L) if not m._spec.children[i]]
+    prog = build_walk(m._spec, targets=leaves)
+    walk, _keep = host_walk(m, prog)
+    q, _, _ = sample_states(m, B, seed=11)
+    T = len(leaves)
+    rng = np.random.default_rng(5)
+    gpos = rng.standard_normal((B, T, 3)).astype(np.float32)
+    gq = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(0),
+                               _ptr(gq), None) == 0
+    orc = Oracle(m._spec)
+    h = 1e-6
+    num = np.zeros((B, n))
+    for d in range(n):
+        qp = q.astype(np.float64); qm = q.astype(np.float64)
+        qp[:, d] += h; qm[:, d] -= h
+        pp, _ = orc.fk(qp, leaves, np.float64); pm, _ = orc.fk(qm, leaves, np.float64)
+        num[:, d] = ((pp - pm) / (2 * h) * gpos).sum(axis=(1, 2))
+    assert close(gq, num, 2e-5), np.abs(gq - num).max()
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _api_loss(m, q, targets, wants):
+    loss = 0.0
+    for t, w in zip(targets, wants):
+        pos, _ = m.compute_forward_kinematics(q, t)
+        loss = loss + torch.nn.functional.mse_loss(pos, w)
+    return loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_backward_vs_reference_autograd(case):
+    g = load_golden_grad()
+    m = learnable_model(g, case, "cuda")
+    targets = [str(t) for t in g[case + "/targets"]]
+    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
+    wants = [torch.from_numpy(g["%s/want/%s" % (case, t)].copy()).cuda() for t in targets]
+    # one call per target, as the reference's loop would do it
+    loss = _api_loss(m, q, targets, wants)
+    loss.backward()
+    assert abs(loss.item() - float(g[case + "/loss"])) < 1e-6
+    assert close(q.grad.cpu().numpy(), g[case + "/grad_q"])
+    for link in g[case + "/learnable"]:
+        body = m._bodies[m._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            assert close(getattr(body, pname).param.grad.cpu().numpy(), g["%s/grad/%s/%s" % (case, link, pname)]), \
+                (case, link, pname)
+    # all targets from ONE multi-target walk (branch-point slots, adjoint slots) give the same gradients
+    m2 = learnable_model(g, case, "cuda")
+    q2 = q.detach().clone().requires_grad_(True)
+    poses = m2.compute_forward_kinematics_all_links(q2)
+    loss2 = sum(torch.nn.functional.mse_loss(poses[t][0], w) for t, w in zip(targets, wants))
+    loss2.backward()
+    assert close(q2.grad.cpu().numpy(), g[case + "/grad_q"])
+    for link in g[case + "/learnable"]:
+        b1 = m._bodies[m._name_to_idx_map[str(link)]]; b2 = m2._bodies[m2._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            assert close(getattr(b2, pname).param.grad.cpu().numpy(), getattr(b1, pname).param.grad.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
+def test_gpu_backward_ragged_batches_vs_emu(emu, B):
+    g = load_golden_grad()
+    case = "allegro_left"
+    targets = [str(t) for t in g[case + "/targets"]]
+    m = learnable_model(g, case, "cuda"); mc = learnable_model(g, case, "cpu")
+    q, _, _ = sample_states(m, B, seed=B)
+    rng = np.random.default_rng(B)
+    wants = [rng.standard_normal((B, 3)).astype(np.float32) * 0.1 for _ in targets]
+    qt = torch.from_numpy(q).cuda().requires_grad_(True)
+    poses = m.compute_forward_kinematics_all_links(qt)
+    loss = sum(torch.nn.functional.mse_loss(poses[t][0], torch.from_numpy(w).cuda()) for t, w in zip(targets, wants))
+    loss.backward()
+    _, _, gq, _, _ = emu_loss_and_grads(emu, mc, q, targets, wants)
+    assert close(qt.grad.cpu().numpy(), gq, 1e-4)
+    for link in g[case + "/learnable"]:
+        b1 = m._bodies[m._name_to_idx_map[str(link)]]; b2 = mc._bodies[mc._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            assert close(getattr(b1, pname).param.grad.cpu().numpy(), getattr(b2, pname).param.grad.numpy(), 1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_config5_iiwa_learnable_batch_16384(emu):
+    """BASELINE config 5: iiwa, learnable trans + rot_angles of iiwa_link_1, batch 16 384, FK + backward."""
+    torch.manual_seed(0)
+    B = 16384
+    m = load_model("iiwa7", "cuda"); mc = load_model("iiwa7", "cpu")
+    init_t = torch.empty(1, 3).normal_(mean=0.0, std=0.1); init_r = torch.empty(1, 3).normal_(mean=0.0, std=0.1)
+    for mm in (m, mc):
+        mm.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3, init_tensor=init_t.clone()))
+        mm.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3, init_tensor=init_r.clone()))
+    gt = load_model("iiwa7", "cuda")
+    q, _, _ = sample_states(m, B, seed=5)
+    qt = torch.from_numpy(q).cuda()
+    with torch.no_grad():
+        want, _ = gt.compute_forward_kinematics(qt, "iiwa_link_ee")
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        pos, _ = m.compute_forward_kinematics(qt, "iiwa_link_ee")
+        loss = torch.nn.functional.mse_loss(pos, want)
+        loss.backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads)), "the batch reduction must be deterministic"
+    _, _, _, _, _ = emu_loss_and_grads(emu, mc, q, ["iiwa_link_ee"], [want.cpu().numpy()])
+    for pg, pc in zip(m.parameters(), mc.parameters()):
+        assert close(pg.grad.cpu().numpy(), pc.grad.numpy(), 1e-4), (pg.grad, pc.grad)
+    # an Adam step on these gradients lowers the loss (the learning loop of the reference example)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    first = None
+    for _ in range(20):
+        opt.zero_grad()
+        pos, _ = m.compute_forward_kinematics(qt, "iiwa_link_ee")
+        loss = torch.nn.functional.mse_loss(pos, want)
+        loss.backward()
+        opt.step()
+        first = first if first is not None else loss.item()
+    assert loss.item() < 0.7 * first
+
+
+@pytest.mark.gpu
+def test_gpu_autograd_refused_where_no_backward_kernel_exists():
+    m = load_model("iiwa7", "cuda")
+    q = torch.zeros(4, 7, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        m.compute_inverse_dynamics(q, torch.zeros(4, 7).cuda(), torch.zeros(4, 7).cuda())
+    with torch.no_grad():
+        m.compute_inverse_dynamics(q, torch.zeros(4, 7).cuda(), torch.zeros(4, 7).cuda())
