@@ -27,11 +27,10 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lq = cx.lds;
     float *stage = cx.lds + round4(WAVE * Sq);
 
-    // all wave-uniform int fields of the walk in two wide scalar loads; the float table's cache
+    // the wave-uniform DoF column of every op in one wide scalar load; the float table's cache
     // lines are touched now so their misses overlap with the q tile load
-    int dof[CAP], sign[CAP];
+    int dof[CAP];
     load_field<CAP>(ops_i, DRM_OPI_DOF, dof);
-    load_field<CAP>(ops_i, DRM_OPI_SIGN, sign);
     WarmRegs<CAP> warm;
     warm_walk_issue<CAP, 1>(ops_f, warm);
     tile_load<NDOF>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
@@ -46,7 +45,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
     Pose ee;
     float z[CAP][3], pj[CAP][3];
-    fk_chain<CAP>(ops_f, dof, sign, qf, ee, z, pj);
+    fk_chain<CAP>(ops_f, dof, qf, ee, z, pj);
 
     // ---- pos [B,3]: 3 floats per lane -> LDS -> coalesced store ------------------------
     if (pos) {
@@ -114,6 +113,82 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<3 * NDOF>(ang + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_ANG));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Full-tile specialisation: every tile has 64 rows, every pointer is 16-byte aligned, pos / quat are
+// wanted, all NDOF columns are driven by the chain and NDOF is odd (linear LDS images).  This is the
+// shape of the metric workload (7-DoF arm, batch a multiple of 64).  Compared with the generic kernel:
+//   * all 16 argument dwords are preloaded into SGPRs by the command processor (kernarg preload,
+//     -mllvm -amdgpu-kernarg-preload-count=16 in the Makefile): the wave issues the walk-table scalar
+//     loads and the q tile's vector loads in its first cycles, ONE memory round trip before the math
+//     instead of kernarg -> table -> data;
+//   * no runtime shape flags, so the whole kernel is one basic block;
+//   * pos / lin_jac / ang_jac are staged in separate LDS regions: one LDS turnaround, then all the
+//     16-byte stores go out back to back.
+// The launcher sends the ragged tail (B % 64 rows) through the generic kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int CAP, int NDOF>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    fk_jacobian_full_tiles_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i,
+                                  const float *__restrict__ q, int n_tiles, int target_perm, float *__restrict__ pos,
+                                  float *__restrict__ quat, float *__restrict__ lin, float *__restrict__ ang) {
+    // argument order: the first 14 dwords are the ones the command processor preloads into SGPRs
+    static_assert(NDOF & 1, "odd row widths only (linear LDS image)");
+    constexpr int SQ = NDOF, SJ = 3 * NDOF;
+    constexpr int Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3, J_FLOATS = round4(WAVE * SJ);
+    constexpr int PER_WAVE = Q_FLOATS + P_FLOATS + 2 * J_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lq = smem + wave * PER_WAVE;
+    float *lp = lq + Q_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    int dof[CAP];
+    load_field<CAP>(ops_i, DRM_OPI_DOF, dof);
+    WarmRegs<CAP> warm;
+    warm_walk_issue<CAP, 1>(ops_f, warm);
+    tile_load<NDOF>(q + b0 * NDOF, WAVE, NDOF, 0u, lq, lane, true);
+    warm_walk_wait(warm);
+    wave_lds_sync();
+
+    const float *qrow = lq + lane * SQ;
+    auto qf = [&](int d) -> float { return qrow[d]; };
+    Pose ee;
+    float z[CAP][3], pj[CAP][3];
+    fk_chain<CAP>(ops_f, dof, qf, ee, z, pj);
+
+    // quat [B,4]: one 16-byte store per lane is already coalesced
+    {
+        float Ru[9], qt[4];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Ru[i] = ee.R[i];
+        unpermute(target_perm, Ru);
+        quat_xyzw(Ru, qt);
+        *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
+    }
+    lp[lane * 3 + 0] = ee.p[0];
+    lp[lane * 3 + 1] = ee.p[1];
+    lp[lane * 3 + 2] = ee.p[2];
+    float *lrow = ll + lane * SJ, *arow = la + lane * SJ;
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const int d = dof[k];
+        if (d >= 0) { // wave-uniform
+            const float dp[3] = {ee.p[0] - pj[k][0], ee.p[1] - pj[k][1], ee.p[2] - pj[k][2]};
+            float c[3];
+            cross3(z[k], dp, c); // robot_model.py:661
+            lrow[d] = c[0]; lrow[NDOF + d] = c[1]; lrow[2 * NDOF + d] = c[2];
+            arow[d] = z[k][0]; arow[NDOF + d] = z[k][1]; arow[2 * NDOF + d] = z[k][2]; // robot_model.py:662
+        }
+    }
+    wave_lds_sync();
+    tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+    tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
+    tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+}
+
 } // namespace drm
 
 using namespace drm;
@@ -124,7 +199,7 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
     if (rc) return rc;
     if (!q || !lin_jac || !ang_jac) return fail(DRM_ERR_INVALID, "q / lin_jac / ang_jac must not be NULL");
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
-    if (w->target_perm < 0 || w->target_perm > 2) return fail(DRM_ERR_INVALID, "target_perm must be 0, 1 or 2");
+    if (w->target_perm < 0 || w->target_perm > 5) return fail(DRM_ERR_INVALID, "target_perm must be in 0..5");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs;
     const int Sq = pad_odd(n), Sj = pad_odd(3 * n);
@@ -143,8 +218,28 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
                            w->dof_mask, q, B, pos, quat, lin_jac, ang_jac, mq, mj, g.lds_per_wave, align,            \
                            (int)w->target_perm);                                                             \
     }
-    if (w->capacity == 8 && n == 7) {
-        DRM_LAUNCH_FKJ(8, 7) // 7-DoF arms (Franka Panda, KUKA iiwa, Fetch arm): fully static tile shapes
+    const uint32_t all_al = AL_Q | AL_POS | AL_QUAT | AL_LIN | AL_ANG;
+#ifdef DRM_NO_FULL_TILES
+    if (false) {
+#else
+    if (w->capacity == 8 && n == 7 && align == all_al && w->dof_mask == 0x7full && B >= WAVE && B / WAVE < 0x7fffffffLL) {
+#endif
+        // 7-DoF arms (Franka Panda, KUKA iiwa): full tiles through the specialised kernel, ragged tail (if any)
+        // through the generic one
+        const int n_tiles = (int)(B / WAVE);
+        hipLaunchKernelGGL((fk_jacobian_full_tiles_kernel<8, 7>),
+                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, w->ops_i, q, n_tiles, (int)w->target_perm,
+                           pos, quat, lin_jac, ang_jac);
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done < B) {
+            rc = launched();
+            if (rc) return rc;
+            return drm_fk_jacobian(w, q + done * n, B - done, pos + done * 3, quat + done * 4, lin_jac + done * 3 * n,
+                                   ang_jac + done * 3 * n, stream);
+        }
+    } else if (w->capacity == 8 && n == 7) {
+        DRM_LAUNCH_FKJ(8, 7) // same arms, ragged / unaligned / partial-output calls: static tile shapes
     } else {
         DRM_DISPATCH_CAP(w->capacity, DRM_LAUNCH_FKJ(C, 0))
     }

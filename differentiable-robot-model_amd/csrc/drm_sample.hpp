@@ -6,9 +6,9 @@
 // as STRAIGHT-LINE code: every loop over ops is fully unrolled, per-op state
 // (joint axes, origins, body forces) lives in registers with static indices,
 // and the only wave-uniform branches left are the rare ones (fixed joint,
-// branch point, target link).  Every joint rotates about its local z axis —
-// the host folds x / y axes into exact permutations of the constants
-// (flatten.py "axis canonicalisation").
+// branch point, target link).  Every joint rotates about its local +z axis by
+// +q — the host folds x / y axes and negative axes into exact signed
+// permutations of the constants (flatten.py "axis canonicalisation").
 //
 // The arithmetic restates, per sample, what the reference spreads over
 // rigid_body.py:130-165, spatial_vector_algebra.py:14-136,175-338 and
@@ -95,7 +95,7 @@ DRM_HD void matT_vec(const float *M, const float *x, float *y) {
     for (int c = 0; c < 3; ++c) y[c] = M[0 * 3 + c] * x[0] + M[1 * 3 + c] * x[1] + M[2 * 3 + c] * x[2];
 }
 
-// J = F * Rot_z(theta), c = cos(theta), s = sin(theta), theta = sign * q
+// J = F * Rot_z(q), c = cos(q), s = sin(q)
 // (rigid_body.py:146-156, spatial_vector_algebra.py:42-53).  c = 1, s = 0 gives J == F exactly.
 DRM_HD void joint_rot_z(const float *__restrict__ F, float c, float s, float *J) {
 #pragma unroll
@@ -139,15 +139,19 @@ DRM_HD void pose_identity(Pose &P) {
     P.p[0] = P.p[1] = P.p[2] = 0.0f;
 }
 
-// undo the axis canonicalisation of a stored frame: R[:, pi(c)] = R~[:, c]
-// perm = 2: identity; 0: joint about x, pi = (1,2,0); 1: joint about y, pi = (2,0,1)
-DRM_HD void unpermute(int perm, float *R) {
-    if (perm != 2) {
+// undo the axis canonicalisation of a stored frame R~ = R P, P = P_a D_s:  R[:, pi(c)] = d(c) R~[:, c]
+// code = a + 3 * (s < 0);  a = 2: pi = identity; a = 0 (joint about x): pi = (1,2,0); a = 1 (about y): pi = (2,0,1);
+// s < 0: d = (1,-1,-1)
+DRM_HD void unpermute(int code, float *R) {
+    if (code != 2) {
+        const float d = code >= 3 ? -1.0f : 1.0f;
+        const int perm = code >= 3 ? code - 3 : code;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float a = R[r * 3 + 0], b = R[r * 3 + 1], c = R[r * 3 + 2];
-            if (perm == 0) { R[r * 3 + 1] = a; R[r * 3 + 2] = b; R[r * 3 + 0] = c; }
-            else           { R[r * 3 + 2] = a; R[r * 3 + 0] = b; R[r * 3 + 1] = c; }
+            const float a = R[r * 3 + 0], b = d * R[r * 3 + 1], c = d * R[r * 3 + 2];
+            if (perm == 0)      { R[r * 3 + 1] = a; R[r * 3 + 2] = b; R[r * 3 + 0] = c; }
+            else if (perm == 1) { R[r * 3 + 2] = a; R[r * 3 + 0] = b; R[r * 3 + 1] = c; }
+            else                { R[r * 3 + 1] = b; R[r * 3 + 2] = c; }
         }
     }
 }
@@ -187,18 +191,18 @@ DRM_HD void quat_xyzw(const float *R, float *q) {
     q[3] = w * scale;
 }
 
-// cos / sign*sin of every op's joint angle, computed up front so the transcendental work is
+// cos / sin of every op's joint angle, computed up front so the transcendental work is
 // off the serial pose chain.  Branch-free on purpose (one basic block lets the compiler issue
 // every scalar load of the walk tables early): fixed joints and padding read DoF 0 and are
-// masked to c = 1, s = 0 (sign = 0).
+// masked to c = 1, s = 0.
 template <int CAP, class QF>
-DRM_HD void joint_trig(const int (&dof)[CAP], const int (&sign)[CAP], QF qf, float *cs, float *sn) {
+DRM_HD void joint_trig(const int (&dof)[CAP], QF qf, float *cs, float *sn) {
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         float c_, s_;
         sincos_f(qf(dof[k] < 0 ? 0 : dof[k]), s_, c_);
         cs[k] = dof[k] < 0 ? 1.0f : c_;
-        sn[k] = s_ * (float)sign[k];
+        sn[k] = dof[k] < 0 ? 0.0f : s_;
     }
 }
 
@@ -213,14 +217,14 @@ DRM_HD void load_field(const int32_t *__restrict__ opi, int field, int (&out)[CA
 // FK + geometric Jacobian along one chain (robot_model.py:626-667).
 // The walk is a chain: op 0 hangs off the root, op k off op k-1.  After the
 // call `ee` is the (canonical) pose of the last op, and for every op k:
-// z[k] = sign * R_k e_z (world joint axis), pj[k] = p_k (world joint origin).
+// z[k] = R~_k e_z (world joint axis), pj[k] = p_k (world joint origin).
 // Column d = dof(k) of the Jacobian is (z[k] x (ee.p - pj[k]), z[k]).
 // ---------------------------------------------------------------------------
 template <int CAP, class QF>
-DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], const int (&sign)[CAP], QF qf, Pose &ee,
-                     float (&z)[CAP][3], float (&pj)[CAP][3]) {
+DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], QF qf, Pose &ee, float (&z)[CAP][3],
+                     float (&pj)[CAP][3]) {
     float cs[CAP], sn[CAP];
-    joint_trig<CAP>(dof, sign, qf, cs, sn);
+    joint_trig<CAP>(dof, qf, cs, sn);
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
@@ -228,8 +232,7 @@ DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], const
         joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
         if (k == 0) compose_root(J, of + DRM_OPF_T, ee);
         else compose(ee, J, of + DRM_OPF_T, ee);
-        const float sg = (float)sign[k];
-        z[k][0] = ee.R[2] * sg; z[k][1] = ee.R[5] * sg; z[k][2] = ee.R[8] * sg;
+        z[k][0] = ee.R[2]; z[k][1] = ee.R[5]; z[k][2] = ee.R[8];
         pj[k][0] = ee.p[0]; pj[k][1] = ee.p[1]; pj[k][2] = ee.p[2];
     }
 }
@@ -244,11 +247,10 @@ DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], const
 template <int CAP, class QF, class SAVE, class LOAD, class EMIT>
 DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, SAVE slot_save,
                     LOAD slot_load, EMIT emit) {
-    int dof[CAP], sign[CAP];
+    int dof[CAP];
     load_field<CAP>(opi, DRM_OPI_DOF, dof);
-    load_field<CAP>(opi, DRM_OPI_SIGN, sign);
     float cs[CAP], sn[CAP];
-    joint_trig<CAP>(dof, sign, qf, cs, sn);
+    joint_trig<CAP>(dof, qf, cs, sn);
     Pose cur;
     pose_identity(cur);
 #pragma unroll
@@ -282,7 +284,7 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
 //     G_k = sum g_d                 (dL/dp_k, world frame)
 //     M_k = sum g_d r^T             (first moment of the target gradients about p_k)
 //     dL/dt_k = R_p^T G_k           dL/dF_k = (R_p^T M_k) (R_p F_k)
-//     dL/dq_k = sign_k z_k . N_k,   z_k = R_k e_z,  N_k = sum r x g_d  (antisymmetric part of M_k)
+//     dL/dq_k = z_k . N_k,          z_k = R~_k e_z,  N_k = sum r x g_d  (antisymmetric part of M_k)
 //   and (G, M) move to the parent as  G_p += G_k,  M_p += M_k + G_k (p_k - p_p)^T.
 //
 //   grad_in(t, G)          adds the loss gradient of target slot t to G[3]
@@ -300,11 +302,10 @@ template <int CAP, class QF, class GIN, class PSAVE, class PLOAD, class AADD, cl
 DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, uint32_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
                              ATAKE adj_take, GQ gq_out, PG param_out) {
-    int dof[CAP], sign[CAP];
+    int dof[CAP];
     load_field<CAP>(opi, DRM_OPI_DOF, dof);
-    load_field<CAP>(opi, DRM_OPI_SIGN, sign);
     float cs[CAP], sn[CAP];
-    joint_trig<CAP>(dof, sign, qf, cs, sn);
+    joint_trig<CAP>(dof, qf, cs, sn);
     // ---- forward: world pose of every op, kept for the adjoint sweep -------
     Pose P[CAP];
     Pose cur;
@@ -348,7 +349,7 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         else par = P[k > 0 ? k - 1 : 0];
         if (want_gq && dof[k] >= 0) {
             const float Nx = tot.M[7] - tot.M[5], Ny = tot.M[2] - tot.M[6], Nz = tot.M[3] - tot.M[1];
-            gq_out(dof[k], (float)sign[k] * (P[k].R[2] * Nx + P[k].R[5] * Ny + P[k].R[8] * Nz));
+            gq_out(dof[k], P[k].R[2] * Nx + P[k].R[5] * Ny + P[k].R[8] * Nz);
         }
         if ((param_mask >> k) & 1u) {
             float dt[3], A[9], Bm[9], dF[9];
@@ -423,13 +424,9 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         const int dof = DRM_OPI(DRM_OPI_DOF, k), src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
         float c_ = 1.0f, s_ = 0.0f, wj = 0.0f, aj = 0.0f;
         if (dof >= 0) {
-            const float sg = (float)DRM_OPI(DRM_OPI_SIGN, k);
-            float q, qd, qdd;
-            qf(dof, q, qd, qdd);
-            sincos_f(q, s_, c_);
-            s_ *= sg;
-            wj = sg * qd;   // joint velocity / acceleration along the joint axis
-            aj = sg * qdd;  // (rigid_body.py:133-136, 159-165)
+            float q;
+            qf(dof, q, wj, aj); // joint velocity / acceleration along the (canonical +z) joint axis
+            sincos_f(q, s_, c_); // (rigid_body.py:133-136, 159-165)
         }
         cs[k] = c_;
         sn[k] = s_;
@@ -489,8 +486,8 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         }
         if (save >= 0) force_take(save, tot); // += children that hang off this branch point, slot reset to 0
         if (dof >= 0) {
-            // tau = sign * f.ang[axis] (+ damping * qd)   (robot_model.py:353-373)
-            float tau = (float)DRM_OPI(DRM_OPI_SIGN, k) * tot.a[2];
+            // tau = f.ang . axis (+ damping * qd)   (robot_model.py:353-373); the axis is +z of the stored frame
+            float tau = tot.a[2];
             if (flags & DRM_RNEA_DAMPING) {
                 float q, qd, qdd;
                 qf(dof, q, qd, qdd);

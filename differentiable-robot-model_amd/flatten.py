@@ -17,21 +17,24 @@ tree is flattened ONCE at model construction:
                  the kernels run it as straight-line code.
 
 Axis canonicalisation (exact, no rounding): the reference rotates a joint about
-its local x, y or z axis (rigid_body.py:149-154).  With the cyclic permutation
-matrix P_a (P_a e_z = e_a) one has Rot_a(q) = P_a Rot_z(q) P_a^T, so storing each
-link frame with permuted columns, R~_i = R_i P_i, turns every joint into a
-rotation about local z:   R~_i = R~_p (P_p^T F_i P_i) Rot_z(s q),   p_i = R~_p (P_p^T t_i) + p_p.
-Permuting rows/columns of the constants is a pure re-indexing, so the kernels
-compute bit-identical products without any per-axis branch; body-frame
-quantities (com, inertia) are re-indexed the same way, and a target link's
-columns are un-permuted when its pose is emitted.
+its local x, y or z axis by sign(axis) * q (rigid_body.py:149-154).  With the
+signed permutation P = P_a D_s (P_a cyclic with P_a e_z = e_a; D_+ = I,
+D_- = diag(1,-1,-1) = Rot_x(pi), so P e_z = s e_a) one has
+Rot_a(s q) = P Rot_z(q) P^T, so storing each link frame as R~_i = R_i P_i turns
+every joint into a rotation about local +z by +q:
+    R~_i = R~_p (P_p^T F_i P_i) Rot_z(q),   p_i = R~_p (P_p^T t_i) + p_p.
+Permuting / negating rows and columns of the constants is exact in floating
+point, so the kernels compute the same products without any per-axis branch or
+sign; body-frame quantities (com, inertia) are transformed the same way, and a
+target link's columns are restored when its pose is emitted.
 
 Device layout of one op (see include/drm_hip.h, DRM_OPF_* / DRM_OPI_*):
   ops_f[k, 0:32] float32: F(9) t(3) mass(1) mcom(3) Io(9) damping(1) pad(6)
   ops_i[0:8, k ] int32  : dof perm sign src save out link flags   (FIELD-MAJOR on the device:
                           one scalar load fetches one field of many ops)
 ``gather`` maps every ops_f entry to a flat index of the [L+1, 32] link table
-(row L = the identity op), so the device table is ONE differentiable gather.
+(row L = the identity op) and ``gsign`` holds its +-1 factor, so the device table
+is ONE differentiable gather and one multiply.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -94,10 +97,18 @@ class RobotSpec:
         return chain[::-1]
 
     def perm_of(self, link: int):
-        """Column permutation of the stored frame of ``link`` (identity for fixed joints / root)."""
+        """Signed column permutation (pi, d) of the stored frame of ``link``: (M P)[:, c] = d[c] * M[:, pi[c]]
+        (identity for fixed joints / root)."""
         if link <= 0 or self.dof[link] < 0:
-            return _PERM[2]
-        return _PERM[int(self.axis_idx[link])]
+            return _PERM[2], (1, 1, 1)
+        s = int(self.axis_sign[link])
+        return _PERM[int(self.axis_idx[link])], (1, s, s)
+
+    def perm_code(self, link: int) -> int:
+        """DRM_OPI_PERM code of ``link``: axis index (2 for fixed joints) + 3 if the axis is negative."""
+        if link <= 0 or self.dof[link] < 0:
+            return 2
+        return int(self.axis_idx[link]) + (3 if self.axis_sign[link] < 0 else 0)
 
 
 def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optional[str]]) -> RobotSpec:
@@ -159,6 +170,7 @@ class WalkProgram:
     ops_i: np.ndarray        # int32 [capacity, OPI_STRIDE]   (identity-padded, op-major: host-side view)
     ops_i_dev: np.ndarray    # int32 [OPI_STRIDE, capacity]   field-major copy = the device layout
     gather: np.ndarray       # int64 [capacity, OPF_STRIDE]   flat indices into the [L+1, OPF_STRIDE] link table
+    gsign: np.ndarray        # float32 [capacity, OPF_STRIDE] +-1 factor of every gathered entry
     n_ops: int
     n_slots: int
     capacity: int            # compiled kernel capacity that fits n_ops
@@ -175,22 +187,27 @@ def _capacity_for(n_ops: int) -> int:
         "walk of %d links exceeds the largest compiled capacity %d" % (n_ops, CAPACITIES[-1]))
 
 
-def _gather_row(spec: RobotSpec, link: int) -> np.ndarray:
-    """Flat link-table indices of one op's constants, with the axis canonicalisation applied."""
+def _gather_row(spec: RobotSpec, link: int):
+    """(flat link-table indices, +-1 factors) of one op's constants, with the axis canonicalisation applied."""
     base = link * OPF_STRIDE
-    pp = spec.perm_of(int(spec.parent[link]))   # rows of F / t follow the parent's stored frame
-    pi = spec.perm_of(link)                     # columns of F and body-frame quantities follow this link's
+    pp, dp = spec.perm_of(int(spec.parent[link]))   # rows of F / t follow the parent's stored frame
+    pi, di = spec.perm_of(link)                     # columns of F and body-frame quantities follow this link's
     row = np.empty(OPF_STRIDE, np.int64)
+    sgn = np.ones(OPF_STRIDE, np.float32)
     for r in range(3):
         for c in range(3):
             row[OPF_F + r * 3 + c] = base + OPF_F + pp[r] * 3 + pi[c]
+            sgn[OPF_F + r * 3 + c] = dp[r] * di[c]
             row[OPF_IO + r * 3 + c] = base + OPF_IO + pi[r] * 3 + pi[c]
+            sgn[OPF_IO + r * 3 + c] = di[r] * di[c]
         row[OPF_T + r] = base + OPF_T + pp[r]
+        sgn[OPF_T + r] = dp[r]
         row[OPF_MCOM + r] = base + OPF_MCOM + pi[r]
+        sgn[OPF_MCOM + r] = di[r]
     row[OPF_MASS] = base + OPF_MASS
     for k in range(OPF_DAMP, OPF_STRIDE):
         row[k] = base + k
-    return row
+    return row, sgn
 
 
 def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False) -> WalkProgram:
@@ -231,8 +248,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                 raise UnsupportedRobotError(
                     "tree needs more than %d nested branch points; not supported by the compiled kernels" % MAX_SLOTS)
         flags = FLAG_CHILD_IS_NEXT if kids else 0
-        perm = int(spec.axis_idx[i]) if spec.dof[i] >= 0 else 2
-        ops.append([int(spec.dof[i]), perm, int(spec.axis_sign[i]), src, save, out_of.get(i, -1), i, flags])
+        # OPI_SIGN is kept for layout stability only: the sign is folded into the constants
+        ops.append([int(spec.dof[i]), spec.perm_code(i), int(spec.axis_sign[i]), src, save, out_of.get(i, -1), i, flags])
         links.append(i)
         for n, c in enumerate(kids):
             visit(c, SRC_PREV if n == 0 else save)
@@ -259,18 +276,19 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     ops_i[:, OPI_LINK] = -1
     ident = L * OPF_STRIDE + np.arange(OPF_STRIDE, dtype=np.int64)
     gather = np.tile(ident, (cap, 1))
+    gsign = np.ones((cap, OPF_STRIDE), np.float32)
     if n_ops:
         ops_i[:n_ops] = np.asarray(ops, np.int32)
         for k, link in enumerate(links):
-            gather[k] = _gather_row(spec, link)
+            gather[k], gsign[k] = _gather_row(spec, link)
     else:
         ops_i[0, OPI_SRC] = SRC_ROOT
     mask = 0
     for row in ops:
         if row[OPI_DOF] >= 0:
             mask |= 1 << row[OPI_DOF]
-    return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, n_ops, max_used,
-                       cap, tlist, mask, unique)
+    return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
+                       max_used, cap, tlist, mask, unique)
 
 
 def identity_table_row() -> np.ndarray:

@@ -82,6 +82,7 @@ class _DeviceWalk:
     program: WalkProgram
     ops_i: torch.Tensor                 # int32 [8, cap] (field-major) on the model device
     gather: torch.Tensor                # int64 [cap * 32] flat indices into the [L+1, 32] link table
+    gsign: torch.Tensor                 # float32 [cap * 32] +-1 factors of the gathered entries
     static_ops_f: Optional[torch.Tensor] = None
 
 
@@ -203,13 +204,14 @@ class DifferentiableRobotModel(torch.nn.Module):
                 program=prog,
                 ops_i=torch.from_numpy(prog.ops_i_dev).to(self._device).contiguous(),
                 gather=torch.from_numpy(prog.gather.reshape(-1)).to(self._device),
+                gsign=torch.from_numpy(prog.gsign.reshape(-1)).to(self._device),
             )
             self._walks[key] = dw
         return dw
 
     def _ops_f(self, dw: _DeviceWalk) -> torch.Tensor:
         """[cap, OPF_STRIDE] constants gathered (and axis-canonicalised) in walk order; ONE differentiable
-        gather from the link table, cached while nothing is learnable."""
+        gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
         if self._learnable:
@@ -219,7 +221,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 with torch.no_grad():
                     self._static_table = self._link_table()
             table = self._static_table
-        ops_f = table.reshape(-1).index_select(0, dw.gather).reshape(dw.program.capacity, OPF_STRIDE)
+        ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
         return ops_f

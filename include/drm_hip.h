@@ -47,11 +47,13 @@ extern "C" {
 
 #define DRM_OPI_STRIDE 8  /* int32 fields per op; ops_i is FIELD-MAJOR: ops_i[field * capacity + k] */
 #define DRM_OPI_DOF 0     /* DoF column driven by this link's joint, -1 = fixed joint          */
-#define DRM_OPI_PERM 1    /* axis canonicalisation of this link's stored frame: 2 = none (joint about z or
-                             fixed), 0 = joint about local x, 1 = about local y (rigid_body.py:149-154);
-                             the kernels rotate every joint about z of the permuted frame and undo
-                             the column permutation when a target pose is emitted                */
-#define DRM_OPI_SIGN 2    /* +1/-1 = sign of the axis entry, 0 for fixed joints                */
+#define DRM_OPI_PERM 1    /* axis canonicalisation of this link's stored frame, a + 3 * (axis negative):
+                             a = 2 joint about local z (or fixed), 0 about local x, 1 about local y
+                             (rigid_body.py:149-154).  The constants are pre-multiplied by the signed
+                             permutation, the kernels rotate every joint about +z of the stored frame by
+                             +q and undo the permutation when a target pose is emitted          */
+#define DRM_OPI_SIGN 2    /* informational: +1/-1 = sign of the axis entry, 0 for fixed joints (the sign
+                             is folded into the constants, kernels do not read it)             */
 #define DRM_OPI_SRC 3     /* parent state: DRM_SRC_PREV, DRM_SRC_ROOT, or a save-slot index    */
 #define DRM_OPI_SAVE 4    /* save-slot this op's state is copied to (branch point), -1 = none  */
 #define DRM_OPI_OUT 5     /* output slot (target index) this op's pose is written to, -1 = none */
@@ -88,7 +90,7 @@ typedef struct drm_walk {
     int32_t n_dofs;       /* n = row width of q / qd / qdd / tau and Jacobian column count   */
     int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS)                              */
     uint64_t dof_mask;    /* bit d set <=> DoF d is driven by an op of this walk             */
-    int32_t target_perm;  /* drm_fk_jacobian: DRM_OPI_PERM of the target (last real) op      */
+    int32_t target_perm;  /* drm_fk_jacobian: DRM_OPI_PERM code (0..5) of the target (last real) op */
     int32_t reserved;
 } drm_walk;
 

@@ -38,10 +38,9 @@ void jac_t(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat
         auto qf = [&](int d) { return q[b * n + d]; };
         Pose ee;
         float z[CAP][3], pj[CAP][3];
-        int dof[CAP], sign[CAP];
+        int dof[CAP];
         load_field<CAP>(w->ops_i, DRM_OPI_DOF, dof);
-        load_field<CAP>(w->ops_i, DRM_OPI_SIGN, sign);
-        fk_chain<CAP>(w->ops_f, dof, sign, qf, ee, z, pj);
+        fk_chain<CAP>(w->ops_f, dof, qf, ee, z, pj);
         if (pos) for (int i = 0; i < 3; ++i) pos[b * 3 + i] = ee.p[i];
         if (quat) {
             float Ru[9];

@@ -44,7 +44,8 @@ def emu_loss_and_grads(emu, m, q, targets, wants):
     prog = build_walk(m._spec, targets=idx)
     assert prog.slots_unique
     table = m._link_table()
-    ops_f_t = table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))].reshape(prog.capacity, 32)
+    ops_f_t = (table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))]
+               * torch.from_numpy(prog.gsign.reshape(-1))).reshape(prog.capacity, 32)
     ops_f = np.ascontiguousarray(ops_f_t.detach().numpy(), np.float32)
     walk, _keep = host_walk(m, prog)
     walk.ops_f = ops_f.ctypes.data

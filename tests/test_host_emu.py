@@ -37,7 +37,8 @@ def _ptr(a):
 
 def host_walk(model, prog):
     table = model._link_table().detach().cpu().numpy().reshape(-1)
-    ops_f = np.ascontiguousarray(table[prog.gather.reshape(-1)].reshape(prog.capacity, 32), np.float32)
+    ops_f = np.ascontiguousarray((table[prog.gather.reshape(-1)] * prog.gsign.reshape(-1)).reshape(prog.capacity, 32),
+                                 np.float32)
     perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
     walk = DrmWalk(ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, prog.n_ops, prog.capacity, model._n_dofs,
                    prog.n_slots, prog.dof_mask, perm, 0)
