@@ -17,7 +17,7 @@ from .flatten import OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -27,7 +27,7 @@ class DrmWalk(ctypes.Structure):
     _fields_ = [("ops_f", ctypes.c_void_p), ("ops_i", ctypes.c_void_p),
                 ("n_ops", ctypes.c_int32), ("capacity", ctypes.c_int32),
                 ("n_dofs", ctypes.c_int32), ("n_slots", ctypes.c_int32),
-                ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -100,7 +100,7 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
     assert ops_i.is_cuda and ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[1] == rows
     target_perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
     return DrmWalk(ops_f.data_ptr(), ops_i.data_ptr(), prog.n_ops, prog.capacity, n_dofs, prog.n_slots,
-                   prog.dof_mask, target_perm, 0)
+                   prog.dof_mask, target_perm, prog.shape)
 
 
 def _stream(device) -> ctypes.c_void_p:

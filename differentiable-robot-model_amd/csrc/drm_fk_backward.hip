@@ -9,7 +9,7 @@
 // per-link constant gradients over the batch.
 //
 // Per sample: in q[n], grad_pos[T,3]; out grad_q[n] (optional).                 n = 7, T = 1: 28 + 12 + 28 = 68 B
-// Per launch: out grad_ops_f[cap, 32] (dL/dF at +0..8, dL/dt at +9..11 of every op selected by param_mask, zeros
+// Per launch: out grad_ops_f[cap, 32] (dL/dF and dL/dt in the FT block of every op selected by param_mask, zeros
 //             elsewhere), reduced DETERMINISTICALLY: each wave strides over tiles and keeps one running sum per
 //             (op, field) in a lane of an accumulator register, writes one row of `partials`, and a second tiny
 //             kernel adds the rows in a fixed order.
@@ -151,12 +151,14 @@ __global__ void __launch_bounds__(WAVE)
     const int k = blockIdx.x;
     const unsigned lane = threadIdx.x;
     const int NV = cap * BWD_FIELDS;
+    // the FT block holds exactly the 12 differentiated constants; the rest of the row has no gradient here
     if (lane < DRM_OPF_STRIDE - BWD_FIELDS) grad_ops_f[k * DRM_OPF_STRIDE + BWD_FIELDS + lane] = 0.0f;
     for (int j = 0; j < BWD_FIELDS; ++j) {
         float s = 0.0f;
         for (int r = (int)lane; r < n_rows; r += WAVE) s += partials[(int64_t)r * NV + k * BWD_FIELDS + j];
         s = wave_sum_lane63(s);
-        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + j] = s;
+        const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
+        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + at] = s;
     }
 }
 

@@ -114,74 +114,89 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Full-tile specialisation: every tile has 64 rows, every pointer is 16-byte aligned, pos / quat are
-// wanted, all NDOF columns are driven by the chain and NDOF is odd (linear LDS images).  This is the
-// shape of the metric workload (7-DoF arm, batch a multiple of 64).  Compared with the generic kernel:
-//   * all 16 argument dwords are preloaded into SGPRs by the command processor (kernarg preload,
-//     -mllvm -amdgpu-kernarg-preload-count=16 in the Makefile): the wave issues the walk-table scalar
-//     loads and the q tile's vector loads in its first cycles, ONE memory round trip before the math
-//     instead of kernarg -> table -> data;
-//   * no runtime shape flags, so the whole kernel is one basic block;
-//   * pos / lin_jac / ang_jac are staged in separate LDS regions: one LDS turnaround, then all the
-//     16-byte stores go out back to back.
-// The launcher sends the ragged tail (B % 64 rows) through the generic kernel.
+// Serial-chain ("arm") specialisation, full tiles only: DRM_WALK_ARM_CHAIN walks (Franka Panda, KUKA iiwa: NJ
+// moving joints in DoF order, then fixed links), every tile has 64 rows, every pointer is 16-byte aligned, pos /
+// quat wanted, NJ odd.  This is the shape of the metric workload.  Differences from the generic kernel:
+//   * the arithmetic runs on packed FP32 pairs (drm_sample.hpp "Packed-FP32 form"): 27 v_pk_* per link instead
+//     of 48 scalar VALU ops, two joints per sincos evaluation;
+//   * the FT blocks of the walk (12 floats per link, < 400 B) are staged ONCE per wave into LDS and read back
+//     as broadcast ds_read_b128s into VGPR pairs (in-order LDS returns let the compiler wait per link, and
+//     packed ops take VGPR pairs without constant-bus limits); no scalar loads, no int table;
+//   * the first 14 argument dwords are preloaded into SGPRs by the command processor (kernarg preload,
+//     HIPFLAGS in the Makefile), so the constant and q-tile loads are issued in the wave's first cycles;
+//   * no runtime shape flags: one basic block from the loads to the stores; pos / lin_jac / ang_jac are staged in
+//     separate LDS regions, so there is one LDS turnaround before the 16-byte stores go out back to back.
+// With one wave per SIMD (batch 65 536) a launch lasts launch floor + issue time + store drain (nothing
+// overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
+// The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int CAP, int NDOF>
+template <int CAP, int NJ>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    fk_jacobian_full_tiles_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i,
-                                  const float *__restrict__ q, int n_tiles, int target_perm, float *__restrict__ pos,
-                                  float *__restrict__ quat, float *__restrict__ lin, float *__restrict__ ang) {
-    // argument order: the first 14 dwords are the ones the command processor preloads into SGPRs
-    static_assert(NDOF & 1, "odd row widths only (linear LDS image)");
-    constexpr int SQ = NDOF, SJ = 3 * NDOF;
-    constexpr int Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3, J_FLOATS = round4(WAVE * SJ);
-    constexpr int PER_WAVE = Q_FLOATS + P_FLOATS + 2 * J_FLOATS;
+    fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
+                           float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
+                           float *__restrict__ ang) {
+    // argument order: everything needed to issue the first loads sits in the preloaded dwords
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    constexpr int SQ = NJ, SJ = 3 * NJ;
+    constexpr int C_FLOATS = round4(CAP * DRM_OPF_FT_FLOATS), Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3,
+                  J_FLOATS = round4(WAVE * SJ);
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + P_FLOATS + 2 * J_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
-    float *lq = smem + wave * PER_WAVE;
-    float *lp = lq + Q_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lp = lq + Q_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
     const int64_t b0 = (int64_t)tile * WAVE;
 
-    int dof[CAP];
-    load_field<CAP>(ops_i, DRM_OPI_DOF, dof);
-    WarmRegs<CAP> warm;
-    warm_walk_issue<CAP, 1>(ops_f, warm);
-    tile_load<NDOF>(q + b0 * NDOF, WAVE, NDOF, 0u, lq, lane, true);
-    warm_walk_wait(warm);
+    // FT blocks -> LDS (one dword per lane and round), in flight together with the q tile
+    constexpr int C_IT = (CAP * DRM_OPF_FT_FLOATS + WAVE - 1) / WAVE;
+    float cv[C_IT];
+#pragma unroll
+    for (int it = 0; it < C_IT; ++it) {
+        const unsigned i = lane + WAVE * it, ic = i < CAP * DRM_OPF_FT_FLOATS ? i : 0u;
+        cv[it] = ops_f[(ic / DRM_OPF_FT_FLOATS) * DRM_OPF_STRIDE + ic % DRM_OPF_FT_FLOATS];
+    }
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+#pragma unroll
+    for (int it = 0; it < C_IT; ++it) {
+        const unsigned i = lane + WAVE * it;
+        if (i < CAP * DRM_OPF_FT_FLOATS) lc[i] = cv[it];
+    }
     wave_lds_sync();
 
-    const float *qrow = lq + lane * SQ;
-    auto qf = [&](int d) -> float { return qrow[d]; };
-    Pose ee;
-    float z[CAP][3], pj[CAP][3];
-    fk_chain<CAP>(ops_f, dof, qf, ee, z, pj);
-
-    // quat [B,4]: one 16-byte store per lane is already coalesced
-    {
-        float Ru[9], qt[4];
+    float qv[NJ];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Ru[i] = ee.R[i];
-        unpermute(target_perm, Ru);
-        quat_xyzw(Ru, qt);
+    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+    PoseP ee;
+    f2 Bk[NJ][3];
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_FT_FLOATS; }, qv, ee, Bk);
+
+    // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
+    // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
+    {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
         *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
     }
-    lp[lane * 3 + 0] = ee.p[0];
-    lp[lane * 3 + 1] = ee.p[1];
-    lp[lane * 3 + 2] = ee.p[2];
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    lp[lane * 3 + 0] = pe[0];
+    lp[lane * 3 + 1] = pe[1];
+    lp[lane * 3 + 2] = pe[2];
     float *lrow = ll + lane * SJ, *arow = la + lane * SJ;
 #pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-        const int d = dof[k];
-        if (d >= 0) { // wave-uniform
-            const float dp[3] = {ee.p[0] - pj[k][0], ee.p[1] - pj[k][1], ee.p[2] - pj[k][2]};
-            float c[3];
-            cross3(z[k], dp, c); // robot_model.py:661
-            lrow[d] = c[0]; lrow[NDOF + d] = c[1]; lrow[2 * NDOF + d] = c[2];
-            arow[d] = z[k][0]; arow[NDOF + d] = z[k][1]; arow[2 * NDOF + d] = z[k][2]; // robot_model.py:662
-        }
+    for (int k = 0; k < NJ; ++k) {
+        const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+        const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+        float c[3];
+        cross3(z, dp, c); // robot_model.py:661
+        // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+        arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2]; // robot_model.py:662
     }
     wave_lds_sync();
     tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
@@ -219,27 +234,29 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
                            (int)w->target_perm);                                                             \
     }
     const uint32_t all_al = AL_Q | AL_POS | AL_QUAT | AL_LIN | AL_ANG;
-#ifdef DRM_NO_FULL_TILES
+#ifdef DRM_NO_ARM_KERNEL
     if (false) {
 #else
-    if (w->capacity == 8 && n == 7 && align == all_al && w->dof_mask == 0x7full && B >= WAVE && B / WAVE < 0x7fffffffLL) {
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && w->target_perm == 2 && align == all_al &&
+        B >= WAVE && B / WAVE < 0x7fffffffLL) {
 #endif
-        // 7-DoF arms (Franka Panda, KUKA iiwa): full tiles through the specialised kernel, ragged tail (if any)
-        // through the generic one
+        // 7-DoF arms (Franka Panda, KUKA iiwa): full tiles through the packed-FP32 chain kernel, ragged tail (if
+        // any) through the generic one
         const int n_tiles = (int)(B / WAVE);
-        hipLaunchKernelGGL((fk_jacobian_full_tiles_kernel<8, 7>),
+        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7>),
                            dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, w->ops_i, q, n_tiles, (int)w->target_perm,
-                           pos, quat, lin_jac, ang_jac);
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done < B) {
             rc = launched();
             if (rc) return rc;
-            return drm_fk_jacobian(w, q + done * n, B - done, pos + done * 3, quat + done * 4, lin_jac + done * 3 * n,
-                                   ang_jac + done * 3 * n, stream);
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_ARM_CHAIN;
+            return drm_fk_jacobian(&generic, q + done * n, B - done, pos + done * 3, quat + done * 4,
+                                   lin_jac + done * 3 * n, ang_jac + done * 3 * n, stream);
         }
     } else if (w->capacity == 8 && n == 7) {
-        DRM_LAUNCH_FKJ(8, 7) // same arms, ragged / unaligned / partial-output calls: static tile shapes
+        DRM_LAUNCH_FKJ(8, 7) // 7-DoF robots, ragged / unaligned / partial-output calls: static tile shapes
     } else {
         DRM_DISPATCH_CAP(w->capacity, DRM_LAUNCH_FKJ(C, 0))
     }

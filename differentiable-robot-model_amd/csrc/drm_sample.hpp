@@ -33,6 +33,13 @@
 #define DRM_HD inline __attribute__((always_inline))
 #endif
 
+// true if the predicate holds in any lane of the wavefront (the host emulation runs one sample at a time)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DRM_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
+#else
+#define DRM_WAVE_ANY(pred) (pred)
+#endif
+
 namespace drm {
 
 // ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.
@@ -111,6 +118,22 @@ struct Pose {
     float p[3];
 };
 
+// R_fixed (row-major) and trans of one op, read out of the row's interleaved FT block (include/drm_hip.h)
+struct OpFT {
+    float F[9];
+    float t[3];
+};
+DRM_HD OpFT load_ft(const float *__restrict__ of) {
+    OpFT o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.F[i * 3 + j] = of[DRM_OPF_FIJ(i, j)];
+        o.t[i] = of[DRM_OPF_TI(i)];
+    }
+    return o;
+}
+
 // world pose of a link from its parent's: R = Rp J, p = Rp t + pp
 // (robot_model.py:186, spatial_vector_algebra.py:98-103)
 DRM_HD void compose(const Pose &par, const float *J, const float *__restrict__ t, Pose &out) {
@@ -156,34 +179,27 @@ DRM_HD void unpermute(int code, float *R) {
     }
 }
 
-// rotation matrix -> quaternion (x, y, z, w), the reference's branch order
-// (spatial_vector_algebra.py:108-136).
+// rotation matrix -> quaternion (x, y, z, w): the reference's algorithm and case order
+// (spatial_vector_algebra.py:108-136: t = trace + 1 > 1 -> "w" case, else the largest diagonal entry picks
+// the x / y / z case, ties resolved as there), written with selects instead of branches so that a wave whose
+// lanes fall into different cases does not execute four masked code paths.  Each case's arithmetic is the
+// reference's, so results are identical to the branchy form.
 DRM_HD void quat_xyzw(const float *R, float *q) {
     const float m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
                 m22 = R[8];
-    float t = ((m00 + m11) + m22) + 1.0f;
-    float x, y, z, w;
-    if (t > 1.0f) {
-        w = t;
-        z = m10 - m01;
-        y = m02 - m20;
-        x = m21 - m12;
-    } else {
-        int i = 0;
-        float mii = m00;
-        if (m11 > m00) { i = 1; mii = m11; }
-        if (m22 > mii) { i = 2; }
-        if (i == 0) {
-            t = m00 - (m11 + m22) + 1.0f;
-            x = t; y = m01 + m10; z = m20 + m02; w = m21 - m12;
-        } else if (i == 1) {
-            t = m11 - (m22 + m00) + 1.0f;
-            y = t; z = m12 + m21; x = m01 + m10; w = m02 - m20;
-        } else {
-            t = m22 - (m00 + m11) + 1.0f;
-            z = t; x = m20 + m02; y = m12 + m21; w = m10 - m01;
-        }
-    }
+    const float d21 = m21 - m12, d02 = m02 - m20, d10 = m10 - m01;
+    const float s01 = m01 + m10, s20 = m20 + m02, s12 = m12 + m21;
+    const float tW = ((m00 + m11) + m22) + 1.0f;
+    const float tX = m00 - (m11 + m22) + 1.0f, tY = m11 - (m22 + m00) + 1.0f, tZ = m22 - (m00 + m11) + 1.0f;
+    const bool isW = tW > 1.0f;
+    const bool yx = m11 > m00;                         // i = 1 beats i = 0
+    const bool isZ = !isW && (m22 > (yx ? m11 : m00)); // i = 2 beats the winner of the first test
+    const bool isY = !isW && !isZ && yx;
+    const float t = isW ? tW : (isZ ? tZ : (isY ? tY : tX));
+    const float x = isW ? d21 : (isZ ? s20 : (isY ? s01 : tX));
+    const float y = isW ? d02 : (isZ ? s12 : (isY ? tY : s01));
+    const float z = isW ? d10 : (isZ ? tZ : (isY ? s12 : s20));
+    const float w = isW ? tW : (isZ ? d10 : (isY ? d02 : d21));
     const float scale = 0.5f * rsqrt_f(t);
     q[0] = x * scale;
     q[1] = y * scale;
@@ -228,12 +244,160 @@ DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], QF qf
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
+        const OpFT o = load_ft(of);
         float J[9];
-        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
-        if (k == 0) compose_root(J, of + DRM_OPF_T, ee);
-        else compose(ee, J, of + DRM_OPF_T, ee);
+        joint_rot_z(o.F, cs[k], sn[k], J);
+        if (k == 0) compose_root(J, o.t, ee);
+        else compose(ee, J, o.t, ee);
         z[k][0] = ee.R[2]; z[k][1] = ee.R[5]; z[k][2] = ee.R[8];
         pj[k][0] = ee.p[0]; pj[k][1] = ee.p[1]; pj[k][2] = ee.p[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Packed-FP32 form of the chain FK (the metric kernel's arithmetic).
+//
+// gfx950 executes v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per VGPR pair) at the rate of a scalar
+// FMA, so the chain is written on 8-byte pairs throughout.  The three rows of a pose evolve
+// independently:   row c of R' = (row c of R) J,   p'_c = p_c + (row c of R) . t,   J = F Rot_z(q),
+// so the state of row c is two pairs  A_c = (R_c0, R_c1),  B_c = (R_c2, p_c)  and one link costs
+//     J01_i = (F_i0, F_i1) cos + (F_i1, F_i0) (sin, -sin)                      6 packed ops (off the chain)
+//     A'_c  = R_c0 J01_0 + R_c1 J01_1 + R_c2 J01_2                              9 packed ops
+//     B'_c  = R_c0 (F_02, t_0) + R_c1 (F_12, t_1) + R_c2 (F_22, t_2) + (0, p_c) 9 packed ops + 3 adds
+// instead of 48 scalar ones; the (F_i0 F_i1) / (F_i2 t_i) pairs are exactly the FT block of an op row
+// (include/drm_hip.h).  After link k, B_c = (z_c, p_c): the world joint axis and origin the Jacobian needs.
+// Same products as joint_rot_z + compose (the sums are associated differently; fp32 rounding only).
+// vector_size(8) is understood by hipcc and by g++ (tests/host_emu).
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((vector_size(8)));
+DRM_HD f2 f2_make(float a, float b) { f2 v = {a, b}; return v; }
+DRM_HD f2 f2_bcast(float a) { f2 v = {a, a}; return v; }
+
+struct PoseP {
+    f2 A[3]; // A[c] = (R_c0, R_c1)
+    f2 B[3]; // B[c] = (R_c2, p_c)
+};
+struct OpPairs {
+    f2 f01[3]; // (F_i0, F_i1)
+    f2 f2t[3]; // (F_i2, t_i)
+};
+DRM_HD OpPairs load_pairs(const float *__restrict__ ft) { // ft = the 12 floats of an FT block (8-byte aligned)
+    OpPairs o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.f01[i] = f2_make(ft[2 * i], ft[2 * i + 1]);
+        o.f2t[i] = f2_make(ft[6 + 2 * i], ft[7 + 2 * i]);
+    }
+    return o;
+}
+// J01_i of a moving joint
+DRM_HD void joint_pairs(const OpPairs &o, float c, float s, f2 (&J01)[3]) {
+    const f2 cc = f2_bcast(c), sm = f2_make(s, -s);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) J01[i] = o.f01[i] * cc + f2_make(o.f01[i][1], o.f01[i][0]) * sm;
+}
+// first link of a chain: the parent is the identity root, so R = J and p = t exactly
+DRM_HD void compose_pairs_root(const f2 (&J01)[3], const OpPairs &o, PoseP &out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out.A[c] = J01[c]; out.B[c] = o.f2t[c]; }
+}
+DRM_HD void compose_pairs(const PoseP &P, const f2 (&J01)[3], const OpPairs &o, PoseP &out) {
+    PoseP n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const f2 r0 = f2_bcast(P.A[c][0]), r1 = f2_bcast(P.A[c][1]), r2 = f2_bcast(P.B[c][0]);
+        n.A[c] = r0 * J01[0] + r1 * J01[1] + r2 * J01[2];
+        f2 b = r0 * o.f2t[0] + r1 * o.f2t[1] + r2 * o.f2t[2];
+        b[1] += P.B[c][1];
+        n.B[c] = b;
+    }
+    out = n;
+}
+DRM_HD void pose_from_pairs(const PoseP &P, Pose &out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out.R[c * 3 + 0] = P.A[c][0]; out.R[c * 3 + 1] = P.A[c][1]; out.R[c * 3 + 2] = P.B[c][0];
+        out.p[c] = P.B[c][1];
+    }
+}
+
+// sin / cos of TWO joint angles at once on packed pairs, for |x| <= 1e5 (the caller routes larger arguments
+// to sincos_f's fp64 reduction).  Written for instruction count, the metric kernel's bottleneck:
+//   * k = rint(x / pi) by the add-magic-constant trick (1.5 * 2^23): no v_rndne / v_cvt, and the parity of k
+//     is bit 0 of the biased sum;
+//   * r = x - k pi by a three-constant Cody-Waite reduction in fp32 FMAs (pi split into three floats, the
+//     classic single-precision scheme), r in [-pi/2, pi/2];
+//   * sin x = (-1)^k sin r, cos x = (-1)^k cos r: ONE shared sign flip (xor with parity << 31), no quadrant
+//     swap / select logic;
+//   * sin r = r + r z S(z), cos r = 1 + z C(z), z = r^2: near-minimax fits on [-pi/2, pi/2] (fit error 1e-10;
+//     evaluated in fp32 the error is rounding-dominated, <= 1.2e-7 absolute, i.e. <= 2 ulp near 1).
+DRM_HD void sincos_pair(f2 x, f2 &s, f2 &c) {
+    const f2 magic = f2_bcast(12582912.0f);                       // 1.5 * 2^23
+    const f2 kb = x * f2_bcast(0.318309886f) + magic;             // low mantissa bits = rint(x / pi)
+    const f2 kf = kb - magic;
+    f2 r = kf * f2_bcast(-3.14159202e+00f) + x;
+    r = kf * f2_bcast(-6.27832947e-07f) + r;
+    r = kf * f2_bcast(-1.07806051e-14f) + r;
+    const f2 z = r * r;
+    f2 ps = z * f2_bcast(-2.3776610902e-08f) + f2_bcast(2.7522166874e-06f);
+    ps = z * ps + f2_bcast(-1.9840880122e-04f);
+    ps = z * ps + f2_bcast(8.3333319053e-03f);
+    ps = z * ps + f2_bcast(-1.6666667163e-01f);
+    const f2 sr = (r * z) * ps + r;
+    f2 pc = z * f2_bcast(1.6759177379e-09f) + f2_bcast(-2.7332046670e-07f);
+    pc = z * pc + f2_bcast(2.4796934667e-05f);
+    pc = z * pc + f2_bcast(-1.3888848480e-03f);
+    pc = z * pc + f2_bcast(4.1666664183e-02f);
+    pc = z * pc + f2_bcast(-0.5f);
+    const f2 cr = z * pc + f2_bcast(1.0f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t flip = __builtin_bit_cast(uint32_t, kb[i]) << 31;
+        s[i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sr[i]) ^ flip);
+        c[i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cr[i]) ^ flip);
+    }
+}
+constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f;
+
+// FK of a serial chain whose first NJ links are moving joints driving DoF columns 0..NJ-1 and whose
+// remaining CAP - NJ links are fixed joints or identity padding (DRM_WALK_ARM_CHAIN).
+//   ft(k)  -> pointer to the FT block of op k (12 floats)
+//   q[d]   -> joint angles of this sample
+// Out: B[k][c] = (z_c, p_c) of every moving joint k, and the end pose.
+template <int CAP, int NJ, class FT>
+DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3]) {
+    float cs[NJ], sn[NJ];
+    bool big = false;
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) { // rare; wave-uniform, so the common path carries no execution-mask juggling
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < NJ; d += 2) {
+            f2 s2, c2;
+            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
+            sn[d] = s2[0]; cs[d] = c2[0];
+            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const OpPairs o = load_pairs(ft(k));
+        f2 J01[3];
+        if (k < NJ) {
+            joint_pairs(o, cs[k], sn[k], J01);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) J01[i] = o.f01[i];
+        }
+        if (k == 0) compose_pairs_root(J01, o, ee);
+        else compose_pairs(ee, J01, o, ee);
+        if (k < NJ) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[k][c] = ee.B[c];
+        }
     }
 }
 
@@ -257,11 +421,12 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
     for (int k = 0; k < CAP; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
         const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
+        const OpFT o = load_ft(of);
         float J[9];
-        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+        joint_rot_z(o.F, cs[k], sn[k], J);
         if (src >= 0) slot_load(src, cur);
-        if (src == DRM_SRC_ROOT) compose_root(J, of + DRM_OPF_T, cur);
-        else compose(cur, J, of + DRM_OPF_T, cur);
+        if (src == DRM_SRC_ROOT) compose_root(J, o.t, cur);
+        else compose(cur, J, o.t, cur);
         if (save >= 0) slot_save(save, cur);
         if (out >= 0) {
             Pose P = cur;
@@ -314,11 +479,12 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
     for (int k = 0; k < CAP; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
         const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        const OpFT o = load_ft(of);
         float J[9];
-        joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+        joint_rot_z(o.F, cs[k], sn[k], J);
         if (src >= 0) pose_load(src, cur);
-        if (src == DRM_SRC_ROOT) compose_root(J, of + DRM_OPF_T, cur);
-        else compose(cur, J, of + DRM_OPF_T, cur);
+        if (src == DRM_SRC_ROOT) compose_root(J, o.t, cur);
+        else compose(cur, J, o.t, cur);
         if (save >= 0) pose_save(save, cur);
         P[k] = cur;
     }
@@ -360,9 +526,8 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
                 for (int c = 0; c < 3; ++c) {
                     A[r * 3 + c] = par.R[0 * 3 + r] * tot.M[0 * 3 + c] + par.R[1 * 3 + r] * tot.M[1 * 3 + c] +
                                    par.R[2 * 3 + r] * tot.M[2 * 3 + c];
-                    Bm[r * 3 + c] = par.R[r * 3 + 0] * of[DRM_OPF_F + 0 * 3 + c] +
-                                    par.R[r * 3 + 1] * of[DRM_OPF_F + 1 * 3 + c] +
-                                    par.R[r * 3 + 2] * of[DRM_OPF_F + 2 * 3 + c];
+                    Bm[r * 3 + c] = par.R[r * 3 + 0] * of[DRM_OPF_FIJ(0, c)] + par.R[r * 3 + 1] * of[DRM_OPF_FIJ(1, c)] +
+                                    par.R[r * 3 + 2] * of[DRM_OPF_FIJ(2, c)];
                 }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -430,11 +595,12 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         }
         cs[k] = c_;
         sn[k] = s_;
+        const OpFT o = load_ft(of);
         float J[9];
-        joint_rot_z(of + DRM_OPF_F, c_, s_, J);
+        joint_rot_z(o.F, c_, s_, J);
         if (src == DRM_SRC_ROOT) motion_root(cur, g);
         if (src >= 0) motion_load(src, cur);
-        const float *t = of + DRM_OPF_T;
+        const float *t = o.t;
         // velocity (robot_model.py:189-193): w = J^T w_p + wj e_z ; v = J^T (v_p + w_p x t)
         float tmp[3], x[3];
         Motion N;
@@ -497,12 +663,13 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         }
         if (src != DRM_SRC_ROOT) {
             // force.transform(joint_pose) (spatial_vector_algebra.py:281-291): lin = J f ; ang = t x (J f) + J n
+            const OpFT o = load_ft(of);
             float J[9], x[3];
-            joint_rot_z(of + DRM_OPF_F, cs[k], sn[k], J);
+            joint_rot_z(o.F, cs[k], sn[k], J);
             Force up;
             mat_vec(J, tot.l, up.l);
             mat_vec(J, tot.a, up.a);
-            cross3(of + DRM_OPF_T, up.l, x);
+            cross3(o.t, up.l, x);
             up.a[0] += x[0]; up.a[1] += x[1]; up.a[2] += x[2];
             if (src >= 0) force_add(src, up);
             else carry = up;

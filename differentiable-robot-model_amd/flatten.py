@@ -29,7 +29,7 @@ sign; body-frame quantities (com, inertia) are transformed the same way, and a
 target link's columns are restored when its pose is emitted.
 
 Device layout of one op (see include/drm_hip.h, DRM_OPF_* / DRM_OPI_*):
-  ops_f[k, 0:32] float32: F(9) t(3) mass(1) mcom(3) Io(9) damping(1) pad(6)
+  ops_f[k, 0:32] float32: FT block(12: F and t interleaved in pairs) mass(1) mcom(3) Io(9) damping(1) pad(6)
   ops_i[0:8, k ] int32  : dof perm sign src save out link flags   (FIELD-MAJOR on the device:
                           one scalar load fetches one field of many ops)
 ``gather`` maps every ops_f entry to a flat index of the [L+1, 32] link table
@@ -43,7 +43,22 @@ import numpy as np
 
 # ---- constants shared with include/drm_hip.h --------------------------------
 OPF_STRIDE = 32
+# link table ([L+1, 32], built by robot_model._link_table): F(9) t(3) mass mcom(3) Io(9) damping
 OPF_F, OPF_T, OPF_MASS, OPF_MCOM, OPF_IO, OPF_DAMP = 0, 9, 12, 13, 16, 25
+OPF_FT_FLOATS = 12
+
+
+# op rows of a walk keep that layout except for the first 12 floats, which interleave F and t as the
+# 8-byte pairs the packed-FP32 chain kernel consumes: (F00 F01)(F10 F11)(F20 F21)(F02 t0)(F12 t1)(F22 t2)
+def opf_fij(i: int, j: int) -> int:
+    return 2 * i + j if j < 2 else 6 + 2 * i
+
+
+def opf_ti(i: int) -> int:
+    return 7 + 2 * i
+
+
+SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
 OPI_STRIDE = 8
 OPI_DOF, OPI_PERM, OPI_SIGN, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
@@ -177,6 +192,7 @@ class WalkProgram:
     targets: List[int]       # link index per output slot
     dof_mask: int            # bit d set <=> DoF d is driven by some op of this walk
     slots_unique: bool = True  # every branch point owns its slot for the whole walk (needed by the backward walk)
+    shape: int = 0           # SHAPE_* bits (drm_walk.shape)
 
 
 def _capacity_for(n_ops: int) -> int:
@@ -196,12 +212,12 @@ def _gather_row(spec: RobotSpec, link: int):
     sgn = np.ones(OPF_STRIDE, np.float32)
     for r in range(3):
         for c in range(3):
-            row[OPF_F + r * 3 + c] = base + OPF_F + pp[r] * 3 + pi[c]
-            sgn[OPF_F + r * 3 + c] = dp[r] * di[c]
+            row[opf_fij(r, c)] = base + OPF_F + pp[r] * 3 + pi[c]
+            sgn[opf_fij(r, c)] = dp[r] * di[c]
             row[OPF_IO + r * 3 + c] = base + OPF_IO + pi[r] * 3 + pi[c]
             sgn[OPF_IO + r * 3 + c] = di[r] * di[c]
-        row[OPF_T + r] = base + OPF_T + pp[r]
-        sgn[OPF_T + r] = dp[r]
+        row[opf_ti(r)] = base + OPF_T + pp[r]
+        sgn[opf_ti(r)] = dp[r]
         row[OPF_MCOM + r] = base + OPF_MCOM + pi[r]
         sgn[OPF_MCOM + r] = di[r]
     row[OPF_MASS] = base + OPF_MASS
@@ -274,7 +290,12 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     ops_i[:, OPI_SAVE] = -1
     ops_i[:, OPI_OUT] = -1
     ops_i[:, OPI_LINK] = -1
+    # identity padding rows gather the identity link-table row THROUGH the op-row layout
     ident = L * OPF_STRIDE + np.arange(OPF_STRIDE, dtype=np.int64)
+    for r in range(3):
+        for c in range(3):
+            ident[opf_fij(r, c)] = L * OPF_STRIDE + OPF_F + r * 3 + c
+        ident[opf_ti(r)] = L * OPF_STRIDE + OPF_T + r
     gather = np.tile(ident, (cap, 1))
     gsign = np.ones((cap, OPF_STRIDE), np.float32)
     if n_ops:
@@ -287,8 +308,11 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     for row in ops:
         if row[OPI_DOF] >= 0:
             mask |= 1 << row[OPI_DOF]
+    n = spec.n_dofs
+    arm = (n_ops >= n and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
+                              for k, row in enumerate(ops)))
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
-                       max_used, cap, tlist, mask, unique)
+                       max_used, cap, tlist, mask, unique, SHAPE_ARM_CHAIN if arm else 0)
 
 
 def identity_table_row() -> np.ndarray:

@@ -158,28 +158,29 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._spec: RobotSpec = build_robot_spec(body_params, parent_names)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
-        self._static_table: Optional[torch.Tensor] = None
+        self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
+        self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
     # ------------------------------------------------------------------ constants
-    def _link_table(self) -> torch.Tensor:
-        """[L + 1, OPF_STRIDE] float32 table of per-link constants on the model device
-        (row L = the identity op used to pad walks).
+    def _link_rows(self, link_idxs) -> torch.Tensor:
+        """[len(link_idxs), OPF_STRIDE] float32 rows of per-link constants on the model device.
 
-        Built with torch ops from the bodies' parameter callables, so gradients
-        reach learnable parametrisations.  The arithmetic mirrors the reference:
+        Built with torch ops from the bodies' parameter callables, so gradients reach learnable
+        parametrisations.  The arithmetic mirrors the reference:
         R_fixed = (Rz(yaw) @ Ry(pitch)) @ Rx(roll)  (rigid_body.py:138-143, spatial_vector_algebra.py:14-53),
         mcom = com * mass, I_o = I_c + mass * S(com) S(com)^T  (spatial_vector_algebra.py:321-327).
         """
         dev = self._device
-        L = len(self._bodies)
+        bodies = [self._bodies[i] for i in link_idxs]
+        L = len(bodies)
         cat = lambda ts, shape: torch.stack([t.reshape(shape).to(dev) for t in ts])
-        rpy = cat([b.rot_angles() for b in self._bodies], (3,))
-        trans = cat([b.trans() for b in self._bodies], (3,))
-        mass = cat([b.inertia.mass() for b in self._bodies], (1,))
-        com = cat([b.inertia.com() for b in self._bodies], (3,))
-        inertia = cat([b.inertia.inertia_mat() for b in self._bodies], (3, 3))
+        rpy = cat([b.rot_angles() for b in bodies], (3,))
+        trans = cat([b.trans() for b in bodies], (3,))
+        mass = cat([b.inertia.mass() for b in bodies], (1,))
+        com = cat([b.inertia.com() for b in bodies], (3,))
+        inertia = cat([b.inertia.inertia_mat() for b in bodies], (3, 3))
         zero1 = torch.zeros(1, device=dev)
-        damping = cat([b.joint_damping() if b.joint_damping() is not None else zero1 for b in self._bodies], (1,))
+        damping = cat([b.joint_damping() if b.joint_damping() is not None else zero1 for b in bodies], (1,))
 
         c, s = torch.cos(rpy), torch.sin(rpy)
         one, zero = torch.ones(L, device=dev), torch.zeros(L, device=dev)
@@ -193,8 +194,24 @@ class DifferentiableRobotModel(torch.nn.Module):
         mcom = com * mass
         table = torch.cat([F.reshape(L, 9), trans, mass, mcom, Io.reshape(L, 9), damping,
                            torch.zeros(L, OPF_STRIDE - 26, device=dev)], dim=1)
-        ident = torch.from_numpy(identity_table_row()).to(dev).reshape(1, OPF_STRIDE)
-        return torch.cat([table.to(torch.float32), ident], dim=0)
+        return table.to(torch.float32)
+
+    def _link_table(self) -> torch.Tensor:
+        """[L + 1, OPF_STRIDE] table of per-link constants (row L = the identity op used to pad walks).
+
+        With learnable parameters only the rows of the links that carry them are rebuilt (differentiably) on
+        top of a cached snapshot of the constant rows: the per-step host work is O(#learnable links), not O(L).
+        """
+        if self._static_table is None:
+            with torch.no_grad():
+                ident = torch.from_numpy(identity_table_row()).to(self._device).reshape(1, OPF_STRIDE)
+                self._static_table = torch.cat([self._link_rows(range(len(self._bodies))), ident], dim=0)
+        if not self._learnable:
+            return self._static_table
+        links = sorted({link for link, _ in self._learnable})
+        if self._learnable_links is None or self._learnable_links.numel() != len(links):
+            self._learnable_links = torch.tensor(links, dtype=torch.int64, device=self._device)
+        return self._static_table.index_copy(0, self._learnable_links, self._link_rows(links))
 
     def _get_walk(self, key, targets=None, whole_tree=False) -> _DeviceWalk:
         dw = self._walks.get(key)
@@ -214,13 +231,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if self._learnable:
-            table = self._link_table()
-        else:
-            if self._static_table is None:
-                with torch.no_grad():
-                    self._static_table = self._link_table()
-            table = self._static_table
+        table = self._link_table()
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
@@ -384,6 +395,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         parent_object.__delattr__(parameter_name)
         parent_object.add_module(parameter_name, parametrization.to(self._device))
         self._learnable.add((self._name_to_idx_map[link_name], parameter_name))
+        self._learnable_links = None
+        for dw in self._walks.values():
+            dw.static_ops_f = None
 
     def _learnable_module(self, link_name: str, parameter_name: str):
         parent_object = self._get_parent_object_of_param(link_name, parameter_name)

@@ -34,12 +34,16 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 1
+#define DRM_ABI_VERSION 2
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
-#define DRM_OPF_F 0       /* [9] R_fixed = Rz(yaw)Ry(pitch)Rx(roll), row-major (rigid_body.py:138-143) */
-#define DRM_OPF_T 9       /* [3] joint origin xyz ("trans", rigid_body.py:48)                   */
+/* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
+ * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
+ *   (F00 F01) (F10 F11) (F20 F21) (F02 t0) (F12 t1) (F22 t2)                                          */
+#define DRM_OPF_FIJ(i, j) ((j) < 2 ? 2 * (i) + (j) : 6 + 2 * (i)) /* entry (i, j) of R_fixed        */
+#define DRM_OPF_TI(i) (7 + 2 * (i))                               /* component i of trans           */
+#define DRM_OPF_FT_FLOATS 12
 #define DRM_OPF_MASS 12   /* [1] link mass                                                     */
 #define DRM_OPF_MCOM 13   /* [3] mass * com                (spatial_vector_algebra.py:323)      */
 #define DRM_OPF_IO 16     /* [9] I_c + m S(c)S(c)^T        (spatial_vector_algebra.py:324-327)  */
@@ -67,6 +71,10 @@ extern "C" {
 #define DRM_MAX_OPS 32    /* largest compiled walk capacity (4, 8, 12, 16, 24, 32)             */
 #define DRM_MAX_DOFS 64   /* largest supported number of DoF columns                           */
 
+/* drm_walk.shape */
+#define DRM_WALK_ARM_CHAIN 1 /* a serial chain: ops 0..n_dofs-1 are moving joints driving DoF columns
+                                0..n_dofs-1 in order, every later op is a fixed joint or padding  */
+
 /* flags of drm_rnea */
 #define DRM_RNEA_GRAVITY 1 /* base acceleration (0,0,+9.81)   (robot_model.py:344-350)         */
 #define DRM_RNEA_DAMPING 2 /* tau += damping * qd             (robot_model.py:368-373)         */
@@ -91,7 +99,7 @@ typedef struct drm_walk {
     int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS)                              */
     uint64_t dof_mask;    /* bit d set <=> DoF d is driven by an op of this walk             */
     int32_t target_perm;  /* drm_fk_jacobian: DRM_OPI_PERM code (0..5) of the target (last real) op */
-    int32_t reserved;
+    int32_t shape;        /* DRM_WALK_* bits describing the walk, so launchers can pick a specialised kernel */
 } drm_walk;
 
 int drm_abi_version(void);
@@ -142,7 +150,7 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
  *   grad_pos   [B, T, 3]     dL/dpos of every target
  *   param_mask               bit k set: produce the constant gradient of op k (its link is learnable)
  *   grad_q     [B, n]        dL/dq, or NULL
- *   grad_ops_f [capacity, DRM_OPF_STRIDE]  dL/dF at +DRM_OPF_F (9), dL/dt at +DRM_OPF_T (3), summed over the
+ *   grad_ops_f [capacity, DRM_OPF_STRIDE]  dL/dF at DRM_OPF_FIJ(i, j), dL/dt at DRM_OPF_TI(i), summed over the
  *                            batch in a fixed order (deterministic); zeros elsewhere.  NULL iff param_mask == 0.
  *   scratch    drm_fk_backward_scratch_floats(B, capacity) floats, owned by the caller
  * The walk must give every branch point its own save slot (flatten.WalkProgram.slots_unique).

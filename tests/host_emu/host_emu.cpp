@@ -59,6 +59,30 @@ void jac_t(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat
     }
 }
 
+// packed-FP32 chain arithmetic of the arm kernel (fk_jacobian_arm_kernel<8, 7>)
+void jac_arm_8_7(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
+    constexpr int CAP = 8, NJ = 7;
+    for (int64_t b = 0; b < B; ++b) {
+        float qv[NJ];
+        for (int d = 0; d < NJ; ++d) qv[d] = q[b * NJ + d];
+        PoseP ee;
+        f2 Bk[NJ][3];
+        fk_chain_pairs<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, qv, ee, Bk);
+        Pose E;
+        pose_from_pairs(ee, E);
+        for (int i = 0; i < 3; ++i) pos[b * 3 + i] = E.p[i];
+        unpermute(w->target_perm, E.R);
+        quat_xyzw(E.R, quat + b * 4);
+        for (int k = 0; k < NJ; ++k) {
+            const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+            const float dp[3] = {E.p[0] - Bk[k][0][1], E.p[1] - Bk[k][1][1], E.p[2] - Bk[k][2][1]};
+            float c[3];
+            cross3(z, dp, c);
+            for (int r = 0; r < 3; ++r) { lin[(b * 3 + r) * NJ + k] = c[r]; ang[(b * 3 + r) * NJ + k] = z[r]; }
+        }
+    }
+}
+
 template <int CAP>
 void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
     const int n = w->n_dofs;
@@ -109,8 +133,11 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
         fk_backward_walk<CAP>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout);
     }
     if (gops)
-        for (int k = 0; k < CAP; ++k)
-            for (int j = 0; j < DRM_OPF_STRIDE; ++j) gops[k * DRM_OPF_STRIDE + j] = j < 12 ? (float)sum[k * 12 + j] : 0.f;
+        for (int k = 0; k < CAP; ++k) {
+            for (int j = 0; j < DRM_OPF_STRIDE; ++j) gops[k * DRM_OPF_STRIDE + j] = 0.f;
+            for (int j = 0; j < 12; ++j)
+                gops[k * DRM_OPF_STRIDE + (j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9))] = (float)sum[k * 12 + j];
+        }
 }
 
 } // namespace
@@ -133,6 +160,11 @@ int emu_fk(const drm_walk *w, const float *q, int64_t B, int32_t T, float *pos, 
 }
 int emu_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
     DISPATCH(jac_t, w, q, B, pos, quat, lin, ang)
+    return 0;
+}
+int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    jac_arm_8_7(w, q, B, pos, quat, lin, ang);
     return 0;
 }
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,

@@ -28,7 +28,7 @@ def _require_gpu_and_native_library():
     assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
     from differentiable_robot_model_amd import backend
     lib = backend.load_library()            # raises if the in-tree .so is missing: no silent fallback
-    assert backend.LIB_PATH.endswith("csrc/libdrm_hip.so") and lib.drm_abi_version() == 1
+    assert backend.LIB_PATH.endswith("csrc/libdrm_hip.so") and lib.drm_abi_version() == backend.ABI_VERSION
 
 
 # ------------------------------------------------------------------ vs the fp64 oracle

@@ -41,7 +41,7 @@ def host_walk(model, prog):
                                  np.float32)
     perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
     walk = DrmWalk(ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, prog.n_ops, prog.capacity, model._n_dofs,
-                   prog.n_slots, prog.dof_mask, perm, 0)
+                   prog.n_slots, prog.dof_mask, perm, prog.shape)
     return walk, ops_f
 
 
@@ -78,6 +78,32 @@ def test_jacobian_every_link(emu, robot):
         assert max_err(pos, op) < 1e-6 and max_err(lin, ol) < 1e-6 and max_err(ang, oa) < 1e-6, (robot, link)
         ok, _ = quat_close(quat, oq, 1e-6)
         assert ok, (robot, link)
+
+
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "fetch_arm_no_gripper"])
+def test_arm_chain_packed_arithmetic(emu, robot):
+    """The packed-FP32 chain arithmetic of fk_jacobian_arm_kernel<8, 7> (pairs, two-joint sincos, fp64 fallback
+    for huge angles) against the fp64 oracle."""
+    m = load_model(robot)
+    L, n = len(m._bodies), m._n_dofs
+    prog = build_walk(m._spec, targets=[L - 1])
+    assert prog.shape & 1 and prog.capacity == 8 and n == 7
+    walk, keep = host_walk(m, prog)
+    q, _, _ = sample_states(m, 257, seed=21)
+    q[5] *= 100.0          # beyond any joint range, still on the fp32 reduction
+    q[6, 3] = 2.5e5        # one huge angle: the whole sample takes the fp64 reduction
+    q[7] = 0.0
+    B = q.shape[0]
+    pos = np.zeros((B, 3), np.float32); quat = np.zeros((B, 4), np.float32)
+    lin = np.full((B, 3, n), np.nan, np.float32); ang = np.full((B, 3, n), np.nan, np.float32)
+    assert emu.emu_fk_jacobian_arm(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(pos), _ptr(quat), _ptr(lin),
+                                   _ptr(ang)) == 0
+    op, oq, ol, oa = Oracle(m._spec).fk_jacobian(q.astype(np.float64), L - 1, np.float64)
+    assert max_err(pos, op) < 2e-6 and max_err(lin, ol) < 2e-6 and max_err(ang, oa) < 1e-6
+    ok, _ = quat_close(quat, oq, 1e-6)
+    assert ok
+    # walks that skip DoF columns (a finger of a hand) are not arm-shaped
+    assert not build_walk(load_model("allegro_left")._spec, targets=[10]).shape & 1
 
 
 @pytest.mark.parametrize("robot", ALL_ROBOTS)

@@ -10,6 +10,7 @@ import torch
 
 from differentiable_robot_model_amd import backend
 from differentiable_robot_model_amd.flatten import (CAPACITIES, OPF_F, OPF_IO, OPF_MCOM, OPF_T, OPI_DOF, OPI_OUT, OPI_SAVE,
+                                                    opf_fij, opf_ti,
                                                     OPI_SRC, SRC_PREV, SRC_ROOT, UnsupportedRobotError, build_walk)
 from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel
 from differentiable_robot_model_amd.urdf_utils import parse_urdf
@@ -107,11 +108,20 @@ def test_axis_canonicalisation_is_a_pure_reindexing():
     for k in range(prog.n_ops):
         link = int(prog.links[k])
         raw = table[link * 32:(link + 1) * 32]
-        for a, b in ((OPF_F, 9), (OPF_T, 3), (OPF_MCOM, 3), (OPF_IO, 9)):
+        # op rows: F and t interleaved in the FT block (first 12 floats), the rest as in the link table
+        f_cols = [opf_fij(i, j) for i in range(3) for j in range(3)]
+        t_cols = [opf_ti(i) for i in range(3)]
+        assert sorted(f_cols + t_cols) == list(range(12))
+        assert sorted(ops_f[k, f_cols].tolist()) == sorted(raw[OPF_F:OPF_F + 9].tolist())
+        assert sorted(ops_f[k, t_cols].tolist()) == sorted(raw[OPF_T:OPF_T + 3].tolist())
+        for a, b in ((OPF_MCOM, 3), (OPF_IO, 9)):
             assert sorted(ops_f[k, a:a + b].tolist()) == sorted(raw[a:a + b].tolist())
+    # the signs only ever flip entries (exact), and only for negative axes
+    assert set(np.unique(prog.gsign).tolist()) <= {-1.0, 1.0}
     ident = ops_f[prog.n_ops:]
-    assert np.array_equal(ident[:, :9], np.tile(np.eye(3, dtype=np.float32).reshape(-1), (len(ident), 1)))
-    assert np.all(ident[:, 9:] == 0)
+    eye = np.zeros(32, np.float32)
+    eye[[opf_fij(0, 0), opf_fij(1, 1), opf_fij(2, 2)]] = 1.0
+    assert np.array_equal(ident, np.tile(eye, (len(ident), 1)))
 
 
 def test_capacity_limit():

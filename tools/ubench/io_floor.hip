@@ -16,7 +16,26 @@
 
 __global__ void __launch_bounds__(256) k_empty(ARGS) {}
 
-template <bool RD, bool WR, int N, int S>
+template <bool NT>
+__device__ __forceinline__ void st4(float4 *p, float4 v) {
+    if (NT) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        v4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4 *>(p));
+    } else {
+        *p = v;
+    }
+}
+
+// one 16-byte store per lane and nothing else: is the cost of writing a fixed end-of-kernel cost or a drain?
+__global__ void __launch_bounds__(256) k_wr_small(ARGS) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    reinterpret_cast<float4 *>(quat + (size_t)tile * 256)[threadIdx.x & 63u] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+template <bool RD, bool WR, int N, int S, bool NT = false>
 __global__ void __launch_bounds__(256) k_model(ARGS) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = blockIdx.x * 4 + wave;
@@ -34,12 +53,12 @@ __global__ void __launch_bounds__(256) k_model(ARGS) {
     float4 *a4 = reinterpret_cast<float4 *>(ang + (size_t)tile * 1344);
     auto store = [&](int i) { // 14 store instructions, i = 0..13
         if (!WR) { if (v.x == 12345.678f) r4[lane] = v; return; }
-        if (i == 0) { if (lane < 48) p4[lane] = v; }
-        else if (i == 1) r4[lane] = v;
-        else if (i < 7) l4[lane + 64 * (i - 2)] = v;
-        else if (i == 7) { if (lane < 16) l4[lane + 320] = v; }
-        else if (i < 13) a4[lane + 64 * (i - 8)] = v;
-        else { if (lane < 16) a4[lane + 320] = v; }
+        if (i == 0) { if (lane < 48) st4<NT>(p4 + lane, v); }
+        else if (i == 1) st4<NT>(r4 + lane, v);
+        else if (i < 7) st4<NT>(l4 + lane + 64 * (i - 2), v);
+        else if (i == 7) { if (lane < 16) st4<NT>(l4 + lane + 320, v); }
+        else if (i < 13) st4<NT>(a4 + lane + 64 * (i - 8), v);
+        else { if (lane < 16) st4<NT>(a4 + lane + 320, v); }
     };
     int next = 0;
 #pragma unroll
@@ -90,6 +109,10 @@ int main(int argc, char **argv) {
         RUN("io (rd+wr)", (k_model<true, true, 0, 1>))
         RUN("rd only", (k_model<true, false, 0, 1>))
         RUN("wr only", (k_model<false, true, 0, 1>))
+        RUN("wr only, nontemporal", (k_model<false, true, 0, 1, true>))
+        RUN("wr 16 B per lane only", k_wr_small)
+        RUN("rd + 800 fma + wr at end, nt", (k_model<true, true, 800, 1, true>))
+        RUN("rd + 800 fma + wr in 7, nt", (k_model<true, true, 800, 7, true>))
         RUN("rd + 400 fma, no wr", (k_model<true, false, 400, 1>))
         RUN("rd + 800 fma, no wr", (k_model<true, false, 800, 1>))
         RUN("rd + 1200 fma, no wr", (k_model<true, false, 1200, 1>))
