@@ -194,7 +194,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         float c[3];
         cross3(z, dp, c); // robot_model.py:661
         // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
+#ifndef DRM_NO_PIN
         asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+#endif
         lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
         arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2]; // robot_model.py:662
     }
