@@ -184,6 +184,9 @@ struct Geometry {
 // waves per block: as many as fit a 64 KiB LDS budget (<= 4); one wave per 64 samples.
 int make_geometry(int64_t B, int lds_floats_per_wave, Geometry &g);
 
+// drm_fk_jacobian.hip: single-target FK of an arm-shaped walk through the packed chain kernel
+int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
+
 template <class K>
 static int ensure_lds(K kernel, size_t bytes) {
     if (bytes > (size_t)64 * 1024) {

@@ -71,6 +71,17 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
     if (n_targets > w->n_ops) return fail(DRM_ERR_INVALID, "more targets than ops in the walk");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs, T = n_targets;
+    if (T == 1 && w->n_ops >= 1) {
+        // 7-DoF arms, one target at the end of the chain: full tiles through the packed-FP32 chain kernel
+        const int64_t done = launch_fk_arm(w, q, B, pos, quat, (hipStream_t)stream);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_ARM_CHAIN;
+            return drm_fk(&generic, q + done * n, B - done, 1, pos + done * 3, quat + done * 4, stream);
+        }
+    }
     Geometry g;
     rc = make_geometry(B, round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + round4(WAVE * pad_odd(4 * T)) +
                               w->n_slots * 12 * WAVE, g);

@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // quat wanted, NJ odd.  This is the shape of the metric workload.  Differences from the generic kernel:
 //   * the arithmetic runs on packed FP32 pairs (drm_sample.hpp "Packed-FP32 form"): 27 v_pk_* per link instead
 //     of 48 scalar VALU ops, two joints per sincos evaluation;
-//   * the FT blocks of the walk (12 floats per link, < 400 B) are staged ONCE per wave into LDS and read back
-//     as broadcast ds_read_b128s into VGPR pairs (in-order LDS returns let the compiler wait per link, and
+//   * the constant rows of the walk (1 KB) are staged ONCE per wave into LDS by one 16-byte load per lane and
+//     the FT blocks are read back as broadcast ds_read_b128s into VGPR pairs (in-order LDS returns let the compiler wait per link, and
 //     packed ops take VGPR pairs without constant-bus limits); no scalar loads, no int table;
 //   * the first 14 argument dwords are preloaded into SGPRs by the command processor (kernarg preload,
 //     HIPFLAGS in the Makefile), so the constant and q-tile loads are issued in the wave's first cycles;
@@ -130,40 +130,43 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
 // The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int CAP, int NJ>
+template <int CAP, int NJ, bool JAC>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
                            float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
                            float *__restrict__ ang) {
-    // argument order: everything needed to issue the first loads sits in the preloaded dwords
+    // argument order: everything needed to issue the first loads sits in the preloaded dwords.
+    // JAC = false is the FK-only form (drm_fk of one target): same chain, no Jacobian columns.
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int SQ = NJ, SJ = 3 * NJ;
-    constexpr int C_FLOATS = round4(CAP * DRM_OPF_FT_FLOATS), Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3,
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3,
                   J_FLOATS = round4(WAVE * SJ);
-    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + P_FLOATS + 2 * J_FLOATS;
+    // pos is staged over the q tile (q lives in registers by then): 51.7 KB per block, three blocks per CU
+    static_assert(P_FLOATS <= Q_FLOATS, "pos staging overlays the q tile");
+#ifdef DRM_ARM_ONE_J_REGION /* development A/B: lin and ang staged one after the other through one region */
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? J_FLOATS : 0);
+#else
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? 2 * J_FLOATS : 0);
+#endif
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
-    float *lq = lc + C_FLOATS, *lp = lq + Q_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
+#ifdef DRM_ARM_ONE_J_REGION
+    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll;
+#else
+    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
+#endif
     const int64_t b0 = (int64_t)tile * WAVE;
 
-    // FT blocks -> LDS (one dword per lane and round), in flight together with the q tile
-    constexpr int C_IT = (CAP * DRM_OPF_FT_FLOATS + WAVE - 1) / WAVE;
-    float cv[C_IT];
-#pragma unroll
-    for (int it = 0; it < C_IT; ++it) {
-        const unsigned i = lane + WAVE * it, ic = i < CAP * DRM_OPF_FT_FLOATS ? i : 0u;
-        cv[it] = ops_f[(ic / DRM_OPF_FT_FLOATS) * DRM_OPF_STRIDE + ic % DRM_OPF_FT_FLOATS];
-    }
+    // the walk's constant rows (1 KB) -> LDS: one 16-byte load per lane, in flight together with the q tile
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
     tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-#pragma unroll
-    for (int it = 0; it < C_IT; ++it) {
-        const unsigned i = lane + WAVE * it;
-        if (i < CAP * DRM_OPF_FT_FLOATS) lc[i] = cv[it];
-    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
 
     float qv[NJ];
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
     PoseP ee;
     f2 Bk[NJ][3];
-    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_FT_FLOATS; }, qv, ee, Bk);
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk);
 
     // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
     // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
@@ -183,27 +186,59 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
     }
     const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    wave_lds_sync(); // every lane has read its q row (program order; the LDS executes a wave's accesses in order)
     lp[lane * 3 + 0] = pe[0];
     lp[lane * 3 + 1] = pe[1];
     lp[lane * 3 + 2] = pe[2];
-    float *lrow = ll + lane * SJ, *arow = la + lane * SJ;
+    if constexpr (JAC) {
+        float *lrow = ll + lane * SJ, *arow = la + lane * SJ;
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) {
-        const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
-        const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
-        float c[3];
-        cross3(z, dp, c); // robot_model.py:661
-        // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
-#ifndef DRM_NO_PIN
-        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        for (int k = 0; k < NJ; ++k) {
+            const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+            const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+            float c[3];
+            cross3(z, dp, c); // robot_model.py:661
+            // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+            lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+#ifndef DRM_ARM_ONE_J_REGION
+            arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2]; // robot_model.py:662
 #endif
-        lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
-        arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2]; // robot_model.py:662
+        }
+        wave_lds_sync();
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+        tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
+#ifdef DRM_ARM_ONE_J_REGION
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) { arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0]; }
+        wave_lds_sync();
+#endif
+        tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+    } else {
+        wave_lds_sync();
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
     }
-    wave_lds_sync();
-    tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
-    tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
-    tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+}
+
+// FK of the single target of an arm-shaped walk through the packed chain kernel (called by drm_fk); returns the
+// number of rows it covered (full tiles), 0 if the call does not qualify.
+int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s) {
+#ifdef DRM_NO_ARM_KERNEL
+    return 0;
+#else
+    const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    if (!((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7 && w->target_perm == 2 &&
+          align == (AL_Q | AL_POS | AL_QUAT) && (((uintptr_t)w->ops_f) & 15u) == 0 && B >= WAVE &&
+          B / WAVE < 0x7fffffffLL))
+        return 0;
+    const int n_tiles = (int)(B / WAVE);
+    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, false>),
+                       dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, pos, quat, (float *)nullptr,
+                       (float *)nullptr);
+    return (int64_t)n_tiles * WAVE;
+#endif
 }
 
 } // namespace drm
@@ -240,12 +275,12 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
     if (false) {
 #else
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && w->target_perm == 2 && align == all_al &&
-        B >= WAVE && B / WAVE < 0x7fffffffLL) {
+        (((uintptr_t)w->ops_f) & 15u) == 0 && B >= WAVE && B / WAVE < 0x7fffffffLL) {
 #endif
         // 7-DoF arms (Franka Panda, KUKA iiwa): full tiles through the packed-FP32 chain kernel, ragged tail (if
         // any) through the generic one
         const int n_tiles = (int)(B / WAVE);
-        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7>),
+        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true>),
                            dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
                            dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
         const int64_t done = (int64_t)n_tiles * WAVE;

@@ -586,22 +586,97 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 //   tau_out(d, value)   -> torque of DoF d
 //   motion / force slots: branch-point state, kept in LDS by the kernel
 // ---------------------------------------------------------------------------
+// Written on packed FP32 pairs like the chain FK: velocity-like and acceleration-like quantities go through the
+// same linear maps (J^T x, x cross t, I x), so they travel as pairs (w_i, alpha_i), (v_i, a_i) and, on the way
+// back, (f_i, n_i); one v_pk_fma_f32 then does the work of two scalar FMAs.
 struct Motion {
-    float w[3];  // angular velocity
-    float v[3];  // linear velocity
-    float al[3]; // angular acceleration
-    float a[3];  // linear acceleration
+    f2 wa[3]; // (angular velocity, angular acceleration)
+    f2 va[3]; // (linear velocity, linear acceleration)
 };
 
 struct Force {
-    float l[3]; // linear
-    float a[3]; // angular
+    f2 la[3]; // (linear, angular)
 };
 
 DRM_HD void motion_root(Motion &M, float g) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) M.w[i] = M.v[i] = M.al[i] = M.a[i] = 0.0f;
-    M.a[2] = g; // robot_model.py:344-350: gravity enters as a base acceleration (0,0,+9.81)
+    for (int i = 0; i < 3; ++i) { M.wa[i] = f2_bcast(0.0f); M.va[i] = f2_bcast(0.0f); }
+    M.va[2] = f2_make(0.0f, g); // robot_model.py:344-350: gravity enters as a base acceleration (0,0,+9.81)
+}
+
+// out = a x b on pairs (element-wise in the pair dimension); b may be a broadcast scalar vector
+DRM_HD void cross3_pp(const f2 *a, const f2 *b, f2 *out) {
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+DRM_HD void cross3_sp(const float *a, const f2 *b, f2 *out) { // scalar vector x pair vector
+    out[0] = f2_bcast(a[1]) * b[2] - f2_bcast(a[2]) * b[1];
+    out[1] = f2_bcast(a[2]) * b[0] - f2_bcast(a[0]) * b[2];
+    out[2] = f2_bcast(a[0]) * b[1] - f2_bcast(a[1]) * b[0];
+}
+DRM_HD void cross3_ps(const f2 *a, const float *b, f2 *out) { // pair vector x scalar vector
+    out[0] = a[1] * f2_bcast(b[2]) - a[2] * f2_bcast(b[1]);
+    out[1] = a[2] * f2_bcast(b[0]) - a[0] * f2_bcast(b[2]);
+    out[2] = a[0] * f2_bcast(b[1]) - a[1] * f2_bcast(b[0]);
+}
+// y = M x, y = M^T x on pairs (M row-major 3x3 scalars)
+DRM_HD void mat_vec_p(const float *M, const f2 *x, f2 *y) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        y[r] = f2_bcast(M[r * 3 + 0]) * x[0] + f2_bcast(M[r * 3 + 1]) * x[1] + f2_bcast(M[r * 3 + 2]) * x[2];
+}
+DRM_HD void matT_vec_p(const float *M, const f2 *x, f2 *y) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        y[c] = f2_bcast(M[0 * 3 + c]) * x[0] + f2_bcast(M[1 * 3 + c]) * x[1] + f2_bcast(M[2 * 3 + c]) * x[2];
+}
+
+// one link of the forward sweep: motion of the link from its parent's (both in their own body frames)
+//   velocity (robot_model.py:189-193):       w = J^T w_p + wj e_z ;          v = J^T (v_p + w_p x t)
+//   acceleration (robot_model.py:269-277):  al = J^T al_p + aj e_z + w x (wj e_z) ;  a = J^T (a_p + al_p x t) + v x (wj e_z)
+DRM_HD void rnea_link_motion(const float *J, const float *t, float wj, float aj, const Motion &par, Motion &out) {
+    f2 x[3], tmp[3];
+    Motion N;
+    matT_vec_p(J, par.wa, N.wa);
+    cross3_ps(par.wa, t, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = par.va[i] + x[i];
+    matT_vec_p(J, tmp, N.va);
+    N.wa[2] += f2_make(wj, aj);
+    N.wa[0][1] += N.wa[1][0] * wj; N.wa[1][1] -= N.wa[0][0] * wj;
+    N.va[0][1] += N.va[1][0] * wj; N.va[1][1] -= N.va[0][0] * wj;
+    out = N;
+}
+// body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
+// pairs: (h, g) = (I v, I a):  lin = m (v, a) - mc x (w, al) ;  ang = Io (w, al) + mc x (v, a)
+DRM_HD void rnea_body_force(float m, const float *mc, const float *Io, const Motion &N, Force &out) {
+    f2 x[3], hgl[3], hga[3], y[3];
+    cross3_sp(mc, N.wa, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hgl[i] = f2_bcast(m) * N.va[i] - x[i];
+    mat_vec_p(Io, N.wa, y);
+    cross3_sp(mc, N.va, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hga[i] = y[i] + x[i];
+    // f.lin = g.lin + w x h.lin ;  f.ang = g.ang + (w x h.ang + v x h.lin)
+    const float w[3] = {N.wa[0][0], N.wa[1][0], N.wa[2][0]}, v[3] = {N.va[0][0], N.va[1][0], N.va[2][0]};
+    const float hl[3] = {hgl[0][0], hgl[1][0], hgl[2][0]}, ha[3] = {hga[0][0], hga[1][0], hga[2][0]};
+    float xl[3], xa[3], ya[3];
+    cross3(w, hl, xl);
+    cross3(w, ha, xa);
+    cross3(v, hl, ya);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.la[i] = f2_make(hgl[i][1] + xl[i], hga[i][1] + (xa[i] + ya[i]));
+}
+// one link of the backward sweep: force.transform(joint_pose) (spatial_vector_algebra.py:281-291):
+// lin = J f ; ang = t x (J f) + J n
+DRM_HD void rnea_link_force_up(const float *J, const float *t, const Force &tot, Force &up) {
+    mat_vec_p(J, tot.la, up.la);
+    const float l[3] = {up.la[0][0], up.la[1][0], up.la[2][0]};
+    up.la[0][1] += t[1] * l[2] - t[2] * l[1];
+    up.la[1][1] += t[2] * l[0] - t[0] * l[2];
+    up.la[2][1] += t[0] * l[1] - t[1] * l[0];
 }
 
 template <int CAP, class QF, class TAU, class MSAVE, class MLOAD, class FADD, class FTAKE>
@@ -631,47 +706,15 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         joint_rot_z(o.F, c_, s_, J);
         if (src == DRM_SRC_ROOT) motion_root(cur, g);
         if (src >= 0) motion_load(src, cur);
-        const float *t = o.t;
-        // velocity (robot_model.py:189-193): w = J^T w_p + wj e_z ; v = J^T (v_p + w_p x t)
-        float tmp[3], x[3];
-        Motion N;
-        matT_vec(J, cur.w, N.w);
-        cross3(cur.w, t, x);
-        tmp[0] = cur.v[0] + x[0]; tmp[1] = cur.v[1] + x[1]; tmp[2] = cur.v[2] + x[2];
-        matT_vec(J, tmp, N.v);
-        N.w[2] += wj;
-        // acceleration (robot_model.py:269-277): al = J^T al_p + aj e_z + w x (wj e_z) ; a = J^T (a_p + al_p x t) + v x (wj e_z)
-        matT_vec(J, cur.al, N.al);
-        cross3(cur.al, t, x);
-        tmp[0] = cur.a[0] + x[0]; tmp[1] = cur.a[1] + x[1]; tmp[2] = cur.a[2] + x[2];
-        matT_vec(J, tmp, N.a);
-        N.al[0] += N.w[1] * wj; N.al[1] -= N.w[0] * wj; N.al[2] += aj;
-        N.a[0] += N.v[1] * wj;  N.a[1] -= N.v[0] * wj;
-        cur = N;
+        rnea_link_motion(J, o.t, wj, aj, cur, cur);
         if (save >= 0) motion_save(save, cur);
-        // body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
-        const float m = of[DRM_OPF_MASS];
-        const float *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
-        float hl[3], ha[3], gl[3], ga[3], y[3];
-        cross3(mc, N.w, x);
-        hl[0] = m * N.v[0] - x[0]; hl[1] = m * N.v[1] - x[1]; hl[2] = m * N.v[2] - x[2];
-        mat_vec(Io, N.w, y);
-        cross3(mc, N.v, x);
-        ha[0] = y[0] + x[0]; ha[1] = y[1] + x[1]; ha[2] = y[2] + x[2];
-        cross3(mc, N.al, x);
-        gl[0] = m * N.a[0] - x[0]; gl[1] = m * N.a[1] - x[1]; gl[2] = m * N.a[2] - x[2];
-        mat_vec(Io, N.al, y);
-        cross3(mc, N.a, x);
-        ga[0] = y[0] + x[0]; ga[1] = y[1] + x[1]; ga[2] = y[2] + x[2];
-        cross3(N.w, hl, x);
-        f[k].l[0] = gl[0] + x[0]; f[k].l[1] = gl[1] + x[1]; f[k].l[2] = gl[2] + x[2];
-        cross3(N.w, ha, x);
-        cross3(N.v, hl, y);
-        f[k].a[0] = ga[0] + (x[0] + y[0]); f[k].a[1] = ga[1] + (x[1] + y[1]); f[k].a[2] = ga[2] + (x[2] + y[2]);
+        rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f[k]);
     }
 
     // ---- backward sweep: accumulate forces towards the root ----------------
-    Force carry = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    Force carry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) carry.la[i] = f2_bcast(0.0f);
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
@@ -679,12 +722,12 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
         Force tot = f[k];
         if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { tot.l[i] += carry.l[i]; tot.a[i] += carry.a[i]; }
+            for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
         }
         if (save >= 0) force_take(save, tot); // += children that hang off this branch point, slot reset to 0
         if (dof >= 0) {
             // tau = f.ang . axis (+ damping * qd)   (robot_model.py:353-373); the axis is +z of the stored frame
-            float tau = tot.a[2];
+            float tau = tot.la[2][1];
             if (flags & DRM_RNEA_DAMPING) {
                 float q, qd, qdd;
                 qf(dof, q, qd, qdd);
@@ -693,17 +736,85 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
             tau_out(dof, tau);
         }
         if (src != DRM_SRC_ROOT) {
-            // force.transform(joint_pose) (spatial_vector_algebra.py:281-291): lin = J f ; ang = t x (J f) + J n
             const OpFT o = load_ft(of);
-            float J[9], x[3];
+            float J[9];
             joint_rot_z(o.F, cs[k], sn[k], J);
             Force up;
-            mat_vec(J, tot.l, up.l);
-            mat_vec(J, tot.a, up.a);
-            cross3(o.t, up.l, x);
-            up.a[0] += x[0]; up.a[1] += x[1]; up.a[2] += x[2];
+            rnea_link_force_up(J, o.t, tot, up);
             if (src >= 0) force_add(src, up);
             else carry = up;
+        }
+    }
+}
+
+// RNEA of a serial chain (DRM_WALK_ARM_CHAIN: NJ moving joints driving DoF columns 0..NJ-1, then CAP - NJ fixed
+// links or identity padding): the straight-line form of rnea_walk without the int table, with the joint
+// transforms kept in registers between the sweeps and two joints per sincos evaluation.
+//   row(k) -> pointer to op k's constant row (DRM_OPF_* layout)
+//   fput(k, Force) / fget(k, Force&) -> body force of link k, parked between the sweeps (LDS in the kernel: the
+//   48 floats would otherwise be the registers that keep a second wave off the SIMD)
+template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ], const float (&qd)[NJ],
+                       const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
+    float cs[NJ], sn[NJ];
+    bool big = false;
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) {
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < NJ; d += 2) {
+            f2 s2, c2;
+            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
+            sn[d] = s2[0]; cs[d] = c2[0];
+            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
+        }
+    }
+    // The joint transforms are rebuilt in the backward sweep (12 VALU ops + three broadcast LDS reads per link)
+    // instead of being kept: 72 fewer live registers.
+    Motion cur;
+    motion_root(cur, gravity ? 9.81f : 0.0f);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const float *of = row(k);
+        const OpFT o = load_ft(of);
+        float J[9];
+        if (k < NJ) {
+            joint_rot_z(o.F, cs[k], sn[k], J);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+        }
+        rnea_link_motion(J, o.t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, cur, cur);
+        Force fk;
+        rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, fk);
+        fput(k, fk);
+    }
+    Force tot;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tot.la[i] = f2_bcast(0.0f);
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = row(k);
+        Force fk;
+        fget(k, fk);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.la[i] += fk.la[i];
+        if (k < NJ) tau[k] = tot.la[2][1] + (damping ? of[DRM_OPF_DAMP] * qd[k] : 0.0f);
+        if (k > 0) {
+            const OpFT o = load_ft(of);
+            float J[9];
+            if (k < NJ) {
+                joint_rot_z(o.F, cs[k], sn[k], J);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+            }
+            Force up;
+            rnea_link_force_up(J, o.t, tot, up);
+            tot = up;
         }
     }
 }

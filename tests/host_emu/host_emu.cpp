@@ -83,21 +83,35 @@ void jac_arm_8_7(const drm_walk *w, const float *q, int64_t B, float *pos, float
     }
 }
 
+void rnea_arm_8_7(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
+    constexpr int CAP = 8, NJ = 7;
+    for (int64_t b = 0; b < B; ++b) {
+        float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+        for (int d = 0; d < NJ; ++d) { qv[d] = q[b * NJ + d]; qdv[d] = qd[b * NJ + d]; qddv[d] = qdd ? qdd[b * NJ + d] : 0.f; }
+        Force park[CAP];
+        rnea_chain<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                            flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv, [&](int k, const Force &F) { park[k] = F; },
+                            [&](int k, Force &F) { F = park[k]; });
+        for (int d = 0; d < NJ; ++d) tau[b * NJ + d] = tv[d];
+    }
+}
+
 template <int CAP>
 void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
     const int n = w->n_dofs;
     for (int64_t b = 0; b < B; ++b) {
         Motion ms[DRM_MAX_SLOTS];
-        Force fs[DRM_MAX_SLOTS] = {};
+        Force fs[DRM_MAX_SLOTS];
+        for (auto &F : fs) for (int i = 0; i < 3; ++i) F.la[i] = f2_bcast(0.f);
         auto qf = [&](int d, float &a, float &v, float &acc) {
             a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f;
         };
         auto out = [&](int d, float v) { tau[b * n + d] = v; };
         auto msave = [&](int s, const Motion &M) { ms[s] = M; };
         auto mload = [&](int s, Motion &M) { M = ms[s]; };
-        auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) { fs[s].l[i] += F.l[i]; fs[s].a[i] += F.a[i]; } };
+        auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) fs[s].la[i] += F.la[i]; };
         auto ftake = [&](int s, Force &F) {
-            for (int i = 0; i < 3; ++i) { F.l[i] += fs[s].l[i]; F.a[i] += fs[s].a[i]; fs[s].l[i] = 0.f; fs[s].a[i] = 0.f; }
+            for (int i = 0; i < 3; ++i) { F.la[i] += fs[s].la[i]; fs[s].la[i] = f2_bcast(0.f); }
         };
         rnea_walk<CAP>(w->ops_f, w->ops_i, flags, qf, out, msave, mload, fadd, ftake);
     }
@@ -165,6 +179,11 @@ int emu_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, fl
 int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     jac_arm_8_7(w, q, B, pos, quat, lin, ang);
+    return 0;
+}
+int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    rnea_arm_8_7(w, q, qd, qdd, B, flags, tau);
     return 0;
 }
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,

@@ -135,6 +135,29 @@ def test_rnea(emu, robot, flags):
     assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "fetch_arm_no_gripper", "fetch_arm_no_gripper_small_damping"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_arm_chain_rnea(emu, robot, flags):
+    """rnea_chain (the arithmetic of rnea_arm_kernel<8, 7>) against the fp64 oracle."""
+    m = load_model(robot)
+    n, B = m._n_dofs, 65
+    q, qd, qdd = sample_states(m, B, seed=31)
+    q[3, 2] = -3.0e5  # fp64 reduction fallback
+    prog = build_walk(m._spec, whole_tree=True)
+    assert prog.shape & 1 and prog.capacity == 8 and n == 7
+    walk, keep = host_walk(m, prog)
+    tau = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea_arm(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau)) == 0
+    ot = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau, ot, atol=2e-5, rtol=2e-5), (robot, np.abs(tau - ot).max())
+    tau0 = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea_arm(ctypes.byref(walk), _ptr(q), _ptr(qd), None, ctypes.c_int64(B), flags, _ptr(tau0)) == 0
+    o0 = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), np.zeros_like(q, np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
+
+
 def test_sincos_large_arguments(emu):
     """The kernels' branch-free sincos keeps fp32 accuracy far outside any joint range."""
     m = load_model("2link_robot")

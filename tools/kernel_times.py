@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Kernel timings (hipGraph of 100 launches, HIP events): Panda FK+Jacobian, RNEA, FK; Allegro 4-tip FK."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gpu_probe import load, sample
+from differentiable_robot_model_amd import backend
+
+
+def graph_time(fn, launches=100, reps=5):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(launches):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / launches * 1e3)
+    return best
+
+
+sizes = [int(a) for a in sys.argv[1:]] or [65536, 1 << 20, 1 << 22]
+m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
+for B in sizes:
+    q, qd, qdd = (t.cuda() for t in sample(m, B))
+    plan = m.plan_fk_and_jacobian(q, link)
+    us = graph_time(plan.launch)
+    print("fk_jacobian panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
+    m.compute_inverse_dynamics(q[:64], qd[:64], qdd[:64])
+    dt = m._walks[("tree",)]; of = m._ops_f(dt)
+    tau = torch.empty(B, 7, device="cuda")
+    lib = backend.load_library(); import ctypes
+    walk = backend._walk_struct(dt.program, of, dt.ops_i, 7)
+    def rnea():
+        backend._check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, tau.data_ptr(),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(rnea)
+    print("rnea        panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s  %5.1f TFLOP/s (2.6 kflop/eval)" %
+          (B, us, B * 112 / us / 1e3, B / us / 1e3, B * 2.6e3 / us / 1e6))
+    idx = m._name_to_idx_map[link]
+    df = m._get_walk(("fk", (idx,)), targets=[idx]); off = m._ops_f(df)
+    pos = torch.empty(B, 1, 3, device="cuda"); quat = torch.empty(B, 1, 4, device="cuda")
+    wf = backend._walk_struct(df.program, off, df.ops_i, 7)
+    def fk():
+        backend._check(lib.drm_fk(ctypes.byref(wf), q.data_ptr(), B, 1, pos.data_ptr(), quat.data_ptr(),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(fk)
+    print("fk          panda B=%8d %9.2f us  %7.1f GB/s (56 B/eval)" % (B, us, B * 56 / us / 1e3))
+ma = load("allegro_left")
+qa = sample(ma, 65536)[0].cuda()
+tips = [ma._name_to_idx_map[t] for t in ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]]
+da = ma._get_walk(("fk", tuple(tips)), targets=tips); ofa = ma._ops_f(da)
+pa = torch.empty(65536, 4, 3, device="cuda"); ra = torch.empty(65536, 4, 4, device="cuda")
+import ctypes
+wa = backend._walk_struct(da.program, ofa, da.ops_i, 16)
+def fka():
+    backend._check(backend.load_library().drm_fk(ctypes.byref(wa), qa.data_ptr(), 65536, 4, pa.data_ptr(), ra.data_ptr(),
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+us = graph_time(fka)
+print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)" % (us, 65536 * 176 / us / 1e3))

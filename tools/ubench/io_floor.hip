@@ -74,6 +74,27 @@ __global__ void __launch_bounds__(256) k_model(ARGS) {
     }
 }
 
+// issue-rate probes: 4 independent FMA chains, N instructions in total, either as one straight-line block
+// (every instruction fetched once, like the real kernels) or as a 16-instruction loop body (fits any fetch buffer)
+template <int N, bool LOOP>
+__global__ void __launch_bounds__(256) k_issue(ARGS) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    float a = threadIdx.x * 1e-3f, b = 1.5f, c = 0.5f, d = 0.25f;
+    if (LOOP) {
+#pragma unroll 1
+        for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a = fmaf(a, 1.0001f, 0.5f); b = fmaf(b, 0.9999f, 0.25f); c = fmaf(c, 1.0002f, 0.125f); d = fmaf(d, 0.9998f, 0.0625f); }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) { a = fmaf(a, 1.0001f, 0.5f); b = fmaf(b, 0.9999f, 0.25f); c = fmaf(c, 1.0002f, 0.125f); d = fmaf(d, 0.9998f, 0.0625f); }
+    }
+    if (a + b + c + d == 12345.678f) quat[threadIdx.x] = a;
+}
+
 template <class K>
 static float run(K kernel, int B, int launches, const float *q, float *pos, float *quat, float *lin, float *ang) {
     hipStream_t s; (void)hipStreamCreate(&s);
@@ -113,6 +134,10 @@ int main(int argc, char **argv) {
         RUN("wr 16 B per lane only", k_wr_small)
         RUN("rd + 800 fma + wr at end, nt", (k_model<true, true, 800, 1, true>))
         RUN("rd + 800 fma + wr in 7, nt", (k_model<true, true, 800, 7, true>))
+        RUN("800 indep fma, straight-line", (k_issue<800, false>))
+        RUN("800 indep fma, loop of 16", (k_issue<800, true>))
+        RUN("1600 indep fma, straight-line", (k_issue<1600, false>))
+        RUN("1600 indep fma, loop of 16", (k_issue<1600, true>))
         RUN("rd + 400 fma, no wr", (k_model<true, false, 400, 1>))
         RUN("rd + 800 fma, no wr", (k_model<true, false, 800, 1>))
         RUN("rd + 1200 fma, no wr", (k_model<true, false, 1200, 1>))
