@@ -32,19 +32,21 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     auto qf = [&](int d) -> float { return qrow[d]; };
     float *prow = lp + lane * Sp;
     float *rrow = lr + lane * Sr;
-    auto slot_save = [&](int s, const Pose &P) {
+    auto slot_save = [&](int s, const PoseP &P) {
         float *b = ls + s * (12 * WAVE) + lane;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) b[i * WAVE] = P.R[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) b[(9 + i) * WAVE] = P.p[i];
+        for (int c = 0; c < 3; ++c) {
+            b[(4 * c + 0) * WAVE] = P.A[c][0]; b[(4 * c + 1) * WAVE] = P.A[c][1];
+            b[(4 * c + 2) * WAVE] = P.B[c][0]; b[(4 * c + 3) * WAVE] = P.B[c][1];
+        }
     };
-    auto slot_load = [&](int s, Pose &P) {
+    auto slot_load = [&](int s, PoseP &P) {
         const float *b = ls + s * (12 * WAVE) + lane;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) P.R[i] = b[i * WAVE];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) P.p[i] = b[(9 + i) * WAVE];
+        for (int c = 0; c < 3; ++c) {
+            P.A[c] = f2_make(b[(4 * c + 0) * WAVE], b[(4 * c + 1) * WAVE]);
+            P.B[c] = f2_make(b[(4 * c + 2) * WAVE], b[(4 * c + 3) * WAVE]);
+        }
     };
     auto emit = [&](int t, const Pose &P) {
         float qt[4];

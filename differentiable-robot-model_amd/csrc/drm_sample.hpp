@@ -42,6 +42,12 @@
 
 namespace drm {
 
+// 8-byte pair of floats: what v_pk_fma_f32 / v_pk_mul_f32 operate on (see "Packed-FP32 form" below);
+// vector_size(8) is understood by hipcc and by g++ (tests/host_emu)
+typedef float f2 __attribute__((vector_size(8)));
+DRM_HD f2 f2_make(float a, float b) { f2 v = {a, b}; return v; }
+DRM_HD f2 f2_bcast(float a) { f2 v = {a, a}; return v; }
+
 // ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.
 #define DRM_OPI(field, k) opi[(field) * CAP + (k)]
 
@@ -207,18 +213,36 @@ DRM_HD void quat_xyzw(const float *R, float *q) {
     q[3] = w * scale;
 }
 
-// cos / sin of every op's joint angle, computed up front so the transcendental work is
-// off the serial pose chain.  Branch-free on purpose (one basic block lets the compiler issue
-// every scalar load of the walk tables early): fixed joints and padding read DoF 0 and are
-// masked to c = 1, s = 0.
+// cos / sin of every op's joint angle, computed up front so the transcendental work is off the serial pose
+// chain, two ops per packed evaluation (sincos_pair below; the rare wave with an angle beyond its range takes
+// sincos_f's fp64 reduction).  Fixed joints and padding read DoF 0 and are masked to c = 1, s = 0.
+DRM_HD void sincos_pair(f2 x, f2 &s, f2 &c);
 template <int CAP, class QF>
 DRM_HD void joint_trig(const int (&dof)[CAP], QF qf, float *cs, float *sn) {
+    static_assert(CAP % 2 == 0, "ops are evaluated in pairs");
+    float ang[CAP];
+    bool big = false;
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
-        float c_, s_;
-        sincos_f(qf(dof[k] < 0 ? 0 : dof[k]), s_, c_);
-        cs[k] = dof[k] < 0 ? 1.0f : c_;
-        sn[k] = dof[k] < 0 ? 0.0f : s_;
+        ang[k] = qf(dof[k] < 0 ? 0 : dof[k]);
+        big = big || !(fabsf(ang[k]) <= 1.0e5f);
+    }
+    if (DRM_WAVE_ANY(big)) {
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) sincos_f(ang[k], sn[k], cs[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < CAP; k += 2) {
+            f2 s2, c2;
+            f2 x = {ang[k], ang[k + 1]};
+            sincos_pair(x, s2, c2);
+            sn[k] = s2[0]; cs[k] = c2[0]; sn[k + 1] = s2[1]; cs[k + 1] = c2[1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        cs[k] = dof[k] < 0 ? 1.0f : cs[k];
+        sn[k] = dof[k] < 0 ? 0.0f : sn[k];
     }
 }
 
@@ -269,9 +293,6 @@ DRM_HD void fk_chain(const float *__restrict__ opf, const int (&dof)[CAP], QF qf
 // Same products as joint_rot_z + compose (the sums are associated differently; fp32 rounding only).
 // vector_size(8) is understood by hipcc and by g++ (tests/host_emu).
 // ---------------------------------------------------------------------------
-typedef float f2 __attribute__((vector_size(8)));
-DRM_HD f2 f2_make(float a, float b) { f2 v = {a, b}; return v; }
-DRM_HD f2 f2_bcast(float a) { f2 v = {a, a}; return v; }
 
 struct PoseP {
     f2 A[3]; // A[c] = (R_c0, R_c1)
@@ -388,7 +409,7 @@ DRM_HD void sincos_pair_v1(f2 x, f2 &s, f2 &c) {
 }
 #define sincos_pair sincos_pair_v1
 #endif
-constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f;
+constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f; // keep in sync with joint_trig
 
 // FK of a serial chain whose first NJ links are moving joints driving DoF columns 0..NJ-1 and whose
 // remaining CAP - NJ links are fixed joints or identity padding (DRM_WALK_ARM_CHAIN).
@@ -446,21 +467,23 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
     load_field<CAP>(opi, DRM_OPI_DOF, dof);
     float cs[CAP], sn[CAP];
     joint_trig<CAP>(dof, qf, cs, sn);
-    Pose cur;
-    pose_identity(cur);
+    // poses travel as packed pairs (see "Packed-FP32 form" above): 27 packed ops per link instead of 48 scalar ones
+    PoseP cur;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { cur.A[c] = f2_make(c == 0, c == 1); cur.B[c] = f2_make(c == 2, 0.0f); }
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
-        const float *of = opf + k * DRM_OPF_STRIDE;
+        const OpPairs o = load_pairs(opf + k * DRM_OPF_STRIDE);
         const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
-        const OpFT o = load_ft(of);
-        float J[9];
-        joint_rot_z(o.F, cs[k], sn[k], J);
+        f2 J01[3];
+        joint_pairs(o, cs[k], sn[k], J01); // c = 1, s = 0 (fixed joint / padding) gives the F pairs back exactly
         if (src >= 0) slot_load(src, cur);
-        if (src == DRM_SRC_ROOT) compose_root(J, o.t, cur);
-        else compose(cur, J, o.t, cur);
+        if (src == DRM_SRC_ROOT) compose_pairs_root(J01, o, cur);
+        else compose_pairs(cur, J01, o, cur);
         if (save >= 0) slot_save(save, cur);
         if (out >= 0) {
-            Pose P = cur;
+            Pose P;
+            pose_from_pairs(cur, P);
             unpermute(DRM_OPI(DRM_OPI_PERM, k), P.R);
             emit(out, P);
         }
@@ -687,23 +710,25 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     Motion cur;
     motion_root(cur, g);
+    {
+        int dofs[CAP];
+        load_field<CAP>(opi, DRM_OPI_DOF, dofs);
+        joint_trig<CAP>(dofs, [&](int d) { float q, v, a; qf(d, q, v, a); return q; }, cs, sn);
+    }
 
     // ---- forward sweep: velocities, accelerations, body forces -------------
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
         const int dof = DRM_OPI(DRM_OPI_DOF, k), src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
-        float c_ = 1.0f, s_ = 0.0f, wj = 0.0f, aj = 0.0f;
+        float wj = 0.0f, aj = 0.0f;
         if (dof >= 0) {
             float q;
-            qf(dof, q, wj, aj); // joint velocity / acceleration along the (canonical +z) joint axis
-            sincos_f(q, s_, c_); // (rigid_body.py:133-136, 159-165)
+            qf(dof, q, wj, aj); // joint velocity / acceleration along the (canonical +z) joint axis (rigid_body.py:133-136, 159-165)
         }
-        cs[k] = c_;
-        sn[k] = s_;
         const OpFT o = load_ft(of);
         float J[9];
-        joint_rot_z(o.F, c_, s_, J);
+        joint_rot_z(o.F, cs[k], sn[k], J);
         if (src == DRM_SRC_ROOT) motion_root(cur, g);
         if (src >= 0) motion_load(src, cur);
         rnea_link_motion(J, o.t, wj, aj, cur, cur);

@@ -17,10 +17,10 @@ template <int CAP>
 void fk_t(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float *quat) {
     const int n = w->n_dofs;
     for (int64_t b = 0; b < B; ++b) {
-        Pose slots[DRM_MAX_SLOTS];
+        PoseP slots[DRM_MAX_SLOTS];
         auto qf = [&](int d) { return q[b * n + d]; };
-        auto save = [&](int s, const Pose &P) { slots[s] = P; };
-        auto load = [&](int s, Pose &P) { P = slots[s]; };
+        auto save = [&](int s, const PoseP &P) { slots[s] = P; };
+        auto load = [&](int s, PoseP &P) { P = slots[s]; };
         auto emit = [&](int t, const Pose &P) {
             float qt[4];
             quat_xyzw(P.R, qt);
