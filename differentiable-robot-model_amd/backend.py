@@ -38,7 +38,7 @@ _lib = None
 _lock = threading.Lock()
 
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
-           "drm_fk_backward_scratch_floats")
+           "drm_fk_backward_scratch_floats", "drm_crba")
 
 
 def load_library(path: str = None):
@@ -72,6 +72,8 @@ def load_library(path: str = None):
         lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp]
         lib.drm_fk_backward_scratch_floats.restype = i64
         lib.drm_fk_backward_scratch_floats.argtypes = [i64, i32]
+        lib.drm_crba.restype = ctypes.c_int
+        lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         _lib = lib
@@ -157,6 +159,20 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
                             _stream(q.device)))
     return tau
+
+
+def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
+    """H [B, n, n] joint-space inertia matrix."""
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    B = q.shape[0]
+    H = torch.empty(B, n_dofs, n_dofs, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return H
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(), _stream(q.device)))
+    return H
 
 
 def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_dofs: int, param_mask: int,

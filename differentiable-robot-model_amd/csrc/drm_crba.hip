@@ -1,0 +1,119 @@
+// drm_crba.hip — K6: joint-space inertia matrix H(q) by the composite-rigid-body algorithm.
+//
+// Replaces DifferentiableRobotModel.compute_lagrangian_inertia_matrix (robot_model.py:402-450), which runs n + 1
+// full inverse-dynamics passes (each ~11 k tiny torch ops) and subtracts the gravity pass; see drm_sample.hpp
+// crba_walk for why the composite-rigid-body form computes the same matrix.
+//
+// Per sample: in q[n] (4 n bytes), out H[n, n] (4 n^2 bytes).          n = 7: 28 + 196 = 224 B, ~2 kflop
+// LDS per wave: [ q : 64 (n|1) ][ H : 64 (n^2|1) ][ inertia slots : n_slots*10*64 ][ axis slots : n_slots*cap*6*64 ]
+// When the H tile does not fit in LDS (n > ~20) lanes store their entries straight to HBM (uncoalesced, rare).
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+template <int CAP, bool DIRECT>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    crba_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int zero_fill,
+                const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t magic_h,
+                int lds_per_wave, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    WaveCtx cx;
+    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
+    const unsigned lane = cx.lane;
+    const int nn = n * n;
+    const int Sq = pad_odd(n), Sh = DIRECT ? 0 : pad_odd(nn);
+    float *lq = cx.lds;
+    float *lh = lq + round4(WAVE * Sq);
+    float *lis = lh + round4(WAVE * Sh);              // inertia slots [slot][10][64]
+    float *lss = lis + n_slots * (10 * WAVE);         // axis slots    [slot][op][6][64]
+
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
+    for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
+    float *hrow = lh + lane * Sh;
+    if (!DIRECT && zero_fill)
+        for (int i = 0; i < nn; ++i) hrow[i] = 0.0f; // pairs of joints on different branches
+    wave_lds_sync();
+
+    const bool live = (int)lane < cx.rows;
+    const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row compute garbage, never stored
+    float *hdst = H + (cx.b0 + lane) * nn;
+    auto qf = [&](int d) -> float { return qrow[d]; };
+    auto islot_add = [&](int s, const Inertia &a) {
+        float *b = lis + s * (10 * WAVE) + lane;
+        b[0] += a.m;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[(1 + i) * WAVE] += a.h[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[(4 + i) * WAVE] += a.I[i];
+    };
+    auto islot_take = [&](int s, Inertia &a) {
+        float *b = lis + s * (10 * WAVE) + lane;
+        a.m += b[0]; b[0] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a.h[i] += b[(1 + i) * WAVE]; b[(1 + i) * WAVE] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
+    };
+    auto sslot_save = [&](int s, int j, const Axis &a) {
+        float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
+    };
+    auto sslot_load = [&](int s, int j, Axis &a) {
+        const float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
+    };
+    auto hout = [&](int di, int dj, float v) {
+        if (DIRECT) {
+            if (live) hdst[di * n + dj] = v;
+        } else {
+            hrow[di * n + dj] = v;
+        }
+    };
+    crba_walk<CAP>(ops_f, ops_i, qf, islot_add, islot_take, sslot_save, sslot_load, hout);
+    if (!DIRECT) {
+        wave_lds_sync();
+        tile_store<0>(H + cx.b0 * nn, cx.rows, nn, magic_h, lh, lane, cx.full && (nn & 1) && (align & AL_TAU));
+    }
+}
+
+} // namespace drm
+
+using namespace drm;
+
+extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !H) return fail(DRM_ERR_INVALID, "q / H must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    if (B == 0) return DRM_OK;
+    const int n = w->n_dofs, nn = n * n;
+    hipStream_t s = (hipStream_t)stream;
+    const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + w->capacity * 6) * WAVE;
+    const bool direct = (size_t)(base + round4(WAVE * pad_odd(nn))) * sizeof(float) > (size_t)MAX_LDS_BYTES;
+    Geometry g;
+    rc = make_geometry(B, base + (direct ? 0 : round4(WAVE * pad_odd(nn))), g);
+    if (rc) return rc;
+    const int zero_fill = (w->shape & DRM_WALK_ARM_CHAIN) ? 0 : 1; // a chain over all DoFs writes every entry
+    if (direct && zero_fill) {
+        hipError_t e = hipMemsetAsync(H, 0, sizeof(float) * (size_t)B * nn, s);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
+    DRM_DISPATCH_CAP(w->capacity, {
+        if (direct) {
+            rc = ensure_lds(crba_kernel<C, true>, g.lds_bytes);
+            if (rc) return rc;
+            hipLaunchKernelGGL((crba_kernel<C, true>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
+                               (int)w->n_slots, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
+        } else {
+            rc = ensure_lds(crba_kernel<C, false>, g.lds_bytes);
+            if (rc) return rc;
+            hipLaunchKernelGGL((crba_kernel<C, false>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
+                               (int)w->n_slots, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
+        }
+    })
+    return launched();
+}

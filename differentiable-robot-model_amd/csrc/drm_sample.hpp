@@ -844,4 +844,157 @@ DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ]
     }
 }
 
+// ---------------------------------------------------------------------------
+// Joint-space inertia matrix H(q) by the composite-rigid-body algorithm.
+//
+// The reference builds H column by column from n + 1 inverse-dynamics passes (robot_model.py:402-450:
+// H[:, j] = ID(q, 0, e_j) - ID(q, 0, 0)); with qd = 0 inverse dynamics is linear in qdd, so H is the matrix of
+// that linear map, which the composite-rigid-body algorithm evaluates directly (same quantity, ~4x fewer
+// flops, exactly symmetric, and without the cancellation against the gravity term):
+//   backward sweep   Ic_k = I_k + sum over children c of (Ic_c moved into frame k)          composite inertias
+//   forward sweep    every ancestor joint axis S_j is carried down the tree in current-frame coordinates;
+//                    at a moving link k:  F = Ic_k S_k,  H[k][k] = S_k . F,  H[k][j] = H[j][k] = F . S_j.
+// Same body-frame Pluecker conventions as the RNEA walk (joint about +z of the stored frame, child -> parent
+// transform x_p = J x_c + t, spatial inertia f = m v - h x w, n = I w + h x v with h = m c).
+//   islot_add / islot_take   branch-point composite inertias (LDS), take = read-and-add, slot reset to 0
+//   sslot_save / sslot_load  branch-point copies of the ancestor axes (LDS), per ancestor op j
+//   hout(di, dj, v)          H[di][dj] = v
+// ---------------------------------------------------------------------------
+struct Inertia {
+    float m;
+    float h[3]; // first moment m c
+    float I[6]; // xx xy xz yy yz zz, about the link origin
+};
+DRM_HD void inertia_zero(Inertia &a) {
+    a.m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.h[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.I[i] = 0.0f;
+}
+DRM_HD void inertia_add(Inertia &a, const Inertia &b) {
+    a.m += b.m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.h[i] += b.h[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.I[i] += b.I[i];
+}
+// inertia c (child frame) expressed in the parent frame, x_p = J x_c + t:
+//   h' = J h + m t,   I' = J I J^T + 2 (w . t) E - w t^T - t w^T   with  w = J h + (m / 2) t
+DRM_HD void inertia_to_parent(const float *J, const float *t, const Inertia &c, Inertia &out) {
+    float g[3], M[9], w[3];
+    mat_vec(J, c.h, g);
+    const float If[9] = {c.I[0], c.I[1], c.I[2], c.I[1], c.I[3], c.I[4], c.I[2], c.I[4], c.I[5]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            M[r * 3 + k] = J[r * 3 + 0] * If[0 * 3 + k] + J[r * 3 + 1] * If[1 * 3 + k] + J[r * 3 + 2] * If[2 * 3 + k];
+    auto R = [&](int r, int k) { return M[r * 3 + 0] * J[k * 3 + 0] + M[r * 3 + 1] * J[k * 3 + 1] + M[r * 3 + 2] * J[k * 3 + 2]; };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = g[i] + 0.5f * c.m * t[i];
+    const float wt2 = 2.0f * (w[0] * t[0] + w[1] * t[1] + w[2] * t[2]);
+    out.I[0] = R(0, 0) + (wt2 - 2.0f * w[0] * t[0]);
+    out.I[1] = R(0, 1) - (w[0] * t[1] + t[0] * w[1]);
+    out.I[2] = R(0, 2) - (w[0] * t[2] + t[0] * w[2]);
+    out.I[3] = R(1, 1) + (wt2 - 2.0f * w[1] * t[1]);
+    out.I[4] = R(1, 2) - (w[1] * t[2] + t[1] * w[2]);
+    out.I[5] = R(2, 2) + (wt2 - 2.0f * w[2] * t[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.h[i] = g[i] + c.m * t[i];
+    out.m = c.m;
+}
+struct Axis { // a joint axis as a motion vector in some frame
+    float ang[3];
+    float lin[3];
+};
+
+template <int CAP, class QF, class IADD, class ITAKE, class SSAVE, class SLOAD, class HOUT>
+DRM_HD void crba_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, IADD islot_add,
+                      ITAKE islot_take, SSAVE sslot_save, SLOAD sslot_load, HOUT hout) {
+    int dof[CAP];
+    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+    float cs[CAP], sn[CAP];
+    joint_trig<CAP>(dof, qf, cs, sn);
+
+    // ---- backward sweep: composite inertias --------------------------------
+    Inertia Ic[CAP];
+    Inertia carry;
+    inertia_zero(carry);
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) inertia_add(tot, carry);
+        if (save >= 0) islot_take(save, tot);
+        Ic[k] = tot;
+        if (src != DRM_SRC_ROOT) {
+            const OpFT o = load_ft(of);
+            float J[9];
+            joint_rot_z(o.F, cs[k], sn[k], J);
+            Inertia up;
+            inertia_to_parent(J, o.t, tot, up);
+            if (src >= 0) islot_add(src, up);
+            else carry = up;
+        }
+    }
+
+    // ---- forward sweep: ancestor axes down the tree, H entries at every moving link ----
+    Axis S[CAP];
+    uint32_t anc = 0, slot_anc[DRM_MAX_SLOTS] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const float *of = opf + k * DRM_OPF_STRIDE;
+        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        // ops above this one on its path to the root (wave-uniform bit mask)
+        if (src == DRM_SRC_ROOT) anc = 0u;
+        else if (src >= 0) anc = slot_anc[src & (DRM_MAX_SLOTS - 1)];
+        else if (k > 0) anc |= 1u << (k > 0 ? k - 1 : 0);
+        const OpFT o = load_ft(of);
+        float J[9];
+        joint_rot_z(o.F, cs[k], sn[k], J);
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            if (((anc >> j) & 1u) && dof[j] >= 0) {
+                if (src >= 0) sslot_load(src, j, S[j]);
+                // motion vector into the child frame: ang' = J^T ang ; lin' = J^T (lin + ang x t)
+                float x[3], y[3];
+                cross3(S[j].ang, o.t, x);
+                y[0] = S[j].lin[0] + x[0]; y[1] = S[j].lin[1] + x[1]; y[2] = S[j].lin[2] + x[2];
+                matT_vec(J, y, S[j].lin);
+                matT_vec(J, S[j].ang, x);
+                S[j].ang[0] = x[0]; S[j].ang[1] = x[1]; S[j].ang[2] = x[2];
+            }
+        }
+        if (dof[k] >= 0) {
+            // F = Ic S_k with S_k = (ang e_z, lin 0):  f = -h x e_z = (-h_y, h_x, 0),  n = I e_z
+            const float fx = -Ic[k].h[1], fy = Ic[k].h[0];
+            const float nx = Ic[k].I[2], ny = Ic[k].I[4], nz = Ic[k].I[5];
+            hout(dof[k], dof[k], nz);
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                if (((anc >> j) & 1u) && dof[j] >= 0) {
+                    const float v = fx * S[j].lin[0] + fy * S[j].lin[1] + (nx * S[j].ang[0] + ny * S[j].ang[1] + nz * S[j].ang[2]);
+                    hout(dof[k], dof[j], v);
+                    hout(dof[j], dof[k], v);
+                }
+            }
+            S[k].ang[0] = 0.0f; S[k].ang[1] = 0.0f; S[k].ang[2] = 1.0f;
+            S[k].lin[0] = 0.0f; S[k].lin[1] = 0.0f; S[k].lin[2] = 0.0f;
+        }
+        if (save >= 0) {
+            slot_anc[save & (DRM_MAX_SLOTS - 1)] = anc | (1u << k);
+#pragma unroll
+            for (int j = 0; j <= k; ++j)
+                if ((((anc | (1u << k)) >> j) & 1u) && dof[j] >= 0) sslot_save(save, j, S[j]);
+        }
+    }
+}
+
 } // namespace drm

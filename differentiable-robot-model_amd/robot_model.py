@@ -378,6 +378,23 @@ class DifferentiableRobotModel(torch.nn.Module):
         return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, None, bool(include_gravity), bool(use_damping),
                             self._n_dofs)
 
+    @tensor_check
+    def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
+                                          use_damping: Optional[bool] = True) -> torch.Tensor:
+        """Joint-space inertia matrix H(q) [B, n, n] (robot_model.py:402-450).
+
+        The reference assembles H from n + 1 inverse-dynamics passes, column j = ID(q, 0, e_j) - ID(q, 0, 0);
+        ``include_gravity`` / ``use_damping`` cancel out of that difference (gravity is subtracted, damping
+        multiplies qd = 0) and are accepted for signature compatibility only.  One fused
+        composite-rigid-body kernel here.
+        """
+        assert q.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        self._require_device()
+        self._refuse_autograd("compute_lagrangian_inertia_matrix", q)
+        dw = self._get_walk(("tree",), whole_tree=True)
+        return backend.crba(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
+
     # ------------------------------------------------------------------ learnable parameters
     def _get_parent_object_of_param(self, link_name: str, parameter_name: str):
         body_idx = self._name_to_idx_map[link_name]

@@ -142,6 +142,15 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
              int32_t flags, float *tau, void *stream);
 
 /*
+ * Joint-space inertia matrix over the whole tree (composite-rigid-body algorithm).
+ * Replaces DifferentiableRobotModel.compute_lagrangian_inertia_matrix (robot_model.py:402-450: n + 1
+ * compute_inverse_dynamics passes, column j = ID(q, 0, e_j) - ID(q, 0, 0)).  The gravity / damping flags of the
+ * reference cancel out of that difference, so there are none here.
+ *   q [B, n]  ->  H [B, n, n]   (symmetric; entries of joints on different branches are zero)
+ */
+int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *stream);
+
+/*
  * Reverse-mode derivative of drm_fk's POSITIONS: what torch autograd computes in the reference when a loss on
  * compute_forward_kinematics' position is back-propagated to q and to learnable `trans` / `rot_angles`
  * (robot_model.py:139-195, 223-248, 669-713; examples/learn_kinematics_of_iiwa.py:25-61).  The quaternion has

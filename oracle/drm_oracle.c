@@ -48,6 +48,9 @@ int drm_oracle_fk_all_poses_f64(const drm_oracle_spec *s, const double *q, int64
 int drm_oracle_fk_jacobian_f64(const drm_oracle_spec *s, const double *q, int64_t B, int link, double *pos, double *quat, double *lj, double *aj) { return oracle_fk_jacobian_f64(s, q, B, link, pos, quat, lj, aj); }
 int drm_oracle_rnea_f64(const drm_oracle_spec *s, const double *q, const double *qd, const double *qdd, int64_t B, int g, int d, double *tau) { return oracle_rnea_f64(s, q, qd, qdd, B, g, d, tau); }
 
+int drm_oracle_mass_matrix_f32(const drm_oracle_spec *s, const float *q, int64_t B, int g, int d, float *H) { return oracle_mass_matrix_f32(s, q, B, g, d, H); }
+int drm_oracle_mass_matrix_f64(const drm_oracle_spec *s, const double *q, int64_t B, int g, int d, double *H) { return oracle_mass_matrix_f64(s, q, B, g, d, H); }
+
 int drm_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

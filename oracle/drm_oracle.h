@@ -36,6 +36,9 @@ int drm_oracle_fk_f64(const drm_oracle_spec *, const double *q, int64_t B, const
 int drm_oracle_fk_all_poses_f64(const drm_oracle_spec *, const double *q, int64_t B, double *Rw, double *pw);
 int drm_oracle_fk_jacobian_f64(const drm_oracle_spec *, const double *q, int64_t B, int link, double *pos, double *quat, double *lin_jac, double *ang_jac);
 int drm_oracle_rnea_f64(const drm_oracle_spec *, const double *q, const double *qd, const double *qdd, int64_t B, int include_gravity, int use_damping, double *tau);
+/* H [B, n, n] = compute_lagrangian_inertia_matrix (rm.py:402-450) */
+int drm_oracle_mass_matrix_f32(const drm_oracle_spec *, const float *q, int64_t B, int include_gravity, int use_damping, float *H);
+int drm_oracle_mass_matrix_f64(const drm_oracle_spec *, const double *q, int64_t B, int include_gravity, int use_damping, double *H);
 int drm_oracle_max_threads(void);
 void drm_oracle_set_threads(int n);
 #ifdef __cplusplus

@@ -408,6 +408,38 @@ static int FN(oracle_rnea)(const drm_oracle_spec *sp, const IO_T *q, const IO_T 
     return err;
 }
 
+/* rm.py:402-450 compute_lagrangian_inertia_matrix: column j = ID(q, 0, e_j) - ID(q, 0, 0) (n + 1 inverse-dynamics
+ * passes; the subtraction of the gravity / damping term is done in REAL like the reference does it in fp32) */
+static int FN(oracle_mass_matrix)(const drm_oracle_spec *sp, const IO_T *q, int64_t B, int include_gravity,
+                                  int use_damping, IO_T *H) {
+    const int L = sp->n_links, n = sp->n_dofs;
+    int err = 0;
+#pragma omp parallel
+    {
+        REAL *buf = (REAL *)malloc(sizeof(REAL) * (size_t)(45 * L + 5 * n + 8));
+        if (!buf) {
+#pragma omp atomic write
+            err = 1;
+        } else {
+            REAL *qq = buf + 45 * L, *zero = qq + n, *ej = zero + n, *t0 = ej + n, *tj = t0 + n;
+#pragma omp for schedule(static)
+            for (int64_t b = 0; b < B; ++b) {
+                for (int d = 0; d < n; ++d) { qq[d] = (REAL)q[b * n + d]; zero[d] = 0; ej[d] = 0; t0[d] = 0; }
+                if (include_gravity) FN(rnea_sample)(sp, qq, zero, zero, include_gravity, use_damping, t0, buf);
+                for (int j = 0; j < n; ++j) {
+                    ej[j] = 1;
+                    for (int d = 0; d < n; ++d) tj[d] = 0;
+                    FN(rnea_sample)(sp, qq, zero, ej, include_gravity, use_damping, tj, buf);
+                    ej[j] = 0;
+                    for (int i = 0; i < n; ++i) H[(b * n + i) * n + j] = (IO_T)(tj[i] - t0[i]);
+                }
+            }
+            free(buf);
+        }
+    }
+    return err;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

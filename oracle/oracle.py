@@ -117,3 +117,14 @@ class Oracle(object):
                 ctypes.c_int(int(bool(include_gravity))), ctypes.c_int(int(bool(use_damping))), _ptr(tau))
         assert rc == 0
         return tau
+
+    def mass_matrix(self, q, include_gravity=True, use_damping=True, dtype=np.float32):
+        """-> H [B,n,n]"""
+        q = self._io(q, dtype)
+        B = q.shape[0]
+        H = np.empty((B, self.n, self.n), dtype)
+        fn = getattr(_lib(), "drm_oracle_mass_matrix_" + ("f32" if dtype == np.float32 else "f64"))
+        rc = fn(ctypes.byref(self._spec), _ptr(q), ctypes.c_int64(B), ctypes.c_int(int(bool(include_gravity))),
+                ctypes.c_int(int(bool(use_damping))), _ptr(H))
+        assert rc == 0
+        return H

@@ -80,3 +80,7 @@ def max_err(a, b):
 
 def load_golden_grad():
     return np.load(os.path.join(GOLDEN_DIR, "golden_grad.npz"), allow_pickle=False)
+
+
+def load_golden_mass():
+    return np.load(os.path.join(GOLDEN_DIR, "golden_mass.npz"), allow_pickle=False)

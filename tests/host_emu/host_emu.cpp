@@ -154,6 +154,24 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
         }
 }
 
+template <int CAP>
+void crba_t(const drm_walk *w, const float *q, int64_t B, float *H) {
+    const int n = w->n_dofs;
+    for (int64_t b = 0; b < B; ++b) {
+        Inertia is[DRM_MAX_SLOTS];
+        for (auto &a : is) inertia_zero(a);
+        static thread_local Axis ss[DRM_MAX_SLOTS][CAP];
+        for (int i = 0; i < n * n; ++i) H[b * n * n + i] = 0.f;
+        auto qf = [&](int d) { return q[b * n + d]; };
+        auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
+        auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
+        auto ssave = [&](int s, int j, const Axis &a) { ss[s][j] = a; };
+        auto sload = [&](int s, int j, Axis &a) { a = ss[s][j]; };
+        auto hout = [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; };
+        crba_walk<CAP>(w->ops_f, w->ops_i, qf, iadd, itake, ssave, sload, hout);
+    }
+}
+
 } // namespace
 
 #define DISPATCH(FN, ...)                        \
@@ -184,6 +202,10 @@ int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos
 int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     rnea_arm_8_7(w, q, qd, qdd, B, flags, tau);
+    return 0;
+}
+int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
+    DISPATCH(crba_t, w, q, B, H)
     return 0;
 }
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,

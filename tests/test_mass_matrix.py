@@ -1,0 +1,98 @@
+"""Joint-space inertia matrix (K6, csrc/drm_crba.hip + drm_sample.hpp::crba_walk).
+
+CPU (not gpu): the oracle's restatement of the reference's n + 1 inverse-dynamics construction
+(robot_model.py:402-450) against matrices recorded from the UNMODIFIED reference (tests/golden/golden_mass.npz,
+made by tests/golden/make_golden_mass.py), and the kernel arithmetic (host emulation) against the fp64 oracle for
+every shipped robot.  GPU (-m gpu): the real kernel through the public API, same checks + properties at full size.
+
+Tolerances: the reference builds H by subtracting two fp32 inverse-dynamics results that both carry the gravity
+torques (tens of N m), so its own H is only symmetric to ~2e-5 (measured, make_golden_mass.py); against the
+reference we therefore hold atol 5e-5, against the fp64 oracle the usual tau tolerance (2e-5 abs / rel).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from differentiable_robot_model_amd.flatten import build_walk
+from helpers import ALL_ROBOTS, GOLDEN_ROBOTS, TOL_TAU, load_golden, load_golden_mass, load_model, sample_states
+from oracle import Oracle
+from test_host_emu import _ptr, emu, host_walk  # noqa: F401  (emu is a fixture)
+
+TOL_H_REF = dict(atol=5e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+def test_oracle_mass_matrix_vs_reference(robot, links):
+    g, gm = load_golden(robot), load_golden_mass()
+    m = load_model(robot)
+    q = g["fast_q"]
+    for tag, grav, damp in (("g1_d1", True, True), ("g0_d0", False, False)):
+        H32 = Oracle(m._spec).mass_matrix(q, grav, damp, np.float32)
+        H64 = Oracle(m._spec).mass_matrix(q.astype(np.float64), grav, damp, np.float64)
+        ref = gm["%s/H_%s" % (robot, tag)]
+        assert np.allclose(H32, ref, **TOL_H_REF), np.abs(H32 - ref).max()
+        assert np.allclose(H64, ref, **TOL_H_REF), np.abs(H64 - ref).max()
+    # the flags cancel out of the construction (what lets the kernel drop them)
+    a = Oracle(m._spec).mass_matrix(q.astype(np.float64), True, True, np.float64)
+    b = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
+    assert np.abs(a - b).max() < 1e-9
+
+
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+def test_emu_crba_vs_oracle(emu, robot):
+    m = load_model(robot)
+    n, B = m._n_dofs, 19
+    q, _, _ = sample_states(m, B, seed=41)
+    prog = build_walk(m._spec, whole_tree=True)
+    walk, keep = host_walk(m, prog)
+    H = np.full((B, n, n), np.nan, np.float32)
+    assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
+    assert np.allclose(H, ref, **TOL_TAU), (robot, np.abs(H - ref).max())
+    assert np.array_equal(H, H.transpose(0, 2, 1)), "CRBA fills both triangles with the same value"
+    assert np.linalg.eigvalsh(H.astype(np.float64)).min() > 0
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
+@pytest.mark.parametrize("B", [1, 64, 130])
+def test_gpu_crba_vs_oracle(robot, B):
+    m = load_model(robot, "cuda")
+    q, _, _ = sample_states(m, B, seed=50 + B)
+    H = m.compute_lagrangian_inertia_matrix(torch.from_numpy(q).cuda()).cpu().numpy()
+    ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
+    assert H.shape == (B, m._n_dofs, m._n_dofs)
+    assert np.allclose(H, ref, **TOL_TAU), (robot, np.abs(H - ref).max())
+    assert np.array_equal(H, H.transpose(0, 2, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+def test_gpu_crba_vs_reference_golden(robot, links):
+    g, gm = load_golden(robot), load_golden_mass()
+    m = load_model(robot, "cuda")
+    q = torch.from_numpy(g["fast_q"]).cuda()
+    for tag, grav, damp in (("g1_d1", True, True), ("g0_d0", False, False)):
+        H = m.compute_lagrangian_inertia_matrix(q, include_gravity=grav, use_damping=damp).cpu().numpy()
+        assert np.allclose(H, gm["%s/H_%s" % (robot, tag)], **TOL_H_REF)
+    H1 = m.compute_lagrangian_inertia_matrix(q[0])          # unbatched call (tensor_check strips the batch dim)
+    assert tuple(H1.shape) == (m._n_dofs, m._n_dofs)
+
+
+@pytest.mark.gpu
+def test_gpu_crba_full_size_consistent_with_rnea():
+    """H qdd = ID(q, 0, qdd) - ID(q, 0, 0): ties the CRBA kernel to the RNEA kernel at batch 65 536."""
+    m = load_model("panda_no_gripper", "cuda")
+    B = 65536
+    q, _, qdd = sample_states(m, B, seed=7)
+    qt, at = torch.from_numpy(q).cuda(), torch.from_numpy(qdd).cuda()
+    H = m.compute_lagrangian_inertia_matrix(qt)
+    zero = torch.zeros_like(qt)
+    lhs = torch.einsum("bij,bj->bi", H, at)
+    rhs = m.compute_inverse_dynamics(qt, zero, at, include_gravity=False, use_damping=False)
+    assert (lhs - rhs).abs().max().item() < 5e-5
+    assert torch.equal(H, H.transpose(1, 2))
+    assert torch.linalg.eigvalsh(H[:4096].double()).min().item() > 0

@@ -41,6 +41,12 @@ for B in sizes:
     us = graph_time(rnea)
     print("rnea        panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s  %5.1f TFLOP/s (2.6 kflop/eval)" %
           (B, us, B * 112 / us / 1e3, B / us / 1e3, B * 2.6e3 / us / 1e6))
+    Hm = torch.empty(B, 7, 7, device="cuda")
+    def crba():
+        backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(crba)
+    print("crba        panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
     idx = m._name_to_idx_map[link]
     df = m._get_walk(("fk", (idx,)), targets=[idx]); off = m._ops_f(df)
     pos = torch.empty(B, 1, 3, device="cuda"); quat = torch.empty(B, 1, 4, device="cuda")
