@@ -197,7 +197,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_eval * B,
-                         "kernel": "drm::fk_jacobian_kernel<8, 7>", "bytes_per_eval": bytes_per_eval,
+                         "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true>", "bytes_per_eval": bytes_per_eval,
                          "launch_us": launch_s * 1e6,
                          "note": "algorithmic bytes / average launch duration (HIP events over the timed region, "
                                  "includes inter-launch gaps); a 65 536-sample launch is one wave per SIMD and "

@@ -144,22 +144,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                   J_FLOATS = round4(WAVE * SJ);
     // pos is staged over the q tile (q lives in registers by then): 51.7 KB per block, three blocks per CU
     static_assert(P_FLOATS <= Q_FLOATS, "pos staging overlays the q tile");
-#ifdef DRM_ARM_ONE_J_REGION /* development A/B: lin and ang staged one after the other through one region */
-    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? J_FLOATS : 0);
-#else
     constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? 2 * J_FLOATS : 0);
-#endif
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
-#ifdef DRM_ARM_ONE_J_REGION
-    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll;
-#else
     float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
-#endif
     const int64_t b0 = (int64_t)tile * WAVE;
 
     // the walk's constant rows (1 KB) -> LDS: one 16-byte load per lane, in flight together with the q tile
@@ -174,24 +166,27 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
     PoseP ee;
     f2 Bk[NJ][3];
-    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk);
+    // The outputs leave in the order they become available, so that the store drain (12.8 MB per launch, the
+    // longest single item of a one-wave-per-SIMD launch) starts as early as possible: ang_jac needs only the joint
+    // axes and goes out while the fixed tail of the chain is still being composed; lin_jac and pos need the end
+    // position; the quaternion takes the most arithmetic and goes last.
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+        if constexpr (JAC) {
+            float *arow = la + lane * SJ;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) { // robot_model.py:662
+                arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0];
+            }
+            wave_lds_sync();
+#ifndef DRM_DEV_NO_JAC_STORE
+            tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+#endif
+        }
+    });
 
-    // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
-    // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
-    {
-        Pose E;
-        float qt[4];
-        pose_from_pairs(ee, E);
-        quat_xyzw(E.R, qt);
-        *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
-    }
     const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
-    wave_lds_sync(); // every lane has read its q row (program order; the LDS executes a wave's accesses in order)
-    lp[lane * 3 + 0] = pe[0];
-    lp[lane * 3 + 1] = pe[1];
-    lp[lane * 3 + 2] = pe[2];
     if constexpr (JAC) {
-        float *lrow = ll + lane * SJ, *arow = la + lane * SJ;
+        float *lrow = ll + lane * SJ;
 #pragma unroll
         for (int k = 0; k < NJ; ++k) {
             const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
@@ -201,23 +196,31 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
             asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
             lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
-#ifndef DRM_ARM_ONE_J_REGION
-            arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2]; // robot_model.py:662
-#endif
         }
+        lp[lane * 3 + 0] = pe[0];
+        lp[lane * 3 + 1] = pe[1];
+        lp[lane * 3 + 2] = pe[2];
         wave_lds_sync();
-        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+#ifndef DRM_DEV_NO_JAC_STORE
         tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
-#ifdef DRM_ARM_ONE_J_REGION
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < NJ; ++k) { arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0]; }
-        wave_lds_sync();
 #endif
-        tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
     } else {
+        wave_lds_sync(); // every lane has read its q row before pos is staged over the q tile
+        lp[lane * 3 + 0] = pe[0];
+        lp[lane * 3 + 1] = pe[1];
+        lp[lane * 3 + 2] = pe[2];
         wave_lds_sync();
         tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+    }
+    // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
+    // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
+    {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
     }
 }
 

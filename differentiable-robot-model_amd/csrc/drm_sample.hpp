@@ -415,9 +415,11 @@ constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f; // keep in sync with joint_trig
 // remaining CAP - NJ links are fixed joints or identity padding (DRM_WALK_ARM_CHAIN).
 //   ft(k)  -> pointer to the FT block of op k (12 floats)
 //   q[d]   -> joint angles of this sample
+//   joints_done()  -> called once, right after the last MOVING joint: every B[k] is final from here on
+//                     (the kernel starts storing the angular Jacobian while the fixed tail is still computed)
 // Out: B[k][c] = (z_c, p_c) of every moving joint k, and the end pose.
-template <int CAP, int NJ, class FT>
-DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3]) {
+template <int CAP, int NJ, class FT, class DONE>
+DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3], DONE joints_done) {
     float cs[NJ], sn[NJ];
     bool big = false;
 #pragma unroll
@@ -450,6 +452,7 @@ DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3
 #pragma unroll
             for (int c = 0; c < 3; ++c) B[k][c] = ee.B[c];
         }
+        if (k == NJ - 1) joints_done();
     }
 }
 

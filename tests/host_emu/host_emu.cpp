@@ -67,7 +67,7 @@ void jac_arm_8_7(const drm_walk *w, const float *q, int64_t B, float *pos, float
         for (int d = 0; d < NJ; ++d) qv[d] = q[b * NJ + d];
         PoseP ee;
         f2 Bk[NJ][3];
-        fk_chain_pairs<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, qv, ee, Bk);
+        fk_chain_pairs<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [] {});
         Pose E;
         pose_from_pairs(ee, E);
         for (int i = 0; i < 3; ++i) pos[b * 3 + i] = E.p[i];

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof_*) into profiles/rNN_*.
+
+  rNN_bench_kernel_stats.csv   the --kernel-trace --stats table of the default bench run
+  rNN_pmc_traffic.json         HBM bytes per launch of the metric kernel: FETCH_SIZE (x2: gfx950 tallies 128-B read
+                               requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB
+  rNN_sq_counters.md           per-wave instruction counts / cycle split of the hot kernels
+usage: python tools/pmc_summary.py r01
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+prof = os.path.join(ROOT, "profiles")
+
+
+def rows(pattern):
+    for path in glob.glob(os.path.join(OUT, pattern)):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                yield r
+
+
+stats = glob.glob(os.path.join(OUT, "prof_stats", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(prof, tag + "_bench_kernel_stats.csv"))
+
+traffic = {"kernel": None, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
+                                      "python bench.py --no-cpu-baseline --steps 50 --warmup 5 [--batch B]",
+           "per_batch": {}}
+for batch in (65536, 4194304):
+    rec = {}
+    for name, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        vals = []
+        for r in rows("prof_%s_%d/*/*_counter_collection.csv" % (name, batch)):
+            if r["Counter_Name"] == key and "fk_jacobian" in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+                traffic["kernel"] = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if vals:
+            rec[key + "_KiB_mean"] = sum(vals) / len(vals)
+            rec[key + "_launches"] = len(vals)
+    if len(rec) == 4:
+        alg = 224 * batch
+        fetch = rec["FETCH_SIZE_KiB_mean"] * 1024 * 2   # gfx950 correction
+        write = rec["WRITE_SIZE_KiB_mean"] * 1024
+        rec.update(fetch_bytes_corrected=fetch, write_bytes=write, traffic_bytes_per_launch=fetch + write,
+                   algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(fetch + write) / alg)
+        traffic["per_batch"][str(batch)] = rec
+with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+
+acc = defaultdict(lambda: defaultdict(list))
+for r in rows("prof_sq/*/*_counter_collection.csv"):
+    k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
+    acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
+lines = ["# SQ counters, %s (rocprofv3 --pmc, MI355X; per wave = counter / SQ_WAVES; cycle counters are quad-cycles)" % tag, "",
+         "| kernel | grid threads | waves | VALU | SALU | SMEM | LDS | WAVE_CYCLES | WAIT_ANY | ACTIVE_INST_ANY |",
+         "|---|---|---|---|---|---|---|---|---|---|"]
+for (k, grid), c in sorted(acc.items()):
+    if "SQ_WAVES" not in c:
+        continue
+    waves = sum(c["SQ_WAVES"]) / len(c["SQ_WAVES"])
+    per = [sum(c[x]) / len(c[x]) / waves if x in c else float("nan") for x in cols]
+    lines.append("| %s | %d | %d | %s |" % (k, grid, waves, " | ".join("%.0f" % v for v in per)))
+with open(os.path.join(prof, tag + "_sq_counters.md"), "w") as f:
+    f.write("\n".join(lines) + "\n")
+print(open(os.path.join(prof, tag + "_sq_counters.md")).read())
+print(json.dumps(traffic["per_batch"], indent=1)[:1200])
