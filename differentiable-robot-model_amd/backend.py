@@ -38,7 +38,8 @@ _lib = None
 _lock = threading.Lock()
 
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
-           "drm_fk_backward_scratch_floats", "drm_crba")
+           "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
+           "drm_rnea_backward_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -72,6 +73,10 @@ def load_library(path: str = None):
         lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp]
         lib.drm_fk_backward_scratch_floats.restype = i64
         lib.drm_fk_backward_scratch_floats.argtypes = [i64, i32]
+        lib.drm_rnea_backward.restype = ctypes.c_int
+        lib.drm_rnea_backward.argtypes = [wp, vp, vp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
+        lib.drm_rnea_backward_scratch_floats.restype = i64
+        lib.drm_rnea_backward_scratch_floats.argtypes = [i64, i32, i32, i32]
         lib.drm_crba.restype = ctypes.c_int
         lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
@@ -159,6 +164,34 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
                             _stream(q.device)))
     return tau
+
+
+def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include_gravity: bool, use_damping: bool,
+                  n_dofs: int, param_mask: int, want_grad_inputs: bool):
+    """((grad_q, grad_qd, grad_qdd) or None, grad_ops_f [cap,32] or None) for a loss gradient on the torques."""
+    lib = load_library()
+    if not prog.slots_unique:
+        raise RuntimeError("backward RNEA needs a walk whose branch points own their save slots")
+    q = _dev_f32(q, "q", n_dofs)
+    qd = _dev_f32(qd, "qd", n_dofs)
+    qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+    grad_tau = _dev_f32(grad_tau, "grad_tau", n_dofs)
+    B, dev = q.shape[0], q.device
+    gin = tuple(torch.empty(B, n_dofs, device=dev, dtype=torch.float32) for _ in range(3)) if want_grad_inputs else None
+    grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
+    if gin is None and grad_ops is None:
+        return None, None
+    scratch = torch.empty(max(1, lib.drm_rnea_backward_scratch_floats(B, prog.capacity, n_dofs, prog.n_slots)),
+                          device=dev, dtype=torch.float32)
+    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with torch.cuda.device(dev):
+        _check(lib.drm_rnea_backward(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), ptr(qdd), B, flags,
+                                     grad_tau.data_ptr(), ctypes.c_uint32(param_mask),
+                                     ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
+                                     ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)))
+    return gin, grad_ops
 
 
 def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):

@@ -144,6 +144,23 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int 
     }
 }
 
+// Sum over the 64 lanes of a wave, result valid in lane 63: DPP row shifts, then row broadcasts (fixed order).
+// Lanes that are shifted in from outside a row or masked off receive `old` = 0, i.e. they add nothing.
+#define DRM_DPP_ADD(v, ctrl, row_mask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    DRM_DPP_ADD(v, 0x111, 0xf); // row_shr:1
+    DRM_DPP_ADD(v, 0x112, 0xf); // row_shr:2
+    DRM_DPP_ADD(v, 0x114, 0xf); // row_shr:4
+    DRM_DPP_ADD(v, 0x118, 0xf); // row_shr:8   -> lane 15 of every row holds the row's sum
+    DRM_DPP_ADD(v, 0x142, 0xa); // row_bcast:15 into rows 1 and 3
+    DRM_DPP_ADD(v, 0x143, 0xc); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+#undef DRM_DPP_ADD
+
+constexpr int BWD_MAX_WAVES = 2048; // 256 CUs x 4 SIMDs x 2: waves of a backward launch = rows of its partial sums
+
 struct WaveCtx {
     unsigned lane;
     int rows;    // valid samples of this tile (wave-uniform)
@@ -183,6 +200,14 @@ struct Geometry {
 
 // waves per block: as many as fit a 64 KiB LDS budget (<= 4); one wave per 64 samples.
 int make_geometry(int64_t B, int lds_floats_per_wave, Geometry &g);
+
+// waves of a backward launch (each strides over tiles and writes one row of partial sums), a multiple of wpb
+static inline int backward_waves(int64_t B, int wpb) {
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    int64_t waves = tiles < BWD_MAX_WAVES ? tiles : BWD_MAX_WAVES;
+    waves = (waves + wpb - 1) / wpb * wpb;
+    return (int)(waves < 1 ? wpb : waves);
+}
 
 // drm_fk_jacobian.hip: single-target FK of an arm-shaped walk through the packed chain kernel
 int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);

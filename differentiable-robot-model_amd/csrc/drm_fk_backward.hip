@@ -21,22 +21,6 @@
 namespace drm {
 
 constexpr int BWD_FIELDS = 12;          // dF (9) + dt (3) per op
-constexpr int BWD_MAX_WAVES = 2048;     // 256 CUs x 4 SIMDs x 2: rows of `partials`
-
-// Sum over the 64 lanes of a wave, result valid in lane 63: DPP row shifts, then row broadcasts (fixed order).
-// Lanes that are shifted in from outside a row or masked off receive `old` = 0, i.e. they add nothing.
-#define DRM_DPP_ADD(v, ctrl, row_mask) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    DRM_DPP_ADD(v, 0x111, 0xf); // row_shr:1
-    DRM_DPP_ADD(v, 0x112, 0xf); // row_shr:2
-    DRM_DPP_ADD(v, 0x114, 0xf); // row_shr:4
-    DRM_DPP_ADD(v, 0x118, 0xf); // row_shr:8   -> lane 15 of every row holds the row's sum
-    DRM_DPP_ADD(v, 0x142, 0xa); // row_bcast:15 into rows 1 and 3
-    DRM_DPP_ADD(v, 0x143, 0xc); // row_bcast:31 into rows 2 and 3
-    return v;
-}
-#undef DRM_DPP_ADD
 
 template <int CAP>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
@@ -160,13 +144,6 @@ __global__ void __launch_bounds__(WAVE)
         const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
         if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + at] = s;
     }
-}
-
-static int backward_waves(int64_t B, int wpb) {
-    const int64_t tiles = (B + WAVE - 1) / WAVE;
-    int64_t waves = tiles < BWD_MAX_WAVES ? tiles : BWD_MAX_WAVES;
-    waves = (waves + wpb - 1) / wpb * wpb;
-    return (int)(waves < 1 ? wpb : waves);
 }
 
 } // namespace drm

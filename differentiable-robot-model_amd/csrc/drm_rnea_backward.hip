@@ -1,0 +1,228 @@
+// drm_rnea_backward.hip — K7: reverse-mode derivative of the RNEA inverse dynamics with respect to the per-link
+// constants (R_fixed, trans, mass, mass * com, I_o, damping) and to q, qd, qdd.
+//
+// Replaces what torch autograd does for the reference when a loss on compute_inverse_dynamics' torques is
+// back-propagated (robot_model.py:305-375 with learnable link parameters robot_model.py:669-713;
+// examples/learn_dynamics_iiwa.py:49-96): there one backward node per tiny torch op of ~11 k ops per call, here four
+// sweeps per sample over the walk (drm_sample.hpp rnea_backward_walk) that recompute the forward pass, plus the
+// same deterministic batch reduction of the constant gradients as drm_fk_backward.
+//
+// Per sample: in q, qd, qdd, grad_tau [n]; out grad_q, grad_qd, grad_qdd [n] (optional).      n = 7: 112 + 84 B
+// Per launch: out grad_ops_f[cap, 32] (every constant of the ops selected by param_mask, zeros elsewhere).
+// Per-link records (24 floats: motion, total force, its adjoint) are parked between the sweeps in LDS, or, when a
+// big walk does not fit, in a slice of the caller's scratch buffer in HBM (PARK_HBM).
+// LDS per wave: [ q qd qdd grad_tau : 4 x 64 (n|1) ][ grad_q grad_qd grad_qdd : 3 x 64 (n|1) ][ slots : n_slots*36*64 ]
+//               [ records : cap*24*64 unless PARK_HBM ]
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+constexpr int REC_FLOATS = 24, SLOT_FLOATS = 36;
+
+template <int CAP, bool PARK_HBM>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int flags,
+                         const float *__restrict__ q, const float *__restrict__ qd, const float *__restrict__ qdd,
+                         const float *__restrict__ gtau, int64_t B, float *__restrict__ gq, float *__restrict__ gqd,
+                         float *__restrict__ gqdd, uint32_t param_mask, float *__restrict__ partials,
+                         float *__restrict__ park_hbm, uint32_t magic_q, int lds_per_wave, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NV = CAP * DRM_OPF_STRIDE, NACC = NV / WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t wave_id = (int64_t)blockIdx.x * wpb + wave_in_block;
+    const int64_t n_waves = (int64_t)gridDim.x * wpb;
+    const int64_t n_tiles = (B + WAVE - 1) / WAVE;
+
+    const int Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem + wave_in_block * lds_per_wave;
+    float *lqd = lq + region, *lqdd = lqd + region, *lgt = lqdd + region;
+    float *lgq = lgt + region, *lgqd = lgq + region, *lgqdd = lgqd + region;
+    float *lsl = lgqdd + region;                                   // slots   [slot][36][64]
+    float *lrec = lsl + n_slots * (SLOT_FLOATS * WAVE);            // records [op][24][64]
+    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)(CAP * REC_FLOATS * WAVE) : lrec) + lane;
+    float *slot = lsl + lane;
+
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t b0 = tile * WAVE;
+        const int64_t left = B - b0;
+        const int rows = left < WAVE ? (int)left : WAVE;
+        const bool full = rows == WAVE, fast = full && (n & 1);
+        const bool live = (int)lane < rows;
+        wave_lds_sync(); // the previous tile's LDS reads are done before this tile overwrites
+        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q));
+        tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
+        if (qdd) tile_load<0>(qdd + b0 * n, rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD));
+        tile_load<0>(gtau + b0 * n, rows, n, magic_q, lgt, lane, fast && (align & AL_TAU));
+        for (int s = 0; s < n_slots * SLOT_FLOATS; ++s) slot[s * WAVE] = 0.0f;
+        wave_lds_sync();
+
+        const unsigned row = lane * Sq;
+        const bool has_qdd = qdd != nullptr;
+        if (gq)
+            for (int d = 0; d < n; ++d) { lgq[row + d] = 0.0f; lgqd[row + d] = 0.0f; lgqdd[row + d] = 0.0f; }
+        auto qf = [&](int d, float &a, float &v, float &c) {
+            a = lq[row + d];
+            v = lqd[row + d];
+            c = has_qdd ? lqdd[row + d] : 0.0f;
+        };
+        auto gt = [&](int d) -> float { return live ? lgt[row + d] : 0.0f; };
+        auto park = [&](int k, int off, const float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) rec[(k * REC_FLOATS + off + i) * WAVE] = v[i];
+        };
+        auto unpark = [&](int k, int off, float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) v[i] = rec[(k * REC_FLOATS + off + i) * WAVE];
+        };
+        auto slot_put = [&](int s, int off, const float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) slot[(s * SLOT_FLOATS + off + i) * WAVE] = v[i];
+        };
+        auto slot_get = [&](int s, int off, float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) v[i] = slot[(s * SLOT_FLOATS + off + i) * WAVE];
+        };
+        auto slot_add = [&](int s, int off, const float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) slot[(s * SLOT_FLOATS + off + i) * WAVE] += v[i];
+        };
+        auto slot_take = [&](int s, int off, float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) {
+                    v[i] = slot[(s * SLOT_FLOATS + off + i) * WAVE];
+                    slot[(s * SLOT_FLOATS + off + i) * WAVE] = 0.0f;
+                }
+        };
+        auto gout = [&](int d, float a, float v, float c) { lgq[row + d] = a; lgqd[row + d] = v; lgqdd[row + d] = c; };
+        float add[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
+        auto param_out = [&](int k, const float *g) {
+#pragma unroll
+            for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) { // the last constant of a row is the damping
+                const float mine = live ? g[j] : 0.0f; // lanes past a partial tile hold garbage
+                const float total = wave_sum_lane63(mine);
+                const int idx = k * DRM_OPF_STRIDE + j;
+                const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
+                if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s;
+            }
+        };
+        rnea_backward_walk<CAP>(ops_f, ops_i, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
+                                slot_add, slot_take, gout, param_out);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += add[a];
+        if (gq) {
+            wave_lds_sync();
+            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, fast && (align & AL_POS));
+            tile_store<0>(gqd + b0 * n, rows, n, magic_q, lgqd, lane, fast && (align & AL_QUAT));
+            tile_store<0>(gqdd + b0 * n, rows, n, magic_q, lgqdd, lane, fast && (align & AL_LIN));
+        }
+    }
+    float *prow = partials + wave_id * NV;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
+}
+
+// grad_ops_f[k, j] = sum over the partial rows in a fixed order (lane l adds rows l, l+64, ..., then the wave adds lanes)
+__global__ void __launch_bounds__(WAVE)
+    rnea_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f) {
+    const int k = blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    const int NV = cap * DRM_OPF_STRIDE;
+    for (int j = 0; j < DRM_OPF_STRIDE; ++j) {
+        float s = 0.0f;
+        for (int r = (int)lane; r < n_rows; r += WAVE) s += partials[(int64_t)r * NV + k * DRM_OPF_STRIDE + j];
+        s = wave_sum_lane63(s);
+        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + j] = s;
+    }
+}
+
+static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, bool park_hbm) {
+    return (size_t)7 * round4(WAVE * pad_odd(n)) + (size_t)n_slots * SLOT_FLOATS * WAVE +
+           (park_hbm ? 0 : (size_t)cap * REC_FLOATS * WAVE);
+}
+
+} // namespace drm
+
+using namespace drm;
+
+extern "C" int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity, int32_t n_dofs, int32_t n_slots) {
+    if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS || n_dofs < 1 || n_dofs > DRM_MAX_DOFS) return 0;
+    const int64_t waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
+    int64_t floats = waves * capacity * DRM_OPF_STRIDE; // partial sums
+    if (rnea_backward_lds_floats(n_dofs, n_slots, capacity, false) * sizeof(float) > (size_t)MAX_LDS_BYTES)
+        floats += waves * (int64_t)capacity * REC_FLOATS * WAVE; // per-link records parked in HBM
+    return floats;
+}
+
+extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B,
+                                 int32_t flags, const float *grad_tau, uint32_t param_mask, float *grad_q, float *grad_qd,
+                                 float *grad_qdd, float *grad_ops_f, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !qd || !grad_tau) return fail(DRM_ERR_INVALID, "q / qd / grad_tau must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    if ((param_mask != 0) != (grad_ops_f != nullptr))
+        return fail(DRM_ERR_INVALID, "grad_ops_f must be given exactly when param_mask selects ops");
+    const bool want_q = grad_q != nullptr;
+    if (want_q != (grad_qd != nullptr) || want_q != (grad_qdd != nullptr))
+        return fail(DRM_ERR_INVALID, "grad_q, grad_qd and grad_qdd are produced together: give all three or none");
+    if (!want_q && !grad_ops_f) return fail(DRM_ERR_INVALID, "nothing to compute");
+    if (!scratch) return fail(DRM_ERR_INVALID, "scratch must not be NULL (drm_rnea_backward_scratch_floats)");
+    if (w->capacity < 32 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
+    const int n = w->n_dofs, cap = w->capacity;
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        if (grad_ops_f) {
+            hipError_t e = hipMemsetAsync(grad_ops_f, 0, sizeof(float) * cap * DRM_OPF_STRIDE, s);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return DRM_OK;
+    }
+    const bool park_hbm = rnea_backward_lds_floats(n, w->n_slots, cap, false) * sizeof(float) > (size_t)MAX_LDS_BYTES;
+    Geometry g;
+    rc = make_geometry(B, (int)rnea_backward_lds_floats(n, w->n_slots, cap, park_hbm), g);
+    if (rc) return rc;
+    const int wpb = (int)(g.block.x / WAVE);
+    const int waves = backward_waves(B, wpb);
+    g.grid = dim3((unsigned)(waves / wpb));
+    float *partials = scratch;
+    float *park = scratch + (int64_t)backward_waves(B, MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE;
+    const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU) |
+                           al16(grad_q, AL_POS) | al16(grad_qd, AL_QUAT) | al16(grad_qdd, AL_LIN);
+#define DRM_LAUNCH_RB(C, HBM)                                                                                          \
+    {                                                                                                                  \
+        rc = ensure_lds(rnea_backward_kernel<C, HBM>, g.lds_bytes);                                                    \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((rnea_backward_kernel<C, HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,     \
+                           (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd, grad_qdd, param_mask, \
+                           partials, park, div_magic(n), g.lds_per_wave, align);                                       \
+    }
+    if (park_hbm) {
+        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_RB(C, true))
+    } else {
+        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_RB(C, false))
+    }
+#undef DRM_LAUNCH_RB
+    rc = launched();
+    if (rc) return rc;
+    if (grad_ops_f) {
+        hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, partials, waves, cap,
+                           grad_ops_f);
+        rc = launched();
+    }
+    return rc;
+}

@@ -848,6 +848,318 @@ DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ]
 }
 
 // ---------------------------------------------------------------------------
+// Reverse-mode derivative of the RNEA walk: what torch autograd computes for the reference when a loss on
+// compute_inverse_dynamics' torques is back-propagated to the learnable link parameters (robot_model.py:305-375
+// with robot_model.py:669-713; examples/learn_dynamics_iiwa.py:49-96) and to q / qd / qdd.
+//
+// Four sweeps per sample over the same walk (per-link state is parked by the caller, LDS in the kernel):
+//   A  k up    motion (w, al, v, a) of every link and its body force                      [= rnea_walk forward]
+//   B  k down  total force tot_k = f_k + sum of the children's forces moved up             [= rnea_walk backward]
+//   C  k up    adjoint of B:  tbar_k = J^T-transformed tbar_parent + gtau_k e_(ang z)
+//   D  k down  adjoint of A:  motion adjoints from the body force and the children, then the adjoints of the
+//              joint transform (J, t) from both sweeps, of the constants (m, mc, Io, damping) and of q, qd, qdd
+// Layout of a parked link record (floats): 0..11 motion (w, v, al, a), 12..17 tot (lin, ang), 18..23 tbar;
+// of a slot record: the same 24 plus 24..35 the motion-adjoint accumulator.
+//   park(k, off, v, n) / unpark(k, off, v, n)                       per-link records
+//   slot_put / slot_get / slot_add / slot_take(s, off, v, n)        branch-point records (take = read and zero)
+//   gtau(d) -> dL/dtau of DoF d;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
+// ---------------------------------------------------------------------------
+DRM_HD void motion_to_floats(const Motion &M, float *v) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { v[i] = M.wa[i][0]; v[3 + i] = M.va[i][0]; v[6 + i] = M.wa[i][1]; v[9 + i] = M.va[i][1]; }
+}
+DRM_HD void motion_from_floats(const float *v, Motion &M) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { M.wa[i] = f2_make(v[i], v[6 + i]); M.va[i] = f2_make(v[3 + i], v[9 + i]); }
+}
+DRM_HD void add_cross(float *acc, const float *a, const float *b) { // acc += a x b
+    acc[0] += a[1] * b[2] - a[2] * b[1];
+    acc[1] += a[2] * b[0] - a[0] * b[2];
+    acc[2] += a[0] * b[1] - a[1] * b[0];
+}
+DRM_HD void sub_cross(float *acc, const float *a, const float *b) { // acc -= a x b
+    acc[0] -= a[1] * b[2] - a[2] * b[1];
+    acc[1] -= a[2] * b[0] - a[0] * b[2];
+    acc[2] -= a[0] * b[1] - a[1] * b[0];
+}
+
+template <int CAP, class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT,
+          class PG>
+DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int flags,
+                               uint32_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
+                               SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    const bool damping = flags & DRM_RNEA_DAMPING;
+    int dof[CAP];
+    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+    float cs[CAP], sn[CAP];
+    joint_trig<CAP>(dof, [&](int d) { float q, v, a; qf(d, q, v, a); return q; }, cs, sn);
+    auto joint = [&](int k, float *J, float *t) {
+        const OpFT o = load_ft(opf + k * DRM_OPF_STRIDE);
+        joint_rot_z(o.F, cs[k], sn[k], J);
+        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+    };
+
+    // ---- A: motions and body forces ------------------------------------------------------------------
+    {
+        Motion cur;
+        motion_root(cur, g);
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const float *of = opf + k * DRM_OPF_STRIDE;
+            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+            float wj = 0.0f, aj = 0.0f, J[9], t[3], rec[12];
+            if (dof[k] >= 0) { float q; qf(dof[k], q, wj, aj); }
+            joint(k, J, t);
+            if (src == DRM_SRC_ROOT) motion_root(cur, g);
+            if (src >= 0) { slot_get(src, 0, rec, 12); motion_from_floats(rec, cur); }
+            rnea_link_motion(J, t, wj, aj, cur, cur);
+            motion_to_floats(cur, rec);
+            if (save >= 0) slot_put(save, 0, rec, 12);
+            park(k, 0, rec, 12);
+            Force f;
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
+            const float fr[6] = {f.la[0][0], f.la[1][0], f.la[2][0], f.la[0][1], f.la[1][1], f.la[2][1]};
+            park(k, 12, fr, 6);
+        }
+    }
+    // ---- B: total forces ---------------------------------------------------------------------------------
+    {
+        float carry[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = CAP - 1; k >= 0; --k) {
+            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+            float tot[6], x[6];
+            unpark(k, 12, tot, 6);
+            if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tot[i] += carry[i];
+            }
+            if (save >= 0) {
+                slot_take(save, 12, x, 6);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tot[i] += x[i];
+            }
+            park(k, 12, tot, 6);
+            if (src != DRM_SRC_ROOT) {
+                float J[9], t[3], up[6];
+                joint(k, J, t);
+                mat_vec(J, tot, up);
+                mat_vec(J, tot + 3, up + 3);
+                add_cross(up + 3, t, up);
+                if (src >= 0) slot_add(src, 12, up, 6);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) carry[i] = up[i];
+                }
+            }
+        }
+    }
+    // ---- C: adjoint of B ---------------------------------------------------------------------------------
+    {
+        float prev[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+            float tb[6] = {0, 0, 0, 0, 0, 0};
+            if (src != DRM_SRC_ROOT) {
+                float ub[6], J[9], t[3], Lb[3];
+                if (src >= 0) slot_get(src, 18, ub, 6);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) ub[i] = prev[i];
+                }
+                joint(k, J, t);
+                Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
+                add_cross(Lb, ub + 3, t); // Lbar' = ubar.lin + ubar.ang x t
+                matT_vec(J, Lb, tb);
+                matT_vec(J, ub + 3, tb + 3);
+            }
+            if (dof[k] >= 0) tb[5] += gtau(dof[k]);
+            park(k, 18, tb, 6);
+            if (save >= 0) slot_put(save, 18, tb, 6);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) prev[i] = tb[i];
+        }
+    }
+    // ---- D: adjoint of A, parameter and input gradients ---------------------------------------------
+    {
+        float carry[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) carry[i] = 0.0f;
+#pragma unroll
+        for (int k = CAP - 1; k >= 0; --k) {
+            const float *of = opf + k * DRM_OPF_STRIDE;
+            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+            // motion adjoint arriving from the children: (wb, vb, alb, ab)
+            float mb[12], x12[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) mb[i] = (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) ? carry[i] : 0.0f;
+            if (save >= 0) {
+                slot_take(save, 24, x12, 12);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) mb[i] += x12[i];
+            }
+            float *wb = mb, *vb = mb + 3, *alb = mb + 6, *ab = mb + 9;
+            float mo[12], fb[6];
+            unpark(k, 0, mo, 12);
+            unpark(k, 18, fb, 6);
+            const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
+            const float *fl = fb, *fa = fb + 3; // adjoint of this link's body force = tbar_k
+            const float m = of[DRM_OPF_MASS];
+            const float *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
+            // body force: hl = m v - mc x w, ha = Io w + mc x v, gl = m a - mc x al, ga = Io al + mc x a,
+            //             f.lin = gl + w x hl,  f.ang = ga + w x ha + v x hl
+            float hl[3], ha[3], x[3];
+            cross3(mc, w, x);
+            hl[0] = m * v[0] - x[0]; hl[1] = m * v[1] - x[1]; hl[2] = m * v[2] - x[2];
+            mat_vec(Io, w, ha);
+            add_cross(ha, mc, v);
+            float hlb[3] = {0, 0, 0}, hab[3] = {0, 0, 0};
+            add_cross(hlb, fl, w); add_cross(hlb, fa, v);
+            add_cross(hab, fa, w);
+            add_cross(wb, hl, fl); add_cross(wb, ha, fa);
+            add_cross(vb, hl, fa);
+            float gm = 0.0f, gmc[3] = {0, 0, 0}, gIo[9];
+            // hl
+            gm += hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2];
+            vb[0] += m * hlb[0]; vb[1] += m * hlb[1]; vb[2] += m * hlb[2];
+            sub_cross(gmc, w, hlb);
+            sub_cross(wb, hlb, mc);
+            // ha
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gIo[r * 3 + c] = hab[r] * w[c] + fa[r] * al[c];
+            matT_vec(Io, hab, x);
+            wb[0] += x[0]; wb[1] += x[1]; wb[2] += x[2];
+            add_cross(gmc, v, hab);
+            add_cross(vb, hab, mc);
+            // gl (adjoint fl)
+            gm += fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
+            ab[0] += m * fl[0]; ab[1] += m * fl[1]; ab[2] += m * fl[2];
+            sub_cross(gmc, al, fl);
+            sub_cross(alb, fl, mc);
+            // ga (adjoint fa)
+            matT_vec(Io, fa, x);
+            alb[0] += x[0]; alb[1] += x[1]; alb[2] += x[2];
+            add_cross(gmc, a, fa);
+            add_cross(ab, fa, mc);
+
+            // link motion from the parent's: adjoint
+            float J[9], t[3], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
+            joint(k, J, t);
+            if (dof[k] >= 0) { float q; qf(dof[k], q, wj, aj); qdk = wj; }
+            float par[12];
+            if (src == DRM_SRC_ROOT) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) par[i] = 0.0f;
+                par[11] = g;
+            } else if (src >= 0) {
+                slot_get(src, 0, par, 12);
+            } else {
+                unpark(k > 0 ? k - 1 : 0, 0, par, 12);
+            }
+            const float *Pw = par, *Pv = par + 3, *Pal = par + 6, *Pa = par + 9;
+            float pb[12], Jb[9], tbr[3] = {0, 0, 0}, wjb = 0.0f, ajb = 0.0f, y[3], yb[3];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) pb[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Jb[i] = 0.0f;
+            float *Pwb = pb, *Pvb = pb + 3, *Palb = pb + 6, *Pab = pb + 9;
+            // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)
+            y[0] = Pa[0]; y[1] = Pa[1]; y[2] = Pa[2];
+            add_cross(y, Pal, t);
+            mat_vec(J, ab, yb);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * ab[c];
+            vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
+            wjb += ab[0] * v[1] - ab[1] * v[0];
+            Pab[0] += yb[0]; Pab[1] += yb[1]; Pab[2] += yb[2];
+            add_cross(Palb, t, yb);
+            add_cross(tbr, yb, Pal);
+            // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)
+            mat_vec(J, alb, x);
+            Palb[0] += x[0]; Palb[1] += x[1]; Palb[2] += x[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pal[r] * alb[c];
+            ajb += alb[2];
+            wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
+            wjb += alb[0] * w[1] - alb[1] * w[0];
+            // v = J^T (Pv + Pw x t)
+            y[0] = Pv[0]; y[1] = Pv[1]; y[2] = Pv[2];
+            add_cross(y, Pw, t);
+            mat_vec(J, vb, yb);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * vb[c];
+            Pvb[0] += yb[0]; Pvb[1] += yb[1]; Pvb[2] += yb[2];
+            add_cross(Pwb, t, yb);
+            add_cross(tbr, yb, Pw);
+            // w = J^T Pw + wj e_z
+            mat_vec(J, wb, x);
+            Pwb[0] += x[0]; Pwb[1] += x[1]; Pwb[2] += x[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pw[r] * wb[c];
+            wjb += wb[2];
+            // the force transform of sweep B: up.lin = J tot.lin, up.ang = J tot.ang + t x (J tot.lin)
+            if (src != DRM_SRC_ROOT) {
+                float ub[6], tot[6], Lb[3], L[3];
+                if (src >= 0) slot_get(src, 18, ub, 6);
+                else unpark(k > 0 ? k - 1 : 0, 18, ub, 6);
+                unpark(k, 12, tot, 6);
+                Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
+                add_cross(Lb, ub + 3, t);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Lb[r] * tot[c] + ub[3 + r] * tot[3 + c];
+                mat_vec(J, tot, L);
+                add_cross(tbr, L, ub + 3);
+            }
+            // J = F Rot_z(q)
+            const float gtk = dof[k] >= 0 ? gtau(dof[k]) : 0.0f;
+            if (want_gq && dof[k] >= 0) {
+                float gq = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gq += Jb[r * 3 + 0] * J[r * 3 + 1] - Jb[r * 3 + 1] * J[r * 3 + 0];
+                gout(dof[k], gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
+            }
+            if ((param_mask >> k) & 1u) {
+                float gr[DRM_OPF_STRIDE];
+#pragma unroll
+                for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * cs[k] - Jb[r * 3 + 1] * sn[k];
+                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * sn[k] + Jb[r * 3 + 1] * cs[k];
+                    gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2];
+                    gr[DRM_OPF_TI(r)] = tbr[r];
+                    gr[DRM_OPF_MCOM + r] = gmc[r];
+                }
+                gr[DRM_OPF_MASS] = gm;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = gIo[i];
+                gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
+                param_out(k, gr);
+            }
+            if (src >= 0) slot_add(src, 24, pb, 12);
+            else if (src != DRM_SRC_ROOT) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) carry[i] = pb[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Joint-space inertia matrix H(q) by the composite-rigid-body algorithm.
 //
 // The reference builds H column by column from n + 1 inverse-dynamics passes (robot_model.py:402-450:

@@ -31,8 +31,8 @@ class PositiveScalar(torch.nn.Module):
         self._min_val = float(min_val)
         if init_param is None:
             value = torch.empty(1).normal_(mean=0.0, std=init_param_std)
-        else:
-            value = torch.as_tensor(init_param, dtype=torch.float32).reshape(1)
+        else:  # init_param is the VALUE to start from, as in the reference: l = sqrt(value - min_val)
+            value = torch.sqrt(torch.as_tensor(init_param, dtype=torch.float32).reshape(1) - self._min_val)
         self.l = torch.nn.Parameter(value.clone())
 
     def forward(self):

@@ -115,6 +115,36 @@ class _FkPositions(torch.autograd.Function):
         return grad_q, grad_ops, None, None, None, None
 
 
+class _InverseDynamics(torch.autograd.Function):
+    """RNEA with a hand-written backward (csrc/drm_rnea_backward.hip): torques are differentiable with respect
+    to q, qd, qdd and to the walk's constant table (and through its gather, to every learnable link parameter)."""
+
+    @staticmethod
+    def forward(ctx, q, qd, qdd, ops_f, dw, gravity, damping, n_dofs, param_mask):
+        tau = backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, n_dofs)
+        ctx.save_for_backward(q, qd, qdd if qdd is not None else q.new_empty(0), ops_f)
+        ctx.has_qdd = qdd is not None
+        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask = dw, (gravity, damping), n_dofs, param_mask
+        return tau
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_tau):
+        q, qd, qdd, ops_f = ctx.saved_tensors
+        qdd = qdd if ctx.has_qdd else None
+        want_in = any(ctx.needs_input_grad[:3])
+        dw = ctx.dw
+        gin, grad_ops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, grad_tau, ctx.flags[0],
+                                              ctx.flags[1], ctx.n_dofs, ctx.param_mask if ctx.needs_input_grad[3] else 0,
+                                              want_in)
+        gq = gqd = gqdd = None
+        if gin is not None:
+            gq = gin[0].to(q.dtype).reshape(q.shape) if ctx.needs_input_grad[0] else None
+            gqd = gin[1].to(qd.dtype).reshape(qd.shape) if ctx.needs_input_grad[1] else None
+            gqdd = gin[2].to(qdd.dtype).reshape(qdd.shape) if (ctx.has_qdd and ctx.needs_input_grad[2]) else None
+        return gq, gqd, gqdd, grad_ops, None, None, None, None, None
+
+
 class DifferentiableRobotModel(torch.nn.Module):
     """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
 
@@ -255,8 +285,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         live = live or (bool(self._learnable) and any(p.requires_grad for p in self.parameters()))
         if live:
             raise NotImplementedError(
-                "%s has no backward kernel yet: call it under torch.no_grad() (gradients are implemented for the "
-                "position output of compute_forward_kinematics[_all_links])" % what)
+                "%s has no backward kernel yet: call it under torch.no_grad() (gradients are implemented for "
+                "compute_inverse_dynamics / compute_non_linear_effects and for the position output of "
+                "compute_forward_kinematics[_all_links])" % what)
 
     def _require_device(self):
         if self._device.type != "cuda":
@@ -359,11 +390,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert qd.shape[1] == self._n_dofs
         assert qdd_des.shape[1] == self._n_dofs
         self._require_device()
-        self._refuse_autograd("compute_inverse_dynamics", q, qd, qdd_des)
-        dw = self._get_walk(("tree",), whole_tree=True)
-        ops_f = self._ops_f(dw)
-        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd_des, bool(include_gravity), bool(use_damping),
-                            self._n_dofs)
+        return self._inverse_dynamics(q, qd, qdd_des, bool(include_gravity), bool(use_damping))
 
     @tensor_check
     def compute_non_linear_effects(self, q: torch.Tensor, qd: torch.Tensor, include_gravity: Optional[bool] = True,
@@ -372,11 +399,21 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2 and qd.ndim == 2
         assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs
         self._require_device()
-        self._refuse_autograd("compute_non_linear_effects", q, qd)
+        return self._inverse_dynamics(q, qd, None, bool(include_gravity), bool(use_damping))
+
+    def _inverse_dynamics(self, q, qd, qdd, gravity: bool, damping: bool) -> torch.Tensor:
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
-        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, None, bool(include_gravity), bool(use_damping),
-                            self._n_dofs)
+        needs_grad = torch.is_grad_enabled() and (ops_f.requires_grad or any(
+            t is not None and t.requires_grad for t in (q, qd, qdd)))
+        if needs_grad:
+            links = {link for link, _ in self._learnable}
+            mask = 0
+            for k, link in enumerate(dw.program.links):
+                if int(link) in links:
+                    mask |= 1 << k
+            return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs, mask)
+        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
 
     @tensor_check
     def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,

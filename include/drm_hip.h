@@ -168,6 +168,25 @@ int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity);
 int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
                     uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
 
+/*
+ * Reverse-mode derivative of drm_rnea: what torch autograd computes in the reference when a loss on
+ * compute_inverse_dynamics' torques is back-propagated to learnable link parameters and to q / qd / qdd
+ * (robot_model.py:305-375, 669-713; examples/learn_dynamics_iiwa.py:49-96).
+ *   q, qd, qdd [B, n], flags      the arguments of the forward call (qdd may be NULL = zeros)
+ *   grad_tau   [B, n]             dL/dtau
+ *   param_mask                    bit k set: produce the constant gradients of op k (its link is learnable)
+ *   grad_q, grad_qd, grad_qdd [B, n]   all three or all NULL
+ *   grad_ops_f [capacity, DRM_OPF_STRIDE]  gradient of every constant of the selected ops in the op-row layout
+ *                                 (FT block, mass, mass*com, I_o, damping), summed over the batch in a fixed order;
+ *                                 zeros elsewhere.  NULL iff param_mask == 0.
+ *   scratch    drm_rnea_backward_scratch_floats(B, capacity, n_dofs, n_slots) floats, owned by the caller
+ * The walk must give every branch point its own save slot (flatten.WalkProgram.slots_unique).
+ */
+int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity, int32_t n_dofs, int32_t n_slots);
+int drm_rnea_backward(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
+                      const float *grad_tau, uint32_t param_mask, float *grad_q, float *grad_qd, float *grad_qdd,
+                      float *grad_ops_f, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

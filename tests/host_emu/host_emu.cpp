@@ -154,6 +154,33 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
         }
 }
 
+// reverse-mode RNEA: per-sample adjoint sweeps, constant gradients summed over the batch in double
+template <int CAP>
+void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, const float *gtau,
+             uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+    const int n = w->n_dofs;
+    static thread_local double sum[CAP * DRM_OPF_STRIDE];
+    for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) sum[i] = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        float rec[CAP][24], slots[DRM_MAX_SLOTS][36];
+        for (auto &s : slots) for (float &x : s) x = 0.f;
+        if (gq) for (int d = 0; d < n; ++d) { gq[b * n + d] = 0.f; gqd[b * n + d] = 0.f; gqdd[b * n + d] = 0.f; }
+        auto qf = [&](int d, float &a, float &v, float &acc) { a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f; };
+        auto gt = [&](int d) { return gtau[b * n + d]; };
+        auto park = [&](int k, int off, const float *v, int cnt) { for (int i = 0; i < cnt; ++i) rec[k][off + i] = v[i]; };
+        auto unpark = [&](int k, int off, float *v, int cnt) { for (int i = 0; i < cnt; ++i) v[i] = rec[k][off + i]; };
+        auto sput = [&](int s, int off, const float *v, int cnt) { for (int i = 0; i < cnt; ++i) slots[s][off + i] = v[i]; };
+        auto sget = [&](int s, int off, float *v, int cnt) { for (int i = 0; i < cnt; ++i) v[i] = slots[s][off + i]; };
+        auto sadd = [&](int s, int off, const float *v, int cnt) { for (int i = 0; i < cnt; ++i) slots[s][off + i] += v[i]; };
+        auto stake = [&](int s, int off, float *v, int cnt) { for (int i = 0; i < cnt; ++i) { v[i] = slots[s][off + i]; slots[s][off + i] = 0.f; } };
+        auto gout = [&](int d, float a, float v, float acc) { gq[b * n + d] = a; gqd[b * n + d] = v; gqdd[b * n + d] = acc; };
+        auto pout = [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; };
+        rnea_backward_walk<CAP>(w->ops_f, w->ops_i, flags, mask, gq != nullptr, qf, gt, park, unpark, sput, sget, sadd, stake,
+                                gout, pout);
+    }
+    if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
+}
+
 template <int CAP>
 void crba_t(const drm_walk *w, const float *q, int64_t B, float *H) {
     const int n = w->n_dofs;
@@ -202,6 +229,11 @@ int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos
 int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     rnea_arm_8_7(w, q, qd, qdd, B, flags, tau);
+    return 0;
+}
+int emu_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
+                      const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+    DISPATCH(rneab_t, w, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops)
     return 0;
 }
 int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {

@@ -220,6 +220,8 @@ def test_gpu_autograd_refused_where_no_backward_kernel_exists():
     m = load_model("iiwa7", "cuda")
     q = torch.zeros(4, 7, device="cuda", requires_grad=True)
     with pytest.raises(NotImplementedError):
-        m.compute_inverse_dynamics(q, torch.zeros(4, 7).cuda(), torch.zeros(4, 7).cuda())
+        m.compute_endeffector_jacobian(q, "iiwa_link_ee")
+    with pytest.raises(NotImplementedError):
+        m.compute_lagrangian_inertia_matrix(q)
     with torch.no_grad():
-        m.compute_inverse_dynamics(q, torch.zeros(4, 7).cuda(), torch.zeros(4, 7).cuda())
+        m.compute_endeffector_jacobian(q, "iiwa_link_ee")
