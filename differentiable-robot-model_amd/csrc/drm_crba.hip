@@ -38,7 +38,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     const bool live = (int)lane < cx.rows;
     const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row compute garbage, never stored
     float *hdst = H + (cx.b0 + lane) * nn;
-    auto qf = [&](int d) -> float { return qrow[d]; };
+    // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
+    // the rare large-angle sincos path, which would change the rounding of the live lanes from run to run
+    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
     auto islot_add = [&](int s, const Inertia &a) {
         float *b = lis + s * (10 * WAVE) + lane;
         b[0] += a.m;

@@ -28,8 +28,11 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
     wave_lds_sync();
 
-    const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row compute garbage, never stored
-    auto qf = [&](int d) -> float { return qrow[d]; };
+    // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
+    // the rare large-angle sincos path, which would change the rounding of the live lanes from run to run
+    const bool live = (int)lane < cx.rows;
+    const float *qrow = lq + lane * Sq;
+    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
     float *prow = lp + lane * Sp;
     float *rrow = lr + lane * Sr;
     auto slot_save = [&](int s, const PoseP &P) {

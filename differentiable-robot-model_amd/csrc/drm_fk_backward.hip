@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         float *gqrow = lgq + lane * Sq;
         if (gq)
             for (int d = 0; d < n; ++d) gqrow[d] = 0.0f; // DoFs that are not on any target's chain
-        auto qf = [&](int d) -> float { return qrow[d]; };
+        auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; }; // zeros, not stale LDS, past a partial tile
         auto grad_in = [&](int t, float *G) {
             G[0] += grow[t * 3 + 0]; G[1] += grow[t * 3 + 1]; G[2] += grow[t * 3 + 2];
         };

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     // never stored (the arithmetic is branch-free, so garbage is harmless)
     const bool live = (int)lane < cx.rows;
     const float *qrow = lq + lane * Sq;
-    auto qf = [&](int d) -> float { return qrow[d]; };
+    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; }; // zeros, not stale LDS, past a partial tile
 
     Pose ee;
     float z[CAP][3], pj[CAP][3];

@@ -33,10 +33,13 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();
 
-    const unsigned row = lane * Sq; // lanes past a partial tile's last row compute garbage, never stored
+    // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
+    // the rare large-angle sincos path, which would change the rounding of the live lanes from run to run
+    const unsigned row = lane * Sq;
+    const bool live = (int)lane < cx.rows;
     const bool has_qdd = qdd != nullptr;
     auto qf = [&](int d, float &a, float &v, float &acc) {
-        a = lq[row + d];
+        a = live ? lq[row + d] : 0.0f;
         v = lqd[row + d];
         acc = has_qdd ? lqdd[row + d] : 0.0f;
     };

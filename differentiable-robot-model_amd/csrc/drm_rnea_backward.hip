@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         if (gq)
             for (int d = 0; d < n; ++d) { lgq[row + d] = 0.0f; lgqd[row + d] = 0.0f; lgqdd[row + d] = 0.0f; }
         auto qf = [&](int d, float &a, float &v, float &c) {
-            a = lq[row + d];
+            a = live ? lq[row + d] : 0.0f; // zeros, not stale LDS, past a partial tile
             v = lqd[row + d];
             c = has_qdd ? lqdd[row + d] : 0.0f;
         };
