@@ -39,7 +39,7 @@ _lock = threading.Lock()
 
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
-           "drm_rnea_backward_scratch_floats")
+           "drm_rnea_backward_scratch_floats", "drm_forward_dynamics")
 
 
 def load_library(path: str = None):
@@ -77,6 +77,8 @@ def load_library(path: str = None):
         lib.drm_rnea_backward.argtypes = [wp, vp, vp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
         lib.drm_rnea_backward_scratch_floats.restype = i64
         lib.drm_rnea_backward_scratch_floats.argtypes = [i64, i32, i32, i32]
+        lib.drm_forward_dynamics.restype = ctypes.c_int
+        lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
         lib.drm_crba.restype = ctypes.c_int
         lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
@@ -192,6 +194,24 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
                                      ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
                                      ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)))
     return gin, grad_ops
+
+
+def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):
+    """qdd [B, n] produced by the joint torques f in state (q, qd)."""
+    lib = load_library()
+    q, qd, f = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs), _dev_f32(f, "f", n_dofs)
+    B = q.shape[0]
+    if qd.shape[0] != B or f.shape[0] != B:
+        raise ValueError("q / qd / f batch sizes differ")
+    qdd = torch.empty(B, n_dofs, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return qdd
+    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
+                                        qdd.data_ptr(), _stream(q.device)))
+    return qdd
 
 
 def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):

@@ -1,0 +1,152 @@
+// drm_forward_dynamics.hip — K8: joint accelerations from joint torques, qdd = H(q)^-1 (f - nle(q, qd)).
+//
+// Replaces DifferentiableRobotModel.compute_forward_dynamics (robot_model.py:487-624, Featherstone's
+// articulated-body algorithm written as three Python loops over the links with 6x6 bmm's per link).  The
+// articulated-body recursion is an O(n) elimination of the linear system H qdd = f - nle; this kernel forms the same
+// system with the two walks it already has — crba_walk for H, rnea_walk with qdd = 0 for the bias torques nle — and
+// solves it per sample by Cholesky in LDS (n <= ~20: ~n^3/3 FMAs, less than one of the walks).  Same result up to
+// fp32 rounding amplified by cond(H), like the reference's own recursion (tolerances in tests/).
+//
+// Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
+// LDS per wave: [ q qd f : 3 x 64 (n|1) ][ H : 64 (n^2|1) ][ slots : n_slots * (28 + 6 cap) * 64 ]
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+template <int CAP>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    forward_dynamics_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots,
+                            int flags, int zero_fill, const float *__restrict__ q, const float *__restrict__ qd,
+                            const float *__restrict__ f, int64_t B, float *__restrict__ qdd, uint32_t magic_q,
+                            int lds_per_wave, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    WaveCtx cx;
+    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
+    const unsigned lane = cx.lane;
+    const int nn = n * n;
+    const int Sq = pad_odd(n), Sh = pad_odd(nn), region = round4(WAVE * Sq);
+    float *lq = cx.lds, *lqd = lq + region, *lf = lqd + region;
+    float *lh = lf + region;
+    float *lis = lh + round4(WAVE * Sh);             // crba inertia slots [slot][10][64]
+    float *lss = lis + n_slots * (10 * WAVE);        // crba axis slots    [slot][op][6][64]
+    float *lms = lss + n_slots * (CAP * 6 * WAVE);   // rnea motion slots  [slot][12][64]
+    float *lfs = lms + n_slots * (12 * WAVE);        // rnea force slots   [slot][6][64]
+    const bool fast = cx.full && (n & 1);
+
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q));
+    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
+    tile_load<0>(f + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_QDD));
+    for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
+    for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
+    float *hrow = lh + lane * Sh;
+    if (zero_fill)
+        for (int i = 0; i < nn; ++i) hrow[i] = 0.0f; // pairs of joints on different branches
+    wave_lds_sync();
+
+    // lanes past a partial tile read zeros (see drm_fk.hip); their H is then a valid inertia matrix as well
+    const bool live = (int)lane < cx.rows;
+    const unsigned row = lane * Sq;
+    auto qf1 = [&](int d) -> float { return live ? lq[row + d] : 0.0f; };
+    {
+        auto islot_add = [&](int s, const Inertia &a) {
+            float *b = lis + s * (10 * WAVE) + lane;
+            b[0] += a.m;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[(1 + i) * WAVE] += a.h[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[(4 + i) * WAVE] += a.I[i];
+        };
+        auto islot_take = [&](int s, Inertia &a) {
+            float *b = lis + s * (10 * WAVE) + lane;
+            a.m += b[0]; b[0] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { a.h[i] += b[(1 + i) * WAVE]; b[(1 + i) * WAVE] = 0.0f; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
+        };
+        auto sslot_save = [&](int s, int j, const Axis &a) {
+            float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
+        };
+        auto sslot_load = [&](int s, int j, Axis &a) {
+            const float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
+        };
+        auto hout = [&](int di, int dj, float v) { hrow[di * n + dj] = v; };
+        crba_walk<CAP>(ops_f, ops_i, qf1, islot_add, islot_take, sslot_save, sslot_load, hout);
+    }
+    {
+        // bias torques: RNEA with zero joint accelerations (robot_model.py:377-400); rhs = f - nle, over f
+        auto qf3 = [&](int d, float &a, float &v, float &acc) {
+            a = live ? lq[row + d] : 0.0f;
+            v = lqd[row + d];
+            acc = 0.0f;
+        };
+        auto tau_out = [&](int d, float v) { lf[row + d] -= v; };
+        auto motion_save = [&](int s, const Motion &M) {
+            float *b = lms + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                b[i * WAVE] = M.wa[i][0]; b[(3 + i) * WAVE] = M.va[i][0]; b[(6 + i) * WAVE] = M.wa[i][1];
+                b[(9 + i) * WAVE] = M.va[i][1];
+            }
+        };
+        auto motion_load = [&](int s, Motion &M) {
+            const float *b = lms + s * (12 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                M.wa[i] = f2_make(b[i * WAVE], b[(6 + i) * WAVE]);
+                M.va[i] = f2_make(b[(3 + i) * WAVE], b[(9 + i) * WAVE]);
+            }
+        };
+        auto force_add = [&](int s, const Force &F) {
+            float *b = lfs + s * (6 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { b[i * WAVE] += F.la[i][0]; b[(3 + i) * WAVE] += F.la[i][1]; }
+        };
+        auto force_take = [&](int s, Force &F) {
+            float *b = lfs + s * (6 * WAVE) + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                F.la[i] += f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+                b[i * WAVE] = 0.0f; b[(3 + i) * WAVE] = 0.0f;
+            }
+        };
+        rnea_walk<CAP>(ops_f, ops_i, flags, qf3, tau_out, motion_save, motion_load, force_add, force_take);
+    }
+    cholesky_solve(n, hrow, lf + row);
+    wave_lds_sync();
+    tile_store<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_TAU));
+}
+
+} // namespace drm
+
+using namespace drm;
+
+extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B,
+                                    int32_t flags, float *qdd, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !qd || !f || !qdd) return fail(DRM_ERR_INVALID, "q / qd / f / qdd must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    if (B == 0) return DRM_OK;
+    const int n = w->n_dofs, nn = n * n;
+    Geometry g;
+    rc = make_geometry(B, 3 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(nn)) +
+                              w->n_slots * (28 + 6 * w->capacity) * WAVE, g);
+    if (rc) return fail(DRM_ERR_UNSUPPORTED, "forward dynamics keeps the %s%ld x %ld inertia matrix of 64 samples in LDS; "
+                                             "this robot does not fit", "", (long)n, (long)n);
+    const int zero_fill = (w->shape & DRM_WALK_ARM_CHAIN) ? 0 : 1;
+    const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
+    hipStream_t s = (hipStream_t)stream;
+    DRM_DISPATCH_CAP(w->capacity, {
+        rc = ensure_lds(forward_dynamics_kernel<C>, g.lds_bytes);
+        if (rc) return rc;
+        hipLaunchKernelGGL(forward_dynamics_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
+                           (int)w->n_slots, (int)flags, zero_fill, q, qd, f, B, qdd, div_magic(n), g.lds_per_wave, align);
+    })
+    return launched();
+}

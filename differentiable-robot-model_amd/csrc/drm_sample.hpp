@@ -1312,4 +1312,35 @@ DRM_HD void crba_walk(const float *__restrict__ opf, const int32_t *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Solve H x = b for one sample, H symmetric positive definite (the joint-space inertia matrix), by an in-place
+// Cholesky factorisation H = L L^T of the lower triangle followed by the two triangular solves.  H is the
+// lane's row-major n x n block (LDS in the kernel); b is overwritten with x.
+// Used by the forward-dynamics kernel: qdd = H^-1 (f - nle) is the same linear system the reference's
+// articulated-body recursion (robot_model.py:487-624) solves link by link.
+// ---------------------------------------------------------------------------
+DRM_HD void cholesky_solve(int n, float *H, float *b) {
+    for (int j = 0; j < n; ++j) {
+        float s = H[j * n + j];
+        for (int k = 0; k < j; ++k) s -= H[j * n + k] * H[j * n + k];
+        const float inv = rsqrt_f(s);
+        H[j * n + j] = inv; // the diagonal keeps 1 / L_jj
+        for (int i = j + 1; i < n; ++i) {
+            float t = H[i * n + j];
+            for (int k = 0; k < j; ++k) t -= H[i * n + k] * H[j * n + k];
+            H[i * n + j] = t * inv;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        float t = b[i];
+        for (int k = 0; k < i; ++k) t -= H[i * n + k] * b[k];
+        b[i] = t * H[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        float t = b[i];
+        for (int k = i + 1; k < n; ++k) t -= H[k * n + i] * b[k];
+        b[i] = t * H[i * n + i];
+    }
+}
+
 } // namespace drm

@@ -432,6 +432,27 @@ class DifferentiableRobotModel(torch.nn.Module):
         dw = self._get_walk(("tree",), whole_tree=True)
         return backend.crba(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
 
+    @tensor_check
+    def compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
+                                 include_gravity: Optional[bool] = True, use_damping: Optional[bool] = False
+                                 ) -> torch.Tensor:
+        """qdd [B,n] that the joint torques ``f`` produce in state (q, qd) (robot_model.py:487-624).
+
+        The reference runs Featherstone's articulated-body recursion; this solves the same linear system
+        H(q) qdd = f - nle(q, qd) in one fused kernel (composite-rigid-body H, RNEA bias torques, Cholesky).
+        With ``use_damping`` the reference subtracts damping * qd from its ``f`` argument IN PLACE
+        (robot_model.py:515-521); here ``f`` is left untouched.
+        """
+        assert q.ndim == 2
+        assert qd.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        assert qd.shape[1] == self._n_dofs
+        self._require_device()
+        self._refuse_autograd("compute_forward_dynamics", q, qd, f)
+        dw = self._get_walk(("tree",), whole_tree=True)
+        return backend.forward_dynamics(dw.program, self._ops_f(dw), dw.ops_i, q, qd, f, bool(include_gravity),
+                                        bool(use_damping), self._n_dofs)
+
     # ------------------------------------------------------------------ learnable parameters
     def _get_parent_object_of_param(self, link_name: str, parameter_name: str):
         body_idx = self._name_to_idx_map[link_name]

@@ -151,6 +151,17 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
 int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *stream);
 
 /*
+ * Forward dynamics over the whole tree: joint accelerations produced by joint torques f in state (q, qd).
+ * Replaces DifferentiableRobotModel.compute_forward_dynamics (robot_model.py:487-624, articulated-body
+ * algorithm).  flags as for drm_rnea: DRM_RNEA_GRAVITY = base acceleration (0,0,+9.81) (robot_model.py:527-533),
+ * DRM_RNEA_DAMPING = the damping torques damping * qd are taken off f first (robot_model.py:515-521; the
+ * caller's f is NOT modified, unlike the reference, which subtracts in place).
+ *   q, qd, f [B, n]  ->  qdd [B, n];  DRM_ERR_UNSUPPORTED when 64 n x n matrices do not fit in LDS (n > ~20)
+ */
+int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,
+                         int32_t flags, float *qdd, void *stream);
+
+/*
  * Reverse-mode derivative of drm_fk's POSITIONS: what torch autograd computes in the reference when a loss on
  * compute_forward_kinematics' position is back-propagated to q and to learnable `trans` / `rot_angles`
  * (robot_model.py:139-195, 223-248, 669-713; examples/learn_kinematics_of_iiwa.py:25-61).  The quaternion has

@@ -51,6 +51,9 @@ int drm_oracle_rnea_f64(const drm_oracle_spec *s, const double *q, const double 
 int drm_oracle_mass_matrix_f32(const drm_oracle_spec *s, const float *q, int64_t B, int g, int d, float *H) { return oracle_mass_matrix_f32(s, q, B, g, d, H); }
 int drm_oracle_mass_matrix_f64(const drm_oracle_spec *s, const double *q, int64_t B, int g, int d, double *H) { return oracle_mass_matrix_f64(s, q, B, g, d, H); }
 
+int drm_oracle_forward_dynamics_f32(const drm_oracle_spec *s, const float *q, const float *qd, const float *f, int64_t B, int g, int d, float *qdd) { return oracle_forward_dynamics_f32(s, q, qd, f, B, g, d, qdd); }
+int drm_oracle_forward_dynamics_f64(const drm_oracle_spec *s, const double *q, const double *qd, const double *f, int64_t B, int g, int d, double *qdd) { return oracle_forward_dynamics_f64(s, q, qd, f, B, g, d, qdd); }
+
 int drm_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -39,6 +39,9 @@ int drm_oracle_rnea_f64(const drm_oracle_spec *, const double *q, const double *
 /* H [B, n, n] = compute_lagrangian_inertia_matrix (rm.py:402-450) */
 int drm_oracle_mass_matrix_f32(const drm_oracle_spec *, const float *q, int64_t B, int include_gravity, int use_damping, float *H);
 int drm_oracle_mass_matrix_f64(const drm_oracle_spec *, const double *q, int64_t B, int include_gravity, int use_damping, double *H);
+/* qdd [B, n] = compute_forward_dynamics (articulated-body algorithm, rm.py:487-624) */
+int drm_oracle_forward_dynamics_f32(const drm_oracle_spec *, const float *q, const float *qd, const float *f, int64_t B, int include_gravity, int use_damping, float *qdd);
+int drm_oracle_forward_dynamics_f64(const drm_oracle_spec *, const double *q, const double *qd, const double *f, int64_t B, int include_gravity, int use_damping, double *qdd);
 int drm_oracle_max_threads(void);
 void drm_oracle_set_threads(int n);
 #ifdef __cplusplus

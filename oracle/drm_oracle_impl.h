@@ -440,6 +440,182 @@ static int FN(oracle_mass_matrix)(const drm_oracle_spec *sp, const IO_T *q, int6
     return err;
 }
 
+
+/* ---- articulated-body algorithm ------------------------------------------------------------------- */
+/* 6-vectors and 6x6 matrices use the reference's get_vector() order: [ang (3); lin (3)] (sva.py:236-237). */
+
+/* DifferentiableSpatialRigidBodyInertia.get_spatial_mat  sva.py:340-372 */
+static void FN(spatial_inertia_mat)(const drm_oracle_spec *sp, int i, REAL *M) {
+    REAL m = (REAL)sp->mass[i];
+    REAL c[3] = {(REAL)sp->com[i * 3], (REAL)sp->com[i * 3 + 1], (REAL)sp->com[i * 3 + 2]};
+    REAL mc[3] = {m * c[0], m * c[1], m * c[2]};
+    REAL S[9], ST[9], SS[9];
+    FN(skew)(c, S);
+    FN(mat3_transpose)(S, ST);
+    FN(mat3_mul)(S, ST, SS);
+    for (int k = 0; k < 36; ++k) M[k] = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) M[r * 6 + k] = (REAL)sp->inertia[i * 9 + r * 3 + k] + m * SS[r * 3 + k];
+    M[3 * 6 + 1] = mc[2];  M[3 * 6 + 2] = -mc[1];
+    M[4 * 6 + 0] = -mc[2]; M[4 * 6 + 2] = mc[0];
+    M[5 * 6 + 0] = mc[1];  M[5 * 6 + 1] = -mc[0];
+    M[0 * 6 + 4] = -mc[2]; M[0 * 6 + 5] = mc[1];
+    M[1 * 6 + 3] = mc[2];  M[1 * 6 + 5] = -mc[0];
+    M[2 * 6 + 3] = -mc[1]; M[2 * 6 + 4] = mc[0];
+    M[3 * 6 + 3] = m; M[4 * 6 + 4] = m; M[5 * 6 + 5] = m;
+}
+
+/*
+ * rm.py:487-624 compute_forward_dynamics for ONE sample (Featherstone's articulated-body algorithm as the
+ * reference writes it, including its 1e-37 smoothing and the `parent_idx > 0` guard).  The reference subtracts the
+ * damping torques from its INPUT tensor in place (rm.py:515-521); here the caller's array is left alone.
+ * scratch: caller provides (27 + 36 + 6*5 + 2) * L REALs.
+ */
+static void FN(aba_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL *qd, const REAL *f_in,
+                           int include_gravity, int use_damping, REAL *qdd, REAL *scratch) {
+    const int L = sp->n_links;
+    REAL *R = scratch, *p = R + 9 * L, *J = p + 3 * L, *vl = J + 9 * L, *va = vl + 3 * L;
+    REAL *IA = va + 3 * L;                 /* [L][36] */
+    REAL *pA = IA + 36 * L;                /* [L][6]  (ang, lin) */
+    REAL *cc = pA + 6 * L, *U = cc + 6 * L, *acc = U + 6 * L, *Sv = acc + 6 * L; /* [L][6] each */
+    REAL *dd = Sv + 6 * L, *uu = dd + L;   /* [L] */
+    FN(kinematic_state)(sp, q, qd, R, p, J, vl, va);
+    for (int i = 1; i < L; ++i) { /* rm.py:539-549 */
+        const int d = sp->dof[i];
+        REAL qdi = (d >= 0) ? qd[d] : 0;
+        REAL jv[3], zero[3] = {0, 0, 0}, ta[3], tl1[3], tl2[3];
+        for (int k = 0; k < 3; ++k) jv[k] = qdi * (REAL)sp->axis[i * 3 + k];
+        /* c = vel.cross_motion_vec(joint_vel)  sva.py:204-213 */
+        FN(cross)(va + i * 3, jv, ta);
+        FN(cross)(va + i * 3, zero, tl1);
+        FN(cross)(vl + i * 3, jv, tl2);
+        for (int k = 0; k < 3; ++k) { cc[i * 6 + k] = ta[k]; cc[i * 6 + 3 + k] = tl1[k] + tl2[k]; }
+        /* pA = vel.cross_force_vec(I vel)  sva.py:215-224 */
+        REAL ivl[3], iva[3], c1[3], c2[3], c3[3];
+        FN(inertia_mul)(sp, i, vl + i * 3, va + i * 3, ivl, iva);
+        FN(cross)(va + i * 3, iva, c1);
+        FN(cross)(vl + i * 3, ivl, c2);
+        FN(cross)(va + i * 3, ivl, c3);
+        for (int k = 0; k < 3; ++k) { pA[i * 6 + k] = c1[k] + c2[k]; pA[i * 6 + 3 + k] = c3[k]; }
+        FN(spatial_inertia_mat)(sp, i, IA + i * 36);
+    }
+    for (int i = L - 1; i > 0; --i) { /* rm.py:551-604 */
+        const int par = sp->parent[i], d = sp->dof[i];
+        REAL *S = Sv + i * 6, *Ui = U + i * 6, *IAi = IA + i * 36;
+        for (int k = 0; k < 3; ++k) { S[k] = (REAL)sp->axis[i * 3 + k]; S[3 + k] = 0; }
+        for (int r = 0; r < 6; ++r) {
+            REAL a = 0;
+            for (int k = 0; k < 6; ++k) a += IAi[r * 6 + k] * S[k];
+            Ui[r] = a;
+        }
+        REAL dot = 0, pAS = 0;
+        for (int k = 0; k < 3; ++k) dot += S[k] * Ui[k];          /* S.dot(U): ang part ... */
+        { REAL l = 0; for (int k = 0; k < 3; ++k) l += S[3 + k] * Ui[3 + k]; dot = dot + l; }
+        for (int k = 0; k < 3; ++k) pAS += pA[i * 6 + k] * S[k];
+        { REAL l = 0; for (int k = 0; k < 3; ++k) l += pA[i * 6 + 3 + k] * S[3 + k]; pAS = pAS + l; }
+        dd[i] = dot;
+        REAL f_i = 0;
+        if (d >= 0) f_i = f_in[d] - (use_damping ? (REAL)sp->damping[i] * qd[d] : 0);
+        uu[i] = (d >= 0) ? f_i - pAS : -pAS;
+        if (par > 0) {
+            REAL Ud[6], IAn[36], tmp[6], pa[6];
+            for (int k = 0; k < 6; ++k) Ud[k] = Ui[k] / (dd[i] + (REAL)1e-37);
+            for (int r = 0; r < 6; ++r)
+                for (int k = 0; k < 6; ++k) IAn[r * 6 + k] = IAi[r * 6 + k] - Ui[r] * Ud[k];
+            for (int r = 0; r < 6; ++r) {
+                REAL a = 0;
+                for (int k = 0; k < 6; ++k) a += IAn[r * 6 + k] * cc[i * 6 + k];
+                tmp[r] = a;
+            }
+            REAL ud = uu[i] / (dd[i] + (REAL)1e-37);
+            for (int k = 0; k < 6; ++k) pa[k] = (pA[i * 6 + k] + tmp[k]) + Ui[k] * ud;
+            /* X = joint_pose.to_matrix()  sva.py:138-154: [[R^T, 0], [-R^T S(t), R^T]] */
+            REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+            REAL JT[9], St[9], Erx[9], X[36], XtI[36];
+            FN(mat3_transpose)(J + i * 9, JT);
+            FN(skew)(t, St);
+            FN(mat3_mul)(JT, St, Erx);
+            for (int k = 0; k < 36; ++k) X[k] = 0;
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) {
+                    X[r * 6 + k] = JT[r * 3 + k];
+                    X[(3 + r) * 6 + k] = -Erx[r * 3 + k];
+                    X[(3 + r) * 6 + 3 + k] = JT[r * 3 + k];
+                }
+            for (int r = 0; r < 6; ++r)
+                for (int k = 0; k < 6; ++k) {
+                    REAL a = 0;
+                    for (int m = 0; m < 6; ++m) a += X[m * 6 + r] * IAn[m * 6 + k];
+                    XtI[r * 6 + k] = a;
+                }
+            for (int r = 0; r < 6; ++r)
+                for (int k = 0; k < 6; ++k) {
+                    REAL a = 0;
+                    for (int m = 0; m < 6; ++m) a += XtI[r * 6 + m] * X[m * 6 + k];
+                    IA[par * 36 + r * 6 + k] += a;
+                }
+            /* parent.pA += pa.transform(joint_pose)  sva.py:281-291: lin = R f ; ang = S(t) R f + R n */
+            REAL bl[3], SR[9], ba[3], ba2[3];
+            FN(mat3_vec)(J + i * 9, pa + 3, bl);
+            FN(mat3_mul)(St, J + i * 9, SR);
+            FN(mat3_vec)(SR, pa + 3, ba);
+            FN(mat3_vec)(J + i * 9, pa, ba2);
+            for (int k = 0; k < 3; ++k) { pA[par * 6 + 3 + k] += bl[k]; pA[par * 6 + k] += ba[k] + ba2[k]; }
+        }
+    }
+    for (int k = 0; k < 6; ++k) acc[k] = 0;
+    acc[5] = include_gravity ? (REAL)9.81 : 0; /* base lin acc (0,0,9.81)  rm.py:527-533 */
+    for (int i = 1; i < L; ++i) { /* rm.py:611-629 */
+        const int par = sp->parent[i], d = sp->dof[i];
+        REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+        REAL JT[9], it[3], S3[9], SR[9], na[3], nl[3], nl2[3];
+        FN(mat3_transpose)(J + i * 9, JT);
+        FN(mat3_vec)(JT, t, it);
+        for (int k = 0; k < 3; ++k) it[k] = -it[k];
+        FN(skew)(it, S3);
+        FN(mat3_mul)(S3, JT, SR);
+        FN(mat3_vec)(JT, acc + par * 6, na);
+        FN(mat3_vec)(SR, acc + par * 6, nl);
+        FN(mat3_vec)(JT, acc + par * 6 + 3, nl2);
+        for (int k = 0; k < 3; ++k) {
+            acc[i * 6 + k] = na[k] + cc[i * 6 + k];
+            acc[i * 6 + 3 + k] = (nl[k] + nl2[k]) + cc[i * 6 + 3 + k];
+        }
+        if (d >= 0) {
+            REAL Ua = 0, Ul = 0;
+            for (int k = 0; k < 3; ++k) { Ua += U[i * 6 + k] * acc[i * 6 + k]; Ul += U[i * 6 + 3 + k] * acc[i * 6 + 3 + k]; }
+            qdd[d] = ((REAL)1 / dd[i]) * (uu[i] - (Ua + Ul));
+            for (int k = 0; k < 6; ++k) acc[i * 6 + k] += Sv[i * 6 + k] * qdd[d];
+        }
+    }
+}
+
+static int FN(oracle_forward_dynamics)(const drm_oracle_spec *sp, const IO_T *q, const IO_T *qd, const IO_T *f, int64_t B,
+                                       int include_gravity, int use_damping, IO_T *qdd) {
+    const int L = sp->n_links, n = sp->n_dofs;
+    int err = 0;
+#pragma omp parallel
+    {
+        REAL *buf = (REAL *)malloc(sizeof(REAL) * (size_t)(95 * L + 4 * n + 8));
+        if (!buf) {
+#pragma omp atomic write
+            err = 1;
+        } else {
+            REAL *qq = buf + 95 * L, *qv = qq + n, *ff = qv + n, *out = ff + n;
+#pragma omp for schedule(static)
+            for (int64_t b = 0; b < B; ++b) {
+                for (int d = 0; d < n; ++d) {
+                    qq[d] = (REAL)q[b * n + d]; qv[d] = (REAL)qd[b * n + d]; ff[d] = (REAL)f[b * n + d]; out[d] = 0;
+                }
+                FN(aba_sample)(sp, qq, qv, ff, include_gravity, use_damping, out, buf);
+                for (int d = 0; d < n; ++d) qdd[b * n + d] = (IO_T)out[d];
+            }
+            free(buf);
+        }
+    }
+    return err;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

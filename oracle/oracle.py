@@ -128,3 +128,14 @@ class Oracle(object):
                 ctypes.c_int(int(bool(use_damping))), _ptr(H))
         assert rc == 0
         return H
+
+    def forward_dynamics(self, q, qd, f, include_gravity=True, use_damping=False, dtype=np.float32):
+        """-> qdd [B,n]"""
+        q, qd, f = self._io(q, dtype), self._io(qd, dtype), self._io(f, dtype)
+        B = q.shape[0]
+        qdd = np.empty((B, self.n), dtype)
+        fn = getattr(_lib(), "drm_oracle_forward_dynamics_" + ("f32" if dtype == np.float32 else "f64"))
+        rc = fn(ctypes.byref(self._spec), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B),
+                ctypes.c_int(int(bool(include_gravity))), ctypes.c_int(int(bool(use_damping))), _ptr(qdd))
+        assert rc == 0
+        return qdd

@@ -199,6 +199,19 @@ void crba_t(const drm_walk *w, const float *q, int64_t B, float *H) {
     }
 }
 
+template <int CAP>
+void fd_t(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
+    const int n = w->n_dofs;
+    static thread_local float H[DRM_MAX_DOFS * DRM_MAX_DOFS];
+    for (int64_t b = 0; b < B; ++b) {
+        crba_t<CAP>(w, q + b * n, 1, H);
+        float *x = qdd + b * n;
+        rnea_t<CAP>(w, q + b * n, qd + b * n, nullptr, 1, flags, x);
+        for (int d = 0; d < n; ++d) x[d] = f[b * n + d] - x[d];
+        cholesky_solve(n, H, x);
+    }
+}
+
 } // namespace
 
 #define DISPATCH(FN, ...)                        \
@@ -234,6 +247,11 @@ int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float
 int emu_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
                       const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
     DISPATCH(rneab_t, w, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops)
+    return 0;
+}
+int emu_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int32_t flags,
+                         float *qdd) {
+    DISPATCH(fd_t, w, q, qd, f, B, flags, qdd)
     return 0;
 }
 int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
