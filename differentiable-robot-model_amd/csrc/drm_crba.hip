@@ -5,7 +5,8 @@
 // crba_walk for why the composite-rigid-body form computes the same matrix.
 //
 // Per sample: in q[n] (4 n bytes), out H[n, n] (4 n^2 bytes).          n = 7: 28 + 196 = 224 B, ~2 kflop
-// LDS per wave: [ q : 64 (n|1) ][ H : 64 (n^2|1) ][ inertia slots : n_slots*10*64 ][ axis slots : n_slots*cap*6*64 ]
+// LDS per wave: [ q : 64 (n|1) ][ H : 64 (n^2|1) ][ inertia slots : n_slots*10*64 ][ axis slots : n_slots*depth*6*64 ]
+// (depth = DRM_WALK_BRANCH_DEPTH: a slot holds the axes of the branch point and of the ops above it)
 // When the H tile does not fit in LDS (n > ~20) lanes store their entries straight to HBM (uncoalesced, rare).
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
@@ -14,7 +15,8 @@ namespace drm {
 
 template <int CAP, bool DIRECT>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    crba_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int zero_fill,
+    crba_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int sdepth,
+                int zero_fill,
                 const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t magic_h,
                 int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -26,7 +28,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lq = cx.lds;
     float *lh = lq + round4(WAVE * Sq);
     float *lis = lh + round4(WAVE * Sh);              // inertia slots [slot][10][64]
-    float *lss = lis + n_slots * (10 * WAVE);         // axis slots    [slot][op][6][64]
+    float *lss = lis + n_slots * (10 * WAVE);         // axis slots    [slot][op < sdepth][6][64]
 
     tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
     for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
@@ -58,12 +60,12 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
     };
     auto sslot_save = [&](int s, int j, const Axis &a) {
-        float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+        float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
     };
     auto sslot_load = [&](int s, int j, Axis &a) {
-        const float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+        const float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
     };
@@ -93,7 +95,9 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs, nn = n * n;
     hipStream_t s = (hipStream_t)stream;
-    const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + w->capacity * 6) * WAVE;
+    const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
+    if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
+    const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + sdepth * 6) * WAVE;
     const bool direct = (size_t)(base + round4(WAVE * pad_odd(nn))) * sizeof(float) > (size_t)MAX_LDS_BYTES;
     Geometry g;
     rc = make_geometry(B, base + (direct ? 0 : round4(WAVE * pad_odd(nn))), g);
@@ -109,12 +113,12 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
             rc = ensure_lds(crba_kernel<C, true>, g.lds_bytes);
             if (rc) return rc;
             hipLaunchKernelGGL((crba_kernel<C, true>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                               (int)w->n_slots, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
+                               (int)w->n_slots, sdepth, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
         } else {
             rc = ensure_lds(crba_kernel<C, false>, g.lds_bytes);
             if (rc) return rc;
             hipLaunchKernelGGL((crba_kernel<C, false>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                               (int)w->n_slots, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
+                               (int)w->n_slots, sdepth, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
         }
     })
     return launched();

@@ -8,7 +8,8 @@
 // fp32 rounding amplified by cond(H), like the reference's own recursion (tolerances in tests/).
 //
 // Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
-// LDS per wave: [ q qd f : 3 x 64 (n|1) ][ H : 64 (n^2|1) ][ slots : n_slots * (28 + 6 cap) * 64 ]
+// LDS per wave: [ q qd f : 3 x 64 (n|1) ][ lower triangle of H : 64 (n(n+1)/2 | 1) ]
+//               [ slots : n_slots * max(10 + 6 depth, 18) * 64, the two walks use them one after the other ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
@@ -17,20 +18,20 @@ namespace drm {
 template <int CAP>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     forward_dynamics_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots,
-                            int flags, int zero_fill, const float *__restrict__ q, const float *__restrict__ qd,
+                            int sdepth, int flags, int zero_fill, const float *__restrict__ q, const float *__restrict__ qd,
                             const float *__restrict__ f, int64_t B, float *__restrict__ qdd, uint32_t magic_q,
                             int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     WaveCtx cx;
     if (!wave_begin(B, lds_per_wave, smem, cx)) return;
     const unsigned lane = cx.lane;
-    const int nn = n * n;
+    const int nn = n * (n + 1) / 2; // packed lower triangle
     const int Sq = pad_odd(n), Sh = pad_odd(nn), region = round4(WAVE * Sq);
     float *lq = cx.lds, *lqd = lq + region, *lf = lqd + region;
     float *lh = lf + region;
     float *lis = lh + round4(WAVE * Sh);             // crba inertia slots [slot][10][64]
-    float *lss = lis + n_slots * (10 * WAVE);        // crba axis slots    [slot][op][6][64]
-    float *lms = lss + n_slots * (CAP * 6 * WAVE);   // rnea motion slots  [slot][12][64]
+    float *lss = lis + n_slots * (10 * WAVE);        // crba axis slots    [slot][op < sdepth][6][64]
+    float *lms = lis;                                // rnea motion slots  [slot][12][64]   (same memory, later)
     float *lfs = lms + n_slots * (12 * WAVE);        // rnea force slots   [slot][6][64]
     const bool fast = cx.full && (n & 1);
 
@@ -38,7 +39,6 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
     tile_load<0>(f + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_QDD));
     for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
-    for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     float *hrow = lh + lane * Sh;
     if (zero_fill)
         for (int i = 0; i < nn; ++i) hrow[i] = 0.0f; // pairs of joints on different branches
@@ -66,18 +66,23 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
         };
         auto sslot_save = [&](int s, int j, const Axis &a) {
-            float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+            float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
         };
         auto sslot_load = [&](int s, int j, Axis &a) {
-            const float *b = lss + (s * CAP + j) * (6 * WAVE) + lane;
+            const float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
         };
-        auto hout = [&](int di, int dj, float v) { hrow[di * n + dj] = v; };
+        auto hout = [&](int di, int dj, float v) {
+            if (di >= dj) hrow[tri_index(di, dj)] = v;
+        };
         crba_walk<CAP>(ops_f, ops_i, qf1, islot_add, islot_take, sslot_save, sslot_load, hout);
     }
+    wave_lds_sync(); // the composite-inertia walk is done with the slot memory
+    for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
+    wave_lds_sync();
     {
         // bias torques: RNEA with zero joint accelerations (robot_model.py:377-400); rhs = f - nle, over f
         auto qf3 = [&](int d, float &a, float &v, float &acc) {
@@ -133,11 +138,13 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if (!q || !qd || !f || !qdd) return fail(DRM_ERR_INVALID, "q / qd / f / qdd must not be NULL");
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
-    const int n = w->n_dofs, nn = n * n;
+    const int n = w->n_dofs, nn = n * (n + 1) / 2;
+    const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
+    if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
     Geometry g;
     rc = make_geometry(B, 3 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(nn)) +
-                              w->n_slots * (28 + 6 * w->capacity) * WAVE, g);
-    if (rc) return fail(DRM_ERR_UNSUPPORTED, "forward dynamics keeps the %s%ld x %ld inertia matrix of 64 samples in LDS; "
+                              w->n_slots * ((10 + 6 * sdepth) > 18 ? (10 + 6 * sdepth) : 18) * WAVE, g);
+    if (rc) return fail(DRM_ERR_UNSUPPORTED, "forward dynamics keeps the %s%ld x %ld inertia matrix (lower triangle) of 64 samples in LDS; "
                                              "this robot does not fit", "", (long)n, (long)n);
     const int zero_fill = (w->shape & DRM_WALK_ARM_CHAIN) ? 0 : 1;
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
@@ -146,7 +153,7 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         rc = ensure_lds(forward_dynamics_kernel<C>, g.lds_bytes);
         if (rc) return rc;
         hipLaunchKernelGGL(forward_dynamics_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                           (int)w->n_slots, (int)flags, zero_fill, q, qd, f, B, qdd, div_magic(n), g.lds_per_wave, align);
+                           (int)w->n_slots, sdepth, (int)flags, zero_fill, q, qd, f, B, qdd, div_magic(n), g.lds_per_wave, align);
     })
     return launched();
 }

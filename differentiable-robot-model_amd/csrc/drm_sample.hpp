@@ -1314,32 +1314,36 @@ DRM_HD void crba_walk(const float *__restrict__ opf, const int32_t *__restrict__
 
 // ---------------------------------------------------------------------------
 // Solve H x = b for one sample, H symmetric positive definite (the joint-space inertia matrix), by an in-place
-// Cholesky factorisation H = L L^T of the lower triangle followed by the two triangular solves.  H is the
-// lane's row-major n x n block (LDS in the kernel); b is overwritten with x.
+// Cholesky factorisation H = L L^T followed by the two triangular solves.  H is the lane's PACKED LOWER TRIANGLE
+// (entry (i, j), i >= j, at i (i + 1) / 2 + j; LDS in the kernel); b is overwritten with x.
 // Used by the forward-dynamics kernel: qdd = H^-1 (f - nle) is the same linear system the reference's
 // articulated-body recursion (robot_model.py:487-624) solves link by link.
 // ---------------------------------------------------------------------------
+DRM_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 DRM_HD void cholesky_solve(int n, float *H, float *b) {
     for (int j = 0; j < n; ++j) {
-        float s = H[j * n + j];
-        for (int k = 0; k < j; ++k) s -= H[j * n + k] * H[j * n + k];
+        float *Hj = H + tri_index(j, 0);
+        float s = Hj[j];
+        for (int k = 0; k < j; ++k) s -= Hj[k] * Hj[k];
         const float inv = rsqrt_f(s);
-        H[j * n + j] = inv; // the diagonal keeps 1 / L_jj
+        Hj[j] = inv; // the diagonal keeps 1 / L_jj
         for (int i = j + 1; i < n; ++i) {
-            float t = H[i * n + j];
-            for (int k = 0; k < j; ++k) t -= H[i * n + k] * H[j * n + k];
-            H[i * n + j] = t * inv;
+            float *Hi = H + tri_index(i, 0);
+            float t = Hi[j];
+            for (int k = 0; k < j; ++k) t -= Hi[k] * Hj[k];
+            Hi[j] = t * inv;
         }
     }
     for (int i = 0; i < n; ++i) {
+        const float *Hi = H + tri_index(i, 0);
         float t = b[i];
-        for (int k = 0; k < i; ++k) t -= H[i * n + k] * b[k];
-        b[i] = t * H[i * n + i];
+        for (int k = 0; k < i; ++k) t -= Hi[k] * b[k];
+        b[i] = t * Hi[i];
     }
     for (int i = n - 1; i >= 0; --i) {
         float t = b[i];
-        for (int k = i + 1; k < n; ++k) t -= H[k * n + i] * b[k];
-        b[i] = t * H[i * n + i];
+        for (int k = i + 1; k < n; ++k) t -= H[tri_index(k, i)] * b[k];
+        b[i] = t * H[tri_index(i, i)];
     }
 }
 

@@ -311,8 +311,10 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     n = spec.n_dofs
     arm = (n_ops >= n and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
                               for k, row in enumerate(ops)))
+    # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
+    branch_depth = max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0)
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
-                       max_used, cap, tlist, mask, unique, SHAPE_ARM_CHAIN if arm else 0)
+                       max_used, cap, tlist, mask, unique, (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8))
 
 
 def identity_table_row() -> np.ndarray:

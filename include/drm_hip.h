@@ -74,6 +74,9 @@ extern "C" {
 /* drm_walk.shape */
 #define DRM_WALK_ARM_CHAIN 1 /* a serial chain: ops 0..n_dofs-1 are moving joints driving DoF columns
                                 0..n_dofs-1 in order, every later op is a fixed joint or padding  */
+#define DRM_WALK_BRANCH_DEPTH(shape) (((shape) >> 8) & 0xff) /* 1 + the largest op index that is a branch
+                                point (0: none): sizes the per-ancestor slot records of drm_crba /
+                                drm_forward_dynamics                                               */
 
 /* flags of drm_rnea */
 #define DRM_RNEA_GRAVITY 1 /* base acceleration (0,0,+9.81)   (robot_model.py:344-350)         */

@@ -202,13 +202,15 @@ void crba_t(const drm_walk *w, const float *q, int64_t B, float *H) {
 template <int CAP>
 void fd_t(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
     const int n = w->n_dofs;
-    static thread_local float H[DRM_MAX_DOFS * DRM_MAX_DOFS];
+    static thread_local float H[DRM_MAX_DOFS * DRM_MAX_DOFS], T[DRM_MAX_DOFS * (DRM_MAX_DOFS + 1) / 2];
     for (int64_t b = 0; b < B; ++b) {
         crba_t<CAP>(w, q + b * n, 1, H);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) T[tri_index(i, j)] = H[i * n + j];
         float *x = qdd + b * n;
         rnea_t<CAP>(w, q + b * n, qd + b * n, nullptr, 1, flags, x);
         for (int d = 0; d < n; ++d) x[d] = f[b * n + d] - x[d];
-        cholesky_solve(n, H, x);
+        cholesky_solve(n, T, x);
     }
 }
 
