@@ -15,9 +15,38 @@ constant, or — after ``make_link_param_learnable`` — an ``nn.Module`` regist
 under the same attribute name (robot_model.py:682-689), whose output feeds the
 kernels' constant table through differentiable torch ops.
 """
+import weakref
 from typing import List, Optional
 
 import torch
+
+
+class LinkPose(object):
+    """World pose of a link after ``update_kinematic_state``: the accessors of the reference's
+    ``CoordinateTransform`` that callers read (spatial_vector_algebra.py:56-136)."""
+
+    def __init__(self, rot: torch.Tensor, trans: torch.Tensor, quat: Optional[torch.Tensor] = None):
+        self._rot, self._trans, self._quat = rot, trans, quat
+
+    def rotation(self):
+        return self._rot
+
+    def translation(self):
+        return self._trans
+
+    def get_quaternion(self):
+        return self._quat
+
+
+class LinkVelocity(object):
+    """Body-frame spatial velocity of a link at its origin: ``.lin`` / ``.ang`` as in the reference's
+    ``SpatialMotionVec`` (spatial_vector_algebra.py:175-250)."""
+
+    def __init__(self, lin: torch.Tensor, ang: torch.Tensor):
+        self.lin, self.ang = lin, ang
+
+    def get_vector(self):
+        return torch.cat([self.ang, self.lin], dim=1)
 
 
 class SpatialRigidBodyInertiaParams(torch.nn.Module):
@@ -56,6 +85,22 @@ class DifferentiableRigidBody(torch.nn.Module):
 
         self.joint_axis = rigid_body_params["joint_axis"]
         self.joint_limits = rigid_body_params["joint_limits"]
+        self._model_ref = None   # set by the model: (weakref to it, this link's index)
+
+    # State written by ``update_kinematic_state`` in the reference (robot_model.py:186, 193).  The kernels keep
+    # no per-link state; these are computed on first access from the (q, qd) the model was last updated with.
+    @property
+    def pose(self) -> LinkPose:
+        model, idx = self._model_ref[0](), self._model_ref[1]
+        return model._link_pose(idx)
+
+    @property
+    def vel(self) -> LinkVelocity:
+        model, idx = self._model_ref[0](), self._model_ref[1]
+        return model._link_velocity(idx)
+
+    def _attach(self, model, idx: int):
+        object.__setattr__(self, "_model_ref", (weakref.ref(model), idx))
 
     # kinematic tree bookkeeping (names as in rigid_body.py:78-82)
     def set_parent(self, link: "DifferentiableRigidBody"):

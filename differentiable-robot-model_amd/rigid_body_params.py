@@ -8,6 +8,8 @@ with ``make_link_param_learnable`` (the reference's own modules included).  The
 three generic ones used by the reference's kinematics examples are provided here
 under the same names and constructor arguments.
 """
+import math
+
 import torch
 
 
@@ -52,3 +54,138 @@ class UnconstrainedTensor(torch.nn.Module):
 
     def forward(self):
         return self.param
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3x3 inertia-matrix parametrisations (reference rigid_body_params.py:58-420).  Same class names, constructor
+# arguments and parameter layout as the reference, so checkpoints and call sites carry over: the six free numbers
+# live in ``self.l`` = [three diagonal entries, then the strictly-lower entries (1,0), (2,0), (2,1)].
+# They run upstream of the kernels (once per step, 3x3), so they are plain torch.
+# ---------------------------------------------------------------------------------------------------------
+_DIAG = ([0, 1, 2], [0, 1, 2])
+_LOWER = ([1, 2, 2], [0, 0, 1])
+
+
+def _pack_diag_lower(mat: torch.Tensor) -> torch.Tensor:
+    mat = torch.as_tensor(mat, dtype=torch.float32).reshape(3, 3)
+    return torch.cat([mat[_DIAG], mat[_LOWER]])
+
+
+def _lower_triangular(l: torch.Tensor) -> torch.Tensor:
+    L = l.new_zeros(3, 3)
+    L[_DIAG] = l[:3]
+    L[_LOWER] = l[3:]
+    return L
+
+
+class Symm3DInertiaMatrixNet(torch.nn.Module):
+    """Any symmetric 3x3 matrix: diag(l[:3]) + off-diagonals l[3:] mirrored.  (reference rigid_body_params.py:387-404)"""
+
+    def __init__(self, init_param_std=0.01, init_param=None, is_initializing_params=True):
+        super().__init__()
+        if init_param is None or not is_initializing_params:
+            value = torch.empty(6).normal_(mean=0.0, std=init_param_std)
+        else:
+            value = _pack_diag_lower(init_param)
+        self.l = torch.nn.Parameter(value.clone())
+
+    def forward(self):
+        off = self.l.new_zeros(3, 3)
+        off[_LOWER] = self.l[3:]
+        return torch.diag(self.l[:3]) + off + off.t()
+
+
+class SymmPosDef3DInertiaMatrixNet(torch.nn.Module):
+    """Symmetric positive definite by construction: L L^T + bias I with L lower triangular from ``l``.
+    (reference rigid_body_params.py:342-384)"""
+
+    def __init__(self, bias=1e-7, init_param_std=0.01, init_param=None, is_initializing_params=True):
+        super().__init__()
+        self.spd_3d_inertia_mat_diag_bias = float(bias)
+        if init_param is None or not is_initializing_params:
+            value = torch.empty(6).normal_(mean=0.0, std=init_param_std)
+        else:
+            target = torch.as_tensor(init_param, dtype=torch.float64).reshape(3, 3) - bias * torch.eye(3, dtype=torch.float64)
+            value = _pack_diag_lower(torch.linalg.cholesky(target).to(torch.float32))
+        self.l = torch.nn.Parameter(value.clone())
+
+    def forward(self):
+        L = _lower_triangular(self.l)
+        return L @ L.t() + self.spd_3d_inertia_mat_diag_bias * torch.eye(3, device=self.l.device)
+
+
+class CovParameterized3DInertiaMatrixNet(torch.nn.Module):
+    """Physically consistent inertia: the density-weighted covariance Sigma = L L^T + bias I is what is
+    parametrised, and I = tr(Sigma) E - Sigma (Wensing et al. 2017, IV.A-B; reference rigid_body_params.py:252-339),
+    which enforces the triangle inequalities of the principal moments."""
+
+    def __init__(self, bias=1.0e-7, init_param_std=0.01, init_param=None, is_initializing_params=True):
+        super().__init__()
+        self.spd_3d_cov_inertia_mat_diag_bias = float(bias)
+        if init_param is None or not is_initializing_params:
+            value = torch.empty(6).normal_(mean=0.0, std=init_param_std)
+        else:
+            inertia = torch.as_tensor(init_param, dtype=torch.float64).reshape(3, 3)
+            cov = 0.5 * torch.trace(inertia) * torch.eye(3, dtype=torch.float64) - inertia
+            value = _pack_diag_lower(torch.linalg.cholesky(cov - bias * torch.eye(3, dtype=torch.float64)).to(torch.float32))
+        self.l = torch.nn.Parameter(value.clone())
+
+    def forward(self):
+        L = _lower_triangular(self.l)
+        eye = torch.eye(3, device=self.l.device)
+        cov = L @ L.t() + self.spd_3d_cov_inertia_mat_diag_bias * eye
+        return torch.trace(cov) * eye - cov
+
+
+def _exp_so3(omega: torch.Tensor) -> torch.Tensor:
+    """Rotation matrix of an axis-angle vector (Rodrigues), well-behaved at zero angle."""
+    theta2 = (omega * omega).sum()
+    theta = torch.sqrt(theta2 + 1e-30)
+    K = omega.new_zeros(3, 3)
+    K[0, 1], K[0, 2], K[1, 0], K[1, 2], K[2, 0], K[2, 1] = -omega[2], omega[1], omega[2], -omega[0], -omega[1], omega[0]
+    a = torch.where(theta2 > 1e-12, torch.sin(theta) / theta, 1.0 - theta2 / 6.0)
+    b = torch.where(theta2 > 1e-12, (1.0 - torch.cos(theta)) / (theta2 + 1e-30), 0.5 - theta2 / 24.0)
+    return torch.eye(3, device=omega.device) + a * K + b * (K @ K)
+
+
+def _log_so3(R: torch.Tensor) -> torch.Tensor:
+    """Axis-angle vector of a rotation matrix (float64 in, angle < pi)."""
+    cos = ((torch.trace(R) - 1.0) / 2.0).clamp(-1.0, 1.0)
+    theta = torch.acos(cos)
+    w = torch.stack([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    scale = torch.where(theta > 1e-8, theta / (2.0 * torch.sin(theta) + 1e-30), torch.tensor(0.5, dtype=R.dtype))
+    return w * scale
+
+
+class TriangParam3DInertiaMatrixNet(torch.nn.Module):
+    """I = R diag(J1, J2, J3) R^T with J3 = sqrt(J1^2 + J2^2 - 2 J1 J2 cos(alpha)), 0 < alpha < pi: principal moments
+    that satisfy the triangle inequalities by construction, R = exp of an axis-angle parameter.
+    (reference rigid_body_params.py:137-249; its constructor passes an argument its ``UnconstrainedTensor`` does not
+    take, so it cannot be instantiated there — the construction it describes is implemented here.)"""
+
+    def __init__(self, bias, init_param_std=0.01, init_param=None, is_initializing_params=True):
+        super().__init__()
+        self._bias = float(bias)
+        axis_angle, j1, j2, alpha_param = torch.empty(3).normal_(mean=0.0, std=init_param_std), None, None, None
+        if init_param is not None and is_initializing_params:
+            inertia = torch.as_tensor(init_param, dtype=torch.float64).reshape(3, 3)
+            R, J, _ = torch.linalg.svd(inertia)
+            if torch.linalg.det(R) < 0:   # a member of SO(3), not just O(3)
+                R = R.clone()
+                R[:, 0] = -R[:, 0]
+            axis_angle = _log_so3(R).to(torch.float32)
+            j1, j2 = J[0].to(torch.float32), J[1].to(torch.float32)
+            assert j1 > bias and j2 > bias, "Please set bias value smaller, such that this condition is satisfied!"
+            alpha = torch.acos(((J[0] ** 2 + J[1] ** 2 - J[2] ** 2) / (2.0 * J[0] * J[1])).clamp(-1.0, 1.0)) / math.pi
+            alpha_param = torch.log(alpha / (1.0 - alpha)).to(torch.float32).reshape(1, 1)   # inverse sigmoid
+        self.inertia_ori_axis_angle = torch.nn.Parameter(axis_angle.clone())
+        self.J1net = PositiveScalar(min_val=bias, init_param_std=0.1, init_param=j1)
+        self.J2net = PositiveScalar(min_val=bias, init_param_std=0.1, init_param=j2)
+        self.alpha_param_net = UnconstrainedTensor(dim1=1, dim2=1, init_tensor=alpha_param, init_std=init_param_std)
+
+    def forward(self):
+        alpha = math.pi * torch.sigmoid(self.alpha_param_net().reshape(()))
+        j1, j2 = self.J1net().reshape(()), self.J2net().reshape(())
+        j3 = torch.sqrt(j1 * j1 + j2 * j2 - 2.0 * j1 * j2 * torch.cos(alpha))
+        R = _exp_so3(self.inertia_ori_axis_angle)
+        return R @ torch.diag(torch.stack([j1, j2, j3])) @ R.t()

@@ -23,7 +23,7 @@ import torch
 
 from . import backend
 from .flatten import OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, identity_table_row
-from .rigid_body import DifferentiableRigidBody
+from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
 
 robot_description_folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robot_data")
@@ -179,11 +179,14 @@ class DifferentiableRobotModel(torch.nn.Module):
             body_params.append(params)
             parent_names.append(None if i == 0 else self._urdf_model.get_name_of_parent_body(link.name))
         for i, body in enumerate(self._bodies):
+            body._attach(self, i)
             if i == 0:
                 continue
             parent = self._bodies[self._name_to_idx_map[parent_names[i]]]
             body.set_parent(parent)
             parent.add_child(body)
+        self._kin_state = None   # (q, qd) of the last update_kinematic_state
+        self._kin_cache = {}
 
         self._spec: RobotSpec = build_robot_spec(body_params, parent_names)
         self._learnable = set()          # {(link_idx, parameter_name)}
@@ -294,6 +297,54 @@ class DifferentiableRobotModel(torch.nn.Module):
             raise RuntimeError(
                 "differentiable-robot-model_amd has no CPU compute path: construct the model with "
                 "device='cuda' on an MI355X (model device is %s)" % self._device)
+
+    # ------------------------------------------------------------------ kinematic state (reference API)
+    @tensor_check
+    def update_kinematic_state(self, q: torch.Tensor, qd: torch.Tensor) -> None:
+        """Record the joint state; ``body.pose`` / ``body.vel`` of every link then reflect it (robot_model.py:139-195).
+
+        The reference walks the tree here and stores a pose and a velocity on every body; the kernels are
+        stateless, so this only remembers (q, qd) and the per-link quantities are evaluated when read:
+        poses by one all-links FK launch, a link's body-frame velocity from its Jacobian (R^T J qd).
+        """
+        assert q.ndim == 2
+        assert qd.ndim == 2
+        assert q.shape[1] == self._n_dofs
+        assert qd.shape[1] == self._n_dofs
+        self._kin_state = (q.detach(), qd.detach())
+        self._kin_cache = {}
+
+    def _all_poses(self):
+        if "poses" not in self._kin_cache:
+            q = self._kin_state[0]
+            with torch.no_grad():
+                pos, quat = self._fk_targets(q, list(range(len(self._bodies))))
+            x, y, z, w = quat.unbind(-1)
+            rot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                               2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                               2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)
+            self._kin_cache["poses"] = (pos, quat, rot.reshape(*quat.shape[:-1], 3, 3))
+        return self._kin_cache["poses"]
+
+    def _link_pose(self, idx: int) -> LinkPose:
+        if self._kin_state is None:   # a fresh body sits at the identity (rigid_body.py:64-76)
+            return LinkPose(torch.eye(3, device=self._device).unsqueeze(0), torch.zeros(1, 3, device=self._device),
+                            torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self._device))
+        pos, quat, rot = self._all_poses()
+        return LinkPose(rot[:, idx], pos[:, idx], quat[:, idx])
+
+    def _link_velocity(self, idx: int) -> LinkVelocity:
+        if self._kin_state is None:
+            return LinkVelocity(torch.zeros(1, 3, device=self._device), torch.zeros(1, 3, device=self._device))
+        key = ("vel", idx)
+        if key not in self._kin_cache:
+            q, qd = self._kin_state
+            rot = self._all_poses()[2][:, idx]
+            with torch.no_grad():
+                lin, ang = self.compute_endeffector_jacobian(q, self._bodies[idx].name)
+            to_body = lambda jac: torch.einsum("bji,bj->bi", rot, torch.einsum("bij,bj->bi", jac, qd))
+            self._kin_cache[key] = LinkVelocity(to_body(lin), to_body(ang))
+        return self._kin_cache[key]
 
     # ------------------------------------------------------------------ FK
     def _fk_targets(self, q: torch.Tensor, link_idxs: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -242,3 +242,25 @@ def test_allegro_fingertips_full_batch():
     moved = (host(pos2) - host(pos)).reshape(65536, 4, 3)
     still = [t for t in range(4) if np.abs(moved[:, t]).max() == 0.0]
     assert len(still) == 3
+
+
+def test_update_kinematic_state_exposes_body_pose_and_velocity():
+    """robot_model.py:139-195: after update_kinematic_state every body carries its world pose and its body-frame
+    spatial velocity; here they are evaluated lazily from the recorded (q, qd)."""
+    m = load_model("panda_no_gripper", "cuda")
+    fresh = m._bodies[3].pose
+    assert torch.equal(fresh.rotation()[0], torch.eye(3).cuda()) and not fresh.translation().any()
+    q, qd, _ = sample_states(m, 33, seed=12)
+    m.update_kinematic_state(dev(q), dev(qd))
+    orc = Oracle(m._spec)
+    R, p = orc.fk_all_poses(q.astype(np.float64), np.float64)
+    for i in (1, 4, 8):
+        pose = m._bodies[i].pose
+        assert max_err(host(pose.translation()), p[:, i]) <= TOL_POS["atol"]
+        assert max_err(host(pose.rotation()), R[:, i]) <= 2e-6
+        # body-frame velocity: v = R^T J_lin qd, w = R^T J_ang qd (oracle Jacobians)
+        _, _, lin, ang = orc.fk_jacobian(q.astype(np.float64), i, np.float64)
+        v_ref = np.einsum("bji,bj->bi", R[:, i], np.einsum("bij,bj->bi", lin, qd.astype(np.float64)))
+        w_ref = np.einsum("bji,bj->bi", R[:, i], np.einsum("bij,bj->bi", ang, qd.astype(np.float64)))
+        vel = m._bodies[i].vel
+        assert max_err(host(vel.lin), v_ref) <= 5e-6 and max_err(host(vel.ang), w_ref) <= 5e-6
