@@ -39,7 +39,8 @@ _lock = threading.Lock()
 
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
-           "drm_rnea_backward_scratch_floats", "drm_forward_dynamics")
+           "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
+           "drm_link_rows_backward")
 
 
 def load_library(path: str = None):
@@ -77,6 +78,10 @@ def load_library(path: str = None):
         lib.drm_rnea_backward.argtypes = [wp, vp, vp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
         lib.drm_rnea_backward_scratch_floats.restype = i64
         lib.drm_rnea_backward_scratch_floats.argtypes = [i64, i32, i32, i32]
+        lib.drm_link_rows.restype = ctypes.c_int
+        lib.drm_link_rows.argtypes = [vp, i32, vp, vp]
+        lib.drm_link_rows_backward.restype = ctypes.c_int
+        lib.drm_link_rows_backward.argtypes = [vp, vp, i32, vp, vp]
         lib.drm_forward_dynamics.restype = ctypes.c_int
         lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
         lib.drm_crba.restype = ctypes.c_int
@@ -194,6 +199,34 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
                                      ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
                                      ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)))
     return gin, grad_ops
+
+
+class LinkRows(torch.autograd.Function):
+    """[n, 20] URDF-level link parameters -> [n, 32] link-table rows, with a hand-written backward: two tiny
+    kernels instead of ~150 eager torch kernels per training step (the reference rebuilds these quantities with one
+    torch op per matrix entry on every call)."""
+
+    @staticmethod
+    def forward(ctx, params):
+        lib = load_library()
+        params = params.contiguous().to(torch.float32)
+        rows = torch.empty(params.shape[0], 32, device=params.device, dtype=torch.float32)
+        with torch.cuda.device(params.device):
+            _check(lib.drm_link_rows(params.data_ptr(), params.shape[0], rows.data_ptr(), _stream(params.device)))
+        ctx.save_for_backward(params)
+        return rows
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_rows):
+        (params,) = ctx.saved_tensors
+        lib = load_library()
+        grad_rows = grad_rows.contiguous().to(torch.float32)
+        grad = torch.empty_like(params)
+        with torch.cuda.device(params.device):
+            _check(lib.drm_link_rows_backward(params.data_ptr(), grad_rows.data_ptr(), params.shape[0], grad.data_ptr(),
+                                              _stream(params.device)))
+        return grad
 
 
 def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):

@@ -130,8 +130,11 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
 // The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
 // ---------------------------------------------------------------------------------------------------
+#ifndef DRM_ARM_WPB
+#define DRM_ARM_WPB MAX_WAVES_PER_BLOCK /* waves per block of the arm kernels (a packing choice: waves are independent) */
+#endif
 template <int CAP, int NJ, bool JAC>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+__global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
     fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
                            float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
                            float *__restrict__ ang) {
@@ -145,9 +148,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     // pos is staged over the q tile (q lives in registers by then): 51.7 KB per block, three blocks per CU
     static_assert(P_FLOATS <= Q_FLOATS, "pos staging overlays the q tile");
     constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? 2 * J_FLOATS : 0);
-    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float smem[DRM_ARM_WPB * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    const int tile = (int)blockIdx.x * DRM_ARM_WPB + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
@@ -237,8 +240,8 @@ int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, 
         return 0;
     const int n_tiles = (int)(B / WAVE);
     hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, false>),
-                       dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, pos, quat, (float *)nullptr,
+                       dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
+                       dim3(WAVE * DRM_ARM_WPB), 0, s, w->ops_f, q, n_tiles, pos, quat, (float *)nullptr,
                        (float *)nullptr);
     return (int64_t)n_tiles * WAVE;
 #endif
@@ -284,8 +287,8 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
         // any) through the generic one
         const int n_tiles = (int)(B / WAVE);
         hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true>),
-                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+                           dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
+                           dim3(WAVE * DRM_ARM_WPB), 0, s, w->ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done < B) {
             rc = launched();

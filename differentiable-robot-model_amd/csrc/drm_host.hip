@@ -2,6 +2,7 @@
 #include <string.h>
 
 #include "drm_common.hpp"
+#include "drm_sample.hpp"
 
 namespace drm {
 
@@ -54,7 +55,48 @@ const char *last_error() { return g_err; }
 
 } // namespace drm
 
+namespace drm {
+__global__ void link_rows_kernel(const float *__restrict__ params, int n_links, float *__restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_links) return;
+    float p[LINK_PARAM_FLOATS], row[DRM_OPF_STRIDE];
+#pragma unroll
+    for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[i * LINK_PARAM_FLOATS + k];
+    link_row(p, row);
+#pragma unroll
+    for (int k = 0; k < DRM_OPF_STRIDE; ++k) rows[i * DRM_OPF_STRIDE + k] = row[k];
+}
+__global__ void link_rows_backward_kernel(const float *__restrict__ params, const float *__restrict__ grad_rows, int n_links,
+                                          float *__restrict__ grad_params) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_links) return;
+    float p[LINK_PARAM_FLOATS], g[DRM_OPF_STRIDE], gp[LINK_PARAM_FLOATS];
+#pragma unroll
+    for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[i * LINK_PARAM_FLOATS + k];
+#pragma unroll
+    for (int k = 0; k < DRM_OPF_STRIDE; ++k) g[k] = grad_rows[i * DRM_OPF_STRIDE + k];
+    link_row_backward(p, g, gp);
+#pragma unroll
+    for (int k = 0; k < LINK_PARAM_FLOATS; ++k) grad_params[i * LINK_PARAM_FLOATS + k] = gp[k];
+}
+} // namespace drm
+
 extern "C" {
+int drm_link_rows(const float *params, int32_t n_links, float *rows, void *stream) {
+    if (!params || !rows || n_links < 0) return drm::fail(DRM_ERR_INVALID, "params / rows must not be NULL, n_links >= 0");
+    if (n_links == 0) return DRM_OK;
+    hipLaunchKernelGGL(drm::link_rows_kernel, dim3((unsigned)((n_links + 63) / 64)), dim3(64), 0, (hipStream_t)stream, params,
+                       (int)n_links, rows);
+    return drm::launched();
+}
+int drm_link_rows_backward(const float *params, const float *grad_rows, int32_t n_links, float *grad_params, void *stream) {
+    if (!params || !grad_rows || !grad_params || n_links < 0)
+        return drm::fail(DRM_ERR_INVALID, "params / grad_rows / grad_params must not be NULL, n_links >= 0");
+    if (n_links == 0) return DRM_OK;
+    hipLaunchKernelGGL(drm::link_rows_backward_kernel, dim3((unsigned)((n_links + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       params, grad_rows, (int)n_links, grad_params);
+    return drm::launched();
+}
 int drm_abi_version(void) { return DRM_ABI_VERSION; }
 const char *drm_last_error(void) { return drm::last_error(); }
 }

@@ -1160,6 +1160,97 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------
+// Link-table rows from URDF-level link parameters, and the reverse-mode derivative of that map: what the
+// reference recomputes with ~60 tiny torch ops per link on every call (rigid_body.py:138-143 R_fixed = (Rz Ry) Rx;
+// spatial_vector_algebra.py:321-327 mcom = m com, I_o = I_c + m S(com) S(com)^T) and differentiates with as many
+// autograd nodes.  One link per thread; used for the rows of LEARNABLE links only (constant rows are built once).
+//   p[20]  : rpy (3), trans (3), mass (1), com (3), inertia_mat (9, about the com), damping (1)
+//   row[32]: link-table layout  F (9) t (3) m (1) mcom (3) I_o (9) damping (1) 0...
+// ---------------------------------------------------------------------------
+constexpr int LINK_PARAM_FLOATS = 20;
+DRM_HD void rpy_factors(const float *rpy, float *Rx, float *Ry, float *Rz, float *cs) {
+    float sr, cr, sp, cp, sy, cy;
+    sincos_f(rpy[0], sr, cr);
+    sincos_f(rpy[1], sp, cp);
+    sincos_f(rpy[2], sy, cy);
+    const float rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp},
+                rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { Rx[i] = rx[i]; Ry[i] = ry[i]; Rz[i] = rz[i]; }
+    cs[0] = sr; cs[1] = cr; cs[2] = sp; cs[3] = cp; cs[4] = sy; cs[5] = cy;
+}
+DRM_HD void mat3_mul(const float *A, const float *B, float *C) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3 + 0] * B[0 * 3 + c] + A[r * 3 + 1] * B[1 * 3 + c] + A[r * 3 + 2] * B[2 * 3 + c];
+}
+DRM_HD void link_row(const float *p, float *row) {
+    float Rx[9], Ry[9], Rz[9], cs[6], T[9];
+    rpy_factors(p, Rx, Ry, Rz, cs);
+    mat3_mul(Rz, Ry, T);
+    mat3_mul(T, Rx, row);
+    const float m = p[6];
+    const float *t = p + 3, *c = p + 7, *I = p + 10;
+    const float c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { row[9 + i] = t[i]; row[13 + i] = c[i] * m; }
+    row[12] = m;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row[16 + r * 3 + k] = I[r * 3 + k] + m * ((r == k ? c2 : 0.0f) - c[r] * c[k]);
+    row[25] = p[19];
+#pragma unroll
+    for (int i = 26; i < DRM_OPF_STRIDE; ++i) row[i] = 0.0f;
+}
+DRM_HD void link_row_backward(const float *p, const float *g, float *gp) {
+    float Rx[9], Ry[9], Rz[9], cs[6], T[9], D[9], E[9];
+    rpy_factors(p, Rx, Ry, Rz, cs);
+    const float sr = cs[0], cr = cs[1], sp = cs[2], cp = cs[3], sy = cs[4], cy = cs[5];
+    auto dot9 = [&](const float *A) {
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a += A[i] * g[i];
+        return a;
+    };
+    // F = (Rz Ry) Rx: derivative factors
+    const float dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp},
+                dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
+    mat3_mul(Rz, Ry, T);
+    mat3_mul(T, dRx, D);
+    gp[0] = dot9(D);
+    mat3_mul(Rz, dRy, E);
+    mat3_mul(E, Rx, D);
+    gp[1] = dot9(D);
+    mat3_mul(dRz, Ry, E);
+    mat3_mul(E, Rx, D);
+    gp[2] = dot9(D);
+    const float m = p[6];
+    const float *c = p + 7;
+    const float *gI = g + 16;
+    const float c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2], trG = gI[0] + gI[4] + gI[8];
+    float gm = g[12], cGc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gp[3 + i] = g[9 + i]; gm += c[i] * g[13 + i]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cGc += gI[r * 3 + k] * c[r] * c[k];
+    gp[6] = gm + (c2 * trG - cGc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float Gc = 0.0f; // ((G + G^T) c)_i
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Gc += (gI[i * 3 + k] + gI[k * 3 + i]) * c[k];
+        gp[7 + i] = m * g[13 + i] + m * (2.0f * c[i] * trG - Gc);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gp[10 + i] = gI[i];
+    gp[19] = g[25];
+}
+
+// ---------------------------------------------------------------------------
 // Joint-space inertia matrix H(q) by the composite-rigid-body algorithm.
 //
 // The reference builds H column by column from n + 1 inverse-dynamics passes (robot_model.py:402-450:

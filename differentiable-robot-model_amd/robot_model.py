@@ -244,7 +244,26 @@ class DifferentiableRobotModel(torch.nn.Module):
         links = sorted({link for link, _ in self._learnable})
         if self._learnable_links is None or self._learnable_links.numel() != len(links):
             self._learnable_links = torch.tensor(links, dtype=torch.int64, device=self._device)
-        return self._static_table.index_copy(0, self._learnable_links, self._link_rows(links))
+        if self._device.type == "cuda":
+            # the rows of the learnable links through the fused parameter kernels (backend.LinkRows)
+            rows = backend.LinkRows.apply(self._link_params(links))
+        else:
+            rows = self._link_rows(links)   # host-side tests of the table construction
+        return self._static_table.index_copy(0, self._learnable_links, rows)
+
+    def _link_params(self, link_idxs) -> torch.Tensor:
+        """[len(link_idxs), 20] rpy, trans, mass, com, inertia_mat, damping of the given links (include/drm_hip.h
+        drm_link_rows), read from the bodies' parameter callables so that gradients reach learnable modules."""
+        dev = self._device
+        zero1 = torch.zeros(1, device=dev)
+        rows = []
+        for i in link_idxs:
+            b = self._bodies[i]
+            damping = b.joint_damping()
+            rows.append(torch.cat([t.reshape(-1).to(dev) for t in (
+                b.rot_angles(), b.trans(), b.inertia.mass(), b.inertia.com(), b.inertia.inertia_mat(),
+                damping if damping is not None else zero1)]))
+        return torch.stack(rows)
 
     def _get_walk(self, key, targets=None, whole_tree=False) -> _DeviceWalk:
         dw = self._walks.get(key)

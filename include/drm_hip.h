@@ -201,6 +201,17 @@ int drm_rnea_backward(const drm_walk *walk, const float *q, const float *qd, con
                       const float *grad_tau, uint32_t param_mask, float *grad_q, float *grad_qd, float *grad_qdd,
                       float *grad_ops_f, float *scratch, void *stream);
 
+/*
+ * Link-table rows from URDF-level link parameters, and the derivative of that map, for the rows of LEARNABLE links
+ * (what the reference recomputes from its parameter modules on every call: rigid_body.py:138-143 R_fixed,
+ * spatial_vector_algebra.py:321-327 mcom and I_o, and differentiates with one autograd node per tiny op).
+ *   params [n_links, 20]  rpy (3) trans (3) mass (1) com (3) inertia_mat (9, about the com) damping (1)
+ *   rows   [n_links, 32]  F (9, row-major) t (3) mass mcom (3) I_o (9) damping 0...   (the host gathers these into
+ *                         walk order; flatten._gather_row)
+ */
+int drm_link_rows(const float *params, int32_t n_links, float *rows, void *stream);
+int drm_link_rows_backward(const float *params, const float *grad_rows, int32_t n_links, float *grad_params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -256,6 +256,15 @@ int emu_forward_dynamics(const drm_walk *w, const float *q, const float *qd, con
     DISPATCH(fd_t, w, q, qd, f, B, flags, qdd)
     return 0;
 }
+int emu_link_rows(const float *params, int32_t n, float *rows) {
+    for (int i = 0; i < n; ++i) link_row(params + i * LINK_PARAM_FLOATS, rows + i * DRM_OPF_STRIDE);
+    return 0;
+}
+int emu_link_rows_backward(const float *params, const float *grad_rows, int32_t n, float *grad_params) {
+    for (int i = 0; i < n; ++i)
+        link_row_backward(params + i * LINK_PARAM_FLOATS, grad_rows + i * DRM_OPF_STRIDE, grad_params + i * LINK_PARAM_FLOATS);
+    return 0;
+}
 int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
     DISPATCH(crba_t, w, q, B, H)
     return 0;

@@ -169,3 +169,41 @@ def test_sincos_large_arguments(emu):
     assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(pos), _ptr(quat)) == 0
     op, oq = Oracle(m._spec).fk(q.astype(np.float64), [3], np.float64)
     assert max_err(pos, op) < 2e-6
+
+
+def test_link_rows_and_their_derivative_vs_torch(emu):
+    """link_row / link_row_backward (the fused parameter kernels) against the torch construction of the same rows
+    (robot_model._link_rows, which mirrors rigid_body.py:138-143 and spatial_vector_algebra.py:321-327) and its
+    autograd."""
+    import torch
+    m = load_model("iiwa7")
+    links = [1, 4, 8]
+    params = m._link_params(links).detach().clone()
+    params += 0.1 * torch.randn(params.shape, generator=torch.Generator().manual_seed(0))   # generic rpy / com / inertia
+    p_np = np.ascontiguousarray(params.numpy(), np.float32)
+    rows = np.zeros((len(links), 32), np.float32)
+    assert emu.emu_link_rows(_ptr(p_np), len(links), _ptr(rows)) == 0
+
+    def torch_rows(p):   # the same map written with torch ops
+        rpy, trans, mass, com, inertia, damp = p[:, 0:3], p[:, 3:6], p[:, 6:7], p[:, 7:10], p[:, 10:19].reshape(-1, 3, 3), p[:, 19:20]
+        c, s = torch.cos(rpy), torch.sin(rpy)
+        one, zero = torch.ones(len(p)), torch.zeros(len(p))
+        mat = lambda r: torch.stack([torch.stack(x, dim=-1) for x in r], dim=-2)
+        Rx = mat([[one, zero, zero], [zero, c[:, 0], -s[:, 0]], [zero, s[:, 0], c[:, 0]]])
+        Ry = mat([[c[:, 1], zero, s[:, 1]], [zero, one, zero], [-s[:, 1], zero, c[:, 1]]])
+        Rz = mat([[c[:, 2], -s[:, 2], zero], [s[:, 2], c[:, 2], zero], [zero, zero, one]])
+        S = mat([[zero, -com[:, 2], com[:, 1]], [com[:, 2], zero, -com[:, 0]], [-com[:, 1], com[:, 0], zero]])
+        Io = inertia + mass.reshape(-1, 1, 1) * (S @ S.transpose(-2, -1))
+        return torch.cat([((Rz @ Ry) @ Rx).reshape(-1, 9), trans, mass, com * mass, Io.reshape(-1, 9), damp,
+                          torch.zeros(len(p), 6)], dim=1)
+
+    pt = params.clone().double().requires_grad_(True)
+    ref = torch_rows(pt.float() if False else pt)
+    assert np.abs(rows - ref.detach().numpy()).max() < 1e-6
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    g[:, 26:] = 0
+    ref.backward(g)
+    g_np = np.ascontiguousarray(g.numpy(), np.float32)
+    gp = np.zeros_like(p_np)
+    assert emu.emu_link_rows_backward(_ptr(p_np), _ptr(g_np), len(links), _ptr(gp)) == 0
+    assert np.abs(gp - pt.grad.numpy()).max() < 2e-6 * max(1.0, np.abs(pt.grad.numpy()).max())
