@@ -48,8 +48,27 @@ typedef float f2 __attribute__((vector_size(8)));
 DRM_HD f2 f2_make(float a, float b) { f2 v = {a, b}; return v; }
 DRM_HD f2 f2_bcast(float a) { f2 v = {a, a}; return v; }
 
-// ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.
-#define DRM_OPI(field, k) opi[(field) * CAP + (k)]
+// ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.  The walks read
+// a single field, the packed control word (DRM_OPI_CTRL, include/drm_hip.h), into `ctl[CAP]` once and decode the
+// fields they branch on with scalar bit-field extracts: no scalar-memory round trip inside the walk.
+// one field of the (field-major) int table for all ops: a single wide scalar load
+template <int CAP>
+DRM_HD void load_field(const int32_t *__restrict__ opi, int field, int (&out)[CAP]) {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) out[k] = opi[field * CAP + k];
+}
+DRM_HD int ctl_field(int ctl, int field) {
+    return field == DRM_OPI_DOF     ? (ctl & 0x7f) - 1
+           : field == DRM_OPI_SRC   ? ((ctl >> 7) & 7) - 2
+           : field == DRM_OPI_SAVE  ? ((ctl >> 10) & 7) - 1
+           : field == DRM_OPI_OUT   ? ((ctl >> 13) & 0x7f) - 1
+           : field == DRM_OPI_PERM  ? (ctl >> 20) & 7
+                                    : (ctl >> 23) & 1; // DRM_OPI_FLAGS
+}
+#define DRM_OPI(field, k) ctl_field(ctl[k], field)
+#define DRM_LOAD_CTL() \
+    int ctl[CAP];      \
+    load_field<CAP>(opi, DRM_OPI_CTRL, ctl)
 
 // sin / cos of a joint angle, branch-free.  Argument reduction k = rint(x 2/pi),
 // r = x - k pi/2 is done in fp64 (two constants), which keeps r exact to fp32
@@ -246,12 +265,6 @@ DRM_HD void joint_trig(const int (&dof)[CAP], QF qf, float *cs, float *sn) {
     }
 }
 
-// one field of the (field-major) int table for all ops: a single wide scalar load
-template <int CAP>
-DRM_HD void load_field(const int32_t *__restrict__ opi, int field, int (&out)[CAP]) {
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) out[k] = opi[field * CAP + k];
-}
 
 // ---------------------------------------------------------------------------
 // FK + geometric Jacobian along one chain (robot_model.py:626-667).
@@ -466,8 +479,10 @@ DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3
 template <int CAP, class QF, class SAVE, class LOAD, class EMIT>
 DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, SAVE slot_save,
                     LOAD slot_load, EMIT emit) {
+    DRM_LOAD_CTL();
     int dof[CAP];
-    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
     float cs[CAP], sn[CAP];
     joint_trig<CAP>(dof, qf, cs, sn);
     // poses travel as packed pairs (see "Packed-FP32 form" above): 27 packed ops per link instead of 48 scalar ones
@@ -524,8 +539,10 @@ template <int CAP, class QF, class GIN, class PSAVE, class PLOAD, class AADD, cl
 DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, uint32_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
                              ATAKE adj_take, GQ gq_out, PG param_out) {
+    DRM_LOAD_CTL();
     int dof[CAP];
-    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
     float cs[CAP], sn[CAP];
     joint_trig<CAP>(dof, qf, cs, sn);
     // ---- forward: world pose of every op, kept for the adjoint sweep -------
@@ -713,9 +730,11 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     Motion cur;
     motion_root(cur, g);
+    DRM_LOAD_CTL();
     {
         int dofs[CAP];
-        load_field<CAP>(opi, DRM_OPI_DOF, dofs);
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) dofs[k] = DRM_OPI(DRM_OPI_DOF, k);
         joint_trig<CAP>(dofs, [&](int d) { float q, v, a; qf(d, q, v, a); return q; }, cs, sn);
     }
 
@@ -890,8 +909,10 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                                SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
+    DRM_LOAD_CTL();
     int dof[CAP];
-    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
     float cs[CAP], sn[CAP];
     joint_trig<CAP>(dof, [&](int d) { float q, v, a; qf(d, q, v, a); return q; }, cs, sn);
     auto joint = [&](int k, float *J, float *t) {
@@ -1318,8 +1339,10 @@ struct Axis { // a joint axis as a motion vector in some frame
 template <int CAP, class QF, class IADD, class ITAKE, class SSAVE, class SLOAD, class HOUT>
 DRM_HD void crba_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, IADD islot_add,
                       ITAKE islot_take, SSAVE sslot_save, SLOAD sslot_load, HOUT hout) {
+    DRM_LOAD_CTL();
     int dof[CAP];
-    load_field<CAP>(opi, DRM_OPI_DOF, dof);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
     float cs[CAP], sn[CAP];
     joint_trig<CAP>(dof, qf, cs, sn);
 

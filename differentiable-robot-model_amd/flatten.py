@@ -30,8 +30,8 @@ target link's columns are restored when its pose is emitted.
 
 Device layout of one op (see include/drm_hip.h, DRM_OPF_* / DRM_OPI_*):
   ops_f[k, 0:32] float32: FT block(12: F and t interleaved in pairs) mass(1) mcom(3) Io(9) damping(1) pad(6)
-  ops_i[0:8, k ] int32  : dof perm sign src save out link flags   (FIELD-MAJOR on the device:
-                          one scalar load fetches one field of many ops)
+  ops_i[0:8, k ] int32  : dof perm ctrl src save out link flags   (FIELD-MAJOR on the device; the kernels read
+                          only `ctrl`, the packed control word, one wide scalar load for the whole walk)
 ``gather`` maps every ops_f entry to a flat index of the [L+1, 32] link table
 (row L = the identity op) and ``gsign`` holds its +-1 factor, so the device table
 is ONE differentiable gather and one multiply.
@@ -60,7 +60,7 @@ def opf_ti(i: int) -> int:
 
 SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
 OPI_STRIDE = 8
-OPI_DOF, OPI_PERM, OPI_SIGN, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
+OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
 FLAG_CHILD_IS_NEXT = 1               # op k+1 is a child of op k (RNEA backward carry)
 MAX_SLOTS = 4                        # save slots available to a walk
@@ -264,8 +264,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                 raise UnsupportedRobotError(
                     "tree needs more than %d nested branch points; not supported by the compiled kernels" % MAX_SLOTS)
         flags = FLAG_CHILD_IS_NEXT if kids else 0
-        # OPI_SIGN is kept for layout stability only: the sign is folded into the constants
-        ops.append([int(spec.dof[i]), spec.perm_code(i), int(spec.axis_sign[i]), src, save, out_of.get(i, -1), i, flags])
+        ops.append([int(spec.dof[i]), spec.perm_code(i), 0, src, save, out_of.get(i, -1), i, flags])
         links.append(i)
         for n, c in enumerate(kids):
             visit(c, SRC_PREV if n == 0 else save)
@@ -304,6 +303,10 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
             gather[k], gsign[k] = _gather_row(spec, link)
     else:
         ops_i[0, OPI_SRC] = SRC_ROOT
+    # the packed control word the kernels read (DRM_OPI_CTRL_PACK in include/drm_hip.h)
+    ops_i[:, OPI_CTRL] = (((ops_i[:, OPI_DOF] + 1) & 0x7f) | (((ops_i[:, OPI_SRC] + 2) & 7) << 7)
+                          | (((ops_i[:, OPI_SAVE] + 1) & 7) << 10) | (((ops_i[:, OPI_OUT] + 1) & 0x7f) << 13)
+                          | ((ops_i[:, OPI_PERM] & 7) << 20) | ((ops_i[:, OPI_FLAGS] & 1) << 23))
     mask = 0
     for row in ops:
         if row[OPI_DOF] >= 0:

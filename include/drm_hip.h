@@ -56,8 +56,19 @@ extern "C" {
                              (rigid_body.py:149-154).  The constants are pre-multiplied by the signed
                              permutation, the kernels rotate every joint about +z of the stored frame by
                              +q and undo the permutation when a target pose is emitted          */
-#define DRM_OPI_SIGN 2    /* informational: +1/-1 = sign of the axis entry, 0 for fixed joints (the sign
-                             is folded into the constants, kernels do not read it)             */
+#define DRM_OPI_CTRL 2    /* the op's control word: every field the kernels branch on, packed so that ONE
+                             wide scalar load brings the control flow of the whole walk (a lone wave cannot
+                             hide a scalar-load round trip per field and op):
+                               bits  0..6  DoF column + 1 (0 = fixed joint)
+                               bits  7..9  source + 2     (0 = root, 1 = previous op, 2.. = save slot)
+                               bits 10..12 save slot + 1  (0 = none)
+                               bits 13..19 output slot + 1 (0 = none)
+                               bits 20..22 DRM_OPI_PERM code
+                               bit  23     DRM_FLAG_CHILD_IS_NEXT
+                             The unpacked fields below stay in the table for hosts and debuggers       */
+#define DRM_OPI_CTRL_PACK(dof, src, save, out, perm, flags)                                                       \
+    ((((dof) + 1) & 0x7f) | ((((src) + 2) & 7) << 7) | ((((save) + 1) & 7) << 10) | ((((out) + 1) & 0x7f) << 13) | \
+     (((perm) & 7) << 20) | (((flags) & 1) << 23))
 #define DRM_OPI_SRC 3     /* parent state: DRM_SRC_PREV, DRM_SRC_ROOT, or a save-slot index    */
 #define DRM_OPI_SAVE 4    /* save-slot this op's state is copied to (branch point), -1 = none  */
 #define DRM_OPI_OUT 5     /* output slot (target index) this op's pose is written to, -1 = none */
