@@ -73,10 +73,26 @@ __device__ __forceinline__ unsigned lds_word(unsigned w, bool padded, uint32_t m
 // fast: the tile is full (64 rows), S is odd (the LDS image is linear) and g is 16-byte
 // aligned -> float4 per lane.  S_CT > 0 fixes S at compile time (all loads are issued
 // before the first LDS write).
+// vec: the tile is full and g is 16-byte aligned but S is even (padded LDS image): 16-byte global accesses, the
+// four floats go to their padded LDS words one by one.
 template <int S_CT>
 __device__ __forceinline__ void tile_load(const float *__restrict__ g, int rows, int S_rt, uint32_t magic, float *lds,
-                                          unsigned lane, bool fast) {
+                                          unsigned lane, bool fast, bool vec = false) {
     const int S = S_CT ? S_CT : S_rt;
+    if (!fast && vec && !(S & 1)) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        const unsigned nvec = 16u * (unsigned)S;
+#pragma unroll 2
+        for (unsigned i = lane; i < nvec; i += 64u) {
+            const float4 v = g4[i];
+            const unsigned w = 4u * i;
+            lds[lds_word(w, true, magic)] = v.x;
+            lds[lds_word(w + 1u, true, magic)] = v.y;
+            lds[lds_word(w + 2u, true, magic)] = v.z;
+            lds[lds_word(w + 3u, true, magic)] = v.w;
+        }
+        return;
+    }
     if (fast) {
         const char *gb = reinterpret_cast<const char *>(g); // uniform base + 32-bit byte offset per lane
         float4 *l4 = reinterpret_cast<float4 *>(lds);
@@ -113,8 +129,19 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ g, int rows,
 // ---- LDS -> HBM, same conventions ---------------------------------------------------
 template <int S_CT>
 __device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int S_rt, uint32_t magic, const float *lds,
-                                           unsigned lane, bool fast) {
+                                           unsigned lane, bool fast, bool vec = false) {
     const int S = S_CT ? S_CT : S_rt;
+    if (!fast && vec && !(S & 1)) {
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        const unsigned nvec = 16u * (unsigned)S;
+#pragma unroll 2
+        for (unsigned i = lane; i < nvec; i += 64u) {
+            const unsigned w = 4u * i;
+            g4[i] = make_float4(lds[lds_word(w, true, magic)], lds[lds_word(w + 1u, true, magic)],
+                                lds[lds_word(w + 2u, true, magic)], lds[lds_word(w + 3u, true, magic)]);
+        }
+        return;
+    }
     if (fast) {
         char *gb = reinterpret_cast<char *>(g);
         const float4 *l4 = reinterpret_cast<const float4 *>(lds);
@@ -159,6 +186,35 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 #undef DRM_DPP_ADD
 
+// The walk's constant rows (CAP x 32 floats, 0.5 - 4 KB) -> wave-private LDS, once per wave: every later read of
+// a link constant is a broadcast LDS read (in-order returns, so the compiler can wait per link) instead of a scalar
+// load whose latency a lone wave cannot hide.  16 bytes per lane and round when the table is 16-byte aligned.
+template <int CAP>
+__device__ __forceinline__ void stage_table(const float *__restrict__ ops_f, float *lds, unsigned lane, bool aligned) {
+    constexpr unsigned N4 = CAP * DRM_OPF_STRIDE / 4;
+    if (aligned) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(ops_f);
+        float4 *l4 = reinterpret_cast<float4 *>(lds);
+        constexpr unsigned IT = (N4 + WAVE - 1) / WAVE;
+        float4 v[IT];
+#pragma unroll
+        for (unsigned it = 0; it < IT; ++it) {
+            const unsigned i = lane + WAVE * it;
+            v[it] = g4[i < N4 ? i : N4 - 1u];
+        }
+#pragma unroll
+        for (unsigned it = 0; it < IT; ++it) pin(v[it]);
+#pragma unroll
+        for (unsigned it = 0; it < IT; ++it) {
+            const unsigned i = lane + WAVE * it;
+            if ((it + 1u) * WAVE <= N4 || i < N4) l4[i] = v[it];
+        }
+    } else {
+#pragma unroll 4
+        for (unsigned i = lane; i < CAP * DRM_OPF_STRIDE; i += WAVE) lds[i] = ops_f[i];
+    }
+}
+
 constexpr int BWD_MAX_WAVES = 2048; // 256 CUs x 4 SIMDs x 2: waves of a backward launch = rows of its partial sums
 
 struct WaveCtx {
@@ -183,7 +239,7 @@ __device__ __forceinline__ bool wave_begin(int64_t B, int lds_floats_per_wave, f
 }
 
 // alignment bits handed over by the launcher (bit set = pointer is 16-byte aligned)
-enum : uint32_t { AL_Q = 1, AL_QD = 2, AL_QDD = 4, AL_POS = 8, AL_QUAT = 16, AL_LIN = 32, AL_ANG = 64, AL_TAU = 128 };
+enum : uint32_t { AL_Q = 1, AL_QD = 2, AL_QDD = 4, AL_POS = 8, AL_QUAT = 16, AL_LIN = 32, AL_ANG = 64, AL_TAU = 128, AL_TABLE = 256 };
 
 // ---- host side ----------------------------------------------------------------------
 int fail(int code, const char *fmt, const char *a = "", long b = 0, long c = 0);

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lis = lh + round4(WAVE * Sh);              // inertia slots [slot][10][64]
     float *lss = lis + n_slots * (10 * WAVE);         // axis slots    [slot][op < sdepth][6][64]
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q), cx.full && (align & AL_Q));
     for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
     float *hrow = lh + lane * Sh;
     if (!DIRECT && zero_fill)
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     crba_walk<CAP>(ops_f, ops_i, qf, islot_add, islot_take, sslot_save, sslot_load, hout);
     if (!DIRECT) {
         wave_lds_sync();
-        tile_store<0>(H + cx.b0 * nn, cx.rows, nn, magic_h, lh, lane, cx.full && (nn & 1) && (align & AL_TAU));
+        tile_store<0>(H + cx.b0 * nn, cx.rows, nn, magic_h, lh, lane, cx.full && (nn & 1) && (align & AL_TAU), cx.full && (align & AL_TAU));
     }
 }
 

@@ -4,7 +4,7 @@
 // T = all links, compute_forward_kinematics_all_links (robot_model.py:197-221; recursion rigid_body.py:85-127).
 //
 // Per sample: in q[n] (4 n bytes), out pos[T,3] quat[T,4] (28 T bytes).
-// LDS per wave: [ q : 64 (n|1) ][ pos : 64 (3T|1) ][ quat : 64 (4T+1) ][ slots : n_slots * 12 * 64 ]
+// LDS per wave: [ constant rows : CAP * 32 ][ q : 64 (n|1) ][ pos : 64 (3T|1) ][ quat : 64 (4T+1) ][ slots : n_slots * 12 * 64 ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
@@ -20,12 +20,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     if (!wave_begin(B, lds_per_wave, smem, cx)) return;
     const unsigned lane = cx.lane;
     const int Sq = pad_odd(n), Sp = pad_odd(3 * T), Sr = pad_odd(4 * T);
-    float *lq = cx.lds;
+    float *lc = cx.lds;
+    float *lq = lc + CAP * DRM_OPF_STRIDE;
     float *lp = lq + round4(WAVE * Sq);
     float *lr = lp + round4(WAVE * Sp);
     float *ls = lr + round4(WAVE * Sr); // save slots: [slot][12][64]
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
+    stage_table<CAP>(ops_f, lc, lane, align & AL_TABLE);
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q), cx.full && (align & AL_Q));
     wave_lds_sync();
 
     // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
@@ -51,16 +53,15 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             P.B[c] = f2_make(b[(4 * c + 2) * WAVE], b[(4 * c + 3) * WAVE]);
         }
     };
-    auto emit = [&](int t, const Pose &P) {
-        float qt[4];
-        quat_xyzw(P.R, qt);
-        prow[t * 3 + 0] = P.p[0]; prow[t * 3 + 1] = P.p[1]; prow[t * 3 + 2] = P.p[2];
+    auto emit = [&](int t, const float *p, const float *qt) {
+        prow[t * 3 + 0] = p[0]; prow[t * 3 + 1] = p[1]; prow[t * 3 + 2] = p[2];
         rrow[t * 4 + 0] = qt[0]; rrow[t * 4 + 1] = qt[1]; rrow[t * 4 + 2] = qt[2]; rrow[t * 4 + 3] = qt[3];
     };
-    fk_walk<CAP>(ops_f, ops_i, qf, slot_save, slot_load, emit);
+    fk_walk<CAP>(lc, ops_i, qf, slot_save, slot_load, emit);
     wave_lds_sync();
-    tile_store<0>(pos + cx.b0 * 3 * T, cx.rows, 3 * T, magic_p, lp, lane, cx.full && ((3 * T) & 1) && (align & AL_POS));
-    tile_store<0>(quat + cx.b0 * 4 * T, cx.rows, 4 * T, magic_r, lr, lane, false);
+    tile_store<0>(pos + cx.b0 * 3 * T, cx.rows, 3 * T, magic_p, lp, lane, cx.full && ((3 * T) & 1) && (align & AL_POS),
+                  cx.full && (align & AL_POS));
+    tile_store<0>(quat + cx.b0 * 4 * T, cx.rows, 4 * T, magic_r, lr, lane, false, cx.full && (align & AL_QUAT));
 }
 
 } // namespace drm
@@ -88,10 +89,10 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
         }
     }
     Geometry g;
-    rc = make_geometry(B, round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + round4(WAVE * pad_odd(4 * T)) +
-                              w->n_slots * 12 * WAVE, g);
+    rc = make_geometry(B, w->capacity * DRM_OPF_STRIDE + round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) +
+                              round4(WAVE * pad_odd(4 * T)) + w->n_slots * 12 * WAVE, g);
     if (rc) return rc;
-    const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT) | al16(w->ops_f, AL_TABLE);
     hipStream_t s = (hipStream_t)stream;
     DRM_DISPATCH_CAP(w->capacity, {
         rc = ensure_lds(fk_kernel<C>, g.lds_bytes);

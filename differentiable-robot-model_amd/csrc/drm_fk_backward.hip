@@ -55,8 +55,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         const bool full = rows == WAVE;
         const bool live = (int)lane < rows;
         wave_lds_sync(); // the previous tile's LDS reads are done before this tile overwrites
-        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, full && (n & 1) && (align & AL_Q));
-        tile_load<0>(gpos + b0 * 3 * T, rows, 3 * T, magic_g, lg, lane, full && ((3 * T) & 1) && (align & AL_POS));
+        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, full && (n & 1) && (align & AL_Q), full && (align & AL_Q));
+        tile_load<0>(gpos + b0 * 3 * T, rows, 3 * T, magic_g, lg, lane, full && ((3 * T) & 1) && (align & AL_POS),
+                     full && (align & AL_POS));
         for (int s = 0; s < n_slots * 12; ++s) las[s * WAVE + lane] = 0.0f;
         wave_lds_sync();
 
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         for (int a = 0; a < NACC; ++a) acc[a] += add[a];
         if (gq) {
             wave_lds_sync();
-            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, full && (n & 1) && (align & AL_TAU));
+            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, full && (n & 1) && (align & AL_TAU), full && (align & AL_TAU));
         }
     }
     // one row of partial sums per wave (zeros for waves that had no tile)

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     load_field<CAP>(ops_i, DRM_OPI_DOF, dof);
     WarmRegs<CAP> warm;
     warm_walk_issue<CAP, 1>(ops_f, warm);
-    tile_load<NDOF>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q));
+    tile_load<NDOF>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q), cx.full && (align & AL_Q));
     warm_walk_wait(warm);
     wave_lds_sync();
 
@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         }
     }
     wave_lds_sync();
-    tile_store<3 * NDOF>(lin + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_LIN));
+    tile_store<3 * NDOF>(lin + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_LIN),
+                         fast_j && (align & AL_LIN));
     wave_lds_sync();
 
     // angular part: z_k   (robot_model.py:662); the off-chain zeros are still in place
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         }
     }
     wave_lds_sync();
-    tile_store<3 * NDOF>(ang + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_ANG));
+    tile_store<3 * NDOF>(ang + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_ANG),
+                         fast_j && (align & AL_ANG));
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -35,9 +35,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lfs = lms + n_slots * (12 * WAVE);        // rnea force slots   [slot][6][64]
     const bool fast = cx.full && (n & 1);
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q));
-    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
-    tile_load<0>(f + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_QDD));
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q), cx.full && (align & AL_Q));
+    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), cx.full && (align & AL_QD));
+    tile_load<0>(f + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_QDD), cx.full && (align & AL_QDD));
     for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
     float *hrow = lh + lane * Sh;
     if (zero_fill)
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
     cholesky_solve(n, hrow, lf + row);
     wave_lds_sync();
-    tile_store<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_TAU));
+    tile_store<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
 }
 
 } // namespace drm

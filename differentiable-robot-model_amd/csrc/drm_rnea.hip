@@ -27,9 +27,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lfs = lms + n_slots * (12 * WAVE);   // force slots  [slot][6][64]
     const bool fast = cx.full && (n & 1);
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q));
-    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
-    if (qdd) tile_load<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD));
+    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q), cx.full && (align & AL_Q));
+    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), cx.full && (align & AL_QD));
+    if (qdd) tile_load<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), cx.full && (align & AL_QDD));
     for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();
 
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     };
     rnea_walk<CAP>(ops_f, ops_i, flags, qf, tau_out, motion_save, motion_load, force_add, force_take);
     wave_lds_sync();
-    tile_store<0>(tau + cx.b0 * n, cx.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU));
+    tile_store<0>(tau + cx.b0 * n, cx.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
 }
 
 // ---------------------------------------------------------------------------------------------------

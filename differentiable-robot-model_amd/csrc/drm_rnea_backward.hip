@@ -56,10 +56,10 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         const bool full = rows == WAVE, fast = full && (n & 1);
         const bool live = (int)lane < rows;
         wave_lds_sync(); // the previous tile's LDS reads are done before this tile overwrites
-        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q));
-        tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD));
-        if (qdd) tile_load<0>(qdd + b0 * n, rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD));
-        tile_load<0>(gtau + b0 * n, rows, n, magic_q, lgt, lane, fast && (align & AL_TAU));
+        tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q), full && (align & AL_Q));
+        tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD), full && (align & AL_QD));
+        if (qdd) tile_load<0>(qdd + b0 * n, rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), full && (align & AL_QDD));
+        tile_load<0>(gtau + b0 * n, rows, n, magic_q, lgt, lane, fast && (align & AL_TAU), full && (align & AL_TAU));
         for (int s = 0; s < n_slots * SLOT_FLOATS; ++s) slot[s * WAVE] = 0.0f;
         wave_lds_sync();
 
@@ -126,9 +126,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         for (int a = 0; a < NACC; ++a) acc[a] += add[a];
         if (gq) {
             wave_lds_sync();
-            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, fast && (align & AL_POS));
-            tile_store<0>(gqd + b0 * n, rows, n, magic_q, lgqd, lane, fast && (align & AL_QUAT));
-            tile_store<0>(gqdd + b0 * n, rows, n, magic_q, lgqdd, lane, fast && (align & AL_LIN));
+            tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, fast && (align & AL_POS), full && (align & AL_POS));
+            tile_store<0>(gqd + b0 * n, rows, n, magic_q, lgqd, lane, fast && (align & AL_QUAT), full && (align & AL_QUAT));
+            tile_store<0>(gqdd + b0 * n, rows, n, magic_q, lgqdd, lane, fast && (align & AL_LIN), full && (align & AL_LIN));
         }
     }
     float *prow = partials + wave_id * NV;

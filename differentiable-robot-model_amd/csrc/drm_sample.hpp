@@ -232,6 +232,28 @@ DRM_HD void quat_xyzw(const float *R, float *q) {
     q[3] = w * scale;
 }
 
+// Orientation of an emitted target: undo the axis canonicalisation, then the quaternion.  Deliberately NOT inlined:
+// the multi-target walk is unrolled over up to 32 links and any of them may be a target, so an inlined copy per
+// link multiplies the code of the kernel (tens of KB of straight-line code that every wave has to fetch once, which
+// is what a small launch then spends its time on); one shared copy costs a call per target instead.
+struct Quat4 {
+    float v[4];
+};
+struct Rot9 {
+    float v[9];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+static __attribute__((noinline))
+#endif
+Quat4 target_quaternion(Rot9 R, int perm_code) {
+    Quat4 q;
+    unpermute(perm_code, R.v);
+    quat_xyzw(R.v, q.v);
+    return q;
+}
+
 // cos / sin of every op's joint angle, computed up front so the transcendental work is off the serial pose
 // chain, two ops per packed evaluation (sincos_pair below; the rare wave with an angle beyond its range takes
 // sincos_f's fp64 reduction).  Fixed joints and padding read DoF 0 and are masked to c = 1, s = 0.
@@ -474,7 +496,7 @@ DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3
 // poses only, 223-248).
 //   qf(d)                  -> joint angle of DoF d for this sample
 //   slot_save(s, Pose) / slot_load(s, Pose&)   -> branch-point poses (kept in LDS by the kernel)
-//   emit(t, Pose)          -> called once per target slot t with the TRUE (un-permuted) pose
+//   emit(t, p[3], q[4])    -> called once per target slot t with its world position and xyzw quaternion
 // ---------------------------------------------------------------------------
 template <int CAP, class QF, class SAVE, class LOAD, class EMIT>
 DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, QF qf, SAVE slot_save,
@@ -502,8 +524,11 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
         if (out >= 0) {
             Pose P;
             pose_from_pairs(cur, P);
-            unpermute(DRM_OPI(DRM_OPI_PERM, k), P.R);
-            emit(out, P);
+            Rot9 R;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R.v[i] = P.R[i];
+            const Quat4 qt = target_quaternion(R, DRM_OPI(DRM_OPI_PERM, k));
+            emit(out, P.p, qt.v);
         }
     }
 }

@@ -21,10 +21,8 @@ void fk_t(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float
         auto qf = [&](int d) { return q[b * n + d]; };
         auto save = [&](int s, const PoseP &P) { slots[s] = P; };
         auto load = [&](int s, PoseP &P) { P = slots[s]; };
-        auto emit = [&](int t, const Pose &P) {
-            float qt[4];
-            quat_xyzw(P.R, qt);
-            for (int i = 0; i < 3; ++i) pos[(b * T + t) * 3 + i] = P.p[i];
+        auto emit = [&](int t, const float *p, const float *qt) {
+            for (int i = 0; i < 3; ++i) pos[(b * T + t) * 3 + i] = p[i];
             for (int i = 0; i < 4; ++i) quat[(b * T + t) * 4 + i] = qt[i];
         };
         fk_walk<CAP>(w->ops_f, w->ops_i, qf, save, load, emit);
