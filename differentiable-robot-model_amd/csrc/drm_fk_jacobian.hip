@@ -132,9 +132,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
 // The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
 // ---------------------------------------------------------------------------------------------------
-#ifndef DRM_ARM_WPB
-#define DRM_ARM_WPB MAX_WAVES_PER_BLOCK /* waves per block of the arm kernels (a packing choice: waves are independent) */
-#endif
+// waves per block of the arm kernels: a packing choice (waves are independent); 1, 2 and 4 measure the same
+#define DRM_ARM_WPB MAX_WAVES_PER_BLOCK
 template <int CAP, int NJ, bool JAC>
 __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
     fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
@@ -183,9 +182,7 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
                 arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0];
             }
             wave_lds_sync();
-#ifndef DRM_DEV_NO_JAC_STORE
             tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
-#endif
         }
     });
 
@@ -206,9 +203,7 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
         lp[lane * 3 + 1] = pe[1];
         lp[lane * 3 + 2] = pe[2];
         wave_lds_sync();
-#ifndef DRM_DEV_NO_JAC_STORE
         tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
-#endif
         tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
     } else {
         wave_lds_sync(); // every lane has read its q row before pos is staged over the q tile

@@ -85,11 +85,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // (drm_sample.hpp rnea_chain), preloaded kernel arguments, one basic block; the per-link body forces are parked
 // in LDS between the two sweeps (registers are what limits occupancy here), over the dead input tiles.
 // ---------------------------------------------------------------------------------------------------
-#ifndef DRM_RNEA_ARM_MIN_BLOCKS
-#define DRM_RNEA_ARM_MIN_BLOCKS 1
-#endif
 template <int CAP, int NJ>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, DRM_RNEA_ARM_MIN_BLOCKS)
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                     const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");

@@ -34,7 +34,7 @@
 #endif
 
 // true if the predicate holds in any lane of the wavefront (the host emulation runs one sample at a time)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DRM_NO_VOTE)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define DRM_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
 #else
 #define DRM_WAVE_ANY(pred) (pred)
@@ -416,34 +416,6 @@ DRM_HD void sincos_pair(f2 x, f2 &s, f2 &c) {
         c[i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cri) ^ flip);
     }
 }
-#if defined(DRM_SINCOS_PAIR_V1) /* development bisect only */
-DRM_HD void sincos_pair_v1(f2 x, f2 &s, f2 &c) {
-    const f2 kf = {rintf(x[0] * 0.636619747f), rintf(x[1] * 0.636619747f)};
-    f2 r = kf * f2_bcast(-1.57079601e+00f) + x;
-    r = kf * f2_bcast(-3.13916473e-07f) + r;
-    r = kf * f2_bcast(-5.39030253e-15f) + r;
-    const f2 z = r * r;
-    f2 ps = z * f2_bcast(2.7557314297e-06f) + f2_bcast(-1.9841270114e-04f);
-    ps = z * ps + f2_bcast(8.3333337680e-03f);
-    ps = z * ps + f2_bcast(-1.6666667163e-01f);
-    const f2 sr = (r * z) * ps + r;
-    f2 pc = z * f2_bcast(-2.7557314297e-07f) + f2_bcast(2.4801587642e-05f);
-    pc = z * pc + f2_bcast(-1.3888889225e-03f);
-    pc = z * pc + f2_bcast(4.1666667908e-02f);
-    pc = z * pc + f2_bcast(-0.5f);
-    const f2 cr = z * pc + f2_bcast(1.0f);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = (int)kf[i];
-        const bool swap = q & 1;
-        const float s0 = swap ? cr[i] : sr[i];
-        const float c0 = swap ? sr[i] : cr[i];
-        s[i] = (q & 2) ? -s0 : s0;
-        c[i] = ((q + 1) & 2) ? -c0 : c0;
-    }
-}
-#define sincos_pair sincos_pair_v1
-#endif
 constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f; // keep in sync with joint_trig
 
 // FK of a serial chain whose first NJ links are moving joints driving DoF columns 0..NJ-1 and whose
