@@ -83,6 +83,42 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
 }
 
+// Serial-chain ("arm") specialisation, full tiles only — the design of fk_jacobian_arm_kernel: constant rows staged
+// once per wave in LDS, packed-FP32 sweeps without the int table (drm_sample.hpp crba_chain), preloaded kernel
+// arguments, one basic block, H staged as a linear LDS image (n^2 = 49 is odd).
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    crba_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles, float *__restrict__ H) {
+    static_assert((NJ & 1) && ((NJ * NJ) & 1), "odd row widths only (linear LDS images)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int NN = NJ * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), H_FLOATS = round4(WAVE * NN);
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + H_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lh = lq + Q_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+
+    float qv[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
+    float *hrow = lh + lane * NN;
+    crba_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
+                        [&](int i, int j, float v) { hrow[i * NJ + j] = v; });
+    wave_lds_sync();
+    tile_store<NN>(H + b0 * NN, WAVE, NN, 0u, lh, lane, true);
+}
+
 } // namespace drm
 
 using namespace drm;
@@ -95,6 +131,23 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs, nn = n * n;
     hipStream_t s = (hipStream_t)stream;
+#ifndef DRM_NO_ARM_KERNEL
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
+        (((uintptr_t)q | (uintptr_t)H | (uintptr_t)w->ops_f) & 15u) == 0) {
+        // 7-DoF arms: full tiles through the packed-FP32 chain kernel, ragged tail through the generic one
+        const int n_tiles = (int)(B / WAVE);
+        hipLaunchKernelGGL((crba_arm_kernel<8, 7>),
+                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, H);
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done == B) return launched();
+        rc = launched();
+        if (rc) return rc;
+        drm_walk generic = *w;
+        generic.shape &= ~DRM_WALK_ARM_CHAIN;
+        return drm_crba(&generic, q + done * n, B - done, H + done * nn, stream);
+    }
+#endif
     const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
     if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
     const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + sdepth * 6) * WAVE;

@@ -1423,6 +1423,90 @@ DRM_HD void crba_walk(const float *__restrict__ opf, const int32_t *__restrict__
     }
 }
 
+// Joint-space inertia matrix of a serial chain (DRM_WALK_ARM_CHAIN: NJ moving joints driving DoF columns 0..NJ-1,
+// then CAP - NJ fixed links or identity padding): crba_walk without the int table and the branch-point machinery,
+// joint axes carried as packed (ang_i, lin_i) pairs, two joints per sincos evaluation.
+//   row(k) -> pointer to op k's constant row;   hout(i, j, v) -> H[i][j] = v (called for both triangles)
+template <int CAP, int NJ, class ROW, class HOUT>
+DRM_HD void crba_chain(ROW row, const float (&q)[NJ], HOUT hout) {
+    float cs[NJ], sn[NJ];
+    bool big = false;
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) {
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < NJ; d += 2) {
+            f2 s2, c2;
+            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
+            sn[d] = s2[0]; cs[d] = c2[0];
+            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
+        }
+    }
+    auto joint = [&](int k, float *J, float *t) {
+        const OpFT o = load_ft(row(k));
+        if (k < NJ) {
+            joint_rot_z(o.F, cs[k], sn[k], J);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+        }
+        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+    };
+    // backward sweep: composite inertias of the moving links (fixed tail links only feed their parent)
+    Inertia Ic[NJ], carry;
+    inertia_zero(carry);
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = row(k);
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        if (k < CAP - 1) inertia_add(tot, carry);
+        if (k < NJ) Ic[k] = tot;
+        if (k > 0) {
+            float J[9], t[3];
+            joint(k, J, t);
+            inertia_to_parent(J, t, tot, carry);
+        }
+    }
+    // forward sweep: the axes of the joints above, in the current frame, as (ang_i, lin_i) pairs
+    f2 S[NJ][3];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        if (k > 0) {
+            float J[9], t[3];
+            joint(k, J, t);
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                // motion vector into the child frame: ang' = J^T ang ; lin' = J^T (lin + ang x t)
+                const float a[3] = {S[j][0][0], S[j][1][0], S[j][2][0]};
+                f2 y[3] = {S[j][0], S[j][1], S[j][2]};
+                y[0][1] += a[1] * t[2] - a[2] * t[1];
+                y[1][1] += a[2] * t[0] - a[0] * t[2];
+                y[2][1] += a[0] * t[1] - a[1] * t[0];
+                matT_vec_p(J, y, S[j]);
+            }
+        }
+        // F = Ic S_k with S_k = (ang e_z, lin 0):  f = (-h_y, h_x, 0),  n = I e_z
+        const float fx = -Ic[k].h[1], fy = Ic[k].h[0];
+        const float nx = Ic[k].I[2], ny = Ic[k].I[4], nz = Ic[k].I[5];
+        hout(k, k, nz);
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            const float v = fx * S[j][0][1] + fy * S[j][1][1] + (nx * S[j][0][0] + ny * S[j][1][0] + nz * S[j][2][0]);
+            hout(k, j, v);
+            hout(j, k, v);
+        }
+        S[k][0] = f2_make(0.0f, 0.0f); S[k][1] = f2_make(0.0f, 0.0f); S[k][2] = f2_make(1.0f, 0.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Solve H x = b for one sample, H symmetric positive definite (the joint-space inertia matrix), by an in-place
 // Cholesky factorisation H = L L^T followed by the two triangular solves.  H is the lane's PACKED LOWER TRIANGLE

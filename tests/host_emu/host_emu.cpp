@@ -263,6 +263,16 @@ int emu_link_rows_backward(const float *params, const float *grad_rows, int32_t 
         link_row_backward(params + i * LINK_PARAM_FLOATS, grad_rows + i * DRM_OPF_STRIDE, grad_params + i * LINK_PARAM_FLOATS);
     return 0;
 }
+int emu_crba_arm(const drm_walk *w, const float *q, int64_t B, float *H) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    for (int64_t b = 0; b < B; ++b) {
+        float qv[7];
+        for (int d = 0; d < 7; ++d) qv[d] = q[b * 7 + d];
+        crba_chain<8, 7>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, qv,
+                         [&](int i, int j, float v) { H[(b * 7 + i) * 7 + j] = v; });
+    }
+    return 0;
+}
 int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
     DISPATCH(crba_t, w, q, B, H)
     return 0;

@@ -55,6 +55,22 @@ def test_emu_crba_vs_oracle(emu, robot):
     assert np.linalg.eigvalsh(H.astype(np.float64)).min() > 0
 
 
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "fetch_arm_no_gripper"])
+def test_emu_crba_arm_chain_vs_oracle(emu, robot):
+    """crba_chain (the arithmetic of crba_arm_kernel<8, 7>) against the fp64 oracle."""
+    m = load_model(robot)
+    n, B = m._n_dofs, 37
+    q, _, _ = sample_states(m, B, seed=43)
+    q[2, 5] = 4.0e5   # fp64 sincos fallback
+    prog = build_walk(m._spec, whole_tree=True)
+    walk, keep = host_walk(m, prog)
+    H = np.full((B, n, n), np.nan, np.float32)
+    assert emu.emu_crba_arm(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
+    assert np.allclose(H, ref, **TOL_TAU), (robot, np.abs(H - ref).max())
+    assert np.array_equal(H, H.transpose(0, 2, 1))
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot", ALL_ROBOTS)
