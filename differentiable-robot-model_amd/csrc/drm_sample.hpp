@@ -1445,18 +1445,22 @@ DRM_HD void crba_chain(ROW row, const float (&q)[NJ], HOUT hout) {
             if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
         }
     }
-    auto joint = [&](int k, float *J, float *t) {
+    // all joint transforms first (kept in registers: both sweeps below read them)
+    float J[CAP][9];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
         const OpFT o = load_ft(row(k));
         if (k < NJ) {
-            joint_rot_z(o.F, cs[k], sn[k], J);
+            joint_rot_z(o.F, cs[k], sn[k], J[k]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+            for (int i = 0; i < 9; ++i) J[k][i] = o.F[i];
         }
-        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
-    };
-    // backward sweep: composite inertias of the moving links (fixed tail links only feed their parent)
-    Inertia Ic[NJ], carry;
+    }
+    // one sweep from the tip to the root: the composite inertia is a running value (nothing is stored per link),
+    // and at every moving link k the force F = Ic_k S_k is walked up the chain as a packed (f_i, n_i) pair vector,
+    // leaving H[j][k] = S_j . F = n_z at every joint j above — the classic column-by-column form of the algorithm.
+    Inertia carry;
     inertia_zero(carry);
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
@@ -1468,42 +1472,28 @@ DRM_HD void crba_chain(ROW row, const float (&q)[NJ], HOUT hout) {
         tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
         tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
         if (k < CAP - 1) inertia_add(tot, carry);
-        if (k < NJ) Ic[k] = tot;
-        if (k > 0) {
-            float J[9], t[3];
-            joint(k, J, t);
-            inertia_to_parent(J, t, tot, carry);
-        }
-    }
-    // forward sweep: the axes of the joints above, in the current frame, as (ang_i, lin_i) pairs
-    f2 S[NJ][3];
+        if (k < NJ) {
+            // F = Ic S_k with S_k = (ang e_z, lin 0):  f = -h x e_z = (-h_y, h_x, 0),  n = I e_z
+            Force F;
+            F.la[0] = f2_make(-tot.h[1], tot.I[2]);
+            F.la[1] = f2_make(tot.h[0], tot.I[4]);
+            F.la[2] = f2_make(0.0f, tot.I[5]);
+            hout(k, k, tot.I[5]);
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) {
-        if (k > 0) {
-            float J[9], t[3];
-            joint(k, J, t);
-#pragma unroll
-            for (int j = 0; j < k; ++j) {
-                // motion vector into the child frame: ang' = J^T ang ; lin' = J^T (lin + ang x t)
-                const float a[3] = {S[j][0][0], S[j][1][0], S[j][2][0]};
-                f2 y[3] = {S[j][0], S[j][1], S[j][2]};
-                y[0][1] += a[1] * t[2] - a[2] * t[1];
-                y[1][1] += a[2] * t[0] - a[0] * t[2];
-                y[2][1] += a[0] * t[1] - a[1] * t[0];
-                matT_vec_p(J, y, S[j]);
+            for (int j = k - 1; j >= 0; --j) {
+                const float *oc = row(j + 1);
+                const float t[3] = {oc[DRM_OPF_TI(0)], oc[DRM_OPF_TI(1)], oc[DRM_OPF_TI(2)]};
+                Force up;
+                rnea_link_force_up(J[j + 1], t, F, up); // into the frame of link j (spatial_vector_algebra.py:281-291)
+                F = up;
+                hout(j, k, F.la[2][1]);
+                hout(k, j, F.la[2][1]);
             }
         }
-        // F = Ic S_k with S_k = (ang e_z, lin 0):  f = (-h_y, h_x, 0),  n = I e_z
-        const float fx = -Ic[k].h[1], fy = Ic[k].h[0];
-        const float nx = Ic[k].I[2], ny = Ic[k].I[4], nz = Ic[k].I[5];
-        hout(k, k, nz);
-#pragma unroll
-        for (int j = 0; j < k; ++j) {
-            const float v = fx * S[j][0][1] + fy * S[j][1][1] + (nx * S[j][0][0] + ny * S[j][1][0] + nz * S[j][2][0]);
-            hout(k, j, v);
-            hout(j, k, v);
+        if (k > 0) {
+            const float t[3] = {of[DRM_OPF_TI(0)], of[DRM_OPF_TI(1)], of[DRM_OPF_TI(2)]};
+            inertia_to_parent(J[k], t, tot, carry);
         }
-        S[k][0] = f2_make(0.0f, 0.0f); S[k][1] = f2_make(0.0f, 0.0f); S[k][2] = f2_make(1.0f, 0.0f);
     }
 }
 
