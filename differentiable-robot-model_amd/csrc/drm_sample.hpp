@@ -47,6 +47,16 @@ namespace drm {
 typedef float f2 __attribute__((vector_size(8)));
 DRM_HD f2 f2_make(float a, float b) { f2 v = {a, b}; return v; }
 DRM_HD f2 f2_bcast(float a) { f2 v = {a, a}; return v; }
+// a * b + c with ONE rounding per lane, guaranteed (not left to the compiler's contraction): the Cody-Waite argument
+// reduction below is only accurate with true FMAs
+DRM_HD f2 f2_fma(f2 a, f2 b, f2 c) {
+#if defined(__clang__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    f2 v = {__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
+    return v;
+#endif
+}
 
 // ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][CAP]: one scalar load fetches a field of many ops.  The walks read
 // a single field, the packed control word (DRM_OPI_CTRL, include/drm_hip.h), into `ctl[CAP]` once and decode the
@@ -389,11 +399,11 @@ DRM_HD void pose_from_pairs(const PoseP &P, Pose &out) {
 //     evaluated in fp32 the error is rounding-dominated, <= 1.2e-7 absolute, i.e. <= 2 ulp near 1).
 DRM_HD void sincos_pair(f2 x, f2 &s, f2 &c) {
     const f2 magic = f2_bcast(12582912.0f);                       // 1.5 * 2^23
-    const f2 kb = x * f2_bcast(0.318309886f) + magic;             // low mantissa bits = rint(x / pi)
+    const f2 kb = f2_fma(x, f2_bcast(0.318309886f), magic);       // low mantissa bits = rint(x / pi)
     const f2 kf = kb - magic;
-    f2 r = kf * f2_bcast(-3.14159202e+00f) + x;
-    r = kf * f2_bcast(-6.27832947e-07f) + r;
-    r = kf * f2_bcast(-1.07806051e-14f) + r;
+    f2 r = f2_fma(kf, f2_bcast(-3.14159202e+00f), x);
+    r = f2_fma(kf, f2_bcast(-6.27832947e-07f), r);
+    r = f2_fma(kf, f2_bcast(-1.07806051e-14f), r);
     const f2 z = r * r;
     f2 ps = z * f2_bcast(-2.3776610902e-08f) + f2_bcast(2.7522166874e-06f);
     ps = z * ps + f2_bcast(-1.9840880122e-04f);
