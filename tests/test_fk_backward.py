@@ -225,3 +225,44 @@ def test_gpu_autograd_refused_where_no_backward_kernel_exists():
         m.compute_lagrangian_inertia_matrix(q)
     with torch.no_grad():
         m.compute_endeffector_jacobian(q, "iiwa_link_ee")
+
+
+@pytest.mark.gpu
+def test_gpu_training_step_is_hipgraph_capturable():
+    """Forward + loss + backward + Adam of the kinematics-learning loop captured ONCE into a hipGraph and replayed:
+    no call on the path synchronises or touches host memory, so the launch-bound loop runs without the host."""
+    torch.manual_seed(0)
+    m = load_model("iiwa7", "cuda"); gt = load_model("iiwa7", "cuda")
+    m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+    m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+    q = torch.from_numpy(sample_states(m, 4096, seed=2)[0]).cuda()
+    with torch.no_grad():
+        want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3, capturable=True)
+
+    def train_step():
+        pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
+        loss = torch.nn.functional.mse_loss(pos, want)
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            train_step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        loss = train_step()
+    graph.replay(); torch.cuda.synchronize()
+    first = loss.item()
+    before = [p.detach().clone() for p in m.parameters()]
+    for _ in range(50):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert loss.item() < 0.6 * first
+    assert all(not torch.equal(a, b) for a, b in zip(before, m.parameters()))
