@@ -150,6 +150,84 @@ __global__ void __launch_bounds__(WAVE)
     }
 }
 
+// Serial-chain ("arm") specialisation, full tiles only: drm_sample.hpp rnea_backward_chain (per-link forces and their
+// adjoints in registers, motions recovered on the way back instead of stored), constants staged once per wave in LDS,
+// gradient tiles staged over the dead input tiles.  Same persistent-wave structure and batch reduction as the
+// generic kernel.
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    rnea_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                             const float *__restrict__ qdd, const float *__restrict__ gtau, int n_tiles, int flags,
+                             uint32_t param_mask, float *__restrict__ gq, float *__restrict__ gqd,
+                             float *__restrict__ gqdd, float *__restrict__ partials) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ);
+    constexpr int PER_WAVE = C_FLOATS + 4 * Q_FLOATS;
+    constexpr int NV = CAP * DRM_OPF_STRIDE, NACC = NV / WAVE;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave_id = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave, n_waves = (int)gridDim.x * MAX_WAVES_PER_BLOCK;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS, *lgt = lqdd + Q_FLOATS;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+
+    for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        wave_lds_sync(); // the previous tile's staged gradients have left
+        tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+        tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
+        if (qdd) tile_load<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
+        tile_load<NJ>(gtau + b0 * NJ, WAVE, NJ, 0u, lgt, lane, true);
+        wave_lds_sync();
+        float qv[NJ], qdv[NJ], qddv[NJ], gtv[NJ];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) {
+            qv[d] = lq[lane * NJ + d];
+            qdv[d] = lqd[lane * NJ + d];
+            qddv[d] = qdd ? lqdd[lane * NJ + d] : 0.0f;
+            gtv[d] = lgt[lane * NJ + d];
+        }
+        wave_lds_sync(); // all rows are in registers: the input tiles may be overwritten by the gradients
+        float add[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
+        rnea_backward_chain<CAP, NJ>(
+            [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+            flags & DRM_RNEA_DAMPING, param_mask, gq != nullptr, qv, qdv, qddv, gtv,
+            [&](int d, float a, float v, float c) {
+                lq[lane * NJ + d] = a; lqd[lane * NJ + d] = v; lqdd[lane * NJ + d] = c;
+            },
+            [&](int k, const float *g) {
+#pragma unroll
+                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+                    const float total = wave_sum_lane63(g[j]);
+                    const int idx = k * DRM_OPF_STRIDE + j;
+                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
+                    if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s;
+                }
+            });
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += add[a];
+        if (gq) {
+            wave_lds_sync();
+            tile_store<NJ>(gq + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+            tile_store<NJ>(gqd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
+            tile_store<NJ>(gqdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
+        }
+    }
+    float *prow = partials + (int64_t)wave_id * NV;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
+}
+
 static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, bool park_hbm) {
     return (size_t)7 * round4(WAVE * pad_odd(n)) + (size_t)n_slots * SLOT_FLOATS * WAVE +
            (park_hbm ? 0 : (size_t)cap * REC_FLOATS * WAVE);
@@ -162,7 +240,7 @@ using namespace drm;
 extern "C" int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity, int32_t n_dofs, int32_t n_slots) {
     if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS || n_dofs < 1 || n_dofs > DRM_MAX_DOFS) return 0;
     const int64_t waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
-    int64_t floats = waves * capacity * DRM_OPF_STRIDE; // partial sums
+    int64_t floats = (waves + MAX_WAVES_PER_BLOCK) * capacity * DRM_OPF_STRIDE; // partial sums (+ a ragged tail's row)
     if (rnea_backward_lds_floats(n_dofs, n_slots, capacity, false) * sizeof(float) > (size_t)MAX_LDS_BYTES)
         floats += waves * (int64_t)capacity * REC_FLOATS * WAVE; // per-link records parked in HBM
     return floats;
@@ -192,6 +270,55 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         }
         return DRM_OK;
     }
+    float *partials = scratch;
+#ifndef DRM_NO_ARM_KERNEL
+    {
+        const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)qd | (uintptr_t)qdd | (uintptr_t)grad_tau | (uintptr_t)grad_q |
+                               (uintptr_t)grad_qd | (uintptr_t)grad_qdd | (uintptr_t)w->ops_f;
+        if ((w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && n == 7 && (ptrs & 15u) == 0 && B >= WAVE &&
+            B / WAVE < 0x7fffffffLL) {
+            // 7-DoF arms: full tiles through the chain kernel, the ragged tail (if any) through the generic one with
+            // its own rows of partial sums appended after the chain kernel's
+            const int n_tiles = (int)(B / WAVE);
+            const int64_t done = (int64_t)n_tiles * WAVE;
+            const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
+            hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                               dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, grad_tau, n_tiles, (int)flags,
+                               param_mask, grad_q, grad_qd, grad_qdd, partials);
+            rc = launched();
+            if (rc) return rc;
+            int rows = waves_a;
+            if (done < B) {
+                // tail: < 64 rows, one wave, through the generic kernel (LDS parking: an arm always fits)
+                Geometry gt;
+                rc = make_geometry(B - done, (int)rnea_backward_lds_floats(n, w->n_slots, cap, false), gt);
+                if (rc) return rc;
+                gt.grid = dim3(1);
+                gt.block = dim3(WAVE);
+                gt.lds_bytes = (size_t)gt.lds_per_wave * sizeof(float);
+                rc = ensure_lds(rnea_backward_kernel<8, false>, gt.lds_bytes);
+                if (rc) return rc;
+                const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU);
+                hipLaunchKernelGGL((rnea_backward_kernel<8, false>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i,
+                                   n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
+                                   qdd ? qdd + done * n : nullptr, grad_tau + done * n, B - done,
+                                   grad_q ? grad_q + done * n : nullptr, grad_qd ? grad_qd + done * n : nullptr,
+                                   grad_qdd ? grad_qdd + done * n : nullptr, param_mask,
+                                   partials + (int64_t)waves_a * cap * DRM_OPF_STRIDE, (float *)nullptr, div_magic(n),
+                                   gt.lds_per_wave, al & ~(AL_POS | AL_QUAT | AL_LIN));
+                rc = launched();
+                if (rc) return rc;
+                rows += 1;
+            }
+            if (grad_ops_f) {
+                hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, partials, rows, cap,
+                                   grad_ops_f);
+                rc = launched();
+            }
+            return rc;
+        }
+    }
+#endif
     const bool park_hbm = rnea_backward_lds_floats(n, w->n_slots, cap, false) * sizeof(float) > (size_t)MAX_LDS_BYTES;
     Geometry g;
     rc = make_geometry(B, (int)rnea_backward_lds_floats(n, w->n_slots, cap, park_hbm), g);
@@ -199,8 +326,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
     const int wpb = (int)(g.block.x / WAVE);
     const int waves = backward_waves(B, wpb);
     g.grid = dim3((unsigned)(waves / wpb));
-    float *partials = scratch;
-    float *park = scratch + (int64_t)backward_waves(B, MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE;
+    float *park = scratch + (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE;
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU) |
                            al16(grad_q, AL_POS) | al16(grad_qd, AL_QUAT) | al16(grad_qdd, AL_LIN);
 #define DRM_LAUNCH_RB(C, HBM)                                                                                          \

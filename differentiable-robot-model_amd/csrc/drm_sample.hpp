@@ -909,6 +909,125 @@ DRM_HD void sub_cross(float *acc, const float *a, const float *b) { // acc -= a 
     acc[2] -= a[0] * b[1] - a[1] * b[0];
 }
 
+// Adjoint of ONE link of the RNEA: given the link's motion `mo` (w, v, al, a), its parent's motion `par`, the adjoint
+// of its total force `fb` (= tbar_k), the motion adjoint `mb` arriving from its children (updated in place to the
+// link's full motion adjoint), and for the force transform of the backward sweep the parent's tbar `ub` and the
+// link's total force `tot`: the adjoints of the parent's motion (pb), of the joint transform (Jb, tb), of the
+// constants (gm, gmc, gIo) and of the joint rate / acceleration (wjb, ajb).
+struct LinkAdjoint {
+    float pb[12], Jb[9], tb[3], gm, gmc[3], gIo[9], wjb, ajb;
+};
+DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const float *J, const float *t, float wj,
+                              const float *mo, const float *fb, const float *par, float *mb, const float *ub,
+                              const float *tot, bool has_parent, LinkAdjoint &out) {
+    float *wb = mb, *vb = mb + 3, *alb = mb + 6, *ab = mb + 9;
+    const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
+    const float *fl = fb, *fa = fb + 3; // adjoint of this link's body force = tbar_k
+    // body force: hl = m v - mc x w, ha = Io w + mc x v, gl = m a - mc x al, ga = Io al + mc x a,
+    //             f.lin = gl + w x hl,  f.ang = ga + w x ha + v x hl
+    float hl[3], ha[3], x[3];
+    cross3(mc, w, x);
+    hl[0] = m * v[0] - x[0]; hl[1] = m * v[1] - x[1]; hl[2] = m * v[2] - x[2];
+    mat_vec(Io, w, ha);
+    add_cross(ha, mc, v);
+    float hlb[3] = {0, 0, 0}, hab[3] = {0, 0, 0};
+    add_cross(hlb, fl, w); add_cross(hlb, fa, v);
+    add_cross(hab, fa, w);
+    add_cross(wb, hl, fl); add_cross(wb, ha, fa);
+    add_cross(vb, hl, fa);
+    float gm = 0.0f;
+    float *gmc = out.gmc, *gIo = out.gIo;
+    gmc[0] = gmc[1] = gmc[2] = 0.0f;
+    gm += hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2];
+    vb[0] += m * hlb[0]; vb[1] += m * hlb[1]; vb[2] += m * hlb[2];
+    sub_cross(gmc, w, hlb);
+    sub_cross(wb, hlb, mc);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gIo[r * 3 + c] = hab[r] * w[c] + fa[r] * al[c];
+    matT_vec(Io, hab, x);
+    wb[0] += x[0]; wb[1] += x[1]; wb[2] += x[2];
+    add_cross(gmc, v, hab);
+    add_cross(vb, hab, mc);
+    gm += fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
+    ab[0] += m * fl[0]; ab[1] += m * fl[1]; ab[2] += m * fl[2];
+    sub_cross(gmc, al, fl);
+    sub_cross(alb, fl, mc);
+    matT_vec(Io, fa, x);
+    alb[0] += x[0]; alb[1] += x[1]; alb[2] += x[2];
+    add_cross(gmc, a, fa);
+    add_cross(ab, fa, mc);
+    out.gm = gm;
+
+    // link motion from the parent's: adjoint
+    const float *Pw = par, *Pv = par + 3, *Pal = par + 6, *Pa = par + 9;
+    float *pb = out.pb, *Jb = out.Jb, *tbr = out.tb, y[3], yb[3];
+    float wjb = 0.0f, ajb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pb[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Jb[i] = 0.0f;
+    tbr[0] = tbr[1] = tbr[2] = 0.0f;
+    float *Pwb = pb, *Pvb = pb + 3, *Palb = pb + 6, *Pab = pb + 9;
+    // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)
+    y[0] = Pa[0]; y[1] = Pa[1]; y[2] = Pa[2];
+    add_cross(y, Pal, t);
+    mat_vec(J, ab, yb);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * ab[c];
+    vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
+    wjb += ab[0] * v[1] - ab[1] * v[0];
+    Pab[0] += yb[0]; Pab[1] += yb[1]; Pab[2] += yb[2];
+    add_cross(Palb, t, yb);
+    add_cross(tbr, yb, Pal);
+    // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)
+    mat_vec(J, alb, x);
+    Palb[0] += x[0]; Palb[1] += x[1]; Palb[2] += x[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pal[r] * alb[c];
+    ajb += alb[2];
+    wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
+    wjb += alb[0] * w[1] - alb[1] * w[0];
+    // v = J^T (Pv + Pw x t)
+    y[0] = Pv[0]; y[1] = Pv[1]; y[2] = Pv[2];
+    add_cross(y, Pw, t);
+    mat_vec(J, vb, yb);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * vb[c];
+    Pvb[0] += yb[0]; Pvb[1] += yb[1]; Pvb[2] += yb[2];
+    add_cross(Pwb, t, yb);
+    add_cross(tbr, yb, Pw);
+    // w = J^T Pw + wj e_z
+    mat_vec(J, wb, x);
+    Pwb[0] += x[0]; Pwb[1] += x[1]; Pwb[2] += x[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pw[r] * wb[c];
+    wjb += wb[2];
+    // the force transform of the backward sweep: up.lin = J tot.lin, up.ang = J tot.ang + t x (J tot.lin)
+    if (has_parent) {
+        float Lb[3], L[3];
+        Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
+        add_cross(Lb, ub + 3, t);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Lb[r] * tot[c] + ub[3 + r] * tot[3 + c];
+        mat_vec(J, tot, L);
+        add_cross(tbr, L, ub + 3);
+    }
+    out.wjb = wjb;
+    out.ajb = ajb;
+}
+
 template <int CAP, class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT,
           class PG>
 DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int flags,
@@ -1028,53 +1147,9 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
 #pragma unroll
                 for (int i = 0; i < 12; ++i) mb[i] += x12[i];
             }
-            float *wb = mb, *vb = mb + 3, *alb = mb + 6, *ab = mb + 9;
             float mo[12], fb[6];
             unpark(k, 0, mo, 12);
             unpark(k, 18, fb, 6);
-            const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
-            const float *fl = fb, *fa = fb + 3; // adjoint of this link's body force = tbar_k
-            const float m = of[DRM_OPF_MASS];
-            const float *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
-            // body force: hl = m v - mc x w, ha = Io w + mc x v, gl = m a - mc x al, ga = Io al + mc x a,
-            //             f.lin = gl + w x hl,  f.ang = ga + w x ha + v x hl
-            float hl[3], ha[3], x[3];
-            cross3(mc, w, x);
-            hl[0] = m * v[0] - x[0]; hl[1] = m * v[1] - x[1]; hl[2] = m * v[2] - x[2];
-            mat_vec(Io, w, ha);
-            add_cross(ha, mc, v);
-            float hlb[3] = {0, 0, 0}, hab[3] = {0, 0, 0};
-            add_cross(hlb, fl, w); add_cross(hlb, fa, v);
-            add_cross(hab, fa, w);
-            add_cross(wb, hl, fl); add_cross(wb, ha, fa);
-            add_cross(vb, hl, fa);
-            float gm = 0.0f, gmc[3] = {0, 0, 0}, gIo[9];
-            // hl
-            gm += hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2];
-            vb[0] += m * hlb[0]; vb[1] += m * hlb[1]; vb[2] += m * hlb[2];
-            sub_cross(gmc, w, hlb);
-            sub_cross(wb, hlb, mc);
-            // ha
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) gIo[r * 3 + c] = hab[r] * w[c] + fa[r] * al[c];
-            matT_vec(Io, hab, x);
-            wb[0] += x[0]; wb[1] += x[1]; wb[2] += x[2];
-            add_cross(gmc, v, hab);
-            add_cross(vb, hab, mc);
-            // gl (adjoint fl)
-            gm += fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
-            ab[0] += m * fl[0]; ab[1] += m * fl[1]; ab[2] += m * fl[2];
-            sub_cross(gmc, al, fl);
-            sub_cross(alb, fl, mc);
-            // ga (adjoint fa)
-            matT_vec(Io, fa, x);
-            alb[0] += x[0]; alb[1] += x[1]; alb[2] += x[2];
-            add_cross(gmc, a, fa);
-            add_cross(ab, fa, mc);
-
-            // link motion from the parent's: adjoint
             float J[9], t[3], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
             joint(k, J, t);
             if (dof[k] >= 0) { float q; qf(dof[k], q, wj, aj); qdk = wj; }
@@ -1088,70 +1163,17 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             } else {
                 unpark(k > 0 ? k - 1 : 0, 0, par, 12);
             }
-            const float *Pw = par, *Pv = par + 3, *Pal = par + 6, *Pa = par + 9;
-            float pb[12], Jb[9], tbr[3] = {0, 0, 0}, wjb = 0.0f, ajb = 0.0f, y[3], yb[3];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) pb[i] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Jb[i] = 0.0f;
-            float *Pwb = pb, *Pvb = pb + 3, *Palb = pb + 6, *Pab = pb + 9;
-            // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)
-            y[0] = Pa[0]; y[1] = Pa[1]; y[2] = Pa[2];
-            add_cross(y, Pal, t);
-            mat_vec(J, ab, yb);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * ab[c];
-            vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
-            wjb += ab[0] * v[1] - ab[1] * v[0];
-            Pab[0] += yb[0]; Pab[1] += yb[1]; Pab[2] += yb[2];
-            add_cross(Palb, t, yb);
-            add_cross(tbr, yb, Pal);
-            // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)
-            mat_vec(J, alb, x);
-            Palb[0] += x[0]; Palb[1] += x[1]; Palb[2] += x[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pal[r] * alb[c];
-            ajb += alb[2];
-            wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
-            wjb += alb[0] * w[1] - alb[1] * w[0];
-            // v = J^T (Pv + Pw x t)
-            y[0] = Pv[0]; y[1] = Pv[1]; y[2] = Pv[2];
-            add_cross(y, Pw, t);
-            mat_vec(J, vb, yb);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * vb[c];
-            Pvb[0] += yb[0]; Pvb[1] += yb[1]; Pvb[2] += yb[2];
-            add_cross(Pwb, t, yb);
-            add_cross(tbr, yb, Pw);
-            // w = J^T Pw + wj e_z
-            mat_vec(J, wb, x);
-            Pwb[0] += x[0]; Pwb[1] += x[1]; Pwb[2] += x[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pw[r] * wb[c];
-            wjb += wb[2];
-            // the force transform of sweep B: up.lin = J tot.lin, up.ang = J tot.ang + t x (J tot.lin)
+            float ub[6] = {0, 0, 0, 0, 0, 0}, tot[6] = {0, 0, 0, 0, 0, 0};
             if (src != DRM_SRC_ROOT) {
-                float ub[6], tot[6], Lb[3], L[3];
                 if (src >= 0) slot_get(src, 18, ub, 6);
                 else unpark(k > 0 ? k - 1 : 0, 18, ub, 6);
                 unpark(k, 12, tot, 6);
-                Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
-                add_cross(Lb, ub + 3, t);
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Lb[r] * tot[c] + ub[3 + r] * tot[3 + c];
-                mat_vec(J, tot, L);
-                add_cross(tbr, L, ub + 3);
             }
+            LinkAdjoint A;
+            rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tot,
+                              src != DRM_SRC_ROOT, A);
+            const float *pb = A.pb, *Jb = A.Jb, *tbr = A.tb, *gmc = A.gmc, *gIo = A.gIo;
+            const float gm = A.gm, wjb = A.wjb, ajb = A.ajb;
             // J = F Rot_z(q)
             const float gtk = dof[k] >= 0 ? gtau(dof[k]) : 0.0f;
             if (want_gq && dof[k] >= 0) {
@@ -1184,6 +1206,154 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                 for (int i = 0; i < 12; ++i) carry[i] = pb[i];
             }
         }
+    }
+}
+
+// Reverse-mode RNEA of a serial chain (DRM_WALK_ARM_CHAIN): the four sweeps of rnea_backward_walk without the int
+// table, slots or parked records.  Total forces and their adjoints of the CAP links live in registers (static
+// indices), and the link motions are NOT stored: the joint transform is orthogonal, so sweep D recovers a parent's
+// motion from its child's (w_p = J (w - wj e_z), v_p = J v - w_p x t, ...) while it walks back to the root.
+//   row(k) -> op k's constant row;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
+template <int CAP, int NJ, class ROW, class GOUT, class PG>
+DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t param_mask, bool want_gq,
+                                const float (&q)[NJ], const float (&qd)[NJ], const float (&qdd)[NJ],
+                                const float (&gtau)[NJ], GOUT gout, PG param_out) {
+    float cs[NJ], sn[NJ];
+    bool big = false;
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) {
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < NJ; d += 2) {
+            f2 s2, c2;
+            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
+            sn[d] = s2[0]; cs[d] = c2[0];
+            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
+        }
+    }
+    const float g = gravity ? 9.81f : 0.0f;
+    auto joint = [&](int k, float *J, float *t) {
+        const OpFT o = load_ft(row(k));
+        if (k < NJ) {
+            joint_rot_z(o.F, cs[k], sn[k], J);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+        }
+        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+    };
+    // ---- A: motions (only the last one is kept) and body forces ----------------------------------------
+    float tot[CAP][6], tb[CAP][6], last[12];
+    {
+        Motion cur;
+        motion_root(cur, g);
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const float *of = row(k);
+            float J[9], t[3];
+            joint(k, J, t);
+            rnea_link_motion(J, t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, cur, cur);
+            Force f;
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { tot[k][i] = f.la[i][0]; tot[k][3 + i] = f.la[i][1]; }
+        }
+        motion_to_floats(cur, last);
+    }
+    // ---- B: total forces ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = CAP - 1; k > 0; --k) {
+        float J[9], t[3], up[6];
+        joint(k, J, t);
+        mat_vec(J, tot[k], up);
+        mat_vec(J, tot[k] + 3, up + 3);
+        add_cross(up + 3, t, up);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tot[k - 1][i] += up[i];
+    }
+    // ---- C: adjoint of B ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tb[k][i] = 0.0f;
+        if (k > 0) {
+            float J[9], t[3], Lb[3];
+            joint(k, J, t);
+            Lb[0] = tb[k - 1][0]; Lb[1] = tb[k - 1][1]; Lb[2] = tb[k - 1][2];
+            add_cross(Lb, tb[k - 1] + 3, t);
+            matT_vec(J, Lb, tb[k]);
+            matT_vec(J, tb[k - 1] + 3, tb[k] + 3);
+        }
+        if (k < NJ) tb[k][5] += gtau[k];
+    }
+    // ---- D: adjoint of A, walking the motions back to the root ------------------------------------------
+    float mo[12], mb[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { mo[i] = last[i]; mb[i] = 0.0f; }
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = row(k);
+        float J[9], t[3];
+        joint(k, J, t);
+        const float wj = k < NJ ? qd[k] : 0.0f, aj = k < NJ ? qdd[k] : 0.0f;
+        // parent's motion from this link's (inverse of rnea_link_motion; J is orthogonal)
+        float par[12];
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) par[i] = 0.0f;
+            par[11] = g;
+        } else {
+            const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
+            float x[3], y[3];
+            x[0] = w[0]; x[1] = w[1]; x[2] = w[2] - wj;
+            mat_vec(J, x, par);                                   // w_p
+            mat_vec(J, v, y);
+            sub_cross(y, par, t);                                 // v_p = J v - w_p x t
+            par[3] = y[0]; par[4] = y[1]; par[5] = y[2];
+            x[0] = al[0] - w[1] * wj; x[1] = al[1] + w[0] * wj; x[2] = al[2] - aj;
+            mat_vec(J, x, par + 6);                               // al_p
+            x[0] = a[0] - v[1] * wj; x[1] = a[1] + v[0] * wj; x[2] = a[2];
+            mat_vec(J, x, y);
+            sub_cross(y, par + 6, t);                             // a_p = J (a - v x wj e_z) - al_p x t
+            par[9] = y[0]; par[10] = y[1]; par[11] = y[2];
+        }
+        const float zero6[6] = {0, 0, 0, 0, 0, 0};
+        LinkAdjoint A;
+        rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, tb[k], par, mb,
+                          k > 0 ? tb[k - 1] : zero6, tot[k], k > 0, A);
+        if (k < NJ) {
+            const float gtk = gtau[k];
+            if (want_gq) {
+                float gq = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gq += A.Jb[r * 3 + 0] * J[r * 3 + 1] - A.Jb[r * 3 + 1] * J[r * 3 + 0];
+                gout(k, gq, A.wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), A.ajb);
+            }
+        }
+        if ((param_mask >> k) & 1u) {
+            const float c_ = k < NJ ? cs[k] : 1.0f, s_ = k < NJ ? sn[k] : 0.0f;
+            float gr[DRM_OPF_STRIDE];
+#pragma unroll
+            for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                gr[DRM_OPF_FIJ(r, 0)] = A.Jb[r * 3 + 0] * c_ - A.Jb[r * 3 + 1] * s_;
+                gr[DRM_OPF_FIJ(r, 1)] = A.Jb[r * 3 + 0] * s_ + A.Jb[r * 3 + 1] * c_;
+                gr[DRM_OPF_FIJ(r, 2)] = A.Jb[r * 3 + 2];
+                gr[DRM_OPF_TI(r)] = A.tb[r];
+                gr[DRM_OPF_MCOM + r] = A.gmc[r];
+            }
+            gr[DRM_OPF_MASS] = A.gm;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = A.gIo[i];
+            gr[DRM_OPF_DAMP] = (damping && k < NJ) ? gtau[k < NJ ? k : 0] * qd[k < NJ ? k : 0] : 0.0f;
+            param_out(k, gr);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { mb[i] = A.pb[i]; mo[i] = par[i]; }
     }
 }
 

@@ -263,6 +263,25 @@ int emu_link_rows_backward(const float *params, const float *grad_rows, int32_t 
         link_row_backward(params + i * LINK_PARAM_FLOATS, grad_rows + i * DRM_OPF_STRIDE, grad_params + i * LINK_PARAM_FLOATS);
     return 0;
 }
+int emu_rnea_backward_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
+                          const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    constexpr int CAP = 8, NJ = 7;
+    static thread_local double sum[CAP * DRM_OPF_STRIDE];
+    for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) sum[i] = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        float qv[NJ], qdv[NJ], qddv[NJ], gt[NJ];
+        for (int d = 0; d < NJ; ++d) {
+            qv[d] = q[b * NJ + d]; qdv[d] = qd[b * NJ + d]; qddv[d] = qdd ? qdd[b * NJ + d] : 0.f; gt[d] = gtau[b * NJ + d];
+        }
+        rnea_backward_chain<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                                     flags & DRM_RNEA_DAMPING, mask, gq != nullptr, qv, qdv, qddv, gt,
+                                     [&](int d, float a, float v, float c) { gq[b * NJ + d] = a; gqd[b * NJ + d] = v; gqdd[b * NJ + d] = c; },
+                                     [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; });
+    }
+    if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
+    return 0;
+}
 int emu_crba_arm(const drm_walk *w, const float *q, int64_t B, float *H) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     for (int64_t b = 0; b < B; ++b) {

@@ -106,6 +106,30 @@ def test_emu_backward_vs_reference_autograd(emu, case):
         assert close(p.grad.numpy(), ref), (case, key, p.grad.numpy().reshape(-1), ref.reshape(-1))
 
 
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "fetch_arm_no_gripper_small_damping"])
+@pytest.mark.parametrize("flags", [0, 3])
+def test_emu_arm_chain_backward_equals_generic_walk(emu, robot, flags):
+    """rnea_backward_chain (registers, motions recovered on the way back) against rnea_backward_walk (parked records),
+    which the test above pins to the reference's autograd."""
+    m = load_model(robot)
+    n, B = m._n_dofs, 21
+    q, qd, qdd = sample_states(m, B, seed=77)
+    gtau = np.random.default_rng(1).standard_normal((B, n)).astype(np.float32)
+    prog = build_walk(m._spec, whole_tree=True)
+    assert prog.shape & 1
+    walk, keep = host_walk(m, prog)
+    mask = 0b10110101
+    out = {}
+    for name in ("emu_rnea_backward", "emu_rnea_backward_arm"):
+        gq, gqd, gqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+        gops = np.full((prog.capacity, 32), np.nan, np.float32)
+        assert getattr(emu, name)(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(gtau),
+                                  ctypes.c_uint32(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+        out[name] = (gq, gqd, gqdd, gops)
+    for a, b in zip(out["emu_rnea_backward"], out["emu_rnea_backward_arm"]):
+        assert close(b, a, 2e-4), np.abs(a - b).max()
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
@@ -170,3 +194,31 @@ def test_gpu_learn_dynamics_loop_lowers_the_loss():
         opt.step()
         first = first if first is not None else loss.item()
     assert loss.item() < 0.5 * first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [64, 200, 4096])
+def test_gpu_arm_chain_backward_vs_emu(emu, B):
+    """7-DoF arms take rnea_backward_arm_kernel for the full tiles and the generic kernel for the ragged tail; both
+    feed one reduction."""
+    g = load_golden_dyn()
+    case = "panda_no_gripper"
+    m, params = learnable_model(g, case, "cuda")
+    mc, params_c = learnable_model(g, case, "cpu")
+    q, qd, qdd = sample_states(m, B, seed=B + 1)
+    want = np.random.default_rng(B).standard_normal((B, 7)).astype(np.float32)
+    tq, tqd, tqdd = (torch.from_numpy(a).cuda().requires_grad_(True) for a in (q, qd, qdd))
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        for t in (tq, tqd, tqdd):
+            t.grad = None
+        loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(tq, tqd, tqdd), torch.from_numpy(want).cuda())
+        loss.backward()
+        grads.append([p.grad.clone() for p in params.values()] + [tq.grad.clone()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads)), "deterministic"
+    _, _, gq, gqd, gqdd = emu_loss_and_grads(emu, mc, q, qd, qdd, want)
+    assert close(tq.grad.cpu().numpy(), gq, 3e-4) and close(tqd.grad.cpu().numpy(), gqd, 3e-4)
+    assert close(tqdd.grad.cpu().numpy(), gqdd, 3e-4)
+    for key in params:
+        assert close(params[key].grad.cpu().numpy(), params_c[key].grad.numpy(), 3e-4), key
