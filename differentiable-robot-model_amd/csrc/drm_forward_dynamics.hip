@@ -127,6 +127,71 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
 }
 
+// Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,
+// rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled Cholesky; constants
+// staged once per wave in LDS, RNEA's body forces parked over the dead input tiles, qdd staged over them at the end.
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    forward_dynamics_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                                const float *__restrict__ f, int n_tiles, int flags, float *__restrict__ qdd) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
+    static_assert(3 * Q_FLOATS <= F_FLOATS, "the input tiles fit under the parking area");
+    constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lf = lqd + Q_FLOATS;
+    float *park = lq + lane; // body forces between RNEA's sweeps: [link][6][64], over the (by then dead) input tiles
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
+    tile_load<NJ>(f + b0 * NJ, WAVE, NJ, 0u, lf, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    float qv[NJ], qdv[NJ], rhs[NJ], zero[NJ], nle[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) {
+        qv[d] = lq[lane * NJ + d];
+        qdv[d] = lqd[lane * NJ + d];
+        rhs[d] = lf[lane * NJ + d];
+        zero[d] = 0.0f;
+    }
+    wave_lds_sync(); // all rows are in registers: the tiles may be overwritten
+    auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    float Ht[NJ * (NJ + 1) / 2];
+    crba_chain<CAP, NJ>(row, qv, [&](int i, int j, float v) {
+        if (i >= j) Ht[tri_index(i, j)] = v;
+    });
+    rnea_chain<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, qv, qdv, zero, nle,
+                        [&](int k, const Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                park[(k * 6 + i) * WAVE] = F.la[i][0];
+                                park[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                            }
+                        },
+                        [&](int k, Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(park[(k * 6 + i) * WAVE], park[(k * 6 + 3 + i) * WAVE]);
+                        });
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) rhs[d] -= nle[d];
+    cholesky_solve_unrolled<NJ>(Ht, rhs);
+    wave_lds_sync(); // every lane is done with the parking area before qdd is staged over it
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = rhs[d];
+    wave_lds_sync();
+    tile_store<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+}
+
 } // namespace drm
 
 using namespace drm;
@@ -139,6 +204,25 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs, nn = n * (n + 1) / 2;
+#ifndef DRM_NO_ARM_KERNEL
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
+        (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
+        // 7-DoF arms: full tiles through the register-resident chain kernel, ragged tail through the generic one
+        const int n_tiles = (int)(B / WAVE);
+        hipLaunchKernelGGL((forward_dynamics_arm_kernel<8, 7>),
+                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, (hipStream_t)stream, w->ops_f, q, qd, f, n_tiles, (int)flags,
+                           qdd);
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done == B) return launched();
+        rc = launched();
+        if (rc) return rc;
+        drm_walk generic = *w;
+        generic.shape &= ~DRM_WALK_ARM_CHAIN;
+        return drm_forward_dynamics(&generic, q + done * n, qd + done * n, f + done * n, B - done, flags, qdd + done * n,
+                                    stream);
+    }
+#endif
     const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
     if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
     Geometry g;

@@ -1684,7 +1684,7 @@ DRM_HD void crba_chain(ROW row, const float (&q)[NJ], HOUT hout) {
 // Used by the forward-dynamics kernel: qdd = H^-1 (f - nle) is the same linear system the reference's
 // articulated-body recursion (robot_model.py:487-624) solves link by link.
 // ---------------------------------------------------------------------------
-DRM_HD int tri_index(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
+DRM_HD constexpr int tri_index(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 DRM_HD void cholesky_solve(int n, float *H, float *b) {
     for (int j = 0; j < n; ++j) {
         float *Hj = H + tri_index(j, 0);
@@ -1708,6 +1708,41 @@ DRM_HD void cholesky_solve(int n, float *H, float *b) {
     for (int i = n - 1; i >= 0; --i) {
         float t = b[i];
         for (int k = i + 1; k < n; ++k) t -= H[tri_index(k, i)] * b[k];
+        b[i] = t * H[tri_index(i, i)];
+    }
+}
+
+// The same factorisation and solves for a compile-time size, fully unrolled: H (packed lower triangle) and b live
+// in registers (the arm kernels: n = 7, 28 + 7 floats).
+template <int N>
+DRM_HD void cholesky_solve_unrolled(float (&H)[N * (N + 1) / 2], float (&b)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float s = H[tri_index(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= H[tri_index(j, k)] * H[tri_index(j, k)];
+        const float inv = rsqrt_f(s);
+        H[tri_index(j, j)] = inv;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            float t = H[tri_index(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= H[tri_index(i, k)] * H[tri_index(j, k)];
+            H[tri_index(i, j)] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float t = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= H[tri_index(i, k)] * b[k];
+        b[i] = t * H[tri_index(i, i)];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        float t = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) t -= H[tri_index(k, i)] * b[k];
         b[i] = t * H[tri_index(i, i)];
     }
 }

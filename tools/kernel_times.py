@@ -47,6 +47,12 @@ for B in sizes:
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(crba)
     print("crba        panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
+    acc = torch.empty(B, 7, device="cuda")
+    def fd():
+        backend._check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 1,
+                                                acc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(fd)
+    print("fwd dyn     panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s" % (B, us, B * 112 / us / 1e3, B / us / 1e3))
     gtau = torch.randn(B, 7, device="cuda")
     us = graph_time(lambda: backend.rnea_backward(dt.program, of, dt.ops_i, q, qd, qdd, gtau, True, True, 7, 0b10, True), launches=20)
     print("rnea bwd    panda B=%8d %9.2f us  %7.1f GB/s (196 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" %
