@@ -40,7 +40,7 @@ _lock = threading.Lock()
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
-           "drm_link_rows_backward")
+           "drm_link_rows_backward", "drm_fk_fanout")
 
 
 def load_library(path: str = None):
@@ -66,6 +66,8 @@ def load_library(path: str = None):
         lib.drm_last_error.argtypes = []
         lib.drm_fk.restype = ctypes.c_int
         lib.drm_fk.argtypes = [wp, vp, i64, i32, vp, vp, vp]
+        lib.drm_fk_fanout.restype = ctypes.c_int
+        lib.drm_fk_fanout.argtypes = [wp, i32, vp, i64, vp, vp, vp]
         lib.drm_fk_jacobian.restype = ctypes.c_int
         lib.drm_fk_jacobian.argtypes = [wp, vp, i64, vp, vp, vp, vp, vp]
         lib.drm_rnea.restype = ctypes.c_int
@@ -133,6 +135,21 @@ def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     with torch.cuda.device(q.device):
         _check(lib.drm_fk(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
                           _stream(q.device)))
+    return pos, quat
+
+
+def fk_fanout(chains, q, n_dofs: int):
+    """FK of 2..4 targets with (nearly) disjoint chains: ``chains`` = [(prog, ops_f, ops_i)] per target."""
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    B, T = q.shape[0], len(chains)
+    pos = torch.empty(B, T, 3, device=q.device, dtype=torch.float32)
+    quat = torch.empty(B, T, 4, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return pos, quat
+    walks = (DrmWalk * T)(*[_walk_struct(p, f.detach(), i, n_dofs) for p, f, i in chains])
+    with torch.cuda.device(q.device):
+        _check(lib.drm_fk_fanout(walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)))
     return pos, quat
 
 

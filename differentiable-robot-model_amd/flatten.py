@@ -226,8 +226,10 @@ def _gather_row(spec: RobotSpec, link: int):
     return row, sgn
 
 
-def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False) -> WalkProgram:
-    """Depth-first walk over the links needed to reach ``targets`` (or all links)."""
+def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False,
+               min_capacity: int = 0) -> WalkProgram:
+    """Depth-first walk over the links needed to reach ``targets`` (or all links); ``min_capacity`` pads it to at least
+    that compiled capacity (chains that are launched together share one)."""
     L = spec.n_links
     needed = np.zeros(L, bool)
     if whole_tree:
@@ -280,7 +282,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     n_ops = len(ops)
     if spec.n_dofs > MAX_DOFS:
         raise UnsupportedRobotError("%d DoFs exceed the supported maximum %d" % (spec.n_dofs, MAX_DOFS))
-    cap = _capacity_for(max(n_ops, 1))
+    cap = _capacity_for(max(n_ops, 1, min_capacity))
     # identity padding: fixed joint, F = I, t = 0, mass-less, chained to the previous op
     ops_i = np.zeros((cap, OPI_STRIDE), np.int32)
     ops_i[:, OPI_DOF] = -1

@@ -191,6 +191,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._spec: RobotSpec = build_robot_spec(body_params, parent_names)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
+        self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
@@ -289,6 +290,28 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw.static_ops_f = ops_f
         return ops_f
 
+    def _fanout_chains(self, targets, merged: _DeviceWalk):
+        """Per-target chain walks for the fan-out FK kernel, or None when the merged walk is the better plan: 2..4
+        targets whose chains overlap so little that walking them separately costs < 1.25x the ops of the merged
+        walk (the fingertips of a hand: every finger hangs off the palm)."""
+        key = ("fanout", tuple(targets))
+        if key not in self._fanout_plans:
+            plan = None
+            if 2 <= len(targets) <= 4:
+                lengths = [len(self._spec.chain_to(t)) for t in targets]
+                if sum(lengths) <= 1.25 * merged.program.n_ops and merged.program.n_ops > 8:
+                    cap = max(build_walk(self._spec, targets=[t]).capacity for t in targets)
+                    plan = []
+                    for t in targets:
+                        prog = build_walk(self._spec, targets=[t], min_capacity=cap)
+                        plan.append(_DeviceWalk(
+                            program=prog,
+                            ops_i=torch.from_numpy(prog.ops_i_dev).to(self._device).contiguous(),
+                            gather=torch.from_numpy(prog.gather.reshape(-1)).to(self._device),
+                            gsign=torch.from_numpy(prog.gsign.reshape(-1)).to(self._device)))
+            self._fanout_plans[key] = plan
+        return self._fanout_plans[key]
+
     def _kinematic_param_mask(self, dw: _DeviceWalk) -> int:
         """bit k set <=> op k's R_fixed / trans come from a learnable parametrisation (needs a constant gradient)."""
         links = {link for link, pname in self._learnable if pname in ("trans", "rot_angles")}
@@ -377,7 +400,11 @@ class DifferentiableRobotModel(torch.nn.Module):
         if non_root:
             dw = self._get_walk(("fk", tuple(non_root)), targets=non_root)
             ops_f = self._ops_f(dw)
-            if torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
+            needs_grad = torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad)
+            fan = None if needs_grad else self._fanout_chains(non_root, dw)
+            if fan is not None:
+                p, r = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs)
+            elif needs_grad:
                 p, r = _FkPositions.apply(q, ops_f, dw, len(non_root), self._n_dofs, self._kinematic_param_mask(dw))
             else:
                 p, r = backend.fk(dw.program, ops_f, dw.ops_i, q, len(non_root), self._n_dofs)
@@ -543,6 +570,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable_links = None
         for dw in self._walks.values():
             dw.static_ops_f = None
+        for plan in self._fanout_plans.values():
+            for dw in plan or []:
+                dw.static_ops_f = None
 
     def _learnable_module(self, link_name: str, parameter_name: str):
         parent_object = self._get_parent_object_of_param(link_name, parameter_name)

@@ -134,6 +134,15 @@ int drm_fk(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets,
            float *pos, float *quat, void *stream);
 
 /*
+ * drm_fk for 2 .. 4 targets whose root->target chains are (nearly) disjoint — the fingertips of a hand: `chains[t]`
+ * is the single-target walk of target t (all with the same capacity and n_dofs, no branch points); a block of T
+ * wavefronts owns 64 samples and wavefront t walks only chain t (the "per-link fan-out" of the parent-index tree).
+ * Same outputs as drm_fk with the merged walk: pos [B, T, 3], quat [B, T, 4].
+ */
+int drm_fk_fanout(const drm_walk *chains, int32_t n_chains, const float *q, int64_t B, float *pos, float *quat,
+                  void *stream);
+
+/*
  * FK + geometric Jacobian of ONE target link; the walk is the root->link chain
  * and its last op is the target.
  * Replaces DifferentiableRobotModel.compute_endeffector_jacobian (robot_model.py:626-667),

@@ -264,3 +264,31 @@ def test_update_kinematic_state_exposes_body_pose_and_velocity():
         w_ref = np.einsum("bji,bj->bi", R[:, i], np.einsum("bij,bj->bi", ang, qd.astype(np.float64)))
         vel = m._bodies[i].vel
         assert max_err(host(vel.lin), v_ref) <= 5e-6 and max_err(host(vel.ang), w_ref) <= 5e-6
+
+
+@pytest.mark.parametrize("robot,tips", [
+    ("allegro_left", ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]),
+    ("allegro_left", ["link_15.0_tip", "link_3.0_tip"]),
+    ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"]),
+])
+@pytest.mark.parametrize("B", [1, 63, 64, 200])
+def test_fanout_fk_equals_merged_walk_and_oracle(robot, tips, B):
+    """Hands: the fingertip chains are disjoint, so `_fk_targets` plans one wavefront per chain (drm_fk_fanout); the
+    merged multi-target walk (drm_fk) and the oracle must agree with it."""
+    from differentiable_robot_model_amd import backend
+    m = load_model(robot, "cuda")
+    idx = [m._name_to_idx_map[t] for t in tips]
+    q, _, _ = sample_states(m, B, seed=300 + B)
+    pos, quat = m._fk_targets(dev(q), idx)
+    dw = m._get_walk(("fk", tuple(idx)), targets=idx)
+    assert m._fanout_chains(idx, dw) is not None, "these targets are expected to take the fan-out plan"
+    pm, qm = backend.fk(dw.program, m._ops_f(dw), dw.ops_i, dev(q), len(idx), m._n_dofs)   # merged walk
+    assert max_err(host(pos), host(pm)) <= 1e-6 and max_err(host(quat), host(qm)) <= 1e-6
+    rp, rq = Oracle(m._spec).fk(q.astype(np.float64), idx, np.float64)
+    assert max_err(host(pos), rp) <= TOL_POS["atol"]
+    ok, _ = quat_close(host(quat), rq, TOL_QUAT["atol"])
+    assert ok
+    # arms keep the merged / chain kernels
+    arm = load_model("panda_no_gripper", "cuda")
+    two = [arm._name_to_idx_map[n] for n in ("panda_link4", "panda_virtual_ee_link")]
+    assert arm._fanout_chains(two, arm._get_walk(("fk", tuple(two)), targets=two)) is None
