@@ -203,7 +203,7 @@ def main():
                                  "includes inter-launch gaps); a 65 536-sample launch is one wave per SIMD and "
                                  "latency-bound, see DESIGN.md §6 for B=2^20..2^22 (>=75% of peak)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(model._spec, model._name_to_idx_map[link],
                                                 q.cpu().numpy(), args.cpu_seconds)
         print(json.dumps(line))

@@ -497,8 +497,9 @@ DRM_HD void fk_walk(const float *__restrict__ opf, const int32_t *__restrict__ o
     for (int k = 0; k < CAP; ++k) {
         const OpPairs o = load_pairs(opf + k * DRM_OPF_STRIDE);
         const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
+        if ((ctl[k] >> 24) & 1) continue; // identity padding behind the last link of the walk (wave-uniform)
         f2 J01[3];
-        joint_pairs(o, cs[k], sn[k], J01); // c = 1, s = 0 (fixed joint / padding) gives the F pairs back exactly
+        joint_pairs(o, cs[k], sn[k], J01); // c = 1, s = 0 (fixed joint) gives the F pairs back exactly
         if (src >= 0) slot_load(src, cur);
         if (src == DRM_SRC_ROOT) compose_pairs_root(J01, o, cur);
         else compose_pairs(cur, J01, o, cur);

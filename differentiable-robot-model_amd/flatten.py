@@ -309,6 +309,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     ops_i[:, OPI_CTRL] = (((ops_i[:, OPI_DOF] + 1) & 0x7f) | (((ops_i[:, OPI_SRC] + 2) & 7) << 7)
                           | (((ops_i[:, OPI_SAVE] + 1) & 7) << 10) | (((ops_i[:, OPI_OUT] + 1) & 0x7f) << 13)
                           | ((ops_i[:, OPI_PERM] & 7) << 20) | ((ops_i[:, OPI_FLAGS] & 1) << 23))
+    ops_i[n_ops:, OPI_CTRL] |= 1 << 24   # identity padding (a walk to the root itself has n_ops = 0: all padding)
     mask = 0
     for row in ops:
         if row[OPI_DOF] >= 0:

@@ -78,3 +78,12 @@ def fka():
                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 us = graph_time(fka)
 print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)" % (us, 65536 * 176 / us / 1e3))
+fan = ma._fanout_chains(tips, da)
+if fan is not None:
+    chains = [(c.program, ma._ops_f(c), c.ops_i) for c in fan]
+    walks = (backend.DrmWalk * len(chains))(*[backend._walk_struct(p, f, i, 16) for p, f, i in chains])
+    def fan_fk():
+        backend._check(backend.load_library().drm_fk_fanout(walks, len(chains), qa.data_ptr(), 65536, pa.data_ptr(), ra.data_ptr(),
+                                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(fan_fk)
+    print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)   fan-out kernel (one wavefront per finger)" % (us, 65536 * 176 / us / 1e3))
