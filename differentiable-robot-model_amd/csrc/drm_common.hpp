@@ -217,6 +217,45 @@ __device__ __forceinline__ void stage_table(const float *__restrict__ ops_f, flo
 
 constexpr int BWD_MAX_WAVES = 2048; // 256 CUs x 4 SIMDs x 2: waves of a backward launch = rows of its partial sums
 
+// Sum of the partial-sum rows a backward launch left behind (one row of NV floats per wave), in a FIXED order so that
+// parameter gradients are bit-stable from run to run: a block of REDUCE_WAVES wavefronts owns 64 consecutive
+// columns (lane = column: every row is read as one 256-byte segment); wavefront w adds rows w, w+16, w+32, ... into
+// REDUCE_UNROLL independent running sums (that many rows in flight per wavefront: the loads are latency-bound),
+// merges them pairwise, and wavefront 0 adds the 16 wave sums in order.  Returns the column total on wavefront 0.
+constexpr int REDUCE_WAVES = 16, REDUCE_UNROLL = 16;
+__device__ __forceinline__ float column_sum(const float *__restrict__ partials, int n_rows, int NV, int column, bool live,
+                                            float (*lds)[WAVE]) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const float *p = partials + (live ? column : 0);
+    float s[REDUCE_UNROLL];
+#pragma unroll
+    for (int u = 0; u < REDUCE_UNROLL; ++u) s[u] = 0.0f;
+    int r = wave;
+    for (; r + (REDUCE_UNROLL - 1) * REDUCE_WAVES < n_rows; r += REDUCE_UNROLL * REDUCE_WAVES) {
+        float v[REDUCE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < REDUCE_UNROLL; ++u) v[u] = p[(int64_t)(r + u * REDUCE_WAVES) * NV];
+#pragma unroll
+        for (int u = 0; u < REDUCE_UNROLL; ++u) s[u] += v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < REDUCE_UNROLL; ++u) // the last, partial round: same slots, rows past the end add nothing
+        s[u] += (r + u * REDUCE_WAVES < n_rows) ? p[(int64_t)(r + u * REDUCE_WAVES) * NV] : 0.0f;
+#pragma unroll
+    for (int w = REDUCE_UNROLL / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) s[u] += s[u + w];
+    lds[wave][lane] = live ? s[0] : 0.0f;
+    __syncthreads();
+    float total = 0.0f;
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < REDUCE_WAVES; ++w) total += lds[w][lane];
+    }
+    return total;
+}
+
 struct WaveCtx {
     unsigned lane;
     int rows;    // valid samples of this tile (wave-uniform)

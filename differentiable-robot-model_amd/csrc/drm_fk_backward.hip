@@ -130,21 +130,22 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
 }
 
-// grad_ops_f[k, j] = sum over the partial rows, fixed order: lane l adds rows l, l+64, ... then the wave adds lanes.
-__global__ void __launch_bounds__(WAVE)
+// grad_ops_f[k, FT field j] = sum over the partial rows of column k * 12 + j, in a fixed order (drm_common.hpp
+// column_sum); the rest of the row has no gradient here and is zeroed.
+__global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
     fk_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f) {
-    const int k = blockIdx.x;
-    const unsigned lane = threadIdx.x;
-    const int NV = cap * BWD_FIELDS;
-    // the FT block holds exactly the 12 differentiated constants; the rest of the row has no gradient here
-    if (lane < DRM_OPF_STRIDE - BWD_FIELDS) grad_ops_f[k * DRM_OPF_STRIDE + BWD_FIELDS + lane] = 0.0f;
-    for (int j = 0; j < BWD_FIELDS; ++j) {
-        float s = 0.0f;
-        for (int r = (int)lane; r < n_rows; r += WAVE) s += partials[(int64_t)r * NV + k * BWD_FIELDS + j];
-        s = wave_sum_lane63(s);
+    __shared__ float lds[REDUCE_WAVES][WAVE];
+    const int NV = cap * BWD_FIELDS, e = (int)blockIdx.x * WAVE + (int)(threadIdx.x & 63u);
+    const float total = column_sum(partials, n_rows, NV, e, e < NV, lds);
+    if (threadIdx.x < WAVE && e < NV) {
+        const int k = e / BWD_FIELDS, j = e % BWD_FIELDS;
         const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
-        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + at] = s;
+        grad_ops_f[k * DRM_OPF_STRIDE + at] = total;
     }
+    // the FT block holds exactly the 12 differentiated constants
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < cap * (DRM_OPF_STRIDE - BWD_FIELDS);
+         i += (int)(gridDim.x * blockDim.x))
+        grad_ops_f[(i / (DRM_OPF_STRIDE - BWD_FIELDS)) * DRM_OPF_STRIDE + BWD_FIELDS + i % (DRM_OPF_STRIDE - BWD_FIELDS)] = 0.0f;
 }
 
 } // namespace drm
@@ -195,7 +196,7 @@ extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int
     rc = launched();
     if (rc) return rc;
     if (grad_ops_f) {
-        hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, scratch, waves, cap,
+        hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s, scratch, waves, cap,
                            grad_ops_f);
         rc = launched();
     }

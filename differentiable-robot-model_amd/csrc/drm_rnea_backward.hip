@@ -136,18 +136,13 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
 }
 
-// grad_ops_f[k, j] = sum over the partial rows in a fixed order (lane l adds rows l, l+64, ..., then the wave adds lanes)
-__global__ void __launch_bounds__(WAVE)
+// grad_ops_f[e] = sum over the partial rows of column e, in a fixed order (drm_common.hpp column_sum)
+__global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
     rnea_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f) {
-    const int k = blockIdx.x;
-    const unsigned lane = threadIdx.x;
-    const int NV = cap * DRM_OPF_STRIDE;
-    for (int j = 0; j < DRM_OPF_STRIDE; ++j) {
-        float s = 0.0f;
-        for (int r = (int)lane; r < n_rows; r += WAVE) s += partials[(int64_t)r * NV + k * DRM_OPF_STRIDE + j];
-        s = wave_sum_lane63(s);
-        if (lane == 63) grad_ops_f[k * DRM_OPF_STRIDE + j] = s;
-    }
+    __shared__ float lds[REDUCE_WAVES][WAVE];
+    const int NV = cap * DRM_OPF_STRIDE, e = (int)blockIdx.x * WAVE + (int)(threadIdx.x & 63u);
+    const float total = column_sum(partials, n_rows, NV, e, e < NV, lds);
+    if (threadIdx.x < WAVE && e < NV) grad_ops_f[e] = total;
 }
 
 // Serial-chain ("arm") specialisation, full tiles only: drm_sample.hpp rnea_backward_chain (per-link forces and their
@@ -311,7 +306,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
                 rows += 1;
             }
             if (grad_ops_f) {
-                hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, partials, rows, cap,
+                hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)(cap * DRM_OPF_STRIDE / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s, partials, rows, cap,
                                    grad_ops_f);
                 rc = launched();
             }
@@ -346,7 +341,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
     rc = launched();
     if (rc) return rc;
     if (grad_ops_f) {
-        hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)cap), dim3(WAVE), 0, s, partials, waves, cap,
+        hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)(cap * DRM_OPF_STRIDE / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s, partials, waves, cap,
                            grad_ops_f);
         rc = launched();
     }
