@@ -9,26 +9,29 @@
 //
 // Per sample: in q, qd, qdd, grad_tau [n]; out grad_q, grad_qd, grad_qdd [n] (optional).      n = 7: 112 + 84 B
 // Per launch: out grad_ops_f[cap, 32] (every constant of the ops selected by param_mask, zeros elsewhere).
-// Per-link records (24 floats: motion, total force, its adjoint) are parked between the sweeps in LDS, or, when a
-// big walk does not fit, in a slice of the caller's scratch buffer in HBM (PARK_HBM).
-// LDS per wave: [ q qd qdd grad_tau : 4 x 64 (n|1) ][ grad_q grad_qd grad_qdd : 3 x 64 (n|1) ][ slots : n_slots*36*64 ]
-//               [ records : cap*24*64 unless PARK_HBM ]
+// Per-link records (26 floats: motion, total force, its adjoint, cos / sin of the joint angle) are parked between
+// the sweeps in LDS, or, when a big walk does not fit, in a slice of the caller's scratch buffer in HBM (PARK_HBM).
+// LDS per wave: [ q qd qdd grad_tau : 4 x 64 (n|1) ][ grad_q grad_qd grad_qdd : 3 x 64 (n|1) ]
+//               [ constant-gradient sums : cap*32 ][ slots : n_slots*36*64 ][ records : cap*26*64 unless PARK_HBM ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
 namespace drm {
 
-constexpr int REC_FLOATS = 24, SLOT_FLOATS = 36;
+constexpr int REC_FLOATS = 26, SLOT_FLOATS = 36;
 
-template <int CAP, bool PARK_HBM>
+// One kernel for every walk: the sweeps loop over the n_ops links (drm_sample.hpp rnea_backward_walk), so neither the
+// code nor the register file grows with the robot; `cap` only fixes the row pitch of grad_ops_f / the partial sums.
+template <bool PARK_HBM>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int flags,
-                         const float *__restrict__ q, const float *__restrict__ qd, const float *__restrict__ qdd,
-                         const float *__restrict__ gtau, int64_t B, float *__restrict__ gq, float *__restrict__ gqd,
-                         float *__restrict__ gqdd, uint32_t param_mask, float *__restrict__ partials,
-                         float *__restrict__ park_hbm, uint32_t magic_q, int lds_per_wave, uint32_t align) {
+    rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n,
+                         int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                         const float *__restrict__ qdd, const float *__restrict__ gtau, int64_t B, float *__restrict__ gq,
+                         float *__restrict__ gqd, float *__restrict__ gqdd, uint32_t param_mask,
+                         float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q, int lds_per_wave,
+                         uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NV = CAP * DRM_OPF_STRIDE, NACC = NV / WAVE;
+    const int NV = cap * DRM_OPF_STRIDE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const unsigned lane = threadIdx.x & 63u;
@@ -40,14 +43,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lq = smem + wave_in_block * lds_per_wave;
     float *lqd = lq + region, *lqdd = lqd + region, *lgt = lqdd + region;
     float *lgq = lgt + region, *lgqd = lgq + region, *lgqdd = lgqd + region;
-    float *lsl = lgqdd + region;                                   // slots   [slot][36][64]
-    float *lrec = lsl + n_slots * (SLOT_FLOATS * WAVE);            // records [op][24][64]
-    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)(CAP * REC_FLOATS * WAVE) : lrec) + lane;
+    float *lacc = lgqdd + region;                                  // this wave's running sums of the constant gradients
+    float *lsl = lacc + NV;                                        // slots   [slot][36][64]
+    float *lrec = lsl + n_slots * (SLOT_FLOATS * WAVE);            // records [op][26][64]
+    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)cap * (REC_FLOATS * WAVE) : lrec) + lane;
     float *slot = lsl + lane;
+    const int32_t *ctl = ops_i + DRM_OPI_CTRL * cap;
 
-    float acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
 
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = tile * WAVE;
@@ -74,14 +77,16 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         };
         auto gt = [&](int d) -> float { return live ? lgt[row + d] : 0.0f; };
         auto park = [&](int k, int off, const float *v, int cnt) {
+            float *r = rec + (k * REC_FLOATS + off) * WAVE;
 #pragma unroll
             for (int i = 0; i < 12; ++i)
-                if (i < cnt) rec[(k * REC_FLOATS + off + i) * WAVE] = v[i];
+                if (i < cnt) r[i * WAVE] = v[i];
         };
         auto unpark = [&](int k, int off, float *v, int cnt) {
+            const float *r = rec + (k * REC_FLOATS + off) * WAVE;
 #pragma unroll
             for (int i = 0; i < 12; ++i)
-                if (i < cnt) v[i] = rec[(k * REC_FLOATS + off + i) * WAVE];
+                if (i < cnt) v[i] = r[i * WAVE];
         };
         auto slot_put = [&](int s, int off, const float *v, int cnt) {
 #pragma unroll
@@ -107,23 +112,16 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                 }
         };
         auto gout = [&](int d, float a, float v, float c) { lgq[row + d] = a; lgqd[row + d] = v; lgqdd[row + d] = c; };
-        float add[NACC];
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
-        auto param_out = [&](int k, const float *g) {
+        auto param_out = [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
 #pragma unroll
             for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) { // the last constant of a row is the damping
                 const float mine = live ? g[j] : 0.0f; // lanes past a partial tile hold garbage
                 const float total = wave_sum_lane63(mine);
-                const int idx = k * DRM_OPF_STRIDE + j;
-                const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
-                if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s;
+                if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wave's fixed order
             }
         };
-        rnea_backward_walk<CAP>(ops_f, ops_i, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
-                                slot_add, slot_take, gout, param_out);
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += add[a];
+        rnea_backward_walk(ops_f, ctl, n_ops, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
+                           slot_add, slot_take, gout, param_out);
         if (gq) {
             wave_lds_sync();
             tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, fast && (align & AL_POS), full && (align & AL_POS));
@@ -131,9 +129,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             tile_store<0>(gqdd + b0 * n, rows, n, magic_q, lgqdd, lane, fast && (align & AL_LIN), full && (align & AL_LIN));
         }
     }
+    wave_lds_sync();
     float *prow = partials + wave_id * NV;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
 // grad_ops_f[e] = sum over the partial rows of column e, in a fixed order (drm_common.hpp column_sum)
@@ -224,7 +222,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 }
 
 static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, bool park_hbm) {
-    return (size_t)7 * round4(WAVE * pad_odd(n)) + (size_t)n_slots * SLOT_FLOATS * WAVE +
+    return (size_t)7 * round4(WAVE * pad_odd(n)) + (size_t)cap * DRM_OPF_STRIDE + (size_t)n_slots * SLOT_FLOATS * WAVE +
            (park_hbm ? 0 : (size_t)cap * REC_FLOATS * WAVE);
 }
 
@@ -291,11 +289,11 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
                 gt.grid = dim3(1);
                 gt.block = dim3(WAVE);
                 gt.lds_bytes = (size_t)gt.lds_per_wave * sizeof(float);
-                rc = ensure_lds(rnea_backward_kernel<8, false>, gt.lds_bytes);
+                rc = ensure_lds(rnea_backward_kernel<false>, gt.lds_bytes);
                 if (rc) return rc;
                 const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU);
-                hipLaunchKernelGGL((rnea_backward_kernel<8, false>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i,
-                                   n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
+                hipLaunchKernelGGL((rnea_backward_kernel<false>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i,
+                                   cap, (int)w->n_ops, n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
                                    qdd ? qdd + done * n : nullptr, grad_tau + done * n, B - done,
                                    grad_q ? grad_q + done * n : nullptr, grad_qd ? grad_qd + done * n : nullptr,
                                    grad_qdd ? grad_qdd + done * n : nullptr, param_mask,
@@ -324,19 +322,15 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
     float *park = scratch + (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE;
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU) |
                            al16(grad_q, AL_POS) | al16(grad_qd, AL_QUAT) | al16(grad_qdd, AL_LIN);
-#define DRM_LAUNCH_RB(C, HBM)                                                                                          \
+#define DRM_LAUNCH_RB(HBM)                                                                                             \
     {                                                                                                                  \
-        rc = ensure_lds(rnea_backward_kernel<C, HBM>, g.lds_bytes);                                                    \
+        rc = ensure_lds(rnea_backward_kernel<HBM>, g.lds_bytes);                                                       \
         if (rc) return rc;                                                                                             \
-        hipLaunchKernelGGL((rnea_backward_kernel<C, HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,     \
-                           (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd, grad_qdd, param_mask, \
-                           partials, park, div_magic(n), g.lds_per_wave, align);                                       \
+        hipLaunchKernelGGL((rnea_backward_kernel<HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, cap,      \
+                           (int)w->n_ops, n, (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd,    \
+                           grad_qdd, param_mask, partials, park, div_magic(n), g.lds_per_wave, align);                 \
     }
-    if (park_hbm) {
-        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_RB(C, true))
-    } else {
-        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_RB(C, false))
-    }
+    if (park_hbm) DRM_LAUNCH_RB(true) else DRM_LAUNCH_RB(false)
 #undef DRM_LAUNCH_RB
     rc = launched();
     if (rc) return rc;

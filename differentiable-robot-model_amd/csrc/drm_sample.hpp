@@ -885,8 +885,8 @@ DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ]
 //   C  k up    adjoint of B:  tbar_k = J^T-transformed tbar_parent + gtau_k e_(ang z)
 //   D  k down  adjoint of A:  motion adjoints from the body force and the children, then the adjoints of the
 //              joint transform (J, t) from both sweeps, of the constants (m, mc, Io, damping) and of q, qd, qdd
-// Layout of a parked link record (floats): 0..11 motion (w, v, al, a), 12..17 tot (lin, ang), 18..23 tbar;
-// of a slot record: the same 24 plus 24..35 the motion-adjoint accumulator.
+// Layout of a parked link record (floats): 0..11 motion (w, v, al, a), 12..17 tot (lin, ang), 18..23 tbar,
+// 24..25 (cos q, sin q) of the link's joint;  of a slot record: the first 24 plus 24..35 the motion-adjoint accumulator.
 //   park(k, off, v, n) / unpark(k, off, v, n)                       per-link records
 //   slot_put / slot_get / slot_add / slot_take(s, off, v, n)        branch-point records (take = read and zero)
 //   gtau(d) -> dL/dtau of DoF d;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
@@ -1029,22 +1029,21 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     out.ajb = ajb;
 }
 
-template <int CAP, class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT,
-          class PG>
-DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, int flags,
+// The sweeps are LOOPS over the n_ops links of the walk (no identity padding, one control word decoded per
+// iteration, nothing indexed by a compile-time op number): the adjoint of one link is ~700 instructions, so a
+// straight-line walk of 24 or 32 links neither fits the instruction cache nor the register file.
+//   ctl = the control-word field of the int table (DRM_OPI_CTRL), n_ops = links of the walk
+template <class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT, class PG>
+DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, int flags,
                                uint32_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
                                SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
-    DRM_LOAD_CTL();
-    int dof[CAP];
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
-    float cs[CAP], sn[CAP];
-    joint_trig<CAP>(dof, [&](int d) { float q, v, a; qf(d, q, v, a); return q; }, cs, sn);
-    auto joint = [&](int k, float *J, float *t) {
+    // joint transform of op k from its constants and the parked (cos, sin) of its angle
+    auto joint = [&](int k, float *J, float *t, float *trig) {
         const OpFT o = load_ft(opf + k * DRM_OPF_STRIDE);
-        joint_rot_z(o.F, cs[k], sn[k], J);
+        unpark(k, 24, trig, 2);
+        joint_rot_z(o.F, trig[0], trig[1], J);
         t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
     };
 
@@ -1052,16 +1051,23 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     {
         Motion cur;
         motion_root(cur, g);
-#pragma unroll
-        for (int k = 0; k < CAP; ++k) {
+#pragma unroll 1
+        for (int k = 0; k < n_ops; ++k) {
             const float *of = opf + k * DRM_OPF_STRIDE;
-            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
-            float wj = 0.0f, aj = 0.0f, J[9], t[3], rec[12];
-            if (dof[k] >= 0) { float q; qf(dof[k], q, wj, aj); }
-            joint(k, J, t);
+            const int c = ctl[k];
+            const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
+            float wj = 0.0f, aj = 0.0f, J[9], rec[12], trig[2] = {1.0f, 0.0f};
+            if (dof >= 0) {
+                float q;
+                qf(dof, q, wj, aj);
+                sincos_f(q, trig[1], trig[0]);
+            }
+            park(k, 24, trig, 2);
+            const OpFT o = load_ft(of);
+            joint_rot_z(o.F, trig[0], trig[1], J);
             if (src == DRM_SRC_ROOT) motion_root(cur, g);
             if (src >= 0) { slot_get(src, 0, rec, 12); motion_from_floats(rec, cur); }
-            rnea_link_motion(J, t, wj, aj, cur, cur);
+            rnea_link_motion(J, o.t, wj, aj, cur, cur);
             motion_to_floats(cur, rec);
             if (save >= 0) slot_put(save, 0, rec, 12);
             park(k, 0, rec, 12);
@@ -1074,12 +1080,13 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     // ---- B: total forces ---------------------------------------------------------------------------------
     {
         float carry[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = CAP - 1; k >= 0; --k) {
-            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+#pragma unroll 1
+        for (int k = n_ops - 1; k >= 0; --k) {
+            const int c = ctl[k];
+            const int src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
             float tot[6], x[6];
             unpark(k, 12, tot, 6);
-            if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
+            if (ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) tot[i] += carry[i];
             }
@@ -1090,8 +1097,8 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             }
             park(k, 12, tot, 6);
             if (src != DRM_SRC_ROOT) {
-                float J[9], t[3], up[6];
-                joint(k, J, t);
+                float J[9], t[3], trig[2], up[6];
+                joint(k, J, t, trig);
                 mat_vec(J, tot, up);
                 mat_vec(J, tot + 3, up + 3);
                 add_cross(up + 3, t, up);
@@ -1106,24 +1113,25 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     // ---- C: adjoint of B ---------------------------------------------------------------------------------
     {
         float prev[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < CAP; ++k) {
-            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+#pragma unroll 1
+        for (int k = 0; k < n_ops; ++k) {
+            const int c = ctl[k];
+            const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
             float tb[6] = {0, 0, 0, 0, 0, 0};
             if (src != DRM_SRC_ROOT) {
-                float ub[6], J[9], t[3], Lb[3];
+                float ub[6], J[9], t[3], trig[2], Lb[3];
                 if (src >= 0) slot_get(src, 18, ub, 6);
                 else {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) ub[i] = prev[i];
                 }
-                joint(k, J, t);
+                joint(k, J, t, trig);
                 Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
                 add_cross(Lb, ub + 3, t); // Lbar' = ubar.lin + ubar.ang x t
                 matT_vec(J, Lb, tb);
                 matT_vec(J, ub + 3, tb + 3);
             }
-            if (dof[k] >= 0) tb[5] += gtau(dof[k]);
+            if (dof >= 0) tb[5] += gtau(dof);
             park(k, 18, tb, 6);
             if (save >= 0) slot_put(save, 18, tb, 6);
 #pragma unroll
@@ -1135,14 +1143,16 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
         float carry[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) carry[i] = 0.0f;
-#pragma unroll
-        for (int k = CAP - 1; k >= 0; --k) {
+#pragma unroll 1
+        for (int k = n_ops - 1; k >= 0; --k) {
             const float *of = opf + k * DRM_OPF_STRIDE;
-            const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+            const int c = ctl[k];
+            const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
             // motion adjoint arriving from the children: (wb, vb, alb, ab)
             float mb[12], x12[12];
+            const bool chained = ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) mb[i] = (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) ? carry[i] : 0.0f;
+            for (int i = 0; i < 12; ++i) mb[i] = chained ? carry[i] : 0.0f;
             if (save >= 0) {
                 slot_take(save, 24, x12, 12);
 #pragma unroll
@@ -1151,9 +1161,9 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             float mo[12], fb[6];
             unpark(k, 0, mo, 12);
             unpark(k, 18, fb, 6);
-            float J[9], t[3], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
-            joint(k, J, t);
-            if (dof[k] >= 0) { float q; qf(dof[k], q, wj, aj); qdk = wj; }
+            float J[9], t[3], trig[2], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
+            joint(k, J, t, trig);
+            if (dof >= 0) { float q; qf(dof, q, wj, aj); qdk = wj; }
             float par[12];
             if (src == DRM_SRC_ROOT) {
 #pragma unroll
@@ -1176,12 +1186,12 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             const float *pb = A.pb, *Jb = A.Jb, *tbr = A.tb, *gmc = A.gmc, *gIo = A.gIo;
             const float gm = A.gm, wjb = A.wjb, ajb = A.ajb;
             // J = F Rot_z(q)
-            const float gtk = dof[k] >= 0 ? gtau(dof[k]) : 0.0f;
-            if (want_gq && dof[k] >= 0) {
+            const float gtk = dof >= 0 ? gtau(dof) : 0.0f;
+            if (want_gq && dof >= 0) {
                 float gq = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) gq += Jb[r * 3 + 0] * J[r * 3 + 1] - Jb[r * 3 + 1] * J[r * 3 + 0];
-                gout(dof[k], gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
+                gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
             }
             if ((param_mask >> k) & 1u) {
                 float gr[DRM_OPF_STRIDE];
@@ -1189,8 +1199,8 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                 for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * cs[k] - Jb[r * 3 + 1] * sn[k];
-                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * sn[k] + Jb[r * 3 + 1] * cs[k];
+                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * trig[0] - Jb[r * 3 + 1] * trig[1];
+                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * trig[1] + Jb[r * 3 + 1] * trig[0];
                     gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2];
                     gr[DRM_OPF_TI(r)] = tbr[r];
                     gr[DRM_OPF_MCOM + r] = gmc[r];

@@ -160,7 +160,7 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
     static thread_local double sum[CAP * DRM_OPF_STRIDE];
     for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) sum[i] = 0.0;
     for (int64_t b = 0; b < B; ++b) {
-        float rec[CAP][24], slots[DRM_MAX_SLOTS][36];
+        float rec[CAP][26], slots[DRM_MAX_SLOTS][36];
         for (auto &s : slots) for (float &x : s) x = 0.f;
         if (gq) for (int d = 0; d < n; ++d) { gq[b * n + d] = 0.f; gqd[b * n + d] = 0.f; gqdd[b * n + d] = 0.f; }
         auto qf = [&](int d, float &a, float &v, float &acc) { a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f; };
@@ -173,8 +173,8 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
         auto stake = [&](int s, int off, float *v, int cnt) { for (int i = 0; i < cnt; ++i) { v[i] = slots[s][off + i]; slots[s][off + i] = 0.f; } };
         auto gout = [&](int d, float a, float v, float acc) { gq[b * n + d] = a; gqd[b * n + d] = v; gqdd[b * n + d] = acc; };
         auto pout = [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; };
-        rnea_backward_walk<CAP>(w->ops_f, w->ops_i, flags, mask, gq != nullptr, qf, gt, park, unpark, sput, sget, sadd, stake,
-                                gout, pout);
+        rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->n_ops, flags, mask, gq != nullptr, qf, gt, park, unpark,
+                           sput, sget, sadd, stake, gout, pout);
     }
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
 }

@@ -87,3 +87,21 @@ if fan is not None:
                                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(fan_fk)
     print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)   fan-out kernel (one wavefront per finger)" % (us, 65536 * 176 / us / 1e3))
+# whole-tree dynamics of a branching robot through the generic (table-driven) kernels: Allegro, 21 links, 16 DoF
+for B in [s for s in sizes if s <= (1 << 20)]:
+    qa, qda, qdda = (t.cuda() for t in sample(ma, B))
+    ma.compute_inverse_dynamics(qa[:64], qda[:64], qdda[:64])
+    dta = ma._walks[("tree",)]; ofa = ma._ops_f(dta)
+    wt = backend._walk_struct(dta.program, ofa, dta.ops_i, 16)
+    lib = backend.load_library()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ta = torch.empty(B, 16, device="cuda"); Ha = torch.empty(B, 16, 16, device="cuda"); aa = torch.empty(B, 16, device="cuda")
+    ga = torch.randn(B, 16, device="cuda")
+    us = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 3, ta.data_ptr(), st())), launches=20)
+    print("rnea        allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
+    us = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(wt), qa.data_ptr(), B, Ha.data_ptr(), st())), launches=20)
+    print("crba        allegro B=%8d %9.2f us  %7.1f GB/s (1088 B/eval) %6.2f Gevals/s" % (B, us, B * 1088 / us / 1e3, B / us / 1e3))
+    us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), st())), launches=20)
+    print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
+    us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
+    print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
