@@ -145,6 +145,43 @@ class _InverseDynamics(torch.autograd.Function):
         return gq, gqd, gqdd, grad_ops, None, None, None, None, None
 
 
+class _ForwardDynamics(torch.autograd.Function):
+    """Forward dynamics with an implicit-function backward: qdd solves ID(q, qd, qdd; theta) = f, so for a loss
+    gradient g on qdd,  lambda = H(q)^-1 g  (one more solve, the same kernel with zero bias) and
+
+        dL/df = lambda,    dL/d(q, qd, theta) = -lambda^T dID/d(q, qd, theta) at (q, qd, qdd),
+
+    which is exactly the RNEA backward kernel fed with grad_tau = lambda (what torch autograd gets by differentiating
+    through the reference's articulated-body recursion, robot_model.py:487-624; examples/learn_forward_dynamics_iiwa.py)."""
+
+    @staticmethod
+    def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask):
+        qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs)
+        ctx.save_for_backward(q, qd, qdd, ops_f)
+        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask = dw, (gravity, damping), n_dofs, param_mask
+        return qdd
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_qdd):
+        q, qd, qdd, ops_f = ctx.saved_tensors
+        dw, n = ctx.dw, ctx.n_dofs
+        lam = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, torch.zeros_like(qd),
+                                       grad_qdd.to(torch.float32).contiguous(), False, False, n)
+        want_in = any(ctx.needs_input_grad[:2])
+        want_ops = ctx.needs_input_grad[3] and ctx.param_mask != 0
+        gq = gqd = grad_ops = None
+        if want_in or want_ops:
+            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, lam, ctx.flags[0], ctx.flags[1], n,
+                                              ctx.param_mask if want_ops else 0, want_in)
+            if gin is not None:
+                gq = -gin[0].reshape(q.shape) if ctx.needs_input_grad[0] else None
+                gqd = -gin[1].reshape(qd.shape) if ctx.needs_input_grad[1] else None
+            grad_ops = -gops if gops is not None else None
+        gf = lam.reshape(grad_qdd.shape) if ctx.needs_input_grad[2] else None
+        return gq, gqd, gf, grad_ops, None, None, None, None, None
+
+
 class DifferentiableRobotModel(torch.nn.Module):
     """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
 
@@ -498,18 +535,23 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._require_device()
         return self._inverse_dynamics(q, qd, None, bool(include_gravity), bool(use_damping))
 
+    def _learnable_op_mask(self, dw) -> int:
+        """Bit k set <=> op k of the walk belongs to a link with a learnable parameter (param_mask of the backward kernels)."""
+        links = {link for link, _ in self._learnable}
+        mask = 0
+        for k, link in enumerate(dw.program.links):
+            if int(link) in links:
+                mask |= 1 << k
+        return mask
+
     def _inverse_dynamics(self, q, qd, qdd, gravity: bool, damping: bool) -> torch.Tensor:
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
         needs_grad = torch.is_grad_enabled() and (ops_f.requires_grad or any(
             t is not None and t.requires_grad for t in (q, qd, qdd)))
         if needs_grad:
-            links = {link for link, _ in self._learnable}
-            mask = 0
-            for k, link in enumerate(dw.program.links):
-                if int(link) in links:
-                    mask |= 1 << k
-            return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs, mask)
+            return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs,
+                                          self._learnable_op_mask(dw))
         return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
 
     @tensor_check
@@ -538,16 +580,20 @@ class DifferentiableRobotModel(torch.nn.Module):
         The reference runs Featherstone's articulated-body recursion; this solves the same linear system
         H(q) qdd = f - nle(q, qd) in one fused kernel (composite-rigid-body H, RNEA bias torques, Cholesky).
         With ``use_damping`` the reference subtracts damping * qd from its ``f`` argument IN PLACE
-        (robot_model.py:515-521); here ``f`` is left untouched.
+        (robot_model.py:515-521); here ``f`` is left untouched.  Differentiable with respect to q, qd, f and the
+        learnable link parameters (implicit differentiation: one more solve + the RNEA backward kernel).
         """
         assert q.ndim == 2
         assert qd.ndim == 2
         assert q.shape[1] == self._n_dofs
         assert qd.shape[1] == self._n_dofs
         self._require_device()
-        self._refuse_autograd("compute_forward_dynamics", q, qd, f)
         dw = self._get_walk(("tree",), whole_tree=True)
-        return backend.forward_dynamics(dw.program, self._ops_f(dw), dw.ops_i, q, qd, f, bool(include_gravity),
+        ops_f = self._ops_f(dw)
+        if torch.is_grad_enabled() and (ops_f.requires_grad or any(t.requires_grad for t in (q, qd, f))):
+            return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
+                                          self._learnable_op_mask(dw))
+        return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
                                         bool(use_damping), self._n_dofs)
 
     # ------------------------------------------------------------------ learnable parameters

@@ -131,3 +131,119 @@ def test_gpu_forward_dynamics_inverts_inverse_dynamics_full_size():
     tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
     back = m.compute_forward_dynamics(q, qd, tau, include_gravity=True, use_damping=True)
     assert ((back - qdd).abs() / (1 + qdd.abs())).max().item() < 5e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gradients of a forward-dynamics loss (examples/learn_forward_dynamics_iiwa.py): implicit differentiation
+# (lambda = H^-1 g, then the RNEA backward with grad_tau = lambda, negated) against torch autograd through the
+# reference's articulated-body recursion (tests/golden/golden_grad_fd.npz, made by tests/golden/make_golden_grad_fd.py).
+# Tolerance: relative to the largest entry of each gradient tensor; the gradient carries cond(H) twice (two solves).
+# ---------------------------------------------------------------------------------------------------------------
+FD_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu"]
+FD_GRAD_RTOL = {"iiwa7": 2e-3, "panda_no_gripper": 2e-3, "trifinger_edu": 1e-2}
+
+
+def load_golden_grad_fd():
+    return np.load(os.path.join(GOLDEN_DIR, "golden_grad_fd.npz"), allow_pickle=False)
+
+
+def learnable_model_fd(g, case, device="cpu"):
+    """test_rnea_backward.learnable_model with the inertia parametrisation of make_golden_grad_fd.py."""
+    from differentiable_robot_model_amd.rigid_body_params import SymmPosDef3DInertiaMatrixNet
+    from test_rnea_backward import parametrization
+    m = load_model(case, device)
+    params = {}
+    for key in g[case + "/keys"]:
+        link, pname, tensor_name = str(key).split("/")
+        mod = SymmPosDef3DInertiaMatrixNet() if (pname == "inertia_mat" and case != "iiwa7") else parametrization(pname)
+        m.make_link_param_learnable(link, pname, mod)
+        p = dict(mod.named_parameters())[tensor_name]
+        with torch.no_grad():
+            p.copy_(torch.from_numpy(g["%s/init/%s" % (case, key)].copy()).reshape(p.shape).to(p.device))
+        params[str(key)] = p
+    return m, params
+
+
+def grad_close(a, b, rtol):
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    return np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-12)
+
+
+@pytest.mark.parametrize("case", FD_GRAD_CASES)
+def test_emu_forward_dynamics_backward_vs_reference_autograd(emu, case):
+    from test_rnea_backward import dynamic_param_mask
+    g = load_golden_grad_fd()
+    m, params = learnable_model_fd(g, case)
+    q, qd, f = (np.ascontiguousarray(g["%s/%s" % (case, k)]) for k in ("q", "qd", "f"))
+    want = g[case + "/want"]
+    prog = build_walk(m._spec, whole_tree=True)
+    table = m._link_table()
+    ops_f_t = (table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))]
+               * torch.from_numpy(prog.gsign.reshape(-1))).reshape(prog.capacity, 32)
+    ops_f = np.ascontiguousarray(ops_f_t.detach().numpy(), np.float32)
+    walk, _keep = host_walk(m, prog)
+    walk.ops_f = ops_f.ctypes.data
+    B, n = q.shape
+    qdd = np.zeros((B, n), np.float32)
+    assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), 3, _ptr(qdd)) == 0
+    assert rel_err(qdd, g[case + "/qdd"]) <= tol_of(case)
+    gqdd = np.ascontiguousarray(2.0 * (qdd - want) / (B * n), np.float32)
+    lam, zero = np.zeros((B, n), np.float32), np.zeros((B, n), np.float32)
+    assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(zero), _ptr(gqdd), ctypes.c_int64(B), 0, _ptr(lam)) == 0
+    gq, gqd, gx = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+    gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(lam),
+                                 ctypes.c_uint32(dynamic_param_mask(m, prog)), _ptr(gq), _ptr(gqd), _ptr(gx), _ptr(gops)) == 0
+    rtol = FD_GRAD_RTOL[case]
+    assert grad_close(-gq, g[case + "/grad_q"], rtol), np.abs(-gq - g[case + "/grad_q"]).max()
+    assert grad_close(-gqd, g[case + "/grad_qd"], rtol)
+    assert grad_close(lam, g[case + "/grad_f"], rtol)
+    m.zero_grad()
+    ops_f_t.backward(torch.from_numpy(-gops))
+    for key, p in params.items():
+        ref = g["%s/grad/%s" % (case, key)]
+        assert grad_close(p.grad.numpy(), ref, rtol), (case, key, p.grad.numpy().reshape(-1), ref.reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FD_GRAD_CASES)
+def test_gpu_forward_dynamics_backward_vs_reference_autograd(case):
+    g = load_golden_grad_fd()
+    m, params = learnable_model_fd(g, case, "cuda")
+    q, qd, f = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).cuda().requires_grad_(True) for k in ("q", "qd", "f"))
+    want = torch.from_numpy(g[case + "/want"].copy()).cuda()
+    qdd = m.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True)
+    loss = torch.nn.functional.mse_loss(qdd, want)
+    loss.backward()
+    rtol = FD_GRAD_RTOL[case]
+    assert abs(loss.item() - float(g[case + "/loss"])) <= 2 * tol_of(case) * max(1.0, float(g[case + "/loss"]))
+    assert grad_close(q.grad.cpu().numpy(), g[case + "/grad_q"], rtol)
+    assert grad_close(qd.grad.cpu().numpy(), g[case + "/grad_qd"], rtol)
+    assert grad_close(f.grad.cpu().numpy(), g[case + "/grad_f"], rtol)
+    for key, p in params.items():
+        assert grad_close(p.grad.cpu().numpy(), g["%s/grad/%s" % (case, key)], rtol), (case, key)
+
+
+@pytest.mark.gpu
+def test_gpu_learn_forward_dynamics_loop_lowers_the_loss():
+    """examples/learn_forward_dynamics_iiwa.py:55-90 in miniature: mass, com and inertia of iiwa_link_1 learned from
+    accelerations of the ground-truth model."""
+    from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, UnconstrainedTensor
+    torch.manual_seed(0)
+    gt = load_model("iiwa7", "cuda")
+    m = load_model("iiwa7", "cuda")
+    m.make_link_param_learnable("iiwa_link_1", "mass", PositiveScalar())
+    m.make_link_param_learnable("iiwa_link_1", "com", UnconstrainedTensor(dim1=1, dim2=3))
+    m.make_link_param_learnable("iiwa_link_1", "inertia_mat", UnconstrainedTensor(dim1=3, dim2=3))
+    q, qd, f = (torch.from_numpy(a).cuda() for a in sample_states(gt, 256, seed=3))
+    with torch.no_grad():
+        want = gt.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True), want)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
