@@ -145,6 +145,41 @@ class _InverseDynamics(torch.autograd.Function):
         return gq, gqd, gqdd, grad_ops, None, None, None, None, None
 
 
+class _MassMatrix(torch.autograd.Function):
+    """Joint-space inertia matrix with a backward built on the reference's own definition of H
+    (robot_model.py:402-450): column j is the inverse dynamics of a unit acceleration of joint j at rest without
+    gravity, H[:, :, j] = ID(q, 0, e_j), so for a loss gradient G on H the gradients with respect to q and to the
+    learnable link parameters are n passes of the RNEA backward kernel with qdd = e_j and grad_tau = G[:, :, j]."""
+
+    @staticmethod
+    def forward(ctx, q, ops_f, dw, n_dofs, param_mask):
+        H = backend.crba(dw.program, ops_f, dw.ops_i, q, n_dofs)
+        ctx.save_for_backward(q, ops_f)
+        ctx.dw, ctx.n_dofs, ctx.param_mask = dw, n_dofs, param_mask
+        return H
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_H):
+        q, ops_f = ctx.saved_tensors
+        dw, n = ctx.dw, ctx.n_dofs
+        want_q = ctx.needs_input_grad[0]
+        mask = ctx.param_mask if ctx.needs_input_grad[1] else 0
+        G = grad_H.to(torch.float32)
+        zero = torch.zeros_like(q)
+        gq = grad_ops = None
+        for j in range(n):
+            unit = torch.zeros_like(q)
+            unit[:, j] = 1.0
+            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, zero, unit, G[:, :, j].contiguous(), False,
+                                              False, n, mask, want_q)
+            if gin is not None:
+                gq = gin[0] if gq is None else gq + gin[0]
+            if gops is not None:
+                grad_ops = gops if grad_ops is None else grad_ops + gops
+        return (gq.reshape(q.shape) if gq is not None else None), grad_ops, None, None, None
+
+
 class _ForwardDynamics(torch.autograd.Function):
     """Forward dynamics with an implicit-function backward: qdd solves ID(q, qd, qdd; theta) = f, so for a loss
     gradient g on qdd,  lambda = H(q)^-1 g  (one more solve, the same kernel with zero bias) and
@@ -562,14 +597,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         The reference assembles H from n + 1 inverse-dynamics passes, column j = ID(q, 0, e_j) - ID(q, 0, 0);
         ``include_gravity`` / ``use_damping`` cancel out of that difference (gravity is subtracted, damping
         multiplies qd = 0) and are accepted for signature compatibility only.  One fused
-        composite-rigid-body kernel here.
+        composite-rigid-body kernel here; differentiable with respect to q and the learnable link parameters
+        (n passes of the RNEA backward kernel, one per column).
         """
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         self._require_device()
-        self._refuse_autograd("compute_lagrangian_inertia_matrix", q)
         dw = self._get_walk(("tree",), whole_tree=True)
-        return backend.crba(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
+        ops_f = self._ops_f(dw)
+        if torch.is_grad_enabled() and (ops_f.requires_grad or q.requires_grad):
+            return _MassMatrix.apply(q, ops_f, dw, self._n_dofs, self._learnable_op_mask(dw))
+        return backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
     @tensor_check
     def compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,

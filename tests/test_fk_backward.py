@@ -221,8 +221,6 @@ def test_gpu_autograd_refused_where_no_backward_kernel_exists():
     q = torch.zeros(4, 7, device="cuda", requires_grad=True)
     with pytest.raises(NotImplementedError):
         m.compute_endeffector_jacobian(q, "iiwa_link_ee")
-    with pytest.raises(NotImplementedError):
-        m.compute_lagrangian_inertia_matrix(q)
     with torch.no_grad():
         m.compute_endeffector_jacobian(q, "iiwa_link_ee")
 

@@ -112,3 +112,73 @@ def test_gpu_crba_full_size_consistent_with_rnea():
     assert (lhs - rhs).abs().max().item() < 5e-5
     assert torch.equal(H, H.transpose(1, 2))
     assert torch.linalg.eigvalsh(H[:4096].double()).min().item() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gradients of a loss on H: n passes of the RNEA backward (column j: qdd = e_j, grad_tau = dL/dH[:, :, j]) against
+# torch autograd through the reference's n + 1 inverse-dynamics construction (tests/golden/golden_grad_mass.npz,
+# made by tests/golden/make_golden_grad_mass.py).
+# ---------------------------------------------------------------------------------------------------------------
+H_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu"]
+H_GRAD_RTOL = 2e-3
+
+
+def load_golden_grad_mass():
+    import os
+    from helpers import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "golden_grad_mass.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("case", H_GRAD_CASES)
+def test_emu_mass_matrix_backward_vs_reference_autograd(emu, case):
+    from test_forward_dynamics import grad_close, learnable_model_fd
+    from test_rnea_backward import dynamic_param_mask
+    g = load_golden_grad_mass()
+    m, params = learnable_model_fd(g, case)
+    q = np.ascontiguousarray(g[case + "/q"])
+    B, n = q.shape
+    prog = build_walk(m._spec, whole_tree=True)
+    table = m._link_table()
+    ops_f_t = (table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))]
+               * torch.from_numpy(prog.gsign.reshape(-1))).reshape(prog.capacity, 32)
+    ops_f = np.ascontiguousarray(ops_f_t.detach().numpy(), np.float32)
+    walk, _keep = host_walk(m, prog)
+    walk.ops_f = ops_f.ctypes.data
+    H = np.full((B, n, n), np.nan, np.float32)
+    assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    assert np.allclose(H, g[case + "/H"], **TOL_H_REF), np.abs(H - g[case + "/H"]).max()
+    G = (2.0 * g[case + "/weight"] * (H - g[case + "/want"]) / H.size).astype(np.float32)
+    zero = np.zeros((B, n), np.float32)
+    gq_sum, gops_sum = np.zeros((B, n), np.float64), np.zeros((prog.capacity, 32), np.float64)
+    mask = dynamic_param_mask(m, prog)
+    for j in range(n):
+        unit = np.zeros((B, n), np.float32); unit[:, j] = 1.0
+        gt = np.ascontiguousarray(G[:, :, j])
+        gq, gqd, gqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+        gops = np.full((prog.capacity, 32), np.nan, np.float32)
+        assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(zero), _ptr(unit), ctypes.c_int64(B), 0, _ptr(gt),
+                                     ctypes.c_uint32(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+        gq_sum += gq; gops_sum += gops
+    assert grad_close(gq_sum, g[case + "/grad_q"], H_GRAD_RTOL), np.abs(gq_sum - g[case + "/grad_q"]).max()
+    m.zero_grad()
+    ops_f_t.backward(torch.from_numpy(gops_sum.astype(np.float32)))
+    for key, p in params.items():
+        ref = g["%s/grad/%s" % (case, key)]
+        assert grad_close(p.grad.numpy(), ref, H_GRAD_RTOL), (case, key, p.grad.numpy().reshape(-1), ref.reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", H_GRAD_CASES)
+def test_gpu_mass_matrix_backward_vs_reference_autograd(case):
+    from test_forward_dynamics import grad_close, learnable_model_fd
+    g = load_golden_grad_mass()
+    m, params = learnable_model_fd(g, case, "cuda")
+    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
+    want, weight = (torch.from_numpy(g[case + "/" + k].copy()).cuda() for k in ("want", "weight"))
+    H = m.compute_lagrangian_inertia_matrix(q)
+    loss = (weight * (H - want) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(g[case + "/loss"])) <= 1e-3 * max(1e-6, float(g[case + "/loss"]))
+    assert grad_close(q.grad.cpu().numpy(), g[case + "/grad_q"], H_GRAD_RTOL)
+    for key, p in params.items():
+        assert grad_close(p.grad.cpu().numpy(), g["%s/grad/%s" % (case, key)], H_GRAD_RTOL), (case, key)
