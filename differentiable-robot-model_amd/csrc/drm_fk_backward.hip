@@ -22,11 +22,14 @@ namespace drm {
 
 constexpr int BWD_FIELDS = 12;          // dF (9) + dt (3) per op
 
-template <int CAP>
+// JAC: the walk is the root -> end-effector chain and the loss also depends on the geometric Jacobian
+// (glin, gang [B, 3, n] = dL/d lin_jac, dL/d ang_jac; gpos may be NULL); magic_g then divides by 3 n as well as by 3 T.
+template <int CAP, bool JAC>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int T,
-                       const float *__restrict__ q, const float *__restrict__ gpos, int64_t B, float *__restrict__ gq,
-                       uint32_t param_mask, float *__restrict__ partials, uint32_t magic_q, uint32_t magic_g,
+                       const float *__restrict__ q, const float *__restrict__ gpos, const float *__restrict__ glin,
+                       const float *__restrict__ gang, int64_t B, float *__restrict__ gq, uint32_t param_mask,
+                       float *__restrict__ partials, uint32_t magic_q, uint32_t magic_g, uint32_t magic_j,
                        int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NV = CAP * BWD_FIELDS, NACC = (NV + WAVE - 1) / WAVE;
@@ -37,12 +40,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     const int64_t n_waves = (int64_t)gridDim.x * wpb;
     const int64_t n_tiles = (B + WAVE - 1) / WAVE;
 
-    const int Sq = pad_odd(n), Sg = pad_odd(3 * T);
+    const int Sq = pad_odd(n), Sg = pad_odd(3 * T), Sj = pad_odd(3 * n);
     float *lq = smem + wave_in_block * lds_per_wave;
     float *lg = lq + round4(WAVE * Sq);
     float *lgq = lg + round4(WAVE * Sg);
     float *lps = lgq + round4(WAVE * Sq);       // pose slots    [slot][12][64]
     float *las = lps + n_slots * (12 * WAVE);   // adjoint slots [slot][12][64]
+    float *ljl = las + n_slots * (12 * WAVE);   // JAC: dL/d lin_jac, dL/d ang_jac tiles, each 64 (3n|1)
+    float *lja = ljl + round4(WAVE * Sj);
 
     float acc[NACC];
 #pragma unroll
@@ -56,8 +61,15 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         const bool live = (int)lane < rows;
         wave_lds_sync(); // the previous tile's LDS reads are done before this tile overwrites
         tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, full && (n & 1) && (align & AL_Q), full && (align & AL_Q));
-        tile_load<0>(gpos + b0 * 3 * T, rows, 3 * T, magic_g, lg, lane, full && ((3 * T) & 1) && (align & AL_POS),
-                     full && (align & AL_POS));
+        if (!JAC || gpos)
+            tile_load<0>(gpos + b0 * 3 * T, rows, 3 * T, magic_g, lg, lane, full && ((3 * T) & 1) && (align & AL_POS),
+                         full && (align & AL_POS));
+        if (JAC) {
+            tile_load<0>(glin + b0 * 3 * n, rows, 3 * n, magic_j, ljl, lane, full && ((3 * n) & 1) && (align & AL_LIN),
+                         full && (align & AL_LIN));
+            tile_load<0>(gang + b0 * 3 * n, rows, 3 * n, magic_j, lja, lane, full && ((3 * n) & 1) && (align & AL_ANG),
+                         full && (align & AL_ANG));
+        }
         for (int s = 0; s < n_slots * 12; ++s) las[s * WAVE + lane] = 0.0f;
         wave_lds_sync();
 
@@ -68,8 +80,12 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             for (int d = 0; d < n; ++d) gqrow[d] = 0.0f; // DoFs that are not on any target's chain
         auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; }; // zeros, not stale LDS, past a partial tile
         auto grad_in = [&](int t, float *G) {
+            if (JAC && !gpos) return;
             G[0] += grow[t * 3 + 0]; G[1] += grow[t * 3 + 1]; G[2] += grow[t * 3 + 2];
         };
+        const float *jlrow = ljl + lane * Sj, *jarow = lja + lane * Sj;
+        auto jac_lin = [&](int d, float *v) { v[0] = jlrow[d]; v[1] = jlrow[n + d]; v[2] = jlrow[2 * n + d]; };
+        auto jac_ang = [&](int d, float *v) { v[0] = jarow[d]; v[1] = jarow[n + d]; v[2] = jarow[2 * n + d]; };
         auto pose_save = [&](int s, const Pose &P) {
             float *b = lps + s * (12 * WAVE) + lane;
 #pragma unroll
@@ -112,8 +128,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                 if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s; // lane idx%64 of accumulator idx/64 owns (k, j)
             }
         };
-        fk_backward_walk<CAP>(ops_f, ops_i, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
-                              adj_take, gq_out, param_out);
+        fk_backward_walk<CAP, JAC>(ops_f, ops_i, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
+                                   adj_take, gq_out, param_out, jac_lin, jac_ang);
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] += add[a];
         if (gq) {
@@ -158,11 +174,10 @@ extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
     return (int64_t)backward_waves(B, MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS;
 }
 
-extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                               uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
-    int rc = check_walk(w);
-    if (rc) return rc;
-    if (!q || !grad_pos) return fail(DRM_ERR_INVALID, "q / grad_pos must not be NULL");
+static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
+                              const float *grad_lin, const float *grad_ang, uint32_t param_mask, float *grad_q,
+                              float *grad_ops_f, float *scratch, void *stream) {
+    const bool jac = grad_lin != nullptr;
     if (B < 0 || n_targets < 1) return fail(DRM_ERR_INVALID, "negative batch or no targets");
     if (n_targets > w->n_ops) return fail(DRM_ERR_INVALID, "more targets than ops in the walk");
     if ((param_mask != 0) != (grad_ops_f != nullptr))
@@ -180,25 +195,52 @@ extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int
         return DRM_OK;
     }
     Geometry g;
-    rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE, g);
+    int rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE +
+                                  (jac ? 2 * round4(WAVE * pad_odd(3 * n)) : 0), g);
     if (rc) return rc;
     const int wpb = (int)(g.block.x / WAVE);
     const int waves = backward_waves(B, wpb);
     g.grid = dim3((unsigned)(waves / wpb));
-    const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU);
-    DRM_DISPATCH_CAP(cap, {
-        rc = ensure_lds(fk_backward_kernel<C>, g.lds_bytes);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fk_backward_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                           (int)w->n_slots, T, q, grad_pos, B, grad_q, param_mask, scratch, div_magic(n),
-                           div_magic(3 * T), g.lds_per_wave, align);
-    })
+    const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU) | al16(grad_lin, AL_LIN) |
+                           al16(grad_ang, AL_ANG);
+#define DRM_LAUNCH_FB(C, JAC)                                                                                          \
+    {                                                                                                                  \
+        rc = ensure_lds(fk_backward_kernel<C, JAC>, g.lds_bytes);                                                      \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((fk_backward_kernel<C, JAC>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,       \
+                           (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q, param_mask, scratch,        \
+                           div_magic(n), div_magic(3 * T), div_magic(3 * n), g.lds_per_wave, align);                   \
+    }
+    if (jac) {
+        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, true))
+    } else {
+        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, false))
+    }
+#undef DRM_LAUNCH_FB
     rc = launched();
     if (rc) return rc;
     if (grad_ops_f) {
-        hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s, scratch, waves, cap,
-                           grad_ops_f);
+        hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + WAVE - 1) / WAVE)),
+                           dim3(WAVE * REDUCE_WAVES), 0, s, scratch, waves, cap, grad_ops_f);
         rc = launched();
     }
     return rc;
+}
+
+extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
+                               uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !grad_pos) return fail(DRM_ERR_INVALID, "q / grad_pos must not be NULL");
+    return fk_backward_launch(w, q, B, n_targets, grad_pos, nullptr, nullptr, param_mask, grad_q, grad_ops_f, scratch, stream);
+}
+
+extern "C" int drm_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *grad_pos,
+                                        const float *grad_lin_jac, const float *grad_ang_jac, uint32_t param_mask,
+                                        float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !grad_lin_jac || !grad_ang_jac) return fail(DRM_ERR_INVALID, "q / grad_lin_jac / grad_ang_jac must not be NULL");
+    if (w->n_slots != 0) return fail(DRM_ERR_INVALID, "the walk must be the root->link chain of the Jacobian's target (no branch points)");
+    return fk_backward_launch(w, q, B, 1, grad_pos, grad_lin_jac, grad_ang_jac, param_mask, grad_q, grad_ops_f, scratch, stream);
 }

@@ -543,10 +543,14 @@ struct Adjoint {
     float M[9];
 };
 
-template <int CAP, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG>
+struct NoJacobianGrad { // fk_backward_walk without Jacobian gradients
+    DRM_HD void operator()(int, float *) const {}
+};
+template <int CAP, bool JAC = false, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG,
+          class GL = NoJacobianGrad, class GA = NoJacobianGrad>
 DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, uint32_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
-                             ATAKE adj_take, GQ gq_out, PG param_out) {
+                             ATAKE adj_take, GQ gq_out, PG param_out, GL glin = GL(), GA gang = GA()) {
     DRM_LOAD_CTL();
     int dof[CAP];
 #pragma unroll
@@ -570,6 +574,25 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         if (save >= 0) pose_save(save, cur);
         P[k] = cur;
     }
+    // ---- Jacobian gradients (JAC: the walk is the root -> end-effector chain, its last op the target) ---------
+    // column d(k) of the geometric Jacobian is (lin, ang) = (z_k x (p_e - p_k), z_k), so loss gradients (l_k, a_k)
+    // on the columns are gradients on the chain's poses:  dL/dz_k = a_k + (p_e - p_k) x l_k  enters M_k as
+    // (dL/dz_k) z_k^T (M = Rbar R^T in general: the position-only case above is its special case),
+    // dL/dp_k = -(l_k x z_k), and dL/dp_e = sum_k l_k x z_k.
+    float Se[3] = {0.0f, 0.0f, 0.0f};
+    if (JAC) {
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            if (dof[k] >= 0) {
+                float l[3];
+                glin(dof[k], l);
+                const float z[3] = {P[k].R[2], P[k].R[5], P[k].R[8]};
+                Se[0] += l[1] * z[2] - l[2] * z[1];
+                Se[1] += l[2] * z[0] - l[0] * z[2];
+                Se[2] += l[0] * z[1] - l[1] * z[0];
+            }
+        }
+    }
     // ---- adjoint sweep -------------------------------------------------------
     Adjoint carry;
 #pragma unroll
@@ -590,6 +613,25 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
             for (int i = 0; i < 9; ++i) tot.M[i] = 0.0f;
         }
         if (out >= 0) grad_in(out, tot.G);
+        if (JAC) {
+            if (out >= 0) { tot.G[0] += Se[0]; tot.G[1] += Se[1]; tot.G[2] += Se[2]; }
+            if (dof[k] >= 0) {
+                float l[3], a[3];
+                glin(dof[k], l);
+                gang(dof[k], a);
+                const float z[3] = {P[k].R[2], P[k].R[5], P[k].R[8]};
+                const float r[3] = {P[CAP - 1].p[0] - P[k].p[0], P[CAP - 1].p[1] - P[k].p[1], P[CAP - 1].p[2] - P[k].p[2]};
+                const float zb[3] = {a[0] + (r[1] * l[2] - r[2] * l[1]), a[1] + (r[2] * l[0] - r[0] * l[2]),
+                                     a[2] + (r[0] * l[1] - r[1] * l[0])};
+                tot.G[0] -= l[1] * z[2] - l[2] * z[1];
+                tot.G[1] -= l[2] * z[0] - l[0] * z[2];
+                tot.G[2] -= l[0] * z[1] - l[1] * z[0];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tot.M[i * 3 + j] += zb[i] * z[j];
+            }
+        }
         if (save >= 0) adj_take(save, tot);
         Pose par;
         if (src >= 0) pose_load(src, par);

@@ -115,6 +115,33 @@ class _FkPositions(torch.autograd.Function):
         return grad_q, grad_ops, None, None, None, None
 
 
+class _FkJacobian(torch.autograd.Function):
+    """Fused FK + geometric Jacobian with a hand-written backward (csrc/drm_fk_backward.hip, JAC form): position and
+    both Jacobians are differentiable with respect to q and to the walk's constant table (learnable ``trans`` /
+    ``rot_angles``), as torch autograd makes them in the reference (robot_model.py:626-667); the quaternion carries no
+    gradient (spatial_vector_algebra.py:108-136)."""
+
+    @staticmethod
+    def forward(ctx, q, ops_f, dw, n_dofs, param_mask):
+        pos, quat, lin, ang = backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, n_dofs)
+        ctx.save_for_backward(q, ops_f)
+        ctx.dw, ctx.n_dofs, ctx.param_mask = dw, n_dofs, param_mask
+        ctx.mark_non_differentiable(quat)
+        return pos, quat, lin, ang
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_pos, _grad_quat, grad_lin, grad_ang):
+        q, ops_f = ctx.saved_tensors
+        want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dw = ctx.dw
+        grad_q, grad_ops = backend.fk_jacobian_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, grad_lin, grad_ang,
+                                                        ctx.n_dofs, ctx.param_mask if want_p else 0, want_q)
+        if grad_q is not None:
+            grad_q = grad_q.to(q.dtype).reshape(q.shape)
+        return grad_q, grad_ops, None, None, None
+
+
 class _InverseDynamics(torch.autograd.Function):
     """RNEA with a hand-written backward (csrc/drm_rnea_backward.hip): torques are differentiable with respect
     to q, qd, qdd and to the walk's constant table (and through its gather, to every learnable link parameter)."""
@@ -393,19 +420,6 @@ class DifferentiableRobotModel(torch.nn.Module):
                 mask |= 1 << k
         return mask
 
-    def _refuse_autograd(self, what: str, *tensors):
-        """The kernels behind ``what`` have no backward yet: refuse loudly rather than return silently detached
-        results where the reference would have propagated gradients."""
-        if not torch.is_grad_enabled():
-            return
-        live = any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
-        live = live or (bool(self._learnable) and any(p.requires_grad for p in self.parameters()))
-        if live:
-            raise NotImplementedError(
-                "%s has no backward kernel yet: call it under torch.no_grad() (gradients are implemented for "
-                "compute_inverse_dynamics / compute_non_linear_effects and for the position output of "
-                "compute_forward_kinematics[_all_links])" % what)
-
     def _require_device(self):
         if self._device.type != "cuda":
             raise RuntimeError(
@@ -530,10 +544,11 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         self._require_device()
-        self._refuse_autograd("compute_endeffector_jacobian / compute_fk_and_jacobian", q)
         idx = self._name_to_idx_map[link_name]
         dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
         ops_f = self._ops_f(dw)
+        if idx != 0 and torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
+            return _FkJacobian.apply(q, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
         return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
     def plan_fk_and_jacobian(self, q: torch.Tensor, link_name: str, want_pose: bool = True

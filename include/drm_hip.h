@@ -204,6 +204,19 @@ int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_t
                     uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
 
 /*
+ * Reverse-mode derivative of drm_fk_jacobian: what torch autograd computes in the reference when a loss on
+ * compute_endeffector_jacobian's outputs (and, optionally, on the target's position) is back-propagated to q and to
+ * learnable `trans` / `rot_angles` (robot_model.py:626-667 on top of 139-195).  The walk is the root->link chain
+ * drm_fk_jacobian takes (no branch points).
+ *   grad_pos      [B, 3]      dL/dpos of the target, or NULL
+ *   grad_lin_jac  [B, 3, n]   dL/dlin_jac      grad_ang_jac  [B, 3, n]   dL/dang_jac
+ *   param_mask, grad_q, grad_ops_f, scratch (drm_fk_backward_scratch_floats)   as for drm_fk_backward
+ */
+int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, const float *grad_pos,
+                             const float *grad_lin_jac, const float *grad_ang_jac, uint32_t param_mask, float *grad_q,
+                             float *grad_ops_f, float *scratch, void *stream);
+
+/*
  * Reverse-mode derivative of drm_rnea: what torch autograd computes in the reference when a loss on
  * compute_inverse_dynamics' torques is back-propagated to learnable link parameters and to q / qd / qdd
  * (robot_model.py:305-375, 669-713; examples/learn_dynamics_iiwa.py:49-96).

@@ -117,7 +117,8 @@ void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd
 
 // reverse-mode FK: per-sample adjoint sweep, constant gradients summed over the batch in double
 template <int CAP>
-void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, uint32_t mask, float *gq, float *gops) {
+void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, const float *glin, const float *gang,
+           uint32_t mask, float *gq, float *gops) {
     const int n = w->n_dofs;
     static thread_local double sum[CAP * 12];
     for (int i = 0; i < CAP * 12; ++i) sum[i] = 0.0;
@@ -126,7 +127,9 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
         Adjoint as[DRM_MAX_SLOTS] = {};
         if (gq) for (int d = 0; d < n; ++d) gq[b * n + d] = 0.f;
         auto qf = [&](int d) { return q[b * n + d]; };
-        auto gin = [&](int t, float *G) { for (int i = 0; i < 3; ++i) G[i] += gpos[(b * T + t) * 3 + i]; };
+        auto gin = [&](int t, float *G) { if (gpos) for (int i = 0; i < 3; ++i) G[i] += gpos[(b * T + t) * 3 + i]; };
+        auto jl = [&](int d, float *v) { for (int i = 0; i < 3; ++i) v[i] = glin[(b * 3 + i) * n + d]; };
+        auto ja = [&](int d, float *v) { for (int i = 0; i < 3; ++i) v[i] = gang[(b * 3 + i) * n + d]; };
         auto psave = [&](int s, const Pose &P) { ps[s] = P; };
         auto pload = [&](int s, Pose &P) { P = ps[s]; };
         auto aadd = [&](int s, const Adjoint &A) {
@@ -142,7 +145,10 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
             for (int j = 0; j < 9; ++j) sum[k * 12 + j] += dF[j];
             for (int j = 0; j < 3; ++j) sum[k * 12 + 9 + j] += dt[j];
         };
-        fk_backward_walk<CAP>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout);
+        if (glin)
+            fk_backward_walk<CAP, true>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout, jl, ja);
+        else
+            fk_backward_walk<CAP>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout);
     }
     if (gops)
         for (int k = 0; k < CAP; ++k) {
@@ -298,7 +304,12 @@ int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
 }
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,
                     float *gops) {
-    DISPATCH(fkb_t, w, q, B, T, gpos, mask, gq, gops)
+    DISPATCH(fkb_t, w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops)
+    return 0;
+}
+int emu_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *gpos, const float *glin,
+                             const float *gang, uint32_t mask, float *gq, float *gops) {
+    DISPATCH(fkb_t, w, q, B, 1, gpos, glin, gang, mask, gq, gops)
     return 0;
 }
 int emu_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {

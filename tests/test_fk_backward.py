@@ -215,14 +215,7 @@ def test_gpu_config5_iiwa_learnable_batch_16384(emu):
     assert loss.item() < 0.7 * first
 
 
-@pytest.mark.gpu
-def test_gpu_autograd_refused_where_no_backward_kernel_exists():
-    m = load_model("iiwa7", "cuda")
-    q = torch.zeros(4, 7, device="cuda", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        m.compute_endeffector_jacobian(q, "iiwa_link_ee")
-    with torch.no_grad():
-        m.compute_endeffector_jacobian(q, "iiwa_link_ee")
+
 
 
 @pytest.mark.gpu
@@ -264,3 +257,110 @@ def test_gpu_training_step_is_hipgraph_capturable():
     torch.cuda.synchronize()
     assert loss.item() < 0.6 * first
     assert all(not torch.equal(a, b) for a, b in zip(before, m.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gradients of a loss on the geometric Jacobian (+ position): the JAC form of the same adjoint sweep (Jacobian-column
+# gradients enter as pose adjoints of the chain links) against torch autograd through the reference's
+# compute_endeffector_jacobian (tests/golden/golden_grad_jac.npz, made by tests/golden/make_golden_grad_jac.py).
+# ---------------------------------------------------------------------------------------------------------------
+JAC_CASES = ["iiwa7", "panda_no_gripper", "allegro_left"]
+
+
+def load_golden_grad_jac():
+    import os
+    from helpers import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "golden_grad_jac.npz"), allow_pickle=False)
+
+
+def jac_learnable_model(g, case, device="cpu"):
+    m = load_model(case, device)
+    params = {}
+    for key in g[case + "/keys"]:
+        link, pname, tensor_name = str(key).split("/")
+        init = torch.from_numpy(g["%s/init/%s" % (case, key)].copy())
+        mod = UnconstrainedTensor(dim1=1, dim2=3, init_tensor=init)
+        m.make_link_param_learnable(link, pname, mod)
+        params[str(key)] = dict(mod.named_parameters())[tensor_name]
+    return m, params
+
+
+def jac_loss(lin, ang, pos, w_lin, w_ang, w_pos):
+    return (w_lin * lin).sum() + (w_ang * ang).sum() + (lin ** 2).sum() + 0.5 * (ang ** 2 * w_ang).sum() + (w_pos * pos).sum()
+
+
+@pytest.mark.parametrize("case", JAC_CASES)
+def test_emu_jacobian_backward_vs_reference_autograd(emu, case):
+    g = load_golden_grad_jac()
+    m, params = jac_learnable_model(g, case)
+    q = np.ascontiguousarray(g[case + "/q"])
+    B, n = q.shape
+    idx = m._name_to_idx_map[str(g[case + "/ee"])]
+    prog = build_walk(m._spec, targets=[idx])
+    table = m._link_table()
+    ops_f_t = (table.reshape(-1)[torch.from_numpy(prog.gather.reshape(-1))]
+               * torch.from_numpy(prog.gsign.reshape(-1))).reshape(prog.capacity, 32)
+    ops_f = np.ascontiguousarray(ops_f_t.detach().numpy(), np.float32)
+    walk, _keep = host_walk(m, prog)
+    walk.ops_f = ops_f.ctypes.data
+    pos, quat = np.zeros((B, 3), np.float32), np.zeros((B, 4), np.float32)
+    lin, ang = np.zeros((B, 3, n), np.float32), np.zeros((B, 3, n), np.float32)
+    assert emu.emu_fk_jacobian(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(pos), _ptr(quat), _ptr(lin), _ptr(ang)) == 0
+    assert np.allclose(lin, g[case + "/lin"], atol=2e-6) and np.allclose(ang, g[case + "/ang"], atol=2e-6)
+    w_lin, w_ang, w_pos = (g[case + "/" + k] for k in ("w_lin", "w_ang", "w_pos"))
+    glin = np.ascontiguousarray(w_lin + 2.0 * lin, np.float32)
+    gang = np.ascontiguousarray(w_ang + ang * w_ang, np.float32)
+    gpos = np.ascontiguousarray(w_pos, np.float32)
+    gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    mask = m._kinematic_param_mask(type("W", (), {"program": prog})())
+    assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
+                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+    assert close(gq, g[case + "/grad_q"]), np.abs(gq - g[case + "/grad_q"]).max()
+    m.zero_grad()
+    ops_f_t.backward(torch.from_numpy(gops))
+    for key, p in params.items():
+        ref = g["%s/grad/%s" % (case, key)]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= GRAD_RTOL * max(np.abs(ref).max(), 1e-3), (case, key, got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", JAC_CASES)
+def test_gpu_jacobian_backward_vs_reference_autograd(case):
+    g = load_golden_grad_jac()
+    m, params = jac_learnable_model(g, case, "cuda")
+    ee = str(g[case + "/ee"])
+    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
+    w_lin, w_ang, w_pos = (torch.from_numpy(g[case + "/" + k].copy()).cuda() for k in ("w_lin", "w_ang", "w_pos"))
+    lin, ang = m.compute_endeffector_jacobian(q, ee)
+    pos, _ = m.compute_forward_kinematics(q, ee)
+    loss = jac_loss(lin, ang, pos, w_lin, w_ang, w_pos)
+    loss.backward()
+    assert abs(loss.item() - float(g[case + "/loss"])) <= 1e-4 * max(1.0, abs(float(g[case + "/loss"])))
+    assert close(q.grad.cpu().numpy(), g[case + "/grad_q"])
+    for key, p in params.items():
+        ref = g["%s/grad/%s" % (case, key)]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= GRAD_RTOL * max(np.abs(ref).max(), 1e-3), (case, key, got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 63, 64, 200])
+def test_gpu_fused_fk_and_jacobian_backward_vs_emu(emu, B):
+    """compute_fk_and_jacobian (pos + both Jacobians from one launch, one backward launch) on ragged batches."""
+    m = load_model("panda_no_gripper", "cuda")
+    mc = load_model("panda_no_gripper")
+    q = sample_states(mc, B, seed=5)[0]
+    rng = np.random.default_rng(1)
+    gpos, glin, gang = (rng.standard_normal(s).astype(np.float32) for s in ((B, 3), (B, 3, 7), (B, 3, 7)))
+    qt = torch.from_numpy(q).cuda().requires_grad_(True)
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(qt, "panda_virtual_ee_link")
+    assert not quat.requires_grad
+    ((pos * torch.from_numpy(gpos).cuda()).sum() + (lin * torch.from_numpy(glin).cuda()).sum()
+     + (ang * torch.from_numpy(gang).cuda()).sum()).backward()
+    prog = build_walk(mc._spec, targets=[mc._name_to_idx_map["panda_virtual_ee_link"]])
+    walk, _keep = host_walk(mc, prog)
+    gq = np.full((B, 7), np.nan, np.float32)
+    assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
+                                        ctypes.c_uint32(0), _ptr(gq), None) == 0
+    assert np.allclose(qt.grad.cpu().numpy(), gq, atol=2e-5, rtol=2e-5)
