@@ -364,3 +364,33 @@ def test_gpu_fused_fk_and_jacobian_backward_vs_emu(emu, B):
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
                                         ctypes.c_uint32(0), _ptr(gq), None) == 0
     assert np.allclose(qt.grad.cpu().numpy(), gq, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", __import__("helpers").ALL_ROBOTS)
+def test_gpu_jacobian_backward_every_robot_vs_emu(emu, robot):
+    """The deepest chain of every shipped robot (all compiled capacities of the JAC kernels), ragged batch, constant
+    gradients of two ops, against the host emulation of the same sweep."""
+    from differentiable_robot_model_amd import backend
+    mc = load_model(robot)
+    m = load_model(robot, "cuda")
+    depth = lambda i: 0 if i == 0 else 1 + depth(int(mc._spec.parent[i]))
+    idx = max(range(len(mc._bodies)), key=depth)
+    n, B = mc._n_dofs, 70
+    prog = build_walk(mc._spec, targets=[idx])
+    q = sample_states(mc, B, seed=11)[0]
+    rng = np.random.default_rng(2)
+    gpos, glin, gang = (rng.standard_normal(s).astype(np.float32) for s in ((B, 3), (B, 3, n), (B, 3, n)))
+    mask = (1 << (prog.n_ops - 1)) | (1 << (prog.n_ops // 2))
+    walk, _keep = host_walk(mc, prog)
+    gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
+                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+    dw = m._get_walk(("chain", idx), targets=[idx])
+    got_q, got_ops = backend.fk_jacobian_backward(dw.program, m._ops_f(dw), dw.ops_i, torch.from_numpy(q).cuda(),
+                                                  torch.from_numpy(gpos).cuda(), torch.from_numpy(glin).cuda(),
+                                                  torch.from_numpy(gang).cuda(), n, mask, True)
+    assert dw.program.capacity == prog.capacity
+    assert np.allclose(got_q.cpu().numpy(), gq, atol=3e-5, rtol=3e-5), (robot, np.abs(got_q.cpu().numpy() - gq).max())
+    scale = max(np.abs(gops).max(), 1e-6)
+    assert np.abs(got_ops.cpu().numpy() - gops).max() <= 1e-4 * scale, (robot, prog.capacity)

@@ -1,0 +1,167 @@
+"""Maximum sizes: synthetic serial chains of 22 and 30 joints (walks of 23 and 31 links -> the 24- and 32-link
+kernel instantiations, which none of the shipped robots' single chains reach), and the limit itself (a 33-link walk
+is refused loudly).  Every kernel family against the fp64 oracle, the backward kernels against the host emulation.
+CPU (not gpu): the kernel arithmetic (host emulation) on the same robots.
+"""
+import contextlib
+import ctypes
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from differentiable_robot_model_amd import DifferentiableRobotModel
+from differentiable_robot_model_amd.flatten import UnsupportedRobotError, build_walk
+from helpers import TOL_JAC, TOL_POS, TOL_QUAT, TOL_TAU, quat_close, sample_states
+from oracle import Oracle
+from test_host_emu import _ptr, emu, host_walk  # noqa: F401  (emu is a fixture)
+
+SIZES = [22, 30]
+
+
+def chain_urdf(n_joints: int) -> str:
+    """A serial arm of n revolute joints about +-x / +-y / +-z with tilted, offset joint frames and full inertias."""
+    rng = np.random.default_rng(1000 + n_joints)
+    axes = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1"]
+    out = ['<?xml version="1.0"?>', '<robot name="chain%d">' % n_joints, '  <link name="base"/>']
+    parent = "base"
+    for i in range(n_joints + 1):
+        name = "link%d" % i if i < n_joints else "tip"
+        A = rng.standard_normal((3, 3)) * 0.02
+        I = A @ A.T + np.eye(3) * 0.003
+        m, c = (0.2 + rng.random() * 0.5, rng.standard_normal(3) * 0.03) if i < n_joints else (0.05, np.zeros(3))
+        out.append('  <link name="%s"><inertial><origin xyz="%.5f %.5f %.5f" rpy="0 0 0"/><mass value="%.5f"/>'
+                   '<inertia ixx="%.6f" ixy="%.6f" ixz="%.6f" iyy="%.6f" iyz="%.6f" izz="%.6f"/></inertial></link>'
+                   % (name, c[0], c[1], c[2], m, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]))
+        xyz, rpy = rng.standard_normal(3) * 0.05 + np.array([0, 0, 0.08]), rng.standard_normal(3) * 0.6
+        if i < n_joints:
+            out.append('  <joint name="j%d" type="revolute"><parent link="%s"/><child link="%s"/>'
+                       '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/><axis xyz="%s"/>'
+                       '<limit effort="10" lower="-2.5" upper="2.5" velocity="3"/><dynamics damping="%.3f"/></joint>'
+                       % (i, parent, name, xyz[0], xyz[1], xyz[2], rpy[0], rpy[1], rpy[2], axes[int(rng.integers(6))],
+                          rng.random() * 0.2))
+        else:
+            out.append('  <joint name="jtip" type="fixed"><parent link="%s"/><child link="tip"/>'
+                       '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/></joint>' % (parent, xyz[0], xyz[1], xyz[2], rpy[0], rpy[1], rpy[2]))
+        parent = name
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+def chain_model(tmp_path, n_joints, device="cpu"):
+    path = os.path.join(str(tmp_path), "chain%d.urdf" % n_joints)
+    with open(path, "w") as f:
+        f.write(chain_urdf(n_joints))
+    with contextlib.redirect_stdout(io.StringIO()):
+        return DifferentiableRobotModel(path, device=device)
+
+
+def test_walks_beyond_the_largest_capacity_are_refused(tmp_path):
+    m = chain_model(tmp_path, 32)          # 32 moving links + tip = 33 ops (the root is not an op)
+    with pytest.raises(UnsupportedRobotError):
+        build_walk(m._spec, whole_tree=True)
+    assert build_walk(m._spec, targets=[32]).capacity == 32   # the chain to the last moving link still fits
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_emu_long_chain_vs_oracle(emu, tmp_path, n):
+    m = chain_model(tmp_path, n)
+    orc, B = Oracle(m._spec), 5
+    q, qd, qdd = sample_states(m, B, seed=n)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    tip = len(m._bodies) - 1
+    prog = build_walk(m._spec, targets=[tip])
+    assert prog.capacity == (24 if n == 22 else 32)
+    walk, _keep = host_walk(m, prog)
+    pos, quat = np.zeros((B, 3), np.float32), np.zeros((B, 4), np.float32)
+    lin, ang = np.zeros((B, 3, n), np.float32), np.zeros((B, 3, n), np.float32)
+    assert emu.emu_fk_jacobian(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(pos), _ptr(quat), _ptr(lin), _ptr(ang)) == 0
+    rp, rq, rl, ra = orc.fk_jacobian(q64, tip, np.float64)
+    assert np.abs(pos - rp).max() <= 4 * TOL_POS["atol"] and np.abs(lin - rl).max() <= 4 * TOL_JAC["atol"]
+    assert np.abs(ang - ra).max() <= 4 * TOL_JAC["atol"] and quat_close(quat, rq, 4 * TOL_QUAT["atol"])[0]
+    tree = build_walk(m._spec, whole_tree=True)
+    twalk, _keep2 = host_walk(m, tree)
+    tau = np.zeros((B, n), np.float32)
+    assert emu.emu_rnea(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(tau)) == 0
+    assert np.allclose(tau, orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+    H = np.zeros((B, n, n), np.float32)
+    assert emu.emu_crba(ctypes.byref(twalk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    assert np.allclose(H, orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("B", [64, 130])
+def test_gpu_long_chain_forward_kernels_vs_oracle(tmp_path, n, B):
+    m = chain_model(tmp_path, n, "cuda")
+    orc = Oracle(m._spec)
+    q, qd, qdd = sample_states(m, B, seed=n + B)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    dev = lambda a: torch.from_numpy(a).cuda()
+    L = len(m._bodies)
+    poses = m.compute_forward_kinematics_all_links(dev(q))
+    op, oq = orc.fk(q64, list(range(L)), np.float64)
+    for i, body in enumerate(m._bodies):
+        p, r = poses[body.name]
+        assert np.abs(p.cpu().numpy() - op[:, i]).max() <= 4 * TOL_POS["atol"], body.name
+        assert quat_close(r.cpu().numpy(), oq[:, i], 4 * TOL_QUAT["atol"])[0], body.name
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(dev(q), "tip")
+    rp, rq, rl, ra = orc.fk_jacobian(q64, L - 1, np.float64)
+    assert np.abs(pos.cpu().numpy() - rp).max() <= 4 * TOL_POS["atol"]
+    assert np.abs(lin.cpu().numpy() - rl).max() <= 4 * TOL_JAC["atol"] and np.abs(ang.cpu().numpy() - ra).max() <= 4 * TOL_JAC["atol"]
+    tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd))
+    assert np.allclose(tau.cpu().numpy(), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+    H = m.compute_lagrangian_inertia_matrix(dev(q))
+    assert np.allclose(H.cpu().numpy(), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU)
+    try:
+        acc = m.compute_forward_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
+    except RuntimeError as err:       # 64 packed n x n triangles must fit in LDS (include/drm_hip.h: n <= ~20)
+        assert "LDS" in str(err) or "unsupported" in str(err).lower(), err
+    else:
+        ref = orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)
+        # cond(H) of a 22-link chain of light links ~1e5: the conditioning-class tolerance of test_forward_dynamics.py
+        assert (np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max() <= 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", SIZES)
+def test_gpu_long_chain_backward_kernels_vs_emu(emu, tmp_path, n):
+    from differentiable_robot_model_amd import backend
+    mc, m = chain_model(tmp_path, n), chain_model(tmp_path, n, "cuda")
+    B, tip = 70, len(mc._bodies) - 1
+    q, qd, qdd = sample_states(mc, B, seed=3 * n)
+    rng = np.random.default_rng(n)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    # Jacobian + position gradients through the chain walk (JAC form of K5)
+    prog = build_walk(mc._spec, targets=[tip])
+    walk, _keep = host_walk(mc, prog)
+    gpos, glin, gang = (rng.standard_normal(s).astype(np.float32) for s in ((B, 3), (B, 3, n), (B, 3, n)))
+    mask = (1 << (prog.n_ops - 1)) | (1 << 3)
+    gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
+                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+    dw = m._get_walk(("chain", tip), targets=[tip])
+    got_q, got_ops = backend.fk_jacobian_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos), dev(glin), dev(gang),
+                                                  n, mask, True)
+    assert np.allclose(got_q.cpu().numpy(), gq, atol=1e-4, rtol=1e-4)
+    assert np.abs(got_ops.cpu().numpy() - gops).max() <= 2e-4 * max(np.abs(gops).max(), 1e-6)
+    # positions only (K5) and the RNEA backward (K7) over the whole tree
+    got_q, _ = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos).reshape(B, 1, 3), 1, n, 0, True)
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(0), _ptr(gq), None) == 0
+    assert np.allclose(got_q.cpu().numpy(), gq, atol=1e-4, rtol=1e-4)
+    tree = build_walk(mc._spec, whole_tree=True)
+    twalk, _keep2 = host_walk(mc, tree)
+    gtau = rng.standard_normal((B, n)).astype(np.float32)
+    eq, eqd, eqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+    eops = np.full((tree.capacity, 32), np.nan, np.float32)
+    tmask = (1 << 2) | (1 << (tree.n_ops - 2))
+    assert emu.emu_rnea_backward(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
+                                 ctypes.c_uint32(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops)) == 0
+    dt = m._get_walk(("tree",), whole_tree=True)
+    gin, gops_t = backend.rnea_backward(dt.program, m._ops_f(dt), dt.ops_i, dev(q), dev(qd), dev(qdd), dev(gtau), True, True,
+                                        n, tmask, True)
+    for got, ref in zip(gin, (eq, eqd, eqdd)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1.0)
+    assert np.abs(gops_t.cpu().numpy() - eops).max() <= 5e-4 * max(np.abs(eops).max(), 1e-6)
