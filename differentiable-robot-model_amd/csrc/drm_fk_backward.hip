@@ -146,6 +146,65 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
 }
 
+// Serial-chain ("arm") specialisation for ONE target at the end of the chain, full tiles only (BASELINE config 5:
+// iiwa, loss on the end-effector position): drm_sample.hpp fk_backward_chain — one packed chain FK per sample and
+// closed-form adjoints instead of stored poses and an adjoint sweep; constants staged once per wave in LDS, the
+// gradient tile staged over the dead q tile.  Same persistent-wave structure and batch reduction as the generic kernel.
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
+                           int n_tiles, uint32_t param_mask, float *__restrict__ gq, float *__restrict__ partials) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
+    constexpr int NV = CAP * BWD_FIELDS, A_FLOATS = round4(NV);
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + G_FLOATS + A_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave_id = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave, n_waves = (int)gridDim.x * MAX_WAVES_PER_BLOCK;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lg = lq + Q_FLOATS;
+    float *lacc = lg + G_FLOATS; // this wave's running sums of the constant gradients
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+
+    for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        wave_lds_sync(); // the previous tile's staged gradients have left
+        tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+        tile_load<3>(gpos + b0 * 3, WAVE, 3, 0u, lg, lane, true);
+        wave_lds_sync();
+        float qv[NJ], gv[3], gqv[NJ];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gv[i] = lg[lane * 3 + i];
+        fk_backward_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, gv, param_mask, gqv,
+                                   [&](int d) -> float { return lq[lane * NJ + d]; },
+                                   [&](int k, const float *dF, const float *dt) {
+#pragma unroll
+                                       for (int j = 0; j < BWD_FIELDS; ++j) {
+                                           const float total = wave_sum_lane63(j < 9 ? dF[j] : dt[j - 9]);
+                                           if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in a fixed order
+                                       }
+                                   });
+        if (gq) {
+            wave_lds_sync(); // every lane is done with its q row
+#pragma unroll
+            for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = gqv[d];
+            wave_lds_sync();
+            tile_store<NJ>(gq + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+        }
+    }
+    wave_lds_sync();
+    float *prow = partials + (int64_t)wave_id * NV;
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
+}
+
 // grad_ops_f[k, FT field j] = sum over the partial rows of column k * 12 + j, in a fixed order (drm_common.hpp
 // column_sum); the rest of the row has no gradient here and is zeroed.
 __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
@@ -171,7 +230,7 @@ using namespace drm;
 extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
     if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS) return 0;
     // rows: waves of the launch rounded up to a full block of MAX_WAVES_PER_BLOCK
-    return (int64_t)backward_waves(B, MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS;
+    return (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS; // + a ragged tail's rows
 }
 
 static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
@@ -194,37 +253,68 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
         }
         return DRM_OK;
     }
-    Geometry g;
-    int rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE +
+    int rc;
+    int rows_done = 0;          // rows of partial sums already written by the arm kernel
+    float *partials = scratch;
+#ifndef DRM_NO_ARM_KERNEL
+    {
+        const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)grad_pos | (uintptr_t)grad_q | (uintptr_t)w->ops_f;
+        if (!jac && T == 1 && (w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && n == 7 && (ptrs & 15u) == 0 && B >= WAVE &&
+            B / WAVE < 0x7fffffffLL) {
+            // 7-DoF arms, one target at the end of the chain: full tiles through the chain kernel, the ragged tail (if
+            // any) through the generic kernel below with its rows of partial sums appended
+            const int n_tiles = (int)(B / WAVE);
+            const int64_t done = (int64_t)n_tiles * WAVE;
+            const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
+            hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                               dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
+                               partials);
+            rc = launched();
+            if (rc) return rc;
+            rows_done = waves_a;
+            partials += (int64_t)waves_a * cap * BWD_FIELDS;
+            q += done * n; grad_pos += done * 3;
+            if (grad_q) grad_q += done * n;
+            B -= done;
+        }
+    }
+#endif
+    int waves = 0;
+    if (B > 0) {
+        Geometry g;
+        rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE +
                                   (jac ? 2 * round4(WAVE * pad_odd(3 * n)) : 0), g);
-    if (rc) return rc;
-    const int wpb = (int)(g.block.x / WAVE);
-    const int waves = backward_waves(B, wpb);
-    g.grid = dim3((unsigned)(waves / wpb));
-    const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU) | al16(grad_lin, AL_LIN) |
-                           al16(grad_ang, AL_ANG);
+        if (rc) return rc;
+        int wpb = (int)(g.block.x / WAVE);
+        if (rows_done) { wpb = 1; g.block = dim3(WAVE); g.lds_bytes = (size_t)g.lds_per_wave * sizeof(float); } // a tail: one wave
+        waves = backward_waves(B, wpb);
+        g.grid = dim3((unsigned)(waves / wpb));
+        const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU) | al16(grad_lin, AL_LIN) |
+                               al16(grad_ang, AL_ANG);
 #define DRM_LAUNCH_FB(C, JAC)                                                                                          \
-    {                                                                                                                  \
-        rc = ensure_lds(fk_backward_kernel<C, JAC>, g.lds_bytes);                                                      \
-        if (rc) return rc;                                                                                             \
-        hipLaunchKernelGGL((fk_backward_kernel<C, JAC>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,       \
-                           (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q, param_mask, scratch,        \
-                           div_magic(n), div_magic(3 * T), div_magic(3 * n), g.lds_per_wave, align);                   \
-    }
-    if (jac) {
-        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, true))
-    } else {
-        DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, false))
-    }
+        {                                                                                                                  \
+            rc = ensure_lds(fk_backward_kernel<C, JAC>, g.lds_bytes);                                                      \
+            if (rc) return rc;                                                                                             \
+            hipLaunchKernelGGL((fk_backward_kernel<C, JAC>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,       \
+                               (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q, param_mask, partials,       \
+                               div_magic(n), div_magic(3 * T), div_magic(3 * n), g.lds_per_wave, align);                   \
+        }
+        if (jac) {
+            DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, true))
+        } else {
+            DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, false))
+        }
 #undef DRM_LAUNCH_FB
-    rc = launched();
-    if (rc) return rc;
+        rc = launched();
+        if (rc) return rc;
+    }
     if (grad_ops_f) {
         hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + WAVE - 1) / WAVE)),
-                           dim3(WAVE * REDUCE_WAVES), 0, s, scratch, waves, cap, grad_ops_f);
+                           dim3(WAVE * REDUCE_WAVES), 0, s, scratch, rows_done + waves, cap, grad_ops_f);
         rc = launched();
+        if (rc) return rc;
     }
-    return rc;
+    return DRM_OK;
 }
 
 extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,

@@ -672,6 +672,58 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
     }
 }
 
+// Reverse-mode FK of a serial chain (DRM_WALK_ARM_CHAIN, one target = the end of the chain) for a loss on the
+// target's POSITION: fk_backward_walk without the int table, the stored poses and the adjoint sweep.  With one
+// target the adjoints are closed-form in the forward quantities (g = dL/dp_e, r_k = p_e - p_k):
+//     dL/dq_k = g . (z_k x r_k)                  (the linear-Jacobian column: fk_chain_pairs already yields z_k, p_k)
+//     dL/dt_k = R_p^T g            dL/dF_k = (R_p^T g) (F_k^T R_p^T r_k)^T        (R_p = rotation of op k's parent)
+// so the sample costs ONE packed chain FK + 7 cross/dot products; the constant gradients of the (few) ops in
+// param_mask re-walk the chain to their parent in a LOOP (wave-uniform, cold, and it must not cost the hot path
+// registers: op numbers are run-time values there, angles come back through q_at).
+//   ft(k) -> FT block of op k;   gq[d] <- dL/dq_d;   q_at(d) -> q[d] for a run-time d;
+//   param_out(k, dF[9], dt[3]) for ops in param_mask (run-time k)
+template <int CAP, int NJ, class FT, class QAT, class PG>
+DRM_HD void fk_backward_chain(FT ft, const float (&q)[NJ], const float (&g)[3], uint32_t param_mask, float (&gq)[NJ],
+                              QAT q_at, PG param_out) {
+    PoseP ee;
+    f2 B[NJ][3];
+    fk_chain_pairs<CAP, NJ>(ft, q, ee, B, [] {});
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const float z[3] = {B[k][0][0], B[k][1][0], B[k][2][0]};
+        const float r[3] = {pe[0] - B[k][0][1], pe[1] - B[k][1][1], pe[2] - B[k][2][1]};
+        gq[k] = g[0] * (z[1] * r[2] - z[2] * r[1]) + g[1] * (z[2] * r[0] - z[0] * r[2]) + g[2] * (z[0] * r[1] - z[1] * r[0]);
+    }
+#pragma unroll 1
+    for (int k = 0; k < CAP; ++k) {
+        if (!((param_mask >> k) & 1u)) continue;
+        Pose par;
+        pose_identity(par);
+#pragma unroll 1
+        for (int j = 0; j < k; ++j) {
+            const OpFT o = load_ft(ft(j));
+            float J[9], c = 1.0f, sn = 0.0f;
+            if (j < NJ) sincos_f(q_at(j), sn, c);
+            joint_rot_z(o.F, c, sn, J);
+            compose(par, J, o.t, par);
+        }
+        const OpFT o = load_ft(ft(k));
+        float a[3], pk[3], r[3], u[3], c[3], dF[9];
+        matT_vec(par.R, g, a);                        // dL/dt_k = R_p^T g
+        mat_vec(par.R, o.t, pk);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = pe[i] - (par.p[i] + pk[i]);
+        matT_vec(par.R, r, u);
+        matT_vec(o.F, u, c);                          // c = F_k^T R_p^T r_k
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dF[i * 3 + j] = a[i] * c[j];
+        param_out(k, dF, a);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // RNEA over the whole tree (robot_model.py:250-375).  Body-frame Pluecker
 // coordinates at the link origin, as in the reference.

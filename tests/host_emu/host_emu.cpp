@@ -288,6 +288,31 @@ int emu_rnea_backward_arm(const drm_walk *w, const float *q, const float *qd, co
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
     return 0;
 }
+int emu_fk_backward_arm(const drm_walk *w, const float *q, int64_t B, const float *gpos, uint32_t mask, float *gq, float *gops) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    constexpr int CAP = 8, NJ = 7;
+    static thread_local double sum[CAP * 12];
+    for (int i = 0; i < CAP * 12; ++i) sum[i] = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        float qv[NJ], gv[3], out[NJ];
+        for (int d = 0; d < NJ; ++d) qv[d] = q[b * NJ + d];
+        for (int i = 0; i < 3; ++i) gv[i] = gpos[b * 3 + i];
+        fk_backward_chain<CAP, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, qv, gv, mask, out,
+                                   [&](int d) { return qv[d]; },
+                                   [&](int k, const float *dF, const float *dt) {
+                                       for (int j = 0; j < 9; ++j) sum[k * 12 + j] += dF[j];
+                                       for (int j = 0; j < 3; ++j) sum[k * 12 + 9 + j] += dt[j];
+                                   });
+        if (gq) for (int d = 0; d < NJ; ++d) gq[b * NJ + d] = out[d];
+    }
+    if (gops)
+        for (int k = 0; k < CAP; ++k) {
+            for (int j = 0; j < DRM_OPF_STRIDE; ++j) gops[k * DRM_OPF_STRIDE + j] = 0.f;
+            for (int j = 0; j < 12; ++j)
+                gops[k * DRM_OPF_STRIDE + (j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9))] = (float)sum[k * 12 + j];
+        }
+    return 0;
+}
 int emu_crba_arm(const drm_walk *w, const float *q, int64_t B, float *H) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     for (int64_t b = 0; b < B; ++b) {

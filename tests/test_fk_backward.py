@@ -394,3 +394,58 @@ def test_gpu_jacobian_backward_every_robot_vs_emu(emu, robot):
     assert np.allclose(got_q.cpu().numpy(), gq, atol=3e-5, rtol=3e-5), (robot, np.abs(got_q.cpu().numpy() - gq).max())
     scale = max(np.abs(gops).max(), 1e-6)
     assert np.abs(got_ops.cpu().numpy() - gops).max() <= 1e-4 * scale, (robot, prog.capacity)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Serial-chain specialisation (fk_backward_chain / fk_backward_arm_kernel<8, 7>): closed-form adjoints of one chain FK
+# against the generic adjoint sweep, which the tests above pin to the reference's autograd.
+# ---------------------------------------------------------------------------------------------------------------
+ARM_ROBOTS = [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee"), ("fetch_arm_no_gripper", None)]
+
+
+def _arm_walk(m, link):
+    idx = m._name_to_idx_map[link] if link else len(m._bodies) - 1
+    prog = build_walk(m._spec, targets=[idx])
+    assert prog.shape & 1 and prog.capacity == 8
+    return idx, prog
+
+
+@pytest.mark.parametrize("robot,link", ARM_ROBOTS)
+def test_emu_arm_chain_fk_backward_equals_generic_walk(emu, robot, link):
+    m = load_model(robot)
+    idx, prog = _arm_walk(m, link)
+    B = 23
+    q = sample_states(m, B, seed=9)[0]
+    gpos = np.random.default_rng(4).standard_normal((B, 3)).astype(np.float32)
+    walk, _keep = host_walk(m, prog)
+    mask = 0b10100101 & ((1 << prog.n_ops) - 1)
+    gq_a, gq_b = (np.full((B, 7), np.nan, np.float32) for _ in range(2))
+    go_a, go_b = (np.full((8, 32), np.nan, np.float32) for _ in range(2))
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq_a), _ptr(go_a)) == 0
+    assert emu.emu_fk_backward_arm(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq_b), _ptr(go_b)) == 0
+    assert np.abs(gq_a - gq_b).max() <= 1e-5 * max(1.0, np.abs(gq_a).max())
+    assert np.abs(go_a - go_b).max() <= 2e-5 * max(1.0, np.abs(go_a).max()), np.abs(go_a - go_b).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,link", ARM_ROBOTS)
+@pytest.mark.parametrize("B", [64, 200, 4096])
+def test_gpu_arm_chain_fk_backward_vs_emu(emu, robot, link, B):
+    """Full tiles through fk_backward_arm_kernel, the ragged tail through the generic kernel, one reduction over both."""
+    from differentiable_robot_model_amd import backend
+    mc, m = load_model(robot), load_model(robot, "cuda")
+    idx, prog = _arm_walk(mc, link)
+    q = sample_states(mc, B, seed=B)[0]
+    gpos = np.random.default_rng(B).standard_normal((B, 3)).astype(np.float32)
+    walk, _keep = host_walk(mc, prog)
+    mask = 0b01001010 & ((1 << prog.n_ops) - 1)
+    gq = np.full((B, 7), np.nan, np.float32); gops = np.full((8, 32), np.nan, np.float32)
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+    dw = m._get_walk(("fk", (idx,)), targets=[idx])
+    for want_q, pm in ((True, mask), (True, 0), (False, mask)):
+        got_q, got_ops = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, torch.from_numpy(q).cuda(),
+                                             torch.from_numpy(gpos).cuda().reshape(B, 1, 3), 1, 7, pm, want_q)
+        if want_q:
+            assert np.allclose(got_q.cpu().numpy(), gq, atol=2e-5, rtol=2e-5), np.abs(got_q.cpu().numpy() - gq).max()
+        if pm:
+            assert np.abs(got_ops.cpu().numpy() - gops).max() <= 1e-4 * max(np.abs(gops).max(), 1e-6) * max(1.0, B / 256)
