@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel timings (hipGraph of 100 launches, HIP events): Panda FK+Jacobian, RNEA, FK; Allegro 4-tip FK."""
+"""Kernel timings (hipGraph of 100 launches, HIP events): Panda FK+Jacobian, RNEA, CRBA, forward dynamics, RNEA
+backward, FK; Allegro 4-tip FK and whole-tree dynamics.  Sizes above 2^22 time the metric kernel only."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,9 @@ for B in sizes:
     plan = m.plan_fk_and_jacobian(q, link)
     us = graph_time(plan.launch)
     print("fk_jacobian panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
+    if B > (1 << 22):   # working set >> the 256 MB Infinity Cache: the metric kernel only
+        del plan
+        continue
     m.compute_inverse_dynamics(q[:64], qd[:64], qdd[:64])
     dt = m._walks[("tree",)]; of = m._ops_f(dt)
     tau = torch.empty(B, 7, device="cuda")
