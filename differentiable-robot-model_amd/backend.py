@@ -116,7 +116,9 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
     rows = prog.capacity
     assert ops_f.is_cuda and ops_f.dtype == torch.float32 and ops_f.is_contiguous() and ops_f.shape[0] == rows
     assert ops_i.is_cuda and ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[1] == rows
-    target_perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
+    target_perm = getattr(prog, "_target_perm", None)
+    if target_perm is None:   # un-permutation of the last op's frame, looked up once per walk
+        target_perm = prog._target_perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
     return DrmWalk(ops_f.data_ptr(), ops_i.data_ptr(), prog.n_ops, prog.capacity, n_dofs, prog.n_slots,
                    prog.dof_mask, target_perm, prog.shape)
 

@@ -480,9 +480,11 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._require_device()
         B = q.shape[0]
         non_root = [i for i in link_idxs if i != 0]
-        pos = torch.zeros(B, len(link_idxs), 3, device=self._device)
-        quat = torch.zeros(B, len(link_idxs), 4, device=self._device)
-        quat[..., 3] = 1.0
+        pos = quat = None
+        if len(non_root) != len(link_idxs):    # the root link's pose is the identity: no kernel needed for it
+            pos = torch.zeros(B, len(link_idxs), 3, device=self._device)
+            quat = torch.zeros(B, len(link_idxs), 4, device=self._device)
+            quat[..., 3] = 1.0
         if non_root:
             dw = self._get_walk(("fk", tuple(non_root)), targets=non_root)
             ops_f = self._ops_f(dw)
