@@ -4,35 +4,39 @@
 // Replaces what torch autograd does for the reference when a loss on compute_forward_kinematics' position is
 // back-propagated (robot_model.py:139-195, 223-248 with learnable link parameters robot_model.py:669-713;
 // examples/learn_kinematics_of_iiwa.py:25-61, examples/run_kinematic_trajectory_opt.py): there, one backward node
-// per tiny torch op of the per-link Python loop; here, one adjoint sweep per sample (drm_sample.hpp
-// fk_backward_walk) that recomputes the FK instead of saving per-link poses, plus a fixed-order reduction of the
-// per-link constant gradients over the batch.
+// per tiny torch op of the per-link Python loop; here, two loops per sample over the links of the walk (drm_sample.hpp
+// fk_backward_walk: the FK again, then one adjoint sweep), plus a fixed-order reduction of the per-link constant
+// gradients over the batch.
 //
 // Per sample: in q[n], grad_pos[T,3]; out grad_q[n] (optional).                 n = 7, T = 1: 28 + 12 + 28 = 68 B
 // Per launch: out grad_ops_f[cap, 32] (dL/dF and dL/dt in the FT block of every op selected by param_mask, zeros
 //             elsewhere), reduced DETERMINISTICALLY: each wave strides over tiles and keeps one running sum per
-//             (op, field) in a lane of an accumulator register, writes one row of `partials`, and a second tiny
-//             kernel adds the rows in a fixed order.
-// LDS per wave: [ q : 64 (n|1) ][ grad_pos : 64 (3T|1) ][ grad_q : 64 (n|1) ][ pose slots : n_slots*12*64 ]
-//               [ adjoint slots : n_slots*12*64 ]
+//             (op, field), writes one row of `partials`, and a second tiny kernel adds the rows in a fixed order.
+// LDS per wave: [ q : 64 (n|1) ][ grad_pos : 64 (3T|1) ][ grad_q : 64 (n|1) ][ constant-gradient sums : cap*12 ]
+//               [ pose slots : n_slots*12*64 ][ adjoint slots : n_slots*12*64 ][ JAC: 2 x 64 (3n|1) ]
+//               [ parked poses : cap*12*64 unless PARK_HBM ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
 namespace drm {
 
 constexpr int BWD_FIELDS = 12;          // dF (9) + dt (3) per op
+constexpr int POSE_FLOATS = 12;         // a parked world pose: R (9) + p (3)
 
+// One kernel for every walk: the sweeps loop over the n_ops links (drm_sample.hpp fk_backward_walk), so neither the code
+// nor the register file grows with the robot; `cap` only fixes the row pitch of grad_ops_f / the partial sums.
 // JAC: the walk is the root -> end-effector chain and the loss also depends on the geometric Jacobian
-// (glin, gang [B, 3, n] = dL/d lin_jac, dL/d ang_jac; gpos may be NULL); magic_g then divides by 3 n as well as by 3 T.
-template <int CAP, bool JAC>
+// (glin, gang [B, 3, n] = dL/d lin_jac, dL/d ang_jac; gpos may be NULL).
+// PARK_HBM: the per-op poses of the forward sweep are parked in a slice of the caller's scratch buffer instead of LDS.
+template <bool JAC, bool PARK_HBM>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    fk_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int T,
-                       const float *__restrict__ q, const float *__restrict__ gpos, const float *__restrict__ glin,
-                       const float *__restrict__ gang, int64_t B, float *__restrict__ gq, uint32_t param_mask,
-                       float *__restrict__ partials, uint32_t magic_q, uint32_t magic_g, uint32_t magic_j,
-                       int lds_per_wave, uint32_t align) {
+    fk_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n,
+                       int n_slots, int T, const float *__restrict__ q, const float *__restrict__ gpos,
+                       const float *__restrict__ glin, const float *__restrict__ gang, int64_t B, float *__restrict__ gq,
+                       uint32_t param_mask, float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q,
+                       uint32_t magic_g, uint32_t magic_j, int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NV = CAP * BWD_FIELDS, NACC = (NV + WAVE - 1) / WAVE;
+    const int NV = cap * BWD_FIELDS;
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
     const unsigned lane = threadIdx.x & 63u;
@@ -44,14 +48,16 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lq = smem + wave_in_block * lds_per_wave;
     float *lg = lq + round4(WAVE * Sq);
     float *lgq = lg + round4(WAVE * Sg);
-    float *lps = lgq + round4(WAVE * Sq);       // pose slots    [slot][12][64]
-    float *las = lps + n_slots * (12 * WAVE);   // adjoint slots [slot][12][64]
-    float *ljl = las + n_slots * (12 * WAVE);   // JAC: dL/d lin_jac, dL/d ang_jac tiles, each 64 (3n|1)
-    float *lja = ljl + round4(WAVE * Sj);
+    float *lacc = lgq + round4(WAVE * Sq);             // this wave's running sums of the constant gradients
+    float *lps = lacc + round4(NV);                     // pose slots    [slot][12][64]
+    float *las = lps + n_slots * (12 * WAVE);           // adjoint slots [slot][12][64]
+    float *ljl = las + n_slots * (12 * WAVE);           // JAC: dL/d lin_jac, dL/d ang_jac tiles, each 64 (3n|1)
+    float *lja = ljl + (JAC ? round4(WAVE * Sj) : 0);
+    float *lpk = lja + (JAC ? round4(WAVE * Sj) : 0);   // parked poses [op][12][64] unless PARK_HBM
+    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)cap * (POSE_FLOATS * WAVE) : lpk) + lane;
+    const int32_t *ctl = ops_i + DRM_OPI_CTRL * cap;
 
-    float acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
 
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = tile * WAVE;
@@ -86,20 +92,22 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         const float *jlrow = ljl + lane * Sj, *jarow = lja + lane * Sj;
         auto jac_lin = [&](int d, float *v) { v[0] = jlrow[d]; v[1] = jlrow[n + d]; v[2] = jlrow[2 * n + d]; };
         auto jac_ang = [&](int d, float *v) { v[0] = jarow[d]; v[1] = jarow[n + d]; v[2] = jarow[2 * n + d]; };
-        auto pose_save = [&](int s, const Pose &P) {
-            float *b = lps + s * (12 * WAVE) + lane;
+        auto put_pose = [&](float *b, const Pose &P) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) b[i * WAVE] = P.R[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) b[(9 + i) * WAVE] = P.p[i];
         };
-        auto pose_load = [&](int s, Pose &P) {
-            const float *b = lps + s * (12 * WAVE) + lane;
+        auto get_pose = [&](const float *b, Pose &P) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) P.R[i] = b[i * WAVE];
 #pragma unroll
             for (int i = 0; i < 3; ++i) P.p[i] = b[(9 + i) * WAVE];
         };
+        auto pose_save = [&](int s, const Pose &P) { put_pose(lps + s * (12 * WAVE) + lane, P); };
+        auto pose_load = [&](int s, Pose &P) { get_pose(lps + s * (12 * WAVE) + lane, P); };
+        auto park = [&](int k, const Pose &P) { put_pose(rec + k * (POSE_FLOATS * WAVE), P); };
+        auto unpark = [&](int k, Pose &P) { get_pose(rec + k * (POSE_FLOATS * WAVE), P); };
         auto adj_add = [&](int s, const Adjoint &A) {
             float *b = las + s * (12 * WAVE) + lane;
 #pragma unroll
@@ -115,35 +123,25 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             for (int i = 0; i < 9; ++i) A.M[i] += b[(3 + i) * WAVE];
         };
         auto gq_out = [&](int d, float v) { gqrow[d] = v; };
-        float add[NACC];
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
-        auto param_out = [&](int k, const float *dF, const float *dt) {
+        auto param_out = [&](int k, const float *dF, const float *dt) { // wave-uniform: only for ops in param_mask
 #pragma unroll
             for (int j = 0; j < BWD_FIELDS; ++j) {
                 const float mine = live ? (j < 9 ? dF[j] : dt[j - 9]) : 0.0f; // lanes past a partial tile hold garbage
                 const float total = wave_sum_lane63(mine);
-                const int idx = k * BWD_FIELDS + j;
-                const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
-                if (lane == (unsigned)(idx % WAVE)) add[idx / WAVE] = s; // lane idx%64 of accumulator idx/64 owns (k, j)
+                if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in this wave's fixed order
             }
         };
-        fk_backward_walk<CAP, JAC>(ops_f, ops_i, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
-                                   adj_take, gq_out, param_out, jac_lin, jac_ang);
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += add[a];
+        fk_backward_walk<JAC>(ops_f, ctl, n_ops, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
+                              adj_take, gq_out, param_out, park, unpark, jac_lin, jac_ang);
         if (gq) {
             wave_lds_sync();
             tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, full && (n & 1) && (align & AL_TAU), full && (align & AL_TAU));
         }
     }
+    wave_lds_sync();
     // one row of partial sums per wave (zeros for waves that had no tile)
     float *prow = partials + wave_id * NV;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        const int idx = a * WAVE + (int)lane;
-        if (idx < NV) prow[idx] = acc[a];
-    }
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
 // Serial-chain ("arm") specialisation for ONE target at the end of the chain, full tiles only (BASELINE config 5:
@@ -227,10 +225,16 @@ __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
 
 using namespace drm;
 
+// walks of more than FK_BACKWARD_LDS_OPS links park their per-op poses in HBM (3 KB per op and wave in LDS otherwise)
+constexpr int FK_BACKWARD_LDS_OPS = 12;
+
 extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
     if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS) return 0;
-    // rows: waves of the launch rounded up to a full block of MAX_WAVES_PER_BLOCK
-    return (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS; // + a ragged tail's rows
+    // rows: waves of the launch rounded up to a full block of MAX_WAVES_PER_BLOCK (+ a ragged tail's rows)
+    const int64_t waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
+    int64_t floats = (waves + MAX_WAVES_PER_BLOCK) * capacity * BWD_FIELDS;
+    if (capacity > FK_BACKWARD_LDS_OPS) floats += (waves + MAX_WAVES_PER_BLOCK) * (int64_t)capacity * POSE_FLOATS * WAVE;
+    return floats;
 }
 
 static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
@@ -254,6 +258,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
         return DRM_OK;
     }
     int rc;
+    const int64_t B_total = B;
     int rows_done = 0;          // rows of partial sums already written by the arm kernel
     float *partials = scratch;
 #ifndef DRM_NO_ARM_KERNEL
@@ -281,28 +286,33 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
 #endif
     int waves = 0;
     if (B > 0) {
+        const bool park_hbm = cap > FK_BACKWARD_LDS_OPS;
         Geometry g;
-        rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + w->n_slots * 24 * WAVE +
-                                  (jac ? 2 * round4(WAVE * pad_odd(3 * n)) : 0), g);
+        rc = make_geometry(B, 2 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + round4(cap * BWD_FIELDS) +
+                                  w->n_slots * 24 * WAVE + (jac ? 2 * round4(WAVE * pad_odd(3 * n)) : 0) +
+                                  (park_hbm ? 0 : cap * POSE_FLOATS * WAVE), g);
         if (rc) return rc;
         int wpb = (int)(g.block.x / WAVE);
         if (rows_done) { wpb = 1; g.block = dim3(WAVE); g.lds_bytes = (size_t)g.lds_per_wave * sizeof(float); } // a tail: one wave
         waves = backward_waves(B, wpb);
         g.grid = dim3((unsigned)(waves / wpb));
+        // parked poses live behind ALL rows of partial sums (the arm kernel's and this launch's)
+        float *park = scratch + (int64_t)(backward_waves(B_total, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * cap * BWD_FIELDS;
         const uint32_t align = al16(q, AL_Q) | al16(grad_pos, AL_POS) | al16(grad_q, AL_TAU) | al16(grad_lin, AL_LIN) |
                                al16(grad_ang, AL_ANG);
-#define DRM_LAUNCH_FB(C, JAC)                                                                                          \
-        {                                                                                                                  \
-            rc = ensure_lds(fk_backward_kernel<C, JAC>, g.lds_bytes);                                                      \
-            if (rc) return rc;                                                                                             \
-            hipLaunchKernelGGL((fk_backward_kernel<C, JAC>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,       \
-                               (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q, param_mask, partials,       \
-                               div_magic(n), div_magic(3 * T), div_magic(3 * n), g.lds_per_wave, align);                   \
-        }
+#define DRM_LAUNCH_FB(JAC, HBM)                                                                                        \
+    {                                                                                                                  \
+        rc = ensure_lds(fk_backward_kernel<JAC, HBM>, g.lds_bytes);                                                    \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((fk_backward_kernel<JAC, HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, cap,   \
+                           (int)w->n_ops, n, (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q,           \
+                           param_mask, partials, park, div_magic(n), div_magic(3 * T), div_magic(3 * n),               \
+                           g.lds_per_wave, align);                                                                     \
+    }
         if (jac) {
-            DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, true))
+            if (park_hbm) DRM_LAUNCH_FB(true, true) else DRM_LAUNCH_FB(true, false)
         } else {
-            DRM_DISPATCH_CAP(cap, DRM_LAUNCH_FB(C, false))
+            if (park_hbm) DRM_LAUNCH_FB(false, true) else DRM_LAUNCH_FB(false, false)
         }
 #undef DRM_LAUNCH_FB
         rc = launched();

@@ -546,65 +546,62 @@ struct Adjoint {
 struct NoJacobianGrad { // fk_backward_walk without Jacobian gradients
     DRM_HD void operator()(int, float *) const {}
 };
-template <int CAP, bool JAC = false, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG,
-          class GL = NoJacobianGrad, class GA = NoJacobianGrad>
-DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ opi, uint32_t param_mask,
+// The two sweeps are LOOPS over the n_ops links of the walk (one control word decoded per iteration, no identity
+// padding, nothing indexed by a compile-time op number), the world pose of every op is parked by the caller between
+// them (LDS, or HBM for walks that do not fit):
+//   ctl = the control-word field of the int table (DRM_OPI_CTRL);   park(k, Pose) / unpark(k, Pose&)
+template <bool JAC = false, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG,
+          class PARK, class UNPARK, class GL = NoJacobianGrad, class GA = NoJacobianGrad>
+DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, uint32_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
-                             ATAKE adj_take, GQ gq_out, PG param_out, GL glin = GL(), GA gang = GA()) {
-    DRM_LOAD_CTL();
-    int dof[CAP];
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) dof[k] = DRM_OPI(DRM_OPI_DOF, k);
-    float cs[CAP], sn[CAP];
-    joint_trig<CAP>(dof, qf, cs, sn);
-    // ---- forward: world pose of every op, kept for the adjoint sweep -------
-    Pose P[CAP];
+                             ATAKE adj_take, GQ gq_out, PG param_out, PARK park, UNPARK unpark, GL glin = GL(),
+                             GA gang = GA()) {
+    // ---- forward: world pose of every op, parked for the adjoint sweep -------
+    // JAC (the walk is the root -> end-effector chain, its last op the target): column d(k) of the geometric Jacobian
+    // is (lin, ang) = (z_k x (p_e - p_k), z_k), so loss gradients (l_k, a_k) on the columns are gradients on the
+    // chain's poses:  dL/dz_k = a_k + (p_e - p_k) x l_k  enters M_k as (dL/dz_k) z_k^T (M = Rbar R^T in general: the
+    // position-only case above is its special case), dL/dp_k = -(l_k x z_k), and dL/dp_e = sum_k l_k x z_k.
+    float Se[3] = {0.0f, 0.0f, 0.0f};
     Pose cur;
     pose_identity(cur);
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) {
+#pragma unroll 1
+    for (int k = 0; k < n_ops; ++k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
-        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k);
+        const int c = ctl[k];
+        const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
         const OpFT o = load_ft(of);
-        float J[9];
-        joint_rot_z(o.F, cs[k], sn[k], J);
+        float J[9], cs = 1.0f, sn = 0.0f;
+        if (dof >= 0) sincos_f(qf(dof), sn, cs);
+        joint_rot_z(o.F, cs, sn, J);
         if (src >= 0) pose_load(src, cur);
         if (src == DRM_SRC_ROOT) compose_root(J, o.t, cur);
         else compose(cur, J, o.t, cur);
         if (save >= 0) pose_save(save, cur);
-        P[k] = cur;
-    }
-    // ---- Jacobian gradients (JAC: the walk is the root -> end-effector chain, its last op the target) ---------
-    // column d(k) of the geometric Jacobian is (lin, ang) = (z_k x (p_e - p_k), z_k), so loss gradients (l_k, a_k)
-    // on the columns are gradients on the chain's poses:  dL/dz_k = a_k + (p_e - p_k) x l_k  enters M_k as
-    // (dL/dz_k) z_k^T (M = Rbar R^T in general: the position-only case above is its special case),
-    // dL/dp_k = -(l_k x z_k), and dL/dp_e = sum_k l_k x z_k.
-    float Se[3] = {0.0f, 0.0f, 0.0f};
-    if (JAC) {
-#pragma unroll
-        for (int k = 0; k < CAP; ++k) {
-            if (dof[k] >= 0) {
-                float l[3];
-                glin(dof[k], l);
-                const float z[3] = {P[k].R[2], P[k].R[5], P[k].R[8]};
-                Se[0] += l[1] * z[2] - l[2] * z[1];
-                Se[1] += l[2] * z[0] - l[0] * z[2];
-                Se[2] += l[0] * z[1] - l[1] * z[0];
-            }
+        park(k, cur);
+        if (JAC && dof >= 0) {
+            float l[3];
+            glin(dof, l);
+            const float z[3] = {cur.R[2], cur.R[5], cur.R[8]};
+            Se[0] += l[1] * z[2] - l[2] * z[1];
+            Se[1] += l[2] * z[0] - l[0] * z[2];
+            Se[2] += l[0] * z[1] - l[1] * z[0];
         }
     }
+    const float pe[3] = {cur.p[0], cur.p[1], cur.p[2]}; // JAC: the last op is the target
     // ---- adjoint sweep -------------------------------------------------------
     Adjoint carry;
 #pragma unroll
     for (int i = 0; i < 3; ++i) carry.G[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) carry.M[i] = 0.0f;
-#pragma unroll
-    for (int k = CAP - 1; k >= 0; --k) {
+#pragma unroll 1
+    for (int k = n_ops - 1; k >= 0; --k) {
         const float *of = opf + k * DRM_OPF_STRIDE;
-        const int src = DRM_OPI(DRM_OPI_SRC, k), save = DRM_OPI(DRM_OPI_SAVE, k), out = DRM_OPI(DRM_OPI_OUT, k);
+        const int c = ctl[k];
+        const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE),
+                  out = ctl_field(c, DRM_OPI_OUT);
         Adjoint tot;
-        if (DRM_OPI(DRM_OPI_FLAGS, k) & DRM_FLAG_CHILD_IS_NEXT) {
+        if (ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT) {
             tot = carry;
         } else {
 #pragma unroll
@@ -612,15 +609,17 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 #pragma unroll
             for (int i = 0; i < 9; ++i) tot.M[i] = 0.0f;
         }
+        Pose Pk;
+        unpark(k, Pk);
         if (out >= 0) grad_in(out, tot.G);
         if (JAC) {
             if (out >= 0) { tot.G[0] += Se[0]; tot.G[1] += Se[1]; tot.G[2] += Se[2]; }
-            if (dof[k] >= 0) {
+            if (dof >= 0) {
                 float l[3], a[3];
-                glin(dof[k], l);
-                gang(dof[k], a);
-                const float z[3] = {P[k].R[2], P[k].R[5], P[k].R[8]};
-                const float r[3] = {P[CAP - 1].p[0] - P[k].p[0], P[CAP - 1].p[1] - P[k].p[1], P[CAP - 1].p[2] - P[k].p[2]};
+                glin(dof, l);
+                gang(dof, a);
+                const float z[3] = {Pk.R[2], Pk.R[5], Pk.R[8]};
+                const float r[3] = {pe[0] - Pk.p[0], pe[1] - Pk.p[1], pe[2] - Pk.p[2]};
                 const float zb[3] = {a[0] + (r[1] * l[2] - r[2] * l[1]), a[1] + (r[2] * l[0] - r[0] * l[2]),
                                      a[2] + (r[0] * l[1] - r[1] * l[0])};
                 tot.G[0] -= l[1] * z[2] - l[2] * z[1];
@@ -636,10 +635,10 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         Pose par;
         if (src >= 0) pose_load(src, par);
         else if (src == DRM_SRC_ROOT || k == 0) pose_identity(par);
-        else par = P[k > 0 ? k - 1 : 0];
-        if (want_gq && dof[k] >= 0) {
+        else unpark(k - 1, par);
+        if (want_gq && dof >= 0) {
             const float Nx = tot.M[7] - tot.M[5], Ny = tot.M[2] - tot.M[6], Nz = tot.M[3] - tot.M[1];
-            gq_out(dof[k], P[k].R[2] * Nx + P[k].R[5] * Ny + P[k].R[8] * Nz);
+            gq_out(dof, Pk.R[2] * Nx + Pk.R[5] * Ny + Pk.R[8] * Nz);
         }
         if ((param_mask >> k) & 1u) {
             float dt[3], A[9], Bm[9], dF[9];
@@ -647,21 +646,21 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    A[r * 3 + c] = par.R[0 * 3 + r] * tot.M[0 * 3 + c] + par.R[1 * 3 + r] * tot.M[1 * 3 + c] +
-                                   par.R[2 * 3 + r] * tot.M[2 * 3 + c];
-                    Bm[r * 3 + c] = par.R[r * 3 + 0] * of[DRM_OPF_FIJ(0, c)] + par.R[r * 3 + 1] * of[DRM_OPF_FIJ(1, c)] +
-                                    par.R[r * 3 + 2] * of[DRM_OPF_FIJ(2, c)];
+                for (int cc = 0; cc < 3; ++cc) {
+                    A[r * 3 + cc] = par.R[0 * 3 + r] * tot.M[0 * 3 + cc] + par.R[1 * 3 + r] * tot.M[1 * 3 + cc] +
+                                    par.R[2 * 3 + r] * tot.M[2 * 3 + cc];
+                    Bm[r * 3 + cc] = par.R[r * 3 + 0] * of[DRM_OPF_FIJ(0, cc)] + par.R[r * 3 + 1] * of[DRM_OPF_FIJ(1, cc)] +
+                                     par.R[r * 3 + 2] * of[DRM_OPF_FIJ(2, cc)];
                 }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    dF[r * 3 + c] = A[r * 3 + 0] * Bm[0 * 3 + c] + A[r * 3 + 1] * Bm[1 * 3 + c] + A[r * 3 + 2] * Bm[2 * 3 + c];
+                for (int cc = 0; cc < 3; ++cc)
+                    dF[r * 3 + cc] = A[r * 3 + 0] * Bm[0 * 3 + cc] + A[r * 3 + 1] * Bm[1 * 3 + cc] + A[r * 3 + 2] * Bm[2 * 3 + cc];
             param_out(k, dF, dt);
         }
         if (src != DRM_SRC_ROOT) {
-            const float r[3] = {P[k].p[0] - par.p[0], P[k].p[1] - par.p[1], P[k].p[2] - par.p[2]};
+            const float r[3] = {Pk.p[0] - par.p[0], Pk.p[1] - par.p[1], Pk.p[2] - par.p[2]};
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -123,8 +123,10 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
     static thread_local double sum[CAP * 12];
     for (int i = 0; i < CAP * 12; ++i) sum[i] = 0.0;
     for (int64_t b = 0; b < B; ++b) {
-        Pose ps[DRM_MAX_SLOTS];
+        Pose ps[DRM_MAX_SLOTS], parked[CAP];
         Adjoint as[DRM_MAX_SLOTS] = {};
+        auto park = [&](int k, const Pose &P) { parked[k] = P; };
+        auto unpark = [&](int k, Pose &P) { P = parked[k]; };
         if (gq) for (int d = 0; d < n; ++d) gq[b * n + d] = 0.f;
         auto qf = [&](int d) { return q[b * n + d]; };
         auto gin = [&](int t, float *G) { if (gpos) for (int i = 0; i < 3; ++i) G[i] += gpos[(b * T + t) * 3 + i]; };
@@ -145,10 +147,13 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
             for (int j = 0; j < 9; ++j) sum[k * 12 + j] += dF[j];
             for (int j = 0; j < 3; ++j) sum[k * 12 + 9 + j] += dt[j];
         };
+        const int32_t *ctl = w->ops_i + DRM_OPI_CTRL * CAP;
         if (glin)
-            fk_backward_walk<CAP, true>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout, jl, ja);
+            fk_backward_walk<true>(w->ops_f, ctl, w->n_ops, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout,
+                                   park, unpark, jl, ja);
         else
-            fk_backward_walk<CAP>(w->ops_f, w->ops_i, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout);
+            fk_backward_walk<false>(w->ops_f, ctl, w->n_ops, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout,
+                                    park, unpark);
     }
     if (gops)
         for (int k = 0; k < CAP; ++k) {
