@@ -151,7 +151,11 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
     if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
     const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + sdepth * 6) * WAVE;
-    const bool direct = (size_t)(base + round4(WAVE * pad_odd(nn))) * sizeof(float) > (size_t)MAX_LDS_BYTES;
+    // the H tile of a wave is 256 n^2 bytes: beyond 32 KB (n >= 12) it decides how many waves a CU can hold, and a
+    // branching robot's H is mostly structural zeros — write the entries straight to HBM over a memset instead
+    // (Allegro, n = 16, 65 536 samples: see profiles/r01_kernel_times.txt)
+    const bool direct = (size_t)round4(WAVE * pad_odd(nn)) * sizeof(float) > (size_t)32 * 1024 ||
+                        (size_t)(base + round4(WAVE * pad_odd(nn))) * sizeof(float) > (size_t)MAX_LDS_BYTES;
     Geometry g;
     rc = make_geometry(B, base + (direct ? 0 : round4(WAVE * pad_odd(nn))), g);
     if (rc) return rc;
