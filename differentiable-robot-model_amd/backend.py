@@ -96,10 +96,15 @@ def load_library(path: str = None):
         return _lib
 
 
+class KernelUnsupported(RuntimeError):
+    """DRM_ERR_UNSUPPORTED: the request is valid but no compiled kernel takes it (e.g. an inertia matrix too large for LDS)."""
+
+
 def _check(rc: int):
     if rc != 0:
         msg = load_library().drm_last_error()
-        raise RuntimeError("drm_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        text = "drm_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?")
+        raise KernelUnsupported(text) if rc == -2 else RuntimeError(text)
 
 
 def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
@@ -262,9 +267,17 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
         return qdd
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(q.device):
-        _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
-                                        qdd.data_ptr(), _stream(q.device)))
+    try:
+        with torch.cuda.device(q.device):
+            _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
+                                            qdd.data_ptr(), _stream(q.device)))
+    except KernelUnsupported:
+        # more DoFs than the fused kernel can keep in LDS (64 packed n x n triangles): the same linear system
+        # H qdd = f - nle from the CRBA and RNEA kernels, factorised on the device by the batched Cholesky of
+        # torch.linalg (hipSOLVER) — slower, but no robot is refused
+        H = crba(prog, ops_f, ops_i, q, n_dofs)
+        bias = rnea(prog, ops_f, ops_i, q, qd, None, include_gravity, use_damping, n_dofs)
+        qdd = torch.cholesky_solve((f - bias).unsqueeze(-1), torch.linalg.cholesky(H)).squeeze(-1)
     return qdd
 
 

@@ -180,7 +180,8 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *st
  * algorithm).  flags as for drm_rnea: DRM_RNEA_GRAVITY = base acceleration (0,0,+9.81) (robot_model.py:527-533),
  * DRM_RNEA_DAMPING = the damping torques damping * qd are taken off f first (robot_model.py:515-521; the
  * caller's f is NOT modified, unlike the reference, which subtracts in place).
- *   q, qd, f [B, n]  ->  qdd [B, n];  DRM_ERR_UNSUPPORTED when 64 n x n matrices do not fit in LDS (n > ~20)
+ *   q, qd, f [B, n]  ->  qdd [B, n];  DRM_ERR_UNSUPPORTED when 64 packed n x n triangles do not fit in LDS (n > ~25:
+ *   the host layer then solves the same system from drm_crba + drm_rnea with a batched device Cholesky)
  */
 int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,
                          int32_t flags, float *qdd, void *stream);

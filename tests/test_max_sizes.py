@@ -115,14 +115,11 @@ def test_gpu_long_chain_forward_kernels_vs_oracle(tmp_path, n, B):
     assert np.allclose(tau.cpu().numpy(), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
     H = m.compute_lagrangian_inertia_matrix(dev(q))
     assert np.allclose(H.cpu().numpy(), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU)
-    try:
-        acc = m.compute_forward_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
-    except RuntimeError as err:       # 64 packed n x n triangles must fit in LDS (include/drm_hip.h: n <= ~20)
-        assert "LDS" in str(err) or "unsupported" in str(err).lower(), err
-    else:
-        ref = orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)
-        # cond(H) of a 22-link chain of light links ~1e5: the conditioning-class tolerance of test_forward_dynamics.py
-        assert (np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max() <= 1e-2
+    # n = 30 does not fit the fused kernel's LDS budget: the CRBA + RNEA + batched-Cholesky path takes over
+    acc = m.compute_forward_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
+    ref = orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)
+    # cond(H) of a long chain of light links ~1e5: the conditioning-class tolerance of test_forward_dynamics.py
+    assert (np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max() <= 1e-2
 
 
 @pytest.mark.gpu
