@@ -1,0 +1,218 @@
+// drm_arm_kernels.hip — the serial-chain ("arm") kernels of the two hottest calls, K2 FK+Jacobian (the metric kernel)
+// and K3 RNEA, in a translation unit of their own: it is the only one compiled with kernel-argument preload
+// (-mllvm -amdgpu-kernarg-preload-count, see the Makefile) — these kernels order their arguments for it, use < 170
+// registers and spill nothing, whereas the big table-driven kernels gain nothing from it and one of them faulted with it.
+// The C ABI entry points (drm_fk_jacobian.hip, drm_fk.hip, drm_rnea.hip) call the launch_* functions below.
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+// ---------------------------------------------------------------------------------------------------
+// Serial-chain ("arm") specialisation, full tiles only: DRM_WALK_ARM_CHAIN walks (Franka Panda, KUKA iiwa: NJ
+// moving joints in DoF order, then fixed links), every tile has 64 rows, every pointer is 16-byte aligned, pos /
+// quat wanted, NJ odd.  This is the shape of the metric workload.  Differences from the generic kernel:
+//   * the arithmetic runs on packed FP32 pairs (drm_sample.hpp "Packed-FP32 form"): 27 v_pk_* per link instead
+//     of 48 scalar VALU ops, two joints per sincos evaluation;
+//   * the constant rows of the walk (1 KB) are staged ONCE per wave into LDS by one 16-byte load per lane and
+//     the FT blocks are read back as broadcast ds_read_b128s into VGPR pairs (in-order LDS returns let the compiler wait per link, and
+//     packed ops take VGPR pairs without constant-bus limits); no scalar loads, no int table;
+//   * the first 14 argument dwords are preloaded into SGPRs by the command processor (kernarg preload,
+//     HIPFLAGS in the Makefile), so the constant and q-tile loads are issued in the wave's first cycles;
+//   * no runtime shape flags: one basic block from the loads to the stores; pos / lin_jac / ang_jac are staged in
+//     separate LDS regions, so there is one LDS turnaround before the 16-byte stores go out back to back.
+// With one wave per SIMD (batch 65 536) a launch lasts launch floor + issue time + store drain (nothing
+// overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
+// The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
+// ---------------------------------------------------------------------------------------------------
+// waves per block of the arm kernels: a packing choice (waves are independent); 1, 2 and 4 measure the same
+#define DRM_ARM_WPB MAX_WAVES_PER_BLOCK
+template <int CAP, int NJ, bool JAC>
+__global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
+    fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
+                           float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
+                           float *__restrict__ ang) {
+    // argument order: everything needed to issue the first loads sits in the preloaded dwords.
+    // JAC = false is the FK-only form (drm_fk of one target): same chain, no Jacobian columns.
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int SQ = NJ, SJ = 3 * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * SQ), P_FLOATS = WAVE * 3,
+                  J_FLOATS = round4(WAVE * SJ);
+    // pos is staged over the q tile (q lives in registers by then): 51.7 KB per block, three blocks per CU
+    static_assert(P_FLOATS <= Q_FLOATS, "pos staging overlays the q tile");
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? 2 * J_FLOATS : 0);
+    __shared__ __attribute__((aligned(16))) float smem[DRM_ARM_WPB * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * DRM_ARM_WPB + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    // the walk's constant rows (1 KB) -> LDS: one 16-byte load per lane, in flight together with the q tile
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+
+    float qv[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+    PoseP ee;
+    f2 Bk[NJ][3];
+    // The outputs leave in the order they become available, so that the store drain (12.8 MB per launch, the
+    // longest single item of a one-wave-per-SIMD launch) starts as early as possible: ang_jac needs only the joint
+    // axes and goes out while the fixed tail of the chain is still being composed; lin_jac and pos need the end
+    // position; the quaternion takes the most arithmetic and goes last.
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+        if constexpr (JAC) {
+            float *arow = la + lane * SJ;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) { // robot_model.py:662
+                arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0];
+            }
+            wave_lds_sync();
+            tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+        }
+    });
+
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    if constexpr (JAC) {
+        float *lrow = ll + lane * SJ;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+            const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+            float c[3];
+            cross3(z, dp, c); // robot_model.py:661
+            // keep the columns scalar: packing two joints' cross products costs more register shuffles than it saves
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+            lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+        }
+        lp[lane * 3 + 0] = pe[0];
+        lp[lane * 3 + 1] = pe[1];
+        lp[lane * 3 + 2] = pe[2];
+        wave_lds_sync();
+        tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+    } else {
+        wave_lds_sync(); // every lane has read its q row before pos is staged over the q tile
+        lp[lane * 3 + 0] = pe[0];
+        lp[lane * 3 + 1] = pe[1];
+        lp[lane * 3 + 2] = pe[2];
+        wave_lds_sync();
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+    }
+    // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
+    // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
+    {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
+    }
+}
+
+// FK of the single target of an arm-shaped walk through the packed chain kernel (called by drm_fk); returns the
+// number of rows it covered (full tiles), 0 if the call does not qualify.
+int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s) {
+#ifdef DRM_NO_ARM_KERNEL
+    return 0;
+#else
+    const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    if (!((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7 && w->target_perm == 2 &&
+          align == (AL_Q | AL_POS | AL_QUAT) && (((uintptr_t)w->ops_f) & 15u) == 0 && B >= WAVE &&
+          B / WAVE < 0x7fffffffLL))
+        return 0;
+    const int n_tiles = (int)(B / WAVE);
+    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, false>),
+                       dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
+                       dim3(WAVE * DRM_ARM_WPB), 0, s, w->ops_f, q, n_tiles, pos, quat, (float *)nullptr,
+                       (float *)nullptr);
+    return (int64_t)n_tiles * WAVE;
+#endif
+}
+
+
+void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, float *pos, float *quat, float *lin_jac,
+                            float *ang_jac, hipStream_t s) {
+    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true>), dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
+                       dim3(WAVE * DRM_ARM_WPB), 0, s, ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Serial-chain ("arm") specialisation, full tiles only (DRM_WALK_ARM_CHAIN walks, 16-byte aligned pointers,
+// NJ odd): the same design as fk_jacobian_arm_kernel — constant rows staged once per wave in LDS (one 16-byte
+// load per lane brings the whole 1 KB table) and read back as broadcast ds_reads, packed-FP32 sweeps
+// (drm_sample.hpp rnea_chain), preloaded kernel arguments, one basic block; the per-link body forces are parked
+// in LDS between the two sweeps (registers are what limits occupancy here), over the dead input tiles.
+// ---------------------------------------------------------------------------------------------------
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                    const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
+    // the q / qd / qdd tiles are dead once every lane holds its rows in registers, so the body-force parking
+    // area overlays them (and tau is staged over it at the end): 13.3 KB per wave, three blocks per CU
+    static_assert(3 * Q_FLOATS <= F_FLOATS, "the input tiles fit under the parking area");
+    constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS;
+    float *lf = lq + lane; // body forces between the sweeps: [link][6][64], over the (by then dead) input tiles
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
+    if (qdd) tile_load<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+
+    float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) {
+        qv[d] = lq[lane * NJ + d];
+        qdv[d] = lqd[lane * NJ + d];
+        qddv[d] = qdd ? lqdd[lane * NJ + d] : 0.0f;
+    }
+    wave_lds_sync(); // all rows are in registers: the tiles may be overwritten
+    rnea_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                        flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv,
+                        [&](int k, const Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                lf[(k * 6 + i) * WAVE] = F.la[i][0];
+                                lf[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                            }
+                        },
+                        [&](int k, Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
+                        });
+    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = tv[d];
+    wave_lds_sync();
+    tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+}
+
+
+void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+                     float *tau, hipStream_t s) {
+    hipLaunchKernelGGL((rnea_arm_kernel<8, 7>), dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+}
+
+} // namespace drm

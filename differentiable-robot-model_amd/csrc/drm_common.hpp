@@ -304,8 +304,12 @@ static inline int backward_waves(int64_t B, int wpb) {
     return (int)(waves < 1 ? wpb : waves);
 }
 
-// drm_fk_jacobian.hip: single-target FK of an arm-shaped walk through the packed chain kernel
+// drm_arm_kernels.hip: the serial-chain kernels of K1 / K2 / K3 (full 64-row tiles, 16-byte aligned pointers)
 int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
+void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, float *pos, float *quat, float *lin_jac,
+                            float *ang_jac, hipStream_t s);
+void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+                     float *tau, hipStream_t s);
 
 template <class K>
 static int ensure_lds(K kernel, size_t bytes) {

@@ -78,70 +78,6 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<0>(tau + cx.b0 * n, cx.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Serial-chain ("arm") specialisation, full tiles only (DRM_WALK_ARM_CHAIN walks, 16-byte aligned pointers,
-// NJ odd): the same design as fk_jacobian_arm_kernel — constant rows staged once per wave in LDS (one 16-byte
-// load per lane brings the whole 1 KB table) and read back as broadcast ds_reads, packed-FP32 sweeps
-// (drm_sample.hpp rnea_chain), preloaded kernel arguments, one basic block; the per-link body forces are parked
-// in LDS between the two sweeps (registers are what limits occupancy here), over the dead input tiles.
-// ---------------------------------------------------------------------------------------------------
-template <int CAP, int NJ>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
-                    const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
-    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
-    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
-    // the q / qd / qdd tiles are dead once every lane holds its rows in registers, so the body-force parking
-    // area overlays them (and tau is staged over it at the end): 13.3 KB per wave, three blocks per CU
-    static_assert(3 * Q_FLOATS <= F_FLOATS, "the input tiles fit under the parking area");
-    constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
-    if (tile >= n_tiles) return;
-    const unsigned lane = threadIdx.x & 63u;
-    float *lc = smem + wave * PER_WAVE;
-    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS;
-    float *lf = lq + lane; // body forces between the sweeps: [link][6][64], over the (by then dead) input tiles
-    const int64_t b0 = (int64_t)tile * WAVE;
-
-    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
-    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-    tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
-    if (qdd) tile_load<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
-    pin(cv);
-    reinterpret_cast<float4 *>(lc)[lane] = cv;
-    wave_lds_sync();
-
-    float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) {
-        qv[d] = lq[lane * NJ + d];
-        qdv[d] = lqd[lane * NJ + d];
-        qddv[d] = qdd ? lqdd[lane * NJ + d] : 0.0f;
-    }
-    wave_lds_sync(); // all rows are in registers: the tiles may be overwritten
-    rnea_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
-                        flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv,
-                        [&](int k, const Force &F) {
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                lf[(k * 6 + i) * WAVE] = F.la[i][0];
-                                lf[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
-                            }
-                        },
-                        [&](int k, Force &F) {
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
-                        });
-    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = tv[d];
-    wave_lds_sync();
-    tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-}
-
 } // namespace drm
 
 using namespace drm;
@@ -164,9 +100,7 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
         align == (AL_Q | AL_QD | AL_TAU | (qdd ? AL_QDD : 0u)) && (((uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the packed-FP32 chain kernel, ragged tail through the generic one
         const int n_tiles = (int)(B / WAVE);
-        hipLaunchKernelGGL((rnea_arm_kernel<8, 7>),
-                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, n_tiles, (int)flags, tau);
+        launch_rnea_arm(w->ops_f, q, qd, qdd, n_tiles, (int)flags, tau, s);
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return launched();
         rc = launched();
