@@ -292,3 +292,28 @@ def test_fanout_fk_equals_merged_walk_and_oracle(robot, tips, B):
     arm = load_model("panda_no_gripper", "cuda")
     two = [arm._name_to_idx_map[n] for n in ("panda_link4", "panda_virtual_ee_link")]
     assert arm._fanout_chains(two, arm._get_walk(("fk", tuple(two)), targets=two)) is None
+
+
+# ------------------------------------------------------------------ random robots x batch sizes
+@pytest.mark.parametrize("seed", range(16))
+def test_random_robot_and_batch_size_vs_oracle(seed):
+    """Every forward call of a random robot at a random (mostly ragged) batch size against the fp64 oracle — partial
+    tiles, unaligned tails of the arm kernels and multi-wave blocks in one sweep."""
+    rng = np.random.default_rng(9000 + seed)
+    robot = ALL_ROBOTS[int(rng.integers(len(ALL_ROBOTS)))]
+    B = int(rng.choice([rng.integers(1, 200), rng.integers(200, 3000), 64 * rng.integers(1, 40) + rng.integers(0, 2)]))
+    m = load_model(robot, "cuda")
+    orc = Oracle(m._spec)
+    q, qd, qdd = sample_states(m, B, seed=seed)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    link = int(rng.integers(1, len(m._bodies)))
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(dev(q), m._bodies[link].name)
+    rp, rq, rl, ra = orc.fk_jacobian(q64, link, np.float64)
+    assert max_err(host(pos), rp) <= TOL_POS["atol"] and quat_close(host(quat), rq, TOL_QUAT["atol"])[0], (robot, B, link)
+    assert max_err(host(lin), rl) <= TOL_JAC["atol"] and max_err(host(ang), ra) <= TOL_JAC["atol"], (robot, B, link)
+    p2, r2 = m.compute_forward_kinematics(dev(q), m._bodies[link].name)
+    assert max_err(host(p2), rp) <= TOL_POS["atol"] and quat_close(host(r2), rq, TOL_QUAT["atol"])[0]
+    tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd))
+    assert np.allclose(host(tau), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU), (robot, B)
+    H = m.compute_lagrangian_inertia_matrix(dev(q))
+    assert np.allclose(host(H), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU), (robot, B)
