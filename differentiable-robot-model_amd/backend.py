@@ -376,3 +376,32 @@ class FkJacobianPlan(object):
 
     def outputs(self):
         return self.pos, self.quat, self.lin, self.ang
+
+
+class InverseDynamicsPlan(object):
+    """A prepared drm_rnea launch on fixed buffers (q, qd, qdd in, tau out): the allocation-free, graph-capturable form of
+    compute_inverse_dynamics for loops that evaluate the same batch shape repeatedly (update q / qd / qdd in place)."""
+
+    def __init__(self, prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
+        self._lib = load_library()
+        self.q, self.qd = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs)
+        self.qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+        B, dev = self.q.shape[0], self.q.device
+        if self.qd.shape[0] != B or (self.qdd is not None and self.qdd.shape[0] != B):
+            raise ValueError("q / qd / qdd batch sizes differ")
+        self.tau = torch.empty(B, n_dofs, device=dev)
+        self._keep = (ops_f, ops_i)
+        self._walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+        flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        self._args = (ctypes.byref(self._walk), self.q.data_ptr(), self.qd.data_ptr(),
+                      self.qdd.data_ptr() if self.qdd is not None else None, B, flags, self.tau.data_ptr())
+        self.batch, self.device = B, dev
+
+    def launch(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self._lib.drm_rnea(*self._args, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            _check(rc)
+
+    def outputs(self):
+        return (self.tau,)

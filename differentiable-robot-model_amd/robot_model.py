@@ -563,6 +563,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
         return backend.FkJacobianPlan(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs, want_pose)
 
+    def plan_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: Optional[torch.Tensor],
+                              include_gravity: bool = True, use_damping: bool = True) -> "backend.InverseDynamicsPlan":
+        """Prepared (allocation-free, graph-capturable) inverse-dynamics launch on fixed buffers; ``qdd_des=None``
+        gives the non-linear effects."""
+        self._require_device()
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
+        dw = self._get_walk(("tree",), whole_tree=True)
+        return backend.InverseDynamicsPlan(dw.program, self._ops_f(dw), dw.ops_i, q, qd, qdd_des, bool(include_gravity),
+                                           bool(use_damping), self._n_dofs)
+
     # ------------------------------------------------------------------ inverse dynamics
     @tensor_check
     def compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,

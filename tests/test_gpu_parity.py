@@ -173,6 +173,31 @@ def test_plan_and_hipgraph_replay_match_direct_call():
     assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref))
 
 
+def test_inverse_dynamics_plan_and_hipgraph_replay_match_direct_call():
+    m = load_model("iiwa7", "cuda")
+    q, qd, qdd = (dev(a) for a in sample_states(m, 3000, seed=12))
+    for acc in (qdd, None):
+        ref = m.compute_inverse_dynamics(q, qd, qdd) if acc is not None else m.compute_non_linear_effects(q, qd)
+        plan = m.plan_inverse_dynamics(q, qd, acc)
+        plan.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.tau, ref)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            plan.launch()
+        plan.tau.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.tau, ref)
+        # new inputs written into the plan's buffers are what the replay sees
+        plan.q.mul_(0.5)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = m.compute_inverse_dynamics(plan.q, qd, qdd) if acc is not None else m.compute_non_linear_effects(plan.q, qd)
+        assert torch.equal(plan.tau, want)
+        plan.q.mul_(2.0)
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 @pytest.mark.parametrize("B", [65536, 1 << 20])
 def test_full_size_properties(B):
