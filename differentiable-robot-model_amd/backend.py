@@ -132,12 +132,18 @@ def _stream(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
+def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze: bool = False):
+    """pos [B, T, 3], quat [B, T, 4] of the walk's targets ([B, 3], [B, 4] for one target with ``squeeze``: the same
+    memory without the T axis, so the single-link API returns it without a slicing op)."""
     lib = load_library()
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
-    pos = torch.empty(B, n_targets, 3, device=q.device, dtype=torch.float32)
-    quat = torch.empty(B, n_targets, 4, device=q.device, dtype=torch.float32)
+    if squeeze and n_targets == 1:
+        pos = torch.empty(B, 3, device=q.device, dtype=torch.float32)
+        quat = torch.empty(B, 4, device=q.device, dtype=torch.float32)
+    else:
+        pos = torch.empty(B, n_targets, 3, device=q.device, dtype=torch.float32)
+        quat = torch.empty(B, n_targets, 4, device=q.device, dtype=torch.float32)
     if B == 0:
         return pos, quat
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)

@@ -523,6 +523,11 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         idx = self._name_to_idx_map[link_name]
+        if idx != 0 and not (torch.is_grad_enabled() and (q.requires_grad or self._learnable)):
+            # the common call: one kernel, outputs allocated in their final shape (no slicing ops on the way out)
+            self._require_device()
+            dw = self._get_walk(("fk", (idx,)), targets=[idx])
+            return backend.fk(dw.program, self._ops_f(dw), dw.ops_i, q, 1, self._n_dofs, squeeze=True)
         pos, quat = self._fk_targets(q, [idx])
         return pos[:, 0], quat[:, 0]
 

@@ -17,10 +17,12 @@ for B in (64, 4096):
         "compute_forward_dynamics": lambda: m.compute_forward_dynamics(q, qd, qdd),
         "plan.launch (prepared)": m.plan_fk_and_jacobian(q, link).launch,
     }
-    for name, fn in calls.items():
-        for _ in range(50): fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2000): fn()
-        torch.cuda.synchronize()
-        print("B=%5d  %-36s %7.1f us per call" % (B, name, (time.perf_counter() - t0) / 2000 * 1e6))
+    for rep in range(2):      # the first pass only warms the host (clocks, allocator, code paths); the second is reported
+        for name, fn in calls.items():
+            for _ in range(50): fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2000): fn()
+            torch.cuda.synchronize()
+            if rep:
+                print("B=%5d  %-36s %7.1f us per call" % (B, name, (time.perf_counter() - t0) / 2000 * 1e6))
