@@ -449,3 +449,38 @@ def test_gpu_arm_chain_fk_backward_vs_emu(emu, robot, link, B):
             assert np.allclose(got_q.cpu().numpy(), gq, atol=2e-5, rtol=2e-5), np.abs(got_q.cpu().numpy() - gq).max()
         if pm:
             assert np.abs(got_ops.cpu().numpy() - gops).max() <= 1e-4 * max(np.abs(gops).max(), 1e-6) * max(1.0, B / 256)
+
+
+@pytest.mark.gpu
+def test_gpu_kinematic_trajectory_optimisation_lowers_the_cost():
+    """examples/run_kinematic_trajectory_opt.py in miniature: an action sequence is optimised through
+    compute_forward_kinematics (B = 1 calls, gradient with respect to q) so that the Panda's end effector approaches a
+    goal position."""
+    torch.manual_seed(0)
+    m = load_model("panda_no_gripper", "cuda")
+    link, horizon = "panda_virtual_ee_link", 8
+    lim = m.get_joint_limits()
+    lo = torch.tensor([j["lower"] for j in lim], device="cuda"); hi = torch.tensor([j["upper"] for j in lim], device="cuda")
+    start = torch.tensor([0.0, 0.0, 0.0, -1.5, 0.0, 1.6, 0.0], device="cuda")
+    with torch.no_grad():
+        goal, _ = m.compute_forward_kinematics(torch.zeros(1, 7, device="cuda"), link)
+    actions = torch.nn.Parameter(torch.zeros(horizon, 7, device="cuda"))
+    opt = torch.optim.Adam([actions], lr=1e-2)
+
+    def rollout():
+        q, ee = start, []
+        for t in range(horizon):
+            q = torch.minimum(torch.maximum(q.detach() + actions[t], lo), hi)
+            pos, _ = m.compute_forward_kinematics(q.reshape(1, 7), link)
+            ee.append(pos.squeeze(0))
+        return torch.stack(ee)
+
+    costs = []
+    for _ in range(40):
+        opt.zero_grad()
+        cost = ((100 * (rollout() - goal)) ** 2).mean()
+        cost.backward()
+        opt.step()
+        costs.append(cost.item())
+    assert actions.grad is not None and torch.isfinite(actions.grad).all()
+    assert costs[-1] < 0.8 * costs[0], (costs[0], costs[-1])
