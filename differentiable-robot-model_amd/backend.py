@@ -40,7 +40,8 @@ _lock = threading.Lock()
 EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
-           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward")
+           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
+           "drm_walk_table_backward")
 
 
 def load_library(path: str = None):
@@ -86,6 +87,10 @@ def load_library(path: str = None):
         lib.drm_link_rows.argtypes = [vp, i32, vp, vp]
         lib.drm_link_rows_backward.restype = ctypes.c_int
         lib.drm_link_rows_backward.argtypes = [vp, vp, i32, vp, vp]
+        lib.drm_walk_table.restype = ctypes.c_int
+        lib.drm_walk_table.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
+        lib.drm_walk_table_backward.restype = ctypes.c_int
+        lib.drm_walk_table_backward.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
         lib.drm_forward_dynamics.restype = ctypes.c_int
         lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
         lib.drm_crba.restype = ctypes.c_int
@@ -259,6 +264,47 @@ class LinkRows(torch.autograd.Function):
             _check(lib.drm_link_rows_backward(params.data_ptr(), grad_rows.data_ptr(), params.shape[0], grad.data_ptr(),
                                               _stream(params.device)))
         return grad
+
+
+class WalkTable(torch.autograd.Function):
+    """The walk table of a robot with learnable links in ONE launch, and its derivative in another (drm_walk_table):
+    ``pieces`` are the outputs of the links' parameter callables (rot_angles, trans, mass, com, inertia_mat, damping per
+    learnable link, 20 floats per link); they are packed, turned into link-table rows and gathered into walk order over
+    ``base`` inside the kernel.  The autograd graph holds this one node instead of a cat / stack / index_copy /
+    index_select / mul chain, and the backward returns views of one [n_links, 20] gradient."""
+
+    @staticmethod
+    def forward(ctx, base, sel, gsign, n_links, *pieces):
+        lib = load_library()
+        dev = base.device
+        params = torch.cat([p.reshape(-1).to(device=dev, dtype=torch.float32) for p in pieces])
+        assert params.numel() == n_links * 20, "20 floats per learnable link"
+        ops_f = torch.empty_like(base)
+        with torch.cuda.device(dev):
+            _check(lib.drm_walk_table(params.data_ptr(), n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
+                                      base.numel(), ops_f.data_ptr(), _stream(dev)))
+        ctx.save_for_backward(params, sel, gsign)
+        ctx.n_links, ctx.shapes = n_links, [tuple(p.shape) for p in pieces]
+        return ops_f
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_ops_f):
+        params, sel, gsign = ctx.saved_tensors
+        lib = load_library()
+        g = grad_ops_f.contiguous().to(torch.float32)
+        grad = torch.empty_like(params)
+        with torch.cuda.device(params.device):
+            _check(lib.drm_walk_table_backward(params.data_ptr(), ctx.n_links, g.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
+                                               g.numel(), grad.data_ptr(), _stream(params.device)))
+        out, off = [], 0
+        for i, shape in enumerate(ctx.shapes):
+            n = 1
+            for d in shape:
+                n *= d
+            out.append(grad[off:off + n].reshape(shape) if ctx.needs_input_grad[4 + i] else None)
+            off += n
+        return (None, None, None, None) + tuple(out)
 
 
 def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):

@@ -79,9 +79,84 @@ __global__ void link_rows_backward_kernel(const float *__restrict__ params, cons
 #pragma unroll
     for (int k = 0; k < LINK_PARAM_FLOATS; ++k) grad_params[i * LINK_PARAM_FLOATS + k] = gp[k];
 }
+// The walk table of a robot with learnable links in ONE launch (and its derivative in another): the rows of the learnable
+// links from their URDF-level parameters, gathered into walk order (with the exact +-1 factors of the axis
+// canonicalisation) over the table of the constant links.  One block; everything is < 8 KB.
+constexpr int WALK_TABLE_THREADS = 256, WALK_TABLE_MAX_LINKS = 32;
+__global__ void __launch_bounds__(WALK_TABLE_THREADS)
+    walk_table_kernel(const float *__restrict__ params, int n_links, const float *__restrict__ base,
+                      const int32_t *__restrict__ sel, const float *__restrict__ gsign, int n_entries,
+                      float *__restrict__ ops_f) {
+    __shared__ float rows[WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE];
+    const int t = (int)threadIdx.x;
+    if (t < n_links) {
+        float p[LINK_PARAM_FLOATS], row[DRM_OPF_STRIDE];
+#pragma unroll
+        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[t * LINK_PARAM_FLOATS + k];
+        link_row(p, row);
+#pragma unroll
+        for (int k = 0; k < DRM_OPF_STRIDE; ++k) rows[t * DRM_OPF_STRIDE + k] = row[k];
+    }
+    __syncthreads();
+    for (int e = t; e < n_entries; e += WALK_TABLE_THREADS) {
+        const int r = sel[e];
+        ops_f[e] = r >= 0 ? rows[r] * gsign[e] : base[e];
+    }
+}
+__global__ void __launch_bounds__(WALK_TABLE_THREADS)
+    walk_table_backward_kernel(const float *__restrict__ params, int n_links, const float *__restrict__ grad_ops_f,
+                               const int32_t *__restrict__ sel, const float *__restrict__ gsign, int n_entries,
+                               float *__restrict__ grad_params) {
+    __shared__ float grows[WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE];
+    __shared__ float ge[DRM_MAX_OPS * DRM_OPF_STRIDE];   // grad * sign of every walk entry
+    __shared__ int se[DRM_MAX_OPS * DRM_OPF_STRIDE];     // its row element (-1: constant)
+    const int t = (int)threadIdx.x;
+    for (int e = t; e < n_entries; e += WALK_TABLE_THREADS) {
+        ge[e] = grad_ops_f[e] * gsign[e];
+        se[e] = sel[e];
+    }
+    __syncthreads();
+    // every row element adds the walk entries gathered from it, in entry order (deterministic); the staged arrays make
+    // this a loop over LDS instead of n_entries dependent global loads per thread
+    for (int r = t; r < n_links * DRM_OPF_STRIDE; r += WALK_TABLE_THREADS) {
+        float s = 0.0f;
+        for (int e = 0; e < n_entries; ++e) s += se[e] == r ? ge[e] : 0.0f;
+        grows[r] = s;
+    }
+    __syncthreads();
+    if (t < n_links) {
+        float p[LINK_PARAM_FLOATS], g[DRM_OPF_STRIDE], gp[LINK_PARAM_FLOATS];
+#pragma unroll
+        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[t * LINK_PARAM_FLOATS + k];
+#pragma unroll
+        for (int k = 0; k < DRM_OPF_STRIDE; ++k) g[k] = grows[t * DRM_OPF_STRIDE + k];
+        link_row_backward(p, g, gp);
+#pragma unroll
+        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) grad_params[t * LINK_PARAM_FLOATS + k] = gp[k];
+    }
+}
 } // namespace drm
 
 extern "C" {
+int drm_walk_table(const float *params, int32_t n_links, const float *base, const int32_t *sel, const float *gsign,
+                   int32_t n_entries, float *ops_f, void *stream) {
+    if (!params || !base || !sel || !gsign || !ops_f) return drm::fail(DRM_ERR_INVALID, "drm_walk_table: NULL argument");
+    if (n_links < 1 || n_links > drm::WALK_TABLE_MAX_LINKS || n_entries < 1 || n_entries > DRM_MAX_OPS * DRM_OPF_STRIDE)
+        return drm::fail(DRM_ERR_INVALID, "drm_walk_table: 1..32 learnable links and at most 32 x 32 walk entries");
+    hipLaunchKernelGGL(drm::walk_table_kernel, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream, params,
+                       (int)n_links, base, sel, gsign, (int)n_entries, ops_f);
+    return drm::launched();
+}
+int drm_walk_table_backward(const float *params, int32_t n_links, const float *grad_ops_f, const int32_t *sel,
+                            const float *gsign, int32_t n_entries, float *grad_params, void *stream) {
+    if (!params || !grad_ops_f || !sel || !gsign || !grad_params)
+        return drm::fail(DRM_ERR_INVALID, "drm_walk_table_backward: NULL argument");
+    if (n_links < 1 || n_links > drm::WALK_TABLE_MAX_LINKS || n_entries < 1 || n_entries > DRM_MAX_OPS * DRM_OPF_STRIDE)
+        return drm::fail(DRM_ERR_INVALID, "drm_walk_table_backward: 1..32 learnable links and at most 32 x 32 walk entries");
+    hipLaunchKernelGGL(drm::walk_table_backward_kernel, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream,
+                       params, (int)n_links, grad_ops_f, sel, gsign, (int)n_entries, grad_params);
+    return drm::launched();
+}
 int drm_link_rows(const float *params, int32_t n_links, float *rows, void *stream) {
     if (!params || !rows || n_links < 0) return drm::fail(DRM_ERR_INVALID, "params / rows must not be NULL, n_links >= 0");
     if (n_links == 0) return DRM_OK;

@@ -9,7 +9,7 @@ rules (robot_model.py:25-84), ``AssertionError`` / ``AttributeError`` /
 over tiny torch ops are replaced by:
 
   host (this file + flatten.py)   URDF -> RobotSpec -> depth-first walk tables, once;
-  device (csrc/drm_kernels.hip)   one fused hand-written HIP kernel per API call,
+  device (csrc/*.hip)             one fused hand-written HIP kernel per API call,
                                   reached through the C ABI of include/drm_hip.h.
 
 There is NO CPU compute path: the compute methods raise if the model does not
@@ -19,6 +19,7 @@ import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import backend
@@ -84,6 +85,7 @@ class _DeviceWalk:
     gather: torch.Tensor                # int64 [cap * 32] flat indices into the [L+1, 32] link table
     gsign: torch.Tensor                 # float32 [cap * 32] +-1 factors of the gathered entries
     static_ops_f: Optional[torch.Tensor] = None
+    learnable_plan: Optional[tuple] = None   # (learnable links, constant walk table, row selector) of _ops_f_learnable
 
 
 class _FkPositions(torch.autograd.Function):
@@ -284,6 +286,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             parent = self._bodies[self._name_to_idx_map[parent_names[i]]]
             body.set_parent(parent)
             parent.add_child(body)
+        self._zero1 = torch.zeros(1, device=self._device)
         self._kin_state = None   # (q, qd) of the last update_kinematic_state
         self._kin_cache = {}
 
@@ -383,11 +386,44 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
+        if self._learnable and self._device.type == "cuda":
+            return self._ops_f_learnable(dw)
         table = self._link_table()
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
         return ops_f
+
+    def _ops_f_learnable(self, dw: _DeviceWalk) -> torch.Tensor:
+        """The walk table with learnable links through ONE fused kernel (backend.WalkTable): the constant entries come
+        from a cached gather of the constant link table, the entries of the learnable links are rebuilt from their
+        parameter callables inside the kernel, and the autograd graph holds a single node."""
+        links = sorted({link for link, _ in self._learnable})
+        key = tuple(links)
+        plan = dw.learnable_plan
+        if plan is None or plan[0] != key:
+            if self._static_table is None:
+                self._link_table()
+            with torch.no_grad():
+                base = (self._static_table.reshape(-1).index_select(0, dw.gather) * dw.gsign).contiguous()
+            gather = dw.program.gather.reshape(-1)
+            row_of = {link: i for i, link in enumerate(links)}
+            sel = np.full(gather.shape, -1, np.int32)
+            for e, flat in enumerate(gather):
+                link, col = divmod(int(flat), OPF_STRIDE)
+                if link in row_of:
+                    sel[e] = row_of[link] * OPF_STRIDE + col
+            plan = dw.learnable_plan = (key, base, torch.from_numpy(sel).to(self._device))
+        _, base, sel = plan
+        zero1 = self._zero1
+        pieces = []
+        for i in links:
+            b = self._bodies[i]
+            damping = b.joint_damping()
+            pieces += [b.rot_angles(), b.trans(), b.inertia.mass(), b.inertia.com(), b.inertia.inertia_mat(),
+                       damping if damping is not None else zero1]
+        ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *pieces)
+        return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
 
     def _fanout_chains(self, targets, merged: _DeviceWalk):
         """Per-target chain walks for the fan-out FK kernel, or None when the merged walk is the better plan: 2..4

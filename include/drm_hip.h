@@ -247,6 +247,23 @@ int drm_rnea_backward(const drm_walk *walk, const float *q, const float *qd, con
 int drm_link_rows(const float *params, int32_t n_links, float *rows, void *stream);
 int drm_link_rows_backward(const float *params, const float *grad_rows, int32_t n_links, float *grad_params, void *stream);
 
+/*
+ * The walk table (ops_f) of a robot with learnable links in ONE launch, and the derivative of that map in another: what
+ * the reference does implicitly by calling its parameter modules inside every per-link op (rigid_body.py:138-143,
+ * spatial_vector_algebra.py:321-327) and differentiating through them.
+ *   params   [n_links, 20]   URDF-level parameters of the learnable links (drm_link_rows layout), n_links <= 32
+ *   base     [n_entries]     the walk table built from the constant links (entries of learnable links are ignored)
+ *   sel      [n_entries]     int32: index into the flattened [n_links, 32] rows for entries that come from a learnable
+ *                            link, -1 for entries taken from `base`
+ *   gsign    [n_entries]     the exact +-1 factors of the axis canonicalisation (flatten.WalkProgram.gsign)
+ *   ops_f    [n_entries]     out (n_entries = capacity * DRM_OPF_STRIDE)
+ * drm_walk_table_backward: grad_ops_f [n_entries] -> grad_params [n_links, 20], summed in a fixed order.
+ */
+int drm_walk_table(const float *params, int32_t n_links, const float *base, const int32_t *sel, const float *gsign,
+                   int32_t n_entries, float *ops_f, void *stream);
+int drm_walk_table_backward(const float *params, int32_t n_links, const float *grad_ops_f, const int32_t *sel,
+                            const float *gsign, int32_t n_entries, float *grad_params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,34 +49,39 @@ for B in (16384, 1 << 20):
           (B, dev_us, wall_us, B / wall_us))
     # the same training step (forward, loss, backward, Adam) captured once into a hipGraph and replayed: the host
     # leaves the loop, what remains is the kernels
-    try:
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    for fused in (False, True):
+        try:
+            state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            # default implementation (foreach) as in the reference's examples, then the fused one
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, **({"fused": True} if fused else {}))
 
-        def train_step():
-            pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
-            loss = torch.nn.functional.mse_loss(pos, want)
-            loss.backward()
-            opt.step()
-            return loss
+            def train_step():
+                pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
+                loss = torch.nn.functional.mse_loss(pos, want)
+                loss.backward()
+                opt.step()
+                return loss
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                opt.zero_grad(set_to_none=True)
-                train_step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            static_loss = train_step()
-        graph.replay(); torch.cuda.synchronize()
-        l0 = static_loss.item()
-        g_us, g_wall = timeit(graph.replay, iters=200)
-        print("config5 hipGraph-captured training step (fwd + loss + bwd + Adam)  %9.1f us (device) %9.1f us (wall)  "
-              "%8.3f Mevals/s   loss %.6f -> %.6f" % (g_us, g_wall, B / g_wall, l0, static_loss.item()))
-    except Exception as err:  # pragma: no cover - depends on the runtime
-        print("graph capture of the training step failed:", repr(err)[:300])
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    opt.zero_grad(set_to_none=True)
+                    train_step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = train_step()
+            graph.replay(); torch.cuda.synchronize()
+            l0 = static_loss.item()
+            g_us, g_wall = timeit(graph.replay, iters=200)
+            print("config5 hipGraph-captured training step (fwd + loss + bwd + %s)  %9.1f us (device) %9.1f us (wall)  "
+                  "%8.3f Mevals/s   loss %.6f -> %.6f" % ("fused Adam" if fused else "Adam", g_us, g_wall, B / g_wall, l0,
+                                                          static_loss.item()))
+            m.load_state_dict(state)
+        except Exception as err:  # pragma: no cover - depends on the runtime
+            print("graph capture of the training step failed:", repr(err)[:300])
     # kernels alone: forward FK + backward, constants fixed
     dw = m._get_walk(("fk", (m._name_to_idx_map["iiwa_link_ee"],)), targets=[m._name_to_idx_map["iiwa_link_ee"]])
     ops_f = m._ops_f(dw).detach()
