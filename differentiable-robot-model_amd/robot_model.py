@@ -386,8 +386,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if self._learnable and self._device.type == "cuda":
-            return self._ops_f_learnable(dw)
+        if self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32:
+            return self._ops_f_learnable(dw)      # (more learnable links than the fused kernel takes: the torch path below)
         table = self._link_table()
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
