@@ -71,11 +71,18 @@ def _pack_diag_lower(mat: torch.Tensor) -> torch.Tensor:
     return torch.cat([mat[_DIAG], mat[_LOWER]])
 
 
-def _lower_triangular(l: torch.Tensor) -> torch.Tensor:
-    L = l.new_zeros(3, 3)
-    L[_DIAG] = l[:3]
-    L[_LOWER] = l[3:]
-    return L
+def _placement(pairs) -> torch.Tensor:
+    """[9, 6] 0/1 matrix M with (M @ l).reshape(3, 3)[r, c] = l[k] for every (r, c, k) in ``pairs``: the six free
+    numbers are placed by ONE matrix-vector product with a constant that lives on the module's device (a registered
+    buffer) — no host-side index tensors, so the parametrisations can be captured into a HIP graph."""
+    M = torch.zeros(9, 6)
+    for r, c, k in pairs:
+        M[3 * r + c, k] = 1.0
+    return M
+
+
+_LOWER_PLACEMENT = [(0, 0, 0), (1, 1, 1), (2, 2, 2), (1, 0, 3), (2, 0, 4), (2, 1, 5)]
+_SYMM_PLACEMENT = _LOWER_PLACEMENT + [(0, 1, 3), (0, 2, 4), (1, 2, 5)]
 
 
 class Symm3DInertiaMatrixNet(torch.nn.Module):
@@ -88,11 +95,10 @@ class Symm3DInertiaMatrixNet(torch.nn.Module):
         else:
             value = _pack_diag_lower(init_param)
         self.l = torch.nn.Parameter(value.clone())
+        self.register_buffer("_place", _placement(_SYMM_PLACEMENT), persistent=False)
 
     def forward(self):
-        off = self.l.new_zeros(3, 3)
-        off[_LOWER] = self.l[3:]
-        return torch.diag(self.l[:3]) + off + off.t()
+        return (self._place @ self.l).reshape(3, 3)
 
 
 class SymmPosDef3DInertiaMatrixNet(torch.nn.Module):
@@ -108,9 +114,10 @@ class SymmPosDef3DInertiaMatrixNet(torch.nn.Module):
             target = torch.as_tensor(init_param, dtype=torch.float64).reshape(3, 3) - bias * torch.eye(3, dtype=torch.float64)
             value = _pack_diag_lower(torch.linalg.cholesky(target).to(torch.float32))
         self.l = torch.nn.Parameter(value.clone())
+        self.register_buffer("_place", _placement(_LOWER_PLACEMENT), persistent=False)
 
     def forward(self):
-        L = _lower_triangular(self.l)
+        L = (self._place @ self.l).reshape(3, 3)
         return L @ L.t() + self.spd_3d_inertia_mat_diag_bias * torch.eye(3, device=self.l.device)
 
 
@@ -129,9 +136,10 @@ class CovParameterized3DInertiaMatrixNet(torch.nn.Module):
             cov = 0.5 * torch.trace(inertia) * torch.eye(3, dtype=torch.float64) - inertia
             value = _pack_diag_lower(torch.linalg.cholesky(cov - bias * torch.eye(3, dtype=torch.float64)).to(torch.float32))
         self.l = torch.nn.Parameter(value.clone())
+        self.register_buffer("_place", _placement(_LOWER_PLACEMENT), persistent=False)
 
     def forward(self):
-        L = _lower_triangular(self.l)
+        L = (self._place @ self.l).reshape(3, 3)
         eye = torch.eye(3, device=self.l.device)
         cov = L @ L.t() + self.spd_3d_cov_inertia_mat_diag_bias * eye
         return torch.trace(cov) * eye - cov
