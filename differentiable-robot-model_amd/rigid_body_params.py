@@ -142,7 +142,7 @@ class CovParameterized3DInertiaMatrixNet(torch.nn.Module):
         L = (self._place @ self.l).reshape(3, 3)
         eye = torch.eye(3, device=self.l.device)
         cov = L @ L.t() + self.spd_3d_cov_inertia_mat_diag_bias * eye
-        return torch.trace(cov) * eye - cov
+        return (cov * eye).sum() * eye - cov   # tr(Sigma) E - Sigma (torch.trace's backward is not graph-capturable)
 
 
 def _exp_so3(omega: torch.Tensor) -> torch.Tensor:
