@@ -109,3 +109,26 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
     print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
+# BASELINE.json configs 2 and 3 as stated: iiwa7 FK + EE Jacobian at 65 536; Panda FK(EE) + RNEA on one GPU's shard of
+# the 2^20 batch (131 072 rows), the two calls captured back to back
+mi = load("iiwa7")
+qi = sample(mi, 65536)[0].cuda()
+plan_i = mi.plan_fk_and_jacobian(qi, "iiwa_link_ee")
+us = graph_time(plan_i.launch)
+print("config 2: fk_jacobian iiwa7 B=   65536 %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (us, 65536 * 224 / us / 1e3, 65536 / us / 1e3))
+Bs = (1 << 20) // 8
+qs, qds, qdds = (t.cuda() for t in sample(m, Bs))
+plan_fk = m.plan_fk_and_jacobian(qs, link, want_pose=True)
+idx = m._name_to_idx_map[link]
+df = m._get_walk(("fk", (idx,)), targets=[idx]); off = m._ops_f(df)
+pos_s = torch.empty(Bs, 1, 3, device="cuda"); quat_s = torch.empty(Bs, 1, 4, device="cuda")
+wf = backend._walk_struct(df.program, off, df.ops_i, 7)
+plan_id = m.plan_inverse_dynamics(qs, qds, qdds)
+lib = backend.load_library()
+def fk_then_rnea():
+    backend._check(lib.drm_fk(ctypes.byref(wf), qs.data_ptr(), Bs, 1, pos_s.data_ptr(), quat_s.data_ptr(),
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    plan_id.launch()
+us = graph_time(fk_then_rnea)
+print("config 3: fk + rnea panda B=  %d (one GPU's shard of 2^20) %9.2f us  %7.1f GB/s (168 B/eval, two calls)  %6.2f Gevals/s"
+      % (Bs, us, Bs * 168 / us / 1e3, Bs / us / 1e3))
