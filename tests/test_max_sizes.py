@@ -162,3 +162,63 @@ def test_gpu_long_chain_backward_kernels_vs_emu(emu, tmp_path, n):
     for got, ref in zip(gin, (eq, eqd, eqdd)):
         assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1.0)
     assert np.abs(gops_t.cpu().numpy() - eops).max() <= 5e-4 * max(np.abs(eops).max(), 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRM_FUZZ_SEEDS", "8"))))
+def test_gpu_random_robot_backward_kernels_vs_emu(emu, seed):
+    """K5 (positions of a random set of targets, and the JAC form on a random chain) and K7 on a random shipped robot at a
+    random batch size, random learnable ops, against the host emulation of the same sweeps."""
+    from differentiable_robot_model_amd import backend
+    from helpers import ALL_ROBOTS, load_model
+    rng = np.random.default_rng(4242 + seed)
+    robot = ALL_ROBOTS[int(rng.integers(len(ALL_ROBOTS)))]
+    mc, m = load_model(robot), load_model(robot, "cuda")
+    n, L = mc._n_dofs, len(mc._bodies)
+    B = int(rng.choice([rng.integers(1, 130), rng.integers(130, 1500)]))
+    q, qd, qdd = sample_states(mc, B, seed=seed)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    # ---- K5, several targets
+    T = int(rng.integers(1, min(4, L - 1) + 1))
+    targets = sorted(int(t) for t in rng.choice(np.arange(1, L), size=T, replace=False))
+    prog = build_walk(mc._spec, targets=targets)
+    if prog.slots_unique:
+        walk, _k = host_walk(mc, prog)
+        gpos = rng.standard_normal((B, T, 3)).astype(np.float32)
+        mask = int(rng.integers(0, 1 << prog.n_ops)) & 0xffffffff
+        gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+        assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(mask),
+                                   _ptr(gq), _ptr(gops) if mask else None) == 0
+        dw = m._get_walk(("fk", tuple(targets)), targets=targets)
+        got_q, got_ops = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos), T, n, mask, True)
+        assert np.abs(got_q.cpu().numpy() - gq).max() <= 1e-4 * max(1.0, np.abs(gq).max()), (robot, B, targets)
+        if mask:
+            assert np.abs(got_ops.cpu().numpy() - gops).max() <= 3e-4 * max(np.abs(gops).max(), 1e-6) * max(1.0, B / 256)
+    # ---- K5, JAC form on the chain to a random link
+    link = int(rng.integers(1, L))
+    cprog = build_walk(mc._spec, targets=[link])
+    cwalk, _k2 = host_walk(mc, cprog)
+    gp, gl, ga = (rng.standard_normal(s).astype(np.float32) for s in ((B, 3), (B, 3, n), (B, 3, n)))
+    gq = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_fk_jacobian_backward(ctypes.byref(cwalk), _ptr(q), ctypes.c_int64(B), _ptr(gp), _ptr(gl), _ptr(ga),
+                                        ctypes.c_uint32(0), _ptr(gq), None) == 0
+    dc = m._get_walk(("chain", link), targets=[link])
+    got_q, _ = backend.fk_jacobian_backward(dc.program, m._ops_f(dc), dc.ops_i, dev(q), dev(gp), dev(gl), dev(ga), n, 0, True)
+    assert np.abs(got_q.cpu().numpy() - gq).max() <= 1e-4 * max(1.0, np.abs(gq).max()), (robot, B, link)
+    # ---- K7 over the whole tree
+    tree = build_walk(mc._spec, whole_tree=True)
+    if tree.slots_unique:
+        twalk, _k3 = host_walk(mc, tree)
+        gtau = rng.standard_normal((B, n)).astype(np.float32)
+        tmask = int(rng.integers(0, 1 << min(tree.n_ops, 31)))
+        eq, eqd, eqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+        eops = np.full((tree.capacity, 32), np.nan, np.float32)
+        assert emu.emu_rnea_backward(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
+                                     ctypes.c_uint32(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops) if tmask else None) == 0
+        dt = m._get_walk(("tree",), whole_tree=True)
+        gin, gops_t = backend.rnea_backward(dt.program, m._ops_f(dt), dt.ops_i, dev(q), dev(qd), dev(qdd), dev(gtau), True, True,
+                                            n, tmask, True)
+        for got, ref in zip(gin, (eq, eqd, eqdd)):
+            assert np.abs(got.cpu().numpy() - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1.0), (robot, B)
+        if tmask:
+            assert np.abs(gops_t.cpu().numpy() - eops).max() <= 1e-3 * max(np.abs(eops).max(), 1e-6) * max(1.0, B / 256)
