@@ -85,6 +85,63 @@ _LOWER_PLACEMENT = [(0, 0, 0), (1, 1, 1), (2, 2, 2), (1, 0, 3), (2, 0, 4), (2, 1
 _SYMM_PLACEMENT = _LOWER_PLACEMENT + [(0, 1, 3), (0, 2, 4), (1, 2, 5)]
 
 
+def _placement_q(qdim: int, symmetric: bool) -> torch.Tensor:
+    """[q*q, q(q+1)/2] placement matrix of the batched helpers below: the first q numbers on the diagonal, the rest on the
+    strictly lower triangle in row-major order (numpy.tril_indices(q, -1): (1,0), (2,0), (2,1), ...), mirrored if asked."""
+    n = qdim * (qdim + 1) // 2
+    M = torch.zeros(qdim * qdim, n)
+    for i in range(qdim):
+        M[i * qdim + i, i] = 1.0
+    k = qdim
+    for r in range(1, qdim):
+        for c in range(r):
+            M[r * qdim + c, k] = 1.0
+            if symmetric:
+                M[c * qdim + r, k] = 1.0
+            k += 1
+    return M
+
+
+class SymmMatNet(torch.nn.Module):
+    """Batched symmetric matrices from their diagonal + strictly-lower entries: ``forward(l [B, q(q+1)/2]) -> [B, q, q]``
+    (reference rigid_body_params.py:59-83; same vector layout)."""
+
+    def __init__(self, qdim):
+        super().__init__()
+        self._qdim = int(qdim)
+        self.register_buffer("_place_q", _placement_q(self._qdim, True), persistent=False)
+
+    def forward(self, l):
+        return (l @ self._place_q.t()).reshape(l.shape[0], self._qdim, self._qdim)
+
+
+class CholeskyNet(torch.nn.Module):
+    """Batched symmetric positive (semi-)definite matrices L L^T from the entries of the lower-triangular factor, with a
+    positive bias on the factor's diagonal (reference rigid_body_params.py:86-132; same vector layout and method names)."""
+
+    def __init__(self, qdim, bias):
+        super().__init__()
+        self._qdim, self._bias = int(qdim), bias
+        self.register_buffer("_place_L", _placement_q(self._qdim, False), persistent=False)
+
+    def get_raw_l(self, raw_l_input):
+        return raw_l_input
+
+    def get_l(self, raw_l_input):
+        raw_l = self.get_raw_l(raw_l_input)
+        shift = torch.zeros(raw_l.shape[-1], device=raw_l.device, dtype=raw_l.dtype)
+        shift[: self._qdim] = self._bias
+        return raw_l + shift
+
+    def get_L(self, l):
+        return (l @ self._place_L.t()).reshape(l.shape[0], self._qdim, self._qdim)
+
+    def get_symm_pos_semi_def_matrix_and_l(self, raw_l_input):
+        l = self.get_l(raw_l_input)
+        L = self.get_L(l)
+        return L @ L.transpose(-2, -1), l
+
+
 class Symm3DInertiaMatrixNet(torch.nn.Module):
     """Any symmetric 3x3 matrix: diag(l[:3]) + off-diagonals l[3:] mirrored.  (reference rigid_body_params.py:387-404)"""
 

@@ -703,6 +703,13 @@ class DifferentiableRobotModel(torch.nn.Module):
         return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
                                         bool(use_damping), self._n_dofs)
 
+    def compute_forward_dynamics_old(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
+                                     include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
+                                     ) -> torch.Tensor:
+        """qdd = H^-1 (f - nle) (robot_model.py:452-485; upstream it calls ``torch.solve``, which current torch no longer
+        has).  The same linear system as ``compute_forward_dynamics`` — note the different default of ``use_damping``."""
+        return self.compute_forward_dynamics(q, qd, f, include_gravity=include_gravity, use_damping=use_damping)
+
     # ------------------------------------------------------------------ learnable parameters
     def _get_parent_object_of_param(self, link_name: str, parameter_name: str):
         body_idx = self._name_to_idx_map[link_name]

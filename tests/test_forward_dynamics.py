@@ -247,3 +247,15 @@ def test_gpu_learn_forward_dynamics_loop_lowers_the_loss():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_gpu_forward_dynamics_old_is_the_same_linear_system():
+    """compute_forward_dynamics_old (robot_model.py:452-485, dead upstream: torch.solve) = H^-1 (f - nle), damping on by default."""
+    m = load_model("iiwa7", "cuda")
+    q, qd, f = (torch.from_numpy(a).cuda() for a in sample_states(m, 100, seed=5))
+    old = m.compute_forward_dynamics_old(q, qd, f)
+    assert torch.equal(old, m.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True))
+    H = m.compute_lagrangian_inertia_matrix(q)
+    nle = m.compute_non_linear_effects(q, qd)
+    assert torch.allclose(torch.einsum("bij,bj->bi", H, old) + nle, f, atol=2e-4, rtol=2e-4)
