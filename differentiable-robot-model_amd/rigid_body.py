@@ -111,6 +111,23 @@ class DifferentiableRigidBody(torch.nn.Module):
     def add_child(self, link: "DifferentiableRigidBody"):
         self._children.append(link)
 
+    # The reference advances its per-link Python recursion through these three methods (rigid_body.py:85-165); here the
+    # whole sweep is one kernel launched from the model, so calling them on a single body has no meaning.
+    def _per_link_step(self, name):
+        raise NotImplementedError(
+            "DifferentiableRigidBody.%s is a step of the reference's per-link Python loop; this engine runs the whole sweep in "
+            "one kernel — call compute_forward_kinematics / update_kinematic_state / compute_inverse_dynamics on the model "
+            "(body.pose and body.vel are filled from the last update_kinematic_state)" % name)
+
+    def update_joint_state(self, q, qd):
+        self._per_link_step("update_joint_state")
+
+    def update_joint_acc(self, qdd):
+        self._per_link_step("update_joint_acc")
+
+    def forward_kinematics(self, q_dict):
+        self._per_link_step("forward_kinematics")
+
     def get_joint_limits(self):
         return self.joint_limits
 

@@ -639,6 +639,12 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._require_device()
         return self._inverse_dynamics(q, qd, None, bool(include_gravity), bool(use_damping))
 
+    def iterative_newton_euler(self, base_lin_acc: torch.Tensor, base_ang_acc: torch.Tensor) -> None:
+        """The reference's RNEA sweeps over per-body state written by ``update_kinematic_state`` (robot_model.py:250-303):
+        an internal step of its Python recursion.  Here both sweeps are one kernel behind ``compute_inverse_dynamics``."""
+        raise NotImplementedError("iterative_newton_euler is an internal step of the reference's per-link recursion; "
+                                  "call compute_inverse_dynamics / compute_non_linear_effects")
+
     def _learnable_op_mask(self, dw) -> int:
         """Bit k set <=> op k of the walk belongs to a link with a learnable parameter (param_mask of the backward kernels)."""
         links = {link for link, _ in self._learnable}
