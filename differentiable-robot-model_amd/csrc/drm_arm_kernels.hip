@@ -21,14 +21,17 @@ namespace drm {
 //     HIPFLAGS in the Makefile), so the constant and q-tile loads are issued in the wave's first cycles;
 //   * no runtime shape flags: one basic block from the loads to the stores; pos / lin_jac / ang_jac are staged in
 //     separate LDS regions, so there is one LDS turnaround before the 16-byte stores go out back to back.
-// With one wave per SIMD (batch 65 536) a launch lasts launch floor + issue time + store drain (nothing
-// overlaps, tools/ubench/io_floor.hip), so instruction count is what this kernel minimises.
-// The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
+//   * outputs are written THROUGH the L2 (store16_wt, drm_common.hpp) in the order they become final, so the 12.8 MB
+//     of a 65 536-sample launch drain while the chain is still being walked instead of after the last wave.
+// With one wave per SIMD (batch 65 536) a launch lasts launch floor + load + issue time + what is left of the store
+// drain after the last store (tools/ubench/metric_lab.hip), so instruction count and the time of the FIRST store are
+// what this kernel minimises.  The launcher sends a ragged tail (B % 64 rows) through the generic kernel.
+// WPB = waves per block, a packing choice (waves are independent): single-wave blocks let a CU hold four waves per
+// SIMD (a 4-wave block's 54 KB of LDS stops at three) — 3.90 -> 3.85 us at 65 536 samples, 33.3 -> 31.0 us at 2^20;
+// the NT form (outputs larger than the Infinity Cache) dispatches fewer, larger blocks.
 // ---------------------------------------------------------------------------------------------------
-// waves per block of the arm kernels: a packing choice (waves are independent); 1, 2 and 4 measure the same
-#define DRM_ARM_WPB MAX_WAVES_PER_BLOCK
-template <int CAP, int NJ, bool JAC>
-__global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
+template <int CAP, int NJ, bool JAC, int WPB, bool NT>
+__global__ void __launch_bounds__(WAVE *WPB)
     fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
                            float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
                            float *__restrict__ ang) {
@@ -42,9 +45,9 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
     // pos is staged over the q tile (q lives in registers by then): 51.7 KB per block, three blocks per CU
     static_assert(P_FLOATS <= Q_FLOATS, "pos staging overlays the q tile");
     constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + (JAC ? 2 * J_FLOATS : 0);
-    __shared__ __attribute__((aligned(16))) float smem[DRM_ARM_WPB * PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = (int)blockIdx.x * DRM_ARM_WPB + wave;
+    const int tile = (int)blockIdx.x * WPB + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
                 arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0];
             }
             wave_lds_sync();
-            tile_store<SJ>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
+            tile_store<SJ, NT>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
         }
     });
 
@@ -96,15 +99,15 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
         lp[lane * 3 + 1] = pe[1];
         lp[lane * 3 + 2] = pe[2];
         wave_lds_sync();
-        tile_store<SJ>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
-        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+        tile_store<SJ, NT>(lin + b0 * SJ, WAVE, SJ, 0u, ll, lane, true);
+        tile_store<3, NT>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
     } else {
         wave_lds_sync(); // every lane has read its q row before pos is staged over the q tile
         lp[lane * 3 + 0] = pe[0];
         lp[lane * 3 + 1] = pe[1];
         lp[lane * 3 + 2] = pe[2];
         wave_lds_sync();
-        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+        tile_store<3, NT>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
     }
     // quat [B,4]: one 16-byte store per lane is already coalesced.  The target of an arm-shaped walk that ends in
     // a fixed link (or a z joint) stores its frame un-permuted (DRM_OPI_PERM code 2, checked by the launcher).
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(WAVE *DRM_ARM_WPB)
         float qt[4];
         pose_from_pairs(ee, E);
         quat_xyzw(E.R, qt);
-        *reinterpret_cast<float4 *>(quat + (b0 + lane) * 4) = make_float4(qt[0], qt[1], qt[2], qt[3]);
+        store16_wt<NT>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
     }
 }
 
@@ -129,10 +132,8 @@ int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, 
           B / WAVE < 0x7fffffffLL))
         return 0;
     const int n_tiles = (int)(B / WAVE);
-    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, false>),
-                       dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
-                       dim3(WAVE * DRM_ARM_WPB), 0, s, w->ops_f, q, n_tiles, pos, quat, (float *)nullptr,
-                       (float *)nullptr);
+    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, false, 1, false>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, q,
+                       n_tiles, pos, quat, (float *)nullptr, (float *)nullptr);
     return (int64_t)n_tiles * WAVE;
 #endif
 }
@@ -140,8 +141,14 @@ int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, 
 
 void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, float *pos, float *quat, float *lin_jac,
                             float *ang_jac, hipStream_t s) {
-    hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true>), dim3((unsigned)((n_tiles + DRM_ARM_WPB - 1) / DRM_ARM_WPB)),
-                       dim3(WAVE * DRM_ARM_WPB), 0, s, ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+    if (stream_past_llc((int64_t)n_tiles * WAVE * 4 * (7 + 6 * 7))) {
+        constexpr int WPB = MAX_WAVES_PER_BLOCK;
+        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, WPB, true>), dim3((unsigned)((n_tiles + WPB - 1) / WPB)),
+                           dim3(WAVE * WPB), 0, s, ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+    } else {
+        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, 1, false>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, ops_f, q,
+                           n_tiles, pos, quat, lin_jac, ang_jac);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

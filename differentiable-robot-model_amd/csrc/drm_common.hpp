@@ -38,6 +38,29 @@ __device__ __forceinline__ void wave_lds_sync() {
 // predicated block that consumes it (which would serialise load -> wait -> store per iteration)
 __device__ __forceinline__ void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
+// 16-byte store of an OUTPUT tensor that writes THROUGH the XCD's L2 (`sc1`).  A plain store leaves its line dirty in the
+// L2 and the end-of-kernel release then writes all of them back at once, serialised behind the last wave: 12.8 MB of
+// Jacobians cost ~1.8 us there.  Written through, the bytes leave while the other waves (and this wave's later links)
+// still compute and the release finds nothing to do: the metric launch (Panda, 65 536 samples) went 4.83 -> 3.92 us, a
+// launch that only moves its bytes 3.67 -> 2.90 us (tools/ubench/metric_lab.hip, profiles/r02_metric_lab.txt); `nt`
+// alone does not do it.  Outputs are never re-read by the kernel that wrote them, so dropping the line from the L2
+// costs nothing.
+// NT adds `nt`: the line is not kept in the 256 MiB Infinity Cache either.  That is right for outputs that are larger
+// than the cache (they would only evict each other: 2^22 samples 159 -> 130 us = 7.2 TB/s) and wrong for outputs that fit
+// (2^20 samples: 33 -> 35 us, and the consumer of a 200 MB result finds it on die), so the launchers choose by size
+// (stream_past_llc below).
+// (Inline asm: there is no builtin for a 16-byte store with cache-policy bits on a flat pointer.  The store reads its
+// data registers for one more state, hence the s_nop inside the statement — cdna_hip_programming.md §5.7.)
+typedef float drm_v4f __attribute__((ext_vector_type(4)));
+template <bool NT = false>
+__device__ __forceinline__ void store16_wt(void *p, float4 v) {
+    const drm_v4f x = {v.x, v.y, v.z, v.w};
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+// outputs of a launch that exceed the Infinity Cache are streamed past it
+static inline bool stream_past_llc(int64_t output_bytes) { return output_bytes > (int64_t)256 * 1024 * 1024; }
+
 // Touch the first `LINES` 64-byte lines of every op of the walk table with scalar loads issued
 // back to back, so the (cold) misses overlap in ONE latency round instead of one per op.
 // Split in two so the kernel can put the q tile's global loads between issue and wait.
@@ -127,18 +150,17 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ g, int rows,
 }
 
 // ---- LDS -> HBM, same conventions ---------------------------------------------------
-template <int S_CT>
+template <int S_CT, bool NT = false>
 __device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int S_rt, uint32_t magic, const float *lds,
                                            unsigned lane, bool fast, bool vec = false) {
     const int S = S_CT ? S_CT : S_rt;
     if (!fast && vec && !(S & 1)) {
         float4 *g4 = reinterpret_cast<float4 *>(g);
         const unsigned nvec = 16u * (unsigned)S;
-#pragma unroll 2
-        for (unsigned i = lane; i < nvec; i += 64u) {
+        for (unsigned i = lane; i < nvec; i += 64u) { // (a loop with an asm statement is not unrolled by hipcc)
             const unsigned w = 4u * i;
-            g4[i] = make_float4(lds[lds_word(w, true, magic)], lds[lds_word(w + 1u, true, magic)],
-                                lds[lds_word(w + 2u, true, magic)], lds[lds_word(w + 3u, true, magic)]);
+            store16_wt<NT>(g4 + i, make_float4(lds[lds_word(w, true, magic)], lds[lds_word(w + 1u, true, magic)],
+                                           lds[lds_word(w + 2u, true, magic)], lds[lds_word(w + 3u, true, magic)]));
         }
         return;
     }
@@ -157,11 +179,10 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int 
 #pragma unroll
             for (unsigned it = 0; it < IT; ++it) {
                 const unsigned i = lane + 64u * it;
-                if ((it + 1u) * 64u <= nvec || i < nvec) *reinterpret_cast<float4 *>(gb + i * 16u) = v[it];
+                if ((it + 1u) * 64u <= nvec || i < nvec) store16_wt<NT>(gb + i * 16u, v[it]);
             }
         } else {
-#pragma unroll 2
-            for (unsigned i = lane; i < nvec; i += 64u) *reinterpret_cast<float4 *>(gb + i * 16u) = l4[i];
+            for (unsigned i = lane; i < nvec; i += 64u) store16_wt<NT>(gb + i * 16u, l4[i]);
         }
     } else {
         const unsigned total = (unsigned)(rows * S);

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         quat_xyzw(Ru, qt);
         float *dst = quat + (cx.b0 + lane) * 4;
         if (align & AL_QUAT) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(qt[0], qt[1], qt[2], qt[3]);
+            store16_wt(dst, make_float4(qt[0], qt[1], qt[2], qt[3]));
         } else {
             dst[0] = qt[0]; dst[1] = qt[1]; dst[2] = qt[2]; dst[3] = qt[3];
         }

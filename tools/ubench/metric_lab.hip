@@ -1,0 +1,617 @@
+// metric_lab.hip — stand-alone A/B bench of variants of the metric kernel (FK + Jacobian, Franka Panda, B = 65 536)
+// on the real walk table, outside torch: every variant is checked against the product kernel's outputs, timed as a
+// replayed hipGraph of K launches (what bench.py does), and the interesting ones are run once more with s_memtime
+// stamps so that a launch can be split into  launch floor | load | compute | store issue | store drain.
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -mllvm -amdgpu-kernarg-preload-count=16 \
+//         -o tools/ubench/metric_lab tools/ubench/metric_lab.hip
+//
+// Variants
+//   ref            the product kernel (drm_arm_kernels.hip), one lane per sample, one wave per SIMD at this batch
+//   lane<FLAVOR>   the same kernel with nt / sc1 / sc0 sc1 stores (does a write-through drain start earlier?)
+//   quad<...>      four lanes per sample: lanes 0..2 of a quad own one ROW of the pose (the rows evolve independently),
+//                  sin/cos split over the quad, cross-row terms through DPP quad_perm; 4 waves per SIMD
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../differentiable-robot-model_amd/csrc/drm_arm_kernels.hip"
+#include "panda_walk.h"
+
+using namespace drm;
+
+// ---------------------------------------------------------------------------------------------------------------
+// store flavours
+// ---------------------------------------------------------------------------------------------------------------
+enum { ST_PLAIN = 0, ST_NT = 1, ST_SC1 = 2, ST_SC0SC1 = 3, ST_SC1NT = 4 };
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int FL>
+__device__ __forceinline__ void store16(float *p, float4 v4) {
+    const v4f v = {v4.x, v4.y, v4.z, v4.w};
+    if constexpr (FL == ST_PLAIN) {
+        *reinterpret_cast<float4 *>(p) = v4;
+    } else if constexpr (FL == ST_NT) {
+        asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (FL == ST_SC1) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (FL == ST_SC1NT) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+template <int FL>
+__device__ __forceinline__ void store4(float *p, float v) {
+    if constexpr (FL == ST_PLAIN) {
+        *p = v;
+    } else if constexpr (FL == ST_NT) {
+        asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (FL == ST_SC1) {
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+// LDS -> HBM of a linear image of N16 float4s (N16 compile-time), 16 B per lane and round
+template <int FL, int N16>
+__device__ __forceinline__ void image_store(float *g, const float *lds, unsigned lane) {
+    constexpr unsigned IT = (N16 + 63) / 64;
+    float4 v[IT];
+#pragma unroll
+    for (unsigned it = 0; it < IT; ++it) {
+        const unsigned i = lane + 64u * it;
+        v[it] = reinterpret_cast<const float4 *>(lds)[i < (unsigned)N16 ? i : N16 - 1u];
+    }
+#pragma unroll
+    for (unsigned it = 0; it < IT; ++it) {
+        const unsigned i = lane + 64u * it;
+        if ((it + 1u) * 64u <= (unsigned)N16 || i < (unsigned)N16) store16<FL>(g + 4u * i, v[it]);
+    }
+}
+
+__device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
+struct Stamp { // per wave, TIMELINE variants only
+    uint64_t t[6];
+    uint32_t hw_id, xcc_id;
+};
+__device__ __forceinline__ void stamp_ids(Stamp *s) {
+    s->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    s->xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lane-per-sample kernel = the product kernel with a store flavour and optional time stamps
+// ---------------------------------------------------------------------------------------------------------------
+template <int FL, bool TL, int WPB = 4, bool ANG_LATE = false>
+__global__ void __launch_bounds__(64 * WPB) fkj_lane_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                       int n_tiles, float *__restrict__ pos, float *__restrict__ quat,
+                                                       float *__restrict__ lin, float *__restrict__ ang, Stamp *tl) {
+    constexpr int CAP = 8, NJ = 7, SQ = NJ, SJ = 3 * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * SQ), J_FLOATS = round4(WAVE * SJ);
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + 2 * J_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (TL) t0 = now();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * WPB + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    float qv[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+    if (TL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = now(); }
+    PoseP ee;
+    f2 Bk[NJ][3];
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+        float *arow = la + lane * SJ;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) { arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0]; }
+        wave_lds_sync();
+        if (TL) t2 = now();
+        if (!ANG_LATE) image_store<FL, 16 * SJ>(ang + b0 * SJ, la, lane);
+    });
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    float *lrow = ll + lane * SJ;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+        const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+        float c[3];
+        cross3(z, dp, c);
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+    }
+    lp[lane * 3 + 0] = pe[0]; lp[lane * 3 + 1] = pe[1]; lp[lane * 3 + 2] = pe[2];
+    wave_lds_sync();
+    image_store<FL, 16 * SJ>(lin + b0 * SJ, ll, lane);
+    image_store<FL, 48>(pos + b0 * 3, lp, lane);
+    if (ANG_LATE) image_store<FL, 16 * SJ>(ang + b0 * SJ, la, lane);
+    {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        store16<FL>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+    }
+    if (TL) {
+        t3 = now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t4 = now();
+        if (lane == 0) {
+            Stamp *s = tl + tile;
+            s->t[0] = t0; s->t[1] = t1; s->t[2] = t2; s->t[3] = t3; s->t[4] = t4; s->t[5] = 0;
+            stamp_ids(s);
+        }
+    }
+}
+
+
+// lane kernel v2: the end position first (B pairs of the trailing fixed link), Jacobians staged together and stored
+// back to back, the end ORIENTATION (only the quaternion needs it) afterwards
+template <int FL, int WPB>
+__global__ void __launch_bounds__(64 * WPB) fkj_lane2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                       int n_tiles, float *__restrict__ pos, float *__restrict__ quat,
+                                                       float *__restrict__ lin, float *__restrict__ ang) {
+    constexpr int CAP = 8, NJ = 7, SQ = NJ, SJ = 3 * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * SQ), J_FLOATS = round4(WAVE * SJ);
+    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + 2 * J_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * WPB + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    float qv[NJ];
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+    PoseP P7;
+    f2 Bk[NJ][3];
+    fk_chain_pairs<NJ, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, P7, Bk, [&]() {});
+    // trailing fixed link, position part only
+    const OpPairs o = load_pairs(lc + NJ * DRM_OPF_STRIDE);
+    f2 Be[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const f2 r0 = f2_bcast(P7.A[c][0]), r1 = f2_bcast(P7.A[c][1]), r2 = f2_bcast(P7.B[c][0]);
+        f2 bb = r0 * o.f2t[0] + r1 * o.f2t[1] + r2 * o.f2t[2];
+        bb[1] += P7.B[c][1];
+        Be[c] = bb;
+    }
+    const float pe[3] = {Be[0][1], Be[1][1], Be[2][1]};
+    float *arow = la + lane * SJ, *lrow = ll + lane * SJ;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+        const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+        float c[3];
+        cross3(z, dp, c);
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        arow[k] = z[0]; arow[NJ + k] = z[1]; arow[2 * NJ + k] = z[2];
+        lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+    }
+    lp[lane * 3 + 0] = pe[0]; lp[lane * 3 + 1] = pe[1]; lp[lane * 3 + 2] = pe[2];
+    wave_lds_sync();
+    image_store<FL, 16 * SJ>(ang + b0 * SJ, la, lane);
+    image_store<FL, 16 * SJ>(lin + b0 * SJ, ll, lane);
+    image_store<FL, 48>(pos + b0 * 3, lp, lane);
+    {
+        PoseP ee;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f2 r0 = f2_bcast(P7.A[c][0]), r1 = f2_bcast(P7.A[c][1]), r2 = f2_bcast(P7.B[c][0]);
+            ee.A[c] = r0 * o.f01[0] + r1 * o.f01[1] + r2 * o.f01[2];
+            ee.B[c] = Be[c];
+        }
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        store16<FL>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// quad kernel: four lanes per sample
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { // quad_perm move (all rows / banks, lanes always in range)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+constexpr int QP_NEXT1 = QP(1, 2, 0, 3), QP_NEXT2 = QP(2, 0, 1, 3);
+
+template <int FL, int WPB, bool PRIO, bool TL>
+__global__ void __launch_bounds__(64 * WPB) fkj_quad_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                            int n_groups, float *__restrict__ pos,
+                                                            float *__restrict__ quat, float *__restrict__ lin,
+                                                            float *__restrict__ ang, Stamp *tl) {
+    constexpr int CAP = 8, NJ = 7, SJ = 3 * NJ, G = 16; // samples per wave
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, J_FLOATS = G * SJ; // 336 floats = 84 float4
+    constexpr int PER_WAVE = C_FLOATS + 2 * J_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (TL) t0 = now();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int grp = (int)blockIdx.x * WPB + wave;
+    if (grp >= n_groups) return;
+    if (PRIO) { // waves w, w+4, w+8, w+12 of a 16-wave block share a SIMD: the earlier ones finish (and store) first
+        const int p = WPB == 16 ? 3 - (wave >> 2) : 3 - (int)((blockIdx.x >> 8) & 3u);
+        if (p == 3) __builtin_amdgcn_s_setprio(3);
+        else if (p == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    }
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned s = lane >> 2, c = lane & 3u;
+    float *lc = smem + wave * PER_WAVE;
+    float *ll = lc + C_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)grp * G;
+
+    // loads: the 1 KB constant table (16 B per lane) and the two joint angles this lane evaluates (c, c + 4)
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    const float *qrow = q + (b0 + s) * NJ;
+    const float qa = qrow[c], qb = qrow[c < 3 ? c + 4 : 3];
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+
+    // sin / cos: lane c of the quad does joints c and c + 4, the quad exchanges them through DPP
+    f2 s2, c2;
+    {
+        const bool big = !(fabsf(qa) <= SINCOS_PAIR_MAX_ARG) || !(fabsf(qb) <= SINCOS_PAIR_MAX_ARG);
+        if (DRM_WAVE_ANY(big)) {
+            float sa, ca, sb, cb;
+            sincos_f(qa, sa, ca);
+            sincos_f(qb, sb, cb);
+            s2 = f2_make(sa, sb); c2 = f2_make(ca, cb);
+        } else {
+            sincos_pair(f2_make(qa, qb), s2, c2);
+        }
+    }
+    if (TL) t1 = now();
+    float cs[NJ], sn[NJ];
+    {
+        const float s_lo = s2[0], s_hi = s2[1], c_lo = c2[0], c_hi = c2[1];
+        cs[0] = dpp<QP(0, 0, 0, 0)>(c_lo); sn[0] = dpp<QP(0, 0, 0, 0)>(s_lo);
+        cs[1] = dpp<QP(1, 1, 1, 1)>(c_lo); sn[1] = dpp<QP(1, 1, 1, 1)>(s_lo);
+        cs[2] = dpp<QP(2, 2, 2, 2)>(c_lo); sn[2] = dpp<QP(2, 2, 2, 2)>(s_lo);
+        cs[3] = dpp<QP(3, 3, 3, 3)>(c_lo); sn[3] = dpp<QP(3, 3, 3, 3)>(s_lo);
+        cs[4] = dpp<QP(0, 0, 0, 0)>(c_hi); sn[4] = dpp<QP(0, 0, 0, 0)>(s_hi);
+        cs[5] = dpp<QP(1, 1, 1, 1)>(c_hi); sn[5] = dpp<QP(1, 1, 1, 1)>(s_hi);
+        cs[6] = dpp<QP(2, 2, 2, 2)>(c_hi); sn[6] = dpp<QP(2, 2, 2, 2)>(s_hi);
+    }
+
+    // the chain on ONE row per lane: A = (R_c0, R_c1), B = (R_c2, p_c); lane 3 of the quad carries row 0 again
+    f2 A = f2_make(c == 0u || c == 3u ? 1.0f : 0.0f, c == 1u ? 1.0f : 0.0f), Bv = f2_make(c == 2u ? 1.0f : 0.0f, 0.0f);
+    float zk[NJ], pk[NJ];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
+        const f2 r0 = f2_bcast(A[0]), r1 = f2_bcast(A[1]), r2 = f2_bcast(Bv[0]);
+        f2 nA = r0 * o.f01[0] + r1 * o.f01[1] + r2 * o.f01[2];
+        f2 nB = r0 * o.f2t[0] + r1 * o.f2t[1] + r2 * o.f2t[2];
+        nB[1] += Bv[1];
+        if (k < NJ) nA = nA * f2_bcast(cs[k]) + f2_make(nA[1], nA[0]) * f2_make(sn[k], -sn[k]);
+        A = nA; Bv = nB;
+        if (k < NJ) { zk[k] = Bv[0]; pk[k] = Bv[1]; }
+        if (k == NJ - 1) { // angular Jacobian rows are final: stage and store them while the fixed tail is composed
+            if (c < 3u) {
+                float *arow = la + s * SJ + c * NJ;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) arow[j] = zk[j];
+            }
+            wave_lds_sync();
+            if (TL) t2 = now();
+            image_store<FL, 84>(ang + b0 * SJ, la, lane);
+        }
+    }
+    const float pe = Bv[1];
+    // linear Jacobian: row c of z_k x (p_e - p_k) = z_(c+1) d_(c+2) - z_(c+2) d_(c+1)   (robot_model.py:661)
+    {
+        float lrow[NJ];
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const float d = pe - pk[k];
+            const float z1 = dpp<QP_NEXT1>(zk[k]), z2 = dpp<QP_NEXT2>(zk[k]);
+            const float d1 = dpp<QP_NEXT1>(d), d2 = dpp<QP_NEXT2>(d);
+            lrow[k] = z1 * d2 - z2 * d1;
+        }
+        if (c < 3u) {
+            float *lr = ll + s * SJ + c * NJ;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) lr[k] = lrow[k];
+        }
+    }
+    wave_lds_sync();
+    image_store<FL, 84>(lin + b0 * SJ, ll, lane);
+    if (c < 3u) store4<FL>(pos + (b0 + s) * 3 + c, pe);
+    // quaternion: every lane of the quad gathers R and keeps component c
+    {
+        float R[9];
+        const float a0 = A[0], a1 = A[1], b0v = Bv[0];
+        R[0] = dpp<QP(0, 0, 0, 0)>(a0); R[1] = dpp<QP(0, 0, 0, 0)>(a1); R[2] = dpp<QP(0, 0, 0, 0)>(b0v);
+        R[3] = dpp<QP(1, 1, 1, 1)>(a0); R[4] = dpp<QP(1, 1, 1, 1)>(a1); R[5] = dpp<QP(1, 1, 1, 1)>(b0v);
+        R[6] = dpp<QP(2, 2, 2, 2)>(a0); R[7] = dpp<QP(2, 2, 2, 2)>(a1); R[8] = dpp<QP(2, 2, 2, 2)>(b0v);
+        float qt[4];
+        quat_xyzw(R, qt);
+        const float mine = c == 0u ? qt[0] : (c == 1u ? qt[1] : (c == 2u ? qt[2] : qt[3]));
+        store4<FL>(quat + b0 * 4 + lane, mine);
+    }
+    if (TL) {
+        t3 = now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t4 = now();
+        if (lane == 0) {
+            Stamp *st = tl + grp;
+            st->t[0] = t0; st->t[1] = t1; st->t[2] = t2; st->t[3] = t3; st->t[4] = t4; st->t[5] = 0;
+            stamp_ids(st);
+        }
+    }
+}
+
+// bytes only: the loads and the stores of the lane kernel, nothing else
+template <int FL, bool RD, bool WR>
+__global__ void __launch_bounds__(256) k_io(const float *__restrict__ q, int n_tiles, float *__restrict__ pos,
+                                            float *__restrict__ quat, float *__restrict__ lin, float *__restrict__ ang) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    if (RD) {
+        const float4 *q4 = reinterpret_cast<const float4 *>(q + (size_t)tile * 448);
+        float4 a = q4[lane], b = q4[lane < 48 ? 64 + lane : 111];
+        v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (!WR) { if (v.x == 12345.678f) reinterpret_cast<float4 *>(quat)[lane] = v; return; }
+    float *p4 = pos + (size_t)tile * 192, *r4 = quat + (size_t)tile * 256, *l4 = lin + (size_t)tile * 1344, *a4 = ang + (size_t)tile * 1344;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) store16<FL>(a4 + 4 * (lane + 64 * i), v);
+    if (lane < 16) store16<FL>(a4 + 4 * (lane + 320), v);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) store16<FL>(l4 + 4 * (lane + 64 * i), v);
+    if (lane < 16) store16<FL>(l4 + 4 * (lane + 320), v);
+    if (lane < 48) store16<FL>(p4 + 4 * lane, v);
+    store16<FL>(r4 + 4 * lane, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch-floor probes
+// ---------------------------------------------------------------------------------------------------------------
+template <int THREADS, int LDS_FLOATS>
+__global__ void __launch_bounds__(THREADS) k_empty(float *out) {
+    if constexpr (LDS_FLOATS > 0) {
+        __shared__ float sm[LDS_FLOATS];
+        sm[threadIdx.x] = 1.0f;
+        if (sm[(threadIdx.x + 1) % THREADS] == 12345.0f) out[0] = 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } \
+    } while (0)
+
+struct Buffers {
+    int B;
+    float *ops_f, *q, *pos, *quat, *lin, *ang;
+    Stamp *tl;
+};
+
+template <class F>
+static void time_graph(const char *name, F launch, hipStream_t s, int K = 200) {
+    for (int i = 0; i < 10; ++i) launch();
+    CK(hipStreamSynchronize(s));
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < K; ++i) launch();
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> us;
+    for (int rep = 0; rep < 9; ++rep) {
+        CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us.push_back(ms * 1e3f / K);
+    }
+    std::sort(us.begin(), us.end());
+    printf("TIME %-44s min %6.3f  med %6.3f  max %6.3f us/launch\n", name, us.front(), us[us.size() / 2], us.back());
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+}
+
+struct Host { std::vector<float> pos, quat, lin, ang; };
+static Host fetch(const Buffers &b) {
+    Host h;
+    h.pos.resize((size_t)b.B * 3); h.quat.resize((size_t)b.B * 4); h.lin.resize((size_t)b.B * 21); h.ang.resize((size_t)b.B * 21);
+    CK(hipMemcpy(h.pos.data(), b.pos, h.pos.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h.quat.data(), b.quat, h.quat.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h.lin.data(), b.lin, h.lin.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h.ang.data(), b.ang, h.ang.size() * 4, hipMemcpyDeviceToHost));
+    return h;
+}
+static void clear(const Buffers &b) {
+    CK(hipMemset(b.pos, 0xff, (size_t)b.B * 12)); CK(hipMemset(b.quat, 0xff, (size_t)b.B * 16));
+    CK(hipMemset(b.lin, 0xff, (size_t)b.B * 84)); CK(hipMemset(b.ang, 0xff, (size_t)b.B * 84));
+}
+static double maxdiff(const std::vector<float> &a, const std::vector<float> &b) {
+    double m = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        double d = fabs((double)a[i] - (double)b[i]);
+        if (!(d <= m)) m = d; // NaN-propagating
+    }
+    return m;
+}
+static void check(const char *name, const Host &ref, const Host &h) {
+    // quaternions up to the global sign
+    double mq = 0; long flips = 0;
+    for (size_t i = 0; i < ref.quat.size(); i += 4) {
+        double dot = 0;
+        for (int j = 0; j < 4; ++j) dot += (double)ref.quat[i + j] * h.quat[i + j];
+        const double sg = dot < 0 ? -1.0 : 1.0;
+        flips += dot < 0;
+        for (int j = 0; j < 4; ++j) { double d = fabs(ref.quat[i + j] - sg * h.quat[i + j]); if (!(d <= mq)) mq = d; }
+    }
+    printf("CHECK %-43s pos %.2e quat %.2e (%ld sign flips) lin %.2e ang %.2e\n", name, maxdiff(ref.pos, h.pos), mq, flips,
+           maxdiff(ref.lin, h.lin), maxdiff(ref.ang, h.ang));
+}
+
+static void timeline(const char *name, const Buffers &b, int n_waves, double total_us) {
+    std::vector<Stamp> st(n_waves);
+    CK(hipMemcpy(st.data(), b.tl, sizeof(Stamp) * n_waves, hipMemcpyDeviceToHost));
+    // clocks are per XCD: normalise inside each XCC
+    for (int x = 0; x < 8; ++x) {
+        uint64_t tmin = ~0ull, tmax = 0; int n = 0;
+        double ph[5] = {0, 0, 0, 0, 0}, phmax[5] = {0, 0, 0, 0, 0}, start_sum = 0, start_max = 0, end_first = 1e30;
+        for (auto &w : st) {
+            if ((int)(w.xcc_id & 0xf) != x) continue;
+            tmin = std::min(tmin, w.t[0]); tmax = std::max(tmax, w.t[4]);
+        }
+        for (auto &w : st) {
+            if ((int)(w.xcc_id & 0xf) != x) continue;
+            ++n;
+            for (int i = 0; i < 4; ++i) { double d = (double)(w.t[i + 1] - w.t[i]); ph[i] += d; phmax[i] = std::max(phmax[i], d); }
+            const double so = (double)(w.t[0] - tmin);
+            start_sum += so; start_max = std::max(start_max, so);
+            end_first = std::min(end_first, (double)(w.t[4] - tmin));
+        }
+        if (!n) continue;
+        if (x == 0 || x == 5)
+            printf("TL %-28s xcc %d waves %4d | span %7.0f ticks | start avg %6.0f max %6.0f | load %6.0f (%6.0f) chain %6.0f (%6.0f) "
+                   "rest+issue %6.0f (%6.0f) drain %6.0f (%6.0f) | first wave done at %6.0f\n",
+                   name, x, n, (double)(tmax - tmin), start_sum / n, start_max, ph[0] / n, phmax[0], ph[1] / n, phmax[1], ph[2] / n,
+                   phmax[2], ph[3] / n, phmax[3], end_first);
+    }
+    (void)total_us;
+}
+
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 65536;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    Buffers b; b.B = B;
+    CK(hipMalloc(&b.ops_f, sizeof(PANDA_OPS_F))); CK(hipMemcpy(b.ops_f, PANDA_OPS_F, sizeof(PANDA_OPS_F), hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.q, (size_t)B * 28)); CK(hipMalloc(&b.pos, (size_t)B * 12)); CK(hipMalloc(&b.quat, (size_t)B * 16));
+    CK(hipMalloc(&b.lin, (size_t)B * 84)); CK(hipMalloc(&b.ang, (size_t)B * 84)); CK(hipMalloc(&b.tl, sizeof(Stamp) * (B / 16)));
+    {
+        std::vector<float> hq((size_t)B * 7);
+        uint64_t x = 88172645463325252ull;
+        for (size_t i = 0; i < hq.size(); ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const double u = (double)(x >> 11) / 9007199254740992.0;
+            hq[i] = (float)(PANDA_LO[i % 7] + (PANDA_HI[i % 7] - PANDA_LO[i % 7]) * u);
+        }
+        CK(hipMemcpy(b.q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int n_tiles = B / 64, n_groups = B / 16;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs, clock %d kHz, B = %d\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, B);
+
+    // ---- launch floors
+    float *dummy; CK(hipMalloc(&dummy, 4096));
+    time_graph("empty 256 blocks x 256", [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(256), dim3(256), 0, s, dummy); }, s);
+    time_graph("empty 1024 blocks x 256", [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(1024), dim3(256), 0, s, dummy); }, s);
+    time_graph("empty 256 blocks x 1024", [&] { hipLaunchKernelGGL((k_empty<1024, 0>), dim3(256), dim3(1024), 0, s, dummy); }, s);
+    time_graph("empty 1 block x 64", [&] { hipLaunchKernelGGL((k_empty<64, 0>), dim3(1), dim3(64), 0, s, dummy); }, s);
+    time_graph("empty 256 x 256, 52 KB LDS", [&] { hipLaunchKernelGGL((k_empty<256, 13000>), dim3(256), dim3(256), 0, s, dummy); }, s);
+
+    // ---- reference = product kernel
+    auto ref_launch = [&] { launch_fk_jacobian_arm(b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang, s); };
+    clear(b); ref_launch(); CK(hipStreamSynchronize(s));
+    const Host ref = fetch(b);
+    time_graph("ref (product kernel)", ref_launch, s);
+
+#define LANE(FL, NAME)                                                                                                   \
+    {                                                                                                                    \
+        auto l = [&] { hipLaunchKernelGGL((fkj_lane_kernel<FL, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.ops_f, b.q, n_tiles, \
+                                          b.pos, b.quat, b.lin, b.ang, b.tl); };                                        \
+        clear(b); l(); CK(hipStreamSynchronize(s)); check(NAME, ref, fetch(b));                                          \
+        time_graph(NAME, l, s);                                                                                          \
+    }
+    LANE(ST_PLAIN, "lane plain")
+    LANE(ST_SC1, "lane sc1")
+#define LANEX(FL, WPB, LATE, NAME)                                                                                       \
+    {                                                                                                                    \
+        auto l = [&] { hipLaunchKernelGGL((fkj_lane_kernel<FL, false, WPB, LATE>), dim3((n_tiles + WPB - 1) / WPB), dim3(64 * WPB), 0, s, \
+                                          b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang, b.tl); };                 \
+        clear(b); l(); CK(hipStreamSynchronize(s)); check(NAME, ref, fetch(b));                                          \
+        time_graph(NAME, l, s);                                                                                          \
+    }
+    LANEX(ST_SC1, 1, false, "lane sc1 wpb1")
+    LANEX(ST_SC1NT, 4, false, "lane sc1nt wpb4")
+    LANEX(ST_SC1NT, 1, false, "lane sc1nt wpb1")
+#define LANE2(FL, WPB, NAME)                                                                                             \
+    {                                                                                                                    \
+        auto l = [&] { hipLaunchKernelGGL((fkj_lane2_kernel<FL, WPB>), dim3((n_tiles + WPB - 1) / WPB), dim3(64 * WPB), 0, s,    \
+                                          b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang); };                       \
+        clear(b); l(); CK(hipStreamSynchronize(s)); check(NAME, ref, fetch(b));                                          \
+        time_graph(NAME, l, s);                                                                                          \
+    }
+    LANE2(ST_SC1, 4, "lane2 sc1 wpb4")
+    LANE2(ST_SC1, 1, "lane2 sc1 wpb1")
+    LANE2(ST_SC1NT, 4, "lane2 sc1nt wpb4")
+    LANE2(ST_SC1NT, 1, "lane2 sc1nt wpb1")
+    LANE2(ST_PLAIN, 4, "lane2 plain wpb4")
+#define IO(FL, RD, WR, NAME) time_graph(NAME, [&] { hipLaunchKernelGGL((k_io<FL, RD, WR>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang); }, s);
+    IO(ST_PLAIN, true, true, "io plain rd+wr")
+    IO(ST_SC1, true, true, "io sc1 rd+wr")
+    IO(ST_SC1, false, true, "io sc1 wr only")
+    IO(ST_SC0SC1, true, true, "io sc0sc1 rd+wr")
+    IO(ST_NT, true, true, "io nt rd+wr")
+    IO(ST_SC1NT, true, true, "io sc1nt rd+wr")
+    IO(ST_PLAIN, true, false, "io rd only")
+    return 0;
+    // ---- timelines (one launch each, after a warm-up launch)
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((fkj_lane_kernel<ST_PLAIN, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.ops_f, b.q, n_tiles, b.pos,
+                           b.quat, b.lin, b.ang, b.tl);
+        CK(hipStreamSynchronize(s));
+    }
+    timeline("lane plain", b, n_tiles, 0);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((fkj_lane_kernel<ST_SC1, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.ops_f, b.q, n_tiles, b.pos,
+                           b.quat, b.lin, b.ang, b.tl);
+        CK(hipStreamSynchronize(s));
+    }
+    timeline("lane sc1", b, n_tiles, 0);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((fkj_quad_kernel<ST_PLAIN, 4, false, true>), dim3((n_groups + 3) / 4), dim3(256), 0, s, b.ops_f, b.q,
+                           n_groups, b.pos, b.quat, b.lin, b.ang, b.tl);
+        CK(hipStreamSynchronize(s));
+    }
+    timeline("quad plain wpb4", b, n_groups, 0);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((fkj_quad_kernel<ST_PLAIN, 16, true, true>), dim3((n_groups + 15) / 16), dim3(1024), 0, s, b.ops_f, b.q,
+                           n_groups, b.pos, b.quat, b.lin, b.ang, b.tl);
+        CK(hipStreamSynchronize(s));
+    }
+    timeline("quad plain wpb16 prio", b, n_groups, 0);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((fkj_quad_kernel<ST_SC1, 16, true, true>), dim3((n_groups + 15) / 16), dim3(1024), 0, s, b.ops_f, b.q,
+                           n_groups, b.pos, b.quat, b.lin, b.ang, b.tl);
+        CK(hipStreamSynchronize(s));
+    }
+    timeline("quad sc1 wpb16 prio", b, n_groups, 0);
+    return 0;
+}
