@@ -1,32 +1,41 @@
 #!/usr/bin/env python3
 """bench.py — FK+Jacobian evals/sec, Franka Panda 7-DoF, batch = 65 536 per GPU (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: a single `drm_fk_jacobian` launch through the
-C ABI producing pos[B,3], quat[B,4], lin_jac[B,3,7], ang_jac[B,3,7] from q[B,7] (what the reference's
-`compute_endeffector_jacobian` computes, robot_model.py:626-667), inputs resident in HBM.
+--config metric (default)
+    One "step" = one pass of the hot path over one batch: a single `drm_fk_jacobian` launch through the C ABI
+    producing pos[B,3], quat[B,4], lin_jac[B,3,7], ang_jac[B,3,7] from q[B,7] (what the reference's
+    `compute_endeffector_jacobian` computes, robot_model.py:626-667), inputs resident in HBM.  Weak scaling: every
+    rank runs its own 65 536-row shard, no data-path collective (every sample is independent).
+--config 3
+    BASELINE.json configuration 3: Panda, GLOBAL batch 2^20 sharded by rows over the ranks (131 072 per GPU at N = 8),
+    one step = FK(end effector) + RNEA inverse dynamics through `drm_fk_rnea` (one fused launch) followed by ONE RCCL
+    `all_gather_into_tensor` of tau + pos + quat (56 B per row) inside the timed step.  Strong scaling.
 
-Timing: W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both
-sides, max over ranks.  The K launches are captured once into a hipGraph (one launch per step, same
-stream, no fusion / skipping) and replayed, so the host does not throttle a ~6 us kernel; `--no-graph`
-launches them eagerly.  HIP events on the launch stream around the timed region give the average
-duration of a launch for the roofline object.
-
-Multi-GPU: the batch shards by rows with no data-path collective (every sample is independent), so
-each rank runs its own 65 536-row shard ("scaling": "weak"); `--gather` adds the optional RCCL
-all-gather of the outputs to the timed step.
+Timing: W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides, max
+over ranks.  For the metric config the K launches are captured once into a hipGraph (one launch per step, same
+stream, no fusion / skipping) and replayed, so the host does not throttle a ~4 us kernel; the captured graph is
+replayed twice untimed first (uploads the executable graph, lets the clocks settle), `--no-graph` launches eagerly.
+HIP events on the launch stream around the timed region give the average duration of a launch for the roofline
+object.
 
 The JSON line also carries
-  "roofline":     algorithmic bytes (224 B/eval) / average launch duration vs the 8 TB/s HBM peak
-  "cpu_baseline": the oracle's fp32 C restatement of the reference (oracle/, "port") timed on this
-                  box's host cores on a bounded sample of the same workload.
+  "roofline":       algorithmic bytes (224 B/eval) / average launch duration vs the 8 TB/s HBM peak at the
+                    metric batch (which is Infinity-Cache resident: 14.7 MB per launch replayed over the same buffers)
+  "roofline_large": the same kernel at batches whose per-launch traffic (0.94 GB / 3.8 GB) is far beyond the 256 MiB
+                    Infinity Cache, i.e. genuine HBM streaming (N = 1 only)
+  "cpu_baseline":   the oracle's fp32 C restatement of the reference (oracle/, "port") timed on this box's host cores
+                    on a bounded sample of the same workload, plus the reference's own CPU numbers measured in the
+                    build container (/root/reference does not exist on the GPU box).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,52 +43,79 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
 EE_LINK = {"panda_no_gripper": "panda_virtual_ee_link", "iiwa7": "iiwa_link_ee"}
+CONFIG3_GLOBAL_BATCH = 1 << 20
+# the reference's own CPU path, measured in the build container where /root/reference exists (BASELINE.md, 8 threads)
+REFERENCE_CPU = {"public_api_evals_per_s": 9.65e3, "tensor_only_evals_per_s": 1.64e6, "threads": 8,
+                 "where": "build container (BASELINE.md): compute_endeffector_jacobian of the unmodified reference, "
+                          "Panda, batch 65 536; the public API spends 6.8 s per call in its Python quaternion loop, "
+                          "'tensor only' stubs that loop out.  Not re-measured in this run: the GPU box has no "
+                          "/root/reference"}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step")
+    ap.add_argument("--config", default="metric", choices=["metric", "3"])
+    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step (metric config)")
     ap.add_argument("--robot", default="panda_no_gripper", choices=sorted(EE_LINK))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--gather", action="store_true", help="all-gather the outputs over RCCL inside every step")
+    ap.add_argument("--gather", action="store_true", help="metric config: all-gather the outputs over RCCL inside every step")
+    ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def respawn_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: become N ranks (one per GPU) by
+    re-executing under torch.distributed.run.  Fails loudly when the node has fewer than N GPUs."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d requested but this node exposes %d HIP device(s); refusing to report a "
+                 "%d-GPU number from fewer GPUs" % (args.gpus, have, args.gpus))
+    from differentiable_robot_model_amd.distributed import torchrun_command
+    cmd = torchrun_command(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    sys.exit(subprocess.call(cmd))
 
 
 def cpu_baseline(spec, link_idx, q_host, seconds):
-    """Oracle (CPU port of the reference algorithm, fp32, OpenMP over samples) on a bounded sample."""
+    """Oracle (CPU port of the reference algorithm, fp32, OpenMP over samples) on a bounded sample: median pass."""
     import numpy as np
 
     from oracle import Oracle  # checker / baseline only — never on the product path
     orc = Oracle(spec)
     cores = Oracle.max_threads()
     q = np.ascontiguousarray(q_host, np.float32)
-    orc.fk_jacobian(q[:1024], link_idx, np.float32)  # page in / spin up the thread pool
-    reps, t0 = 0, time.perf_counter()
+    for _ in range(3):
+        orc.fk_jacobian(q, link_idx, np.float32)  # page in / spin up the thread pool
+    times, t_start = [], time.perf_counter()
     while True:  # bounded by wall time, not by a pass count guessed from one (possibly cold) pass
+        t0 = time.perf_counter()
         orc.fk_jacobian(q, link_idx, np.float32)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 100000:
+        t1 = time.perf_counter()
+        times.append(t1 - t0)
+        if t1 - t_start >= seconds or len(times) >= 100000:
             break
-    evals = reps * q.shape[0]
-    return {"value": evals / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "%d passes over the same %d-sample batch (%.1f s wall on all host cores), fp32 C restatement of the "
-                      "reference algorithm (oracle/drm_oracle.c), OpenMP over samples" % (reps, q.shape[0], dt)}
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": q.shape[0] / med, "unit": "evals/s", "cores": cores, "kind": "port",
+            "best": q.shape[0] / times[0], "mean": q.shape[0] * len(times) / sum(times),
+            "sample": "%d passes over the same %d-sample batch (%.1f s wall on all host cores; value = the median pass, "
+                      "the host is shared so single passes swing), fp32 C restatement of the reference algorithm "
+                      "(oracle/drm_oracle.c), OpenMP over samples" % (len(times), q.shape[0], sum(times)),
+            "reference_cpu": REFERENCE_CPU}
 
 
 def recorded_traffic(batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), if this
-    batch size was profiled; PMC counters cannot be collected from inside the timed run."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, newest round first),
+    if this batch size was profiled; PMC counters cannot be collected from inside the timed run."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
@@ -92,37 +128,115 @@ def recorded_traffic(batch):
     return None, None
 
 
+def sample_q(model, B, device, seed):
+    """q ~ U(lower, upper) per joint (data_utils.py:49-67 distribution), resident in HBM."""
+    import torch
+    lim = model.get_joint_limits()
+    lo = torch.tensor([j["lower"] for j in lim], device=device)
+    hi = torch.tensor([j["upper"] for j in lim], device=device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    return (lo + (hi - lo) * torch.rand(B, len(lim), device=device, generator=gen)).contiguous(), gen
+
+
+def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=2):
+    """EXACTLY K launches between barrier + synchronize on both sides; returns (wall seconds, device seconds from HIP
+    events on the launch stream, whether a hipGraph was used)."""
+    import torch
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(K):
+                    launch()
+            for _ in range(warm_replays):   # untimed: uploads the executable graph, lets the clocks settle
+                graph.replay()
+            torch.cuda.synchronize()
+        except Exception as err:  # pragma: no cover - depends on the runtime
+            print("hipGraph capture failed (%s); launching eagerly" % err, file=sys.stderr)
+            graph = None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(K):
+            launch()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, graph is not None
+
+
 def main():
     args = parse_args()
+    respawn_if_needed(args)
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU compute path)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (node exposes %d)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)                                     # every rank answers over RCCL before anything is timed
+        ranks_seen = int(probe.item())
+        if ranks_seen != world or dist.get_world_size() != world:
+            sys.exit("bench.py: RCCL sees %d ranks, expected %d" % (ranks_seen, world))
 
     import contextlib
     import io
 
+    from differentiable_robot_model_amd.distributed import shard_bounds
     from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel, robot_description_folder
     with contextlib.redirect_stdout(io.StringIO()):
         model = DifferentiableRobotModel(os.path.join(robot_description_folder, args.robot + ".urdf"), device=device)
     link = EE_LINK[args.robot]
+    n, K, W = model._n_dofs, args.steps, args.warmup
+    stream = torch.cuda.current_stream(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    if args.config == "3":
+        line = run_config3(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max, shard_bounds)
+    else:
+        line = run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max):
+    import torch
+    import torch.distributed as dist
     n, B, K, W = model._n_dofs, args.batch, args.steps, args.warmup
-
-    # synthetic inputs, resident in HBM: q ~ U(lower, upper) per joint (data_utils.py:49-67 distribution)
-    lim = model.get_joint_limits()
-    lo = torch.tensor([j["lower"] for j in lim], device=device)
-    hi = torch.tensor([j["upper"] for j in lim], device=device)
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    q = (lo + (hi - lo) * torch.rand(B, n, device=device, generator=gen)).contiguous()
-
+    q, _ = sample_q(model, B, device, 1234 + rank)
     plan = model.plan_fk_and_jacobian(q, link)
     gathered = None
     if args.gather and world > 1:
@@ -134,82 +248,137 @@ def main():
             for out, loc in zip(gathered, plan.outputs()):
                 dist.all_gather_into_tensor(out, loc)
 
-    def barrier():
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    wall, dev_time, graphed = timed_graph_region(step, K, stream, barrier, use_graph=not args.no_graph and gathered is None)
+    wall, dev_time = reduce_max([wall, dev_time])
+
+    bytes_per_eval = 4 * (n + 7 + 6 * n)            # q in; pos, quat, lin_jac, ang_jac out
+    launch_s = dev_time / K                         # average duration of one launch, HIP events on the launch stream
+    achieved = bytes_per_eval * B / launch_s / 1e9
+    traffic, traffic_src = recorded_traffic(B) if args.robot == "panda_no_gripper" else (None, None)
+    line = {
+        "metric": "FK+Jacobian evals/sec, Panda 7-DoF, batch=65 536 @1/2/4/8 MI355X",
+        "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen,
+        "config": {"workload": "Franka Panda 7-DoF (panda_no_gripper), FK + end-effector geometric Jacobian to "
+                               "panda_virtual_ee_link, batch=%d per GPU, q~U(joint limits), inputs resident in HBM"
+                               % B if args.robot == "panda_no_gripper" else "%s FK+Jacobian batch=%d" % (args.robot, B),
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "batch-sharded x%d" % world,
+                   "launch": "hipGraph of K launches (replayed twice untimed first)" if graphed else "eager launches",
+                   "gather": bool(gathered is not None)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                     "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true, 1, false>", "bytes_per_eval": bytes_per_eval,
+                     "launch_us": launch_s * 1e6,
+                     "note": "algorithmic bytes / average launch duration (HIP events over the timed region, includes "
+                             "inter-launch gaps).  At this batch the 14.7 MB of a launch are replayed over the same buffers "
+                             "and stay in the 256 MiB Infinity Cache: `achieved` is an effective rate against the HBM peak, "
+                             "bounded by launch floor (1.66 us) + write-through drain of 12.8 MB (a launch that only moves "
+                             "the bytes takes 2.9 us = 0.63, profiles/r02_metric_lab.txt); genuine HBM streaming is in "
+                             "roofline_large"},
+    }
+    if rank == 0 and world == 1 and not args.no_large and args.robot == "panda_no_gripper":
+        line["roofline_large"] = roofline_large(model, link, device, stream, bytes_per_eval)
+    if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
+        line["cpu_baseline"] = cpu_baseline(model._spec, model._name_to_idx_map[link], q.cpu().numpy(), args.cpu_seconds)
+    return line
+
+
+def roofline_large(model, link, device, stream, bytes_per_eval):
+    """The metric kernel at batches whose per-launch traffic is far beyond the Infinity Cache (256 MiB): every launch
+    streams its inputs from and its outputs to HBM.  Same measurement as the metric leg (hipGraph, HIP events)."""
+    import torch
+    out = []
+    for B, K in ((1 << 22, 100), (1 << 24, 25)):   # ~15 ms of streaming each: long enough for the clocks to settle
+        need = B * bytes_per_eval * 1.1
+        free, _ = torch.cuda.mem_get_info(device)
+        if free < need:
+            out.append({"batch": B, "skipped": "needs %.1f GB of HBM, %.1f GB free" % (need / 1e9, free / 1e9)})
+            continue
+        q, _ = sample_q(model, B, device, 99)
+        plan = model.plan_fk_and_jacobian(q, link)
+        for _ in range(3):
+            plan.launch()
+        torch.cuda.synchronize()
+        _, dev_time, graphed = timed_graph_region(plan.launch, K, stream, lambda: None, warm_replays=3)
+        launch_s = dev_time / K
+        achieved = bytes_per_eval * B / launch_s / 1e9
+        out.append({"batch": B, "steps": K, "launch_us": launch_s * 1e6, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_per_eval * B,
+                    "evals_per_s": B / launch_s,
+                    "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true, 4, true> (outputs streamed past the Infinity Cache)"})
+        del plan, q
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max, shard_bounds):
+    """BASELINE configuration 3: global batch 2^20 sharded by rows, FK(EE) + RNEA per shard (one fused launch), one RCCL
+    all-gather of tau | pos | quat per step."""
+    import torch
+    import torch.distributed as dist
+    n, K, W = model._n_dofs, args.steps, args.warmup
+    G = CONFIG3_GLOBAL_BATCH
+    lo, hi = shard_bounds(G, world, rank)
+    rows = hi - lo
+    q, gen = sample_q(model, rows, device, 4321 + rank)
+    lim = model.get_joint_limits()
+    vmax = torch.tensor([j["velocity"] for j in lim], device=device)
+    qd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()   # data_utils.py:70-98
+    qdd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
+    plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
+    width = n + 3 + 4                                                    # tau | pos | quat = 56 B per row
+    packed = torch.empty(rows, width, device=device)
+    gathered = torch.empty(world * rows, width, device=device) if world > 1 and G % world == 0 else None
+    if world > 1 and gathered is None:
+        sys.exit("bench.py --config 3: 2^20 rows do not split evenly over %d ranks" % world)
+
+    def compute():
+        plan.launch()
+
+    def exchange():
         if world > 1:
-            dist.barrier()
+            torch.cat([plan.tau, plan.pos, plan.quat], dim=1, out=packed)
+            dist.all_gather_into_tensor(gathered, packed)
+
+    def step():
+        compute()
+        exchange()
 
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph and gathered is None:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(K):
-                    plan.launch()
-            graph.replay()  # one untimed replay (uploads the executable graph)
-            torch.cuda.synchronize()
-        except Exception as err:  # pragma: no cover - depends on the runtime
-            if rank == 0:
-                print("hipGraph capture failed (%s); launching eagerly" % err, file=sys.stderr)
-            graph = None
-
-    stream = torch.cuda.current_stream(device)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(K):
-            step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-
-    elapsed = torch.tensor([t1 - t0, ev0.elapsed_time(ev1) * 1e-3], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    wall, dev_time = float(elapsed[0]), float(elapsed[1])
-
-    if rank == 0:
-        bytes_per_eval = 4 * (n + 7 + 6 * n)        # q in; pos, quat, lin_jac, ang_jac out
-        launch_s = dev_time / K                     # average duration of one launch, HIP events on the launch stream
-        achieved = bytes_per_eval * B / launch_s / 1e9
-        traffic, traffic_src = recorded_traffic(B) if args.robot == "panda_no_gripper" else (None, None)
-        line = {
-            "metric": "FK+Jacobian evals/sec, Panda 7-DoF, batch=65 536 @1/2/4/8 MI355X",
-            "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Franka Panda 7-DoF (panda_no_gripper), FK + end-effector geometric Jacobian to "
-                                   "panda_virtual_ee_link, batch=%d per GPU, q~U(joint limits), inputs resident in HBM"
-                                   % B if args.robot == "panda_no_gripper" else "%s FK+Jacobian batch=%d" % (args.robot, B),
-                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": "batch-sharded x%d" % world,
-                       "launch": "hipGraph of K launches" if graph is not None else "eager launches",
-                       "gather": bool(gathered is not None)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_eval * B,
-                         "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true>", "bytes_per_eval": bytes_per_eval,
-                         "launch_us": launch_s * 1e6,
-                         "note": "algorithmic bytes / average launch duration (HIP events over the timed region, "
-                                 "includes inter-launch gaps); a 65 536-sample launch is one wave per SIMD and "
-                                 "latency-bound, see DESIGN.md §6 for B=2^20..2^22 (>=75% of peak)"},
-        }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(model._spec, model._name_to_idx_map[link],
-                                                q.cpu().numpy(), args.cpu_seconds)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # the compute of a step alone (graph of K launches), then the full step with the collective (eager: RCCL)
+    _, dev_compute, _ = timed_graph_region(compute, K, stream, barrier, use_graph=not args.no_graph)
+    wall, dev_time, _ = timed_graph_region(step, K, stream, barrier, use_graph=False)
+    wall, dev_time, dev_compute = reduce_max([wall, dev_time, dev_compute])
+    bytes_per_eval = 4 * (3 * n + n + 7)                                 # q qd qdd in; tau pos quat out = 140 B
+    launch_s = dev_compute / K
+    achieved = bytes_per_eval * rows / launch_s / 1e9
+    return {
+        "metric": "FK + RNEA evals/sec, Panda 7-DoF, global batch 2^20 sharded over the GPUs (BASELINE.json configuration 3)",
+        "value": G * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen,
+        "config": {"workload": "Franka Panda 7-DoF, FK(panda_virtual_ee_link) + RNEA inverse dynamics (gravity, damping), "
+                               "global batch %d = %d rows per GPU, q~U(limits), qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); "
+                               "one fused drm_fk_rnea launch + one all_gather_into_tensor of tau|pos|quat per step" % (G, rows),
+                   "batch_per_gpu": rows, "global_batch": G, "parallelism": "batch-sharded x%d" % world,
+                   "launch": "eager step (kernel + RCCL collective)", "gather": world > 1,
+                   "gather_bytes_per_rank": rows * width * 4 if world > 1 else 0},
+        "compute_us_per_step": dev_compute / K * 1e6, "step_us_with_gather": dev_time / K * 1e6,
+        "gather_us_per_step": max(0.0, (dev_time - dev_compute) / K * 1e6) if world > 1 else 0.0,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "drm::fk_rnea_arm_kernel<8, 7>", "bytes_per_eval": bytes_per_eval,
+                     "launch_us": launch_s * 1e6,
+                     "note": "the fused kernel alone (hipGraph of K launches, HIP events); RNEA sits at the vector-FP32 / HBM "
+                             "ridge (2.6 kflop per 140 B), see DESIGN.md"},
+    }
 
 
 if __name__ == "__main__":

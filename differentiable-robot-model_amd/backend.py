@@ -17,7 +17,7 @@ from .flatten import OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -41,7 +41,7 @@ EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "dr
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
-           "drm_walk_table_backward")
+           "drm_walk_table_backward", "drm_fk_rnea")
 
 
 def load_library(path: str = None):
@@ -95,6 +95,8 @@ def load_library(path: str = None):
         lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
         lib.drm_crba.restype = ctypes.c_int
         lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
+        lib.drm_fk_rnea.restype = ctypes.c_int
+        lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         _lib = lib
@@ -428,6 +430,41 @@ class FkJacobianPlan(object):
 
     def outputs(self):
         return self.pos, self.quat, self.lin, self.ang
+
+
+class FkInverseDynamicsPlan(object):
+    """A prepared drm_fk_rnea launch on fixed buffers: q, qd, qdd -> tau and the pose (pos, quat) of one link.  For a
+    serial 7-DoF arm whose last link is the target (Franka Panda, KUKA iiwa) that is ONE fused kernel; BASELINE
+    configuration 3 (bench.py --config 3) runs it on every GPU's shard."""
+
+    def __init__(self, tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
+        # tree / chain: (WalkProgram, ops_f, ops_i) of the whole-tree walk and of the root -> link walk
+        self._lib = load_library()
+        self.q, self.qd = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs)
+        self.qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+        B, dev = self.q.shape[0], self.q.device
+        if self.qd.shape[0] != B or (self.qdd is not None and self.qdd.shape[0] != B):
+            raise ValueError("q / qd / qdd batch sizes differ")
+        self.tau = torch.empty(B, n_dofs, device=dev)
+        self.pos = torch.empty(B, 3, device=dev)
+        self.quat = torch.empty(B, 4, device=dev)
+        self._keep = (tree[1], tree[2], chain[1], chain[2])
+        self._tree = _walk_struct(tree[0], tree[1].detach(), tree[2], n_dofs)
+        self._chain = _walk_struct(chain[0], chain[1].detach(), chain[2], n_dofs)
+        flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        self._args = (ctypes.byref(self._tree), ctypes.byref(self._chain), int(target_op), self.q.data_ptr(),
+                      self.qd.data_ptr(), self.qdd.data_ptr() if self.qdd is not None else None, B, flags,
+                      self.tau.data_ptr(), self.pos.data_ptr(), self.quat.data_ptr())
+        self.batch, self.device = B, dev
+
+    def launch(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self._lib.drm_fk_rnea(*self._args, ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            _check(rc)
+
+    def outputs(self):
+        return self.tau, self.pos, self.quat
 
 
 class InverseDynamicsPlan(object):

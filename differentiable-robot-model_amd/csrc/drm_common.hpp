@@ -331,6 +331,8 @@ void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, flo
                             float *ang_jac, hipStream_t s);
 void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s);
+void launch_fk_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+                        float *tau, float *pos, float *quat, hipStream_t s);
 
 template <class K>
 static int ensure_lds(K kernel, size_t bytes) {

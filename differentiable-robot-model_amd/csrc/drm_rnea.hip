@@ -119,3 +119,37 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     })
     return launched();
 }
+
+extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
+                           const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, void *stream) {
+    int rc = check_walk(tree);
+    if (rc) return rc;
+    rc = check_walk(chain);
+    if (rc) return rc;
+    if (!q || !qd || !tau || !pos || !quat) return fail(DRM_ERR_INVALID, "q / qd / tau / pos / quat must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    if (tree->n_dofs != chain->n_dofs) return fail(DRM_ERR_INVALID, "the two walks belong to different robots");
+    if (B == 0) return DRM_OK;
+    const int n = tree->n_dofs;
+    hipStream_t s = (hipStream_t)stream;
+#ifndef DRM_NO_ARM_KERNEL
+    const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(tau, AL_TAU) | al16(pos, AL_POS) |
+                           al16(quat, AL_QUAT);
+    if ((tree->shape & DRM_WALK_ARM_CHAIN) && tree->capacity == 8 && n == 7 && target_op == tree->n_ops - 1 &&
+        chain->target_perm == 2 && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)tree->ops_f) & 15u) == 0 &&
+        align == (AL_Q | AL_QD | AL_TAU | AL_POS | AL_QUAT | (qdd ? AL_QDD : 0u))) {
+        // a serial 7-DoF arm whose last link is the target: full tiles through the fused kernel
+        const int n_tiles = (int)(B / WAVE);
+        launch_fk_rnea_arm(tree->ops_f, q, qd, qdd, n_tiles, (int)flags, tau, pos, quat, s);
+        rc = launched();
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (rc || done == B) return rc;
+        q += done * n; qd += done * n; qdd = qdd ? qdd + done * n : nullptr;
+        tau += done * n; pos += done * 3; quat += done * 4; B -= done;
+    }
+#endif
+    // every other robot (and a ragged tail): the two walks one after the other on the same stream
+    rc = drm_fk(chain, q, B, 1, pos, quat, stream);
+    if (rc) return rc;
+    return drm_rnea(tree, q, qd, qdd, B, flags, tau, stream);
+}

@@ -435,9 +435,9 @@ constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f; // keep in sync with joint_trig
 //   joints_done()  -> called once, right after the last MOVING joint: every B[k] is final from here on
 //                     (the kernel starts storing the angular Jacobian while the fixed tail is still computed)
 // Out: B[k][c] = (z_c, p_c) of every moving joint k, and the end pose.
-template <int CAP, int NJ, class FT, class DONE>
-DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3], DONE joints_done) {
-    float cs[NJ], sn[NJ];
+// cos / sin of the NJ joint angles of a chain, two joints per packed evaluation
+template <int NJ>
+DRM_HD void chain_trig(const float (&q)[NJ], float (&cs)[NJ], float (&sn)[NJ]) {
     bool big = false;
 #pragma unroll
     for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
@@ -453,6 +453,11 @@ DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3
             if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
         }
     }
+}
+// the chain itself, given cos / sin of the joint angles (the fused FK + RNEA kernel shares them between its two walks)
+template <int CAP, int NJ, class FT, class DONE>
+DRM_HD void fk_chain_pairs_trig(FT ft, const float (&cs)[NJ], const float (&sn)[NJ], PoseP &ee, f2 (&B)[NJ][3],
+                                DONE joints_done) {
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         const OpPairs o = load_pairs(ft(k));
@@ -471,6 +476,12 @@ DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3
         }
         if (k == NJ - 1) joints_done();
     }
+}
+template <int CAP, int NJ, class FT, class DONE>
+DRM_HD void fk_chain_pairs(FT ft, const float (&q)[NJ], PoseP &ee, f2 (&B)[NJ][3], DONE joints_done) {
+    float cs[NJ], sn[NJ];
+    chain_trig<NJ>(q, cs, sn);
+    fk_chain_pairs_trig<CAP, NJ>(ft, cs, sn, ee, B, joints_done);
 }
 
 // ---------------------------------------------------------------------------
@@ -902,24 +913,18 @@ DRM_HD void rnea_walk(const float *__restrict__ opf, const int32_t *__restrict__
 //   fput(k, Force) / fget(k, Force&) -> body force of link k, parked between the sweeps (LDS in the kernel: the
 //   48 floats would otherwise be the registers that keep a second wave off the SIMD)
 template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
+                            const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget);
+template <int CAP, int NJ, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ], const float (&qd)[NJ],
                        const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
     float cs[NJ], sn[NJ];
-    bool big = false;
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
-    if (DRM_WAVE_ANY(big)) {
-#pragma unroll
-        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
-    } else {
-#pragma unroll
-        for (int d = 0; d < NJ; d += 2) {
-            f2 s2, c2;
-            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
-            sn[d] = s2[0]; cs[d] = c2[0];
-            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
-        }
-    }
+    chain_trig<NJ>(q, cs, sn);
+    rnea_chain_trig<CAP, NJ>(row, gravity, damping, cs, sn, qd, qdd, tau, fput, fget);
+}
+template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
+                            const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
     // The joint transforms are rebuilt in the backward sweep (12 VALU ops + three broadcast LDS reads per link)
     // instead of being kept: 72 fewer live registers.
     Motion cur;

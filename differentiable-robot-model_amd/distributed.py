@@ -56,3 +56,51 @@ def all_gather_rows(local: torch.Tensor, batch: int, group=None) -> torch.Tensor
 
 def gather_outputs(outputs: Sequence[torch.Tensor], batch: int, group=None) -> List[torch.Tensor]:
     return [all_gather_rows(t, batch, group) for t in outputs]
+
+
+def free_port() -> int:
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous of a single-node launch)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def torchrun_command(nproc: int, script: str, script_args: Sequence[str], port: int = 0) -> List[str]:
+    """The single-node launch line that turns `script` into `nproc` ranks (one per GPU): what `bench.py --gpus N` executes
+    when it is started without a rendezvous in its environment.  127.0.0.1, never the container hostname."""
+    import sys
+    if nproc < 1:
+        raise ValueError("nproc must be >= 1")
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script] + list(script_args)
+
+
+def all_reduce_gradients(params, group=None, average: bool = False) -> None:
+    """Sum (or average) the gradients of the learnable link parameters over the ranks of a batch-sharded training step.
+
+    The backward kernels (drm_fk_backward / drm_rnea_backward) leave on every rank the parameter gradients of ITS rows:
+    6 .. 12 floats per learnable link.  They are flattened into ONE buffer and reduced with ONE
+    all_reduce (latency-bound, < 1 KB for the reference's learn_kinematics_of_iiwa.py workload), then scattered back, so
+    every rank steps its optimiser on the gradient of the whole batch.  Parameters without a gradient contribute zeros
+    (a rank whose shard is empty still takes part in the collective)."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    world = dist.get_world_size(group)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params])
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    off = 0
+    for p in params:
+        k = p.numel()
+        g = flat[off:off + k].reshape(p.shape).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += k

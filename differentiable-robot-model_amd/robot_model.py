@@ -615,6 +615,40 @@ class DifferentiableRobotModel(torch.nn.Module):
         return backend.InverseDynamicsPlan(dw.program, self._ops_f(dw), dw.ops_i, q, qd, qdd_des, bool(include_gravity),
                                            bool(use_damping), self._n_dofs)
 
+    def plan_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: Optional[torch.Tensor],
+                                     link_name: str, include_gravity: bool = True, use_damping: bool = True
+                                     ) -> "backend.FkInverseDynamicsPlan":
+        """Prepared launch of inverse dynamics + the pose of ``link_name`` on fixed buffers (drm_fk_rnea): what the
+        reference computes with compute_inverse_dynamics (robot_model.py:305-375) followed by
+        compute_forward_kinematics (robot_model.py:223-248) on the same q.  One fused kernel for a serial 7-DoF arm
+        whose last link is the target, the two walks back to back otherwise."""
+        self._require_device()
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
+        idx = self._name_to_idx_map[link_name]
+        if idx == 0:
+            raise ValueError("the root link has the identity pose; use plan_inverse_dynamics")
+        tree = self._get_walk(("tree",), whole_tree=True)
+        chain = self._get_walk(("chain", idx), targets=[idx])
+        ops = [int(k) for k, link in enumerate(tree.program.links) if int(link) == idx]
+        return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
+                                             (chain.program, self._ops_f(chain), chain.ops_i), ops[0] if ops else -1,
+                                             q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs)
+
+    @tensor_check
+    def compute_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor, link_name: str,
+                                        include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
+                                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(tau [B,n], pos [B,3], quat [B,4]): compute_inverse_dynamics and compute_forward_kinematics of one link from
+        a single pass over q (not differentiable; use the two separate methods under autograd)."""
+        assert q.ndim == 2 and qd.ndim == 2 and qdd_des.ndim == 2
+        assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs and qdd_des.shape[1] == self._n_dofs
+        plan = self.plan_fk_and_inverse_dynamics(q.detach(), qd.detach(), qdd_des.detach(), link_name,
+                                                 bool(include_gravity), bool(use_damping))
+        with torch.cuda.device(self._device):
+            plan.launch()
+        return plan.tau, plan.pos, plan.quat
+
     # ------------------------------------------------------------------ inverse dynamics
     @tensor_check
     def compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,

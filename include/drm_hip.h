@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 2
+#define DRM_ABI_VERSION 3
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -164,6 +164,20 @@ int drm_fk_jacobian(const drm_walk *walk, const float *q, int64_t B,
  */
 int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B,
              int32_t flags, float *tau, void *stream);
+
+/*
+ * Inverse dynamics AND the pose of one link in one call: what a caller of the reference gets from
+ * compute_inverse_dynamics (robot_model.py:305-375) followed by compute_forward_kinematics (robot_model.py:223-248) on
+ * the same q — the reference walks the tree twice, re-evaluating every joint transform (BASELINE configuration 3).
+ *   tree      the whole-tree walk drm_rnea takes;   chain   the root->link walk drm_fk takes (one target)
+ *   target_op index of the FK target among the ops of `tree`, or -1 if unknown: when the tree is a serial 7-DoF arm and
+ *             the target is its last link, both results come from ONE fused launch (one read of q, one sin/cos
+ *             evaluation, one constant table); otherwise the two walks are launched one after the other.
+ *   q, qd, qdd [B, n] (qdd may be NULL)  ->  tau [B, n], pos [B, 3], quat [B, 4];  flags as for drm_rnea.
+ * Results are bit-identical to drm_rnea + drm_fk.
+ */
+int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
+                const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, void *stream);
 
 /*
  * Joint-space inertia matrix over the whole tree (composite-rigid-body algorithm).

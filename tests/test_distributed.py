@@ -71,3 +71,68 @@ def test_shard_and_gather_world_size_2(tmp_path, batch):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_torchrun_spawn_path(tmp_path):
+    """`python bench.py --gpus N` without a rendezvous re-executes itself through distributed.torchrun_command; the same
+    line must bring up N ranks that see each other (gloo here, RCCL on the GPU node)."""
+    import subprocess
+    import sys
+    from differentiable_robot_model_amd.distributed import torchrun_command
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "procs", "spawn_probe.py")
+    cmd = torchrun_command(2, probe, [str(tmp_path)])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "127.0.0.1" in cmd
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    subprocess.run(cmd, check=True, env=env, timeout=300)
+    assert sorted(os.listdir(tmp_path)) == ["rank0", "rank1"]
+    for r in (0, 1):
+        world, seen, addr = open(os.path.join(str(tmp_path), "rank%d" % r)).read().split()
+        assert (world, seen, addr) == ("2", "2", "127.0.0.1")
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus 2` on a box with fewer than two GPUs must fail loudly instead of reporting n_gpus = 1."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and '"n_gpus"' not in r.stdout
+    # a rank count that disagrees with --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "2", "--warmup", "1"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def _grad_worker(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from differentiable_robot_model_amd.distributed import all_reduce_gradients
+        torch.manual_seed(0)
+        # a "learnable link": trans [1,3] and rot_angles [1,3] (learn_kinematics_of_iiwa.py), loss = mean over the batch
+        trans = torch.nn.Parameter(torch.randn(1, 3)); rot = torch.nn.Parameter(torch.randn(1, 3))
+        frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)
+        x = torch.randn(10, 3)
+        lo, hi = shard_bounds(10, world, rank)
+        loss = ((x[lo:hi] * trans).sum() + (x[lo:hi].pow(2) * rot).sum()) / 10.0     # this rank's share of the mean
+        loss.backward()
+        all_reduce_gradients([trans, rot, frozen])
+        want_t = x.sum(0, keepdim=True) / 10.0
+        want_r = x.pow(2).sum(0, keepdim=True) / 10.0
+        assert torch.allclose(trans.grad, want_t, atol=1e-6) and torch.allclose(rot.grad, want_r, atol=1e-6)
+        assert frozen.grad is None
+        open(os.path.join(result_dir, "ok%d" % rank), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_gradients_world_size_2(tmp_path):
+    """the backward of a batch-sharded step adds ONE all-reduce of the parameter gradients."""
+    mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]

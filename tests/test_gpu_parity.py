@@ -342,3 +342,68 @@ def test_random_robot_and_batch_size_vs_oracle(seed):
     assert np.allclose(host(tau), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU), (robot, B)
     H = m.compute_lagrangian_inertia_matrix(dev(q))
     assert np.allclose(host(H), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU), (robot, B)
+
+
+# ------------------------------------------------------------------ fused FK + inverse dynamics (drm_fk_rnea)
+@pytest.mark.parametrize("robot,link", [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee"),
+                                        ("panda_no_gripper", "panda_link4"), ("allegro_left", "link_15.0_tip"),
+                                        ("fetch_arm_no_gripper", "virtual_ee_link")])
+@pytest.mark.parametrize("B", [1, 64, 257, 4096])
+def test_fk_and_inverse_dynamics_one_call(robot, link, B):
+    """tau, pos, quat of drm_fk_rnea (one fused launch for a serial 7-DoF arm whose last link is the target, the two
+    walks back to back otherwise) are BIT-identical to the separate calls and agree with the fp64 oracle."""
+    m = load_model(robot, "cuda")
+    q, qd, qdd = sample_states(m, B, seed=700 + B)
+    for grav, damp in ((True, True), (False, False)):
+        tau, pos, quat = m.compute_fk_and_inverse_dynamics(dev(q), dev(qd), dev(qdd), link, grav, damp)
+        t2 = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+        p2, r2 = m.compute_forward_kinematics(dev(q), link)
+        assert torch.equal(tau, t2) and torch.equal(pos, p2) and torch.equal(quat, r2), (robot, link, B)
+    orc = Oracle(m._spec)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    tau, pos, quat = m.compute_fk_and_inverse_dynamics(dev(q), dev(qd), dev(qdd), link)
+    rp, rq = orc.fk(q64, [m._name_to_idx_map[link]], np.float64)
+    assert max_err(host(pos), rp[:, 0]) <= TOL_POS["atol"] and quat_close(host(quat), rq[:, 0], TOL_QUAT["atol"])[0]
+    assert np.allclose(host(tau), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+
+
+def test_fk_and_inverse_dynamics_plan_under_hipgraph_config3_shard():
+    """BASELINE configuration 3, one GPU's shard of 2^20 (131 072 rows) and the full 2^20: the fused plan replayed from a
+    hipGraph against the separate calls (bit-exact) and 4 096 random rows against the oracle."""
+    m = load_model("panda_no_gripper", "cuda")
+    ee = "panda_virtual_ee_link"
+    orc = Oracle(m._spec)
+    for B in (131072, 1 << 20):
+        q, qd, qdd = (dev(a) for a in sample_states(m, B, seed=B, vel=0.4, acc=0.8))
+        plan = m.plan_fk_and_inverse_dynamics(q, qd, qdd, ee)
+        graph = torch.cuda.CUDAGraph()
+        plan.launch()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            plan.launch()
+        for t in plan.outputs():
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.tau, m.compute_inverse_dynamics(q, qd, qdd))
+        p2, r2 = m.compute_forward_kinematics(q, ee)
+        assert torch.equal(plan.pos, p2) and torch.equal(plan.quat, r2)
+        sel = torch.randperm(B, generator=torch.Generator().manual_seed(2))[:4096].cuda()
+        q64, qd64, qdd64 = (host(a[sel]).astype(np.float64) for a in (q, qd, qdd))
+        rp, rq = orc.fk(q64, [8], np.float64)
+        assert max_err(host(plan.pos[sel]), rp[:, 0]) <= TOL_POS["atol"]
+        assert quat_close(host(plan.quat[sel]), rq[:, 0], TOL_QUAT["atol"])[0]
+        assert np.allclose(host(plan.tau[sel]), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+
+
+def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
+    """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
+    the fp64 oracle (the oracle does 65 536 rows in well under a second)."""
+    m = load_model("iiwa7", "cuda")
+    q, _, _ = sample_states(m, 65536, seed=22)
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(dev(q), "iiwa_link_ee")
+    rp, rq, rl, ra = Oracle(m._spec).fk_jacobian(q.astype(np.float64), m._name_to_idx_map["iiwa_link_ee"], np.float64)
+    assert max_err(host(pos), rp) <= TOL_POS["atol"]
+    assert max_err(host(lin), rl) <= TOL_JAC["atol"] and max_err(host(ang), ra) <= TOL_JAC["atol"]
+    ok, flips = quat_close(host(quat), rq, TOL_QUAT["atol"])
+    assert ok and flips <= 2, flips       # the sign may only differ on a branch boundary of sva.py:117-128

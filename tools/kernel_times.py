@@ -132,3 +132,12 @@ def fk_then_rnea():
 us = graph_time(fk_then_rnea)
 print("config 3: fk + rnea panda B=  %d (one GPU's shard of 2^20) %9.2f us  %7.1f GB/s (168 B/eval, two calls)  %6.2f Gevals/s"
       % (Bs, us, Bs * 168 / us / 1e3, Bs / us / 1e3))
+for Bf in (Bs, 1 << 20):
+    qf, qdf, qddf = (t.cuda() for t in sample(m, Bf))
+    plan_f = m.plan_fk_and_inverse_dynamics(qf, qdf, qddf, link)
+    us = graph_time(plan_f.launch)
+    print("config 3: fk + rnea panda B=%8d, ONE fused launch (drm_fk_rnea) %9.2f us  %7.1f GB/s (140 B/eval)  %6.2f Gevals/s"
+          % (Bf, us, Bf * 140 / us / 1e3, Bf / us / 1e3))
+    plan_r = m.plan_inverse_dynamics(qf, qdf, qddf)
+    us = graph_time(plan_r.launch)
+    print("          rnea alone      B=%8d %9.2f us" % (Bf, us))

@@ -86,7 +86,7 @@ __device__ __forceinline__ void stamp_ids(Stamp *s) {
 // ---------------------------------------------------------------------------------------------------------------
 // lane-per-sample kernel = the product kernel with a store flavour and optional time stamps
 // ---------------------------------------------------------------------------------------------------------------
-template <int FL, bool TL, int WPB = 4, bool ANG_LATE = false>
+template <int FL, bool TL, int WPB = 4, bool ANG_LATE = false, bool DIRECTQ = false>
 __global__ void __launch_bounds__(64 * WPB) fkj_lane_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
                                                        int n_tiles, float *__restrict__ pos, float *__restrict__ quat,
                                                        float *__restrict__ lin, float *__restrict__ ang, Stamp *tl) {
@@ -104,13 +104,21 @@ __global__ void __launch_bounds__(64 * WPB) fkj_lane_kernel(const float *__restr
     float *lq = lc + C_FLOATS, *lp = lq, *ll = lq + Q_FLOATS, *la = ll + J_FLOATS;
     const int64_t b0 = (int64_t)tile * WAVE;
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
-    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    float qv[NJ];
+    if (DIRECTQ) {
+        const float *qr = q + (b0 + lane) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = qr[d];
+    } else {
+        tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    }
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
-    float qv[NJ];
+    if (!DIRECTQ) {
 #pragma unroll
-    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+        for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * SQ + d];
+    }
     if (TL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = now(); }
     PoseP ee;
     f2 Bk[NJ][3];
@@ -559,6 +567,15 @@ int main(int argc, char **argv) {
         time_graph(NAME, l, s);                                                                                          \
     }
     LANEX(ST_SC1, 1, false, "lane sc1 wpb1")
+#define LANED(FL, WPB, NAME)                                                                                             \
+    {                                                                                                                    \
+        auto l = [&] { hipLaunchKernelGGL((fkj_lane_kernel<FL, false, WPB, false, true>), dim3((n_tiles + WPB - 1) / WPB), dim3(64 * WPB), 0, s, \
+                                          b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang, b.tl); };                 \
+        clear(b); l(); CK(hipStreamSynchronize(s)); check(NAME, ref, fetch(b));                                          \
+        time_graph(NAME, l, s);                                                                                          \
+    }
+    LANED(ST_SC1, 1, "lane sc1 wpb1 directq")
+    LANED(ST_SC1, 4, "lane sc1 wpb4 directq")
     LANEX(ST_SC1NT, 4, false, "lane sc1nt wpb4")
     LANEX(ST_SC1NT, 1, false, "lane sc1nt wpb1")
 #define LANE2(FL, WPB, NAME)                                                                                             \
