@@ -13,11 +13,11 @@ import threading
 
 import torch
 
-from .flatten import OPI_PERM, WalkProgram
+from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -27,7 +27,10 @@ class DrmWalk(ctypes.Structure):
     _fields_ = [("ops_f", ctypes.c_void_p), ("ops_i", ctypes.c_void_p),
                 ("n_ops", ctypes.c_int32), ("capacity", ctypes.c_int32),
                 ("n_dofs", ctypes.c_int32), ("n_slots", ctypes.c_int32),
-                ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32)]
+                ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32),
+                ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
+                ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
+                ("prefix_end", ctypes.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -41,7 +44,7 @@ EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "dr
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
-           "drm_walk_table_backward", "drm_fk_rnea")
+           "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -92,7 +95,9 @@ def load_library(path: str = None):
         lib.drm_walk_table_backward.restype = ctypes.c_int
         lib.drm_walk_table_backward.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
         lib.drm_forward_dynamics.restype = ctypes.c_int
-        lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
+        lib.drm_forward_dynamics.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.drm_forward_dynamics_scratch_floats.restype = i64
+        lib.drm_forward_dynamics_scratch_floats.argtypes = [wp, i64]
         lib.drm_crba.restype = ctypes.c_int
         lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
         lib.drm_fk_rnea.restype = ctypes.c_int
@@ -131,8 +136,19 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
     target_perm = getattr(prog, "_target_perm", None)
     if target_perm is None:   # un-permutation of the last op's frame, looked up once per walk
         target_perm = prog._target_perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
-    return DrmWalk(ops_f.data_ptr(), ops_i.data_ptr(), prog.n_ops, prog.capacity, n_dofs, prog.n_slots,
-                   prog.dof_mask, target_perm, prog.shape)
+    return fill_walk_struct(DrmWalk, prog, ops_f.data_ptr(), ops_i.data_ptr(), n_dofs, target_perm)
+
+
+def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_dofs: int, target_perm: int):
+    """`struct drm_walk` of a WalkProgram whose tables live at the given addresses (device here, host in tests/host_emu)."""
+    w = cls(ops_f_ptr, ops_i_ptr, prog.n_ops, prog.capacity, n_dofs, prog.n_slots, prog.dof_mask, target_perm, prog.shape)
+    w.n_segments = prog.n_segments
+    for i, v in enumerate(prog.seg_begin):
+        w.seg_begin[i] = int(v)
+    for i, (lo, cnt) in enumerate(prog.seg_dof):
+        w.seg_dof_lo[i], w.seg_dof_cnt[i] = int(lo), int(cnt)
+    w.prefix_end = int(prog.prefix_end)
+    return w
 
 
 def _stream(device) -> ctypes.c_void_p:
@@ -321,17 +337,13 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
         return qdd
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    try:
-        with torch.cuda.device(q.device):
-            _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
-                                            qdd.data_ptr(), _stream(q.device)))
-    except KernelUnsupported:
-        # more DoFs than the fused kernel can keep in LDS (64 packed n x n triangles): the same linear system
-        # H qdd = f - nle from the CRBA and RNEA kernels, factorised on the device by the batched Cholesky of
-        # torch.linalg (hipSOLVER) — slower, but no robot is refused
-        H = crba(prog, ops_f, ops_i, q, n_dofs)
-        bias = rnea(prog, ops_f, ops_i, q, qd, None, include_gravity, use_damping, n_dofs)
-        qdd = torch.cholesky_solve((f - bias).unsqueeze(-1), torch.linalg.cholesky(H)).squeeze(-1)
+    # robots whose inertia-matrix triangle does not fit in LDS (> ~30 DoF in one segment) factorise it in HBM scratch
+    need = int(lib.drm_forward_dynamics_scratch_floats(ctypes.byref(walk), B))
+    scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
+    with torch.cuda.device(q.device):
+        _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
+                                        qdd.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                                        _stream(q.device)))
     return qdd
 
 

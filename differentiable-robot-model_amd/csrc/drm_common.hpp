@@ -192,6 +192,26 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, int rows, int 
     }
 }
 
+// LDS -> HBM of a whole [rows, S] tile by ALL threads of a block (the tile of a fanned-out launch belongs to the block, not
+// to one wavefront): 16-byte accesses when the tile is full and g is 16-byte aligned (`vec`), 4-byte ones otherwise.
+template <bool NT = false>
+__device__ __forceinline__ void block_tile_store(float *__restrict__ g, int rows, int S, uint32_t magic, const float *lds,
+                                                 bool vec) {
+    const bool padded = !(S & 1);
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    if (vec) {
+        const unsigned nvec = 16u * (unsigned)S; // rows == 64
+        for (unsigned i = tid; i < nvec; i += nt) {
+            const unsigned w = 4u * i;
+            store16_wt<NT>(g + w, make_float4(lds[lds_word(w, padded, magic)], lds[lds_word(w + 1u, padded, magic)],
+                                              lds[lds_word(w + 2u, padded, magic)], lds[lds_word(w + 3u, padded, magic)]));
+        }
+    } else {
+        const unsigned total = (unsigned)(rows * S);
+        for (unsigned w = tid; w < total; w += nt) g[w] = lds[lds_word(w, padded, magic)];
+    }
+}
+
 // Sum over the 64 lanes of a wave, result valid in lane 63: DPP row shifts, then row broadcasts (fixed order).
 // Lanes that are shifted in from outside a row or masked off receive `old` = 0, i.e. they add nothing.
 #define DRM_DPP_ADD(v, ctrl, row_mask) \
@@ -343,15 +363,5 @@ static int ensure_lds(K kernel, size_t bytes) {
     }
     return DRM_OK;
 }
-
-#define DRM_DISPATCH_CAP(cap, CALL)                  \
-    switch (cap) {                                   \
-    case 4: { constexpr int C = 4; CALL; } break;    \
-    case 8: { constexpr int C = 8; CALL; } break;    \
-    case 12: { constexpr int C = 12; CALL; } break;  \
-    case 16: { constexpr int C = 16; CALL; } break;  \
-    case 24: { constexpr int C = 24; CALL; } break;  \
-    default: { constexpr int C = 32; CALL; } break;  \
-    }
 
 } // namespace drm

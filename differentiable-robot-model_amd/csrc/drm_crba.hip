@@ -2,84 +2,74 @@
 //
 // Replaces DifferentiableRobotModel.compute_lagrangian_inertia_matrix (robot_model.py:402-450), which runs n + 1
 // full inverse-dynamics passes (each ~11 k tiny torch ops) and subtracts the gravity pass; see drm_sample.hpp
-// crba_walk for why the composite-rigid-body form computes the same matrix.
+// ("Joint-space inertia matrix") for why the composite-rigid-body form computes the same matrix.
 //
 // Per sample: in q[n] (4 n bytes), out H[n, n] (4 n^2 bytes).          n = 7: 28 + 196 = 224 B, ~2 kflop
-// LDS per wave: [ q : 64 (n|1) ][ H : 64 (n^2|1) ][ inertia slots : n_slots*10*64 ][ axis slots : n_slots*depth*6*64 ]
-// (depth = DRM_WALK_BRANCH_DEPTH: a slot holds the axes of the branch point and of the ops above it)
-// When the H tile does not fit in LDS (n > ~20) lanes store their entries straight to HBM (uncoalesced, rare).
+// 7-DoF arm chains run crba_arm_kernel below; every other robot the loop-structured kernel.
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
-template <int CAP, bool DIRECT>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    crba_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int sdepth,
-                int zero_fill,
-                const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t magic_h,
-                int lds_per_wave, uint32_t align) {
+// Loop-structured composite-rigid-body algorithm of any robot (drm_tree.hpp crba_tree_walk): one tile of 64 samples per
+// block, one wavefront per segment — the sub-trees off the fixed root give the diagonal blocks of H, everything between
+// two of them is a structural zero (the block zero-fills the tile once, the wavefronts write their blocks).
+// LDS: [ table ][ q : 64 (n|1) ][ H : 64 (n^2|1), unless DIRECT ] shared, then per wavefront
+//      [ cos / sin / value per op : max_seg_ops * 3 * 64 ][ inertia slots : n_slots * 10 * 64 ]
+// DIRECT: the H tile does not fit (n > ~23): lanes store their entries straight to HBM over a zeroed H.
+template <bool DIRECT>
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t magic_h,
+                     uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    WaveCtx cx;
-    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
-    const unsigned lane = cx.lane;
-    const int nn = n * n;
+    const TileCtx tc = tile_begin(B);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, nn = n * n;
     const int Sq = pad_odd(n), Sh = DIRECT ? 0 : pad_odd(nn);
-    float *lq = cx.lds;
+    float *lq = smem + table_lds_floats(a.n_ops);
     float *lh = lq + round4(WAVE * Sq);
-    float *lis = lh + round4(WAVE * Sh);              // inertia slots [slot][10][64]
-    float *lss = lis + n_slots * (10 * WAVE);         // axis slots    [slot][op < sdepth][6][64]
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    float *ltr = smem + a.wave_off[wave];                          // [op - first][3][64]
+    float *lis = ltr + (last - first) * (CRBA_PARK_FLOATS * WAVE); // inertia slots [slot][10][64]
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q), cx.full && (align & AL_Q));
-    for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
+    const TableLds tab = stage_tree_table(a, smem);
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
+    for (int s = 0; s < a.n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
+    if (!DIRECT) { // pairs of joints on different branches / in different segments
+        const unsigned total = (unsigned)round4(WAVE * Sh);
+        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) lh[i] = 0.0f;
+    }
+    __syncthreads();
+
+    const bool live = (int)lane < tc.rows;
+    const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row read zero angles, their H is never stored
     float *hrow = lh + lane * Sh;
-    if (!DIRECT && zero_fill)
-        for (int i = 0; i < nn; ++i) hrow[i] = 0.0f; // pairs of joints on different branches
-    wave_lds_sync();
-
-    const bool live = (int)lane < cx.rows;
-    const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row compute garbage, never stored
-    float *hdst = H + (cx.b0 + lane) * nn;
-    // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
-    // the rare large-angle sincos path, which would change the rounding of the live lanes from run to run
-    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
-    auto islot_add = [&](int s, const Inertia &a) {
-        float *b = lis + s * (10 * WAVE) + lane;
-        b[0] += a.m;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) b[(1 + i) * WAVE] += a.h[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) b[(4 + i) * WAVE] += a.I[i];
-    };
-    auto islot_take = [&](int s, Inertia &a) {
-        float *b = lis + s * (10 * WAVE) + lane;
-        a.m += b[0]; b[0] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { a.h[i] += b[(1 + i) * WAVE]; b[(1 + i) * WAVE] = 0.0f; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
-    };
-    auto sslot_save = [&](int s, int j, const Axis &a) {
-        float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
-    };
-    auto sslot_load = [&](int s, int j, Axis &a) {
-        const float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
-    };
-    auto hout = [&](int di, int dj, float v) {
-        if (DIRECT) {
-            if (live) hdst[di * n + dj] = v;
-        } else {
-            hrow[di * n + dj] = v;
-        }
-    };
-    crba_walk<CAP>(ops_f, ops_i, qf, islot_add, islot_take, sslot_save, sslot_load, hout);
+    float *hdst = H + (tc.b0 + lane) * nn;
+    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    crba_prepare(first, last, ctl, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
+                 [&](int k, float c, float s, float x) {
+                     float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+                     b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
+                 });
+    crba_tree_walk(
+        first, last, ctl, [&](int k) { return tab.row(k); },
+        [&](int k, float &c, float &s, float &x) {
+            const float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+            c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+        },
+        [&](int s, const Inertia &I) { lds_add_inertia(lis, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lis, s, lane, I); },
+        [&](int di, int dj, float v) {
+            if (DIRECT) {
+                if (live) hdst[di * n + dj] = v;
+            } else {
+                hrow[di * n + dj] = v;
+            }
+        });
     if (!DIRECT) {
-        wave_lds_sync();
-        tile_store<0>(H + cx.b0 * nn, cx.rows, nn, magic_h, lh, lane, cx.full && (nn & 1) && (align & AL_TAU), cx.full && (align & AL_TAU));
+        __syncthreads();
+        block_tile_store(H + tc.b0 * nn, tc.rows, nn, magic_h, lh, tc.full && (align & AL_TAU)); // 256 n^2 bytes: every wavefront helps
     }
 }
 
@@ -148,35 +138,38 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
         return drm_crba(&generic, q + done * n, B - done, H + done * nn, stream);
     }
 #endif
-    const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
-    if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
-    const int base = round4(WAVE * pad_odd(n)) + w->n_slots * (10 + sdepth * 6) * WAVE;
-    // the H tile of a wave is 256 n^2 bytes: beyond 32 KB (n >= 12) it decides how many waves a CU can hold, and a
-    // branching robot's H is mostly structural zeros — write the entries straight to HBM over a memset instead
-    // (Allegro, n = 16, 65 536 samples: see profiles/r01_kernel_times.txt)
-    const bool direct = (size_t)round4(WAVE * pad_odd(nn)) * sizeof(float) > (size_t)32 * 1024 ||
-                        (size_t)(base + round4(WAVE * pad_odd(nn))) * sizeof(float) > (size_t)MAX_LDS_BYTES;
-    Geometry g;
-    rc = make_geometry(B, base + (direct ? 0 : round4(WAVE * pad_odd(nn))), g);
-    if (rc) return rc;
-    const int zero_fill = (w->shape & DRM_WALK_ARM_CHAIN) ? 0 : 1; // a chain over all DoFs writes every entry
-    if (direct && zero_fill) {
+    if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
+    if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
+    TreeArgs a = tree_args(w);
+    const size_t tile = (size_t)round4(WAVE * pad_odd(nn));
+    auto plan = [&](TreeArgs &t, bool with_tile) {
+        const size_t shared = (size_t)table_lds_floats(t.n_ops) + round4(WAVE * pad_odd(n)) + (with_tile ? tile : 0);
+        return sizeof(float) * layout_waves(t, shared, CRBA_PARK_FLOATS * WAVE, t.n_slots * 10 * WAVE, [](int) { return 0; });
+    };
+    // the H tile of a block is 256 n^2 bytes; when it does not fit a CU's LDS next to the rest the entries go straight to HBM
+    // over a memset instead (n > ~23)
+    bool direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
+    size_t lds = plan(a, !direct);
+    if (lds > (size_t)MAX_LDS_BYTES && a.n_segments > 1) {
+        a = tree_args(w, true);
+        direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
+        lds = plan(a, !direct);
+    }
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+    const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
+    if (direct) {
         hipError_t e = hipMemsetAsync(H, 0, sizeof(float) * (size_t)B * nn, s);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+        rc = ensure_lds_tree(crba_tree_kernel<true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(crba_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n),
+                           div_magic(nn), align);
+    } else {
+        rc = ensure_lds_tree(crba_tree_kernel<false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(crba_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n),
+                           div_magic(nn), align);
     }
-    const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
-    DRM_DISPATCH_CAP(w->capacity, {
-        if (direct) {
-            rc = ensure_lds(crba_kernel<C, true>, g.lds_bytes);
-            if (rc) return rc;
-            hipLaunchKernelGGL((crba_kernel<C, true>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                               (int)w->n_slots, sdepth, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
-        } else {
-            rc = ensure_lds(crba_kernel<C, false>, g.lds_bytes);
-            if (rc) return rc;
-            hipLaunchKernelGGL((crba_kernel<C, false>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                               (int)w->n_slots, sdepth, zero_fill, q, B, H, div_magic(n), div_magic(nn), g.lds_per_wave, align);
-        }
-    })
     return launched();
 }

@@ -8,111 +8,90 @@
 // LDS per wave: [ q tile : 64 (n|1) ][ staging : 64 max(3n|1, 3) ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
-// NDOF > 0 fixes the row width at compile time (tile copies fully unrolled, immediate LDS offsets).
-template <int CAP, int NDOF>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    fk_jacobian_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n_rt, uint64_t dof_mask,
-                       const float *__restrict__ q, int64_t B, float *__restrict__ pos, float *__restrict__ quat,
-                       float *__restrict__ lin, float *__restrict__ ang, uint32_t magic_q, uint32_t magic_j,
-                       int lds_per_wave, uint32_t align, int target_perm) {
+// Loop-structured FK + Jacobian of one chain of any robot (drm_tree.hpp fk_jacobian_tree_walk): one wavefront per tile.
+// The walk leaves the world axis z_k of every moving joint in the ang_jac tile and its origin p_k in the lin_jac tile
+// (same positions); once the end position is known a second loop over the chain turns p_k into z_k x (p_e - p_k)
+// (robot_model.py:661; a prismatic joint's column is (z_k, 0)).  Columns of DoFs off the chain stay zero.
+// LDS: [ table ][ q : 64 (n|1) ][ pos : 64 x 3 ][ lin : 64 (3n|1) ][ ang : 64 (3n|1) ]
+__global__ void __launch_bounds__(WAVE)
+    fk_jacobian_tree_kernel(TreeArgs a, uint64_t dof_mask, const float *__restrict__ q, int64_t B, float *__restrict__ pos,
+                            float *__restrict__ quat, float *__restrict__ lin, float *__restrict__ ang, uint32_t magic_q,
+                            uint32_t magic_j, uint32_t align, int target_perm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    WaveCtx cx;
-    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
-    const unsigned lane = cx.lane;
-    const int n = NDOF ? NDOF : n_rt;
-    const int Sq = pad_odd(n), Sj = pad_odd(3 * n);
-    float *lq = cx.lds;
-    float *stage = cx.lds + round4(WAVE * Sq);
+    const TileCtx tc = tile_begin(B);
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), Sj = pad_odd(3 * n);
+    float *lq = smem + table_lds_floats(a.n_ops);
+    float *lp = lq + round4(WAVE * Sq);
+    float *ll = lp + round4(WAVE * 3);
+    float *la = ll + round4(WAVE * Sj);
 
-    // the wave-uniform DoF column of every op in one wide scalar load; the float table's cache
-    // lines are touched now so their misses overlap with the q tile load
-    int dof[CAP];
-    load_field<CAP>(ops_i, DRM_OPI_DOF, dof);
-    WarmRegs<CAP> warm;
-    warm_walk_issue<CAP, 1>(ops_f, warm);
-    tile_load<NDOF>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, cx.full && (n & 1) && (align & AL_Q), cx.full && (align & AL_Q));
-    warm_walk_wait(warm);
+    const TableLds tab = stage_tree_table(a, smem);
+    tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
     wave_lds_sync();
 
-    // lanes beyond the last valid row of a partial tile read stale LDS and compute garbage that is
-    // never stored (the arithmetic is branch-free, so garbage is harmless)
-    const bool live = (int)lane < cx.rows;
+    // lanes beyond the last valid row of a partial tile compute garbage that is never stored; they read zero angles
+    const bool live = (int)lane < tc.rows;
     const float *qrow = lq + lane * Sq;
-    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; }; // zeros, not stale LDS, past a partial tile
-
-    Pose ee;
-    float z[CAP][3], pj[CAP][3];
-    fk_chain<CAP>(ops_f, dof, qf, ee, z, pj);
-
-    // ---- pos [B,3]: 3 floats per lane -> LDS -> coalesced store ------------------------
-    if (pos) {
-        stage[lane * 3 + 0] = ee.p[0];
-        stage[lane * 3 + 1] = ee.p[1];
-        stage[lane * 3 + 2] = ee.p[2];
-        wave_lds_sync();
-        tile_store<3>(pos + cx.b0 * 3, cx.rows, 3, 0u, stage, lane, cx.full && (align & AL_POS));
-        wave_lds_sync();
+    float *lrow = ll + lane * Sj, *arow = la + lane * Sj;
+    const uint64_t all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    if ((dof_mask & all) != all) {
+        for (int d = 0; d < n; ++d)
+            if (!((dof_mask >> d) & 1ull)) {
+                lrow[d] = 0.0f; lrow[n + d] = 0.0f; lrow[2 * n + d] = 0.0f;
+                arow[d] = 0.0f; arow[n + d] = 0.0f; arow[2 * n + d] = 0.0f;
+            }
     }
+    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    PoseP ee;
+    fk_jacobian_tree_walk(a.n_ops, ctl, [&](int k) { return tab.row(k); }, [&](int d) -> float { return live ? qrow[d] : 0.0f; }, ee,
+                          [&](int d, const float *z, const float *p, bool) {
+                              arow[d] = z[0]; arow[n + d] = z[1]; arow[2 * n + d] = z[2];
+                              lrow[d] = p[0]; lrow[n + d] = p[1]; lrow[2 * n + d] = p[2];
+                          });
+    Pose E;
+    pose_from_pairs(ee, E);
+#pragma unroll 1
+    for (int k = 0; k < a.n_ops; ++k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding || ct.dof < 0) continue;
+        const int d = ct.dof;
+        const float z[3] = {arow[d], arow[n + d], arow[2 * n + d]};
+        if (ct.prismatic) {
+            lrow[d] = z[0]; lrow[n + d] = z[1]; lrow[2 * n + d] = z[2];
+            arow[d] = 0.0f; arow[n + d] = 0.0f; arow[2 * n + d] = 0.0f;
+        } else {
+            const float dp[3] = {E.p[0] - lrow[d], E.p[1] - lrow[n + d], E.p[2] - lrow[2 * n + d]};
+            float c[3];
+            cross3(z, dp, c);
+            lrow[d] = c[0]; lrow[n + d] = c[1]; lrow[2 * n + d] = c[2];
+        }
+    }
+    if (pos) { lp[lane * 3 + 0] = E.p[0]; lp[lane * 3 + 1] = E.p[1]; lp[lane * 3 + 2] = E.p[2]; }
+    wave_lds_sync();
+    const bool fast_j = tc.full, odd_j = (3 * n) & 1;
+    tile_store<0>(ang + tc.b0 * 3 * n, tc.rows, 3 * n, magic_j, la, lane, fast_j && odd_j && (align & AL_ANG), fast_j && (align & AL_ANG));
+    tile_store<0>(lin + tc.b0 * 3 * n, tc.rows, 3 * n, magic_j, ll, lane, fast_j && odd_j && (align & AL_LIN), fast_j && (align & AL_LIN));
+    if (pos) tile_store<3>(pos + tc.b0 * 3, tc.rows, 3, 0u, lp, lane, tc.full && (align & AL_POS));
     // ---- quat [B,4]: one 16-byte store per lane is already coalesced -------------------
     if (quat && live) {
-        // the target is the last REAL op; padding ops are identities, so `ee` still carries the
-        // target's canonical frame: undo its column permutation before the quaternion
-        float Ru[9], qt[4];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Ru[i] = ee.R[i];
-        unpermute(target_perm, Ru);
-        quat_xyzw(Ru, qt);
-        float *dst = quat + (cx.b0 + lane) * 4;
+        // the target is the last REAL op: undo its column permutation before the quaternion
+        float qt[4];
+        unpermute(target_perm, E.R);
+        quat_xyzw(E.R, qt);
+        float *dst = quat + (tc.b0 + lane) * 4;
         if (align & AL_QUAT) {
             store16_wt(dst, make_float4(qt[0], qt[1], qt[2], qt[3]));
         } else {
             dst[0] = qt[0]; dst[1] = qt[1]; dst[2] = qt[2]; dst[3] = qt[3];
         }
     }
-    // ---- Jacobians [B,3,n]: column d of op k at row offset r*n + d ----------------------
-    float *jrow = stage + lane * Sj;
-    const uint64_t all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    const bool fast_j = cx.full; // 3n is odd iff n is odd; checked per tensor below
-    const bool odd_j = (3 * n) & 1;
-
-    // linear part: z_k x (p_e - p_k)   (robot_model.py:661)
-    if ((dof_mask & all) != all) {
-        for (int d = 0; d < n; ++d)
-            if (!((dof_mask >> d) & 1ull)) { jrow[d] = 0.0f; jrow[n + d] = 0.0f; jrow[2 * n + d] = 0.0f; }
-    }
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-        const int d = dof[k];
-        if (d >= 0) {
-            const float dp[3] = {ee.p[0] - pj[k][0], ee.p[1] - pj[k][1], ee.p[2] - pj[k][2]};
-            float c[3];
-            cross3(z[k], dp, c);
-            jrow[d] = c[0];
-            jrow[n + d] = c[1];
-            jrow[2 * n + d] = c[2];
-        }
-    }
-    wave_lds_sync();
-    tile_store<3 * NDOF>(lin + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_LIN),
-                         fast_j && (align & AL_LIN));
-    wave_lds_sync();
-
-    // angular part: z_k   (robot_model.py:662); the off-chain zeros are still in place
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-        const int d = dof[k];
-        if (d >= 0) {
-            jrow[d] = z[k][0];
-            jrow[n + d] = z[k][1];
-            jrow[2 * n + d] = z[k][2];
-        }
-    }
-    wave_lds_sync();
-    tile_store<3 * NDOF>(ang + cx.b0 * 3 * n, cx.rows, 3 * n, magic_j, stage, lane, fast_j && odd_j && (align & AL_ANG),
-                         fast_j && (align & AL_ANG));
 }
 
 } // namespace drm
@@ -128,22 +107,9 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
     if (w->target_perm < 0 || w->target_perm > 5) return fail(DRM_ERR_INVALID, "target_perm must be in 0..5");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs;
-    const int Sq = pad_odd(n), Sj = pad_odd(3 * n);
-    Geometry g;
-    rc = make_geometry(B, round4(WAVE * Sq) + round4(WAVE * (Sj > 3 ? Sj : 3)), g);
-    if (rc) return rc;
     const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT) | al16(lin_jac, AL_LIN) |
                            al16(ang_jac, AL_ANG);
-    const uint32_t mq = div_magic(n), mj = div_magic(3 * n);
     hipStream_t s = (hipStream_t)stream;
-#define DRM_LAUNCH_FKJ(C, N)                                                                                         \
-    {                                                                                                                \
-        rc = ensure_lds(fk_jacobian_kernel<C, N>, g.lds_bytes);                                                      \
-        if (rc) return rc;                                                                                           \
-        hipLaunchKernelGGL((fk_jacobian_kernel<C, N>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,       \
-                           w->dof_mask, q, B, pos, quat, lin_jac, ang_jac, mq, mj, g.lds_per_wave, align,            \
-                           (int)w->target_perm);                                                             \
-    }
     const uint32_t all_al = AL_Q | AL_POS | AL_QUAT | AL_LIN | AL_ANG;
 #ifdef DRM_NO_ARM_KERNEL
     if (false) {
@@ -164,11 +130,18 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
             return drm_fk_jacobian(&generic, q + done * n, B - done, pos + done * 3, quat + done * 4,
                                    lin_jac + done * 3 * n, ang_jac + done * 3 * n, stream);
         }
-    } else if (w->capacity == 8 && n == 7) {
-        DRM_LAUNCH_FKJ(8, 7) // 7-DoF robots, ragged / unaligned / partial-output calls: static tile shapes
     } else {
-        DRM_DISPATCH_CAP(w->capacity, DRM_LAUNCH_FKJ(C, 0))
+        if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
+        TreeArgs a = tree_args(w);
+        a.n_segments = 1; a.prefix_end = 0;
+        const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(WAVE * 3) +
+                                                    2 * round4(WAVE * pad_odd(3 * n)));
+        rc = ensure_lds_tree(fk_jacobian_tree_kernel, lds);
+        if (rc) return rc;
+        const int64_t tiles = (B + WAVE - 1) / WAVE;
+        if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+        hipLaunchKernelGGL(fk_jacobian_tree_kernel, dim3((unsigned)tiles), dim3(WAVE), lds, s, a, w->dof_mask, q, B, pos, quat, lin_jac,
+                           ang_jac, div_magic(n), div_magic(3 * n), align, (int)w->target_perm);
     }
-#undef DRM_LAUNCH_FKJ
     return launched();
 }

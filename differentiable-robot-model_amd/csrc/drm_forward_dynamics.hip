@@ -3,129 +3,134 @@
 // Replaces DifferentiableRobotModel.compute_forward_dynamics (robot_model.py:487-624, Featherstone's
 // articulated-body algorithm written as three Python loops over the links with 6x6 bmm's per link).  The
 // articulated-body recursion is an O(n) elimination of the linear system H qdd = f - nle; this kernel forms the same
-// system with the two walks it already has — crba_walk for H, rnea_walk with qdd = 0 for the bias torques nle — and
-// solves it per sample by Cholesky in LDS (n <= ~20: ~n^3/3 FMAs, less than one of the walks).  Same result up to
-// fp32 rounding amplified by cond(H), like the reference's own recursion (tolerances in tests/).
+// system with the two walks it already has — the composite-rigid-body walk for H, RNEA with qdd = 0 for the bias torques
+// nle — and solves it per sample by an L^T D L factorisation taken from the leaves to the root, the elimination order of
+// the articulated-body recursion (~n^3/3 FMAs, less than one of the walks).  Same result up to fp32 rounding amplified by
+// the conditioning of the sub-trees, like the reference's own recursion (tolerances in tests/).
 //
 // Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
-// LDS per wave: [ q qd f : 3 x 64 (n|1) ][ lower triangle of H : 64 (n(n+1)/2 | 1) ]
-//               [ slots : n_slots * max(10 + 6 depth, 18) * 64, the two walks use them one after the other ]
+// 7-DoF arm chains run forward_dynamics_arm_kernel below; every other robot the loop-structured kernel.
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
-template <int CAP>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    forward_dynamics_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots,
-                            int sdepth, int flags, int zero_fill, const float *__restrict__ q, const float *__restrict__ qd,
-                            const float *__restrict__ f, int64_t B, float *__restrict__ qdd, uint32_t magic_q,
-                            int lds_per_wave, uint32_t align) {
+// Loop-structured forward dynamics of any robot: one tile of 64 samples per block, one wavefront per segment of the walk.
+// Segments are independent (their joints share no link that moves), so H is block diagonal: every wavefront forms ITS
+// block (drm_tree.hpp crba_tree_walk, packed lower triangle with segment-local DoF indices), the bias torques of its
+// joints (rnea_tree_walk with qdd = 0, robot_model.py:377-400) and solves its block by the leaf-to-root L^T D L
+// factorisation (drm_sample.hpp ltdl_solve) — an Allegro hand is four 4 x 4 systems per sample, not one 16 x 16.
+// LDS: [ table ][ q ][ qd ][ f -> rhs -> qdd ] shared, then per wavefront
+//      [ records : max_seg_ops * 9 * 64 (RNEA; CRBA's cos / sin / value first) ][ slots : n_slots * 18 * 64 ]
+//      [ triangle : 64 (nt|1), nt = largest block's n (n + 1) / 2 — unless HBM ]
+// HBM: the triangle lives in caller-provided scratch, [tile][segment][entry][64] (robots beyond ~30 DoF per segment).
+template <bool HBM>
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    forward_dynamics_tree_kernel(TreeArgs a, int flags, int nt_max, const float *__restrict__ q, const float *__restrict__ qd,
+                                 const float *__restrict__ f, int64_t B, float *__restrict__ qdd, float *__restrict__ scratch,
+                                 uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    WaveCtx cx;
-    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
-    const unsigned lane = cx.lane;
-    const int nn = n * (n + 1) / 2; // packed lower triangle
-    const int Sq = pad_odd(n), Sh = pad_odd(nn), region = round4(WAVE * Sq);
-    float *lq = cx.lds, *lqd = lq + region, *lf = lqd + region;
-    float *lh = lf + region;
-    float *lis = lh + round4(WAVE * Sh);             // crba inertia slots [slot][10][64]
-    float *lss = lis + n_slots * (10 * WAVE);        // crba axis slots    [slot][op < sdepth][6][64]
-    float *lms = lis;                                // rnea motion slots  [slot][12][64]   (same memory, later)
-    float *lfs = lms + n_slots * (12 * WAVE);        // rnea force slots   [slot][6][64]
-    const bool fast = cx.full && (n & 1);
+    const TileCtx tc = tile_begin(B);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lf = lqd + region;
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
+    float *park = smem + a.wave_off[wave];
+    float *lsl = park + (last - first) * (RNEA_PARK_FLOATS * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
+    float *lms = lsl, *lfs = lsl + a.n_slots * (12 * WAVE);
+    float *ltri = lsl + a.n_slots * (18 * WAVE) + lane * pad_odd(nt); // this lane's packed triangle (LDS form)
+    float *gtri = HBM ? scratch + ((int64_t)blockIdx.x * a.n_segments + wave) * (int64_t)nt_max * WAVE + lane : nullptr;
+    auto tri = [&](int i) -> float & { return HBM ? gtri[(int64_t)i * WAVE] : ltri[i]; };
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q), cx.full && (align & AL_Q));
-    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), cx.full && (align & AL_QD));
-    tile_load<0>(f + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_QDD), cx.full && (align & AL_QDD));
-    for (int s = 0; s < n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
-    float *hrow = lh + lane * Sh;
-    if (zero_fill)
-        for (int i = 0; i < nn; ++i) hrow[i] = 0.0f; // pairs of joints on different branches
-    wave_lds_sync();
+    const TableLds tab = stage_tree_table(a, smem);
+    const bool fast = tc.full && (n & 1);
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+    if (wave == (a.n_segments > 1 ? 1 : 0))
+        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+    if (wave == (a.n_segments > 2 ? 2 : 0))
+        tile_load<0>(f + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
+    for (int s = 0; s < a.n_slots * 10; ++s) lsl[s * WAVE + lane] = 0.0f;
+    for (int i = 0; i < nt; ++i) tri(i) = 0.0f; // pairs of joints on different branches
+    __syncthreads();
 
     // lanes past a partial tile read zeros (see drm_fk.hip); their H is then a valid inertia matrix as well
-    const bool live = (int)lane < cx.rows;
+    const bool live = (int)lane < tc.rows;
     const unsigned row = lane * Sq;
-    auto qf1 = [&](int d) -> float { return live ? lq[row + d] : 0.0f; };
-    {
-        auto islot_add = [&](int s, const Inertia &a) {
-            float *b = lis + s * (10 * WAVE) + lane;
-            b[0] += a.m;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) b[(1 + i) * WAVE] += a.h[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b[(4 + i) * WAVE] += a.I[i];
-        };
-        auto islot_take = [&](int s, Inertia &a) {
-            float *b = lis + s * (10 * WAVE) + lane;
-            a.m += b[0]; b[0] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { a.h[i] += b[(1 + i) * WAVE]; b[(1 + i) * WAVE] = 0.0f; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
-        };
-        auto sslot_save = [&](int s, int j, const Axis &a) {
-            float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { b[i * WAVE] = a.ang[i]; b[(3 + i) * WAVE] = a.lin[i]; }
-        };
-        auto sslot_load = [&](int s, int j, Axis &a) {
-            const float *b = lss + (s * sdepth + j) * (6 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { a.ang[i] = b[i * WAVE]; a.lin[i] = b[(3 + i) * WAVE]; }
-        };
-        auto hout = [&](int di, int dj, float v) {
-            if (di >= dj) hrow[tri_index(di, dj)] = v;
-        };
-        crba_walk<CAP>(ops_f, ops_i, qf1, islot_add, islot_take, sslot_save, sslot_load, hout);
-    }
+    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    auto rowf = [&](int k) { return tab.row(k); };
+    crba_prepare(first, last, ctl, [&](int d) -> float { return live ? lq[row + d] : 0.0f; },
+                 [&](int k, float c, float s, float x) {
+                     float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+                     b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
+                 });
+    crba_tree_walk(
+        first, last, ctl, rowf,
+        [&](int k, float &c, float &s, float &x) {
+            const float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+            c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+        },
+        [&](int s, const Inertia &I) { lds_add_inertia(lsl, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lsl, s, lane, I); },
+        [&](int di, int dj, float v) {
+            if (di >= dj) tri(tri_index(di - lo, dj - lo)) = v;
+        });
     wave_lds_sync(); // the composite-inertia walk is done with the slot memory
-    for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
+    for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();
-    {
-        // bias torques: RNEA with zero joint accelerations (robot_model.py:377-400); rhs = f - nle, over f
-        auto qf3 = [&](int d, float &a, float &v, float &acc) {
-            a = live ? lq[row + d] : 0.0f;
+    // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f
+    rnea_tree_walk(
+        a.prefix_end, first, last, ctl, rowf, flags,
+        [&](int d, float &x, float &v, float &acc) {
+            x = live ? lq[row + d] : 0.0f;
             v = lqd[row + d];
             acc = 0.0f;
-        };
-        auto tau_out = [&](int d, float v) { lf[row + d] -= v; };
-        auto motion_save = [&](int s, const Motion &M) {
-            float *b = lms + s * (12 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                b[i * WAVE] = M.wa[i][0]; b[(3 + i) * WAVE] = M.va[i][0]; b[(6 + i) * WAVE] = M.wa[i][1];
-                b[(9 + i) * WAVE] = M.va[i][1];
-            }
-        };
-        auto motion_load = [&](int s, Motion &M) {
-            const float *b = lms + s * (12 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                M.wa[i] = f2_make(b[i * WAVE], b[(6 + i) * WAVE]);
-                M.va[i] = f2_make(b[(3 + i) * WAVE], b[(9 + i) * WAVE]);
-            }
-        };
-        auto force_add = [&](int s, const Force &F) {
-            float *b = lfs + s * (6 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { b[i * WAVE] += F.la[i][0]; b[(3 + i) * WAVE] += F.la[i][1]; }
-        };
-        auto force_take = [&](int s, Force &F) {
-            float *b = lfs + s * (6 * WAVE) + lane;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                F.la[i] += f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
-                b[i * WAVE] = 0.0f; b[(3 + i) * WAVE] = 0.0f;
-            }
-        };
-        rnea_walk<CAP>(ops_f, ops_i, flags, qf3, tau_out, motion_save, motion_load, force_add, force_take);
-    }
-    cholesky_solve(n, hrow, lf + row);
-    wave_lds_sync();
-    tile_store<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
+        },
+        [&](int d, float v) { lf[row + d] -= v; },
+        [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
+        [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
+        [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
+        [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+    ltdl_solve_acc(cnt, tri, lf + row + lo);
+    __syncthreads();
+    if (wave == 0)
+        tile_store<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
 }
+
+// geometry of a launch: LDS bytes with the triangle in LDS, or (hbm = true) in scratch
+struct FdPlan {
+    TreeArgs a;
+    int nt_max;
+    bool hbm;
+    size_t lds;
+};
+static FdPlan fd_plan(const drm_walk *w) {
+    FdPlan p;
+    auto lay = [&](bool single, bool hbm) {
+        p.a = tree_args(w, single);
+        p.nt_max = 1;
+        for (int s = 0; s < p.a.n_segments; ++s) {
+            const int c = p.a.seg_dof_cnt[s], nt = c * (c + 1) / 2;
+            if (nt > p.nt_max) p.nt_max = nt;
+        }
+        const TreeArgs &a = p.a;
+        const size_t shared = (size_t)table_lds_floats(a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(a.n));
+        p.hbm = hbm;
+        p.lds = sizeof(float) * layout_waves(p.a, shared, RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE, [&](int s) {
+            const int c = a.seg_dof_cnt[s];
+            return hbm ? 0 : round4(WAVE * pad_odd(c * (c + 1) / 2));
+        });
+        return p.lds <= (size_t)MAX_LDS_BYTES;
+    };
+    // in order of preference: fanned out with the triangles in LDS, one wavefront with its triangle in LDS, triangles in HBM
+    if (lay(false, false)) return p;
+    if (w->n_segments > 1 && lay(true, false)) return p;
+    if (lay(false, true)) return p;
+    lay(true, true);
+    return p;
+}
+
 
 // Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,
 // rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled Cholesky; constants
@@ -184,7 +189,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                         });
 #pragma unroll
     for (int d = 0; d < NJ; ++d) rhs[d] -= nle[d];
-    cholesky_solve_unrolled<NJ>(Ht, rhs);
+    ltdl_solve_unrolled<NJ>(Ht, rhs);
     wave_lds_sync(); // every lane is done with the parking area before qdd is staged over it
 #pragma unroll
     for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = rhs[d];
@@ -196,14 +201,22 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
 using namespace drm;
 
+extern "C" int64_t drm_forward_dynamics_scratch_floats(const drm_walk *w, int64_t B) {
+    if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) return 0;
+    const FdPlan p = fd_plan(w);
+    if (!p.hbm) return 0;
+    return ((B + WAVE - 1) / WAVE) * (int64_t)p.a.n_segments * p.nt_max * WAVE;
+}
+
 extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B,
-                                    int32_t flags, float *qdd, void *stream) {
+                                    int32_t flags, float *qdd, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !qd || !f || !qdd) return fail(DRM_ERR_INVALID, "q / qd / f / qdd must not be NULL");
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
-    const int n = w->n_dofs, nn = n * (n + 1) / 2;
+    const int n = w->n_dofs;
 #ifndef DRM_NO_ARM_KERNEL
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
@@ -220,24 +233,28 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         drm_walk generic = *w;
         generic.shape &= ~DRM_WALK_ARM_CHAIN;
         return drm_forward_dynamics(&generic, q + done * n, qd + done * n, f + done * n, B - done, flags, qdd + done * n,
-                                    stream);
+                                    scratch, stream);
     }
 #endif
-    const int sdepth = DRM_WALK_BRANCH_DEPTH(w->shape);
-    if (w->n_slots > 0 && sdepth == 0) return fail(DRM_ERR_INVALID, "walk has save slots but no branch depth in shape");
-    Geometry g;
-    rc = make_geometry(B, 3 * round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(nn)) +
-                              w->n_slots * ((10 + 6 * sdepth) > 18 ? (10 + 6 * sdepth) : 18) * WAVE, g);
-    if (rc) return fail(DRM_ERR_UNSUPPORTED, "forward dynamics keeps the %s%ld x %ld inertia matrix (lower triangle) of 64 samples in LDS; "
-                                             "this robot does not fit", "", (long)n, (long)n);
-    const int zero_fill = (w->shape & DRM_WALK_ARM_CHAIN) ? 0 : 1;
+    if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
+    if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
+    const FdPlan p = fd_plan(w);
+    if (p.hbm && !scratch)
+        return fail(DRM_ERR_INVALID, "this robot's inertia matrix does not fit in LDS: pass drm_forward_dynamics_scratch_floats() floats of scratch");
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
     hipStream_t s = (hipStream_t)stream;
-    DRM_DISPATCH_CAP(w->capacity, {
-        rc = ensure_lds(forward_dynamics_kernel<C>, g.lds_bytes);
+    if (p.hbm) {
+        rc = ensure_lds_tree(forward_dynamics_tree_kernel<true>, p.lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(forward_dynamics_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n,
-                           (int)w->n_slots, sdepth, (int)flags, zero_fill, q, qd, f, B, qdd, div_magic(n), g.lds_per_wave, align);
-    })
+        hipLaunchKernelGGL(forward_dynamics_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags,
+                           p.nt_max, q, qd, f, B, qdd, scratch, div_magic(n), align);
+    } else {
+        rc = ensure_lds_tree(forward_dynamics_tree_kernel<false>, p.lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(forward_dynamics_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags,
+                           p.nt_max, q, qd, f, B, qdd, scratch, div_magic(n), align);
+    }
     return launched();
 }

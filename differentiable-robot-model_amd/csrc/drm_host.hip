@@ -17,8 +17,8 @@ int check_walk(const drm_walk *w) {
     if (!w) return fail(DRM_ERR_INVALID, "walk is NULL");
     if (!w->ops_f || !w->ops_i) return fail(DRM_ERR_INVALID, "walk tables are NULL");
     const int c = w->capacity;
-    if (c != 4 && c != 8 && c != 12 && c != 16 && c != 24 && c != 32)
-        return fail(DRM_ERR_UNSUPPORTED, "walk capacity %s%ld is not one of 4/8/12/16/24/32", "", c);
+    if (c < 4 || (c & 3) || c > 0xffff)
+        return fail(DRM_ERR_INVALID, "walk capacity %s%ld is not a multiple of 4 in [4, 65535]", "", c);
     if (w->n_ops < 0 || w->n_ops > c)
         return fail(DRM_ERR_INVALID, "walk has %s%ld ops but capacity %ld", "", w->n_ops, c);
     if (w->n_dofs < 1 || w->n_dofs > DRM_MAX_DOFS)

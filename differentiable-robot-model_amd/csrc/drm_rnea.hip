@@ -5,77 +5,69 @@
 // compute_non_linear_effects (robot_model.py:377-400, qdd = NULL).
 //
 // Per sample: in q, qd, qdd [n] (12 n bytes), out tau[n] (4 n bytes).   n = 7: 112 B, ~2.6 kflop.
-// LDS per wave: [ q ][ qd ][ qdd ][ tau ] each 64 (n|1), then [ motion slots : n_slots*12*64 ][ force slots : n_slots*6*64 ]
+// 7-DoF arm chains run rnea_arm_kernel (drm_arm_kernels.hip); every other robot the loop-structured kernel below.
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
-template <int CAP>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    rnea_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int n, int n_slots, int flags,
-                const float *__restrict__ q, const float *__restrict__ qd, const float *__restrict__ qdd, int64_t B,
-                float *__restrict__ tau, uint32_t magic_q, int lds_per_wave, uint32_t align) {
+// Loop-structured RNEA of any robot (drm_tree.hpp rnea_tree_walk, block layout in drm_tree_dev.hpp): one tile of 64
+// samples per block, one wavefront per segment of the walk.
+// LDS: [ table ][ q ][ qd ][ qdd ][ tau ] shared, then per wavefront [ records : max_seg_ops * 9 * 64 ]
+//      [ motion slots : n_slots * 12 * 64 ][ force slots : n_slots * 6 * 64 ]   (per-wavefront areas: TreeArgs.wave_off)
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    rnea_tree_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                     const float *__restrict__ qdd, int64_t B, float *__restrict__ tau, uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    WaveCtx cx;
-    if (!wave_begin(B, lds_per_wave, smem, cx)) return;
-    const unsigned lane = cx.lane;
-    const int Sq = pad_odd(n);
-    const int region = round4(WAVE * Sq);
-    float *lq = cx.lds, *lqd = lq + region, *lqdd = lqd + region, *ltau = lqdd + region;
-    float *lms = ltau + region;                 // motion slots [slot][12][64]
-    float *lfs = lms + n_slots * (12 * WAVE);   // force slots  [slot][6][64]
-    const bool fast = cx.full && (n & 1);
+    const TileCtx tc = tile_begin(B);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lqdd = lqd + region, *ltau = lqdd + region;
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    float *park = smem + a.wave_off[wave];
+    float *lms = park + (last - first) * (RNEA_PARK_FLOATS * WAVE); // motion slots [slot][12][64]
+    float *lfs = lms + a.n_slots * (12 * WAVE);                     // force slots  [slot][6][64]
 
-    tile_load<0>(q + cx.b0 * n, cx.rows, n, magic_q, lq, lane, fast && (align & AL_Q), cx.full && (align & AL_Q));
-    tile_load<0>(qd + cx.b0 * n, cx.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), cx.full && (align & AL_QD));
-    if (qdd) tile_load<0>(qdd + cx.b0 * n, cx.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), cx.full && (align & AL_QDD));
-    for (int s = 0; s < n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
-    wave_lds_sync();
+    const TableLds tab = stage_tree_table(a, smem);
+    const bool fast = tc.full && (n & 1);
+    // the three input tiles are loaded by the first three wavefronts of the block (by one, if it is alone)
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+    if (wave == (a.n_segments > 1 ? 1 : 0))
+        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+    if (qdd && wave == (a.n_segments > 2 ? 2 : 0))
+        tile_load<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
+    for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
+    __syncthreads();
 
     // lanes past a partial tile read zeros (not stale LDS): their angles must not be able to push the wave onto
     // the rare large-angle sincos path, which would change the rounding of the live lanes from run to run
     const unsigned row = lane * Sq;
-    const bool live = (int)lane < cx.rows;
+    const bool live = (int)lane < tc.rows;
     const bool has_qdd = qdd != nullptr;
-    auto qf = [&](int d, float &a, float &v, float &acc) {
-        a = live ? lq[row + d] : 0.0f;
-        v = lqd[row + d];
-        acc = has_qdd ? lqdd[row + d] : 0.0f;
-    };
-    auto tau_out = [&](int d, float v) { ltau[row + d] = v; };
-    auto motion_save = [&](int s, const Motion &M) {
-        float *b = lms + s * (12 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            b[i * WAVE] = M.wa[i][0]; b[(3 + i) * WAVE] = M.va[i][0]; b[(6 + i) * WAVE] = M.wa[i][1];
-            b[(9 + i) * WAVE] = M.va[i][1];
-        }
-    };
-    auto motion_load = [&](int s, Motion &M) {
-        const float *b = lms + s * (12 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            M.wa[i] = f2_make(b[i * WAVE], b[(6 + i) * WAVE]);
-            M.va[i] = f2_make(b[(3 + i) * WAVE], b[(9 + i) * WAVE]);
-        }
-    };
-    auto force_add = [&](int s, const Force &F) {
-        float *b = lfs + s * (6 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { b[i * WAVE] += F.la[i][0]; b[(3 + i) * WAVE] += F.la[i][1]; }
-    };
-    auto force_take = [&](int s, Force &F) {
-        float *b = lfs + s * (6 * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            F.la[i] += f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
-            b[i * WAVE] = 0.0f; b[(3 + i) * WAVE] = 0.0f;
-        }
-    };
-    rnea_walk<CAP>(ops_f, ops_i, flags, qf, tau_out, motion_save, motion_load, force_add, force_take);
-    wave_lds_sync();
-    tile_store<0>(tau + cx.b0 * n, cx.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), cx.full && (align & AL_TAU));
+    rnea_tree_walk(
+        a.prefix_end, first, last, [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); },
+        [&](int k) { return tab.row(k); }, flags,
+        [&](int d, float &x, float &v, float &acc) {
+            x = live ? lq[row + d] : 0.0f;
+            v = lqd[row + d];
+            acc = has_qdd ? lqdd[row + d] : 0.0f;
+        },
+        [&](int d, float v) { ltau[row + d] = v; },
+        [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
+        [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
+        [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
+        [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+    __syncthreads();
+    if (wave == 0)
+        tile_store<0>(tau + tc.b0 * n, tc.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
+}
+
+// LDS bytes of a launch (fills a.wave_off)
+static size_t rnea_tree_lds(TreeArgs &a) {
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n));
+    return sizeof(float) * layout_waves(a, shared, RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE, [](int) { return 0; });
 }
 
 } // namespace drm
@@ -90,9 +82,6 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs;
-    Geometry g;
-    rc = make_geometry(B, 4 * round4(WAVE * pad_odd(n)) + w->n_slots * 18 * WAVE, g);
-    if (rc) return rc;
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(tau, AL_TAU);
     hipStream_t s = (hipStream_t)stream;
 #ifndef DRM_NO_ARM_KERNEL
@@ -111,12 +100,20 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
                         tau + done * n, stream);
     }
 #endif
-    DRM_DISPATCH_CAP(w->capacity, {
-        rc = ensure_lds(rnea_kernel<C>, g.lds_bytes);
-        if (rc) return rc;
-        hipLaunchKernelGGL(rnea_kernel<C>, g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, n, (int)w->n_slots,
-                           (int)flags, q, qd, qdd, B, tau, div_magic(n), g.lds_per_wave, align);
-    })
+    if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
+    if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
+    TreeArgs a = tree_args(w);
+    size_t lds = rnea_tree_lds(a);
+    if (lds > (size_t)MAX_LDS_BYTES && a.n_segments > 1) { // the segments do not fit side by side: one wavefront walks them all
+        a = tree_args(w, true);
+        lds = rnea_tree_lds(a);
+    }
+    rc = ensure_lds_tree(rnea_tree_kernel, lds);
+    if (rc) return rc;
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+    hipLaunchKernelGGL(rnea_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd, qdd, B,
+                       tau, div_magic(n), align);
     return launched();
 }
 

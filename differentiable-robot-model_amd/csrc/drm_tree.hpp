@@ -1,0 +1,364 @@
+// drm_tree.hpp — per-sample arithmetic of the LOOP-STRUCTURED forward walks: FK of many targets, FK + Jacobian of one
+// chain, RNEA, the composite-rigid-body inertia matrix and forward dynamics of ANY robot (trees, hands, arms with
+// grippers; revolute / continuous and prismatic joints; any number of links).
+//
+// One lane owns one sample; a walk is a LOOP over the n_ops links of the flattened tree (flatten.py build_walk), one
+// pair of wide control words (DRM_OPI_W0 / W1, include/drm_hip.h) decoded per iteration, the per-link constants read
+// from the op table (LDS in the kernels), nothing indexed by a compile-time op number.  The straight-line walks this
+// replaces were compiled per capacity (4 .. 32 links): rnea<24> held 502 registers, crba<CAP> was O(CAP^2) code, the
+// library took 2.5 minutes to build and stopped at 32 links.  State that outlives an iteration is handed to the caller
+// through callbacks (LDS in the kernels, plain arrays in tests/host_emu):
+//   save slots     the state of a branch point, read by its later children (one slot per open branch point)
+//   per-op records what a second sweep needs from the first (body force + cos / sin of the joint angle)
+// Every joint moves about / along +z of its stored frame (flatten.py folds the axis into the constants): a revolute
+// joint turns it by q (rigid_body.py:146-156), a prismatic joint slides it by q (the reference models those as
+// revolute, robot_model.py:122-126 — SURVEY.md §8 f4 asks for the correct model; reference_compat restores the other).
+//
+// Like drm_sample.hpp this header compiles with g++ for tests/host_emu (test infrastructure only).
+#pragma once
+
+#include "drm_sample.hpp"
+
+namespace drm {
+
+struct OpCtl {
+    int dof, src, save, out, perm, parent; // DRM_OPI_* meanings; parent = op index of the parent link, -1 = root
+    bool child_next, padding, prismatic;
+};
+DRM_HD OpCtl decode_ctl(int w0, int w1) {
+    OpCtl c;
+    c.dof = (w0 & 0xff) - 1;
+    c.src = ((w0 >> 8) & 0xff) - 2;
+    c.save = ((w0 >> 16) & 0xff) - 1;
+    c.child_next = (w0 >> 24) & 1;
+    c.padding = (w0 >> 25) & 1;
+    c.prismatic = (w0 >> 26) & 1;
+    c.perm = (w0 >> 27) & 7;
+    c.out = (w1 & 0xffff) - 1;
+    c.parent = ((w1 >> 16) & 0xffff) - 1;
+    return c;
+}
+
+// sin / cos of one joint angle: sincos_pair's algorithm on scalars (same constants, same operation order), with the
+// same wave-uniform escape to the fp64 reduction for |x| > 1e5
+DRM_HD void sincos_one(float x, float &s, float &c) {
+    if (DRM_WAVE_ANY(!(fabsf(x) <= SINCOS_PAIR_MAX_ARG))) {
+        sincos_f(x, s, c);
+        return;
+    }
+    const float magic = 12582912.0f;
+    const float kb = __builtin_fmaf(x, 0.318309886f, magic);
+    const float kf = kb - magic;
+    float r = __builtin_fmaf(kf, -3.14159202e+00f, x);
+    r = __builtin_fmaf(kf, -6.27832947e-07f, r);
+    r = __builtin_fmaf(kf, -1.07806051e-14f, r);
+    const float z = r * r;
+    float ps = z * -2.3776610902e-08f + 2.7522166874e-06f;
+    ps = z * ps + -1.9840880122e-04f;
+    ps = z * ps + 8.3333319053e-03f;
+    ps = z * ps + -1.6666667163e-01f;
+    const float sr = (r * z) * ps + r;
+    float pc = z * 1.6759177379e-09f + -2.7332046670e-07f;
+    pc = z * pc + 2.4796934667e-05f;
+    pc = z * pc + -1.3888848480e-03f;
+    pc = z * pc + 4.1666664183e-02f;
+    pc = z * pc + -0.5f;
+    const float cr = z * pc + 1.0f;
+    const uint32_t flip = __builtin_bit_cast(uint32_t, kb) << 31;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sr) ^ flip);
+    c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cr) ^ flip);
+}
+
+// joint transform of one op (child -> parent: x_p = J x_c + t) from its constants and joint value:
+//   revolute   J = F Rot_z(q), t = trans          prismatic   J = F, t = trans + F e_z q          fixed  J = F, t = trans
+DRM_HD void joint_transform(const OpFT &o, bool moving, bool prismatic, float q, float c, float s, float *J, float *t) {
+    if (moving && !prismatic) {
+        joint_rot_z(o.F, c, s, J);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+    }
+    const float d = (moving && prismatic) ? q : 0.0f;
+    t[0] = o.t[0] + o.F[2] * d;
+    t[1] = o.t[1] + o.F[5] * d;
+    t[2] = o.t[2] + o.F[8] * d;
+}
+
+// one link of the pose chain on packed pairs; prismatic joints slide along the NEW z axis: p += R e_z q
+DRM_HD void pose_step(const OpPairs &o, const OpCtl &ct, float q, bool from_root, PoseP &cur) {
+    float c = 1.0f, s = 0.0f;
+    if (ct.dof >= 0 && !ct.prismatic) sincos_one(q, s, c);
+    f2 J01[3];
+    joint_pairs(o, c, s, J01); // c = 1, s = 0 gives the F pairs back exactly
+    if (from_root) compose_pairs_root(J01, o, cur);
+    else compose_pairs(cur, J01, o, cur);
+    if (ct.dof >= 0 && ct.prismatic) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cur.B[r][1] += cur.B[r][0] * q;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// FK of many targets over a (possibly branching) walk (robot_model.py:139-195 poses only, 223-248, 197-221).
+//   ctl(k, w0, w1)  the two control words of op k (wave-uniform)      row(k)  op k's constant row
+//   qf(d)           joint value of DoF d
+//   slot_save(s, PoseP) / slot_load(s, PoseP&)   branch-point poses
+//   emit(t, p[3], q[4])   world position and xyzw quaternion of target slot t
+// ---------------------------------------------------------------------------
+template <class CTL, class ROW, class QF, class SAVE, class LOAD, class EMIT>
+DRM_HD void fk_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, SAVE slot_save, LOAD slot_load, EMIT emit) {
+    PoseP cur;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { cur.A[c] = f2_make(c == 0, c == 1); cur.B[c] = f2_make(c == 2, 0.0f); }
+#pragma unroll 1
+    for (int k = 0; k < n_ops; ++k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding) continue;
+        const OpPairs o = load_pairs(row(k));
+        const float q = ct.dof >= 0 ? qf(ct.dof) : 0.0f;
+        if (ct.src >= 0) slot_load(ct.src, cur);
+        pose_step(o, ct, q, ct.src == DRM_SRC_ROOT, cur);
+        if (ct.save >= 0) slot_save(ct.save, cur);
+        if (ct.out >= 0) {
+            Pose P;
+            pose_from_pairs(cur, P);
+            Rot9 R;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R.v[i] = P.R[i];
+            const Quat4 qt = target_quaternion(R, ct.perm);
+            emit(ct.out, P.p, qt.v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// FK + geometric Jacobian along one chain (robot_model.py:626-667): op 0 hangs off the root, op k off op k - 1.
+//   column(d, z[3], p[3], prismatic)  called once per moving op: world joint axis and origin of DoF d; the caller forms
+//                                     (lin, ang) = (z x (p_e - p), z) for a revolute and (z, 0) for a prismatic joint
+// Returns the canonical pose of the last real op in `ee`.
+// ---------------------------------------------------------------------------
+template <class CTL, class ROW, class QF, class COL>
+DRM_HD void fk_jacobian_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, PoseP &ee, COL column) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ee.A[c] = f2_make(c == 0, c == 1); ee.B[c] = f2_make(c == 2, 0.0f); }
+#pragma unroll 1
+    for (int k = 0; k < n_ops; ++k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding) continue;
+        const OpPairs o = load_pairs(row(k));
+        const float q = ct.dof >= 0 ? qf(ct.dof) : 0.0f;
+        pose_step(o, ct, q, k == 0, ee);
+        if (ct.dof >= 0) {
+            const float z[3] = {ee.B[0][0], ee.B[1][0], ee.B[2][0]};
+            // a prismatic joint has moved the origin along z already; the column of a prismatic joint is (z, 0)
+            const float p[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+            column(ct.dof, z, p, ct.prismatic);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RNEA over one segment of the tree (robot_model.py:250-375): the static prefix ops [0, p_end) are replayed for their
+// motions, then ops [a, b) (a run of whole sub-trees): forward sweep (motions, body forces), backward sweep (forces
+// towards the root, torques).  Body-frame Pluecker coordinates at the link origin, as in the reference.
+//   qf(d, q, qd, qdd)  joint state of DoF d            tau_out(d, v)  torque of DoF d
+//   park(k, F, c, s, q) / unpark(k, F, c, s, q)   per-op record between the sweeps
+//   motion_save / motion_load(s, Motion)           branch-point motions
+//   force_add(s, Force) / force_take(s, Force&)    branch-point force accumulators (take = add into F and reset)
+// ---------------------------------------------------------------------------
+DRM_HD void motion_step(const float *J, const float *t, float wj, float aj, bool prismatic, const Motion &par, Motion &out) {
+    if (!prismatic) {
+        rnea_link_motion(J, t, wj, aj, par, out);
+        return;
+    }
+    // v = J^T (v_p + w_p x t) + e_z qd ;  a = J^T (a_p + al_p x t) + e_z qdd + w x (e_z qd)   (joint velocity (0, e_z qd))
+    f2 x[3], tmp[3];
+    Motion N;
+    matT_vec_p(J, par.wa, N.wa);
+    cross3_ps(par.wa, t, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = par.va[i] + x[i];
+    matT_vec_p(J, tmp, N.va);
+    N.va[2] += f2_make(wj, aj);
+    N.va[0][1] += N.wa[1][0] * wj;
+    N.va[1][1] -= N.wa[0][0] * wj;
+    out = N;
+}
+
+template <class CTL, class ROW, class QF, class TAU, class PARK, class UNPARK, class MSAVE, class MLOAD, class FADD, class FTAKE>
+DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags, QF qf, TAU tau_out, PARK park,
+                           UNPARK unpark, MSAVE motion_save, MLOAD motion_load, FADD force_add, FTAKE force_take) {
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    Motion cur;
+    motion_root(cur, g);
+    // ---- forward sweep ------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int k = (p_end > 0 ? 0 : a); k < b; k = (k + 1 == p_end ? a : k + 1)) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding) continue;
+        const float *of = row(k);
+        float q = 0.0f, wj = 0.0f, aj = 0.0f, c = 1.0f, s = 0.0f;
+        if (ct.dof >= 0) {
+            qf(ct.dof, q, wj, aj);
+            if (!ct.prismatic) sincos_one(q, s, c);
+        }
+        const OpFT o = load_ft(of);
+        float J[9], t[3];
+        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+        if (ct.src == DRM_SRC_ROOT) motion_root(cur, g);
+        if (ct.src >= 0) motion_load(ct.src, cur);
+        motion_step(J, t, wj, aj, ct.prismatic, cur, cur);
+        if (ct.save >= 0) motion_save(ct.save, cur);
+        if (k >= a) {
+            Force f;
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
+            park(k, f, c, s, q);
+        }
+    }
+    // ---- backward sweep -------------------------------------------------------------------------------------
+    Force carry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) carry.la[i] = f2_bcast(0.0f);
+#pragma unroll 1
+    for (int k = b - 1; k >= a; --k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding) continue;
+        const float *of = row(k);
+        Force tot;
+        float c, s, q;
+        unpark(k, tot, c, s, q);
+        if (ct.child_next) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+        }
+        if (ct.save >= 0) force_take(ct.save, tot);
+        if (ct.dof >= 0) {
+            // tau = S^T f: the angular z component for a revolute joint (robot_model.py:353-373), the linear one for a
+            // prismatic joint; + damping * qd
+            float tau = ct.prismatic ? tot.la[2][0] : tot.la[2][1];
+            if (flags & DRM_RNEA_DAMPING) {
+                float qq, qd, qdd;
+                qf(ct.dof, qq, qd, qdd);
+                tau += of[DRM_OPF_DAMP] * qd;
+            }
+            tau_out(ct.dof, tau);
+        }
+        if (ct.src != DRM_SRC_ROOT && ct.parent >= a) { // (a parent in the static prefix takes no force)
+            const OpFT o = load_ft(of);
+            float J[9], t[3];
+            joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+            Force up;
+            rnea_link_force_up(J, t, tot, up);
+            if (ct.src >= 0) force_add(ct.src, up);
+            else carry = up;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Joint-space inertia matrix H(q) of one segment by the composite-rigid-body algorithm (what the reference builds from
+// n + 1 inverse-dynamics passes, robot_model.py:402-450; see the note at `struct Inertia` in drm_sample.hpp).
+// One sweep from the leaves to the root: the composite inertia of the sub-tree below op k is complete when the sweep
+// reaches k; if k moves, F = Ic_k S_k is walked up the chain of k's ancestors (parent indices from W1) and leaves
+// H[j][k] = S_j . F at every moving ancestor j.  S = (ang e_z, lin 0) for a revolute joint, (0, e_z) for a prismatic one.
+//   trig(k, c, s, q)             cos / sin / value of op k's joint (the caller computes them once per op, see crba_prepare)
+//   islot_add / islot_take       branch-point composite inertias (take = add into the argument and reset)
+//   hout(di, dj, v)              H[di][dj] = v (called for both triangles)
+// ---------------------------------------------------------------------------
+template <class CTL, class ROW, class TRIG, class IADD, class ITAKE, class HOUT>
+DRM_HD void crba_tree_walk(int a, int b, CTL ctl, ROW row, TRIG trig, IADD islot_add, ITAKE islot_take, HOUT hout) {
+    Inertia carry;
+    inertia_zero(carry);
+#pragma unroll 1
+    for (int k = b - 1; k >= a; --k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.padding) continue;
+        const float *of = row(k);
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        if (ct.child_next) inertia_add(tot, carry);
+        if (ct.save >= 0) islot_take(ct.save, tot);
+        const OpFT o = load_ft(of);
+        float J[9], t[3], c, s, q;
+        trig(k, c, s, q);
+        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+        if (ct.dof >= 0) {
+            // F = Ic S_k.  revolute: f = -h x e_z = (-h_y, h_x, 0), n = I e_z;  prismatic: f = m e_z, n = h x e_z = (h_y, -h_x, 0)
+            Force F;
+            if (!ct.prismatic) {
+                F.la[0] = f2_make(-tot.h[1], tot.I[2]);
+                F.la[1] = f2_make(tot.h[0], tot.I[4]);
+                F.la[2] = f2_make(0.0f, tot.I[5]);
+                hout(ct.dof, ct.dof, tot.I[5]);
+            } else {
+                F.la[0] = f2_make(0.0f, tot.h[1]);
+                F.la[1] = f2_make(0.0f, -tot.h[0]);
+                F.la[2] = f2_make(tot.m, 0.0f);
+                hout(ct.dof, ct.dof, tot.m);
+            }
+            // up the ancestors: this op's own transform first, then its parent's, ...
+            Force up;
+            rnea_link_force_up(J, t, F, up);
+            int anc = ct.parent;
+#pragma unroll 1
+            while (anc >= a) {
+                int v0, v1;
+                ctl(anc, v0, v1);
+                const OpCtl ca = decode_ctl(v0, v1);
+                if (ca.dof >= 0) {
+                    const float v = ca.prismatic ? up.la[2][0] : up.la[2][1];
+                    hout(ca.dof, ct.dof, v);
+                    hout(ct.dof, ca.dof, v);
+                }
+                if (ca.parent < a) break;
+                const OpFT oa = load_ft(row(anc));
+                float Ja[9], ta[3], ca_c, ca_s, ca_q;
+                trig(anc, ca_c, ca_s, ca_q);
+                joint_transform(oa, ca.dof >= 0, ca.prismatic, ca_q, ca_c, ca_s, Ja, ta);
+                Force nxt;
+                rnea_link_force_up(Ja, ta, up, nxt);
+                up = nxt;
+                anc = ca.parent;
+            }
+        }
+        if (ct.src != DRM_SRC_ROOT && ct.parent >= a) {
+            Inertia upI;
+            inertia_to_parent(J, t, tot, upI);
+            if (ct.src >= 0) islot_add(ct.src, upI);
+            else carry = upI;
+        }
+    }
+}
+
+// cos / sin / value of the joint of every op of [a, b), handed to `put(k, c, s, q)` (parked by the caller for crba_tree_walk)
+template <class CTL, class QF, class PUT>
+DRM_HD void crba_prepare(int a, int b, CTL ctl, QF qf, PUT put) {
+#pragma unroll 1
+    for (int k = a; k < b; ++k) {
+        int w0, w1;
+        ctl(k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        float q = 0.0f, c = 1.0f, s = 0.0f;
+        if (!ct.padding && ct.dof >= 0) {
+            q = qf(ct.dof);
+            if (!ct.prismatic) sincos_one(q, s, c);
+        }
+        put(k, c, s, q);
+    }
+}
+
+} // namespace drm

@@ -1,0 +1,216 @@
+// drm_tree_dev.hpp — device-side plumbing shared by the loop-structured ("tree") kernels: K1 drm_fk, K2 drm_fk_jacobian,
+// K3 drm_rnea, K6 drm_crba, K8 drm_forward_dynamics for every robot that is not a 7-DoF arm chain (drm_tree.hpp holds
+// their per-sample arithmetic).
+//
+// Block layout.  A block owns ONE tile of 64 consecutive samples and has one wavefront per SEGMENT of the walk (sub-trees
+// hanging off the fixed root are independent dynamics problems, include/drm_hip.h drm_walk.seg_begin; the kinematics
+// kernels have one segment): lane = sample, wavefront = sub-tree — the per-link fan-out over wavefronts that K1 already did
+// for the fingertips of a hand, now for the dynamics too (Allegro: four 5-link fingers per tile instead of one 20-link
+// walk; four times the waves and a quarter of the per-wave LDS).
+// Shared by the block, in LDS:
+//   * the op table of the walk (n_ops x 32 floats) and its two control-word columns, staged once per block: every
+//     per-link constant is a broadcast LDS read, control words come back through v_readfirstlane; no scalar-memory
+//     round trip inside the loops, no compile-time capacity;
+//   * the input tiles (row-per-sample tensors <-> lane-per-sample access through an odd row stride, drm_common.hpp)
+//     and the output tile, loaded / stored once per block with coalesced 16-byte accesses.
+// Private to a wavefront, in LDS: the per-op records between two sweeps and the save slots of its branch points.
+#pragma once
+
+#include "drm_common.hpp"
+#include "drm_tree.hpp"
+
+namespace drm {
+
+struct TreeArgs { // by value in the kernel arguments
+    const float *ops_f;
+    const int32_t *ops_i;
+    int32_t cap, n_ops, n, n_slots, n_segments, prefix_end, max_seg_ops;
+    int32_t seg_begin[DRM_MAX_SEGMENTS + 1];
+    int32_t seg_dof_lo[DRM_MAX_SEGMENTS];
+    int32_t seg_dof_cnt[DRM_MAX_SEGMENTS];
+    int32_t wave_off[DRM_MAX_SEGMENTS]; // LDS offset (floats) of every wavefront's private area, set by the launcher
+};
+
+// single = true: ignore the segments, one wavefront walks everything (what a launch falls back to when the private areas
+// of all the segments do not fit a CU's LDS side by side)
+static inline TreeArgs tree_args(const drm_walk *w, bool single = false) {
+    TreeArgs a;
+    a.ops_f = w->ops_f; a.ops_i = w->ops_i;
+    a.cap = w->capacity; a.n_ops = w->n_ops; a.n = w->n_dofs; a.n_slots = w->n_slots;
+    a.n_segments = (!single && w->n_segments >= 1 && w->n_segments <= DRM_MAX_SEGMENTS) ? w->n_segments : 1;
+    a.prefix_end = a.n_segments > 1 ? w->prefix_end : 0;
+    a.max_seg_ops = 0;
+    for (int s = 0; s < DRM_MAX_SEGMENTS; ++s) {
+        const bool on = s < a.n_segments;
+        a.seg_begin[s] = on ? (a.n_segments > 1 ? w->seg_begin[s] : 0) : w->n_ops;
+        a.seg_dof_lo[s] = on ? (a.n_segments > 1 ? w->seg_dof_lo[s] : 0) : 0;
+        a.seg_dof_cnt[s] = on ? (a.n_segments > 1 ? w->seg_dof_cnt[s] : w->n_dofs) : 0;
+    }
+    a.seg_begin[a.n_segments] = w->n_ops;
+    for (int s = a.n_segments + 1; s <= DRM_MAX_SEGMENTS; ++s) a.seg_begin[s] = w->n_ops;
+    for (int s = 0; s < a.n_segments; ++s) {
+        const int len = a.seg_begin[s + 1] - a.seg_begin[s];
+        if (len > a.max_seg_ops) a.max_seg_ops = len;
+    }
+    for (int s = 0; s < DRM_MAX_SEGMENTS; ++s) a.wave_off[s] = 0;
+    return a;
+}
+
+// Lay the wavefronts' private LDS areas out one after the other behind `shared` floats: wavefront s gets
+// ops_s * per_op + per_wave + extra(s) floats.  Returns the total in floats.
+template <class EXTRA>
+static inline size_t layout_waves(TreeArgs &a, size_t shared, int per_op, int per_wave, EXTRA extra) {
+    size_t off = shared;
+    for (int s = 0; s < a.n_segments; ++s) {
+        a.wave_off[s] = (int32_t)off;
+        off += (size_t)round4((a.seg_begin[s + 1] - a.seg_begin[s]) * per_op + per_wave + extra(s));
+    }
+    return off;
+}
+
+// validity of the segment description handed over in a drm_walk (host side)
+static inline bool segments_ok(const drm_walk *w) {
+    if (w->n_segments < 1 || w->n_segments > DRM_MAX_SEGMENTS) return false;
+    if (w->n_segments == 1) return true;
+    if (w->prefix_end < 0 || w->seg_begin[0] != w->prefix_end || w->seg_begin[w->n_segments] != w->n_ops) return false;
+    for (int s = 0; s < w->n_segments; ++s) {
+        if (w->seg_begin[s + 1] < w->seg_begin[s]) return false;
+        if (w->seg_dof_lo[s] < 0 || w->seg_dof_cnt[s] < 0 || w->seg_dof_lo[s] + w->seg_dof_cnt[s] > w->n_dofs) return false;
+    }
+    return true;
+}
+
+// floats of LDS the staged table takes (op rows + two control-word columns)
+__host__ __device__ static inline int table_lds_floats(int n_ops) { return round4(n_ops * DRM_OPF_STRIDE) + round4(2 * (n_ops > 0 ? n_ops : 1)); }
+
+struct TableLds {
+    const float *f;   // [n_ops][32]
+    const int *w;     // [2][n_ops]
+    int n_ops;
+    __device__ __forceinline__ const float *row(int k) const { return f + k * DRM_OPF_STRIDE; }
+    __device__ __forceinline__ void ctl(int k, int &w0, int &w1) const {
+        w0 = __builtin_amdgcn_readfirstlane(w[k]);
+        w1 = __builtin_amdgcn_readfirstlane(w[n_ops + k]);
+    }
+};
+
+// all threads of the block copy the table into LDS (16 bytes per thread and round); the caller synchronises
+__device__ __forceinline__ TableLds stage_tree_table(const TreeArgs &a, float *lds) {
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    float *lf = lds;
+    int *lw = reinterpret_cast<int *>(lds + round4(a.n_ops * DRM_OPF_STRIDE));
+    const unsigned n4 = (unsigned)a.n_ops * (DRM_OPF_STRIDE / 4);
+    const float4 *g4 = reinterpret_cast<const float4 *>(a.ops_f); // ops_f is 16-byte aligned (checked by the launcher)
+    for (unsigned i = tid; i < n4; i += nt) reinterpret_cast<float4 *>(lf)[i] = g4[i];
+    for (unsigned i = tid; i < (unsigned)a.n_ops; i += nt) {
+        lw[i] = a.ops_i[DRM_OPI_W0 * a.cap + i];
+        lw[a.n_ops + i] = a.ops_i[DRM_OPI_W1 * a.cap + i];
+    }
+    TableLds t;
+    t.f = lf; t.w = lw; t.n_ops = a.n_ops;
+    return t;
+}
+
+// ---- save slots in LDS, [slot][component][64] ------------------------------------------------------------------
+__device__ __forceinline__ void lds_put_pose(float *slots, int s, unsigned lane, const PoseP &P) {
+    float *b = slots + s * (12 * WAVE) + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        b[(4 * c + 0) * WAVE] = P.A[c][0]; b[(4 * c + 1) * WAVE] = P.A[c][1];
+        b[(4 * c + 2) * WAVE] = P.B[c][0]; b[(4 * c + 3) * WAVE] = P.B[c][1];
+    }
+}
+__device__ __forceinline__ void lds_get_pose(const float *slots, int s, unsigned lane, PoseP &P) {
+    const float *b = slots + s * (12 * WAVE) + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        P.A[c] = f2_make(b[(4 * c + 0) * WAVE], b[(4 * c + 1) * WAVE]);
+        P.B[c] = f2_make(b[(4 * c + 2) * WAVE], b[(4 * c + 3) * WAVE]);
+    }
+}
+__device__ __forceinline__ void lds_put_motion(float *slots, int s, unsigned lane, const Motion &M) {
+    float *b = slots + s * (12 * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        b[i * WAVE] = M.wa[i][0]; b[(3 + i) * WAVE] = M.va[i][0]; b[(6 + i) * WAVE] = M.wa[i][1]; b[(9 + i) * WAVE] = M.va[i][1];
+    }
+}
+__device__ __forceinline__ void lds_get_motion(const float *slots, int s, unsigned lane, Motion &M) {
+    const float *b = slots + s * (12 * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M.wa[i] = f2_make(b[i * WAVE], b[(6 + i) * WAVE]);
+        M.va[i] = f2_make(b[(3 + i) * WAVE], b[(9 + i) * WAVE]);
+    }
+}
+__device__ __forceinline__ void lds_add_force(float *slots, int s, unsigned lane, const Force &F) {
+    float *b = slots + s * (6 * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { b[i * WAVE] += F.la[i][0]; b[(3 + i) * WAVE] += F.la[i][1]; }
+}
+__device__ __forceinline__ void lds_take_force(float *slots, int s, unsigned lane, Force &F) {
+    float *b = slots + s * (6 * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F.la[i] += f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+        b[i * WAVE] = 0.0f; b[(3 + i) * WAVE] = 0.0f;
+    }
+}
+__device__ __forceinline__ void lds_add_inertia(float *slots, int s, unsigned lane, const Inertia &a) {
+    float *b = slots + s * (10 * WAVE) + lane;
+    b[0] += a.m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[(1 + i) * WAVE] += a.h[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[(4 + i) * WAVE] += a.I[i];
+}
+__device__ __forceinline__ void lds_take_inertia(float *slots, int s, unsigned lane, Inertia &a) {
+    float *b = slots + s * (10 * WAVE) + lane;
+    a.m += b[0]; b[0] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a.h[i] += b[(1 + i) * WAVE]; b[(1 + i) * WAVE] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
+}
+
+// per-op records between the sweeps of RNEA: [op - first][9][64] = body force (6) + cos, sin, value of the joint
+constexpr int RNEA_PARK_FLOATS = 9;
+__device__ __forceinline__ void lds_park_rnea(float *park, int k, unsigned lane, const Force &F, float c, float s, float q) {
+    float *b = park + k * (RNEA_PARK_FLOATS * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
+    b[6 * WAVE] = c; b[7 * WAVE] = s; b[8 * WAVE] = q;
+}
+__device__ __forceinline__ void lds_unpark_rnea(const float *park, int k, unsigned lane, Force &F, float &c, float &s, float &q) {
+    const float *b = park + k * (RNEA_PARK_FLOATS * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+    c = b[6 * WAVE]; s = b[7 * WAVE]; q = b[8 * WAVE];
+}
+// per-op (cos, sin, value) of CRBA: [op - first][3][64]
+constexpr int CRBA_PARK_FLOATS = 3;
+
+// one block = one tile: rows of the tile and whether it is full
+struct TileCtx {
+    int64_t b0;
+    int rows;
+    bool full;
+};
+__device__ __forceinline__ TileCtx tile_begin(int64_t B) {
+    TileCtx t;
+    t.b0 = (int64_t)blockIdx.x * WAVE;
+    const int64_t left = B - t.b0;
+    t.rows = left < WAVE ? (int)left : WAVE;
+    t.full = t.rows == WAVE;
+    return t;
+}
+
+template <class K>
+static int ensure_lds_tree(K kernel, size_t bytes) {
+    if (bytes > (size_t)MAX_LDS_BYTES)
+        return fail(DRM_ERR_UNSUPPORTED, "the per-link records of this robot need %s%ld bytes of LDS per 64-sample tile (max %ld)",
+                    "", (long)bytes, (long)MAX_LDS_BYTES);
+    return ensure_lds(kernel, bytes);
+}
+
+} // namespace drm

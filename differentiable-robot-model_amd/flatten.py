@@ -59,14 +59,16 @@ def opf_ti(i: int) -> int:
 
 
 SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
-OPI_STRIDE = 8
-OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS = range(8)
+OPI_STRIDE = 10
+OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS, OPI_W0, OPI_W1 = range(10)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
 FLAG_CHILD_IS_NEXT = 1               # op k+1 is a child of op k (RNEA backward carry)
-MAX_SLOTS = 4                        # save slots available to a walk
-CAPACITIES = (4, 8, 12, 16, 24, 32)  # compiled walk capacities
-MAX_OPS = CAPACITIES[-1]
+MAX_SLOTS = 16                       # save slots available to a walk (forward kernels)
+MAX_SLOTS_BACKWARD = 4               # ... and to the backward kernels (3-bit fields of the packed control word)
+MAX_OPS_BACKWARD = 64                # largest walk the backward kernels take (DRM_MAX_OPS)
+MAX_SEGMENTS = 8                     # independent root-level sub-walks a dynamics launch fans out over (DRM_MAX_SEGMENTS)
 MAX_DOFS = 64                        # DoF columns addressable by one walk
+KIND_FIXED, KIND_REVOLUTE, KIND_PRISMATIC = 0, 1, 2
 
 # _PERM[a][c] = index pi_a(c) with P_a e_c = e_{pi_a(c)};  (M P_a)[:, c] = M[:, pi_a(c)]
 _PERM = {0: (1, 2, 0), 1: (2, 0, 1), 2: (0, 1, 2)}
@@ -93,6 +95,22 @@ class RobotSpec:
     com: np.ndarray               # [L,3]
     inertia: np.ndarray           # [L,9]
     children: List[List[int]] = field(default_factory=list)
+    kind: Optional[np.ndarray] = None       # int32 [L]: KIND_FIXED / KIND_REVOLUTE / KIND_PRISMATIC
+    skew: Optional[np.ndarray] = None       # bool [L]: the joint axis is not +-x / y / z (axis_rot carries it)
+    axis_rot: Optional[np.ndarray] = None   # float32 [L,3,3]: for skew axes, a rotation R_a with R_a e_z = axis
+
+    def __post_init__(self):
+        L = len(self.link_names)
+        if self.kind is None:
+            self.kind = np.where(self.dof >= 0, KIND_REVOLUTE, KIND_FIXED).astype(np.int32)
+        if self.skew is None:
+            self.skew = np.zeros(L, bool)
+        if self.axis_rot is None:
+            self.axis_rot = np.tile(np.eye(3, dtype=np.float32), (L, 1, 1))
+
+    @property
+    def skew_links(self) -> List[int]:
+        return [int(i) for i in np.nonzero(self.skew)[0]]
 
     @property
     def n_links(self):
@@ -114,20 +132,38 @@ class RobotSpec:
     def perm_of(self, link: int):
         """Signed column permutation (pi, d) of the stored frame of ``link``: (M P)[:, c] = d[c] * M[:, pi[c]]
         (identity for fixed joints / root)."""
-        if link <= 0 or self.dof[link] < 0:
-            return _PERM[2], (1, 1, 1)
+        if link <= 0 or self.dof[link] < 0 or self.skew[link]:
+            return _PERM[2], (1, 1, 1)   # (a skew-axis link hands its TRUE frame to its children: op B of build_walk)
         s = int(self.axis_sign[link])
         return _PERM[int(self.axis_idx[link])], (1, s, s)
 
     def perm_code(self, link: int) -> int:
         """DRM_OPI_PERM code of ``link``: axis index (2 for fixed joints) + 3 if the axis is negative."""
-        if link <= 0 or self.dof[link] < 0:
+        if link <= 0 or self.dof[link] < 0 or self.skew[link]:
             return 2
         return int(self.axis_idx[link]) + (3 if self.axis_sign[link] < 0 else 0)
 
 
-def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optional[str]]) -> RobotSpec:
-    """body_params[i] = dict from URDFRobotModel.get_body_parameters_from_urdf(i, link)."""
+def axis_rotation(axis: np.ndarray) -> np.ndarray:
+    """A rotation R_a (float64) with R_a e_z = axis / |axis|: the smallest one (about e_z x axis)."""
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    v = np.cross([0.0, 0.0, 1.0], a)
+    c = a[2]
+    if c < -1.0 + 1e-12:                       # axis = -e_z: half a turn about x
+        return np.diag([1.0, -1.0, -1.0])
+    K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+    return np.eye(3) + K + K @ K / (1.0 + c)
+
+
+def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optional[str]],
+                     reference_compat: bool = False) -> RobotSpec:
+    """body_params[i] = dict from URDFRobotModel.get_body_parameters_from_urdf(i, link).
+
+    Joint models: "revolute" / "continuous" turn about their axis, "prismatic" slide along it, any
+    unit axis is accepted.  The reference models every non-fixed joint as a revolute one about +-x / y / z
+    (robot_model.py:122-126, rigid_body.py:133,149-154) — wrong for the gripper fingers of panda.urdf;
+    ``reference_compat=True`` reproduces that (prismatic = revolute) for parity runs against it."""
     L = len(body_params)
     names = [bp["link_name"] for bp in body_params]
     if len(set(names)) != L:
@@ -137,6 +173,9 @@ def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optiona
     dof = np.full(L, -1, np.int32)
     axis_idx = np.full(L, 2, np.int32)
     axis_sign = np.zeros(L, np.int32)
+    kind = np.zeros(L, np.int32)
+    skew = np.zeros(L, bool)
+    axis_rot = np.tile(np.eye(3, dtype=np.float32), (L, 1, 1))
     controlled = []
     f32 = lambda t, shape: np.asarray(t.detach().cpu().numpy(), np.float32).reshape(shape)
     rpy = np.zeros((L, 3), np.float32); trans = np.zeros((L, 3), np.float32)
@@ -159,24 +198,37 @@ def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optiona
         if bp["joint_damping"] is not None:
             damping[i] = f32(bp["joint_damping"], 1)[0]
         mass[i] = f32(bp["mass"], 1)[0]; com[i] = f32(bp["com"], 3); inertia[i] = f32(bp["inertia_mat"], 9)
-        if bp["joint_type"] != "fixed":
+        jtype = bp["joint_type"]
+        if jtype != "fixed":
+            if jtype not in ("revolute", "continuous", "prismatic"):
+                raise UnsupportedRobotError("joint of link %s has type %r; supported: fixed, revolute, continuous, "
+                                            "prismatic" % (names[i], jtype))
             dof[i] = len(controlled)
             controlled.append(i)
+            kind[i] = KIND_PRISMATIC if (jtype == "prismatic" and not reference_compat) else KIND_REVOLUTE
             a = axis[i]
             nz = np.nonzero(a)[0]
-            if len(nz) != 1 or abs(a[nz[0]]) != 1.0:
-                # reference: rotation picks x, then y, else z with sign(axis) (rigid_body.py:149-154) and the
-                # torque extraction needs exactly one non-zero entry (robot_model.py:356-358)
-                raise UnsupportedRobotError(
-                    "joint of link %s has axis %s; only +-unit x/y/z axes are supported (the reference "
-                    "silently mis-handles anything else)" % (names[i], a.tolist()))
-            axis_idx[i] = nz[0]
-            axis_sign[i] = 1 if a[nz[0]] > 0 else -1
+            if len(nz) == 1 and abs(a[nz[0]]) == 1.0:
+                # +-x / y / z: folded into an exact signed permutation of the constants (see the module docstring)
+                axis_idx[i] = nz[0]
+                axis_sign[i] = 1 if a[nz[0]] > 0 else -1
+            else:
+                norm = float(np.linalg.norm(a.astype(np.float64)))
+                if reference_compat or not np.isfinite(norm) or norm < 1e-6:
+                    # the reference rotates such a joint about z by sign(axis_z) q and cannot extract its torque
+                    # (rigid_body.py:149-154, robot_model.py:356-358): there is nothing meaningful to reproduce
+                    raise UnsupportedRobotError(
+                        "joint of link %s has axis %s; the reference only handles +-unit x/y/z axes%s"
+                        % (names[i], a.tolist(), "" if reference_compat else " and a zero axis has no direction"))
+                skew[i] = True
+                axis_rot[i] = axis_rotation(a).astype(np.float32)
+                axis_idx[i] = 2
+                axis_sign[i] = 1
     children = [[] for _ in range(L)]
     for i in range(1, L):
         children[parent[i]].append(i)
     return RobotSpec(names, parent, dof, axis_idx, axis_sign, controlled,
-                     rpy, trans, axis, damping, mass, com, inertia, children)
+                     rpy, trans, axis, damping, mass, com, inertia, children, kind, skew, axis_rot)
 
 
 @dataclass
@@ -193,14 +245,29 @@ class WalkProgram:
     dof_mask: int            # bit d set <=> DoF d is driven by some op of this walk
     slots_unique: bool = True  # every branch point owns its slot for the whole walk (needed by the backward walk)
     shape: int = 0           # SHAPE_* bits (drm_walk.shape)
+    seg_begin: Sequence[int] = (0, 0)     # op ranges of the independent root-level sub-walks (drm_walk.seg_begin)
+    seg_dof: Sequence[tuple] = ((0, 0),)  # (first DoF column, count) of every segment
+    op_of_link: Optional[dict] = None     # link index -> op that carries the link's TRUE frame (targets, body forces)
+    prefix_end: int = 0                   # ops [0, prefix_end) are static (fixed joints off the root): every segment replays them
+
+    @property
+    def n_segments(self) -> int:
+        return len(self.seg_begin) - 1
+
+    @property
+    def backward_ok(self) -> bool:
+        """The backward kernels read the 3-bit fields of the packed control word and park one record per op."""
+        return self.n_slots <= MAX_SLOTS_BACKWARD and self.capacity <= MAX_OPS_BACKWARD and len(self.targets) <= 126
 
 
 def _capacity_for(n_ops: int) -> int:
-    for c in CAPACITIES:
-        if n_ops <= c:
-            return c
-    raise UnsupportedRobotError(
-        "walk of %d links exceeds the largest compiled capacity %d" % (n_ops, CAPACITIES[-1]))
+    """Rows of the op tables: 4 or 8 for short walks (the 7-DoF arm kernels are compiled for 8), else n_ops rounded up to
+    a multiple of 4 (16-byte rows of the field-major int table)."""
+    if n_ops <= 4:
+        return 4
+    if n_ops <= 8:
+        return 8
+    return (n_ops + 3) // 4 * 4
 
 
 def _gather_row(spec: RobotSpec, link: int):
@@ -226,10 +293,46 @@ def _gather_row(spec: RobotSpec, link: int):
     return row, sgn
 
 
+def virtual_rows(spec: RobotSpec):
+    """Link-table rows beyond the identity row L: two per skew-axis link, (L + 1 + 2 j, L + 2 + 2 j) for the j-th one."""
+    return {link: (spec.n_links + 1 + 2 * j, spec.n_links + 2 + 2 * j) for j, link in enumerate(spec.skew_links)}
+
+
+def _gather_plain(row_index: int):
+    """An op whose constants are one link-table row as it stands (op-row layout, no permutation)."""
+    base = row_index * OPF_STRIDE
+    row = base + np.arange(OPF_STRIDE, dtype=np.int64)
+    for r in range(3):
+        for c in range(3):
+            row[opf_fij(r, c)] = base + OPF_F + r * 3 + c
+        row[opf_ti(r)] = base + OPF_T + r
+    return row, np.ones(OPF_STRIDE, np.float32)
+
+
+def _gather_axis_op(spec: RobotSpec, link: int, row_index: int):
+    """Op A of a skew-axis link: virtual row `row_index` (F R_a, t), its rows following the parent's stored frame."""
+    row, sgn = _gather_plain(row_index)
+    base = row_index * OPF_STRIDE
+    pp, dp = spec.perm_of(int(spec.parent[link]))
+    for r in range(3):
+        for c in range(3):
+            row[opf_fij(r, c)] = base + OPF_F + pp[r] * 3 + c
+            sgn[opf_fij(r, c)] = dp[r]
+        row[opf_ti(r)] = base + OPF_T + pp[r]
+        sgn[opf_ti(r)] = dp[r]
+    return row, sgn
+
+
 def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False,
                min_capacity: int = 0) -> WalkProgram:
     """Depth-first walk over the links needed to reach ``targets`` (or all links); ``min_capacity`` pads it to at least
-    that compiled capacity (chains that are launched together share one)."""
+    that capacity (chains that are launched together share one).
+
+    A link whose joint axis is not +-x / y / z becomes TWO ops (Rot_a(q) = R_a Rot_z(q) R_a^T with R_a e_z = a):
+      A  the joint: fixed part F R_a, trans t, moving about +z, massless (virtual link-table row);
+      B  a fixed joint with F = R_a^T, t = 0 that carries the link's own frame, mass and inertia; the link's children
+         and any output slot hang off B.
+    Both are exact restatements of x_parent = F Rot_a(q) x_child + t, so no kernel knows about general axes."""
     L = spec.n_links
     needed = np.zeros(L, bool)
     if whole_tree:
@@ -243,15 +346,23 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
         if t in out_of:
             raise ValueError("duplicate target link %s" % spec.link_names[t])
         out_of[t] = slot
+    vrows = virtual_rows(spec)
 
-    ops, links = [], []
+    # op record: [dof, perm, ctrl, src, save, out, link, flags, w0, w1] + (parent op, prismatic, gather kind)
+    ops, links, parent_op, prismatic, gkind = [], [], [], [], []
     # slots are handed out fresh while there are any (so that a slot keeps its branch point's state for the
     # whole walk, which the backward walk relies on) and only recycled once all MAX_SLOTS have been used
     free_slots = []
     max_used = 0
     unique = True
+    op_of_link = {}
 
-    def visit(i, src):
+    def emit(i, dof, perm, src, save, out, flags, par, pris, gk):
+        ops.append([dof, perm, 0, src, save, out, i, flags, 0, 0])
+        links.append(i); parent_op.append(par); prismatic.append(pris); gkind.append(gk)
+        return len(ops) - 1
+
+    def visit(i, src, par):
         nonlocal max_used, unique
         kids = [c for c in spec.children[i] if needed[c]]
         save = -1
@@ -264,12 +375,17 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                 unique = False
             else:
                 raise UnsupportedRobotError(
-                    "tree needs more than %d nested branch points; not supported by the compiled kernels" % MAX_SLOTS)
+                    "tree needs more than %d nested branch points; not supported by the kernels" % MAX_SLOTS)
         flags = FLAG_CHILD_IS_NEXT if kids else 0
-        ops.append([int(spec.dof[i]), spec.perm_code(i), 0, src, save, out_of.get(i, -1), i, flags])
-        links.append(i)
+        pris = int(spec.kind[i] == KIND_PRISMATIC)
+        if spec.skew[i]:
+            a = emit(i, int(spec.dof[i]), 2, src, -1, -1, FLAG_CHILD_IS_NEXT, par, pris, ("axis", vrows[i][0]))
+            me = emit(i, -1, 2, SRC_PREV, save, out_of.get(i, -1), flags, a, 0, ("plain", vrows[i][1]))
+        else:
+            me = emit(i, int(spec.dof[i]), spec.perm_code(i), src, save, out_of.get(i, -1), flags, par, pris, ("link", i))
+        op_of_link[i] = me
         for n, c in enumerate(kids):
-            visit(c, SRC_PREV if n == 0 else save)
+            visit(c, SRC_PREV if n == 0 else save, me)
         if save >= 0:
             free_slots.append(save)
 
@@ -277,12 +393,14 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     # children all read SRC_ROOT, so a root with several children costs no slot
     for c in spec.children[0]:
         if needed[c]:
-            visit(c, SRC_ROOT)
+            visit(c, SRC_ROOT, -1)
     # a target that IS the root has no op: handled by the caller (identity pose)
     n_ops = len(ops)
     if spec.n_dofs > MAX_DOFS:
         raise UnsupportedRobotError("%d DoFs exceed the supported maximum %d" % (spec.n_dofs, MAX_DOFS))
-    cap = _capacity_for(max(n_ops, 1, min_capacity))
+    if n_ops > 0xfffe or len(tlist) > 0xfffe:
+        raise UnsupportedRobotError("walk of %d links / %d targets exceeds the 16-bit fields of the control words" % (n_ops, len(tlist)))
+    cap = max(_capacity_for(max(n_ops, 1)), int(min_capacity))
     # identity padding: fixed joint, F = I, t = 0, mass-less, chained to the previous op
     ops_i = np.zeros((cap, OPI_STRIDE), np.int32)
     ops_i[:, OPI_DOF] = -1
@@ -292,35 +410,107 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     ops_i[:, OPI_OUT] = -1
     ops_i[:, OPI_LINK] = -1
     # identity padding rows gather the identity link-table row THROUGH the op-row layout
-    ident = L * OPF_STRIDE + np.arange(OPF_STRIDE, dtype=np.int64)
-    for r in range(3):
-        for c in range(3):
-            ident[opf_fij(r, c)] = L * OPF_STRIDE + OPF_F + r * 3 + c
-        ident[opf_ti(r)] = L * OPF_STRIDE + OPF_T + r
+    ident, _ = _gather_plain(L)
     gather = np.tile(ident, (cap, 1))
     gsign = np.ones((cap, OPF_STRIDE), np.float32)
+    par_arr = np.full(cap, -1, np.int64)
+    pris_arr = np.zeros(cap, np.int64)
     if n_ops:
         ops_i[:n_ops] = np.asarray(ops, np.int32)
-        for k, link in enumerate(links):
-            gather[k], gsign[k] = _gather_row(spec, link)
+        par_arr[:n_ops] = parent_op
+        pris_arr[:n_ops] = prismatic
+        for k, (gk, arg) in enumerate(gkind):
+            if gk == "link":
+                gather[k], gsign[k] = _gather_row(spec, arg)
+            elif gk == "axis":
+                gather[k], gsign[k] = _gather_axis_op(spec, links[k], arg)
+            else:
+                gather[k], gsign[k] = _gather_plain(arg)
     else:
         ops_i[0, OPI_SRC] = SRC_ROOT
-    # the packed control word the kernels read (DRM_OPI_CTRL_PACK in include/drm_hip.h)
+    padding = np.zeros(cap, np.int64)
+    padding[n_ops:] = 1   # (a walk to the root itself has n_ops = 0: all padding)
+    # the packed control word the backward and arm kernels read (DRM_OPI_CTRL_PACK in include/drm_hip.h) ...
     ops_i[:, OPI_CTRL] = (((ops_i[:, OPI_DOF] + 1) & 0x7f) | (((ops_i[:, OPI_SRC] + 2) & 7) << 7)
                           | (((ops_i[:, OPI_SAVE] + 1) & 7) << 10) | (((ops_i[:, OPI_OUT] + 1) & 0x7f) << 13)
                           | ((ops_i[:, OPI_PERM] & 7) << 20) | ((ops_i[:, OPI_FLAGS] & 1) << 23))
-    ops_i[n_ops:, OPI_CTRL] |= 1 << 24   # identity padding (a walk to the root itself has n_ops = 0: all padding)
+    ops_i[n_ops:, OPI_CTRL] |= 1 << 24
+    # ... and the two wide control words of the loop-structured forward kernels (DRM_W0_PACK / DRM_W1_PACK)
+    i64 = lambda col: ops_i[:, col].astype(np.int64)
+    w0 = (((i64(OPI_DOF) + 1) & 0xff) | (((i64(OPI_SRC) + 2) & 0xff) << 8) | (((i64(OPI_SAVE) + 1) & 0xff) << 16)
+          | ((i64(OPI_FLAGS) & 1) << 24) | (padding << 25) | (pris_arr << 26) | ((i64(OPI_PERM) & 7) << 27))
+    w1 = ((i64(OPI_OUT) + 1) & 0xffff) | (((par_arr + 1) & 0xffff) << 16)
+    ops_i[:, OPI_W0] = w0.astype(np.uint32).view(np.int32)
+    ops_i[:, OPI_W1] = w1.astype(np.uint32).view(np.int32)
     mask = 0
     for row in ops:
         if row[OPI_DOF] >= 0:
             mask |= 1 << row[OPI_DOF]
     n = spec.n_dofs
-    arm = (n_ops >= n and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
-                              for k, row in enumerate(ops)))
+    arm = (n_ops >= n and not any(prismatic)
+           and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
+                   for k, row in enumerate(ops)))
     # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
-    branch_depth = max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0)
+    branch_depth = min(255, max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0))
+    prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
-                       max_used, cap, tlist, mask, unique, (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8))
+                       max_used, cap, tlist, mask, unique, (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8),
+                       seg_begin, seg_dof, op_of_link, prefix_end)
+
+
+def _segments(ops, parent_op, n_ops: int, n_dofs: int):
+    """Split a whole-tree walk into independent dynamics problems, one wavefront each (drm_walk.seg_begin):
+
+    * the STATIC PREFIX ops [0, p): fixed joints whose parents are the root or other prefix ops (a mounting plate, the
+      base link of a TriFinger) — they never move, so every wavefront replays them (forward sweeps only);
+    * the sub-trees that hang off the root or off a prefix op are independent of each other; consecutive ones are packed
+      into at most MAX_SEGMENTS runs no longer than the largest sub-tree (a block is as slow as its longest run).
+    Returns (prefix_end, seg_begin, seg_dof); one segment covering everything when the DoF columns of a run are not
+    contiguous or there is nothing to split."""
+    whole = (0, [0, n_ops], [(0, n_dofs)])
+    p = 0
+    while p < n_ops and ops[p][OPI_DOF] < 0 and parent_op[p] < p and (ops[p][OPI_SRC] == SRC_ROOT or parent_op[p] >= 0):
+        p += 1   # (parent_op[p] < p always holds in a depth-first walk: the prefix is closed under "parent of")
+    if p == n_ops:
+        return whole
+    starts = [k for k in range(p, n_ops) if parent_op[k] < p]
+    if len(starts) < 2 or starts[0] != p:
+        return whole
+    bounds = starts + [n_ops]
+    sizes = [bounds[j + 1] - bounds[j] for j in range(len(starts))]
+    limit = max(sizes)
+    while True:
+        cuts, acc = [p], 0
+        for j, sz in enumerate(sizes):
+            # a run may only start at a sub-tree whose first op does not continue from the previous op
+            can_cut = ops[bounds[j]][OPI_SRC] != SRC_PREV
+            if acc and acc + sz > limit and can_cut:
+                cuts.append(bounds[j])
+                acc = 0
+            acc += sz
+        cuts.append(n_ops)
+        if len(cuts) - 1 <= MAX_SEGMENTS:
+            break
+        limit += 1
+    if len(cuts) - 1 < 2:
+        return whole
+    seg_dof = []
+    for a, b in zip(cuts, cuts[1:]):
+        dofs = sorted(ops[k][OPI_DOF] for k in range(a, b) if ops[k][OPI_DOF] >= 0)
+        if not dofs:
+            seg_dof.append((0, 0))
+        elif dofs[-1] - dofs[0] + 1 != len(dofs):
+            return whole
+        else:
+            seg_dof.append((dofs[0], len(dofs)))
+    return p, cuts, seg_dof
+
+
+def virtual_row_constants(spec: RobotSpec):
+    """(links, R_a [S,3,3] float32) of the skew-axis links, in virtual-row order (robot_model._link_table builds
+    row A = (F R_a, t, massless, damping) and row B = (R_a^T, 0, mass, mcom, I_o, 0) from them)."""
+    links = spec.skew_links
+    return links, (spec.axis_rot[links] if links else np.zeros((0, 3, 3), np.float32))
 
 
 def identity_table_row() -> np.ndarray:

@@ -23,7 +23,8 @@ import numpy as np
 import torch
 
 from . import backend
-from .flatten import OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, identity_table_row
+from .flatten import (KIND_PRISMATIC, OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, identity_table_row,
+                      virtual_row_constants)
 from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
 
@@ -249,9 +250,12 @@ class _ForwardDynamics(torch.autograd.Function):
 class DifferentiableRobotModel(torch.nn.Module):
     """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
 
-    def __init__(self, urdf_path: str, name="", device=None):
+    def __init__(self, urdf_path: str, name="", device=None, reference_compat: bool = False):
+        """``reference_compat=True`` models prismatic joints the way the reference does — as revolute joints about their
+        axis (robot_model.py:122-126) — for parity runs against it; by default they slide."""
         super().__init__()
         self.name = name
+        self._reference_compat = bool(reference_compat)
         if device is None:
             # the reference defaults to CPU (robot_model.py:100-104); this engine only computes on a HIP
             # device, so pick it when there is one
@@ -290,7 +294,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._kin_state = None   # (q, qd) of the last update_kinematic_state
         self._kin_cache = {}
 
-        self._spec: RobotSpec = build_robot_spec(body_params, parent_names)
+        self._spec: RobotSpec = build_robot_spec(body_params, parent_names, reference_compat=self._reference_compat)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
@@ -341,7 +345,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         if self._static_table is None:
             with torch.no_grad():
                 ident = torch.from_numpy(identity_table_row()).to(self._device).reshape(1, OPF_STRIDE)
-                self._static_table = torch.cat([self._link_rows(range(len(self._bodies))), ident], dim=0)
+                base = torch.cat([self._link_rows(range(len(self._bodies))), ident], dim=0)
+                self._static_table = self._with_virtual_rows(base)
         if not self._learnable:
             return self._static_table
         links = sorted({link for link, _ in self._learnable})
@@ -352,7 +357,24 @@ class DifferentiableRobotModel(torch.nn.Module):
             rows = backend.LinkRows.apply(self._link_params(links))
         else:
             rows = self._link_rows(links)   # host-side tests of the table construction
-        return self._static_table.index_copy(0, self._learnable_links, rows)
+        L1 = len(self._bodies) + 1
+        return self._with_virtual_rows(self._static_table[:L1].index_copy(0, self._learnable_links, rows))
+
+    def _with_virtual_rows(self, base: torch.Tensor) -> torch.Tensor:
+        """Append the two virtual rows of every link whose joint axis is not +-x / y / z (flatten.build_walk):
+        A = (F R_a, t, massless, damping) — the joint itself, turning about +z — and B = (R_a^T, 0, mass, mcom, I_o, 0),
+        the fixed step back into the link's own frame.  Differentiable in the link's row (torch ops)."""
+        links, Ra = virtual_row_constants(self._spec)
+        if not links:
+            return base
+        Ra_t = torch.from_numpy(np.ascontiguousarray(Ra)).to(self._device)
+        rows = base[torch.tensor(links, device=self._device)]
+        S = len(links)
+        zeros = lambda k: torch.zeros(S, k, device=self._device)
+        FA = (rows[:, 0:9].reshape(S, 3, 3) @ Ra_t).reshape(S, 9)
+        row_a = torch.cat([FA, rows[:, 9:12], zeros(13), rows[:, 25:26], zeros(OPF_STRIDE - 26)], dim=1)
+        row_b = torch.cat([Ra_t.transpose(1, 2).reshape(S, 9), zeros(3), rows[:, 12:25], zeros(OPF_STRIDE - 25)], dim=1)
+        return torch.cat([base, torch.stack([row_a, row_b], dim=1).reshape(2 * S, OPF_STRIDE)], dim=0)
 
     def _link_params(self, link_idxs) -> torch.Tensor:
         """[len(link_idxs), 20] rpy, trans, mass, com, inertia_mat, damping of the given links (include/drm_hip.h
@@ -386,7 +408,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32:
+        if (self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32
+                and not self._spec.skew.any()):
             return self._ops_f_learnable(dw)      # (more learnable links than the fused kernel takes: the torch path below)
         table = self._link_table()
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)

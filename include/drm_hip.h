@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 3
+#define DRM_ABI_VERSION 4
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -49,7 +49,7 @@ extern "C" {
 #define DRM_OPF_IO 16     /* [9] I_c + m S(c)S(c)^T        (spatial_vector_algebra.py:324-327)  */
 #define DRM_OPF_DAMP 25   /* [1] joint damping             (robot_model.py:368-373)             */
 
-#define DRM_OPI_STRIDE 8  /* int32 fields per op; ops_i is FIELD-MAJOR: ops_i[field * capacity + k] */
+#define DRM_OPI_STRIDE 10 /* int32 fields per op; ops_i is FIELD-MAJOR: ops_i[field * capacity + k] */
 #define DRM_OPI_DOF 0     /* DoF column driven by this link's joint, -1 = fixed joint          */
 #define DRM_OPI_PERM 1    /* axis canonicalisation of this link's stored frame, a + 3 * (axis negative):
                              a = 2 joint about local z (or fixed), 0 about local x, 1 about local y
@@ -76,11 +76,33 @@ extern "C" {
 #define DRM_OPI_LINK 6    /* link index in URDF <link> order (informational)                   */
 #define DRM_OPI_FLAGS 7   /* DRM_FLAG_*                                                        */
 
+#define DRM_OPI_W0 8      /* the two control words of the loop-structured forward kernels (drm_fk, drm_fk_jacobian,
+                             drm_rnea, drm_crba, drm_forward_dynamics of robots that are not 7-DoF arm chains): wider
+                             fields than DRM_OPI_CTRL, so walks may have any number of links, 16 save slots and
+                             prismatic joints.  W0:
+                               bits  0..7  DoF column + 1 (0 = fixed joint)
+                               bits  8..15 source + 2     (0 = root, 1 = previous op, 2.. = save slot)
+                               bits 16..23 save slot + 1  (0 = none)
+                               bit  24     DRM_FLAG_CHILD_IS_NEXT
+                               bit  25     identity padding op
+                               bit  26     prismatic joint: the link slides along +z of its stored frame by q (URDF
+                                           type "prismatic"; everything else that moves is revolute about +z)
+                               bits 27..29 DRM_OPI_PERM code                                                    */
+#define DRM_OPI_W1 9      /* W1: bits 0..15 output slot + 1 (0 = none), bits 16..31 op index of the parent + 1 (0 = root) */
+#define DRM_W0_PACK(dof, src, save, child_next, padding, prismatic, perm)                                       \
+    ((((dof) + 1) & 0xff) | ((((src) + 2) & 0xff) << 8) | ((((save) + 1) & 0xff) << 16) | (((child_next) & 1) << 24) | \
+     (((padding) & 1) << 25) | (((prismatic) & 1) << 26) | (((perm) & 7) << 27))
+#define DRM_W1_PACK(out, parent_op) ((((out) + 1) & 0xffff) | ((((parent_op) + 1) & 0xffff) << 16))
+
 #define DRM_SRC_PREV (-1) /* parent = previous op of the walk                                  */
 #define DRM_SRC_ROOT (-2) /* parent = the fixed root link (identity pose, zero velocity)       */
 #define DRM_FLAG_CHILD_IS_NEXT 1 /* op k+1 is a child of op k                                  */
-#define DRM_MAX_SLOTS 4   /* save slots a walk may use (kept in LDS)                           */
-#define DRM_MAX_OPS 32    /* largest compiled walk capacity (4, 8, 12, 16, 24, 32)             */
+#define DRM_MAX_SLOTS 16  /* save slots a walk may use in the forward kernels (kept in LDS)    */
+#define DRM_MAX_SLOTS_BACKWARD 4 /* ... and in the backward kernels (3-bit fields of DRM_OPI_CTRL) */
+#define DRM_MAX_OPS 64    /* largest walk the BACKWARD kernels and drm_walk_table take; the forward kernels are bounded
+                             by the LDS their per-link records need (DRM_ERR_UNSUPPORTED beyond that, ~70 links) */
+#define DRM_MAX_SEGMENTS 8 /* independent sub-walks (sub-trees hanging off the fixed root) a dynamics launch fans out
+                              over the wavefronts of a block                                      */
 #define DRM_MAX_DOFS 64   /* largest supported number of DoF columns                           */
 
 /* drm_walk.shape */
@@ -103,18 +125,30 @@ extern "C" {
 /*
  * A walk, as produced by flatten.build_walk().  ops_f / ops_i hold `capacity`
  * rows: n_ops real ones followed by identity padding (fixed joint, F = I,
- * t = 0, mass 0, DRM_SRC_PREV), so the kernels run the walk as straight-line code.
+ * t = 0, mass 0, DRM_SRC_PREV); capacity is 4 or 8 for walks of up to 8 links (the
+ * 7-DoF arm kernels are compiled for 8 and run the walk as straight-line code), n_ops rounded up to a
+ * multiple of 4 beyond that (every other kernel loops over the n_ops links).
  */
 typedef struct drm_walk {
     const float *ops_f;   /* device [capacity, DRM_OPF_STRIDE]                               */
     const int32_t *ops_i; /* device [DRM_OPI_STRIDE, capacity]  (field-major)                */
     int32_t n_ops;        /* links visited                                                   */
-    int32_t capacity;     /* 4, 8, 12, 16, 24 or 32: selects the compiled kernel             */
+    int32_t capacity;     /* rows of ops_f / ops_i (>= n_ops, a multiple of 4)               */
     int32_t n_dofs;       /* n = row width of q / qd / qdd / tau and Jacobian column count   */
-    int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS)                              */
+    int32_t n_slots;      /* save slots used (<= DRM_MAX_SLOTS; backward kernels: <= DRM_MAX_SLOTS_BACKWARD) */
     uint64_t dof_mask;    /* bit d set <=> DoF d is driven by an op of this walk             */
     int32_t target_perm;  /* drm_fk_jacobian: DRM_OPI_PERM code (0..5) of the target (last real) op */
     int32_t shape;        /* DRM_WALK_* bits describing the walk, so launchers can pick a specialised kernel */
+    /* Segments: sub-trees that hang off the fixed root are independent dynamics problems (the fingers of a hand on a
+     * fixed palm).  Ops seg_begin[s] .. seg_begin[s+1]-1 form segment s (a run of whole root-level sub-trees, in walk
+     * order); its joints drive the DoF columns seg_dof_lo[s] .. seg_dof_lo[s] + seg_dof_cnt[s] - 1 and no others.
+     * A block of n_segments wavefronts owns 64 samples, wavefront s walks segment s.  n_segments = 1: the whole walk. */
+    int32_t n_segments;
+    int32_t seg_begin[DRM_MAX_SEGMENTS + 1];
+    int32_t seg_dof_lo[DRM_MAX_SEGMENTS];
+    int32_t seg_dof_cnt[DRM_MAX_SEGMENTS];
+    int32_t prefix_end;   /* ops 0 .. prefix_end-1 are STATIC (fixed joints hanging off the root: a mounting plate, the base
+                             link of a TriFinger); every segment replays them before its own ops, forward sweeps only */
 } drm_walk;
 
 int drm_abi_version(void);
@@ -194,11 +228,13 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *st
  * algorithm).  flags as for drm_rnea: DRM_RNEA_GRAVITY = base acceleration (0,0,+9.81) (robot_model.py:527-533),
  * DRM_RNEA_DAMPING = the damping torques damping * qd are taken off f first (robot_model.py:515-521; the
  * caller's f is NOT modified, unlike the reference, which subtracts in place).
- *   q, qd, f [B, n]  ->  qdd [B, n];  DRM_ERR_UNSUPPORTED when 64 packed n x n triangles do not fit in LDS (n > ~25:
- *   the host layer then solves the same system from drm_crba + drm_rnea with a batched device Cholesky)
+ *   q, qd, f [B, n]  ->  qdd [B, n]
+ *   scratch   drm_forward_dynamics_scratch_floats(walk, B) floats owned by the caller (0 for every shipped robot: the
+ *             packed triangle of a segment's inertia matrix lives in LDS; beyond ~30 DoF per segment it lives there)
  */
+int64_t drm_forward_dynamics_scratch_floats(const drm_walk *walk, int64_t B);
 int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,
-                         int32_t flags, float *qdd, void *stream);
+                         int32_t flags, float *qdd, float *scratch, void *stream);
 
 /*
  * Reverse-mode derivative of drm_fk's POSITIONS: what torch autograd computes in the reference when a loss on

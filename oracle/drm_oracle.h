@@ -21,6 +21,9 @@ typedef struct drm_oracle_spec {
     const float *mass;      /* [L]                                               */
     const float *com;       /* [L,3] inertial origin xyz                         */
     const float *inertia;   /* [L,9] inertia about the com, row-major            */
+    const int32_t *kind;    /* [L] or NULL: 0 fixed, 1 revolute / continuous, 2 prismatic.  NULL = the reference's
+                               model (every moving joint revolute, robot_model.py:122-126).  EXTENSION beyond the
+                               reference, see drm_oracle_impl.h "joint models"                 */
 } drm_oracle_spec;
 
 #ifdef __cplusplus

@@ -92,15 +92,77 @@ static REAL FN(sgn)(REAL x) { return (REAL)((x > 0) - (x < 0)); } /* torch.sign 
  * axis chosen by |axis[0]|==1 -> x, elif |axis[1]|==1 -> y, else z (rb.py:149-154).
  * Fixed joints keep the pose built once in rb.py:64-67 with q = 0.
  */
+/*
+ * Joint models.  The reference knows ONE: a revolute joint about +-x / y / z (rb.py:149-154; every non-fixed joint,
+ * prismatic ones included, rm.py:122-126) — that is what the code below does whenever sp->kind is NULL and the axis has
+ * a single +-1 entry, line by line as in the reference.  EXTENSION (no reference behaviour exists to
+ * restate, the reference mis-rotates such joints and cannot extract their torque, rm.py:356-358), textbook forms:
+ *   - a revolute joint about ANY unit axis a: Rot_a(q) by Rodrigues' formula, joint velocity (ang a qd, lin 0),
+ *     torque a . f_ang;
+ *   - a prismatic joint (kind 2) along a: no rotation, translation trans + R_fixed a q, joint velocity (ang 0, lin a qd),
+ *     torque a . f_lin, Jacobian column (lin R a, ang 0)          (Featherstone, Rigid Body Dynamics Algorithms, ch. 4).
+ */
+static int FN(is_prismatic)(const drm_oracle_spec *sp, int i) { return sp->kind && sp->kind[i] == 2; }
+static int FN(axis_aligned)(const drm_oracle_spec *sp, int i) {
+    int nz = 0, one = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float a = sp->axis[i * 3 + k];
+        nz += a != 0;
+        one += (a == 1.0f || a == -1.0f);
+    }
+    return nz <= 1 && (nz == 0 || one == 1);
+}
+static void FN(unit_axis)(const drm_oracle_spec *sp, int i, REAL *a) {
+    double x = sp->axis[i * 3], y = sp->axis[i * 3 + 1], z = sp->axis[i * 3 + 2];
+    double nrm = sqrt(x * x + y * y + z * z);
+    if (FN(axis_aligned)(sp, i) || nrm == 0) nrm = 1;   /* the reference uses the axis as written */
+    a[0] = (REAL)(x / nrm); a[1] = (REAL)(y / nrm); a[2] = (REAL)(z / nrm);
+}
 static void FN(joint_rotation)(const drm_oracle_spec *sp, int i, REAL q, REAL *J) {
     REAL rpy[3] = {(REAL)sp->rpy[i * 3], (REAL)sp->rpy[i * 3 + 1], (REAL)sp->rpy[i * 3 + 2]};
     REAL ax[3] = {(REAL)sp->axis[i * 3], (REAL)sp->axis[i * 3 + 1], (REAL)sp->axis[i * 3 + 2]};
     REAL F[9], Rq[9];
     FN(fixed_rotation)(rpy, F);
-    if (FABS(ax[0]) == 1)      FN(axis_rot)(0, FN(sgn)(ax[0]) * q, Rq);
-    else if (FABS(ax[1]) == 1) FN(axis_rot)(1, FN(sgn)(ax[1]) * q, Rq);
-    else                       FN(axis_rot)(2, FN(sgn)(ax[2]) * q, Rq);
+    if (FN(is_prismatic)(sp, i)) {                      /* extension: a sliding joint does not rotate */
+        for (int k = 0; k < 9; ++k) J[k] = F[k];
+        return;
+    }
+    if (FN(axis_aligned)(sp, i)) {                      /* the reference, rb.py:149-154 */
+        if (FABS(ax[0]) == 1)      FN(axis_rot)(0, FN(sgn)(ax[0]) * q, Rq);
+        else if (FABS(ax[1]) == 1) FN(axis_rot)(1, FN(sgn)(ax[1]) * q, Rq);
+        else                       FN(axis_rot)(2, FN(sgn)(ax[2]) * q, Rq);
+    } else {                                            /* extension: Rodrigues, R = I + s K + (1 - c) K^2 */
+        REAL a[3], K[9], KK[9];
+        FN(unit_axis)(sp, i, a);
+        FN(skew)(a, K);
+        FN(mat3_mul)(K, K, KK);
+        const REAL c = COS(q), s_ = SIN(q);
+        for (int k = 0; k < 9; ++k) Rq[k] = ((k % 4 == 0) ? (REAL)1 : (REAL)0) + s_ * K[k] + ((REAL)1 - c) * KK[k];
+    }
     FN(mat3_mul)(F, Rq, J);
+}
+/* joint origin in the parent frame: `trans` (rb.py:143-145), plus the slide of a prismatic joint (extension) */
+static void FN(joint_trans)(const drm_oracle_spec *sp, int i, REAL q, REAL *t) {
+    for (int k = 0; k < 3; ++k) t[k] = (REAL)sp->trans[i * 3 + k];
+    if (FN(is_prismatic)(sp, i)) {
+        REAL rpy[3] = {(REAL)sp->rpy[i * 3], (REAL)sp->rpy[i * 3 + 1], (REAL)sp->rpy[i * 3 + 2]};
+        REAL F[9], a[3], Fa[3];
+        FN(fixed_rotation)(rpy, F);
+        FN(unit_axis)(sp, i, a);
+        FN(mat3_vec)(F, a, Fa);
+        for (int k = 0; k < 3; ++k) t[k] += Fa[k] * q;
+    }
+}
+/* joint velocity / acceleration (lin, ang) for a joint rate r: rb.py:133-136, 159-165 = (0, r axis); prismatic (r axis, 0) */
+static void FN(joint_rate)(const drm_oracle_spec *sp, int i, REAL r, REAL *lin, REAL *ang) {
+    for (int k = 0; k < 3; ++k) { lin[k] = 0; ang[k] = 0; }
+    if (FN(is_prismatic)(sp, i) || !FN(axis_aligned)(sp, i)) {
+        REAL a[3];
+        FN(unit_axis)(sp, i, a);
+        for (int k = 0; k < 3; ++k) (FN(is_prismatic)(sp, i) ? lin : ang)[k] = r * a[k];
+    } else {
+        for (int k = 0; k < 3; ++k) ang[k] = r * (REAL)sp->axis[i * 3 + k];
+    }
 }
 
 /*
@@ -119,7 +181,8 @@ static void FN(kinematic_state)(const drm_oracle_spec *sp, const REAL *q, const 
     for (int i = 1; i < L; ++i) {
         const int par = sp->parent[i], d = sp->dof[i];
         REAL qi = (d >= 0) ? q[d] : 0, qdi = (d >= 0 && qd) ? qd[d] : 0;
-        REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+        REAL t[3];
+        FN(joint_trans)(sp, i, qi, t);
         REAL *Ji = J + i * 9;
         FN(joint_rotation)(sp, i, qi, Ji);
         /* body.pose = parent.pose.multiply_transform(joint_pose)  rm.py:186, sva.py:98-103 */
@@ -140,9 +203,11 @@ static void FN(kinematic_state)(const drm_oracle_spec *sp, const REAL *q, const 
         FN(mat3_vec)(SR, va + par * 3, nl);
         FN(mat3_vec)(JT, vl + par * 3, nl2);
         /* body.vel = joint_vel.add_motion_vec(new_vel); joint_vel = (0, qd @ axis)  rb.py:133-136, rm.py:193 */
+        REAL jvl[3], jva[3];
+        FN(joint_rate)(sp, i, qdi, jvl, jva);
         for (int k = 0; k < 3; ++k) {
-            vl[i * 3 + k] = (REAL)0 + (nl[k] + nl2[k]);
-            va[i * 3 + k] = qdi * (REAL)sp->axis[i * 3 + k] + na[k];
+            vl[i * 3 + k] = jvl[k] + (nl[k] + nl2[k]);
+            va[i * 3 + k] = jva[k] + na[k];
         }
     }
 }
@@ -215,7 +280,8 @@ static void FN(rnea_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL
     for (int i = 1; i < L; ++i) {
         const int par = sp->parent[i], d = sp->dof[i];
         REAL qdi = (d >= 0) ? qd[d] : 0, qddi = (d >= 0) ? qdd[d] : 0;
-        REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+        REAL t[3];
+        FN(joint_trans)(sp, i, (d >= 0) ? q[d] : 0, t);
         REAL JT[9], it[3], S[9], SR[9];
         FN(mat3_transpose)(J + i * 9, JT);
         FN(mat3_vec)(JT, t, it);
@@ -227,18 +293,16 @@ static void FN(rnea_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL
         FN(mat3_vec)(SR, aa + par * 3, nl);
         FN(mat3_vec)(JT, al + par * 3, nl2);
         /* joint_vel / joint_acc = (0, qd*axis) / (0, qdd*axis)  rb.py:133-136,159-165 */
-        REAL jv[3], ja[3], zero[3] = {0, 0, 0};
-        for (int k = 0; k < 3; ++k) {
-            jv[k] = qdi * (REAL)sp->axis[i * 3 + k];
-            ja[k] = qddi * (REAL)sp->axis[i * 3 + k];
-        }
+        REAL jv[3], ja[3], jvl[3], jal[3];
+        FN(joint_rate)(sp, i, qdi, jvl, jv);
+        FN(joint_rate)(sp, i, qddi, jal, ja);
         /* tmp = body.vel.cross_motion_vec(body.joint_vel)  sva.py:204-213 */
         REAL ta[3], tl1[3], tl2[3];
         FN(cross)(va + i * 3, jv, ta);
-        FN(cross)(va + i * 3, zero, tl1);
+        FN(cross)(va + i * 3, jvl, tl1);
         FN(cross)(vl + i * 3, jv, tl2);
         for (int k = 0; k < 3; ++k) {
-            al[i * 3 + k] = ((nl[k] + nl2[k]) + (REAL)0) + (tl1[k] + tl2[k]);
+            al[i * 3 + k] = ((nl[k] + nl2[k]) + jal[k]) + (tl1[k] + tl2[k]);
             aa[i * 3 + k] = (na[k] + ja[k]) + ta[k];
         }
     }
@@ -258,7 +322,8 @@ static void FN(rnea_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL
             fa[i * 3 + k] = (fa[i * 3 + k] + iaa[k]) + (c1[k] + c2[k]);
         }
         /* backprop_force = body.force.transform(joint_pose)  sva.py:281-291 */
-        REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+        REAL t[3];
+        FN(joint_trans)(sp, i, (sp->dof[i] >= 0) ? q[sp->dof[i]] : 0, t);
         REAL S[9], SR[9], bl[3], ba[3], ba2[3];
         FN(mat3_vec)(J + i * 9, fl + i * 3, bl);
         FN(skew)(t, S);
@@ -274,10 +339,18 @@ static void FN(rnea_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL
     for (int i = 1; i < L; ++i) {
         const int d = sp->dof[i];
         if (d < 0) continue;
-        int k = 0; /* int(torch.where(axis)[0]) */
-        while (k < 2 && sp->axis[i * 3 + k] == 0) ++k;
-        REAL sign = FN(sgn)((REAL)sp->axis[i * 3 + k]);
-        REAL f = (REAL)0 + sign * fa[i * 3 + k];
+        REAL f;
+        if (FN(is_prismatic)(sp, i) || !FN(axis_aligned)(sp, i)) {   /* extension: tau = S^T f */
+            REAL a[3];
+            FN(unit_axis)(sp, i, a);
+            const REAL *ff = FN(is_prismatic)(sp, i) ? fl + i * 3 : fa + i * 3;
+            f = (a[0] * ff[0] + a[1] * ff[1]) + a[2] * ff[2];
+        } else {
+            int k = 0; /* int(torch.where(axis)[0]) */
+            while (k < 2 && sp->axis[i * 3 + k] == 0) ++k;
+            REAL sign = FN(sgn)((REAL)sp->axis[i * 3 + k]);
+            f = (REAL)0 + sign * fa[i * 3 + k];
+        }
         if (use_damping) f += (REAL)sp->damping[i] * qd[d];
         tau[d] = f;
     }
@@ -364,9 +437,13 @@ static int FN(oracle_fk_jacobian)(const drm_oracle_spec *sp, const IO_T *q, int6
                 for (int i = link; i != 0; i = sp->parent[i]) {
                     const int d = sp->dof[i];
                     if (d < 0) continue;
-                    REAL ax[3] = {(REAL)sp->axis[i * 3], (REAL)sp->axis[i * 3 + 1], (REAL)sp->axis[i * 3 + 2]};
-                    REAL z[3], dp[3], c[3];
+                    REAL ax[3], z[3], dp[3], c[3];
+                    FN(unit_axis)(sp, i, ax);
                     FN(mat3_vec)(R + i * 9, ax, z);                           /* rm.py:660 */
+                    if (FN(is_prismatic)(sp, i)) {                            /* extension: column (z, 0) */
+                        for (int k = 0; k < 3; ++k) { lj[k * n + d] = (IO_T)z[k]; aj[k * n + d] = 0; }
+                        continue;
+                    }
                     for (int k = 0; k < 3; ++k) dp[k] = p[link * 3 + k] - p[i * 3 + k];
                     c[0] = z[1] * dp[2] - z[2] * dp[1];                       /* torch.cross rm.py:661 */
                     c[1] = z[2] * dp[0] - z[0] * dp[2];
@@ -483,11 +560,11 @@ static void FN(aba_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL 
     for (int i = 1; i < L; ++i) { /* rm.py:539-549 */
         const int d = sp->dof[i];
         REAL qdi = (d >= 0) ? qd[d] : 0;
-        REAL jv[3], zero[3] = {0, 0, 0}, ta[3], tl1[3], tl2[3];
-        for (int k = 0; k < 3; ++k) jv[k] = qdi * (REAL)sp->axis[i * 3 + k];
+        REAL jv[3], jvl[3], ta[3], tl1[3], tl2[3];
+        FN(joint_rate)(sp, i, qdi, jvl, jv);
         /* c = vel.cross_motion_vec(joint_vel)  sva.py:204-213 */
         FN(cross)(va + i * 3, jv, ta);
-        FN(cross)(va + i * 3, zero, tl1);
+        FN(cross)(va + i * 3, jvl, tl1);
         FN(cross)(vl + i * 3, jv, tl2);
         for (int k = 0; k < 3; ++k) { cc[i * 6 + k] = ta[k]; cc[i * 6 + 3 + k] = tl1[k] + tl2[k]; }
         /* pA = vel.cross_force_vec(I vel)  sva.py:215-224 */
@@ -502,7 +579,7 @@ static void FN(aba_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL 
     for (int i = L - 1; i > 0; --i) { /* rm.py:551-604 */
         const int par = sp->parent[i], d = sp->dof[i];
         REAL *S = Sv + i * 6, *Ui = U + i * 6, *IAi = IA + i * 36;
-        for (int k = 0; k < 3; ++k) { S[k] = (REAL)sp->axis[i * 3 + k]; S[3 + k] = 0; }
+        FN(joint_rate)(sp, i, (REAL)1, S + 3, S);   /* S = (ang, lin) of a unit joint rate; (axis, 0) in the reference */
         for (int r = 0; r < 6; ++r) {
             REAL a = 0;
             for (int k = 0; k < 6; ++k) a += IAi[r * 6 + k] * S[k];
@@ -530,7 +607,8 @@ static void FN(aba_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL 
             REAL ud = uu[i] / (dd[i] + (REAL)1e-37);
             for (int k = 0; k < 6; ++k) pa[k] = (pA[i * 6 + k] + tmp[k]) + Ui[k] * ud;
             /* X = joint_pose.to_matrix()  sva.py:138-154: [[R^T, 0], [-R^T S(t), R^T]] */
-            REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+            REAL t[3];
+            FN(joint_trans)(sp, i, (d >= 0) ? q[d] : 0, t);
             REAL JT[9], St[9], Erx[9], X[36], XtI[36];
             FN(mat3_transpose)(J + i * 9, JT);
             FN(skew)(t, St);
@@ -567,7 +645,8 @@ static void FN(aba_sample)(const drm_oracle_spec *sp, const REAL *q, const REAL 
     acc[5] = include_gravity ? (REAL)9.81 : 0; /* base lin acc (0,0,9.81)  rm.py:527-533 */
     for (int i = 1; i < L; ++i) { /* rm.py:611-629 */
         const int par = sp->parent[i], d = sp->dof[i];
-        REAL t[3] = {(REAL)sp->trans[i * 3], (REAL)sp->trans[i * 3 + 1], (REAL)sp->trans[i * 3 + 2]};
+        REAL t[3];
+        FN(joint_trans)(sp, i, (d >= 0) ? q[d] : 0, t);
         REAL JT[9], it[3], S3[9], SR[9], na[3], nl[3], nl2[3];
         FN(mat3_transpose)(J + i * 9, JT);
         FN(mat3_vec)(JT, t, it);

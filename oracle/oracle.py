@@ -29,7 +29,8 @@ class _Spec(ctypes.Structure):
     _fields_ = [("n_links", ctypes.c_int32), ("n_dofs", ctypes.c_int32),
                 ("parent", ctypes.c_void_p), ("dof", ctypes.c_void_p), ("rpy", ctypes.c_void_p),
                 ("trans", ctypes.c_void_p), ("axis", ctypes.c_void_p), ("damping", ctypes.c_void_p),
-                ("mass", ctypes.c_void_p), ("com", ctypes.c_void_p), ("inertia", ctypes.c_void_p)]
+                ("mass", ctypes.c_void_p), ("com", ctypes.c_void_p), ("inertia", ctypes.c_void_p),
+                ("kind", ctypes.c_void_p)]
 
 
 _LIB = None
@@ -58,8 +59,13 @@ class Oracle(object):
             trans=c(spec.trans, np.float32), axis=c(spec.axis, np.float32), damping=c(spec.damping, np.float32),
             mass=c(spec.mass, np.float32), com=c(spec.com, np.float32), inertia=c(spec.inertia, np.float32))
         k = self._keep
+        # joint kinds (0 fixed, 1 revolute, 2 prismatic): the EXTENSION of drm_oracle_impl.h "joint models"; a spec without
+        # them (or with reference_compat) is the reference's model, every moving joint revolute
+        kind = getattr(spec, "kind", None)
+        k["kind"] = c(kind, np.int32) if kind is not None else None
         self._spec = _Spec(self.L, self.n, _ptr(k["parent"]), _ptr(k["dof"]), _ptr(k["rpy"]), _ptr(k["trans"]),
-                           _ptr(k["axis"]), _ptr(k["damping"]), _ptr(k["mass"]), _ptr(k["com"]), _ptr(k["inertia"]))
+                           _ptr(k["axis"]), _ptr(k["damping"]), _ptr(k["mass"]), _ptr(k["com"]), _ptr(k["inertia"]),
+                           _ptr(k["kind"]) if k["kind"] is not None else None)
 
     @staticmethod
     def set_threads(n):

@@ -44,9 +44,12 @@ def urdf_path(name):
     return os.path.join(robot_description_folder, name + ".urdf")
 
 
-def load_model(name, device="cpu"):
+def load_model(name, device="cpu", reference_compat=True):
+    """Models are loaded the way the reference models their joints by default (prismatic = revolute, robot_model.py:122-126):
+    most tests compare with the reference's goldens or with the oracle's restatement of it.  The tests of the correct
+    prismatic / general-axis models pass reference_compat=False."""
     with contextlib.redirect_stdout(io.StringIO()):
-        return DifferentiableRobotModel(urdf_path(name), device=device)
+        return DifferentiableRobotModel(urdf_path(name), device=device, reference_compat=reference_compat)
 
 
 def load_golden(name):

@@ -7,17 +7,28 @@
 // drm_kernels.hip are NOT covered here; the `-m gpu` tests cover the real thing.
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../differentiable-robot-model_amd/csrc/drm_sample.hpp"
+#include "../../differentiable-robot-model_amd/csrc/drm_tree.hpp"
 
 using namespace drm;
 
 namespace {
 
-template <int CAP>
-void fk_t(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float *quat) {
+// the control words of a walk for the loop-structured walks (drm_tree.hpp)
+struct Ctl {
+    const int32_t *w0, *w1;
+    explicit Ctl(const drm_walk *w) : w0(w->ops_i + DRM_OPI_W0 * w->capacity), w1(w->ops_i + DRM_OPI_W1 * w->capacity) {}
+    void operator()(int k, int &a, int &b) const { a = w0[k]; b = w1[k]; }
+};
+
+void fk_loop(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float *quat) {
     const int n = w->n_dofs;
+    const Ctl ctl(w);
     for (int64_t b = 0; b < B; ++b) {
         PoseP slots[DRM_MAX_SLOTS];
+        auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
         auto qf = [&](int d) { return q[b * n + d]; };
         auto save = [&](int s, const PoseP &P) { slots[s] = P; };
         auto load = [&](int s, PoseP &P) { P = slots[s]; };
@@ -25,34 +36,42 @@ void fk_t(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float
             for (int i = 0; i < 3; ++i) pos[(b * T + t) * 3 + i] = p[i];
             for (int i = 0; i < 4; ++i) quat[(b * T + t) * 4 + i] = qt[i];
         };
-        fk_walk<CAP>(w->ops_f, w->ops_i, qf, save, load, emit);
+        fk_tree_walk(w->n_ops, ctl, row, qf, save, load, emit);
     }
 }
 
-template <int CAP>
-void jac_t(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
+void jac_loop(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
     const int n = w->n_dofs;
+    const Ctl ctl(w);
     for (int64_t b = 0; b < B; ++b) {
+        auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
         auto qf = [&](int d) { return q[b * n + d]; };
-        Pose ee;
-        float z[CAP][3], pj[CAP][3];
-        int dof[CAP];
-        load_field<CAP>(w->ops_i, DRM_OPI_DOF, dof);
-        fk_chain<CAP>(w->ops_f, dof, qf, ee, z, pj);
-        if (pos) for (int i = 0; i < 3; ++i) pos[b * 3 + i] = ee.p[i];
-        if (quat) {
-            float Ru[9];
-            for (int i = 0; i < 9; ++i) Ru[i] = ee.R[i];
-            unpermute(w->target_perm, Ru);
-            quat_xyzw(Ru, quat + b * 4);
-        }
         for (int i = 0; i < 3 * n; ++i) { lin[b * 3 * n + i] = 0.f; ang[b * 3 * n + i] = 0.f; }
-        for (int k = 0; k < CAP; ++k) {
-            const int d = w->ops_i[DRM_OPI_DOF * CAP + k];
-            if (d < 0) continue;
-            float dp[3] = {ee.p[0] - pj[k][0], ee.p[1] - pj[k][1], ee.p[2] - pj[k][2]}, c[3];
-            cross3(z[k], dp, c);
-            for (int r = 0; r < 3; ++r) { lin[(b * 3 + r) * n + d] = c[r]; ang[(b * 3 + r) * n + d] = z[k][r]; }
+        PoseP ee;
+        // like the kernel: the walk leaves (z, p) of every moving joint in the two tiles, a second pass forms the columns
+        std::vector<char> pris(n, 0), on(n, 0);
+        fk_jacobian_tree_walk(w->n_ops, ctl, row, qf, ee, [&](int d, const float *z, const float *p, bool prismatic) {
+            for (int r = 0; r < 3; ++r) { ang[(b * 3 + r) * n + d] = z[r]; lin[(b * 3 + r) * n + d] = p[r]; }
+            pris[d] = prismatic; on[d] = 1;
+        });
+        Pose E;
+        pose_from_pairs(ee, E);
+        for (int d = 0; d < n; ++d) {
+            if (!on[d]) continue;
+            float z[3], p[3], c[3];
+            for (int r = 0; r < 3; ++r) { z[r] = ang[(b * 3 + r) * n + d]; p[r] = lin[(b * 3 + r) * n + d]; }
+            if (pris[d]) {
+                for (int r = 0; r < 3; ++r) { lin[(b * 3 + r) * n + d] = z[r]; ang[(b * 3 + r) * n + d] = 0.f; }
+            } else {
+                const float dp[3] = {E.p[0] - p[0], E.p[1] - p[1], E.p[2] - p[2]};
+                cross3(z, dp, c);
+                for (int r = 0; r < 3; ++r) lin[(b * 3 + r) * n + d] = c[r];
+            }
+        }
+        if (pos) for (int i = 0; i < 3; ++i) pos[b * 3 + i] = E.p[i];
+        if (quat) {
+            unpermute(w->target_perm, E.R);
+            quat_xyzw(E.R, quat + b * 4);
         }
     }
 }
@@ -94,36 +113,44 @@ void rnea_arm_8_7(const drm_walk *w, const float *q, const float *qd, const floa
     }
 }
 
-template <int CAP>
-void rnea_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
+struct ParkRec { Force f; float c, s, q; };
+
+void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
     const int n = w->n_dofs;
+    const Ctl ctl(w);
+    std::vector<ParkRec> rec(w->capacity);
     for (int64_t b = 0; b < B; ++b) {
-        Motion ms[DRM_MAX_SLOTS];
-        Force fs[DRM_MAX_SLOTS];
-        for (auto &F : fs) for (int i = 0; i < 3; ++i) F.la[i] = f2_bcast(0.f);
-        auto qf = [&](int d, float &a, float &v, float &acc) {
-            a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f;
-        };
-        auto out = [&](int d, float v) { tau[b * n + d] = v; };
-        auto msave = [&](int s, const Motion &M) { ms[s] = M; };
-        auto mload = [&](int s, Motion &M) { M = ms[s]; };
-        auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) fs[s].la[i] += F.la[i]; };
-        auto ftake = [&](int s, Force &F) {
-            for (int i = 0; i < 3; ++i) { F.la[i] += fs[s].la[i]; fs[s].la[i] = f2_bcast(0.f); }
-        };
-        rnea_walk<CAP>(w->ops_f, w->ops_i, flags, qf, out, msave, mload, fadd, ftake);
+        for (int seg = 0; seg < w->n_segments; ++seg) {
+            Motion ms[DRM_MAX_SLOTS];
+            Force fs[DRM_MAX_SLOTS];
+            for (auto &F : fs) for (int i = 0; i < 3; ++i) F.la[i] = f2_bcast(0.f);
+            auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
+            auto qf = [&](int d, float &a, float &v, float &acc) {
+                a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f;
+            };
+            auto out = [&](int d, float v) { tau[b * n + d] = v; };
+            auto park = [&](int k, const Force &F, float c, float s, float qq) { rec[k] = ParkRec{F, c, s, qq}; };
+            auto unpark = [&](int k, Force &F, float &c, float &s, float &qq) { F = rec[k].f; c = rec[k].c; s = rec[k].s; qq = rec[k].q; };
+            auto msave = [&](int s, const Motion &M) { ms[s] = M; };
+            auto mload = [&](int s, Motion &M) { M = ms[s]; };
+            auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) fs[s].la[i] += F.la[i]; };
+            auto ftake = [&](int s, Force &F) {
+                for (int i = 0; i < 3; ++i) { F.la[i] += fs[s].la[i]; fs[s].la[i] = f2_bcast(0.f); }
+            };
+            rnea_tree_walk(w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1], ctl, row, flags, qf, out, park, unpark,
+                           msave, mload, fadd, ftake);
+        }
     }
 }
 
 // reverse-mode FK: per-sample adjoint sweep, constant gradients summed over the batch in double
-template <int CAP>
 void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, const float *glin, const float *gang,
            uint32_t mask, float *gq, float *gops) {
-    const int n = w->n_dofs;
-    static thread_local double sum[CAP * 12];
-    for (int i = 0; i < CAP * 12; ++i) sum[i] = 0.0;
+    const int n = w->n_dofs, CAP = w->capacity;
+    std::vector<double> sum((size_t)CAP * 12, 0.0);
+    std::vector<Pose> parked(CAP);
     for (int64_t b = 0; b < B; ++b) {
-        Pose ps[DRM_MAX_SLOTS], parked[CAP];
+        Pose ps[DRM_MAX_SLOTS];
         Adjoint as[DRM_MAX_SLOTS] = {};
         auto park = [&](int k, const Pose &P) { parked[k] = P; };
         auto unpark = [&](int k, Pose &P) { P = parked[k]; };
@@ -164,14 +191,14 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
 }
 
 // reverse-mode RNEA: per-sample adjoint sweeps, constant gradients summed over the batch in double
-template <int CAP>
 void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, const float *gtau,
              uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
-    const int n = w->n_dofs;
-    static thread_local double sum[CAP * DRM_OPF_STRIDE];
-    for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) sum[i] = 0.0;
+    const int n = w->n_dofs, CAP = w->capacity;
+    std::vector<double> sum((size_t)CAP * DRM_OPF_STRIDE, 0.0);
+    std::vector<float> recv((size_t)CAP * 26);
+    float (*rec)[26] = reinterpret_cast<float (*)[26]>(recv.data());
     for (int64_t b = 0; b < B; ++b) {
-        float rec[CAP][26], slots[DRM_MAX_SLOTS][36];
+        float slots[DRM_MAX_SLOTS][36];
         for (auto &s : slots) for (float &x : s) x = 0.f;
         if (gq) for (int d = 0; d < n; ++d) { gq[b * n + d] = 0.f; gqd[b * n + d] = 0.f; gqdd[b * n + d] = 0.f; }
         auto qf = [&](int d, float &a, float &v, float &acc) { a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f; };
@@ -190,59 +217,57 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
 }
 
-template <int CAP>
-void crba_t(const drm_walk *w, const float *q, int64_t B, float *H) {
+struct TrigRec { float c, s, q; };
+
+void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
     const int n = w->n_dofs;
+    const Ctl ctl(w);
+    std::vector<TrigRec> tr(w->capacity);
     for (int64_t b = 0; b < B; ++b) {
-        Inertia is[DRM_MAX_SLOTS];
-        for (auto &a : is) inertia_zero(a);
-        static thread_local Axis ss[DRM_MAX_SLOTS][CAP];
         for (int i = 0; i < n * n; ++i) H[b * n * n + i] = 0.f;
-        auto qf = [&](int d) { return q[b * n + d]; };
-        auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
-        auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
-        auto ssave = [&](int s, int j, const Axis &a) { ss[s][j] = a; };
-        auto sload = [&](int s, int j, Axis &a) { a = ss[s][j]; };
-        auto hout = [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; };
-        crba_walk<CAP>(w->ops_f, w->ops_i, qf, iadd, itake, ssave, sload, hout);
+        for (int seg = 0; seg < w->n_segments; ++seg) {
+            Inertia is[DRM_MAX_SLOTS];
+            for (auto &a : is) inertia_zero(a);
+            const int a0 = w->seg_begin[seg], b0 = w->seg_begin[seg + 1];
+            auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
+            auto qf = [&](int d) { return q[b * n + d]; };
+            crba_prepare(a0, b0, ctl, qf, [&](int k, float c, float s, float qq) { tr[k] = TrigRec{c, s, qq}; });
+            auto trig = [&](int k, float &c, float &s, float &qq) { c = tr[k].c; s = tr[k].s; qq = tr[k].q; };
+            auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
+            auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
+            auto hout = [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; };
+            crba_tree_walk(a0, b0, ctl, row, trig, iadd, itake, hout);
+        }
     }
 }
 
-template <int CAP>
-void fd_t(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
+// forward dynamics: per segment, H (packed lower triangle of the segment's block) + bias torques + L^T D L solve
+void fd_loop(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
     const int n = w->n_dofs;
-    static thread_local float H[DRM_MAX_DOFS * DRM_MAX_DOFS], T[DRM_MAX_DOFS * (DRM_MAX_DOFS + 1) / 2];
+    std::vector<float> H((size_t)n * n), T((size_t)n * (n + 1) / 2), x(n);
     for (int64_t b = 0; b < B; ++b) {
-        crba_t<CAP>(w, q + b * n, 1, H);
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j <= i; ++j) T[tri_index(i, j)] = H[i * n + j];
-        float *x = qdd + b * n;
-        rnea_t<CAP>(w, q + b * n, qd + b * n, nullptr, 1, flags, x);
-        for (int d = 0; d < n; ++d) x[d] = f[b * n + d] - x[d];
-        cholesky_solve(n, T, x);
+        crba_loop(w, q + b * n, 1, H.data());
+        rnea_loop(w, q + b * n, qd + b * n, nullptr, 1, flags, x.data());
+        for (int seg = 0; seg < w->n_segments; ++seg) {
+            const int lo = w->seg_dof_lo[seg], cnt = w->seg_dof_cnt[seg];
+            for (int i = 0; i < cnt; ++i)
+                for (int j = 0; j <= i; ++j) T[tri_index(i, j)] = H[(lo + i) * n + lo + j];
+            float *r = qdd + b * n + lo;
+            for (int d = 0; d < cnt; ++d) r[d] = f[b * n + lo + d] - x[lo + d];
+            ltdl_solve(cnt, T.data(), r);
+        }
     }
 }
 
 } // namespace
 
-#define DISPATCH(FN, ...)                        \
-    switch (w->capacity) {                       \
-    case 4: FN<4>(__VA_ARGS__); break;           \
-    case 8: FN<8>(__VA_ARGS__); break;           \
-    case 12: FN<12>(__VA_ARGS__); break;         \
-    case 16: FN<16>(__VA_ARGS__); break;         \
-    case 24: FN<24>(__VA_ARGS__); break;         \
-    case 32: FN<32>(__VA_ARGS__); break;         \
-    default: return -2;                          \
-    }
-
 extern "C" {
 int emu_fk(const drm_walk *w, const float *q, int64_t B, int32_t T, float *pos, float *quat) {
-    DISPATCH(fk_t, w, q, B, T, pos, quat)
+    fk_loop(w, q, B, T, pos, quat);
     return 0;
 }
 int emu_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
-    DISPATCH(jac_t, w, q, B, pos, quat, lin, ang)
+    jac_loop(w, q, B, pos, quat, lin, ang);
     return 0;
 }
 int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang) {
@@ -257,12 +282,12 @@ int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float
 }
 int emu_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
                       const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
-    DISPATCH(rneab_t, w, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops)
+    rneab_t(w, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops);
     return 0;
 }
 int emu_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int32_t flags,
                          float *qdd) {
-    DISPATCH(fd_t, w, q, qd, f, B, flags, qdd)
+    fd_loop(w, q, qd, f, B, flags, qdd);
     return 0;
 }
 int emu_link_rows(const float *params, int32_t n, float *rows) {
@@ -329,21 +354,21 @@ int emu_crba_arm(const drm_walk *w, const float *q, int64_t B, float *H) {
     return 0;
 }
 int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
-    DISPATCH(crba_t, w, q, B, H)
+    crba_loop(w, q, B, H);
     return 0;
 }
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,
                     float *gops) {
-    DISPATCH(fkb_t, w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops)
+    fkb_t(w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops);
     return 0;
 }
 int emu_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *gpos, const float *glin,
                              const float *gang, uint32_t mask, float *gq, float *gops) {
-    DISPATCH(fkb_t, w, q, B, 1, gpos, glin, gang, mask, gq, gops)
+    fkb_t(w, q, B, 1, gpos, glin, gang, mask, gq, gops);
     return 0;
 }
 int emu_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
-    DISPATCH(rnea_t, w, q, qd, qdd, B, flags, tau)
+    rnea_loop(w, q, qd, qdd, B, flags, tau);
     return 0;
 }
 }

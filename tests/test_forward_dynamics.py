@@ -1,4 +1,4 @@
-"""Forward dynamics (K8, csrc/drm_forward_dynamics.hip: composite-rigid-body H + RNEA bias torques + Cholesky).
+"""Forward dynamics (K8, csrc/drm_forward_dynamics.hip: composite-rigid-body H + RNEA bias torques + leaf-to-root L^T D L solve).
 
 CPU (not gpu): the oracle's line-by-line restatement of the reference's articulated-body recursion
 (robot_model.py:487-624) against accelerations recorded from the UNMODIFIED reference (tests/golden/golden_fd.npz,
@@ -27,13 +27,12 @@ import os
 TOL = 2e-3
 TOL_ARMS = 1e-4
 ARMS = ("panda_no_gripper", "iiwa7", "2link_robot", "panda")
-# a 7-DoF arm carrying a 16-DoF hand: cond(H) ~ 1e8 (kilogram links above gram links).  A dense factorisation of H
-# loses cond(H) * eps where the articulated-body recursion divides joint by joint; held to 1e-2
-TOL_BY_ROBOT = {"iiwa7_allegro": 1e-2}
 
 
 def tol_of(robot):
-    return TOL_BY_ROBOT.get(robot, TOL_ARMS if robot in ARMS else TOL)
+    # one bound for every robot that carries gram-scale links, a 7-DoF arm with a 16-DoF hand (cond(H) ~ 1e8) included:
+    # H is factorised L^T D L from the distal joints inwards, like the reference's recursion (drm_sample.hpp ltdl_solve)
+    return TOL_ARMS if robot in ARMS else TOL
 FLAGS = ((1, 0), (1, 1), (0, 0))
 
 

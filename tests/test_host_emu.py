@@ -31,8 +31,10 @@ def emu(request):
     cxx = request.param
     src = os.path.join(HERE, "host_emu", "host_emu.cpp")
     lib = os.path.join(HERE, "host_emu", "libdrm_host_emu%s.so" % ("" if cxx == "g++" else "_clang"))
-    hdr = os.path.join(HERE, "..", "differentiable-robot-model_amd", "csrc", "drm_sample.hpp")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    csrc = os.path.join(HERE, "..", "differentiable-robot-model_amd", "csrc")
+    deps = [src, os.path.join(csrc, "drm_sample.hpp"), os.path.join(csrc, "drm_tree.hpp"),
+            os.path.join(HERE, "..", "include", "drm_hip.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
         # -O1: the straight-line templates take minutes at -O2/-O3 and the checks here are about arithmetic and
         # front-end semantics (the clang quirk above reproduces at every optimisation level), not about speed
         subprocess.check_call([cxx if cxx == "g++" else ROCM_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared",
@@ -49,8 +51,8 @@ def host_walk(model, prog):
     ops_f = np.ascontiguousarray((table[prog.gather.reshape(-1)] * prog.gsign.reshape(-1)).reshape(prog.capacity, 32),
                                  np.float32)
     perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
-    walk = DrmWalk(ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, prog.n_ops, prog.capacity, model._n_dofs,
-                   prog.n_slots, prog.dof_mask, perm, prog.shape)
+    from differentiable_robot_model_amd.backend import fill_walk_struct
+    walk = fill_walk_struct(DrmWalk, prog, ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, model._n_dofs, perm)
     return walk, ops_f
 
 

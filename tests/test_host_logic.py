@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from differentiable_robot_model_amd import backend
-from differentiable_robot_model_amd.flatten import (CAPACITIES, OPF_F, OPF_IO, OPF_MCOM, OPF_T, OPI_DOF, OPI_OUT, OPI_SAVE,
+from differentiable_robot_model_amd.flatten import (OPF_F, OPF_IO, OPF_MCOM, OPF_T, OPI_DOF, OPI_OUT, OPI_SAVE,
                                                     opf_fij, opf_ti,
                                                     OPI_SRC, SRC_PREV, SRC_ROOT, UnsupportedRobotError, build_walk)
 from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel
@@ -57,8 +57,15 @@ def test_lenient_xml_and_bad_robots(tmp_path):
     skew.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="revolute"><parent link="a"/>'
                     '<child link="b"/><axis xyz="0 0.7071 0.7071"/><limit lower="-1" upper="1" effort="1" velocity="1"/>'
                     '</joint></robot>')
+    with pytest.raises(UnsupportedRobotError):      # the reference cannot model this axis (rigid_body.py:149-154) ...
+        DifferentiableRobotModel(str(skew), device="cpu", reference_compat=True)
+    ok = DifferentiableRobotModel(str(skew), device="cpu")   # ... the engine does: the joint becomes two ops
+    assert ok._spec.skew.tolist() == [False, True] and build_walk(ok._spec, whole_tree=True).n_ops == 2
+    floating = tmp_path / "floating.urdf"
+    floating.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="floating"><parent link="a"/>'
+                        '<child link="b"/><limit lower="-1" upper="1" effort="1" velocity="1"/></joint></robot>')
     with pytest.raises(UnsupportedRobotError):
-        DifferentiableRobotModel(str(skew), device="cpu")
+        DifferentiableRobotModel(str(floating), device="cpu")
     order = tmp_path / "order.urdf"
     order.write_text('<robot name="r"><link name="a"/><link name="c"/><link name="b"/>'
                      '<joint name="j1" type="fixed"><parent link="a"/><child link="b"/></joint>'
@@ -74,7 +81,7 @@ def test_walk_program_invariants(robot):
     spec = m._spec
     L = spec.n_links
     prog = build_walk(spec, whole_tree=True)
-    assert prog.n_ops == L - 1 and prog.capacity in CAPACITIES and prog.capacity >= prog.n_ops
+    assert prog.n_ops == L - 1 and prog.capacity % 4 == 0 and prog.n_ops <= prog.capacity < prog.n_ops + 8
     assert sorted(prog.links.tolist()) == list(range(1, L))
     assert prog.dof_mask == (1 << spec.n_dofs) - 1
     saved = {}
@@ -195,6 +202,9 @@ def test_abi_argument_errors_need_no_gpu():
     assert b"NULL" in lib.drm_last_error()
     w = backend.DrmWalk(1, 1, 9, 8, 7, 0, 0, 2, 0)   # n_ops > capacity
     assert lib.drm_rnea(ctypes.byref(w), None, None, None, 1, 0, None, None) == -1
-    w = backend.DrmWalk(1, 1, 8, 10, 7, 0, 0, 2, 0)  # unsupported capacity
+    w = backend.DrmWalk(1, 1, 8, 10, 7, 0, 0, 2, 0)  # capacity is not a multiple of 4
+    assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -1
+    w = backend.DrmWalk(1, 1, 8, 8, 7, 17, 0, 2, 0)  # more save slots than the kernels have
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -2
-    assert ctypes.sizeof(backend.DrmWalk) == 48
+    # struct drm_walk: 48 bytes of scalars + n_segments + seg_begin[9] + seg_dof_lo[8] + seg_dof_cnt[8] + prefix_end
+    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1) + 4

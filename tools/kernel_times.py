@@ -54,7 +54,7 @@ for B in sizes:
     acc = torch.empty(B, 7, device="cuda")
     def fd():
         backend._check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 1,
-                                                acc.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                acc.data_ptr(), None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(fd)
     print("fwd dyn     panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s" % (B, us, B * 112 / us / 1e3, B / us / 1e3))
     gtau = torch.randn(B, 7, device="cuda")
@@ -105,7 +105,7 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     print("rnea        allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(wt), qa.data_ptr(), B, Ha.data_ptr(), st())), launches=20)
     print("crba        allegro B=%8d %9.2f us  %7.1f GB/s (1088 B/eval) %6.2f Gevals/s" % (B, us, B * 1088 / us / 1e3, B / us / 1e3))
-    us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), st())), launches=20)
+    us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), None, st())), launches=20)
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
     print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
