@@ -77,9 +77,9 @@ def load_library(path: str = None):
         lib.drm_rnea.restype = ctypes.c_int
         lib.drm_rnea.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
         lib.drm_fk_backward.restype = ctypes.c_int
-        lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp]
+        lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
         lib.drm_fk_jacobian_backward.restype = ctypes.c_int
-        lib.drm_fk_jacobian_backward.argtypes = [wp, vp, i64, vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
+        lib.drm_fk_jacobian_backward.argtypes = [wp, vp, i64, vp, vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
         lib.drm_fk_backward_scratch_floats.restype = i64
         lib.drm_fk_backward_scratch_floats.argtypes = [i64, i32]
         lib.drm_rnea_backward.restype = ctypes.c_int
@@ -362,8 +362,9 @@ def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
 
 
 def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_dofs: int, param_mask: int,
-                want_grad_q: bool):
-    """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for a loss gradient on the target positions."""
+                want_grad_q: bool, grad_rot=None):
+    """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for a loss gradient on the target positions (grad_pos
+    [B,T,3]) and, optionally, on the target rotation matrices (grad_rot [B,T,3,3])."""
     lib = load_library()
     if not prog.slots_unique:
         raise RuntimeError("backward FK needs a walk whose branch points own their save slots (more than %d "
@@ -371,6 +372,8 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     grad_pos = _dev_f32(grad_pos.reshape(B, n_targets * 3), "grad_pos", n_targets * 3)
+    if grad_rot is not None:
+        grad_rot = _dev_f32(grad_rot.reshape(B, n_targets * 9), "grad_rot", n_targets * 9)
     dev = q.device
     grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
     grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
@@ -380,13 +383,14 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     with torch.cuda.device(dev):
         _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
+                                   grad_rot.data_ptr() if grad_rot is not None else None,
                                    ctypes.c_uint32(param_mask), grad_q.data_ptr() if want_grad_q else None,
                                    grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
     return grad_q, grad_ops
 
 
 def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin, grad_ang, n_dofs: int,
-                         param_mask: int, want_grad_q: bool):
+                         param_mask: int, want_grad_q: bool, grad_rot=None):
     """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for loss gradients on the Jacobian (and, optionally, the
     target position) of the chain walk ``prog``."""
     lib = load_library()
@@ -395,6 +399,7 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
     grad_lin = _dev_f32(grad_lin.reshape(B, 3 * n_dofs), "grad_lin_jac", 3 * n_dofs)
     grad_ang = _dev_f32(grad_ang.reshape(B, 3 * n_dofs), "grad_ang_jac", 3 * n_dofs)
     grad_pos = _dev_f32(grad_pos.reshape(B, 3), "grad_pos", 3) if grad_pos is not None else None
+    grad_rot = _dev_f32(grad_rot.reshape(B, 9), "grad_rot", 9) if grad_rot is not None else None
     grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
     grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
     if grad_q is None and grad_ops is None:
@@ -403,7 +408,8 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     with torch.cuda.device(dev):
         _check(lib.drm_fk_jacobian_backward(ctypes.byref(walk), q.data_ptr(), B,
-                                            grad_pos.data_ptr() if grad_pos is not None else None, grad_lin.data_ptr(),
+                                            grad_pos.data_ptr() if grad_pos is not None else None,
+                                            grad_rot.data_ptr() if grad_rot is not None else None, grad_lin.data_ptr(),
                                             grad_ang.data_ptr(), ctypes.c_uint32(param_mask),
                                             grad_q.data_ptr() if want_grad_q else None,
                                             grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))

@@ -32,7 +32,8 @@ template <bool JAC, bool PARK_HBM>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n,
                        int n_slots, int T, const float *__restrict__ q, const float *__restrict__ gpos,
-                       const float *__restrict__ glin, const float *__restrict__ gang, int64_t B, float *__restrict__ gq,
+                       const float *__restrict__ grot, const float *__restrict__ glin, const float *__restrict__ gang, int64_t B,
+                       float *__restrict__ gq,
                        uint32_t param_mask, float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q,
                        uint32_t magic_g, uint32_t magic_j, int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,8 +132,16 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                 if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in this wave's fixed order
             }
         };
+        // dL/dR of a target (the loss reads its quaternion): 9 floats per (sample, target), read straight from HBM
+        const float *rrow = grot ? grot + (b0 + (live ? lane : 0u)) * (int64_t)(9 * T) : nullptr;
+        auto rot_in = [&](int t, float *Rb) -> bool {
+            if (!grot) return false;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rb[i] = live ? rrow[t * 9 + i] : 0.0f;
+            return true;
+        };
         fk_backward_walk<JAC>(ops_f, ctl, n_ops, param_mask, gq != nullptr, qf, grad_in, pose_save, pose_load, adj_add,
-                              adj_take, gq_out, param_out, park, unpark, jac_lin, jac_ang);
+                              adj_take, gq_out, param_out, park, unpark, jac_lin, jac_ang, rot_in);
         if (gq) {
             wave_lds_sync();
             tile_store<0>(gq + b0 * n, rows, n, magic_q, lgq, lane, full && (n & 1) && (align & AL_TAU), full && (align & AL_TAU));
@@ -238,7 +247,7 @@ extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
 }
 
 static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                              const float *grad_lin, const float *grad_ang, uint32_t param_mask, float *grad_q,
+                              const float *grad_rot, const float *grad_lin, const float *grad_ang, uint32_t param_mask, float *grad_q,
                               float *grad_ops_f, float *scratch, void *stream) {
     const bool jac = grad_lin != nullptr;
     if (B < 0 || n_targets < 1) return fail(DRM_ERR_INVALID, "negative batch or no targets");
@@ -264,7 +273,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
 #ifndef DRM_NO_ARM_KERNEL
     {
         const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)grad_pos | (uintptr_t)grad_q | (uintptr_t)w->ops_f;
-        if (!jac && T == 1 && (w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && n == 7 && (ptrs & 15u) == 0 && B >= WAVE &&
+        if (!jac && !grad_rot && T == 1 && (w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && n == 7 && (ptrs & 15u) == 0 && B >= WAVE &&
             B / WAVE < 0x7fffffffLL) {
             // 7-DoF arms, one target at the end of the chain: full tiles through the chain kernel, the ragged tail (if
             // any) through the generic kernel below with its rows of partial sums appended
@@ -278,7 +287,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             if (rc) return rc;
             rows_done = waves_a;
             partials += (int64_t)waves_a * cap * BWD_FIELDS;
-            q += done * n; grad_pos += done * 3;
+            q += done * n; grad_pos += done * 3;   // (grad_rot is NULL on this path)
             if (grad_q) grad_q += done * n;
             B -= done;
         }
@@ -305,7 +314,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
         rc = ensure_lds(fk_backward_kernel<JAC, HBM>, g.lds_bytes);                                                    \
         if (rc) return rc;                                                                                             \
         hipLaunchKernelGGL((fk_backward_kernel<JAC, HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, cap,   \
-                           (int)w->n_ops, n, (int)w->n_slots, T, q, grad_pos, grad_lin, grad_ang, B, grad_q,           \
+                           (int)w->n_ops, n, (int)w->n_slots, T, q, grad_pos, grad_rot, grad_lin, grad_ang, B, grad_q, \
                            param_mask, partials, park, div_magic(n), div_magic(3 * T), div_magic(3 * n),               \
                            g.lds_per_wave, align);                                                                     \
     }
@@ -328,19 +337,26 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
 }
 
 extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                               uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+                               const float *grad_rot, uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch,
+                               void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !grad_pos) return fail(DRM_ERR_INVALID, "q / grad_pos must not be NULL");
-    return fk_backward_launch(w, q, B, n_targets, grad_pos, nullptr, nullptr, param_mask, grad_q, grad_ops_f, scratch, stream);
+    if (w->n_slots > DRM_MAX_SLOTS_BACKWARD || w->capacity > DRM_MAX_OPS)
+        return fail(DRM_ERR_UNSUPPORTED, "the backward kernels take walks of up to %s%ld links and %ld save slots", "", (long)DRM_MAX_OPS,
+                    (long)DRM_MAX_SLOTS_BACKWARD);
+    return fk_backward_launch(w, q, B, n_targets, grad_pos, grad_rot, nullptr, nullptr, param_mask, grad_q, grad_ops_f, scratch,
+                              stream);
 }
 
 extern "C" int drm_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *grad_pos,
-                                        const float *grad_lin_jac, const float *grad_ang_jac, uint32_t param_mask,
-                                        float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+                                        const float *grad_rot, const float *grad_lin_jac, const float *grad_ang_jac,
+                                        uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !grad_lin_jac || !grad_ang_jac) return fail(DRM_ERR_INVALID, "q / grad_lin_jac / grad_ang_jac must not be NULL");
     if (w->n_slots != 0) return fail(DRM_ERR_INVALID, "the walk must be the root->link chain of the Jacobian's target (no branch points)");
-    return fk_backward_launch(w, q, B, 1, grad_pos, grad_lin_jac, grad_ang_jac, param_mask, grad_q, grad_ops_f, scratch, stream);
+    if (w->capacity > DRM_MAX_OPS) return fail(DRM_ERR_UNSUPPORTED, "the backward kernels take walks of up to %s%ld links", "", (long)DRM_MAX_OPS);
+    return fk_backward_launch(w, q, B, 1, grad_pos, grad_rot, grad_lin_jac, grad_ang_jac, param_mask, grad_q, grad_ops_f, scratch,
+                              stream);
 }

@@ -444,16 +444,23 @@ struct Adjoint {
 struct NoJacobianGrad { // fk_backward_walk without Jacobian gradients
     DRM_HD void operator()(int, float *) const {}
 };
+struct NoRotationGrad { // fk_backward_walk without gradients on the targets' rotations
+    DRM_HD bool operator()(int, float *) const { return false; }
+};
 // The two sweeps are LOOPS over the n_ops links of the walk (one control word decoded per iteration, no identity
 // padding, nothing indexed by a compile-time op number), the world pose of every op is parked by the caller between
 // them (LDS, or HBM for walks that do not fit):
 //   ctl = the control-word field of the int table (DRM_OPI_CTRL);   park(k, Pose) / unpark(k, Pose&)
+//   grot(t, Rbar[9]) -> true if the loss depends on the ROTATION R_t of target t (the quaternion output: the reference
+//   copies entries of R into it, spatial_vector_algebra.py:108-136, so torch autograd differentiates through them), with
+//   Rbar = dL/dR_t, row-major, for the target's TRUE frame (after the axis canonicalisation is undone).  A rotation
+//   adjoint enters the sweep as  M_t += Rbar R_t^T  (M = Rbar R^T in general; see the JAC note below).
 template <bool JAC = false, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG,
-          class PARK, class UNPARK, class GL = NoJacobianGrad, class GA = NoJacobianGrad>
+          class PARK, class UNPARK, class GL = NoJacobianGrad, class GA = NoJacobianGrad, class GR = NoRotationGrad>
 DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, uint32_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
                              ATAKE adj_take, GQ gq_out, PG param_out, PARK park, UNPARK unpark, GL glin = GL(),
-                             GA gang = GA()) {
+                             GA gang = GA(), GR grot = GR()) {
     // ---- forward: world pose of every op, parked for the adjoint sweep -------
     // JAC (the walk is the root -> end-effector chain, its last op the target): column d(k) of the geometric Jacobian
     // is (lin, ang) = (z_k x (p_e - p_k), z_k), so loss gradients (l_k, a_k) on the columns are gradients on the
@@ -509,7 +516,21 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         }
         Pose Pk;
         unpark(k, Pk);
-        if (out >= 0) grad_in(out, tot.G);
+        if (out >= 0) {
+            grad_in(out, tot.G);
+            float Rb[9];
+            if (grot(out, Rb)) {
+                float Rt[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rt[i] = Pk.R[i];
+                unpermute(ctl_field(c, DRM_OPI_PERM), Rt); // the frame the quaternion was taken from
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        tot.M[i * 3 + j] += Rb[i * 3 + 0] * Rt[j * 3 + 0] + Rb[i * 3 + 1] * Rt[j * 3 + 1] + Rb[i * 3 + 2] * Rt[j * 3 + 2];
+            }
+        }
         if (JAC) {
             if (out >= 0) { tot.G[0] += Se[0]; tot.G[1] += Se[1]; tot.G[2] += Se[2]; }
             if (dof >= 0) {

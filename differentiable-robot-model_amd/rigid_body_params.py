@@ -31,10 +31,12 @@ class PositiveScalar(torch.nn.Module):
     def __init__(self, min_val=0.0, init_param_std=1.0, init_param=None):
         super().__init__()
         self._min_val = float(min_val)
+        # `l` is 0-dim and forward() returns a 0-dim value, as in the reference (rigid_body_params.py:27-43): its
+        # state_dicts (`...mass.l`) load here unchanged
         if init_param is None:
-            value = torch.empty(1).normal_(mean=0.0, std=init_param_std)
+            value = torch.empty(1).normal_(mean=0.0, std=init_param_std).squeeze()
         else:  # init_param is the VALUE to start from, as in the reference: l = sqrt(value - min_val)
-            value = torch.sqrt(torch.as_tensor(init_param, dtype=torch.float32).reshape(1) - self._min_val)
+            value = torch.sqrt(torch.as_tensor(init_param, dtype=torch.float32).reshape(()) - self._min_val)
         self.l = torch.nn.Parameter(value.clone())
 
     def forward(self):

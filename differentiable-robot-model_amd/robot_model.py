@@ -89,30 +89,77 @@ class _DeviceWalk:
     learnable_plan: Optional[tuple] = None   # (learnable links, constant walk table, row selector) of _ops_f_learnable
 
 
+def _quat_grad_to_rot(quat: torch.Tensor, grad_quat: torch.Tensor) -> torch.Tensor:
+    """dL/dR [..., 3, 3] of the rotation matrix a quaternion output was taken from, given dL/dquat [..., 4] (xyzw).
+
+    The reference's get_quaternion (spatial_vector_algebra.py:108-136) copies sums and differences of entries of R into
+    the un-normalised quaternion u inside autograd and scales it by 0.5 / math.sqrt(t) — a Python float, i.e. a constant
+    to autograd.  So dL/du = dL/dquat * scale and dL/dR scatters dL/du back onto the entries each case reads:
+      t = tr R + 1 > 1:  u = (R21 - R12, R02 - R20, R10 - R01, t)
+      else, with i the largest diagonal entry and (i, j, k) cyclic:  t = R_ii - (R_jj + R_kk) + 1,
+                         u_i = t, u_j = R_ij + R_ji, u_k = R_ki + R_ik, u_w = R_kj - R_jk.
+    R is rebuilt from the (unit) quaternion output; the case is re-derived from it with the reference's tests."""
+    x, y, z, w = quat.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)
+    r = lambda i, j: R[..., 3 * i + j]
+    tW = r(0, 0) + r(1, 1) + r(2, 2) + 1
+    isW = tW > 1
+    yx = r(1, 1) > r(0, 0)
+    isZ = ~isW & (r(2, 2) > torch.where(yx, r(1, 1), r(0, 0)))
+    isY = ~isW & ~isZ & yx
+    isX = ~isW & ~isZ & ~isY
+    tX = r(0, 0) - (r(1, 1) + r(2, 2)) + 1
+    tY = r(1, 1) - (r(2, 2) + r(0, 0)) + 1
+    tZ = r(2, 2) - (r(0, 0) + r(1, 1)) + 1
+    t = torch.where(isW, tW, torch.where(isZ, tZ, torch.where(isY, tY, tX)))
+    gu = grad_quat * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
+    gx, gy, gz, gw = gu.unbind(-1)
+    zero = torch.zeros_like(gx)
+    out = torch.zeros_like(R)
+
+    def scatter(mask, entries):
+        for (i, j), v in entries:
+            out[..., 3 * i + j] += torch.where(mask, v, zero)
+
+    scatter(isW, [((2, 1), gx), ((1, 2), -gx), ((0, 2), gy), ((2, 0), -gy), ((1, 0), gz), ((0, 1), -gz),
+                  ((0, 0), gw), ((1, 1), gw), ((2, 2), gw)])
+    for mask, (i, j, k), (gi, gj, gk) in ((isX, (0, 1, 2), (gx, gy, gz)), (isY, (1, 2, 0), (gy, gz, gx)),
+                                          (isZ, (2, 0, 1), (gz, gx, gy))):
+        scatter(mask, [((i, i), gi), ((j, j), -gi), ((k, k), -gi), ((i, j), gj), ((j, i), gj), ((k, i), gk), ((i, k), gk),
+                       ((k, j), gw), ((j, k), -gw)])
+    return out.reshape(quat.shape[:-1] + (3, 3))
+
+
 class _FkPositions(torch.autograd.Function):
     """FK of the walk's targets with a hand-written backward (csrc/drm_fk_backward.hip).
 
-    Differentiable: positions with respect to q and to the walk's constant table (and through its gather, to
-    learnable ``trans`` / ``rot_angles`` parametrisations).  The quaternion output carries no gradient, as in
-    the reference (spatial_vector_algebra.py:108-136 builds it outside autograd).
+    Differentiable with respect to q and to the walk's constant table (and through its gather, to learnable ``trans`` /
+    ``rot_angles`` parametrisations): the positions, and the quaternions the way the reference's are — through the
+    entries of R they are assembled from, with the normalisation held constant (spatial_vector_algebra.py:108-136;
+    _quat_grad_to_rot above).
     """
 
     @staticmethod
     def forward(ctx, q, ops_f, dw, n_targets, n_dofs, param_mask):
         pos, quat = backend.fk(dw.program, ops_f, dw.ops_i, q, n_targets, n_dofs)
-        ctx.save_for_backward(q, ops_f)
+        ctx.save_for_backward(q, ops_f, quat)
         ctx.dw, ctx.n_targets, ctx.n_dofs, ctx.param_mask = dw, n_targets, n_dofs, param_mask
-        ctx.mark_non_differentiable(quat)
+        ctx.set_materialize_grads(False)
         return pos, quat
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_pos, _grad_quat):
-        q, ops_f = ctx.saved_tensors
+    def backward(ctx, grad_pos, grad_quat):
+        q, ops_f, quat = ctx.saved_tensors
         want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dw = ctx.dw
+        if grad_pos is None:
+            grad_pos = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
+        grad_rot = _quat_grad_to_rot(quat, grad_quat.to(torch.float32)) if grad_quat is not None else None
         grad_q, grad_ops = backend.fk_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, ctx.n_targets, ctx.n_dofs,
-                                               ctx.param_mask if want_p else 0, want_q)
+                                               ctx.param_mask if want_p else 0, want_q, grad_rot)
         if grad_q is not None:
             grad_q = grad_q.to(q.dtype).reshape(q.shape)
         return grad_q, grad_ops, None, None, None, None
@@ -121,25 +168,29 @@ class _FkPositions(torch.autograd.Function):
 class _FkJacobian(torch.autograd.Function):
     """Fused FK + geometric Jacobian with a hand-written backward (csrc/drm_fk_backward.hip, JAC form): position and
     both Jacobians are differentiable with respect to q and to the walk's constant table (learnable ``trans`` /
-    ``rot_angles``), as torch autograd makes them in the reference (robot_model.py:626-667); the quaternion carries no
-    gradient (spatial_vector_algebra.py:108-136)."""
+    ``rot_angles``), as torch autograd makes them in the reference (robot_model.py:626-667); so is the quaternion, through
+    the entries of R it is assembled from (_quat_grad_to_rot)."""
 
     @staticmethod
     def forward(ctx, q, ops_f, dw, n_dofs, param_mask):
         pos, quat, lin, ang = backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, n_dofs)
-        ctx.save_for_backward(q, ops_f)
+        ctx.save_for_backward(q, ops_f, quat)
         ctx.dw, ctx.n_dofs, ctx.param_mask = dw, n_dofs, param_mask
-        ctx.mark_non_differentiable(quat)
+        ctx.set_materialize_grads(False)
         return pos, quat, lin, ang
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_pos, _grad_quat, grad_lin, grad_ang):
-        q, ops_f = ctx.saved_tensors
+    def backward(ctx, grad_pos, grad_quat, grad_lin, grad_ang):
+        q, ops_f, quat = ctx.saved_tensors
         want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dw = ctx.dw
+        zeros = lambda: torch.zeros(q.shape[0], 3, ctx.n_dofs, device=q.device, dtype=torch.float32)
+        grad_lin = grad_lin if grad_lin is not None else zeros()
+        grad_ang = grad_ang if grad_ang is not None else zeros()
+        grad_rot = _quat_grad_to_rot(quat, grad_quat.to(torch.float32)) if grad_quat is not None else None
         grad_q, grad_ops = backend.fk_jacobian_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, grad_lin, grad_ang,
-                                                        ctx.n_dofs, ctx.param_mask if want_p else 0, want_q)
+                                                        ctx.n_dofs, ctx.param_mask if want_p else 0, want_q, grad_rot)
         if grad_q is not None:
             grad_q = grad_q.to(q.dtype).reshape(q.shape)
         return grad_q, grad_ops, None, None, None
@@ -179,7 +230,8 @@ class _MassMatrix(torch.autograd.Function):
     """Joint-space inertia matrix with a backward built on the reference's own definition of H
     (robot_model.py:402-450): column j is the inverse dynamics of a unit acceleration of joint j at rest without
     gravity, H[:, :, j] = ID(q, 0, e_j), so for a loss gradient G on H the gradients with respect to q and to the
-    learnable link parameters are n passes of the RNEA backward kernel with qdd = e_j and grad_tau = G[:, :, j]."""
+    learnable link parameters are those of the RNEA with qdd = e_j and grad_tau = G[:, :, j], summed over j — one launch of
+    the RNEA backward kernel over the batch stacked n times."""
 
     @staticmethod
     def forward(ctx, q, ops_f, dw, n_dofs, param_mask):
@@ -196,18 +248,27 @@ class _MassMatrix(torch.autograd.Function):
         want_q = ctx.needs_input_grad[0]
         mask = ctx.param_mask if ctx.needs_input_grad[1] else 0
         G = grad_H.to(torch.float32)
-        zero = torch.zeros_like(q)
+        qf = q.to(torch.float32)
+        B = qf.shape[0]
+        # all columns in ONE launch of the RNEA backward kernel: the batch is stacked n times (rows j B .. (j + 1) B - 1 carry
+        # qdd = e_j and grad_tau = G[:, :, j]); the kernel's fixed-order reduction sums the parameter gradients over all of
+        # them.  Very large batches go in groups of columns (at most 2^22 stacked rows per launch).
+        group = max(1, min(n, (1 << 22) // max(B, 1)))
         gq = grad_ops = None
-        for j in range(n):
-            unit = torch.zeros_like(q)
-            unit[:, j] = 1.0
-            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, zero, unit, G[:, :, j].contiguous(), False,
-                                              False, n, mask, want_q)
+        eye = torch.eye(n, device=qf.device, dtype=torch.float32)
+        for j0 in range(0, n, group):
+            cols = min(group, n - j0)
+            qs = qf.repeat(cols, 1)
+            unit = eye[j0:j0 + cols].repeat_interleave(B, dim=0)
+            gt = G[:, :, j0:j0 + cols].permute(2, 0, 1).reshape(cols * B, n).contiguous()
+            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, qs, torch.zeros_like(qs), unit, gt, False, False, n,
+                                              mask, want_q)
             if gin is not None:
-                gq = gin[0] if gq is None else gq + gin[0]
+                part = gin[0].reshape(cols, B, n).sum(dim=0)
+                gq = part if gq is None else gq + part
             if gops is not None:
                 grad_ops = gops if grad_ops is None else grad_ops + gops
-        return (gq.reshape(q.shape) if gq is not None else None), grad_ops, None, None, None
+        return (gq.to(q.dtype).reshape(q.shape) if gq is not None else None), grad_ops, None, None, None
 
 
 class _ForwardDynamics(torch.autograd.Function):
@@ -479,6 +540,16 @@ class DifferentiableRobotModel(torch.nn.Module):
                 mask |= 1 << k
         return mask
 
+    def _differentiable(self, dw: _DeviceWalk) -> None:
+        """The backward kernels know revolute and fixed joints, walks of up to 64 links and 4 nested branch points."""
+        if (self._spec.kind == KIND_PRISMATIC).any():
+            raise NotImplementedError(
+                "gradients through a robot with prismatic joints are not implemented yet (the forward kernels model them; "
+                "the backward kernels do not) — detach the inputs, or load the robot with reference_compat=True")
+        if not dw.program.backward_ok:
+            raise NotImplementedError("gradients need a walk of <= 64 links with <= 4 nested branch points (this one: %d links, "
+                                      "%d slots)" % (dw.program.n_ops, dw.program.n_slots))
+
     def _require_device(self):
         if self._device.type != "cuda":
             raise RuntimeError(
@@ -552,6 +623,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             if fan is not None:
                 p, r = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs)
             elif needs_grad:
+                self._differentiable(dw)
                 p, r = _FkPositions.apply(q, ops_f, dw, len(non_root), self._n_dofs, self._kinematic_param_mask(dw))
             else:
                 p, r = backend.fk(dw.program, ops_f, dw.ops_i, q, len(non_root), self._n_dofs)
@@ -614,6 +686,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
         ops_f = self._ops_f(dw)
         if idx != 0 and torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
+            self._differentiable(dw)
             return _FkJacobian.apply(q, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
         return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
@@ -653,9 +726,9 @@ class DifferentiableRobotModel(torch.nn.Module):
             raise ValueError("the root link has the identity pose; use plan_inverse_dynamics")
         tree = self._get_walk(("tree",), whole_tree=True)
         chain = self._get_walk(("chain", idx), targets=[idx])
-        ops = [int(k) for k, link in enumerate(tree.program.links) if int(link) == idx]
         return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
-                                             (chain.program, self._ops_f(chain), chain.ops_i), ops[0] if ops else -1,
+                                             (chain.program, self._ops_f(chain), chain.ops_i),
+                                             int(tree.program.op_of_link.get(idx, -1)),
                                              q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs)
 
     @tensor_check
@@ -717,6 +790,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         needs_grad = torch.is_grad_enabled() and (ops_f.requires_grad or any(
             t is not None and t.requires_grad for t in (q, qd, qdd)))
         if needs_grad:
+            self._differentiable(dw)
             return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs,
                                           self._learnable_op_mask(dw))
         return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
@@ -738,6 +812,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
         if torch.is_grad_enabled() and (ops_f.requires_grad or q.requires_grad):
+            self._differentiable(dw)
             return _MassMatrix.apply(q, ops_f, dw, self._n_dofs, self._learnable_op_mask(dw))
         return backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
@@ -761,6 +836,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         dw = self._get_walk(("tree",), whole_tree=True)
         ops_f = self._ops_f(dw)
         if torch.is_grad_enabled() and (ops_f.requires_grad or any(t.requires_grad for t in (q, qd, f))):
+            self._differentiable(dw)
             return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
                                           self._learnable_op_mask(dw))
         return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),

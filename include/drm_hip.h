@@ -237,12 +237,15 @@ int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, 
                          int32_t flags, float *qdd, float *scratch, void *stream);
 
 /*
- * Reverse-mode derivative of drm_fk's POSITIONS: what torch autograd computes in the reference when a loss on
- * compute_forward_kinematics' position is back-propagated to q and to learnable `trans` / `rot_angles`
- * (robot_model.py:139-195, 223-248, 669-713; examples/learn_kinematics_of_iiwa.py:25-61).  The quaternion has
- * no gradient in the reference (spatial_vector_algebra.py:108-136) and none here.
+ * Reverse-mode derivative of drm_fk: what torch autograd computes in the reference when a loss on
+ * compute_forward_kinematics' outputs is back-propagated to q and to learnable `trans` / `rot_angles`
+ * (robot_model.py:139-195, 223-248, 669-713; examples/learn_kinematics_of_iiwa.py:25-61).
  *   q          [B, n]        joint angles of the forward call
  *   grad_pos   [B, T, 3]     dL/dpos of every target
+ *   grad_rot   [B, T, 3, 3]  dL/dR of every target's rotation matrix, or NULL.  The reference's quaternion is made of
+ *                            entries of R copied inside autograd (spatial_vector_algebra.py:108-136; only its
+ *                            normalisation is detached), so a loss on the quaternion is a loss on R: the host layer turns
+ *                            dL/dquat into dL/dR (robot_model._quat_grad_to_rot), the kernel carries it through the chain
  *   param_mask               bit k set: produce the constant gradient of op k (its link is learnable)
  *   grad_q     [B, n]        dL/dq, or NULL
  *   grad_ops_f [capacity, DRM_OPF_STRIDE]  dL/dF at DRM_OPF_FIJ(i, j), dL/dt at DRM_OPF_TI(i), summed over the
@@ -252,18 +255,18 @@ int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, 
  */
 int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity);
 int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                    uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
+                    const float *grad_rot, uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
 
 /*
  * Reverse-mode derivative of drm_fk_jacobian: what torch autograd computes in the reference when a loss on
  * compute_endeffector_jacobian's outputs (and, optionally, on the target's position) is back-propagated to q and to
  * learnable `trans` / `rot_angles` (robot_model.py:626-667 on top of 139-195).  The walk is the root->link chain
  * drm_fk_jacobian takes (no branch points).
- *   grad_pos      [B, 3]      dL/dpos of the target, or NULL
+ *   grad_pos      [B, 3]      dL/dpos of the target, or NULL        grad_rot  [B, 3, 3]  dL/dR of the target, or NULL
  *   grad_lin_jac  [B, 3, n]   dL/dlin_jac      grad_ang_jac  [B, 3, n]   dL/dang_jac
  *   param_mask, grad_q, grad_ops_f, scratch (drm_fk_backward_scratch_floats)   as for drm_fk_backward
  */
-int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, const float *grad_pos,
+int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, const float *grad_pos, const float *grad_rot,
                              const float *grad_lin_jac, const float *grad_ang_jac, uint32_t param_mask, float *grad_q,
                              float *grad_ops_f, float *scratch, void *stream);
 

@@ -145,7 +145,7 @@ void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *
 
 // reverse-mode FK: per-sample adjoint sweep, constant gradients summed over the batch in double
 void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, const float *glin, const float *gang,
-           uint32_t mask, float *gq, float *gops) {
+           uint32_t mask, float *gq, float *gops, const float *grot = nullptr) {
     const int n = w->n_dofs, CAP = w->capacity;
     std::vector<double> sum((size_t)CAP * 12, 0.0);
     std::vector<Pose> parked(CAP);
@@ -175,12 +175,17 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
             for (int j = 0; j < 3; ++j) sum[k * 12 + 9 + j] += dt[j];
         };
         const int32_t *ctl = w->ops_i + DRM_OPI_CTRL * CAP;
+        auto rot = [&](int t, float *Rb) {
+            if (!grot) return false;
+            for (int i = 0; i < 9; ++i) Rb[i] = grot[(b * T + t) * 9 + i];
+            return true;
+        };
         if (glin)
             fk_backward_walk<true>(w->ops_f, ctl, w->n_ops, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout,
-                                   park, unpark, jl, ja);
+                                   park, unpark, jl, ja, rot);
         else
             fk_backward_walk<false>(w->ops_f, ctl, w->n_ops, mask, gq != nullptr, qf, gin, psave, pload, aadd, atake, gqo, pout,
-                                    park, unpark);
+                                    park, unpark, NoJacobianGrad(), NoJacobianGrad(), rot);
     }
     if (gops)
         for (int k = 0; k < CAP; ++k) {
@@ -360,6 +365,11 @@ int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
 int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,
                     float *gops) {
     fkb_t(w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops);
+    return 0;
+}
+int emu_fk_backward_rot(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, const float *grot,
+                        uint32_t mask, float *gq, float *gops) {
+    fkb_t(w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops, grot);
     return 0;
 }
 int emu_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *gpos, const float *glin,
