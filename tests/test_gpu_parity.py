@@ -407,3 +407,20 @@ def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     assert max_err(host(lin), rl) <= TOL_JAC["atol"] and max_err(host(ang), ra) <= TOL_JAC["atol"]
     ok, flips = quat_close(host(quat), rq, TOL_QUAT["atol"])
     assert ok and flips <= 2, flips       # the sign may only differ on a branch boundary of sva.py:117-128
+
+
+def test_quaternion_on_branch_boundaries_gpu():
+    """The kernels' quaternion on the case boundaries of the reference's get_quaternion (sva.py:117-128): the reference's
+    value and SIGN wherever the rotation is more than 1e-5 from a boundary (tests/golden/golden_quat_branches.npz); the
+    batch is padded to full tiles so that the arm kernel takes it, and run once more ragged through the loop-structured one."""
+    from test_oracle_golden import check_quaternion_branches
+
+    def fk(robot, q, link):
+        m = load_model(robot, "cuda")
+        reps = -(-64 // q.shape[0])
+        full = np.tile(q, (reps, 1))[:64 * (reps * q.shape[0] // 64) or 64]
+        pos, quat = m.compute_forward_kinematics(dev(np.ascontiguousarray(full)), link)
+        p_r, q_r = m.compute_forward_kinematics(dev(np.ascontiguousarray(q[:33])), link)     # ragged: tree kernel
+        assert max_err(host(p_r), host(pos)[:33]) <= 1e-6
+        return host(pos)[:q.shape[0]], host(quat)[:q.shape[0]]
+    check_quaternion_branches(fk)

@@ -210,3 +210,24 @@ def test_link_rows_and_their_derivative_vs_torch(emu):
     gp = np.zeros_like(p_np)
     assert emu.emu_link_rows_backward(_ptr(p_np), _ptr(g_np), len(links), _ptr(gp)) == 0
     assert np.abs(gp - pt.grad.numpy()).max() < 2e-6 * max(1.0, np.abs(pt.grad.numpy()).max())
+
+
+def test_quaternion_on_branch_boundaries(emu):
+    """The select-based quaternion of the kernels on the case boundaries of the reference's algorithm
+    (tests/golden/golden_quat_branches.npz): the reference's sign wherever the margin exceeds 1e-5."""
+    from test_oracle_golden import check_quaternion_branches
+
+    def fk(robot, q, link):
+        m = load_model(robot)
+        prog = build_walk(m._spec, targets=[m._name_to_idx_map[link]])
+        walk, _keep = host_walk(m, prog)
+        B = q.shape[0]
+        pos = np.zeros((B, 3), np.float32); quat = np.zeros((B, 4), np.float32)
+        lin = np.zeros((B, 3, 7), np.float32); ang = np.zeros((B, 3, 7), np.float32)
+        qc = np.ascontiguousarray(q, np.float32)
+        assert emu.emu_fk_jacobian_arm(ctypes.byref(walk), _ptr(qc), ctypes.c_int64(B), _ptr(pos), _ptr(quat), _ptr(lin), _ptr(ang)) == 0
+        p2 = np.zeros((B, 1, 3), np.float32); q2 = np.zeros((B, 1, 4), np.float32)
+        assert emu.emu_fk(ctypes.byref(walk), _ptr(qc), ctypes.c_int64(B), 1, _ptr(p2), _ptr(q2)) == 0
+        assert np.abs(p2[:, 0] - pos).max() < 1e-6          # the loop-structured walk agrees with the arm chain
+        return pos, quat
+    check_quaternion_branches(fk)
