@@ -13,39 +13,48 @@
 namespace drm {
 
 // Loop-structured composite-rigid-body algorithm of any robot (drm_tree.hpp crba_tree_walk): one tile of 64 samples per
-// block, one wavefront per segment — the sub-trees off the fixed root give the diagonal blocks of H, everything between
-// two of them is a structural zero (the block zero-fills the tile once, the wavefronts write their blocks).
-// LDS: [ table ][ q : 64 (n|1) ][ H : 64 (n^2|1), unless DIRECT ] shared, then per wavefront
-//      [ cos / sin / value per op : max_seg_ops * 3 * 64 ][ inertia slots : n_slots * 10 * 64 ]
-// DIRECT: the H tile does not fit (n > ~23): lanes store their entries straight to HBM over a zeroed H.
+// block, one wavefront per segment.  The sub-trees off the fixed root give the diagonal blocks of H and everything between
+// two of them is a structural zero (an Allegro hand: four 4 x 4 blocks in a 16 x 16 matrix), so a wavefront keeps only ITS
+// block (cnt x cnt floats per sample) in LDS; once all are done the whole block of threads assembles the [64, n, n] rows —
+// block entries where a row and a column belong to the same segment, zeros elsewhere — and writes them with coalesced
+// 16-byte stores.  (Staging the full 256 n^2-byte tile instead allowed one block per CU for n = 16: 1 330 -> 697 us at
+// 2^20 samples; this form: see profiles/.)
+// LDS: [ table ][ q : 64 (n|1) ][ segment map : dof -> (segment's first dof, its dof count, its block's LDS offset) ]
+//      shared, then per wavefront [ cos / sin / value per op : ops * 3 * 64 ][ inertia slots : n_slots * 10 * 64 ]
+//      [ block : 64 (cnt^2|1), unless DIRECT ]
+// DIRECT: a block does not fit (a single segment with more than ~23 DoFs): lanes store their entries straight to HBM over
+// a zeroed H.
 template <bool DIRECT>
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
-    crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t magic_h,
-                     uint32_t align) {
+    crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileCtx tc = tile_begin(B);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, nn = n * n;
-    const int Sq = pad_odd(n), Sh = DIRECT ? 0 : pad_odd(nn);
+    const int Sq = pad_odd(n);
     float *lq = smem + table_lds_floats(a.n_ops);
-    float *lh = lq + round4(WAVE * Sq);
+    int *lmap = reinterpret_cast<int *>(lq + round4(WAVE * Sq)); // [3][n]: segment lo, cnt, block offset (floats) per DoF
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], Sb = pad_odd(cnt * cnt);
     float *ltr = smem + a.wave_off[wave];                          // [op - first][3][64]
     float *lis = ltr + (last - first) * (CRBA_PARK_FLOATS * WAVE); // inertia slots [slot][10][64]
+    float *lb = lis + a.n_slots * (10 * WAVE);                     // this segment's block of H: [64][cnt^2 | 1]
 
     const TableLds tab = stage_tree_table(a, smem);
     if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
     for (int s = 0; s < a.n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
-    if (!DIRECT) { // pairs of joints on different branches / in different segments
-        const unsigned total = (unsigned)round4(WAVE * Sh);
-        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) lh[i] = 0.0f;
+    if (!DIRECT) {
+        for (int i = (int)lane; i < WAVE * Sb; i += WAVE) lb[i] = 0.0f; // pairs of joints on different branches of the segment
+        for (int d = (int)lane; d < cnt; d += WAVE) {
+            lmap[lo + d] = lo; lmap[n + lo + d] = cnt; lmap[2 * n + lo + d] = (int)(lb - smem);
+        }
     }
     __syncthreads();
 
     const bool live = (int)lane < tc.rows;
     const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row read zero angles, their H is never stored
-    float *hrow = lh + lane * Sh;
+    float *brow = lb + lane * Sb;
     float *hdst = H + (tc.b0 + lane) * nn;
     auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
     crba_prepare(first, last, ctl, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
@@ -64,12 +73,32 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
             if (DIRECT) {
                 if (live) hdst[di * n + dj] = v;
             } else {
-                hrow[di * n + dj] = v;
+                brow[(di - lo) * cnt + (dj - lo)] = v;
             }
         });
     if (!DIRECT) {
         __syncthreads();
-        block_tile_store(H + tc.b0 * nn, tc.rows, nn, magic_h, lh, tc.full && (align & AL_TAU)); // 256 n^2 bytes: every wavefront helps
+        // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
+        auto entry = [&](unsigned b, unsigned r, unsigned c) -> float {
+            const int slo = lmap[r], scnt = lmap[n + r];
+            const unsigned cc = c - (unsigned)slo;
+            if (cc >= (unsigned)scnt) return 0.0f;
+            return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + (r - (unsigned)slo) * (unsigned)scnt + cc];
+        };
+        float *g = H + tc.b0 * nn;
+        if (tc.full && !(n & 3) && (align & AL_TAU)) {
+            const unsigned per_row = (unsigned)n >> 2, per_sample = (unsigned)nn >> 2, total = WAVE * per_sample;
+            for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+                const unsigned b = i / per_sample, j = i - b * per_sample, r = j / per_row, c = (j - r * per_row) * 4u;
+                store16_wt(g + 4u * i, make_float4(entry(b, r, c), entry(b, r, c + 1u), entry(b, r, c + 2u), entry(b, r, c + 3u)));
+            }
+        } else {
+            const unsigned total = (unsigned)tc.rows * (unsigned)nn;
+            for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+                const unsigned b = i / (unsigned)nn, j = i - b * (unsigned)nn, r = j / (unsigned)n;
+                g[i] = entry(b, r, j - r * (unsigned)n);
+            }
+        }
     }
 }
 
@@ -141,20 +170,21 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     TreeArgs a = tree_args(w);
-    const size_t tile = (size_t)round4(WAVE * pad_odd(nn));
-    auto plan = [&](TreeArgs &t, bool with_tile) {
-        const size_t shared = (size_t)table_lds_floats(t.n_ops) + round4(WAVE * pad_odd(n)) + (with_tile ? tile : 0);
-        return sizeof(float) * layout_waves(t, shared, CRBA_PARK_FLOATS * WAVE, t.n_slots * 10 * WAVE, [](int) { return 0; });
+    auto plan = [&](TreeArgs &t, bool with_blocks) {
+        const size_t shared = (size_t)table_lds_floats(t.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n);
+        return sizeof(float) * layout_waves(t, shared, CRBA_PARK_FLOATS * WAVE, t.n_slots * 10 * WAVE, [&](int sg) {
+            const int c = t.seg_dof_cnt[sg];
+            return with_blocks ? round4(WAVE * pad_odd(c * c)) : 0;
+        });
     };
-    // the H tile of a block is 256 n^2 bytes; when it does not fit a CU's LDS next to the rest the entries go straight to HBM
-    // over a memset instead (n > ~23)
+    // every segment keeps its cnt x cnt block of 64 samples in LDS; when that does not fit a CU the entries go straight to
+    // HBM over a memset instead (one segment with more than ~23 DoFs)
     bool direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
-    size_t lds = plan(a, !direct);
-    if (lds > (size_t)MAX_LDS_BYTES && a.n_segments > 1) {
+    if (direct && a.n_segments > 1) {
         a = tree_args(w, true);
         direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
-        lds = plan(a, !direct);
     }
+    const size_t lds = plan(a, !direct);
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
@@ -163,13 +193,11 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
         rc = ensure_lds_tree(crba_tree_kernel<true>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n),
-                           div_magic(nn), align);
+        hipLaunchKernelGGL(crba_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
     } else {
         rc = ensure_lds_tree(crba_tree_kernel<false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n),
-                           div_magic(nn), align);
+        hipLaunchKernelGGL(crba_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
     }
     return launched();
 }

@@ -16,6 +16,10 @@ namespace drm {
 // samples per block, one wavefront per segment of the walk.
 // LDS: [ table ][ q ][ qd ][ qdd ][ tau ] shared, then per wavefront [ records : max_seg_ops * 9 * 64 ]
 //      [ motion slots : n_slots * 12 * 64 ][ force slots : n_slots * 6 * 64 ]   (per-wavefront areas: TreeArgs.wave_off)
+// SHORT > 0: no segment has more than SHORT ops (the fingers of a hand): drm_tree.hpp rnea_tree_walk_short keeps the per-op
+// records in registers, the per-wavefront LDS area holds the save slots only.
+constexpr int RNEA_SHORT_OPS = 6;
+template <int SHORT>
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     rnea_tree_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
                      const float *__restrict__ qdd, int64_t B, float *__restrict__ tau, uint32_t magic_q, uint32_t align) {
@@ -27,7 +31,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lqdd = lqd + region, *ltau = lqdd + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     float *park = smem + a.wave_off[wave];
-    float *lms = park + (last - first) * (RNEA_PARK_FLOATS * WAVE); // motion slots [slot][12][64]
+    float *lms = park + (SHORT ? 0 : (last - first) * (RNEA_PARK_FLOATS * WAVE)); // motion slots [slot][12][64]
     float *lfs = lms + a.n_slots * (12 * WAVE);                     // force slots  [slot][6][64]
 
     const TableLds tab = stage_tree_table(a, smem);
@@ -46,28 +50,37 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const unsigned row = lane * Sq;
     const bool live = (int)lane < tc.rows;
     const bool has_qdd = qdd != nullptr;
-    rnea_tree_walk(
-        a.prefix_end, first, last, [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); },
-        [&](int k) { return tab.row(k); }, flags,
-        [&](int d, float &x, float &v, float &acc) {
-            x = live ? lq[row + d] : 0.0f;
-            v = lqd[row + d];
-            acc = has_qdd ? lqdd[row + d] : 0.0f;
-        },
-        [&](int d, float v) { ltau[row + d] = v; },
-        [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
-        [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
-        [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
-        [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    auto rowf = [&](int k) { return tab.row(k); };
+    auto qf = [&](int d, float &x, float &v, float &acc) {
+        x = live ? lq[row + d] : 0.0f;
+        v = lqd[row + d];
+        acc = has_qdd ? lqdd[row + d] : 0.0f;
+    };
+    auto tau_out = [&](int d, float v) { ltau[row + d] = v; };
+    auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
+    auto mload = [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); };
+    auto fadd = [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); };
+    auto ftake = [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); };
+    if constexpr (SHORT > 0) {
+        rnea_tree_walk_short<SHORT>(a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out, msave, mload, fadd, ftake);
+    } else {
+        rnea_tree_walk(
+            a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out,
+            [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
+            [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); }, msave, mload,
+            fadd, ftake);
+    }
     __syncthreads();
     if (wave == 0)
         tile_store<0>(tau + tc.b0 * n, tc.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
 }
 
 // LDS bytes of a launch (fills a.wave_off)
-static size_t rnea_tree_lds(TreeArgs &a) {
+static size_t rnea_tree_lds(TreeArgs &a, bool records_in_registers) {
     const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n));
-    return sizeof(float) * layout_waves(a, shared, RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE, [](int) { return 0; });
+    return sizeof(float) * layout_waves(a, shared, records_in_registers ? 0 : RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE,
+                                        [](int) { return 0; });
 }
 
 } // namespace drm
@@ -103,17 +116,25 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     TreeArgs a = tree_args(w);
-    size_t lds = rnea_tree_lds(a);
+    const bool shorts = a.max_seg_ops <= RNEA_SHORT_OPS;
+    size_t lds = rnea_tree_lds(a, shorts);
     if (lds > (size_t)MAX_LDS_BYTES && a.n_segments > 1) { // the segments do not fit side by side: one wavefront walks them all
         a = tree_args(w, true);
-        lds = rnea_tree_lds(a);
+        lds = rnea_tree_lds(a, false);
     }
-    rc = ensure_lds_tree(rnea_tree_kernel, lds);
-    if (rc) return rc;
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
-    hipLaunchKernelGGL(rnea_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd, qdd, B,
-                       tau, div_magic(n), align);
+    if (a.max_seg_ops <= RNEA_SHORT_OPS) {
+        rc = ensure_lds_tree(rnea_tree_kernel<RNEA_SHORT_OPS>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rnea_tree_kernel<RNEA_SHORT_OPS>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd,
+                           qdd, B, tau, div_magic(n), align);
+    } else {
+        rc = ensure_lds_tree(rnea_tree_kernel<0>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rnea_tree_kernel<0>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd, qdd, B,
+                           tau, div_magic(n), align);
+    }
     return launched();
 }
 

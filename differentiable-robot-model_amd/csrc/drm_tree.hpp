@@ -115,7 +115,6 @@ DRM_HD void fk_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, SAVE slot_save, LOA
         int w0, w1;
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        if (ct.padding) continue;
         const OpPairs o = load_pairs(row(k));
         const float q = ct.dof >= 0 ? qf(ct.dof) : 0.0f;
         if (ct.src >= 0) slot_load(ct.src, cur);
@@ -148,7 +147,6 @@ DRM_HD void fk_jacobian_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, PoseP &ee,
         int w0, w1;
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        if (ct.padding) continue;
         const OpPairs o = load_pairs(row(k));
         const float q = ct.dof >= 0 ? qf(ct.dof) : 0.0f;
         pose_step(o, ct, q, k == 0, ee);
@@ -189,6 +187,60 @@ DRM_HD void motion_step(const float *J, const float *t, float wj, float aj, bool
     out = N;
 }
 
+// one op of the forward sweep: its motion from the parent's (cur is updated), its body force and what the backward sweep
+// needs again (cos / sin / value of the joint)
+template <class ROW, class QF, class MSAVE, class MLOAD>
+DRM_HD void rnea_forward_step(int k, const OpCtl &ct, ROW row, float g, QF qf, MSAVE motion_save, MLOAD motion_load, Motion &cur,
+                              bool want_force, Force &f, float &c, float &s, float &q) {
+    const float *of = row(k);
+    float wj = 0.0f, aj = 0.0f;
+    q = 0.0f; c = 1.0f; s = 0.0f;
+    if (ct.dof >= 0) {
+        qf(ct.dof, q, wj, aj);
+        if (!ct.prismatic) sincos_one(q, s, c);
+    }
+    const OpFT o = load_ft(of);
+    float J[9], t[3];
+    joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+    if (ct.src == DRM_SRC_ROOT) motion_root(cur, g);
+    if (ct.src >= 0) motion_load(ct.src, cur);
+    motion_step(J, t, wj, aj, ct.prismatic, cur, cur);
+    if (ct.save >= 0) motion_save(ct.save, cur);
+    if (want_force) rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
+}
+// one op of the backward sweep: tot = this op's body force on entry, the total force of its sub-tree when the torque is
+// taken; then moved into the parent's frame (carry / slot)
+template <class ROW, class QF, class TAU, class FADD, class FTAKE>
+DRM_HD void rnea_backward_step(int k, int a, const OpCtl &ct, ROW row, int flags, QF qf, TAU tau_out, FADD force_add,
+                               FTAKE force_take, Force &tot, float c, float s, float q, Force &carry) {
+    const float *of = row(k);
+    if (ct.child_next) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+    }
+    if (ct.save >= 0) force_take(ct.save, tot);
+    if (ct.dof >= 0) {
+        // tau = S^T f: the angular z component for a revolute joint (robot_model.py:353-373), the linear one for a
+        // prismatic joint; + damping * qd
+        float tau = ct.prismatic ? tot.la[2][0] : tot.la[2][1];
+        if (flags & DRM_RNEA_DAMPING) {
+            float qq, qd, qdd;
+            qf(ct.dof, qq, qd, qdd);
+            tau += of[DRM_OPF_DAMP] * qd;
+        }
+        tau_out(ct.dof, tau);
+    }
+    if (ct.src != DRM_SRC_ROOT && ct.parent >= a) { // (a parent in the static prefix takes no force)
+        const OpFT o = load_ft(of);
+        float J[9], t[3];
+        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+        Force up;
+        rnea_link_force_up(J, t, tot, up);
+        if (ct.src >= 0) force_add(ct.src, up);
+        else carry = up;
+    }
+}
+
 template <class CTL, class ROW, class QF, class TAU, class PARK, class UNPARK, class MSAVE, class MLOAD, class FADD, class FTAKE>
 DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags, QF qf, TAU tau_out, PARK park,
                            UNPARK unpark, MSAVE motion_save, MLOAD motion_load, FADD force_add, FTAKE force_take) {
@@ -201,25 +253,10 @@ DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags,
         int w0, w1;
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        if (ct.padding) continue;
-        const float *of = row(k);
-        float q = 0.0f, wj = 0.0f, aj = 0.0f, c = 1.0f, s = 0.0f;
-        if (ct.dof >= 0) {
-            qf(ct.dof, q, wj, aj);
-            if (!ct.prismatic) sincos_one(q, s, c);
-        }
-        const OpFT o = load_ft(of);
-        float J[9], t[3];
-        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
-        if (ct.src == DRM_SRC_ROOT) motion_root(cur, g);
-        if (ct.src >= 0) motion_load(ct.src, cur);
-        motion_step(J, t, wj, aj, ct.prismatic, cur, cur);
-        if (ct.save >= 0) motion_save(ct.save, cur);
-        if (k >= a) {
-            Force f;
-            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
-            park(k, f, c, s, q);
-        }
+        Force f;
+        float c, s, q;
+        rnea_forward_step(k, ct, row, g, qf, motion_save, motion_load, cur, k >= a, f, c, s, q);
+        if (k >= a) park(k, f, c, s, q);
     }
     // ---- backward sweep -------------------------------------------------------------------------------------
     Force carry;
@@ -230,36 +267,50 @@ DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags,
         int w0, w1;
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        if (ct.padding) continue;
-        const float *of = row(k);
         Force tot;
         float c, s, q;
         unpark(k, tot, c, s, q);
-        if (ct.child_next) {
+        rnea_backward_step(k, a, ct, row, flags, qf, tau_out, force_add, force_take, tot, c, s, q, carry);
+    }
+}
+
+// The same walk for a SHORT segment (at most MAXOPS ops after the static prefix — a finger of a hand): both sweeps are
+// unrolled, so the per-op records (body force, cos / sin / value) stay in REGISTERS instead of being parked in LDS.  With
+// the records gone a 64-sample tile of a hand needs 16 KB of LDS instead of 66 KB and the launch is bounded by registers
+// (four wavefronts per SIMD), not by LDS (two).
+template <int MAXOPS, class CTL, class ROW, class QF, class TAU, class MSAVE, class MLOAD, class FADD, class FTAKE>
+DRM_HD void rnea_tree_walk_short(int p_end, int a, int b, CTL ctl, ROW row, int flags, QF qf, TAU tau_out, MSAVE motion_save,
+                                 MLOAD motion_load, FADD force_add, FTAKE force_take) {
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    Motion cur;
+    motion_root(cur, g);
+#pragma unroll 1
+    for (int k = 0; k < p_end; ++k) { // the static prefix: motions only
+        int w0, w1;
+        ctl(k, w0, w1);
+        Force f;
+        float c, s, q;
+        rnea_forward_step(k, decode_ctl(w0, w1), row, g, qf, motion_save, motion_load, cur, false, f, c, s, q);
+    }
+    Force f[MAXOPS];
+    float cc[MAXOPS], ss[MAXOPS], qq[MAXOPS];
+    int w0s[MAXOPS], w1s[MAXOPS];
+    const int len = b - a;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+    for (int i = 0; i < MAXOPS; ++i) {
+        if (i < len) {
+            ctl(a + i, w0s[i], w1s[i]);
+            rnea_forward_step(a + i, decode_ctl(w0s[i], w1s[i]), row, g, qf, motion_save, motion_load, cur, true, f[i], cc[i], ss[i], qq[i]);
         }
-        if (ct.save >= 0) force_take(ct.save, tot);
-        if (ct.dof >= 0) {
-            // tau = S^T f: the angular z component for a revolute joint (robot_model.py:353-373), the linear one for a
-            // prismatic joint; + damping * qd
-            float tau = ct.prismatic ? tot.la[2][0] : tot.la[2][1];
-            if (flags & DRM_RNEA_DAMPING) {
-                float qq, qd, qdd;
-                qf(ct.dof, qq, qd, qdd);
-                tau += of[DRM_OPF_DAMP] * qd;
-            }
-            tau_out(ct.dof, tau);
-        }
-        if (ct.src != DRM_SRC_ROOT && ct.parent >= a) { // (a parent in the static prefix takes no force)
-            const OpFT o = load_ft(of);
-            float J[9], t[3];
-            joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
-            Force up;
-            rnea_link_force_up(J, t, tot, up);
-            if (ct.src >= 0) force_add(ct.src, up);
-            else carry = up;
-        }
+    }
+    Force carry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) carry.la[i] = f2_bcast(0.0f);
+#pragma unroll
+    for (int i = MAXOPS - 1; i >= 0; --i) {
+        if (i < len)
+            rnea_backward_step(a + i, a, decode_ctl(w0s[i], w1s[i]), row, flags, qf, tau_out, force_add, force_take, f[i], cc[i], ss[i],
+                               qq[i], carry);
     }
 }
 
@@ -282,7 +333,6 @@ DRM_HD void crba_tree_walk(int a, int b, CTL ctl, ROW row, TRIG trig, IADD islot
         int w0, w1;
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        if (ct.padding) continue;
         const float *of = row(k);
         Inertia tot;
         tot.m = of[DRM_OPF_MASS];
@@ -353,7 +403,7 @@ DRM_HD void crba_prepare(int a, int b, CTL ctl, QF qf, PUT put) {
         ctl(k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
         float q = 0.0f, c = 1.0f, s = 0.0f;
-        if (!ct.padding && ct.dof >= 0) {
+        if (ct.dof >= 0) {
             q = qf(ct.dof);
             if (!ct.prismatic) sincos_one(q, s, c);
         }

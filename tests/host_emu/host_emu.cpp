@@ -377,6 +377,27 @@ int emu_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const
     fkb_t(w, q, B, 1, gpos, glin, gang, mask, gq, gops);
     return 0;
 }
+int emu_rnea_short(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
+    // the register-parked form of short segments (drm_tree.hpp rnea_tree_walk_short<6>)
+    const int n = w->n_dofs;
+    const Ctl ctl(w);
+    for (int s = 0; s < w->n_segments; ++s)
+        if (w->seg_begin[s + 1] - w->seg_begin[s] > 6) return -2;
+    for (int64_t b = 0; b < B; ++b)
+        for (int seg = 0; seg < w->n_segments; ++seg) {
+            Motion ms[DRM_MAX_SLOTS];
+            Force fs[DRM_MAX_SLOTS];
+            for (auto &F : fs) for (int i = 0; i < 3; ++i) F.la[i] = f2_bcast(0.f);
+            rnea_tree_walk_short<6>(
+                w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1], ctl, [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, flags,
+                [&](int d, float &a, float &v, float &acc) { a = q[b * n + d]; v = qd[b * n + d]; acc = qdd ? qdd[b * n + d] : 0.f; },
+                [&](int d, float v) { tau[b * n + d] = v; }, [&](int sl, const Motion &M) { ms[sl] = M; },
+                [&](int sl, Motion &M) { M = ms[sl]; },
+                [&](int sl, const Force &F) { for (int i = 0; i < 3; ++i) fs[sl].la[i] += F.la[i]; },
+                [&](int sl, Force &F) { for (int i = 0; i < 3; ++i) { F.la[i] += fs[sl].la[i]; fs[sl].la[i] = f2_bcast(0.f); } });
+        }
+    return 0;
+}
 int emu_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
     rnea_loop(w, q, qd, qdd, B, flags, tau);
     return 0;

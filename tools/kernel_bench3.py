@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Launch the loop-structured (tree) kernels on the Allegro hand a few times — for rocprofv3 counter runs."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gpu_probe import load, sample
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ma = load("allegro_left")
+qa, qda, qdda = (t.cuda() for t in sample(ma, B))
+tips = [ma._name_to_idx_map[t] for t in ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]]
+for _ in range(5):
+    ma._fk_targets(qa, tips)
+    tau = ma.compute_inverse_dynamics(qa, qda, qdda)
+    H = ma.compute_lagrangian_inertia_matrix(qa)
+    a = ma.compute_forward_dynamics(qa, qda, qdda)
+torch.cuda.synchronize()
+print("done")
