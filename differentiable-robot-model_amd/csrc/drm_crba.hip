@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row read zero angles, their H is never stored
     float *brow = lb + lane * Sb;
     float *hdst = H + (tc.b0 + lane) * nn;
-    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    const TableLds &ctl = tab;
     crba_prepare(first, last, ctl, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
                  [&](int k, float c, float s, float x) {
                      float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;

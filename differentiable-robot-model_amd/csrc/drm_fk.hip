@@ -34,14 +34,14 @@ __global__ void __launch_bounds__(WAVE)
     const float *qrow = lq + lane * Sq;
     float *prow = lp + lane * Sp;
     float *rrow = lr + lane * Sr;
-    fk_tree_walk(
-        a.n_ops, [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); }, [&](int k) { return tab.row(k); },
-        [&](int d) -> float { return live ? qrow[d] : 0.0f; }, [&](int s, const PoseP &P) { lds_put_pose(ls, s, lane, P); },
-        [&](int s, PoseP &P) { lds_get_pose(ls, s, lane, P); },
-        [&](int t, const float *p, const float *qt) {
-            prow[t * 3 + 0] = p[0]; prow[t * 3 + 1] = p[1]; prow[t * 3 + 2] = p[2];
-            rrow[t * 4 + 0] = qt[0]; rrow[t * 4 + 1] = qt[1]; rrow[t * 4 + 2] = qt[2]; rrow[t * 4 + 3] = qt[3];
-        });
+    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
+    auto ssave = [&](int s, const PoseP &P) { lds_put_pose(ls, s, lane, P); };
+    auto sload = [&](int s, PoseP &P) { lds_get_pose(ls, s, lane, P); };
+    auto emit = [&](int t, const float *p, const float *qt) {
+        prow[t * 3 + 0] = p[0]; prow[t * 3 + 1] = p[1]; prow[t * 3 + 2] = p[2];
+        rrow[t * 4 + 0] = qt[0]; rrow[t * 4 + 1] = qt[1]; rrow[t * 4 + 2] = qt[2]; rrow[t * 4 + 3] = qt[3];
+    };
+    fk_tree_walk(a.n_ops, tab, [&](int k) { return tab.row(k); }, qf, ssave, sload, emit);
     wave_lds_sync();
     tile_store<0>(pos + tc.b0 * 3 * T, tc.rows, 3 * T, magic_p, lp, lane, tc.full && ((3 * T) & 1) && (align & AL_POS),
                   tc.full && (align & AL_POS));
@@ -95,18 +95,15 @@ __global__ void __launch_bounds__(WAVE * 4)
     const float *qrow = lq + lane * Sq;
     float *prow = lp + lane * Sp + wave * 3;
     float *rrow = lr + lane * Sr + wave * 4;
+    TableLds chain;
+    chain.f = lt; chain.w = lw; chain.n_ops = n_ops;
+    auto emit1 = [&](int, const float *p, const float *qt) { // the chain's single target = column `wave` of the row
+        prow[0] = p[0]; prow[1] = p[1]; prow[2] = p[2];
+        rrow[0] = qt[0]; rrow[1] = qt[1]; rrow[2] = qt[2]; rrow[3] = qt[3];
+    };
     fk_tree_walk(
-        n_ops,
-        [&](int k, int &w0, int &w1) {
-            w0 = __builtin_amdgcn_readfirstlane(lw[k]);
-            w1 = __builtin_amdgcn_readfirstlane(lw[n_ops + k]);
-        },
-        [&](int k) { return lt + k * DRM_OPF_STRIDE; }, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
-        [&](int, const PoseP &) {}, [&](int, PoseP &) {},
-        [&](int, const float *p, const float *qt) { // the chain's single target = column `wave` of the row
-            prow[0] = p[0]; prow[1] = p[1]; prow[2] = p[2];
-            rrow[0] = qt[0]; rrow[1] = qt[1]; rrow[2] = qt[2]; rrow[3] = qt[3];
-        });
+        n_ops, chain, [&](int k) { return lt + k * DRM_OPF_STRIDE; }, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
+        [&](int, const PoseP &) {}, [&](int, PoseP &) {}, emit1);
     __syncthreads();
     // the assembled [64, 3T] and [64, 4T] tiles leave with coalesced stores, one tensor per wave pair
     if (wave == 0)

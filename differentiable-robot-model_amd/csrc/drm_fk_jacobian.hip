@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(WAVE)
                 arow[d] = 0.0f; arow[n + d] = 0.0f; arow[2 * n + d] = 0.0f;
             }
     }
-    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    const TableLds &ctl = tab;
     PoseP ee;
     fk_jacobian_tree_walk(a.n_ops, ctl, [&](int k) { return tab.row(k); }, [&](int d) -> float { return live ? qrow[d] : 0.0f; }, ee,
                           [&](int d, const float *z, const float *p, bool) {
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(WAVE)
 #pragma unroll 1
     for (int k = 0; k < a.n_ops; ++k) {
         int w0, w1;
-        ctl(k, w0, w1);
+        ctl_words(ctl, k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
         if (ct.padding || ct.dof < 0) continue;
         const int d = ct.dof;

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     // lanes past a partial tile read zeros (see drm_fk.hip); their H is then a valid inertia matrix as well
     const bool live = (int)lane < tc.rows;
     const unsigned row = lane * Sq;
-    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
     crba_prepare(first, last, ctl, [&](int d) -> float { return live ? lq[row + d] : 0.0f; },
                  [&](int k, float c, float s, float x) {

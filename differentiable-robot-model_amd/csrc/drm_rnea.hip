@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const unsigned row = lane * Sq;
     const bool live = (int)lane < tc.rows;
     const bool has_qdd = qdd != nullptr;
-    auto ctl = [&](int k, int &w0, int &w1) { tab.ctl(k, w0, w1); };
+    const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
     auto qf = [&](int d, float &x, float &v, float &acc) {
         x = live ? lq[row + d] : 0.0f;

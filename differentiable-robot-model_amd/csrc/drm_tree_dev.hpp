@@ -88,10 +88,9 @@ struct TableLds {
     const int *w;     // [2][n_ops]
     int n_ops;
     __device__ __forceinline__ const float *row(int k) const { return f + k * DRM_OPF_STRIDE; }
-    __device__ __forceinline__ void ctl(int k, int &w0, int &w1) const {
-        w0 = __builtin_amdgcn_readfirstlane(w[k]);
-        w1 = __builtin_amdgcn_readfirstlane(w[n_ops + k]);
-    }
+    // the CTL interface of drm_tree.hpp: request the two control words of op k, then make a requested word wave-uniform
+    __device__ __forceinline__ void raw(int k, int &r0, int &r1) const { r0 = w[k]; r1 = w[n_ops + k]; }
+    __device__ __forceinline__ int uniform(int r) const { return __builtin_amdgcn_readfirstlane(r); }
 };
 
 // all threads of the block copy the table into LDS (16 bytes per thread and round); the caller synchronises

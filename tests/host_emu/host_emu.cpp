@@ -20,7 +20,8 @@ namespace {
 struct Ctl {
     const int32_t *w0, *w1;
     explicit Ctl(const drm_walk *w) : w0(w->ops_i + DRM_OPI_W0 * w->capacity), w1(w->ops_i + DRM_OPI_W1 * w->capacity) {}
-    void operator()(int k, int &a, int &b) const { a = w0[k]; b = w1[k]; }
+    void raw(int k, int &a, int &b) const { a = w0[k]; b = w1[k]; }
+    int uniform(int r) const { return r; }
 };
 
 void fk_loop(const drm_walk *w, const float *q, int64_t B, int T, float *pos, float *quat) {
