@@ -4,7 +4,8 @@
   rNN_bench_kernel_stats.csv   the --kernel-trace --stats table of the default bench run
   rNN_pmc_traffic.json         HBM bytes per launch of the metric kernel: FETCH_SIZE (x2: gfx950 tallies 128-B read
                                requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB
-  rNN_sq_counters.md           per-wave instruction counts / cycle split of the hot kernels
+  rNN_sq_counters.md           per-wave instruction counts / cycle split of the hot kernels (arm and loop-form)
+  rNN_all_kernels_rocprof_stats.csv, rNN_bench_{default,config3,under_rocprofv3}.json, rNN_kernel_times.txt, rNN_metric_lab.txt
 usage: python tools/pmc_summary.py r01
 """
 import csv
@@ -31,6 +32,30 @@ def rows(pattern):
 stats = glob.glob(os.path.join(OUT, "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(prof, tag + "_bench_kernel_stats.csv"))
+stats = glob.glob(os.path.join(OUT, "prof_all", "*", "*_kernel_stats.csv"))
+if stats:   # rows of our kernels only
+    with open(stats[0]) as f, open(os.path.join(prof, tag + "_all_kernels_rocprof_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or "drm::" in line:
+                g.write(line)
+
+
+def last_json_line(path):
+    if not os.path.exists(path):
+        return None
+    lines = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
+    return lines[-1] if lines else None
+
+
+for src, dst in (("prof_stats.log", "_bench_under_rocprofv3.json"), ("bench_default.json", "_bench_default.json"),
+                 ("bench_config3.json", "_bench_config3.json")):
+    line = last_json_line(os.path.join(OUT, src))
+    if line:
+        with open(os.path.join(prof, tag + dst), "w") as f:
+            f.write(line + "\n")
+for src, dst in (("kernel_times.txt", "_kernel_times.txt"), ("metric_lab.txt", "_metric_lab.txt")):
+    if os.path.exists(os.path.join(OUT, src)):
+        shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 
 traffic = {"kernel": None, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
                                       "python bench.py --no-cpu-baseline --steps 50 --warmup 5 [--batch B]",
@@ -57,7 +82,7 @@ with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 
 acc = defaultdict(lambda: defaultdict(list))
-for r in rows("prof_sq/*/*_counter_collection.csv"):
+for r in list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")):
     k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
     acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]

@@ -1,27 +1,36 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): rocprofv3 evidence for the bench command.  Raw outputs -> gpurun_out/prof_*/,
-# summarised afterwards by tools/pmc_summary.py into profiles/.
-#   pass 1: --kernel-trace --stats            (per-kernel durations of the default bench run)
+# summarised afterwards by tools/pmc_summary.py <tag> into profiles/.
+#   pass 1: --kernel-trace --stats            (per-kernel durations of the default bench run, JSON line kept)
 #   pass 2: --kernel-trace --pmc FETCH_SIZE    (separate passes: FETCH_SIZE and WRITE_SIZE do not fit together,
 #   pass 3: --kernel-trace --pmc WRITE_SIZE     and counter runs must not be combined with API tracing)
-#   pass 4: SQ counters for the instruction mix
+#   pass 4: SQ counters for the instruction mix (arm kernels: kernel_bench.py, loop-form kernels: kernel_bench3.py)
+#   pass 5: --kernel-trace --stats of tools/kernel_times.py (which kernel every entry point dispatches to)
+# plus the unprofiled lines: bench.py default, bench.py --config 3, tools/kernel_times.py, the metric lab's I/O floor.
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline"
+python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
 for batch in 65536 4194304; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $B --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
+PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
+python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
+[ -x $ROOT/tools/ubench/metric_lab ] && $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
 cd $ROOT
-find gpurun_out -name "*.csv" | head -40
 # keep what travels back small: per-dispatch counter rows of OUR kernels only
 for f in $(find gpurun_out -name "*counter_collection.csv"); do
   head -1 $f > $f.small; grep "drm::" $f >> $f.small; mv $f.small $f
 done
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 du -sh gpurun_out
+tail -3 $OUT/bench_default.json $OUT/bench_config3.json | cut -c1-1500
