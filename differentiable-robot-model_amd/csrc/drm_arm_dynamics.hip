@@ -1,0 +1,168 @@
+// drm_arm_dynamics.hip — the serial-chain ("arm") dynamics kernels: K3 RNEA and the fused FK + RNEA launch of BASELINE
+// configuration 3.  Same design and build flags as drm_arm_kernels.hip (kernel-argument preload) except that this unit,
+// like every dynamics unit, is compiled with -fno-slp-vectorize: the SLP vectoriser packs the scalar cross products of
+// the body force into v_pk_* ops whose operand pairs it then has to assemble with v_mov (4 moves per packed FMA) —
+// 1 608 -> 1 465 VALU per wave here, 50.5 -> 46.6 us at 2^20 (the FK + Jacobian kernel, whose pairs are laid out by hand,
+// is 6 % shorter WITH it and stays in drm_arm_kernels.hip).
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+// ---------------------------------------------------------------------------------------------------
+// Serial-chain ("arm") specialisation, full tiles only (DRM_WALK_ARM_CHAIN walks, 16-byte aligned pointers,
+// NJ odd): the same design as fk_jacobian_arm_kernel — constant rows staged once per wave in LDS (one 16-byte
+// load per lane brings the whole 1 KB table) and read back as broadcast ds_reads, packed-FP32 sweeps
+// (drm_sample.hpp rnea_chain), preloaded kernel arguments, one basic block; the per-link body forces are parked
+// in LDS between the two sweeps (registers are what limits occupancy here).
+// ---------------------------------------------------------------------------------------------------
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                    const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
+    // body-force parking area between the sweeps (tau is staged over it at the end): 13.3 KB per wave
+    static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
+    constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS;
+    float *lf = lq + lane; // body forces between the sweeps: [link][6][64]
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    // constant rows -> LDS (16 bytes per lane); every lane reads its own rows of q / qd / qdd straight into registers
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+    {
+        const int64_t row = (b0 + lane) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = q[row + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = qd[row + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? qdd[row + d] : 0.0f;
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    rnea_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                        flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv,
+                        [&](int k, const Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                lf[(k * 6 + i) * WAVE] = F.la[i][0];
+                                lf[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                            }
+                        },
+                        [&](int k, Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
+                        });
+    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = tv[d];
+    wave_lds_sync();
+    tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+}
+
+
+void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+                     float *tau, hipStream_t s) {
+    hipLaunchKernelGGL((rnea_arm_kernel<8, 7>), dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused FK(target) + RNEA of a serial chain whose LAST link is the FK target (BASELINE configuration 3: Panda,
+// q / qd / qdd -> tau, pos, quat; 140 B per evaluation instead of the 168 B and two launch floors of drm_fk +
+// drm_rnea): one load of q, one sin/cos evaluation, one staged constant table; the FK chain runs first (its pose goes out
+// while the dynamics sweeps run), then the RNEA sweeps of rnea_arm_kernel.  Arithmetic is that of the two separate
+// kernels, bit for bit (drm_sample.hpp: fk_chain_pairs_trig / rnea_chain_trig on shared cos / sin).
+// ---------------------------------------------------------------------------------------------------
+template <int CAP, int NJ>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+    fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                       const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
+                       float *__restrict__ pos, float *__restrict__ quat) {
+    static_assert(NJ & 1, "odd row widths only (linear LDS image)");
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), P_FLOATS = WAVE * 3,
+                  F_FLOATS = CAP * 6 * WAVE;
+    static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
+    constexpr int PER_WAVE = C_FLOATS + P_FLOATS + F_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * PER_WAVE;
+    float *lp = lc + C_FLOATS, *lq = lp + P_FLOATS;
+    float *lf = lq + lane;
+    const int64_t b0 = (int64_t)tile * WAVE;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+    {
+        const int64_t row = (b0 + lane) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = q[row + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = qd[row + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? qdd[row + d] : 0.0f;
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+
+    float cs[NJ], sn[NJ];
+    chain_trig<NJ>(qv, cs, sn);
+    auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    {   // forward kinematics of the last link (robot_model.py:223-248)
+        PoseP ee;
+        f2 Bk[NJ][3];
+        fk_chain_pairs_trig<CAP, NJ>(row, cs, sn, ee, Bk, [] {});
+        lp[lane * 3 + 0] = ee.B[0][1];
+        lp[lane * 3 + 1] = ee.B[1][1];
+        lp[lane * 3 + 2] = ee.B[2][1];
+        wave_lds_sync();
+        tile_store<3>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        store16_wt(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+    }
+    // inverse dynamics (robot_model.py:305-375)
+    rnea_chain_trig<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+                             [&](int k, const Force &F) {
+#pragma unroll
+                                 for (int i = 0; i < 3; ++i) {
+                                     lf[(k * 6 + i) * WAVE] = F.la[i][0];
+                                     lf[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                                 }
+                             },
+                             [&](int k, Force &F) {
+#pragma unroll
+                                 for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
+                             });
+    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = tv[d];
+    wave_lds_sync();
+    tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+}
+
+void launch_fk_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+                        float *tau, float *pos, float *quat, hipStream_t s) {
+    hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7>), dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
+                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+}
+
+} // namespace drm

@@ -171,22 +171,26 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
     wave_lds_sync(); // all rows are in registers: the tiles may be overwritten
     auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    // bias torques first (RNEA with qdd = 0), H afterwards: the 28 floats of the triangle are not live across the RNEA
+    // walk, whose own peak is what decides between one and two waves per SIMD; cos / sin are shared by the two walks
+    float cs[NJ], sn[NJ];
+    chain_trig<NJ>(qv, cs, sn);
+    rnea_chain_trig<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, zero, nle,
+                             [&](int k, const Force &F) {
+#pragma unroll
+                                 for (int i = 0; i < 3; ++i) {
+                                     park[(k * 6 + i) * WAVE] = F.la[i][0];
+                                     park[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                                 }
+                             },
+                             [&](int k, Force &F) {
+#pragma unroll
+                                 for (int i = 0; i < 3; ++i) F.la[i] = f2_make(park[(k * 6 + i) * WAVE], park[(k * 6 + 3 + i) * WAVE]);
+                             });
     float Ht[NJ * (NJ + 1) / 2];
-    crba_chain<CAP, NJ>(row, qv, [&](int i, int j, float v) {
+    crba_chain_trig<CAP, NJ>(row, cs, sn, [&](int i, int j, float v) {
         if (i >= j) Ht[tri_index(i, j)] = v;
     });
-    rnea_chain<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, qv, qdv, zero, nle,
-                        [&](int k, const Force &F) {
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                park[(k * 6 + i) * WAVE] = F.la[i][0];
-                                park[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
-                            }
-                        },
-                        [&](int k, Force &F) {
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(park[(k * 6 + i) * WAVE], park[(k * 6 + 3 + i) * WAVE]);
-                        });
 #pragma unroll
     for (int d = 0; d < NJ; ++d) rhs[d] -= nle[d];
     ltdl_solve_unrolled<NJ>(Ht, rhs);

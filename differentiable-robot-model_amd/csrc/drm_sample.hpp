@@ -1456,23 +1456,16 @@ DRM_HD void inertia_to_parent(const float *J, const float *t, const Inertia &c, 
 // joint axes carried as packed (ang_i, lin_i) pairs, two joints per sincos evaluation.
 //   row(k) -> pointer to op k's constant row;   hout(i, j, v) -> H[i][j] = v (called for both triangles)
 template <int CAP, int NJ, class ROW, class HOUT>
+DRM_HD void crba_chain_trig(ROW row, const float (&cs)[NJ], const float (&sn)[NJ], HOUT hout);
+template <int CAP, int NJ, class ROW, class HOUT>
 DRM_HD void crba_chain(ROW row, const float (&q)[NJ], HOUT hout) {
     float cs[NJ], sn[NJ];
-    bool big = false;
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
-    if (DRM_WAVE_ANY(big)) {
-#pragma unroll
-        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
-    } else {
-#pragma unroll
-        for (int d = 0; d < NJ; d += 2) {
-            f2 s2, c2;
-            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
-            sn[d] = s2[0]; cs[d] = c2[0];
-            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
-        }
-    }
+    chain_trig<NJ>(q, cs, sn);
+    crba_chain_trig<CAP, NJ>(row, cs, sn, hout);
+}
+// ... given cos / sin of the joint angles (the forward-dynamics arm kernel shares them with its RNEA walk)
+template <int CAP, int NJ, class ROW, class HOUT>
+DRM_HD void crba_chain_trig(ROW row, const float (&cs)[NJ], const float (&sn)[NJ], HOUT hout) {
     // all joint transforms first (kept in registers: both sweeps below read them)
     float J[CAP][9];
 #pragma unroll

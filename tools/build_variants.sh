@@ -11,7 +11,7 @@ BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -w"
 while [ $# -ge 2 ]; do
   name=$1; extra=$2; shift 2
   tmp=$(mktemp -d)
-  for f in drm_host drm_arm_kernels drm_fk_jacobian drm_fk drm_rnea drm_fk_backward drm_crba drm_rnea_backward drm_forward_dynamics; do
+  for f in drm_host drm_arm_kernels drm_arm_dynamics drm_fk_jacobian drm_fk drm_rnea drm_fk_backward drm_crba drm_rnea_backward drm_forward_dynamics; do
     /opt/rocm/bin/hipcc $BASE $extra -c -o "$tmp/$f.o" "$CSRC/$f.hip" &
   done
   wait
