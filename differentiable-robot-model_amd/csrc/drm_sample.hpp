@@ -68,6 +68,7 @@ DRM_HD int ctl_field(int ctl, int field) {
            : field == DRM_OPI_PERM  ? (ctl >> 20) & 7
                                     : (ctl >> 23) & 1; // DRM_OPI_FLAGS
 }
+DRM_HD bool ctl_prismatic(int ctl) { return (ctl >> 25) & 1; }
 // sin / cos of a joint angle, branch-free.  Argument reduction k = rint(x 2/pi),
 // r = x - k pi/2 is done in fp64 (two constants), which keeps r exact to fp32
 // rounding for |x| < ~1e9 without a slow path; the kernels then use degree-9/10
@@ -475,15 +476,20 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         const int c = ctl[k];
         const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
         const OpFT o = load_ft(of);
+        const bool pris = ctl_prismatic(c);
         float J[9], cs = 1.0f, sn = 0.0f;
-        if (dof >= 0) sincos_f(qf(dof), sn, cs);
+        if (dof >= 0 && !pris) sincos_f(qf(dof), sn, cs);
         joint_rot_z(o.F, cs, sn, J);
         if (src >= 0) pose_load(src, cur);
         if (src == DRM_SRC_ROOT) compose_root(J, o.t, cur);
         else compose(cur, J, o.t, cur);
+        if (dof >= 0 && pris) { // a prismatic joint slides the frame along its own z axis: p += R e_z q
+            const float d = qf(dof);
+            cur.p[0] += cur.R[2] * d; cur.p[1] += cur.R[5] * d; cur.p[2] += cur.R[8] * d;
+        }
         if (save >= 0) pose_save(save, cur);
         park(k, cur);
-        if (JAC && dof >= 0) {
+        if (JAC && dof >= 0 && !pris) { // (the column of a prismatic joint, (z, 0), does not depend on p_e)
             float l[3];
             glin(dof, l);
             const float z[3] = {cur.R[2], cur.R[5], cur.R[8]};
@@ -531,9 +537,18 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
                         tot.M[i * 3 + j] += Rb[i * 3 + 0] * Rt[j * 3 + 0] + Rb[i * 3 + 1] * Rt[j * 3 + 1] + Rb[i * 3 + 2] * Rt[j * 3 + 2];
             }
         }
+        const bool pris = ctl_prismatic(c);
         if (JAC) {
             if (out >= 0) { tot.G[0] += Se[0]; tot.G[1] += Se[1]; tot.G[2] += Se[2]; }
-            if (dof >= 0) {
+            if (dof >= 0 && pris) { // column (lin, ang) = (z_k, 0):  dL/dz_k = l_k
+                float l[3];
+                glin(dof, l);
+                const float z[3] = {Pk.R[2], Pk.R[5], Pk.R[8]};
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tot.M[i * 3 + j] += l[i] * z[j];
+            } else if (dof >= 0) {
                 float l[3], a[3];
                 glin(dof, l);
                 gang(dof, a);
@@ -556,8 +571,12 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
         else if (src == DRM_SRC_ROOT || k == 0) pose_identity(par);
         else unpark(k - 1, par);
         if (want_gq && dof >= 0) {
-            const float Nx = tot.M[7] - tot.M[5], Ny = tot.M[2] - tot.M[6], Nz = tot.M[3] - tot.M[1];
-            gq_out(dof, Pk.R[2] * Nx + Pk.R[5] * Ny + Pk.R[8] * Nz);
+            if (pris) { // everything below the joint translates along z_k with q
+                gq_out(dof, Pk.R[2] * tot.G[0] + Pk.R[5] * tot.G[1] + Pk.R[8] * tot.G[2]);
+            } else {
+                const float Nx = tot.M[7] - tot.M[5], Ny = tot.M[2] - tot.M[6], Nz = tot.M[3] - tot.M[1];
+                gq_out(dof, Pk.R[2] * Nx + Pk.R[5] * Ny + Pk.R[8] * Nz);
+            }
         }
         if ((param_mask >> k) & 1u) {
             float dt[3], A[9], Bm[9], dF[9];
@@ -576,6 +595,10 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
                     dF[r * 3 + cc] = A[r * 3 + 0] * Bm[0 * 3 + cc] + A[r * 3 + 1] * Bm[1 * 3 + cc] + A[r * 3 + 2] * Bm[2 * 3 + cc];
+            if (dof >= 0 && pris) { // p_k also depends on F through the slide F e_z q
+                const float d = qf(dof);
+                dF[2] += dt[0] * d; dF[5] += dt[1] * d; dF[8] += dt[2] * d;
+            }
             param_out(k, dF, dt);
         }
         if (src != DRM_SRC_ROOT) {
@@ -711,6 +734,42 @@ DRM_HD void rnea_link_motion(const float *J, const float *t, float wj, float aj,
     N.va[0][1] += N.va[1][0] * wj; N.va[1][1] -= N.va[0][0] * wj;
     out = N;
 }
+// joint transform of one op (child -> parent: x_p = J x_c + t) from its constants and joint value:
+//   revolute   J = F Rot_z(q), t = trans          prismatic   J = F, t = trans + F e_z q          fixed  J = F, t = trans
+DRM_HD void joint_transform(const OpFT &o, bool moving, bool prismatic, float q, float c, float s, float *J, float *t) {
+    if (moving && !prismatic) {
+        joint_rot_z(o.F, c, s, J);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+    }
+    const float d = (moving && prismatic) ? q : 0.0f;
+    t[0] = o.t[0] + o.F[2] * d;
+    t[1] = o.t[1] + o.F[5] * d;
+    t[2] = o.t[2] + o.F[8] * d;
+}
+
+// the same for a prismatic joint (joint velocity (0, e_z qd)); used by the loop-structured walks (drm_tree.hpp) and the
+// backward walk below
+DRM_HD void motion_step(const float *J, const float *t, float wj, float aj, bool prismatic, const Motion &par, Motion &out) {
+    if (!prismatic) {
+        rnea_link_motion(J, t, wj, aj, par, out);
+        return;
+    }
+    // v = J^T (v_p + w_p x t) + e_z qd ;  a = J^T (a_p + al_p x t) + e_z qdd + w x (e_z qd)   (joint velocity (0, e_z qd))
+    f2 x[3], tmp[3];
+    Motion N;
+    matT_vec_p(J, par.wa, N.wa);
+    cross3_ps(par.wa, t, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = par.va[i] + x[i];
+    matT_vec_p(J, tmp, N.va);
+    N.va[2] += f2_make(wj, aj);
+    N.va[0][1] += N.wa[1][0] * wj;
+    N.va[1][1] -= N.wa[0][0] * wj;
+    out = N;
+}
+
 // body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
 // pairs: (h, g) = (I v, I a):  lin = m (v, a) - mc x (w, al) ;  ang = Io (w, al) + mc x (v, a)
 DRM_HD void rnea_body_force(float m, const float *mc, const float *Io, const Motion &N, Force &out) {
@@ -854,7 +913,7 @@ struct LinkAdjoint {
 };
 DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const float *J, const float *t, float wj,
                               const float *mo, const float *fb, const float *par, float *mb, const float *ub,
-                              const float *tot, bool has_parent, LinkAdjoint &out) {
+                              const float *tot, bool has_parent, LinkAdjoint &out, bool prismatic = false) {
     float *wb = mb, *vb = mb + 3, *alb = mb + 6, *ab = mb + 9;
     const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
     const float *fl = fb, *fa = fb + 3; // adjoint of this link's body force = tbar_k
@@ -905,7 +964,7 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     for (int i = 0; i < 9; ++i) Jb[i] = 0.0f;
     tbr[0] = tbr[1] = tbr[2] = 0.0f;
     float *Pwb = pb, *Pvb = pb + 3, *Palb = pb + 6, *Pab = pb + 9;
-    // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)
+    // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)            [prismatic: ... + aj e_z + (w_y wj, -w_x wj, 0)]
     y[0] = Pa[0]; y[1] = Pa[1]; y[2] = Pa[2];
     add_cross(y, Pal, t);
     mat_vec(J, ab, yb);
@@ -913,22 +972,30 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * ab[c];
-    vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
-    wjb += ab[0] * v[1] - ab[1] * v[0];
+    if (prismatic) {
+        ajb += ab[2];
+        wb[1] += ab[0] * wj; wb[0] -= ab[1] * wj;
+        wjb += ab[0] * w[1] - ab[1] * w[0];
+    } else {
+        vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
+        wjb += ab[0] * v[1] - ab[1] * v[0];
+    }
     Pab[0] += yb[0]; Pab[1] += yb[1]; Pab[2] += yb[2];
     add_cross(Palb, t, yb);
     add_cross(tbr, yb, Pal);
-    // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)
+    // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)             [prismatic: al = J^T Pal]
     mat_vec(J, alb, x);
     Palb[0] += x[0]; Palb[1] += x[1]; Palb[2] += x[2];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pal[r] * alb[c];
-    ajb += alb[2];
-    wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
-    wjb += alb[0] * w[1] - alb[1] * w[0];
-    // v = J^T (Pv + Pw x t)
+    if (!prismatic) {
+        ajb += alb[2];
+        wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
+        wjb += alb[0] * w[1] - alb[1] * w[0];
+    }
+    // v = J^T (Pv + Pw x t)                                    [prismatic: ... + wj e_z]
     y[0] = Pv[0]; y[1] = Pv[1]; y[2] = Pv[2];
     add_cross(y, Pw, t);
     mat_vec(J, vb, yb);
@@ -936,17 +1003,18 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * vb[c];
+    if (prismatic) wjb += vb[2];
     Pvb[0] += yb[0]; Pvb[1] += yb[1]; Pvb[2] += yb[2];
     add_cross(Pwb, t, yb);
     add_cross(tbr, yb, Pw);
-    // w = J^T Pw + wj e_z
+    // w = J^T Pw + wj e_z                                      [prismatic: w = J^T Pw]
     mat_vec(J, wb, x);
     Pwb[0] += x[0]; Pwb[1] += x[1]; Pwb[2] += x[2];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pw[r] * wb[c];
-    wjb += wb[2];
+    if (!prismatic) wjb += wb[2];
     // the force transform of the backward sweep: up.lin = J tot.lin, up.ang = J tot.ang + t x (J tot.lin)
     if (has_parent) {
         float Lb[3], L[3];
@@ -974,11 +1042,12 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
     // joint transform of op k from its constants and the parked (cos, sin) of its angle
-    auto joint = [&](int k, float *J, float *t, float *trig) {
+    // (a prismatic op parks (1, q) instead: J = F, t = trans + F e_z q)
+    auto joint = [&](int k, int c, float *J, float *t, float *trig) {
         const OpFT o = load_ft(opf + k * DRM_OPF_STRIDE);
         unpark(k, 24, trig, 2);
-        joint_rot_z(o.F, trig[0], trig[1], J);
-        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+        const bool pris = ctl_prismatic(c);
+        joint_transform(o, ctl_field(c, DRM_OPI_DOF) >= 0, pris, trig[1], trig[0], trig[1], J, t);
     };
 
     // ---- A: motions and body forces ------------------------------------------------------------------
@@ -990,18 +1059,20 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             const float *of = opf + k * DRM_OPF_STRIDE;
             const int c = ctl[k];
             const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
-            float wj = 0.0f, aj = 0.0f, J[9], rec[12], trig[2] = {1.0f, 0.0f};
+            const bool pris = ctl_prismatic(c);
+            float wj = 0.0f, aj = 0.0f, J[9], t[3], rec[12], trig[2] = {1.0f, 0.0f};
             if (dof >= 0) {
                 float q;
                 qf(dof, q, wj, aj);
-                sincos_f(q, trig[1], trig[0]);
+                if (pris) trig[1] = q;
+                else sincos_f(q, trig[1], trig[0]);
             }
             park(k, 24, trig, 2);
             const OpFT o = load_ft(of);
-            joint_rot_z(o.F, trig[0], trig[1], J);
+            joint_transform(o, dof >= 0, pris, trig[1], trig[0], trig[1], J, t);
             if (src == DRM_SRC_ROOT) motion_root(cur, g);
             if (src >= 0) { slot_get(src, 0, rec, 12); motion_from_floats(rec, cur); }
-            rnea_link_motion(J, o.t, wj, aj, cur, cur);
+            motion_step(J, t, wj, aj, pris, cur, cur);
             motion_to_floats(cur, rec);
             if (save >= 0) slot_put(save, 0, rec, 12);
             park(k, 0, rec, 12);
@@ -1032,7 +1103,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             park(k, 12, tot, 6);
             if (src != DRM_SRC_ROOT) {
                 float J[9], t[3], trig[2], up[6];
-                joint(k, J, t, trig);
+                joint(k, c, J, t, trig);
                 mat_vec(J, tot, up);
                 mat_vec(J, tot + 3, up + 3);
                 add_cross(up + 3, t, up);
@@ -1059,13 +1130,13 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
 #pragma unroll
                     for (int i = 0; i < 6; ++i) ub[i] = prev[i];
                 }
-                joint(k, J, t, trig);
+                joint(k, c, J, t, trig);
                 Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
                 add_cross(Lb, ub + 3, t); // Lbar' = ubar.lin + ubar.ang x t
                 matT_vec(J, Lb, tb);
                 matT_vec(J, ub + 3, tb + 3);
             }
-            if (dof >= 0) tb[5] += gtau(dof);
+            if (dof >= 0) tb[ctl_prismatic(c) ? 2 : 5] += gtau(dof); // tau = S^T f: angular z (revolute), linear z (prismatic)
             park(k, 18, tb, 6);
             if (save >= 0) slot_put(save, 18, tb, 6);
 #pragma unroll
@@ -1096,7 +1167,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             unpark(k, 0, mo, 12);
             unpark(k, 18, fb, 6);
             float J[9], t[3], trig[2], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
-            joint(k, J, t, trig);
+            joint(k, c, J, t, trig);
             if (dof >= 0) { float q; qf(dof, q, wj, aj); qdk = wj; }
             float par[12];
             if (src == DRM_SRC_ROOT) {
@@ -1116,26 +1187,33 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             }
             LinkAdjoint A;
             rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tot,
-                              src != DRM_SRC_ROOT, A);
+                              src != DRM_SRC_ROOT, A, ctl_prismatic(c));
             const float *pb = A.pb, *Jb = A.Jb, *tbr = A.tb, *gmc = A.gmc, *gIo = A.gIo;
             const float gm = A.gm, wjb = A.wjb, ajb = A.ajb;
             // J = F Rot_z(q)
             const float gtk = dof >= 0 ? gtau(dof) : 0.0f;
+            const bool pris = ctl_prismatic(c);
             if (want_gq && dof >= 0) {
                 float gq = 0.0f;
+                if (pris) { // t = trans + F e_z q
+                    gq = tbr[0] * J[2] + tbr[1] * J[5] + tbr[2] * J[8];
+                } else {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) gq += Jb[r * 3 + 0] * J[r * 3 + 1] - Jb[r * 3 + 1] * J[r * 3 + 0];
+                    for (int r = 0; r < 3; ++r) gq += Jb[r * 3 + 0] * J[r * 3 + 1] - Jb[r * 3 + 1] * J[r * 3 + 0];
+                }
                 gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
             }
             if ((param_mask >> k) & 1u) {
                 float gr[DRM_OPF_STRIDE];
 #pragma unroll
                 for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+                // revolute: J = F Rot_z(q);  prismatic: J = F and t = trans + F e_z q (trig = (1, q))
+                const float cq = pris ? 1.0f : trig[0], sq = pris ? 0.0f : trig[1], dq = pris ? trig[1] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * trig[0] - Jb[r * 3 + 1] * trig[1];
-                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * trig[1] + Jb[r * 3 + 1] * trig[0];
-                    gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2];
+                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * cq - Jb[r * 3 + 1] * sq;
+                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * sq + Jb[r * 3 + 1] * cq;
+                    gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2] + tbr[r] * dq;
                     gr[DRM_OPF_TI(r)] = tbr[r];
                     gr[DRM_OPF_MCOM + r] = gmc[r];
                 }

@@ -79,21 +79,6 @@ DRM_HD void sincos_one(float x, float &s, float &c) {
     c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cr) ^ flip);
 }
 
-// joint transform of one op (child -> parent: x_p = J x_c + t) from its constants and joint value:
-//   revolute   J = F Rot_z(q), t = trans          prismatic   J = F, t = trans + F e_z q          fixed  J = F, t = trans
-DRM_HD void joint_transform(const OpFT &o, bool moving, bool prismatic, float q, float c, float s, float *J, float *t) {
-    if (moving && !prismatic) {
-        joint_rot_z(o.F, c, s, J);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) J[i] = o.F[i];
-    }
-    const float d = (moving && prismatic) ? q : 0.0f;
-    t[0] = o.t[0] + o.F[2] * d;
-    t[1] = o.t[1] + o.F[5] * d;
-    t[2] = o.t[2] + o.F[8] * d;
-}
-
 // one link of the pose chain on packed pairs; prismatic joints slide along the NEW z axis: p += R e_z q
 DRM_HD void pose_step(const OpPairs &o, const OpCtl &ct, float q, bool from_root, PoseP &cur) {
     float c = 1.0f, s = 0.0f;
@@ -182,25 +167,6 @@ DRM_HD void fk_jacobian_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, PoseP &ee,
 //   motion_save / motion_load(s, Motion)           branch-point motions
 //   force_add(s, Force) / force_take(s, Force&)    branch-point force accumulators (take = add into F and reset)
 // ---------------------------------------------------------------------------
-DRM_HD void motion_step(const float *J, const float *t, float wj, float aj, bool prismatic, const Motion &par, Motion &out) {
-    if (!prismatic) {
-        rnea_link_motion(J, t, wj, aj, par, out);
-        return;
-    }
-    // v = J^T (v_p + w_p x t) + e_z qd ;  a = J^T (a_p + al_p x t) + e_z qdd + w x (e_z qd)   (joint velocity (0, e_z qd))
-    f2 x[3], tmp[3];
-    Motion N;
-    matT_vec_p(J, par.wa, N.wa);
-    cross3_ps(par.wa, t, x);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) tmp[i] = par.va[i] + x[i];
-    matT_vec_p(J, tmp, N.va);
-    N.va[2] += f2_make(wj, aj);
-    N.va[0][1] += N.wa[1][0] * wj;
-    N.va[1][1] -= N.wa[0][0] * wj;
-    out = N;
-}
-
 // one op of the forward sweep: its motion from the parent's (cur is updated), its body force and what the backward sweep
 // needs again (cos / sin / value of the joint)
 template <class ROW, class QF, class MSAVE, class MLOAD>

@@ -435,6 +435,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                           | (((ops_i[:, OPI_SAVE] + 1) & 7) << 10) | (((ops_i[:, OPI_OUT] + 1) & 0x7f) << 13)
                           | ((ops_i[:, OPI_PERM] & 7) << 20) | ((ops_i[:, OPI_FLAGS] & 1) << 23))
     ops_i[n_ops:, OPI_CTRL] |= 1 << 24
+    ops_i[:, OPI_CTRL] |= (pris_arr << 25).astype(np.int32)
     # ... and the two wide control words of the loop-structured forward kernels (DRM_W0_PACK / DRM_W1_PACK)
     i64 = lambda col: ops_i[:, col].astype(np.int64)
     w0 = (((i64(OPI_DOF) + 1) & 0xff) | (((i64(OPI_SRC) + 2) & 0xff) << 8) | (((i64(OPI_SAVE) + 1) & 0xff) << 16)

@@ -541,11 +541,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         return mask
 
     def _differentiable(self, dw: _DeviceWalk) -> None:
-        """The backward kernels know revolute and fixed joints, walks of up to 64 links and 4 nested branch points."""
-        if (self._spec.kind == KIND_PRISMATIC).any():
-            raise NotImplementedError(
-                "gradients through a robot with prismatic joints are not implemented yet (the forward kernels model them; "
-                "the backward kernels do not) — detach the inputs, or load the robot with reference_compat=True")
+        """The backward kernels take walks of up to 64 links and 4 nested branch points (any joint model)."""
         if not dw.program.backward_ok:
             raise NotImplementedError("gradients need a walk of <= 64 links with <= 4 nested branch points (this one: %d links, "
                                       "%d slots)" % (dw.program.n_ops, dw.program.n_slots))

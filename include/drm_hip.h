@@ -66,6 +66,7 @@ extern "C" {
                                bits 20..22 DRM_OPI_PERM code
                                bit  23     DRM_FLAG_CHILD_IS_NEXT
                                bit  24     identity padding op (kernels may skip it)
+                               bit  25     prismatic joint (slides along +z of the stored frame by q)
                              The unpacked fields below stay in the table for hosts and debuggers       */
 #define DRM_OPI_CTRL_PACK(dof, src, save, out, perm, flags)                                                       \
     ((((dof) + 1) & 0x7f) | ((((src) + 2) & 7) << 7) | ((((save) + 1) & 7) << 10) | ((((out) + 1) & 0x7f) << 13) | \
