@@ -16,7 +16,9 @@ namespace drm {
 // (drm_sample.hpp rnea_chain), preloaded kernel arguments, one basic block; the per-link body forces are parked
 // in LDS between the two sweeps (registers are what limits occupancy here).
 // ---------------------------------------------------------------------------------------------------
-template <int CAP, int NJ>
+// LINKS = the links the dynamics sweeps visit: CAP, or NJ when the walk has no ops behind its moving joints (the host
+// folded the fixed tail into the last moving link, flatten.fold_link_table; the rest of the table is identity padding).
+template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                     const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
-    rnea_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+    rnea_chain<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
                         flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv,
                         [&](int k, const Force &F) {
 #pragma unroll
@@ -72,10 +74,11 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 }
 
 
-void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s) {
-    hipLaunchKernelGGL((rnea_arm_kernel<8, 7>), dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+    const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
+    if (links == 7) hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+    else hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -85,7 +88,8 @@ void launch_rnea_arm(const float *ops_f, const float *q, const float *qd, const 
 // while the dynamics sweeps run), then the RNEA sweeps of rnea_arm_kernel.  Arithmetic is that of the two separate
 // kernels, bit for bit (drm_sample.hpp: fk_chain_pairs_trig / rnea_chain_trig on shared cos / sin).
 // ---------------------------------------------------------------------------------------------------
-template <int CAP, int NJ>
+// (LINKS as above: the FK chain always walks all CAP ops, the dynamics sweeps the first LINKS)
+template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         store16_wt(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
     }
     // inverse dynamics (robot_model.py:305-375)
-    rnea_chain_trig<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+    rnea_chain_trig<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
                              [&](int k, const Force &F) {
 #pragma unroll
                                  for (int i = 0; i < 3; ++i) {
@@ -159,10 +163,13 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
 }
 
-void launch_fk_rnea_arm(const float *ops_f, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                         float *tau, float *pos, float *quat, hipStream_t s) {
-    hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7>), dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                       dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+    const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
+    if (links == 7)
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+    else
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
 }
 
 } // namespace drm

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
 // Serial-chain ("arm") specialisation, full tiles only — the design of fk_jacobian_arm_kernel: constant rows staged
 // once per wave in LDS, packed-FP32 sweeps without the int table (drm_sample.hpp crba_chain), preloaded kernel
 // arguments, one basic block, H staged as a linear LDS image (n^2 = 49 is odd).
-template <int CAP, int NJ>
+// LINKS: the links the sweep visits (NJ when the host folded the fixed tail into the last moving link, else CAP).
+template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     crba_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles, float *__restrict__ H) {
     static_assert((NJ & 1) && ((NJ * NJ) & 1), "odd row widths only (linear LDS images)");
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 #pragma unroll
     for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
     float *hrow = lh + lane * NN;
-    crba_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
+    crba_chain<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
                         [&](int i, int j, float v) { hrow[i * NJ + j] = v; });
     wave_lds_sync();
     tile_store<NN>(H + b0 * NN, WAVE, NN, 0u, lh, lane, true);
@@ -155,9 +156,9 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
         (((uintptr_t)q | (uintptr_t)H | (uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the packed-FP32 chain kernel, ragged tail through the generic one
         const int n_tiles = (int)(B / WAVE);
-        hipLaunchKernelGGL((crba_arm_kernel<8, 7>),
-                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, n_tiles, H);
+        const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
+        if (arm_links(w) == 7) hipLaunchKernelGGL((crba_arm_kernel<8, 7, 7>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
+        else hipLaunchKernelGGL((crba_arm_kernel<8, 7, 8>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return launched();
         rc = launched();

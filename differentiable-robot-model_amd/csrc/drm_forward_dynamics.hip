@@ -21,7 +21,7 @@ namespace drm {
 // block (drm_tree.hpp crba_tree_walk, packed lower triangle with segment-local DoF indices), the bias torques of its
 // joints (rnea_tree_walk with qdd = 0, robot_model.py:377-400) and solves its block by the leaf-to-root L^T D L
 // factorisation (drm_sample.hpp ltdl_solve) — an Allegro hand is four 4 x 4 systems per sample, not one 16 x 16.
-// LDS: [ table ][ q ][ qd ][ f -> rhs -> qdd ] shared, then per wavefront
+// LDS: [ table ][ q ][ qd ][ f -> rhs -> qdd ][ residual of the refinement step ] shared, then per wavefront
 //      [ records : max_seg_ops * 9 * 64 (RNEA; CRBA's cos / sin / value first) ][ slots : n_slots * 18 * 64 ]
 //      [ triangle : 64 (nt|1), nt = largest block's n (n + 1) / 2 — unless HBM ]
 // HBM: the triangle lives in caller-provided scratch, [tile][segment][entry][64] (robots beyond ~30 DoF per segment).
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
-    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lf = lqd + region;
+    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lf = lqd + region, *lres = lf + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
     float *park = smem + a.wave_off[wave];
@@ -92,7 +92,31 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
         [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
         [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
-    ltdl_solve_acc(cnt, tri, lf + row + lo);
+    ltdl_factor_acc(cnt, tri);
+    ltdl_apply_acc(cnt, tri, lf + row + lo);
+    if (flags & DRM_FD_REFINE) {
+        // one step of iterative refinement: r = f - ID(q, qd, x0) by the inverse-dynamics walk (it never forms H, so its
+        // rounding errors are those of the torques, not cond(H) times them), x1 = x0 + H^-1 r with the factors at hand;
+        // the residual has a tile of its own (lres).
+        wave_lds_sync();
+        for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
+        wave_lds_sync();
+        float *lr = lres + row; // residual tile (same layout as lf)
+        rnea_tree_walk(
+            a.prefix_end, first, last, ctl, rowf, flags,
+            [&](int d, float &x, float &v, float &acc) {
+                x = live ? lq[row + d] : 0.0f;
+                v = lqd[row + d];
+                acc = (d >= lo && d < lo + cnt) ? lf[row + d] : 0.0f; // (prefix ops carry no DoF: every DoF read is this segment's)
+            },
+            [&](int d, float v) { lr[d] = (live ? f[(tc.b0 + lane) * n + d] : 0.0f) - v; },
+            [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
+            [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
+            [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
+            [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+        ltdl_apply_acc(cnt, tri, lr + lo);
+        for (int d = lo; d < lo + cnt; ++d) lf[row + d] += lr[d];
+    }
     __syncthreads();
     if (wave == 0)
         tile_store<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
@@ -115,7 +139,7 @@ static FdPlan fd_plan(const drm_walk *w) {
             if (nt > p.nt_max) p.nt_max = nt;
         }
         const TreeArgs &a = p.a;
-        const size_t shared = (size_t)table_lds_floats(a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(a.n));
+        const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n)); // q, qd, f -> qdd, residual
         p.hbm = hbm;
         p.lds = sizeof(float) * layout_waves(p.a, shared, RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE, [&](int s) {
             const int c = a.seg_dof_cnt[s];
@@ -135,7 +159,8 @@ static FdPlan fd_plan(const drm_walk *w) {
 // Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,
 // rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled Cholesky; constants
 // staged once per wave in LDS, RNEA's body forces parked over the dead input tiles, qdd staged over them at the end.
-template <int CAP, int NJ>
+// LINKS: the links the sweeps visit (NJ when the host folded the fixed tail into the last moving link, else CAP).
+template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     forward_dynamics_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                                 const float *__restrict__ f, int n_tiles, int flags, float *__restrict__ qdd) {
@@ -175,7 +200,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     // walk, whose own peak is what decides between one and two waves per SIMD; cos / sin are shared by the two walks
     float cs[NJ], sn[NJ];
     chain_trig<NJ>(qv, cs, sn);
-    rnea_chain_trig<CAP, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, zero, nle,
+    rnea_chain_trig<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, zero, nle,
                              [&](int k, const Force &F) {
 #pragma unroll
                                  for (int i = 0; i < 3; ++i) {
@@ -188,7 +213,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                                  for (int i = 0; i < 3; ++i) F.la[i] = f2_make(park[(k * 6 + i) * WAVE], park[(k * 6 + 3 + i) * WAVE]);
                              });
     float Ht[NJ * (NJ + 1) / 2];
-    crba_chain_trig<CAP, NJ>(row, cs, sn, [&](int i, int j, float v) {
+    crba_chain_trig<LINKS, NJ>(row, cs, sn, [&](int i, int j, float v) {
         if (i >= j) Ht[tri_index(i, j)] = v;
     });
 #pragma unroll
@@ -226,10 +251,13 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the register-resident chain kernel, ragged tail through the generic one
         const int n_tiles = (int)(B / WAVE);
-        hipLaunchKernelGGL((forward_dynamics_arm_kernel<8, 7>),
-                           dim3((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)),
-                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, (hipStream_t)stream, w->ops_f, q, qd, f, n_tiles, (int)flags,
-                           qdd);
+        const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
+        if (arm_links(w) == 7)
+            hipLaunchKernelGGL((forward_dynamics_arm_kernel<8, 7, 7>), grid, block, 0, (hipStream_t)stream, w->ops_f, q, qd, f,
+                               n_tiles, (int)flags, qdd);
+        else
+            hipLaunchKernelGGL((forward_dynamics_arm_kernel<8, 7, 8>), grid, block, 0, (hipStream_t)stream, w->ops_f, q, qd, f,
+                               n_tiles, (int)flags, qdd);
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return launched();
         rc = launched();

@@ -1618,7 +1618,7 @@ DRM_HD float recip_f(float x) {
 // H(i) -> reference to element i of the packed triangle (an LDS row, or a strided HBM scratch area for robots whose
 // triangle does not fit in LDS)
 template <class HA>
-DRM_HD void ltdl_solve_acc(int n, HA H, float *b) {
+DRM_HD void ltdl_factor_acc(int n, HA H) {
     for (int k = n - 1; k >= 0; --k) {
         const int rk = tri_index(k, 0);
         const float inv = recip_f(H(rk + k));
@@ -1632,6 +1632,10 @@ DRM_HD void ltdl_solve_acc(int n, HA H, float *b) {
             H(rk + i) = a;                                             // L[k][i]
         }
     }
+}
+// b <- (L^T D L)^-1 b with the factors left by ltdl_factor_acc
+template <class HA>
+DRM_HD void ltdl_apply_acc(int n, HA H, float *b) {
     for (int i = n - 1; i >= 0; --i) {       // y = L^-T b
         const int ri = tri_index(i, 0);
         const float bi = b[i];
@@ -1643,6 +1647,11 @@ DRM_HD void ltdl_solve_acc(int n, HA H, float *b) {
         for (int j = 0; j < i; ++j) t -= H(ri + j) * b[j];
         b[i] = t;
     }
+}
+template <class HA>
+DRM_HD void ltdl_solve_acc(int n, HA H, float *b) {
+    ltdl_factor_acc(n, H);
+    ltdl_apply_acc(n, H, b);
 }
 DRM_HD void ltdl_solve(int n, float *H, float *b) {
     ltdl_solve_acc(n, [H](int i) -> float & { return H[i]; }, b);

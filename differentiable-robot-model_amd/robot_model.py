@@ -23,8 +23,8 @@ import numpy as np
 import torch
 
 from . import backend
-from .flatten import (KIND_PRISMATIC, OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, identity_table_row,
-                      virtual_row_constants)
+from .flatten import (OPF_STRIDE, REFINE_MASS_SPREAD, RobotSpec, WalkProgram, build_robot_spec, build_walk, fold_link_table,
+                      foldable_links, identity_table_row, mass_spread, virtual_row_constants)
 from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
 
@@ -86,6 +86,7 @@ class _DeviceWalk:
     gather: torch.Tensor                # int64 [cap * 32] flat indices into the [L+1, 32] link table
     gsign: torch.Tensor                 # float32 [cap * 32] +-1 factors of the gathered entries
     static_ops_f: Optional[torch.Tensor] = None
+    folded: bool = False                # a dynamics walk without the foldable links, on the folded link table
     learnable_plan: Optional[tuple] = None   # (learnable links, constant walk table, row selector) of _ops_f_learnable
 
 
@@ -281,10 +282,10 @@ class _ForwardDynamics(torch.autograd.Function):
     through the reference's articulated-body recursion, robot_model.py:487-624; examples/learn_forward_dynamics_iiwa.py)."""
 
     @staticmethod
-    def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask):
-        qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs)
+    def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask, refine=True):
+        qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs, refine)
         ctx.save_for_backward(q, qd, qdd, ops_f)
-        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask = dw, (gravity, damping), n_dofs, param_mask
+        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask, ctx.refine = dw, (gravity, damping), n_dofs, param_mask, refine
         return qdd
 
     @staticmethod
@@ -293,7 +294,7 @@ class _ForwardDynamics(torch.autograd.Function):
         q, qd, qdd, ops_f = ctx.saved_tensors
         dw, n = ctx.dw, ctx.n_dofs
         lam = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, torch.zeros_like(qd),
-                                       grad_qdd.to(torch.float32).contiguous(), False, False, n)
+                                       grad_qdd.to(torch.float32).contiguous(), False, False, n, ctx.refine)
         want_in = any(ctx.needs_input_grad[:2])
         want_ops = ctx.needs_input_grad[3] and ctx.param_mask != 0
         gq = gqd = grad_ops = None
@@ -305,7 +306,7 @@ class _ForwardDynamics(torch.autograd.Function):
                 gqd = -gin[1].reshape(qd.shape) if ctx.needs_input_grad[1] else None
             grad_ops = -gops if gops is not None else None
         gf = lam.reshape(grad_qdd.shape) if ctx.needs_input_grad[2] else None
-        return gq, gqd, gf, grad_ops, None, None, None, None, None
+        return gq, gqd, gf, grad_ops, None, None, None, None, None, None
 
 
 class DifferentiableRobotModel(torch.nn.Module):
@@ -360,6 +361,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
+        self._static_table_folded: Optional[torch.Tensor] = None   # ... with the foldable links folded into their parents
+        # forward dynamics: one step of iterative refinement (DRM_FD_REFINE) for robots whose inertia matrix is badly
+        # conditioned — light links far out on heavy ones (flatten.mass_spread); settable (True / False) by the user
+        self.forward_dynamics_refinement: bool = mass_spread(self._spec) > REFINE_MASS_SPREAD
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
     # ------------------------------------------------------------------ constants
@@ -451,23 +456,49 @@ class DifferentiableRobotModel(torch.nn.Module):
                 damping if damping is not None else zero1)]))
         return torch.stack(rows)
 
-    def _get_walk(self, key, targets=None, whole_tree=False) -> _DeviceWalk:
+    def _get_walk(self, key, targets=None, whole_tree=False, folded=False) -> _DeviceWalk:
         dw = self._walks.get(key)
         if dw is None:
-            prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree)
+            prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree, drop_folded=folded and whole_tree)
             dw = _DeviceWalk(
                 program=prog,
                 ops_i=torch.from_numpy(prog.ops_i_dev).to(self._device).contiguous(),
                 gather=torch.from_numpy(prog.gather.reshape(-1)).to(self._device),
                 gsign=torch.from_numpy(prog.gsign.reshape(-1)).to(self._device),
+                folded=folded,
             )
             self._walks[key] = dw
         return dw
+
+    def _dynamics_walk(self) -> _DeviceWalk:
+        """The whole-tree walk of the forward dynamics kernels.  While nothing is learnable, links behind fixed joints
+        with no moving joint below them (end-effector frames, fingertips) are folded into their parents: their inertia
+        is added to the parent's row once on the host (flatten.fold_link_table) and the walk leaves them out — the same
+        torques / inertia matrix / accelerations from fewer ops (Panda 8 -> 7, Allegro 21 -> 17).  Autograd paths and
+        robots with learnable parameters use the full walk (gradients belong to the individual links)."""
+        if self._learnable or not foldable_links(self._spec).any():
+            return self._get_walk(("tree",), whole_tree=True)
+        return self._get_walk(("tree", "folded"), whole_tree=True, folded=True)
+
+    def _folded_table(self) -> torch.Tensor:
+        assert not self._learnable
+        if self._static_table_folded is None:
+            self._link_table()
+            L1 = len(self._bodies) + 1
+            with torch.no_grad():
+                base = fold_link_table(self._spec, self._static_table[:L1].cpu().numpy())
+                self._static_table_folded = self._with_virtual_rows(
+                    torch.from_numpy(base.astype(np.float32)).to(self._device))
+        return self._static_table_folded
 
     def _ops_f(self, dw: _DeviceWalk) -> torch.Tensor:
         """[cap, OPF_STRIDE] constants gathered (and axis-canonicalised) in walk order; ONE differentiable
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
+            return dw.static_ops_f
+        if dw.folded:
+            table = self._folded_table()
+            dw.static_ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
             return dw.static_ops_f
         if (self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32
                 and not self._spec.skew.any()):
@@ -703,7 +734,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._require_device()
         assert q.ndim == 2 and q.shape[1] == self._n_dofs
         assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
-        dw = self._get_walk(("tree",), whole_tree=True)
+        dw = self._dynamics_walk()
         return backend.InverseDynamicsPlan(dw.program, self._ops_f(dw), dw.ops_i, q, qd, qdd_des, bool(include_gravity),
                                            bool(use_damping), self._n_dofs)
 
@@ -720,8 +751,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         idx = self._name_to_idx_map[link_name]
         if idx == 0:
             raise ValueError("the root link has the identity pose; use plan_inverse_dynamics")
-        tree = self._get_walk(("tree",), whole_tree=True)
-        chain = self._get_walk(("chain", idx), targets=[idx])
+        tree = self._dynamics_walk()
+        chain = self._get_walk(("chain", idx) + (("folded",) if tree.folded else ()), targets=[idx], folded=tree.folded)
         return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
                                              (chain.program, self._ops_f(chain), chain.ops_i),
                                              int(tree.program.op_of_link.get(idx, -1)),
@@ -789,7 +820,8 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._differentiable(dw)
             return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs,
                                           self._learnable_op_mask(dw))
-        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
+        dw = self._dynamics_walk()
+        return backend.rnea(dw.program, self._ops_f(dw), dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
 
     @tensor_check
     def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
@@ -810,7 +842,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         if torch.is_grad_enabled() and (ops_f.requires_grad or q.requires_grad):
             self._differentiable(dw)
             return _MassMatrix.apply(q, ops_f, dw, self._n_dofs, self._learnable_op_mask(dw))
-        return backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+        dw = self._dynamics_walk()
+        return backend.crba(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
 
     @tensor_check
     def compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
@@ -834,9 +867,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         if torch.is_grad_enabled() and (ops_f.requires_grad or any(t.requires_grad for t in (q, qd, f))):
             self._differentiable(dw)
             return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
-                                          self._learnable_op_mask(dw))
-        return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
-                                        bool(use_damping), self._n_dofs)
+                                          self._learnable_op_mask(dw), self.forward_dynamics_refinement)
+        dw = self._dynamics_walk()
+        return backend.forward_dynamics(dw.program, self._ops_f(dw), dw.ops_i, q, qd, f, bool(include_gravity),
+                                        bool(use_damping), self._n_dofs, self.forward_dynamics_refinement)
 
     def compute_forward_dynamics_old(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
                                      include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True

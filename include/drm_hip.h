@@ -116,6 +116,9 @@ extern "C" {
 /* flags of drm_rnea */
 #define DRM_RNEA_GRAVITY 1 /* base acceleration (0,0,+9.81)   (robot_model.py:344-350)         */
 #define DRM_RNEA_DAMPING 2 /* tau += damping * qd             (robot_model.py:368-373)         */
+#define DRM_FD_REFINE 4    /* drm_forward_dynamics only: one step of iterative refinement, qdd += H^-1 (f - ID(q, qd, qdd)),
+                              the residual taken by the inverse-dynamics walk (which never forms H): recovers the accuracy of
+                              the reference's articulated-body recursion on ill-conditioned trees (an arm carrying a hand)  */
 
 /* error codes */
 #define DRM_OK 0
@@ -208,6 +211,11 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
  *   target_op index of the FK target among the ops of `tree`, or -1 if unknown: when the tree is a serial 7-DoF arm and
  *             the target is its last link, both results come from ONE fused launch (one read of q, one sin/cos
  *             evaluation, one constant table); otherwise the two walks are launched one after the other.
+ *             FOLDED TREES: a host may leave links behind fixed leaf joints (an end-effector frame) out of `tree` after
+ *             adding their inertia to their parents' rows (the dynamics are unchanged; fewer ops).  If `tree` then holds
+ *             exactly the n moving joints of a serial 7-DoF arm and `chain` is that arm up to the target, the fused launch
+ *             reads ONE table, chain->ops_f: the caller guarantees that its first n rows carry the same constants as
+ *             tree->ops_f (both gathered from the same folded link table); target_op is ignored (-1).
  *   q, qd, qdd [B, n] (qdd may be NULL)  ->  tau [B, n], pos [B, 3], quat [B, 4];  flags as for drm_rnea.
  * Results are bit-identical to drm_rnea + drm_fk.
  */
@@ -230,6 +238,8 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *st
  * DRM_RNEA_DAMPING = the damping torques damping * qd are taken off f first (robot_model.py:515-521; the
  * caller's f is NOT modified, unlike the reference, which subtracts in place).
  *   q, qd, f [B, n]  ->  qdd [B, n]
+ *   DRM_FD_REFINE (flags) adds one refinement step (one more inverse-dynamics walk + two triangular solves); the 7-DoF arm
+ *   kernel, whose H is well conditioned (errors ~1e-5), ignores it.
  *   scratch   drm_forward_dynamics_scratch_floats(walk, B) floats owned by the caller (0 for every shipped robot: the
  *             packed triangle of a segment's inertia matrix lives in LDS; beyond ~30 DoF per segment it lives there)
  */

@@ -262,6 +262,18 @@ void fd_loop(const drm_walk *w, const float *q, const float *qd, const float *f,
             for (int d = 0; d < cnt; ++d) r[d] = f[b * n + lo + d] - x[lo + d];
             ltdl_solve(cnt, T.data(), r);
         }
+        if (flags & DRM_FD_REFINE) { // x1 = x0 + H^-1 (f - ID(q, qd, x0)), factors reused (T is per segment: refactorise here)
+            rnea_loop(w, q + b * n, qd + b * n, qdd + b * n, 1, flags, x.data());
+            for (int seg = 0; seg < w->n_segments; ++seg) {
+                const int lo = w->seg_dof_lo[seg], cnt = w->seg_dof_cnt[seg];
+                for (int i = 0; i < cnt; ++i)
+                    for (int j = 0; j <= i; ++j) T[tri_index(i, j)] = H[(lo + i) * n + lo + j];
+                std::vector<float> r(cnt);
+                for (int d = 0; d < cnt; ++d) r[d] = f[b * n + lo + d] - x[lo + d];
+                ltdl_solve(cnt, T.data(), r.data());
+                for (int d = 0; d < cnt; ++d) qdd[b * n + lo + d] += r[d];
+            }
+        }
     }
 }
 

@@ -7,9 +7,13 @@ arithmetic (host emulation) against the fp64 oracle for every shipped robot.  GP
 
 Tolerance: forward dynamics amplifies fp32 rounding by cond(H) (up to ~1e6 for the Jaco's gram-scale finger links,
 where |qdd| reaches 1e6 rad/s^2); the reference's own fp32 result is 1.5e-4 (relative to 1 + |qdd|) away from an fp64
-evaluation there.  Accelerations are therefore compared as |d qdd| <= tol * (1 + |qdd|) with tol = 2e-3 against
-fp64 and against the reference (hands, grippers, mobile bases with gram-scale links), 1e-4 for the arms (observed:
-<= 5e-5 arms, <= 8e-4 hands).
+evaluation there.  Accelerations are therefore compared as |d qdd| <= tol * (1 + |qdd|) with tol = 1e-3 against
+fp64 and against the reference (hands, grippers, mobile bases with gram-scale links), 1e-4 for the arms.  Robots whose
+sub-tree masses spread over more than two decades (flatten.mass_spread: Fetch, Jaco, an arm carrying a hand) take one
+step of iterative refinement by default (DRM_FD_REFINE: the residual f - ID(q, qd, qdd) from the inverse-dynamics walk),
+which brings the kernel to the accuracy of the reference's fp32 articulated-body recursion (observed vs fp64 on 200
+random states: Fetch 1.6e-3 -> 4.7e-5 where the fp32 ABA has 1.3e-4; Jaco 7e-4 -> 3e-5 / 2.4e-4; iiwa7 + Allegro
+6e-4 -> 4e-4 / 3e-4).
 """
 import ctypes
 
@@ -24,7 +28,7 @@ from test_host_emu import _ptr, emu, host_walk  # noqa: F401  (emu is a fixture)
 
 import os
 
-TOL = 2e-3
+TOL = 1e-3
 TOL_ARMS = 1e-4
 ARMS = ("panda_no_gripper", "iiwa7", "2link_robot", "panda")
 

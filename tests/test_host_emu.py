@@ -11,9 +11,10 @@ import subprocess
 
 import numpy as np
 import pytest
+import torch
 
 from differentiable_robot_model_amd.backend import DrmWalk
-from differentiable_robot_model_amd.flatten import OPI_PERM, build_walk
+from differentiable_robot_model_amd.flatten import OPI_PERM, build_walk, fold_link_table, foldable_links
 from helpers import ALL_ROBOTS, load_model, max_err, quat_close, sample_states
 from oracle import Oracle
 
@@ -237,3 +238,50 @@ def test_quaternion_on_branch_boundaries(emu):
         assert np.abs(p2[:, 0] - pos).max() < 1e-6          # the loop-structured walk agrees with the arm chain
         return pos, quat
     check_quaternion_branches(fk)
+
+
+# ---------------------------------------------------------------------------------------------- folded fixed links
+def folded_host_walk(model, prog):
+    """host_walk on the folded link table (flatten.fold_link_table; robot_model._folded_table on the device)."""
+    L1 = len(model._bodies) + 1
+    base = fold_link_table(model._spec, model._link_table().detach().cpu().numpy()[:L1])
+    table = model._with_virtual_rows(torch.from_numpy(base.astype(np.float32))).numpy().reshape(-1)
+    ops_f = np.ascontiguousarray((table[prog.gather.reshape(-1)] * prog.gsign.reshape(-1)).reshape(prog.capacity, 32),
+                                 np.float32)
+    from differentiable_robot_model_amd.backend import fill_walk_struct
+    walk = fill_walk_struct(DrmWalk, prog, ops_f.ctypes.data, prog.ops_i_dev.ctypes.data, model._n_dofs, 2)
+    return walk, ops_f
+
+
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "allegro_left", "trifinger_edu", "panda", "fetch"])
+def test_folding_fixed_leaf_links_into_their_parents_leaves_the_dynamics_unchanged(emu, robot):
+    """flatten.foldable_links / fold_link_table: a dynamics walk without the links behind fixed leaf joints, on a table
+    whose parent rows carry their inertia, gives the torques, inertia matrix and accelerations of the full walk (and of
+    the oracle, which knows nothing about folding)."""
+    m = load_model(robot)
+    fold = foldable_links(m._spec)
+    assert fold.any()
+    full = build_walk(m._spec, whole_tree=True)
+    short = build_walk(m._spec, whole_tree=True, drop_folded=True)
+    assert short.n_ops == full.n_ops - int(fold[1:].sum())
+    B, n = 19, m._n_dofs
+    q, qd, qdd = sample_states(m, B, seed=31)
+    res = []
+    for walk, _keep in (host_walk(m, full), folded_host_walk(m, short)):
+        tau = np.zeros((B, n), np.float32); H = np.zeros((B, n, n), np.float32); acc = np.zeros((B, n), np.float32)
+        assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(tau)) == 0
+        assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+        assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(acc)) == 0
+        res.append((tau, H, acc))
+    (t0, H0, a0), (t1, H1, a1) = res
+    assert np.allclose(t1, t0, rtol=2e-5, atol=2e-5) and np.allclose(H1, H0, rtol=2e-5, atol=2e-5)
+    assert (np.abs(a1 - a0) / (1 + np.abs(a0))).max() < 2e-3
+    orc = Oracle(m._spec)
+    assert np.allclose(t1, orc.rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), True, True, np.float64),
+                       rtol=2e-5, atol=2e-5)
+    # the chain walk to a folded link on the folded table: FK constants untouched, its own inertia gone
+    tip = int(np.nonzero(fold)[0][-1])
+    chain = build_walk(m._spec, targets=[tip])
+    _w, ops_f = folded_host_walk(m, chain)
+    _w0, ops_f0 = host_walk(m, chain)
+    assert np.array_equal(ops_f[:, :12], ops_f0[:, :12]) and not ops_f[chain.n_ops - 1, 12:25].any()
