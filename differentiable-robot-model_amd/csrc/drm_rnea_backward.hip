@@ -146,8 +146,9 @@ __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
 // Serial-chain ("arm") specialisation, full tiles only: drm_sample.hpp rnea_backward_chain (per-link forces and their
 // adjoints in registers, motions recovered on the way back instead of stored), constants staged once per wave in LDS,
 // gradient tiles staged over the dead input tiles.  Same persistent-wave structure and batch reduction as the
-// generic kernel.
-template <int CAP, int NJ>
+// generic kernel.  LINKS: the links the sweeps visit (NJ when the walk ends at its last moving joint — the host folded the
+// fixed tail into it, flatten.fold_link_table, which it only does when nothing is learnable — else CAP).
+template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     rnea_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                              const float *__restrict__ qdd, const float *__restrict__ gtau, int n_tiles, int flags,
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         float add[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
-        rnea_backward_chain<CAP, NJ>(
+        rnea_backward_chain<LINKS, NJ>(
             [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
             flags & DRM_RNEA_DAMPING, param_mask, gq != nullptr, qv, qdv, qddv, gtv,
             [&](int d, float a, float v, float c) {
@@ -275,9 +276,14 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
             const int n_tiles = (int)(B / WAVE);
             const int64_t done = (int64_t)n_tiles * WAVE;
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
-            hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
-                               dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, grad_tau, n_tiles, (int)flags,
-                               param_mask, grad_q, grad_qd, grad_qdd, partials);
+            if (arm_links(w) == 7)
+                hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                                   dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, grad_tau, n_tiles, (int)flags,
+                                   param_mask, grad_q, grad_qd, grad_qdd, partials);
+            else
+                hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7, 8>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                                   dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, grad_tau, n_tiles, (int)flags,
+                                   param_mask, grad_q, grad_qd, grad_qdd, partials);
             rc = launched();
             if (rc) return rc;
             int rows = waves_a;

@@ -474,8 +474,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         """The whole-tree walk of the forward dynamics kernels.  While nothing is learnable, links behind fixed joints
         with no moving joint below them (end-effector frames, fingertips) are folded into their parents: their inertia
         is added to the parent's row once on the host (flatten.fold_link_table) and the walk leaves them out — the same
-        torques / inertia matrix / accelerations from fewer ops (Panda 8 -> 7, Allegro 21 -> 17).  Autograd paths and
-        robots with learnable parameters use the full walk (gradients belong to the individual links)."""
+        torques / inertia matrix / accelerations — and the same gradients with respect to q, qd, qdd / f — from fewer ops
+        (Panda 8 -> 7, Allegro 21 -> 17).  With learnable parameters the full walk runs (their gradients belong to the
+        individual links)."""
         if self._learnable or not foldable_links(self._spec).any():
             return self._get_walk(("tree",), whole_tree=True)
         return self._get_walk(("tree", "folded"), whole_tree=True, folded=True)
@@ -812,7 +813,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         return mask
 
     def _inverse_dynamics(self, q, qd, qdd, gravity: bool, damping: bool) -> torch.Tensor:
-        dw = self._get_walk(("tree",), whole_tree=True)
+        dw = self._dynamics_walk()    # (the full walk whenever a link parameter is learnable)
         ops_f = self._ops_f(dw)
         needs_grad = torch.is_grad_enabled() and (ops_f.requires_grad or any(
             t is not None and t.requires_grad for t in (q, qd, qdd)))
@@ -820,8 +821,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._differentiable(dw)
             return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs,
                                           self._learnable_op_mask(dw))
-        dw = self._dynamics_walk()
-        return backend.rnea(dw.program, self._ops_f(dw), dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
+        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
 
     @tensor_check
     def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
@@ -837,13 +837,12 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         self._require_device()
-        dw = self._get_walk(("tree",), whole_tree=True)
+        dw = self._dynamics_walk()
         ops_f = self._ops_f(dw)
         if torch.is_grad_enabled() and (ops_f.requires_grad or q.requires_grad):
             self._differentiable(dw)
             return _MassMatrix.apply(q, ops_f, dw, self._n_dofs, self._learnable_op_mask(dw))
-        dw = self._dynamics_walk()
-        return backend.crba(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
+        return backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
 
     @tensor_check
     def compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
@@ -862,14 +861,13 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.shape[1] == self._n_dofs
         assert qd.shape[1] == self._n_dofs
         self._require_device()
-        dw = self._get_walk(("tree",), whole_tree=True)
+        dw = self._dynamics_walk()
         ops_f = self._ops_f(dw)
         if torch.is_grad_enabled() and (ops_f.requires_grad or any(t.requires_grad for t in (q, qd, f))):
             self._differentiable(dw)
             return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
                                           self._learnable_op_mask(dw), self.forward_dynamics_refinement)
-        dw = self._dynamics_walk()
-        return backend.forward_dynamics(dw.program, self._ops_f(dw), dw.ops_i, q, qd, f, bool(include_gravity),
+        return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
                                         bool(use_damping), self._n_dofs, self.forward_dynamics_refinement)
 
     def compute_forward_dynamics_old(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,

@@ -429,25 +429,32 @@ def test_quaternion_on_branch_boundaries_gpu():
 # ------------------------------------------------------------------ folded fixed leaf links (robot_model._dynamics_walk)
 @pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "allegro_left", "trifinger_edu", "fetch"])
 def test_folded_dynamics_walk_matches_the_full_walk(robot):
-    """Without learnable parameters the forward dynamics calls run a walk without the links behind fixed leaf joints
-    (their inertia folded into the parents' rows once on the host); under autograd the full walk runs.  Same torques,
-    inertia matrix and accelerations within the parity tolerances — and fewer ops."""
+    """Without learnable parameters the dynamics calls (and their backward kernels) run a walk without the links behind
+    fixed leaf joints, whose inertia is folded into the parents' rows once on the host.  Same torques, inertia matrix,
+    accelerations and input gradients as the full walk within the parity tolerances — from fewer ops."""
+    from differentiable_robot_model_amd import backend
     m = load_model(robot, "cuda")
-    B = 300
+    B, n = 300, m._n_dofs
     q, qd, qdd = (dev(a) for a in sample_states(m, B, seed=77))
     folded = m._dynamics_walk()
     full = m._get_walk(("tree",), whole_tree=True)
     assert folded.folded and folded.program.n_ops < full.program.n_ops
-    tau = m.compute_inverse_dynamics(q, qd, qdd)
+    f = dev(np.random.default_rng(5).uniform(-1, 1, (B, n)).astype(np.float32))   # (as in test_forward_dynamics.py)
+    qg, qdg, qddg = (t.clone().requires_grad_(True) for t in (q, qd, qdd))
+    tau = m.compute_inverse_dynamics(qg, qdg, qddg)
     H = m.compute_lagrangian_inertia_matrix(q)
-    f = dev(np.random.default_rng(5).uniform(-1, 1, (B, m._n_dofs)).astype(np.float32))   # (as in test_forward_dynamics.py)
     acc = m.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True)
-    qg = q.clone().requires_grad_(True)                       # autograd: the unfolded walk
-    tau_full = m.compute_inverse_dynamics(qg, qd, qdd).detach()
-    H_full = m.compute_lagrangian_inertia_matrix(qg).detach()
-    acc_full = m.compute_forward_dynamics(qg, qd, f, include_gravity=True, use_damping=True).detach()
-    assert torch.allclose(tau, tau_full, **TOL_TAU) and torch.allclose(H, H_full, **TOL_TAU)
-    assert ((acc - acc_full).abs() / (1 + acc_full.abs())).max().item() < 2e-3
+    gtau = dev(np.random.default_rng(6).standard_normal((B, n)).astype(np.float32))
+    tau.backward(gtau)
+    of = m._ops_f(full)
+    tau_full = backend.rnea(full.program, of, full.ops_i, q, qd, qdd, True, True, n)
+    H_full = backend.crba(full.program, of, full.ops_i, q, n)
+    acc_full = backend.forward_dynamics(full.program, of, full.ops_i, q, qd, f, True, True, n, m.forward_dynamics_refinement)
+    gin, _ = backend.rnea_backward(full.program, of, full.ops_i, q, qd, qdd, gtau, True, True, n, 0, True)
+    assert torch.allclose(tau.detach(), tau_full, **TOL_TAU) and torch.allclose(H, H_full, **TOL_TAU)
+    assert ((acc - acc_full).abs() / (1 + acc_full.abs())).max().item() < 1e-3
+    for got, ref in zip((qg.grad, qdg.grad, qddg.grad), gin):
+        assert (got - ref).abs().max().item() <= 1e-3 * max(ref.abs().max().item(), 1e-6)
     # a learnable parameter switches folding off (gradients belong to the individual links)
     from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
     last = m._bodies[-1].name

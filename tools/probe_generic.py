@@ -28,7 +28,7 @@ lib = backend.load_library()
 for B in [int(a) for a in sys.argv[1:]] or [65536, 1 << 20]:
     q, qd, qdd = (t.cuda() for t in sample(m, B))
     m.compute_inverse_dynamics(q[:64], qd[:64], qdd[:64])
-    dt = m._walks[("tree",)]; of = m._ops_f(dt)
+    dt = m._get_walk(("tree",), whole_tree=True); of = m._ops_f(dt)
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for generic in (False, True):
         walk = backend._walk_struct(dt.program, of, dt.ops_i, 7)
@@ -39,3 +39,18 @@ for B in [int(a) for a in sys.argv[1:]] or [65536, 1 << 20]:
         t2 = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(), st())))
         t3 = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 1, acc.data_ptr(), None, st())))
         print("B=%8d %s  rnea %8.2f  crba %8.2f  fd %8.2f us" % (B, "tree" if generic else "arm ", t1, t2, t3))
+
+# RNEA backward: arm kernel vs the loop-structured kernel on the same robot
+import dataclasses
+for B in [65536, 1 << 20]:
+    q, qd, qdd = (t.cuda() for t in sample(m, B))
+    gtau = torch.randn(B, 7, device="cuda")
+    dt = m._get_walk(("tree",), whole_tree=True); of = m._ops_f(dt)
+    for generic in (False, True):
+        prog = dataclasses.replace(dt.program, shape=dt.program.shape & ~1) if generic else dt.program
+        for mask in (0, 0b10):
+            us = graph_time(lambda: backend.rnea_backward(prog, of, dt.ops_i, q, qd, qdd, gtau, True, True, 7, mask, True), launches=20)
+            print("B=%8d rnea bwd %s mask=%d  %8.2f us" % (B, "tree" if generic else "arm ", mask, us))
+    df = m._dynamics_walk(); off = m._ops_f(df)
+    us = graph_time(lambda: backend.rnea_backward(df.program, off, df.ops_i, q, qd, qdd, gtau, True, True, 7, 0, True), launches=20)
+    print("B=%8d rnea bwd arm, folded walk (7 links), input gradients only  %8.2f us" % (B, us))
