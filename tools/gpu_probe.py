@@ -86,7 +86,7 @@ def timing():
         print("fk_jac  B=%8d  %9.1f us/call (api %9.1f)  %7.2f Mevals/s  %6.1f GB/s algorithmic" %
               (B, us, us_api, B / us, B * 224 / us / 1e3), flush=True)
         m.compute_inverse_dynamics(q, qd, qdd)
-        dt = m._walks[("tree",)]
+        dt = m._get_walk(("tree",), whole_tree=True)
         us = timeit(lambda: backend.rnea(dt.program, m._ops_f(dt), dt.ops_i, q, qd, qdd, True, True, 7))
         print("rnea    B=%8d  %9.1f us/call  %7.2f Mevals/s  %6.1f GB/s algorithmic" %
               (B, us, B / us, B * 112 / us / 1e3), flush=True)

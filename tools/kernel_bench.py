@@ -22,7 +22,7 @@ for B in sizes:
     for _ in range(30):
         backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, 7)
     m.compute_inverse_dynamics(q, qd, qdd)
-    dt = m._walks[("tree",)]
+    dt = m._dynamics_walk()
     for _ in range(30):
         backend.rnea(dt.program, m._ops_f(dt), dt.ops_i, q, qd, qdd, True, True, 7)
     torch.cuda.synchronize()

@@ -35,7 +35,7 @@ for B in sizes:
         del plan
         continue
     m.compute_inverse_dynamics(q[:64], qd[:64], qdd[:64])
-    dt = m._walks[("tree",)]; of = m._ops_f(dt)          # the full walk (backward kernels)
+    dt = m._get_walk(("tree",), whole_tree=True); of = m._ops_f(dt)          # the full walk (backward kernels)
     df = m._dynamics_walk()                              # forward dynamics: fixed leaf links folded into their parents
     tau = torch.empty(B, 7, device="cuda")
     lib = backend.load_library(); import ctypes
@@ -96,7 +96,7 @@ if fan is not None:
 for B in [s for s in sizes if s <= (1 << 20)]:
     qa, qda, qdda = (t.cuda() for t in sample(ma, B))
     ma.compute_inverse_dynamics(qa[:64], qda[:64], qdda[:64])
-    dta = ma._walks[("tree",)]; ofa = ma._ops_f(dta)
+    dta = ma._get_walk(("tree",), whole_tree=True); ofa = ma._ops_f(dta)
     dfa = ma._dynamics_walk()
     wt = backend._walk_struct(dfa.program, ma._ops_f(dfa), dfa.ops_i, 16)
     lib = backend.load_library()
@@ -110,7 +110,7 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), None, st())), launches=20)
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 5, aa.data_ptr(), None, st())), launches=20)
-    print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s  with the refinement step (API default)" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
+    print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s  with the refinement step (DRM_FD_REFINE; the API turns it on for badly conditioned robots only, not for this hand)" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
     print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
 # BASELINE.json configs 2 and 3 as stated: iiwa7 FK + EE Jacobian at 65 536; Panda FK(EE) + RNEA on one GPU's shard of

@@ -33,4 +33,4 @@ for f in $(find gpurun_out -name "*counter_collection.csv"); do
 done
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 du -sh gpurun_out
-tail -3 $OUT/bench_default.json $OUT/bench_config3.json | cut -c1-1500
+tail -n 3 $OUT/bench_default.json $OUT/bench_config3.json | cut -c1-1500
