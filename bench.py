@@ -156,6 +156,7 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
             print("hipGraph capture failed (%s); launching eagerly" % err, file=sys.stderr)
             graph = None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream); ev1.record(stream)   # untimed: an event's first record creates it (~10 us on this stack)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -166,6 +167,8 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
         for _ in range(K):
             launch()
     ev1.record(stream)
+    while not ev1.query():      # poll instead of sleeping in the driver: a blocking wait adds its wake-up latency
+        pass                    # (10-20 us) to a timed region that is only ~80 us long at the driver's --steps 20
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()

@@ -14,11 +14,14 @@ import torch
 
 
 class UnconstrainedScalar(torch.nn.Module):
-    """A free scalar; forward() -> [1].  (reference rigid_body_params.py:14-23)"""
+    """A free scalar; forward() -> the parameter as it was given ([1] by default, the shape of ``init_val`` otherwise, as
+    in the reference, rigid_body_params.py:14-23: state_dicts carry over)."""
 
     def __init__(self, init_val=None):
         super().__init__()
-        value = torch.rand(1) if init_val is None else torch.as_tensor(init_val, dtype=torch.float32).reshape(1)
+        value = torch.rand(1) if init_val is None else torch.as_tensor(init_val, dtype=torch.float32)
+        if value.numel() != 1:
+            raise ValueError("UnconstrainedScalar takes one value, got shape %s" % (tuple(value.shape),))
         self.param = torch.nn.Parameter(value.clone())
 
     def forward(self):
