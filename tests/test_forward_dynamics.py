@@ -262,3 +262,53 @@ def test_gpu_forward_dynamics_old_is_the_same_linear_system():
     H = m.compute_lagrangian_inertia_matrix(q)
     nle = m.compute_non_linear_effects(q, qd)
     assert torch.allclose(torch.einsum("bij,bj->bi", H, old) + nle, f, atol=2e-4, rtol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------- refinement step
+def test_mass_spread_selects_the_badly_conditioned_robots():
+    """flatten.mass_spread: largest / smallest sub-tree mass behind a moving joint; above REFINE_MASS_SPREAD the model
+    turns the refinement step of forward dynamics on."""
+    from differentiable_robot_model_amd.flatten import REFINE_MASS_SPREAD, mass_spread
+    want = {"panda_no_gripper": False, "iiwa7": False, "allegro_left": False, "trifinger_edu": False,
+            "fetch": True, "jaco": True, "iiwa7_allegro": True}
+    for robot, refine in want.items():
+        m = load_model(robot)
+        assert (mass_spread(m._spec) > REFINE_MASS_SPREAD) == refine == m.forward_dynamics_refinement, robot
+
+
+@pytest.mark.parametrize("robot", ["fetch", "jaco", "iiwa7_allegro"])
+def test_emu_refinement_step_recovers_aba_accuracy(emu, robot):
+    """DRM_FD_REFINE (flag 4): qdd += H^-1 (f - ID(q, qd, qdd)).  On the robots that need it the error against the fp64
+    oracle drops towards the level of the reference's own fp32 articulated-body recursion (the oracle's fp32 build)."""
+    m = load_model(robot)
+    n, B = m._n_dofs, 120
+    q, qd, _ = sample_states(m, B, seed=61)
+    f = np.random.default_rng(3).uniform(-1, 1, (B, n)).astype(np.float32)
+    prog = build_walk(m._spec, whole_tree=True)
+    walk, keep = host_walk(m, prog)
+    orc = Oracle(m._spec)
+    args = (q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), 1, 1)
+    ref, aba32 = orc.forward_dynamics(*args, np.float64), orc.forward_dynamics(*args, np.float32)
+    err = {}
+    for flags in (3, 7):
+        out = np.full((B, n), np.nan, np.float32)
+        assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(out)) == 0
+        err[flags] = rel_err(out, ref)
+    # (the fp32 ABA of the oracle, for orientation: 3e-5 .. 3e-4 on these robots)
+    assert err[7] < 0.7 * err[3] and err[7] < max(5e-4, 2.0 * rel_err(aba32, ref)), (robot, err, rel_err(aba32, ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["fetch", "jaco"])
+def test_gpu_refinement_is_on_by_default_where_it_matters(robot):
+    m = load_model(robot, "cuda")
+    assert m.forward_dynamics_refinement
+    n, B = m._n_dofs, 200
+    q, qd, _ = sample_states(m, B, seed=61)
+    f = np.random.default_rng(3).uniform(-1, 1, (B, n)).astype(np.float32)
+    tq, tqd, tf = (torch.from_numpy(a).cuda() for a in (q, qd, f))
+    ref = Oracle(m._spec).forward_dynamics(q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), 1, 1, np.float64)
+    refined = rel_err(m.compute_forward_dynamics(tq, tqd, tf, True, True).cpu().numpy(), ref)
+    m.forward_dynamics_refinement = False
+    plain = rel_err(m.compute_forward_dynamics(tq, tqd, tf, True, True).cpu().numpy(), ref)
+    assert refined < 2e-4 and refined < 0.5 * plain, (robot, refined, plain)
