@@ -906,14 +906,23 @@ DRM_HD void sub_cross(float *acc, const float *a, const float *b) { // acc -= a 
 // Adjoint of ONE link of the RNEA: given the link's motion `mo` (w, v, al, a), its parent's motion `par`, the adjoint
 // of its total force `fb` (= tbar_k), the motion adjoint `mb` arriving from its children (updated in place to the
 // link's full motion adjoint), and for the force transform of the backward sweep the parent's tbar `ub` and the
-// link's total force `tot`: the adjoints of the parent's motion (pb), of the joint transform (Jb, tb), of the
-// constants (gm, gmc, gIo) and of the joint rate / acceleration (wjb, ajb).
+// link's total force `tot`: the adjoints of the parent's motion (pb), of the joint value / rate / acceleration
+// (gq, wjb, ajb) and — only when `want_params`, i.e. for the few links with learnable constants — of the joint transform
+// (Jb, tb) and of the inertial constants (gm, gmc, gIo).
+//
+// gq without Jb.  With J = F Rot_z(q), dL/dq = sum_r Jb[r][0] J[r][1] - Jb[r][1] J[r][0], and Jb is a sum of outer
+// products y (x) x; each contributes x[0] (J^T y)[1] - x[1] (J^T y)[0], and every J^T y is a quantity the forward sweep
+// produced: J^T (Pa + Pal x t) = a - (v_y wj, -v_x wj, 0), J^T Pal = al - (w_y wj, -w_x wj, aj), J^T (Pv + Pw x t) = v,
+// J^T Pw = w - wj e_z, J^T (ubar.lin + ubar.ang x t) = tbar.lin, J^T ubar.ang = tbar.ang (- gtau e_z).  Eight dot-product
+// terms of two factors instead of 63 multiply-adds for Jb — on every link, learnable or not.  (A prismatic joint's gq is
+// tb . F e_z, so tb is formed for it as well.)
 struct LinkAdjoint {
-    float pb[12], Jb[9], tb[3], gm, gmc[3], gIo[9], wjb, ajb;
+    float pb[12], Jb[9], tb[3], gm, gmc[3], gIo[9], wjb, ajb, gq;
 };
 DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const float *J, const float *t, float wj,
                               const float *mo, const float *fb, const float *par, float *mb, const float *ub,
-                              const float *tot, bool has_parent, LinkAdjoint &out, bool prismatic = false) {
+                              const float *tot, bool has_parent, LinkAdjoint &out, bool prismatic = false,
+                              bool want_params = true) {
     float *wb = mb, *vb = mb + 3, *alb = mb + 6, *ab = mb + 9;
     const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
     const float *fl = fb, *fa = fb + 3; // adjoint of this link's body force = tbar_k
@@ -929,106 +938,107 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     add_cross(hab, fa, w);
     add_cross(wb, hl, fl); add_cross(wb, ha, fa);
     add_cross(vb, hl, fa);
-    float gm = 0.0f;
-    float *gmc = out.gmc, *gIo = out.gIo;
-    gmc[0] = gmc[1] = gmc[2] = 0.0f;
-    gm += hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2];
     vb[0] += m * hlb[0]; vb[1] += m * hlb[1]; vb[2] += m * hlb[2];
-    sub_cross(gmc, w, hlb);
     sub_cross(wb, hlb, mc);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gIo[r * 3 + c] = hab[r] * w[c] + fa[r] * al[c];
     matT_vec(Io, hab, x);
     wb[0] += x[0]; wb[1] += x[1]; wb[2] += x[2];
-    add_cross(gmc, v, hab);
     add_cross(vb, hab, mc);
-    gm += fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
     ab[0] += m * fl[0]; ab[1] += m * fl[1]; ab[2] += m * fl[2];
-    sub_cross(gmc, al, fl);
     sub_cross(alb, fl, mc);
     matT_vec(Io, fa, x);
     alb[0] += x[0]; alb[1] += x[1]; alb[2] += x[2];
-    add_cross(gmc, a, fa);
     add_cross(ab, fa, mc);
-    out.gm = gm;
+    if (want_params) {
+        float gm = hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2];
+        gm += fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
+        out.gm = gm;
+        float *gmc = out.gmc, *gIo = out.gIo;
+        gmc[0] = gmc[1] = gmc[2] = 0.0f;
+        sub_cross(gmc, w, hlb);
+        add_cross(gmc, v, hab);
+        sub_cross(gmc, al, fl);
+        add_cross(gmc, a, fa);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gIo[r * 3 + c] = hab[r] * w[c] + fa[r] * al[c];
+    }
 
     // link motion from the parent's: adjoint
     const float *Pw = par, *Pv = par + 3, *Pal = par + 6, *Pa = par + 9;
-    float *pb = out.pb, *Jb = out.Jb, *tbr = out.tb, y[3], yb[3];
-    float wjb = 0.0f, ajb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pb[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Jb[i] = 0.0f;
-    tbr[0] = tbr[1] = tbr[2] = 0.0f;
+    float *pb = out.pb, *Jb = out.Jb, *tbr = out.tb, ya[3], yv[3], yb[3];
+    float wjb = 0.0f, ajb = 0.0f, gq = 0.0f;
+    const bool want_tb = want_params || prismatic;
     float *Pwb = pb, *Pvb = pb + 3, *Palb = pb + 6, *Pab = pb + 9;
     // a = J^T (Pa + Pal x t) + (v_y wj, -v_x wj, 0)            [prismatic: ... + aj e_z + (w_y wj, -w_x wj, 0)]
-    y[0] = Pa[0]; y[1] = Pa[1]; y[2] = Pa[2];
-    add_cross(y, Pal, t);
     mat_vec(J, ab, yb);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * ab[c];
     if (prismatic) {
         ajb += ab[2];
         wb[1] += ab[0] * wj; wb[0] -= ab[1] * wj;
         wjb += ab[0] * w[1] - ab[1] * w[0];
     } else {
+        gq += ab[0] * (a[1] + v[0] * wj) - ab[1] * (a[0] - v[1] * wj);
         vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
         wjb += ab[0] * v[1] - ab[1] * v[0];
     }
-    Pab[0] += yb[0]; Pab[1] += yb[1]; Pab[2] += yb[2];
-    add_cross(Palb, t, yb);
-    add_cross(tbr, yb, Pal);
+    Pab[0] = yb[0]; Pab[1] = yb[1]; Pab[2] = yb[2];
+    cross3(t, yb, Palb);
+    if (want_tb) cross3(yb, Pal, tbr);
     // al = J^T Pal + aj e_z + (w_y wj, -w_x wj, 0)             [prismatic: al = J^T Pal]
     mat_vec(J, alb, x);
     Palb[0] += x[0]; Palb[1] += x[1]; Palb[2] += x[2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pal[r] * alb[c];
     if (!prismatic) {
+        gq += alb[0] * (al[1] + w[0] * wj) - alb[1] * (al[0] - w[1] * wj);
         ajb += alb[2];
         wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
         wjb += alb[0] * w[1] - alb[1] * w[0];
     }
     // v = J^T (Pv + Pw x t)                                    [prismatic: ... + wj e_z]
-    y[0] = Pv[0]; y[1] = Pv[1]; y[2] = Pv[2];
-    add_cross(y, Pw, t);
     mat_vec(J, vb, yb);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += y[r] * vb[c];
     if (prismatic) wjb += vb[2];
-    Pvb[0] += yb[0]; Pvb[1] += yb[1]; Pvb[2] += yb[2];
-    add_cross(Pwb, t, yb);
-    add_cross(tbr, yb, Pw);
+    else gq += vb[0] * v[1] - vb[1] * v[0];
+    Pvb[0] = yb[0]; Pvb[1] = yb[1]; Pvb[2] = yb[2];
+    cross3(t, yb, Pwb);
+    if (want_tb) add_cross(tbr, yb, Pw);
     // w = J^T Pw + wj e_z                                      [prismatic: w = J^T Pw]
     mat_vec(J, wb, x);
     Pwb[0] += x[0]; Pwb[1] += x[1]; Pwb[2] += x[2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Pw[r] * wb[c];
-    if (!prismatic) wjb += wb[2];
+    if (!prismatic) {
+        gq += wb[0] * w[1] - wb[1] * w[0];
+        wjb += wb[2];
+    }
     // the force transform of the backward sweep: up.lin = J tot.lin, up.ang = J tot.ang + t x (J tot.lin)
-    if (has_parent) {
-        float Lb[3], L[3];
-        Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
-        add_cross(Lb, ub + 3, t);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Lb[r] * tot[c] + ub[3 + r] * tot[3 + c];
+    if (has_parent && !prismatic) gq += tot[0] * fb[1] - tot[1] * fb[0] + tot[3] * fb[4] - tot[4] * fb[3];
+    if (has_parent && want_tb) {
+        float L[3];
         mat_vec(J, tot, L);
         add_cross(tbr, L, ub + 3);
     }
+    if (want_params) {
+        // Jb = (Pa + Pal x t) (x) ab + Pal (x) alb + (Pv + Pw x t) (x) vb + Pw (x) wb  [+ the force transform's terms]
+        ya[0] = Pa[0]; ya[1] = Pa[1]; ya[2] = Pa[2];
+        add_cross(ya, Pal, t);
+        yv[0] = Pv[0]; yv[1] = Pv[1]; yv[2] = Pv[2];
+        add_cross(yv, Pw, t);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Jb[r * 3 + c] = ya[r] * ab[c] + Pal[r] * alb[c] + yv[r] * vb[c] + Pw[r] * wb[c];
+        if (has_parent) {
+            float Lb[3];
+            Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
+            add_cross(Lb, ub + 3, t);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jb[r * 3 + c] += Lb[r] * tot[c] + ub[3 + r] * tot[3 + c];
+        }
+    }
+    if (prismatic) gq = tbr[0] * J[2] + tbr[1] * J[5] + tbr[2] * J[8]; // t = trans + F e_z q
     out.wjb = wjb;
     out.ajb = ajb;
+    out.gq = gq;
 }
 
 // The sweeps are LOOPS over the n_ops links of the walk (no identity padding, one control word decoded per
@@ -1187,22 +1197,13 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             }
             LinkAdjoint A;
             rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tot,
-                              src != DRM_SRC_ROOT, A, ctl_prismatic(c));
+                              src != DRM_SRC_ROOT, A, ctl_prismatic(c), (param_mask >> k) & 1u);
             const float *pb = A.pb, *Jb = A.Jb, *tbr = A.tb, *gmc = A.gmc, *gIo = A.gIo;
             const float gm = A.gm, wjb = A.wjb, ajb = A.ajb;
             // J = F Rot_z(q)
             const float gtk = dof >= 0 ? gtau(dof) : 0.0f;
             const bool pris = ctl_prismatic(c);
-            if (want_gq && dof >= 0) {
-                float gq = 0.0f;
-                if (pris) { // t = trans + F e_z q
-                    gq = tbr[0] * J[2] + tbr[1] * J[5] + tbr[2] * J[8];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) gq += Jb[r * 3 + 0] * J[r * 3 + 1] - Jb[r * 3 + 1] * J[r * 3 + 0];
-                }
-                gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
-            }
+            if (want_gq && dof >= 0) gout(dof, A.gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
             if ((param_mask >> k) & 1u) {
                 float gr[DRM_OPF_STRIDE];
 #pragma unroll
@@ -1232,31 +1233,22 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     }
 }
 
-// Reverse-mode RNEA of a serial chain (DRM_WALK_ARM_CHAIN): the four sweeps of rnea_backward_walk without the int
-// table, slots or parked records.  Total forces and their adjoints of the CAP links live in registers (static
-// indices), and the link motions are NOT stored: the joint transform is orthogonal, so sweep D recovers a parent's
-// motion from its child's (w_p = J (w - wj e_z), v_p = J v - w_p x t, ...) while it walks back to the root.
+// Reverse-mode RNEA of a serial chain (DRM_WALK_ARM_CHAIN): the sweeps of rnea_backward_walk without the int table, slots
+// or parked records — and without ANY per-link storage.  Every joint transform is orthogonal, so what the forward sweeps
+// (A: motions, C: force adjoints) leave at the tip of the chain is enough: sweep D recovers each parent's motion and
+// force adjoint from its child's while it walks back to the root
+//     w_p = J (w - wj e_z),  v_p = J v - w_p x t, ...        ubar.ang = J tbar.ang,  ubar.lin = J tbar.lin - ubar.ang x t
+// recomputes the body force of the link it is at from that motion, and carries the total force of the sub-tree below it
+// along (sweep B folded into D).  Live state: one motion, one force adjoint, one total force, one motion adjoint — the
+// kernel runs at two or three waves per SIMD instead of one (the earlier form kept tot[CAP][6] and tbar[CAP][6] in registers:
+// 256 VGPR + 180 AGPR).
 //   row(k) -> op k's constant row;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
 template <int CAP, int NJ, class ROW, class GOUT, class PG>
 DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t param_mask, bool want_gq,
                                 const float (&q)[NJ], const float (&qd)[NJ], const float (&qdd)[NJ],
                                 const float (&gtau)[NJ], GOUT gout, PG param_out) {
     float cs[NJ], sn[NJ];
-    bool big = false;
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d]) <= SINCOS_PAIR_MAX_ARG);
-    if (DRM_WAVE_ANY(big)) {
-#pragma unroll
-        for (int d = 0; d < NJ; ++d) sincos_f(q[d], sn[d], cs[d]);
-    } else {
-#pragma unroll
-        for (int d = 0; d < NJ; d += 2) {
-            f2 s2, c2;
-            sincos_pair(f2_make(q[d], q[d + 1 < NJ ? d + 1 : d]), s2, c2);
-            sn[d] = s2[0]; cs[d] = c2[0];
-            if (d + 1 < NJ) { sn[d + 1] = s2[1]; cs[d + 1] = c2[1]; }
-        }
-    }
+    chain_trig<NJ>(q, cs, sn);
     const float g = gravity ? 9.81f : 0.0f;
     auto joint = [&](int k, float *J, float *t) {
         const OpFT o = load_ft(row(k));
@@ -1268,66 +1260,51 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t pa
         }
         t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
     };
-    // ---- A: motions (only the last one is kept) and body forces ----------------------------------------
-    float tot[CAP][6], tb[CAP][6], last[12];
+    // ---- A: motions up the chain (only the tip's is kept);  C: adjoints of the total forces, likewise ------------
+    float mo[12], tbk[6];
     {
         Motion cur;
         motion_root(cur, g);
 #pragma unroll
+        for (int i = 0; i < 6; ++i) tbk[i] = 0.0f;
+#pragma unroll
         for (int k = 0; k < CAP; ++k) {
-            const float *of = row(k);
             float J[9], t[3];
             joint(k, J, t);
             rnea_link_motion(J, t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, cur, cur);
-            Force f;
-            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
+            if (k > 0) { // tbar_k = (J^T (ubar.lin + ubar.ang x t), J^T ubar.ang), ubar = tbar_(k-1)
+                float Lb[3], nx[6];
+                Lb[0] = tbk[0]; Lb[1] = tbk[1]; Lb[2] = tbk[2];
+                add_cross(Lb, tbk + 3, t);
+                matT_vec(J, Lb, nx);
+                matT_vec(J, tbk + 3, nx + 3);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { tot[k][i] = f.la[i][0]; tot[k][3 + i] = f.la[i][1]; }
+                for (int i = 0; i < 6; ++i) tbk[i] = nx[i];
+            }
+            if (k < NJ) tbk[5] += gtau[k];
         }
-        motion_to_floats(cur, last);
+        motion_to_floats(cur, mo);
     }
-    // ---- B: total forces ------------------------------------------------------------------------------------
+    // ---- D (with B): back to the root ----------------------------------------------------------------------------
+    float mb[12], carry[6];
 #pragma unroll
-    for (int k = CAP - 1; k > 0; --k) {
-        float J[9], t[3], up[6];
-        joint(k, J, t);
-        mat_vec(J, tot[k], up);
-        mat_vec(J, tot[k] + 3, up + 3);
-        add_cross(up + 3, t, up);
+    for (int i = 0; i < 12; ++i) mb[i] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) tot[k - 1][i] += up[i];
-    }
-    // ---- C: adjoint of B ------------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) tb[k][i] = 0.0f;
-        if (k > 0) {
-            float J[9], t[3], Lb[3];
-            joint(k, J, t);
-            Lb[0] = tb[k - 1][0]; Lb[1] = tb[k - 1][1]; Lb[2] = tb[k - 1][2];
-            add_cross(Lb, tb[k - 1] + 3, t);
-            matT_vec(J, Lb, tb[k]);
-            matT_vec(J, tb[k - 1] + 3, tb[k] + 3);
-        }
-        if (k < NJ) tb[k][5] += gtau[k];
-    }
-    // ---- D: adjoint of A, walking the motions back to the root ------------------------------------------
-    float mo[12], mb[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { mo[i] = last[i]; mb[i] = 0.0f; }
+    for (int i = 0; i < 6; ++i) carry[i] = 0.0f;
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
         const float *of = row(k);
         float J[9], t[3];
         joint(k, J, t);
         const float wj = k < NJ ? qd[k] : 0.0f, aj = k < NJ ? qdd[k] : 0.0f;
-        // parent's motion from this link's (inverse of rnea_link_motion; J is orthogonal)
-        float par[12];
+        // parent's motion and force adjoint from this link's (inverses of rnea_link_motion / of sweep C; J is orthogonal)
+        float par[12], ub[6];
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) par[i] = 0.0f;
             par[11] = g;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ub[i] = 0.0f;
         } else {
             const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
             float x[3], y[3];
@@ -1342,20 +1319,25 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t pa
             mat_vec(J, x, y);
             sub_cross(y, par + 6, t);                             // a_p = J (a - v x wj e_z) - al_p x t
             par[9] = y[0]; par[10] = y[1]; par[11] = y[2];
+            x[0] = tbk[3]; x[1] = tbk[4]; x[2] = tbk[5] - (k < NJ ? gtau[k] : 0.0f);
+            mat_vec(J, x, ub + 3);                                // ubar.ang
+            mat_vec(J, tbk, ub);
+            sub_cross(ub, ub + 3, t);                             // ubar.lin = J tbar.lin - ubar.ang x t
         }
-        const float zero6[6] = {0, 0, 0, 0, 0, 0};
-        LinkAdjoint A;
-        rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, tb[k], par, mb,
-                          k > 0 ? tb[k - 1] : zero6, tot[k], k > 0, A);
-        if (k < NJ) {
-            const float gtk = gtau[k];
-            if (want_gq) {
-                float gq = 0.0f;
+        // total force of the sub-tree at this link: its own body force (from the recovered motion) + what came up
+        float tot[6];
+        {
+            Motion M;
+            motion_from_floats(mo, M);
+            Force f;
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, f);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) gq += A.Jb[r * 3 + 0] * J[r * 3 + 1] - A.Jb[r * 3 + 1] * J[r * 3 + 0];
-                gout(k, gq, A.wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), A.ajb);
-            }
+            for (int i = 0; i < 3; ++i) { tot[i] = f.la[i][0] + carry[i]; tot[3 + i] = f.la[i][1] + carry[3 + i]; }
         }
+        LinkAdjoint A;
+        rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, tbk, par, mb, ub, tot, k > 0, A,
+                          false, (param_mask >> k) & 1u);
+        if (k < NJ && want_gq) gout(k, A.gq, A.wjb + (damping ? of[DRM_OPF_DAMP] * gtau[k] : 0.0f), A.ajb);
         if ((param_mask >> k) & 1u) {
             const float c_ = k < NJ ? cs[k] : 1.0f, s_ = k < NJ ? sn[k] : 0.0f;
             float gr[DRM_OPF_STRIDE];
@@ -1375,8 +1357,18 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t pa
             gr[DRM_OPF_DAMP] = (damping && k < NJ) ? gtau[k < NJ ? k : 0] * qd[k < NJ ? k : 0] : 0.0f;
             param_out(k, gr);
         }
+        if (k > 0) { // the sub-tree's force in the parent's frame: lin = J f, ang = J n + t x (J f)
+            float up[6];
+            mat_vec(J, tot, up);
+            mat_vec(J, tot + 3, up + 3);
+            add_cross(up + 3, t, up);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) carry[i] = up[i];
+        }
 #pragma unroll
         for (int i = 0; i < 12; ++i) { mb[i] = A.pb[i]; mo[i] = par[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tbk[i] = ub[i];
     }
 }
 
