@@ -772,8 +772,16 @@ DRM_HD void motion_step(const float *J, const float *t, float wj, float aj, bool
 
 // body force f = I a + v x* (I v)  (robot_model.py:289-293, spatial_vector_algebra.py:321-338, 215-224)
 // pairs: (h, g) = (I v, I a):  lin = m (v, a) - mc x (w, al) ;  ang = Io (w, al) + mc x (v, a)
+DRM_HD void rnea_body_force_hg(float m, const float *mc, const float *Io, const Motion &N, Force &out, f2 (&hgl)[3],
+                               f2 (&hga)[3]);
 DRM_HD void rnea_body_force(float m, const float *mc, const float *Io, const Motion &N, Force &out) {
-    f2 x[3], hgl[3], hga[3], y[3];
+    f2 hgl[3], hga[3];
+    rnea_body_force_hg(m, mc, Io, N, out, hgl, hga);
+}
+// ... also handing out the momentum-like pairs (h, g).lin = hgl, (h, g).ang = hga (the packed adjoint needs h again)
+DRM_HD void rnea_body_force_hg(float m, const float *mc, const float *Io, const Motion &N, Force &out, f2 (&hgl)[3],
+                               f2 (&hga)[3]) {
+    f2 x[3], y[3];
     cross3_sp(mc, N.wa, x);
 #pragma unroll
     for (int i = 0; i < 3; ++i) hgl[i] = f2_bcast(m) * N.va[i] - x[i];
@@ -1041,6 +1049,128 @@ DRM_HD void rnea_link_adjoint(float m, const float *mc, const float *Io, const f
     out.gq = gq;
 }
 
+// ---------------------------------------------------------------------------
+// The same adjoint on PACKED pairs, for the straight-line arm form (rnea_backward_chain): the forward sweeps pair
+// velocity- with acceleration-like quantities, (w, al), (v, a), because both go through the same linear maps — and so do
+// their adjoints, (wb, alb), (vb, ab), and the adjoints of the momentum-like pairs (h, g): X = (hlb, fl), Y = (hab, fa).
+// Every product with J, Io, mc x and t x below handles both halves at once; what stays scalar are the products of two
+// per-sample vectors (the crosses with w, v, fl, fa) and the closed-form dL/dq terms.
+//   M   the link's motion,  Pm  its parent's,  T[i] = (tbar.lin_i, tbar.ang_i),  tot = the sub-tree's total force
+//   hgl / hga   the (h, g) pairs of the link's body force (rnea_body_force_hg)
+//   B   in: motion adjoint arriving from the children; out: the link's full motion adjoint (the extras read it)
+//   pb  motion adjoint handed to the parent;  YV = (J vb, J ab) pairs, kept for the extras
+// ---------------------------------------------------------------------------
+struct LinkAdjointP {
+    Motion pb;
+    f2 YV[3];
+    float hlb[3], hab[3], wjb, ajb, gq;
+};
+DRM_HD void rnea_link_adjoint_packed(float m, const float *mc, const float *Io, const float *J, const float *t, float wj,
+                                     const Motion &M, const f2 (&hgl)[3], const f2 (&hga)[3], const f2 (&T)[3],
+                                     const Force &tot, bool has_parent, Motion &B, LinkAdjointP &out) {
+    const float w[3] = {M.wa[0][0], M.wa[1][0], M.wa[2][0]}, v[3] = {M.va[0][0], M.va[1][0], M.va[2][0]};
+    const float al[3] = {M.wa[0][1], M.wa[1][1], M.wa[2][1]}, a[3] = {M.va[0][1], M.va[1][1], M.va[2][1]};
+    const float fl[3] = {T[0][0], T[1][0], T[2][0]}, fa[3] = {T[0][1], T[1][1], T[2][1]};
+    const float hl[3] = {hgl[0][0], hgl[1][0], hgl[2][0]}, ha[3] = {hga[0][0], hga[1][0], hga[2][0]};
+    // f.lin = gl + w x hl,  f.ang = ga + w x ha + v x hl:  adjoints of h, and of (w, v) through the crosses
+    float *hlb = out.hlb, *hab = out.hab, xw[3] = {0, 0, 0}, xv[3];
+    cross3(fl, w, hlb); add_cross(hlb, fa, v);
+    cross3(fa, w, hab);
+    add_cross(xw, hl, fl); add_cross(xw, ha, fa);
+    cross3(hl, fa, xv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { B.wa[i][0] += xw[i]; B.va[i][0] += xv[i]; }
+    // (hl, gl) = m (v, a) - mc x (w, al);  (ha, ga) = Io (w, al) + mc x (v, a)
+    f2 X[3], Y[3], c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { X[i] = f2_make(hlb[i], fl[i]); Y[i] = f2_make(hab[i], fa[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.va[i] += f2_bcast(m) * X[i];
+    cross3_ps(X, mc, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.wa[i] -= c[i];
+    matT_vec_p(Io, Y, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.wa[i] += c[i];
+    cross3_ps(Y, mc, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.va[i] += c[i];
+    // the link's motion from its parent's (revolute joint about +z):
+    //   (w, al) = J^T (Pw, Pal) + (wj, aj) e_z + (0, (w_y wj, -w_x wj, 0));  (v, a) = J^T ((Pv, Pa) + (Pw, Pal) x t) + (0, (v_y wj, -v_x wj, 0))
+    const float ab0 = B.va[0][1], ab1 = B.va[1][1], alb0 = B.wa[0][1], alb1 = B.wa[1][1];
+    float gq = ab0 * (a[1] + v[0] * wj) - ab1 * (a[0] - v[1] * wj) + alb0 * (al[1] + w[0] * wj) - alb1 * (al[0] - w[1] * wj);
+    float wjb = ab0 * v[1] - ab1 * v[0] + alb0 * w[1] - alb1 * w[0];
+    B.va[1][0] += ab0 * wj; B.va[0][0] -= ab1 * wj;
+    B.wa[1][0] += alb0 * wj; B.wa[0][0] -= alb1 * wj;
+    gq += B.va[0][0] * v[1] - B.va[1][0] * v[0] + B.wa[0][0] * w[1] - B.wa[1][0] * w[0];
+    wjb += B.wa[2][0];
+    out.ajb = B.wa[2][1];
+    mat_vec_p(J, B.va, out.YV);                 // (J vb, J ab) = (Pvb, Pab)
+    cross3_sp(t, out.YV, out.pb.wa);            // (t x J vb, t x J ab) into (Pwb, Palb)
+    mat_vec_p(J, B.wa, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { out.pb.wa[i] += c[i]; out.pb.va[i] = out.YV[i]; }
+    if (has_parent) { // the force transform of the backward sweep (see rnea_link_adjoint)
+        const f2 d = tot.la[0] * T[1] - tot.la[1] * T[0];
+        gq += d[0] + d[1];
+    }
+    out.wjb = wjb;
+    out.gq = gq;
+}
+// The adjoints of a LEARNABLE link's constants, from what rnea_link_adjoint_packed left (cold path: a few links at most):
+// the op row's gradient gr[DRM_OPF_STRIDE] apart from the damping entry.  ub = the parent's tbar (lin, ang).
+DRM_HD void rnea_link_param_adjoint(float m, const float *mc, const float *Io, const float *J, const float *t, float c_, float s_,
+                                    const Motion &M, const Motion &Pm, const f2 (&T)[3], const float *ub, const Force &tot,
+                                    bool has_parent, const Motion &B, const LinkAdjointP &A, float *gr) {
+    const float w[3] = {M.wa[0][0], M.wa[1][0], M.wa[2][0]}, v[3] = {M.va[0][0], M.va[1][0], M.va[2][0]};
+    const float al[3] = {M.wa[0][1], M.wa[1][1], M.wa[2][1]}, a[3] = {M.va[0][1], M.va[1][1], M.va[2][1]};
+    const float Pw[3] = {Pm.wa[0][0], Pm.wa[1][0], Pm.wa[2][0]}, Pv[3] = {Pm.va[0][0], Pm.va[1][0], Pm.va[2][0]};
+    const float Pal[3] = {Pm.wa[0][1], Pm.wa[1][1], Pm.wa[2][1]}, Pa[3] = {Pm.va[0][1], Pm.va[1][1], Pm.va[2][1]};
+    const float fl[3] = {T[0][0], T[1][0], T[2][0]}, fa[3] = {T[0][1], T[1][1], T[2][1]};
+    const float wb[3] = {B.wa[0][0], B.wa[1][0], B.wa[2][0]}, vb[3] = {B.va[0][0], B.va[1][0], B.va[2][0]};
+    const float alb[3] = {B.wa[0][1], B.wa[1][1], B.wa[2][1]}, ab[3] = {B.va[0][1], B.va[1][1], B.va[2][1]};
+    const float yv[3] = {A.YV[0][0], A.YV[1][0], A.YV[2][0]}, ya[3] = {A.YV[0][1], A.YV[1][1], A.YV[2][1]}; // J vb, J ab
+    const float tl[3] = {tot.la[0][0], tot.la[1][0], tot.la[2][0]}, ta[3] = {tot.la[0][1], tot.la[1][1], tot.la[2][1]};
+    const float *hlb = A.hlb, *hab = A.hab;
+#pragma unroll
+    for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+    gr[DRM_OPF_MASS] = hlb[0] * v[0] + hlb[1] * v[1] + hlb[2] * v[2] + fl[0] * a[0] + fl[1] * a[1] + fl[2] * a[2];
+    float gmc[3] = {0, 0, 0};
+    sub_cross(gmc, w, hlb); add_cross(gmc, v, hab); sub_cross(gmc, al, fl); add_cross(gmc, a, fa);
+    float Jb[9], tbr[3], y1[3], y2[3];
+    y1[0] = Pa[0]; y1[1] = Pa[1]; y1[2] = Pa[2];
+    add_cross(y1, Pal, t);
+    y2[0] = Pv[0]; y2[1] = Pv[1]; y2[2] = Pv[2];
+    add_cross(y2, Pw, t);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) Jb[r * 3 + cc] = y1[r] * ab[cc] + Pal[r] * alb[cc] + y2[r] * vb[cc] + Pw[r] * wb[cc];
+    cross3(ya, Pal, tbr);
+    add_cross(tbr, yv, Pw);
+    if (has_parent) {
+        float Lb[3], L[3];
+        Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
+        add_cross(Lb, ub + 3, t);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) Jb[r * 3 + cc] += Lb[r] * tl[cc] + ub[3 + r] * ta[cc];
+        mat_vec(J, tl, L);
+        add_cross(tbr, L, ub + 3);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * c_ - Jb[r * 3 + 1] * s_;
+        gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * s_ + Jb[r * 3 + 1] * c_;
+        gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2];
+        gr[DRM_OPF_TI(r)] = tbr[r];
+        gr[DRM_OPF_MCOM + r] = gmc[r];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) gr[DRM_OPF_IO + r * 3 + cc] = hab[r] * w[cc] + fa[r] * al[cc];
+    }
+}
+
 // The sweeps are LOOPS over the n_ops links of the walk (no identity padding, one control word decoded per
 // iteration, nothing indexed by a compile-time op number): the adjoint of one link is ~700 instructions, so a
 // straight-line walk of 24 or 32 links neither fits the instruction cache nor the register file.
@@ -1261,36 +1391,34 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t pa
         t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
     };
     // ---- A: motions up the chain (only the tip's is kept);  C: adjoints of the total forces, likewise ------------
-    float mo[12], tbk[6];
-    {
-        Motion cur;
-        motion_root(cur, g);
+    // T[i] = (tbar.lin_i, tbar.ang_i): both halves go through J^T together
+    Motion M;
+    f2 T[3];
+    motion_root(M, g);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) tbk[i] = 0.0f;
+    for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
 #pragma unroll
-        for (int k = 0; k < CAP; ++k) {
-            float J[9], t[3];
-            joint(k, J, t);
-            rnea_link_motion(J, t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, cur, cur);
-            if (k > 0) { // tbar_k = (J^T (ubar.lin + ubar.ang x t), J^T ubar.ang), ubar = tbar_(k-1)
-                float Lb[3], nx[6];
-                Lb[0] = tbk[0]; Lb[1] = tbk[1]; Lb[2] = tbk[2];
-                add_cross(Lb, tbk + 3, t);
-                matT_vec(J, Lb, nx);
-                matT_vec(J, tbk + 3, nx + 3);
+    for (int k = 0; k < CAP; ++k) {
+        float J[9], t[3];
+        joint(k, J, t);
+        rnea_link_motion(J, t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, M, M);
+        if (k > 0) { // tbar_k = (J^T (ubar.lin + ubar.ang x t), J^T ubar.ang), ubar = tbar_(k-1)
+            const float ua[3] = {T[0][1], T[1][1], T[2][1]};
+            f2 x[3] = {T[0], T[1], T[2]}, y[3];
+            x[0][0] += ua[1] * t[2] - ua[2] * t[1];
+            x[1][0] += ua[2] * t[0] - ua[0] * t[2];
+            x[2][0] += ua[0] * t[1] - ua[1] * t[0];
+            matT_vec_p(J, x, y);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) tbk[i] = nx[i];
-            }
-            if (k < NJ) tbk[5] += gtau[k];
+            for (int i = 0; i < 3; ++i) T[i] = y[i];
         }
-        motion_to_floats(cur, mo);
+        if (k < NJ) T[2][1] += gtau[k];
     }
     // ---- D (with B): back to the root ----------------------------------------------------------------------------
-    float mb[12], carry[6];
+    Motion B;      // motion adjoint: B.wa = (wb, alb), B.va = (vb, ab)
+    Force carry;   // total force of the links below, in this link's frame
 #pragma unroll
-    for (int i = 0; i < 12; ++i) mb[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) carry[i] = 0.0f;
+    for (int i = 0; i < 3; ++i) { B.wa[i] = f2_bcast(0.0f); B.va[i] = f2_bcast(0.0f); carry.la[i] = f2_bcast(0.0f); }
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
         const float *of = row(k);
@@ -1298,77 +1426,53 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t pa
         joint(k, J, t);
         const float wj = k < NJ ? qd[k] : 0.0f, aj = k < NJ ? qdd[k] : 0.0f;
         // parent's motion and force adjoint from this link's (inverses of rnea_link_motion / of sweep C; J is orthogonal)
-        float par[12], ub[6];
+        Motion Pm;
+        f2 U[3];
         if (k == 0) {
+            motion_root(Pm, g);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) par[i] = 0.0f;
-            par[11] = g;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ub[i] = 0.0f;
+            for (int i = 0; i < 3; ++i) U[i] = f2_bcast(0.0f);
         } else {
-            const float *w = mo, *v = mo + 3, *al = mo + 6, *a = mo + 9;
-            float x[3], y[3];
-            x[0] = w[0]; x[1] = w[1]; x[2] = w[2] - wj;
-            mat_vec(J, x, par);                                   // w_p
-            mat_vec(J, v, y);
-            sub_cross(y, par, t);                                 // v_p = J v - w_p x t
-            par[3] = y[0]; par[4] = y[1]; par[5] = y[2];
-            x[0] = al[0] - w[1] * wj; x[1] = al[1] + w[0] * wj; x[2] = al[2] - aj;
-            mat_vec(J, x, par + 6);                               // al_p
-            x[0] = a[0] - v[1] * wj; x[1] = a[1] + v[0] * wj; x[2] = a[2];
-            mat_vec(J, x, y);
-            sub_cross(y, par + 6, t);                             // a_p = J (a - v x wj e_z) - al_p x t
-            par[9] = y[0]; par[10] = y[1]; par[11] = y[2];
-            x[0] = tbk[3]; x[1] = tbk[4]; x[2] = tbk[5] - (k < NJ ? gtau[k] : 0.0f);
-            mat_vec(J, x, ub + 3);                                // ubar.ang
-            mat_vec(J, tbk, ub);
-            sub_cross(ub, ub + 3, t);                             // ubar.lin = J tbar.lin - ubar.ang x t
+            const float w0 = M.wa[0][0], w1 = M.wa[1][0], v0 = M.va[0][0], v1 = M.va[1][0];
+            f2 x[3] = {M.wa[0], M.wa[1], M.wa[2]}, y[3], c[3];
+            x[0][1] -= w1 * wj; x[1][1] += w0 * wj; x[2] -= f2_make(wj, aj);
+            mat_vec_p(J, x, Pm.wa);                               // (w_p, al_p) = J ((w, al) - joint terms)
+            x[0] = M.va[0]; x[1] = M.va[1]; x[2] = M.va[2];
+            x[0][1] -= v1 * wj; x[1][1] += v0 * wj;
+            mat_vec_p(J, x, y);
+            cross3_ps(Pm.wa, t, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Pm.va[i] = y[i] - c[i];   // (v_p, a_p) = J (...) - (w_p, al_p) x t
+            x[0] = T[0]; x[1] = T[1]; x[2] = T[2];
+            if (k < NJ) x[2][1] -= gtau[k];
+            mat_vec_p(J, x, U);                                   // (J tbar.lin, ubar.ang)
+            const float ua[3] = {U[0][1], U[1][1], U[2][1]};
+            U[0][0] -= ua[1] * t[2] - ua[2] * t[1];               // ubar.lin = J tbar.lin - ubar.ang x t
+            U[1][0] -= ua[2] * t[0] - ua[0] * t[2];
+            U[2][0] -= ua[0] * t[1] - ua[1] * t[0];
         }
         // total force of the sub-tree at this link: its own body force (from the recovered motion) + what came up
-        float tot[6];
-        {
-            Motion M;
-            motion_from_floats(mo, M);
-            Force f;
-            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, f);
+        Force tot;
+        f2 hgl[3], hga[3];
+        rnea_body_force_hg(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, tot, hgl, hga);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { tot[i] = f.la[i][0] + carry[i]; tot[3 + i] = f.la[i][1] + carry[3 + i]; }
-        }
-        LinkAdjoint A;
-        rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, tbk, par, mb, ub, tot, k > 0, A,
-                          false, (param_mask >> k) & 1u);
+        for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+        LinkAdjointP A;
+        rnea_link_adjoint_packed(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, M, hgl, hga, T, tot, k > 0, B, A);
         if (k < NJ && want_gq) gout(k, A.gq, A.wjb + (damping ? of[DRM_OPF_DAMP] * gtau[k] : 0.0f), A.ajb);
         if ((param_mask >> k) & 1u) {
-            const float c_ = k < NJ ? cs[k] : 1.0f, s_ = k < NJ ? sn[k] : 0.0f;
             float gr[DRM_OPF_STRIDE];
-#pragma unroll
-            for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                gr[DRM_OPF_FIJ(r, 0)] = A.Jb[r * 3 + 0] * c_ - A.Jb[r * 3 + 1] * s_;
-                gr[DRM_OPF_FIJ(r, 1)] = A.Jb[r * 3 + 0] * s_ + A.Jb[r * 3 + 1] * c_;
-                gr[DRM_OPF_FIJ(r, 2)] = A.Jb[r * 3 + 2];
-                gr[DRM_OPF_TI(r)] = A.tb[r];
-                gr[DRM_OPF_MCOM + r] = A.gmc[r];
-            }
-            gr[DRM_OPF_MASS] = A.gm;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = A.gIo[i];
+            const float ub[6] = {U[0][0], U[1][0], U[2][0], U[0][1], U[1][1], U[2][1]};
+            rnea_link_param_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, k < NJ ? cs[k] : 1.0f,
+                                    k < NJ ? sn[k] : 0.0f, M, Pm, T, ub, tot, k > 0, B, A, gr);
             gr[DRM_OPF_DAMP] = (damping && k < NJ) ? gtau[k < NJ ? k : 0] * qd[k < NJ ? k : 0] : 0.0f;
             param_out(k, gr);
         }
-        if (k > 0) { // the sub-tree's force in the parent's frame: lin = J f, ang = J n + t x (J f)
-            float up[6];
-            mat_vec(J, tot, up);
-            mat_vec(J, tot + 3, up + 3);
-            add_cross(up + 3, t, up);
+        if (k > 0) rnea_link_force_up(J, t, tot, carry); // the sub-tree's force in the parent's frame
+        B = A.pb;
+        M = Pm;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) carry[i] = up[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { mb[i] = A.pb[i]; mo[i] = par[i]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) tbk[i] = ub[i];
+        for (int i = 0; i < 3; ++i) T[i] = U[i];
     }
 }
 
