@@ -172,6 +172,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+    // ONE learnable link (the common case: system identification of a payload or of one link): its 26 constant gradients
+    // are summed per LANE over this wave's tiles and reduced across the wave once at the end — 26 adds per tile instead of
+    // 26 DPP reductions (230 VALU).  Several learnable links keep the per-tile reduction (a register set each would not fit).
+    const bool single = __builtin_popcount(param_mask) == 1;
+    const int single_k = single ? __builtin_ctz(param_mask) : 0;
+    float psum[DRM_OPF_DAMP + 1];
+#pragma unroll
+    for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) psum[j] = 0.0f;
 
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
@@ -200,6 +208,11 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                 lq[lane * NJ + d] = a; lqd[lane * NJ + d] = v; lqdd[lane * NJ + d] = c;
             },
             [&](int k, const float *g) {
+                if (single) {
+#pragma unroll
+                    for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) psum[j] += g[j];
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
                     const float total = wave_sum_lane63(g[j]);
@@ -215,6 +228,17 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             tile_store<NJ>(gq + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
             tile_store<NJ>(gqd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
             tile_store<NJ>(gqdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
+        }
+    }
+    if (single) {
+#pragma unroll
+        for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+            const float total = wave_sum_lane63(psum[j]);
+            const int idx = single_k * DRM_OPF_STRIDE + j;
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, total), 63));
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+                if (idx / WAVE == a && lane == (unsigned)(idx % WAVE)) acc[a] = s;
         }
     }
     float *prow = partials + (int64_t)wave_id * NV;
