@@ -146,7 +146,8 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures (multi-rank runs)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(K):
                     launch()
             for _ in range(warm_replays):   # untimed: uploads the executable graph, lets the clocks settle
