@@ -17,7 +17,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 RNEA_GRAVITY, RNEA_DAMPING, FD_REFINE = 1, 2, 4
 

@@ -9,23 +9,27 @@
 //
 // Per sample: in q, qd, qdd, grad_tau [n]; out grad_q, grad_qd, grad_qdd [n] (optional).      n = 7: 112 + 84 B
 // Per launch: out grad_ops_f[cap, 32] (every constant of the ops selected by param_mask, zeros elsewhere).
-// Per-link records (26 floats: motion, total force, its adjoint, cos / sin of the joint angle) are parked between
-// the sweeps in LDS, or, when a big walk does not fit, in a slice of the caller's scratch buffer in HBM (PARK_HBM).
-// LDS per wave: [ q qd qdd grad_tau : 4 x 64 (n|1) ][ grad_q grad_qd grad_qdd : 3 x 64 (n|1) ]
-//               [ constant-gradient sums : cap*32 ][ slots : n_slots*36*64 ][ records : cap*26*64 unless PARK_HBM ]
+// Between the two sweeps every link keeps (cos, sin) of its joint angle and every LEAF link its motion and force adjoint
+// (2 + 18 floats, drm_sample.hpp rnea_backward_walk) in LDS, or, when a big walk does not fit, in a slice of the caller's
+// scratch buffer in HBM (PARK_HBM).  The input tiles double as the gradient tiles (a DoF's q, qd, qdd are last read by
+// the op that then writes its gradients).
+// LDS per wave: [ q -> grad_q, qd -> grad_qd, qdd -> grad_qdd, grad_tau : 4 x 64 (n|1) ][ constant-gradient sums : cap*32 ]
+//               [ slots : n_slots*36*64 ][ records : (n_ops*2 + n_leaves*18)*64 unless PARK_HBM ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
 namespace drm {
 
-constexpr int REC_FLOATS = 26, SLOT_FLOATS = 36;
+constexpr int REC_FLOATS = 26, SLOT_FLOATS = 36; // (REC_FLOATS: the conservative per-op figure of the scratch query)
+constexpr int TRIG_FLOATS = 2, LEAF_FLOATS = 18;
+__host__ __device__ static inline int record_floats(int n_ops, int n_leaves) { return (n_ops * TRIG_FLOATS + n_leaves * LEAF_FLOATS) * WAVE; }
 
 // One kernel for every walk: the sweeps loop over the n_ops links (drm_sample.hpp rnea_backward_walk), so neither the
 // code nor the register file grows with the robot; `cap` only fixes the row pitch of grad_ops_f / the partial sums.
 template <bool PARK_HBM>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
-    rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n,
-                         int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+    rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n_leaves,
+                         int n, int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
                          const float *__restrict__ qdd, const float *__restrict__ gtau, int64_t B, float *__restrict__ gq,
                          float *__restrict__ gqd, float *__restrict__ gqdd, uint32_t param_mask,
                          float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q, int lds_per_wave,
@@ -42,11 +46,12 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     const int Sq = pad_odd(n), region = round4(WAVE * Sq);
     float *lq = smem + wave_in_block * lds_per_wave;
     float *lqd = lq + region, *lqdd = lqd + region, *lgt = lqdd + region;
-    float *lgq = lgt + region, *lgqd = lgq + region, *lgqdd = lgqd + region;
-    float *lacc = lgqdd + region;                                  // this wave's running sums of the constant gradients
+    float *lgq = lq, *lgqd = lqd, *lgqdd = lqdd;                   // gradients over the inputs (see the header comment)
+    float *lacc = lgt + region;                                    // this wave's running sums of the constant gradients
     float *lsl = lacc + NV;                                        // slots   [slot][36][64]
-    float *lrec = lsl + n_slots * (SLOT_FLOATS * WAVE);            // records [op][26][64]
-    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)cap * (REC_FLOATS * WAVE) : lrec) + lane;
+    float *lrec = lsl + n_slots * (SLOT_FLOATS * WAVE);            // records: [op][2][64] trig, then [leaf][18][64]
+    float *rec = (PARK_HBM ? park_hbm + wave_id * (int64_t)record_floats(n_ops, n_leaves) : lrec) + lane;
+    float *rec_leaf = rec + n_ops * (TRIG_FLOATS * WAVE);
     float *slot = lsl + lane;
     const int32_t *ctl = ops_i + DRM_OPI_CTRL * cap;
 
@@ -68,22 +73,27 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
         const unsigned row = lane * Sq;
         const bool has_qdd = qdd != nullptr;
-        if (gq)
-            for (int d = 0; d < n; ++d) { lgq[row + d] = 0.0f; lgqd[row + d] = 0.0f; lgqdd[row + d] = 0.0f; }
         auto qf = [&](int d, float &a, float &v, float &c) {
             a = live ? lq[row + d] : 0.0f; // zeros, not stale LDS, past a partial tile
             v = lqd[row + d];
             c = has_qdd ? lqdd[row + d] : 0.0f;
         };
         auto gt = [&](int d) -> float { return live ? lgt[row + d] : 0.0f; };
+        // record of op k: offset 24 = (cos, sin) of every op; offsets 0 (motion, 12) and 18 (tbar, 6) of LEAF ops only, at
+        // the leaf's ordinal (bits 26..31 of the control word)
+        auto where = [&](int k, int off) -> float * {
+            if (off == 24) return rec + k * (TRIG_FLOATS * WAVE);
+            const int leaf = (int)(((uint32_t)ctl[k]) >> 26);
+            return rec_leaf + (leaf * LEAF_FLOATS + (off == 0 ? 0 : 12)) * WAVE;
+        };
         auto park = [&](int k, int off, const float *v, int cnt) {
-            float *r = rec + (k * REC_FLOATS + off) * WAVE;
+            float *r = where(k, off);
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 if (i < cnt) r[i * WAVE] = v[i];
         };
         auto unpark = [&](int k, int off, float *v, int cnt) {
-            const float *r = rec + (k * REC_FLOATS + off) * WAVE;
+            const float *r = where(k, off);
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 if (i < cnt) v[i] = r[i * WAVE];
@@ -246,9 +256,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
 }
 
-static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, bool park_hbm) {
-    return (size_t)7 * round4(WAVE * pad_odd(n)) + (size_t)cap * DRM_OPF_STRIDE + (size_t)n_slots * SLOT_FLOATS * WAVE +
-           (park_hbm ? 0 : (size_t)cap * REC_FLOATS * WAVE);
+static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, int n_ops, int n_leaves, bool park_hbm) {
+    return (size_t)4 * round4(WAVE * pad_odd(n)) + (size_t)cap * DRM_OPF_STRIDE + (size_t)n_slots * SLOT_FLOATS * WAVE +
+           (park_hbm ? 0 : (size_t)record_floats(n_ops, n_leaves));
 }
 
 } // namespace drm
@@ -259,8 +269,9 @@ extern "C" int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity,
     if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS || n_dofs < 1 || n_dofs > DRM_MAX_DOFS) return 0;
     const int64_t waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
     int64_t floats = (waves + MAX_WAVES_PER_BLOCK) * capacity * DRM_OPF_STRIDE; // partial sums (+ a ragged tail's row)
-    if (rnea_backward_lds_floats(n_dofs, n_slots, capacity, false) * sizeof(float) > (size_t)MAX_LDS_BYTES)
-        floats += waves * (int64_t)capacity * REC_FLOATS * WAVE; // per-link records parked in HBM
+    // records parked in HBM when they do not fit LDS; sized for the worst case (every op a leaf): the query does not see the walk
+    if (rnea_backward_lds_floats(n_dofs, n_slots, capacity, capacity, capacity, false) * sizeof(float) > (size_t)MAX_LDS_BYTES)
+        floats += waves * (int64_t)capacity * REC_FLOATS * WAVE;
     return floats;
 }
 
@@ -279,7 +290,9 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
     if (!want_q && !grad_ops_f) return fail(DRM_ERR_INVALID, "nothing to compute");
     if (!scratch) return fail(DRM_ERR_INVALID, "scratch must not be NULL (drm_rnea_backward_scratch_floats)");
     if (w->capacity < 32 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
-    const int n = w->n_dofs, cap = w->capacity;
+    const int n = w->n_dofs, cap = w->capacity, n_leaves = DRM_WALK_LEAVES(w->shape);
+    if (w->n_ops > 0 && (n_leaves < 1 || n_leaves > w->n_ops || n_leaves > 64))
+        return fail(DRM_ERR_INVALID, "walk without its leaf count (drm_walk.shape bits 16..23; host built for an older ABI?)");
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
         if (grad_ops_f) {
@@ -314,7 +327,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
             if (done < B) {
                 // tail: < 64 rows, one wave, through the generic kernel (LDS parking: an arm always fits)
                 Geometry gt;
-                rc = make_geometry(B - done, (int)rnea_backward_lds_floats(n, w->n_slots, cap, false), gt);
+                rc = make_geometry(B - done, (int)rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, false), gt);
                 if (rc) return rc;
                 gt.grid = dim3(1);
                 gt.block = dim3(WAVE);
@@ -323,7 +336,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
                 if (rc) return rc;
                 const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU);
                 hipLaunchKernelGGL((rnea_backward_kernel<false>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i,
-                                   cap, (int)w->n_ops, n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
+                                   cap, (int)w->n_ops, n_leaves, n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
                                    qdd ? qdd + done * n : nullptr, grad_tau + done * n, B - done,
                                    grad_q ? grad_q + done * n : nullptr, grad_qd ? grad_qd + done * n : nullptr,
                                    grad_qdd ? grad_qdd + done * n : nullptr, param_mask,
@@ -342,9 +355,9 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         }
     }
 #endif
-    const bool park_hbm = rnea_backward_lds_floats(n, w->n_slots, cap, false) * sizeof(float) > (size_t)MAX_LDS_BYTES;
+    const bool park_hbm = rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, false) * sizeof(float) > (size_t)MAX_LDS_BYTES;
     Geometry g;
-    rc = make_geometry(B, (int)rnea_backward_lds_floats(n, w->n_slots, cap, park_hbm), g);
+    rc = make_geometry(B, (int)rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, park_hbm), g);
     if (rc) return rc;
     const int wpb = (int)(g.block.x / WAVE);
     const int waves = backward_waves(B, wpb);
@@ -357,7 +370,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         rc = ensure_lds(rnea_backward_kernel<HBM>, g.lds_bytes);                                                       \
         if (rc) return rc;                                                                                             \
         hipLaunchKernelGGL((rnea_backward_kernel<HBM>), g.grid, g.block, g.lds_bytes, s, w->ops_f, w->ops_i, cap,      \
-                           (int)w->n_ops, n, (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd,    \
+                           (int)w->n_ops, n_leaves, n, (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd,    \
                            grad_qdd, param_mask, partials, park, div_magic(n), g.lds_per_wave, align);                 \
     }
     if (park_hbm) DRM_LAUNCH_RB(true) else DRM_LAUNCH_RB(false)

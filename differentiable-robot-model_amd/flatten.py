@@ -491,6 +491,15 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                           | ((ops_i[:, OPI_PERM] & 7) << 20) | ((ops_i[:, OPI_FLAGS] & 1) << 23))
     ops_i[n_ops:, OPI_CTRL] |= 1 << 24
     ops_i[:, OPI_CTRL] |= (pris_arr << 25).astype(np.int32)
+    # bits 26..31: ordinal of a LEAF op (no child follows it in the walk) among the leaves — the loop-structured RNEA backward
+    # kernel parks a motion / force-adjoint record per leaf only (drm_sample.hpp rnea_backward_walk)
+    n_leaves = 0
+    leaf_ord = np.zeros(cap, np.int64)
+    for k in range(n_ops):
+        if not (ops_i[k, OPI_FLAGS] & FLAG_CHILD_IS_NEXT):
+            leaf_ord[k] = n_leaves & 63
+            n_leaves += 1
+    ops_i[:, OPI_CTRL] = ((ops_i[:, OPI_CTRL].astype(np.int64) & 0x3ffffff) | (leaf_ord << 26)).astype(np.uint32).view(np.int32)
     # ... and the two wide control words of the loop-structured forward kernels (DRM_W0_PACK / DRM_W1_PACK)
     i64 = lambda col: ops_i[:, col].astype(np.int64)
     w0 = (((i64(OPI_DOF) + 1) & 0xff) | (((i64(OPI_SRC) + 2) & 0xff) << 8) | (((i64(OPI_SAVE) + 1) & 0xff) << 16)
@@ -510,7 +519,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     branch_depth = min(255, max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0))
     prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
-                       max_used, cap, tlist, mask, unique, (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8),
+                       max_used, cap, tlist, mask, unique,
+                       (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8) | (min(n_leaves, 255) << 16),
                        seg_begin, seg_dof, op_of_link, prefix_end)
 
 

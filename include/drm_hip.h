@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 4
+#define DRM_ABI_VERSION 5
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -67,6 +67,7 @@ extern "C" {
                                bit  23     DRM_FLAG_CHILD_IS_NEXT
                                bit  24     identity padding op (kernels may skip it)
                                bit  25     prismatic joint (slides along +z of the stored frame by q)
+                               bits 26..31 ordinal of a LEAF op (no child follows it in the walk) among the walk's leaves
                              The unpacked fields below stay in the table for hosts and debuggers       */
 #define DRM_OPI_CTRL_PACK(dof, src, save, out, perm, flags)                                                       \
     ((((dof) + 1) & 0x7f) | ((((src) + 2) & 7) << 7) | ((((save) + 1) & 7) << 10) | ((((out) + 1) & 0x7f) << 13) | \
@@ -109,6 +110,7 @@ extern "C" {
 /* drm_walk.shape */
 #define DRM_WALK_ARM_CHAIN 1 /* a serial chain: ops 0..n_dofs-1 are moving joints driving DoF columns
                                 0..n_dofs-1 in order, every later op is a fixed joint or padding  */
+#define DRM_WALK_LEAVES(shape) (((shape) >> 16) & 0xff) /* number of leaf ops (ops no child follows), see DRM_OPI_CTRL */
 #define DRM_WALK_BRANCH_DEPTH(shape) (((shape) >> 8) & 0xff) /* 1 + the largest op index that is a branch
                                 point (0: none): sizes the per-ancestor slot records of drm_crba /
                                 drm_forward_dynamics                                               */
