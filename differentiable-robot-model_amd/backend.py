@@ -30,7 +30,7 @@ class DrmWalk(ctypes.Structure):
                 ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
-                ("prefix_end", ctypes.c_int32)]
+                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1))]
 
 
 class NativeLibraryError(RuntimeError):
@@ -148,6 +148,8 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     for i, (lo, cnt) in enumerate(prog.seg_dof):
         w.seg_dof_lo[i], w.seg_dof_cnt[i] = int(lo), int(cnt)
     w.prefix_end = int(prog.prefix_end)
+    for i, v in enumerate(prog.seg_leaf_begin):
+        w.seg_leaf_begin[i] = int(v)
     return w
 
 

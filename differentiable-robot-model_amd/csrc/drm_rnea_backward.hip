@@ -17,6 +17,7 @@
 //               [ slots : n_slots*36*64 ][ records : (n_ops*2 + n_leaves*18)*64 unless PARK_HBM ]
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                 if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wave's fixed order
             }
         };
-        rnea_backward_walk(ops_f, ctl, n_ops, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
+        rnea_backward_walk(ops_f, ctl, 0, 0, n_ops, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
                            slot_add, slot_take, gout, param_out);
         if (gq) {
             wave_lds_sync();
@@ -141,6 +142,127 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
     wave_lds_sync();
     float *prow = partials + wave_id * NV;
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
+}
+
+
+// The same walk FANNED OUT over the walk's segments (independent sub-trees hanging off the static prefix — the fingers of a
+// hand): a block owns one 64-sample tile at a time, wavefront s walks segment s (rnea_backward_walk replays the prefix for
+// it).  What one wavefront parks is a finger's worth (2 floats per op + 18 per leaf), so a hand fits LDS with eight
+// wavefronts per CU where the single-wavefront form, parking the whole tree, ran one or two.
+// Shared LDS: [ q -> grad_q, qd -> grad_qd, qdd -> grad_qdd, grad_tau ][ slots : n_slots*36*64 ]; the slots of prefix branch
+// points are written by every wavefront with the same values (their replay of the prefix) and only read afterwards; slots
+// inside a segment belong to that segment.  Per wavefront: [ constant-gradient sums : cap*32 ][ records ].
+// Not for launches that want the constant gradients of PREFIX ops (the host checks): nothing flows into the prefix here.
+struct FanArgs {
+    int32_t n_seg, p_end;
+    int32_t seg_begin[DRM_MAX_SEGMENTS + 1], leaf_begin[DRM_MAX_SEGMENTS + 1], wave_off[DRM_MAX_SEGMENTS];
+};
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    rnea_backward_fan_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, FanArgs fa, int cap, int n,
+                             int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                             const float *__restrict__ qdd, const float *__restrict__ gtau, int64_t B, float *__restrict__ gq,
+                             float *__restrict__ gqd, float *__restrict__ gqdd, uint32_t param_mask,
+                             float *__restrict__ partials, uint32_t magic_q, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NV = cap * DRM_OPF_STRIDE;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t n_tiles = (B + WAVE - 1) / WAVE;
+    const int Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem, *lqd = lq + region, *lqdd = lqd + region, *lgt = lqdd + region;
+    float *lsl = lgt + region;                                      // slots [slot][36][64], shared
+    float *lacc = smem + fa.wave_off[wave];                         // this wavefront's sums of the constant gradients
+    float *rec = lacc + NV + lane;                                  // its records: [op - a][2][64], then [leaf][18][64]
+    const int a = fa.seg_begin[wave], b = fa.seg_begin[wave + 1], leaf0 = fa.leaf_begin[wave];
+    float *rec_leaf = rec + (b - a) * (TRIG_FLOATS * WAVE);
+    float *slot = lsl + lane;
+    const int32_t *ctl = ops_i + DRM_OPI_CTRL * cap;
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * WAVE;
+        const int64_t left = B - b0;
+        const int rows = left < WAVE ? (int)left : WAVE;
+        const bool full = rows == WAVE, fast = full && (n & 1);
+        const bool live = (int)lane < rows;
+        __syncthreads(); // the previous tile's gradients have left, its slots are dead
+        if (wave == 0) tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q), full && (align & AL_Q));
+        if (wave == 1 % fa.n_seg) tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD), full && (align & AL_QD));
+        if (qdd && wave == 2 % fa.n_seg)
+            tile_load<0>(qdd + b0 * n, rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), full && (align & AL_QDD));
+        if (wave == 3 % fa.n_seg) tile_load<0>(gtau + b0 * n, rows, n, magic_q, lgt, lane, fast && (align & AL_TAU), full && (align & AL_TAU));
+        for (int s = wave; s < n_slots * SLOT_FLOATS; s += fa.n_seg) slot[s * WAVE] = 0.0f;
+        __syncthreads();
+
+        const unsigned row = lane * Sq;
+        const bool has_qdd = qdd != nullptr;
+        auto qf = [&](int d, float &x, float &v, float &c) {
+            x = live ? lq[row + d] : 0.0f; // zeros, not stale LDS, past a partial tile
+            v = lqd[row + d];
+            c = has_qdd ? lqdd[row + d] : 0.0f;
+        };
+        auto gt = [&](int d) -> float { return live ? lgt[row + d] : 0.0f; };
+        auto where = [&](int k, int off) -> float * {
+            if (off == 24) return rec + (k - a) * (TRIG_FLOATS * WAVE);
+            const int leaf = (int)(((uint32_t)ctl[k]) >> 26) - leaf0;
+            return rec_leaf + (leaf * LEAF_FLOATS + (off == 0 ? 0 : 12)) * WAVE;
+        };
+        auto park = [&](int k, int off, const float *v, int cnt) {
+            float *r = where(k, off);
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) r[i * WAVE] = v[i];
+        };
+        auto unpark = [&](int k, int off, float *v, int cnt) {
+            const float *r = where(k, off);
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) v[i] = r[i * WAVE];
+        };
+        auto slot_put = [&](int s, int off, const float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) slot[(s * SLOT_FLOATS + off + i) * WAVE] = v[i];
+        };
+        auto slot_get = [&](int s, int off, float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) v[i] = slot[(s * SLOT_FLOATS + off + i) * WAVE];
+        };
+        auto slot_add = [&](int s, int off, const float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) slot[(s * SLOT_FLOATS + off + i) * WAVE] += v[i];
+        };
+        auto slot_take = [&](int s, int off, float *v, int cnt) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < cnt) {
+                    v[i] = slot[(s * SLOT_FLOATS + off + i) * WAVE];
+                    slot[(s * SLOT_FLOATS + off + i) * WAVE] = 0.0f;
+                }
+        };
+        auto gout = [&](int d, float x, float v, float c) { lq[row + d] = x; lqd[row + d] = v; lqdd[row + d] = c; };
+        auto param_out = [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
+#pragma unroll
+            for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+                const float mine = live ? g[j] : 0.0f;
+                const float total = wave_sum_lane63(mine);
+                if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
+            }
+        };
+        rnea_backward_walk(ops_f, ctl, fa.p_end, a, b, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
+                           slot_add, slot_take, gout, param_out);
+        __syncthreads();
+        if (gq) {
+            if (wave == 0) tile_store<0>(gq + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_POS), full && (align & AL_POS));
+            if (wave == 1 % fa.n_seg) tile_store<0>(gqd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QUAT), full && (align & AL_QUAT));
+            if (wave == 2 % fa.n_seg) tile_store<0>(gqdd + b0 * n, rows, n, magic_q, lqdd, lane, fast && (align & AL_LIN), full && (align & AL_LIN));
+        }
+    }
+    wave_lds_sync();
+    float *prow = partials + ((int64_t)blockIdx.x * fa.n_seg + wave) * NV;
     for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
@@ -268,7 +390,11 @@ using namespace drm;
 extern "C" int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity, int32_t n_dofs, int32_t n_slots) {
     if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS || n_dofs < 1 || n_dofs > DRM_MAX_DOFS) return 0;
     const int64_t waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
-    int64_t floats = (waves + MAX_WAVES_PER_BLOCK) * capacity * DRM_OPF_STRIDE; // partial sums (+ a ragged tail's row)
+    // rows of partial sums: one per wavefront (+ a ragged tail's); the fanned-out launch has one per tile AND segment
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    int64_t rows = tiles * DRM_MAX_SEGMENTS < BWD_MAX_WAVES ? tiles * DRM_MAX_SEGMENTS : BWD_MAX_WAVES;
+    if (rows < waves) rows = waves;
+    int64_t floats = (rows + MAX_WAVES_PER_BLOCK) * capacity * DRM_OPF_STRIDE;
     // records parked in HBM when they do not fit LDS; sized for the worst case (every op a leaf): the query does not see the walk
     if (rnea_backward_lds_floats(n_dofs, n_slots, capacity, capacity, capacity, false) * sizeof(float) > (size_t)MAX_LDS_BYTES)
         floats += waves * (int64_t)capacity * REC_FLOATS * WAVE;
@@ -355,6 +481,48 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         }
     }
 #endif
+    // fanned out over the segments when the walk has several, none of the prefix ops is learnable and a block's LDS fits twice
+    // per CU or better than the single-wavefront form would
+    if (w->n_segments > 1 && segments_ok(w) && w->prefix_end < 32 && !(param_mask & ((1u << w->prefix_end) - 1u))) {
+        FanArgs fa;
+        fa.n_seg = w->n_segments; fa.p_end = w->prefix_end;
+        const size_t shared = (size_t)4 * round4(WAVE * pad_odd(n)) + (size_t)w->n_slots * SLOT_FLOATS * WAVE;
+        size_t off = shared;
+        bool ok = true;
+        for (int sgm = 0; sgm <= DRM_MAX_SEGMENTS; ++sgm) {
+            fa.seg_begin[sgm] = sgm <= w->n_segments ? w->seg_begin[sgm] : w->n_ops;
+            fa.leaf_begin[sgm] = sgm <= w->n_segments ? w->seg_leaf_begin[sgm] : n_leaves;
+        }
+        for (int sgm = 0; sgm < DRM_MAX_SEGMENTS; ++sgm) {
+            fa.wave_off[sgm] = (int32_t)off;
+            if (sgm < w->n_segments) {
+                const int ops_s = fa.seg_begin[sgm + 1] - fa.seg_begin[sgm], leaves_s = fa.leaf_begin[sgm + 1] - fa.leaf_begin[sgm];
+                if (ops_s < 0 || leaves_s < 0 || leaves_s > ops_s) ok = false;
+                off += (size_t)round4(cap * DRM_OPF_STRIDE + record_floats(ops_s, leaves_s));
+            }
+        }
+        const size_t lds_bytes = off * sizeof(float);
+        if (ok && lds_bytes <= (size_t)MAX_LDS_BYTES) {
+            const int64_t tiles = (B + WAVE - 1) / WAVE;
+            int64_t blocks = BWD_MAX_WAVES / w->n_segments;
+            if (blocks > tiles) blocks = tiles;
+            rc = ensure_lds(rnea_backward_fan_kernel, lds_bytes);
+            if (rc) return rc;
+            const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU) |
+                                al16(grad_q, AL_POS) | al16(grad_qd, AL_QUAT) | al16(grad_qdd, AL_LIN);
+            hipLaunchKernelGGL(rnea_backward_fan_kernel, dim3((unsigned)blocks), dim3((unsigned)(WAVE * w->n_segments)), lds_bytes, s,
+                               w->ops_f, w->ops_i, fa, cap, n, (int)w->n_slots, (int)flags, q, qd, qdd, grad_tau, B, grad_q, grad_qd,
+                               grad_qdd, param_mask, partials, div_magic(n), al);
+            rc = launched();
+            if (rc) return rc;
+            if (grad_ops_f) {
+                hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)(cap * DRM_OPF_STRIDE / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s,
+                                   partials, (int)(blocks * w->n_segments), cap, grad_ops_f);
+                rc = launched();
+            }
+            return rc;
+        }
+    }
     const bool park_hbm = rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, false) * sizeof(float) > (size_t)MAX_LDS_BYTES;
     Geometry g;
     rc = make_geometry(B, (int)rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, park_hbm), g);
@@ -362,7 +530,13 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
     const int wpb = (int)(g.block.x / WAVE);
     const int waves = backward_waves(B, wpb);
     g.grid = dim3((unsigned)(waves / wpb));
-    float *park = scratch + (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE;
+    float *park;
+    {
+        const int64_t tiles = (B + WAVE - 1) / WAVE, w0 = backward_waves(B, MAX_WAVES_PER_BLOCK);
+        int64_t rows = tiles * DRM_MAX_SEGMENTS < BWD_MAX_WAVES ? tiles * DRM_MAX_SEGMENTS : BWD_MAX_WAVES;
+        if (rows < w0) rows = w0;
+        park = scratch + (rows + MAX_WAVES_PER_BLOCK) * cap * DRM_OPF_STRIDE; // behind the rows of partial sums (scratch query)
+    }
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU) |
                            al16(grad_q, AL_POS) | al16(grad_qd, AL_QUAT) | al16(grad_qdd, AL_LIN);
 #define DRM_LAUNCH_RB(HBM)                                                                                             \

@@ -1219,15 +1219,20 @@ DRM_HD void tbar_parent(const float *J, const float *t, const f2 (&T)[3], f2 (&U
 //         walk (through the slots at branch points).
 // Per link only 2 floats are parked, per leaf 18 more (the earlier four-sweep form parked 26 per link and read most of
 // them three times — for a hand that traffic, in HBM because it did not fit LDS, was the kernel's whole run time).
-//   ctl = the control-word field of the int table (DRM_OPI_CTRL), n_ops = links of the walk
+//   ctl = the control-word field of the int table (DRM_OPI_CTRL)
+//   ops: the static prefix [0, p_end) is replayed on the way up (motions only matter), then ops [a, b) — one SEGMENT of the
+//        walk (independent sub-trees hanging off the prefix; a wavefront each in the kernel); the way down visits [a, b)
+//        only: nothing is handed to a prefix op (they have no DoF; the caller must not ask for their constants' gradients).
+//        The whole walk in one go: p_end = 0, a = 0, b = n_ops.
 //   park / unpark(k, off, v, n): record of link k — floats 0..11 motion (w, v, al, a), 18..23 tbar (leaves only), 24..25 trig
 //   slot records: 0..11 motion, 12..17 total-force accumulator, 18..23 tbar, 24..35 motion-adjoint accumulator
 template <class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT, class PG>
-DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, int flags,
+DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int p_end, int a, int b, int flags,
                                uint32_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
                                SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
+    uint32_t prefix_slots = 0; // slots owned by prefix ops: read on the way up, never added to on the way down
     auto tbar_to_floats = [](const f2 (&T)[3], float *v) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) { v[i] = T[i][0]; v[3 + i] = T[i][1]; }
@@ -1244,11 +1249,13 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
 #pragma unroll
         for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
 #pragma unroll 1
-        for (int k = 0; k < n_ops; ++k) {
+        for (int k = (p_end > 0 ? 0 : a); k < b; k = (k + 1 == p_end ? a : k + 1)) {
             const float *of = opf + k * DRM_OPF_STRIDE;
             const int c = ctl[k];
             const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
             const bool pris = ctl_prismatic(c);
+            const bool mine = k >= a; // (a prefix op: nothing is parked for it)
+            if (!mine && save >= 0) prefix_slots |= 1u << save;
             float wj = 0.0f, aj = 0.0f, J[9], t[3], rec[12], trig[2] = {1.0f, 0.0f};
             if (dof >= 0) {
                 float q;
@@ -1256,7 +1263,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                 if (pris) trig[1] = q;
                 else sincos_f(q, trig[1], trig[0]);
             }
-            park(k, 24, trig, 2);
+            if (mine) park(k, 24, trig, 2);
             const OpFT o = load_ft(of);
             joint_transform(o, dof >= 0, pris, trig[1], trig[0], trig[1], J, t);
             if (src == DRM_SRC_ROOT) {
@@ -1278,7 +1285,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                 for (int i = 0; i < 3; ++i) T[i] = Tn[i];
             }
             if (dof >= 0) T[2][pris ? 0 : 1] += gtau(dof); // tau = S^T f: angular z (revolute), linear z (prismatic)
-            const bool leaf = !(ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT);
+            const bool leaf = mine && !(ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT);
             if (save >= 0 || leaf) {
                 float tb[6];
                 motion_to_floats(cur, rec);
@@ -1298,7 +1305,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             Pm.wa[i] = Pm.va[i] = pbn.wa[i] = pbn.va[i] = U[i] = up.la[i] = f2_bcast(0.0f);
         }
 #pragma unroll 1
-        for (int k = n_ops - 1; k >= 0; --k) {
+        for (int k = b - 1; k >= a; --k) {
             const float *of = opf + k * DRM_OPF_STRIDE;
             const int c = ctl[k];
             const int dof = ctl_field(c, DRM_OPI_DOF), src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
@@ -1403,7 +1410,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
             if (want_gq && dof >= 0) gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
             if (has_parent) {
                 rnea_link_force_up(J, t, tot, up); // the sub-tree's force in the parent's frame
-                if (src >= 0) {
+                if (src >= 0 && !((prefix_slots >> src) & 1u)) {
                     float x12[12], x6[6];
                     motion_to_floats(pbn, x12);
 #pragma unroll

@@ -249,6 +249,7 @@ class WalkProgram:
     seg_dof: Sequence[tuple] = ((0, 0),)  # (first DoF column, count) of every segment
     op_of_link: Optional[dict] = None     # link index -> op that carries the link's TRUE frame (targets, body forces)
     prefix_end: int = 0                   # ops [0, prefix_end) are static (fixed joints off the root): every segment replays them
+    seg_leaf_begin: Sequence[int] = (0, 0)  # leaf ordinals of every segment (drm_walk.seg_leaf_begin)
 
     @property
     def n_segments(self) -> int:
@@ -518,10 +519,12 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
     branch_depth = min(255, max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0))
     prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
+    is_leaf = [not (ops_i[k, OPI_FLAGS] & FLAG_CHILD_IS_NEXT) for k in range(n_ops)]
+    seg_leaf_begin = [int(sum(is_leaf[:b])) for b in seg_begin]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8) | (min(n_leaves, 255) << 16),
-                       seg_begin, seg_dof, op_of_link, prefix_end)
+                       seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
 
 
 def _segments(ops, parent_op, n_ops: int, n_dofs: int):

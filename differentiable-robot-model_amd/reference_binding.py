@@ -36,7 +36,7 @@ class DrmWalk(ctypes.Structure):
                 ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
-                ("prefix_end", ctypes.c_int32)]
+                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1))]
 
 
 def link_table(body_params: Sequence[dict], device, spec=None) -> torch.Tensor:
@@ -119,6 +119,8 @@ class HipBinding(object):
             for i, (lo, cnt) in enumerate(prog.seg_dof):
                 w.seg_dof_lo[i], w.seg_dof_cnt[i] = int(lo), int(cnt)
             w.prefix_end = int(prog.prefix_end)
+            for i, v in enumerate(prog.seg_leaf_begin):
+                w.seg_leaf_begin[i] = int(v)
             self._walks[key] = (w, ops_f, ops_i, prog)
         return self._walks[key]
 

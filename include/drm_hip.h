@@ -155,6 +155,9 @@ typedef struct drm_walk {
     int32_t seg_dof_cnt[DRM_MAX_SEGMENTS];
     int32_t prefix_end;   /* ops 0 .. prefix_end-1 are STATIC (fixed joints hanging off the root: a mounting plate, the base
                              link of a TriFinger); every segment replays them before its own ops, forward sweeps only */
+    int32_t seg_leaf_begin[DRM_MAX_SEGMENTS + 1]; /* leaf ordinals (DRM_OPI_CTRL bits 26..31) of segment s:
+                             seg_leaf_begin[s] .. seg_leaf_begin[s+1]-1 (leaves are numbered in walk order, those of the
+                             prefix first); read by the RNEA backward kernel when it fans the segments out over wavefronts */
 } drm_walk;
 
 int drm_abi_version(void);

@@ -217,8 +217,19 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
         auto stake = [&](int s, int off, float *v, int cnt) { for (int i = 0; i < cnt; ++i) { v[i] = slots[s][off + i]; slots[s][off + i] = 0.f; } };
         auto gout = [&](int d, float a, float v, float acc) { gq[b * n + d] = a; gqd[b * n + d] = v; gqdd[b * n + d] = acc; };
         auto pout = [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; };
-        rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->n_ops, flags, mask, gq != nullptr, qf, gt, park, unpark,
-                           sput, sget, sadd, stake, gout, pout);
+        // segment by segment, as the fanned-out kernel does it (one wavefront each there); a walk with learnable prefix ops
+        // in one go
+        const uint32_t prefix_mask = w->prefix_end >= 32 ? 0xffffffffu : ((1u << w->prefix_end) - 1u);
+        if (w->n_segments > 1 && !(mask & prefix_mask)) {
+            for (int seg = 0; seg < w->n_segments; ++seg) {
+                for (auto &s : slots) for (float &x : s) x = 0.f;
+                rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1], flags,
+                                   mask, gq != nullptr, qf, gt, park, unpark, sput, sget, sadd, stake, gout, pout);
+            }
+        } else {
+            rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, 0, 0, w->n_ops, flags, mask, gq != nullptr, qf, gt, park, unpark,
+                               sput, sget, sadd, stake, gout, pout);
+        }
     }
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
 }

@@ -206,5 +206,19 @@ def test_abi_argument_errors_need_no_gpu():
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -1
     w = backend.DrmWalk(1, 1, 8, 8, 7, 17, 0, 2, 0)  # more save slots than the kernels have
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -2
-    # struct drm_walk: 48 bytes of scalars + n_segments + seg_begin[9] + seg_dof_lo[8] + seg_dof_cnt[8] + prefix_end
-    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1) + 4
+    # struct drm_walk: 48 bytes of scalars + n_segments + seg_begin[9] + seg_dof_lo[8] + seg_dof_cnt[8] + prefix_end + seg_leaf_begin[9]
+    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1 + 9)
+
+
+def test_rnea_backward_scratch_covers_the_fanned_out_launch():
+    """drm_rnea_backward_scratch_floats: one row of partial sums (capacity x 32 floats) per wavefront — and the launch that
+    fans a hand's fingers out over wavefronts writes one per tile AND segment (up to 8), capped at 2048: a query sized for
+    one row per tile let that launch write past the scratch buffer (caught as an intermittent GPU fault at B = 700)."""
+    lib = backend.load_library()
+    lib.drm_rnea_backward_scratch_floats.restype = ctypes.c_int64
+    lib.drm_rnea_backward_scratch_floats.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    cap, n = 20, 16
+    for B in (1, 64, 700, 65536, 1 << 20):
+        tiles = (B + 63) // 64
+        rows = min(tiles * 8, 2048)
+        assert lib.drm_rnea_backward_scratch_floats(B, cap, n, 1) >= rows * cap * 32, B
