@@ -366,6 +366,36 @@ constexpr float SINCOS_PAIR_MAX_ARG = 1.0e5f;
 //   joints_done()  -> called once, right after the last MOVING joint: every B[k] is final from here on
 //                     (the kernel starts storing the angular Jacobian while the fixed tail is still computed)
 // Out: B[k][c] = (z_c, p_c) of every moving joint k, and the end pose.
+// sin / cos of one joint angle: sincos_pair's algorithm on scalars (same constants, same operation order), with the
+// same wave-uniform escape to the fp64 reduction for |x| > 1e5
+DRM_HD void sincos_one(float x, float &s, float &c) {
+    if (DRM_WAVE_ANY(!(fabsf(x) <= SINCOS_PAIR_MAX_ARG))) {
+        sincos_f(x, s, c);
+        return;
+    }
+    const float magic = 12582912.0f;
+    const float kb = __builtin_fmaf(x, 0.318309886f, magic);
+    const float kf = kb - magic;
+    float r = __builtin_fmaf(kf, -3.14159202e+00f, x);
+    r = __builtin_fmaf(kf, -6.27832947e-07f, r);
+    r = __builtin_fmaf(kf, -1.07806051e-14f, r);
+    const float z = r * r;
+    float ps = z * -2.3776610902e-08f + 2.7522166874e-06f;
+    ps = z * ps + -1.9840880122e-04f;
+    ps = z * ps + 8.3333319053e-03f;
+    ps = z * ps + -1.6666667163e-01f;
+    const float sr = (r * z) * ps + r;
+    float pc = z * 1.6759177379e-09f + -2.7332046670e-07f;
+    pc = z * pc + 2.4796934667e-05f;
+    pc = z * pc + -1.3888848480e-03f;
+    pc = z * pc + 4.1666664183e-02f;
+    pc = z * pc + -0.5f;
+    const float cr = z * pc + 1.0f;
+    const uint32_t flip = __builtin_bit_cast(uint32_t, kb) << 31;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sr) ^ flip);
+    c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cr) ^ flip);
+}
+
 // cos / sin of the NJ joint angles of a chain, two joints per packed evaluation
 template <int NJ>
 DRM_HD void chain_trig(const float (&q)[NJ], float (&cs)[NJ], float (&sn)[NJ]) {
@@ -1261,7 +1291,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
                 float q;
                 qf(dof, q, wj, aj);
                 if (pris) trig[1] = q;
-                else sincos_f(q, trig[1], trig[0]);
+                else sincos_one(q, trig[1], trig[0]);
             }
             if (mine) park(k, 24, trig, 2);
             const OpFT o = load_ft(of);

@@ -49,36 +49,6 @@ DRM_HD void ctl_words(const CTL &ctl, int k, int &w0, int &w1) {
     w1 = ctl.uniform(r1);
 }
 
-// sin / cos of one joint angle: sincos_pair's algorithm on scalars (same constants, same operation order), with the
-// same wave-uniform escape to the fp64 reduction for |x| > 1e5
-DRM_HD void sincos_one(float x, float &s, float &c) {
-    if (DRM_WAVE_ANY(!(fabsf(x) <= SINCOS_PAIR_MAX_ARG))) {
-        sincos_f(x, s, c);
-        return;
-    }
-    const float magic = 12582912.0f;
-    const float kb = __builtin_fmaf(x, 0.318309886f, magic);
-    const float kf = kb - magic;
-    float r = __builtin_fmaf(kf, -3.14159202e+00f, x);
-    r = __builtin_fmaf(kf, -6.27832947e-07f, r);
-    r = __builtin_fmaf(kf, -1.07806051e-14f, r);
-    const float z = r * r;
-    float ps = z * -2.3776610902e-08f + 2.7522166874e-06f;
-    ps = z * ps + -1.9840880122e-04f;
-    ps = z * ps + 8.3333319053e-03f;
-    ps = z * ps + -1.6666667163e-01f;
-    const float sr = (r * z) * ps + r;
-    float pc = z * 1.6759177379e-09f + -2.7332046670e-07f;
-    pc = z * pc + 2.4796934667e-05f;
-    pc = z * pc + -1.3888848480e-03f;
-    pc = z * pc + 4.1666664183e-02f;
-    pc = z * pc + -0.5f;
-    const float cr = z * pc + 1.0f;
-    const uint32_t flip = __builtin_bit_cast(uint32_t, kb) << 31;
-    s = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sr) ^ flip);
-    c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, cr) ^ flip);
-}
-
 // one link of the pose chain on packed pairs; prismatic joints slide along the NEW z axis: p += R e_z q
 DRM_HD void pose_step(const OpPairs &o, const OpCtl &ct, float q, bool from_root, PoseP &cur) {
     float c = 1.0f, s = 0.0f;

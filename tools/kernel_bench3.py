@@ -16,3 +16,13 @@ for _ in range(5):
     a = ma.compute_forward_dynamics(qa, qda, qdda)
 torch.cuda.synchronize()
 print("done")
+# the loop-structured RNEA backward (fanned out over the fingers): input gradients, then with one learnable link
+from differentiable_robot_model_amd import backend
+full = ma._get_walk(("tree",), whole_tree=True)
+of = ma._ops_f(full)
+gt = torch.randn(B, ma._n_dofs, device="cuda")
+for _ in range(3):
+    backend.rnea_backward(full.program, of, full.ops_i, qa, qda, qdda, gt, True, True, ma._n_dofs, 0, True)
+    backend.rnea_backward(full.program, of, full.ops_i, qa, qda, qdda, gt, True, True, ma._n_dofs, 1 << 5, True)
+torch.cuda.synchronize()
+print("done backward")
