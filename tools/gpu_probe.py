@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Development probe run on the GPU box: parity sweep over all robots + kernel timings."""
+"""Development probe run on the GPU box: eager kernel timings; provides `load` / `sample` to the other tools.  (Parity
+against the oracle lives in tests/ only: nothing outside tests/, smoke() and bench.py's cpu_baseline touches oracle/.)"""
 import contextlib
 import io
 import os
@@ -13,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import differentiable_robot_model_amd as drm  # noqa: E402
 from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel, robot_description_folder  # noqa: E402
-from oracle import Oracle  # noqa: E402
 
 
 def load(name, device="cuda"):
@@ -28,34 +28,6 @@ def sample(model, B, seed=0):
     n = model._n_dofs
     return (lo + (hi - lo) * torch.rand(B, n, generator=g), torch.rand(B, n, generator=g) * 2 - 1,
             torch.rand(B, n, generator=g) * 4 - 2)
-
-
-def parity():
-    worst = {}
-    for name in sorted(f[:-5] for f in os.listdir(robot_description_folder) if f.endswith(".urdf")):
-        m = load(name)
-        orc = Oracle(m._spec)
-        L = len(m._bodies)
-        for B in (1, 63, 64, 65, 200):
-            q, qd, qdd = sample(m, B, seed=B)
-            f64 = lambda t: t.numpy().astype(np.float64)
-            link = L - 1
-            pos, quat, lin, ang = m.compute_fk_and_jacobian(q.cuda(), m._bodies[link].name)
-            tau = m.compute_inverse_dynamics(q.cuda(), qd.cuda(), qdd.cuda())
-            allp = m.compute_forward_kinematics_all_links(q.cuda())
-            op, oq, ol, oa = orc.fk_jacobian(f64(q), link, np.float64)
-            ot = orc.rnea(f64(q), f64(qd), f64(qdd), True, True, np.float64)
-            ap, aq = orc.fk(f64(q), list(range(L)), np.float64)
-            sgn = np.sign((oq * quat.cpu().numpy()).sum(-1, keepdims=True))
-            e = dict(pos=np.abs(pos.cpu().numpy() - op).max(), quat=np.abs(quat.cpu().numpy() * sgn - oq).max(),
-                     lin=np.abs(lin.cpu().numpy() - ol).max(), ang=np.abs(ang.cpu().numpy() - oa).max(),
-                     tau=(np.abs(tau.cpu().numpy() - ot) / (1 + np.abs(ot))).max())
-            e["all_pos"] = max(np.abs(allp[m._bodies[i].name][0].cpu().numpy() - ap[:, i]).max() for i in range(L))
-            for k, v in e.items():
-                worst[k] = max(worst.get(k, 0.0), float(v))
-            bad = {k: v for k, v in e.items() if not (v < 2e-5)}
-            print("%-38s B=%4d %s %s" % (name, B, {k: "%.1e" % v for k, v in e.items()}, "BAD" if bad else ""), flush=True)
-    print("WORST", {k: "%.2e" % v for k, v in worst.items()})
 
 
 def timeit(fn, iters=50, warm=5):
@@ -105,7 +77,5 @@ if __name__ == "__main__":
     t0 = time.time()
     import __graft_entry__
     __graft_entry__.smoke()
-    if "--no-parity" not in sys.argv:
-        parity()
     timing()
     print("probe done in %.1fs" % (time.time() - t0))

@@ -32,6 +32,9 @@ def rows(pattern):
 stats = glob.glob(os.path.join(OUT, "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(prof, tag + "_bench_kernel_stats.csv"))
+stats = glob.glob(os.path.join(OUT, "prof_stats_k20", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(prof, tag + "_bench_k20_kernel_stats.csv"))
 stats = glob.glob(os.path.join(OUT, "prof_all", "*", "*_kernel_stats.csv"))
 if stats:   # rows of our kernels only
     with open(stats[0]) as f, open(os.path.join(prof, tag + "_all_kernels_rocprof_stats.csv"), "w") as g:
@@ -48,6 +51,7 @@ def last_json_line(path):
 
 
 for src, dst in (("prof_stats.log", "_bench_under_rocprofv3.json"), ("bench_default.json", "_bench_default.json"),
+                 ("prof_stats_k20.log", "_bench_k20_under_rocprofv3.json"), ("bench_k20.json", "_bench_k20.json"),
                  ("bench_config3.json", "_bench_config3.json")):
     line = last_json_line(os.path.join(OUT, src))
     if line:

@@ -16,6 +16,9 @@ B="python $ROOT/bench.py --no-cpu-baseline"
 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
+# the same with the flags the round driver passes (a 20-launch timed region)
+python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_k20 -- $B --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_k20.log 2>&1
 for batch in 65536 4194304; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
