@@ -157,7 +157,7 @@ static FdPlan fd_plan(const drm_walk *w) {
 
 
 // Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,
-// rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled Cholesky; constants
+// rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled L^T D L solve; constants
 // staged once per wave in LDS, RNEA's body forces parked over the dead input tiles, qdd staged over them at the end.
 // LINKS: the links the sweeps visit (NJ when the host folded the fixed tail into the last moving link, else CAP).
 template <int CAP, int NJ, int LINKS>

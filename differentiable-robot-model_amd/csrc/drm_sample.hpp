@@ -910,14 +910,17 @@ DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&c
 // compute_inverse_dynamics' torques is back-propagated to the learnable link parameters (robot_model.py:305-375
 // with robot_model.py:669-713; examples/learn_dynamics_iiwa.py:49-96) and to q / qd / qdd.
 //
-// Four sweeps per sample over the same walk (per-link state is parked by the caller, LDS in the kernel):
+// Mathematically four sweeps over the walk
 //   A  k up    motion (w, al, v, a) of every link and its body force                      [= the RNEA forward sweep]
 //   B  k down  total force tot_k = f_k + sum of the children's forces moved up             [= the RNEA backward sweep]
 //   C  k up    adjoint of B:  tbar_k = J^T-transformed tbar_parent + gtau_k e_(ang z)
 //   D  k down  adjoint of A:  motion adjoints from the body force and the children, then the adjoints of the
 //              joint transform (J, t) from both sweeps, of the constants (m, mc, Io, damping) and of q, qd, qdd
-// Layout of a parked link record (floats): 0..11 motion (w, v, al, a), 12..17 tot (lin, ang), 18..23 tbar,
-// 24..25 (cos q, sin q) of the link's joint;  of a slot record: the first 24 plus 24..35 the motion-adjoint accumulator.
+// run as TWO: A and C together on the way up; D on the way down with B folded in (the body force is recomputed from the
+// motion, the sub-tree's force travels with the walk) and every parent's motion / tbar recovered from its child's — see
+// rnea_backward_walk (any tree) and rnea_backward_chain (serial arms) below.
+// Layout of a parked link record (floats): 0..11 motion (w, v, al, a) and 18..23 tbar of LEAF links, 24..25 (cos q, sin q)
+// of every link;  of a slot record: 0..11 motion, 12..17 total-force accumulator, 18..23 tbar, 24..35 motion-adjoint accumulator.
 //   park(k, off, v, n) / unpark(k, off, v, n)                       per-link records
 //   slot_put / slot_get / slot_add / slot_take(s, off, v, n)        branch-point records (take = read and zero)
 //   gtau(d) -> dL/dtau of DoF d;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask

@@ -851,7 +851,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         """qdd [B,n] that the joint torques ``f`` produce in state (q, qd) (robot_model.py:487-624).
 
         The reference runs Featherstone's articulated-body recursion; this solves the same linear system
-        H(q) qdd = f - nle(q, qd) in one fused kernel (composite-rigid-body H, RNEA bias torques, Cholesky).
+        H(q) qdd = f - nle(q, qd) in one fused kernel (composite-rigid-body H, RNEA bias torques, leaf-to-root L^T D L solve;
+        one step of iterative refinement for badly conditioned robots, ``self.forward_dynamics_refinement``).
         With ``use_damping`` the reference subtracts damping * qd from its ``f`` argument IN PLACE
         (robot_model.py:515-521); here ``f`` is left untouched.  Differentiable with respect to q, qd, f and the
         learnable link parameters (implicit differentiation: one more solve + the RNEA backward kernel).
