@@ -324,16 +324,30 @@ def _gather_axis_op(spec: RobotSpec, link: int, row_index: int):
     return row, sgn
 
 
-def foldable_links(spec: RobotSpec) -> np.ndarray:
+def foldable_links(spec: RobotSpec, keep: Sequence[int] = ()) -> np.ndarray:
     """bool [L]: links behind a FIXED joint with no moving joint below them — end-effector frames, fingertips, sensor
     mounts.  They are rigidly attached to their nearest non-foldable ancestor, so a dynamics walk may leave them out when
     that ancestor's row carries their inertia as well (fold_link_table): same torques / inertia matrix / accelerations,
-    one op less per such link (Panda: 8 -> 7 ops, Allegro: 21 -> 17)."""
+    one op less per such link (Panda: 8 -> 7 ops, Allegro: 21 -> 17).
+    ``keep``: links that must stay ops of their own — those with learnable parameters (their constants change every step
+    and their gradients are theirs); a link whose fold target is such a link stays as well (the target's row is rebuilt
+    from its parameters alone), and may in turn take its own foldable children."""
     L = spec.n_links
-    fold = np.zeros(L, bool)
-    for i in range(L - 1, 0, -1):      # children come after their parents in URDF <link> order
-        fold[i] = spec.kind[i] == KIND_FIXED and all(fold[c] for c in spec.children[i])
-    return fold
+    keep = set(int(i) for i in keep)
+    while True:
+        fold = np.zeros(L, bool)
+        for i in range(L - 1, 0, -1):      # children come after their parents in URDF <link> order
+            fold[i] = spec.kind[i] == KIND_FIXED and i not in keep and all(fold[c] for c in spec.children[i])
+        bad = set()
+        for i in np.nonzero(fold)[0]:
+            t = int(spec.parent[i])
+            while t > 0 and fold[t]:
+                t = int(spec.parent[t])
+            if t in keep and spec.parent[i] >= 0:
+                bad.add(int(i))
+        if not bad:
+            return fold
+        keep |= bad
 
 
 def mass_spread(spec: RobotSpec) -> float:
@@ -351,13 +365,14 @@ def mass_spread(spec: RobotSpec) -> float:
 REFINE_MASS_SPREAD = 100.0
 
 
-def fold_link_table(spec: RobotSpec, table: np.ndarray) -> np.ndarray:
+def fold_link_table(spec: RobotSpec, table: np.ndarray, fold: Optional[np.ndarray] = None) -> np.ndarray:
     """The [L+1(+...), 32] link table with the inertia of every foldable link moved into its parent's row (composite
     rigid body, expressed in the parent link's frame): m' = m_p + m,  (mc)' = (mc)_p + F (mc) + m t,
     I_o' = I_o,p + F I_o F^T + m [(t.t) E - t t^T] + 2 (h.t) E - h t^T - t h^T  with h = F (mc).  fp64 on the host, once per
     robot.  Rows keep their F / t (FK through such a link is unchanged); a foldable link hanging off the root is dropped."""
     out = np.array(table, np.float64, copy=True)
-    fold = foldable_links(spec)
+    if fold is None:
+        fold = foldable_links(spec)
     for i in range(spec.n_links - 1, 0, -1):
         if not fold[i]:
             continue
@@ -379,10 +394,10 @@ def fold_link_table(spec: RobotSpec, table: np.ndarray) -> np.ndarray:
 
 
 def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_tree: bool = False,
-               min_capacity: int = 0, drop_folded: bool = False) -> WalkProgram:
+               min_capacity: int = 0, drop_folded: bool = False, fold: Optional[np.ndarray] = None) -> WalkProgram:
     """Depth-first walk over the links needed to reach ``targets`` (or all links); ``min_capacity`` pads it to at least
     that capacity (chains that are launched together share one).  ``drop_folded``: a whole-tree walk without the
-    foldable links (foldable_links; to be run on a table from fold_link_table).
+    foldable links (``fold``, default foldable_links(spec); to be run on a table from fold_link_table with the same mask).
 
     A link whose joint axis is not +-x / y / z becomes TWO ops (Rot_a(q) = R_a Rot_z(q) R_a^T with R_a e_z = a):
       A  the joint: fixed part F R_a, trans t, moving about +z, massless (virtual link-table row);
@@ -392,7 +407,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     L = spec.n_links
     needed = np.zeros(L, bool)
     if whole_tree:
-        needed[1:] = ~foldable_links(spec)[1:] if drop_folded else True
+        needed[1:] = ~(fold if fold is not None else foldable_links(spec))[1:] if drop_folded else True
     tlist = [int(t) for t in (targets or [])]
     for t in tlist:
         for i in spec.chain_to(t):

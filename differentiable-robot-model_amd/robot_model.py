@@ -87,6 +87,7 @@ class _DeviceWalk:
     gsign: torch.Tensor                 # float32 [cap * 32] +-1 factors of the gathered entries
     static_ops_f: Optional[torch.Tensor] = None
     folded: bool = False                # a dynamics walk without the foldable links, on the folded link table
+    fold_key: Optional[tuple] = None    # ... folded for this set of kept (learnable) links (robot_model._fold_mask)
     learnable_plan: Optional[tuple] = None   # (learnable links, constant walk table, row selector) of _ops_f_learnable
 
 
@@ -361,7 +362,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
-        self._static_table_folded: Optional[torch.Tensor] = None   # ... with the foldable links folded into their parents
+        self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
+        self._fold_masks: Dict[tuple, np.ndarray] = {}          # kept (learnable) links -> foldable_links(spec, keep)
         # forward dynamics: one step of iterative refinement (DRM_FD_REFINE) for robots whose inertia matrix is badly
         # conditioned — light links far out on heavy ones (flatten.mass_spread); settable (True / False) by the user
         self.forward_dynamics_refinement: bool = mass_spread(self._spec) > REFINE_MASS_SPREAD
@@ -402,8 +404,9 @@ class DifferentiableRobotModel(torch.nn.Module):
                            torch.zeros(L, OPF_STRIDE - 26, device=dev)], dim=1)
         return table.to(torch.float32)
 
-    def _link_table(self) -> torch.Tensor:
-        """[L + 1, OPF_STRIDE] table of per-link constants (row L = the identity op used to pad walks).
+    def _link_table(self, fold_key: Optional[tuple] = None) -> torch.Tensor:
+        """[L + 1, OPF_STRIDE] table of per-link constants (row L = the identity op used to pad walks); ``fold_key``: with
+        the links of that fold mask folded into their parents (_dynamics_walk).
 
         With learnable parameters only the rows of the links that carry them are rebuilt (differentiably) on
         top of a cached snapshot of the constant rows: the per-step host work is O(#learnable links), not O(L).
@@ -414,7 +417,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 base = torch.cat([self._link_rows(range(len(self._bodies))), ident], dim=0)
                 self._static_table = self._with_virtual_rows(base)
         if not self._learnable:
-            return self._static_table
+            return self._static_table if fold_key is None else self._with_virtual_rows(self._static_rows(fold_key))
         links = sorted({link for link, _ in self._learnable})
         if self._learnable_links is None or self._learnable_links.numel() != len(links):
             self._learnable_links = torch.tensor(links, dtype=torch.int64, device=self._device)
@@ -423,8 +426,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             rows = backend.LinkRows.apply(self._link_params(links))
         else:
             rows = self._link_rows(links)   # host-side tests of the table construction
-        L1 = len(self._bodies) + 1
-        return self._with_virtual_rows(self._static_table[:L1].index_copy(0, self._learnable_links, rows))
+        return self._with_virtual_rows(self._static_rows(fold_key).index_copy(0, self._learnable_links, rows))
 
     def _with_virtual_rows(self, base: torch.Tensor) -> torch.Tensor:
         """Append the two virtual rows of every link whose joint axis is not +-x / y / z (flatten.build_walk):
@@ -456,55 +458,61 @@ class DifferentiableRobotModel(torch.nn.Module):
                 damping if damping is not None else zero1)]))
         return torch.stack(rows)
 
-    def _get_walk(self, key, targets=None, whole_tree=False, folded=False) -> _DeviceWalk:
+    def _get_walk(self, key, targets=None, whole_tree=False, folded=False, fold_key=None) -> _DeviceWalk:
         dw = self._walks.get(key)
         if dw is None:
-            prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree, drop_folded=folded and whole_tree)
+            prog = build_walk(self._spec, targets=targets, whole_tree=whole_tree, drop_folded=folded and whole_tree,
+                              fold=self._fold_masks[fold_key] if folded else None)
             dw = _DeviceWalk(
                 program=prog,
                 ops_i=torch.from_numpy(prog.ops_i_dev).to(self._device).contiguous(),
                 gather=torch.from_numpy(prog.gather.reshape(-1)).to(self._device),
                 gsign=torch.from_numpy(prog.gsign.reshape(-1)).to(self._device),
-                folded=folded,
+                folded=folded, fold_key=fold_key if folded else None,
             )
             self._walks[key] = dw
         return dw
 
-    def _dynamics_walk(self) -> _DeviceWalk:
-        """The whole-tree walk of the forward dynamics kernels.  While nothing is learnable, links behind fixed joints
-        with no moving joint below them (end-effector frames, fingertips) are folded into their parents: their inertia
-        is added to the parent's row once on the host (flatten.fold_link_table) and the walk leaves them out — the same
-        torques / inertia matrix / accelerations — and the same gradients with respect to q, qd, qdd / f — from fewer ops
-        (Panda 8 -> 7, Allegro 21 -> 17).  With learnable parameters the full walk runs (their gradients belong to the
-        individual links)."""
-        if self._learnable or not foldable_links(self._spec).any():
-            return self._get_walk(("tree",), whole_tree=True)
-        return self._get_walk(("tree", "folded"), whole_tree=True, folded=True)
+    def _fold_key(self) -> tuple:
+        """The links that must stay ops of their own (those with learnable parameters), as the key of a fold mask."""
+        key = tuple(sorted({link for link, _ in self._learnable}))
+        if key not in self._fold_masks:
+            self._fold_masks[key] = foldable_links(self._spec, keep=key)
+        return key
 
-    def _folded_table(self) -> torch.Tensor:
-        assert not self._learnable
-        if self._static_table_folded is None:
+    def _dynamics_walk(self) -> _DeviceWalk:
+        """The whole-tree walk of the dynamics kernels, forward and backward.  Links behind fixed joints with no moving
+        joint below them (end-effector frames, fingertips) are folded into their parents: their inertia is added to the
+        parent's row once on the host (flatten.fold_link_table) and the walk leaves them out — the same torques / inertia
+        matrix / accelerations and the same gradients from fewer ops (Panda 8 -> 7, Allegro 21 -> 17).  Links with learnable
+        parameters stay ops of their own, and so does whatever would have been folded into them (flatten.foldable_links)."""
+        key = self._fold_key()
+        if not self._fold_masks[key].any():
+            return self._get_walk(("tree",), whole_tree=True)
+        return self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
+
+    def _static_rows(self, fold_key: Optional[tuple]) -> torch.Tensor:
+        """[L + 1, OPF_STRIDE] snapshot of the constant rows, with the links of a fold mask folded into their parents."""
+        if self._static_table is None:
             self._link_table()
-            L1 = len(self._bodies) + 1
+        L1 = len(self._bodies) + 1
+        if fold_key is None:
+            return self._static_table[:L1]
+        if fold_key not in self._static_folded:
             with torch.no_grad():
-                base = fold_link_table(self._spec, self._static_table[:L1].cpu().numpy())
-                self._static_table_folded = self._with_virtual_rows(
-                    torch.from_numpy(base.astype(np.float32)).to(self._device))
-        return self._static_table_folded
+                rows = fold_link_table(self._spec, self._static_table[:L1].cpu().numpy(), self._fold_masks[fold_key])
+                self._static_folded[fold_key] = torch.from_numpy(rows.astype(np.float32)).to(self._device)
+        return self._static_folded[fold_key]
 
     def _ops_f(self, dw: _DeviceWalk) -> torch.Tensor:
         """[cap, OPF_STRIDE] constants gathered (and axis-canonicalised) in walk order; ONE differentiable
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if dw.folded:
-            table = self._folded_table()
-            dw.static_ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
-            return dw.static_ops_f
         if (self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32
                 and not self._spec.skew.any()):
             return self._ops_f_learnable(dw)      # (more learnable links than the fused kernel takes: the torch path below)
-        table = self._link_table()
+        table = self._link_table(dw.fold_key)
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
@@ -518,10 +526,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         key = tuple(links)
         plan = dw.learnable_plan
         if plan is None or plan[0] != key:
-            if self._static_table is None:
-                self._link_table()
             with torch.no_grad():
-                base = (self._static_table.reshape(-1).index_select(0, dw.gather) * dw.gsign).contiguous()
+                static = self._with_virtual_rows(self._static_rows(dw.fold_key))
+                base = (static.reshape(-1).index_select(0, dw.gather) * dw.gsign).contiguous()
             gather = dw.program.gather.reshape(-1)
             row_of = {link: i for i, link in enumerate(links)}
             sel = np.full(gather.shape, -1, np.int32)
@@ -753,7 +760,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         if idx == 0:
             raise ValueError("the root link has the identity pose; use plan_inverse_dynamics")
         tree = self._dynamics_walk()
-        chain = self._get_walk(("chain", idx) + (("folded",) if tree.folded else ()), targets=[idx], folded=tree.folded)
+        chain = self._get_walk(("chain", idx) + (("folded", tree.fold_key) if tree.folded else ()), targets=[idx],
+                               folded=tree.folded, fold_key=tree.fold_key)
         return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
                                              (chain.program, self._ops_f(chain), chain.ops_i),
                                              int(tree.program.op_of_link.get(idx, -1)),

@@ -455,9 +455,29 @@ def test_folded_dynamics_walk_matches_the_full_walk(robot):
     assert ((acc - acc_full).abs() / (1 + acc_full.abs())).max().item() < 1e-3
     for got, ref in zip((qg.grad, qdg.grad, qddg.grad), gin):
         assert (got - ref).abs().max().item() <= 1e-3 * max(ref.abs().max().item(), 1e-6)
-    # a learnable parameter switches folding off (gradients belong to the individual links)
+    # a link with learnable parameters stays an op of its own (its gradients are its own); the other leaves still fold
     from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
-    last = m._bodies[-1].name
-    m.make_link_param_learnable(last, "trans", UnconstrainedTensor(1, 3, init_tensor=m._bodies[-1].trans().detach().reshape(1, 3).clone()))
-    assert not m._dynamics_walk().folded
-    assert torch.allclose(m.compute_inverse_dynamics(q, qd, qdd).detach(), tau_full, **TOL_TAU)
+    from differentiable_robot_model_amd.flatten import foldable_links
+    last = len(m._bodies) - 1
+    assert foldable_links(m._spec)[last]
+    m.make_link_param_learnable(m._bodies[last].name, "trans",
+                                UnconstrainedTensor(1, 3, init_tensor=m._bodies[last].trans().detach().reshape(1, 3).clone()))
+    dw = m._dynamics_walk()
+    assert last in [int(i) for i in dw.program.links]
+    assert dw.program.n_ops == full.program.n_ops - int(foldable_links(m._spec, keep=[last]).sum())
+    tq = q.clone().requires_grad_(True)
+    tau_l = m.compute_inverse_dynamics(tq, qd, qdd)
+    assert torch.allclose(tau_l.detach(), tau_full, **TOL_TAU)
+    tau_l.backward(gtau)
+    assert (tq.grad - gin[0]).abs().max().item() <= 1e-3 * max(gin[0].abs().max().item(), 1e-6)
+    p = m._bodies[last].trans.param
+    _, gops = backend.rnea_backward(full.program, of, full.ops_i, q, qd, qdd, gtau, True, True, n, m._learnable_op_mask(full), False)
+    assert p.grad is not None and torch.isfinite(p.grad).all()
+    # dL/dtrans of the learnable link through the folded walk == through the full walk (the op's trans entries of grad_ops_f)
+    k = full.program.op_of_link[last]
+    perm_free = [int(full.program.gather[k, c]) % 32 for c in (7, 9, 11)]   # where the op row's trans entries come from
+    assert sorted(perm_free) == [9, 10, 11]
+    ref_t = torch.zeros(3, device="cuda")
+    for c in (7, 9, 11):
+        ref_t[int(full.program.gather[k, c]) % 32 - 9] += gops[k, c] * float(full.program.gsign[k, c])
+    assert torch.allclose(p.grad.reshape(-1), ref_t, rtol=1e-3, atol=1e-5 * max(1.0, float(ref_t.abs().max())))

@@ -241,10 +241,10 @@ def test_quaternion_on_branch_boundaries(emu):
 
 
 # ---------------------------------------------------------------------------------------------- folded fixed links
-def folded_host_walk(model, prog):
+def folded_host_walk(model, prog, fold=None):
     """host_walk on the folded link table (flatten.fold_link_table; robot_model._folded_table on the device)."""
     L1 = len(model._bodies) + 1
-    base = fold_link_table(model._spec, model._link_table().detach().cpu().numpy()[:L1])
+    base = fold_link_table(model._spec, model._link_table().detach().cpu().numpy()[:L1], fold)
     table = model._with_virtual_rows(torch.from_numpy(base.astype(np.float32))).numpy().reshape(-1)
     ops_f = np.ascontiguousarray((table[prog.gather.reshape(-1)] * prog.gsign.reshape(-1)).reshape(prog.capacity, 32),
                                  np.float32)
@@ -285,3 +285,31 @@ def test_folding_fixed_leaf_links_into_their_parents_leaves_the_dynamics_unchang
     _w, ops_f = folded_host_walk(m, chain)
     _w0, ops_f0 = host_walk(m, chain)
     assert np.array_equal(ops_f[:, :12], ops_f0[:, :12]) and not ops_f[chain.n_ops - 1, 12:25].any()
+
+
+def test_folding_keeps_learnable_links_and_what_would_fold_into_them(emu):
+    """foldable_links(keep=...): a link with learnable parameters stays an op of its own, and so does a fixed leaf whose fold
+    target is such a link; everything else still folds, and the dynamics are unchanged."""
+    m = load_model("allegro_left")
+    names = m._name_to_idx_map
+    tip, tip_parent = names["link_3.0_tip"], names["link_3.0"]
+    assert m._spec.parent[tip] == tip_parent
+    everything = foldable_links(m._spec)
+    assert everything[tip] and everything.sum() >= 4
+    keep_tip = foldable_links(m._spec, keep=[tip])
+    assert not keep_tip[tip] and keep_tip.sum() == everything.sum() - 1
+    keep_parent = foldable_links(m._spec, keep=[tip_parent])          # the tip would fold INTO a learnable link: it stays
+    assert not keep_parent[tip] and not keep_parent[tip_parent] and keep_parent.sum() == everything.sum() - 1
+    B, n = 11, m._n_dofs
+    q, qd, qdd = sample_states(m, B, seed=8)
+    full = build_walk(m._spec, whole_tree=True)
+    walk, _k = host_walk(m, full)
+    ref = np.zeros((B, n), np.float32)
+    assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(ref)) == 0
+    for fold in (keep_tip, keep_parent):
+        short = build_walk(m._spec, whole_tree=True, drop_folded=True, fold=fold)
+        assert short.n_ops == full.n_ops - int(fold.sum())
+        swalk, _k2 = folded_host_walk(m, short, fold)
+        tau = np.zeros((B, n), np.float32)
+        assert emu.emu_rnea(ctypes.byref(swalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(tau)) == 0
+        assert np.allclose(tau, ref, rtol=2e-5, atol=2e-5)
