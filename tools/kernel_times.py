@@ -62,6 +62,16 @@ for B in sizes:
     us = graph_time(lambda: backend.rnea_backward(dt.program, of, dt.ops_i, q, qd, qdd, gtau, True, True, 7, 0b10, True), launches=20)
     print("rnea bwd    panda B=%8d %9.2f us  %7.1f GB/s (196 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" %
           (B, us, B * 196 / us / 1e3, B / us / 1e3))
+    if B == sizes[0]:   # the walk the API runs for that case: the end-effector frame folded into link 7, link 2 learnable
+        from differentiable_robot_model_amd.rigid_body_params import UnconstrainedScalar
+        ml = load("panda_no_gripper")
+        ml.make_link_param_learnable("panda_link2", "mass", UnconstrainedScalar(init_val=2.0))
+    dl = ml._dynamics_walk(); ofl = ml._ops_f(dl).detach(); maskl = ml._learnable_op_mask(dl)
+    us = graph_time(lambda: backend.rnea_backward(dl.program, ofl, dl.ops_i, q, qd, qdd, gtau, True, True, 7, maskl, True), launches=20)
+    print("rnea bwd    panda B=%8d %9.2f us  the same on the %d-op walk the API builds (fixed tail folded)" % (B, us, dl.program.n_ops))
+    dfz = m._dynamics_walk()
+    us = graph_time(lambda: backend.rnea_backward(dfz.program, m._ops_f(dfz), dfz.ops_i, q, qd, qdd, gtau, True, True, 7, 0, True), launches=20)
+    print("rnea bwd    panda B=%8d %9.2f us  input gradients only (%d-op walk)" % (B, us, dfz.program.n_ops))
     idx = m._name_to_idx_map[link]
     df = m._get_walk(("fk", (idx,)), targets=[idx]); off = m._ops_f(df)
     pos = torch.empty(B, 1, 3, device="cuda"); quat = torch.empty(B, 1, 4, device="cuda")
