@@ -289,14 +289,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ);
-    constexpr int PER_WAVE = C_FLOATS + 4 * Q_FLOATS;
+    constexpr int PER_WAVE = C_FLOATS + 3 * Q_FLOATS; // constants + the three gradient tiles
     constexpr int NV = CAP * DRM_OPF_STRIDE, NACC = NV / WAVE;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int wave_id = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave, n_waves = (int)gridDim.x * MAX_WAVES_PER_BLOCK;
     float *lc = smem + wave * PER_WAVE;
-    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS, *lgt = lqdd + Q_FLOATS;
+    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS; // staging of grad_q / grad_qd / grad_qdd
 
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
     pin(cv);
@@ -315,21 +315,21 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
-        wave_lds_sync(); // the previous tile's staged gradients have left
-        tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-        tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
-        if (qdd) tile_load<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
-        tile_load<NJ>(gtau + b0 * NJ, WAVE, NJ, 0u, lgt, lane, true);
-        wave_lds_sync();
+        // every lane reads its own rows of q / qd / qdd / grad_tau straight into registers (28 contiguous bytes per lane and
+        // array: the cache lines are shared by neighbouring lanes; no LDS round trip, as in the forward arm kernels)
         float qv[NJ], qdv[NJ], qddv[NJ], gtv[NJ];
+        {
+            const int64_t r0 = (b0 + lane) * NJ;
 #pragma unroll
-        for (int d = 0; d < NJ; ++d) {
-            qv[d] = lq[lane * NJ + d];
-            qdv[d] = lqd[lane * NJ + d];
-            qddv[d] = qdd ? lqdd[lane * NJ + d] : 0.0f;
-            gtv[d] = lgt[lane * NJ + d];
+            for (int d = 0; d < NJ; ++d) qv[d] = q[r0 + d];
+#pragma unroll
+            for (int d = 0; d < NJ; ++d) qdv[d] = qd[r0 + d];
+#pragma unroll
+            for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? qdd[r0 + d] : 0.0f;
+#pragma unroll
+            for (int d = 0; d < NJ; ++d) gtv[d] = gtau[r0 + d];
         }
-        wave_lds_sync(); // all rows are in registers: the input tiles may be overwritten by the gradients
+        wave_lds_sync(); // the previous tile's staged gradients have left the LDS tiles
         float add[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) add[a] = 0.0f;
