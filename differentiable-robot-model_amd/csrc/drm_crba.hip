@@ -112,26 +112,27 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     static_assert((NJ & 1) && ((NJ * NJ) & 1), "odd row widths only (linear LDS images)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int NN = NJ * NJ;
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), H_FLOATS = round4(WAVE * NN);
-    constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + H_FLOATS;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, H_FLOATS = round4(WAVE * NN);
+    constexpr int PER_WAVE = C_FLOATS + H_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
-    float *lq = lc + C_FLOATS, *lh = lq + Q_FLOATS;
+    float *lh = lc + C_FLOATS;
     const int64_t b0 = (int64_t)tile * WAVE;
 
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
-    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    float qv[NJ];
+    {
+        const float *qrow = q + (b0 + lane) * NJ; // this lane's own row, straight into registers
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = qrow[d];
+    }
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
-
-    float qv[NJ];
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
     float *hrow = lh + lane * NN;
     crba_chain<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
                         [&](int i, int j, float v) { hrow[i * NJ + j] = v; });

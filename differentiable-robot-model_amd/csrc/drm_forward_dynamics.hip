@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
-    static_assert(3 * Q_FLOATS <= F_FLOATS, "the input tiles fit under the parking area");
+    static_assert(Q_FLOATS <= F_FLOATS, "the qdd tile fits under the parking area");
     constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -175,26 +175,25 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     if (tile >= n_tiles) return;
     const unsigned lane = threadIdx.x & 63u;
     float *lc = smem + wave * PER_WAVE;
-    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lf = lqd + Q_FLOATS;
-    float *park = lq + lane; // body forces between RNEA's sweeps: [link][6][64], over the (by then dead) input tiles
+    float *lq = lc + C_FLOATS;
+    float *park = lq + lane; // body forces between RNEA's sweeps: [link][6][64]; qdd is staged over them at the end
     const int64_t b0 = (int64_t)tile * WAVE;
 
+    // constant rows -> LDS (16 bytes per lane); every lane reads its own rows of q / qd / f straight into registers
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
-    tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-    tile_load<NJ>(qd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
-    tile_load<NJ>(f + b0 * NJ, WAVE, NJ, 0u, lf, lane, true);
+    float qv[NJ], qdv[NJ], rhs[NJ], zero[NJ], nle[NJ];
+    {
+        const int64_t r0 = (b0 + lane) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = q[r0 + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = qd[r0 + d];
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) { rhs[d] = f[r0 + d]; zero[d] = 0.0f; }
+    }
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
-    float qv[NJ], qdv[NJ], rhs[NJ], zero[NJ], nle[NJ];
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) {
-        qv[d] = lq[lane * NJ + d];
-        qdv[d] = lqd[lane * NJ + d];
-        rhs[d] = lf[lane * NJ + d];
-        zero[d] = 0.0f;
-    }
-    wave_lds_sync(); // all rows are in registers: the tiles may be overwritten
     auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
     // bias torques first (RNEA with qdd = 0), H afterwards: the 28 floats of the triangle are not live across the RNEA
     // walk, whose own peak is what decides between one and two waves per SIMD; cos / sin are shared by the two walks
