@@ -12,6 +12,8 @@
 
 namespace drm {
 
+constexpr int CRBA_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
+
 // Loop-structured composite-rigid-body algorithm of any robot (drm_tree.hpp crba_tree_walk): one tile of 64 samples per
 // block, one wavefront per segment.  The sub-trees off the fixed root give the diagonal blocks of H and everything between
 // two of them is a structural zero (an Allegro hand: four 4 x 4 blocks in a 16 x 16 matrix), so a wavefront keeps only ITS
@@ -57,25 +59,29 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     float *brow = lb + lane * Sb;
     float *hdst = H + (tc.b0 + lane) * nn;
     const TableLds &ctl = tab;
-    crba_prepare(first, last, ctl, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
-                 [&](int k, float c, float s, float x) {
-                     float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-                     b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
-                 });
-    crba_tree_walk(
-        first, last, ctl, [&](int k) { return tab.row(k); },
-        [&](int k, float &c, float &s, float &x) {
-            const float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-            c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
-        },
-        [&](int s, const Inertia &I) { lds_add_inertia(lis, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lis, s, lane, I); },
-        [&](int di, int dj, float v) {
-            if (DIRECT) {
-                if (live) hdst[di * n + dj] = v;
-            } else {
-                brow[(di - lo) * cnt + (dj - lo)] = v;
-            }
+    auto hout = [&](int di, int dj, float v) {
+        if (DIRECT) {
+            if (live) hdst[di * n + dj] = v;
+        } else {
+            brow[(di - lo) * cnt + (dj - lo)] = v;
+        }
+    };
+    auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
+    // a short serial segment (a finger): the unrolled walk with the joint transforms in registers; anything else: the loop
+    if (!crba_tree_walk_short<CRBA_SHORT_OPS>(first, last, ctl, [&](int k) { return tab.row(k); }, qf, hout)) {
+        crba_prepare(first, last, ctl, qf, [&](int k, float c, float s, float x) {
+            float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+            b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
         });
+        crba_tree_walk(
+            first, last, ctl, [&](int k) { return tab.row(k); },
+            [&](int k, float &c, float &s, float &x) {
+                const float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+                c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+            },
+            [&](int s, const Inertia &I) { lds_add_inertia(lis, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lis, s, lane, I); },
+            hout);
+    }
     if (!DIRECT) {
         __syncthreads();
         // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
@@ -87,10 +93,24 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         };
         float *g = H + tc.b0 * nn;
         if (tc.full && !(n & 3) && (align & AL_TAU)) {
+            // one 16-byte store per thread and round, linear in the tile: thread i writes float4 i.  The (sample, row, column)
+            // of a float4 is kept incrementally (no integer divisions in the loop) and its row's segment is looked up once.
             const unsigned per_row = (unsigned)n >> 2, per_sample = (unsigned)nn >> 2, total = WAVE * per_sample;
+            const unsigned row_magic = per_row > 1u ? 0xffffffffu / per_row + 1u : 0u; // j / per_row for j < 2^16 (per_row = 1: j)
+            unsigned b = threadIdx.x / per_sample, j = threadIdx.x - b * per_sample;
             for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
-                const unsigned b = i / per_sample, j = i - b * per_sample, r = j / per_row, c = (j - r * per_row) * 4u;
-                store16_wt(g + 4u * i, make_float4(entry(b, r, c), entry(b, r, c + 1u), entry(b, r, c + 2u), entry(b, r, c + 3u)));
+                const unsigned r = per_row > 1u ? __umulhi(j, row_magic) : j, c = (j - r * per_row) * 4u;
+                const int slo = lmap[r], scnt = lmap[n + r];
+                const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + (r - (unsigned)slo) * (unsigned)scnt;
+                float v[4];
+#pragma unroll
+                for (unsigned e = 0; e < 4u; ++e) {
+                    const unsigned cc = c + e - (unsigned)slo;
+                    v[e] = cc < (unsigned)scnt ? src[cc] : 0.0f;
+                }
+                store16_wt(g + 4u * i, make_float4(v[0], v[1], v[2], v[3]));
+                j += blockDim.x;
+                while (j >= per_sample) { j -= per_sample; ++b; }
             }
         } else {
             const unsigned total = (unsigned)tc.rows * (unsigned)nn;

@@ -16,6 +16,8 @@
 
 namespace drm {
 
+constexpr int FD_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
+
 // Loop-structured forward dynamics of any robot: one tile of 64 samples per block, one wavefront per segment of the walk.
 // Segments are independent (their joints share no link that moves), so H is block diagonal: every wavefront forms ITS
 // block (drm_tree.hpp crba_tree_walk, packed lower triangle with segment-local DoF indices), the bias torques of its
@@ -61,21 +63,25 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const unsigned row = lane * Sq;
     const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
-    crba_prepare(first, last, ctl, [&](int d) -> float { return live ? lq[row + d] : 0.0f; },
-                 [&](int k, float c, float s, float x) {
-                     float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-                     b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
-                 });
-    crba_tree_walk(
-        first, last, ctl, rowf,
-        [&](int k, float &c, float &s, float &x) {
-            const float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-            c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
-        },
-        [&](int s, const Inertia &I) { lds_add_inertia(lsl, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lsl, s, lane, I); },
-        [&](int di, int dj, float v) {
-            if (di >= dj) tri(tri_index(di - lo, dj - lo)) = v;
+    auto hput = [&](int di, int dj, float v) {
+        if (di >= dj) tri(tri_index(di - lo, dj - lo)) = v;
+    };
+    auto qval = [&](int d) -> float { return live ? lq[row + d] : 0.0f; };
+    // a short serial segment (a finger): the unrolled walk with the joint transforms in registers; anything else: the loop
+    if (!crba_tree_walk_short<FD_SHORT_OPS>(first, last, ctl, rowf, qval, hput)) {
+        crba_prepare(first, last, ctl, qval, [&](int k, float c, float s, float x) {
+            float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+            b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
         });
+        crba_tree_walk(
+            first, last, ctl, rowf,
+            [&](int k, float &c, float &s, float &x) {
+                const float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
+                c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+            },
+            [&](int s, const Inertia &I) { lds_add_inertia(lsl, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lsl, s, lane, I); },
+            hput);
+    }
     wave_lds_sync(); // the composite-inertia walk is done with the slot memory
     for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();

@@ -344,6 +344,90 @@ DRM_HD void crba_tree_walk(int a, int b, CTL ctl, ROW row, TRIG trig, IADD islot
     }
 }
 
+// The same for a SHORT SERIAL segment (ops a .. a + len - 1, each the child of the one before it, at most MAXOPS of them — a
+// finger of a hand, a leg): both loops unrolled, every op's joint transform built ONCE and kept in registers, nothing
+// parked.  The generic walk above rebuilds an ancestor's transform (12 LDS reads, 12 multiply-adds, a control-word decode)
+// for every (joint, ancestor) pair and parks cos / sin per op; here a 5-op finger costs about a third of its instructions.
+// Returns false (nothing done) when the segment is not such a chain — the caller then runs crba_tree_walk.
+//   qf(d) -> joint value of DoF d;   hout(di, dj, v) as above
+template <int MAXOPS, class CTL, class ROW, class QF, class HOUT>
+DRM_HD bool crba_tree_walk_short(int a, int b, CTL ctl, ROW row, QF qf, HOUT hout) {
+    const int len = b - a;
+    if (len < 1 || len > MAXOPS) return false;
+    int dofs[MAXOPS];
+    bool pris[MAXOPS];
+    bool serial = true;
+#pragma unroll
+    for (int i = 0; i < MAXOPS; ++i) {
+        dofs[i] = -1;
+        pris[i] = false;
+        if (i < len) {
+            int w0, w1;
+            ctl_words(ctl, a + i, w0, w1);
+            const OpCtl ct = decode_ctl(w0, w1);
+            dofs[i] = ct.dof;
+            pris[i] = ct.prismatic;
+            serial = serial && ct.save < 0 && (i == 0 || ct.parent == a + i - 1);
+        }
+    }
+    if (!serial) return false;
+    float J[MAXOPS][9], t[MAXOPS][3];
+#pragma unroll
+    for (int i = 0; i < MAXOPS; ++i) {
+        if (i < len) {
+            const OpFT o = load_ft(row(a + i));
+            float q = 0.0f, c = 1.0f, s = 0.0f;
+            if (dofs[i] >= 0) {
+                q = qf(dofs[i]);
+                if (!pris[i]) sincos_one(q, s, c);
+            }
+            joint_transform(o, dofs[i] >= 0, pris[i], q, c, s, J[i], t[i]);
+        }
+    }
+    Inertia carry;
+    inertia_zero(carry);
+#pragma unroll
+    for (int i = MAXOPS - 1; i >= 0; --i) {
+        if (i < len) {
+            const float *of = row(a + i);
+            Inertia tot;
+            tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) tot.h[x] = of[DRM_OPF_MCOM + x];
+            tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+            tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+            if (i < len - 1) inertia_add(tot, carry);
+            if (dofs[i] >= 0) {
+                Force F;
+                if (!pris[i]) {
+                    F.la[0] = f2_make(-tot.h[1], tot.I[2]);
+                    F.la[1] = f2_make(tot.h[0], tot.I[4]);
+                    F.la[2] = f2_make(0.0f, tot.I[5]);
+                    hout(dofs[i], dofs[i], tot.I[5]);
+                } else {
+                    F.la[0] = f2_make(0.0f, tot.h[1]);
+                    F.la[1] = f2_make(0.0f, -tot.h[0]);
+                    F.la[2] = f2_make(tot.m, 0.0f);
+                    hout(dofs[i], dofs[i], tot.m);
+                }
+#pragma unroll
+                for (int j = i - 1; j >= 0; --j) { // into the frame of op a + j (through op a + j + 1's transform)
+                    Force up;
+                    rnea_link_force_up(J[j + 1], t[j + 1], F, up);
+                    F = up;
+                    if (dofs[j] >= 0) {
+                        const float v = pris[j] ? F.la[2][0] : F.la[2][1];
+                        hout(dofs[j], dofs[i], v);
+                        hout(dofs[i], dofs[j], v);
+                    }
+                }
+            }
+            if (i > 0) inertia_to_parent(J[i], t[i], tot, carry);
+        }
+    }
+    return true;
+}
+
 // cos / sin / value of the joint of every op of [a, b), handed to `put(k, c, s, q)` (parked by the caller for crba_tree_walk)
 template <class CTL, class QF, class PUT>
 DRM_HD void crba_prepare(int a, int b, CTL ctl, QF qf, PUT put) {

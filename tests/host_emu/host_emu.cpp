@@ -253,7 +253,8 @@ void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
             auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
             auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
             auto hout = [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; };
-            crba_tree_walk(a0, b0, ctl, row, trig, iadd, itake, hout);
+            // as the kernels: the unrolled short-serial form where it applies, the loop otherwise
+            if (!crba_tree_walk_short<6>(a0, b0, ctl, row, qf, hout)) crba_tree_walk(a0, b0, ctl, row, trig, iadd, itake, hout);
         }
     }
 }
