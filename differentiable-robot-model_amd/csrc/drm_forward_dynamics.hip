@@ -41,7 +41,9 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
     float *park = smem + a.wave_off[wave];
-    float *lsl = park + (last - first) * (RNEA_PARK_FLOATS * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
+    // per-op records: RNEA's 9 floats, or just CRBA's 3 when every segment is short (the RNEA walk then keeps its own in registers)
+    const bool short_segments = a.max_seg_ops <= FD_SHORT_OPS;
+    float *lsl = park + (last - first) * ((short_segments ? CRBA_PARK_FLOATS : RNEA_PARK_FLOATS) * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
     float *lms = lsl, *lfs = lsl + a.n_slots * (12 * WAVE);
     float *ltri = lsl + a.n_slots * (18 * WAVE) + lane * pad_odd(nt); // this lane's packed triangle (LDS form)
     float *gtri = HBM ? scratch + ((int64_t)blockIdx.x * a.n_segments + wave) * (int64_t)nt_max * WAVE + lane : nullptr;
@@ -85,19 +87,22 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     wave_lds_sync(); // the composite-inertia walk is done with the slot memory
     for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();
-    // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f
-    rnea_tree_walk(
-        a.prefix_end, first, last, ctl, rowf, flags,
-        [&](int d, float &x, float &v, float &acc) {
-            x = live ? lq[row + d] : 0.0f;
-            v = lqd[row + d];
-            acc = 0.0f;
-        },
-        [&](int d, float v) { lf[row + d] -= v; },
-        [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
-        [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
-        [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
-        [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+    // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f.  Short segments (the fingers of a hand) take the
+    // unrolled walk that keeps its per-op records in registers (drm_tree.hpp rnea_tree_walk_short), as drm_rnea does.
+    auto park_f = [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); };
+    auto unpark_f = [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); };
+    auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
+    auto mload = [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); };
+    auto fadd = [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); };
+    auto ftake = [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); };
+    auto q_bias = [&](int d, float &x, float &v, float &acc) {
+        x = live ? lq[row + d] : 0.0f;
+        v = lqd[row + d];
+        acc = 0.0f;
+    };
+    auto tau_bias = [&](int d, float v) { lf[row + d] -= v; };
+    if (short_segments) rnea_tree_walk_short<FD_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, q_bias, tau_bias, msave, mload, fadd, ftake);
+    else rnea_tree_walk(a.prefix_end, first, last, ctl, rowf, flags, q_bias, tau_bias, park_f, unpark_f, msave, mload, fadd, ftake);
     ltdl_factor_acc(cnt, tri);
     ltdl_apply_acc(cnt, tri, lf + row + lo);
     if (flags & DRM_FD_REFINE) {
@@ -108,18 +113,14 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
         wave_lds_sync();
         float *lr = lres + row; // residual tile (same layout as lf)
-        rnea_tree_walk(
-            a.prefix_end, first, last, ctl, rowf, flags,
-            [&](int d, float &x, float &v, float &acc) {
-                x = live ? lq[row + d] : 0.0f;
-                v = lqd[row + d];
-                acc = (d >= lo && d < lo + cnt) ? lf[row + d] : 0.0f; // (prefix ops carry no DoF: every DoF read is this segment's)
-            },
-            [&](int d, float v) { lr[d] = (live ? f[(tc.b0 + lane) * n + d] : 0.0f) - v; },
-            [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
-            [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); },
-            [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
-            [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+        auto q_res = [&](int d, float &x, float &v, float &acc) {
+            x = live ? lq[row + d] : 0.0f;
+            v = lqd[row + d];
+            acc = (d >= lo && d < lo + cnt) ? lf[row + d] : 0.0f; // (prefix ops carry no DoF: every DoF read is this segment's)
+        };
+        auto tau_res = [&](int d, float v) { lr[d] = (live ? f[(tc.b0 + lane) * n + d] : 0.0f) - v; };
+        if (short_segments) rnea_tree_walk_short<FD_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, q_res, tau_res, msave, mload, fadd, ftake);
+        else rnea_tree_walk(a.prefix_end, first, last, ctl, rowf, flags, q_res, tau_res, park_f, unpark_f, msave, mload, fadd, ftake);
         ltdl_apply_acc(cnt, tri, lr + lo);
         for (int d = lo; d < lo + cnt; ++d) lf[row + d] += lr[d];
     }
@@ -147,7 +148,8 @@ static FdPlan fd_plan(const drm_walk *w) {
         const TreeArgs &a = p.a;
         const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n)); // q, qd, f -> qdd, residual
         p.hbm = hbm;
-        p.lds = sizeof(float) * layout_waves(p.a, shared, RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE, [&](int s) {
+        const int per_op = (a.max_seg_ops <= FD_SHORT_OPS ? CRBA_PARK_FLOATS : RNEA_PARK_FLOATS) * WAVE;
+        p.lds = sizeof(float) * layout_waves(p.a, shared, per_op, a.n_slots * 18 * WAVE, [&](int s) {
             const int c = a.seg_dof_cnt[s];
             return hbm ? 0 : round4(WAVE * pad_odd(c * (c + 1) / 2));
         });
