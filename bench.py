@@ -171,8 +171,8 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
     while not ev1.query():      # poll instead of sleeping in the driver: a blocking wait adds its wake-up latency
         pass                    # (10-20 us) to a timed region that is only ~80 us long at the driver's --steps 20
     torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
+    t1 = time.perf_counter()    # this rank's K steps are done; the caller takes the MAX over ranks
+    barrier()                   # (closing barrier of the bracket: its own latency, ~50 us over 8 GPUs, is not a step)
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, graph is not None
 
 
