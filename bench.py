@@ -339,10 +339,13 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     vmax = torch.tensor([j["velocity"] for j in lim], device=device)
     qd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()   # data_utils.py:70-98
     qdd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
-    plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
-    width = n + 3 + 4                                                    # tau | pos | quat = 56 B per row
-    packed = torch.empty(rows, width, device=device)
-    gathered = torch.empty(world * rows, width, device=device) if world > 1 and G % world == 0 else None
+    # tau | pos | quat of a shard live in ONE allocation (three contiguous blocks), so the collective sends the kernel's own
+    # output buffer: no packing kernel between the launch and the all-gather
+    width = n + 3 + 4                                                    # 56 B per row
+    flat = torch.empty(rows * width, device=device)
+    outs = (flat[:rows * n].view(rows, n), flat[rows * n:rows * (n + 3)].view(rows, 3), flat[rows * (n + 3):].view(rows, 4))
+    plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link, outputs=outs)
+    gathered = torch.empty(world * rows * width, device=device) if world > 1 and G % world == 0 else None
     if world > 1 and gathered is None:
         sys.exit("bench.py --config 3: 2^20 rows do not split evenly over %d ranks" % world)
 
@@ -351,8 +354,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
 
     def exchange():
         if world > 1:
-            torch.cat([plan.tau, plan.pos, plan.quat], dim=1, out=packed)
-            dist.all_gather_into_tensor(gathered, packed)
+            dist.all_gather_into_tensor(gathered, flat)   # rank r's blocks at gathered[r * rows * width:]
 
     def step():
         compute()
@@ -375,7 +377,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen,
         "config": {"workload": "Franka Panda 7-DoF, FK(panda_virtual_ee_link) + RNEA inverse dynamics (gravity, damping), "
                                "global batch %d = %d rows per GPU, q~U(limits), qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); "
-                               "one fused drm_fk_rnea launch + one all_gather_into_tensor of tau|pos|quat per step" % (G, rows),
+                               "one fused drm_fk_rnea launch + one all_gather_into_tensor of its output buffer (tau|pos|quat blocks) per step" % (G, rows),
                    "batch_per_gpu": rows, "global_batch": G, "parallelism": "batch-sharded x%d" % world,
                    "launch": "eager step (kernel + RCCL collective)", "gather": world > 1,
                    "gather_bytes_per_rank": rows * width * 4 if world > 1 else 0},

@@ -459,7 +459,8 @@ class FkInverseDynamicsPlan(object):
     serial 7-DoF arm whose last link is the target (Franka Panda, KUKA iiwa) that is ONE fused kernel; BASELINE
     configuration 3 (bench.py --config 3) runs it on every GPU's shard."""
 
-    def __init__(self, tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
+    def __init__(self, tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int,
+                 outputs=None):
         # tree / chain: (WalkProgram, ops_f, ops_i) of the whole-tree walk and of the root -> link walk
         self._lib = load_library()
         self.q, self.qd = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs)
@@ -467,9 +468,15 @@ class FkInverseDynamicsPlan(object):
         B, dev = self.q.shape[0], self.q.device
         if self.qd.shape[0] != B or (self.qdd is not None and self.qdd.shape[0] != B):
             raise ValueError("q / qd / qdd batch sizes differ")
-        self.tau = torch.empty(B, n_dofs, device=dev)
-        self.pos = torch.empty(B, 3, device=dev)
-        self.quat = torch.empty(B, 4, device=dev)
+        if outputs is None:
+            self.tau = torch.empty(B, n_dofs, device=dev)
+            self.pos = torch.empty(B, 3, device=dev)
+            self.quat = torch.empty(B, 4, device=dev)
+        else:   # caller-owned buffers (e.g. three views of ONE allocation that a collective then sends as it stands)
+            self.tau, self.pos, self.quat = outputs
+            for t, cols in ((self.tau, n_dofs), (self.pos, 3), (self.quat, 4)):
+                if t.shape != (B, cols) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                    raise ValueError("outputs must be contiguous float32 [B, %d] tensors on the inputs' device" % cols)
         self._keep = (tree[1], tree[2], chain[1], chain[2])
         self._tree = _walk_struct(tree[0], tree[1].detach(), tree[2], n_dofs)
         self._chain = _walk_struct(chain[0], chain[1].detach(), chain[2], n_dofs)

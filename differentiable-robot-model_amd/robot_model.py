@@ -747,12 +747,13 @@ class DifferentiableRobotModel(torch.nn.Module):
                                            bool(use_damping), self._n_dofs)
 
     def plan_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: Optional[torch.Tensor],
-                                     link_name: str, include_gravity: bool = True, use_damping: bool = True
-                                     ) -> "backend.FkInverseDynamicsPlan":
+                                     link_name: str, include_gravity: bool = True, use_damping: bool = True,
+                                     outputs=None) -> "backend.FkInverseDynamicsPlan":
         """Prepared launch of inverse dynamics + the pose of ``link_name`` on fixed buffers (drm_fk_rnea): what the
         reference computes with compute_inverse_dynamics (robot_model.py:305-375) followed by
         compute_forward_kinematics (robot_model.py:223-248) on the same q.  One fused kernel for a serial 7-DoF arm
-        whose last link is the target, the two walks back to back otherwise."""
+        whose last link is the target, the two walks back to back otherwise.  ``outputs``: caller-owned (tau [B,n], pos [B,3],
+        quat [B,4]) buffers to write into."""
         self._require_device()
         assert q.ndim == 2 and q.shape[1] == self._n_dofs
         assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
@@ -765,7 +766,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
                                              (chain.program, self._ops_f(chain), chain.ops_i),
                                              int(tree.program.op_of_link.get(idx, -1)),
-                                             q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs)
+                                             q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs,
+                                             outputs=outputs)
 
     @tensor_check
     def compute_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor, link_name: str,

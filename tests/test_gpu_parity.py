@@ -481,3 +481,22 @@ def test_folded_dynamics_walk_matches_the_full_walk(robot):
     for c in (7, 9, 11):
         ref_t[int(full.program.gather[k, c]) % 32 - 9] += gops[k, c] * float(full.program.gsign[k, c])
     assert torch.allclose(p.grad.reshape(-1), ref_t, rtol=1e-3, atol=1e-5 * max(1.0, float(ref_t.abs().max())))
+
+
+def test_fused_plan_writes_into_caller_owned_output_blocks():
+    """plan_fk_and_inverse_dynamics(outputs=...): tau | pos | quat as three contiguous blocks of ONE buffer (what bench.py
+    --config 3 hands to the all-gather as it stands) — same values as the plan's own buffers."""
+    m = load_model("panda_no_gripper", "cuda")
+    B, n = 4096, m._n_dofs
+    q, qd, qdd = (dev(a) for a in sample_states(m, B, seed=91))
+    flat = torch.full((B * (n + 7),), float("nan"), device="cuda")
+    outs = (flat[:B * n].view(B, n), flat[B * n:B * (n + 3)].view(B, 3), flat[B * (n + 3):].view(B, 4))
+    plan = m.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link", outputs=outs)
+    plan.launch()
+    ref = m.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link")
+    ref.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.tau, ref.tau) and torch.equal(plan.pos, ref.pos) and torch.equal(plan.quat, ref.quat)
+    assert not torch.isnan(flat).any()
+    with pytest.raises(ValueError):
+        m.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link", outputs=(outs[0], outs[1], outs[2][:, :3]))
