@@ -23,6 +23,7 @@ namespace drm {
 
 constexpr int REC_FLOATS = 26, SLOT_FLOATS = 36; // (REC_FLOATS: the conservative per-op figure of the scratch query)
 constexpr int TRIG_FLOATS = 2, LEAF_FLOATS = 18;
+constexpr int BWD_SHORT_OPS = 6; // segments of up to this many ops in a row take rnea_backward_walk_short in the fanned-out kernel
 __host__ __device__ static inline int record_floats(int n_ops, int n_leaves) { return (n_ops * TRIG_FLOATS + n_leaves * LEAF_FLOATS) * WAVE; }
 
 // One kernel for every walk: the sweeps loop over the n_ops links (drm_sample.hpp rnea_backward_walk), so neither the
@@ -252,8 +253,11 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
                 if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
             }
         };
-        rnea_backward_walk(ops_f, ctl, fa.p_end, a, b, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
-                           slot_add, slot_take, gout, param_out);
+        // a short serial segment (a finger): the unrolled walk that parks nothing; anything else: the loops
+        if (!rnea_backward_walk_short<BWD_SHORT_OPS>(ops_f, ctl, fa.p_end, a, b, flags, param_mask, gq != nullptr, qf, gt, slot_put,
+                                                     slot_get, gout, param_out))
+            rnea_backward_walk(ops_f, ctl, fa.p_end, a, b, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
+                               slot_add, slot_take, gout, param_out);
         __syncthreads();
         if (gq) {
             if (wave == 0) tile_store<0>(gq + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_POS), full && (align & AL_POS));

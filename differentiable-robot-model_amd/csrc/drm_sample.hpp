@@ -1456,6 +1456,140 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
     }
 }
 
+// The same walk for a SHORT SERIAL segment with revolute / fixed joints only (ops a .. b - 1, each the child of the one before
+// it, at most MAXOPS of them, none a branch point — a finger of a hand): both sweeps unrolled, cos / sin of the joints in
+// registers, NOTHING parked: like rnea_backward_chain, the way down starts from the tip's motion and force adjoint and recovers
+// every parent's.  The static prefix (fixed joints by construction) is replayed in a loop for its motions and branch-point slots.
+// Returns false (nothing done) when the segment is not of that shape — the caller then runs rnea_backward_walk.
+template <int MAXOPS, class QF, class GT, class SPUT, class SGET, class GOUT, class PG>
+DRM_HD bool rnea_backward_walk_short(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int p_end, int a, int b,
+                                     int flags, uint32_t param_mask, bool want_gq, QF qf, GT gtau, SPUT slot_put, SGET slot_get,
+                                     GOUT gout, PG param_out) {
+    const int len = b - a;
+    if (len < 1 || len > MAXOPS) return false;
+    int dofs[MAXOPS], src0 = DRM_SRC_ROOT;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < MAXOPS; ++i) {
+        dofs[i] = -1;
+        if (i < len) {
+            const int c = ctl[a + i];
+            dofs[i] = ctl_field(c, DRM_OPI_DOF);
+            const bool next = ctl_field(c, DRM_OPI_FLAGS) & DRM_FLAG_CHILD_IS_NEXT;
+            ok = ok && !ctl_prismatic(c) && ctl_field(c, DRM_OPI_SAVE) < 0 && next == (i + 1 < len) &&
+                 (i == 0 || ctl_field(c, DRM_OPI_SRC) == DRM_SRC_PREV);
+            if (i == 0) src0 = ctl_field(c, DRM_OPI_SRC);
+        }
+    }
+    if (!ok || (src0 == DRM_SRC_PREV && a != p_end)) return false; // (PREV at the head: the op before it must be the prefix tip)
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    const bool damping = flags & DRM_RNEA_DAMPING;
+    // ---- the prefix: motions of its (fixed) links, branch points into their slots (tbar of a prefix link is zero) ----
+    Motion M;
+    motion_root(M, g);
+#pragma unroll 1
+    for (int k = 0; k < p_end; ++k) {
+        const int c = ctl[k];
+        const int src = ctl_field(c, DRM_OPI_SRC), save = ctl_field(c, DRM_OPI_SAVE);
+        const OpFT o = load_ft(opf + k * DRM_OPF_STRIDE);
+        float rec[12];
+        if (src == DRM_SRC_ROOT) motion_root(M, g);
+        if (src >= 0) { slot_get(src, 0, rec, 12); motion_from_floats(rec, M); }
+        rnea_link_motion(o.F, o.t, 0.0f, 0.0f, M, M);
+        if (save >= 0) {
+            const float zero6[6] = {0, 0, 0, 0, 0, 0};
+            motion_to_floats(M, rec);
+            slot_put(save, 0, rec, 12);
+            slot_put(save, 18, zero6, 6);
+        }
+    }
+    if (src0 == DRM_SRC_ROOT) motion_root(M, g);
+    if (src0 >= 0) { float rec[12]; slot_get(src0, 0, rec, 12); motion_from_floats(rec, M); }
+    const bool rooted = src0 == DRM_SRC_ROOT; // the head's parent is the world: no force adjoint comes from above, none goes up
+    // ---- up ---------------------------------------------------------------------------------------------------------
+    float cs[MAXOPS], sn[MAXOPS], wjs[MAXOPS], ajs[MAXOPS];
+    f2 T[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
+    auto joint = [&](int i, float *J, float *t) {
+        const OpFT o = load_ft(opf + (a + i) * DRM_OPF_STRIDE);
+        joint_rot_z(o.F, cs[i], sn[i], J); // (cos, sin) = (1, 0) for a fixed joint: J == F exactly
+        t[0] = o.t[0]; t[1] = o.t[1]; t[2] = o.t[2];
+    };
+#pragma unroll
+    for (int i = 0; i < MAXOPS; ++i) {
+        cs[i] = 1.0f; sn[i] = 0.0f; wjs[i] = 0.0f; ajs[i] = 0.0f;
+        if (i < len) {
+            if (dofs[i] >= 0) {
+                float q;
+                qf(dofs[i], q, wjs[i], ajs[i]);
+                sincos_one(q, sn[i], cs[i]);
+            }
+            float J[9], t[3];
+            joint(i, J, t);
+            rnea_link_motion(J, t, wjs[i], ajs[i], M, M);
+            if (i > 0 || !rooted) {
+                f2 Tn[3];
+                tbar_child(J, t, T, Tn);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) T[x] = Tn[x];
+            }
+            if (dofs[i] >= 0) T[2][1] += gtau(dofs[i]);
+        }
+    }
+    // ---- down -------------------------------------------------------------------------------------------------------
+    Motion B;
+    Force carry;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { B.wa[x] = B.va[x] = carry.la[x] = f2_bcast(0.0f); }
+#pragma unroll
+    for (int i = MAXOPS - 1; i >= 0; --i) {
+        if (i < len) {
+            const int k = a + i;
+            const float *of = opf + k * DRM_OPF_STRIDE;
+            float J[9], t[3];
+            joint(i, J, t);
+            const float gtk = dofs[i] >= 0 ? gtau(dofs[i]) : 0.0f;
+            const bool has_parent = i > 0 || !rooted;
+            Motion Pm;
+            f2 U[3];
+            if (has_parent) {
+                motion_parent(J, t, wjs[i], ajs[i], false, M, Pm);
+                f2 x[3] = {T[0], T[1], T[2]};
+                x[2][1] -= gtk;
+                tbar_parent(J, t, x, U);
+            } else {
+                motion_root(Pm, g);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) U[x] = f2_bcast(0.0f);
+            }
+            Force tot;
+            f2 hgl[3], hga[3];
+            rnea_body_force_hg(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, tot, hgl, hga);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) tot.la[x] += carry.la[x];
+            LinkAdjointP A;
+            rnea_link_adjoint_packed(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wjs[i], M, hgl, hga, T, tot, has_parent,
+                                     B, A);
+            if (want_gq && dofs[i] >= 0) gout(dofs[i], A.gq, A.wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), A.ajb);
+            if ((param_mask >> k) & 1u) {
+                float gr[DRM_OPF_STRIDE];
+                const float ub[6] = {U[0][0], U[1][0], U[2][0], U[0][1], U[1][1], U[2][1]};
+                rnea_link_param_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, cs[i], sn[i], M, Pm, T, ub, tot,
+                                        has_parent, B, A, gr);
+                gr[DRM_OPF_DAMP] = damping ? gtk * wjs[i] : 0.0f;
+                param_out(k, gr);
+            }
+            if (i > 0) rnea_link_force_up(J, t, tot, carry);
+            B = A.pb;
+            M = Pm;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) T[x] = U[x];
+        }
+    }
+    return true;
+}
+
 // Reverse-mode RNEA of a serial chain (DRM_WALK_ARM_CHAIN): the sweeps of rnea_backward_walk without the int table, slots
 // or parked records — and without ANY per-link storage.  Every joint transform is orthogonal, so what the forward sweeps
 // (A: motions, C: force adjoints) leave at the tip of the chain is enough: sweep D recovers each parent's motion and

@@ -223,8 +223,10 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
         if (w->n_segments > 1 && !(mask & prefix_mask)) {
             for (int seg = 0; seg < w->n_segments; ++seg) {
                 for (auto &s : slots) for (float &x : s) x = 0.f;
-                rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1], flags,
-                                   mask, gq != nullptr, qf, gt, park, unpark, sput, sget, sadd, stake, gout, pout);
+                if (!rnea_backward_walk_short<6>(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->prefix_end, w->seg_begin[seg],
+                                                 w->seg_begin[seg + 1], flags, mask, gq != nullptr, qf, gt, sput, sget, gout, pout))
+                    rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1],
+                                       flags, mask, gq != nullptr, qf, gt, park, unpark, sput, sget, sadd, stake, gout, pout);
             }
         } else {
             rnea_backward_walk(w->ops_f, w->ops_i + DRM_OPI_CTRL * CAP, 0, 0, w->n_ops, flags, mask, gq != nullptr, qf, gt, park, unpark,
