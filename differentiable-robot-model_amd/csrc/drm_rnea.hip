@@ -14,11 +14,12 @@ namespace drm {
 
 // Loop-structured RNEA of any robot (drm_tree.hpp rnea_tree_walk, block layout in drm_tree_dev.hpp): one tile of 64
 // samples per block, one wavefront per segment of the walk.
-// LDS: [ table ][ q ][ qd ][ qdd ][ tau ] shared, then per wavefront [ records : max_seg_ops * 9 * 64 ]
+// LDS: [ table ][ tau ]([ q ][ qd ][ qdd ] in the SHORT form) shared, then per wavefront [ body forces : ops * 6 * 64 ]
 //      [ motion slots : n_slots * 12 * 64 ][ force slots : n_slots * 6 * 64 ]   (per-wavefront areas: TreeArgs.wave_off)
 // SHORT > 0: no segment has more than SHORT ops (the fingers of a hand): drm_tree.hpp rnea_tree_walk_short keeps the per-op
 // records in registers, the per-wavefront LDS area holds the save slots only.
 constexpr int RNEA_SHORT_OPS = 6;
+constexpr int RNEA_FORCE_FLOATS = 6; // what this kernel parks per op between the sweeps: the body force
 template <int SHORT>
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     rnea_tree_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
@@ -28,20 +29,29 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
-    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lqdd = lqd + region, *ltau = lqdd + region;
+    constexpr bool tiles = SHORT > 0; // the short form stages the inputs of a tile in LDS once for its wavefronts (see below)
+    float *ltau = smem + table_lds_floats(a.n_ops);
+    float *lq = ltau + region, *lqd = lq + region, *lqdd = lqd + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     float *park = smem + a.wave_off[wave];
-    float *lms = park + (SHORT ? 0 : (last - first) * (RNEA_PARK_FLOATS * WAVE)); // motion slots [slot][12][64]
+    float *lms = park + (SHORT ? 0 : (last - first) * (RNEA_FORCE_FLOATS * WAVE)); // motion slots [slot][12][64]
     float *lfs = lms + a.n_slots * (12 * WAVE);                     // force slots  [slot][6][64]
 
+    // LDS per sample is what bounds the wavefronts per CU of a big single-segment robot (an arm carrying a hand: one
+    // wavefront per CU with the inputs staged and 9 floats parked per op), so: the joint state is read straight from each
+    // lane's rows of q / qd / qdd (two or three reads per op, cache hits after the first), only the body force is parked
+    // (6 floats per op: cos / sin are recomputed on the way back), and the one LDS tile left is tau's, for a coalesced store.
+    // The SHORT form (fingers of a hand, a wavefront each; nothing parked) stages the three input tiles once per block, as
+    // before: they are shared, and the form is bounded by registers (96 VGPR = five waves per SIMD), not by LDS.
     const TableLds tab = stage_tree_table(a, smem);
     const bool fast = tc.full && (n & 1);
-    // the three input tiles are loaded by the first three wavefronts of the block (by one, if it is alone)
-    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
-    if (wave == (a.n_segments > 1 ? 1 : 0))
-        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
-    if (qdd && wave == (a.n_segments > 2 ? 2 : 0))
-        tile_load<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
+    if constexpr (tiles) {
+        if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+        if (wave == (a.n_segments > 1 ? 1 : 0))
+            tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+        if (qdd && wave == (a.n_segments > 2 ? 2 : 0))
+            tile_load<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
+    }
     for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     __syncthreads();
 
@@ -52,10 +62,17 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const bool has_qdd = qdd != nullptr;
     const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
+    const int64_t grow = (tc.b0 + (live ? (int64_t)lane : 0)) * n; // (lanes past a partial tile read row 0 of it, then zeros)
     auto qf = [&](int d, float &x, float &v, float &acc) {
-        x = live ? lq[row + d] : 0.0f;
-        v = lqd[row + d];
-        acc = has_qdd ? lqdd[row + d] : 0.0f;
+        if constexpr (tiles) {
+            x = live ? lq[row + d] : 0.0f;
+            v = lqd[row + d];
+            acc = has_qdd ? lqdd[row + d] : 0.0f;
+        } else {
+            x = live ? q[grow + d] : 0.0f;
+            v = live ? qd[grow + d] : 0.0f;
+            acc = (has_qdd && live) ? qdd[grow + d] : 0.0f;
+        }
     };
     auto tau_out = [&](int d, float v) { ltau[row + d] = v; };
     auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
@@ -67,9 +84,26 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     } else {
         rnea_tree_walk(
             a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out,
-            [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); },
-            [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); }, msave, mload,
-            fadd, ftake);
+            [&](int k, const Force &F, float, float, float) {
+                float *b = park + (k - first) * (RNEA_FORCE_FLOATS * WAVE) + lane;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
+            },
+            [&](int k, Force &F, float &c, float &s, float &x) {
+                const float *b = park + (k - first) * (RNEA_FORCE_FLOATS * WAVE) + lane;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                x = 0.0f; c = 1.0f; s = 0.0f;
+                if (ct.dof >= 0) {
+                    float v, acc;
+                    qf(ct.dof, x, v, acc);
+                    if (!ct.prismatic) sincos_one(x, s, c);
+                }
+            },
+            msave, mload, fadd, ftake);
     }
     __syncthreads();
     if (wave == 0)
@@ -78,8 +112,9 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
 
 // LDS bytes of a launch (fills a.wave_off)
 static size_t rnea_tree_lds(TreeArgs &a, bool records_in_registers) {
-    const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n));
-    return sizeof(float) * layout_waves(a, shared, records_in_registers ? 0 : RNEA_PARK_FLOATS * WAVE, a.n_slots * 18 * WAVE,
+    // table + the tau tile (+ the three input tiles when several wavefronts share them)
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + (records_in_registers ? 4 : 1) * (size_t)round4(WAVE * pad_odd(a.n));
+    return sizeof(float) * layout_waves(a, shared, records_in_registers ? 0 : RNEA_FORCE_FLOATS * WAVE, a.n_slots * 18 * WAVE,
                                         [](int) { return 0; });
 }
 
