@@ -12,6 +12,7 @@
 
 namespace drm {
 
+constexpr int CRBA_BLOCKS = 0, CRBA_TRIANGLE = 1, CRBA_DIRECT = 2; // how a segment's part of H reaches HBM (crba_tree_kernel<MODE>)
 constexpr int CRBA_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
 
 // Loop-structured composite-rigid-body algorithm of any robot (drm_tree.hpp crba_tree_walk): one tile of 64 samples per
@@ -23,12 +24,12 @@ constexpr int CRBA_SHORT_OPS = 6; // segments of up to this many ops in a row ta
 // 2^20 samples; this form: see profiles/.)
 // LDS: [ table ][ q : 64 (n|1) ][ segment map : dof -> (segment's first dof, its dof count, its block's LDS offset) ]
 //      shared, then per wavefront [ cos / sin / value per op : ops * 3 * 64 ][ inertia slots : n_slots * 10 * 64 ]
-//      [ block : 64 (cnt^2|1), unless DIRECT ]
-// DIRECT: a block does not fit (a single segment with more than ~23 DoFs): lanes store their entries straight to HBM over
-// a zeroed H.
-template <bool DIRECT>
+//      [ block : 64 (cnt^2 | 1), or (CRBA_TRIANGLE) 64 (cnt (cnt + 1) / 2 | 1), or (CRBA_DIRECT) nothing: lanes store their
+//        entries straight to HBM over a zeroed H ]
+template <int MODE>
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t align) {
+    constexpr bool DIRECT = MODE == CRBA_DIRECT, TRI = MODE == CRBA_TRIANGLE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileCtx tc = tile_begin(B);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -38,7 +39,8 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     float *lq = smem + table_lds_floats(a.n_ops);
     int *lmap = reinterpret_cast<int *>(lq + round4(WAVE * Sq)); // [3][n]: segment lo, cnt, block offset (floats) per DoF
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
-    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], Sb = pad_odd(cnt * cnt);
+    // staged per segment: the cnt x cnt block, or (TRI: one big segment) the lower triangle of the symmetric block
+    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], Sb = pad_odd(TRI ? cnt * (cnt + 1) / 2 : cnt * cnt);
     float *ltr = smem + a.wave_off[wave];                          // [op - first][3][64]
     float *lis = ltr + (last - first) * (CRBA_PARK_FLOATS * WAVE); // inertia slots [slot][10][64]
     float *lb = lis + a.n_slots * (10 * WAVE);                     // this segment's block of H: [64][cnt^2 | 1]
@@ -62,6 +64,8 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     auto hout = [&](int di, int dj, float v) {
         if (DIRECT) {
             if (live) hdst[di * n + dj] = v;
+        } else if (TRI) {
+            if (di >= dj) brow[tri_index(di - lo, dj - lo)] = v;
         } else {
             brow[(di - lo) * cnt + (dj - lo)] = v;
         }
@@ -87,9 +91,11 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
         auto entry = [&](unsigned b, unsigned r, unsigned c) -> float {
             const int slo = lmap[r], scnt = lmap[n + r];
-            const unsigned cc = c - (unsigned)slo;
+            const unsigned cc = c - (unsigned)slo, rr = r - (unsigned)slo;
             if (cc >= (unsigned)scnt) return 0.0f;
-            return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + (r - (unsigned)slo) * (unsigned)scnt + cc];
+            if (!TRI) return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + rr * (unsigned)scnt + cc];
+            const unsigned hi = rr > cc ? rr : cc, lw = rr > cc ? cc : rr;
+            return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * (scnt + 1) / 2) + hi * (hi + 1u) / 2u + lw];
         };
         float *g = H + tc.b0 * nn;
         if (tc.full && !(n & 3) && (align & AL_TAU)) {
@@ -101,12 +107,16 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
             for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
                 const unsigned r = per_row > 1u ? __umulhi(j, row_magic) : j, c = (j - r * per_row) * 4u;
                 const int slo = lmap[r], scnt = lmap[n + r];
-                const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + (r - (unsigned)slo) * (unsigned)scnt;
+                const unsigned rr = r - (unsigned)slo, rbase = TRI ? rr * (rr + 1u) / 2u : rr * (unsigned)scnt;
+                const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(TRI ? scnt * (scnt + 1) / 2 : scnt * scnt);
                 float v[4];
 #pragma unroll
                 for (unsigned e = 0; e < 4u; ++e) {
                     const unsigned cc = c + e - (unsigned)slo;
-                    v[e] = cc < (unsigned)scnt ? src[cc] : 0.0f;
+                    if (TRI) // entry (rr, cc) of the symmetric block from its packed lower triangle
+                        v[e] = cc >= (unsigned)scnt ? 0.0f : cc <= rr ? src[rbase + cc] : src[cc * (cc + 1u) / 2u + rr];
+                    else
+                        v[e] = cc < (unsigned)scnt ? src[rbase + cc] : 0.0f;
                 }
                 store16_wt(g + 4u * i, make_float4(v[0], v[1], v[2], v[3]));
                 j += blockDim.x;
@@ -192,34 +202,44 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     TreeArgs a = tree_args(w);
-    auto plan = [&](TreeArgs &t, bool with_blocks) {
+    // how a segment's part of H is staged: its cnt x cnt block (small segments: the fingers of a hand), the lower
+    // triangle of its symmetric block (a segment of more than 8 DoF: half the LDS), or not at all (DIRECT: lanes store their entries
+    // straight to HBM over a memset) when staging would leave fewer than two blocks per CU — a big walk (an arm carrying a
+    // hand, 23 DoF) is bound by the latency of its serial ancestor walks, so wavefronts per CU matter more to it than
+    // coalesced stores (measured at 2^20: 3.7 ms direct against 11 ms with one staged wavefront per CU).
+    auto plan = [&](TreeArgs &t, int mode) {
         const size_t shared = (size_t)table_lds_floats(t.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n);
         return sizeof(float) * layout_waves(t, shared, CRBA_PARK_FLOATS * WAVE, t.n_slots * 10 * WAVE, [&](int sg) {
             const int c = t.seg_dof_cnt[sg];
-            return with_blocks ? round4(WAVE * pad_odd(c * c)) : 0;
+            return mode == CRBA_DIRECT ? 0 : round4(WAVE * pad_odd(mode == CRBA_TRIANGLE ? c * (c + 1) / 2 : c * c));
         });
     };
-    // every segment keeps its cnt x cnt block of 64 samples in LDS; when that does not fit a CU the entries go straight to
-    // HBM over a memset instead (one segment with more than ~23 DoFs)
-    bool direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
-    if (direct && a.n_segments > 1) {
+    int max_cnt = 0;
+    for (int sg = 0; sg < a.n_segments; ++sg) max_cnt = a.seg_dof_cnt[sg] > max_cnt ? a.seg_dof_cnt[sg] : max_cnt;
+    int mode = max_cnt <= 8 ? CRBA_BLOCKS : CRBA_TRIANGLE; // (small blocks: the plain indexing of a full block is cheaper to assemble)
+    if (plan(a, mode) > (size_t)MAX_LDS_BYTES && a.n_segments > 1) {
         a = tree_args(w, true);
-        direct = plan(a, true) > (size_t)MAX_LDS_BYTES;
+        mode = CRBA_TRIANGLE;
     }
-    const size_t lds = plan(a, !direct);
+    if (plan(a, mode) > (size_t)MAX_LDS_BYTES / 2) mode = CRBA_DIRECT;
+    const size_t lds = plan(a, mode);
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
-    if (direct) {
+    if (mode == CRBA_DIRECT) {
         hipError_t e = hipMemsetAsync(H, 0, sizeof(float) * (size_t)B * nn, s);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-        rc = ensure_lds_tree(crba_tree_kernel<true>, lds);
+        rc = ensure_lds_tree(crba_tree_kernel<CRBA_DIRECT>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
+        hipLaunchKernelGGL(crba_tree_kernel<CRBA_DIRECT>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
+    } else if (mode == CRBA_TRIANGLE) {
+        rc = ensure_lds_tree(crba_tree_kernel<CRBA_TRIANGLE>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(crba_tree_kernel<CRBA_TRIANGLE>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
     } else {
-        rc = ensure_lds_tree(crba_tree_kernel<false>, lds);
+        rc = ensure_lds_tree(crba_tree_kernel<CRBA_BLOCKS>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
+        hipLaunchKernelGGL(crba_tree_kernel<CRBA_BLOCKS>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
     }
     return launched();
 }

@@ -17,6 +17,7 @@
 namespace drm {
 
 constexpr int FD_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
+constexpr int FD_FORCE_FLOATS = 6; // what the RNEA walks of this kernel park per op: the body force
 
 // Loop-structured forward dynamics of any robot: one tile of 64 samples per block, one wavefront per segment of the walk.
 // Segments are independent (their joints share no link that moves), so H is block diagonal: every wavefront forms ITS
@@ -37,13 +38,17 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
-    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lf = lqd + region, *lres = lf + region;
+    // Every segment short (fingers): the four tiles of round 1, shared by the wavefronts.  Otherwise (an arm carrying a gripper
+    // or a hand: LDS per sample is what bounds the wavefronts per CU) q and qd are read straight from global memory and only
+    // the f -> rhs -> qdd tile and the residual tile are staged.
+    const bool short_segments = a.max_seg_ops <= FD_SHORT_OPS;
+    float *lf = smem + table_lds_floats(a.n_ops), *lres = lf + region, *lq = lres + region, *lqd = lq + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
     float *park = smem + a.wave_off[wave];
-    // per-op records: RNEA's 9 floats, or just CRBA's 3 when every segment is short (the RNEA walk then keeps its own in registers)
-    const bool short_segments = a.max_seg_ops <= FD_SHORT_OPS;
-    float *lsl = park + (last - first) * ((short_segments ? CRBA_PARK_FLOATS : RNEA_PARK_FLOATS) * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
+    // per-op records: the body force of the RNEA walk (6 floats; cos / sin are recomputed on the way back), or just CRBA's 3
+    // when every segment is short (the RNEA walk then keeps its own in registers)
+    float *lsl = park + (last - first) * ((short_segments ? CRBA_PARK_FLOATS : FD_FORCE_FLOATS) * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
     float *lms = lsl, *lfs = lsl + a.n_slots * (12 * WAVE);
     float *ltri = lsl + a.n_slots * (18 * WAVE) + lane * pad_odd(nt); // this lane's packed triangle (LDS form)
     float *gtri = HBM ? scratch + ((int64_t)blockIdx.x * a.n_segments + wave) * (int64_t)nt_max * WAVE + lane : nullptr;
@@ -51,9 +56,11 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
 
     const TableLds tab = stage_tree_table(a, smem);
     const bool fast = tc.full && (n & 1);
-    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
-    if (wave == (a.n_segments > 1 ? 1 : 0))
-        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+    if (short_segments) {
+        if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+        if (wave == (a.n_segments > 1 ? 1 : 0))
+            tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+    }
     if (wave == (a.n_segments > 2 ? 2 : 0))
         tile_load<0>(f + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
     for (int s = 0; s < a.n_slots * 10; ++s) lsl[s * WAVE + lane] = 0.0f;
@@ -63,12 +70,15 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     // lanes past a partial tile read zeros (see drm_fk.hip); their H is then a valid inertia matrix as well
     const bool live = (int)lane < tc.rows;
     const unsigned row = lane * Sq;
+    const int64_t grow = (tc.b0 + (live ? (int64_t)lane : 0)) * n;
+    auto q_at = [&](int d) -> float { return !live ? 0.0f : short_segments ? lq[row + d] : q[grow + d]; };
+    auto qd_at = [&](int d) -> float { return short_segments ? lqd[row + d] : (live ? qd[grow + d] : 0.0f); };
     const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
     auto hput = [&](int di, int dj, float v) {
         if (di >= dj) tri(tri_index(di - lo, dj - lo)) = v;
     };
-    auto qval = [&](int d) -> float { return live ? lq[row + d] : 0.0f; };
+    auto qval = [&](int d) -> float { return q_at(d); };
     // a short serial segment (a finger): the unrolled walk with the joint transforms in registers; anything else: the loop
     if (!crba_tree_walk_short<FD_SHORT_OPS>(first, last, ctl, rowf, qval, hput)) {
         crba_prepare(first, last, ctl, qval, [&](int k, float c, float s, float x) {
@@ -89,15 +99,31 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     wave_lds_sync();
     // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f.  Short segments (the fingers of a hand) take the
     // unrolled walk that keeps its per-op records in registers (drm_tree.hpp rnea_tree_walk_short), as drm_rnea does.
-    auto park_f = [&](int k, const Force &F, float c, float s, float x) { lds_park_rnea(park, k - first, lane, F, c, s, x); };
-    auto unpark_f = [&](int k, Force &F, float &c, float &s, float &x) { lds_unpark_rnea(park, k - first, lane, F, c, s, x); };
+    auto park_f = [&](int k, const Force &F, float, float, float) {
+        float *b = park + (k - first) * (FD_FORCE_FLOATS * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
+    };
+    auto unpark_f = [&](int k, Force &F, float &c, float &s, float &x) {
+        const float *b = park + (k - first) * (FD_FORCE_FLOATS * WAVE) + lane;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        x = 0.0f; c = 1.0f; s = 0.0f;
+        if (ct.dof >= 0) {
+            x = q_at(ct.dof);
+            if (!ct.prismatic) sincos_one(x, s, c);
+        }
+    };
     auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
     auto mload = [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); };
     auto fadd = [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); };
     auto ftake = [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); };
     auto q_bias = [&](int d, float &x, float &v, float &acc) {
-        x = live ? lq[row + d] : 0.0f;
-        v = lqd[row + d];
+        x = q_at(d);
+        v = qd_at(d);
         acc = 0.0f;
     };
     auto tau_bias = [&](int d, float v) { lf[row + d] -= v; };
@@ -114,8 +140,8 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         wave_lds_sync();
         float *lr = lres + row; // residual tile (same layout as lf)
         auto q_res = [&](int d, float &x, float &v, float &acc) {
-            x = live ? lq[row + d] : 0.0f;
-            v = lqd[row + d];
+            x = q_at(d);
+            v = qd_at(d);
             acc = (d >= lo && d < lo + cnt) ? lf[row + d] : 0.0f; // (prefix ops carry no DoF: every DoF read is this segment's)
         };
         auto tau_res = [&](int d, float v) { lr[d] = (live ? f[(tc.b0 + lane) * n + d] : 0.0f) - v; };
@@ -146,9 +172,11 @@ static FdPlan fd_plan(const drm_walk *w) {
             if (nt > p.nt_max) p.nt_max = nt;
         }
         const TreeArgs &a = p.a;
-        const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n)); // q, qd, f -> qdd, residual
+        const bool shorts = a.max_seg_ops <= FD_SHORT_OPS;
+        // f -> qdd and the residual (+ q and qd when every segment is short: see the kernel)
+        const size_t shared = (size_t)table_lds_floats(a.n_ops) + (shorts ? 4 : 2) * (size_t)round4(WAVE * pad_odd(a.n));
         p.hbm = hbm;
-        const int per_op = (a.max_seg_ops <= FD_SHORT_OPS ? CRBA_PARK_FLOATS : RNEA_PARK_FLOATS) * WAVE;
+        const int per_op = (shorts ? CRBA_PARK_FLOATS : FD_FORCE_FLOATS) * WAVE;
         p.lds = sizeof(float) * layout_waves(p.a, shared, per_op, a.n_slots * 18 * WAVE, [&](int s) {
             const int c = a.seg_dof_cnt[s];
             return hbm ? 0 : round4(WAVE * pad_odd(c * (c + 1) / 2));
