@@ -17,9 +17,9 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
-RNEA_GRAVITY, RNEA_DAMPING, FD_REFINE = 1, 2, 4
+RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
 
 class DrmWalk(ctypes.Structure):
@@ -327,10 +327,8 @@ class WalkTable(torch.autograd.Function):
         return (None, None, None, None) + tuple(out)
 
 
-def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int,
-                     refine: bool = True):
-    """qdd [B, n] produced by the joint torques f in state (q, qd).  ``refine``: one step of iterative refinement with the
-    inverse-dynamics walk as residual (DRM_FD_REFINE; the 7-DoF arm kernel, whose H is well conditioned, ignores it)."""
+def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):
+    """qdd [B, n] produced by the joint torques f in state (q, qd)."""
     lib = load_library()
     q, qd, f = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs), _dev_f32(f, "f", n_dofs)
     B = q.shape[0]
@@ -339,9 +337,9 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
     qdd = torch.empty(B, n_dofs, device=q.device, dtype=torch.float32)
     if B == 0:
         return qdd
-    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0) | (FD_REFINE if refine else 0)
+    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    # robots whose inertia-matrix triangle does not fit in LDS (> ~30 DoF in one segment) factorise it in HBM scratch
+    # the per-link records of the articulated-body sweeps, when the launch keeps them in HBM
     need = int(lib.drm_forward_dynamics_scratch_floats(ctypes.byref(walk), B))
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
     with torch.cuda.device(q.device):

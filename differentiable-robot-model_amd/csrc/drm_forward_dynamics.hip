@@ -10,6 +10,10 @@
 //
 // Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
 // 7-DoF arm chains run forward_dynamics_arm_kernel below; every other robot the loop-structured kernel.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 #include "drm_tree_dev.hpp"
@@ -17,180 +21,234 @@
 namespace drm {
 
 constexpr int FD_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
-constexpr int FD_FORCE_FLOATS = 6; // what the RNEA walks of this kernel park per op: the body force
 
-// Loop-structured forward dynamics of any robot: one tile of 64 samples per block, one wavefront per segment of the walk.
-// Segments are independent (their joints share no link that moves), so H is block diagonal: every wavefront forms ITS
-// block (drm_tree.hpp crba_tree_walk, packed lower triangle with segment-local DoF indices), the bias torques of its
-// joints (rnea_tree_walk with qdd = 0, robot_model.py:377-400) and solves its block by the leaf-to-root L^T D L
-// factorisation (drm_sample.hpp ltdl_solve) — an Allegro hand is four 4 x 4 systems per sample, not one 16 x 16.
-// LDS: [ table ][ q ][ qd ][ f -> rhs -> qdd ][ residual of the refinement step ] shared, then per wavefront
-//      [ records : max_seg_ops * 9 * 64 (RNEA; CRBA's cos / sin / value first) ][ slots : n_slots * 18 * 64 ]
-//      [ triangle : 64 (nt|1), nt = largest block's n (n + 1) / 2 — unless HBM ]
-// HBM: the triangle lives in caller-provided scratch, [tile][segment][entry][64] (robots beyond ~30 DoF per segment).
-template <bool HBM>
+// Forward dynamics of a robot whose segments are all SHORT (the fingers of a hand, at most FD_SHORT_OPS ops each): one tile
+// of 64 samples per block, one wavefront per segment.  Segments are independent (their joints share no link that moves),
+// so H is block diagonal: every wavefront forms ITS block (drm_tree.hpp crba_tree_walk_short, packed lower triangle with
+// segment-local DoF indices), the bias torques of its joints (rnea_tree_walk_short with qdd = 0, robot_model.py:377-400)
+// and solves its block by the leaf-to-root L^T D L factorisation (drm_sample.hpp ltdl_factor_acc) — an Allegro hand is
+// four 4 x 4 systems per sample, not one 16 x 16.  Both walks keep their per-op records in registers.
+// LDS: [ table ][ f -> rhs -> qdd ][ q ][ qd ] shared, then per wavefront
+//      [ slots : n_slots * 18 * 64 ][ triangle : 64 (nt|1) ]
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
-    forward_dynamics_tree_kernel(TreeArgs a, int flags, int nt_max, const float *__restrict__ q, const float *__restrict__ qd,
-                                 const float *__restrict__ f, int64_t B, float *__restrict__ qdd, float *__restrict__ scratch,
-                                 uint32_t magic_q, uint32_t align) {
+    forward_dynamics_tree_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                                 const float *__restrict__ f, int64_t B, float *__restrict__ qdd, uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileCtx tc = tile_begin(B);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
-    // Every segment short (fingers): the four tiles of round 1, shared by the wavefronts.  Otherwise (an arm carrying a gripper
-    // or a hand: LDS per sample is what bounds the wavefronts per CU) q and qd are read straight from global memory and only
-    // the f -> rhs -> qdd tile and the residual tile are staged.
-    const bool short_segments = a.max_seg_ops <= FD_SHORT_OPS;
-    float *lf = smem + table_lds_floats(a.n_ops), *lres = lf + region, *lq = lres + region, *lqd = lq + region;
+    float *lf = smem + table_lds_floats(a.n_ops), *lq = lf + region, *lqd = lq + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
     const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
-    float *park = smem + a.wave_off[wave];
-    // per-op records: the body force of the RNEA walk (6 floats; cos / sin are recomputed on the way back), or just CRBA's 3
-    // when every segment is short (the RNEA walk then keeps its own in registers)
-    float *lsl = park + (last - first) * ((short_segments ? CRBA_PARK_FLOATS : FD_FORCE_FLOATS) * WAVE); // slots: inertia [slot][10][64], then motion [12] + force [6]
+    float *lsl = smem + a.wave_off[wave]; // slots: inertia [slot][10][64], then motion [12] + force [6]
     float *lms = lsl, *lfs = lsl + a.n_slots * (12 * WAVE);
-    float *ltri = lsl + a.n_slots * (18 * WAVE) + lane * pad_odd(nt); // this lane's packed triangle (LDS form)
-    float *gtri = HBM ? scratch + ((int64_t)blockIdx.x * a.n_segments + wave) * (int64_t)nt_max * WAVE + lane : nullptr;
-    auto tri = [&](int i) -> float & { return HBM ? gtri[(int64_t)i * WAVE] : ltri[i]; };
+    float *ltri = lsl + a.n_slots * (18 * WAVE) + lane * pad_odd(nt); // this lane's packed triangle
+    auto tri = [&](int i) -> float & { return ltri[i]; };
 
     const TableLds tab = stage_tree_table(a, smem);
     const bool fast = tc.full && (n & 1);
-    if (short_segments) {
-        if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
-        if (wave == (a.n_segments > 1 ? 1 : 0))
-            tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
-    }
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+    if (wave == (a.n_segments > 1 ? 1 : 0))
+        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
     if (wave == (a.n_segments > 2 ? 2 : 0))
         tile_load<0>(f + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
-    for (int s = 0; s < a.n_slots * 10; ++s) lsl[s * WAVE + lane] = 0.0f;
-    for (int i = 0; i < nt; ++i) tri(i) = 0.0f; // pairs of joints on different branches
+    for (int i = 0; i < nt; ++i) tri(i) = 0.0f;
     __syncthreads();
 
     // lanes past a partial tile read zeros (see drm_fk.hip); their H is then a valid inertia matrix as well
     const bool live = (int)lane < tc.rows;
     const unsigned row = lane * Sq;
-    const int64_t grow = (tc.b0 + (live ? (int64_t)lane : 0)) * n;
-    auto q_at = [&](int d) -> float { return !live ? 0.0f : short_segments ? lq[row + d] : q[grow + d]; };
-    auto qd_at = [&](int d) -> float { return short_segments ? lqd[row + d] : (live ? qd[grow + d] : 0.0f); };
     const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
     auto hput = [&](int di, int dj, float v) {
         if (di >= dj) tri(tri_index(di - lo, dj - lo)) = v;
     };
-    auto qval = [&](int d) -> float { return q_at(d); };
-    // a short serial segment (a finger): the unrolled walk with the joint transforms in registers; anything else: the loop
+    auto qval = [&](int d) -> float { return live ? lq[row + d] : 0.0f; };
+    // a serial segment (a finger): the unrolled walk with the joint transforms in registers; a short segment that branches
+    // takes the loop, its cos / sin recomputed where the loop asks for them
     if (!crba_tree_walk_short<FD_SHORT_OPS>(first, last, ctl, rowf, qval, hput)) {
-        crba_prepare(first, last, ctl, qval, [&](int k, float c, float s, float x) {
-            float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-            b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
-        });
+        for (int s = 0; s < a.n_slots * 10; ++s) lsl[s * WAVE + lane] = 0.0f;
+        wave_lds_sync();
         crba_tree_walk(
             first, last, ctl, rowf,
             [&](int k, float &c, float &s, float &x) {
-                const float *b = park + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-                c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                x = 0.0f; c = 1.0f; s = 0.0f;
+                if (ct.dof >= 0) {
+                    x = qval(ct.dof);
+                    if (!ct.prismatic) sincos_one(x, s, c);
+                }
             },
             [&](int s, const Inertia &I) { lds_add_inertia(lsl, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lsl, s, lane, I); },
             hput);
+        wave_lds_sync(); // the composite-inertia walk is done with the slot memory
     }
-    wave_lds_sync(); // the composite-inertia walk is done with the slot memory
     for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     wave_lds_sync();
-    // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f.  Short segments (the fingers of a hand) take the
-    // unrolled walk that keeps its per-op records in registers (drm_tree.hpp rnea_tree_walk_short), as drm_rnea does.
-    auto park_f = [&](int k, const Force &F, float, float, float) {
-        float *b = park + (k - first) * (FD_FORCE_FLOATS * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
-    };
-    auto unpark_f = [&](int k, Force &F, float &c, float &s, float &x) {
-        const float *b = park + (k - first) * (FD_FORCE_FLOATS * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
-        int w0, w1;
-        ctl_words(ctl, k, w0, w1);
-        const OpCtl ct = decode_ctl(w0, w1);
-        x = 0.0f; c = 1.0f; s = 0.0f;
-        if (ct.dof >= 0) {
-            x = q_at(ct.dof);
-            if (!ct.prismatic) sincos_one(x, s, c);
-        }
-    };
+    // bias torques: RNEA with zero joint accelerations; rhs = f - nle, over f
     auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
     auto mload = [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); };
     auto fadd = [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); };
     auto ftake = [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); };
     auto q_bias = [&](int d, float &x, float &v, float &acc) {
-        x = q_at(d);
-        v = qd_at(d);
+        x = qval(d);
+        v = lqd[row + d];
         acc = 0.0f;
     };
     auto tau_bias = [&](int d, float v) { lf[row + d] -= v; };
-    if (short_segments) rnea_tree_walk_short<FD_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, q_bias, tau_bias, msave, mload, fadd, ftake);
-    else rnea_tree_walk(a.prefix_end, first, last, ctl, rowf, flags, q_bias, tau_bias, park_f, unpark_f, msave, mload, fadd, ftake);
+    rnea_tree_walk_short<FD_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, q_bias, tau_bias, msave, mload, fadd, ftake);
     ltdl_factor_acc(cnt, tri);
     ltdl_apply_acc(cnt, tri, lf + row + lo);
-    if (flags & DRM_FD_REFINE) {
-        // one step of iterative refinement: r = f - ID(q, qd, x0) by the inverse-dynamics walk (it never forms H, so its
-        // rounding errors are those of the torques, not cond(H) times them), x1 = x0 + H^-1 r with the factors at hand;
-        // the residual has a tile of its own (lres).
-        wave_lds_sync();
-        for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
-        wave_lds_sync();
-        float *lr = lres + row; // residual tile (same layout as lf)
-        auto q_res = [&](int d, float &x, float &v, float &acc) {
-            x = q_at(d);
-            v = qd_at(d);
-            acc = (d >= lo && d < lo + cnt) ? lf[row + d] : 0.0f; // (prefix ops carry no DoF: every DoF read is this segment's)
-        };
-        auto tau_res = [&](int d, float v) { lr[d] = (live ? f[(tc.b0 + lane) * n + d] : 0.0f) - v; };
-        if (short_segments) rnea_tree_walk_short<FD_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, q_res, tau_res, msave, mload, fadd, ftake);
-        else rnea_tree_walk(a.prefix_end, first, last, ctl, rowf, flags, q_res, tau_res, park_f, unpark_f, msave, mload, fadd, ftake);
-        ltdl_apply_acc(cnt, tri, lr + lo);
-        for (int d = lo; d < lo + cnt; ++d) lf[row + d] += lr[d];
-    }
     __syncthreads();
     if (wave == 0)
         tile_store<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lf, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
 }
 
-// geometry of a launch: LDS bytes with the triangle in LDS, or (hbm = true) in scratch
-struct FdPlan {
-    TreeArgs a;
-    int nt_max;
-    bool hbm;
-    size_t lds;
-};
-static FdPlan fd_plan(const drm_walk *w) {
-    FdPlan p;
-    auto lay = [&](bool single, bool hbm) {
-        p.a = tree_args(w, single);
-        p.nt_max = 1;
-        for (int s = 0; s < p.a.n_segments; ++s) {
-            const int c = p.a.seg_dof_cnt[s], nt = c * (c + 1) / 2;
-            if (nt > p.nt_max) p.nt_max = nt;
-        }
-        const TreeArgs &a = p.a;
-        const bool shorts = a.max_seg_ops <= FD_SHORT_OPS;
-        // f -> qdd and the residual (+ q and qd when every segment is short: see the kernel)
-        const size_t shared = (size_t)table_lds_floats(a.n_ops) + (shorts ? 4 : 2) * (size_t)round4(WAVE * pad_odd(a.n));
-        p.hbm = hbm;
-        const int per_op = (shorts ? CRBA_PARK_FLOATS : FD_FORCE_FLOATS) * WAVE;
-        p.lds = sizeof(float) * layout_waves(p.a, shared, per_op, a.n_slots * 18 * WAVE, [&](int s) {
-            const int c = a.seg_dof_cnt[s];
-            return hbm ? 0 : round4(WAVE * pad_odd(c * (c + 1) / 2));
-        });
-        return p.lds <= (size_t)MAX_LDS_BYTES;
-    };
-    // in order of preference: fanned out with the triangles in LDS, one wavefront with its triangle in LDS, triangles in HBM
-    if (lay(false, false)) return p;
-    if (w->n_segments > 1 && lay(true, false)) return p;
-    if (lay(false, true)) return p;
-    lay(true, true);
-    return p;
+// LDS bytes of that launch (0: does not apply — a segment is too long, or the hand does not fit)
+static size_t fd_short_plan(const drm_walk *w, TreeArgs &a) {
+    a = tree_args(w, false);
+    if (a.max_seg_ops > FD_SHORT_OPS) return 0;
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(a.n));
+    const size_t lds = sizeof(float) * layout_waves(a, shared, 0, a.n_slots * 18 * WAVE, [&](int s) {
+        const int c = a.seg_dof_cnt[s];
+        return round4(WAVE * pad_odd(c * (c + 1) / 2));
+    });
+    return lds <= (size_t)MAX_LDS_BYTES ? lds : 0;
 }
 
+// Every other robot: the articulated-body walk (drm_tree.hpp aba_tree_walk), one wavefront per segment, 64 samples per tile.
+// What a sample needs between the sweeps (8 floats per link) would take a CU's LDS after two tiles of an arm with a hand, so
+// those records live in HBM scratch, [op][8][64] per block: coalesced 256-byte accesses that the walk issues one op ahead of
+// their use.  The grid is PERSISTENT — as many blocks as the chip holds at once, each looping over tiles — so the scratch is
+// a few tens of MB whatever the batch and is re-read from L2 / Infinity Cache, never from HBM.
+// LDS: [ table ][ q ][ qd ][ f -> qdd ] shared (staged per tile with coalesced 16-byte accesses), then per wavefront
+//      [ slots : n_slots * (12 + 27) * 64 ]
+constexpr int ABA_REC_FLOATS = 8;        // between the sweeps: the link velocity (6), then U (6), 1 / D, u
+constexpr int ABA_BODY_FLOATS = 27;      // a branch point's accumulators: articulated inertia (21) + bias force (6)
+constexpr int ABA_SLOT_FLOATS = 12 + ABA_BODY_FLOATS;
+
+__device__ __forceinline__ void lds_add_body(float *slots, int s, unsigned lane, const ArtBody &a) {
+    float *b = slots + s * (ABA_BODY_FLOATS * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { b[(2 * i) * WAVE] += a.I.MA[i][0]; b[(2 * i + 1) * WAVE] += a.I.MA[i][1]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) b[(12 + i) * WAVE] += a.I.B[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { b[(21 + 2 * i) * WAVE] += a.p.la[i][0]; b[(22 + 2 * i) * WAVE] += a.p.la[i][1]; }
+}
+__device__ __forceinline__ void lds_take_body(float *slots, int s, unsigned lane, ArtBody &a) {
+    float *b = slots + s * (ABA_BODY_FLOATS * WAVE) + lane;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.I.MA[i] += f2_make(b[(2 * i) * WAVE], b[(2 * i + 1) * WAVE]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.I.B[i] += b[(12 + i) * WAVE];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.p.la[i] += f2_make(b[(21 + 2 * i) * WAVE], b[(22 + 2 * i) * WAVE]);
+#pragma unroll
+    for (int i = 0; i < ABA_BODY_FLOATS; ++i) b[i * WAVE] = 0.0f;
+}
+
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    forward_dynamics_aba_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                                const float *__restrict__ f, int64_t B, int n_tiles, float *__restrict__ qdd, float *__restrict__ scratch,
+                                uint32_t magic_q, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lf = lqd + region;
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    float *lms = smem + a.wave_off[wave], *lbs = lms + a.n_slots * (12 * WAVE);
+    float *recs = scratch + ((int64_t)blockIdx.x * a.n_ops + first) * (ABA_REC_FLOATS * WAVE) + lane;
+    const TableLds tab = stage_tree_table(a, smem);
+    for (int s = 0; s < a.n_slots * ABA_BODY_FLOATS; ++s) lbs[s * WAVE + lane] = 0.0f; // (every take leaves its slot at zero again)
+    const unsigned row = lane * Sq;
+    auto rec = [&](int k) -> float * { return recs + (k - first) * (ABA_REC_FLOATS * WAVE); };
+
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        __syncthreads(); // the table is staged / the previous tile's accelerations have left the f tile
+        const int64_t b0 = (int64_t)tile * WAVE;
+        const int rows = B - b0 < WAVE ? (int)(B - b0) : WAVE;
+        const bool full = rows == WAVE, fast = full && (n & 1);
+        if (wave == 0) tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q), full && (align & AL_Q));
+        if (wave == (a.n_segments > 1 ? 1 : 0))
+            tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD), full && (align & AL_QD));
+        if (wave == (a.n_segments > 2 ? 2 : 0))
+            tile_load<0>(f + b0 * n, rows, n, magic_q, lf, lane, fast && (align & AL_QDD), full && (align & AL_QDD));
+        __syncthreads();
+        // lanes past a partial tile walk a robot at rest with no torques (their LDS rows are never read or written)
+        const bool live = (int)lane < rows;
+        aba_tree_walk(
+            a.prefix_end, first, last, tab, [&](int k) { return tab.row(k); }, flags,
+            [&](int d, float &x, float &v) {
+                x = live ? lq[row + d] : 0.0f;
+                v = live ? lqd[row + d] : 0.0f;
+            },
+            [&](int d) -> float { return live ? lf[row + d] : 0.0f; },
+            [&](int d, float v) {
+                if (live) lf[row + d] = v;
+            },
+            [&](int k, const Motion &M) {
+                float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { b[i * WAVE] = M.wa[i][0]; b[(3 + i) * WAVE] = M.va[i][0]; }
+            },
+            [&](int k, Motion &M) {
+                const float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { M.wa[i] = f2_make(b[i * WAVE], 0.0f); M.va[i] = f2_make(b[(3 + i) * WAVE], 0.0f); }
+            },
+            [&](int k, const float *r) {
+                float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < ABA_REC_FLOATS; ++i) b[i * WAVE] = r[i];
+            },
+            [&](int k, float *r) {
+                const float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < ABA_REC_FLOATS; ++i) r[i] = b[i * WAVE];
+            },
+            [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
+            [&](int s, const ArtBody &b) { lds_add_body(lbs, s, lane, b); }, [&](int s, ArtBody &b) { lds_take_body(lbs, s, lane, b); });
+        __syncthreads();
+        if (wave == 0) tile_store<0>(qdd + b0 * n, rows, n, magic_q, lf, lane, fast && (align & AL_TAU), full && (align & AL_TAU));
+    }
+}
+
+// geometry of that launch: LDS bytes per block and the number of blocks the device holds at once (the persistent grid)
+struct AbaPlan {
+    TreeArgs a;
+    size_t lds;
+    int resident;
+};
+static int aba_plan(const drm_walk *w, AbaPlan &p) {
+    p.a = tree_args(w, false);
+    const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(p.a.n));
+    p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * ABA_SLOT_FLOATS * WAVE, [](int) { return 0; });
+    int rc = ensure_lds_tree(forward_dynamics_aba_kernel, p.lds);
+    if (rc) return rc;
+    // blocks per CU by the runtime's own occupancy rule (LDS and registers), times the CUs of the current device
+    static std::mutex mu;
+    static std::map<std::pair<size_t, int>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipGetDevice failed");
+    const auto key = std::make_pair(p.lds * 64 + (size_t)p.a.n_segments, dev);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_dynamics_aba_kernel, WAVE * p.a.n_segments, p.lds) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            return fail(DRM_ERR_LAUNCH, "occupancy query failed");
+        it = cache.emplace(key, per_cu * cus).first;
+    }
+    p.resident = it->second;
+    return DRM_OK;
+}
 
 // Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,
 // rnea_chain) with H's lower triangle and the right-hand side in REGISTERS and a fully unrolled L^T D L solve; constants
@@ -267,10 +325,16 @@ using namespace drm;
 
 extern "C" int64_t drm_forward_dynamics_scratch_floats(const drm_walk *w, int64_t B) {
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
-    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) return 0;
-    const FdPlan p = fd_plan(w);
-    if (!p.hbm) return 0;
-    return ((B + WAVE - 1) / WAVE) * (int64_t)p.a.n_segments * p.nt_max * WAVE;
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
+        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
+        if (B == 0) return 0;
+    }
+    TreeArgs a;
+    if (fd_short_plan(w, a)) return 0;
+    AbaPlan p;
+    if (aba_plan(w, p)) return 0;
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_ops * ABA_REC_FLOATS * WAVE;
 }
 
 extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B,
@@ -305,23 +369,26 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
 #endif
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
-    const FdPlan p = fd_plan(w);
-    if (p.hbm && !scratch)
-        return fail(DRM_ERR_INVALID, "this robot's inertia matrix does not fit in LDS: pass drm_forward_dynamics_scratch_floats() floats of scratch");
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
-    const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
     hipStream_t s = (hipStream_t)stream;
-    if (p.hbm) {
-        rc = ensure_lds_tree(forward_dynamics_tree_kernel<true>, p.lds);
+    TreeArgs fingers;
+    if (const size_t lds = fd_short_plan(w, fingers)) {
+        const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
+        rc = ensure_lds_tree(forward_dynamics_tree_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(forward_dynamics_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags,
-                           p.nt_max, q, qd, f, B, qdd, scratch, div_magic(n), align);
-    } else {
-        rc = ensure_lds_tree(forward_dynamics_tree_kernel<false>, p.lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(forward_dynamics_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags,
-                           p.nt_max, q, qd, f, B, qdd, scratch, div_magic(n), align);
+        hipLaunchKernelGGL(forward_dynamics_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, (int)flags,
+                           q, qd, f, B, qdd, div_magic(n), align);
+        return launched();
     }
+    AbaPlan p;
+    rc = aba_plan(w, p);
+    if (rc) return rc;
+    if (!scratch)
+        return fail(DRM_ERR_INVALID, "this robot runs the articulated-body kernel: pass drm_forward_dynamics_scratch_floats() floats of scratch");
+    const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
+    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    hipLaunchKernelGGL(forward_dynamics_aba_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags, q, qd, f, B,
+                       (int)tiles, qdd, scratch, div_magic(n), align);
     return launched();
 }

@@ -445,4 +445,258 @@ DRM_HD void crba_prepare(int a, int b, CTL ctl, QF qf, PUT put) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Forward dynamics of one segment by the articulated-body algorithm, the reference's own algorithm
+// (robot_model.py:487-624): O(ops) instead of the O(n^3) factorisation of H, nothing per sample but 8 floats per op
+// between the sweeps — what robots with one long segment (an arm carrying a gripper or a hand) need, where the packed
+// triangle of H in LDS left one wavefront per CU.
+//   sweep 1, root -> leaves  (robot_model.py:539-549)  link velocities; parked (6 floats per op)
+//   sweep 2, leaves -> root  (robot_model.py:551-604)  articulated inertia IA and bias force pA of every sub-tree; at a
+//            moving joint  U = IA S,  D = S . U,  u = f - damping qd - S . pA  (parked: U, 1 / D, u),
+//            Ia = IA - U U^T / D,  pa = pA + Ia c + U u / D,  both moved into the parent's frame
+//   sweep 3, root -> leaves  (robot_model.py:611-629)  a' = X a_parent + c,  qdd = (u - U . a') / D,  a = a' + S qdd
+// c = v x (S qd) is the velocity-product acceleration; sweep 3 recomputes the velocities next to the accelerations (the
+// packed pairs of `Motion` carry both through the same instructions).  Fixed joints have S = 0: nothing is eliminated.
+// Body-frame Pluecker coordinates at the link origin as everywhere else; S = (e_z, 0) revolute, (0, e_z) prismatic.
+// ---------------------------------------------------------------------------
+// A symmetric 6 x 6 inertia acting on a motion (w, v):  n = A w + B v,  f = B^T w + M v
+struct ArtInertia {
+    f2 MA[6];   // (M_ij, A_ij) for ij = 00 01 02 11 12 22: the two symmetric blocks go through the same rotations as pairs
+    float B[9]; // row major
+};
+DRM_HD constexpr int sym_index(int i, int j) { return i <= j ? (i == 0 ? j : i + j + 1) : (j == 0 ? i : i + j + 1); }
+static_assert(sym_index(0, 0) == 0 && sym_index(0, 2) == 2 && sym_index(1, 1) == 3 && sym_index(2, 1) == 4 && sym_index(2, 2) == 5, "packing");
+
+struct ArtBody { // what travels towards the root: the articulated inertia and bias force of a sub-tree
+    ArtInertia I;
+    Force p; // (lin, ang) pairs
+};
+DRM_HD void art_zero(ArtBody &a) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.I.MA[i] = f2_bcast(0.0f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.I.B[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.p.la[i] = f2_bcast(0.0f);
+}
+DRM_HD void art_add(ArtBody &a, const ArtBody &b) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.I.MA[i] += b.I.MA[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.I.B[i] += b.I.B[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.p.la[i] += b.p.la[i];
+}
+// rigid-body inertia of a link row: A = I_o, M = m 1, B = skew(m c)   (n = I_o w + mc x v,  f = m v - mc x w)
+DRM_HD void art_from_link(const float *of, ArtInertia &I) {
+    const float m = of[DRM_OPF_MASS], *h = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
+    I.MA[0] = f2_make(m, Io[0]); I.MA[1] = f2_make(0.0f, Io[1]); I.MA[2] = f2_make(0.0f, Io[2]);
+    I.MA[3] = f2_make(m, Io[4]); I.MA[4] = f2_make(0.0f, Io[5]); I.MA[5] = f2_make(m, Io[8]);
+    I.B[0] = 0.0f;  I.B[1] = -h[2]; I.B[2] = h[1];
+    I.B[3] = h[2];  I.B[4] = 0.0f;  I.B[5] = -h[0];
+    I.B[6] = -h[1]; I.B[7] = h[0];  I.B[8] = 0.0f;
+}
+// X^T I X for the transform of a child into its parent's frame (x_p = J x_c + t; parent motion -> child motion is
+// w_c = J^T w_p, v_c = J^T (v_p - t x w_p)).  With the blocks rotated first (A' = J A J^T, ...) and T = skew(t):
+//   M_p = M' ;  B_p = B' + T M' ;  A_p = A' - B' T + T B_p^T       (robot_model.py:590-596 forms the 6 x 6 products)
+DRM_HD void art_inertia_to_parent(const float *J, const float *t, const ArtInertia &c, ArtInertia &out) {
+    f2 P[9], R[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            P[r * 3 + k] = f2_bcast(J[r * 3 + 0]) * c.MA[sym_index(0, k)] + f2_bcast(J[r * 3 + 1]) * c.MA[sym_index(1, k)] +
+                           f2_bcast(J[r * 3 + 2]) * c.MA[sym_index(2, k)];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j)
+            R[sym_index(i, j)] = P[i * 3 + 0] * f2_bcast(J[j * 3 + 0]) + P[i * 3 + 1] * f2_bcast(J[j * 3 + 1]) + P[i * 3 + 2] * f2_bcast(J[j * 3 + 2]);
+    float Q[9], Br[9], Bp[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Q[r * 3 + k] = J[r * 3 + 0] * c.B[0 * 3 + k] + J[r * 3 + 1] * c.B[1 * 3 + k] + J[r * 3 + 2] * c.B[2 * 3 + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Br[i * 3 + j] = Q[i * 3 + 0] * J[j * 3 + 0] + Q[i * 3 + 1] * J[j * 3 + 1] + Q[i * 3 + 2] * J[j * 3 + 2];
+    // B_p = B' + T M': column j of T M' is t x (column j of M')
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float m0 = R[sym_index(0, j)][0], m1 = R[sym_index(1, j)][0], m2 = R[sym_index(2, j)][0];
+        Bp[0 * 3 + j] = Br[0 * 3 + j] + (t[1] * m2 - t[2] * m1);
+        Bp[1 * 3 + j] = Br[1 * 3 + j] + (t[2] * m0 - t[0] * m2);
+        Bp[2 * 3 + j] = Br[2 * 3 + j] + (t[0] * m1 - t[1] * m0);
+    }
+    // A_p[i][j] = A'[i][j] - (row i of B' x t)[j] + (t x row j of B_p)[i]
+    auto cross_c = [](const float *a, const float *b, int c) { // component c of a x b
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        return a[c1] * b[c2] - a[c2] * b[c1];
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            const float a = R[sym_index(i, j)][1] - cross_c(Br + 3 * i, t, j) + cross_c(t, Bp + 3 * j, i);
+            out.MA[sym_index(i, j)] = f2_make(R[sym_index(i, j)][0], a);
+        }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.B[i] = Bp[i];
+}
+
+// one op of sweep 2.  `tot` = this op's own inertia + bias force + what its children handed up; on return `up` is the
+// op's contribution to its parent (in the parent's frame).  U (lin, ang pairs), 1 / D and u go to rec[8].
+DRM_HD void aba_eliminate(bool moving, bool prismatic, const float *J, const float *t, float qd, float f_joint, const Motion &vel,
+                          ArtBody &tot, float *rec, bool want_up, ArtBody &up) {
+    if (moving) {
+        // U = IA S as (lin, ang) pairs: revolute = column "angular z" of IA, prismatic = column "linear z"
+        f2 U[3];
+        float D, sp;
+        if (!prismatic) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) U[i] = f2_make(tot.I.B[2 * 3 + i], tot.I.MA[sym_index(i, 2)][1]);
+            D = tot.I.MA[5][1];
+            sp = tot.p.la[2][1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) U[i] = f2_make(tot.I.MA[sym_index(i, 2)][0], tot.I.B[i * 3 + 2]);
+            D = tot.I.MA[5][0];
+            sp = tot.p.la[2][0];
+        }
+        const float Dinv = 1.0f / D, u = f_joint - sp;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { rec[i] = U[i][0]; rec[3 + i] = U[i][1]; }
+        rec[6] = Dinv; rec[7] = u;
+        if (want_up) {
+            // Ia = IA - U U^T / D
+            f2 Us[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Us[i] = U[i] * f2_bcast(Dinv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j) tot.I.MA[sym_index(i, j)] -= Us[i] * U[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tot.I.B[i * 3 + j] -= Us[i][1] * U[j][0];
+            // c = v x (S qd) as (lin, ang) pairs: revolute (v x e_z, w x e_z) qd, prismatic (w x e_z, 0) qd;  x e_z = (y, -x, 0)
+            const float w0 = vel.wa[0][0], w1 = vel.wa[1][0], v0 = vel.va[0][0], v1 = vel.va[1][0];
+            f2 c0, c1;
+            if (!prismatic) { c0 = f2_make(v1 * qd, w1 * qd); c1 = f2_make(-v0 * qd, -w0 * qd); }
+            else { c0 = f2_make(w1 * qd, 0.0f); c1 = f2_make(-w0 * qd, 0.0f); }
+            // pa = pA + Ia c + U u / D:   lin_i = M_ij cl_j + B_ji ca_j ,  ang_i = A_ij ca_j + B_ij cl_j   (j = 0, 1)
+            const float ud = u * Dinv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f2 acc = tot.I.MA[sym_index(i, 0)] * c0 + tot.I.MA[sym_index(i, 1)] * c1;
+                acc += f2_make(tot.I.B[0 * 3 + i] * c0[1] + tot.I.B[1 * 3 + i] * c1[1], tot.I.B[i * 3 + 0] * c0[0] + tot.I.B[i * 3 + 1] * c1[0]);
+                tot.p.la[i] += acc + U[i] * f2_bcast(ud);
+            }
+        }
+    }
+    if (want_up) {
+        art_inertia_to_parent(J, t, tot.I, up.I);
+        rnea_link_force_up(J, t, tot.p, up.p);
+    }
+}
+
+//   qf(d, q, qd)         joint state of DoF d           fj(d)  joint torque (the caller takes damping off; robot_model.py:515-521)
+//   out(d, v)            joint acceleration of DoF d
+//   vpark(k, Motion) / vunpark(k, Motion&)   the velocity halves of op k's motion, sweep 1 -> 2
+//   rpark(k, rec[8]) / runpark(k, rec[8])    U, 1 / D, u of a moving op, sweep 2 -> 3
+//   motion_save / motion_load                branch-point motions (sweeps 1 and 3)
+//   body_add(s, ArtBody) / body_take(s, ArtBody&)   branch-point accumulators of sweep 2 (take = add into the argument and reset)
+template <class CTL, class ROW, class QF, class FJ, class OUT, class VPARK, class VUNPARK, class RPARK, class RUNPARK, class MSAVE,
+          class MLOAD, class BADD, class BTAKE>
+DRM_HD void aba_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags, QF qf, FJ fj, OUT out, VPARK vpark, VUNPARK vunpark,
+                          RPARK rpark, RUNPARK runpark, MSAVE motion_save, MLOAD motion_load, BADD body_add, BTAKE body_take) {
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    // the joint transform of op k and its joint state
+    auto joint = [&](int k, const OpCtl &ct, float *J, float *t, float &qd) {
+        float q = 0.0f, c = 1.0f, s = 0.0f;
+        qd = 0.0f;
+        if (ct.dof >= 0) {
+            qf(ct.dof, q, qd);
+            if (!ct.prismatic) sincos_one(q, s, c);
+        }
+        const OpFT o = load_ft(row(k));
+        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+    };
+    // ---- sweeps 1 and 3 share their loop: the motion of every op from its parent's --------------------------------
+    // (the records may live in HBM: every sweep asks for the record of the NEXT op before it works on the current one)
+    auto down = [&](bool third) {
+        Motion cur;
+        motion_root(cur, third ? g : 0.0f);
+        float ahead[8];
+        if (third) runpark(a, ahead);
+#pragma unroll 1
+        for (int k = (p_end > 0 ? 0 : a); k < b; k = (k + 1 == p_end ? a : k + 1)) {
+            int w0, w1;
+            ctl_words(ctl, k, w0, w1);
+            const OpCtl ct = decode_ctl(w0, w1);
+            float rec[8];
+            if (third && k >= a) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rec[i] = ahead[i];
+                if (k + 1 < b) runpark(k + 1, ahead);
+            }
+            float J[9], t[3], qd;
+            joint(k, ct, J, t, qd);
+            if (ct.src == DRM_SRC_ROOT) motion_root(cur, third ? g : 0.0f);
+            if (ct.src >= 0) motion_load(ct.src, cur);
+            motion_step(J, t, qd, 0.0f, ct.prismatic, cur, cur); // acceleration halves: a' = X a_parent + c
+            if (third && ct.dof >= 0 && k >= a) {
+                float dot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dot += rec[i] * cur.va[i][1] + rec[3 + i] * cur.wa[i][1];
+                const float qdd = (rec[7] - dot) * rec[6];
+                out(ct.dof, qdd);
+                if (ct.prismatic) cur.va[2][1] += qdd;
+                else cur.wa[2][1] += qdd;
+            }
+            if (ct.save >= 0) motion_save(ct.save, cur);
+            if (!third && k >= a) vpark(k, cur);
+        }
+    };
+    down(false);
+    // ---- sweep 2 -------------------------------------------------------------------------------------------------
+    ArtBody carry;
+    art_zero(carry);
+    Motion vahead;
+    vunpark(b - 1, vahead);
+#pragma unroll 1
+    for (int k = b - 1; k >= a; --k) {
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        const float *of = row(k);
+        const Motion vel = vahead; // acceleration halves zero: the body force below is then the bias force v x* (I v)
+        if (k > a) vunpark(k - 1, vahead);
+        ArtBody tot;
+        art_from_link(of, tot.I);
+        rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, vel, tot.p);
+        if (ct.child_next) art_add(tot, carry);
+        if (ct.save >= 0) body_take(ct.save, tot);
+        float J[9], t[3], qd;
+        joint(k, ct, J, t, qd);
+        float fjoint = 0.0f;
+        if (ct.dof >= 0) {
+            fjoint = fj(ct.dof);
+            if (flags & DRM_RNEA_DAMPING) fjoint -= of[DRM_OPF_DAMP] * qd;
+        }
+        const bool want_up = ct.src != DRM_SRC_ROOT && ct.parent >= a; // (a parent in the static prefix takes nothing)
+        float rec[8];
+        ArtBody up;
+        aba_eliminate(ct.dof >= 0, ct.prismatic, J, t, qd, fjoint, vel, tot, rec, want_up, up);
+        if (ct.dof >= 0) rpark(k, rec);
+        if (want_up) {
+            if (ct.src >= 0) body_add(ct.src, up);
+            else carry = up;
+        }
+    }
+    down(true);
+}
+
 } // namespace drm

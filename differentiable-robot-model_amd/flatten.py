@@ -350,21 +350,6 @@ def foldable_links(spec: RobotSpec, keep: Sequence[int] = ()) -> np.ndarray:
         keep |= bad
 
 
-def mass_spread(spec: RobotSpec) -> float:
-    """Largest / smallest sub-tree mass hanging off a moving joint: a cheap, configuration-free proxy for the condition
-    number of the joint-space inertia matrix (a 7-DoF arm: ~30; an Allegro hand on its own: ~10; a Fetch or an arm carrying a
-    hand: > 1000).  forward dynamics takes its refinement step above REFINE_MASS_SPREAD."""
-    L = spec.n_links
-    sub = np.asarray(spec.mass, np.float64).copy()
-    for i in range(L - 1, 0, -1):
-        sub[int(spec.parent[i])] += sub[i]
-    moving = [sub[i] for i in range(1, L) if spec.dof[i] >= 0 and sub[i] > 0]
-    return float(max(moving) / min(moving)) if moving else 1.0
-
-
-REFINE_MASS_SPREAD = 100.0
-
-
 def fold_link_table(spec: RobotSpec, table: np.ndarray, fold: Optional[np.ndarray] = None) -> np.ndarray:
     """The [L+1(+...), 32] link table with the inertia of every foldable link moved into its parent's row (composite
     rigid body, expressed in the parent link's frame): m' = m_p + m,  (mc)' = (mc)_p + F (mc) + m t,

@@ -23,8 +23,8 @@ import numpy as np
 import torch
 
 from . import backend
-from .flatten import (OPF_STRIDE, REFINE_MASS_SPREAD, RobotSpec, WalkProgram, build_robot_spec, build_walk, fold_link_table,
-                      foldable_links, identity_table_row, mass_spread, virtual_row_constants)
+from .flatten import (OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, fold_link_table,
+                      foldable_links, identity_table_row, virtual_row_constants)
 from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
 
@@ -283,10 +283,10 @@ class _ForwardDynamics(torch.autograd.Function):
     through the reference's articulated-body recursion, robot_model.py:487-624; examples/learn_forward_dynamics_iiwa.py)."""
 
     @staticmethod
-    def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask, refine=True):
-        qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs, refine)
+    def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask):
+        qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs)
         ctx.save_for_backward(q, qd, qdd, ops_f)
-        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask, ctx.refine = dw, (gravity, damping), n_dofs, param_mask, refine
+        ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask = dw, (gravity, damping), n_dofs, param_mask
         return qdd
 
     @staticmethod
@@ -295,7 +295,7 @@ class _ForwardDynamics(torch.autograd.Function):
         q, qd, qdd, ops_f = ctx.saved_tensors
         dw, n = ctx.dw, ctx.n_dofs
         lam = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, torch.zeros_like(qd),
-                                       grad_qdd.to(torch.float32).contiguous(), False, False, n, ctx.refine)
+                                       grad_qdd.to(torch.float32).contiguous(), False, False, n)
         want_in = any(ctx.needs_input_grad[:2])
         want_ops = ctx.needs_input_grad[3] and ctx.param_mask != 0
         gq = gqd = grad_ops = None
@@ -364,9 +364,6 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
         self._fold_masks: Dict[tuple, np.ndarray] = {}          # kept (learnable) links -> foldable_links(spec, keep)
-        # forward dynamics: one step of iterative refinement (DRM_FD_REFINE) for robots whose inertia matrix is badly
-        # conditioned — light links far out on heavy ones (flatten.mass_spread); settable (True / False) by the user
-        self.forward_dynamics_refinement: bool = mass_spread(self._spec) > REFINE_MASS_SPREAD
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
     # ------------------------------------------------------------------ constants
@@ -860,9 +857,10 @@ class DifferentiableRobotModel(torch.nn.Module):
                                  ) -> torch.Tensor:
         """qdd [B,n] that the joint torques ``f`` produce in state (q, qd) (robot_model.py:487-624).
 
-        The reference runs Featherstone's articulated-body recursion; this solves the same linear system
-        H(q) qdd = f - nle(q, qd) in one fused kernel (composite-rigid-body H, RNEA bias torques, leaf-to-root L^T D L solve;
-        one step of iterative refinement for badly conditioned robots, ``self.forward_dynamics_refinement``).
+        One kernel launch: Featherstone's articulated-body recursion, as in the reference, for robots with a long
+        segment (an arm carrying a gripper or a hand); for 7-DoF arms and for hands (short independent fingers) the same
+        linear system H(q) qdd = f - nle(q, qd) formed and solved in registers (composite-rigid-body H, RNEA bias torques,
+        leaf-to-root L^T D L elimination).
         With ``use_damping`` the reference subtracts damping * qd from its ``f`` argument IN PLACE
         (robot_model.py:515-521); here ``f`` is left untouched.  Differentiable with respect to q, qd, f and the
         learnable link parameters (implicit differentiation: one more solve + the RNEA backward kernel).
@@ -877,9 +875,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         if torch.is_grad_enabled() and (ops_f.requires_grad or any(t.requires_grad for t in (q, qd, f))):
             self._differentiable(dw)
             return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
-                                          self._learnable_op_mask(dw), self.forward_dynamics_refinement)
+                                          self._learnable_op_mask(dw))
         return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
-                                        bool(use_damping), self._n_dofs, self.forward_dynamics_refinement)
+                                        bool(use_damping), self._n_dofs)
 
     def compute_forward_dynamics_old(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
                                      include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 5
+#define DRM_ABI_VERSION 6
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -118,9 +118,6 @@ extern "C" {
 /* flags of drm_rnea */
 #define DRM_RNEA_GRAVITY 1 /* base acceleration (0,0,+9.81)   (robot_model.py:344-350)         */
 #define DRM_RNEA_DAMPING 2 /* tau += damping * qd             (robot_model.py:368-373)         */
-#define DRM_FD_REFINE 4    /* drm_forward_dynamics only: one step of iterative refinement, qdd += H^-1 (f - ID(q, qd, qdd)),
-                              the residual taken by the inverse-dynamics walk (which never forms H): recovers the accuracy of
-                              the reference's articulated-body recursion on ill-conditioned trees (an arm carrying a hand)  */
 
 /* error codes */
 #define DRM_OK 0
@@ -243,10 +240,13 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *st
  * DRM_RNEA_DAMPING = the damping torques damping * qd are taken off f first (robot_model.py:515-521; the
  * caller's f is NOT modified, unlike the reference, which subtracts in place).
  *   q, qd, f [B, n]  ->  qdd [B, n]
- *   DRM_FD_REFINE (flags) adds one refinement step (one more inverse-dynamics walk + two triangular solves); the 7-DoF arm
- *   kernel, whose H is well conditioned (errors ~1e-5), ignores it.
- *   scratch   drm_forward_dynamics_scratch_floats(walk, B) floats owned by the caller (0 for every shipped robot: the
- *             packed triangle of a segment's inertia matrix lives in LDS; beyond ~30 DoF per segment it lives there)
+ * Three kernels: 7-DoF arm chains and robots whose segments are all short (the fingers of a hand) form H and the bias
+ * torques and solve H qdd = f - nle by an L^T D L factorisation in registers / LDS (the same elimination, H is at most
+ * 7 x 7 there); every other robot (an arm carrying a gripper or a hand, a mobile manipulator) runs the articulated-body
+ * recursion itself, three sweeps over the walk with 8 floats per link and sample between them.
+ *   scratch   drm_forward_dynamics_scratch_floats(walk, B) floats owned by the caller: the per-link records of the
+ *             articulated-body sweeps when the launch keeps them in HBM instead of LDS (0 when it does not; never read
+ *             or written then, may be NULL)
  */
 int64_t drm_forward_dynamics_scratch_floats(const drm_walk *walk, int64_t B);
 int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,

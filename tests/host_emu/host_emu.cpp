@@ -262,8 +262,43 @@ void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
 }
 
 // forward dynamics: per segment, H (packed lower triangle of the segment's block) + bias torques + L^T D L solve
+// ... by the articulated-body walk, segment by segment (what the kernel runs when a segment is longer than 6 ops)
+void aba_loop(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
+    const int n = w->n_dofs;
+    const Ctl ctl(w);
+    std::vector<Motion> vel(w->capacity);
+    std::vector<float> recs((size_t)w->capacity * 8);
+    for (int64_t b = 0; b < B; ++b)
+        for (int seg = 0; seg < w->n_segments; ++seg) {
+            Motion ms[DRM_MAX_SLOTS];
+            ArtBody bs[DRM_MAX_SLOTS];
+            for (auto &a : bs) art_zero(a);
+            aba_tree_walk(
+                w->n_segments > 1 ? w->prefix_end : 0, w->seg_begin[seg], w->seg_begin[seg + 1], ctl,
+                [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, flags,
+                [&](int d, float &x, float &v) { x = q[b * n + d]; v = qd[b * n + d]; }, [&](int d) { return f[b * n + d]; },
+                [&](int d, float v) { qdd[b * n + d] = v; },
+                [&](int k, const Motion &M) { vel[k] = M; },
+                [&](int k, Motion &M) {
+                    for (int i = 0; i < 3; ++i) { M.wa[i] = f2_make(vel[k].wa[i][0], 0.f); M.va[i] = f2_make(vel[k].va[i][0], 0.f); }
+                },
+                [&](int k, const float *r) { for (int i = 0; i < 8; ++i) recs[k * 8 + i] = r[i]; },
+                [&](int k, float *r) { for (int i = 0; i < 8; ++i) r[i] = recs[k * 8 + i]; },
+                [&](int sl, const Motion &M) { ms[sl] = M; }, [&](int sl, Motion &M) { M = ms[sl]; },
+                [&](int sl, const ArtBody &a) { art_add(bs[sl], a); },
+                [&](int sl, ArtBody &a) { art_add(a, bs[sl]); art_zero(bs[sl]); });
+        }
+}
+
+static bool short_segments(const drm_walk *w) {
+    for (int s = 0; s < w->n_segments; ++s)
+        if (w->seg_begin[s + 1] - w->seg_begin[s] > 6) return false;
+    return true;
+}
+
 void fd_loop(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
     const int n = w->n_dofs;
+    if (!short_segments(w)) return aba_loop(w, q, qd, f, B, flags, qdd);
     std::vector<float> H((size_t)n * n), T((size_t)n * (n + 1) / 2), x(n);
     for (int64_t b = 0; b < B; ++b) {
         crba_loop(w, q + b * n, 1, H.data());
@@ -275,18 +310,6 @@ void fd_loop(const drm_walk *w, const float *q, const float *qd, const float *f,
             float *r = qdd + b * n + lo;
             for (int d = 0; d < cnt; ++d) r[d] = f[b * n + lo + d] - x[lo + d];
             ltdl_solve(cnt, T.data(), r);
-        }
-        if (flags & DRM_FD_REFINE) { // x1 = x0 + H^-1 (f - ID(q, qd, x0)), factors reused (T is per segment: refactorise here)
-            rnea_loop(w, q + b * n, qd + b * n, qdd + b * n, 1, flags, x.data());
-            for (int seg = 0; seg < w->n_segments; ++seg) {
-                const int lo = w->seg_dof_lo[seg], cnt = w->seg_dof_cnt[seg];
-                for (int i = 0; i < cnt; ++i)
-                    for (int j = 0; j <= i; ++j) T[tri_index(i, j)] = H[(lo + i) * n + lo + j];
-                std::vector<float> r(cnt);
-                for (int d = 0; d < cnt; ++d) r[d] = f[b * n + lo + d] - x[lo + d];
-                ltdl_solve(cnt, T.data(), r.data());
-                for (int d = 0; d < cnt; ++d) qdd[b * n + lo + d] += r[d];
-            }
         }
     }
 }

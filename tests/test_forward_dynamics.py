@@ -1,4 +1,5 @@
-"""Forward dynamics (K8, csrc/drm_forward_dynamics.hip: composite-rigid-body H + RNEA bias torques + leaf-to-root L^T D L solve).
+"""Forward dynamics (K8, csrc/drm_forward_dynamics.hip: the articulated-body recursion for robots with a long segment,
+composite-rigid-body H + RNEA bias torques + leaf-to-root L^T D L solve for 7-DoF arms and hands).
 
 CPU (not gpu): the oracle's line-by-line restatement of the reference's articulated-body recursion
 (robot_model.py:487-624) against accelerations recorded from the UNMODIFIED reference (tests/golden/golden_fd.npz,
@@ -8,12 +9,9 @@ arithmetic (host emulation) against the fp64 oracle for every shipped robot.  GP
 Tolerance: forward dynamics amplifies fp32 rounding by cond(H) (up to ~1e6 for the Jaco's gram-scale finger links,
 where |qdd| reaches 1e6 rad/s^2); the reference's own fp32 result is 1.5e-4 (relative to 1 + |qdd|) away from an fp64
 evaluation there.  Accelerations are therefore compared as |d qdd| <= tol * (1 + |qdd|) with tol = 1e-3 against
-fp64 and against the reference (hands, grippers, mobile bases with gram-scale links), 1e-4 for the arms.  Robots whose
-sub-tree masses spread over more than two decades (flatten.mass_spread: Fetch, Jaco, an arm carrying a hand) take one
-step of iterative refinement by default (DRM_FD_REFINE: the residual f - ID(q, qd, qdd) from the inverse-dynamics walk),
-which brings the kernel to the accuracy of the reference's fp32 articulated-body recursion (observed vs fp64 on 200
-random states: Fetch 1.6e-3 -> 4.7e-5 where the fp32 ABA has 1.3e-4; Jaco 7e-4 -> 3e-5 / 2.4e-4; iiwa7 + Allegro
-6e-4 -> 4e-4 / 3e-4).
+fp64 and against the reference (hands, grippers, mobile bases with gram-scale links), 1e-4 for the arms.  The robots
+that are badly conditioned (Fetch, Jaco, an arm carrying a hand: sub-tree masses spread over more than two decades) run
+the articulated-body kernel, whose error is that of the reference's own fp32 recursion (3e-5 .. 2e-4 against fp64).
 """
 import ctypes
 
@@ -264,51 +262,43 @@ def test_gpu_forward_dynamics_old_is_the_same_linear_system():
     assert torch.allclose(torch.einsum("bij,bj->bi", H, old) + nle, f, atol=2e-4, rtol=2e-4)
 
 
-# ---------------------------------------------------------------------------------------------- refinement step
-def test_mass_spread_selects_the_badly_conditioned_robots():
-    """flatten.mass_spread: largest / smallest sub-tree mass behind a moving joint; above REFINE_MASS_SPREAD the model
-    turns the refinement step of forward dynamics on."""
-    from differentiable_robot_model_amd.flatten import REFINE_MASS_SPREAD, mass_spread
-    want = {"panda_no_gripper": False, "iiwa7": False, "allegro_left": False, "trifinger_edu": False,
-            "fetch": True, "jaco": True, "iiwa7_allegro": True}
-    for robot, refine in want.items():
-        m = load_model(robot)
-        assert (mass_spread(m._spec) > REFINE_MASS_SPREAD) == refine == m.forward_dynamics_refinement, robot
+# ---------------------------------------------------------------------------------------------- articulated-body walk
+LONG_SEGMENT_ROBOTS = ["fetch", "jaco", "iiwa7_allegro", "panda"]
 
 
-@pytest.mark.parametrize("robot", ["fetch", "jaco", "iiwa7_allegro"])
-def test_emu_refinement_step_recovers_aba_accuracy(emu, robot):
-    """DRM_FD_REFINE (flag 4): qdd += H^-1 (f - ID(q, qd, qdd)).  On the robots that need it the error against the fp64
-    oracle drops towards the level of the reference's own fp32 articulated-body recursion (the oracle's fp32 build)."""
+@pytest.mark.parametrize("robot", LONG_SEGMENT_ROBOTS)
+def test_emu_articulated_body_walk_has_the_accuracy_of_the_reference_recursion(emu, robot):
+    """drm_tree.hpp aba_tree_walk in fp32 against the fp64 oracle: no worse than the reference's own recursion evaluated in
+    fp32 (the oracle's fp32 build), on the whole-tree walk and on the folded walk the API launches."""
+    from test_host_emu import folded_host_walk
     m = load_model(robot)
     n, B = m._n_dofs, 120
     q, qd, _ = sample_states(m, B, seed=61)
     f = np.random.default_rng(3).uniform(-1, 1, (B, n)).astype(np.float32)
-    prog = build_walk(m._spec, whole_tree=True)
-    walk, keep = host_walk(m, prog)
     orc = Oracle(m._spec)
     args = (q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), 1, 1)
     ref, aba32 = orc.forward_dynamics(*args, np.float64), orc.forward_dynamics(*args, np.float32)
-    err = {}
-    for flags in (3, 7):
+    prog = build_walk(m._spec, whole_tree=True)
+    assert max(prog.seg_begin[s + 1] - prog.seg_begin[s] for s in range(prog.n_segments)) > 6  # (what selects the walk)
+    walk, keep = host_walk(m, prog)
+    fprog = build_walk(m._spec, whole_tree=True, drop_folded=True)
+    fwalk, fkeep = folded_host_walk(m, fprog)
+    for w in (walk, fwalk):
         out = np.full((B, n), np.nan, np.float32)
-        assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(out)) == 0
-        err[flags] = rel_err(out, ref)
-    # (the fp32 ABA of the oracle, for orientation: 3e-5 .. 3e-4 on these robots)
-    assert err[7] < 0.7 * err[3] and err[7] < max(5e-4, 2.0 * rel_err(aba32, ref)), (robot, err, rel_err(aba32, ref))
+        assert emu.emu_forward_dynamics(ctypes.byref(w), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), 3, _ptr(out)) == 0
+        assert rel_err(out, ref) < max(3e-4, 3.0 * rel_err(aba32, ref)), (robot, rel_err(out, ref), rel_err(aba32, ref))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["fetch", "jaco"])
-def test_gpu_refinement_is_on_by_default_where_it_matters(robot):
+@pytest.mark.parametrize("robot", LONG_SEGMENT_ROBOTS)
+def test_gpu_articulated_body_kernel_vs_fp64_oracle(robot):
     m = load_model(robot, "cuda")
-    assert m.forward_dynamics_refinement
     n, B = m._n_dofs, 200
     q, qd, _ = sample_states(m, B, seed=61)
     f = np.random.default_rng(3).uniform(-1, 1, (B, n)).astype(np.float32)
     tq, tqd, tf = (torch.from_numpy(a).cuda() for a in (q, qd, f))
-    ref = Oracle(m._spec).forward_dynamics(q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), 1, 1, np.float64)
-    refined = rel_err(m.compute_forward_dynamics(tq, tqd, tf, True, True).cpu().numpy(), ref)
-    m.forward_dynamics_refinement = False
-    plain = rel_err(m.compute_forward_dynamics(tq, tqd, tf, True, True).cpu().numpy(), ref)
-    assert refined < 2e-4 and refined < 0.5 * plain, (robot, refined, plain)
+    args = (q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), 1, 1)
+    orc = Oracle(m._spec)
+    ref, aba32 = orc.forward_dynamics(*args, np.float64), orc.forward_dynamics(*args, np.float32)
+    got = rel_err(m.compute_forward_dynamics(tq, tqd, tf, True, True).cpu().numpy(), ref)
+    assert got < max(3e-4, 3.0 * rel_err(aba32, ref)), (robot, got, rel_err(aba32, ref))

@@ -449,7 +449,7 @@ def test_folded_dynamics_walk_matches_the_full_walk(robot):
     of = m._ops_f(full)
     tau_full = backend.rnea(full.program, of, full.ops_i, q, qd, qdd, True, True, n)
     H_full = backend.crba(full.program, of, full.ops_i, q, n)
-    acc_full = backend.forward_dynamics(full.program, of, full.ops_i, q, qd, f, True, True, n, m.forward_dynamics_refinement)
+    acc_full = backend.forward_dynamics(full.program, of, full.ops_i, q, qd, f, True, True, n)
     gin, _ = backend.rnea_backward(full.program, of, full.ops_i, q, qd, qdd, gtau, True, True, n, 0, True)
     assert torch.allclose(tau.detach(), tau_full, **TOL_TAU) and torch.allclose(H, H_full, **TOL_TAU)
     assert ((acc - acc_full).abs() / (1 + acc_full.abs())).max().item() < 1e-3

@@ -119,8 +119,6 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     print("crba        allegro B=%8d %9.2f us  %7.1f GB/s (1088 B/eval) %6.2f Gevals/s" % (B, us, B * 1088 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), None, st())), launches=20)
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
-    us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 5, aa.data_ptr(), None, st())), launches=20)
-    print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s  with the refinement step (DRM_FD_REFINE; the API turns it on for badly conditioned robots only, not for this hand)" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
     print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
 # BASELINE.json configs 2 and 3 as stated: iiwa7 FK + EE Jacobian at 65 536; Panda FK(EE) + RNEA on one GPU's shard of

@@ -17,14 +17,17 @@ def graph_time(fn, launches=20, reps=3):
         best = min(best, s.elapsed_time(e) / launches * 1e3)
     return best
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+ONLY_FD = len(sys.argv) > 2 and sys.argv[2] == "fd"   # probe_robots.py B fd: the forward-dynamics column only
 for robot in ("panda_no_gripper", "panda", "fetch", "fetch_arm_no_gripper", "jaco", "iiwa7_allegro", "trifinger_edu"):
     m = load(robot)
     q, qd, qdd = (t.cuda() for t in sample(m, B))
     ee = m._bodies[-1].name
     dw = m._dynamics_walk()
-    t_fkj = graph_time(lambda: m.compute_endeffector_jacobian(q, ee))
-    t_id = graph_time(lambda: m.compute_inverse_dynamics(q, qd, qdd))
-    t_h = graph_time(lambda: m.compute_lagrangian_inertia_matrix(q))
+    t_fkj = t_id = t_h = float("nan")
+    if not ONLY_FD:
+        t_fkj = graph_time(lambda: m.compute_endeffector_jacobian(q, ee))
+        t_id = graph_time(lambda: m.compute_inverse_dynamics(q, qd, qdd))
+        t_h = graph_time(lambda: m.compute_lagrangian_inertia_matrix(q))
     t_fd = graph_time(lambda: m.compute_forward_dynamics(q, qd, qdd))
     print("%-22s n=%2d ops=%2d segs=%d  FK+Jac(%s) %7.1f  RNEA %7.1f  CRBA %7.1f  FD %7.1f us" % (
         robot, m._n_dofs, dw.program.n_ops, dw.program.n_segments, ee[:14], t_fkj, t_id, t_h, t_fd), flush=True)
