@@ -28,6 +28,7 @@ rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- pytho
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
+python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
 [ -x $ROOT/tools/ubench/metric_lab ] && $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
 cd $ROOT
 # keep what travels back small: per-dispatch counter rows of OUR kernels only
