@@ -2,14 +2,15 @@
 //
 // Replaces DifferentiableRobotModel.compute_forward_dynamics (robot_model.py:487-624, Featherstone's
 // articulated-body algorithm written as three Python loops over the links with 6x6 bmm's per link).  The
-// articulated-body recursion is an O(n) elimination of the linear system H qdd = f - nle; this kernel forms the same
-// system with the two walks it already has — the composite-rigid-body walk for H, RNEA with qdd = 0 for the bias torques
-// nle — and solves it per sample by an L^T D L factorisation taken from the leaves to the root, the elimination order of
-// the articulated-body recursion (~n^3/3 FMAs, less than one of the walks).  Same result up to fp32 rounding amplified by
-// the conditioning of the sub-trees, like the reference's own recursion (tolerances in tests/).
+// articulated-body recursion is an O(n) elimination of the linear system H qdd = f - nle.  Where H is small — 7-DoF arm
+// chains (forward_dynamics_arm_kernel) and robots whose segments are all short, the fingers of a hand
+// (forward_dynamics_tree_kernel) — the kernels form the same system with the two walks they already have, the
+// composite-rigid-body walk for H and RNEA with qdd = 0 for the bias torques nle, and solve it per sample in registers / LDS by
+// an L^T D L factorisation taken from the leaves to the root, the elimination order of the recursion.  Every other robot (an
+// arm carrying a gripper or a hand, a mobile manipulator) runs the recursion itself (forward_dynamics_aba_kernel): H of a
+// 23-DoF robot would take a CU's LDS after one tile, and cond(H) times the rounding of its entries is what the result loses.
 //
 // Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
-// 7-DoF arm chains run forward_dynamics_arm_kernel below; every other robot the loop-structured kernel.
 #include <map>
 #include <mutex>
 #include <utility>

@@ -1925,8 +1925,7 @@ DRM_HD void crba_chain_trig(ROW row, const float (&cs)[NJ], const float (&sn)[NJ
 // Eliminating the distal joints first is what the reference's articulated-body recursion does (robot_model.py:487-624
 // works from the leaves to the root and divides joint by joint): the Schur complements then only ADD the small
 // inertias of the finger / wrist links to the large entries of the joints above them.  A Cholesky factorisation from
-// joint 0 down subtracts kilogram-scale terms from gram-scale blocks instead and loses cond(H) * eps there (a 7-DoF arm
-// carrying a 16-DoF hand: 1e-2 relative error in fp32 against 2e-4 this way).  Same flops as Cholesky.
+// joint 0 down subtracts kilogram-scale terms from gram-scale blocks instead and loses cond(H) * eps there.  Same flops as Cholesky.
 // H is the lane's PACKED LOWER TRIANGLE (entry (i, j), i >= j, at i (i + 1) / 2 + j; LDS in the kernel); b is
 // overwritten with x.  Used by the forward-dynamics kernels: qdd = H^-1 (f - nle).
 // ---------------------------------------------------------------------------
@@ -1938,8 +1937,7 @@ DRM_HD float recip_f(float x) {
     return 1.0f / x;
 #endif
 }
-// H(i) -> reference to element i of the packed triangle (an LDS row, or a strided HBM scratch area for robots whose
-// triangle does not fit in LDS)
+// H(i) -> reference to element i of the packed triangle (an LDS row in the kernel)
 template <class HA>
 DRM_HD void ltdl_factor_acc(int n, HA H) {
     for (int k = n - 1; k >= 0; --k) {

@@ -245,8 +245,8 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *st
  * 7 x 7 there); every other robot (an arm carrying a gripper or a hand, a mobile manipulator) runs the articulated-body
  * recursion itself, three sweeps over the walk with 8 floats per link and sample between them.
  *   scratch   drm_forward_dynamics_scratch_floats(walk, B) floats owned by the caller: the per-link records of the
- *             articulated-body sweeps when the launch keeps them in HBM instead of LDS (0 when it does not; never read
- *             or written then, may be NULL)
+ *             articulated-body sweeps, [resident block][link][8][64] — bounded by what the device holds at once (tens of
+ *             MB), not by B.  0 for the arm and finger kernels: scratch is then never touched and may be NULL
  */
 int64_t drm_forward_dynamics_scratch_floats(const drm_walk *walk, int64_t B);
 int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,

@@ -38,8 +38,10 @@ def emu(request):
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
         # -O1: the straight-line templates take minutes at -O2/-O3 and the checks here are about arithmetic and
         # front-end semantics (the clang quirk above reproduces at every optimisation level), not about speed
+        tmp = "%s.%d.tmp" % (lib, os.getpid())   # (pytest-xdist workers may all find the library stale at once)
         subprocess.check_call([cxx if cxx == "g++" else ROCM_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared",
-                               "-ffp-contract=fast", "-mfma", "-w", "-o", lib, src])
+                               "-ffp-contract=fast", "-mfma", "-w", "-o", tmp, src])
+        os.replace(tmp, lib)
     return ctypes.CDLL(lib)
 
 
