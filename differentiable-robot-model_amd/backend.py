@@ -44,7 +44,7 @@ EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "dr
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
-           "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats")
+           "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -99,7 +99,9 @@ def load_library(path: str = None):
         lib.drm_forward_dynamics_scratch_floats.restype = i64
         lib.drm_forward_dynamics_scratch_floats.argtypes = [wp, i64]
         lib.drm_crba.restype = ctypes.c_int
-        lib.drm_crba.argtypes = [wp, vp, i64, vp, vp]
+        lib.drm_crba.argtypes = [wp, vp, i64, vp, vp, vp]
+        lib.drm_crba_scratch_floats.restype = i64
+        lib.drm_crba_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_rnea.restype = ctypes.c_int
         lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
@@ -358,8 +360,12 @@ def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     if B == 0:
         return H
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    # robots with a long segment collect the lower triangle of H in scratch before its rows are written
+    need = int(lib.drm_crba_scratch_floats(ctypes.byref(walk), B))
+    scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
     with torch.cuda.device(q.device):
-        _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(), _stream(q.device)))
+        _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(),
+                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
     return H
 
 

@@ -12,24 +12,18 @@
 
 namespace drm {
 
-constexpr int CRBA_BLOCKS = 0, CRBA_TRIANGLE = 1, CRBA_DIRECT = 2; // how a segment's part of H reaches HBM (crba_tree_kernel<MODE>)
 constexpr int CRBA_SHORT_OPS = 6; // segments of up to this many ops in a row take crba_tree_walk_short
 
-// Loop-structured composite-rigid-body algorithm of any robot (drm_tree.hpp crba_tree_walk): one tile of 64 samples per
-// block, one wavefront per segment.  The sub-trees off the fixed root give the diagonal blocks of H and everything between
-// two of them is a structural zero (an Allegro hand: four 4 x 4 blocks in a 16 x 16 matrix), so a wavefront keeps only ITS
-// block (cnt x cnt floats per sample) in LDS; once all are done the whole block of threads assembles the [64, n, n] rows —
-// block entries where a row and a column belong to the same segment, zeros elsewhere — and writes them with coalesced
-// 16-byte stores.  (Staging the full 256 n^2-byte tile instead allowed one block per CU for n = 16: 1 330 -> 697 us at
-// 2^20 samples; this form: see profiles/.)
+// Robots whose segments are all SHORT (the fingers of a hand): one tile of 64 samples per block, one wavefront per segment.
+// The sub-trees off the fixed root give the diagonal blocks of H and everything between two of them is a structural zero (an
+// Allegro hand: four 4 x 4 blocks in a 16 x 16 matrix), so a wavefront keeps only ITS block (cnt x cnt floats per sample) in
+// LDS; once all are done the whole block of threads assembles the [64, n, n] rows — block entries where a row and a column
+// belong to the same segment, zeros elsewhere — and writes them with coalesced 16-byte stores.  (Staging the full
+// 256 n^2-byte tile instead allowed one block per CU for n = 16: 1 330 -> 697 us at 2^20 samples; this form: see profiles/.)
 // LDS: [ table ][ q : 64 (n|1) ][ segment map : dof -> (segment's first dof, its dof count, its block's LDS offset) ]
-//      shared, then per wavefront [ cos / sin / value per op : ops * 3 * 64 ][ inertia slots : n_slots * 10 * 64 ]
-//      [ block : 64 (cnt^2 | 1), or (CRBA_TRIANGLE) 64 (cnt (cnt + 1) / 2 | 1), or (CRBA_DIRECT) nothing: lanes store their
-//        entries straight to HBM over a zeroed H ]
-template <int MODE>
+//      shared, then per wavefront [ inertia slots : n_slots * 10 * 64 ][ block : 64 (cnt^2 | 1) ]
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t align) {
-    constexpr bool DIRECT = MODE == CRBA_DIRECT, TRI = MODE == CRBA_TRIANGLE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileCtx tc = tile_begin(B);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -39,97 +33,248 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     float *lq = smem + table_lds_floats(a.n_ops);
     int *lmap = reinterpret_cast<int *>(lq + round4(WAVE * Sq)); // [3][n]: segment lo, cnt, block offset (floats) per DoF
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
-    // staged per segment: the cnt x cnt block, or (TRI: one big segment) the lower triangle of the symmetric block
-    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], Sb = pad_odd(TRI ? cnt * (cnt + 1) / 2 : cnt * cnt);
-    float *ltr = smem + a.wave_off[wave];                          // [op - first][3][64]
-    float *lis = ltr + (last - first) * (CRBA_PARK_FLOATS * WAVE); // inertia slots [slot][10][64]
-    float *lb = lis + a.n_slots * (10 * WAVE);                     // this segment's block of H: [64][cnt^2 | 1]
+    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], Sb = pad_odd(cnt * cnt);
+    float *lis = smem + a.wave_off[wave];        // inertia slots [slot][10][64]
+    float *lb = lis + a.n_slots * (10 * WAVE);   // this segment's block of H: [64][cnt^2 | 1]
 
     const TableLds tab = stage_tree_table(a, smem);
     if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
     for (int s = 0; s < a.n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f;
-    if (!DIRECT) {
-        for (int i = (int)lane; i < WAVE * Sb; i += WAVE) lb[i] = 0.0f; // pairs of joints on different branches of the segment
-        for (int d = (int)lane; d < cnt; d += WAVE) {
-            lmap[lo + d] = lo; lmap[n + lo + d] = cnt; lmap[2 * n + lo + d] = (int)(lb - smem);
-        }
+    for (int i = (int)lane; i < WAVE * Sb; i += WAVE) lb[i] = 0.0f; // pairs of joints on different branches of the segment
+    for (int d = (int)lane; d < cnt; d += WAVE) {
+        lmap[lo + d] = lo; lmap[n + lo + d] = cnt; lmap[2 * n + lo + d] = (int)(lb - smem);
     }
     __syncthreads();
 
     const bool live = (int)lane < tc.rows;
     const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row read zero angles, their H is never stored
     float *brow = lb + lane * Sb;
-    float *hdst = H + (tc.b0 + lane) * nn;
     const TableLds &ctl = tab;
-    auto hout = [&](int di, int dj, float v) {
-        if (DIRECT) {
-            if (live) hdst[di * n + dj] = v;
-        } else if (TRI) {
-            if (di >= dj) brow[tri_index(di - lo, dj - lo)] = v;
-        } else {
-            brow[(di - lo) * cnt + (dj - lo)] = v;
-        }
-    };
+    auto hout = [&](int di, int dj, float v) { brow[(di - lo) * cnt + (dj - lo)] = v; };
     auto qf = [&](int d) -> float { return live ? qrow[d] : 0.0f; };
-    // a short serial segment (a finger): the unrolled walk with the joint transforms in registers; anything else: the loop
+    // a serial segment (a finger): the unrolled walk with the joint transforms in registers; a short segment that branches
+    // takes the loop, its cos / sin recomputed where the loop asks for them
     if (!crba_tree_walk_short<CRBA_SHORT_OPS>(first, last, ctl, [&](int k) { return tab.row(k); }, qf, hout)) {
-        crba_prepare(first, last, ctl, qf, [&](int k, float c, float s, float x) {
-            float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-            b[0] = c; b[WAVE] = s; b[2 * WAVE] = x;
-        });
         crba_tree_walk(
             first, last, ctl, [&](int k) { return tab.row(k); },
             [&](int k, float &c, float &s, float &x) {
-                const float *b = ltr + (k - first) * (CRBA_PARK_FLOATS * WAVE) + lane;
-                c = b[0]; s = b[WAVE]; x = b[2 * WAVE];
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                x = 0.0f; c = 1.0f; s = 0.0f;
+                if (ct.dof >= 0) {
+                    x = qf(ct.dof);
+                    if (!ct.prismatic) sincos_one(x, s, c);
+                }
             },
             [&](int s, const Inertia &I) { lds_add_inertia(lis, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lis, s, lane, I); },
             hout);
     }
-    if (!DIRECT) {
-        __syncthreads();
-        // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
-        auto entry = [&](unsigned b, unsigned r, unsigned c) -> float {
+    __syncthreads();
+    // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
+    auto entry = [&](unsigned b, unsigned r, unsigned c) -> float {
+        const int slo = lmap[r], scnt = lmap[n + r];
+        const unsigned cc = c - (unsigned)slo, rr = r - (unsigned)slo;
+        if (cc >= (unsigned)scnt) return 0.0f;
+        return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + rr * (unsigned)scnt + cc];
+    };
+    float *g = H + tc.b0 * nn;
+    if (tc.full && !(n & 3) && (align & AL_TAU)) {
+        // one 16-byte store per thread and round, linear in the tile: thread i writes float4 i.  The (sample, row, column)
+        // of a float4 is kept incrementally (no integer divisions in the loop) and its row's segment is looked up once.
+        const unsigned per_row = (unsigned)n >> 2, per_sample = (unsigned)nn >> 2, total = WAVE * per_sample;
+        const unsigned row_magic = per_row > 1u ? 0xffffffffu / per_row + 1u : 0u; // j / per_row for j < 2^16 (per_row = 1: j)
+        unsigned b = threadIdx.x / per_sample, j = threadIdx.x - b * per_sample;
+        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+            const unsigned r = per_row > 1u ? __umulhi(j, row_magic) : j, c = (j - r * per_row) * 4u;
             const int slo = lmap[r], scnt = lmap[n + r];
-            const unsigned cc = c - (unsigned)slo, rr = r - (unsigned)slo;
-            if (cc >= (unsigned)scnt) return 0.0f;
-            if (!TRI) return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + rr * (unsigned)scnt + cc];
-            const unsigned hi = rr > cc ? rr : cc, lw = rr > cc ? cc : rr;
-            return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * (scnt + 1) / 2) + hi * (hi + 1u) / 2u + lw];
-        };
-        float *g = H + tc.b0 * nn;
-        if (tc.full && !(n & 3) && (align & AL_TAU)) {
-            // one 16-byte store per thread and round, linear in the tile: thread i writes float4 i.  The (sample, row, column)
-            // of a float4 is kept incrementally (no integer divisions in the loop) and its row's segment is looked up once.
-            const unsigned per_row = (unsigned)n >> 2, per_sample = (unsigned)nn >> 2, total = WAVE * per_sample;
-            const unsigned row_magic = per_row > 1u ? 0xffffffffu / per_row + 1u : 0u; // j / per_row for j < 2^16 (per_row = 1: j)
-            unsigned b = threadIdx.x / per_sample, j = threadIdx.x - b * per_sample;
-            for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
-                const unsigned r = per_row > 1u ? __umulhi(j, row_magic) : j, c = (j - r * per_row) * 4u;
-                const int slo = lmap[r], scnt = lmap[n + r];
-                const unsigned rr = r - (unsigned)slo, rbase = TRI ? rr * (rr + 1u) / 2u : rr * (unsigned)scnt;
-                const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(TRI ? scnt * (scnt + 1) / 2 : scnt * scnt);
-                float v[4];
+            const unsigned rr = r - (unsigned)slo, rbase = rr * (unsigned)scnt;
+            const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt);
+            float v[4];
 #pragma unroll
-                for (unsigned e = 0; e < 4u; ++e) {
-                    const unsigned cc = c + e - (unsigned)slo;
-                    if (TRI) // entry (rr, cc) of the symmetric block from its packed lower triangle
-                        v[e] = cc >= (unsigned)scnt ? 0.0f : cc <= rr ? src[rbase + cc] : src[cc * (cc + 1u) / 2u + rr];
-                    else
-                        v[e] = cc < (unsigned)scnt ? src[rbase + cc] : 0.0f;
-                }
-                store16_wt(g + 4u * i, make_float4(v[0], v[1], v[2], v[3]));
-                j += blockDim.x;
-                while (j >= per_sample) { j -= per_sample; ++b; }
+            for (unsigned e = 0; e < 4u; ++e) {
+                const unsigned cc = c + e - (unsigned)slo;
+                v[e] = cc < (unsigned)scnt ? src[rbase + cc] : 0.0f;
             }
-        } else {
-            const unsigned total = (unsigned)tc.rows * (unsigned)nn;
-            for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
-                const unsigned b = i / (unsigned)nn, j = i - b * (unsigned)nn, r = j / (unsigned)n;
-                g[i] = entry(b, r, j - r * (unsigned)n);
-            }
+            store16_wt(g + 4u * i, make_float4(v[0], v[1], v[2], v[3]));
+            j += blockDim.x;
+            while (j >= per_sample) { j -= per_sample; ++b; }
+        }
+    } else {
+        const unsigned total = (unsigned)tc.rows * (unsigned)nn;
+        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+            const unsigned b = i / (unsigned)nn, j = i - b * (unsigned)nn, r = j / (unsigned)n;
+            g[i] = entry(b, r, j - r * (unsigned)n);
         }
     }
+}
+
+// LDS bytes of that launch (0: does not apply — a segment is too long, or the blocks do not fit)
+static size_t crba_short_plan(const drm_walk *w, TreeArgs &a) {
+    a = tree_args(w, false);
+    if (a.max_seg_ops > CRBA_SHORT_OPS) return 0;
+    const int n = a.n;
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n);
+    const size_t lds = sizeof(float) * layout_waves(a, shared, 0, a.n_slots * 10 * WAVE, [&](int sg) {
+        const int c = a.seg_dof_cnt[sg];
+        return round4(WAVE * pad_odd(c * c));
+    });
+    return lds <= (size_t)MAX_LDS_BYTES ? lds : 0;
+}
+
+// Every other robot (an arm carrying a gripper or a hand, a mobile manipulator: a segment of more than CRBA_SHORT_OPS ops).
+// The walk is drm_tree.hpp crba_set_walk: the forces of all the joints below an op travel up the tree together (LDS, 6 floats
+// per joint and sample), every op's transform is built once.
+// A 23-DoF segment's part of H is 2 KB per sample: staged in LDS, even as a triangle, it left one wavefront per CU, and lanes
+// storing their entries straight to H — 4 bytes each, 2 KB apart, 64 cache lines per instruction — kept the address path
+// busy instead.  Here the lower triangle of a segment's block goes to HBM scratch, [entry][64] per block and segment
+// (coalesced; the grid is PERSISTENT, so the scratch is sized by what the chip holds at once and stays in L2), and after the
+// walk every wavefront writes the rows of ITS segment: a row's entries come back from scratch with coalesced loads, are turned
+// through a [64][n|1] LDS buffer and leave as runs of n floats per sample.
+// LDS: [ table ][ q : 64 (n|1) ] shared, then per wavefront
+//      [ inertia slots : n_slots * 10 * 64 ][ forces : cnt * 6 * 64, later the row buffer : 64 (n|1) ][ sub-tree tables ]
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    crba_rows_kernel(TreeArgs a, int nt_max, const float *__restrict__ q, int64_t B, int n_tiles, float *__restrict__ H,
+                     float *__restrict__ scratch, uint32_t magic_q, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, nn = n * n, Sq = pad_odd(n);
+    float *lq = smem + table_lds_floats(a.n_ops);
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1], n_seg_ops = last - first;
+    const int lo = a.seg_dof_lo[wave], cnt = a.seg_dof_cnt[wave], nt = cnt * (cnt + 1) / 2;
+    float *lis = smem + a.wave_off[wave];          // inertia slots [slot][10][64]
+    float *lfo = lis + a.n_slots * (10 * WAVE);    // forces [slot of a moving op][6][64]; after the walk: one row of H, [64][n|1]
+    float *lrow = lfo;
+    const int fo_floats = cnt * (6 * WAVE) > round4(WAVE * Sq) ? cnt * (6 * WAVE) : round4(WAVE * Sq);
+    int *t_lo = reinterpret_cast<int *>(lfo + fo_floats), *t_end = t_lo + n_seg_ops + 1, *t_dof = t_end + n_seg_ops;
+    // this wavefront's triangles in scratch, SAMPLE-major [64][ntp]: a lane scatters its own entries during the walk (one store
+    // per entry), the rows are then written sample by sample from coalesced reads
+    const int ntp = round4(nt);
+    float *tri = scratch + ((int64_t)blockIdx.x * a.n_segments + wave) * (int64_t)nt_max * WAVE;
+    const TableLds tab = stage_tree_table(a, smem);
+    for (int s = 0; s < a.n_slots * 10; ++s) lis[s * WAVE + lane] = 0.0f; // (every take leaves its slot at zero again)
+    __syncthreads();
+    const TableLds &ctl = tab;
+    // (every lane writes the same wave-uniform values)
+    crba_set_tables(first, last, ctl, [&](int k, int v) { t_lo[k - first] = v; }, [&](int k, int v) { t_end[k - first] = v; },
+                    [&](int k) { return __builtin_amdgcn_readfirstlane(t_end[k - first]); }, [&](int m, int d) { t_dof[m] = d; });
+
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        __syncthreads(); // every wavefront is done with the previous tile's q
+        const int64_t b0 = (int64_t)tile * WAVE;
+        const int rows = B - b0 < WAVE ? (int)(B - b0) : WAVE;
+        const bool full = rows == WAVE;
+        if (wave == 0) tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, full && (n & 1) && (align & AL_Q), full && (align & AL_Q));
+        for (int i = (int)lane; i < 16 * ntp; i += WAVE) // pairs of joints on different branches of the segment stay zero
+            reinterpret_cast<float4 *>(tri)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+        const bool live = (int)lane < rows;
+        const float *qrow = lq + lane * Sq; // lanes past a partial tile's last row read zero angles, their H is never stored
+        crba_set_walk(
+            first, last, ctl, [&](int k) { return tab.row(k); },
+            [&](int k, float &c, float &s, float &x) {
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                x = 0.0f; c = 1.0f; s = 0.0f;
+                if (ct.dof >= 0) {
+                    x = live ? qrow[ct.dof] : 0.0f;
+                    if (!ct.prismatic) sincos_one(x, s, c);
+                }
+            },
+            [&](int k) { return __builtin_amdgcn_readfirstlane(t_lo[k - first]); },
+            [&](int k) { return __builtin_amdgcn_readfirstlane(t_lo[__builtin_amdgcn_readfirstlane(t_end[k - first]) + 1 - first]); },
+            [&](int m) { return t_dof[m]; },
+            [&](int m, Force &F) {
+                const float *b = lfo + m * (6 * WAVE) + lane;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+            },
+            [&](int m, const Force &F) {
+                float *b = lfo + m * (6 * WAVE) + lane;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
+            },
+            [&](int s, const Inertia &I) { lds_add_inertia(lis, s, lane, I); }, [&](int s, Inertia &I) { lds_take_inertia(lis, s, lane, I); },
+            [&](int di, int dj, float v) {
+                if (di >= dj) tri[lane * ntp + tri_index(di - lo, dj - lo)] = v;
+            });
+        wave_lds_sync(); // the forces are dead: their LDS becomes the row buffer
+        // rows lo .. lo + cnt - 1 of H for the tile's samples: block entries inside the segment's columns, zeros outside.
+        // G samples per round: their triangles come back with 16-byte loads, twelve in flight per lane (one at a time, each
+        // would wait out a round trip to L2 / Infinity Cache), into the LDS the forces have left; then every sample's cnt x n
+        // floats leave as 4-byte stores of consecutive lanes — consecutive addresses.
+        float *g = H + b0 * nn;
+        const int G0 = fo_floats / ntp < WAVE ? (fo_floats / ntp) & ~3 : WAVE; // (a multiple of 4 keeps the float4 copies aligned)
+        const int G = G0 > 0 ? G0 : 1, per_sample = cnt * n;
+        const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
+        for (int s0 = 0; s0 < rows; s0 += G) {
+            const int gs = rows - s0 < G ? rows - s0 : G;
+            const float4 *t4 = reinterpret_cast<const float4 *>(tri + s0 * ntp);
+            float4 *l4 = reinterpret_cast<float4 *>(lrow);
+            const int n4 = gs * (ntp >> 2);
+            for (int i0 = 0; i0 < n4; i0 += 12 * WAVE) {
+                float4 v[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * WAVE + (int)lane;
+                    v[u] = i < n4 ? t4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * WAVE + (int)lane;
+                    if (i < n4) l4[i] = v[u];
+                }
+            }
+            wave_lds_sync();
+            // element j of a sample's cnt x n floats = (row j / n, column j % n), kept incrementally; which triangle entry it is
+            // does not depend on the sample, so it is worked out once and the samples are an inner loop of independent copies
+            unsigned r = lane / (unsigned)n, c = lane - r * (unsigned)n;
+            for (int j = (int)lane; j < per_sample; j += WAVE) {
+                const int cc = (int)c - lo;
+                const bool inside = cc >= 0 && cc < cnt;
+                const int hi = (int)r > cc ? (int)r : cc, lw = (int)r > cc ? cc : (int)r;
+                const float *src = lrow + (inside ? tri_index(hi, lw) : 0);
+                float *dst = g + (int64_t)s0 * nn + lo * n + j;
+#pragma unroll 8
+                for (int gi = 0; gi < gs; ++gi) dst[(int64_t)gi * nn] = inside ? src[gi * ntp] : 0.0f;
+                r += step_r; c += step_c;
+                if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+struct CrbaRowsPlan {
+    TreeArgs a;
+    int nt_max, resident;
+    size_t lds;
+};
+static int crba_rows_plan(const drm_walk *w, CrbaRowsPlan &p) {
+    // one wavefront per segment; all the segments through one wavefront when their private areas do not fit side by side
+    for (int single = 0; single < 2; ++single) {
+        p.a = tree_args(w, single != 0);
+        const int n = p.a.n;
+        p.nt_max = 1;
+        for (int sg = 0; sg < p.a.n_segments; ++sg) {
+            const int c = p.a.seg_dof_cnt[sg];
+            if (c * (c + 1) / 2 > p.nt_max) p.nt_max = c * (c + 1) / 2;
+        }
+        p.nt_max = round4(p.nt_max); // (the triangles are copied with 16-byte accesses)
+        const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + round4(WAVE * pad_odd(n));
+        p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * 10 * WAVE, [&](int sg) {
+            const int forces = p.a.seg_dof_cnt[sg] * 6 * WAVE, row = round4(WAVE * pad_odd(n));
+            const int ops = p.a.seg_begin[sg + 1] - p.a.seg_begin[sg];
+            return (forces > row ? forces : row) + round4(2 * ops + 1 + p.a.seg_dof_cnt[sg]);
+        });
+        if (p.lds <= (size_t)MAX_LDS_BYTES || w->n_segments <= 1) break;
+    }
+    int rc = ensure_lds_tree(crba_rows_kernel, p.lds);
+    if (rc) return rc;
+    return resident_blocks(crba_rows_kernel, WAVE * p.a.n_segments, p.lds, p.resident);
 }
 
 // Serial-chain ("arm") specialisation, full tiles only — the design of fk_jacobian_arm_kernel: constant rows staged
@@ -174,7 +319,21 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
 using namespace drm;
 
-extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, void *stream) {
+extern "C" int64_t drm_crba_scratch_floats(const drm_walk *w, int64_t B) {
+    if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
+        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
+        if (B == 0) return 0;
+    }
+    TreeArgs a;
+    if (crba_short_plan(w, a)) return 0;
+    CrbaRowsPlan p;
+    if (crba_rows_plan(w, p)) return 0;
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_segments * p.nt_max * WAVE;
+}
+
+extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !H) return fail(DRM_ERR_INVALID, "q / H must not be NULL");
@@ -196,50 +355,28 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
         if (rc) return rc;
         drm_walk generic = *w;
         generic.shape &= ~DRM_WALK_ARM_CHAIN;
-        return drm_crba(&generic, q + done * n, B - done, H + done * nn, stream);
+        return drm_crba(&generic, q + done * n, B - done, H + done * nn, scratch, stream);
     }
 #endif
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
-    TreeArgs a = tree_args(w);
-    // how a segment's part of H is staged: its cnt x cnt block (small segments: the fingers of a hand), the lower
-    // triangle of its symmetric block (a segment of more than 8 DoF: half the LDS), or not at all (DIRECT: lanes store their entries
-    // straight to HBM over a memset) when staging would leave fewer than two blocks per CU — a big walk (an arm carrying a
-    // hand, 23 DoF) is bound by the latency of its serial ancestor walks, so wavefronts per CU matter more to it than
-    // coalesced stores (measured at 2^20: 3.7 ms direct against 11 ms with one staged wavefront per CU).
-    auto plan = [&](TreeArgs &t, int mode) {
-        const size_t shared = (size_t)table_lds_floats(t.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n);
-        return sizeof(float) * layout_waves(t, shared, CRBA_PARK_FLOATS * WAVE, t.n_slots * 10 * WAVE, [&](int sg) {
-            const int c = t.seg_dof_cnt[sg];
-            return mode == CRBA_DIRECT ? 0 : round4(WAVE * pad_odd(mode == CRBA_TRIANGLE ? c * (c + 1) / 2 : c * c));
-        });
-    };
-    int max_cnt = 0;
-    for (int sg = 0; sg < a.n_segments; ++sg) max_cnt = a.seg_dof_cnt[sg] > max_cnt ? a.seg_dof_cnt[sg] : max_cnt;
-    int mode = max_cnt <= 8 ? CRBA_BLOCKS : CRBA_TRIANGLE; // (small blocks: the plain indexing of a full block is cheaper to assemble)
-    if (plan(a, mode) > (size_t)MAX_LDS_BYTES && a.n_segments > 1) {
-        a = tree_args(w, true);
-        mode = CRBA_TRIANGLE;
-    }
-    if (plan(a, mode) > (size_t)MAX_LDS_BYTES / 2) mode = CRBA_DIRECT;
-    const size_t lds = plan(a, mode);
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
-    if (mode == CRBA_DIRECT) {
-        hipError_t e = hipMemsetAsync(H, 0, sizeof(float) * (size_t)B * nn, s);
-        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-        rc = ensure_lds_tree(crba_tree_kernel<CRBA_DIRECT>, lds);
+    TreeArgs fingers;
+    if (const size_t lds = crba_short_plan(w, fingers)) {
+        rc = ensure_lds_tree(crba_tree_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<CRBA_DIRECT>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
-    } else if (mode == CRBA_TRIANGLE) {
-        rc = ensure_lds_tree(crba_tree_kernel<CRBA_TRIANGLE>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<CRBA_TRIANGLE>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
-    } else {
-        rc = ensure_lds_tree(crba_tree_kernel<CRBA_BLOCKS>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel<CRBA_BLOCKS>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, q, B, H, div_magic(n), align);
+        hipLaunchKernelGGL(crba_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, q, B, H, div_magic(n), align);
+        return launched();
     }
+    CrbaRowsPlan p;
+    rc = crba_rows_plan(w, p);
+    if (rc) return rc;
+    if (!scratch || ((uintptr_t)scratch & 15u))
+        return fail(DRM_ERR_INVALID, "this robot's inertia matrix is assembled through scratch: pass drm_crba_scratch_floats() floats, 16-byte aligned");
+    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    hipLaunchKernelGGL(crba_rows_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, p.nt_max, q, B, (int)tiles, H, scratch,
+                       div_magic(n), align);
     return launched();
 }

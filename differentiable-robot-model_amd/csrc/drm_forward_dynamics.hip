@@ -11,10 +11,6 @@
 // 23-DoF robot would take a CU's LDS after one tile, and cond(H) times the rounding of its entries is what the result loses.
 //
 // Per sample: in q, qd, f [n] (12 n bytes), out qdd [n] (4 n bytes).          n = 7: 112 B
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 #include "drm_tree_dev.hpp"
@@ -227,28 +223,16 @@ struct AbaPlan {
     int resident;
 };
 static int aba_plan(const drm_walk *w, AbaPlan &p) {
-    p.a = tree_args(w, false);
-    const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(p.a.n));
-    p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * ABA_SLOT_FLOATS * WAVE, [](int) { return 0; });
+    // one wavefront per segment; all the segments through one wavefront when their save slots do not fit side by side
+    for (int single = 0; single < 2; ++single) {
+        p.a = tree_args(w, single != 0);
+        const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(p.a.n));
+        p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * ABA_SLOT_FLOATS * WAVE, [](int) { return 0; });
+        if (p.lds <= (size_t)MAX_LDS_BYTES || w->n_segments <= 1) break;
+    }
     int rc = ensure_lds_tree(forward_dynamics_aba_kernel, p.lds);
     if (rc) return rc;
-    // blocks per CU by the runtime's own occupancy rule (LDS and registers), times the CUs of the current device
-    static std::mutex mu;
-    static std::map<std::pair<size_t, int>, int> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipGetDevice failed");
-    const auto key = std::make_pair(p.lds * 64 + (size_t)p.a.n_segments, dev);
-    auto it = cache.find(key);
-    if (it == cache.end()) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_dynamics_aba_kernel, WAVE * p.a.n_segments, p.lds) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
-            return fail(DRM_ERR_LAUNCH, "occupancy query failed");
-        it = cache.emplace(key, per_cu * cus).first;
-    }
-    p.resident = it->second;
-    return DRM_OK;
+    return resident_blocks(forward_dynamics_aba_kernel, WAVE * p.a.n_segments, p.lds, p.resident);
 }
 
 // Serial-chain ("arm") specialisation, full tiles only: the chain forms of the two walks (drm_sample.hpp crba_chain,

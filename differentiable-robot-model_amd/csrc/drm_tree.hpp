@@ -344,6 +344,106 @@ DRM_HD void crba_tree_walk(int a, int b, CTL ctl, ROW row, TRIG trig, IADD islot
     }
 }
 
+// The same matrix for a LONG segment (an arm carrying a gripper or a hand), organised so that nothing is walked twice.  The
+// walk above climbs from every moving op to the root of its segment — for each (joint, ancestor) pair a control-word decode,
+// the ancestor's constants and cos / sin out of LDS, its transform rebuilt, one force moved up: ~150 pairs on a 7-DoF arm
+// with a 16-DoF hand, each a serial chain of LDS round trips that a lone wavefront cannot hide (measured: 30 cycles per
+// instruction).  Here the forces F_c = Ic_c S_c of ALL the joints below an op travel up together: when the sweep reaches op
+// i they are already expressed in i's frame, H[i][c] = S_i . F_c is read off for every c in the sub-tree, and all of them
+// are moved into the parent's frame by i's transform, which is built ONCE.  Same multiply-adds in the same order per entry
+// (bit-identical results), but the inner loop is over independent vectors.
+//   sub-tree bookkeeping (wave-uniform, computed once per walk by crba_set_tables): the ops of a sub-tree are contiguous in the
+//   walk, so are the slots of its moving ops —  slot_lo(k) = moving ops of the segment before op k;  slot_hi(k) = slot_lo of the
+//   first op after k's sub-tree;  slot_dof(m) = DoF column of the m-th moving op
+//   fget(m, Force&) / fput(m, Force)   the force of slot m (LDS in the kernel)
+//   trig(k, c, s, q) as above, called once per op;  islot_add / islot_take / hout as above
+template <class CTL, class ROW, class TRIG, class SLO, class SHI, class SDOF, class FGET, class FPUT, class IADD, class ITAKE, class HOUT>
+DRM_HD void crba_set_walk(int a, int b, CTL ctl, ROW row, TRIG trig, SLO slot_lo, SHI slot_hi, SDOF slot_dof, FGET fget, FPUT fput,
+                          IADD islot_add, ITAKE islot_take, HOUT hout) {
+    Inertia carry;
+    inertia_zero(carry);
+#pragma unroll 1
+    for (int k = b - 1; k >= a; --k) {
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        const float *of = row(k);
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        if (ct.child_next) inertia_add(tot, carry);
+        if (ct.save >= 0) islot_take(ct.save, tot);
+        const OpFT o = load_ft(of);
+        float J[9], t[3], c, s, q;
+        trig(k, c, s, q);
+        joint_transform(o, ct.dof >= 0, ct.prismatic, q, c, s, J, t);
+        const int m0 = slot_lo(k), m1 = slot_hi(k);
+        const bool moving = ct.dof >= 0, up = ct.src != DRM_SRC_ROOT && ct.parent >= a;
+        if (moving) {
+            // F = Ic S_k.  revolute: f = -h x e_z = (-h_y, h_x, 0), n = I e_z;  prismatic: f = m e_z, n = h x e_z = (h_y, -h_x, 0)
+            Force F;
+            if (!ct.prismatic) {
+                F.la[0] = f2_make(-tot.h[1], tot.I[2]);
+                F.la[1] = f2_make(tot.h[0], tot.I[4]);
+                F.la[2] = f2_make(0.0f, tot.I[5]);
+            } else {
+                F.la[0] = f2_make(0.0f, tot.h[1]);
+                F.la[1] = f2_make(0.0f, -tot.h[0]);
+                F.la[2] = f2_make(tot.m, 0.0f);
+            }
+            fput(m0, F);
+        }
+        if (moving || up) {
+            for (int m = m0; m < m1; ++m) {
+                Force F;
+                fget(m, F);
+                if (moving) {
+                    const float v = ct.prismatic ? F.la[2][0] : F.la[2][1];
+                    const int dj = slot_dof(m);
+                    hout(ct.dof, dj, v);
+                    if (dj != ct.dof) hout(dj, ct.dof, v);
+                }
+                if (up) {
+                    Force nxt;
+                    rnea_link_force_up(J, t, F, nxt);
+                    fput(m, nxt);
+                }
+            }
+        }
+        if (up) {
+            Inertia upI;
+            inertia_to_parent(J, t, tot, upI);
+            if (ct.src >= 0) islot_add(ct.src, upI);
+            else carry = upI;
+        }
+    }
+}
+// the wave-uniform tables of crba_set_walk for ops [a, b): put_lo(k, v) for k in [a, b], put_hi(k, v) for k in [a, b),
+// put_dof(m, dof); get_hi(k) reads back what put_hi stored (the caller's arrays: LDS in the kernel)
+template <class CTL, class PLO, class PHI, class GHI, class PDOF>
+DRM_HD void crba_set_tables(int a, int b, CTL ctl, PLO put_lo, PHI put_hi, GHI get_hi, PDOF put_dof) {
+    int m = 0;
+    for (int k = a; k < b; ++k) { // slots in walk order
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        put_lo(k, m);
+        if (ct.dof >= 0) put_dof(m++, ct.dof);
+    }
+    put_lo(b, m);
+    // last op of every sub-tree: a parent's sub-tree ends where its last child's does (children come after their parent)
+    for (int k = a; k < b; ++k) put_hi(k, k);
+    for (int k = b - 1; k >= a; --k) {
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        if (ct.parent >= a && get_hi(k) > get_hi(ct.parent)) put_hi(ct.parent, get_hi(k));
+    }
+}
+
 // The same for a SHORT SERIAL segment (ops a .. a + len - 1, each the child of the one before it, at most MAXOPS of them — a
 // finger of a hand, a leg): both loops unrolled, every op's joint transform built ONCE and kept in registers, nothing
 // parked.  The generic walk above rebuilds an ancestor's transform (12 LDS reads, 12 multiply-adds, a control-word decode)

@@ -16,6 +16,10 @@
 // Private to a wavefront, in LDS: the per-op records between two sweeps and the save slots of its branch points.
 #pragma once
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "drm_common.hpp"
 #include "drm_tree.hpp"
 
@@ -210,6 +214,30 @@ static int ensure_lds_tree(K kernel, size_t bytes) {
         return fail(DRM_ERR_UNSUPPORTED, "the per-link records of this robot need %s%ld bytes of LDS per 64-sample tile (max %ld)",
                     "", (long)bytes, (long)MAX_LDS_BYTES);
     return ensure_lds(kernel, bytes);
+}
+
+
+// How many blocks of `kernel` (threads per block, dynamic LDS bytes) the current device holds at once: the grid of the
+// PERSISTENT kernels, whose blocks loop over tiles and own a slice of caller-provided scratch each.  The runtime's own
+// occupancy rule (LDS, registers) per CU times the number of CUs; cached per kernel, geometry and device.
+template <class K>
+static int resident_blocks(K kernel, int threads, size_t lds, int &out) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, size_t>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipGetDevice failed");
+    const auto key = std::make_tuple(dev, threads, lds);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            return fail(DRM_ERR_LAUNCH, "occupancy query failed");
+        it = cache.emplace(key, per_cu * cus).first;
+    }
+    out = it->second;
+    return DRM_OK;
 }
 
 } // namespace drm

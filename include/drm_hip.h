@@ -230,8 +230,13 @@ int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, 
  * compute_inverse_dynamics passes, column j = ID(q, 0, e_j) - ID(q, 0, 0)).  The gravity / damping flags of the
  * reference cancel out of that difference, so there are none here.
  *   q [B, n]  ->  H [B, n, n]   (symmetric; entries of joints on different branches are zero)
+ *   scratch   drm_crba_scratch_floats(walk, B) floats owned by the caller: robots with a long segment (an arm carrying a
+ *             gripper or a hand) collect the lower triangle of H there, [resident block][segment][entry][64] — bounded by
+ *             what the device holds at once, not by B — before its rows are written.  0 for 7-DoF arms and for hands
+ *             (short independent fingers): scratch is then never touched and may be NULL
  */
-int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, void *stream);
+int64_t drm_crba_scratch_floats(const drm_walk *walk, int64_t B);
+int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, float *scratch, void *stream);
 
 /*
  * Forward dynamics over the whole tree: joint accelerations produced by joint torques f in state (q, qd).

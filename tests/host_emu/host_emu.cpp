@@ -242,6 +242,8 @@ void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
     const int n = w->n_dofs;
     const Ctl ctl(w);
     std::vector<TrigRec> tr(w->capacity);
+    bool long_segments = false;
+    for (int s = 0; s < w->n_segments; ++s) long_segments = long_segments || w->seg_begin[s + 1] - w->seg_begin[s] > 6;
     for (int64_t b = 0; b < B; ++b) {
         for (int i = 0; i < n * n; ++i) H[b * n * n + i] = 0.f;
         for (int seg = 0; seg < w->n_segments; ++seg) {
@@ -255,8 +257,19 @@ void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
             auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
             auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
             auto hout = [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; };
-            // as the kernels: the unrolled short-serial form where it applies, the loop otherwise
-            if (!crba_tree_walk_short<6>(a0, b0, ctl, row, qf, hout)) crba_tree_walk(a0, b0, ctl, row, trig, iadd, itake, hout);
+            // as the kernels: robots with a segment of more than 6 ops take the walk that moves all the forces of a sub-tree up
+            // together; otherwise the unrolled short-serial form where it applies, the loop where it does not
+            if (long_segments) {
+                std::vector<int> t_lo(b0 - a0 + 1), t_end(b0 - a0), t_dof(n);
+                std::vector<Force> fs(n);
+                crba_set_tables(a0, b0, ctl, [&](int k, int v) { t_lo[k - a0] = v; }, [&](int k, int v) { t_end[k - a0] = v; },
+                                [&](int k) { return t_end[k - a0]; }, [&](int m, int d) { t_dof[m] = d; });
+                crba_set_walk(a0, b0, ctl, row, trig, [&](int k) { return t_lo[k - a0]; }, [&](int k) { return t_lo[t_end[k - a0] + 1 - a0]; },
+                              [&](int m) { return t_dof[m]; }, [&](int m, Force &F) { F = fs[m]; }, [&](int m, const Force &F) { fs[m] = F; },
+                              iadd, itake, hout);
+            } else if (!crba_tree_walk_short<6>(a0, b0, ctl, row, qf, hout)) {
+                crba_tree_walk(a0, b0, ctl, row, trig, iadd, itake, hout);
+            }
         }
     }
 }

@@ -48,7 +48,7 @@ for B in sizes:
           (B, us, B * 112 / us / 1e3, B / us / 1e3, B * 2.6e3 / us / 1e6))
     Hm = torch.empty(B, 7, 7, device="cuda")
     def crba():
-        backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(),
+        backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(), None,
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(crba)
     print("crba        panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
@@ -115,7 +115,7 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     ga = torch.randn(B, 16, device="cuda")
     us = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 3, ta.data_ptr(), st())), launches=20)
     print("rnea        allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
-    us = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(wt), qa.data_ptr(), B, Ha.data_ptr(), st())), launches=20)
+    us = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(wt), qa.data_ptr(), B, Ha.data_ptr(), None, st())), launches=20)
     print("crba        allegro B=%8d %9.2f us  %7.1f GB/s (1088 B/eval) %6.2f Gevals/s" % (B, us, B * 1088 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend._check(lib.drm_forward_dynamics(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 1, aa.data_ptr(), None, st())), launches=20)
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))

@@ -24,6 +24,9 @@ for robot in ("panda_no_gripper", "panda", "fetch", "fetch_arm_no_gripper", "jac
     ee = m._bodies[-1].name
     dw = m._dynamics_walk()
     t_fkj = t_id = t_h = float("nan")
+    if len(sys.argv) > 2 and sys.argv[2] == "crba":
+        print("%-22s CRBA %7.1f us" % (robot, graph_time(lambda: m.compute_lagrangian_inertia_matrix(q))), flush=True)
+        continue
     if not ONLY_FD:
         t_fkj = graph_time(lambda: m.compute_endeffector_jacobian(q, ee))
         t_id = graph_time(lambda: m.compute_inverse_dynamics(q, qd, qdd))
