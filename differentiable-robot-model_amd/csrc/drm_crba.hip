@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
             },
             [&](int k) { return __builtin_amdgcn_readfirstlane(t_lo[k - first]); },
             [&](int k) { return __builtin_amdgcn_readfirstlane(t_lo[__builtin_amdgcn_readfirstlane(t_end[k - first]) + 1 - first]); },
-            [&](int m) { return t_dof[m]; },
+            [&](int m) { return __builtin_amdgcn_readfirstlane(t_dof[m]); },
             [&](int m, Force &F) {
                 const float *b = lfo + m * (6 * WAVE) + lane;
 #pragma unroll

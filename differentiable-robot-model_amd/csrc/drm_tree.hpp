@@ -396,21 +396,33 @@ DRM_HD void crba_set_walk(int a, int b, CTL ctl, ROW row, TRIG trig, SLO slot_lo
             }
             fput(m0, F);
         }
-        if (moving || up) {
+        // (three loops instead of one with the op's flags tested per vector)
+        auto entry = [&](int m, const Force &F) { // H[k][c] = S_k . F_c: the z component, angular (revolute) or linear (prismatic)
+            const float v = ct.prismatic ? F.la[2][0] : F.la[2][1];
+            const int dj = slot_dof(m);
+            hout(ct.dof, dj, v);
+            if (dj != ct.dof) hout(dj, ct.dof, v);
+        };
+        if (moving && up) {
+            for (int m = m0; m < m1; ++m) {
+                Force F, nxt;
+                fget(m, F);
+                entry(m, F);
+                rnea_link_force_up(J, t, F, nxt);
+                fput(m, nxt);
+            }
+        } else if (moving) {
             for (int m = m0; m < m1; ++m) {
                 Force F;
                 fget(m, F);
-                if (moving) {
-                    const float v = ct.prismatic ? F.la[2][0] : F.la[2][1];
-                    const int dj = slot_dof(m);
-                    hout(ct.dof, dj, v);
-                    if (dj != ct.dof) hout(dj, ct.dof, v);
-                }
-                if (up) {
-                    Force nxt;
-                    rnea_link_force_up(J, t, F, nxt);
-                    fput(m, nxt);
-                }
+                entry(m, F);
+            }
+        } else if (up) {
+            for (int m = m0; m < m1; ++m) {
+                Force F, nxt;
+                fget(m, F);
+                rnea_link_force_up(J, t, F, nxt);
+                fput(m, nxt);
             }
         }
         if (up) {
