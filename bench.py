@@ -24,7 +24,9 @@ object.
 
 The JSON line also carries
   "roofline":       algorithmic bytes (224 B/eval) / average launch duration vs the 8 TB/s HBM peak at the
-                    metric batch (which is Infinity-Cache resident: 14.7 MB per launch replayed over the same buffers)
+                    metric batch (which is Infinity-Cache resident: 14.7 MB per launch replayed over the same buffers);
+                    with fewer than 200 steps a "steady_state" entry adds the same launch measured over a region of 200
+                    (a 20-step region carries one graph-launch latency, ~9 us, in its average)
   "roofline_large": the same kernel at batches whose per-launch traffic (0.94 GB / 3.8 GB) is far beyond the 256 MiB
                     Infinity Cache, i.e. genuine HBM streaming (N = 1 only)
   "cpu_baseline":   the oracle's fp32 C restatement of the reference (oracle/, "port") timed on this box's host cores
@@ -286,6 +288,16 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
                              "the bytes takes 2.9 us = 0.63, profiles/r02_metric_lab.txt); genuine HBM streaming is in "
                              "roofline_large"},
     }
+    if graphed and K < 200 and gathered is None:
+        # a short timed region (the round driver passes --steps 20: ~80 us of kernels) carries the latency of one graph
+        # launch, ~9 us between the start event and the first kernel, in its average; the same launches in a region of 200
+        # (its own graph, its own events; not part of the timed region above) give the kernel's steady-state duration
+        _, dev200, _ = timed_graph_region(step, 200, stream, barrier, use_graph=True)
+        (dev200,) = reduce_max([dev200])
+        line["roofline"]["steady_state"] = {
+            "steps": 200, "launch_us": dev200 / 200 * 1e6, "achieved": bytes_per_eval * B / (dev200 / 200) / 1e9,
+            "frac": bytes_per_eval * B / (dev200 / 200) / 1e9 / HBM_PEAK_GBS,
+            "note": "same launch, a separate region of 200 (HIP events): what `launch_us` converges to as --steps grows"}
     if rank == 0 and world == 1 and not args.no_large and args.robot == "panda_no_gripper":
         line["roofline_large"] = roofline_large(model, link, device, stream, bytes_per_eval)
     if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
