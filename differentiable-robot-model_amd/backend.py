@@ -44,7 +44,8 @@ EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "dr
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
-           "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats")
+           "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
+           "drm_rnea_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -75,7 +76,9 @@ def load_library(path: str = None):
         lib.drm_fk_jacobian.restype = ctypes.c_int
         lib.drm_fk_jacobian.argtypes = [wp, vp, i64, vp, vp, vp, vp, vp]
         lib.drm_rnea.restype = ctypes.c_int
-        lib.drm_rnea.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp]
+        lib.drm_rnea.argtypes = [wp, vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.drm_rnea_scratch_floats.restype = i64
+        lib.drm_rnea_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_backward.restype = ctypes.c_int
         lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
         lib.drm_fk_jacobian_backward.restype = ctypes.c_int
@@ -103,7 +106,7 @@ def load_library(path: str = None):
         lib.drm_crba_scratch_floats.restype = i64
         lib.drm_crba_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_rnea.restype = ctypes.c_int
-        lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp]
+        lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         _lib = lib
@@ -225,11 +228,18 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
         return tau
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    scratch = _rnea_scratch(lib, walk, B, q.device)
     with torch.cuda.device(q.device):
         _check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(),
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
-                            _stream(q.device)))
+                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
     return tau
+
+
+def _rnea_scratch(lib, walk, B, device):
+    """The body forces robots with a long segment keep between the two sweeps of drm_rnea (None: not needed)."""
+    need = int(lib.drm_rnea_scratch_floats(ctypes.byref(walk), B))
+    return torch.empty(need, device=device, dtype=torch.float32) if need > 0 else None
 
 
 def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include_gravity: bool, use_damping: bool,
@@ -485,9 +495,11 @@ class FkInverseDynamicsPlan(object):
         self._tree = _walk_struct(tree[0], tree[1].detach(), tree[2], n_dofs)
         self._chain = _walk_struct(chain[0], chain[1].detach(), chain[2], n_dofs)
         flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        self._scratch = _rnea_scratch(self._lib, self._tree, B, dev)
         self._args = (ctypes.byref(self._tree), ctypes.byref(self._chain), int(target_op), self.q.data_ptr(),
                       self.qd.data_ptr(), self.qdd.data_ptr() if self.qdd is not None else None, B, flags,
-                      self.tau.data_ptr(), self.pos.data_ptr(), self.quat.data_ptr())
+                      self.tau.data_ptr(), self.pos.data_ptr(), self.quat.data_ptr(),
+                      self._scratch.data_ptr() if self._scratch is not None else None)
         self.batch, self.device = B, dev
 
     def launch(self, stream=None):
@@ -515,8 +527,10 @@ class InverseDynamicsPlan(object):
         self._keep = (ops_f, ops_i)
         self._walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
         flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        self._scratch = _rnea_scratch(self._lib, self._walk, B, dev)
         self._args = (ctypes.byref(self._walk), self.q.data_ptr(), self.qd.data_ptr(),
-                      self.qdd.data_ptr() if self.qdd is not None else None, B, flags, self.tau.data_ptr())
+                      self.qdd.data_ptr() if self.qdd is not None else None, B, flags, self.tau.data_ptr(),
+                      self._scratch.data_ptr() if self._scratch is not None else None)
         self.batch, self.device = B, dev
 
     def launch(self, stream=None):

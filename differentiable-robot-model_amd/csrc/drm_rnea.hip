@@ -12,15 +12,14 @@
 
 namespace drm {
 
-// Loop-structured RNEA of any robot (drm_tree.hpp rnea_tree_walk, block layout in drm_tree_dev.hpp): one tile of 64
-// samples per block, one wavefront per segment of the walk.
-// LDS: [ table ][ tau ]([ q ][ qd ][ qdd ] in the SHORT form) shared, then per wavefront [ body forces : ops * 6 * 64 ]
+// Robots whose segments are all SHORT (the fingers of a hand, at most RNEA_SHORT_OPS ops each): one tile of 64 samples per
+// block, one wavefront per segment (block layout in drm_tree_dev.hpp); drm_tree.hpp rnea_tree_walk_short keeps the per-op
+// records in registers, so the per-wavefront LDS area holds the save slots only and the form is bounded by registers (96 VGPR =
+// five waves per SIMD), not by LDS.
+// LDS: [ table ][ tau ][ q ][ qd ][ qdd ] shared (staged once per block with coalesced 16-byte accesses), then per wavefront
 //      [ motion slots : n_slots * 12 * 64 ][ force slots : n_slots * 6 * 64 ]   (per-wavefront areas: TreeArgs.wave_off)
-// SHORT > 0: no segment has more than SHORT ops (the fingers of a hand): drm_tree.hpp rnea_tree_walk_short keeps the per-op
-// records in registers, the per-wavefront LDS area holds the save slots only.
 constexpr int RNEA_SHORT_OPS = 6;
-constexpr int RNEA_FORCE_FLOATS = 6; // what this kernel parks per op between the sweeps: the body force
-template <int SHORT>
+constexpr int RNEA_FORCE_FLOATS = 6; // what the long form keeps per op between the sweeps: the body force
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     rnea_tree_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
                      const float *__restrict__ qdd, int64_t B, float *__restrict__ tau, uint32_t magic_q, uint32_t align) {
@@ -29,29 +28,19 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
-    constexpr bool tiles = SHORT > 0; // the short form stages the inputs of a tile in LDS once for its wavefronts (see below)
     float *ltau = smem + table_lds_floats(a.n_ops);
     float *lq = ltau + region, *lqd = lq + region, *lqdd = lqd + region;
     const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
-    float *park = smem + a.wave_off[wave];
-    float *lms = park + (SHORT ? 0 : (last - first) * (RNEA_FORCE_FLOATS * WAVE)); // motion slots [slot][12][64]
-    float *lfs = lms + a.n_slots * (12 * WAVE);                     // force slots  [slot][6][64]
+    float *lms = smem + a.wave_off[wave];          // motion slots [slot][12][64]
+    float *lfs = lms + a.n_slots * (12 * WAVE);    // force slots  [slot][6][64]
 
-    // LDS per sample is what bounds the wavefronts per CU of a big single-segment robot (an arm carrying a hand: one
-    // wavefront per CU with the inputs staged and 9 floats parked per op), so: the joint state is read straight from each
-    // lane's rows of q / qd / qdd (two or three reads per op, cache hits after the first), only the body force is parked
-    // (6 floats per op: cos / sin are recomputed on the way back), and the one LDS tile left is tau's, for a coalesced store.
-    // The SHORT form (fingers of a hand, a wavefront each; nothing parked) stages the three input tiles once per block, as
-    // before: they are shared, and the form is bounded by registers (96 VGPR = five waves per SIMD), not by LDS.
     const TableLds tab = stage_tree_table(a, smem);
     const bool fast = tc.full && (n & 1);
-    if constexpr (tiles) {
-        if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
-        if (wave == (a.n_segments > 1 ? 1 : 0))
-            tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
-        if (qdd && wave == (a.n_segments > 2 ? 2 : 0))
-            tile_load<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
-    }
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, fast && (align & AL_Q), tc.full && (align & AL_Q));
+    if (wave == (a.n_segments > 1 ? 1 : 0))
+        tile_load<0>(qd + tc.b0 * n, tc.rows, n, magic_q, lqd, lane, fast && (align & AL_QD), tc.full && (align & AL_QD));
+    if (qdd && wave == (a.n_segments > 2 ? 2 : 0))
+        tile_load<0>(qdd + tc.b0 * n, tc.rows, n, magic_q, lqdd, lane, fast && (align & AL_QDD), tc.full && (align & AL_QDD));
     for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f;
     __syncthreads();
 
@@ -62,68 +51,147 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     const bool has_qdd = qdd != nullptr;
     const TableLds &ctl = tab;
     auto rowf = [&](int k) { return tab.row(k); };
-    const int64_t grow = (tc.b0 + (live ? (int64_t)lane : 0)) * n; // (lanes past a partial tile read row 0 of it, then zeros)
     auto qf = [&](int d, float &x, float &v, float &acc) {
-        if constexpr (tiles) {
-            x = live ? lq[row + d] : 0.0f;
-            v = lqd[row + d];
-            acc = has_qdd ? lqdd[row + d] : 0.0f;
-        } else {
-            x = live ? q[grow + d] : 0.0f;
-            v = live ? qd[grow + d] : 0.0f;
-            acc = (has_qdd && live) ? qdd[grow + d] : 0.0f;
-        }
+        x = live ? lq[row + d] : 0.0f;
+        v = lqd[row + d];
+        acc = has_qdd ? lqdd[row + d] : 0.0f;
     };
     auto tau_out = [&](int d, float v) { ltau[row + d] = v; };
     auto msave = [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); };
     auto mload = [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); };
     auto fadd = [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); };
     auto ftake = [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); };
-    if constexpr (SHORT > 0) {
-        rnea_tree_walk_short<SHORT>(a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out, msave, mload, fadd, ftake);
-    } else {
-        rnea_tree_walk(
-            a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out,
-            [&](int k, const Force &F, float, float, float) {
-                float *b = park + (k - first) * (RNEA_FORCE_FLOATS * WAVE) + lane;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
-            },
-            [&](int k, Force &F, float &c, float &s, float &x) {
-                const float *b = park + (k - first) * (RNEA_FORCE_FLOATS * WAVE) + lane;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
-                int w0, w1;
-                ctl_words(ctl, k, w0, w1);
-                const OpCtl ct = decode_ctl(w0, w1);
-                x = 0.0f; c = 1.0f; s = 0.0f;
-                if (ct.dof >= 0) {
-                    float v, acc;
-                    qf(ct.dof, x, v, acc);
-                    if (!ct.prismatic) sincos_one(x, s, c);
-                }
-            },
-            msave, mload, fadd, ftake);
-    }
+    rnea_tree_walk_short<RNEA_SHORT_OPS>(a.prefix_end, first, last, ctl, rowf, flags, qf, tau_out, msave, mload, fadd, ftake);
     __syncthreads();
     if (wave == 0)
         tile_store<0>(tau + tc.b0 * n, tc.rows, n, magic_q, ltau, lane, fast && (align & AL_TAU), tc.full && (align & AL_TAU));
 }
 
-// LDS bytes of a launch (fills a.wave_off)
-static size_t rnea_tree_lds(TreeArgs &a, bool records_in_registers) {
-    // table + the tau tile (+ the three input tiles when several wavefronts share them)
-    const size_t shared = (size_t)table_lds_floats(a.n_ops) + (records_in_registers ? 4 : 1) * (size_t)round4(WAVE * pad_odd(a.n));
-    return sizeof(float) * layout_waves(a, shared, records_in_registers ? 0 : RNEA_FORCE_FLOATS * WAVE, a.n_slots * 18 * WAVE,
-                                        [](int) { return 0; });
+// LDS bytes of that launch (0: does not apply — a segment is too long, or the hand does not fit)
+static size_t rnea_short_plan(const drm_walk *w, TreeArgs &a) {
+    a = tree_args(w, false);
+    if (a.max_seg_ops > RNEA_SHORT_OPS) return 0;
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + 4 * (size_t)round4(WAVE * pad_odd(a.n));
+    const size_t lds = sizeof(float) * layout_waves(a, shared, 0, a.n_slots * 18 * WAVE, [](int) { return 0; });
+    return lds <= (size_t)MAX_LDS_BYTES ? lds : 0;
+}
+
+// Every other robot (an arm carrying a gripper or a hand, a mobile manipulator: a segment of more than RNEA_SHORT_OPS ops):
+// the loop form of the walk (drm_tree.hpp rnea_tree_walk), one wavefront per segment, on the pattern of the articulated-body
+// kernel (drm_forward_dynamics.hip).  The body forces the backward sweep needs again — 6 floats per link and sample, which in
+// LDS left an arm with a hand three wavefronts per CU — live in HBM scratch, [op][6][64] per block (coalesced; fetched one op
+// ahead of their use); the grid is PERSISTENT, so the scratch is sized by what the chip holds at once and stays in L2; q / qd /
+// qdd are staged per tile with coalesced 16-byte loads (read straight from global memory, one 4-byte access per lane and DoF,
+// they thrash a CU's L1 at this occupancy) and tau leaves through the tile qdd came in by.
+// LDS: [ table ][ q ][ qd ][ qdd -> tau ] shared, then per wavefront [ motion slots : n_slots * 12 * 64 ][ force slots : n_slots * 6 * 64 ]
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    rnea_records_kernel(TreeArgs a, int flags, const float *__restrict__ q, const float *__restrict__ qd,
+                        const float *__restrict__ qdd, int64_t B, int n_tiles, float *__restrict__ tau, float *__restrict__ scratch,
+                        uint32_t magic_q, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lq = smem + table_lds_floats(a.n_ops), *lqd = lq + region, *lt = lqd + region; // lt: qdd in, tau out
+    const int first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    float *lms = smem + a.wave_off[wave];          // motion slots [slot][12][64]
+    float *lfs = lms + a.n_slots * (12 * WAVE);    // force slots  [slot][6][64]
+    float *recs = scratch + ((int64_t)blockIdx.x * a.n_ops + first) * (RNEA_FORCE_FLOATS * WAVE) + lane;
+    const TableLds tab = stage_tree_table(a, smem);
+    for (int s = 0; s < a.n_slots * 6; ++s) lfs[s * WAVE + lane] = 0.0f; // (every take leaves its slot at zero again)
+    const unsigned row = lane * Sq;
+    const bool has_qdd = qdd != nullptr;
+    const TableLds &ctl = tab;
+    auto rowf = [&](int k) { return tab.row(k); };
+    auto rec = [&](int k) -> float * { return recs + (k - first) * (RNEA_FORCE_FLOATS * WAVE); };
+
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        __syncthreads(); // the table is staged / the previous tile's torques have left the tile
+        const int64_t b0 = (int64_t)tile * WAVE;
+        const int rows = B - b0 < WAVE ? (int)(B - b0) : WAVE;
+        const bool full = rows == WAVE, fast = full && (n & 1);
+        if (wave == 0) tile_load<0>(q + b0 * n, rows, n, magic_q, lq, lane, fast && (align & AL_Q), full && (align & AL_Q));
+        if (wave == (a.n_segments > 1 ? 1 : 0))
+            tile_load<0>(qd + b0 * n, rows, n, magic_q, lqd, lane, fast && (align & AL_QD), full && (align & AL_QD));
+        if (has_qdd && wave == (a.n_segments > 2 ? 2 : 0))
+            tile_load<0>(qdd + b0 * n, rows, n, magic_q, lt, lane, fast && (align & AL_QDD), full && (align & AL_QDD));
+        __syncthreads();
+        // lanes past a partial tile walk a robot at rest (zeros, not stale LDS: see rnea_tree_kernel); nothing of theirs is stored
+        const bool live = (int)lane < rows;
+        auto qf = [&](int d, float &x, float &v, float &acc) {
+            x = live ? lq[row + d] : 0.0f;
+            v = live ? lqd[row + d] : 0.0f;
+            acc = (has_qdd && live) ? lt[row + d] : 0.0f;
+        };
+        rnea_tree_walk(
+            a.prefix_end, first, last, ctl, rowf, flags, qf, [&](int d, float v) { lt[row + d] = v; },
+            [&](int k, const Force &F, float, float, float) {
+                float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
+            },
+            [&](int k, Force &F) {
+                const float *b = rec(k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
+            },
+            [&](int k, float &c, float &s, float &x) {
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                x = 0.0f; c = 1.0f; s = 0.0f;
+                if (ct.dof >= 0) {
+                    x = live ? lq[row + ct.dof] : 0.0f;
+                    if (!ct.prismatic) sincos_one(x, s, c);
+                }
+            },
+            [&](int s, const Motion &M) { lds_put_motion(lms, s, lane, M); }, [&](int s, Motion &M) { lds_get_motion(lms, s, lane, M); },
+            [&](int s, const Force &F) { lds_add_force(lfs, s, lane, F); }, [&](int s, Force &F) { lds_take_force(lfs, s, lane, F); });
+        __syncthreads();
+        if (wave == 0) tile_store<0>(tau + b0 * n, rows, n, magic_q, lt, lane, fast && (align & AL_TAU), full && (align & AL_TAU));
+    }
+}
+
+// geometry of that launch: LDS bytes per block and the number of blocks the device holds at once (the persistent grid)
+struct RneaRecordsPlan {
+    TreeArgs a;
+    size_t lds;
+    int resident;
+};
+static int rnea_records_plan(const drm_walk *w, RneaRecordsPlan &p) {
+    // one wavefront per segment; all the segments through one wavefront when their save slots do not fit side by side
+    for (int single = 0; single < 2; ++single) {
+        p.a = tree_args(w, single != 0);
+        const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(p.a.n));
+        p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * 18 * WAVE, [](int) { return 0; });
+        if (p.lds <= (size_t)MAX_LDS_BYTES || w->n_segments <= 1) break;
+    }
+    int rc = ensure_lds_tree(rnea_records_kernel, p.lds);
+    if (rc) return rc;
+    return resident_blocks(rnea_records_kernel, WAVE * p.a.n_segments, p.lds, p.resident);
 }
 
 } // namespace drm
 
 using namespace drm;
 
+extern "C" int64_t drm_rnea_scratch_floats(const drm_walk *w, int64_t B) {
+    if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
+    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
+        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
+        if (B == 0) return 0;
+    }
+    TreeArgs a;
+    if (rnea_short_plan(w, a)) return 0;
+    RneaRecordsPlan p;
+    if (rnea_records_plan(w, p)) return 0;
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_ops * RNEA_FORCE_FLOATS * WAVE;
+}
+
 extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
-                        float *tau, void *stream) {
+                        float *tau, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !qd || !tau) return fail(DRM_ERR_INVALID, "q / qd / tau must not be NULL");
@@ -145,36 +213,35 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
         drm_walk generic = *w;
         generic.shape &= ~DRM_WALK_ARM_CHAIN;
         return drm_rnea(&generic, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags,
-                        tau + done * n, stream);
+                        tau + done * n, scratch, stream);
     }
 #endif
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
-    TreeArgs a = tree_args(w);
-    const bool shorts = a.max_seg_ops <= RNEA_SHORT_OPS;
-    size_t lds = rnea_tree_lds(a, shorts);
-    if (lds > (size_t)MAX_LDS_BYTES && a.n_segments > 1) { // the segments do not fit side by side: one wavefront walks them all
-        a = tree_args(w, true);
-        lds = rnea_tree_lds(a, false);
-    }
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
-    if (a.max_seg_ops <= RNEA_SHORT_OPS) {
-        rc = ensure_lds_tree(rnea_tree_kernel<RNEA_SHORT_OPS>, lds);
+    TreeArgs fingers;
+    if (const size_t lds = rnea_short_plan(w, fingers)) {
+        rc = ensure_lds_tree(rnea_tree_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(rnea_tree_kernel<RNEA_SHORT_OPS>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd,
-                           qdd, B, tau, div_magic(n), align);
-    } else {
-        rc = ensure_lds_tree(rnea_tree_kernel<0>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(rnea_tree_kernel<0>, dim3((unsigned)tiles), dim3(WAVE * a.n_segments), lds, s, a, (int)flags, q, qd, qdd, B,
+        hipLaunchKernelGGL(rnea_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, (int)flags, q, qd, qdd, B,
                            tau, div_magic(n), align);
+        return launched();
     }
+    RneaRecordsPlan p;
+    rc = rnea_records_plan(w, p);
+    if (rc) return rc;
+    if (!scratch)
+        return fail(DRM_ERR_INVALID, "this robot's inverse dynamics keeps its per-link records in scratch: pass drm_rnea_scratch_floats() floats");
+    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    hipLaunchKernelGGL(rnea_records_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags, q, qd, qdd, B,
+                       (int)tiles, tau, scratch, div_magic(n), align);
     return launched();
 }
 
 extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
-                           const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, void *stream) {
+                           const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch,
+                           void *stream) {
     int rc = check_walk(tree);
     if (rc) return rc;
     rc = check_walk(chain);
@@ -209,5 +276,5 @@ extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t 
     // every other robot (and a ragged tail): the two walks one after the other on the same stream
     rc = drm_fk(chain, q, B, 1, pos, quat, stream);
     if (rc) return rc;
-    return drm_rnea(tree, q, qd, qdd, B, flags, tau, stream);
+    return drm_rnea(tree, q, qd, qdd, B, flags, tau, scratch, stream);
 }

@@ -191,9 +191,11 @@ DRM_HD void rnea_backward_step(int k, int a, const OpCtl &ct, ROW row, int flags
     }
 }
 
-template <class CTL, class ROW, class QF, class TAU, class PARK, class UNPARK, class MSAVE, class MLOAD, class FADD, class FTAKE>
+// (unpark(k, F) fetches the body force parked for op k — the records may live in HBM, so the backward sweep asks for op k - 1's
+// before it works on op k; trig(k, c, s, q) gives cos / sin / value of op k's joint again)
+template <class CTL, class ROW, class QF, class TAU, class PARK, class UNPARK, class TRIG, class MSAVE, class MLOAD, class FADD, class FTAKE>
 DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags, QF qf, TAU tau_out, PARK park,
-                           UNPARK unpark, MSAVE motion_save, MLOAD motion_load, FADD force_add, FTAKE force_take) {
+                           UNPARK unpark, TRIG trig, MSAVE motion_save, MLOAD motion_load, FADD force_add, FTAKE force_take) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     Motion cur;
     motion_root(cur, g);
@@ -212,14 +214,17 @@ DRM_HD void rnea_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags,
     Force carry;
 #pragma unroll
     for (int i = 0; i < 3; ++i) carry.la[i] = f2_bcast(0.0f);
+    Force ahead;
+    unpark(b - 1, ahead);
 #pragma unroll 1
     for (int k = b - 1; k >= a; --k) {
         int w0, w1;
         ctl_words(ctl, k, w0, w1);
         const OpCtl ct = decode_ctl(w0, w1);
-        Force tot;
+        Force tot = ahead;
+        if (k > a) unpark(k - 1, ahead);
         float c, s, q;
-        unpark(k, tot, c, s, q);
+        trig(k, c, s, q);
         rnea_backward_step(k, a, ct, row, flags, qf, tau_out, force_add, force_take, tot, c, s, q, carry);
     }
 }

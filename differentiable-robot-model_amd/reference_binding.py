@@ -167,8 +167,12 @@ class HipBinding(object):
         tau = q.new_empty(B, self.n)
         w = self.walk(("tree",), whole_tree=True)[0]
         flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        # (robots with a long segment keep their per-link body forces in caller-owned scratch between the two sweeps)
+        self.lib.drm_rnea_scratch_floats.restype = ctypes.c_int64
+        need = int(self.lib.drm_rnea_scratch_floats(ctypes.byref(w), ctypes.c_int64(B)))
+        scratch = q.new_empty(need) if need > 0 else None
         self._check(self.lib.drm_rnea(ctypes.byref(w), self._p(q), self._p(qd), self._p(qdd), ctypes.c_int64(B), ctypes.c_int32(flags),
-                                      self._p(tau), self._stream()))
+                                      self._p(tau), self._p(scratch) if scratch is not None else None, self._stream()))
         return tau
 
 

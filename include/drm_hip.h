@@ -201,9 +201,14 @@ int drm_fk_jacobian(const drm_walk *walk, const float *q, int64_t B,
  * iterative_newton_euler robot_model.py:250-303).  With qdd = NULL the joint
  * accelerations are zero: compute_non_linear_effects (robot_model.py:377-400).
  *   q, qd, qdd [B, n]  ->  tau [B, n];  flags = DRM_RNEA_GRAVITY | DRM_RNEA_DAMPING
+ *   scratch   drm_rnea_scratch_floats(walk, B) floats owned by the caller: robots with a long segment (an arm carrying a
+ *             gripper or a hand) keep the body force of every link there between the two sweeps,
+ *             [resident block][link][6][64] — bounded by what the device holds at once, not by B.  0 for 7-DoF arms and
+ *             for hands (short independent fingers): scratch is then never touched and may be NULL
  */
+int64_t drm_rnea_scratch_floats(const drm_walk *walk, int64_t B);
 int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B,
-             int32_t flags, float *tau, void *stream);
+             int32_t flags, float *tau, float *scratch, void *stream);
 
 /*
  * Inverse dynamics AND the pose of one link in one call: what a caller of the reference gets from
@@ -219,10 +224,11 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
  *             reads ONE table, chain->ops_f: the caller guarantees that its first n rows carry the same constants as
  *             tree->ops_f (both gathered from the same folded link table); target_op is ignored (-1).
  *   q, qd, qdd [B, n] (qdd may be NULL)  ->  tau [B, n], pos [B, 3], quat [B, 4];  flags as for drm_rnea.
+ *   scratch   drm_rnea_scratch_floats(tree, B) floats, as for drm_rnea (0 for the fused launch)
  * Results are bit-identical to drm_rnea + drm_fk.
  */
 int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
-                const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, void *stream);
+                const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch, void *stream);
 
 /*
  * Joint-space inertia matrix over the whole tree (composite-rigid-body algorithm).

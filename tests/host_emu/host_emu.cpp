@@ -131,7 +131,8 @@ void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *
             };
             auto out = [&](int d, float v) { tau[b * n + d] = v; };
             auto park = [&](int k, const Force &F, float c, float s, float qq) { rec[k] = ParkRec{F, c, s, qq}; };
-            auto unpark = [&](int k, Force &F, float &c, float &s, float &qq) { F = rec[k].f; c = rec[k].c; s = rec[k].s; qq = rec[k].q; };
+            auto unpark = [&](int k, Force &F) { F = rec[k].f; };
+            auto trig = [&](int k, float &c, float &s, float &qq) { c = rec[k].c; s = rec[k].s; qq = rec[k].q; };
             auto msave = [&](int s, const Motion &M) { ms[s] = M; };
             auto mload = [&](int s, Motion &M) { M = ms[s]; };
             auto fadd = [&](int s, const Force &F) { for (int i = 0; i < 3; ++i) fs[s].la[i] += F.la[i]; };
@@ -139,7 +140,7 @@ void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *
                 for (int i = 0; i < 3; ++i) { F.la[i] += fs[s].la[i]; fs[s].la[i] = f2_bcast(0.f); }
             };
             rnea_tree_walk(w->prefix_end, w->seg_begin[seg], w->seg_begin[seg + 1], ctl, row, flags, qf, out, park, unpark,
-                           msave, mload, fadd, ftake);
+                           trig, msave, mload, fadd, ftake);
         }
     }
 }

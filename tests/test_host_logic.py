@@ -201,7 +201,7 @@ def test_abi_argument_errors_need_no_gpu():
     assert lib.drm_fk_jacobian(None, None, 1, None, None, None, None, None) == -1
     assert b"NULL" in lib.drm_last_error()
     w = backend.DrmWalk(1, 1, 9, 8, 7, 0, 0, 2, 0)   # n_ops > capacity
-    assert lib.drm_rnea(ctypes.byref(w), None, None, None, 1, 0, None, None) == -1
+    assert lib.drm_rnea(ctypes.byref(w), None, None, None, 1, 0, None, None, None) == -1
     w = backend.DrmWalk(1, 1, 8, 10, 7, 0, 0, 2, 0)  # capacity is not a multiple of 4
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -1
     w = backend.DrmWalk(1, 1, 8, 8, 7, 17, 0, 2, 0)  # more save slots than the kernels have

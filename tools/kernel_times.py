@@ -41,7 +41,7 @@ for B in sizes:
     lib = backend.load_library(); import ctypes
     walk = backend._walk_struct(df.program, m._ops_f(df), df.ops_i, 7)
     def rnea():
-        backend._check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, tau.data_ptr(),
+        backend._check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, tau.data_ptr(), None,
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(rnea)
     print("rnea        panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s  %5.1f TFLOP/s (2.6 kflop/eval)" %
@@ -113,7 +113,7 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ta = torch.empty(B, 16, device="cuda"); Ha = torch.empty(B, 16, 16, device="cuda"); aa = torch.empty(B, 16, device="cuda")
     ga = torch.randn(B, 16, device="cuda")
-    us = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 3, ta.data_ptr(), st())), launches=20)
+    us = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(wt), qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), B, 3, ta.data_ptr(), None, st())), launches=20)
     print("rnea        allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(wt), qa.data_ptr(), B, Ha.data_ptr(), None, st())), launches=20)
     print("crba        allegro B=%8d %9.2f us  %7.1f GB/s (1088 B/eval) %6.2f Gevals/s" % (B, us, B * 1088 / us / 1e3, B / us / 1e3))

@@ -35,7 +35,8 @@ for B in [int(a) for a in sys.argv[1:]] or [65536, 1 << 20]:
         if generic:
             walk.shape &= ~1
         tau = torch.empty(B, 7, device="cuda"); Hm = torch.empty(B, 7, 7, device="cuda"); acc = torch.empty(B, 7, device="cuda")
-        t1 = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, tau.data_ptr(), st())))
+        scr1 = torch.empty(max(1, int(lib.drm_rnea_scratch_floats(ctypes.byref(walk), B))), device="cuda")
+        t1 = graph_time(lambda: backend._check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, tau.data_ptr(), scr1.data_ptr(), st())))
         scr2 = torch.empty(max(1, int(lib.drm_crba_scratch_floats(ctypes.byref(walk), B))), device="cuda")
         t2 = graph_time(lambda: backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(), scr2.data_ptr(), st())))
         scr = torch.empty(max(1, int(lib.drm_forward_dynamics_scratch_floats(ctypes.byref(walk), B))), device="cuda")
