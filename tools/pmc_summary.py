@@ -86,11 +86,14 @@ with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 
 acc = defaultdict(lambda: defaultdict(list))
-for r in list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")):
+for r in (list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")) +
+          list(rows("prof_sq4_*/*/*_counter_collection.csv"))):
     k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
     acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
-lines = ["# SQ counters, %s (rocprofv3 --pmc, MI355X; per wave = counter / SQ_WAVES; cycle counters are quad-cycles)" % tag, "",
+lines = ["# SQ counters, %s (rocprofv3 --pmc, MI355X; per wave = counter / SQ_WAVES; cycle counters are quad-cycles)" % tag,
+         "(persistent kernels — rnea_records_kernel, crba_rows_kernel, forward_dynamics_aba_kernel — run several 64-sample tiles per wave:"
+         " tiles = ceil(B / 64), waves = the grid)", "",
          "| kernel | grid threads | waves | VALU | SALU | SMEM | LDS | WAVE_CYCLES | WAIT_ANY | ACTIVE_INST_ANY |",
          "|---|---|---|---|---|---|---|---|---|---|"]
 for (k, grid), c in sorted(acc.items()):

@@ -26,6 +26,10 @@ done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
+# robots with one long segment (an arm with its gripper / hand): RNEA, mass matrix, forward dynamics at 262 144 samples
+for r in panda iiwa7_allegro; do
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench4.py $r 262144 > $OUT/prof_sq4_$r.log 2>&1
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
