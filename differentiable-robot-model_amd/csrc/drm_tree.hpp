@@ -275,7 +275,7 @@ DRM_HD void rnea_tree_walk_short(int p_end, int a, int b, CTL ctl, ROW row, int 
 // One sweep from the leaves to the root: the composite inertia of the sub-tree below op k is complete when the sweep
 // reaches k; if k moves, F = Ic_k S_k is walked up the chain of k's ancestors (parent indices from W1) and leaves
 // H[j][k] = S_j . F at every moving ancestor j.  S = (ang e_z, lin 0) for a revolute joint, (0, e_z) for a prismatic one.
-//   trig(k, c, s, q)             cos / sin / value of op k's joint (the caller computes them once per op, see crba_prepare)
+//   trig(k, c, s, q)             cos / sin / value of op k's joint
 //   islot_add / islot_take       branch-point composite inertias (take = add into the argument and reset)
 //   hout(di, dj, v)              H[di][dj] = v (called for both triangles)
 // ---------------------------------------------------------------------------
@@ -543,23 +543,6 @@ DRM_HD bool crba_tree_walk_short(int a, int b, CTL ctl, ROW row, QF qf, HOUT hou
         }
     }
     return true;
-}
-
-// cos / sin / value of the joint of every op of [a, b), handed to `put(k, c, s, q)` (parked by the caller for crba_tree_walk)
-template <class CTL, class QF, class PUT>
-DRM_HD void crba_prepare(int a, int b, CTL ctl, QF qf, PUT put) {
-#pragma unroll 1
-    for (int k = a; k < b; ++k) {
-        int w0, w1;
-        ctl_words(ctl, k, w0, w1);
-        const OpCtl ct = decode_ctl(w0, w1);
-        float q = 0.0f, c = 1.0f, s = 0.0f;
-        if (ct.dof >= 0) {
-            q = qf(ct.dof);
-            if (!ct.prismatic) sincos_one(q, s, c);
-        }
-        put(k, c, s, q);
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -2,18 +2,25 @@
 // K3 drm_rnea, K6 drm_crba, K8 drm_forward_dynamics for every robot that is not a 7-DoF arm chain (drm_tree.hpp holds
 // their per-sample arithmetic).
 //
-// Block layout.  A block owns ONE tile of 64 consecutive samples and has one wavefront per SEGMENT of the walk (sub-trees
+// Block layout.  A block works on tiles of 64 consecutive samples and has one wavefront per SEGMENT of the walk (sub-trees
 // hanging off the fixed root are independent dynamics problems, include/drm_hip.h drm_walk.seg_begin; the kinematics
 // kernels have one segment): lane = sample, wavefront = sub-tree — the per-link fan-out over wavefronts that K1 already did
 // for the fingertips of a hand, now for the dynamics too (Allegro: four 5-link fingers per tile instead of one 20-link
 // walk; four times the waves and a quarter of the per-wave LDS).
+// Two shapes of launch:
+//   * one block per tile (kinematics; dynamics of robots whose segments are all short — fingers — with both sweeps unrolled
+//     and the per-op records in registers);
+//   * a PERSISTENT grid (dynamics of robots with a long segment: rnea_records_kernel, crba_rows_kernel,
+//     forward_dynamics_aba_kernel): as many blocks as the device holds at once (resident_blocks below), each looping over
+//     tiles and owning a slice of caller-provided HBM scratch for what a sample needs between two sweeps.
 // Shared by the block, in LDS:
 //   * the op table of the walk (n_ops x 32 floats) and its two control-word columns, staged once per block: every
 //     per-link constant is a broadcast LDS read, control words come back through v_readfirstlane; no scalar-memory
 //     round trip inside the loops, no compile-time capacity;
 //   * the input tiles (row-per-sample tensors <-> lane-per-sample access through an odd row stride, drm_common.hpp)
-//     and the output tile, loaded / stored once per block with coalesced 16-byte accesses.
-// Private to a wavefront, in LDS: the per-op records between two sweeps and the save slots of its branch points.
+//     and the output tile, loaded / stored once per tile with coalesced 16-byte accesses.
+// Private to a wavefront, in LDS: the save slots of its branch points (and whatever a kernel adds: a finger's block of H,
+// the forces of the mass-matrix walk).
 #pragma once
 
 #include <map>
@@ -175,23 +182,6 @@ __device__ __forceinline__ void lds_take_inertia(float *slots, int s, unsigned l
 #pragma unroll
     for (int i = 0; i < 6; ++i) { a.I[i] += b[(4 + i) * WAVE]; b[(4 + i) * WAVE] = 0.0f; }
 }
-
-// per-op records between the sweeps of RNEA: [op - first][9][64] = body force (6) + cos, sin, value of the joint
-constexpr int RNEA_PARK_FLOATS = 9;
-__device__ __forceinline__ void lds_park_rnea(float *park, int k, unsigned lane, const Force &F, float c, float s, float q) {
-    float *b = park + k * (RNEA_PARK_FLOATS * WAVE) + lane;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { b[i * WAVE] = F.la[i][0]; b[(3 + i) * WAVE] = F.la[i][1]; }
-    b[6 * WAVE] = c; b[7 * WAVE] = s; b[8 * WAVE] = q;
-}
-__device__ __forceinline__ void lds_unpark_rnea(const float *park, int k, unsigned lane, Force &F, float &c, float &s, float &q) {
-    const float *b = park + k * (RNEA_PARK_FLOATS * WAVE) + lane;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) F.la[i] = f2_make(b[i * WAVE], b[(3 + i) * WAVE]);
-    c = b[6 * WAVE]; s = b[7 * WAVE]; q = b[8 * WAVE];
-}
-// per-op (cos, sin, value) of CRBA: [op - first][3][64]
-constexpr int CRBA_PARK_FLOATS = 3;
 
 // one block = one tile: rows of the tile and whether it is full
 struct TileCtx {

@@ -253,7 +253,17 @@ void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
             const int a0 = w->seg_begin[seg], b0 = w->seg_begin[seg + 1];
             auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
             auto qf = [&](int d) { return q[b * n + d]; };
-            crba_prepare(a0, b0, ctl, qf, [&](int k, float c, float s, float qq) { tr[k] = TrigRec{c, s, qq}; });
+            for (int k = a0; k < b0; ++k) { // cos / sin / value of every op's joint
+                int w0, w1;
+                ctl_words(ctl, k, w0, w1);
+                const OpCtl ct = decode_ctl(w0, w1);
+                TrigRec t{1.f, 0.f, 0.f};
+                if (ct.dof >= 0) {
+                    t.q = qf(ct.dof);
+                    if (!ct.prismatic) sincos_one(t.q, t.s, t.c);
+                }
+                tr[k] = t;
+            }
             auto trig = [&](int k, float &c, float &s, float &qq) { c = tr[k].c; s = tr[k].s; qq = tr[k].q; };
             auto iadd = [&](int s, const Inertia &a) { inertia_add(is[s], a); };
             auto itake = [&](int s, Inertia &a) { inertia_add(a, is[s]); inertia_zero(is[s]); };
