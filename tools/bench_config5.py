@@ -87,8 +87,24 @@ for B in (16384, 1 << 20):
     ops_f = m._ops_f(dw).detach()
     gpos = torch.randn(B, 1, 3, device="cuda")
     mask = m._kinematic_param_mask(dw)
-    us_f, _ = timeit(lambda: backend.fk(dw.program, ops_f, dw.ops_i, q, 1, 7))
-    us_b, _ = timeit(lambda: backend.fk_backward(dw.program, ops_f, dw.ops_i, q, gpos, 1, 7, mask, False))
-    us_bq, _ = timeit(lambda: backend.fk_backward(dw.program, ops_f, dw.ops_i, q, gpos, 1, 7, mask, True))
-    print("  kernels: fk %.1f us, backward(params) %.1f us, backward(params + grad_q) %.1f us -> %.1f GB/s of 96 B/eval" %
-          (us_f, us_b, us_bq, B * 96 / (us_f + us_bq) / 1e3))
+    def graph_us(fn, launches=50):
+        """launches captured into one hipGraph: kernel time without the host (an eager call costs 12-19 us of Python + ctypes,
+        more than these kernels take at 16 384 samples)"""
+        fn(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(launches):
+                fn()
+        g.replay(); torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+            best = min(best, s.elapsed_time(e) / launches * 1e3)
+        return best
+
+    us_f = graph_us(lambda: backend.fk(dw.program, ops_f, dw.ops_i, q, 1, 7))
+    us_b = graph_us(lambda: backend.fk_backward(dw.program, ops_f, dw.ops_i, q, gpos, 1, 7, mask, False))
+    us_bq = graph_us(lambda: backend.fk_backward(dw.program, ops_f, dw.ops_i, q, gpos, 1, 7, mask, True))
+    print("  kernels (hipGraph of 50 launches each, incl. their scratch memsets / reductions): fk %.1f us, backward(params) %.1f us, "
+          "backward(params + grad_q) %.1f us -> %.1f GB/s of 96 B/eval" % (us_f, us_b, us_bq, B * 96 / (us_f + us_bq) / 1e3))

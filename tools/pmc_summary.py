@@ -5,7 +5,7 @@
   rNN_pmc_traffic.json         HBM bytes per launch of the metric kernel: FETCH_SIZE (x2: gfx950 tallies 128-B read
                                requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB
   rNN_sq_counters.md           per-wave instruction counts / cycle split of the hot kernels (arm and loop-form)
-  rNN_all_kernels_rocprof_stats.csv, rNN_bench_{default,config3,under_rocprofv3}.json, rNN_kernel_times.txt, rNN_metric_lab.txt, rNN_probe_robots.txt
+  rNN_all_kernels_rocprof_stats.csv, rNN_bench_{default,config3,under_rocprofv3}.json, rNN_kernel_times.txt, rNN_metric_lab.txt, rNN_probe_robots.txt, rNN_config5.txt
 usage: python tools/pmc_summary.py r01
 """
 import csv
@@ -57,7 +57,8 @@ for src, dst in (("prof_stats.log", "_bench_under_rocprofv3.json"), ("bench_defa
     if line:
         with open(os.path.join(prof, tag + dst), "w") as f:
             f.write(line + "\n")
-for src, dst in (("kernel_times.txt", "_kernel_times.txt"), ("metric_lab.txt", "_metric_lab.txt"), ("probe_robots.txt", "_probe_robots.txt")):
+for src, dst in (("kernel_times.txt", "_kernel_times.txt"), ("metric_lab.txt", "_metric_lab.txt"), ("probe_robots.txt", "_probe_robots.txt"),
+                 ("config5.txt", "_config5.txt")):
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 

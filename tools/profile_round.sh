@@ -33,6 +33,7 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
+python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
 [ -x $ROOT/tools/ubench/metric_lab ] && $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
 cd $ROOT
 # keep what travels back small: per-dispatch counter rows of OUR kernels only
