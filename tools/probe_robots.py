@@ -32,5 +32,10 @@ for robot in ("panda_no_gripper", "panda", "fetch", "fetch_arm_no_gripper", "jac
         t_id = graph_time(lambda: m.compute_inverse_dynamics(q, qd, qdd))
         t_h = graph_time(lambda: m.compute_lagrangian_inertia_matrix(q))
     t_fd = graph_time(lambda: m.compute_forward_dynamics(q, qd, qdd))
-    print("%-22s n=%2d ops=%2d segs=%d  FK+Jac(%s) %7.1f  RNEA %7.1f  CRBA %7.1f  FD %7.1f us" % (
-        robot, m._n_dofs, dw.program.n_ops, dw.program.n_segments, ee[:14], t_fkj, t_id, t_h, t_fd), flush=True)
+    t_bwd = float("nan")
+    if not ONLY_FD and dw.program.backward_ok:
+        from differentiable_robot_model_amd import backend
+        of, gt = m._ops_f(dw), torch.randn(B, m._n_dofs, device="cuda")
+        t_bwd = graph_time(lambda: backend.rnea_backward(dw.program, of, dw.ops_i, q, qd, qdd, gt, True, True, m._n_dofs, 0, True), launches=5)
+    print("%-22s n=%2d ops=%2d segs=%d  FK+Jac(%s) %7.1f  RNEA %7.1f  CRBA %7.1f  FD %7.1f  RNEA backward (input gradients) %7.1f us" % (
+        robot, m._n_dofs, dw.program.n_ops, dw.program.n_segments, ee[:14], t_fkj, t_id, t_h, t_fd, t_bwd), flush=True)
