@@ -222,3 +222,60 @@ def test_rnea_backward_scratch_covers_the_fanned_out_launch():
         tiles = (B + 63) // 64
         rows = min(tiles * 8, 2048)
         assert lib.drm_rnea_backward_scratch_floats(B, cap, n, 1) >= rows * cap * 32, B
+
+
+# ---------------------------------------------------------------------------------------------- scratch of the persistent kernels
+SCRATCH_QUERIES = ("drm_rnea_scratch_floats", "drm_crba_scratch_floats", "drm_forward_dynamics_scratch_floats")
+
+
+
+
+def test_scratch_queries_answer_zero_without_a_device():
+    """The scratch of the persistent dynamics kernels is sized by what the DEVICE holds at once (occupancy x CUs): on a box
+    without one the queries return 0 and say why; they do not crash."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    from differentiable_robot_model_amd.flatten import build_walk
+    from helpers import load_model
+    from test_host_emu import host_walk
+    lib = backend.load_library()
+    m = load_model("iiwa7_allegro")
+    walk, _keep = host_walk(m, build_walk(m._spec, whole_tree=True))
+    for name in SCRATCH_QUERIES:
+        assert getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(1000)) == 0
+        assert lib.drm_last_error() != b""
+
+
+@pytest.mark.gpu
+def test_gpu_scratch_of_the_persistent_kernels():
+    """Robots with a long segment (an arm carrying a hand) need caller-owned scratch for inverse dynamics, the mass matrix and
+    forward dynamics: the queries are positive, do NOT grow with the batch once the grid is full (persistent blocks own a
+    slice each), and a launch without scratch is refused; 7-DoF arms and hands need none."""
+    import torch
+    from helpers import load_model, sample_states
+    lib = backend.load_library()
+    m = load_model("iiwa7_allegro", "cuda")
+    dw = m._dynamics_walk()
+    of = m._ops_f(dw)
+    walk = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
+    for name in SCRATCH_QUERIES:
+        small, big, bigger = (int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
+        assert 0 < small < big == bigger < (1 << 28), (name, small, big, bigger)   # < 1 GiB whatever the batch
+    B, n = 130, m._n_dofs
+    q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(m, B, seed=3))
+    out, H = torch.empty(B, n, device="cuda"), torch.empty(B, n, n, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1
+    assert b"scratch" in lib.drm_last_error()
+    assert lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(), None, st) == -1
+    assert b"scratch" in lib.drm_last_error()
+    assert lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1
+    assert b"scratch" in lib.drm_last_error()
+    torch.cuda.synchronize()
+    for robot in ("panda_no_gripper", "allegro_left"):
+        r = load_model(robot, "cuda")
+        rw = r._dynamics_walk()
+        w = backend._walk_struct(rw.program, r._ops_f(rw), rw.ops_i, r._n_dofs)
+        for name in SCRATCH_QUERIES:
+            assert getattr(lib, name)(ctypes.byref(w), ctypes.c_int64(1 << 20)) == 0, (robot, name)
