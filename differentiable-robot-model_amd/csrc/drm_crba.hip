@@ -207,10 +207,11 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         // would wait out a round trip to L2 / Infinity Cache), into the LDS the forces have left; then every sample's cnt x n
         // floats leave as 4-byte stores of consecutive lanes — consecutive addresses.
         float *g = H + b0 * nn;
-        const int G0 = fo_floats / ntp < WAVE ? (fo_floats / ntp) & ~3 : WAVE; // (a multiple of 4 keeps the float4 copies aligned)
+        // (a multiple of 4 keeps the float4 copies aligned; a segment without joints — a camera on a fixed mount — has no rows)
+        const int G0 = ntp == 0 ? WAVE : fo_floats / ntp < WAVE ? (fo_floats / ntp) & ~3 : WAVE;
         const int G = G0 > 0 ? G0 : 1, per_sample = cnt * n;
         const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
-        for (int s0 = 0; s0 < rows; s0 += G) {
+        for (int s0 = 0; s0 < rows && cnt > 0; s0 += G) {
             const int gs = rows - s0 < G ? rows - s0 : G;
             const float4 *t4 = reinterpret_cast<const float4 *>(tri + s0 * ntp);
             float4 *l4 = reinterpret_cast<float4 *>(lrow);
