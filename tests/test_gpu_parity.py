@@ -500,3 +500,35 @@ def test_fused_plan_writes_into_caller_owned_output_blocks():
     assert not torch.isnan(flat).any()
     with pytest.raises(ValueError):
         m.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link", outputs=(outs[0], outs[1], outs[2][:, :3]))
+
+
+# ------------------------------------------------------------------ bench.py: the JSON line the round driver reads
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the driver's fields, the roofline object of
+    the dominant kernel (plus its 200-launch steady-state figure when K is small) and the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-large", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "evals/s" and d["dtype"] == "f32"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"] and d["config"]["batch_per_gpu"] == 65536
+    assert abs(d["value"] - 65536 * 20 / (d["ms_per_step"] * 1e-3 * 20)) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(roof["achieved"] - 224 * 65536 / (roof["launch_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
+    assert roof["launch_us"] * 1e-3 <= d["ms_per_step"] * 1.001          # a launch is not longer than a step
+    assert 0.2 < roof["frac"] < 1.0 and 0.2 < roof["steady_state"]["frac"] < 1.0 and roof["steady_state"]["steps"] == 200
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "evals/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
