@@ -137,3 +137,30 @@ def test_gpu_random_tree_dynamics_vs_oracle(tmp_path, seed):
     acc = m.compute_forward_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
     ref = orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)
     assert rel(acc.cpu().numpy(), ref) < 1e-3, (seed, B, rel(acc.cpu().numpy(), ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["iiwa7_allegro", "fetch", "panda"])
+def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
+    """Inverse dynamics, the mass matrix and forward dynamics of robots with a long segment run on a PERSISTENT grid: at
+    150 001 samples (2 344 tiles, the last one ragged) every block loops over several tiles and re-uses its slice of scratch.
+    Rows from the start, the middle and the ragged end of that launch must be bit-identical to the same rows launched on their
+    own (a sample's arithmetic does not depend on its tile), and a few of them are checked against the fp64 oracle."""
+    from helpers import load_model
+    mc, m = load_model(robot), load_model(robot, "cuda")
+    B, n = 150001, m._n_dofs
+    q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(mc, B, seed=5))
+    tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    H = m.compute_lagrangian_inertia_matrix(q)
+    acc = m.compute_forward_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    for lo in (0, 70000, 131072 - 65, B - 130):
+        sl = slice(lo, lo + 130)
+        assert torch.equal(tau[sl], m.compute_inverse_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)), lo
+        assert torch.equal(H[sl], m.compute_lagrangian_inertia_matrix(q[sl])), lo
+        assert torch.equal(acc[sl], m.compute_forward_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)), lo
+    rows = [0, 63, 64, 99999, B - 1]
+    orc = Oracle(mc._spec)
+    q64, qd64, qdd64 = (t[rows].cpu().numpy().astype(np.float64) for t in (q, qd, qdd))
+    assert np.allclose(tau[rows].cpu().numpy(), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+    assert np.allclose(H[rows].cpu().numpy(), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU)
+    assert rel(acc[rows].cpu().numpy(), orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)) < 1e-3
