@@ -44,6 +44,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument` otherwise);
+# the images export it already — keep it for every rank this script spawns
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
 EE_LINK = {"panda_no_gripper": "panda_virtual_ee_link", "iiwa7": "iiwa_link_ee"}
