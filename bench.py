@@ -30,8 +30,11 @@ The JSON line also carries
   "roofline_large": the same kernel at batches whose per-launch traffic (0.94 GB / 3.8 GB) is far beyond the 256 MiB
                     Infinity Cache, i.e. genuine HBM streaming (N = 1 only)
   "cpu_baseline":   the oracle's fp32 C restatement of the reference (oracle/, "port") timed on this box's host cores
-                    on a bounded sample of the same workload, plus the reference's own CPU numbers measured in the
-                    build container (/root/reference does not exist on the GPU box).
+                    on a bounded sample of the same workload, and under "reference" the UNMODIFIED reference itself
+                    (oracle/_ref/, staged from /root/reference by oracle/stage_ref.py) timed on the same host cores in
+                    the same run on the same joint states: (A) its public compute_endeffector_jacobian on 4 096 rows
+                    (linear extrapolation stated), (B) tensor-only (Python quaternion loop stubbed) on all 65 536 rows,
+                    all threads and 1 thread, min of 3 — plus the HIP path's deviation from the reference's outputs.
 """
 import argparse
 import json
@@ -51,12 +54,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
 EE_LINK = {"panda_no_gripper": "panda_virtual_ee_link", "iiwa7": "iiwa_link_ee"}
 CONFIG3_GLOBAL_BATCH = 1 << 20
-# the reference's own CPU path, measured in the build container where /root/reference exists (BASELINE.md, 8 threads)
-REFERENCE_CPU = {"public_api_evals_per_s": 9.65e3, "tensor_only_evals_per_s": 1.64e6, "threads": 8,
-                 "where": "build container (BASELINE.md): compute_endeffector_jacobian of the unmodified reference, "
-                          "Panda, batch 65 536; the public API spends 6.8 s per call in its Python quaternion loop, "
-                          "'tensor only' stubs that loop out.  Not re-measured in this run: the GPU box has no "
-                          "/root/reference"}
 
 
 def parse_args(argv=None):
@@ -90,6 +87,46 @@ def respawn_if_needed(args):
     sys.exit(subprocess.call(cmd))
 
 
+def reference_cpu(robot, link, q_host, qd_host=None, qdd_host=None, gpu_outputs=None, public_rows=4096):
+    """The UNMODIFIED reference, timed on THIS box's host cores in THIS run: oracle/ref_timing.py runs in its own
+    interpreter (the bench process never imports the reference) on the SAME joint states the GPU leg used.  The reference
+    is pure Python; oracle/stage_ref.py stages it from /root/reference into the git-ignored oracle/_ref/, which ships to
+    the GPU box with the snapshot.  `gpu_outputs` (dict of host arrays of the HIP path on the same rows): the largest
+    deviation from the reference's own outputs is reported next to the timings."""
+    import tempfile
+
+    import numpy as np
+    script = os.path.join(ROOT, "oracle", "ref_timing.py")
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, script, "--robot", robot, "--link", link, "--public-rows", str(public_rows),
+               "--q", os.path.join(tmp, "q.npy"), "--out-npz", os.path.join(tmp, "ref.npz")]
+        np.save(os.path.join(tmp, "q.npy"), np.ascontiguousarray(q_host, np.float32))
+        if qd_host is not None and qdd_host is not None:
+            np.save(os.path.join(tmp, "qd.npy"), np.ascontiguousarray(qd_host, np.float32))
+            np.save(os.path.join(tmp, "qdd.npy"), np.ascontiguousarray(qdd_host, np.float32))
+            cmd += ["--qd", os.path.join(tmp, "qd.npy"), "--qdd", os.path.join(tmp, "qdd.npy")]
+        try:
+            env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")   # host cores only
+            done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+            rec = json.loads(done.stdout.decode().strip().splitlines()[-1])
+        except Exception as err:  # the baseline leg must never take the GPU numbers down with it
+            return {"kind": "reference", "error": "%s: %s" % (type(err).__name__, err)}
+        if gpu_outputs and "error" not in rec and os.path.exists(os.path.join(tmp, "ref.npz")):
+            ref = np.load(os.path.join(tmp, "ref.npz"))
+            rows, dev = rec.get("outputs_npz_rows", 0), {}
+            for key, got in gpu_outputs.items():
+                if key in ref.files:
+                    want, got = ref[key], np.asarray(got)[:rows]
+                    if key == "quat":   # sign of the whole quaternion: the reference's own branch rule decides it
+                        dev["quat_sign_flips"] = int((np.sum(want * got, -1) < 0).sum())
+                    scale = 1.0 + np.abs(want) if key == "tau" else 1.0
+                    dev[key] = float((np.abs(got - want) / scale).max())
+            rec["gpu_vs_reference_max_abs"] = dev
+            rec["gpu_vs_reference_note"] = ("HIP path vs the reference's own fp32 outputs on the first %d rows of this "
+                                            "run's batch (tau relative to 1 + |tau|)" % rows)
+    return rec
+
+
 def cpu_baseline(spec, link_idx, q_host, seconds):
     """Oracle (CPU port of the reference algorithm, fp32, OpenMP over samples) on a bounded sample: median pass."""
     import numpy as np
@@ -114,8 +151,7 @@ def cpu_baseline(spec, link_idx, q_host, seconds):
             "best": q.shape[0] / times[0], "mean": q.shape[0] * len(times) / sum(times),
             "sample": "%d passes over the same %d-sample batch (%.1f s wall on all host cores; value = the median pass, "
                       "the host is shared so single passes swing), fp32 C restatement of the reference algorithm "
-                      "(oracle/drm_oracle.c), OpenMP over samples" % (len(times), q.shape[0], sum(times)),
-            "reference_cpu": REFERENCE_CPU}
+                      "(oracle/drm_oracle.c), OpenMP over samples" % (len(times), q.shape[0], sum(times))}
 
 
 def recorded_traffic(batch):
@@ -281,7 +317,9 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                     "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
+                     "traffic_note": "RECORDED figure: rocprofv3 --pmc passes of this same command, committed under "
+                                     "profiles/ (PMC counters cannot be read from inside the timed run)", "algorithmic_bytes_per_launch": bytes_per_eval * B,
                      "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true, 1, false>", "bytes_per_eval": bytes_per_eval,
                      "launch_us": launch_s * 1e6,
                      "note": "algorithmic bytes / average launch duration (HIP events over the timed region, includes "
@@ -305,6 +343,11 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         line["roofline_large"] = roofline_large(model, link, device, stream, bytes_per_eval)
     if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         line["cpu_baseline"] = cpu_baseline(model._spec, model._name_to_idx_map[link], q.cpu().numpy(), args.cpu_seconds)
+        plan.launch()
+        torch.cuda.synchronize()
+        names = ("pos", "quat", "lin_jac", "ang_jac")
+        line["cpu_baseline"]["reference"] = reference_cpu(
+            args.robot, link, q.cpu().numpy(), gpu_outputs={k: t.cpu().numpy() for k, t in zip(names, plan.outputs())})
     return line
 
 

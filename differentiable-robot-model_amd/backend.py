@@ -17,7 +17,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -80,13 +80,13 @@ def load_library(path: str = None):
         lib.drm_rnea_scratch_floats.restype = i64
         lib.drm_rnea_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_backward.restype = ctypes.c_int
-        lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
+        lib.drm_fk_backward.argtypes = [wp, vp, i64, i32, vp, vp, ctypes.c_uint64, vp, vp, vp, vp]
         lib.drm_fk_jacobian_backward.restype = ctypes.c_int
-        lib.drm_fk_jacobian_backward.argtypes = [wp, vp, i64, vp, vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp]
+        lib.drm_fk_jacobian_backward.argtypes = [wp, vp, i64, vp, vp, vp, vp, ctypes.c_uint64, vp, vp, vp, vp]
         lib.drm_fk_backward_scratch_floats.restype = i64
         lib.drm_fk_backward_scratch_floats.argtypes = [i64, i32]
         lib.drm_rnea_backward.restype = ctypes.c_int
-        lib.drm_rnea_backward.argtypes = [wp, vp, vp, vp, i64, i32, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
+        lib.drm_rnea_backward.argtypes = [wp, vp, vp, vp, i64, i32, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
         lib.drm_rnea_backward_scratch_floats.restype = i64
         lib.drm_rnea_backward_scratch_floats.argtypes = [i64, i32, i32, i32]
         lib.drm_link_rows.restype = ctypes.c_int
@@ -264,7 +264,7 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
     ptr = lambda t: t.data_ptr() if t is not None else None
     with torch.cuda.device(dev):
         _check(lib.drm_rnea_backward(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), ptr(qdd), B, flags,
-                                     grad_tau.data_ptr(), ctypes.c_uint32(param_mask),
+                                     grad_tau.data_ptr(), ctypes.c_uint64(param_mask),
                                      ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
                                      ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)))
     return gin, grad_ops
@@ -402,7 +402,7 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
     with torch.cuda.device(dev):
         _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
                                    grad_rot.data_ptr() if grad_rot is not None else None,
-                                   ctypes.c_uint32(param_mask), grad_q.data_ptr() if want_grad_q else None,
+                                   ctypes.c_uint64(param_mask), grad_q.data_ptr() if want_grad_q else None,
                                    grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
     return grad_q, grad_ops
 
@@ -428,7 +428,7 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
         _check(lib.drm_fk_jacobian_backward(ctypes.byref(walk), q.data_ptr(), B,
                                             grad_pos.data_ptr() if grad_pos is not None else None,
                                             grad_rot.data_ptr() if grad_rot is not None else None, grad_lin.data_ptr(),
-                                            grad_ang.data_ptr(), ctypes.c_uint32(param_mask),
+                                            grad_ang.data_ptr(), ctypes.c_uint64(param_mask),
                                             grad_q.data_ptr() if want_grad_q else None,
                                             grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
     return grad_q, grad_ops

@@ -19,13 +19,14 @@ namespace drm {
 // LINKS = the links the dynamics sweeps visit: CAP, or NJ when the walk has no ops behind its moving joints (the host
 // folded the fixed tail into the last moving link, flatten.fold_link_table; the rest of the table is identity padding).
 template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LINKS < CAP ? 3 : 2, LINKS < CAP ? 3 : 2)))
     rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                     const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
-    // body-force parking area between the sweeps (tau is staged over it at the end): 13.3 KB per wave
+    // body-force parking area between the sweeps (tau is staged over it at the end), one [6][64] record per PARKED link:
+    // LINKS - DRM_RNEA_KEEP of them (the last links' forces stay in registers, drm_sample.hpp rnea_chain_trig)
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = (LINKS - DRM_RNEA_KEEP) * 6 * WAVE;
     static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
     constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
@@ -89,15 +90,19 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
 // kernels, bit for bit (drm_sample.hpp: fk_chain_pairs_trig / rnea_chain_trig on shared cos / sin).
 // ---------------------------------------------------------------------------------------------------
 // (LINKS as above: the FK chain always walks all CAP ops, the dynamics sweeps the first LINKS)
+// amdgpu_waves_per_eu: the register allocator's occupancy goal follows the LDS footprint, and with the LINKS-sized parking
+// area it would settle on 170 VGPRs, two short of a third wave per SIMD; the attribute holds it to <= 168
 template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LINKS < CAP ? 3 : 2, LINKS < CAP ? 3 : 2)))
     fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
                        float *__restrict__ pos, float *__restrict__ quat) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    // parking area sized by the links actually parked (LINKS - DRM_RNEA_KEEP), not by the table capacity: with LINKS = 7
+    // a four-wave block takes 44 KB instead of 56 KB and a CU holds three of them (164 VGPR allow three waves per SIMD)
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), P_FLOATS = WAVE * 3,
-                  F_FLOATS = CAP * 6 * WAVE;
+                  F_FLOATS = (LINKS - DRM_RNEA_KEEP) * 6 * WAVE;
     static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
     constexpr int PER_WAVE = C_FLOATS + P_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                        int n_slots, int T, const float *__restrict__ q, const float *__restrict__ gpos,
                        const float *__restrict__ grot, const float *__restrict__ glin, const float *__restrict__ gang, int64_t B,
                        float *__restrict__ gq,
-                       uint32_t param_mask, float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q,
+                       uint64_t param_mask, float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q,
                        uint32_t magic_g, uint32_t magic_j, int lds_per_wave, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NV = cap * BWD_FIELDS;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 template <int CAP, int NJ>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
-                           int n_tiles, uint32_t param_mask, float *__restrict__ gq, float *__restrict__ partials) {
+                           int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *__restrict__ partials) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
@@ -247,7 +247,7 @@ extern "C" int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity) {
 }
 
 static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                              const float *grad_rot, const float *grad_lin, const float *grad_ang, uint32_t param_mask, float *grad_q,
+                              const float *grad_rot, const float *grad_lin, const float *grad_ang, uint64_t param_mask, float *grad_q,
                               float *grad_ops_f, float *scratch, void *stream) {
     const bool jac = grad_lin != nullptr;
     if (B < 0 || n_targets < 1) return fail(DRM_ERR_INVALID, "negative batch or no targets");
@@ -256,7 +256,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
         return fail(DRM_ERR_INVALID, "grad_ops_f must be given exactly when param_mask selects ops");
     if (!grad_q && !grad_ops_f) return fail(DRM_ERR_INVALID, "nothing to compute: grad_q and grad_ops_f are both NULL");
     if (!scratch) return fail(DRM_ERR_INVALID, "scratch must not be NULL (drm_fk_backward_scratch_floats)");
-    if (w->capacity < 32 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
+    if (w->capacity < 64 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
     const int n = w->n_dofs, T = n_targets, cap = w->capacity;
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
@@ -337,7 +337,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
 }
 
 extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                               const float *grad_rot, uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch,
+                               const float *grad_rot, uint64_t param_mask, float *grad_q, float *grad_ops_f, float *scratch,
                                void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
@@ -351,7 +351,7 @@ extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int
 
 extern "C" int drm_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *grad_pos,
                                         const float *grad_rot, const float *grad_lin_jac, const float *grad_ang_jac,
-                                        uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+                                        uint64_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
     if (!q || !grad_lin_jac || !grad_ang_jac) return fail(DRM_ERR_INVALID, "q / grad_lin_jac / grad_ang_jac must not be NULL");

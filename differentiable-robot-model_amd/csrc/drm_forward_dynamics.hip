@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                                 const float *__restrict__ f, int n_tiles, int flags, float *__restrict__ qdd) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = CAP * 6 * WAVE;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = (LINKS - DRM_RNEA_KEEP) * 6 * WAVE;
     static_assert(Q_FLOATS <= F_FLOATS, "the qdd tile fits under the parking area");
     constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     rnea_backward_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, int cap, int n_ops, int n_leaves,
                          int n, int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
                          const float *__restrict__ qdd, const float *__restrict__ gtau, int64_t B, float *__restrict__ gq,
-                         float *__restrict__ gqd, float *__restrict__ gqdd, uint32_t param_mask,
+                         float *__restrict__ gqd, float *__restrict__ gqdd, uint64_t param_mask,
                          float *__restrict__ partials, float *__restrict__ park_hbm, uint32_t magic_q, int lds_per_wave,
                          uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     rnea_backward_fan_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, FanArgs fa, int cap, int n,
                              int n_slots, int flags, const float *__restrict__ q, const float *__restrict__ qd,
                              const float *__restrict__ qdd, const float *__restrict__ gtau, int64_t B, float *__restrict__ gq,
-                             float *__restrict__ gqd, float *__restrict__ gqdd, uint32_t param_mask,
+                             float *__restrict__ gqd, float *__restrict__ gqdd, uint64_t param_mask,
                              float *__restrict__ partials, uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NV = cap * DRM_OPF_STRIDE;
@@ -288,7 +288,7 @@ template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     rnea_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                              const float *__restrict__ qdd, const float *__restrict__ gtau, int n_tiles, int flags,
-                             uint32_t param_mask, float *__restrict__ gq, float *__restrict__ gqd,
+                             uint64_t param_mask, float *__restrict__ gq, float *__restrict__ gqd,
                              float *__restrict__ gqdd, float *__restrict__ partials) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
@@ -311,8 +311,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     // ONE learnable link (the common case: system identification of a payload or of one link): its 26 constant gradients
     // are summed per LANE over this wave's tiles and reduced across the wave once at the end — 26 adds per tile instead of
     // 26 DPP reductions (230 VALU).  Several learnable links keep the per-tile reduction (a register set each would not fit).
-    const bool single = __builtin_popcount(param_mask) == 1;
-    const int single_k = single ? __builtin_ctz(param_mask) : 0;
+    const bool single = __builtin_popcountll(param_mask) == 1;
+    const int single_k = single ? __builtin_ctzll(param_mask) : 0;
     float psum[DRM_OPF_DAMP + 1];
 #pragma unroll
     for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) psum[j] = 0.0f;
@@ -406,7 +406,7 @@ extern "C" int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity,
 }
 
 extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B,
-                                 int32_t flags, const float *grad_tau, uint32_t param_mask, float *grad_q, float *grad_qd,
+                                 int32_t flags, const float *grad_tau, uint64_t param_mask, float *grad_q, float *grad_qd,
                                  float *grad_qdd, float *grad_ops_f, float *scratch, void *stream) {
     int rc = check_walk(w);
     if (rc) return rc;
@@ -419,7 +419,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         return fail(DRM_ERR_INVALID, "grad_q, grad_qd and grad_qdd are produced together: give all three or none");
     if (!want_q && !grad_ops_f) return fail(DRM_ERR_INVALID, "nothing to compute");
     if (!scratch) return fail(DRM_ERR_INVALID, "scratch must not be NULL (drm_rnea_backward_scratch_floats)");
-    if (w->capacity < 32 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
+    if (w->capacity < 64 && (param_mask >> w->capacity)) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
     const int n = w->n_dofs, cap = w->capacity, n_leaves = DRM_WALK_LEAVES(w->shape);
     if (w->n_ops > 0 && (n_leaves < 1 || n_leaves > w->n_ops || n_leaves > 64))
         return fail(DRM_ERR_INVALID, "walk without its leaf count (drm_walk.shape bits 16..23; host built for an older ABI?)");
@@ -487,7 +487,7 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
 #endif
     // fanned out over the segments when the walk has several, none of the prefix ops is learnable and a block's LDS fits twice
     // per CU or better than the single-wavefront form would
-    if (w->n_segments > 1 && segments_ok(w) && w->prefix_end < 32 && !(param_mask & ((1u << w->prefix_end) - 1u))) {
+    if (w->n_segments > 1 && segments_ok(w) && w->prefix_end < 64 && !(param_mask & ((1ull << w->prefix_end) - 1ull))) {
         FanArgs fa;
         fa.n_seg = w->n_segments; fa.p_end = w->prefix_end;
         const size_t shared = (size_t)4 * round4(WAVE * pad_odd(n)) + (size_t)w->n_slots * SLOT_FLOATS * WAVE;

@@ -488,7 +488,7 @@ struct NoRotationGrad { // fk_backward_walk without gradients on the targets' ro
 //   adjoint enters the sweep as  M_t += Rbar R_t^T  (M = Rbar R^T in general; see the JAC note below).
 template <bool JAC = false, class QF, class GIN, class PSAVE, class PLOAD, class AADD, class ATAKE, class GQ, class PG,
           class PARK, class UNPARK, class GL = NoJacobianGrad, class GA = NoJacobianGrad, class GR = NoRotationGrad>
-DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, uint32_t param_mask,
+DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int n_ops, uint64_t param_mask,
                              bool want_gq, QF qf, GIN grad_in, PSAVE pose_save, PLOAD pose_load, AADD adj_add,
                              ATAKE adj_take, GQ gq_out, PG param_out, PARK park, UNPARK unpark, GL glin = GL(),
                              GA gang = GA(), GR grot = GR()) {
@@ -654,7 +654,7 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 //   ft(k) -> FT block of op k;   gq[d] <- dL/dq_d;   q_at(d) -> q[d] for a run-time d;
 //   param_out(k, dF[9], dt[3]) for ops in param_mask (run-time k)
 template <int CAP, int NJ, class FT, class QAT, class PG>
-DRM_HD void fk_backward_chain(FT ft, const float (&q)[NJ], const float (&g)[3], uint32_t param_mask, float (&gq)[NJ],
+DRM_HD void fk_backward_chain(FT ft, const float (&q)[NJ], const float (&g)[3], uint64_t param_mask, float (&gq)[NJ],
                               QAT q_at, PG param_out) {
     PoseP ee;
     f2 B[NJ][3];
@@ -845,25 +845,42 @@ DRM_HD void rnea_link_force_up(const float *J, const float *t, const Force &tot,
 //   row(k) -> pointer to op k's constant row (DRM_OPF_* layout)
 //   fput(k, Force) / fget(k, Force&) -> body force of link k, parked between the sweeps (LDS in the kernel: the
 //   48 floats would otherwise be the registers that keep a second wave off the SIMD)
-template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+//   KEEP: the body forces of the last KEEP links never leave the registers (only links 0 .. CAP-KEEP-1 are parked; fput /
+//   fget see no others).  Measured and left at 0: with KEEP = 1 or 2 the register allocator loses the LDS stores as anchors
+//   and needs 194-220 VGPRs for the same arithmetic (24-41 spilled under a three-wave bound), profiles/r03_resource_usage.txt
+#ifndef DRM_RNEA_KEEP
+#define DRM_RNEA_KEEP 0
+#endif
+// A scheduling barrier between the links of the straight-line sweeps (device code only).  Without it the compiler hoists
+// the constant reads (broadcast ds_read_b128) of later links over the current one and the live ranges pile up: 164-170 VGPRs;
+// with it 136, no spills, and the kernels are 3-7 % faster (profiles/r03_ab_rnea_fence.txt).  -DDRM_RNEA_NO_FENCE for A/B runs.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DRM_RNEA_NO_FENCE)
+#define DRM_RNEA_LINK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DRM_RNEA_LINK_FENCE() ((void)0)
+#endif
+template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
                             const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget);
-template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ], const float (&qd)[NJ],
                        const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
     float cs[NJ], sn[NJ];
     chain_trig<NJ>(q, cs, sn);
-    rnea_chain_trig<CAP, NJ>(row, gravity, damping, cs, sn, qd, qdd, tau, fput, fget);
+    rnea_chain_trig<CAP, NJ, KEEP>(row, gravity, damping, cs, sn, qd, qdd, tau, fput, fget);
 }
-template <int CAP, int NJ, class ROW, class FPUT, class FGET>
+template <int CAP, int NJ, int KEEP, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
                             const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
+    static_assert(KEEP >= 0 && KEEP < CAP, "at least one parked link");
+    Force kept[KEEP > 0 ? KEEP : 1];
     // The joint transforms are rebuilt in the backward sweep (12 VALU ops + three broadcast LDS reads per link)
     // instead of being kept: 72 fewer live registers.
     Motion cur;
     motion_root(cur, gravity ? 9.81f : 0.0f);
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
+        DRM_RNEA_LINK_FENCE();
         const float *of = row(k);
         const OpFT o = load_ft(of);
         float J[9];
@@ -876,16 +893,19 @@ DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&c
         rnea_link_motion(J, o.t, k < NJ ? qd[k] : 0.0f, k < NJ ? qdd[k] : 0.0f, cur, cur);
         Force fk;
         rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, fk);
-        fput(k, fk);
+        if (k >= CAP - KEEP) kept[k - (CAP - KEEP)] = fk;
+        else fput(k, fk);
     }
     Force tot;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tot.la[i] = f2_bcast(0.0f);
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
+        DRM_RNEA_LINK_FENCE();
         const float *of = row(k);
         Force fk;
-        fget(k, fk);
+        if (k >= CAP - KEEP) fk = kept[k - (CAP - KEEP)];
+        else fget(k, fk);
 #pragma unroll
         for (int i = 0; i < 3; ++i) tot.la[i] += fk.la[i];
         if (k < NJ) tau[k] = tot.la[2][1] + (damping ? of[DRM_OPF_DAMP] * qd[k] : 0.0f);
@@ -1261,7 +1281,7 @@ DRM_HD void tbar_parent(const float *J, const float *t, const f2 (&T)[3], f2 (&U
 //   slot records: 0..11 motion, 12..17 total-force accumulator, 18..23 tbar, 24..35 motion-adjoint accumulator
 template <class QF, class GT, class PARK, class UNPARK, class SPUT, class SGET, class SADD, class STAKE, class GOUT, class PG>
 DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int p_end, int a, int b, int flags,
-                               uint32_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
+                               uint64_t param_mask, bool want_gq, QF qf, GT gtau, PARK park, UNPARK unpark, SPUT slot_put,
                                SGET slot_get, SADD slot_add, STAKE slot_take, GOUT gout, PG param_out) {
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     const bool damping = flags & DRM_RNEA_DAMPING;
@@ -1463,7 +1483,7 @@ DRM_HD void rnea_backward_walk(const float *__restrict__ opf, const int32_t *__r
 // Returns false (nothing done) when the segment is not of that shape — the caller then runs rnea_backward_walk.
 template <int MAXOPS, class QF, class GT, class SPUT, class SGET, class GOUT, class PG>
 DRM_HD bool rnea_backward_walk_short(const float *__restrict__ opf, const int32_t *__restrict__ ctl, int p_end, int a, int b,
-                                     int flags, uint32_t param_mask, bool want_gq, QF qf, GT gtau, SPUT slot_put, SGET slot_get,
+                                     int flags, uint64_t param_mask, bool want_gq, QF qf, GT gtau, SPUT slot_put, SGET slot_get,
                                      GOUT gout, PG param_out) {
     const int len = b - a;
     if (len < 1 || len > MAXOPS) return false;
@@ -1601,7 +1621,7 @@ DRM_HD bool rnea_backward_walk_short(const float *__restrict__ opf, const int32_
 // 256 VGPR + 180 AGPR).
 //   row(k) -> op k's constant row;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
 template <int CAP, int NJ, class ROW, class GOUT, class PG>
-DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint32_t param_mask, bool want_gq,
+DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint64_t param_mask, bool want_gq,
                                 const float (&q)[NJ], const float (&qd)[NJ], const float (&qdd)[NJ],
                                 const float (&gtau)[NJ], GOUT gout, PG param_out) {
     float cs[NJ], sn[NJ];

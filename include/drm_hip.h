@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 6
+#define DRM_ABI_VERSION 7
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -282,7 +282,7 @@ int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, 
  */
 int64_t drm_fk_backward_scratch_floats(int64_t B, int32_t capacity);
 int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets, const float *grad_pos,
-                    const float *grad_rot, uint32_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
+                    const float *grad_rot, uint64_t param_mask, float *grad_q, float *grad_ops_f, float *scratch, void *stream);
 
 /*
  * Reverse-mode derivative of drm_fk_jacobian: what torch autograd computes in the reference when a loss on
@@ -294,7 +294,7 @@ int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_t
  *   param_mask, grad_q, grad_ops_f, scratch (drm_fk_backward_scratch_floats)   as for drm_fk_backward
  */
 int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, const float *grad_pos, const float *grad_rot,
-                             const float *grad_lin_jac, const float *grad_ang_jac, uint32_t param_mask, float *grad_q,
+                             const float *grad_lin_jac, const float *grad_ang_jac, uint64_t param_mask, float *grad_q,
                              float *grad_ops_f, float *scratch, void *stream);
 
 /*
@@ -313,7 +313,7 @@ int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, co
  */
 int64_t drm_rnea_backward_scratch_floats(int64_t B, int32_t capacity, int32_t n_dofs, int32_t n_slots);
 int drm_rnea_backward(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
-                      const float *grad_tau, uint32_t param_mask, float *grad_q, float *grad_qd, float *grad_qdd,
+                      const float *grad_tau, uint64_t param_mask, float *grad_q, float *grad_qd, float *grad_qdd,
                       float *grad_ops_f, float *scratch, void *stream);
 
 /*

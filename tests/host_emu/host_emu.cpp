@@ -147,7 +147,7 @@ void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *
 
 // reverse-mode FK: per-sample adjoint sweep, constant gradients summed over the batch in double
 void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpos, const float *glin, const float *gang,
-           uint32_t mask, float *gq, float *gops, const float *grot = nullptr) {
+           uint64_t mask, float *gq, float *gops, const float *grot = nullptr) {
     const int n = w->n_dofs, CAP = w->capacity;
     std::vector<double> sum((size_t)CAP * 12, 0.0);
     std::vector<Pose> parked(CAP);
@@ -199,7 +199,7 @@ void fkb_t(const drm_walk *w, const float *q, int64_t B, int T, const float *gpo
 
 // reverse-mode RNEA: per-sample adjoint sweeps, constant gradients summed over the batch in double
 void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, const float *gtau,
-             uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+             uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
     const int n = w->n_dofs, CAP = w->capacity;
     std::vector<double> sum((size_t)CAP * DRM_OPF_STRIDE, 0.0);
     std::vector<float> recv((size_t)CAP * 26);
@@ -220,7 +220,7 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
         auto pout = [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; };
         // segment by segment, as the fanned-out kernel does it (one wavefront each there); a walk with learnable prefix ops
         // in one go
-        const uint32_t prefix_mask = w->prefix_end >= 32 ? 0xffffffffu : ((1u << w->prefix_end) - 1u);
+        const uint64_t prefix_mask = w->prefix_end >= 64 ? ~0ull : ((1ull << w->prefix_end) - 1ull);
         if (w->n_segments > 1 && !(mask & prefix_mask)) {
             for (int seg = 0; seg < w->n_segments; ++seg) {
                 for (auto &s : slots) for (float &x : s) x = 0.f;
@@ -360,7 +360,7 @@ int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float
     return 0;
 }
 int emu_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
-                      const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+                      const float *gtau, uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
     rneab_t(w, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops);
     return 0;
 }
@@ -379,7 +379,7 @@ int emu_link_rows_backward(const float *params, const float *grad_rows, int32_t 
     return 0;
 }
 int emu_rnea_backward_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
-                          const float *gtau, uint32_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+                          const float *gtau, uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     constexpr int CAP = 8, NJ = 7;
     static thread_local double sum[CAP * DRM_OPF_STRIDE];
@@ -397,7 +397,7 @@ int emu_rnea_backward_arm(const drm_walk *w, const float *q, const float *qd, co
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
     return 0;
 }
-int emu_fk_backward_arm(const drm_walk *w, const float *q, int64_t B, const float *gpos, uint32_t mask, float *gq, float *gops) {
+int emu_fk_backward_arm(const drm_walk *w, const float *q, int64_t B, const float *gpos, uint64_t mask, float *gq, float *gops) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     constexpr int CAP = 8, NJ = 7;
     static thread_local double sum[CAP * 12];
@@ -436,18 +436,18 @@ int emu_crba(const drm_walk *w, const float *q, int64_t B, float *H) {
     crba_loop(w, q, B, H);
     return 0;
 }
-int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint32_t mask, float *gq,
+int emu_fk_backward(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, uint64_t mask, float *gq,
                     float *gops) {
     fkb_t(w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops);
     return 0;
 }
 int emu_fk_backward_rot(const drm_walk *w, const float *q, int64_t B, int32_t T, const float *gpos, const float *grot,
-                        uint32_t mask, float *gq, float *gops) {
+                        uint64_t mask, float *gq, float *gops) {
     fkb_t(w, q, B, T, gpos, nullptr, nullptr, mask, gq, gops, grot);
     return 0;
 }
 int emu_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *gpos, const float *glin,
-                             const float *gang, uint32_t mask, float *gq, float *gops) {
+                             const float *gang, uint64_t mask, float *gq, float *gops) {
     fkb_t(w, q, B, 1, gpos, glin, gang, mask, gq, gops);
     return 0;
 }

@@ -57,7 +57,7 @@ def emu_loss_and_grads(emu, m, q, targets, wants):
     gpos = np.ascontiguousarray(2.0 * (pos - want) / (B * 3), np.float32)
     gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
     mask = m._kinematic_param_mask(type("W", (), {"program": prog})())
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(mask),
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint64(mask),
                                _ptr(gq), _ptr(gops)) == 0
     m.zero_grad()
     ops_f_t.backward(torch.from_numpy(gops))
@@ -101,7 +101,7 @@ def test_emu_grad_q_vs_oracle_central_differences(emu, robot):
     rng = np.random.default_rng(5)
     gpos = rng.standard_normal((B, T, 3)).astype(np.float32)
     gq = np.full((B, n), np.nan, np.float32)
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(0),
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint64(0),
                                _ptr(gq), None) == 0
     orc = Oracle(m._spec)
     h = 1e-6
@@ -314,7 +314,7 @@ def test_emu_jacobian_backward_vs_reference_autograd(emu, case):
     gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
     mask = m._kinematic_param_mask(type("W", (), {"program": prog})())
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
-                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+                                        ctypes.c_uint64(mask), _ptr(gq), _ptr(gops)) == 0
     assert close(gq, g[case + "/grad_q"]), np.abs(gq - g[case + "/grad_q"]).max()
     m.zero_grad()
     ops_f_t.backward(torch.from_numpy(gops))
@@ -361,7 +361,7 @@ def test_gpu_fused_fk_and_jacobian_backward_vs_emu(emu, B):
     walk, _keep = host_walk(mc, prog)
     gq = np.full((B, 7), np.nan, np.float32)
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
-                                        ctypes.c_uint32(0), _ptr(gq), None) == 0
+                                        ctypes.c_uint64(0), _ptr(gq), None) == 0
     assert np.allclose(qt.grad.cpu().numpy(), gq, atol=2e-5, rtol=2e-5)
 
 
@@ -384,7 +384,7 @@ def test_gpu_jacobian_backward_every_robot_vs_emu(emu, robot):
     walk, _keep = host_walk(mc, prog)
     gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
-                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+                                        ctypes.c_uint64(mask), _ptr(gq), _ptr(gops)) == 0
     dw = m._get_walk(("chain", idx), targets=[idx])
     got_q, got_ops = backend.fk_jacobian_backward(dw.program, m._ops_f(dw), dw.ops_i, torch.from_numpy(q).cuda(),
                                                   torch.from_numpy(gpos).cuda(), torch.from_numpy(glin).cuda(),
@@ -420,8 +420,8 @@ def test_emu_arm_chain_fk_backward_equals_generic_walk(emu, robot, link):
     mask = 0b10100101 & ((1 << prog.n_ops) - 1)
     gq_a, gq_b = (np.full((B, 7), np.nan, np.float32) for _ in range(2))
     go_a, go_b = (np.full((8, 32), np.nan, np.float32) for _ in range(2))
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq_a), _ptr(go_a)) == 0
-    assert emu.emu_fk_backward_arm(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq_b), _ptr(go_b)) == 0
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint64(mask), _ptr(gq_a), _ptr(go_a)) == 0
+    assert emu.emu_fk_backward_arm(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), ctypes.c_uint64(mask), _ptr(gq_b), _ptr(go_b)) == 0
     assert np.abs(gq_a - gq_b).max() <= 1e-5 * max(1.0, np.abs(gq_a).max())
     assert np.abs(go_a - go_b).max() <= 2e-5 * max(1.0, np.abs(go_a).max()), np.abs(go_a - go_b).max()
 
@@ -439,7 +439,7 @@ def test_gpu_arm_chain_fk_backward_vs_emu(emu, robot, link, B):
     walk, _keep = host_walk(mc, prog)
     mask = 0b01001010 & ((1 << prog.n_ops) - 1)
     gq = np.full((B, 7), np.nan, np.float32); gops = np.full((8, 32), np.nan, np.float32)
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint64(mask), _ptr(gq), _ptr(gops)) == 0
     dw = m._get_walk(("fk", (idx,)), targets=[idx])
     for want_q, pm in ((True, mask), (True, 0), (False, mask)):
         got_q, got_ops = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, torch.from_numpy(q).cuda(),
@@ -543,7 +543,7 @@ def test_emu_quaternion_backward_vs_reference_autograd(emu, case, mode):
     gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
     mask = m._kinematic_param_mask(type("W", (), {"program": prog})())
     assert emu.emu_fk_backward_rot(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), _ptr(grot),
-                                   ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+                                   ctypes.c_uint64(mask), _ptr(gq), _ptr(gops)) == 0
     m.zero_grad()
     ops_f_t.backward(torch.from_numpy(gops))
     assert close(gq, g[key + "/grad_q"]), np.abs(gq - g[key + "/grad_q"]).max()

@@ -194,7 +194,7 @@ def test_emu_forward_dynamics_backward_vs_reference_autograd(emu, case):
     gq, gqd, gx = (np.full((B, n), np.nan, np.float32) for _ in range(3))
     gops = np.full((prog.capacity, 32), np.nan, np.float32)
     assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(lam),
-                                 ctypes.c_uint32(dynamic_param_mask(m, prog)), _ptr(gq), _ptr(gqd), _ptr(gx), _ptr(gops)) == 0
+                                 ctypes.c_uint64(dynamic_param_mask(m, prog)), _ptr(gq), _ptr(gqd), _ptr(gx), _ptr(gops)) == 0
     rtol = FD_GRAD_RTOL[case]
     assert grad_close(-gq, g[case + "/grad_q"], rtol), np.abs(-gq - g[case + "/grad_q"]).max()
     assert grad_close(-gqd, g[case + "/grad_qd"], rtol)

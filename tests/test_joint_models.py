@@ -444,21 +444,21 @@ def test_emu_input_gradients_through_sliding_and_skew_joints_vs_oracle_differenc
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
     gq = np.full((B, n), np.nan, np.float32)
     gpos = f32(W["pos"].reshape(B, 1, 3))
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(0), _ptr(gq), None) == 0
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint64(0), _ptr(gq), None) == 0
     pos_only = _fd_inputs(m._spec, tip, q, qd, qdd, dict(W, quat=np.zeros((B, 4))))[0, 0]
     assert _grad_close(gq, pos_only, 1e-4), np.abs(gq - pos_only).max()
     gq = np.full((B, n), np.nan, np.float32)
     zero = np.zeros((B, 3), np.float32)
     glin, gang = f32(W["lin"]), f32(W["ang"])
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(zero), _ptr(glin), _ptr(gang),
-                                        ctypes.c_uint32(0), _ptr(gq), None) == 0
+                                        ctypes.c_uint64(0), _ptr(gq), None) == 0
     assert _grad_close(gq, ref[1, 0], 1e-4), np.abs(gq - ref[1, 0]).max()
     tree = build_walk(m._spec, whole_tree=True)
     twalk, _k2 = host_walk(m, tree)
     g3 = [np.full((B, n), np.nan, np.float32) for _ in range(3)]
     gtau = f32(W["tau"])
     assert emu.emu_rnea_backward(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
-                                 ctypes.c_uint32(0), _ptr(g3[0]), _ptr(g3[1]), _ptr(g3[2]), None) == 0
+                                 ctypes.c_uint64(0), _ptr(g3[0]), _ptr(g3[1]), _ptr(g3[2]), None) == 0
     for which in range(3):
         assert _grad_close(g3[which], ref[2, which], 1e-4), (which, np.abs(g3[which] - ref[2, which]).max())
 

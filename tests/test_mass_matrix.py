@@ -157,7 +157,7 @@ def test_emu_mass_matrix_backward_vs_reference_autograd(emu, case):
         gq, gqd, gqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
         gops = np.full((prog.capacity, 32), np.nan, np.float32)
         assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(zero), _ptr(unit), ctypes.c_int64(B), 0, _ptr(gt),
-                                     ctypes.c_uint32(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+                                     ctypes.c_uint64(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
         gq_sum += gq; gops_sum += gops
     assert grad_close(gq_sum, g[case + "/grad_q"], H_GRAD_RTOL), np.abs(gq_sum - g[case + "/grad_q"]).max()
     m.zero_grad()

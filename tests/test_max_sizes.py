@@ -144,7 +144,7 @@ def test_gpu_long_chain_backward_kernels_vs_emu(emu, tmp_path, n):
     mask = (1 << (prog.n_ops - 1)) | (1 << 3)
     gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
     assert emu.emu_fk_jacobian_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(gpos), _ptr(glin), _ptr(gang),
-                                        ctypes.c_uint32(mask), _ptr(gq), _ptr(gops)) == 0
+                                        ctypes.c_uint64(mask), _ptr(gq), _ptr(gops)) == 0
     dw = m._get_walk(("chain", tip), targets=[tip])
     got_q, got_ops = backend.fk_jacobian_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos), dev(glin), dev(gang),
                                                   n, mask, True)
@@ -152,7 +152,7 @@ def test_gpu_long_chain_backward_kernels_vs_emu(emu, tmp_path, n):
     assert np.abs(got_ops.cpu().numpy() - gops).max() <= 2e-4 * max(np.abs(gops).max(), 1e-6)
     # positions only (K5) and the RNEA backward (K7) over the whole tree
     got_q, _ = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos).reshape(B, 1, 3), 1, n, 0, True)
-    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint32(0), _ptr(gq), None) == 0
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint64(0), _ptr(gq), None) == 0
     assert np.allclose(got_q.cpu().numpy(), gq, atol=1e-4, rtol=1e-4)
     tree = build_walk(mc._spec, whole_tree=True)
     twalk, _keep2 = host_walk(mc, tree)
@@ -161,7 +161,7 @@ def test_gpu_long_chain_backward_kernels_vs_emu(emu, tmp_path, n):
     eops = np.full((tree.capacity, 32), np.nan, np.float32)
     tmask = (1 << 2) | (1 << (tree.n_ops - 2))
     assert emu.emu_rnea_backward(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
-                                 ctypes.c_uint32(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops)) == 0
+                                 ctypes.c_uint64(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops)) == 0
     dt = m._get_walk(("tree",), whole_tree=True)
     gin, gops_t = backend.rnea_backward(dt.program, m._ops_f(dt), dt.ops_i, dev(q), dev(qd), dev(qdd), dev(gtau), True, True,
                                         n, tmask, True)
@@ -191,9 +191,9 @@ def test_gpu_random_robot_backward_kernels_vs_emu(emu, seed):
     if prog.slots_unique:
         walk, _k = host_walk(mc, prog)
         gpos = rng.standard_normal((B, T, 3)).astype(np.float32)
-        mask = int(rng.integers(0, 1 << prog.n_ops)) & 0xffffffff
+        mask = int(rng.integers(0, 1 << prog.n_ops))
         gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
-        assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint32(mask),
+        assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), T, _ptr(gpos), ctypes.c_uint64(mask),
                                    _ptr(gq), _ptr(gops) if mask else None) == 0
         dw = m._get_walk(("fk", tuple(targets)), targets=targets)
         got_q, got_ops = backend.fk_backward(dw.program, m._ops_f(dw), dw.ops_i, dev(q), dev(gpos), T, n, mask, True)
@@ -207,7 +207,7 @@ def test_gpu_random_robot_backward_kernels_vs_emu(emu, seed):
     gp, gl, ga = (rng.standard_normal(s).astype(np.float32) for s in ((B, 3), (B, 3, n), (B, 3, n)))
     gq = np.full((B, n), np.nan, np.float32)
     assert emu.emu_fk_jacobian_backward(ctypes.byref(cwalk), _ptr(q), ctypes.c_int64(B), _ptr(gp), _ptr(gl), _ptr(ga),
-                                        ctypes.c_uint32(0), _ptr(gq), None) == 0
+                                        ctypes.c_uint64(0), _ptr(gq), None) == 0
     dc = m._get_walk(("chain", link), targets=[link])
     got_q, _ = backend.fk_jacobian_backward(dc.program, m._ops_f(dc), dc.ops_i, dev(q), dev(gp), dev(gl), dev(ga), n, 0, True)
     assert np.abs(got_q.cpu().numpy() - gq).max() <= 1e-4 * max(1.0, np.abs(gq).max()), (robot, B, link)
@@ -216,11 +216,11 @@ def test_gpu_random_robot_backward_kernels_vs_emu(emu, seed):
     if tree.slots_unique:
         twalk, _k3 = host_walk(mc, tree)
         gtau = rng.standard_normal((B, n)).astype(np.float32)
-        tmask = int(rng.integers(0, 1 << min(tree.n_ops, 31)))
+        tmask = int(rng.integers(0, 1 << min(tree.n_ops, 63)))
         eq, eqd, eqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
         eops = np.full((tree.capacity, 32), np.nan, np.float32)
         assert emu.emu_rnea_backward(ctypes.byref(twalk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
-                                     ctypes.c_uint32(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops) if tmask else None) == 0
+                                     ctypes.c_uint64(tmask), _ptr(eq), _ptr(eqd), _ptr(eqdd), _ptr(eops) if tmask else None) == 0
         dt = m._get_walk(("tree",), whole_tree=True)
         gin, gops_t = backend.rnea_backward(dt.program, m._ops_f(dt), dt.ops_i, dev(q), dev(qd), dev(qdd), dev(gtau), True, True,
                                             n, tmask, True)
@@ -228,3 +228,89 @@ def test_gpu_random_robot_backward_kernels_vs_emu(emu, seed):
             assert np.abs(got.cpu().numpy() - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1.0), (robot, B)
         if tmask:
             assert np.abs(gops_t.cpu().numpy() - eops).max() <= 1e-3 * max(np.abs(eops).max(), 1e-6) * max(1.0, B / 256)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A learnable link BEYOND op 32 (the backward kernels' param_mask is 64 bits wide: ABI 7; a 32-bit mask silently aliased
+# op k to op k - 32).  Yardstick: central differences of the fp64 oracle on the perturbed robot description.
+# ---------------------------------------------------------------------------------------------------------------------
+def _chain45_losses(spec, tip, q64, qd64, qdd64, Wp, Wt):
+    orc = Oracle(spec)
+    pos, _ = orc.fk(q64, [tip], np.float64)
+    tau = orc.rnea(q64, qd64, qdd64, True, True, np.float64)
+    return float((Wp * pos[:, 0]).sum()), float((Wt * tau).sum())
+
+
+def _chain45_fd(spec, link, field, tip, args, Wp, Wt, h=1e-3):
+    import dataclasses
+    arr = np.asarray(getattr(spec, field), np.float32)
+    row = arr[link].reshape(-1)
+    g = np.zeros((2, row.size))
+    for e in range(row.size):
+        vals = []
+        for sgn in (+1, -1):
+            a2 = arr.copy()
+            a2.reshape(arr.shape[0], -1)[link, e] = np.float32(row[e] + sgn * h)
+            vals.append((float(a2.reshape(arr.shape[0], -1)[link, e]),
+                         _chain45_losses(dataclasses.replace(spec, **{field: a2}), tip, *args, Wp, Wt)))
+        for j in range(2):
+            g[j, e] = (vals[0][1][j] - vals[1][1][j]) / (vals[0][0] - vals[1][0])
+    return g
+
+
+@pytest.mark.gpu
+def test_gpu_learnable_link_beyond_op_32_vs_oracle_differences(tmp_path):
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedScalar, UnconstrainedTensor
+    m = chain_model(tmp_path, 45, "cuda")
+    spec, tip, n, B = m._spec, len(m._bodies) - 1, 45, 6
+    link = m._name_to_idx_map["link40"]
+    t_mod = UnconstrainedTensor(1, 3, init_tensor=torch.from_numpy(np.asarray(spec.trans[link], np.float32).reshape(1, 3).copy()))
+    m_mod = UnconstrainedScalar(init_val=float(spec.mass[link]))
+    m.make_link_param_learnable("link40", "trans", t_mod)
+    m.make_link_param_learnable("link40", "mass", m_mod)
+    dw = m._dynamics_walk()
+    mask = m._learnable_op_mask(dw)
+    assert mask and mask >> 32, "the learnable link must sit beyond op 32 for this test to mean anything (mask %x)" % mask
+    q, qd, qdd = sample_states(m, B, seed=77)
+    rng = np.random.default_rng(5)
+    Wp, Wt = rng.standard_normal((B, 3)), rng.standard_normal((B, n))
+    args = [a.astype(np.float64) for a in (q, qd, qdd)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    pos, _ = m.compute_forward_kinematics(dev(q), "tip")
+    loss_p = (dev(Wp) * pos).sum()
+    loss_p.backward()
+    g_trans_pos = t_mod.param.grad.cpu().numpy().reshape(-1).copy()
+    m.zero_grad()
+    tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
+    loss_t = (dev(Wt) * tau).sum()
+    loss_t.backward()
+    g_trans_tau = t_mod.param.grad.cpu().numpy().reshape(-1).copy()
+    g_mass_tau = m_mod.param.grad.cpu().numpy().reshape(-1).copy()
+    want = _chain45_losses(spec, tip, *args, Wp, Wt)
+    assert abs(loss_p.item() - want[0]) <= 2e-4 * max(1.0, abs(want[0])) and abs(loss_t.item() - want[1]) <= 2e-3 * max(1.0, abs(want[1]))
+    fd_t = _chain45_fd(spec, link, "trans", tip, args, Wp, Wt)
+    fd_m = _chain45_fd(spec, link, "mass", tip, args, Wp, Wt)
+    close = lambda got, ref: np.abs(got - ref).max() <= 5e-3 * max(np.abs(ref).max(), 5e-3)
+    assert np.abs(fd_t[0]).max() > 1e-2 and np.abs(fd_m[1]).max() > 1e-2          # the gradients are not trivially zero
+    assert close(g_trans_pos, fd_t[0]), (g_trans_pos, fd_t[0])
+    assert close(g_trans_tau, fd_t[1]), (g_trans_tau, fd_t[1])
+    assert close(g_mass_tau, fd_m[1]), (g_mass_tau, fd_m[1])
+
+
+def test_emu_learnable_op_beyond_32_gets_its_own_gradient(emu, tmp_path):
+    """CPU: the host emulation of K5 with ONLY bit 40 of the mask set writes the constant gradient of op 40 and nothing
+    into op 8 (= 40 - 32, where a 32-bit shift would have landed) or any other row."""
+    m = chain_model(tmp_path, 45)
+    spec, tip, n, B = m._spec, len(m._bodies) - 1, 45, 4
+    prog = build_walk(spec, targets=[tip])
+    walk, _keep = host_walk(m, prog)
+    k = 40
+    q, qd, qdd = sample_states(m, B, seed=78)
+    rng = np.random.default_rng(6)
+    gpos = rng.standard_normal((B, 1, 3)).astype(np.float32)
+    gq = np.full((B, n), np.nan, np.float32); gops = np.full((prog.capacity, 32), np.nan, np.float32)
+    assert emu.emu_fk_backward(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), 1, _ptr(gpos), ctypes.c_uint64(1 << k),
+                               _ptr(gq), _ptr(gops)) == 0
+    assert np.abs(gops[k]).max() > 1e-3 and np.abs(gops[k - 32]).max() == 0.0
+    rows = [r for r in range(prog.capacity) if r != k]
+    assert np.abs(gops[rows]).max() == 0.0

@@ -88,7 +88,7 @@ def emu_loss_and_grads(emu, m, q, qd, qdd, want):
     gops = np.full((prog.capacity, 32), np.nan, np.float32)
     mask = dynamic_param_mask(m, prog)
     assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), 3, _ptr(gtau),
-                                 ctypes.c_uint32(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+                                 ctypes.c_uint64(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
     m.zero_grad()
     ops_f_t.backward(torch.from_numpy(gops))
     return loss, tau, gq, gqd, gqdd
@@ -127,7 +127,7 @@ def test_emu_arm_chain_backward_equals_generic_walk(emu, robot, flags):
         gq, gqd, gqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
         gops = np.full((prog.capacity, 32), np.nan, np.float32)
         assert getattr(emu, name)(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(gtau),
-                                  ctypes.c_uint32(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+                                  ctypes.c_uint64(mask), _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
         out[name] = (gq, gqd, gqdd, gops)
     for a, b in zip(out["emu_rnea_backward"], out["emu_rnea_backward_arm"]):
         assert close(b, a, 2e-4), np.abs(a - b).max()

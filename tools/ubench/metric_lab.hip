@@ -450,6 +450,23 @@ static void time_graph(const char *name, F launch, hipStream_t s, int K = 200) {
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
 }
 
+template <class F>
+static void time_eager(const char *name, F launch, hipStream_t s, int K = 200) {
+    for (int i = 0; i < 10; ++i) launch();
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> us;
+    for (int rep = 0; rep < 9; ++rep) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < K; ++i) launch();
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us.push_back(ms * 1e3f / K);
+    }
+    std::sort(us.begin(), us.end());
+    printf("EAGER %-43s min %6.3f  med %6.3f  max %6.3f us/launch\n", name, us.front(), us[us.size() / 2], us.back());
+}
+
 struct Host { std::vector<float> pos, quat, lin, ang; };
 static Host fetch(const Buffers &b) {
     Host h;
@@ -536,8 +553,23 @@ int main(int argc, char **argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device %s, %d CUs, clock %d kHz, B = %d\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, B);
 
-    // ---- launch floors
     float *dummy; CK(hipMalloc(&dummy, 4096));
+    if (argc > 2 && !strcmp(argv[2], "overhead")) {
+        // `metric_lab B overhead`: THREE kernels only — nothing / the bytes only / the product kernel — each timed here with
+        // HIP events (graph of 200, and 200 eager launches), so that the SAME process run under
+        // `rocprofv3 --kernel-trace --stats` shows what the tracer reports for a kernel whose true duration is known.
+        auto empty = [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(n_tiles), dim3(64), 0, s, dummy); };
+        auto io = [&] { hipLaunchKernelGGL((k_io<ST_SC1, true, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang); };
+        auto prod = [&] { launch_fk_jacobian_arm(b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang, s); };
+        time_graph("overhead: empty (n_tiles blocks x 64)", empty, s);
+        time_graph("overhead: io sc1 rd+wr", io, s);
+        time_graph("overhead: product kernel", prod, s);
+        time_eager("overhead: empty (n_tiles blocks x 64)", empty, s);
+        time_eager("overhead: io sc1 rd+wr", io, s);
+        time_eager("overhead: product kernel", prod, s);
+        return 0;
+    }
+    // ---- launch floors
     time_graph("empty 256 blocks x 256", [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(256), dim3(256), 0, s, dummy); }, s);
     time_graph("empty 1024 blocks x 256", [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(1024), dim3(256), 0, s, dummy); }, s);
     time_graph("empty 256 blocks x 1024", [&] { hipLaunchKernelGGL((k_empty<1024, 0>), dim3(256), dim3(1024), 0, s, dummy); }, s);
