@@ -69,7 +69,20 @@ def parse_args(argv=None):
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
-    return ap.parse_args(argv)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 path: nccl (= RCCL over xGMI, the product path) or gloo "
+                         "(collectives staged through the host; what lets N ranks share ONE GPU, see --shared-gpu)")
+    ap.add_argument("--shared-gpu", action="store_true", default=os.environ.get("DRM_BENCH_SHARED_GPU") == "1",
+                    help="TEST MODE (also DRM_BENCH_SHARED_GPU=1): the N ranks share the visible GPU(s) round-robin instead of "
+                         "owning one each, so that every line of the multi-rank path runs on a 1-GPU box.  Implies "
+                         "--backend gloo (RCCL refuses two ranks on one device); the JSON line says so and is not a scaling number")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the timed region, rank 0 recomputes ALL ranks' rows in one single-rank launch and compares the "
+                         "gathered buffer with it bit for bit (gather_verified in the JSON line)")
+    args = ap.parse_args(argv)
+    if args.shared_gpu:
+        args.backend = "gloo"
+    return args
 
 
 def respawn_if_needed(args):
@@ -79,7 +92,7 @@ def respawn_if_needed(args):
         return
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.shared_gpu and have >= 1):
         sys.exit("bench.py: --gpus %d requested but this node exposes %d HIP device(s); refusing to report a "
                  "%d-GPU number from fewer GPUs" % (args.gpus, have, args.gpus))
     from differentiable_robot_model_amd.distributed import torchrun_command
@@ -231,19 +244,25 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU compute path)")
-    if local_rank >= torch.cuda.device_count():
-        sys.exit("bench.py: rank %d has no GPU (node exposes %d)" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and not args.shared_gpu:
+        sys.exit("bench.py: rank %d has no GPU (node exposes %d)" % (local_rank, n_dev))
+    dev_index = local_rank % n_dev if args.shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
-        probe = torch.ones(1, device=device)
-        dist.all_reduce(probe)                                     # every rank answers over RCCL before anything is timed
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+            probe = torch.ones(1, device=device)
+        else:
+            dist.init_process_group(backend="gloo")
+            probe = torch.ones(1)
+        dist.all_reduce(probe)                                     # every rank answers before anything is timed
         ranks_seen = int(probe.item())
         if ranks_seen != world or dist.get_world_size() != world:
-            sys.exit("bench.py: RCCL sees %d ranks, expected %d" % (ranks_seen, world))
+            sys.exit("bench.py: %s sees %d ranks, expected %d" % (args.backend, ranks_seen, world))
 
     import contextlib
     import io
@@ -261,7 +280,7 @@ def main():
             dist.barrier()
 
     def reduce_max(vals):
-        t = torch.tensor(vals, device=device, dtype=torch.float64)
+        t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
@@ -279,7 +298,8 @@ def main():
 
 def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max):
     import torch
-    import torch.distributed as dist
+
+    from differentiable_robot_model_amd.distributed import all_gather_flat
     n, B, K, W = model._n_dofs, args.batch, args.steps, args.warmup
     q, _ = sample_q(model, B, device, 1234 + rank)
     plan = model.plan_fk_and_jacobian(q, link)
@@ -291,7 +311,7 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         plan.launch()
         if gathered is not None:
             for out, loc in zip(gathered, plan.outputs()):
-                dist.all_gather_into_tensor(out, loc)
+                all_gather_flat(out, loc)
 
     for _ in range(W):
         step()
@@ -299,6 +319,18 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
     wall, dev_time, graphed = timed_graph_region(step, K, stream, barrier, use_graph=not args.no_graph and gathered is None)
     wall, dev_time = reduce_max([wall, dev_time])
 
+    verified = None
+    if args.verify_gather and gathered is not None:
+        step()
+        torch.cuda.synchronize()
+        ok = 1
+        if rank == 0:   # every rank's q again (same seeds), ONE single-rank launch over all rows, bit-for-bit comparison
+            whole = model.plan_fk_and_jacobian(torch.cat([sample_q(model, B, device, 1234 + r)[0] for r in range(world)]), link)
+            whole.launch()
+            torch.cuda.synchronize()
+            for got, want in zip(gathered, whole.outputs()):
+                ok &= int(torch.equal(got, want))
+        verified = bool(ok)
     bytes_per_eval = 4 * (n + 7 + 6 * n)            # q in; pos, quat, lin_jac, ang_jac out
     launch_s = dev_time / K                         # average duration of one launch, HIP events on the launch stream
     achieved = bytes_per_eval * B / launch_s / 1e9
@@ -307,13 +339,15 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         "metric": "FK+Jacobian evals/sec, Panda 7-DoF, batch=65 536 @1/2/4/8 MI355X",
         "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen,
+        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "gather_verified": verified,
+        "distributed": test_mode_fields(args, world),
         "config": {"workload": "Franka Panda 7-DoF (panda_no_gripper), FK + end-effector geometric Jacobian to "
                                "panda_virtual_ee_link, batch=%d per GPU, q~U(joint limits), inputs resident in HBM"
                                % B if args.robot == "panda_no_gripper" else "%s FK+Jacobian batch=%d" % (args.robot, B),
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": "batch-sharded x%d" % world,
                    "launch": "hipGraph of K launches (replayed twice untimed first)" if graphed else "eager launches",
-                   "gather": bool(gathered is not None)},
+                   "gather": bool(gathered is not None),
+                   "gather_bytes_per_rank": B * 4 * (7 + 6 * n) if gathered is not None else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
@@ -383,20 +417,39 @@ def roofline_large(model, link, device, stream, bytes_per_eval):
     return out
 
 
+def config3_inputs(model, rows, device, seed):
+    """q ~ U(limits), qd ~ U(+-0.2 vmax), qdd ~ U(+-0.4 vmax): the distribution of data_utils.py:70-98, resident in HBM."""
+    import torch
+    n = model._n_dofs
+    q, gen = sample_q(model, rows, device, seed)
+    vmax = torch.tensor([j["velocity"] for j in model.get_joint_limits()], device=device)
+    qd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()
+    qdd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
+    return q, qd, qdd
+
+
+def test_mode_fields(args, world):
+    import torch
+    out = {"backend": args.backend if world > 1 else None}
+    if args.shared_gpu and world > 1:
+        out["shared_gpu"] = True
+        out["devices_used"] = min(world, torch.cuda.device_count())
+        out["note"] = ("TEST MODE: %d ranks share %d device(s), collectives staged through the host by gloo — this line "
+                       "exercises the multi-rank code path and is NOT a scaling measurement" % (world, out["devices_used"]))
+    return out
+
+
 def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max, shard_bounds):
     """BASELINE configuration 3: global batch 2^20 sharded by rows, FK(EE) + RNEA per shard (one fused launch), one RCCL
     all-gather of tau | pos | quat per step."""
     import torch
-    import torch.distributed as dist
+
+    from differentiable_robot_model_amd.distributed import all_gather_flat
     n, K, W = model._n_dofs, args.steps, args.warmup
     G = CONFIG3_GLOBAL_BATCH
     lo, hi = shard_bounds(G, world, rank)
     rows = hi - lo
-    q, gen = sample_q(model, rows, device, 4321 + rank)
-    lim = model.get_joint_limits()
-    vmax = torch.tensor([j["velocity"] for j in lim], device=device)
-    qd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()   # data_utils.py:70-98
-    qdd = ((torch.rand(rows, n, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
+    q, qd, qdd = config3_inputs(model, rows, device, 4321 + rank)
     # tau | pos | quat of a shard live in ONE allocation (three contiguous blocks), so the collective sends the kernel's own
     # output buffer: no packing kernel between the launch and the all-gather
     width = n + 3 + 4                                                    # 56 B per row
@@ -412,7 +465,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
 
     def exchange():
         if world > 1:
-            dist.all_gather_into_tensor(gathered, flat)   # rank r's blocks at gathered[r * rows * width:]
+            all_gather_flat(gathered, flat)               # rank r's blocks at gathered[r * rows * width:]
 
     def step():
         compute()
@@ -425,6 +478,27 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     _, dev_compute, _ = timed_graph_region(compute, K, stream, barrier, use_graph=not args.no_graph)
     wall, dev_time, _ = timed_graph_region(step, K, stream, barrier, use_graph=False)
     wall, dev_time, dev_compute = reduce_max([wall, dev_time, dev_compute])
+    verified = None
+    if args.verify_gather and world > 1:
+        # rank 0 rebuilds EVERY rank's inputs (same seeds), runs them as ONE single-rank launch over all 2^20 rows and holds
+        # the gathered buffer to it bit for bit: rank r's tau | pos | quat blocks at gathered[r * rows * width:]
+        step()
+        torch.cuda.synchronize()
+        ok = 1
+        if rank == 0:
+            parts = [config3_inputs(model, rows, device, 4321 + r) for r in range(world)]
+            qa, qda, qdda = (torch.cat([p[i] for p in parts]) for i in range(3))
+            whole = model.plan_fk_and_inverse_dynamics(qa, qda, qdda, link)
+            whole.launch()
+            torch.cuda.synchronize()
+            tau_w, pos_w, quat_w = whole.outputs()
+            for r in range(world):
+                blk = gathered[r * rows * width:(r + 1) * rows * width]
+                sl = slice(r * rows, (r + 1) * rows)
+                ok &= int(torch.equal(blk[:rows * n].view(rows, n), tau_w[sl]))
+                ok &= int(torch.equal(blk[rows * n:rows * (n + 3)].view(rows, 3), pos_w[sl].reshape(rows, 3)))
+                ok &= int(torch.equal(blk[rows * (n + 3):].view(rows, 4), quat_w[sl].reshape(rows, 4)))
+        verified = bool(ok)
     bytes_per_eval = 4 * (3 * n + n + 7)                                 # q qd qdd in; tau pos quat out = 140 B
     launch_s = dev_compute / K
     achieved = bytes_per_eval * rows / launch_s / 1e9
@@ -432,7 +506,8 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         "metric": "FK + RNEA evals/sec, Panda 7-DoF, global batch 2^20 sharded over the GPUs (BASELINE.json configuration 3)",
         "value": G * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen,
+        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "gather_verified": verified,
+        "distributed": test_mode_fields(args, world),
         "config": {"workload": "Franka Panda 7-DoF, FK(panda_virtual_ee_link) + RNEA inverse dynamics (gravity, damping), "
                                "global batch %d = %d rows per GPU, q~U(limits), qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); "
                                "one fused drm_fk_rnea launch + one all_gather_into_tensor of its output buffer (tau|pos|quat blocks) per step" % (G, rows),

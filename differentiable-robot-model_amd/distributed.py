@@ -54,6 +54,26 @@ def all_gather_rows(local: torch.Tensor, batch: int, group=None) -> torch.Tensor
     return torch.cat([out[r, :sizes[r]] for r in range(world)], dim=0)
 
 
+_host_stage = {}
+
+
+def all_gather_flat(out: torch.Tensor, local: torch.Tensor, group=None) -> None:
+    """`all_gather_into_tensor(out, local)` for equal-sized contiguous shards, whatever the backend: RCCL ("nccl") moves
+    the device buffers themselves over xGMI; under gloo (CPU tests, or N ranks sharing one GPU in bench.py's test mode)
+    device tensors are staged through pinned host buffers, because gloo's collectives run on the host."""
+    if dist.get_backend(group) != "gloo" or not local.is_cuda:
+        dist.all_gather_into_tensor(out, local, group=group)
+        return
+    key = (out.numel(), local.numel(), local.dtype)
+    if key not in _host_stage:
+        _host_stage[key] = (torch.empty(out.numel(), dtype=local.dtype).pin_memory(),
+                            torch.empty(local.numel(), dtype=local.dtype).pin_memory())
+    h_out, h_loc = _host_stage[key]
+    h_loc.copy_(local.reshape(-1), non_blocking=False)
+    dist.all_gather_into_tensor(h_out, h_loc, group=group)
+    out.reshape(-1).copy_(h_out, non_blocking=False)
+
+
 def gather_outputs(outputs: Sequence[torch.Tensor], batch: int, group=None) -> List[torch.Tensor]:
     return [all_gather_rows(t, batch, group) for t in outputs]
 
