@@ -92,7 +92,14 @@ class URDF:
 
     @classmethod
     def from_xml_file(cls, path):
-        root = ET.parse(path).getroot()
+        try:
+            root = ET.parse(path).getroot()
+        except ET.ParseError:
+            # fetch.urdf carries an undeclared "sensor:" namespace prefix inside a <gazebo> block (the real urdf_parser_py
+            # reads it through lxml's recovering parser); neutralise prefixes — <gazebo> content is never looked at
+            import re
+            with open(path) as f:
+                root = ET.fromstring(re.sub(r"<(/?)([A-Za-z_][\w.-]*):", r"<\1\2_", f.read()))
         robot = cls()
         robot.name = root.get("name", "")
         robot.links = [_Link(n) for n in root.findall("link")]

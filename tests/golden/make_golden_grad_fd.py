@@ -31,7 +31,23 @@ CASES = [
      {"panda_link3": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "panda_link6": ["mass", "joint_damping"]}, 21),
     ("trifinger_edu", "trifinger_edu_description/trifinger_edu.urdf",
      {"finger_middle_link_120": ["mass", "com", "inertia_mat", "trans", "rot_angles", "joint_damping"]}, 9),
+    # round 3: robots with one long segment — forward dynamics runs the articulated-body kernel there and its gradient the
+    # implicit differentiation through it (lambda = H^-1 g by the same kernel, then the RNEA backward); see make_golden_grad_dyn.py
+    ("fetch", "fetch_description/urdf/fetch.urdf",
+     {"shoulder_lift_link": ["mass", "com", "inertia_mat", "trans", "rot_angles", "joint_damping"],
+      "r_gripper_finger_link": ["mass", "com"]}, 8),
+    ("jaco", "kinova_description/urdf/jaco.urdf",
+     {"j2n6s300_link_3": ["mass", "com", "inertia_mat", "trans", "rot_angles", "joint_damping"],
+      "j2n6s300_link_finger_tip_2": ["mass", "com"]}, 8),
+    ("panda", "panda_description/urdf/panda.urdf",
+     {"panda_link4": ["mass", "com", "inertia_mat", "trans", "rot_angles", "joint_damping"],
+      "panda_leftfinger": ["mass", "com"]}, 9),
+    ("iiwa7_allegro", "kuka_iiwa/urdf/iiwa7_allegro.urdf",
+     {"iiwa_link_3": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "link_13.0": ["mass", "com", "joint_damping"]}, 6),
 ]
+
+
+WELL_SCALED = ("fetch", "jaco", "panda", "iiwa7_allegro")
 
 
 def parametrization(rbp, pname, case):
@@ -67,7 +83,16 @@ def main():
         mk = lambda a: torch.tensor(a, dtype=torch.float32, requires_grad=True)
         q = mk(np.random.uniform(lo, hi, size=(B, n)))
         qd = mk(np.random.uniform(-1.0, 1.0, size=(B, n)))
-        f = mk(np.random.uniform(-2.0, 2.0, size=(B, n)))
+        if name in WELL_SCALED:
+            # torques that produce accelerations of order one: the inverse dynamics of the ground-truth model for
+            # qdd ~ U(-2, 2) (random torques of +-2 Nm throw a 10 g fingertip link to 1e5 rad/s^2, where an fp32 gradient —
+            # the reference's included — is rounding noise); the loss comes from the learnable model's random parameters
+            with torch.no_grad():
+                qdd0 = torch.tensor(np.random.uniform(-2.0, 2.0, size=(B, n)), dtype=torch.float32)
+                f0 = gt.compute_inverse_dynamics(q.detach(), qd.detach(), qdd0, include_gravity=True, use_damping=True)
+            f = mk(f0.numpy().copy())
+        else:
+            f = mk(np.random.uniform(-2.0, 2.0, size=(B, n)))
         with torch.no_grad():
             # the reference subtracts the damping torques from its `f` argument in place (robot_model.py:515-521)
             want = gt.compute_forward_dynamics(q.detach(), qd.detach(), f.detach().clone(), include_gravity=True, use_damping=True)

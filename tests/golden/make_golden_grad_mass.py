@@ -24,6 +24,15 @@ CASES = [
      {"panda_link3": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "panda_link6": ["mass"]}, 9),
     ("trifinger_edu", "trifinger_edu_description/trifinger_edu.urdf",
      {"finger_middle_link_120": ["mass", "com", "inertia_mat", "trans", "rot_angles"]}, 5),
+    # round 3: robots with one long segment (persistent kernels, HBM-parked records); see make_golden_grad_dyn.py
+    ("fetch", "fetch_description/urdf/fetch.urdf",
+     {"shoulder_lift_link": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "r_gripper_finger_link": ["mass"]}, 4),
+    ("jaco", "kinova_description/urdf/jaco.urdf",
+     {"j2n6s300_link_3": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "j2n6s300_link_finger_tip_2": ["mass", "com"]}, 4),
+    ("panda", "panda_description/urdf/panda.urdf",
+     {"panda_link4": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "panda_leftfinger": ["mass", "com"]}, 5),
+    ("iiwa7_allegro", "kuka_iiwa/urdf/iiwa7_allegro.urdf",
+     {"iiwa_link_3": ["mass", "com", "inertia_mat", "trans", "rot_angles"], "link_13.0": ["mass", "com"]}, 3),
 ]
 
 

@@ -68,12 +68,31 @@ def sample_states(model, B, seed=0, vel=1.0, acc=2.0):
     return q, qd, qdd
 
 
-def quat_close(a, b, atol):
-    """Quaternions agree, allowing the global sign flip that fp32 rounding can trigger at the
-    branch boundaries of the reference's algorithm (spatial_vector_algebra.py:117-128)."""
+def quat_branch_margin(b):
+    """Distance of a rotation (given as the reference quaternion b = xyzw) from the nearest case boundary that the
+    reference's get_quaternion actually evaluates for it (spatial_vector_algebra.py:117-128): tr R = 0 first; in the
+    else-branch the diagonal comparisons R11 > R00 and R22 > R_ii.  From b alone: tr R = 4 w^2 - 1, R00 = 1 - 2 (y^2 + z^2), ..."""
+    b = np.asarray(b, np.float64)
+    b = b / np.linalg.norm(b, axis=-1, keepdims=True)
+    x, y, z, w = (b[..., i] for i in range(4))
+    tr = 4.0 * w * w - 1.0
+    d = np.stack([1 - 2 * (y * y + z * z), 1 - 2 * (x * x + z * z), 1 - 2 * (x * x + y * y)], -1)
+    m01 = np.abs(d[..., 1] - d[..., 0])
+    dii = np.maximum(d[..., 0], d[..., 1])
+    m2 = np.abs(d[..., 2] - dii)
+    return np.where(tr > 0, np.abs(tr), np.minimum(np.abs(tr), np.minimum(m01, m2)))
+
+
+def quat_close(a, b, atol, margin=1e-5):
+    """Quaternions agree WITH THE REFERENCE'S SIGN (the sign is part of the reference's output: its case rule makes one
+    component positive) on every row whose rotation is further than `margin` from a case boundary of
+    spatial_vector_algebra.py:117-128; on rows within the margin (fp32 rounding of R is ~3e-7, so either case is a correct
+    answer there) the global sign may differ.  Returns (ok, number of sign flips) — flips can only be rows within the margin."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    near = (quat_branch_margin(b) <= margin)[..., None]
     sgn = np.sign((a * b).sum(-1, keepdims=True))
     sgn[sgn == 0] = 1.0
+    sgn = np.where(near, sgn, 1.0)
     return np.abs(a * sgn - b).max() <= atol, int((sgn < 0).sum())
 
 

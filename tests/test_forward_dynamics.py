@@ -140,8 +140,16 @@ def test_gpu_forward_dynamics_inverts_inverse_dynamics_full_size():
 # reference's articulated-body recursion (tests/golden/golden_grad_fd.npz, made by tests/golden/make_golden_grad_fd.py).
 # Tolerance: relative to the largest entry of each gradient tensor; the gradient carries cond(H) twice (two solves).
 # ---------------------------------------------------------------------------------------------------------------
-FD_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu"]
-FD_GRAD_RTOL = {"iiwa7": 2e-3, "panda_no_gripper": 2e-3, "trifinger_edu": 1e-2}
+FD_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu", "fetch", "jaco", "panda", "iiwa7_allegro"]
+FD_GRAD_RTOL = {"iiwa7": 2e-3, "panda_no_gripper": 2e-3, "trifinger_edu": 1e-2, "fetch": 1e-2, "jaco": 1e-2, "panda": 2e-3,
+                "iiwa7_allegro": 1e-2}
+
+
+# forward value of the PERTURBED robot (the learnable link's trans / com / inertia start from random values, which leaves a
+# gram-scale finger or a gripper behind a badly placed link): two fp32 evaluations of that system — the reference's and
+# the kernel's — differ by up to 5e-3 relative on single entries; neither is the yardstick, the gradients below are held
+# to FD_GRAD_RTOL of their largest entry all the same
+FD_GRAD_FWD_TOL = {"fetch": 1e-2, "jaco": 1e-2, "iiwa7_allegro": 1e-2}
 
 
 def load_golden_grad_fd():
@@ -187,7 +195,7 @@ def test_emu_forward_dynamics_backward_vs_reference_autograd(emu, case):
     B, n = q.shape
     qdd = np.zeros((B, n), np.float32)
     assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), 3, _ptr(qdd)) == 0
-    assert rel_err(qdd, g[case + "/qdd"]) <= tol_of(case)
+    assert rel_err(qdd, g[case + "/qdd"]) <= FD_GRAD_FWD_TOL.get(case, tol_of(case))
     gqdd = np.ascontiguousarray(2.0 * (qdd - want) / (B * n), np.float32)
     lam, zero = np.zeros((B, n), np.float32), np.zeros((B, n), np.float32)
     assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(zero), _ptr(gqdd), ctypes.c_int64(B), 0, _ptr(lam)) == 0
@@ -217,7 +225,7 @@ def test_gpu_forward_dynamics_backward_vs_reference_autograd(case):
     loss = torch.nn.functional.mse_loss(qdd, want)
     loss.backward()
     rtol = FD_GRAD_RTOL[case]
-    assert abs(loss.item() - float(g[case + "/loss"])) <= 2 * tol_of(case) * max(1.0, float(g[case + "/loss"]))
+    assert abs(loss.item() - float(g[case + "/loss"])) <= 2 * FD_GRAD_FWD_TOL.get(case, tol_of(case)) * max(1.0, float(g[case + "/loss"]))
     assert grad_close(q.grad.cpu().numpy(), g[case + "/grad_q"], rtol)
     assert grad_close(qd.grad.cpu().numpy(), g[case + "/grad_qd"], rtol)
     assert grad_close(f.grad.cpu().numpy(), g[case + "/grad_f"], rtol)

@@ -119,7 +119,7 @@ def test_gpu_crba_full_size_consistent_with_rnea():
 # torch autograd through the reference's n + 1 inverse-dynamics construction (tests/golden/golden_grad_mass.npz,
 # made by tests/golden/make_golden_grad_mass.py).
 # ---------------------------------------------------------------------------------------------------------------
-H_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu"]
+H_GRAD_CASES = ["iiwa7", "panda_no_gripper", "trifinger_edu", "fetch", "jaco", "panda", "iiwa7_allegro"]
 H_GRAD_RTOL = 2e-3
 
 
