@@ -75,8 +75,95 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// The same launch with TWO SAMPLES PER LANE (drm_sample.hpp rnea_chain2_trig): a wavefront owns a tile of 128 consecutive
+// samples, lane l the rows l and l + 64 of it.  Every instruction of the recursion is a full packed-FP32 op; a third
+// fewer instructions per sample than rnea_arm_kernel.  One wavefront per block (the per-wave LDS is what bounds the
+// number of resident waves: constants 1 KB + (LINKS - 1) parked forces x 3 KB).
+//   q / qd / qdd: row l of the tile into the low halves, row l + 64 into the high halves of the register pairs (dword loads
+//   that share cache lines across the wave, as in the one-sample kernels); tau leaves through a [128][NJ] LDS image.
+// ---------------------------------------------------------------------------------------------------
+constexpr int TILE2 = 2 * WAVE;
+// Which form a launch takes.  Up to 1 024 64-sample tiles the one-sample kernels put one wave on every SIMD of the chip
+// (256 CUs x 4) and nothing is gained by halving the number of waves (65 536 samples: 5.3 us against 5.8 us, fused 6.2
+// against 7.3); beyond that the SIMDs hold several waves and the kernel with fewer instructions per sample wins
+// (131 072: 6.4 against 7.5 us, fused 7.7 against 8.5; 2^20: 32 against 38.5 us, fused 41 against 48.5; profiles/r03_ab_rnea_two_samples.txt).
+constexpr int TWO_SAMPLE_MIN_TILES = 1024;
+#ifndef DRM_RNEA2_WAVES
+#define DRM_RNEA2_WAVES 3
+#endif
+template <int CAP, int NJ, int LINKS>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_RNEA2_WAVES, DRM_RNEA2_WAVES))) rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                         const float *__restrict__ qd, const float *__restrict__ qdd, int n_tiles,
+                                                         int flags, float *__restrict__ tau) {
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - DRM_RNEA2_KEEP) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
+                  F_FLOATS = P_FLOATS > T_FLOATS ? P_FLOATS : T_FLOATS; // tau is staged over the parking area at the end
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + F_FLOATS];
+    const int tile = (int)blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    float *lc = smem, *lt = smem + C_FLOATS;
+    f2 *lf = reinterpret_cast<f2 *>(lt) + lane; // parked body forces: [link][6][64] pairs
+    const int64_t b0 = (int64_t)tile * TILE2;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    f2 qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+    {
+        const int64_t ra = (b0 + lane) * NJ, rb = ra + (int64_t)WAVE * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = f2_make(q[ra + d], q[rb + d]);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = f2_make(qd[ra + d], qd[rb + d]);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? f2_make(qdd[ra + d], qdd[rb + d]) : f2_bcast(0.0f);
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    f2 cs[NJ], sn[NJ];
+    chain_trig2<NJ>(qv, cs, sn);
+    rnea_chain2_trig<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                                flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+                                [&](int k, const Force2 &F) {
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        lf[(k * 6 + i) * WAVE] = F.f[i];
+                                        lf[(k * 6 + 3 + i) * WAVE] = F.n[i];
+                                    }
+                                },
+                                [&](int k, Force2 &F) {
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        F.f[i] = lf[(k * 6 + i) * WAVE];
+                                        F.n[i] = lf[(k * 6 + 3 + i) * WAVE];
+                                    }
+                                });
+    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) {
+        lt[lane * NJ + d] = tv[d][0];
+        lt[(WAVE + lane) * NJ + d] = tv[d][1];
+    }
+    wave_lds_sync();
+    tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true); // 128 rows of NJ floats = 64 "rows" of 2 NJ
+}
+
 void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s) {
+#ifndef DRM_RNEA_ONE_SAMPLE_PER_LANE
+    // pairs of 64-sample tiles through the two-samples-per-lane kernel, an odd last tile through the one-sample kernel
+    const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0;
+    if (n2 > 0) {
+        if (links == 7) hipLaunchKernelGGL((rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau);
+        else hipLaunchKernelGGL((rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau);
+    }
+    if (n2 > 0) {
+        if (!(n_tiles & 1)) return;
+        const int64_t done = (int64_t)n2 * TILE2 * 7;
+        q += done; qd += done; qdd = qdd ? qdd + done : nullptr; tau += done;
+        n_tiles = 1;
+    }
+#endif
     const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
     if (links == 7) hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
     else hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
@@ -168,8 +255,103 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
     tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
 }
 
+// The fused launch with two samples per lane: FK chain of all CAP ops first (pose out while the dynamics sweeps run), then
+// rnea_chain2_trig on the first LINKS ops; cos / sin shared.
+template <int CAP, int NJ, int LINKS>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_RNEA2_WAVES, DRM_RNEA2_WAVES)))
+    fk_rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau, float *__restrict__ pos,
+                        float *__restrict__ quat) {
+    static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - DRM_RNEA2_KEEP) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
+                  F_FLOATS = P_FLOATS > T_FLOATS ? P_FLOATS : T_FLOATS;
+    static_assert(TILE2 * 3 <= F_FLOATS, "the position tile fits into the staging area");
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + F_FLOATS];
+    const int tile = (int)blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    float *lc = smem, *lt = smem + C_FLOATS;
+    f2 *lf = reinterpret_cast<f2 *>(lt) + lane;
+    const int64_t b0 = (int64_t)tile * TILE2;
+
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    f2 qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
+    {
+        const int64_t ra = (b0 + lane) * NJ, rb = ra + (int64_t)WAVE * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = f2_make(q[ra + d], q[rb + d]);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = f2_make(qd[ra + d], qd[rb + d]);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? f2_make(qdd[ra + d], qdd[rb + d]) : f2_bcast(0.0f);
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    f2 cs[NJ], sn[NJ];
+    chain_trig2<NJ>(qv, cs, sn);
+    auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    {   // forward kinematics of the last link (robot_model.py:223-248)
+        Pose2 ee;
+        fk_chain2_trig<CAP, NJ>(row, cs, sn, ee);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lt[lane * 3 + c] = ee.p[c][0];
+            lt[(WAVE + lane) * 3 + c] = ee.p[c][1];
+        }
+        wave_lds_sync();
+        tile_store<6>(pos + b0 * 3, WAVE, 6, 0u, lt, lane, true); // 128 rows of 3 floats
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float R[9], qt[4];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = ee.R[i][h];
+            quat_xyzw(R, qt);
+            store16_wt(quat + (b0 + h * WAVE + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+        }
+        wave_lds_sync(); // the position tile has left before the parking area is written
+    }
+    rnea_chain2_trig<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+                                [&](int k, const Force2 &F) {
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        lf[(k * 6 + i) * WAVE] = F.f[i];
+                                        lf[(k * 6 + 3 + i) * WAVE] = F.n[i];
+                                    }
+                                },
+                                [&](int k, Force2 &F) {
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) {
+                                        F.f[i] = lf[(k * 6 + i) * WAVE];
+                                        F.n[i] = lf[(k * 6 + 3 + i) * WAVE];
+                                    }
+                                });
+    wave_lds_sync();
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) {
+        lt[lane * NJ + d] = tv[d][0];
+        lt[(WAVE + lane) * NJ + d] = tv[d][1];
+    }
+    wave_lds_sync();
+    tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true);
+}
+
 void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                         float *tau, float *pos, float *quat, hipStream_t s) {
+#ifndef DRM_RNEA_ONE_SAMPLE_PER_LANE
+    const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0; // pairs of 64-sample tiles: two samples per lane; an odd last tile: the one-sample kernel
+    if (n2 > 0) {
+        if (links == 7)
+            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau, pos, quat);
+        else
+            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau, pos, quat);
+    }
+    if (n2 > 0) {
+        if (!(n_tiles & 1)) return;
+        const int64_t rows = (int64_t)n2 * TILE2;
+        q += rows * 7; qd += rows * 7; qdd = qdd ? qdd + rows * 7 : nullptr; tau += rows * 7; pos += rows * 3; quat += rows * 4;
+        n_tiles = 1;
+    }
+#endif
     const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
     if (links == 7)
         hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);

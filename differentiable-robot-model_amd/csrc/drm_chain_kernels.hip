@@ -1,0 +1,313 @@
+// drm_chain_kernels.hip — straight-line, register-resident kernels for ANY serial chain of up to 16 ops (round 3).
+//
+// The 7-DoF arm kernels (drm_arm_kernels.hip) are compiled for one shape: ops 0..6 moving and driving DoF columns 0..6.
+// Every other chain — the arm of a Panda WITH its gripper up to a fingertip (11 ops, 9 DoF columns), a Jaco finger (13),
+// an iiwa7 + Allegro fingertip (14), a finger of a hand (6) — used to take the loop-structured kernels (drm_tree.hpp):
+// control words decoded per op, q staged through LDS, two to three times the instructions per link.  The kernels here
+// keep the arm kernels' design (constant rows staged once per wave in LDS and read back as broadcast ds_read_b128s,
+// packed-FP32 pose pairs in registers, per-lane q loads, write-through / non-temporal 16-byte stores) and take the
+// shape of the chain from the walk's control words instead of from template parameters:
+//   * W0[k] (include/drm_hip.h) of the CAP ops arrives with ONE wide scalar load; the DoF column of op k is a
+//     wave-uniform SGPR value: q is read per lane at a uniform offset, Jacobian columns land at a uniform LDS offset;
+//   * a fixed op is a joint at angle 0 (cos = 1, sin = 0 make J == F exactly): the walk is one basic block for every chain;
+//   * identity padding ops (F = I, t = 0) compose exactly and are simply walked.
+// Chains with a prismatic joint do not qualify (DRM_WALK_SERIAL_CHAIN is not set for them, flatten.py); a ragged tail of
+// B % 64 rows goes through the loop-structured kernel, as for the arm kernels.
+//
+//   chain_fk_kernel<CAP, JAC, NT>   K1 / K2 of one chain: pos, quat (+ lin_jac, ang_jac [B, 3, n]; columns of DoFs off the
+//                                   chain are zero, robot_model.py:645-648)             one wavefront per 64-sample tile
+//   fk_fan_chain_kernel<CAP>        K1 of T <= 4 disjoint chains (the fingertips of a hand, BASELINE configuration 4):
+//                                   wavefront t of a block walks chain t, the [64, 3T] / [64, 4T] tiles are assembled in
+//                                   LDS and leave as linear 16-byte stores
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+// DoF column of every op of a serial chain (-1: fixed joint or padding), from the walk's W0 words (wave-uniform)
+template <int CAP>
+__device__ __forceinline__ void chain_dofs(const int32_t *__restrict__ ops_i, int n_ops, int (&dof)[CAP]) {
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * CAP; // field-major table of capacity CAP
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const int w = w0[k];
+        dof[k] = (k < n_ops && !((w >> 25) & 1)) ? (w & 0xff) - 1 : -1;
+    }
+}
+
+// cos / sin of the joint angle of every op, two ops per packed evaluation.  Ops that do not move carry the angle 0 and are
+// evaluated like the others (cos 0 = 1, sin 0 = 0 exactly): skipping them pair by pair behind wave-uniform branches was
+// tried and costs more than it saves — the merges after every branch triple the register count of the 16-op kernel
+// USED (even, CAP - 2 or CAP): ops USED .. CAP-1 are known to be padding (the launcher picks the instantiation from n_ops)
+// and are neither evaluated nor walked
+template <int CAP, int USED>
+__device__ __forceinline__ void chain_trig_all(const float (&q)[CAP], float (&cs)[CAP], float (&sn)[CAP]) {
+    static_assert(!(USED & 1) && USED <= CAP, "ops are evaluated in pairs");
+    bool big = false;
+#pragma unroll
+    for (int k = 0; k < USED; ++k) big = big || !(fabsf(q[k]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) { // rare; wave-uniform
+#pragma unroll
+        for (int k = 0; k < USED; ++k) sincos_f(q[k], sn[k], cs[k]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < USED; k += 2) {
+        f2 s2, c2;
+        sincos_pair(f2_make(q[k], q[k + 1]), s2, c2);
+        sn[k] = s2[0]; cs[k] = c2[0]; sn[k + 1] = s2[1]; cs[k + 1] = c2[1];
+    }
+}
+
+// this lane's joint angles, one dword load per op at a wave-uniform column offset (0 for ops that do not move)
+template <int CAP, int USED>
+__device__ __forceinline__ void chain_load_q(const float *__restrict__ qrow, const int (&dof)[CAP], float (&qv)[CAP]) {
+#pragma unroll
+    for (int k = 0; k < USED; ++k) {
+        const float v = qrow[dof[k] < 0 ? 0 : dof[k]];
+        qv[k] = dof[k] < 0 ? 0.0f : v;
+    }
+}
+
+template <int CAP>
+__device__ __forceinline__ void chain_stage_table(const float *__restrict__ ops_f, float *lc, unsigned lane) {
+    constexpr unsigned N4 = CAP * DRM_OPF_STRIDE / 4, IT = (N4 + WAVE - 1) / WAVE;
+    float4 v[IT];
+#pragma unroll
+    for (unsigned it = 0; it < IT; ++it) {
+        const unsigned i = lane + WAVE * it;
+        v[it] = reinterpret_cast<const float4 *>(ops_f)[i < N4 ? i : N4 - 1];
+    }
+#pragma unroll
+    for (unsigned it = 0; it < IT; ++it) {
+        const unsigned i = lane + WAVE * it;
+        if ((it + 1) * WAVE <= N4 || i < N4) reinterpret_cast<float4 *>(lc)[i] = v[it];
+    }
+}
+
+// the chain itself: pose of the last op; B[k] = (z_k, p_k) pairs of every op's frame (what a Jacobian column needs)
+template <int CAP, int USED, bool KEEP_B>
+__device__ __forceinline__ void chain_walk(const float *lc, const float (&cs)[CAP], const float (&sn)[CAP], PoseP &ee,
+                                           f2 (&B)[KEEP_B ? CAP : 1][3]) {
+#pragma unroll
+    for (int k = 0; k < USED; ++k) {
+        // a scheduling barrier every other op: without it the compiler hoists the constant reads of all later ops to the
+        // top of the walk (CAP = 16: 210-256 VGPRs, one wave per SIMD); two ops per window keep enough reads in flight
+        if (CAP > 8 || KEEP_B) __builtin_amdgcn_sched_barrier(0);
+        const OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
+        f2 J01[3];
+        joint_pairs(o, cs[k], sn[k], J01);
+        if (k == 0) compose_pairs_root(J01, o, ee);
+        else compose_pairs(ee, J01, o, ee);
+        if constexpr (KEEP_B) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[k][c] = ee.B[c];
+        }
+    }
+}
+
+// LDS (dynamic): [ table : CAP x 32 ][ pos : 64 x 3 ][ Jacobian staging : 64 x (3n | 1), ang_jac first, then lin_jac ]
+template <int CAP, int USED, bool JAC, bool NT>
+__global__ void __launch_bounds__(WAVE)
+    chain_fk_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q, int n_ops, int n,
+                    int target_perm, uint64_t dof_mask, float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
+                    float *__restrict__ ang, uint32_t magic_j) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = WAVE * 3;
+    const unsigned lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    float *lc = smem, *lp = smem + C_FLOATS, *lj = lp + P_FLOATS;
+
+    int dof[CAP];
+    chain_dofs<CAP>(ops_i, n_ops, dof);
+    chain_stage_table<CAP>(ops_f, lc, lane);
+    float qv[CAP];
+    chain_load_q<CAP, USED>(q + (b0 + lane) * n, dof, qv);
+    wave_lds_sync();
+    float cs[CAP], sn[CAP];
+    chain_trig_all<CAP, USED>(qv, cs, sn);
+
+    PoseP ee;
+    f2 Bk[JAC ? CAP : 1][3];
+    chain_walk<CAP, USED, JAC>(lc, cs, sn, ee, Bk);
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+
+    if constexpr (JAC) {
+        const int S = 3 * n, Sj = pad_odd(S);
+        float *row = lj + lane * Sj;
+        const uint64_t all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+        if ((dof_mask & all) != all) { // columns of DoFs off the chain are zero in both Jacobians (wave-uniform loop)
+            for (int d = 0; d < n; ++d)
+                if (!((dof_mask >> d) & 1ull)) { row[d] = 0.0f; row[n + d] = 0.0f; row[2 * n + d] = 0.0f; }
+        }
+#pragma unroll
+        for (int k = 0; k < USED; ++k)
+            if (dof[k] >= 0) { // ang_jac[:, :, dof] = z_k   (robot_model.py:662)
+                float *c = row + dof[k];
+                c[0] = Bk[k][0][0]; c[n] = Bk[k][1][0]; c[2 * n] = Bk[k][2][0];
+            }
+        wave_lds_sync();
+        tile_store<0, NT>(ang + b0 * S, WAVE, S, magic_j, lj, lane, (S & 1) != 0, true);
+        wave_lds_sync(); // the tile has been read before lin_jac is staged over it
+#pragma unroll
+        for (int k = 0; k < USED; ++k)
+            if (dof[k] >= 0) { // lin_jac[:, :, dof] = z_k x (p_e - p_k)   (robot_model.py:661)
+                const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+                const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+                float cr[3];
+                cross3(z, dp, cr);
+                float *c = row + dof[k];
+                c[0] = cr[0]; c[n] = cr[1]; c[2 * n] = cr[2];
+            }
+    }
+    lp[lane * 3 + 0] = pe[0];
+    lp[lane * 3 + 1] = pe[1];
+    lp[lane * 3 + 2] = pe[2];
+    wave_lds_sync();
+    if constexpr (JAC) tile_store<0, NT>(lin + b0 * 3 * n, WAVE, 3 * n, magic_j, lj, lane, ((3 * n) & 1) != 0, true);
+    tile_store<3, NT>(pos + b0 * 3, WAVE, 3, 0u, lp, lane, true);
+    {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        unpermute(target_perm, E.R); // the target is the last REAL op: undo its column permutation before the quaternion
+        quat_xyzw(E.R, qt);
+        store16_wt<NT>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+    }
+}
+
+struct FanChains {
+    const float *ops_f[4];
+    const int32_t *ops_i[4];
+    int32_t n_ops[4];
+    int32_t perm[4];
+};
+
+// LDS (static): four chain tables, then the block's [64, 3T] position and [64, 4T] quaternion tiles (linear images)
+template <int CAP, int USED>
+__global__ void __launch_bounds__(WAVE * 4)
+    fk_fan_chain_kernel(FanChains tab, int T, int n, const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat) {
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE;
+    __shared__ __attribute__((aligned(16))) float smem[4 * C_FLOATS + WAVE * 12 + WAVE * 16];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + WAVE * 12;
+    // wave-uniform choice of this wave's chain (T <= 4)
+    const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
+    const int32_t *ops_i = wave == 0 ? tab.ops_i[0] : wave == 1 ? tab.ops_i[1] : wave == 2 ? tab.ops_i[2] : tab.ops_i[3];
+    const int n_ops = wave == 0 ? tab.n_ops[0] : wave == 1 ? tab.n_ops[1] : wave == 2 ? tab.n_ops[2] : tab.n_ops[3];
+    const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
+
+    int dof[CAP];
+    chain_dofs<CAP>(ops_i, n_ops, dof);
+    chain_stage_table<CAP>(ops_f, lc, lane);
+    float qv[CAP];
+    chain_load_q<CAP, USED>(q + (b0 + lane) * n, dof, qv);
+    wave_lds_sync();
+    float cs[CAP], sn[CAP];
+    chain_trig_all<CAP, USED>(qv, cs, sn);
+    PoseP ee;
+    f2 unused[1][3];
+    chain_walk<CAP, USED, false>(lc, cs, sn, ee, unused);
+    {
+        float *p = lp + (lane * T + wave) * 3;
+        p[0] = ee.B[0][1]; p[1] = ee.B[1][1]; p[2] = ee.B[2][1];
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        unpermute(perm, E.R);
+        quat_xyzw(E.R, qt);
+        reinterpret_cast<float4 *>(lr)[lane * T + wave] = make_float4(qt[0], qt[1], qt[2], qt[3]);
+    }
+    __syncthreads();
+    // [64, 3T] and [64, 4T] row-major tiles: linear in LDS and in HBM, 16 bytes per thread and round
+    const unsigned tid = threadIdx.x, nth = WAVE * (unsigned)T;
+    float4 *gp = reinterpret_cast<float4 *>(pos + b0 * 3 * T), *gr = reinterpret_cast<float4 *>(quat + b0 * 4 * T);
+    for (unsigned i = tid; i < (unsigned)(WAVE * 3 * T / 4); i += nth) store16_wt(gp + i, reinterpret_cast<const float4 *>(lp)[i]);
+    for (unsigned i = tid; i < (unsigned)(WAVE * T); i += nth) store16_wt(gr + i, reinterpret_cast<const float4 *>(lr)[i]);
+}
+
+// ---- launchers (called by drm_fk / drm_fk_jacobian / drm_fk_fanout); return the rows they covered (full tiles), 0 = not taken
+static bool chain_ok(const drm_walk *w) {
+    return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->capacity == 8 || w->capacity == 12 || w->capacity == 16) && w->n_ops >= 1 &&
+           w->n_slots == 0 && (((uintptr_t)w->ops_f) & 15u) == 0 && w->target_perm >= 0 && w->target_perm <= 5;
+}
+
+template <int CAP, int USED, bool JAC>
+static void launch_chain_used(const drm_walk *w, const float *q, int n_tiles, float *pos, float *quat, float *lin, float *ang, hipStream_t s) {
+    const int n = w->n_dofs;
+    const size_t lds = sizeof(float) * (size_t)(CAP * DRM_OPF_STRIDE + WAVE * 3 + (JAC ? round4(WAVE * pad_odd(3 * n)) : 0));
+    const bool nt = stream_past_llc((int64_t)n_tiles * WAVE * 4 * (7 + (JAC ? 6 * n : 0)));
+    if (nt) {
+        ensure_lds((chain_fk_kernel<CAP, USED, JAC, true>), lds);
+        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, true>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, w->ops_i, q, w->n_ops,
+                           n, (int)w->target_perm, w->dof_mask, pos, quat, lin, ang, div_magic(3 * n));
+    } else {
+        ensure_lds((chain_fk_kernel<CAP, USED, JAC, false>), lds);
+        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, false>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, w->ops_i, q, w->n_ops,
+                           n, (int)w->target_perm, w->dof_mask, pos, quat, lin, ang, div_magic(3 * n));
+    }
+}
+// the instantiation whose walked ops (USED = CAP - 2 or CAP) cover the chain's n_ops
+template <int CAP, bool JAC>
+static void launch_chain(const drm_walk *w, const float *q, int n_tiles, float *pos, float *quat, float *lin, float *ang, hipStream_t s) {
+    if (w->n_ops <= CAP - 2) launch_chain_used<CAP, CAP - 2, JAC>(w, q, n_tiles, pos, quat, lin, ang, s);
+    else launch_chain_used<CAP, CAP, JAC>(w, q, n_tiles, pos, quat, lin, ang, s);
+}
+
+int64_t launch_chain_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang,
+                                 hipStream_t s) {
+#ifdef DRM_NO_CHAIN_KERNEL
+    return 0;
+#else
+    const uint32_t al = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT) | al16(lin, AL_LIN) | al16(ang, AL_ANG);
+    if (!chain_ok(w) || !pos || !quat || al != (AL_Q | AL_POS | AL_QUAT | AL_LIN | AL_ANG) || B < WAVE || B / WAVE >= 0x7fffffffLL ||
+        w->n_dofs > 32)
+        return 0;
+    const int n_tiles = (int)(B / WAVE);
+    if (w->capacity == 8) launch_chain<8, true>(w, q, n_tiles, pos, quat, lin, ang, s);
+    else if (w->capacity == 12) launch_chain<12, true>(w, q, n_tiles, pos, quat, lin, ang, s);
+    else launch_chain<16, true>(w, q, n_tiles, pos, quat, lin, ang, s);
+    return (int64_t)n_tiles * WAVE;
+#endif
+}
+
+int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s) {
+#ifdef DRM_NO_CHAIN_KERNEL
+    return 0;
+#else
+    const uint32_t al = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    if (!chain_ok(w) || al != (AL_Q | AL_POS | AL_QUAT) || B < WAVE || B / WAVE >= 0x7fffffffLL) return 0;
+    const int n_tiles = (int)(B / WAVE);
+    if (w->capacity == 8) launch_chain<8, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
+    else if (w->capacity == 12) launch_chain<12, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
+    else launch_chain<16, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
+    return (int64_t)n_tiles * WAVE;
+#endif
+}
+
+int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s) {
+#ifdef DRM_NO_CHAIN_KERNEL
+    return 0;
+#else
+    const uint32_t al = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    if (T < 2 || T > 4 || al != (AL_Q | AL_POS | AL_QUAT) || B < WAVE || B / WAVE >= 0x7fffffffLL) return 0;
+    FanChains tab;
+    int longest = 0;
+    for (int t = 0; t < 4; ++t) {
+        const drm_walk *w = chains + (t < T ? t : 0);
+        if (!chain_ok(w) || w->capacity != 8) return 0;
+        tab.ops_f[t] = w->ops_f; tab.ops_i[t] = w->ops_i; tab.n_ops[t] = w->n_ops; tab.perm[t] = w->target_perm;
+        if (w->n_ops > longest) longest = w->n_ops;
+    }
+    const int n_tiles = (int)(B / WAVE);
+    if (longest <= 6)
+        hipLaunchKernelGGL((fk_fan_chain_kernel<8, 6>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat);
+    else
+        hipLaunchKernelGGL((fk_fan_chain_kernel<8, 8>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat);
+    return (int64_t)n_tiles * WAVE;
+#endif
+}
+
+} // namespace drm

@@ -357,6 +357,13 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
 void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                         float *tau, float *pos, float *quat, hipStream_t s);
 
+// drm_chain_kernels.hip: straight-line kernels for any serial chain of capacity 8 / 12 / 16 (DRM_WALK_SERIAL_CHAIN); they
+// return the rows they covered (full 64-row tiles), 0 when the call does not qualify
+int64_t launch_chain_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang,
+                                 hipStream_t s);
+int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
+int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
+
 template <class K>
 static int ensure_lds(K kernel, size_t bytes) {
     if (bytes > (size_t)64 * 1024) {

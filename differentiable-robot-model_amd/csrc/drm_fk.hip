@@ -139,6 +139,14 @@ extern "C" int drm_fk_fanout(const drm_walk *chains, int32_t n_chains, const flo
     tab.cap = chains[0].capacity;
     if (B == 0) return DRM_OK;
     const int n = chains[0].n_dofs, T = n_chains;
+    {   // chains of capacity 8 (the fingers of a hand): full tiles through the straight-line fan-out kernel
+        const int64_t done = launch_fk_fan_chains(chains, T, q, B, pos, quat, (hipStream_t)stream);
+        if (done > 0) {
+            int rc = launched();
+            if (rc || done == B) return rc;
+            q += done * n; pos += done * 3 * T; quat += done * 4 * T; B -= done;
+        }
+    }
     const int64_t tiles = (B + WAVE - 1) / WAVE;
     if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const size_t lds = sizeof(float) * (size_t)(round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) + round4(WAVE * pad_odd(4 * T)) +
@@ -163,12 +171,14 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
     const int n = w->n_dofs, T = n_targets;
     if (T == 1 && w->n_ops >= 1) {
         // 7-DoF arms, one target at the end of the chain: full tiles through the packed-FP32 chain kernel
-        const int64_t done = launch_fk_arm(w, q, B, pos, quat, (hipStream_t)stream);
+        int64_t done = launch_fk_arm(w, q, B, pos, quat, (hipStream_t)stream);
+        // ... any other serial chain of up to 16 ops through the straight-line chain kernel (drm_chain_kernels.hip)
+        if (done == 0) done = launch_chain_fk(w, q, B, pos, quat, (hipStream_t)stream);
         if (done > 0) {
             rc = launched();
             if (rc || done == B) return rc;
             drm_walk generic = *w;
-            generic.shape &= ~DRM_WALK_ARM_CHAIN;
+            generic.shape &= ~(DRM_WALK_ARM_CHAIN | DRM_WALK_SERIAL_CHAIN);
             return drm_fk(&generic, q + done * n, B - done, 1, pos + done * 3, quat + done * 4, stream);
         }
     }

@@ -131,6 +131,17 @@ extern "C" int drm_fk_jacobian(const drm_walk *w, const float *q, int64_t B, flo
                                    lin_jac + done * 3 * n, ang_jac + done * 3 * n, stream);
         }
     } else {
+        // any other serial chain of up to 16 ops (an arm with its gripper up to a fingertip, a finger of a hand): full tiles
+        // through the straight-line chain kernel, a ragged tail through the loop-structured one below
+        const int64_t done = launch_chain_fk_jacobian(w, q, B, pos, quat, lin_jac, ang_jac, s);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_SERIAL_CHAIN;
+            return drm_fk_jacobian(&generic, q + done * n, B - done, pos + done * 3, quat + done * 4, lin_jac + done * 3 * n,
+                                   ang_jac + done * 3 * n, stream);
+        }
         if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
         TreeArgs a = tree_args(w);
         a.n_segments = 1; a.prefix_end = 0;

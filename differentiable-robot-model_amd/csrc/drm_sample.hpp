@@ -57,6 +57,15 @@ DRM_HD f2 f2_fma(f2 a, f2 b, f2 c) {
 #endif
 }
 
+// keeps a pair out of a later contraction: the value is rounded here (host: a volatile-free identity the optimiser cannot see through)
+DRM_HD void pin2(f2 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#else
+    asm volatile("" : "+x"(v));
+#endif
+}
+
 // ops_i is stored FIELD-MAJOR, [DRM_OPI_STRIDE][capacity].  The backward walks read a single field, the packed control
 // word (DRM_OPI_CTRL, include/drm_hip.h), and decode the fields they branch on with scalar bit-field extracts; the
 // loop-structured forward walks (drm_tree.hpp) read the two wider words DRM_OPI_W0 / W1.
@@ -922,6 +931,248 @@ DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&c
             rnea_link_force_up(J, o.t, tot, up);
             tot = up;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RNEA of a serial chain, TWO SAMPLES PER LANE.
+//
+// The form above pairs velocity- with acceleration-like quantities of ONE sample, which leaves the genuinely scalar
+// parts of the recursion (the joint rotation, the v x* (I v) cross products, a third of the motion update, the sincos
+// of an odd joint count) on half-empty instructions: 1 141 VALU instructions per 64 samples, 512 of them packed.  Here a
+// pair is the SAME quantity of two samples (rows b and b + 64 of a 128-sample tile), so every instruction of the
+// per-sample recursion is a full v_pk_*_f32: the instruction count per sample drops by a third (profiles/r03_*), the
+// wave-uniform link constants enter as broadcast operands (op_sel), and two dword loads of consecutive tiles land in
+// the two halves of a register pair without a move.  The price is registers (two samples of state per lane: two waves per
+// SIMD) — which is what an issue-bound kernel can afford.
+// Arithmetic per sample: the reference's formulas in the association order written below; same
+// results as rnea_chain_trig up to fp32 rounding (the sums are associated differently).
+// ---------------------------------------------------------------------------
+struct Motion2 {
+    f2 w[3], al[3], v[3], a[3]; // angular / linear velocity and acceleration, body frame; [i] = (sample A, sample B)
+};
+struct Force2 {
+    f2 f[3], n[3]; // linear, angular
+};
+// the first two columns of J = F Rot_z(q) per sample; the third column is the constant F[:, 2]
+struct Joint2 {
+    f2 c0[3], c1[3];
+};
+DRM_HD void joint2_moving(const float *F, f2 c, f2 s, Joint2 &J) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        J.c0[r] = f2_bcast(F[r * 3 + 0]) * c + f2_bcast(F[r * 3 + 1]) * s;
+        J.c1[r] = f2_bcast(F[r * 3 + 1]) * c - f2_bcast(F[r * 3 + 0]) * s;
+    }
+}
+DRM_HD void joint2_fixed(const float *F, Joint2 &J) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { J.c0[r] = f2_bcast(F[r * 3 + 0]); J.c1[r] = f2_bcast(F[r * 3 + 1]); }
+}
+DRM_HD void joint2_T(const Joint2 &J, const float *F, const f2 *x, f2 *y) { // y = J^T x
+    y[0] = J.c0[0] * x[0] + J.c0[1] * x[1] + J.c0[2] * x[2];
+    y[1] = J.c1[0] * x[0] + J.c1[1] * x[1] + J.c1[2] * x[2];
+    y[2] = f2_bcast(F[2]) * x[0] + f2_bcast(F[5]) * x[1] + f2_bcast(F[8]) * x[2];
+}
+DRM_HD void joint2_N(const Joint2 &J, const float *F, const f2 *x, f2 *y) { // y = J x
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[r] = J.c0[r] * x[0] + J.c1[r] * x[1] + f2_bcast(F[r * 3 + 2]) * x[2];
+}
+DRM_HD void cross2_vc(const f2 *a, const float *b, f2 *out) { // per-sample vector x constant vector
+    out[0] = a[1] * f2_bcast(b[2]) - a[2] * f2_bcast(b[1]);
+    out[1] = a[2] * f2_bcast(b[0]) - a[0] * f2_bcast(b[2]);
+    out[2] = a[0] * f2_bcast(b[1]) - a[1] * f2_bcast(b[0]);
+}
+DRM_HD void cross2_cv(const float *a, const f2 *b, f2 *out) { // constant vector x per-sample vector
+    out[0] = f2_bcast(a[1]) * b[2] - f2_bcast(a[2]) * b[1];
+    out[1] = f2_bcast(a[2]) * b[0] - f2_bcast(a[0]) * b[2];
+    out[2] = f2_bcast(a[0]) * b[1] - f2_bcast(a[1]) * b[0];
+}
+DRM_HD void cross2_vv(const f2 *a, const f2 *b, f2 *out) {
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+// motion of a link from its parent's (rnea_link_motion on sample pairs); wj / aj = joint velocity / acceleration (0 for a fixed link)
+DRM_HD void rnea2_link_motion(const Joint2 &J, const float *F, const float *t, f2 wj, f2 aj, const Motion2 &par, Motion2 &out) {
+    Motion2 N;
+    f2 x[3], tmp[3];
+    joint2_T(J, F, par.w, N.w);
+    joint2_T(J, F, par.al, N.al);
+    cross2_vc(par.w, t, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = par.v[i] + x[i];
+    joint2_T(J, F, tmp, N.v);
+    cross2_vc(par.al, t, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = par.a[i] + x[i];
+    joint2_T(J, F, tmp, N.a);
+    N.w[2] += wj;
+    N.al[2] += aj;
+    N.al[0] += N.w[1] * wj; N.al[1] -= N.w[0] * wj; // w x (wj e_z)
+    N.a[0] += N.v[1] * wj;  N.a[1] -= N.v[0] * wj;  // v x (wj e_z)
+    out = N;
+}
+// the first link of a chain: its parent is the resting root (w = al = v = 0, a = (0, 0, g))
+DRM_HD void rnea2_first_motion(const Joint2 &J, const float *F, float g, f2 wj, f2 aj, Motion2 &out) {
+    const f2 z = f2_bcast(0.0f);
+    out.w[0] = z; out.w[1] = z; out.w[2] = wj;
+    out.al[0] = z; out.al[1] = z; out.al[2] = aj;
+    out.v[0] = z; out.v[1] = z; out.v[2] = z;
+    out.a[0] = J.c0[2] * f2_bcast(g); out.a[1] = J.c1[2] * f2_bcast(g); out.a[2] = f2_bcast(F[8] * g);
+}
+// f = I a + v x* (I v) (rnea_body_force on sample pairs)
+DRM_HD void rnea2_body_force(float m, const float *mc, const float *Io, const Motion2 &N, Force2 &out) {
+    f2 hl[3], ha[3], gl[3], ga[3], x[3], y[3];
+    cross2_cv(mc, N.w, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hl[i] = f2_bcast(m) * N.v[i] - x[i];
+    cross2_cv(mc, N.v, x);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        ha[r] = f2_bcast(Io[r * 3 + 0]) * N.w[0] + f2_bcast(Io[r * 3 + 1]) * N.w[1] + f2_bcast(Io[r * 3 + 2]) * N.w[2] + x[r];
+    cross2_cv(mc, N.al, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gl[i] = f2_bcast(m) * N.a[i] - x[i];
+    cross2_cv(mc, N.a, x);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        ga[r] = f2_bcast(Io[r * 3 + 0]) * N.al[0] + f2_bcast(Io[r * 3 + 1]) * N.al[1] + f2_bcast(Io[r * 3 + 2]) * N.al[2] + x[r];
+    cross2_vv(N.w, hl, x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.f[i] = gl[i] + x[i];
+    cross2_vv(N.w, ha, x);
+    cross2_vv(N.v, hl, y);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.n[i] = ga[i] + (x[i] + y[i]);
+}
+//   row(k) -> op k's constant row;  cs / sn / qd / qdd / tau: [d] = (sample A, sample B)
+//   fput(k, Force2) / fget(k, Force2&): body forces of links 0 .. LINKS-2 between the sweeps (the last link's is consumed
+//   the moment it exists and never parked)
+//   KEEP2: that many more of the last links keep their forces in registers (parked: links 0 .. LINKS-2-KEEP2)
+#ifndef DRM_RNEA2_KEEP
+#define DRM_RNEA2_KEEP 5
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DRM_RNEA2_NO_FENCE)
+#define DRM_RNEA2_LINK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DRM_RNEA2_LINK_FENCE() ((void)0)
+#endif
+template <int LINKS, int NJ, int KEEP2 = DRM_RNEA2_KEEP, class ROW, class FPUT, class FGET>
+DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)[NJ], const f2 (&sn)[NJ], const f2 (&qd)[NJ],
+                             const f2 (&qdd)[NJ], f2 (&tau)[NJ], FPUT fput, FGET fget) {
+    static_assert(LINKS >= NJ && LINKS >= 2 + KEEP2, "moving joints first, then fixed links");
+    constexpr int PARKED = LINKS - 1 - KEEP2;
+    Motion2 cur;
+    Force2 tot;
+    Force2 kept[KEEP2 > 0 ? KEEP2 : 1];
+#pragma unroll
+    for (int k = 0; k < LINKS; ++k) {
+        DRM_RNEA2_LINK_FENCE();
+        const float *of = row(k);
+        const OpFT o = load_ft(of);
+        Joint2 J;
+        if (k < NJ) joint2_moving(o.F, cs[k], sn[k], J);
+        else joint2_fixed(o.F, J);
+        const f2 wj = k < NJ ? qd[k] : f2_bcast(0.0f), aj = k < NJ ? qdd[k] : f2_bcast(0.0f);
+        if (k == 0) rnea2_first_motion(J, o.F, gravity ? 9.81f : 0.0f, wj, aj, cur);
+        else rnea2_link_motion(J, o.F, o.t, wj, aj, cur, cur);
+        Force2 fk;
+        rnea2_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, fk);
+        if (k < PARKED) fput(k, fk);
+        else if (k < LINKS - 1) kept[k - PARKED] = fk;
+        else tot = fk;
+    }
+#pragma unroll
+    for (int k = LINKS - 1; k >= 0; --k) {
+        DRM_RNEA2_LINK_FENCE();
+        const float *of = row(k);
+        if (k < LINKS - 1) {
+            Force2 fk;
+            if (k < PARKED) fget(k, fk);
+            else fk = kept[k - PARKED];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { tot.f[i] += fk.f[i]; tot.n[i] += fk.n[i]; }
+        }
+        if (k < NJ) tau[k] = damping ? tot.n[2] + f2_bcast(of[DRM_OPF_DAMP]) * qd[k] : tot.n[2];
+        if (k > 0) {
+            const OpFT o = load_ft(of);
+            Joint2 J;
+            if (k < NJ) joint2_moving(o.F, cs[k], sn[k], J);
+            else joint2_fixed(o.F, J);
+            Force2 up;
+            joint2_N(J, o.F, tot.f, up.f);
+            joint2_N(J, o.F, tot.n, up.n);
+            f2 x[3];
+            cross2_cv(o.t, up.f, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) up.n[i] += x[i];
+            tot = up;
+        }
+    }
+}
+// world pose of the last link of a chain, two samples per lane: R = R_p J, p = R_p t + p_p per link (robot_model.py:186,
+// spatial_vector_algebra.py:98-103), in the association order of the one-sample pair form (fk_chain_pairs_trig /
+// compose_pairs) so that the fused FK + RNEA launch returns what compute_forward_kinematics returns, bit for bit.
+struct Pose2 {
+    f2 R[9], p[3];
+};
+template <int CAP, int NJ, class ROW>
+DRM_HD void fk_chain2_trig(ROW row, const f2 (&cs)[NJ], const f2 (&sn)[NJ], Pose2 &ee) {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        DRM_RNEA2_LINK_FENCE();
+        const OpFT o = load_ft(row(k));
+        f2 J0[3], J1[3]; // columns 0 and 1 of J = F Rot_z(q) (joint_pairs: f01 c + (f1, f0) (s, -s)); column 2 is F[:, 2]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (k < NJ) {
+                J0[i] = f2_bcast(o.F[i * 3 + 0]) * cs[k] + f2_bcast(o.F[i * 3 + 1]) * sn[k];
+                J1[i] = f2_bcast(o.F[i * 3 + 1]) * cs[k] + f2_bcast(o.F[i * 3 + 0]) * -sn[k];
+            } else {
+                J0[i] = f2_bcast(o.F[i * 3 + 0]);
+                J1[i] = f2_bcast(o.F[i * 3 + 1]);
+            }
+        }
+        if (k == 0) { // the parent is the identity root: R = J, p = t exactly
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                ee.R[c * 3 + 0] = J0[c]; ee.R[c * 3 + 1] = J1[c]; ee.R[c * 3 + 2] = f2_bcast(o.F[c * 3 + 2]);
+                ee.p[c] = f2_bcast(o.t[c]);
+            }
+        } else {
+            Pose2 n;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f2 r0 = ee.R[c * 3 + 0], r1 = ee.R[c * 3 + 1], r2 = ee.R[c * 3 + 2];
+                n.R[c * 3 + 0] = r0 * J0[0] + r1 * J0[1] + r2 * J0[2];
+                n.R[c * 3 + 1] = r0 * J1[0] + r1 * J1[1] + r2 * J1[2];
+                n.R[c * 3 + 2] = r0 * f2_bcast(o.F[2]) + r1 * f2_bcast(o.F[5]) + r2 * f2_bcast(o.F[8]);
+                f2 b = r0 * f2_bcast(o.t[0]) + r1 * f2_bcast(o.t[1]) + r2 * f2_bcast(o.t[2]);
+                pin2(b); // the translation joins AFTER the rounded sum, as in compose_pairs (b[1] += p)
+                n.p[c] = b + ee.p[c];
+            }
+            ee = n;
+        }
+    }
+}
+// cos / sin of the NJ joint angles of two samples
+template <int NJ>
+DRM_HD void chain_trig2(const f2 (&q)[NJ], f2 (&cs)[NJ], f2 (&sn)[NJ]) {
+    bool big = false;
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) big = big || !(fabsf(q[d][0]) <= SINCOS_PAIR_MAX_ARG) || !(fabsf(q[d][1]) <= SINCOS_PAIR_MAX_ARG);
+    if (DRM_WAVE_ANY(big)) { // rare; wave-uniform
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) {
+            float s0, c0, s1, c1;
+            sincos_f(q[d][0], s0, c0);
+            sincos_f(q[d][1], s1, c1);
+            sn[d] = f2_make(s0, s1); cs[d] = f2_make(c0, c1);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) sincos_pair(q[d], sn[d], cs[d]);
     }
 }
 

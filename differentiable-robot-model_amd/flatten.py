@@ -59,6 +59,7 @@ def opf_ti(i: int) -> int:
 
 
 SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
+SHAPE_SERIAL_CHAIN = 2               # DRM_WALK_SERIAL_CHAIN
 OPI_STRIDE = 10
 OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS, OPI_W0, OPI_W1 = range(10)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
@@ -516,6 +517,10 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     arm = (n_ops >= n and not any(prismatic)
            and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
                    for k, row in enumerate(ops)))
+    # DRM_WALK_SERIAL_CHAIN: one root-to-target chain, whatever its joints (the straight-line chain kernels take it)
+    serial = (n_ops >= 1 and not any(prismatic) and max_used == 0
+              and all(row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV) and row[OPI_SAVE] < 0 for k, row in enumerate(ops))
+              and all((row[OPI_OUT] >= 0) == (k == n_ops - 1) for k, row in enumerate(ops)))
     # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
     branch_depth = min(255, max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0))
     prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
@@ -523,7 +528,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     seg_leaf_begin = [int(sum(is_leaf[:b])) for b in seg_begin]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
-                       (SHAPE_ARM_CHAIN if arm else 0) | (branch_depth << 8) | (min(n_leaves, 255) << 16),
+                       (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
+                       | (min(n_leaves, 255) << 16),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
 
 

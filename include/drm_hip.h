@@ -110,6 +110,10 @@ extern "C" {
 /* drm_walk.shape */
 #define DRM_WALK_ARM_CHAIN 1 /* a serial chain: ops 0..n_dofs-1 are moving joints driving DoF columns
                                 0..n_dofs-1 in order, every later op is a fixed joint or padding  */
+#define DRM_WALK_SERIAL_CHAIN 2 /* a serial chain of ANY shape: op 0 hangs off the root, every other op off the previous one,
+                                no save slots, no prismatic joint, the single target is the last op; moving and fixed ops
+                                in any order, any DoF columns.  Walks of capacity 8 / 12 / 16 with this bit take the
+                                straight-line chain kernels (drm_chain_kernels.hip) in drm_fk / drm_fk_jacobian / drm_fk_fanout */
 #define DRM_WALK_LEAVES(shape) (((shape) >> 16) & 0xff) /* number of leaf ops (ops no child follows), see DRM_OPI_CTRL */
 #define DRM_WALK_BRANCH_DEPTH(shape) (((shape) >> 8) & 0xff) /* 1 + the largest op index that is a branch
                                 point (0: none): sizes the per-ancestor slot records of drm_crba /

@@ -114,6 +114,27 @@ void rnea_arm_8_7(const drm_walk *w, const float *q, const float *qd, const floa
     }
 }
 
+// the arithmetic of rnea_arm2_kernel: samples (b, b + 1) share a lane as (A, B); LINKS = 8 (whole table) or 7 (tail folded)
+template <int LINKS>
+void rnea_arm2_8_7(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
+    constexpr int NJ = 7;
+    for (int64_t b = 0; b < B; b += 2) {
+        const int64_t b1 = b + 1 < B ? b + 1 : b;
+        f2 qv[NJ], qdv[NJ], qddv[NJ], tv[NJ], cs[NJ], sn[NJ];
+        for (int d = 0; d < NJ; ++d) {
+            qv[d] = f2_make(q[b * NJ + d], q[b1 * NJ + d]);
+            qdv[d] = f2_make(qd[b * NJ + d], qd[b1 * NJ + d]);
+            qddv[d] = qdd ? f2_make(qdd[b * NJ + d], qdd[b1 * NJ + d]) : f2_bcast(0.f);
+        }
+        chain_trig2<NJ>(qv, cs, sn);
+        Force2 park[LINKS];
+        rnea_chain2_trig<LINKS, NJ>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                                    flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv, [&](int k, const Force2 &F) { park[k] = F; },
+                                    [&](int k, Force2 &F) { F = park[k]; });
+        for (int d = 0; d < NJ; ++d) { tau[b * NJ + d] = tv[d][0]; tau[b1 * NJ + d] = tv[d][1]; }
+    }
+}
+
 struct ParkRec { Force f; float c, s, q; };
 
 void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
@@ -357,6 +378,12 @@ int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos
 int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     rnea_arm_8_7(w, q, qd, qdd, B, flags, tau);
+    return 0;
+}
+int emu_rnea_arm2(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
+    if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
+    if (w->n_ops == 7) rnea_arm2_8_7<7>(w, q, qd, qdd, B, flags, tau);
+    else rnea_arm2_8_7<8>(w, q, qd, qdd, B, flags, tau);
     return 0;
 }
 int emu_rnea_backward(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,

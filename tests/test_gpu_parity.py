@@ -401,6 +401,53 @@ def test_fk_and_inverse_dynamics_plan_under_hipgraph_config3_shard():
         assert np.allclose(host(plan.tau[sel]), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
 
 
+@pytest.mark.parametrize("robot,link", [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee")])
+def test_two_samples_per_lane_kernels_every_row_vs_oracle(robot, link):
+    """Launches of more than 1 024 tiles take the two-samples-per-lane kernels (rnea_arm2_kernel / fk_rnea_arm2_kernel: a
+    wavefront owns 128 rows).  B = 1 027 tiles + 17 rows: 513 pairs through them, the odd tile through the one-sample
+    kernel, the ragged tail through the loop kernel — EVERY row against the fp64 oracle, on the folded 7-link table (the API)
+    and on the full 8-link table (drm_rnea on the unfolded walk), fused and separate."""
+    import ctypes
+    from differentiable_robot_model_amd import backend
+    m = load_model(robot, "cuda")
+    B, n = 1027 * 64 + 17, 7
+    q, qd, qdd = sample_states(m, B, seed=4242, vel=0.6, acc=1.2)
+    q[40000, 3] = 1.5e5          # one sample of a pair takes the fp64 argument reduction: wave-uniform fallback
+    orc = Oracle(m._spec)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    ee = m._name_to_idx_map[link]
+    rp, rq = orc.fk(q64, [ee], np.float64)
+    for grav, damp in ((True, True), (False, False)):
+        ref = orc.rnea(q64, qd64, qdd64, grav, damp, np.float64)
+        tau, pos, quat = m.compute_fk_and_inverse_dynamics(dev(q), dev(qd), dev(qdd), link, grav, damp)
+        t2 = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+        assert torch.equal(tau, t2)
+        assert np.allclose(host(tau), ref, **TOL_TAU)
+        assert max_err(host(pos), rp[:, 0]) <= TOL_POS["atol"] and quat_close(host(quat), rq[:, 0], TOL_QUAT["atol"])[0]
+        p2, r2 = m.compute_forward_kinematics(dev(q), link)
+        # bit for bit the separate call — except in the 128-row tile of the sample with the huge angle: the large-argument
+        # sincos fallback is wave-uniform, and a wave is 128 rows in the fused launch but 64 in compute_forward_kinematics
+        same = torch.ones(B, dtype=torch.bool, device="cuda")
+        same[40000 // 128 * 128:(40000 // 128 + 1) * 128] = False
+        assert torch.equal(pos[same], p2[same]) and torch.equal(quat[same], r2[same])
+        assert (pos - p2).abs().max().item() <= 1e-6 and (quat - r2).abs().max().item() <= 1e-6
+        # the unfolded walk: all 8 links are ops (LINKS = 8 instantiation)
+        dt = m._get_walk(("tree",), whole_tree=True)
+        assert dt.program.n_ops == 8
+        walk = backend._walk_struct(dt.program, m._ops_f(dt), dt.ops_i, n)
+        out = torch.empty(B, n, device="cuda")
+        dq, dqd, dqdd = dev(q), dev(qd), dev(qdd)
+        lib = backend.load_library()
+        scratch = torch.empty(max(1, lib.drm_rnea_scratch_floats(ctypes.byref(walk), B)), device="cuda")   # the ragged tail's records
+        backend._check(lib.drm_rnea(ctypes.byref(walk), dq.data_ptr(), dqd.data_ptr(), dqdd.data_ptr(), B,
+                                    (1 if grav else 0) | (2 if damp else 0), out.data_ptr(), scratch.data_ptr(),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert np.allclose(host(out), ref, **TOL_TAU)
+    # non-linear effects (qdd = NULL)
+    nle = m.compute_non_linear_effects(dev(q), dev(qd))
+    assert np.allclose(host(nle), orc.rnea(q64, qd64, np.zeros_like(q64), True, True, np.float64), **TOL_TAU)
+
+
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
     the fp64 oracle (the oracle does 65 536 rows in well under a second)."""

@@ -170,6 +170,37 @@ def test_arm_chain_rnea(emu, robot, flags):
     assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "fetch_arm_no_gripper_small_damping"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("folded", [False, True])
+def test_arm_chain_rnea_two_samples_per_lane(emu, robot, flags, folded):
+    """rnea_chain2_trig (the arithmetic of rnea_arm2_kernel: every quantity a pair over two samples) against the fp64 oracle
+    and against the one-sample form; on the full 8-link table and on the 7-link table with the fixed tail folded."""
+    m = load_model(robot)
+    n, B = m._n_dofs, 67
+    q, qd, qdd = sample_states(m, B, seed=37)
+    q[4, 1] = 2.0e5  # fp64 reduction fallback for one sample of a pair
+    if folded:
+        prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
+        assert prog.n_ops == 7 and prog.capacity == 8
+        walk, keep = folded_host_walk(m, prog)
+    else:
+        prog = build_walk(m._spec, whole_tree=True)
+        walk, keep = host_walk(m, prog)
+    tau = np.full((B, n), np.nan, np.float32); tau1 = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea_arm2(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau)) == 0
+    assert emu.emu_rnea_arm(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau1)) == 0
+    ot = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau, ot, atol=2e-5, rtol=2e-5), (robot, np.abs(tau - ot).max())
+    assert np.allclose(tau, tau1, atol=1e-5, rtol=1e-5)
+    tau0 = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_rnea_arm2(ctypes.byref(walk), _ptr(q), _ptr(qd), None, ctypes.c_int64(B), flags, _ptr(tau0)) == 0
+    o0 = Oracle(m._spec).rnea(q.astype(np.float64), qd.astype(np.float64), np.zeros_like(q, np.float64),
+                              bool(flags & 1), bool(flags & 2), np.float64)
+    assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
+
+
 def test_sincos_large_arguments(emu):
     """The kernels' branch-free sincos keeps fp32 accuracy far outside any joint range."""
     m = load_model("2link_robot")
