@@ -131,7 +131,10 @@ def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
         raise ValueError("%s must be [B, %d], got %s" % (name, cols, tuple(t.shape)))
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() & 15:   # a row slice of a larger tensor: the fast kernels (and the scratch sizes) assume 16-byte alignment
+        t = t.clone()
+    return t
 
 
 def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_dofs: int) -> DrmWalk:
@@ -146,7 +149,9 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
 
 def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_dofs: int, target_perm: int):
     """`struct drm_walk` of a WalkProgram whose tables live at the given addresses (device here, host in tests/host_emu)."""
-    w = cls(ops_f_ptr, ops_i_ptr, prog.n_ops, prog.capacity, n_dofs, prog.n_slots, prog.dof_mask, target_perm, prog.shape)
+    shape = int(prog.shape) & 0xffffffff   # the top byte carries (P, K, L) of DRM_WALK_ARM_HAND: bit 31 may be set
+    w = cls(ops_f_ptr, ops_i_ptr, prog.n_ops, prog.capacity, n_dofs, prog.n_slots, prog.dof_mask, target_perm,
+            shape - (1 << 32) if shape >> 31 else shape)
     w.n_segments = prog.n_segments
     for i, v in enumerate(prog.seg_begin):
         w.seg_begin[i] = int(v)

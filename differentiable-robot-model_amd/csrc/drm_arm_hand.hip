@@ -1,0 +1,135 @@
+// drm_arm_hand.hip — K3 (inverse dynamics) of robots shaped like "an arm that carries a hand" (round 3): P serial prefix
+// ops and K serial sub-chains of L ops that all hang off the last prefix op (DRM_WALK_ARM_HAND, include/drm_hip.h).
+// Franka Panda with its gripper (P, K, L) = (9, 2, 1), Kinova Jaco (7, 3, 2), KUKA iiwa7 + Allegro hand (8, 4, 4).
+//
+// These robots are ONE dynamics segment (everything hangs off the moving arm), so the loop-structured kernel
+// (drm_rnea.hip rnea_records_kernel) walks a whole 64-sample tile with one wavefront, parks every link's body force
+// (LDS or HBM scratch) and decodes two control words per op: 183 / 256 / 437 us at 2^20 samples.  Here the walk is
+// straight-line code for the shape (drm_sample.hpp rnea_arm_hand): the prefix is the arm kernels' chain walk, every
+// sub-chain runs forward and backward while the palm's motion is in registers, so only the P - 1 prefix forces are parked
+// (LDS, 1.5 KB per link and wave) and a CU holds 9-11 wavefronts.  Which DoF column an op drives comes from the walk's
+// W0 words (scalar loads): fixed ops and arbitrary DoF numbering need no template parameters beyond (P, L); K is a
+// run-time loop count.  Full 64-row tiles only; a ragged tail goes through the loop-structured kernel.
+// Build flags as drm_arm_dynamics.hip (kernel-argument preload, no SLP vectoriser).
+#include "drm_common.hpp"
+#include "drm_sample.hpp"
+
+namespace drm {
+
+constexpr int AH_MAX_OPS = 32; // P + K L of any compiled shape (sizes the torque tile)
+
+// LDS (static — with a dynamic allocation the compiler's occupancy guess goes wrong and the same code needs 300 registers):
+// [ table : AH_MAX_OPS x 32 ][ torques of the sub-chain ops : 16 x 64 ][ parking : (P - 1) x 6 x 64 | tau tile : 64 x (n | 1) ]
+template <int P, int L>
+__global__ void __launch_bounds__(WAVE)
+    rnea_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
+                         const float *__restrict__ qd, const float *__restrict__ qdd, int K, int cap, int n, int flags,
+                         float *__restrict__ tau, uint32_t magic_n) {
+    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE, H_FLOATS = 16 * WAVE;
+    constexpr int PARK = (P - 1) * 6 * WAVE, TILE = round4(WAVE * pad_odd(AH_MAX_OPS));
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + H_FLOATS + (PARK > TILE ? PARK : TILE)];
+    const unsigned lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    const int n_ops = P + K * L;
+    float *lc = smem, *lh = smem + C_FLOATS + lane, *lt = smem + C_FLOATS + H_FLOATS;
+    float *lf = lt + lane; // parked body forces of the prefix: [op][6][64]
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * cap; // control words (wave-uniform scalar loads): bits 0..7 = DoF column + 1
+
+    // DoF column of the prefix ops (-1: fixed)
+    int dof[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
+    // constant rows -> LDS
+    for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
+        reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    // this lane's rows, one dword load per op and array at a wave-uniform column (fixed ops: column 0, value dropped):
+    // uniform base (tile + column) + ONE 32-bit per-lane byte offset shared by every load
+    const unsigned row_off = lane * (unsigned)n * 4u;
+    const char *qb = reinterpret_cast<const char *>(q + b0 * n), *qdb = reinterpret_cast<const char *>(qd + b0 * n),
+               *qddb = reinterpret_cast<const char *>(qdd ? qdd + b0 * n : q + b0 * n);
+    const bool has_qdd = qdd != nullptr;
+    auto joint_state = [&](int d, float &a, float &v, float &acc) {
+        const int c = (d < 0 ? 0 : d) * 4;
+        const float x = *reinterpret_cast<const float *>(qb + c + row_off), y = *reinterpret_cast<const float *>(qdb + c + row_off),
+                    z = *reinterpret_cast<const float *>(qddb + c + row_off);
+        a = d < 0 ? 0.0f : x; v = d < 0 ? 0.0f : y; acc = (d < 0 || !has_qdd) ? 0.0f : z;
+    };
+    float qv[P], qdv[P], qddv[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) joint_state(dof[k], qv[k], qdv[k], qddv[k]);
+    wave_lds_sync();
+    float cs[P], sn[P], tp[P];
+    chain_trig<P>(qv, cs, sn);
+    // bits of an op: 1 = moves, 2 = prismatic (W0 bit 26)
+    auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
+    rnea_arm_hand<P, L>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY,
+                        flags & DRM_RNEA_DAMPING, qv, cs, sn, qdv, qddv,
+                        [&](int j, int i, float &a, float &v, float &acc) { joint_state((w0[P + j * L + i] & 0xff) - 1, a, v, acc); }, tp,
+                        [&](int j, int i, float t) { lh[(j * L + i) * WAVE] = t; },
+                        [&](int k, const Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                lf[(k * 6 + i) * WAVE] = F.la[i][0];
+                                lf[(k * 6 + 3 + i) * WAVE] = F.la[i][1];
+                            }
+                        },
+                        [&](int k, Force &F) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
+                        });
+    wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
+    float *trow = lt + lane * pad_odd(n);
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        if (dof[k] >= 0) trow[dof[k]] = tp[k];
+    for (int k = 0; k < K * L; ++k) {
+        const int d = (w0[P + k] & 0xff) - 1;
+        if (d >= 0) trow[d] = lh[k * WAVE];
+    }
+    wave_lds_sync();
+    tile_store<0>(tau + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) != 0, true);
+}
+
+// the (P, L) this library is compiled for: those of the robots it ships (robot_data/); anything else keeps the loop kernel
+#define DRM_ARM_HAND_SHAPES(X) X(9, 1) X(7, 2) X(8, 4)
+
+static bool shape_of(const drm_walk *w, int &P, int &K, int &L) {
+    if (!(w->shape & DRM_WALK_ARM_HAND)) return false;
+    P = DRM_WALK_AH_P(w->shape); K = DRM_WALK_AH_K(w->shape); L = DRM_WALK_AH_L(w->shape);
+    if (P + K * L != w->n_ops || w->n_ops > AH_MAX_OPS || K * L > 16 || w->n_dofs > w->n_ops) return false;
+#define X(p, l) if (P == p && L == l) return true;
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    return false;
+}
+
+bool arm_hand_compiled(const drm_walk *w) {
+#ifdef DRM_NO_ARM_HAND_KERNEL
+    return false;
+#else
+    int P, K, L;
+    return shape_of(w, P, K, L);
+#endif
+}
+
+// rows covered (full tiles), 0 = the call does not qualify
+int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
+                             hipStream_t s) {
+    int P, K, L;
+    if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || B < WAVE || B / WAVE >= 0x7fffffffLL || (((uintptr_t)w->ops_f) & 15u) != 0)
+        return 0;
+    const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(tau, AL_TAU) | (qdd ? al16(qdd, AL_QDD) : AL_QDD);
+    if (al != (AL_Q | AL_QD | AL_QDD | AL_TAU)) return 0;
+    const int n_tiles = (int)(B / WAVE), n = w->n_dofs;
+#define X(p, l)                                                                                                                   \
+    if (P == p && L == l) {                                                                                                       \
+        hipLaunchKernelGGL((rnea_arm_hand_kernel<p, l>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, qd, qdd, K, \
+                           (int)w->capacity, n, flags, tau, div_magic(n));                                                        \
+        return (int64_t)n_tiles * WAVE;                                                                                           \
+    }
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    return 0;
+}
+
+} // namespace drm

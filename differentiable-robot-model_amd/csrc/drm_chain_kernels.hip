@@ -59,12 +59,14 @@ __device__ __forceinline__ void chain_trig_all(const float (&q)[CAP], float (&cs
     }
 }
 
-// this lane's joint angles, one dword load per op at a wave-uniform column offset (0 for ops that do not move)
+// this lane's joint angles, one dword load per op at a wave-uniform column (ops that do not move: column 0, value dropped).
+// Addressing: uniform base (tile + column, an SGPR pair) + one 32-bit per-lane byte offset shared by all the loads
 template <int CAP, int USED>
-__device__ __forceinline__ void chain_load_q(const float *__restrict__ qrow, const int (&dof)[CAP], float (&qv)[CAP]) {
+__device__ __forceinline__ void chain_load_q(const float *__restrict__ qtile, unsigned row_off, const int (&dof)[CAP], float (&qv)[CAP]) {
+    const char *qb = reinterpret_cast<const char *>(qtile);
 #pragma unroll
     for (int k = 0; k < USED; ++k) {
-        const float v = qrow[dof[k] < 0 ? 0 : dof[k]];
+        const float v = *reinterpret_cast<const float *>(qb + (dof[k] < 0 ? 0 : dof[k]) * 4 + row_off);
         qv[k] = dof[k] < 0 ? 0.0f : v;
     }
 }
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(WAVE)
     chain_dofs<CAP>(ops_i, n_ops, dof);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
-    chain_load_q<CAP, USED>(q + (b0 + lane) * n, dof, qv);
+    chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
     wave_lds_sync();
     float cs[CAP], sn[CAP];
     chain_trig_all<CAP, USED>(qv, cs, sn);
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(WAVE * 4)
     chain_dofs<CAP>(ops_i, n_ops, dof);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
-    chain_load_q<CAP, USED>(q + (b0 + lane) * n, dof, qv);
+    chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
     wave_lds_sync();
     float cs[CAP], sn[CAP];
     chain_trig_all<CAP, USED>(qv, cs, sn);

@@ -364,6 +364,11 @@ int64_t launch_chain_fk_jacobian(const drm_walk *w, const float *q, int64_t B, f
 int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
 int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
 
+// drm_arm_hand.hip: inverse dynamics of DRM_WALK_ARM_HAND walks whose (P, K, L) is compiled in; rows covered, 0 = not taken
+int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
+                             hipStream_t s);
+bool arm_hand_compiled(const drm_walk *w);
+
 template <class K>
 static int ensure_lds(K kernel, size_t bytes) {
     if (bytes > (size_t)64 * 1024) {

@@ -182,6 +182,10 @@ extern "C" int64_t drm_rnea_scratch_floats(const drm_walk *w, int64_t B) {
         B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
         if (B == 0) return 0;
     }
+    if (arm_hand_compiled(w)) {
+        B %= WAVE; // full tiles run the straight-line arm + hand kernel (drm_arm_hand.hip)
+        if (B == 0) return 0;
+    }
     TreeArgs a;
     if (rnea_short_plan(w, a)) return 0;
     RneaRecordsPlan p;
@@ -216,6 +220,23 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
                         tau + done * n, scratch, stream);
     }
 #endif
+    {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel
+        const int64_t done = launch_rnea_arm_hand(w, q, qd, qdd, B, (int)flags, tau, s);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_ARM_HAND;
+            return drm_rnea(&generic, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, tau + done * n,
+                            scratch, stream);
+        }
+    }
+    // drm_rnea_scratch_floats sizes the scratch of a 7-DoF arm chain / an arm with a hand for the ragged tail only (their full
+    // tiles run kernels that need none) — which holds when the fast path is taken, i.e. for 16-byte aligned pointers.  A
+    // misaligned call would send every row through the loop kernel and overrun that scratch: refuse it.
+    if (B >= WAVE && ((((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w)) &&
+        align != (AL_Q | AL_QD | AL_TAU | (qdd ? AL_QDD : 0u)))
+        return fail(DRM_ERR_INVALID, "q / qd / qdd / tau must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;

@@ -935,6 +935,107 @@ DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&c
 }
 
 // ---------------------------------------------------------------------------
+// RNEA of "an arm that carries a hand": P serial prefix ops (the arm, with whatever fixed links sit in it: a base, a
+// flange, a palm) and K serial sub-chains of L ops each that all hang off the LAST prefix op (the fingers of a gripper
+// or a hand; Franka Panda with its gripper: P = 9, K = 2, L = 1; Kinova Jaco: 7, 3, 2; KUKA iiwa7 + Allegro: 8, 4, 4).
+// Straight-line form of drm_tree.hpp rnea_tree_walk for this shape: the prefix is rnea_chain_trig's walk; a sub-chain
+// runs its forward AND backward sweep while the palm's motion is still in registers, so its body forces never leave the
+// registers and only the prefix's are parked (the loop form parks every link: 35 KB of LDS per 64 samples on the arm with
+// a hand, three wavefronts per CU).  Every op is walked as a joint about +z: a fixed op has angle 0, cos = 1, sin = 0
+// (J == F exactly) and zero joint velocity / acceleration, so the shape needs no flags.
+//   row(k)      -> op k's constant row (walk order: prefix, then sub-chain 0, sub-chain 1, ...)
+//   cs / sn / qd / qdd -> of the prefix ops; hq(j, i, q, qd, qdd) -> joint state of op i of sub-chain j, fetched when the
+//                  sub-chain starts (0 for a fixed op)
+//   tau_p[k]    -> generalised force at prefix op k (+ damping); htau(j, i, value) the same for a sub-chain op; the
+//                  caller drops those of fixed ops
+//   fput / fget -> body forces of prefix ops 0 .. P-2 between the sweeps
+// The sub-chains are a ROLLED loop (K is a run-time count): unrolled, the register allocator needed 250 (K = 3, L = 2) to 600
+// (K = 4, L = 4) registers for what is the same 130-register body K times.
+// ---------------------------------------------------------------------------
+//   kind(op)    -> wave-uniform bits of op (walk order): 1 = the joint moves, 2 = it is prismatic (slides along +z by q;
+//                  its torque is the z FORCE at the op).  q[] of the prefix ops is only read for prismatic joints.
+template <int P, int L, class ROW, class KIND, class HQ, class HTAU, class FPUT, class FGET>
+DRM_HD void rnea_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, const float (&q)[P], const float (&cs)[P],
+                          const float (&sn)[P], const float (&qd)[P], const float (&qdd)[P], HQ hq, float (&tau_p)[P], HTAU htau,
+                          FPUT fput, FGET fget) {
+    Motion cur;
+    Force tot;
+    motion_root(cur, gravity ? 9.81f : 0.0f);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        DRM_RNEA_LINK_FENCE();
+        const float *of = row(k);
+        const int kd = kind(k);
+        float J[9], t[3];
+        joint_transform(load_ft(of), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
+        motion_step(J, t, qd[k], qdd[k], kd & 2, cur, cur);
+        Force fk;
+        rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, cur, fk);
+        if (k < P - 1) fput(k, fk);
+        else tot = fk;
+    }
+    // the sub-chains: forward and backward sweep of each while `cur` (the motion of the last prefix op) stays live
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        float hqv[L], hqd[L], hqdd[L], hc[L], hs[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) hq(j, i, hqv[i], hqd[i], hqdd[i]);
+        chain_trig<L>(hqv, hc, hs);
+        Motion M = cur;
+        Force fs[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            DRM_RNEA_LINK_FENCE();
+            const float *of = row(P + j * L + i);
+            const int kd = kind(P + j * L + i);
+            float J[9], t[3];
+            joint_transform(load_ft(of), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+            motion_step(J, t, hqd[i], hqdd[i], kd & 2, M, M);
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, fs[i]);
+        }
+        Force ft = fs[L - 1];
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            DRM_RNEA_LINK_FENCE();
+            const float *of = row(P + j * L + i);
+            const int kd = kind(P + j * L + i);
+            if (i < L - 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ft.la[c] += fs[i].la[c];
+            }
+            htau(j, i, ((kd & 2) ? ft.la[2][0] : ft.la[2][1]) + (damping ? of[DRM_OPF_DAMP] * hqd[i] : 0.0f));
+            float J[9], t[3];
+            joint_transform(load_ft(of), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+            Force up;
+            rnea_link_force_up(J, t, ft, up); // after i = 0: in the frame of the last prefix op
+            ft = up;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tot.la[c] += ft.la[c];
+    }
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) {
+        DRM_RNEA_LINK_FENCE();
+        const float *of = row(k);
+        const int kd = kind(k);
+        if (k < P - 1) {
+            Force fk;
+            fget(k, fk);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tot.la[c] += fk.la[c];
+        }
+        tau_p[k] = ((kd & 2) ? tot.la[2][0] : tot.la[2][1]) + (damping ? of[DRM_OPF_DAMP] * qd[k] : 0.0f);
+        if (k > 0) {
+            float J[9], t[3];
+            joint_transform(load_ft(of), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
+            Force up;
+            rnea_link_force_up(J, t, tot, up);
+            tot = up;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // RNEA of a serial chain, TWO SAMPLES PER LANE.
 //
 // The form above pairs velocity- with acceleration-like quantities of ONE sample, which leaves the genuinely scalar

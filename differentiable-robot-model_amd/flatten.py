@@ -60,6 +60,28 @@ def opf_ti(i: int) -> int:
 
 SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
 SHAPE_SERIAL_CHAIN = 2               # DRM_WALK_SERIAL_CHAIN
+SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top byte, DRM_WALK_AH_PACK)
+
+
+def arm_hand_shape(parent_op, n_ops: int, prismatic) -> int:
+    """DRM_WALK_AH_PACK(P, K, L) when the walk is a serial prefix of P ops carrying K >= 2 serial sub-chains of L ops each, all
+    hanging off op P-1 (an arm with its gripper or hand; prismatic joints welcome), else 0."""
+    if n_ops < 3 or parent_op[0] != -1:
+        return 0
+    breaks = [k for k in range(1, n_ops) if parent_op[k] != k - 1]
+    if not breaks:
+        return 0
+    hub = parent_op[breaks[0]]
+    if hub < 0 or any(parent_op[k] != hub for k in breaks):
+        return 0
+    P = hub + 1
+    K = 1 + len(breaks)
+    if (n_ops - P) % K:
+        return 0
+    L = (n_ops - P) // K
+    if not (1 <= L <= 4 and 2 <= K <= 4 and P <= 15) or breaks != [P + j * L for j in range(1, K)]:
+        return 0
+    return SHAPE_ARM_HAND | (P << 24) | ((K - 1) << 28) | ((L - 1) << 30)
 OPI_STRIDE = 10
 OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS, OPI_W0, OPI_W1 = range(10)
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
@@ -529,7 +551,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
-                       | (min(n_leaves, 255) << 16),
+                       | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
 
 

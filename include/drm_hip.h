@@ -114,6 +114,13 @@ extern "C" {
                                 no save slots, no prismatic joint, the single target is the last op; moving and fixed ops
                                 in any order, any DoF columns.  Walks of capacity 8 / 12 / 16 with this bit take the
                                 straight-line chain kernels (drm_chain_kernels.hip) in drm_fk / drm_fk_jacobian / drm_fk_fanout */
+#define DRM_WALK_ARM_HAND 4 /* "an arm that carries a hand": ops 0 .. P-1 form a serial chain (op 0 off the root) and the remaining
+                              K * L ops are K serial sub-chains of L ops each, every one hanging off op P-1, in walk order.
+                              P, K, L travel in the top byte of shape: */
+#define DRM_WALK_AH_P(shape) ((int)(((uint32_t)(shape) >> 24) & 0xf))
+#define DRM_WALK_AH_K(shape) ((int)(((uint32_t)(shape) >> 28) & 0x3) + 1)
+#define DRM_WALK_AH_L(shape) ((int)(((uint32_t)(shape) >> 30) & 0x3) + 1)
+#define DRM_WALK_AH_PACK(P, K, L) ((uint32_t)DRM_WALK_ARM_HAND | ((uint32_t)(P) << 24) | ((uint32_t)((K) - 1) << 28) | ((uint32_t)((L) - 1) << 30))
 #define DRM_WALK_LEAVES(shape) (((shape) >> 16) & 0xff) /* number of leaf ops (ops no child follows), see DRM_OPI_CTRL */
 #define DRM_WALK_BRANCH_DEPTH(shape) (((shape) >> 8) & 0xff) /* 1 + the largest op index that is a branch
                                 point (0: none): sizes the per-ancestor slot records of drm_crba /

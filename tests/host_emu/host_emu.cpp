@@ -135,6 +135,29 @@ void rnea_arm2_8_7(const drm_walk *w, const float *q, const float *qd, const flo
     }
 }
 
+// the arithmetic of rnea_arm_hand_kernel<P, L> (one sample per lane; K sub-chains of L ops behind a prefix of P ops)
+template <int P, int L>
+void rnea_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
+    const int n = w->n_dofs;
+    const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
+    auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
+    for (int64_t b = 0; b < B; ++b) {
+        auto state = [&](int d, float &a, float &v, float &acc) {
+            a = d < 0 ? 0.f : q[b * n + d]; v = d < 0 ? 0.f : qd[b * n + d]; acc = (d < 0 || !qdd) ? 0.f : qdd[b * n + d];
+        };
+        float qv[P], qdv[P], qddv[P], cs[P], sn[P], tp[P];
+        for (int k = 0; k < P; ++k) state(dof_of(k), qv[k], qdv[k], qddv[k]);
+        chain_trig<P>(qv, cs, sn);
+        Force park[P];
+        auto kind = [&](int op) { const int x = w0[op]; return ((x & 0xff) ? 1 : 0) | (((x >> 26) & 1) << 1); };
+        rnea_arm_hand<P, L>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING,
+                            qv, cs, sn, qdv, qddv, [&](int j, int i, float &a, float &v, float &acc) { state(dof_of(P + j * L + i), a, v, acc); },
+                            tp, [&](int j, int i, float t) { const int d = dof_of(P + j * L + i); if (d >= 0) tau[b * n + d] = t; },
+                            [&](int k, const Force &F) { park[k] = F; }, [&](int k, Force &F) { F = park[k]; });
+        for (int k = 0; k < P; ++k) if (dof_of(k) >= 0) tau[b * n + dof_of(k)] = tp[k];
+    }
+}
+
 struct ParkRec { Force f; float c, s, q; };
 
 void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
@@ -378,6 +401,16 @@ int emu_fk_jacobian_arm(const drm_walk *w, const float *q, int64_t B, float *pos
 int emu_rnea_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
     if (!(w->shape & DRM_WALK_ARM_CHAIN) || w->capacity != 8 || w->n_dofs != 7) return -2;
     rnea_arm_8_7(w, q, qd, qdd, B, flags, tau);
+    return 0;
+}
+int emu_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
+    if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
+    const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (P + K * L != w->n_ops) return -1;
+    if (P == 9 && L == 1) rnea_arm_hand_emu<9, 1>(w, K, q, qd, qdd, B, flags, tau);
+    else if (P == 7 && L == 2) rnea_arm_hand_emu<7, 2>(w, K, q, qd, qdd, B, flags, tau);
+    else if (P == 8 && L == 4) rnea_arm_hand_emu<8, 4>(w, K, q, qd, qdd, B, flags, tau);
+    else return -2;
     return 0;
 }
 int emu_rnea_arm2(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {

@@ -448,6 +448,29 @@ def test_two_samples_per_lane_kernels_every_row_vs_oracle(robot, link):
     assert np.allclose(host(nle), orc.rnea(q64, qd64, np.zeros_like(q64), True, True, np.float64), **TOL_TAU)
 
 
+@pytest.mark.parametrize("robot,compat", [("panda", True), ("panda", False), ("jaco", True), ("iiwa7_allegro", True)])
+def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
+    """drm_arm_hand.hip: the straight-line kernel for P prefix ops + K sub-chains of L ops (Panda with gripper — its fingers as
+    the reference models them and as the prismatic joints they are —, Jaco, iiwa7 + Allegro): full tiles + a ragged tail,
+    every row against the fp64 oracle, all four flag combinations; the non-linear effects (qdd = NULL) too."""
+    from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
+    m = load_model(robot, "cuda", reference_compat=compat)
+    assert m._dynamics_walk().program.shape & SHAPE_ARM_HAND
+    B = 64 * 37 + 11
+    q, qd, qdd = sample_states(m, B, seed=91)
+    orc = Oracle(m._spec)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    for grav in (True, False):
+        for damp in (True, False):
+            tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+            assert np.allclose(host(tau), orc.rnea(q64, qd64, qdd64, grav, damp, np.float64), **TOL_TAU), (robot, grav, damp)
+    nle = m.compute_non_linear_effects(dev(q), dev(qd))
+    assert np.allclose(host(nle), orc.rnea(q64, qd64, np.zeros_like(q64), True, True, np.float64), **TOL_TAU)
+    # rows of full tiles are the same whether or not a tail follows them
+    t_full = m.compute_inverse_dynamics(dev(q[:64 * 37]), dev(qd[:64 * 37]), dev(qdd[:64 * 37]))
+    assert torch.equal(t_full, m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd))[:64 * 37])
+
+
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
     the fp64 oracle (the oracle does 65 536 rows in well under a second)."""

@@ -261,13 +261,22 @@ def test_gpu_scratch_of_the_persistent_kernels():
     walk = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
     for name in SCRATCH_QUERIES:
         small, big, bigger = (int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
+        if name == "drm_rnea_scratch_floats":
+            # inverse dynamics of an arm that carries a hand: full 64-row tiles run the straight-line kernel (drm_arm_hand.hip,
+            # no scratch); only a ragged tail still goes through the persistent loop kernel
+            assert small == big == bigger == 0, (name, small, big, bigger)
+            assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
+            continue
         assert 0 < small < big == bigger < (1 << 28), (name, small, big, bigger)   # < 1 GiB whatever the batch
     B, n = 130, m._n_dofs
     q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(m, B, seed=3))
     out, H = torch.empty(B, n, device="cuda"), torch.empty(B, n, n, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1
-    assert b"scratch" in lib.drm_last_error()
+    assert b"scratch" in lib.drm_last_error()          # (the two rows behind the two full tiles)
+    # ... and a misaligned view is refused outright: the scratch of these walks is sized for the aligned fast path
+    assert lib.drm_rnea(ctypes.byref(walk), q[1:].data_ptr(), qd[1:].data_ptr(), qdd[1:].data_ptr(), B - 1, 3, out[1:].data_ptr(), None, st) == -1
+    assert b"aligned" in lib.drm_last_error()
     assert lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(), None, st) == -1
     assert b"scratch" in lib.drm_last_error()
     assert lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1

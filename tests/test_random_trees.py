@@ -153,9 +153,20 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
     tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
     H = m.compute_lagrangian_inertia_matrix(q)
     acc = m.compute_forward_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
+    arm_hand = bool(m._dynamics_walk().program.shape & SHAPE_ARM_HAND)
     for lo in (0, 70000, 131072 - 65, B - 130):
         sl = slice(lo, lo + 130)
-        assert torch.equal(tau[sl], m.compute_inverse_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)), lo
+        alone = m.compute_inverse_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)
+        if arm_hand:
+            # inverse dynamics of an arm that carries a hand: full 64-row tiles run the straight-line kernel (drm_arm_hand.hip),
+            # only the ragged tail of a launch the persistent loop kernel — the same row is bit-identical wherever the SAME kernel
+            # computes it, and agrees to rounding between the two kernels
+            assert np.allclose(tau[sl].cpu().numpy(), alone.cpu().numpy(), **TOL_TAU), lo
+            if lo % 64 == 0 and lo + 128 <= B - B % 64:
+                assert torch.equal(tau[lo:lo + 128], alone[:128]), lo
+        else:
+            assert torch.equal(tau[sl], alone), lo
         assert torch.equal(H[sl], m.compute_lagrangian_inertia_matrix(q[sl])), lo
         assert torch.equal(acc[sl], m.compute_forward_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)), lo
     rows = [0, 63, 64, 99999, B - 1]
