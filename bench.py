@@ -517,7 +517,9 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         "compute_us_per_step": dev_compute / K * 1e6, "step_us_with_gather": dev_time / K * 1e6,
         "gather_us_per_step": max(0.0, (dev_time - dev_compute) / K * 1e6) if world > 1 else 0.0,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "drm::fk_rnea_arm_kernel<8, 7, 7>", "bytes_per_eval": bytes_per_eval,
+                     "traffic": None,
+                     "kernel": "drm::fk_rnea_arm2_kernel<8, 7, 7> (two samples per lane)" if rows > 1024 * 64
+                               else "drm::fk_rnea_arm_kernel<8, 7, 7>", "bytes_per_eval": bytes_per_eval,
                      "launch_us": launch_s * 1e6,
                      "note": "the fused kernel alone (hipGraph of K launches, HIP events); RNEA sits at the vector-FP32 / HBM "
                              "ridge (2.6 kflop per 140 B), see DESIGN.md"},

@@ -62,6 +62,36 @@ for src, dst in (("kernel_times.txt", "_kernel_times.txt"), ("metric_lab.txt", "
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 
+# round 3 additions: one stats file per batch size, the eagerly launched run, rocprofv3's overhead on kernels of known duration,
+# the two-rank lines (ranks sharing the GPU), which kernel the robot probe dispatches to, the arm-dynamics A/B
+for batch in (65536, 4194304, 16777216):
+    st = glob.glob(os.path.join(OUT, "prof_stats_%d" % batch, "*", "*_kernel_stats.csv"))
+    if st:
+        shutil.copy(st[0], os.path.join(prof, "%s_bench_kernel_stats_%d.csv" % (tag, batch)))
+for d, name in (("prof_stats_eager", "_bench_eager_kernel_stats.csv"), ("prof_overhead", "_overhead_kernel_stats.csv")):
+    st = glob.glob(os.path.join(OUT, d, "*", "*_kernel_stats.csv"))
+    if st:
+        shutil.copy(st[0], os.path.join(prof, tag + name))
+st = glob.glob(os.path.join(OUT, "prof_robots", "*", "*_kernel_stats.csv"))
+if st:
+    with open(st[0]) as f, open(os.path.join(prof, tag + "_probe_robots_rocprof_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or "drm::" in line:
+                g.write(line)
+for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two_ranks_shared_gpu.json"),
+                 ("bench_metric_two_ranks_shared_gpu.json", "_bench_metric_two_ranks_shared_gpu.json"),
+                 ("prof_stats_eager.log", "_bench_eager_under_rocprofv3.json")):
+    line = last_json_line(os.path.join(OUT, src))
+    if line:
+        with open(os.path.join(prof, tag + dst), "w") as f:
+            f.write(line + "\n")
+for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt")):
+    if os.path.exists(os.path.join(OUT, src)):
+        shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
+if os.path.exists(os.path.join(OUT, "overhead_under_rocprofv3.txt")):
+    with open(os.path.join(OUT, "overhead_under_rocprofv3.txt")) as f, open(os.path.join(prof, tag + "_overhead_under_rocprofv3.txt"), "w") as g:
+        g.writelines(ln for ln in f if ln.startswith(("TIME", "EAGER", "device")))
+
 traffic = {"kernel": None, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
                                       "python bench.py --no-cpu-baseline --steps 50 --warmup 5 [--batch B]",
            "per_batch": {}}

@@ -1,12 +1,11 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): rocprofv3 evidence for the bench command.  Raw outputs -> gpurun_out/prof_*/,
-# summarised afterwards by tools/pmc_summary.py <tag> into profiles/.
-#   pass 1: --kernel-trace --stats            (per-kernel durations of the default bench run, JSON line kept)
-#   pass 2: --kernel-trace --pmc FETCH_SIZE    (separate passes: FETCH_SIZE and WRITE_SIZE do not fit together,
-#   pass 3: --kernel-trace --pmc WRITE_SIZE     and counter runs must not be combined with API tracing)
-#   pass 4: SQ counters for the instruction mix (arm kernels: kernel_bench.py, loop-form kernels: kernel_bench3.py)
-#   pass 5: --kernel-trace --stats of tools/kernel_times.py (which kernel every entry point dispatches to)
-# plus the unprofiled lines: bench.py default, bench.py --config 3, tools/kernel_times.py, the metric lab's I/O floor.
+# Run on the GPU box (gpurun -- bash tools/profile_round.sh): every measurement of a round.  Raw outputs -> gpurun_out/,
+# condensed afterwards by tools/pmc_summary.py <tag> into profiles/.
+#   unprofiled lines: bench.py default / driver flags / --config 3 / two ranks sharing the GPU; kernel_times, probe_robots,
+#                     config 5, the A/B of the arm dynamics kernels, the metric lab (I/O floors, rocprofv3's own overhead)
+#   rocprofv3 --kernel-trace --stats: bench default (graph replay), the same eagerly launched, one run per batch size,
+#                     kernel_times + probe_robots (which kernel every entry point dispatches to)
+#   rocprofv3 --pmc:  FETCH_SIZE / WRITE_SIZE (separate passes, never with API tracing), SQ counters of the hot kernels
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -14,11 +13,18 @@ export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline"
 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
-# the same with the flags the round driver passes (a 20-launch timed region)
 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
+python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
+python $ROOT/bench.py --gpus 2 --config 3 --steps 20 --warmup 5 --shared-gpu --verify-gather > $OUT/bench_config3_two_ranks_shared_gpu.json 2> $OUT/bench_config3_two_ranks.err
+python $ROOT/bench.py --gpus 2 --gather --steps 20 --warmup 5 --shared-gpu --verify-gather --no-large --no-cpu-baseline > $OUT/bench_metric_two_ranks_shared_gpu.json 2> $OUT/bench_metric_two_ranks.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_k20 -- $B --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_k20.log 2>&1
+# one stats file per batch size; 65 536 also launched eagerly (graph replays report the tracer's own period, r03_rocprof_overhead.md)
+for batch in 65536 4194304 16777216; do
+  steps=200; [ $batch -gt 65536 ] && steps=50
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$batch -- $B --no-large --batch $batch --steps $steps > $OUT/prof_stats_$batch.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_eager -- $B --no-large --no-graph > $OUT/prof_stats_eager.log 2>&1
 for batch in 65536 4194304; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
@@ -26,15 +32,20 @@ done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
-# robots with one long segment (an arm with its gripper / hand): RNEA, mass matrix, forward dynamics at 262 144 samples
 for r in panda iiwa7_allegro; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench4.py $r 262144 > $OUT/prof_sq4_$r.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
+python $ROOT/tools/ab_rnea.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_rnea.txt
 python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
-[ -x $ROOT/tools/ubench/metric_lab ] && $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
+if [ -x $ROOT/tools/ubench/metric_lab ]; then
+  $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
+  $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_plain.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_overhead -- $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_under_rocprofv3.txt 2>&1
+fi
 cd $ROOT
 # keep what travels back small: per-dispatch counter rows of OUR kernels only
 for f in $(find gpurun_out -name "*counter_collection.csv"); do
@@ -42,4 +53,4 @@ for f in $(find gpurun_out -name "*counter_collection.csv"); do
 done
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 du -sh gpurun_out
-tail -n 3 $OUT/bench_default.json $OUT/bench_config3.json | cut -c1-1500
+tail -c 1200 $OUT/bench_default.json; echo; tail -c 600 $OUT/bench_config3.json; echo; cat $OUT/kernel_times.txt | grep -v amdgpu | tail -30

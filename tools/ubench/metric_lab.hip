@@ -404,6 +404,18 @@ __global__ void __launch_bounds__(256) k_io(const float *__restrict__ q, int n_t
 // ---------------------------------------------------------------------------------------------------------------
 // launch-floor probes
 // ---------------------------------------------------------------------------------------------------------------
+// bytes only, the shape of BASELINE configuration 4 (Allegro, four fingertips): 64 B of q in, 48 B of pos + 64 B of quat out
+// per sample; one block of four waves per 64-sample tile as the fan-out kernel launches it
+template <int FL>
+__global__ void __launch_bounds__(256) k_io_config4(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat) {
+    const unsigned tid = threadIdx.x;
+    const size_t tile = blockIdx.x;
+    const float4 a = reinterpret_cast<const float4 *>(q + tile * 1024)[tid]; // 64 rows x 16 floats = 256 float4
+    float4 v = make_float4(a.x + 1.f, a.y, a.z, a.w);
+    if (tid < 192) store16<FL>(pos + tile * 768 + 4 * tid, v);   // 64 x 12 floats
+    store16<FL>(quat + tile * 1024 + 4 * tid, v);                // 64 x 16 floats
+}
+
 template <int THREADS, int LDS_FLOATS>
 __global__ void __launch_bounds__(THREADS) k_empty(float *out) {
     if constexpr (LDS_FLOATS > 0) {
@@ -561,6 +573,13 @@ int main(int argc, char **argv) {
         auto empty = [&] { hipLaunchKernelGGL((k_empty<256, 0>), dim3(n_tiles), dim3(64), 0, s, dummy); };
         auto io = [&] { hipLaunchKernelGGL((k_io<ST_SC1, true, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang); };
         auto prod = [&] { launch_fk_jacobian_arm(b.ops_f, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang, s); };
+        {   // I/O floor of configuration 4's shape (176 B per sample)
+            float *q16, *p12, *r16;
+            CK(hipMalloc(&q16, (size_t)B * 64)); CK(hipMalloc(&p12, (size_t)B * 48)); CK(hipMalloc(&r16, (size_t)B * 64));
+            CK(hipMemset(q16, 0, (size_t)B * 64));
+            time_graph("io floor, config-4 shape (176 B/sample) sc1", [&] { hipLaunchKernelGGL((k_io_config4<ST_SC1>), dim3(n_tiles), dim3(256), 0, s, q16, p12, r16); }, s);
+            time_graph("io floor, config-4 shape (176 B/sample) plain", [&] { hipLaunchKernelGGL((k_io_config4<ST_PLAIN>), dim3(n_tiles), dim3(256), 0, s, q16, p12, r16); }, s);
+        }
         time_graph("overhead: empty (n_tiles blocks x 64)", empty, s);
         time_graph("overhead: io sc1 rd+wr", io, s);
         time_graph("overhead: product kernel", prod, s);
