@@ -181,7 +181,7 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
 // area it would settle on 170 VGPRs, two short of a third wave per SIMD; the attribute holds it to <= 168
 template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LINKS < CAP ? 3 : 2, LINKS < CAP ? 3 : 2)))
-    fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+    fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ ops_tail, const float *__restrict__ q, const float *__restrict__ qd,
                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
                        float *__restrict__ pos, float *__restrict__ quat) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
@@ -202,7 +202,10 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
     float *lf = lq + lane;
     const int64_t b0 = (int64_t)tile * WAVE;
 
-    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    // rows 0 .. LINKS-1 (the ops the dynamics sweeps visit, with whatever the host folded into them) come from the TREE walk's
+    // table, rows LINKS .. CAP-1 (the fixed tail the FK chain still walks) from the CHAIN walk's: the two tables need not agree
+    // on the inertial columns, and the FT blocks of rows 0 .. LINKS-1 are the same in both (folding never touches them)
+    float4 cv = reinterpret_cast<const float4 *>(lane < LINKS * (DRM_OPF_STRIDE / 4) ? ops_f : ops_tail)[lane];
     float qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
     {
         const int64_t row = (b0 + lane) * NJ;
@@ -259,7 +262,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
 // rnea_chain2_trig on the first LINKS ops; cos / sin shared.
 template <int CAP, int NJ, int LINKS>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_RNEA2_WAVES, DRM_RNEA2_WAVES)))
-    fk_rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+    fk_rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ ops_tail, const float *__restrict__ q, const float *__restrict__ qd,
                         const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau, float *__restrict__ pos,
                         float *__restrict__ quat) {
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
     f2 *lf = reinterpret_cast<f2 *>(lt) + lane;
     const int64_t b0 = (int64_t)tile * TILE2;
 
-    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float4 cv = reinterpret_cast<const float4 *>(lane < LINKS * (DRM_OPF_STRIDE / 4) ? ops_f : ops_tail)[lane]; // as in fk_rnea_arm_kernel
     f2 qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
     {
         const int64_t ra = (b0 + lane) * NJ, rb = ra + (int64_t)WAVE * NJ;
@@ -335,15 +338,15 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
     tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true);
 }
 
-void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                         float *tau, float *pos, float *quat, hipStream_t s) {
 #ifndef DRM_RNEA_ONE_SAMPLE_PER_LANE
     const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0; // pairs of 64-sample tiles: two samples per lane; an odd last tile: the one-sample kernel
     if (n2 > 0) {
         if (links == 7)
-            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau, pos, quat);
+            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat);
         else
-            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau, pos, quat);
+            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat);
     }
     if (n2 > 0) {
         if (!(n_tiles & 1)) return;
@@ -354,9 +357,9 @@ void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const flo
 #endif
     const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
     if (links == 7)
-        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
     else
-        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
 }
 
 } // namespace drm

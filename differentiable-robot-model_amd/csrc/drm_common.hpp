@@ -354,7 +354,7 @@ void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, flo
 inline int arm_links(const drm_walk *w) { return w->n_ops == w->n_dofs ? w->n_dofs : w->capacity; }
 void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s);
-void launch_fk_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
+void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                         float *tau, float *pos, float *quat, hipStream_t s);
 
 // drm_chain_kernels.hip: straight-line kernels for any serial chain of capacity 8 / 12 / 16 (DRM_WALK_SERIAL_CHAIN); they

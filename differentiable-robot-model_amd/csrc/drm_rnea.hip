@@ -277,16 +277,16 @@ extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t 
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(tau, AL_TAU) | al16(pos, AL_POS) |
                            al16(quat, AL_QUAT);
     // a serial 7-DoF arm whose last link is the target.  Two shapes: the tree walk IS the chain (target_op its last op), or
-    // the tree walk holds the moving joints only (the host folded the fixed tail into the last of them and built BOTH tables
-    // from the folded link table, so the chain's first n rows carry the tree's constants): one table either way.
+    // the tree walk holds the moving joints only (the host folded the fixed tail into the last of them).  Either way the
+    // dynamics rows come from the TREE walk's table and only the fixed tail the FK chain still walks from the CHAIN walk's.
     const bool same = target_op == tree->n_ops - 1 && tree->n_ops == chain->n_ops;
     const bool folded = tree->n_ops == n && chain->n_ops > n && (chain->shape & DRM_WALK_ARM_CHAIN) && chain->capacity == 8;
-    const float *table = same ? tree->ops_f : chain->ops_f;
     if ((tree->shape & DRM_WALK_ARM_CHAIN) && tree->capacity == 8 && n == 7 && (same || folded) &&
-        chain->target_perm == 2 && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)table) & 15u) == 0 &&
+        chain->target_perm == 2 && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)tree->ops_f) & 15u) == 0 &&
+        (((uintptr_t)chain->ops_f) & 15u) == 0 &&
         align == (AL_Q | AL_QD | AL_TAU | AL_POS | AL_QUAT | (qdd ? AL_QDD : 0u))) {
         const int n_tiles = (int)(B / WAVE);
-        launch_fk_rnea_arm(table, same ? arm_links(tree) : n, q, qd, qdd, n_tiles, (int)flags, tau, pos, quat, s);
+        launch_fk_rnea_arm(tree->ops_f, chain->ops_f, same ? arm_links(tree) : n, q, qd, qdd, n_tiles, (int)flags, tau, pos, quat, s);
         rc = launched();
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (rc || done == B) return rc;

@@ -358,6 +358,19 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._kin_cache = {}
 
         self._spec: RobotSpec = build_robot_spec(body_params, parent_names, reference_compat=self._reference_compat)
+        if not self._reference_compat:
+            # a drop-in user should know where this engine deliberately departs from upstream's numbers
+            from .flatten import KIND_PRISMATIC
+            sliding = [b.name for i, b in enumerate(self._bodies) if self._spec.kind[i] == KIND_PRISMATIC]
+            skew = [b.name for i, b in enumerate(self._bodies) if self._spec.skew[i]]
+            if sliding or skew:
+                import warnings
+                warnings.warn(
+                    "%s: %s modelled as what the URDF says (prismatic joints slide, joints turn about their true axis); the "
+                    "reference treats every non-fixed joint as an axis-aligned revolute joint (robot_model.py:122-126, "
+                    "rigid_body.py:149-154), so FK / Jacobians / dynamics of these links differ from upstream's.  Pass "
+                    "reference_compat=True for upstream's numbers." % (os.path.basename(urdf_path),
+                                                                       ", ".join(sliding + skew)), stacklevel=2)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._fanout_plans: Dict[tuple, Optional[list]] = {}

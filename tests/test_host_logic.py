@@ -288,3 +288,20 @@ def test_gpu_scratch_of_the_persistent_kernels():
         w = backend._walk_struct(rw.program, r._ops_f(rw), rw.ops_i, r._n_dofs)
         for name in SCRATCH_QUERIES:
             assert getattr(lib, name)(ctypes.byref(w), ctypes.c_int64(1 << 20)) == 0, (robot, name)
+
+
+def test_departures_from_the_reference_are_announced():
+    """A robot whose joints this engine models differently from upstream (prismatic joints that slide) says so once at
+    construction; reference_compat=True, and robots without such joints, stay silent."""
+    import contextlib
+    import io
+    import warnings
+    from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel, robot_description_folder
+    path = lambda r: os.path.join(robot_description_folder, r + ".urdf")
+    with warnings.catch_warnings(record=True) as seen, contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter("always")
+        DifferentiableRobotModel(path("panda"), device="cpu")
+        DifferentiableRobotModel(path("panda"), device="cpu", reference_compat=True)
+        DifferentiableRobotModel(path("iiwa7"), device="cpu")
+    texts = [str(w.message) for w in seen if "reference_compat" in str(w.message)]
+    assert len(texts) == 1 and "panda_leftfinger" in texts[0] and "robot_model.py:122-126" in texts[0]
