@@ -87,24 +87,19 @@ __device__ __forceinline__ void chain_stage_table(const float *__restrict__ ops_
     }
 }
 
-// the chain itself: pose of the last op; B[k] = (z_k, p_k) pairs of every op's frame (what a Jacobian column needs)
-template <int CAP, int USED, bool KEEP_B>
-__device__ __forceinline__ void chain_walk(const float *lc, const float (&cs)[CAP], const float (&sn)[CAP], PoseP &ee,
-                                           f2 (&B)[KEEP_B ? CAP : 1][3]) {
+// the chain itself: pose of the last op; frame(k, B) is handed the (z_k, p_k) pairs of every op's frame as soon as they exist
+template <int CAP, int USED, bool FENCE, class FRAME>
+__device__ __forceinline__ void chain_walk(const float *lc, const float (&cs)[CAP], const float (&sn)[CAP], PoseP &ee, FRAME frame) {
 #pragma unroll
     for (int k = 0; k < USED; ++k) {
-        // a scheduling barrier every other op: without it the compiler hoists the constant reads of all later ops to the
-        // top of the walk (CAP = 16: 210-256 VGPRs, one wave per SIMD); two ops per window keep enough reads in flight
-        if (CAP > 8 || KEEP_B) __builtin_amdgcn_sched_barrier(0);
+        // a scheduling barrier per op: without it the compiler hoists the constant reads of all later ops to the top of the walk
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
         const OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
         f2 J01[3];
         joint_pairs(o, cs[k], sn[k], J01);
         if (k == 0) compose_pairs_root(J01, o, ee);
         else compose_pairs(ee, J01, o, ee);
-        if constexpr (KEEP_B) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) B[k][c] = ee.B[c];
-        }
+        frame(k, ee.B);
     }
 }
 
@@ -129,37 +124,44 @@ __global__ void __launch_bounds__(WAVE)
     float cs[CAP], sn[CAP];
     chain_trig_all<CAP, USED>(qv, cs, sn);
 
-    PoseP ee;
-    f2 Bk[JAC ? CAP : 1][3];
-    chain_walk<CAP, USED, JAC>(lc, cs, sn, ee, Bk);
-    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
-
+    // Jacobian (robot_model.py:651-665): column `dof` of ang_jac is z_k, of lin_jac z_k x (p_e - p_k) = z_k x p_e - z_k x p_k.
+    // z_k goes into the staging tile the moment frame k exists (it IS the ang_jac column); what stays in registers per op is
+    // z_k x p_k, three floats instead of the six of (z_k, p_k) — the difference between two and three waves per SIMD at 10 ops.
+    const int S = 3 * n, Sj = pad_odd(S);
+    float *row = lj + lane * Sj;
+    float zxp[JAC ? USED : 1][3];
     if constexpr (JAC) {
-        const int S = 3 * n, Sj = pad_odd(S);
-        float *row = lj + lane * Sj;
         const uint64_t all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
         if ((dof_mask & all) != all) { // columns of DoFs off the chain are zero in both Jacobians (wave-uniform loop)
             for (int d = 0; d < n; ++d)
                 if (!((dof_mask >> d) & 1ull)) { row[d] = 0.0f; row[n + d] = 0.0f; row[2 * n + d] = 0.0f; }
         }
-#pragma unroll
-        for (int k = 0; k < USED; ++k)
-            if (dof[k] >= 0) { // ang_jac[:, :, dof] = z_k   (robot_model.py:662)
+    }
+    PoseP ee;
+    chain_walk<CAP, USED, (CAP > 8 || JAC)>(lc, cs, sn, ee, [&](int k, const f2 (&B)[3]) {
+        if constexpr (JAC) {
+            const float z[3] = {B[0][0], B[1][0], B[2][0]}, p[3] = {B[0][1], B[1][1], B[2][1]};
+            cross3(z, p, zxp[k]);
+            if (dof[k] >= 0) {
                 float *c = row + dof[k];
-                c[0] = Bk[k][0][0]; c[n] = Bk[k][1][0]; c[2 * n] = Bk[k][2][0];
+                c[0] = z[0]; c[n] = z[1]; c[2 * n] = z[2];
             }
+        }
+    });
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+
+    if constexpr (JAC) {
         wave_lds_sync();
         tile_store<0, NT>(ang + b0 * S, WAVE, S, magic_j, lj, lane, (S & 1) != 0, true);
-        wave_lds_sync(); // the tile has been read before lin_jac is staged over it
+        wave_lds_sync(); // the tile has left; each lane now turns the z_k of ITS row into the lin_jac columns, in place
 #pragma unroll
         for (int k = 0; k < USED; ++k)
-            if (dof[k] >= 0) { // lin_jac[:, :, dof] = z_k x (p_e - p_k)   (robot_model.py:661)
-                const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
-                const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
-                float cr[3];
-                cross3(z, dp, cr);
+            if (dof[k] >= 0) {
                 float *c = row + dof[k];
-                c[0] = cr[0]; c[n] = cr[1]; c[2 * n] = cr[2];
+                const float z[3] = {c[0], c[n], c[2 * n]};
+                float cr[3];
+                cross3(z, pe, cr);
+                c[0] = cr[0] - zxp[k][0]; c[n] = cr[1] - zxp[k][1]; c[2 * n] = cr[2] - zxp[k][2];
             }
     }
     lp[lane * 3 + 0] = pe[0];
@@ -210,8 +212,7 @@ __global__ void __launch_bounds__(WAVE * 4)
     float cs[CAP], sn[CAP];
     chain_trig_all<CAP, USED>(qv, cs, sn);
     PoseP ee;
-    f2 unused[1][3];
-    chain_walk<CAP, USED, false>(lc, cs, sn, ee, unused);
+    chain_walk<CAP, USED, false>(lc, cs, sn, ee, [](int, const f2 (&)[3]) {});
     {
         float *p = lp + (lane * T + wave) * 3;
         p[0] = ee.B[0][1]; p[1] = ee.B[1][1]; p[2] = ee.B[2][1];
