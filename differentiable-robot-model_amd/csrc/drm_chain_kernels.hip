@@ -11,8 +11,8 @@
 //     wave-uniform SGPR value: q is read per lane at a uniform offset, Jacobian columns land at a uniform LDS offset;
 //   * a fixed op is a joint at angle 0 (cos = 1, sin = 0 make J == F exactly): the walk is one basic block for every chain;
 //   * identity padding ops (F = I, t = 0) compose exactly and are simply walked.
-// Chains with a prismatic joint do not qualify (DRM_WALK_SERIAL_CHAIN is not set for them, flatten.py); a ragged tail of
-// B % 64 rows goes through the loop-structured kernel, as for the arm kernels.
+// A prismatic joint (W0 bit 26) keeps J = F and slides its origin along +z by q; its Jacobian column is (z, 0).  A ragged
+// tail of B % 64 rows goes through the loop-structured kernel, as for the arm kernels.
 //
 //   chain_fk_kernel<CAP, JAC, NT>   K1 / K2 of one chain: pos, quat (+ lin_jac, ang_jac [B, 3, n]; columns of DoFs off the
 //                                   chain are zero, robot_model.py:645-648)             one wavefront per 64-sample tile
@@ -25,13 +25,16 @@
 namespace drm {
 
 // DoF column of every op of a serial chain (-1: fixed joint or padding), from the walk's W0 words (wave-uniform)
+//   pris: bit k set <=> op k is a prismatic joint (slides along +z of its frame by q instead of turning about it)
 template <int CAP>
-__device__ __forceinline__ void chain_dofs(const int32_t *__restrict__ ops_i, int n_ops, int (&dof)[CAP]) {
+__device__ __forceinline__ void chain_dofs(const int32_t *__restrict__ ops_i, int n_ops, int (&dof)[CAP], unsigned &pris) {
     const int32_t *w0 = ops_i + DRM_OPI_W0 * CAP; // field-major table of capacity CAP
+    pris = 0u;
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         const int w = w0[k];
         dof[k] = (k < n_ops && !((w >> 25) & 1)) ? (w & 0xff) - 1 : -1;
+        if (dof[k] >= 0 && ((w >> 26) & 1)) pris |= 1u << k;
     }
 }
 
@@ -88,20 +91,28 @@ __device__ __forceinline__ void chain_stage_table(const float *__restrict__ ops_
 }
 
 // the chain itself: pose of the last op; frame(k, B) is handed the (z_k, p_k) pairs of every op's frame as soon as they exist
+// A prismatic op (wave-uniform bit of `pris`) keeps J = F and slides: t += F e_z q (drm_tree.hpp joint_transform).
 template <int CAP, int USED, bool FENCE, class FRAME>
-__device__ __forceinline__ void chain_walk(const float *lc, const float (&cs)[CAP], const float (&sn)[CAP], PoseP &ee, FRAME frame) {
+__device__ __forceinline__ void chain_walk(const float *lc, const float (&q)[CAP], const float (&cs)[CAP], const float (&sn)[CAP],
+                                           unsigned pris, PoseP &ee, FRAME frame) {
 #pragma unroll
     for (int k = 0; k < USED; ++k) {
         // a scheduling barrier per op: without it the compiler hoists the constant reads of all later ops to the top of the walk
         if (FENCE) __builtin_amdgcn_sched_barrier(0);
-        const OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
+        OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
         f2 J01[3];
-        joint_pairs(o, cs[k], sn[k], J01);
+        if ((pris >> k) & 1u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { J01[i] = o.f01[i]; o.f2t[i][1] += o.f2t[i][0] * q[k]; }
+        } else {
+            joint_pairs(o, cs[k], sn[k], J01);
+        }
         if (k == 0) compose_pairs_root(J01, o, ee);
         else compose_pairs(ee, J01, o, ee);
         frame(k, ee.B);
     }
 }
+// (a prismatic joint's sincos is never used; its angle is zeroed before the evaluation so that it cannot trip the large-argument path)
 
 // LDS (dynamic): [ table : CAP x 32 ][ pos : 64 x 3 ][ Jacobian staging : 64 x (3n | 1), ang_jac first, then lin_jac ]
 template <int CAP, int USED, bool JAC, bool NT>
@@ -116,13 +127,16 @@ __global__ void __launch_bounds__(WAVE)
     float *lc = smem, *lp = smem + C_FLOATS, *lj = lp + P_FLOATS;
 
     int dof[CAP];
-    chain_dofs<CAP>(ops_i, n_ops, dof);
+    unsigned pris;
+    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
     chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
     wave_lds_sync();
-    float cs[CAP], sn[CAP];
-    chain_trig_all<CAP, USED>(qv, cs, sn);
+    float cs[CAP], sn[CAP], qa[CAP];
+#pragma unroll
+    for (int k = 0; k < USED; ++k) qa[k] = ((pris >> k) & 1u) ? 0.0f : qv[k];
+    chain_trig_all<CAP, USED>(qa, cs, sn);
 
     // Jacobian (robot_model.py:651-665): column `dof` of ang_jac is z_k, of lin_jac z_k x (p_e - p_k) = z_k x p_e - z_k x p_k.
     // z_k goes into the staging tile the moment frame k exists (it IS the ang_jac column); what stays in registers per op is
@@ -138,13 +152,19 @@ __global__ void __launch_bounds__(WAVE)
         }
     }
     PoseP ee;
-    chain_walk<CAP, USED, (CAP > 8 || JAC)>(lc, cs, sn, ee, [&](int k, const f2 (&B)[3]) {
+    // (a prismatic joint's column is (lin, ang) = (z_k, 0): z_k waits in the registers of z_k x p_k)
+    chain_walk<CAP, USED, (CAP > 8 || JAC)>(lc, qv, cs, sn, pris, ee, [&](int k, const f2 (&B)[3]) {
         if constexpr (JAC) {
             const float z[3] = {B[0][0], B[1][0], B[2][0]}, p[3] = {B[0][1], B[1][1], B[2][1]};
-            cross3(z, p, zxp[k]);
             if (dof[k] >= 0) {
                 float *c = row + dof[k];
-                c[0] = z[0]; c[n] = z[1]; c[2 * n] = z[2];
+                if ((pris >> k) & 1u) {
+                    zxp[k][0] = z[0]; zxp[k][1] = z[1]; zxp[k][2] = z[2];
+                    c[0] = 0.0f; c[n] = 0.0f; c[2 * n] = 0.0f;
+                } else {
+                    cross3(z, p, zxp[k]);
+                    c[0] = z[0]; c[n] = z[1]; c[2 * n] = z[2];
+                }
             }
         }
     });
@@ -158,10 +178,14 @@ __global__ void __launch_bounds__(WAVE)
         for (int k = 0; k < USED; ++k)
             if (dof[k] >= 0) {
                 float *c = row + dof[k];
-                const float z[3] = {c[0], c[n], c[2 * n]};
-                float cr[3];
-                cross3(z, pe, cr);
-                c[0] = cr[0] - zxp[k][0]; c[n] = cr[1] - zxp[k][1]; c[2 * n] = cr[2] - zxp[k][2];
+                if ((pris >> k) & 1u) {
+                    c[0] = zxp[k][0]; c[n] = zxp[k][1]; c[2 * n] = zxp[k][2];
+                } else {
+                    const float z[3] = {c[0], c[n], c[2 * n]};
+                    float cr[3];
+                    cross3(z, pe, cr);
+                    c[0] = cr[0] - zxp[k][0]; c[n] = cr[1] - zxp[k][1]; c[2 * n] = cr[2] - zxp[k][2];
+                }
             }
     }
     lp[lane * 3 + 0] = pe[0];
@@ -204,15 +228,18 @@ __global__ void __launch_bounds__(WAVE * 4)
     const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
 
     int dof[CAP];
-    chain_dofs<CAP>(ops_i, n_ops, dof);
+    unsigned pris;
+    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
     chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
     wave_lds_sync();
-    float cs[CAP], sn[CAP];
-    chain_trig_all<CAP, USED>(qv, cs, sn);
+    float cs[CAP], sn[CAP], qa[CAP];
+#pragma unroll
+    for (int k = 0; k < USED; ++k) qa[k] = ((pris >> k) & 1u) ? 0.0f : qv[k];
+    chain_trig_all<CAP, USED>(qa, cs, sn);
     PoseP ee;
-    chain_walk<CAP, USED, false>(lc, cs, sn, ee, [](int, const f2 (&)[3]) {});
+    chain_walk<CAP, USED, false>(lc, qv, cs, sn, pris, ee, [](int, const f2 (&)[3]) {});
     {
         float *p = lp + (lane * T + wave) * 3;
         p[0] = ee.B[0][1]; p[1] = ee.B[1][1]; p[2] = ee.B[2][1];

@@ -540,7 +540,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
            and all(row[OPI_DOF] == (k if k < n else -1) and row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV)
                    for k, row in enumerate(ops)))
     # DRM_WALK_SERIAL_CHAIN: one root-to-target chain, whatever its joints (the straight-line chain kernels take it)
-    serial = (n_ops >= 1 and not any(prismatic) and max_used == 0
+    serial = (n_ops >= 1 and max_used == 0
               and all(row[OPI_SRC] == (SRC_ROOT if k == 0 else SRC_PREV) and row[OPI_SAVE] < 0 for k, row in enumerate(ops))
               and all((row[OPI_OUT] >= 0) == (k == n_ops - 1) for k, row in enumerate(ops)))
     # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
