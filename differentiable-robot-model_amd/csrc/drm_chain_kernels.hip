@@ -41,11 +41,11 @@ __device__ __forceinline__ void chain_dofs(const int32_t *__restrict__ ops_i, in
 // cos / sin of the joint angle of every op, two ops per packed evaluation.  Ops that do not move carry the angle 0 and are
 // evaluated like the others (cos 0 = 1, sin 0 = 0 exactly): skipping them pair by pair behind wave-uniform branches was
 // tried and costs more than it saves — the merges after every branch triple the register count of the 16-op kernel
-// USED (even, CAP - 2 or CAP): ops USED .. CAP-1 are known to be padding (the launcher picks the instantiation from n_ops)
+// USED: ops USED .. CAP-1 are known to be padding (the launcher picks the instantiation from n_ops)
 // and are neither evaluated nor walked
 template <int CAP, int USED>
 __device__ __forceinline__ void chain_trig_all(const float (&q)[CAP], float (&cs)[CAP], float (&sn)[CAP]) {
-    static_assert(!(USED & 1) && USED <= CAP, "ops are evaluated in pairs");
+    static_assert(USED <= CAP, "ops USED .. CAP-1 are padding");
     bool big = false;
 #pragma unroll
     for (int k = 0; k < USED; ++k) big = big || !(fabsf(q[k]) <= SINCOS_PAIR_MAX_ARG);
@@ -57,8 +57,9 @@ __device__ __forceinline__ void chain_trig_all(const float (&q)[CAP], float (&cs
 #pragma unroll
     for (int k = 0; k < USED; k += 2) {
         f2 s2, c2;
-        sincos_pair(f2_make(q[k], q[k + 1]), s2, c2);
-        sn[k] = s2[0]; cs[k] = c2[0]; sn[k + 1] = s2[1]; cs[k + 1] = c2[1];
+        sincos_pair(f2_make(q[k], q[k + 1 < USED ? k + 1 : k]), s2, c2);
+        sn[k] = s2[0]; cs[k] = c2[0];
+        if (k + 1 < USED) { sn[k + 1] = s2[1]; cs[k + 1] = c2[1]; }
     }
 }
 
@@ -332,10 +333,13 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
         if (w->n_ops > longest) longest = w->n_ops;
     }
     const int n_tiles = (int)(B / WAVE);
-    if (longest <= 6)
-        hipLaunchKernelGGL((fk_fan_chain_kernel<8, 6>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat);
-    else
-        hipLaunchKernelGGL((fk_fan_chain_kernel<8, 8>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat);
+    // the instantiation that walks exactly the longest chain's ops (shorter chains of the same launch walk identity padding)
+#define FAN(U) hipLaunchKernelGGL((fk_fan_chain_kernel<8, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat)
+    if (longest <= 5) FAN(5);
+    else if (longest == 6) FAN(6);
+    else if (longest == 7) FAN(7);
+    else FAN(8);
+#undef FAN
     return (int64_t)n_tiles * WAVE;
 #endif
 }
