@@ -1,4 +1,4 @@
-// drm_chain_kernels.hip — straight-line, register-resident kernels for ANY serial chain of up to 16 ops (round 3).
+// drm_chain_kernels.hip — straight-line, register-resident kernels for ANY serial chain of up to 16 ops (round 3; walk capacities 4 / 8 / 12 / 16).
 //
 // The 7-DoF arm kernels (drm_arm_kernels.hip) are compiled for one shape: ops 0..6 moving and driving DoF columns 0..6.
 // Every other chain — the arm of a Panda WITH its gripper up to a fingertip (11 ops, 9 DoF columns), a Jaco finger (13),
@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(WAVE * 4)
 
 // ---- launchers (called by drm_fk / drm_fk_jacobian / drm_fk_fanout); return the rows they covered (full tiles), 0 = not taken
 static bool chain_ok(const drm_walk *w) {
-    return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->capacity == 8 || w->capacity == 12 || w->capacity == 16) && w->n_ops >= 1 &&
+    return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->capacity == 4 || w->capacity == 8 || w->capacity == 12 || w->capacity == 16) &&
+           w->n_ops >= 1 &&
            w->n_slots == 0 && (((uintptr_t)w->ops_f) & 15u) == 0 && w->target_perm >= 0 && w->target_perm <= 5;
 }
 
@@ -283,7 +284,7 @@ static void launch_chain_used(const drm_walk *w, const float *q, int n_tiles, fl
 // the instantiation whose walked ops (USED = CAP - 2 or CAP) cover the chain's n_ops
 template <int CAP, bool JAC>
 static void launch_chain(const drm_walk *w, const float *q, int n_tiles, float *pos, float *quat, float *lin, float *ang, hipStream_t s) {
-    if (w->n_ops <= CAP - 2) launch_chain_used<CAP, CAP - 2, JAC>(w, q, n_tiles, pos, quat, lin, ang, s);
+    if (CAP > 4 && w->n_ops <= CAP - 2) launch_chain_used<CAP, (CAP > 4 ? CAP - 2 : CAP), JAC>(w, q, n_tiles, pos, quat, lin, ang, s);
     else launch_chain_used<CAP, CAP, JAC>(w, q, n_tiles, pos, quat, lin, ang, s);
 }
 
@@ -297,7 +298,8 @@ int64_t launch_chain_fk_jacobian(const drm_walk *w, const float *q, int64_t B, f
         w->n_dofs > 32)
         return 0;
     const int n_tiles = (int)(B / WAVE);
-    if (w->capacity == 8) launch_chain<8, true>(w, q, n_tiles, pos, quat, lin, ang, s);
+    if (w->capacity == 4) launch_chain<4, true>(w, q, n_tiles, pos, quat, lin, ang, s);
+    else if (w->capacity == 8) launch_chain<8, true>(w, q, n_tiles, pos, quat, lin, ang, s);
     else if (w->capacity == 12) launch_chain<12, true>(w, q, n_tiles, pos, quat, lin, ang, s);
     else launch_chain<16, true>(w, q, n_tiles, pos, quat, lin, ang, s);
     return (int64_t)n_tiles * WAVE;
@@ -311,7 +313,8 @@ int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos
     const uint32_t al = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
     if (!chain_ok(w) || al != (AL_Q | AL_POS | AL_QUAT) || B < WAVE || B / WAVE >= 0x7fffffffLL) return 0;
     const int n_tiles = (int)(B / WAVE);
-    if (w->capacity == 8) launch_chain<8, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
+    if (w->capacity == 4) launch_chain<4, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
+    else if (w->capacity == 8) launch_chain<8, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
     else if (w->capacity == 12) launch_chain<12, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
     else launch_chain<16, false>(w, q, n_tiles, pos, quat, nullptr, nullptr, s);
     return (int64_t)n_tiles * WAVE;

@@ -112,7 +112,7 @@ extern "C" {
                                 0..n_dofs-1 in order, every later op is a fixed joint or padding  */
 #define DRM_WALK_SERIAL_CHAIN 2 /* a serial chain of ANY shape: op 0 hangs off the root, every other op off the previous one,
                                 no save slots, the single target is the last op; revolute, prismatic and fixed ops
-                                in any order, any DoF columns.  Walks of capacity 8 / 12 / 16 with this bit take the
+                                in any order, any DoF columns.  Walks of capacity 4 / 8 / 12 / 16 with this bit take the
                                 straight-line chain kernels (drm_chain_kernels.hip) in drm_fk / drm_fk_jacobian / drm_fk_fanout */
 #define DRM_WALK_ARM_HAND 4 /* "an arm that carries a hand": ops 0 .. P-1 form a serial chain (op 0 off the root) and the remaining
                               K * L ops are K serial sub-chains of L ops each, every one hanging off op P-1, in walk order.

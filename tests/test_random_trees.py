@@ -175,3 +175,37 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
     assert np.allclose(tau[rows].cpu().numpy(), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
     assert np.allclose(H[rows].cpu().numpy(), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU)
     assert rel(acc[rows].cpu().numpy(), orc.forward_dynamics(q64, qd64, qdd64, True, True, np.float64)) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_gpu_random_tree_fk_and_jacobian_to_every_link_vs_oracle(tmp_path, seed):
+    """The root-to-link walk of ANY link is a serial chain, so on these random trees (revolute / prismatic / fixed joints in any
+    order, skew axes as two ops, arbitrary DoF numbering, chains of 1 .. 20+ ops) `compute_fk_and_jacobian` runs the
+    straight-line chain kernels (drm_chain_kernels.hip, capacities 4 / 8 / 12 / 16) for full tiles and the loop kernel for the
+    ragged tail and for longer chains: every link, every row against the fp64 oracle; FK alone (drm_fk) must return the
+    same pose."""
+    from differentiable_robot_model_amd.flatten import SHAPE_SERIAL_CHAIN
+    from helpers import TOL_JAC, TOL_POS, TOL_QUAT, quat_close
+    mc, m = tree_model(tmp_path, seed), tree_model(tmp_path, seed, "cuda")
+    B = 64 * 3 + 5
+    q, _, _ = sample_states(mc, B, seed=seed)
+    q64 = q.astype(np.float64)
+    orc = Oracle(mc._spec)
+    dq = torch.from_numpy(q).cuda()
+    took_chain_kernel = 0
+    for idx, body in enumerate(mc._bodies):
+        if idx == 0:
+            continue
+        prog = build_walk(mc._spec, targets=[idx])
+        assert prog.shape & SHAPE_SERIAL_CHAIN, (seed, body.name)
+        took_chain_kernel += prog.capacity in (4, 8, 12, 16)
+        pos, quat, lin, ang = m.compute_fk_and_jacobian(dq, body.name)
+        rp, rq, rl, ra = orc.fk_jacobian(q64, idx, np.float64)
+        scale = max(1.0, float(np.abs(rp).max()))
+        assert np.abs(pos.cpu().numpy() - rp).max() <= TOL_POS["atol"] * scale, (seed, body.name)
+        assert quat_close(quat.cpu().numpy(), rq, 2 * TOL_QUAT["atol"])[0], (seed, body.name)
+        assert np.abs(lin.cpu().numpy() - rl).max() <= TOL_JAC["atol"] * scale and np.abs(ang.cpu().numpy() - ra).max() <= TOL_JAC["atol"], (seed, body.name)
+        p2, r2 = m.compute_forward_kinematics(dq, body.name)
+        assert np.abs(p2.cpu().numpy() - rp).max() <= TOL_POS["atol"] * scale and quat_close(r2.cpu().numpy(), rq, 2 * TOL_QUAT["atol"])[0]
+    assert took_chain_kernel > 0
