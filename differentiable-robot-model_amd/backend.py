@@ -124,6 +124,18 @@ def _check(rc: int):
         raise KernelUnsupported(text) if rc == -2 else RuntimeError(text)
 
 
+def _plan_input(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
+    """A plan launches on the caller's OWN buffers (an MPC loop writes the next state into them and replays): the tensor must
+    already be what the kernels take — fp32, contiguous, 16-byte aligned — because a silent copy would detach the plan from
+    the buffer the caller keeps writing to."""
+    out = _dev_f32(t, name, cols)
+    if out.data_ptr() != t.data_ptr():
+        raise ValueError("%s of a plan must be a contiguous, 16-byte aligned fp32 tensor (got dtype %s, contiguous %s, data_ptr %% 16 = %d): "
+                         "a plan launches on the caller's own buffer and cannot work on a copy"
+                         % (name, t.dtype, t.is_contiguous(), t.data_ptr() & 15))
+    return out
+
+
 def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
         raise RuntimeError("%s must be a tensor on a HIP device (got %s)" % (name, getattr(t, "device", type(t))))
@@ -448,7 +460,7 @@ class FkJacobianPlan(object):
 
     def __init__(self, prog: WalkProgram, ops_f, ops_i, q, n_dofs: int, want_pose: bool = True):
         self._lib = load_library()
-        self.q = _dev_f32(q, "q", n_dofs)
+        self.q = _plan_input(q, "q", n_dofs)
         B = self.q.shape[0]
         dev = self.q.device
         self.pos = torch.empty(B, 3, device=dev) if want_pose else None
@@ -482,8 +494,8 @@ class FkInverseDynamicsPlan(object):
                  outputs=None):
         # tree / chain: (WalkProgram, ops_f, ops_i) of the whole-tree walk and of the root -> link walk
         self._lib = load_library()
-        self.q, self.qd = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs)
-        self.qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+        self.q, self.qd = _plan_input(q, "q", n_dofs), _plan_input(qd, "qd", n_dofs)
+        self.qdd = _plan_input(qdd, "qdd", n_dofs) if qdd is not None else None
         B, dev = self.q.shape[0], self.q.device
         if self.qd.shape[0] != B or (self.qdd is not None and self.qdd.shape[0] != B):
             raise ValueError("q / qd / qdd batch sizes differ")
@@ -523,8 +535,8 @@ class InverseDynamicsPlan(object):
 
     def __init__(self, prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
         self._lib = load_library()
-        self.q, self.qd = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs)
-        self.qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
+        self.q, self.qd = _plan_input(q, "q", n_dofs), _plan_input(qd, "qd", n_dofs)
+        self.qdd = _plan_input(qdd, "qdd", n_dofs) if qdd is not None else None
         B, dev = self.q.shape[0], self.q.device
         if self.qd.shape[0] != B or (self.qdd is not None and self.qdd.shape[0] != B):
             raise ValueError("q / qd / qdd batch sizes differ")

@@ -305,3 +305,26 @@ def test_departures_from_the_reference_are_announced():
         DifferentiableRobotModel(path("iiwa7"), device="cpu")
     texts = [str(w.message) for w in seen if "reference_compat" in str(w.message)]
     assert len(texts) == 1 and "panda_leftfinger" in texts[0] and "robot_model.py:122-126" in texts[0]
+
+
+@pytest.mark.gpu
+def test_gpu_plans_refuse_buffers_they_would_have_to_copy():
+    """A prepared launch works on the caller's own q / qd / qdd (an MPC loop overwrites them and replays); a misaligned row
+    slice or a non-fp32 tensor would have to be copied, which would silently detach the plan from the caller's buffer."""
+    import torch
+    from helpers import load_model
+    m = load_model("panda_no_gripper", "cuda")
+    q = torch.zeros(130, 7, device="cuda")
+    plan = m.plan_fk_and_jacobian(q, "panda_virtual_ee_link")
+    assert plan.q.data_ptr() == q.data_ptr()
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        m.plan_fk_and_jacobian(q[1:], "panda_virtual_ee_link")
+    with pytest.raises(ValueError, match="own buffer"):
+        m.plan_inverse_dynamics(q.double(), q, q)
+    # the eager API takes the same slice (the binding clones it)
+    pos, quat, lin, ang = m.compute_fk_and_jacobian(q[1:], "panda_virtual_ee_link")
+    assert torch.equal(pos, plan_out(m, q)[0][1:])
+
+
+def plan_out(m, q):
+    return m.compute_fk_and_jacobian(q, "panda_virtual_ee_link")
