@@ -13,6 +13,7 @@
 // Build flags as drm_arm_dynamics.hip (kernel-argument preload, no SLP vectoriser).
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_tree.hpp"
 
 namespace drm {
 
@@ -90,6 +91,73 @@ __global__ void __launch_bounds__(WAVE)
     tile_store<0>(tau + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) != 0, true);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K8 (forward dynamics) of the same shapes: the articulated-body recursion of drm_tree.hpp aba_arm_hand — prefix records in
+// one 8-float LDS slot per op (velocities, then U, 1/D, u), sub-chains visited twice instead of stored: no scratch, 14-18 KB
+// of LDS per wave.  The loop form (forward_dynamics_aba_kernel) needs HBM scratch and holds five wavefronts per CU.
+// LDS (static): [ table ][ slots : P x 8 x 64 | qdd tile : 64 x (n | 1) staged over them once sweep 3 of the prefix is done ]
+// ---------------------------------------------------------------------------------------------------
+template <int P, int L>
+__global__ void __launch_bounds__(WAVE)
+    forward_dynamics_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
+                                     const float *__restrict__ qd, const float *__restrict__ f, int K, int cap, int n, int flags,
+                                     float *__restrict__ qdd, uint32_t magic_n) {
+    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE;
+    constexpr int SLOTS = P * 8 * WAVE, TILE = round4(WAVE * pad_odd(AH_MAX_OPS));
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + (SLOTS > TILE ? SLOTS : TILE)];
+    const unsigned lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    const int n_ops = P + K * L;
+    float *lc = smem, *lt = smem + C_FLOATS;
+    float *ls = lt + lane; // prefix slots: [op][8][64]
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
+
+    int dof[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
+    for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
+        reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    const unsigned row_off = lane * (unsigned)n * 4u;
+    const char *qb = reinterpret_cast<const char *>(q + b0 * n), *qdb = reinterpret_cast<const char *>(qd + b0 * n),
+               *fb = reinterpret_cast<const char *>(f + b0 * n);
+    auto joint_state = [&](int d, float &a, float &v, float &t) {
+        const int c = (d < 0 ? 0 : d) * 4;
+        const float x = *reinterpret_cast<const float *>(qb + c + row_off), y = *reinterpret_cast<const float *>(qdb + c + row_off),
+                    z = *reinterpret_cast<const float *>(fb + c + row_off);
+        a = d < 0 ? 0.0f : x; v = d < 0 ? 0.0f : y; t = d < 0 ? 0.0f : z;
+    };
+    float qv[P], qdv[P], fv[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) joint_state(dof[k], qv[k], qdv[k], fv[k]);
+    wave_lds_sync();
+    float cs[P], sn[P], out[P];
+    chain_trig<P>(qv, cs, sn);
+    auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
+    float *trow = lt + lane * pad_odd(n);
+    bool tile_open = false; // the slots turn into the qdd tile once the prefix's third sweep has read its last record
+    aba_arm_hand<P, L>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY,
+                       flags & DRM_RNEA_DAMPING, qv, cs, sn, qdv, fv,
+                       [&](int j, int i, float &a, float &v, float &t) { joint_state((w0[P + j * L + i] & 0xff) - 1, a, v, t); }, out,
+                       [&](int j, int i, float a) {
+                           if (!tile_open) { wave_lds_sync(); tile_open = true; }
+                           trow[(w0[P + j * L + i] & 0xff) - 1] = a;
+                       },
+                       [&](int k, const float *s8) {
+#pragma unroll
+                           for (int c = 0; c < 8; ++c) ls[(k * 8 + c) * WAVE] = s8[c];
+                       },
+                       [&](int k, float *s8) {
+#pragma unroll
+                           for (int c = 0; c < 8; ++c) s8[c] = ls[(k * 8 + c) * WAVE];
+                       });
+    if (!tile_open) wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        if (dof[k] >= 0) trow[dof[k]] = out[k];
+    wave_lds_sync();
+    tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) != 0, true);
+}
+
 // the (P, L) this library is compiled for: those of the robots it ships (robot_data/); anything else keeps the loop kernel
 #define DRM_ARM_HAND_SHAPES(X) X(9, 1) X(7, 2) X(8, 4)
 
@@ -130,6 +198,30 @@ int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd,
     DRM_ARM_HAND_SHAPES(X)
 #undef X
     return 0;
+}
+
+// forward dynamics: rows covered (full tiles), 0 = the call does not qualify
+int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags,
+                                         float *qdd, hipStream_t s) {
+#ifdef DRM_NO_ARM_HAND_FD
+    return 0;
+#else
+    int P, K, L;
+    if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || B < WAVE || B / WAVE >= 0x7fffffffLL || (((uintptr_t)w->ops_f) & 15u) != 0)
+        return 0;
+    const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
+    if (al != (AL_Q | AL_QD | AL_QDD | AL_TAU)) return 0;
+    const int n_tiles = (int)(B / WAVE), n = w->n_dofs;
+#define X(p, l)                                                                                                                   \
+    if (P == p && L == l) {                                                                                                       \
+        hipLaunchKernelGGL((forward_dynamics_arm_hand_kernel<p, l>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, qd, \
+                           f, K, (int)w->capacity, n, flags, qdd, div_magic(n));                                                  \
+        return (int64_t)n_tiles * WAVE;                                                                                           \
+    }
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    return 0;
+#endif
 }
 
 } // namespace drm

@@ -314,6 +314,10 @@ extern "C" int64_t drm_forward_dynamics_scratch_floats(const drm_walk *w, int64_
         B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
         if (B == 0) return 0;
     }
+    if (arm_hand_compiled(w)) {
+        B %= WAVE; // full tiles run the straight-line arm + hand kernel (drm_arm_hand.hip), which needs no scratch
+        if (B == 0) return 0;
+    }
     TreeArgs a;
     if (fd_short_plan(w, a)) return 0;
     AbaPlan p;
@@ -352,6 +356,21 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
                                     scratch, stream);
     }
 #endif
+    {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel
+        const int64_t done = launch_forward_dynamics_arm_hand(w, q, qd, f, B, (int)flags, qdd, (hipStream_t)stream);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_ARM_HAND;
+            return drm_forward_dynamics(&generic, q + done * n, qd + done * n, f + done * n, B - done, flags, qdd + done * n, scratch,
+                                        stream);
+        }
+    }
+    // (as in drm_rnea: the scratch of these walks is sized for the aligned fast path — refuse what would overrun it)
+    if (B >= WAVE && ((((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w)) &&
+        (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd) & 15u) != 0)
+        return fail(DRM_ERR_INVALID, "q / qd / f / qdd must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;

@@ -799,4 +799,175 @@ DRM_HD void aba_tree_walk(int p_end, int a, int b, CTL ctl, ROW row, int flags, 
     down(true);
 }
 
+// ---------------------------------------------------------------------------
+// Forward dynamics of "an arm that carries a hand" (DRM_WALK_ARM_HAND: P serial prefix ops, K serial sub-chains of L ops
+// hanging off the last prefix op) by the articulated-body recursion, straight-line for the shape (round 3).
+// The loop form above keeps 8 floats per op between its sweeps in HBM scratch and decodes control words per op; here
+//   * the prefix keeps its velocities (sweep 1 -> 2) and then U, 1/D, u (sweep 2 -> 3) in ONE 8-float LDS slot per op;
+//   * a sub-chain never stores anything: its sweeps 1 + 2 run once to hand the palm its articulated inertia and bias force,
+//     and once more — when the palm's acceleration is known — to rebuild U, 1/D, u in registers for its sweep 3.  The second
+//     evaluation costs the sub-chains' sweep 2 again (~half of the work of a hand) and buys a kernel without scratch whose
+//     LDS footprint is the prefix alone.
+//   row(op), kind(op) (1 = moves, 2 = prismatic)   as in rnea_arm_hand
+//   q / cs / sn / qd / fj of the prefix ops (fj = joint torque);  hq(j, i, q, qd, f) of a sub-chain op
+//   out_p[k], hout(j, i, qdd)   joint accelerations (the caller drops those of fixed ops)
+//   sput(k, s[8]) / sget(k, s[8])   the prefix's per-op LDS slot
+// ---------------------------------------------------------------------------
+DRM_HD Motion velocity_halves(const Motion &M) { // (w, 0), (v, 0): what the bias force v x* (I v) and c = v x (S qd) are built from
+    Motion V;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { V.wa[i] = f2_make(M.wa[i][0], 0.0f); V.va[i] = f2_make(M.va[i][0], 0.0f); }
+    return V;
+}
+// qdd of a moving op from its record and the acceleration a' = X a_parent + c that sweep 3 has just formed in `cur`
+DRM_HD float aba_joint_acceleration(const float *rec, bool prismatic, Motion &cur) {
+    float dot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dot += rec[i] * cur.va[i][1] + rec[3 + i] * cur.wa[i][1];
+    const float qdd = (rec[7] - dot) * rec[6];
+    if (prismatic) cur.va[2][1] += qdd;
+    else cur.wa[2][1] += qdd;
+    return qdd;
+}
+template <int P, int L, class ROW, class KIND, class HQ, class HOUT, class SPUT, class SGET>
+DRM_HD void aba_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, const float (&q)[P], const float (&cs)[P],
+                         const float (&sn)[P], const float (&qd)[P], const float (&fj)[P], HQ hq, float (&out_p)[P], HOUT hout,
+                         SPUT sput, SGET sget) {
+    auto prefix_joint = [&](int k, float *J, float *t) {
+        const int kd = kind(k);
+        joint_transform(load_ft(row(k)), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
+    };
+    // ---- sweep 1 of the prefix: velocities --------------------------------------------------------------------------
+    Motion cur;
+    motion_root(cur, 0.0f);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        DRM_RNEA_LINK_FENCE();
+        float J[9], t[3];
+        prefix_joint(k, J, t);
+        motion_step(J, t, qd[k], 0.0f, kind(k) & 2, cur, cur);
+        const float s[8] = {cur.wa[0][0], cur.wa[1][0], cur.wa[2][0], cur.va[0][0], cur.va[1][0], cur.va[2][0], 0.0f, 0.0f};
+        sput(k, s);
+    }
+    // sweeps 1 + 2 of sub-chain j from the palm's motion; recs != nullptr: keep U, 1/D, u of its ops; returns what it hands up
+    auto sub_chain_up = [&](int j, const Motion &palm, const float (&hqv)[L], const float (&hqd)[L], const float (&hf)[L],
+                            const float (&hc)[L], const float (&hs)[L], float (*recs)[8], ArtBody &handed) {
+        Motion M = palm, v[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            DRM_RNEA_LINK_FENCE();
+            const int op = P + j * L + i, kd = kind(op);
+            float J[9], t[3];
+            joint_transform(load_ft(row(op)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+            motion_step(J, t, hqd[i], 0.0f, kd & 2, M, M);
+            v[i] = velocity_halves(M);
+        }
+        ArtBody carry;
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            DRM_RNEA_LINK_FENCE();
+            const int op = P + j * L + i, kd = kind(op);
+            const float *of = row(op);
+            ArtBody tot;
+            art_from_link(of, tot.I);
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, v[i], tot.p);
+            if (i < L - 1) art_add(tot, carry);
+            float J[9], t[3];
+            joint_transform(load_ft(of), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+            // f - damping qd as ONE rounding: on a finger both terms are ~3 N m and their difference ~0.02, and 1 / D of a fingertip
+            // is 6e4 — a separately rounded product costs two digits of the distal accelerations (the loop form's `fjoint -= d qd`
+            // is contracted into the same FMA by the compiler; a select in between would keep it from doing so here)
+            const float fjoint = !(kd & 1) ? 0.0f : (damping ? __builtin_fmaf(-of[DRM_OPF_DAMP], hqd[i], hf[i]) : hf[i]);
+            float rec[8];
+            ArtBody up;
+            const bool want_up = (recs == nullptr) || i > 0;
+            aba_eliminate(kd & 1, kd & 2, J, t, hqd[i], fjoint, v[i], tot, rec, want_up, up);
+            if (recs != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) recs[i][c] = rec[c];
+            }
+            if (want_up) carry = up;
+        }
+        handed = carry;
+    };
+    // ---- first visit of the sub-chains: what they hand to the palm ---------------------------------------------------
+    const Motion palm_v = velocity_halves(cur);
+    ArtBody acc;
+    art_zero(acc);
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        float hqv[L], hqd[L], hf[L], hc[L], hs[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) hq(j, i, hqv[i], hqd[i], hf[i]);
+        chain_trig<L>(hqv, hc, hs);
+        ArtBody up;
+        sub_chain_up(j, palm_v, hqv, hqd, hf, hc, hs, nullptr, up);
+        art_add(acc, up);
+    }
+    // ---- sweep 2 of the prefix ----------------------------------------------------------------------------------------
+    {
+        ArtBody carry = acc;
+#pragma unroll
+        for (int k = P - 1; k >= 0; --k) {
+            DRM_RNEA_LINK_FENCE();
+            const float *of = row(k);
+            const int kd = kind(k);
+            float s[8];
+            sget(k, s);
+            Motion vel;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { vel.wa[i] = f2_make(s[i], 0.0f); vel.va[i] = f2_make(s[3 + i], 0.0f); }
+            ArtBody tot;
+            art_from_link(of, tot.I);
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, vel, tot.p);
+            art_add(tot, carry);
+            float J[9], t[3];
+            prefix_joint(k, J, t);
+            const float fjoint = !(kd & 1) ? 0.0f : (damping ? __builtin_fmaf(-of[DRM_OPF_DAMP], qd[k], fj[k]) : fj[k]);
+            float rec[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            ArtBody up;
+            aba_eliminate(kd & 1, kd & 2, J, t, qd[k], fjoint, vel, tot, rec, k > 0, up);
+            sput(k, rec);
+            if (k > 0) carry = up;
+        }
+    }
+    // ---- sweep 3 of the prefix ----------------------------------------------------------------------------------------
+    motion_root(cur, gravity ? 9.81f : 0.0f);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        DRM_RNEA_LINK_FENCE();
+        const int kd = kind(k);
+        float J[9], t[3];
+        prefix_joint(k, J, t);
+        motion_step(J, t, qd[k], 0.0f, kd & 2, cur, cur); // acceleration halves: a' = X a_parent + c
+        out_p[k] = 0.0f;
+        if (kd & 1) {
+            float rec[8];
+            sget(k, rec);
+            out_p[k] = aba_joint_acceleration(rec, kd & 2, cur);
+        }
+    }
+    // ---- second visit of the sub-chains: U, 1/D, u again, then their sweep 3 from the palm's acceleration --------------
+    const Motion palm_v2 = velocity_halves(cur);
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        float hqv[L], hqd[L], hf[L], hc[L], hs[L], recs[L][8];
+#pragma unroll
+        for (int i = 0; i < L; ++i) hq(j, i, hqv[i], hqd[i], hf[i]);
+        chain_trig<L>(hqv, hc, hs);
+        ArtBody unused;
+        sub_chain_up(j, palm_v2, hqv, hqd, hf, hc, hs, recs, unused);
+        Motion M = cur;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            DRM_RNEA_LINK_FENCE();
+            const int op = P + j * L + i, kd = kind(op);
+            float J[9], t[3];
+            joint_transform(load_ft(row(op)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+            motion_step(J, t, hqd[i], 0.0f, kd & 2, M, M);
+            if (kd & 1) hout(j, i, aba_joint_acceleration(recs[i], kd & 2, M));
+        }
+    }
+}
+
 } // namespace drm

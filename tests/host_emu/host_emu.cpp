@@ -158,6 +158,29 @@ void rnea_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd
     }
 }
 
+// the arithmetic of forward_dynamics_arm_hand_kernel<P, L>
+template <int P, int L>
+void fd_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, const float *f, int64_t B, int flags, float *qdd) {
+    const int n = w->n_dofs;
+    const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
+    auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
+    auto kind = [&](int op) { const int x = w0[op]; return ((x & 0xff) ? 1 : 0) | (((x >> 26) & 1) << 1); };
+    for (int64_t b = 0; b < B; ++b) {
+        auto state = [&](int d, float &a, float &v, float &t) {
+            a = d < 0 ? 0.f : q[b * n + d]; v = d < 0 ? 0.f : qd[b * n + d]; t = d < 0 ? 0.f : f[b * n + d];
+        };
+        float qv[P], qdv[P], fv[P], cs[P], sn[P], out[P], slot[P][8];
+        for (int k = 0; k < P; ++k) state(dof_of(k), qv[k], qdv[k], fv[k]);
+        chain_trig<P>(qv, cs, sn);
+        aba_arm_hand<P, L>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING,
+                           qv, cs, sn, qdv, fv, [&](int j, int i, float &a, float &v, float &t) { state(dof_of(P + j * L + i), a, v, t); }, out,
+                           [&](int j, int i, float a) { const int d = dof_of(P + j * L + i); if (d >= 0) qdd[b * n + d] = a; },
+                           [&](int k, const float *s8) { for (int c = 0; c < 8; ++c) slot[k][c] = s8[c]; },
+                           [&](int k, float *s8) { for (int c = 0; c < 8; ++c) s8[c] = slot[k][c]; });
+        for (int k = 0; k < P; ++k) if (dof_of(k) >= 0) qdd[b * n + dof_of(k)] = out[k];
+    }
+}
+
 struct ParkRec { Force f; float c, s, q; };
 
 void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
@@ -410,6 +433,16 @@ int emu_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const 
     if (P == 9 && L == 1) rnea_arm_hand_emu<9, 1>(w, K, q, qd, qdd, B, flags, tau);
     else if (P == 7 && L == 2) rnea_arm_hand_emu<7, 2>(w, K, q, qd, qdd, B, flags, tau);
     else if (P == 8 && L == 4) rnea_arm_hand_emu<8, 4>(w, K, q, qd, qdd, B, flags, tau);
+    else return -2;
+    return 0;
+}
+int emu_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int32_t flags, float *qdd) {
+    if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
+    const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (P + K * L != w->n_ops) return -1;
+    if (P == 9 && L == 1) fd_arm_hand_emu<9, 1>(w, K, q, qd, f, B, flags, qdd);
+    else if (P == 7 && L == 2) fd_arm_hand_emu<7, 2>(w, K, q, qd, f, B, flags, qdd);
+    else if (P == 8 && L == 4) fd_arm_hand_emu<8, 4>(w, K, q, qd, f, B, flags, qdd);
     else return -2;
     return 0;
 }

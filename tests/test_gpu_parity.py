@@ -469,6 +469,32 @@ def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
     # rows of full tiles are the same whether or not a tail follows them
     t_full = m.compute_inverse_dynamics(dev(q[:64 * 37]), dev(qd[:64 * 37]), dev(qdd[:64 * 37]))
     assert torch.equal(t_full, m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd))[:64 * 37])
+    # forward dynamics of the same shapes (forward_dynamics_arm_hand_kernel: the articulated-body recursion, sub-chains visited
+    # twice instead of stored), on torques that produce accelerations of order one (tau = ID(q, qd, qdd)): every row against the
+    # fp64 oracle and against the loop-structured kernel (the walk without its shape bit), both flag settings
+    import ctypes
+    from differentiable_robot_model_amd import backend
+    lib = backend.load_library()
+    dw = m._dynamics_walk()
+    generic = backend._walk_struct(dw.program, m._ops_f(dw), dw.ops_i, m._n_dofs)
+    generic.shape &= ~SHAPE_ARM_HAND
+    dq, dqd = dev(q), dev(qd)
+    worst = 0.0
+    for grav, damp in ((True, True), (False, False)):
+        tau = m.compute_inverse_dynamics(dq, dqd, dev(qdd), include_gravity=grav, use_damping=damp)
+        acc = m.compute_forward_dynamics(dq, dqd, tau, include_gravity=grav, use_damping=damp)
+        ref = orc.forward_dynamics(q64, qd64, host(tau).astype(np.float64), grav, damp, np.float64)
+        err = float((np.abs(host(acc) - ref) / (1.0 + np.abs(ref))).max())
+        loop = torch.empty_like(acc)
+        scratch = torch.empty(max(1, lib.drm_forward_dynamics_scratch_floats(ctypes.byref(generic), B)), device="cuda")
+        backend._check(lib.drm_forward_dynamics(ctypes.byref(generic), dq.data_ptr(), dqd.data_ptr(), tau.data_ptr(), B,
+                                                (1 if grav else 0) | (2 if damp else 0), loop.data_ptr(), scratch.data_ptr(),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        err_loop = float((np.abs(host(loop) - ref) / (1.0 + np.abs(ref))).max())
+        worst = max(worst, err)
+        print("forward dynamics %s grav=%d damp=%d: straight-line %.2e, loop kernel %.2e (rel. to 1 + |qdd|, fp64 oracle)" % (robot, grav, damp, err, err_loop))
+        # cond(H) of the arm with a 16-DoF hand is ~1e8: both fp32 recursions sit at 1e-3 there (tests/test_forward_dynamics.py)
+        assert err <= max(1e-3, 2.0 * err_loop), (robot, grav, damp, err, err_loop)
 
 
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():

@@ -230,6 +230,25 @@ def test_arm_that_carries_a_hand(emu, robot, shape, flags):
         assert not (build_walk(mo._spec, whole_tree=True, drop_folded=True).shape & SHAPE_ARM_HAND), other
 
 
+@pytest.mark.parametrize("robot", ["panda", "jaco", "iiwa7_allegro", "panda:sliding-fingers"])
+@pytest.mark.parametrize("flags", [0, 3])
+def test_forward_dynamics_of_an_arm_that_carries_a_hand(emu, robot, flags):
+    """aba_arm_hand (the arithmetic of forward_dynamics_arm_hand_kernel: the articulated-body recursion with the sub-chains
+    visited twice instead of stored) against the fp64 oracle and against the loop form of the recursion."""
+    m = load_model(robot.split(":")[0], reference_compat=":" not in robot)
+    n, B = m._n_dofs, 17
+    q, qd, f = sample_states(m, B, seed=43)
+    prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
+    walk, keep = folded_host_walk(m, prog)
+    acc = np.full((B, n), np.nan, np.float32); acc_loop = np.full((B, n), np.nan, np.float32)
+    assert emu.emu_forward_dynamics_arm_hand(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(acc)) == 0
+    assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(acc_loop)) == 0
+    ref = Oracle(m._spec).forward_dynamics(q.astype(np.float64), qd.astype(np.float64), f.astype(np.float64), bool(flags & 1), bool(flags & 2), np.float64)
+    rel = lambda a, b: float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+    assert rel(acc, ref) < 1e-3, (robot, rel(acc, ref))
+    assert rel(acc, acc_loop) < 1e-3, (robot, rel(acc, acc_loop))
+
+
 def test_sincos_large_arguments(emu):
     """The kernels' branch-free sincos keeps fp32 accuracy far outside any joint range."""
     m = load_model("2link_robot")

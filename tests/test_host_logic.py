@@ -261,9 +261,9 @@ def test_gpu_scratch_of_the_persistent_kernels():
     walk = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
     for name in SCRATCH_QUERIES:
         small, big, bigger = (int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
-        if name == "drm_rnea_scratch_floats":
-            # inverse dynamics of an arm that carries a hand: full 64-row tiles run the straight-line kernel (drm_arm_hand.hip,
-            # no scratch); only a ragged tail still goes through the persistent loop kernel
+        if name in ("drm_rnea_scratch_floats", "drm_forward_dynamics_scratch_floats"):
+            # inverse and forward dynamics of an arm that carries a hand: full 64-row tiles run the straight-line kernels
+            # (drm_arm_hand.hip, no scratch); only a ragged tail still goes through the persistent loop kernels
             assert small == big == bigger == 0, (name, small, big, bigger)
             assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
             continue

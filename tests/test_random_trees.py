@@ -168,7 +168,13 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
         else:
             assert torch.equal(tau[sl], alone), lo
         assert torch.equal(H[sl], m.compute_lagrangian_inertia_matrix(q[sl])), lo
-        assert torch.equal(acc[sl], m.compute_forward_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)), lo
+        acc_alone = m.compute_forward_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)
+        if arm_hand:   # (as for inverse dynamics above: full tiles and the ragged tail run different kernels on these robots)
+            assert rel(acc[sl].cpu().numpy(), acc_alone.cpu().numpy()) < 1e-3, lo
+            if lo % 64 == 0 and lo + 128 <= B - B % 64:
+                assert torch.equal(acc[lo:lo + 128], acc_alone[:128]), lo
+        else:
+            assert torch.equal(acc[sl], acc_alone), lo
     rows = [0, 63, 64, 99999, B - 1]
     orc = Oracle(mc._spec)
     q64, qd64, qdd64 = (t[rows].cpu().numpy().astype(np.float64) for t in (q, qd, qdd))
