@@ -14,6 +14,7 @@
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 #include "drm_tree.hpp"
+#include "drm_tree_dev.hpp"
 
 namespace drm {
 
@@ -158,6 +159,96 @@ __global__ void __launch_bounds__(WAVE)
     tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) != 0, true);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K6 (mass matrix) of the same shapes: drm_tree.hpp crba_arm_hand — a walk that parks nothing (the loop form,
+// crba_rows_kernel, keeps the column forces of all the joints below an op in LDS: 35 KB per 64 samples on the arm with a hand,
+// three wavefronts per CU).  The output path is the loop form's: a lane scatters its lower-triangle entries into a
+// sample-major slice of caller-owned HBM scratch (persistent grid: the slices stay cache-resident), the rows of H are then
+// written sample by sample from coalesced reads through an LDS buffer.
+// LDS (static): [ table ][ row buffer : 4096 floats ]
+// ---------------------------------------------------------------------------------------------------
+constexpr int AH_ROWBUF_FLOATS = 4096;
+template <int P, int L>
+__global__ void __launch_bounds__(WAVE)
+    crba_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q, int K, int cap,
+                         int n, int n_tiles, float *__restrict__ H, float *__restrict__ scratch) {
+    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + AH_ROWBUF_FLOATS];
+    const unsigned lane = threadIdx.x;
+    const int n_ops = P + K * L, nn = n * n, ntp = round4(n * (n + 1) / 2);
+    float *lc = smem, *lrow = smem + C_FLOATS;
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
+    float *tri = scratch + (int64_t)blockIdx.x * ntp * WAVE; // this wave's triangles, SAMPLE-major [64][ntp]
+    int dof[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
+    for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
+        reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
+    auto dof_of = [&](int op) { return (w0[op] & 0xff) - 1; };
+    const int G0 = (AH_ROWBUF_FLOATS / ntp) & ~3, G = G0 > WAVE ? WAVE : G0; // samples per assembly round
+    const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        for (int i = (int)lane; i < 16 * ntp; i += WAVE) // pairs of joints on different sub-chains stay zero
+            reinterpret_cast<float4 *>(tri)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const unsigned row_off = lane * (unsigned)n * 4u;
+        const char *qb = reinterpret_cast<const char *>(q + b0 * n);
+        auto q_of = [&](int d) {
+            const float x = *reinterpret_cast<const float *>(qb + (d < 0 ? 0 : d) * 4 + row_off);
+            return d < 0 ? 0.0f : x;
+        };
+        float qv[P], cs[P], sn[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) qv[k] = q_of(dof[k]);
+        __syncthreads(); // the zero fill has landed before this lane's entries follow it (and the table is staged)
+        chain_trig<P>(qv, cs, sn);
+        crba_arm_hand<P, L>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, kind, dof_of, K, qv, cs, sn,
+                            [&](int j, int i) { return q_of(dof_of(P + j * L + i)); },
+                            [&](int di, int dj, float v) {
+                                const int hi = di > dj ? di : dj, lw = di > dj ? dj : di;
+                                tri[lane * ntp + tri_index(hi, lw)] = v;
+                            });
+        __syncthreads(); // every entry of the tile is in scratch
+        // the rows of H, G samples per round: their triangles come back with 16-byte loads (twelve in flight per lane) into the
+        // row buffer, then every sample's n x n floats leave as 4-byte stores of consecutive lanes — consecutive addresses
+        float *g = H + b0 * nn;
+        for (int s0 = 0; s0 < WAVE; s0 += G) {
+            const int gs = WAVE - s0 < G ? WAVE - s0 : G;
+            const float4 *t4 = reinterpret_cast<const float4 *>(tri + s0 * ntp);
+            float4 *l4 = reinterpret_cast<float4 *>(lrow);
+            const int n4 = gs * (ntp >> 2);
+            for (int i0 = 0; i0 < n4; i0 += 12 * WAVE) {
+                float4 v[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * WAVE + (int)lane;
+                    v[u] = i < n4 ? t4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = i0 + u * WAVE + (int)lane;
+                    if (i < n4) l4[i] = v[u];
+                }
+            }
+            wave_lds_sync();
+            unsigned r = lane / (unsigned)n, c = lane - r * (unsigned)n;
+            for (int j = (int)lane; j < nn; j += WAVE) {
+                const int hi = (int)(r > c ? r : c), lw = (int)(r > c ? c : r);
+                const float *src = lrow + tri_index(hi, lw);
+                float *dst = g + (int64_t)s0 * nn + j;
+#pragma unroll 4
+                for (int gi = 0; gi < gs; ++gi) dst[(int64_t)gi * nn] = src[gi * ntp];
+                r += step_r; c += step_c;
+                if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
+            }
+            wave_lds_sync();
+        }
+        __syncthreads(); // the slice is free for the next tile
+    }
+}
+
 // the (P, L) this library is compiled for: those of the robots it ships (robot_data/); anything else keeps the loop kernel
 #define DRM_ARM_HAND_SHAPES(X) X(9, 1) X(7, 2) X(8, 4)
 
@@ -217,6 +308,50 @@ int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, cons
         hipLaunchKernelGGL((forward_dynamics_arm_hand_kernel<p, l>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, qd, \
                            f, K, (int)w->capacity, n, flags, qdd, div_magic(n));                                                  \
         return (int64_t)n_tiles * WAVE;                                                                                           \
+    }
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    return 0;
+#endif
+}
+
+// mass matrix: blocks of the persistent grid for `tiles` full tiles, and the scratch floats they need (0: shape not compiled)
+static int crba_arm_hand_grid(const drm_walk *w, int64_t tiles, int &grid) {
+    int P, K, L, resident = 0;
+    if (!shape_of(w, P, K, L)) return DRM_ERR_UNSUPPORTED;
+    int rc = DRM_ERR_UNSUPPORTED;
+#define X(p, l) if (P == p && L == l) rc = resident_blocks((crba_arm_hand_kernel<p, l>), WAVE, 0, resident);
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    if (rc) return rc;
+    grid = (int)(tiles < resident ? tiles : (int64_t)resident);
+    return DRM_OK;
+}
+int64_t crba_arm_hand_scratch_floats(const drm_walk *w, int64_t B) {
+#ifdef DRM_NO_ARM_HAND_CRBA
+    return 0;
+#else
+    int grid = 0;
+    if (!arm_hand_compiled(w) || B < WAVE || crba_arm_hand_grid(w, B / WAVE, grid)) return 0;
+    const int n = w->n_dofs;
+    return (int64_t)grid * round4(n * (n + 1) / 2) * WAVE;
+#endif
+}
+int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, hipStream_t s) {
+#ifdef DRM_NO_ARM_HAND_CRBA
+    return 0;
+#else
+    int P, K, L, grid = 0;
+    if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || B < WAVE || B / WAVE >= 0x7fffffffLL || !scratch ||
+        (((uintptr_t)w->ops_f | (uintptr_t)q | (uintptr_t)H | (uintptr_t)scratch) & 15u) != 0)
+        return 0;
+    const int n_tiles = (int)(B / WAVE), n = w->n_dofs;
+    if (crba_arm_hand_grid(w, n_tiles, grid)) return 0;
+#define X(p, l)                                                                                                                  \
+    if (P == p && L == l) {                                                                                                      \
+        hipLaunchKernelGGL((crba_arm_hand_kernel<p, l>), dim3((unsigned)grid), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, K,       \
+                           (int)w->capacity, n, n_tiles, H, scratch);                                                            \
+        return (int64_t)n_tiles * WAVE;                                                                                          \
     }
     DRM_ARM_HAND_SHAPES(X)
 #undef X

@@ -970,4 +970,139 @@ DRM_HD void aba_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Joint-space inertia matrix of "an arm that carries a hand" (DRM_WALK_ARM_HAND) by the composite-rigid-body algorithm,
+// straight-line for the shape (round 3).  Nothing is parked: a sub-chain keeps its L joint transforms in registers, walks
+// the column force F = Ic S of each of its joints up to the palm as it appears, then carries its L forces together up the
+// prefix (one transform per prefix op and force, the prefix's joint transforms rebuilt from cos / sin on the way) and hands
+// the palm its composite inertia; the prefix then runs the chain form (crba_chain_trig) with the palm's composite added.
+//   row(op), kind(op) (1 = moves, 2 = prismatic), dof(op)   wave-uniform
+//   q / cs / sn of the prefix ops;  hq(j, i) -> joint value of op i of sub-chain j
+//   hout(di, dj, v)   H[di][dj] = H[dj][di] = v, called once per pair of joints on a common root path (and per diagonal entry);
+//                     pairs on different sub-chains are structurally zero and never reported
+// ---------------------------------------------------------------------------
+DRM_HD void inertia_from_row(const float *of, Inertia &I) {
+    I.m = of[DRM_OPF_MASS];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) I.h[i] = of[DRM_OPF_MCOM + i];
+    I.I[0] = of[DRM_OPF_IO + 0]; I.I[1] = of[DRM_OPF_IO + 1]; I.I[2] = of[DRM_OPF_IO + 2];
+    I.I[3] = of[DRM_OPF_IO + 4]; I.I[4] = of[DRM_OPF_IO + 5]; I.I[5] = of[DRM_OPF_IO + 8];
+}
+// F = Ic S for a joint about / along +z; returns S . F (the diagonal entry)
+DRM_HD float crba_column_force(const Inertia &tot, bool prismatic, Force &F) {
+    if (!prismatic) { // f = -h x e_z = (-h_y, h_x, 0), n = I e_z
+        F.la[0] = f2_make(-tot.h[1], tot.I[2]);
+        F.la[1] = f2_make(tot.h[0], tot.I[4]);
+        F.la[2] = f2_make(0.0f, tot.I[5]);
+        return tot.I[5];
+    }
+    F.la[0] = f2_make(0.0f, tot.h[1]); // f = m e_z, n = h x e_z = (h_y, -h_x, 0)
+    F.la[1] = f2_make(0.0f, -tot.h[0]);
+    F.la[2] = f2_make(tot.m, 0.0f);
+    return tot.m;
+}
+template <int P, int L, class ROW, class KIND, class DOF, class HQ, class HOUT>
+DRM_HD void crba_arm_hand(ROW row, KIND kind, DOF dof, int K, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq,
+                          HOUT hout) {
+    auto prefix_joint = [&](int k, float *J, float *t) {
+        const int kd = kind(k);
+        joint_transform(load_ft(row(k)), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
+    };
+    auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; }; // S . F
+    Inertia palm; // what the sub-chains hand to the last prefix op
+    inertia_zero(palm);
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        float hqv[L], hc[L], hs[L], Jf[L][9], tf[L][3];
+#pragma unroll
+        for (int i = 0; i < L; ++i) hqv[i] = hq(j, i);
+        chain_trig<L>(hqv, hc, hs);
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int kd = kind(P + j * L + i);
+            joint_transform(load_ft(row(P + j * L + i)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], Jf[i], tf[i]);
+        }
+        Force Fp[L]; // column forces of the sub-chain's joints, in the palm's frame once the sweep below is through
+        Inertia carry;
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            DRM_RNEA_LINK_FENCE();
+            const int op = P + j * L + i, kd = kind(op);
+            Inertia tot;
+            inertia_from_row(row(op), tot);
+            if (i < L - 1) inertia_add(tot, carry);
+            if (kd & 1) {
+                Force F;
+                hout(dof(op), dof(op), crba_column_force(tot, kd & 2, F));
+#pragma unroll
+                for (int a = i - 1; a >= 0; --a) { // up the sub-chain: into the frame of its op a
+                    Force up;
+                    rnea_link_force_up(Jf[a + 1], tf[a + 1], F, up);
+                    F = up;
+                    const int ka = kind(P + j * L + a);
+                    if (ka & 1) hout(dof(P + j * L + a), dof(op), along(F, ka & 2));
+                }
+                rnea_link_force_up(Jf[0], tf[0], F, Fp[i]); // ... and into the palm's
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Fp[i].la[c] = f2_bcast(0.0f);
+            }
+            Inertia up;
+            inertia_to_parent(Jf[i], tf[i], tot, up);
+            if (i > 0) carry = up;
+            else inertia_add(palm, up);
+        }
+        // the L forces together up the prefix
+#pragma unroll
+        for (int k = P - 1; k >= 0; --k) {
+            DRM_RNEA_LINK_FENCE();
+            const int kk = kind(k);
+            if (kk & 1) {
+#pragma unroll
+                for (int i = 0; i < L; ++i)
+                    if (kind(P + j * L + i) & 1) hout(dof(k), dof(P + j * L + i), along(Fp[i], kk & 2));
+            }
+            if (k > 0) {
+                float J[9], t[3];
+                prefix_joint(k, J, t);
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    Force up;
+                    rnea_link_force_up(J, t, Fp[i], up);
+                    Fp[i] = up;
+                }
+            }
+        }
+    }
+    // the prefix: composite inertias from the palm to the root, every joint's column force walked up its ancestors
+    Inertia carry = palm;
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) {
+        DRM_RNEA_LINK_FENCE();
+        const int kd = kind(k);
+        Inertia tot;
+        inertia_from_row(row(k), tot);
+        inertia_add(tot, carry);
+        if (kd & 1) {
+            Force F;
+            hout(dof(k), dof(k), crba_column_force(tot, kd & 2, F));
+#pragma unroll
+            for (int a = k - 1; a >= 0; --a) {
+                float J[9], t[3];
+                prefix_joint(a + 1, J, t);
+                Force up;
+                rnea_link_force_up(J, t, F, up);
+                F = up;
+                const int ka = kind(a);
+                if (ka & 1) hout(dof(a), dof(k), along(F, ka & 2));
+            }
+        }
+        if (k > 0) {
+            float J[9], t[3];
+            prefix_joint(k, J, t);
+            inertia_to_parent(J, t, tot, carry);
+        }
+    }
+}
+
 } // namespace drm

@@ -181,6 +181,24 @@ void fd_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, 
     }
 }
 
+// the arithmetic of crba_arm_hand_kernel<P, L>
+template <int P, int L>
+void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, float *H) {
+    const int n = w->n_dofs;
+    const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
+    auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
+    auto kind = [&](int op) { const int x = w0[op]; return ((x & 0xff) ? 1 : 0) | (((x >> 26) & 1) << 1); };
+    for (int64_t b = 0; b < B; ++b) {
+        for (int i = 0; i < n * n; ++i) H[b * n * n + i] = 0.f;
+        float qv[P], cs[P], sn[P];
+        for (int k = 0; k < P; ++k) qv[k] = dof_of(k) < 0 ? 0.f : q[b * n + dof_of(k)];
+        chain_trig<P>(qv, cs, sn);
+        crba_arm_hand<P, L>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, kind, dof_of, K, qv, cs, sn,
+                            [&](int j, int i) { const int d = dof_of(P + j * L + i); return d < 0 ? 0.f : q[b * n + d]; },
+                            [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; H[(b * n + dj) * n + di] = v; });
+    }
+}
+
 struct ParkRec { Force f; float c, s, q; };
 
 void rnea_loop(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
@@ -443,6 +461,16 @@ int emu_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float
     if (P == 9 && L == 1) fd_arm_hand_emu<9, 1>(w, K, q, qd, f, B, flags, qdd);
     else if (P == 7 && L == 2) fd_arm_hand_emu<7, 2>(w, K, q, qd, f, B, flags, qdd);
     else if (P == 8 && L == 4) fd_arm_hand_emu<8, 4>(w, K, q, qd, f, B, flags, qdd);
+    else return -2;
+    return 0;
+}
+int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H) {
+    if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
+    const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (P + K * L != w->n_ops) return -1;
+    if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H);
+    else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H);
+    else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H);
     else return -2;
     return 0;
 }

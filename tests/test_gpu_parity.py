@@ -495,6 +495,22 @@ def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
         print("forward dynamics %s grav=%d damp=%d: straight-line %.2e, loop kernel %.2e (rel. to 1 + |qdd|, fp64 oracle)" % (robot, grav, damp, err, err_loop))
         # cond(H) of the arm with a 16-DoF hand is ~1e8: both fp32 recursions sit at 1e-3 there (tests/test_forward_dynamics.py)
         assert err <= max(1e-3, 2.0 * err_loop), (robot, grav, damp, err, err_loop)
+    # the joint-space inertia matrix of the same shapes (crba_arm_hand_kernel: column forces of a sub-chain carried together up
+    # the prefix, nothing parked): every row against the fp64 oracle, symmetric bit for bit, the full tiles identical whether
+    # or not a tail follows, and against the loop-structured kernel
+    H = m.compute_lagrangian_inertia_matrix(dq)
+    ref = orc.mass_matrix(q64, dtype=np.float64)
+    TOL_H = dict(atol=5e-5, rtol=2e-5)        # tests/test_mass_matrix.py
+    assert np.allclose(host(H), ref, **TOL_H), (robot, float(np.abs(host(H) - ref).max()))
+    assert torch.equal(H, H.transpose(1, 2))
+    assert torch.equal(H[:64 * 37], m.compute_lagrangian_inertia_matrix(dq[:64 * 37]))
+    n = m._n_dofs
+    loop = torch.empty_like(H)
+    scratch = torch.empty(max(1, lib.drm_crba_scratch_floats(ctypes.byref(generic), B)), device="cuda")
+    backend._check(lib.drm_crba(ctypes.byref(generic), dq.data_ptr(), B, loop.data_ptr(), scratch.data_ptr(),
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.allclose(host(loop), ref, **TOL_H)
+    print("mass matrix %s: straight-line %.2e, loop kernel %.2e (max abs, fp64 oracle)" % (robot, float(np.abs(host(H) - ref).max()), float(np.abs(host(loop) - ref).max())))
 
 
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():

@@ -249,6 +249,24 @@ def test_forward_dynamics_of_an_arm_that_carries_a_hand(emu, robot, flags):
     assert rel(acc, acc_loop) < 1e-3, (robot, rel(acc, acc_loop))
 
 
+@pytest.mark.parametrize("robot", ["panda", "jaco", "iiwa7_allegro", "panda:sliding-fingers"])
+def test_mass_matrix_of_an_arm_that_carries_a_hand(emu, robot):
+    """crba_arm_hand (the arithmetic of crba_arm_hand_kernel: a sub-chain's column forces carried together up the prefix, nothing
+    parked) against the fp64 oracle and the loop form of the composite-rigid-body walk; structural zeros stay zero."""
+    m = load_model(robot.split(":")[0], reference_compat=":" not in robot)
+    n, B = m._n_dofs, 11
+    q, _, _ = sample_states(m, B, seed=47)
+    prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
+    walk, keep = folded_host_walk(m, prog)
+    H = np.full((B, n, n), np.nan, np.float32); H_loop = np.full((B, n, n), np.nan, np.float32)
+    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H_loop)) == 0
+    ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
+    assert np.allclose(H, ref, atol=2e-5, rtol=2e-5), (robot, np.abs(H - ref).max())
+    assert np.allclose(H, H_loop, atol=1e-5, rtol=1e-5)
+    assert np.array_equal(H, np.swapaxes(H, 1, 2))
+
+
 def test_sincos_large_arguments(emu):
     """The kernels' branch-free sincos keeps fp32 accuracy far outside any joint range."""
     m = load_model("2link_robot")
