@@ -160,92 +160,122 @@ __global__ void __launch_bounds__(WAVE)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K6 (mass matrix) of the same shapes: drm_tree.hpp crba_arm_hand — a walk that parks nothing (the loop form,
-// crba_rows_kernel, keeps the column forces of all the joints below an op in LDS: 35 KB per 64 samples on the arm with a hand,
-// three wavefronts per CU).  The output path is the loop form's: a lane scatters its lower-triangle entries into a
-// sample-major slice of caller-owned HBM scratch (persistent grid: the slices stay cache-resident), the rows of H are then
-// written sample by sample from coalesced reads through an LDS buffer.
-// LDS (static): [ table ][ row buffer : 4096 floats ]
+// K6 (mass matrix) of the same shapes: drm_tree.hpp crba_arm_hand_sub / crba_arm_hand_prefix — a walk that parks nothing (the
+// loop form, crba_rows_kernel, keeps the column forces of all the joints below an op in LDS: 35 KB per 64 samples on the arm
+// with a hand, three wavefronts per CU) — and an output path without scratch.  H is 4 n^2 bytes per sample (2.1 KB at 23 DoF):
+// the kernel is bound by writing it, so the entries must leave as whole cache lines, and a lane that keeps a sample cannot do
+// that (its entries are 4 n^2 bytes apart; through a slice of HBM scratch and back the tile's triangle crossed the memory
+// system three times: 1.8 ms per 2^20 samples, 0.33 ms of it the walk).  Here a BLOCK owns 64 samples and has one wavefront
+// per sub-chain: wavefront j walks sub-chain j (its own entries, its L column forces up the prefix), the K composites meet in
+// the palm through LDS, the prefix's columns are dealt round-robin to the wavefronts; every entry goes to an LDS triangle
+// [slot][64 + 1] (the pad: the writers are 64 lanes of one slot, the readers 64 slots of one sample), and the block then writes
+// the 64 matrices as consecutive floats, 256 bytes per store instruction.
+// LDS (static): [ table ][ K composites : 10 x 64 each ][ triangle : slots x 65 ]
+//               9 + 2x1 ops: 24 KB, 7 + 3x2: 31 KB, 8 + 4x4: 66 KB (two blocks = eight wavefronts per CU)
 // ---------------------------------------------------------------------------------------------------
-constexpr int AH_ROWBUF_FLOATS = 4096;
+// (non-temporal stores of H: 1 068 us instead of 675 us per 2^20 samples of the 23-DoF arm with a hand — they are not merged
+// into lines on the way out)
+#ifndef DRM_AH_H_NT
+#define DRM_AH_H_NT 0
+#endif
+template <int NT>
+__device__ __forceinline__ void store_f32(float *p, float v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+constexpr int AH_TRI_STRIDE = WAVE + 1;
+// wavefronts (= sub-chains) the mass-matrix kernel of a shape reserves LDS for: a gripper's two fingers, the Jaco's three, the
+// Allegro's four; a robot of the shape with more of them takes the loop kernel
+constexpr int crba_max_k(int L) { return L == 1 ? 2 : L == 2 ? 3 : 4; }
 template <int P, int L>
-__global__ void __launch_bounds__(WAVE)
+struct AhTriangle { // slots of the pairs (oa <= ob) of ops on a common root path
+    static constexpr int KMAX = crba_max_k(L), OPS = P + KMAX * L;
+    static constexpr int PPN = P * (P + 1) / 2, SUBN = L * P + L * (L + 1) / 2, SLOTS = PPN + KMAX * SUBN;
+    static DRM_HD int slot(int oa, int ob) {
+        if (ob < P) return ob * (ob + 1) / 2 + oa;
+        const int j = (ob - P) / L, i = ob - P - j * L;
+        return PPN + j * SUBN + i * P + i * (i + 1) / 2 + (oa < P ? oa : oa - j * L);
+    }
+    static DRM_HD bool related(int oa, int ob) { return oa < P || (oa - P) / L == (ob - P) / L; }
+};
+template <int P, int L>
+__global__ void __launch_bounds__(WAVE *crba_max_k(L))
     crba_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q, int K, int cap,
-                         int n, int n_tiles, float *__restrict__ H, float *__restrict__ scratch) {
-    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE;
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + AH_ROWBUF_FLOATS];
-    const unsigned lane = threadIdx.x;
-    const int n_ops = P + K * L, nn = n * n, ntp = round4(n * (n + 1) / 2);
-    float *lc = smem, *lrow = smem + C_FLOATS;
+                         int n, float *__restrict__ H) {
+    using T = AhTriangle<P, L>;
+    constexpr int C_FLOATS = T::OPS * DRM_OPF_STRIDE, X_FLOATS = T::KMAX * 10 * WAVE;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + X_FLOATS + T::SLOTS * AH_TRI_STRIDE];
+    __shared__ int op_of_dof[AH_MAX_OPS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n_ops = P + K * L, nn = n * n;
+    float *lc = smem, *lx = smem + C_FLOATS, *tri = lx + X_FLOATS;
     const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
-    float *tri = scratch + (int64_t)blockIdx.x * ntp * WAVE; // this wave's triangles, SAMPLE-major [64][ntp]
-    int dof[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
-    for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
+    for (unsigned i = threadIdx.x; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += blockDim.x)
         reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    if ((int)threadIdx.x < n_ops) {
+        const int d = (w0[threadIdx.x] & 0xff) - 1;
+        if (d >= 0) op_of_dof[d] = (int)threadIdx.x;
+    }
     auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
     auto dof_of = [&](int op) { return (w0[op] & 0xff) - 1; };
-    const int G0 = (AH_ROWBUF_FLOATS / ntp) & ~3, G = G0 > WAVE ? WAVE : G0; // samples per assembly round
-    const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
-#pragma unroll 1
-    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int64_t b0 = (int64_t)tile * WAVE;
-        for (int i = (int)lane; i < 16 * ntp; i += WAVE) // pairs of joints on different sub-chains stay zero
-            reinterpret_cast<float4 *>(tri)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const unsigned row_off = lane * (unsigned)n * 4u;
-        const char *qb = reinterpret_cast<const char *>(q + b0 * n);
-        auto q_of = [&](int d) {
-            const float x = *reinterpret_cast<const float *>(qb + (d < 0 ? 0 : d) * 4 + row_off);
-            return d < 0 ? 0.0f : x;
-        };
-        float qv[P], cs[P], sn[P];
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    const unsigned row_off = lane * (unsigned)n * 4u;
+    const char *qb = reinterpret_cast<const char *>(q + b0 * n);
+    auto q_of = [&](int d) {
+        const float x = *reinterpret_cast<const float *>(qb + (d < 0 ? 0 : d) * 4 + row_off);
+        return d < 0 ? 0.0f : x;
+    };
+    float qv[P], cs[P], sn[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) qv[k] = q_of(dof[k]);
-        __syncthreads(); // the zero fill has landed before this lane's entries follow it (and the table is staged)
-        chain_trig<P>(qv, cs, sn);
-        crba_arm_hand<P, L>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, kind, dof_of, K, qv, cs, sn,
-                            [&](int j, int i) { return q_of(dof_of(P + j * L + i)); },
-                            [&](int di, int dj, float v) {
-                                const int hi = di > dj ? di : dj, lw = di > dj ? dj : di;
-                                tri[lane * ntp + tri_index(hi, lw)] = v;
-                            });
-        __syncthreads(); // every entry of the tile is in scratch
-        // the rows of H, G samples per round: their triangles come back with 16-byte loads (twelve in flight per lane) into the
-        // row buffer, then every sample's n x n floats leave as 4-byte stores of consecutive lanes — consecutive addresses
-        float *g = H + b0 * nn;
-        for (int s0 = 0; s0 < WAVE; s0 += G) {
-            const int gs = WAVE - s0 < G ? WAVE - s0 : G;
-            const float4 *t4 = reinterpret_cast<const float4 *>(tri + s0 * ntp);
-            float4 *l4 = reinterpret_cast<float4 *>(lrow);
-            const int n4 = gs * (ntp >> 2);
-            for (int i0 = 0; i0 < n4; i0 += 12 * WAVE) {
-                float4 v[12];
+    for (int k = 0; k < P; ++k) qv[k] = q_of(dof_of(k));
+    __syncthreads(); // the table is staged
+    chain_trig<P>(qv, cs, sn);
+    auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    auto hout = [&](int oa, int ob, float v) { tri[T::slot(oa, ob) * AH_TRI_STRIDE + lane] = v; };
+    {
+        Inertia part;
+        crba_arm_hand_sub<P, L>(row, kind, wave, qv, cs, sn, [&](int i) { return q_of(dof_of(P + wave * L + i)); }, hout, part);
+        float *x = lx + wave * (10 * WAVE) + lane;
+        x[0] = part.m;
 #pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const int i = i0 + u * WAVE + (int)lane;
-                    v[u] = i < n4 ? t4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
+        for (int i = 0; i < 3; ++i) x[(1 + i) * WAVE] = part.h[i];
 #pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const int i = i0 + u * WAVE + (int)lane;
-                    if (i < n4) l4[i] = v[u];
-                }
-            }
-            wave_lds_sync();
-            unsigned r = lane / (unsigned)n, c = lane - r * (unsigned)n;
-            for (int j = (int)lane; j < nn; j += WAVE) {
-                const int hi = (int)(r > c ? r : c), lw = (int)(r > c ? c : r);
-                const float *src = lrow + tri_index(hi, lw);
-                float *dst = g + (int64_t)s0 * nn + j;
-#pragma unroll 4
-                for (int gi = 0; gi < gs; ++gi) dst[(int64_t)gi * nn] = src[gi * ntp];
-                r += step_r; c += step_c;
-                if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
-            }
-            wave_lds_sync();
+        for (int i = 0; i < 6; ++i) x[(4 + i) * WAVE] = part.I[i];
+    }
+    __syncthreads(); // what every sub-chain hands the palm
+    {
+        Inertia palm;
+        inertia_zero(palm);
+        for (int j = 0; j < K; ++j) { // (in sub-chain order on every wavefront: the same floats)
+            const float *x = lx + j * (10 * WAVE) + lane;
+            Inertia part;
+            part.m = x[0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) part.h[i] = x[(1 + i) * WAVE];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) part.I[i] = x[(4 + i) * WAVE];
+            inertia_add(palm, part);
         }
-        __syncthreads(); // the slice is free for the next tile
+        crba_arm_hand_prefix<P>(row, kind, qv, cs, sn, palm, wave, K, hout);
+    }
+    __syncthreads(); // every entry of the 64 samples is in the triangle
+    // wavefront w writes the matrices of its share of the samples: element e of a matrix = (row e / n, column e % n), its slot
+    // worked out once per lane, the samples an inner loop of independent copies (consecutive lanes, consecutive addresses)
+    const int s_lo = wave * WAVE / K, s_hi = (wave + 1) * WAVE / K;
+    const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
+    unsigned r = lane / (unsigned)n, c = lane - r * (unsigned)n;
+    float *g = H + b0 * nn;
+    for (int e = (int)lane; e < nn; e += WAVE) {
+        const int a0 = op_of_dof[r], a1 = op_of_dof[c];
+        const int oa = a0 < a1 ? a0 : a1, ob = a0 < a1 ? a1 : a0;
+        const bool live = T::related(oa, ob);
+        const float *src = tri + (live ? T::slot(oa, ob) : 0) * AH_TRI_STRIDE;
+        float *dst = g + e;
+#pragma unroll 8
+        for (int sm = s_lo; sm < s_hi; ++sm) store_f32<DRM_AH_H_NT>(dst + (int64_t)sm * nn, live ? src[sm] : 0.0f);
+        r += step_r; c += step_c;
+        if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
     }
 }
 
@@ -315,42 +345,28 @@ int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, cons
 #endif
 }
 
-// mass matrix: blocks of the persistent grid for `tiles` full tiles, and the scratch floats they need (0: shape not compiled)
-static int crba_arm_hand_grid(const drm_walk *w, int64_t tiles, int &grid) {
-    int P, K, L, resident = 0;
-    if (!shape_of(w, P, K, L)) return DRM_ERR_UNSUPPORTED;
-    int rc = DRM_ERR_UNSUPPORTED;
-#define X(p, l) if (P == p && L == l) rc = resident_blocks((crba_arm_hand_kernel<p, l>), WAVE, 0, resident);
-    DRM_ARM_HAND_SHAPES(X)
-#undef X
-    if (rc) return rc;
-    grid = (int)(tiles < resident ? tiles : (int64_t)resident);
-    return DRM_OK;
-}
-int64_t crba_arm_hand_scratch_floats(const drm_walk *w, int64_t B) {
+// the mass-matrix kernel has a wavefront per sub-chain
+bool crba_arm_hand_applies(const drm_walk *w) {
 #ifdef DRM_NO_ARM_HAND_CRBA
-    return 0;
+    return false;
 #else
-    int grid = 0;
-    if (!arm_hand_compiled(w) || B < WAVE || crba_arm_hand_grid(w, B / WAVE, grid)) return 0;
-    const int n = w->n_dofs;
-    return (int64_t)grid * round4(n * (n + 1) / 2) * WAVE;
+    int P, K, L;
+    return arm_hand_compiled(w) && shape_of(w, P, K, L) && K <= crba_max_k(L);
 #endif
 }
-int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, hipStream_t s) {
+int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, hipStream_t s) {
 #ifdef DRM_NO_ARM_HAND_CRBA
     return 0;
 #else
-    int P, K, L, grid = 0;
-    if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || B < WAVE || B / WAVE >= 0x7fffffffLL || !scratch ||
-        (((uintptr_t)w->ops_f | (uintptr_t)q | (uintptr_t)H | (uintptr_t)scratch) & 15u) != 0)
+    int P, K, L;
+    if (!crba_arm_hand_applies(w) || !shape_of(w, P, K, L) || B < WAVE || B / WAVE >= 0x7fffffffLL ||
+        (((uintptr_t)w->ops_f | (uintptr_t)q | (uintptr_t)H) & 15u) != 0)
         return 0;
-    const int n_tiles = (int)(B / WAVE), n = w->n_dofs;
-    if (crba_arm_hand_grid(w, n_tiles, grid)) return 0;
+    const int n_tiles = (int)(B / WAVE);
 #define X(p, l)                                                                                                                  \
     if (P == p && L == l) {                                                                                                      \
-        hipLaunchKernelGGL((crba_arm_hand_kernel<p, l>), dim3((unsigned)grid), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, K,       \
-                           (int)w->capacity, n, n_tiles, H, scratch);                                                            \
+        hipLaunchKernelGGL((crba_arm_hand_kernel<p, l>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f, w->ops_i, q, K, \
+                           (int)w->capacity, (int)w->n_dofs, H);                                                                 \
         return (int64_t)n_tiles * WAVE;                                                                                          \
     }
     DRM_ARM_HAND_SHAPES(X)

@@ -368,8 +368,8 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
 int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
                              hipStream_t s);
 bool arm_hand_compiled(const drm_walk *w);
-int64_t crba_arm_hand_scratch_floats(const drm_walk *w, int64_t B);
-int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, hipStream_t s);
+bool crba_arm_hand_applies(const drm_walk *w);
+int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, hipStream_t s);
 int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags,
                                          float *qdd, hipStream_t s);
 

@@ -326,17 +326,16 @@ extern "C" int64_t drm_crba_scratch_floats(const drm_walk *w, int64_t B) {
         B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
         if (B == 0) return 0;
     }
-    // an arm that carries a hand: full tiles through the straight-line kernel (drm_arm_hand.hip: one 64-sample triangle slice per
-    // resident wave), the ragged tail through a loop kernel; ONE buffer serves both launches (they follow each other)
-    const int64_t fast = crba_arm_hand_scratch_floats(w, B);
-    if (fast > 0) B %= WAVE;
+    if (crba_arm_hand_applies(w)) {
+        B %= WAVE; // full tiles run the straight-line kernel (drm_arm_hand.hip, no scratch); a ragged tail a loop kernel
+        if (B == 0) return 0;
+    }
     TreeArgs a;
-    if (B == 0 || crba_short_plan(w, a)) return fast;
+    if (crba_short_plan(w, a)) return 0;
     CrbaRowsPlan p;
-    if (crba_rows_plan(w, p)) return fast;
+    if (crba_rows_plan(w, p)) return 0;
     const int64_t tiles = (B + WAVE - 1) / WAVE;
-    const int64_t loop = (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_segments * p.nt_max * WAVE;
-    return fast > loop ? fast : loop;
+    return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_segments * p.nt_max * WAVE;
 }
 
 extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, void *stream) {
@@ -365,7 +364,7 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     }
 #endif
     {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel
-        const int64_t done = launch_crba_arm_hand(w, q, B, H, scratch, s);
+        const int64_t done = launch_crba_arm_hand(w, q, B, H, s);
         if (done > 0) {
             rc = launched();
             if (rc || done == B) return rc;
@@ -374,7 +373,7 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
             return drm_crba(&generic, q + done * n, B - done, H + done * nn, scratch, stream);
         }
     }
-    if (B >= WAVE && arm_hand_compiled(w) && scratch && (((uintptr_t)q | (uintptr_t)H) & 15u) != 0)
+    if (B >= WAVE && crba_arm_hand_applies(w) && (((uintptr_t)q | (uintptr_t)H) & 15u) != 0)
         return fail(DRM_ERR_INVALID, "q / H must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");

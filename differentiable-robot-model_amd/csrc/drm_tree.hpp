@@ -975,11 +975,14 @@ DRM_HD void aba_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, 
 // straight-line for the shape (round 3).  Nothing is parked: a sub-chain keeps its L joint transforms in registers, walks
 // the column force F = Ic S of each of its joints up to the palm as it appears, then carries its L forces together up the
 // prefix (one transform per prefix op and force, the prefix's joint transforms rebuilt from cos / sin on the way) and hands
-// the palm its composite inertia; the prefix then runs the chain form (crba_chain_trig) with the palm's composite added.
-//   row(op), kind(op) (1 = moves, 2 = prismatic), dof(op)   wave-uniform
-//   q / cs / sn of the prefix ops;  hq(j, i) -> joint value of op i of sub-chain j
-//   hout(di, dj, v)   H[di][dj] = H[dj][di] = v, called once per pair of joints on a common root path (and per diagonal entry);
-//                     pairs on different sub-chains are structurally zero and never reported
+// the palm its composite inertia; the prefix then runs the chain form (crba_chain_trig) with the palm's composites added.
+// Two pieces, so that a block can give every sub-chain its own wavefront (drm_arm_hand.hip) and share the prefix's columns:
+//   crba_arm_hand_sub<P, L>(.., j, .., palm)       sub-chain j: its entries, and what it hands the palm
+//   crba_arm_hand_prefix<P>(.., palm, first, step) the columns P-1-first, P-1-first-step, ... of the prefix (composites of all)
+//   row(op), kind(op) (1 = moves, 2 = prismatic)   wave-uniform
+//   q / cs / sn of the prefix ops;  hq(i) -> joint value of op i of the sub-chain
+//   hout(oa, ob, v)   the entry of the joints of ops oa <= ob (ob's column force seen by oa's axis), once per pair of moving
+//                     ops on a common root path (and per diagonal entry); pairs on different sub-chains are structurally zero
 // ---------------------------------------------------------------------------
 DRM_HD void inertia_from_row(const float *of, Inertia &I) {
     I.m = of[DRM_OPF_MASS];
@@ -1001,81 +1004,81 @@ DRM_HD float crba_column_force(const Inertia &tot, bool prismatic, Force &F) {
     F.la[2] = f2_make(tot.m, 0.0f);
     return tot.m;
 }
-template <int P, int L, class ROW, class KIND, class DOF, class HQ, class HOUT>
-DRM_HD void crba_arm_hand(ROW row, KIND kind, DOF dof, int K, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq,
-                          HOUT hout) {
+template <int P, int L, class ROW, class KIND, class HQ, class HOUT>
+DRM_HD void crba_arm_hand_sub(ROW row, KIND kind, int j, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq,
+                              HOUT hout, Inertia &palm) {
+    auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; }; // S . F
+    float hqv[L], hc[L], hs[L], Jf[L][9], tf[L][3];
+#pragma unroll
+    for (int i = 0; i < L; ++i) hqv[i] = hq(i);
+    chain_trig<L>(hqv, hc, hs);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int kd = kind(P + j * L + i);
+        joint_transform(load_ft(row(P + j * L + i)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], Jf[i], tf[i]);
+    }
+    Force Fp[L]; // column forces of the sub-chain's joints, in the palm's frame once the sweep below is through
+    Inertia carry;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+        DRM_RNEA_LINK_FENCE();
+        const int op = P + j * L + i, kd = kind(op);
+        Inertia tot;
+        inertia_from_row(row(op), tot);
+        if (i < L - 1) inertia_add(tot, carry);
+        if (kd & 1) {
+            Force F;
+            hout(op, op, crba_column_force(tot, kd & 2, F));
+#pragma unroll
+            for (int a = i - 1; a >= 0; --a) { // up the sub-chain: into the frame of its op a
+                Force up;
+                rnea_link_force_up(Jf[a + 1], tf[a + 1], F, up);
+                F = up;
+                const int ka = kind(P + j * L + a);
+                if (ka & 1) hout(P + j * L + a, op, along(F, ka & 2));
+            }
+            rnea_link_force_up(Jf[0], tf[0], F, Fp[i]); // ... and into the palm's
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Fp[i].la[c] = f2_bcast(0.0f);
+        }
+        if (i > 0) inertia_to_parent(Jf[i], tf[i], tot, carry);
+        else inertia_to_parent(Jf[i], tf[i], tot, palm);
+    }
+    // the L forces together up the prefix
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) {
+        DRM_RNEA_LINK_FENCE();
+        const int kk = kind(k);
+        if (kk & 1) {
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+                if (kind(P + j * L + i) & 1) hout(k, P + j * L + i, along(Fp[i], kk & 2));
+        }
+        if (k > 0) {
+            float J[9], t[3];
+            joint_transform(load_ft(row(k)), kk & 1, kk & 2, q[k], cs[k], sn[k], J, t);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                Force up;
+                rnea_link_force_up(J, t, Fp[i], up);
+                Fp[i] = up;
+            }
+        }
+    }
+}
+// the prefix: composite inertias from the palm to the root, the column forces of ops P-1-first, P-1-first-step, ... walked up
+// their ancestors (first = 0, step = 1: every column)
+template <int P, class ROW, class KIND, class HOUT>
+DRM_HD void crba_arm_hand_prefix(ROW row, KIND kind, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], const Inertia &palm,
+                                 int first, int step, HOUT hout) {
     auto prefix_joint = [&](int k, float *J, float *t) {
         const int kd = kind(k);
         joint_transform(load_ft(row(k)), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
     };
-    auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; }; // S . F
-    Inertia palm; // what the sub-chains hand to the last prefix op
-    inertia_zero(palm);
-#pragma unroll 1
-    for (int j = 0; j < K; ++j) {
-        float hqv[L], hc[L], hs[L], Jf[L][9], tf[L][3];
-#pragma unroll
-        for (int i = 0; i < L; ++i) hqv[i] = hq(j, i);
-        chain_trig<L>(hqv, hc, hs);
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const int kd = kind(P + j * L + i);
-            joint_transform(load_ft(row(P + j * L + i)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], Jf[i], tf[i]);
-        }
-        Force Fp[L]; // column forces of the sub-chain's joints, in the palm's frame once the sweep below is through
-        Inertia carry;
-#pragma unroll
-        for (int i = L - 1; i >= 0; --i) {
-            DRM_RNEA_LINK_FENCE();
-            const int op = P + j * L + i, kd = kind(op);
-            Inertia tot;
-            inertia_from_row(row(op), tot);
-            if (i < L - 1) inertia_add(tot, carry);
-            if (kd & 1) {
-                Force F;
-                hout(dof(op), dof(op), crba_column_force(tot, kd & 2, F));
-#pragma unroll
-                for (int a = i - 1; a >= 0; --a) { // up the sub-chain: into the frame of its op a
-                    Force up;
-                    rnea_link_force_up(Jf[a + 1], tf[a + 1], F, up);
-                    F = up;
-                    const int ka = kind(P + j * L + a);
-                    if (ka & 1) hout(dof(P + j * L + a), dof(op), along(F, ka & 2));
-                }
-                rnea_link_force_up(Jf[0], tf[0], F, Fp[i]); // ... and into the palm's
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Fp[i].la[c] = f2_bcast(0.0f);
-            }
-            Inertia up;
-            inertia_to_parent(Jf[i], tf[i], tot, up);
-            if (i > 0) carry = up;
-            else inertia_add(palm, up);
-        }
-        // the L forces together up the prefix
-#pragma unroll
-        for (int k = P - 1; k >= 0; --k) {
-            DRM_RNEA_LINK_FENCE();
-            const int kk = kind(k);
-            if (kk & 1) {
-#pragma unroll
-                for (int i = 0; i < L; ++i)
-                    if (kind(P + j * L + i) & 1) hout(dof(k), dof(P + j * L + i), along(Fp[i], kk & 2));
-            }
-            if (k > 0) {
-                float J[9], t[3];
-                prefix_joint(k, J, t);
-#pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    Force up;
-                    rnea_link_force_up(J, t, Fp[i], up);
-                    Fp[i] = up;
-                }
-            }
-        }
-    }
-    // the prefix: composite inertias from the palm to the root, every joint's column force walked up its ancestors
+    auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; };
     Inertia carry = palm;
+    int next = first; // ops (counted from the palm) until the next column of this caller
 #pragma unroll
     for (int k = P - 1; k >= 0; --k) {
         DRM_RNEA_LINK_FENCE();
@@ -1083,9 +1086,11 @@ DRM_HD void crba_arm_hand(ROW row, KIND kind, DOF dof, int K, const float (&q)[P
         Inertia tot;
         inertia_from_row(row(k), tot);
         inertia_add(tot, carry);
-        if (kd & 1) {
+        const bool mine = next == 0;
+        next = mine ? step - 1 : next - 1;
+        if ((kd & 1) && mine) {
             Force F;
-            hout(dof(k), dof(k), crba_column_force(tot, kd & 2, F));
+            hout(k, k, crba_column_force(tot, kd & 2, F));
 #pragma unroll
             for (int a = k - 1; a >= 0; --a) {
                 float J[9], t[3];
@@ -1094,7 +1099,7 @@ DRM_HD void crba_arm_hand(ROW row, KIND kind, DOF dof, int K, const float (&q)[P
                 rnea_link_force_up(J, t, F, up);
                 F = up;
                 const int ka = kind(a);
-                if (ka & 1) hout(dof(a), dof(k), along(F, ka & 2));
+                if (ka & 1) hout(a, k, along(F, ka & 2));
             }
         }
         if (k > 0) {
@@ -1103,6 +1108,19 @@ DRM_HD void crba_arm_hand(ROW row, KIND kind, DOF dof, int K, const float (&q)[P
             inertia_to_parent(J, t, tot, carry);
         }
     }
+}
+// the whole matrix from one caller: the sub-chains one after the other, then every column of the prefix
+template <int P, int L, class ROW, class KIND, class HQ, class HOUT>
+DRM_HD void crba_arm_hand(ROW row, KIND kind, int K, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq, HOUT hout) {
+    Inertia palm; // what the sub-chains hand to the last prefix op
+    inertia_zero(palm);
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        Inertia part;
+        crba_arm_hand_sub<P, L>(row, kind, j, q, cs, sn, [&](int i) { return hq(j, i); }, hout, part);
+        inertia_add(palm, part);
+    }
+    crba_arm_hand_prefix<P>(row, kind, q, cs, sn, palm, 0, 1, hout);
 }
 
 } // namespace drm

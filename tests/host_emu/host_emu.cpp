@@ -183,7 +183,7 @@ void fd_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, 
 
 // the arithmetic of crba_arm_hand_kernel<P, L>
 template <int P, int L>
-void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, float *H) {
+void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, float *H, bool split) {
     const int n = w->n_dofs;
     const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
     auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
@@ -193,9 +193,23 @@ void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, floa
         float qv[P], cs[P], sn[P];
         for (int k = 0; k < P; ++k) qv[k] = dof_of(k) < 0 ? 0.f : q[b * n + dof_of(k)];
         chain_trig<P>(qv, cs, sn);
-        crba_arm_hand<P, L>([&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, kind, dof_of, K, qv, cs, sn,
-                            [&](int j, int i) { const int d = dof_of(P + j * L + i); return d < 0 ? 0.f : q[b * n + d]; },
-                            [&](int di, int dj, float v) { H[(b * n + di) * n + dj] = v; H[(b * n + dj) * n + di] = v; });
+        auto row = [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; };
+        auto hq = [&](int j, int i) { const int d = dof_of(P + j * L + i); return d < 0 ? 0.f : q[b * n + d]; };
+        auto hout = [&](int oa, int ob, float v) {
+            const int di = dof_of(oa), dj = dof_of(ob);
+            H[(b * n + di) * n + dj] = v; H[(b * n + dj) * n + di] = v;
+        };
+        if (!split) { crba_arm_hand<P, L>(row, kind, K, qv, cs, sn, hq, hout); continue; }
+        // as the kernel runs it: a wavefront per sub-chain, the palm's composites summed in sub-chain order, the prefix's
+        // columns dealt round-robin to the K wavefronts
+        Inertia palm;
+        inertia_zero(palm);
+        for (int j = 0; j < K; ++j) {
+            Inertia part;
+            crba_arm_hand_sub<P, L>(row, kind, j, qv, cs, sn, [&](int i) { return hq(j, i); }, hout, part);
+            inertia_add(palm, part);
+        }
+        for (int j = 0; j < K; ++j) crba_arm_hand_prefix<P>(row, kind, qv, cs, sn, palm, j, K, hout);
     }
 }
 
@@ -464,13 +478,13 @@ int emu_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float
     else return -2;
     return 0;
 }
-int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H) {
+int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, int32_t split) {
     if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
     const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
     if (P + K * L != w->n_ops) return -1;
-    if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H);
-    else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H);
-    else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H);
+    if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H, split != 0);
+    else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H, split != 0);
+    else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H, split != 0);
     else return -2;
     return 0;
 }

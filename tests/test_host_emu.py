@@ -259,7 +259,11 @@ def test_mass_matrix_of_an_arm_that_carries_a_hand(emu, robot):
     prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
     walk, keep = folded_host_walk(m, prog)
     H = np.full((B, n, n), np.nan, np.float32); H_loop = np.full((B, n, n), np.nan, np.float32)
-    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
+    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H), 0) == 0
+    # ... and as the kernel splits it (a wavefront per sub-chain, the prefix's columns dealt to them): the same floats
+    H_split = np.full((B, n, n), np.nan, np.float32)
+    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H_split), 1) == 0
+    assert np.array_equal(H, H_split)
     assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H_loop)) == 0
     ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
     assert np.allclose(H, ref, atol=2e-5, rtol=2e-5), (robot, np.abs(H - ref).max())

@@ -249,9 +249,9 @@ def test_scratch_queries_answer_zero_without_a_device():
 
 @pytest.mark.gpu
 def test_gpu_scratch_of_the_persistent_kernels():
-    """Robots with a long segment (an arm carrying a hand) need caller-owned scratch for inverse dynamics, the mass matrix and
-    forward dynamics: the queries are positive, do NOT grow with the batch once the grid is full (persistent blocks own a
-    slice each), and a launch without scratch is refused; 7-DoF arms and hands need none."""
+    """Robots with a long segment (an arm carrying a hand) need caller-owned scratch wherever their rows go through the loop
+    kernels (inverse dynamics, the mass matrix, forward dynamics): the queries say how much, do NOT grow with the batch once the
+    grid is full (persistent blocks own a slice each), and a launch without scratch is refused; 7-DoF arms and hands need none."""
     import torch
     from helpers import load_model, sample_states
     lib = backend.load_library()
@@ -261,12 +261,16 @@ def test_gpu_scratch_of_the_persistent_kernels():
     walk = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
     for name in SCRATCH_QUERIES:
         small, big, bigger = (int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
-        if name in ("drm_rnea_scratch_floats", "drm_forward_dynamics_scratch_floats"):
-            # inverse and forward dynamics of an arm that carries a hand: full 64-row tiles run the straight-line kernels
-            # (drm_arm_hand.hip, no scratch); only a ragged tail still goes through the persistent loop kernels
-            assert small == big == bigger == 0, (name, small, big, bigger)
-            assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
-            continue
+        # an arm that carries a hand: full 64-row tiles run the straight-line kernels (drm_arm_hand.hip, no scratch); only a
+        # ragged tail still goes through the persistent loop kernels
+        assert small == big == bigger == 0, (name, small, big, bigger)
+        assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
+    # ... the same walk without its shape bit takes the persistent loop kernels for every row: their scratch does NOT grow with
+    # the batch once the grid is full (a persistent block owns a slice)
+    generic = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
+    generic.shape &= ~4
+    for name in SCRATCH_QUERIES:
+        small, big, bigger = (int(getattr(lib, name)(ctypes.byref(generic), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
         assert 0 < small < big == bigger < (1 << 28), (name, small, big, bigger)   # < 1 GiB whatever the batch
     B, n = 130, m._n_dofs
     q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(m, B, seed=3))

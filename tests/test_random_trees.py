@@ -167,7 +167,13 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
                 assert torch.equal(tau[lo:lo + 128], alone[:128]), lo
         else:
             assert torch.equal(tau[sl], alone), lo
-        assert torch.equal(H[sl], m.compute_lagrangian_inertia_matrix(q[sl])), lo
+        H_alone = m.compute_lagrangian_inertia_matrix(q[sl])
+        if arm_hand:
+            assert np.allclose(H[sl].cpu().numpy(), H_alone.cpu().numpy(), **TOL_TAU), lo
+            if lo % 64 == 0 and lo + 128 <= B - B % 64:
+                assert torch.equal(H[lo:lo + 128], H_alone[:128]), lo
+        else:
+            assert torch.equal(H[sl], H_alone), lo
         acc_alone = m.compute_forward_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)
         if arm_hand:   # (as for inverse dynamics above: full tiles and the ragged tail run different kernels on these robots)
             assert rel(acc[sl].cpu().numpy(), acc_alone.cpu().numpy()) < 1e-3, lo
