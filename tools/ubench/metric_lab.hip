@@ -416,6 +416,19 @@ __global__ void __launch_bounds__(256) k_io_config4(const float *__restrict__ q,
     store16<FL>(quat + tile * 1024 + 4 * tid, v);                // 64 x 16 floats
 }
 
+// bytes only, any shape: a block of 256 lanes per 64-sample tile reads the tile's 64 * IN floats and writes its 64 * OUT floats
+// with 16-byte accesses (IN, OUT runtime, both tiles 16-byte aligned because 64 * 4 bytes divides them): the floor of a
+// streaming launch whose outputs do not fit the Infinity Cache
+template <int FL>
+__global__ void __launch_bounds__(256) k_io_shape(const float *__restrict__ in, float *__restrict__ out, int in_floats, int out_floats) {
+    const size_t tile = blockIdx.x;
+    const float4 *i4 = reinterpret_cast<const float4 *>(in + tile * 64 * in_floats);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < 16 * in_floats; i += 256) { const float4 a = i4[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    float *o = out + tile * 64 * out_floats;
+    for (int i = threadIdx.x; i < 16 * out_floats; i += 256) store16<FL>(o + 4 * i, v);
+}
+
 template <int THREADS, int LDS_FLOATS>
 __global__ void __launch_bounds__(THREADS) k_empty(float *out) {
     if constexpr (LDS_FLOATS > 0) {
@@ -566,6 +579,33 @@ int main(int argc, char **argv) {
     printf("device %s, %d CUs, clock %d kHz, B = %d\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, B);
 
     float *dummy; CK(hipMalloc(&dummy, 4096));
+    if (argc > 2 && !strcmp(argv[2], "floors")) {
+        // `metric_lab B floors`: what the bytes alone cost for the input / output shapes of the other entry points at B samples
+        struct Shape { const char *name; int in, out; };
+        const Shape shapes[] = {
+            {"FK + Jacobian, Panda with gripper (9 DoF)", 9, 7 + 6 * 9},  {"FK + Jacobian, Jaco (12 DoF)", 12, 7 + 6 * 12},
+            {"FK + Jacobian, iiwa7 + Allegro (23 DoF)", 23, 7 + 6 * 23},  {"FK + Jacobian, Fetch (14 DoF)", 14, 7 + 6 * 14},
+            {"inverse dynamics, 7 DoF", 21, 7},                           {"inverse dynamics, 9 DoF", 27, 9},
+            {"inverse dynamics, 12 DoF", 36, 12},                         {"inverse dynamics, 23 DoF", 69, 23},
+            {"mass matrix, 7 DoF", 7, 49},                                {"mass matrix, 9 DoF", 9, 81},
+            {"mass matrix, 12 DoF", 12, 144},                             {"mass matrix, 16 DoF", 16, 256},
+            {"mass matrix, 23 DoF", 23, 529},                             {"FK + inverse dynamics, 7 DoF (config 3)", 21, 14},
+        };
+        size_t max_in = 0, max_out = 0;
+        for (const Shape &sh : shapes) { max_in = std::max(max_in, (size_t)sh.in); max_out = std::max(max_out, (size_t)sh.out); }
+        float *in, *out;
+        CK(hipMalloc(&in, (size_t)B * max_in * 4)); CK(hipMalloc(&out, (size_t)B * max_out * 4));
+        CK(hipMemset(in, 0, (size_t)B * max_in * 4));
+        for (const Shape &sh : shapes) {
+            char name[128];
+            const double mb = (double)B * (sh.in + sh.out) * 4 / 1e6;
+            snprintf(name, sizeof name, "floor %-42s %4d B/sample %7.1f MB plain", sh.name, (sh.in + sh.out) * 4, mb);
+            time_graph(name, [&] { hipLaunchKernelGGL((k_io_shape<ST_PLAIN>), dim3(n_tiles), dim3(256), 0, s, in, out, sh.in, sh.out); }, s);
+            snprintf(name, sizeof name, "floor %-42s %4d B/sample %7.1f MB nt", sh.name, (sh.in + sh.out) * 4, mb);
+            time_graph(name, [&] { hipLaunchKernelGGL((k_io_shape<ST_SC1NT>), dim3(n_tiles), dim3(256), 0, s, in, out, sh.in, sh.out); }, s);
+        }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "overhead")) {
         // `metric_lab B overhead`: THREE kernels only — nothing / the bytes only / the product kernel — each timed here with
         // HIP events (graph of 200, and 200 eager launches), so that the SAME process run under
