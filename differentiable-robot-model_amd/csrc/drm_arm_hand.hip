@@ -169,24 +169,16 @@ __global__ void __launch_bounds__(WAVE)
 // per sub-chain: wavefront j walks sub-chain j (its own entries, its L column forces up the prefix), the K composites meet in
 // the palm through LDS, the prefix's columns are dealt round-robin to the wavefronts; every entry goes to an LDS triangle
 // [slot][64 + 1] (the pad: the writers are 64 lanes of one slot, the readers 64 slots of one sample), and the block then writes
-// the 64 matrices as consecutive floats, 256 bytes per store instruction.
+// the 64 matrices as one run of 16-byte stores, written through the L2 and — beyond the Infinity Cache — past it (bytes-only
+// launches of this shape, tools/ubench/metric_lab floors: 2.3 GB take 723 us with plain stores, 403 us with sc1 nt).
 // LDS (static): [ table ][ K composites : 10 x 64 each ][ triangle : slots x 65 ]
 //               9 + 2x1 ops: 24 KB, 7 + 3x2: 31 KB, 8 + 4x4: 66 KB (two blocks = eight wavefronts per CU)
 // ---------------------------------------------------------------------------------------------------
-// (non-temporal stores of H: 1 068 us instead of 675 us per 2^20 samples of the 23-DoF arm with a hand — they are not merged
-// into lines on the way out)
-#ifndef DRM_AH_H_NT
-#define DRM_AH_H_NT 0
-#endif
-template <int NT>
-__device__ __forceinline__ void store_f32(float *p, float v) {
-    if (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
 constexpr int AH_TRI_STRIDE = WAVE + 1;
-// wavefronts (= sub-chains) the mass-matrix kernel of a shape reserves LDS for: a gripper's two fingers, the Jaco's three, the
-// Allegro's four; a robot of the shape with more of them takes the loop kernel
-constexpr int crba_max_k(int L) { return L == 1 ? 2 : L == 2 ? 3 : 4; }
+// wavefronts (= sub-chains) the mass-matrix kernel of a shape reserves LDS for: a gripper's two fingers (and the tool frame
+// that stays an op beside them when the hand is learnable), the Jaco's three, the Allegro's four; a robot of the shape with
+// more of them takes the loop kernel
+constexpr int crba_max_k(int L) { return L <= 2 ? 3 : 4; }
 template <int P, int L>
 struct AhTriangle { // slots of the pairs (oa <= ob) of ops on a common root path
     static constexpr int KMAX = crba_max_k(L), OPS = P + KMAX * L;
@@ -198,14 +190,15 @@ struct AhTriangle { // slots of the pairs (oa <= ob) of ops on a common root pat
     }
     static DRM_HD bool related(int oa, int ob) { return oa < P || (oa - P) / L == (ob - P) / L; }
 };
-template <int P, int L>
+template <int P, int L, bool NT>
 __global__ void __launch_bounds__(WAVE *crba_max_k(L))
     crba_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q, int K, int cap,
                          int n, float *__restrict__ H) {
     using T = AhTriangle<P, L>;
-    constexpr int C_FLOATS = T::OPS * DRM_OPF_STRIDE, X_FLOATS = T::KMAX * 10 * WAVE;
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + X_FLOATS + T::SLOTS * AH_TRI_STRIDE];
-    __shared__ int op_of_dof[AH_MAX_OPS];
+    constexpr int C_FLOATS = T::OPS * DRM_OPF_STRIDE, X_FLOATS = T::KMAX * 10 * WAVE, ZERO_SLOT = T::SLOTS;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + X_FLOATS + (T::SLOTS + 1) * AH_TRI_STRIDE];
+    __shared__ int op_of_dof[T::OPS];
+    __shared__ int slot_of[T::OPS * T::OPS]; // element (row, column) of a matrix -> its slot x stride (the zero slot: unrelated joints)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int n_ops = P + K * L, nn = n * n;
@@ -217,6 +210,7 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
         const int d = (w0[threadIdx.x] & 0xff) - 1;
         if (d >= 0) op_of_dof[d] = (int)threadIdx.x;
     }
+    if (threadIdx.x <= WAVE) tri[ZERO_SLOT * AH_TRI_STRIDE + threadIdx.x] = 0.0f;
     auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
     auto dof_of = [&](int op) { return (w0[op] & 0xff) - 1; };
     const int64_t b0 = (int64_t)blockIdx.x * WAVE;
@@ -230,12 +224,24 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
 #pragma unroll
     for (int k = 0; k < P; ++k) qv[k] = q_of(dof_of(k));
     __syncthreads(); // the table is staged
+    {
+        unsigned r = threadIdx.x / (unsigned)n, c = threadIdx.x - r * (unsigned)n;
+        const unsigned step_r = blockDim.x / (unsigned)n, step_c = blockDim.x - step_r * (unsigned)n;
+        for (int e = (int)threadIdx.x; e < nn; e += (int)blockDim.x) {
+            const int a0 = op_of_dof[r], a1 = op_of_dof[c];
+            const int oa = a0 < a1 ? a0 : a1, ob = a0 < a1 ? a1 : a0;
+            slot_of[e] = (T::related(oa, ob) ? T::slot(oa, ob) : ZERO_SLOT) * AH_TRI_STRIDE;
+            r += step_r; c += step_c;
+            if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
+        }
+    }
     chain_trig<P>(qv, cs, sn);
     auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
     auto hout = [&](int oa, int ob, float v) { tri[T::slot(oa, ob) * AH_TRI_STRIDE + lane] = v; };
+    Force Fp[L];
     {
         Inertia part;
-        crba_arm_hand_sub<P, L>(row, kind, wave, qv, cs, sn, [&](int i) { return q_of(dof_of(P + wave * L + i)); }, hout, part);
+        crba_arm_hand_sub<P, L>(row, kind, wave, [&](int i) { return q_of(dof_of(P + wave * L + i)); }, hout, Fp, part);
         float *x = lx + wave * (10 * WAVE) + lane;
         x[0] = part.m;
 #pragma unroll
@@ -257,30 +263,33 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
             for (int i = 0; i < 6; ++i) part.I[i] = x[(4 + i) * WAVE];
             inertia_add(palm, part);
         }
-        crba_arm_hand_prefix<P>(row, kind, qv, cs, sn, palm, wave, K, hout);
+        crba_arm_hand_prefix<P, L>(row, kind, wave, qv, cs, sn, palm, Fp, wave, K, hout);
     }
     __syncthreads(); // every entry of the 64 samples is in the triangle
-    // wavefront w writes the matrices of its share of the samples: element e of a matrix = (row e / n, column e % n), its slot
-    // worked out once per lane, the samples an inner loop of independent copies (consecutive lanes, consecutive addresses)
-    const int s_lo = wave * WAVE / K, s_hi = (wave + 1) * WAVE / K;
-    const unsigned step_r = WAVE / (unsigned)n, step_c = WAVE - step_r * (unsigned)n; // 64 = step_r * n + step_c
-    unsigned r = lane / (unsigned)n, c = lane - r * (unsigned)n;
+    // The tile's 64 matrices are 64 n^2 consecutive floats, 16-byte aligned as a whole (a single matrix is not, n^2 being odd
+    // for most robots): the block writes them as 16 n^2 float4, each of its four floats looked up by (sample, element) — the
+    // element's slot from the table, the sample the row of the slot.
+    const int n4 = 16 * nn, stride = 4 * (int)blockDim.x;
+    const int inc_s = stride / nn, inc_e = stride - inc_s * nn;
+    int sm = (4 * (int)threadIdx.x) / nn, e = 4 * (int)threadIdx.x - sm * nn;
     float *g = H + b0 * nn;
-    for (int e = (int)lane; e < nn; e += WAVE) {
-        const int a0 = op_of_dof[r], a1 = op_of_dof[c];
-        const int oa = a0 < a1 ? a0 : a1, ob = a0 < a1 ? a1 : a0;
-        const bool live = T::related(oa, ob);
-        const float *src = tri + (live ? T::slot(oa, ob) : 0) * AH_TRI_STRIDE;
-        float *dst = g + e;
-#pragma unroll 8
-        for (int sm = s_lo; sm < s_hi; ++sm) store_f32<DRM_AH_H_NT>(dst + (int64_t)sm * nn, live ? src[sm] : 0.0f);
-        r += step_r; c += step_c;
-        if (c >= (unsigned)n) { c -= (unsigned)n; ++r; }
+    for (int f = (int)threadIdx.x; f < n4; f += (int)blockDim.x) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool wrap = e + c >= nn;
+            v[c] = tri[slot_of[wrap ? e + c - nn : e + c] + (wrap ? sm + 1 : sm)];
+        }
+        store16_wt<NT>(g + 4 * f, make_float4(v[0], v[1], v[2], v[3]));
+        sm += inc_s; e += inc_e;
+        if (e >= nn) { e -= nn; ++sm; }
     }
 }
 
-// the (P, L) this library is compiled for: those of the robots it ships (robot_data/); anything else keeps the loop kernel
-#define DRM_ARM_HAND_SHAPES(X) X(9, 1) X(7, 2) X(8, 4)
+// the (P, L) this library is compiled for: those of the robots it ships (robot_data/) — Panda with gripper 7 + 2 x 1, Jaco
+// 6 + 3 x 2, iiwa7 + Allegro 7 + 4 x 4 once the host has folded every fixed joint (flatten.foldable_links), and 9 + 2 x 1,
+// 7 + 3 x 2, 8 + 4 x 4 when learnable links keep the flange / palm an op of its own; anything else keeps the loop kernel
+#define DRM_ARM_HAND_SHAPES(X) X(7, 1) X(6, 2) X(7, 4) X(9, 1) X(7, 2) X(8, 4)
 
 static bool shape_of(const drm_walk *w, int &P, int &K, int &L) {
     if (!(w->shape & DRM_WALK_ARM_HAND)) return false;
@@ -351,7 +360,7 @@ bool crba_arm_hand_applies(const drm_walk *w) {
     return false;
 #else
     int P, K, L;
-    return arm_hand_compiled(w) && shape_of(w, P, K, L) && K <= crba_max_k(L);
+    return arm_hand_compiled(w) && shape_of(w, P, K, L) && K >= 2 && K <= crba_max_k(L);
 #endif
 }
 int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, hipStream_t s) {
@@ -363,10 +372,15 @@ int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float
         (((uintptr_t)w->ops_f | (uintptr_t)q | (uintptr_t)H) & 15u) != 0)
         return 0;
     const int n_tiles = (int)(B / WAVE);
+    const bool nt = stream_past_llc((int64_t)n_tiles * WAVE * w->n_dofs * w->n_dofs * 4);
 #define X(p, l)                                                                                                                  \
     if (P == p && L == l) {                                                                                                      \
-        hipLaunchKernelGGL((crba_arm_hand_kernel<p, l>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f, w->ops_i, q, K, \
-                           (int)w->capacity, (int)w->n_dofs, H);                                                                 \
+        if (nt)                                                                                                                  \
+            hipLaunchKernelGGL((crba_arm_hand_kernel<p, l, true>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f,      \
+                               w->ops_i, q, K, (int)w->capacity, (int)w->n_dofs, H);                                             \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((crba_arm_hand_kernel<p, l, false>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f,     \
+                               w->ops_i, q, K, (int)w->capacity, (int)w->n_dofs, H);                                             \
         return (int64_t)n_tiles * WAVE;                                                                                          \
     }
     DRM_ARM_HAND_SHAPES(X)

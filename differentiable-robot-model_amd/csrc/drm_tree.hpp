@@ -977,8 +977,9 @@ DRM_HD void aba_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, 
 // prefix (one transform per prefix op and force, the prefix's joint transforms rebuilt from cos / sin on the way) and hands
 // the palm its composite inertia; the prefix then runs the chain form (crba_chain_trig) with the palm's composites added.
 // Two pieces, so that a block can give every sub-chain its own wavefront (drm_arm_hand.hip) and share the prefix's columns:
-//   crba_arm_hand_sub<P, L>(.., j, .., palm)       sub-chain j: its entries, and what it hands the palm
-//   crba_arm_hand_prefix<P>(.., palm, first, step) the columns P-1-first, P-1-first-step, ... of the prefix (composites of all)
+//   crba_arm_hand_sub<P, L>(.., j, .., Fp, palm)            sub-chain j: its own entries, its L column forces in the palm's
+//                                                           frame, and the composite it hands the palm
+//   crba_arm_hand_prefix<P, L>(.., palm, Fp, first, step)   see there
 //   row(op), kind(op) (1 = moves, 2 = prismatic)   wave-uniform
 //   q / cs / sn of the prefix ops;  hq(i) -> joint value of op i of the sub-chain
 //   hout(oa, ob, v)   the entry of the joints of ops oa <= ob (ob's column force seen by oa's axis), once per pair of moving
@@ -1005,8 +1006,7 @@ DRM_HD float crba_column_force(const Inertia &tot, bool prismatic, Force &F) {
     return tot.m;
 }
 template <int P, int L, class ROW, class KIND, class HQ, class HOUT>
-DRM_HD void crba_arm_hand_sub(ROW row, KIND kind, int j, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq,
-                              HOUT hout, Inertia &palm) {
+DRM_HD void crba_arm_hand_sub(ROW row, KIND kind, int j, HQ hq, HOUT hout, Force (&Fp)[L], Inertia &palm) {
     auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; }; // S . F
     float hqv[L], hc[L], hs[L], Jf[L][9], tf[L][3];
 #pragma unroll
@@ -1017,7 +1017,6 @@ DRM_HD void crba_arm_hand_sub(ROW row, KIND kind, int j, const float (&q)[P], co
         const int kd = kind(P + j * L + i);
         joint_transform(load_ft(row(P + j * L + i)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], Jf[i], tf[i]);
     }
-    Force Fp[L]; // column forces of the sub-chain's joints, in the palm's frame once the sweep below is through
     Inertia carry;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
@@ -1045,40 +1044,26 @@ DRM_HD void crba_arm_hand_sub(ROW row, KIND kind, int j, const float (&q)[P], co
         if (i > 0) inertia_to_parent(Jf[i], tf[i], tot, carry);
         else inertia_to_parent(Jf[i], tf[i], tot, palm);
     }
-    // the L forces together up the prefix
-#pragma unroll
-    for (int k = P - 1; k >= 0; --k) {
-        DRM_RNEA_LINK_FENCE();
-        const int kk = kind(k);
-        if (kk & 1) {
-#pragma unroll
-            for (int i = 0; i < L; ++i)
-                if (kind(P + j * L + i) & 1) hout(k, P + j * L + i, along(Fp[i], kk & 2));
-        }
-        if (k > 0) {
-            float J[9], t[3];
-            joint_transform(load_ft(row(k)), kk & 1, kk & 2, q[k], cs[k], sn[k], J, t);
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                Force up;
-                rnea_link_force_up(J, t, Fp[i], up);
-                Fp[i] = up;
-            }
-        }
-    }
 }
-// the prefix: composite inertias from the palm to the root, the column forces of ops P-1-first, P-1-first-step, ... walked up
-// their ancestors (first = 0, step = 1: every column)
-template <int P, class ROW, class KIND, class HOUT>
-DRM_HD void crba_arm_hand_prefix(ROW row, KIND kind, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], const Inertia &palm,
-                                 int first, int step, HOUT hout) {
-    auto prefix_joint = [&](int k, float *J, float *t) {
-        const int kd = kind(k);
-        joint_transform(load_ft(row(k)), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
-    };
+// The prefix, ONE sweep from the palm to the root for everything a caller carries: the composite inertias (of all the ops),
+// the L column forces Fp of sub-chain j, and the column forces of the prefix ops P-1-first, P-1-first-step, ... (step >= 2: at
+// most (P + 1) / 2 of them live at once); every op's joint transform is built once per sweep and moves all of them.
+template <int P, int L, class ROW, class KIND, class HOUT>
+DRM_HD void crba_arm_hand_prefix(ROW row, KIND kind, int j, const float (&q)[P], const float (&cs)[P], const float (&sn)[P],
+                                 const Inertia &palm, Force (&Fp)[L], int first, int step, HOUT hout) {
+    constexpr int LIVE = (P + 1) / 2;
     auto along = [](const Force &F, bool prismatic) { return prismatic ? F.la[2][0] : F.la[2][1]; };
+    Force Fl[LIVE];
+    int col[LIVE];    // the op whose column slot i carries (wave-uniform; below 0: none)
+    bool live[LIVE];
+#pragma unroll
+    for (int i = 0; i < LIVE; ++i) {
+        col[i] = P - 1 - first - i * step;
+        live[i] = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Fl[i].la[c] = f2_bcast(0.0f);
+    }
     Inertia carry = palm;
-    int next = first; // ops (counted from the palm) until the next column of this caller
 #pragma unroll
     for (int k = P - 1; k >= 0; --k) {
         DRM_RNEA_LINK_FENCE();
@@ -1086,41 +1071,38 @@ DRM_HD void crba_arm_hand_prefix(ROW row, KIND kind, const float (&q)[P], const 
         Inertia tot;
         inertia_from_row(row(k), tot);
         inertia_add(tot, carry);
-        const bool mine = next == 0;
-        next = mine ? step - 1 : next - 1;
-        if ((kd & 1) && mine) {
-            Force F;
-            hout(k, k, crba_column_force(tot, kd & 2, F));
+        if (kd & 1) {
 #pragma unroll
-            for (int a = k - 1; a >= 0; --a) {
-                float J[9], t[3];
-                prefix_joint(a + 1, J, t);
-                Force up;
-                rnea_link_force_up(J, t, F, up);
-                F = up;
-                const int ka = kind(a);
-                if (ka & 1) hout(a, k, along(F, ka & 2));
+            for (int i = 0; i < L; ++i)
+                if (kind(P + j * L + i) & 1) hout(k, P + j * L + i, along(Fp[i], kd & 2));
+#pragma unroll
+            for (int i = 0; i < LIVE; ++i) {
+                if (live[i]) hout(k, col[i], along(Fl[i], kd & 2));
+                if (col[i] == k) {
+                    hout(k, k, crba_column_force(tot, kd & 2, Fl[i]));
+                    live[i] = true;
+                }
             }
         }
         if (k > 0) {
             float J[9], t[3];
-            prefix_joint(k, J, t);
+            joint_transform(load_ft(row(k)), kd & 1, kd & 2, q[k], cs[k], sn[k], J, t);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                Force up;
+                rnea_link_force_up(J, t, Fp[i], up);
+                Fp[i] = up;
+            }
+#pragma unroll
+            for (int i = 0; i < LIVE; ++i)
+                if (live[i]) {
+                    Force up;
+                    rnea_link_force_up(J, t, Fl[i], up);
+                    Fl[i] = up;
+                }
             inertia_to_parent(J, t, tot, carry);
         }
     }
-}
-// the whole matrix from one caller: the sub-chains one after the other, then every column of the prefix
-template <int P, int L, class ROW, class KIND, class HQ, class HOUT>
-DRM_HD void crba_arm_hand(ROW row, KIND kind, int K, const float (&q)[P], const float (&cs)[P], const float (&sn)[P], HQ hq, HOUT hout) {
-    Inertia palm; // what the sub-chains hand to the last prefix op
-    inertia_zero(palm);
-#pragma unroll 1
-    for (int j = 0; j < K; ++j) {
-        Inertia part;
-        crba_arm_hand_sub<P, L>(row, kind, j, q, cs, sn, [&](int i) { return hq(j, i); }, hout, part);
-        inertia_add(palm, part);
-    }
-    crba_arm_hand_prefix<P>(row, kind, q, cs, sn, palm, 0, 1, hout);
 }
 
 } // namespace drm

@@ -294,10 +294,11 @@ def _capacity_for(n_ops: int) -> int:
     return (n_ops + 3) // 4 * 4
 
 
-def _gather_row(spec: RobotSpec, link: int):
-    """(flat link-table indices, +-1 factors) of one op's constants, with the axis canonicalisation applied."""
+def _gather_row(spec: RobotSpec, link: int, parent: Optional[int] = None):
+    """(flat link-table indices, +-1 factors) of one op's constants, with the axis canonicalisation applied.  ``parent``: the
+    link whose frame the row's F / t are expressed in (default: the link's parent)."""
     base = link * OPF_STRIDE
-    pp, dp = spec.perm_of(int(spec.parent[link]))   # rows of F / t follow the parent's stored frame
+    pp, dp = spec.perm_of(int(spec.parent[link]) if parent is None else int(parent))   # rows of F / t follow the parent's stored frame
     pi, di = spec.perm_of(link)                     # columns of F and body-frame quantities follow this link's
     row = np.empty(OPF_STRIDE, np.int64)
     sgn = np.ones(OPF_STRIDE, np.float32)
@@ -333,11 +334,11 @@ def _gather_plain(row_index: int):
     return row, np.ones(OPF_STRIDE, np.float32)
 
 
-def _gather_axis_op(spec: RobotSpec, link: int, row_index: int):
+def _gather_axis_op(spec: RobotSpec, link: int, row_index: int, parent: Optional[int] = None):
     """Op A of a skew-axis link: virtual row `row_index` (F R_a, t), its rows following the parent's stored frame."""
     row, sgn = _gather_plain(row_index)
     base = row_index * OPF_STRIDE
-    pp, dp = spec.perm_of(int(spec.parent[link]))
+    pp, dp = spec.perm_of(int(spec.parent[link]) if parent is None else int(parent))
     for r in range(3):
         for c in range(3):
             row[opf_fij(r, c)] = base + OPF_F + pp[r] * 3 + c
@@ -348,40 +349,53 @@ def _gather_axis_op(spec: RobotSpec, link: int, row_index: int):
 
 
 def foldable_links(spec: RobotSpec, keep: Sequence[int] = ()) -> np.ndarray:
-    """bool [L]: links behind a FIXED joint with no moving joint below them — end-effector frames, fingertips, sensor
-    mounts.  They are rigidly attached to their nearest non-foldable ancestor, so a dynamics walk may leave them out when
-    that ancestor's row carries their inertia as well (fold_link_table): same torques / inertia matrix / accelerations,
-    one op less per such link (Panda: 8 -> 7 ops, Allegro: 21 -> 17).
+    """bool [L]: links behind a FIXED joint — end-effector frames, fingertips, sensor mounts, and the plates, flanges and palms
+    between moving joints.  Such a link is rigidly attached to its nearest non-foldable ancestor (its fold target), so a
+    dynamics walk may leave it out when the target's row carries its inertia as well and the rows of the links below it
+    carry its transform (fold_link_table): same torques / inertia matrix / accelerations, one op less per such link
+    (Panda: 8 -> 7 ops, Panda with gripper: 12 -> 9, Allegro: 20 -> 16, Fetch: 24 -> 14).
     ``keep``: links that must stay ops of their own — those with learnable parameters (their constants change every step
-    and their gradients are theirs); a link whose fold target is such a link stays as well (the target's row is rebuilt
-    from its parameters alone), and may in turn take its own foldable children."""
+    and their gradients are theirs).  A link whose fold target is such a link stays as well (the target's row is rebuilt
+    from its parameters alone), and so does the fixed parent of such a link (the link's own row is rebuilt from ITS
+    parameters alone and could not carry the parent's transform)."""
     L = spec.n_links
     keep = set(int(i) for i in keep)
     while True:
         fold = np.zeros(L, bool)
-        for i in range(L - 1, 0, -1):      # children come after their parents in URDF <link> order
-            fold[i] = spec.kind[i] == KIND_FIXED and i not in keep and all(fold[c] for c in spec.children[i])
+        for i in range(1, L):
+            fold[i] = spec.kind[i] == KIND_FIXED and i not in keep and not spec.skew[i]
         bad = set()
         for i in np.nonzero(fold)[0]:
-            t = int(spec.parent[i])
-            while t > 0 and fold[t]:
-                t = int(spec.parent[t])
-            if t in keep and spec.parent[i] >= 0:
+            if effective_parent(spec, fold, int(i)) in keep and spec.parent[i] >= 0:
                 bad.add(int(i))
+        for i in keep:
+            if 0 < i < L and spec.parent[i] > 0 and fold[spec.parent[i]]:
+                bad.add(int(spec.parent[i]))
         if not bad:
             return fold
         keep |= bad
 
 
+def effective_parent(spec: RobotSpec, fold: np.ndarray, link: int) -> int:
+    """The nearest ancestor of ``link`` that is not folded (0: the root)."""
+    t = int(spec.parent[link])
+    while t > 0 and fold[t]:
+        t = int(spec.parent[t])
+    return t
+
+
 def fold_link_table(spec: RobotSpec, table: np.ndarray, fold: Optional[np.ndarray] = None) -> np.ndarray:
     """The [L+1(+...), 32] link table with the inertia of every foldable link moved into its parent's row (composite
     rigid body, expressed in the parent link's frame): m' = m_p + m,  (mc)' = (mc)_p + F (mc) + m t,
-    I_o' = I_o,p + F I_o F^T + m [(t.t) E - t t^T] + 2 (h.t) E - h t^T - t h^T  with h = F (mc).  fp64 on the host, once per
-    robot.  Rows keep their F / t (FK through such a link is unchanged); a foldable link hanging off the root is dropped."""
+    I_o' = I_o,p + F I_o F^T + m [(t.t) E - t t^T] + 2 (h.t) E - h t^T - t h^T  with h = F (mc), and with the transforms of
+    the folded links between a link and its nearest non-folded ancestor composed into THAT link's F / t
+    (x_anc = F_f (F_c x + t_c) + t_f).  fp64 on the host, once per robot.  The folded rows keep their own F / t (FK to such a
+    link, walked through its folded ancestors, is unchanged); a foldable link hanging off the root loses its inertia."""
     out = np.array(table, np.float64, copy=True)
     if fold is None:
         fold = foldable_links(spec)
-    for i in range(spec.n_links - 1, 0, -1):
+    orig = out.copy()
+    for i in range(spec.n_links - 1, 0, -1):      # children come after their parents in URDF <link> order
         if not fold[i]:
             continue
         row = out[i]
@@ -398,6 +412,17 @@ def fold_link_table(spec: RobotSpec, table: np.ndarray, fold: Optional[np.ndarra
         row[OPF_MASS] = 0.0
         row[OPF_MCOM:OPF_MCOM + 3] = 0.0
         row[OPF_IO:OPF_IO + 9] = 0.0
+    for i in range(1, spec.n_links):
+        if fold[i]:
+            continue
+        F, t = orig[i, OPF_F:OPF_F + 9].reshape(3, 3).copy(), orig[i, OPF_T:OPF_T + 3].copy()
+        p = int(spec.parent[i])
+        while p > 0 and fold[p]:
+            Fp, tp = orig[p, OPF_F:OPF_F + 9].reshape(3, 3), orig[p, OPF_T:OPF_T + 3]
+            F, t = Fp @ F, Fp @ t + tp
+            p = int(spec.parent[p])
+        out[i, OPF_F:OPF_F + 9] = F.reshape(9)
+        out[i, OPF_T:OPF_T + 3] = t
     return out
 
 
@@ -414,12 +439,36 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     Both are exact restatements of x_parent = F Rot_a(q) x_child + t, so no kernel knows about general axes."""
     L = spec.n_links
     needed = np.zeros(L, bool)
+    if drop_folded and fold is None:
+        fold = foldable_links(spec)
     if whole_tree:
-        needed[1:] = ~(fold if fold is not None else foldable_links(spec))[1:] if drop_folded else True
+        needed[1:] = ~fold[1:] if drop_folded else True
     tlist = [int(t) for t in (targets or [])]
+    if fold is not None and not whole_tree and len(tlist) != 1:
+        raise ValueError("a walk on a folded link table is the whole tree or the chain to one target")
     for t in tlist:
-        for i in spec.chain_to(t):
-            needed[i] = True
+        chain = spec.chain_to(t)
+        for n, i in enumerate(chain):
+            # on a folded table a non-folded link's row carries the transforms of the folded links between it and its nearest
+            # non-folded ancestor: those are not walked again (the folded links at the END of the chain kept their own rows)
+            needed[i] = fold is None or not fold[i] or all(fold[c] for c in chain[n + 1:])
+    dropped = np.zeros(L, bool) if fold is None else (fold & ~needed)   # folded links the walk steps over
+
+    def kids_of(i):
+        out = []
+        for c in spec.children[i]:
+            if needed[c]:
+                out.append(c)
+            elif dropped[c]:
+                out += kids_of(c)
+        return out
+
+    def frame_parent(i):
+        """The link whose frame row i's F / t are expressed in: the nearest ancestor that is not stepped over."""
+        t = int(spec.parent[i])
+        while t > 0 and dropped[t]:
+            t = int(spec.parent[t])
+        return t
     out_of = {}
     for slot, t in enumerate(tlist):
         if t in out_of:
@@ -443,7 +492,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
 
     def visit(i, src, par):
         nonlocal max_used, unique
-        kids = [c for c in spec.children[i] if needed[c]]
+        kids = kids_of(i)
         save = -1
         if len(kids) > 1:
             if max_used < MAX_SLOTS:
@@ -470,9 +519,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
 
     # the root (link 0) has the identity pose and is never an op; its needed
     # children all read SRC_ROOT, so a root with several children costs no slot
-    for c in spec.children[0]:
-        if needed[c]:
-            visit(c, SRC_ROOT, -1)
+    for c in kids_of(0):
+        visit(c, SRC_ROOT, -1)
     # a target that IS the root has no op: handled by the caller (identity pose)
     n_ops = len(ops)
     if spec.n_dofs > MAX_DOFS:
@@ -500,9 +548,9 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
         pris_arr[:n_ops] = prismatic
         for k, (gk, arg) in enumerate(gkind):
             if gk == "link":
-                gather[k], gsign[k] = _gather_row(spec, arg)
+                gather[k], gsign[k] = _gather_row(spec, arg, frame_parent(arg))
             elif gk == "axis":
-                gather[k], gsign[k] = _gather_axis_op(spec, links[k], arg)
+                gather[k], gsign[k] = _gather_axis_op(spec, links[k], arg, frame_parent(links[k]))
             else:
                 gather[k], gsign[k] = _gather_plain(arg)
     else:

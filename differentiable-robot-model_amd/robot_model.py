@@ -491,11 +491,13 @@ class DifferentiableRobotModel(torch.nn.Module):
         return key
 
     def _dynamics_walk(self) -> _DeviceWalk:
-        """The whole-tree walk of the dynamics kernels, forward and backward.  Links behind fixed joints with no moving
-        joint below them (end-effector frames, fingertips) are folded into their parents: their inertia is added to the
-        parent's row once on the host (flatten.fold_link_table) and the walk leaves them out — the same torques / inertia
-        matrix / accelerations and the same gradients from fewer ops (Panda 8 -> 7, Allegro 21 -> 17).  Links with learnable
-        parameters stay ops of their own, and so does whatever would have been folded into them (flatten.foldable_links)."""
+        """The whole-tree walk of the dynamics kernels, forward and backward.  Links behind fixed joints (end-effector frames,
+        fingertips, and the flanges / palms / plates between moving joints) are folded away: their inertia is added to the
+        nearest moving ancestor's row and their transform composed into the rows of the links below them, once on the host
+        (flatten.fold_link_table), and the walk leaves them out — the same torques / inertia matrix / accelerations and the
+        same gradients from one op per DoF (Panda 8 -> 7, Panda with gripper 12 -> 9, Allegro 20 -> 16, Fetch 24 -> 14).  Links
+        with learnable parameters stay ops of their own, and so does whatever would have been folded into them or would have
+        had to carry a transform for them (flatten.foldable_links)."""
         key = self._fold_key()
         if not self._fold_masks[key].any():
             return self._get_walk(("tree",), whole_tree=True)

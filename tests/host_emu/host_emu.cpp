@@ -183,7 +183,7 @@ void fd_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, 
 
 // the arithmetic of crba_arm_hand_kernel<P, L>
 template <int P, int L>
-void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, float *H, bool split) {
+void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, float *H) {
     const int n = w->n_dofs;
     const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
     auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
@@ -199,17 +199,16 @@ void crba_arm_hand_emu(const drm_walk *w, int K, const float *q, int64_t B, floa
             const int di = dof_of(oa), dj = dof_of(ob);
             H[(b * n + di) * n + dj] = v; H[(b * n + dj) * n + di] = v;
         };
-        if (!split) { crba_arm_hand<P, L>(row, kind, K, qv, cs, sn, hq, hout); continue; }
-        // as the kernel runs it: a wavefront per sub-chain, the palm's composites summed in sub-chain order, the prefix's
-        // columns dealt round-robin to the K wavefronts
-        Inertia palm;
+        // as the kernel runs it: a wavefront per sub-chain, the palm's composites summed in sub-chain order, every wavefront
+        // sweeps the prefix with its sub-chain's forces and its share of the prefix's columns
+        Inertia palm, part[4];
+        Force Fp[4][L];
         inertia_zero(palm);
         for (int j = 0; j < K; ++j) {
-            Inertia part;
-            crba_arm_hand_sub<P, L>(row, kind, j, qv, cs, sn, [&](int i) { return hq(j, i); }, hout, part);
-            inertia_add(palm, part);
+            crba_arm_hand_sub<P, L>(row, kind, j, [&](int i) { return hq(j, i); }, hout, Fp[j], part[j]);
+            inertia_add(palm, part[j]);
         }
-        for (int j = 0; j < K; ++j) crba_arm_hand_prefix<P>(row, kind, qv, cs, sn, palm, j, K, hout);
+        for (int j = 0; j < K; ++j) crba_arm_hand_prefix<P, L>(row, kind, j, qv, cs, sn, palm, Fp[j], j, K, hout);
     }
 }
 
@@ -462,6 +461,9 @@ int emu_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const 
     if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
     const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
     if (P + K * L != w->n_ops) return -1;
+    if (P == 7 && L == 1) { rnea_arm_hand_emu<7, 1>(w, K, q, qd, qdd, B, flags, tau); return 0; }
+    if (P == 6 && L == 2) { rnea_arm_hand_emu<6, 2>(w, K, q, qd, qdd, B, flags, tau); return 0; }
+    if (P == 7 && L == 4) { rnea_arm_hand_emu<7, 4>(w, K, q, qd, qdd, B, flags, tau); return 0; }
     if (P == 9 && L == 1) rnea_arm_hand_emu<9, 1>(w, K, q, qd, qdd, B, flags, tau);
     else if (P == 7 && L == 2) rnea_arm_hand_emu<7, 2>(w, K, q, qd, qdd, B, flags, tau);
     else if (P == 8 && L == 4) rnea_arm_hand_emu<8, 4>(w, K, q, qd, qdd, B, flags, tau);
@@ -472,19 +474,25 @@ int emu_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float
     if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
     const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
     if (P + K * L != w->n_ops) return -1;
+    if (P == 7 && L == 1) { fd_arm_hand_emu<7, 1>(w, K, q, qd, f, B, flags, qdd); return 0; }
+    if (P == 6 && L == 2) { fd_arm_hand_emu<6, 2>(w, K, q, qd, f, B, flags, qdd); return 0; }
+    if (P == 7 && L == 4) { fd_arm_hand_emu<7, 4>(w, K, q, qd, f, B, flags, qdd); return 0; }
     if (P == 9 && L == 1) fd_arm_hand_emu<9, 1>(w, K, q, qd, f, B, flags, qdd);
     else if (P == 7 && L == 2) fd_arm_hand_emu<7, 2>(w, K, q, qd, f, B, flags, qdd);
     else if (P == 8 && L == 4) fd_arm_hand_emu<8, 4>(w, K, q, qd, f, B, flags, qdd);
     else return -2;
     return 0;
 }
-int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, int32_t split) {
+int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H) {
     if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
     const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
-    if (P + K * L != w->n_ops) return -1;
-    if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H, split != 0);
-    else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H, split != 0);
-    else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H, split != 0);
+    if (P + K * L != w->n_ops || K < 2 || K > 4) return -1;
+    if (P == 7 && L == 1) { crba_arm_hand_emu<7, 1>(w, K, q, B, H); return 0; }
+    if (P == 6 && L == 2) { crba_arm_hand_emu<6, 2>(w, K, q, B, H); return 0; }
+    if (P == 7 && L == 4) { crba_arm_hand_emu<7, 4>(w, K, q, B, H); return 0; }
+    if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H);
+    else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H);
+    else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H);
     else return -2;
     return 0;
 }

@@ -201,23 +201,36 @@ def test_arm_chain_rnea_two_samples_per_lane(emu, robot, flags, folded):
     assert np.allclose(tau0, o0, atol=2e-5, rtol=2e-5)
 
 
-@pytest.mark.parametrize("robot,shape", [("panda", (9, 2, 1)), ("jaco", (7, 3, 2)), ("iiwa7_allegro", (8, 4, 4)),
-                                         ("panda:sliding-fingers", (9, 2, 1))])
+def arm_hand_case(case):
+    """"robot[:sliding-fingers][+kept link]" -> (model, folded dynamics walk, its host struct).  ":sliding-fingers": the
+    gripper's prismatic joints modelled as such (reference_compat=False), not as the reference does; "+link": that link keeps
+    an op of its own, as it does when it has learnable parameters (the flange / palm stays in the prefix)."""
+    name, _, kept = case.partition("+")
+    m = load_model(name.split(":")[0], reference_compat=":" not in name)
+    fold = foldable_links(m._spec, keep=[m._name_to_idx_map[kept]] if kept else [])
+    prog = build_walk(m._spec, whole_tree=True, drop_folded=True, fold=fold)
+    walk, keep = folded_host_walk(m, prog, fold)
+    return m, prog, walk, keep
+
+
+ARM_HAND_CASES = ["panda", "jaco", "iiwa7_allegro", "panda:sliding-fingers", "panda+panda_hand", "jaco+j2n6s300_link_base",
+                  "iiwa7_allegro+palm_link"]
+ARM_HAND_SHAPES = [(7, 2, 1), (6, 3, 2), (7, 4, 4), (7, 2, 1), (9, 3, 1), (7, 3, 2), (8, 4, 4)]
+
+
+@pytest.mark.parametrize("robot,shape", list(zip(ARM_HAND_CASES, ARM_HAND_SHAPES)))
 @pytest.mark.parametrize("flags", [0, 3])
 def test_arm_that_carries_a_hand(emu, robot, shape, flags):
     """flatten.arm_hand_shape finds (P, K, L) of the folded dynamics walk; rnea_arm_hand (the arithmetic of rnea_arm_hand_kernel:
     sub-chains swept forward and backward while the palm's motion is live, only the prefix forces parked) against the fp64
     oracle and against the loop form of the walk."""
     from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
-    # "panda:sliding-fingers": the gripper's prismatic joints modelled as such (reference_compat=False), not as the reference does
-    m = load_model(robot.split(":")[0], reference_compat=":" not in robot)
+    m, prog, walk, keep = arm_hand_case(robot)
     n, B = m._n_dofs, 23
     q, qd, qdd = sample_states(m, B, seed=41)
     q[5, 2] = -2.5e5
-    prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
     sh = prog.shape & 0xffffffff
     assert sh & SHAPE_ARM_HAND and ((sh >> 24) & 0xf, ((sh >> 28) & 3) + 1, ((sh >> 30) & 3) + 1) == shape
-    walk, keep = folded_host_walk(m, prog)
     tau = np.full((B, n), np.nan, np.float32); tau_loop = np.full((B, n), np.nan, np.float32)
     assert emu.emu_rnea_arm_hand(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau)) == 0
     assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(tau_loop)) == 0
@@ -230,16 +243,14 @@ def test_arm_that_carries_a_hand(emu, robot, shape, flags):
         assert not (build_walk(mo._spec, whole_tree=True, drop_folded=True).shape & SHAPE_ARM_HAND), other
 
 
-@pytest.mark.parametrize("robot", ["panda", "jaco", "iiwa7_allegro", "panda:sliding-fingers"])
+@pytest.mark.parametrize("robot", ARM_HAND_CASES)
 @pytest.mark.parametrize("flags", [0, 3])
 def test_forward_dynamics_of_an_arm_that_carries_a_hand(emu, robot, flags):
     """aba_arm_hand (the arithmetic of forward_dynamics_arm_hand_kernel: the articulated-body recursion with the sub-chains
     visited twice instead of stored) against the fp64 oracle and against the loop form of the recursion."""
-    m = load_model(robot.split(":")[0], reference_compat=":" not in robot)
+    m, prog, walk, keep = arm_hand_case(robot)
     n, B = m._n_dofs, 17
     q, qd, f = sample_states(m, B, seed=43)
-    prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
-    walk, keep = folded_host_walk(m, prog)
     acc = np.full((B, n), np.nan, np.float32); acc_loop = np.full((B, n), np.nan, np.float32)
     assert emu.emu_forward_dynamics_arm_hand(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(acc)) == 0
     assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(f), ctypes.c_int64(B), flags, _ptr(acc_loop)) == 0
@@ -249,21 +260,15 @@ def test_forward_dynamics_of_an_arm_that_carries_a_hand(emu, robot, flags):
     assert rel(acc, acc_loop) < 1e-3, (robot, rel(acc, acc_loop))
 
 
-@pytest.mark.parametrize("robot", ["panda", "jaco", "iiwa7_allegro", "panda:sliding-fingers"])
+@pytest.mark.parametrize("robot", ARM_HAND_CASES)
 def test_mass_matrix_of_an_arm_that_carries_a_hand(emu, robot):
     """crba_arm_hand (the arithmetic of crba_arm_hand_kernel: a sub-chain's column forces carried together up the prefix, nothing
     parked) against the fp64 oracle and the loop form of the composite-rigid-body walk; structural zeros stay zero."""
-    m = load_model(robot.split(":")[0], reference_compat=":" not in robot)
+    m, prog, walk, keep = arm_hand_case(robot)
     n, B = m._n_dofs, 11
     q, _, _ = sample_states(m, B, seed=47)
-    prog = build_walk(m._spec, whole_tree=True, drop_folded=True)
-    walk, keep = folded_host_walk(m, prog)
     H = np.full((B, n, n), np.nan, np.float32); H_loop = np.full((B, n, n), np.nan, np.float32)
-    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H), 0) == 0
-    # ... and as the kernel splits it (a wavefront per sub-chain, the prefix's columns dealt to them): the same floats
-    H_split = np.full((B, n, n), np.nan, np.float32)
-    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H_split), 1) == 0
-    assert np.array_equal(H, H_split)
+    assert emu.emu_crba_arm_hand(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H)) == 0
     assert emu.emu_crba(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), _ptr(H_loop)) == 0
     ref = Oracle(m._spec).mass_matrix(q.astype(np.float64), False, False, np.float64)
     assert np.allclose(H, ref, atol=2e-5, rtol=2e-5), (robot, np.abs(H - ref).max())
@@ -357,10 +362,11 @@ def folded_host_walk(model, prog, fold=None):
 
 
 @pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7", "allegro_left", "trifinger_edu", "panda", "fetch"])
-def test_folding_fixed_leaf_links_into_their_parents_leaves_the_dynamics_unchanged(emu, robot):
-    """flatten.foldable_links / fold_link_table: a dynamics walk without the links behind fixed leaf joints, on a table
-    whose parent rows carry their inertia, gives the torques, inertia matrix and accelerations of the full walk (and of
-    the oracle, which knows nothing about folding)."""
+def test_folding_fixed_links_into_their_parents_leaves_the_dynamics_unchanged(emu, robot):
+    """flatten.foldable_links / fold_link_table: a dynamics walk without the links behind fixed joints (tool frames and
+    fingertips, and the flanges / palms / mounting plates between moving joints), on a table whose rows carry their inertia
+    (the nearest moving ancestor's) and their transforms (the links below), gives the torques, inertia matrix and
+    accelerations of the full walk (and of the oracle, which knows nothing about folding)."""
     m = load_model(robot)
     fold = foldable_links(m._spec)
     assert fold.any()
@@ -382,12 +388,32 @@ def test_folding_fixed_leaf_links_into_their_parents_leaves_the_dynamics_unchang
     orc = Oracle(m._spec)
     assert np.allclose(t1, orc.rnea(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), True, True, np.float64),
                        rtol=2e-5, atol=2e-5)
-    # the chain walk to a folded link on the folded table: FK constants untouched, its own inertia gone
+    # the chain walk to a folded link on the folded table (drm_fk_rnea's second walk): it steps over the folded links whose
+    # transforms the rows below them carry, keeps the folded links at its end — the same pose as the full chain on the plain
+    # table, the target's own inertia gone
     tip = int(np.nonzero(fold)[0][-1])
-    chain = build_walk(m._spec, targets=[tip])
-    _w, ops_f = folded_host_walk(m, chain)
-    _w0, ops_f0 = host_walk(m, chain)
-    assert np.array_equal(ops_f[:, :12], ops_f0[:, :12]) and not ops_f[chain.n_ops - 1, 12:25].any()
+    chain0 = build_walk(m._spec, targets=[tip])
+    chain = build_walk(m._spec, targets=[tip], fold=fold)
+    assert chain.n_ops <= chain0.n_ops
+    w1, ops_f = folded_host_walk(m, chain, fold)
+    w0, _ops_f0 = host_walk(m, chain0)
+    assert not ops_f[chain.n_ops - 1, 12:25].any()
+    poses = []
+    for w in (w0, w1):
+        pos = np.zeros((B, 1, 3), np.float32); quat = np.zeros((B, 1, 4), np.float32)
+        assert emu.emu_fk(ctypes.byref(w), _ptr(q), ctypes.c_int64(B), 1, _ptr(pos), _ptr(quat)) == 0
+        poses.append((pos, quat))
+    assert max_err(poses[0][0], poses[1][0]) < 2e-6 and quat_close(poses[0][1][:, 0], poses[1][1][:, 0], 2e-6)[0]
+    # ... and so for every link of the robot as the target
+    for link in range(1, m._spec.n_links):
+        poses = []
+        plain, stepped = build_walk(m._spec, targets=[link]), build_walk(m._spec, targets=[link], fold=fold)   # (own the tables)
+        for w, _k in (host_walk(m, plain), folded_host_walk(m, stepped, fold)):
+            pos = np.zeros((4, 1, 3), np.float32); quat = np.zeros((4, 1, 4), np.float32)
+            assert emu.emu_fk(ctypes.byref(w), _ptr(q), ctypes.c_int64(4), 1, _ptr(pos), _ptr(quat)) == 0
+            poses.append((pos, quat))
+        assert max_err(poses[0][0], poses[1][0]) < 2e-6, m._spec.link_names[link]
+        assert quat_close(poses[0][1][:, 0], poses[1][1][:, 0], 2e-6)[0], m._spec.link_names[link]
 
 
 def test_folding_keeps_learnable_links_and_what_would_fold_into_them(emu):
