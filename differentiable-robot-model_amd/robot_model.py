@@ -91,20 +91,17 @@ class _DeviceWalk:
     learnable_plan: Optional[tuple] = None   # (learnable links, constant walk table, row selector) of _ops_f_learnable
 
 
-def _quat_grad_to_rot(quat: torch.Tensor, grad_quat: torch.Tensor) -> torch.Tensor:
-    """dL/dR [..., 3, 3] of the rotation matrix a quaternion output was taken from, given dL/dquat [..., 4] (xyzw).
-
-    The reference's get_quaternion (spatial_vector_algebra.py:108-136) copies sums and differences of entries of R into
-    the un-normalised quaternion u inside autograd and scales it by 0.5 / math.sqrt(t) — a Python float, i.e. a constant
-    to autograd.  So dL/du = dL/dquat * scale and dL/dR scatters dL/du back onto the entries each case reads:
-      t = tr R + 1 > 1:  u = (R21 - R12, R02 - R20, R10 - R01, t)
-      else, with i the largest diagonal entry and (i, j, k) cyclic:  t = R_ii - (R_jj + R_kk) + 1,
-                         u_i = t, u_j = R_ij + R_ji, u_k = R_ki + R_ik, u_w = R_kj - R_jk.
-    R is rebuilt from the (unit) quaternion output; the case is re-derived from it with the reference's tests."""
+def _rot_from_quat(quat: torch.Tensor) -> torch.Tensor:
+    """[..., 9] row-major rotation matrix of a unit quaternion (xyzw); the same for q and -q."""
     x, y, z, w = quat.unbind(-1)
-    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)
+
+
+def _quat_cases(R: torch.Tensor):
+    """The case of the reference's get_quaternion (spatial_vector_algebra.py:117-128) each rotation falls into — masks
+    (isW, isX, isY, isZ) — and its t (the quaternion is u * 0.5 / sqrt(t))."""
     r = lambda i, j: R[..., 3 * i + j]
     tW = r(0, 0) + r(1, 1) + r(2, 2) + 1
     isW = tW > 1
@@ -116,22 +113,122 @@ def _quat_grad_to_rot(quat: torch.Tensor, grad_quat: torch.Tensor) -> torch.Tens
     tY = r(1, 1) - (r(2, 2) + r(0, 0)) + 1
     tZ = r(2, 2) - (r(0, 0) + r(1, 1)) + 1
     t = torch.where(isW, tW, torch.where(isZ, tZ, torch.where(isY, tY, tX)))
-    gu = grad_quat * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
+    return (isW, isX, isY, isZ), t
+
+
+_QUAT_CYCLES = ((0, 1, 2), (1, 2, 0), (2, 0, 1))    # (i, j, k) of the X / Y / Z cases
+
+
+def _u_from_rot(R: torch.Tensor, masks) -> torch.Tensor:
+    """The un-normalised quaternion u [..., 4] (xyzw) the given case assembles from the entries of R — linear in R."""
+    r = lambda i, j: R[..., 3 * i + j]
+    isW = masks[0]
+    u = [torch.where(isW, a, torch.zeros_like(a)) for a in (r(2, 1) - r(1, 2), r(0, 2) - r(2, 0), r(1, 0) - r(0, 1),
+                                                          r(0, 0) + r(1, 1) + r(2, 2) + 1)]
+    for mask, (i, j, k) in zip(masks[1:], _QUAT_CYCLES):
+        vals = {i: r(i, i) - (r(j, j) + r(k, k)) + 1, j: r(i, j) + r(j, i), k: r(k, i) + r(i, k), 3: r(k, j) - r(j, k)}
+        for c, val in vals.items():
+            u[c] = torch.where(mask, val, u[c])
+    return torch.stack(u, dim=-1)
+
+
+def _u_grad_to_rot(masks, gu: torch.Tensor) -> torch.Tensor:
+    """dL/dR [..., 3, 3] from dL/du [..., 4]: the transpose of _u_from_rot."""
     gx, gy, gz, gw = gu.unbind(-1)
     zero = torch.zeros_like(gx)
-    out = torch.zeros_like(R)
+    out = torch.zeros(gu.shape[:-1] + (9,), device=gu.device, dtype=gu.dtype)
 
     def scatter(mask, entries):
         for (i, j), v in entries:
             out[..., 3 * i + j] += torch.where(mask, v, zero)
 
-    scatter(isW, [((2, 1), gx), ((1, 2), -gx), ((0, 2), gy), ((2, 0), -gy), ((1, 0), gz), ((0, 1), -gz),
-                  ((0, 0), gw), ((1, 1), gw), ((2, 2), gw)])
-    for mask, (i, j, k), (gi, gj, gk) in ((isX, (0, 1, 2), (gx, gy, gz)), (isY, (1, 2, 0), (gy, gz, gx)),
-                                          (isZ, (2, 0, 1), (gz, gx, gy))):
+    scatter(masks[0], [((2, 1), gx), ((1, 2), -gx), ((0, 2), gy), ((2, 0), -gy), ((1, 0), gz), ((0, 1), -gz),
+                       ((0, 0), gw), ((1, 1), gw), ((2, 2), gw)])
+    for mask, (i, j, k), (gi, gj, gk) in zip(masks[1:], _QUAT_CYCLES, ((gx, gy, gz), (gy, gz, gx), (gz, gx, gy))):
         scatter(mask, [((i, i), gi), ((j, j), -gi), ((k, k), -gi), ((i, j), gj), ((j, i), gj), ((k, i), gk), ((i, k), gk),
                        ((k, j), gw), ((j, k), -gw)])
-    return out.reshape(quat.shape[:-1] + (3, 3))
+    return out.reshape(gu.shape[:-1] + (3, 3))
+
+
+def _quat_grad_to_rot(quat: torch.Tensor, grad_quat: torch.Tensor) -> torch.Tensor:
+    """dL/dR [..., 3, 3] of the rotation matrix a quaternion output was taken from, given dL/dquat [..., 4] (xyzw).
+
+    The reference's get_quaternion (spatial_vector_algebra.py:108-136) copies sums and differences of entries of R into
+    the un-normalised quaternion u inside autograd and scales it by 0.5 / math.sqrt(t) — a Python float, i.e. a constant
+    to autograd.  So dL/du = dL/dquat * scale and dL/dR scatters dL/du back onto the entries each case reads:
+      t = tr R + 1 > 1:  u = (R21 - R12, R02 - R20, R10 - R01, t)
+      else, with i the largest diagonal entry and (i, j, k) cyclic:  t = R_ii - (R_jj + R_kk) + 1,
+                         u_i = t, u_j = R_ij + R_ji, u_k = R_ki + R_ik, u_w = R_kj - R_jk.
+    R is rebuilt from the (unit) quaternion output; the case is re-derived from it with the reference's tests."""
+    masks, t = _quat_cases(_rot_from_quat(quat))
+    return _u_grad_to_rot(masks, grad_quat * (0.5 * torch.rsqrt(t)).unsqueeze(-1))
+
+
+SECOND_ORDER_STEP = 4e-2    # h of the Richardson-extrapolated central differences below (radians / input units per unit direction)
+
+
+class _GradLaunch(torch.autograd.Function):
+    """A first-order gradient launch  g(x; c) = J(x)^T c  as a differentiable node, so that `create_graph=True` works
+    through the hand-written backward kernels (gradient penalties, Hessian-vector products, Hessians row by row; the
+    reference gets these from torch autograd on its tensor ops).  There is no second-order adjoint kernel: both derivatives
+    of the node are DIRECTIONAL derivatives along the incoming cotangent u, taken as central differences of first-order
+    launches with one Richardson step,
+        d/dc:  J(x) u          = d/de fwd(x + e u)          (four forward launches)
+        d/dx:  d/dx <g(x;c),u> = d/de bwd(x + e u; c)       (four backward launches)
+    with e = h / max|u_b| per sample and D = (4 D(h/2) - D(h)) / 3.  The outputs are trigonometric polynomials of q and at
+    most quadratic in qd / qdd, so the truncation error (h^4) is below the fp32 noise of the differences: second derivatives
+    come out to ~1e-4 relative to the gradient's scale (tests/test_second_order.py holds them to the reference's autograd
+    at 2e-3).  Third derivatives are not provided (this node's backward is once-differentiable).
+
+    fwd(xs) -> tuple of outputs;  bwd(xs, cs) -> tuple of gradients, one per x;  args = xs (n_x tensors, [B, ...]) then cs."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, n_x, *args):
+        xs, cs = args[:n_x], args[n_x:]
+        grads = bwd(xs, cs)
+        ctx.fwd, ctx.bwd, ctx.n_x = fwd, bwd, n_x
+        ctx.save_for_backward(*args)
+        return tuple(grads)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *us):
+        args = ctx.saved_tensors
+        n_x = ctx.n_x
+        xs, cs = args[:n_x], args[n_x:]
+        us = [u.to(torch.float32) if u is not None else torch.zeros_like(x) for u, x in zip(us, xs)]
+        B = xs[0].shape[0]
+        scale = torch.stack([u.reshape(B, -1).abs().amax(dim=1) for u in us]).amax(dim=0).clamp_min(1e-30)   # [B]
+        bc = lambda t, like: t.reshape((B,) + (1,) * (like.ndim - 1))
+        ds = [u / bc(scale, u) for u in us]
+        at = lambda e: [x + e * d for x, d in zip(xs, ds)]
+
+        def directional(f):
+            h = SECOND_ORDER_STEP
+            out = None
+            for step, weight in ((0.5 * h, 4.0 / 3.0), (h, -1.0 / 3.0)):
+                hi, lo = f(at(step)), f(at(-step))
+                part = [(a - b) * (weight / (2.0 * step)) for a, b in zip(hi, lo)]
+                out = part if out is None else [o + p for o, p in zip(out, part)]
+            return [o * bc(scale, o) for o in out]
+
+        need = ctx.needs_input_grad[3:]
+        g_x = [None] * n_x
+        g_c = [None] * len(cs)
+        if any(need[:n_x]):
+            got = directional(lambda X: ctx.bwd(X, cs))
+            g_x = [g if need[i] else None for i, g in enumerate(got)]
+        if any(need[n_x:]):
+            got = directional(lambda X: ctx.fwd(X))
+            g_c = [g if need[n_x + j] else None for j, g in enumerate(got)]
+        return (None, None, None, *g_x, *g_c)
+
+
+def _refuse_second_order_in_parameters(needs_table_grad: bool):
+    if needs_table_grad:
+        raise NotImplementedError(
+            "create_graph=True with learnable link parameters: second derivatives are provided with respect to the joint-state "
+            "inputs (q, qd, qdd) and the output cotangents only — see INTEGRATION.md, 'Second derivatives'")
 
 
 class _FkPositions(torch.autograd.Function):
@@ -152,13 +249,41 @@ class _FkPositions(torch.autograd.Function):
         return pos, quat
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_pos, grad_quat):
         q, ops_f, quat = ctx.saved_tensors
         want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dw = ctx.dw
         if grad_pos is None:
             grad_pos = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
+        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
+            _refuse_second_order_in_parameters(want_p)
+            if not want_q:
+                return None, None, None, None, None, None
+            table, T, n = ops_f.detach(), ctx.n_targets, ctx.n_dofs
+            if grad_quat is None:
+                grad_quat = torch.zeros_like(quat)
+
+            # the quaternion's case and scale are constants of the reference's graph (_quat_grad_to_rot): u = A_case R
+            masks, t = _quat_cases(_rot_from_quat(quat.detach()))
+
+            def fwd(X):
+                pos, qt = backend.fk(dw.program, table, dw.ops_i, X[0], T, n)
+                return pos, _u_from_rot(_rot_from_quat(qt), masks)
+
+            def bwd(X, C):
+                return (backend.fk_backward(dw.program, table, dw.ops_i, X[0], C[0], T, n, 0, True,
+                                            _u_grad_to_rot(masks, C[1]))[0].reshape(X[0].shape),)
+
+            with torch.enable_grad():
+                grad_u = grad_quat.to(torch.float32) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
+                (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), grad_pos.to(torch.float32), grad_u)
+            return grad_q.to(q.dtype), None, None, None, None, None
+        with torch.no_grad():
+            return _FkPositions._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, want_q, want_p)
+
+    @staticmethod
+    def _first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, want_q, want_p):
+        dw = ctx.dw
         grad_rot = _quat_grad_to_rot(quat, grad_quat.to(torch.float32)) if grad_quat is not None else None
         grad_q, grad_ops = backend.fk_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, ctx.n_targets, ctx.n_dofs,
                                                ctx.param_mask if want_p else 0, want_q, grad_rot)
@@ -182,7 +307,6 @@ class _FkJacobian(torch.autograd.Function):
         return pos, quat, lin, ang
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_pos, grad_quat, grad_lin, grad_ang):
         q, ops_f, quat = ctx.saved_tensors
         want_q, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -190,6 +314,35 @@ class _FkJacobian(torch.autograd.Function):
         zeros = lambda: torch.zeros(q.shape[0], 3, ctx.n_dofs, device=q.device, dtype=torch.float32)
         grad_lin = grad_lin if grad_lin is not None else zeros()
         grad_ang = grad_ang if grad_ang is not None else zeros()
+        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
+            _refuse_second_order_in_parameters(want_p)
+            if not want_q:
+                return None, None, None, None, None
+            table, n = ops_f.detach(), ctx.n_dofs
+            f32 = lambda t, like: (t if t is not None else torch.zeros_like(like)).to(torch.float32)
+            pos_like = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
+
+            masks, t = _quat_cases(_rot_from_quat(quat.detach()))     # (constants of the reference's graph, as in _FkPositions)
+
+            def fwd(X):
+                pos, qt, lin, ang = backend.fk_jacobian(dw.program, table, dw.ops_i, X[0], n)
+                return pos, _u_from_rot(_rot_from_quat(qt), masks), lin, ang
+
+            def bwd(X, C):
+                return (backend.fk_jacobian_backward(dw.program, table, dw.ops_i, X[0], C[0], C[2], C[3], n, 0, True,
+                                                     _u_grad_to_rot(masks, C[1]))[0].reshape(X[0].shape),)
+
+            with torch.enable_grad():
+                grad_u = f32(grad_quat, quat) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
+                (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), f32(grad_pos, pos_like), grad_u,
+                                              grad_lin.to(torch.float32), grad_ang.to(torch.float32))
+            return grad_q.to(q.dtype), None, None, None, None
+        with torch.no_grad():
+            return _FkJacobian._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, want_q, want_p)
+
+    @staticmethod
+    def _first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, want_q, want_p):
+        dw = ctx.dw
         grad_rot = _quat_grad_to_rot(quat, grad_quat.to(torch.float32)) if grad_quat is not None else None
         grad_q, grad_ops = backend.fk_jacobian_backward(dw.program, ops_f, dw.ops_i, q, grad_pos, grad_lin, grad_ang,
                                                         ctx.n_dofs, ctx.param_mask if want_p else 0, want_q, grad_rot)
@@ -211,11 +364,38 @@ class _InverseDynamics(torch.autograd.Function):
         return tau
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_tau):
         q, qd, qdd, ops_f = ctx.saved_tensors
         qdd = qdd if ctx.has_qdd else None
         want_in = any(ctx.needs_input_grad[:3])
+        dw = ctx.dw
+        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
+            _refuse_second_order_in_parameters(ctx.needs_input_grad[3])
+            if not want_in:
+                return (None,) * 9
+            table, n, (gravity, damping) = ops_f.detach(), ctx.n_dofs, ctx.flags
+            has_qdd = ctx.has_qdd
+
+            def fwd(X):
+                return (backend.rnea(dw.program, table, dw.ops_i, X[0], X[1], X[2] if has_qdd else None, gravity, damping, n),)
+
+            def bwd(X, C):
+                gin, _ = backend.rnea_backward(dw.program, table, dw.ops_i, X[0], X[1], X[2] if has_qdd else None, C[0],
+                                               gravity, damping, n, 0, True)
+                return tuple(g.reshape(X[0].shape) for g in gin[:3 if has_qdd else 2])
+
+            xs = [q.to(torch.float32), qd.to(torch.float32)] + ([qdd.to(torch.float32)] if has_qdd else [])
+            with torch.enable_grad():
+                got = _GradLaunch.apply(fwd, bwd, len(xs), *xs, grad_tau.to(torch.float32))
+            gq = got[0].to(q.dtype) if ctx.needs_input_grad[0] else None
+            gqd = got[1].to(qd.dtype) if ctx.needs_input_grad[1] else None
+            gqdd = got[2].to(qdd.dtype) if (has_qdd and ctx.needs_input_grad[2]) else None
+            return gq, gqd, gqdd, None, None, None, None, None, None
+        with torch.no_grad():
+            return _InverseDynamics._first_order(ctx, q, qd, qdd, ops_f, grad_tau, want_in)
+
+    @staticmethod
+    def _first_order(ctx, q, qd, qdd, ops_f, grad_tau, want_in):
         dw = ctx.dw
         gin, grad_ops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, grad_tau, ctx.flags[0],
                                               ctx.flags[1], ctx.n_dofs, ctx.param_mask if ctx.needs_input_grad[3] else 0,

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -v Warn | tail -12
-python tools/probe_robots.py 2>&1 | grep "n="
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v Warn | grep "Error\|passed\|failed\|^FAILED" | tail
