@@ -286,6 +286,83 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K7 (reverse-mode inverse dynamics) of the same shapes: drm_sample.hpp rnea_backward_arm_hand — straight-line, nothing stored
+// per link (parents recovered from their children on the way back), the palm's motion / force adjoint and the two sums of what
+// the sub-chains hand it in 36 LDS floats per sample.  The loop form (rnea_backward_kernel) parks (cos, sin) per link, motion
+// and force adjoint per leaf and 36 floats per branch point: 35 KB per wavefront on a Panda with gripper — one wavefront per
+// SIMD, 408 us per 2^20 samples against 105 us for the arm alone.  Persistent wavefronts (one row of constant-gradient sums
+// each, summed in a fixed order by rnea_backward_reduce_kernel), full 64-row tiles; a ragged tail takes the loop kernel.
+// LDS (static): [ table ][ constant-gradient sums : cap x 32 ][ palm : 36 x 64 ][ grad_q | grad_qd | grad_qdd tiles : 64 x (n | 1) ]
+// ---------------------------------------------------------------------------------------------------
+template <int P, int L>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+    rnea_backward_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
+                                  const float *__restrict__ qd, const float *__restrict__ qdd, const float *__restrict__ gtau, int K,
+                                  int cap, int n, int n_tiles, int flags, uint64_t param_mask, float *__restrict__ gq,
+                                  float *__restrict__ gqd, float *__restrict__ gqdd, float *__restrict__ partials, uint32_t magic_n) {
+    constexpr int OPS = P + 4 * L, C_FLOATS = OPS * DRM_OPF_STRIDE, A_FLOATS = round4(OPS) * DRM_OPF_STRIDE;
+    constexpr int PALM = 36 * WAVE, TILE = round4(WAVE * pad_odd(OPS));
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + A_FLOATS + PALM + 3 * TILE];
+    const unsigned lane = threadIdx.x;
+    const int n_ops = P + K * L, NV = cap * DRM_OPF_STRIDE;
+    float *lc = smem, *lacc = lc + C_FLOATS, *lp = lacc + A_FLOATS + lane, *lt = lacc + A_FLOATS + PALM;
+    const int Sq = pad_odd(n), region = round4(WAVE * Sq);
+    float *lgq = lt, *lgqd = lt + region, *lgqdd = lgqd + region;
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
+    int dof[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
+    for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
+        reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+    auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
+    const bool has_qdd = qdd != nullptr;
+    const unsigned row_off = lane * (unsigned)n * 4u, trow = lane * (unsigned)Sq;
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        const char *qb = reinterpret_cast<const char *>(q + b0 * n), *qdb = reinterpret_cast<const char *>(qd + b0 * n),
+                   *qddb = reinterpret_cast<const char *>(has_qdd ? qdd + b0 * n : q + b0 * n),
+                   *gtb = reinterpret_cast<const char *>(gtau + b0 * n);
+        // a joint's state where a sweep needs it: one dword load per array at a wave-uniform column (fixed ops: column 0, value
+        // dropped) — the lines are in the L2 after the first touch.  (Staging the four input tiles in LDS first was slower:
+        // 323 -> 340 us on the Panda with gripper; the wait is not on these loads.)
+        auto joint_state = [&](int d, float &a, float &v, float &acc, float &g) {
+            const int c = (d < 0 ? 0 : d) * 4;
+            const float x = *reinterpret_cast<const float *>(qb + c + row_off), y = *reinterpret_cast<const float *>(qdb + c + row_off),
+                        z = *reinterpret_cast<const float *>(qddb + c + row_off), u = *reinterpret_cast<const float *>(gtb + c + row_off);
+            a = d < 0 ? 0.0f : x; v = d < 0 ? 0.0f : y; acc = (d < 0 || !has_qdd) ? 0.0f : z; g = d < 0 ? 0.0f : u;
+        };
+        wave_lds_sync(); // the table is staged; the previous tile's gradients have left the tiles
+        rnea_backward_arm_hand<P, L>(
+            [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING,
+            param_mask, gq != nullptr, [&](int k, float &a, float &v, float &acc, float &g) { joint_state(dof[k], a, v, acc, g); },
+            [&](int j, int i, float &a, float &v, float &acc, float &g) { joint_state((w0[P + j * L + i] & 0xff) - 1, a, v, acc, g); },
+            [&](int op, float a, float v, float acc) {
+                const int d = (w0[op] & 0xff) - 1;
+                lgq[trow + d] = a; lgqd[trow + d] = v; lgqdd[trow + d] = acc;
+            },
+            [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
+#pragma unroll
+                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+                    const float total = wave_sum_lane63(g[j]);
+                    if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
+                }
+            },
+            [&](int i, float x) { lp[i * WAVE] = x; }, [&](int i) { return lp[i * WAVE]; });
+        if (gq) {
+            wave_lds_sync();
+            tile_store<0>(gq + b0 * n, WAVE, n, magic_n, lgq, lane, (n & 1) != 0, true);
+            tile_store<0>(gqd + b0 * n, WAVE, n, magic_n, lgqd, lane, (n & 1) != 0, true);
+            tile_store<0>(gqdd + b0 * n, WAVE, n, magic_n, lgqdd, lane, (n & 1) != 0, true);
+        }
+    }
+    wave_lds_sync();
+    float *prow = partials + (int64_t)blockIdx.x * NV;
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
+}
+
 // the (P, L) this library is compiled for: those of the robots it ships (robot_data/) — Panda with gripper 7 + 2 x 1, Jaco
 // 6 + 3 x 2, iiwa7 + Allegro 7 + 4 x 4 once the host has folded every fixed joint (flatten.foldable_links), and 9 + 2 x 1,
 // 7 + 3 x 2, 8 + 4 x 4 when learnable links keep the flange / palm an op of its own; anything else keeps the loop kernel
@@ -381,6 +458,34 @@ int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float
         else                                                                                                                     \
             hipLaunchKernelGGL((crba_arm_hand_kernel<p, l, false>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f,     \
                                w->ops_i, q, K, (int)w->capacity, (int)w->n_dofs, H);                                             \
+        return (int64_t)n_tiles * WAVE;                                                                                          \
+    }
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    return 0;
+#endif
+}
+
+// reverse-mode inverse dynamics: the full tiles of B; returns the rows done (0: not this walk) and the rows of partial sums
+// the launch wrote (one per block) in `partial_rows`
+int64_t launch_rnea_backward_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, const float *gtau,
+                                      int64_t B, int flags, uint64_t param_mask, float *gq, float *gqd, float *gqdd, float *partials,
+                                      int &partial_rows, hipStream_t s) {
+#ifdef DRM_NO_ARM_HAND_BACKWARD
+    return 0;
+#else
+    int P, K, L;
+    const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)qd | (uintptr_t)qdd | (uintptr_t)gtau | (uintptr_t)gq | (uintptr_t)gqd |
+                           (uintptr_t)gqdd | (uintptr_t)w->ops_f;
+    if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || K > 4 || B < WAVE || B / WAVE >= 0x7fffffffLL || (ptrs & 15u) != 0) return 0;
+    const int n_tiles = (int)(B / WAVE);
+    const int grid = n_tiles < BWD_MAX_WAVES ? n_tiles : BWD_MAX_WAVES;
+#define X(p, l)                                                                                                                  \
+    if (P == p && L == l) {                                                                                                      \
+        hipLaunchKernelGGL((rnea_backward_arm_hand_kernel<p, l>), dim3((unsigned)grid), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, \
+                           qd, qdd, gtau, K, (int)w->capacity, (int)w->n_dofs, n_tiles, flags, param_mask, gq, gqd, gqdd,        \
+                           partials, div_magic(w->n_dofs));                                                                      \
+        partial_rows = grid;                                                                                                     \
         return (int64_t)n_tiles * WAVE;                                                                                          \
     }
     DRM_ARM_HAND_SHAPES(X)

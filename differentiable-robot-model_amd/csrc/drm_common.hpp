@@ -369,6 +369,9 @@ int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd,
                              hipStream_t s);
 bool arm_hand_compiled(const drm_walk *w);
 bool crba_arm_hand_applies(const drm_walk *w);
+int64_t launch_rnea_backward_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, const float *gtau,
+                                      int64_t B, int flags, uint64_t param_mask, float *gq, float *gqd, float *gqdd, float *partials,
+                                      int &partial_rows, hipStream_t s);
 int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H, hipStream_t s);
 int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags,
                                          float *qdd, hipStream_t s);

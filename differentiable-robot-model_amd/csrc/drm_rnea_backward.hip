@@ -485,6 +485,45 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         }
     }
 #endif
+    {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel,
+        // the ragged tail (< 64 rows, one wavefront) through the loop kernel with its row of partial sums appended
+        int rows = 0;
+        const int64_t done = launch_rnea_backward_arm_hand(w, q, qd, qdd, grad_tau, B, (int)flags, param_mask, grad_q, grad_qd, grad_qdd,
+                                                           partials, rows, s);
+        if (done > 0) {
+            rc = launched();
+            if (rc) return rc;
+            if (done < B) {
+                const size_t need = rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, false) * sizeof(float);
+                if (need > (size_t)MAX_LDS_BYTES) return fail(DRM_ERR_UNSUPPORTED, "the tail of this walk does not fit LDS");
+                Geometry gt;
+                rc = make_geometry(B - done, (int)(need / sizeof(float)), gt);
+                if (rc) return rc;
+                gt.grid = dim3(1);
+                gt.block = dim3(WAVE);
+                gt.lds_bytes = (size_t)gt.lds_per_wave * sizeof(float);
+                rc = ensure_lds(rnea_backward_kernel<false>, gt.lds_bytes);
+                if (rc) return rc;
+                const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU);
+                hipLaunchKernelGGL((rnea_backward_kernel<false>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i, cap,
+                                   (int)w->n_ops, n_leaves, n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n,
+                                   qdd ? qdd + done * n : nullptr, grad_tau + done * n, B - done,
+                                   grad_q ? grad_q + done * n : nullptr, grad_qd ? grad_qd + done * n : nullptr,
+                                   grad_qdd ? grad_qdd + done * n : nullptr, param_mask,
+                                   partials + (int64_t)rows * cap * DRM_OPF_STRIDE, (float *)nullptr, div_magic(n), gt.lds_per_wave,
+                                   al & ~(AL_POS | AL_QUAT | AL_LIN));
+                rc = launched();
+                if (rc) return rc;
+                rows += 1;
+            }
+            if (grad_ops_f) {
+                hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)(cap * DRM_OPF_STRIDE / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s,
+                                   partials, rows, cap, grad_ops_f);
+                rc = launched();
+            }
+            return rc;
+        }
+    }
     // fanned out over the segments when the walk has several, none of the prefix ops is learnable and a block's LDS fits twice
     // per CU or better than the single-wavefront form would
     if (w->n_segments > 1 && segments_ok(w) && w->prefix_end < 64 && !(param_mask & ((1ull << w->prefix_end) - 1ull))) {

@@ -2076,6 +2076,229 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint64_t pa
 }
 
 // ---------------------------------------------------------------------------
+// Reverse-mode RNEA of "an arm that carries a hand" (DRM_WALK_ARM_HAND: P serial prefix ops, K serial sub-chains of L ops off
+// the last prefix op), straight-line like rnea_backward_chain and with the same idea: nothing is stored per link, every
+// parent's motion and force adjoint are recovered from its child's on the way back.  What a tree adds is the palm (op P - 1):
+// its motion and force adjoint are put away once (36 floats with the two sums below; put / get), every sub-chain starts its
+// way up from them, walks back down to them and ADDS what it hands the palm — its total force and its motion adjoint — to the
+// sums; the prefix then walks back from the palm with the sums as if they had come from a single child.
+//   one link of the way down (sweep D with B folded in), any joint kind:
+//     in : M, T = the link's motion and force adjoint; B = motion adjoint from below; carry = force from below (link frame)
+//     out: M, T = the PARENT's (recovered); B = the adjoint handed to the parent; carry = the sub-tree's force in the parent's
+//          frame; gq / gqd / gqdd of the joint; param_out(op, row gradient) when `learn`
+// ---------------------------------------------------------------------------
+template <class PG>
+DRM_HD void rnea_backward_link_down(const float *of, int op, bool moving, bool pris, const float *J, const float *t, float c, float s,
+                                    float qv, float wj, float aj, float gtk, bool has_parent, float g, bool damping, bool learn,
+                                    Motion &M, f2 (&T)[3], Motion &B, Force &carry, float &gq, float &gqd, float &gqdd,
+                                    PG param_out) {
+    Motion Pm, pbn;
+    f2 U[3];
+    if (has_parent) {
+        motion_parent(J, t, wj, aj, pris, M, Pm);
+        f2 x[3] = {T[0], T[1], T[2]};
+        x[2][pris ? 0 : 1] -= gtk;
+        tbar_parent(J, t, x, U);
+    } else {
+        motion_root(Pm, g);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[i] = f2_bcast(0.0f);
+    }
+    Force tot;
+    f2 hgl[3], hga[3];
+    rnea_body_force_hg(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, tot, hgl, hga);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+    float wjb, ajb;
+    if (!pris) {
+        LinkAdjointP A;
+        rnea_link_adjoint_packed(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, M, hgl, hga, T, tot, has_parent, B, A);
+        gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+        pbn = A.pb;
+        if (learn) {
+            float gr[DRM_OPF_STRIDE];
+            const float ub[6] = {U[0][0], U[1][0], U[2][0], U[0][1], U[1][1], U[2][1]};
+            rnea_link_param_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, c, s, M, Pm, T, ub, tot, has_parent, B, A, gr);
+            gr[DRM_OPF_DAMP] = (damping && moving) ? gtk * wj : 0.0f;
+            param_out(op, gr);
+        }
+    } else { // a sliding joint: the scalar form (its motion subspace differs; rare)
+        float mo[12], mb[12], par[12], fb[6], ub[6], tf[6];
+        motion_to_floats(M, mo); motion_to_floats(B, mb); motion_to_floats(Pm, par);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fb[i] = T[i][0]; fb[3 + i] = T[i][1]; ub[i] = U[i][0]; ub[3 + i] = U[i][1];
+            tf[i] = tot.la[i][0]; tf[3 + i] = tot.la[i][1];
+        }
+        LinkAdjoint A;
+        rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, par, mb, ub, tf, has_parent, A, true, learn);
+        gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+        motion_from_floats(A.pb, pbn);
+        if (learn) { // J = F and t = trans + F e_z q
+            float gr[DRM_OPF_STRIDE];
+#pragma unroll
+            for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                gr[DRM_OPF_FIJ(r, 0)] = A.Jb[r * 3 + 0];
+                gr[DRM_OPF_FIJ(r, 1)] = A.Jb[r * 3 + 1];
+                gr[DRM_OPF_FIJ(r, 2)] = A.Jb[r * 3 + 2] + A.tb[r] * qv;
+                gr[DRM_OPF_TI(r)] = A.tb[r];
+                gr[DRM_OPF_MCOM + r] = A.gmc[r];
+            }
+            gr[DRM_OPF_MASS] = A.gm;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = A.gIo[i];
+            gr[DRM_OPF_DAMP] = damping ? gtk * wj : 0.0f;
+            param_out(op, gr);
+        }
+    }
+    gqd = wjb + ((damping && moving) ? of[DRM_OPF_DAMP] * gtk : 0.0f);
+    gqdd = ajb;
+    if (has_parent) {
+        Force up;
+        rnea_link_force_up(J, t, tot, up); // the sub-tree's force in the parent's frame
+        carry = up;
+    }
+    B = pbn;
+    M = Pm;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = U[i];
+}
+
+//   row(op), kind(op) (1 = moves, 2 = prismatic)        wave-uniform
+//   pq(k, q, qd, qdd, gtau) joint state and dL/dtau of prefix op k (0 where fixed);  hq(j, i, q, qd, qdd, gtau) of op i of sub-chain j
+//   gout(op, gq, gqd, gqdd) for every moving op;  param_out(op, g[DRM_OPF_STRIDE]) for ops in param_mask
+//   put(i, x) / get(i) -> x    36 lane-private floats (the palm's motion 0..11 and force adjoint 12..17, the sums 18..35)
+template <int P, int L, class ROW, class KIND, class PQ, class HQ, class GOUT, class PG, class PUT, class GET>
+DRM_HD void rnea_backward_arm_hand(ROW row, KIND kind, int K, bool gravity, bool damping, uint64_t param_mask, bool want_gq, PQ pq, HQ hq,
+                                   GOUT gout, PG param_out, PUT put, GET get) {
+    const float g = gravity ? 9.81f : 0.0f;
+    // a prefix op's joint state is fetched (and its cos / sin formed) where each sweep needs it: nothing of the prefix stays in
+    // registers while the sub-chains run
+    auto prefix_joint = [&](int k, float *J, float *t, float &qk, float &wj, float &aj, float &gtk, float &c, float &s) {
+        const int kd = kind(k);
+        pq(k, qk, wj, aj, gtk);
+        c = 1.0f; s = 0.0f;
+        if ((kd & 1) && !(kd & 2)) sincos_one(qk, s, c);
+        joint_transform(load_ft(row(k)), kd & 1, kd & 2, qk, c, s, J, t);
+    };
+    // ---- up the prefix: motions (A) and force adjoints (C); only the palm's are kept --------------------------------------
+    {
+        Motion M;
+        f2 T[3];
+        motion_root(M, g);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[i] = f2_bcast(0.0f);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int kd = kind(k);
+            float J[9], t[3], qk, wj, aj, gtk, c, sn_;
+            prefix_joint(k, J, t, qk, wj, aj, gtk, c, sn_);
+            motion_step(J, t, wj, aj, kd & 2, M, M);
+            if (k > 0) {
+                f2 Tn[3];
+                tbar_child(J, t, T, Tn);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) T[i] = Tn[i];
+            }
+            if (kd & 1) T[2][(kd & 2) ? 0 : 1] += gtk;
+        }
+        float rec[12];
+        motion_to_floats(M, rec);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) put(i, rec[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { put(12 + i, T[i][0]); put(15 + i, T[i][1]); }
+#pragma unroll
+        for (int i = 18; i < 36; ++i) put(i, 0.0f);
+    }
+    // ---- every sub-chain: up from the palm, back down to it, its force and motion adjoint into the sums -------------------
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        float hqv[L], hqd[L], hqdd[L], hgt[L], hc[L], hs[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) hq(j, i, hqv[i], hqd[i], hqdd[i], hgt[i]);
+        chain_trig<L>(hqv, hc, hs);
+        auto joint = [&](int i, float *J, float *t) {
+            const int kd = kind(P + j * L + i);
+            joint_transform(load_ft(row(P + j * L + i)), kd & 1, kd & 2, hqv[i], hc[i], hs[i], J, t);
+        };
+        Motion M;
+        f2 T[3];
+        {
+            float rec[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) rec[i] = get(i);
+            motion_from_floats(rec, M);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T[i] = f2_make(get(12 + i), get(15 + i));
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int kd = kind(P + j * L + i);
+            float J[9], t[3];
+            joint(i, J, t);
+            motion_step(J, t, hqd[i], hqdd[i], kd & 2, M, M);
+            f2 Tn[3];
+            tbar_child(J, t, T, Tn);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) T[x] = Tn[x];
+            if (kd & 1) T[2][(kd & 2) ? 0 : 1] += hgt[i];
+        }
+        Motion B;
+        Force carry;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { B.wa[x] = B.va[x] = carry.la[x] = f2_bcast(0.0f); }
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const int op = P + j * L + i, kd = kind(op);
+            float J[9], t[3], gq, gqd, gqdd;
+            joint(i, J, t);
+            rnea_backward_link_down(row(op), op, kd & 1, kd & 2, J, t, hc[i], hs[i], hqv[i], hqd[i], hqdd[i], (kd & 1) ? hgt[i] : 0.0f,
+                                    true, g, damping, (param_mask >> op) & 1u, M, T, B, carry, gq, gqd, gqdd, param_out);
+            if (want_gq && (kd & 1)) gout(op, gq, gqd, gqdd);
+        }
+        float rec[12];
+        motion_to_floats(B, rec);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) put(18 + i, get(18 + i) + rec[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            put(30 + i, get(30 + i) + carry.la[i][0]);
+            put(33 + i, get(33 + i) + carry.la[i][1]);
+        }
+    }
+    // ---- down the prefix from the palm, the sums standing in for a single child --------------------------------------------
+    Motion M, B;
+    f2 T[3];
+    Force carry;
+    {
+        float rec[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rec[i] = get(i);
+        motion_from_floats(rec, M);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rec[i] = get(18 + i);
+        motion_from_floats(rec, B);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T[i] = f2_make(get(12 + i), get(15 + i));
+            carry.la[i] = f2_make(get(30 + i), get(33 + i));
+        }
+    }
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) {
+        const int kd = kind(k);
+        float J[9], t[3], gq, gqd, gqdd, qk, wj, aj, gtk, c, sn_;
+        prefix_joint(k, J, t, qk, wj, aj, gtk, c, sn_);
+        rnea_backward_link_down(row(k), k, kd & 1, kd & 2, J, t, c, sn_, qk, wj, aj, (kd & 1) ? gtk : 0.0f, k > 0, g, damping,
+                                (param_mask >> k) & 1u, M, T, B, carry, gq, gqd, gqdd, param_out);
+        if (want_gq && (kd & 1)) gout(k, gq, gqd, gqdd);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Link-table rows from URDF-level link parameters, and the reverse-mode derivative of that map: what the
 // reference recomputes with ~60 tiny torch ops per link on every call (rigid_body.py:138-143 R_fixed = (Rz Ry) Rx;
 // spatial_vector_algebra.py:321-327 mcom = m com, I_o = I_c + m S(com) S(com)^T) and differentiates with as many

@@ -335,6 +335,36 @@ void rneab_t(const drm_walk *w, const float *q, const float *qd, const float *qd
     if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
 }
 
+// the arithmetic of rnea_backward_arm_hand_kernel<P, L>
+template <int P, int L>
+void rneab_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, const float *qdd, int64_t B, int flags,
+                        const float *gtau, uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+    const int n = w->n_dofs, CAP = w->capacity;
+    const int32_t *w0 = w->ops_i + DRM_OPI_W0 * w->capacity;
+    auto dof_of = [&](int k) { return (w0[k] & 0xff) - 1; };
+    auto kind = [&](int op) { const int x = w0[op]; return ((x & 0xff) ? 1 : 0) | (((x >> 26) & 1) << 1); };
+    std::vector<double> sum((size_t)CAP * DRM_OPF_STRIDE, 0.0);
+    for (int64_t b = 0; b < B; ++b) {
+        auto at = [&](const float *a, int d) { return (d < 0 || !a) ? 0.f : a[b * n + d]; };
+        float palm[36];
+        rnea_backward_arm_hand<P, L>(
+            [&](int k) { return w->ops_f + k * DRM_OPF_STRIDE; }, kind, K, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, mask,
+            gq != nullptr,
+            [&](int k, float &a, float &v, float &acc, float &g) {
+                const int d = dof_of(k);
+                a = at(q, d); v = at(qd, d); acc = at(qdd, d); g = at(gtau, d);
+            },
+            [&](int j, int i, float &a, float &v, float &acc, float &g) {
+                const int d = dof_of(P + j * L + i);
+                a = at(q, d); v = at(qd, d); acc = at(qdd, d); g = at(gtau, d);
+            },
+            [&](int op, float a, float v, float acc) { const int d = dof_of(op); gq[b * n + d] = a; gqd[b * n + d] = v; gqdd[b * n + d] = acc; },
+            [&](int k, const float *g) { for (int j = 0; j < DRM_OPF_STRIDE; ++j) sum[k * DRM_OPF_STRIDE + j] += g[j]; },
+            [&](int i, float x) { palm[i] = x; }, [&](int i) { return palm[i]; });
+    }
+    if (gops) for (int i = 0; i < CAP * DRM_OPF_STRIDE; ++i) gops[i] = (float)sum[i];
+}
+
 struct TrigRec { float c, s, q; };
 
 void crba_loop(const drm_walk *w, const float *q, int64_t B, float *H) {
@@ -520,6 +550,16 @@ int emu_link_rows_backward(const float *params, const float *grad_rows, int32_t 
     for (int i = 0; i < n; ++i)
         link_row_backward(params + i * LINK_PARAM_FLOATS, grad_rows + i * DRM_OPF_STRIDE, grad_params + i * LINK_PARAM_FLOATS);
     return 0;
+}
+int emu_rnea_backward_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
+                               const float *gtau, uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {
+    if (!(w->shape & DRM_WALK_ARM_HAND)) return -2;
+    const int P = DRM_WALK_AH_P(w->shape), K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (P + K * L != w->n_ops) return -1;
+#define X(p, l) if (P == p && L == l) { rneab_arm_hand_emu<p, l>(w, K, q, qd, qdd, B, flags, gtau, mask, gq, gqd, gqdd, gops); return 0; }
+    X(7, 1) X(6, 2) X(7, 4) X(9, 1) X(7, 2) X(8, 4)
+#undef X
+    return -2;
 }
 int emu_rnea_backward_arm(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
                           const float *gtau, uint64_t mask, float *gq, float *gqd, float *gqdd, float *gops) {

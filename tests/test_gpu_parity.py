@@ -513,6 +513,53 @@ def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
     print("mass matrix %s: straight-line %.2e, loop kernel %.2e (max abs, fp64 oracle)" % (robot, float(np.abs(host(H) - ref).max()), float(np.abs(host(loop) - ref).max())))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,compat", [("panda", True), ("panda", False), ("jaco", True), ("iiwa7_allegro", True)])
+def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(robot, compat):
+    """rnea_backward_arm_hand_kernel (full tiles of an arm + hand walk; nothing stored per link) against the loop-structured
+    backward kernel on the same walk without its shape bit — the kernel the reference-autograd goldens hold (their batches are
+    below one tile): input gradients and the constant gradients of three ops (a prefix link, the palm's parent op, a fingertip),
+    full tiles + ragged tail, with and without qdd; and through the API against a float64 finite difference of the oracle."""
+    import ctypes
+    from differentiable_robot_model_amd import backend
+    from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
+    m = load_model(robot, "cuda", reference_compat=compat)
+    dw = m._dynamics_walk()
+    assert dw.program.shape & SHAPE_ARM_HAND
+    B, n = 64 * 9 + 5, m._n_dofs
+    q, qd, qdd = (dev(a) for a in sample_states(m, B, seed=97))
+    gtau = torch.randn(B, n, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    of = m._ops_f(dw)
+    P = (dw.program.shape >> 24) & 0xf
+    mask = (1 << 1) | (1 << (P - 1)) | (1 << (dw.program.n_ops - 1))
+
+    import copy
+    generic = copy.copy(dw.program)     # the same walk, shape bit cleared: the loop kernel takes every row
+    generic.shape = dw.program.shape & ~SHAPE_ARM_HAND & 0xffffff
+    for use_qdd in (True, False):
+        for grav, damp in ((True, True), (False, False)):
+            got = backend.rnea_backward(dw.program, of, dw.ops_i, q, qd, qdd if use_qdd else None, gtau, grav, damp, n, mask, True)
+            ref = backend.rnea_backward(generic, of, dw.ops_i, q, qd, qdd if use_qdd else None, gtau, grav, damp, n, mask, True)
+            for a, b, name in zip(got[0], ref[0], ("grad_q", "grad_qd", "grad_qdd")):
+                scale = max(1.0, float(b.abs().max()))
+                assert float((a - b).abs().max()) <= 5e-5 * scale, (robot, name, use_qdd, grav, float((a - b).abs().max()), scale)
+            scale = max(1.0, float(ref[1].abs().max()))
+            assert float((got[1] - ref[1]).abs().max()) <= 2e-4 * scale, (robot, "grad_ops_f", float((got[1] - ref[1]).abs().max()), scale)
+            assert float(got[1].abs().max()) > 0
+    # through autograd, against central differences of the fp64 oracle along a random direction
+    orc = Oracle(m._spec)
+    tq = q.clone().requires_grad_(True)
+    tau = m.compute_inverse_dynamics(tq, qd, qdd, include_gravity=True, use_damping=True)
+    (tau * gtau).sum().backward()
+    v = np.random.default_rng(0).standard_normal((B, n))
+    q64, qd64, qdd64 = (host(t).astype(np.float64) for t in (q, qd, qdd))
+    e = 1e-6
+    fd = ((orc.rnea(q64 + e * v, qd64, qdd64, True, True, np.float64) - orc.rnea(q64 - e * v, qd64, qdd64, True, True, np.float64))
+          / (2 * e) * host(gtau)).sum(axis=1)
+    mine = (host(tq.grad).astype(np.float64) * v).sum(axis=1)
+    assert np.abs(mine - fd).max() <= 2e-3 * max(1.0, float(np.abs(fd).max())), float(np.abs(mine - fd).max())
+
+
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
     the fp64 oracle (the oracle does 65 536 rows in well under a second)."""

@@ -261,6 +261,38 @@ def test_forward_dynamics_of_an_arm_that_carries_a_hand(emu, robot, flags):
 
 
 @pytest.mark.parametrize("robot", ARM_HAND_CASES)
+@pytest.mark.parametrize("flags", [0, 3])
+def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(emu, robot, flags):
+    """rnea_backward_arm_hand (the arithmetic of rnea_backward_arm_hand_kernel: nothing stored per link, the palm's motion and
+    force adjoint put away once, every sub-chain adding its force and motion adjoint to the sums the prefix walks back with)
+    against the loop form of the adjoint walk (itself held to the reference's autograd by the golden gradient tests): input
+    gradients and the constant gradients of a learnable prefix link, palm and fingertip."""
+    m, prog, walk, keep = arm_hand_case(robot)
+    n, B = m._n_dofs, 13
+    q, qd, qdd = sample_states(m, B, seed=53)
+    gtau = np.random.default_rng(5).standard_normal((B, n)).astype(np.float32)
+    mask = (1 << 1) | (1 << (((prog.shape >> 24) & 0xf) - 1)) | (1 << (prog.n_ops - 1))
+    outs = []
+    for fn in (emu.emu_rnea_backward_arm_hand, emu.emu_rnea_backward):
+        gq, gqd, gqdd = (np.full((B, n), np.nan, np.float32) for _ in range(3))
+        gops = np.zeros((prog.capacity, 32), np.float32)
+        assert fn(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), ctypes.c_int64(B), flags, _ptr(gtau), ctypes.c_uint64(mask),
+                  _ptr(gq), _ptr(gqd), _ptr(gqdd), _ptr(gops)) == 0
+        outs.append((gq, gqd, gqdd, gops))
+    for a, b, name in zip(outs[0], outs[1], ("grad_q", "grad_qd", "grad_qdd", "grad_ops_f")):
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-5 * scale, (robot, name, float(np.abs(a - b).max()), scale)
+    assert np.abs(outs[0][3]).max() > 0
+    # without qdd (the non-linear effects' gradient)
+    g0 = [np.full((B, n), np.nan, np.float32) for _ in range(3)]
+    g1 = [np.full((B, n), np.nan, np.float32) for _ in range(3)]
+    for fn, gs in ((emu.emu_rnea_backward_arm_hand, g0), (emu.emu_rnea_backward, g1)):
+        assert fn(ctypes.byref(walk), _ptr(q), _ptr(qd), None, ctypes.c_int64(B), flags, _ptr(gtau), ctypes.c_uint64(0),
+                  _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), None) == 0
+    assert np.abs(g0[0] - g1[0]).max() <= 2e-5 * max(1.0, float(np.abs(g1[0]).max()))
+
+
+@pytest.mark.parametrize("robot", ARM_HAND_CASES)
 def test_mass_matrix_of_an_arm_that_carries_a_hand(emu, robot):
     """crba_arm_hand (the arithmetic of crba_arm_hand_kernel: a sub-chain's column forces carried together up the prefix, nothing
     parked) against the fp64 oracle and the loop form of the composite-rigid-body walk; structural zeros stay zero."""
