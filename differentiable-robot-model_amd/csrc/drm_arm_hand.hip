@@ -293,7 +293,9 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
 // and force adjoint per leaf and 36 floats per branch point: 35 KB per wavefront on a Panda with gripper — one wavefront per
 // SIMD, 408 us per 2^20 samples against 105 us for the arm alone.  Persistent wavefronts (one row of constant-gradient sums
 // each, summed in a fixed order by rnea_backward_reduce_kernel), full 64-row tiles; a ragged tail takes the loop kernel.
-// LDS (static): [ table ][ constant-gradient sums : cap x 32 ][ palm : 36 x 64 ][ grad_q | grad_qd | grad_qdd tiles : 64 x (n | 1) ]
+// LDS (static): [ table ][ palm : 36 x 64 ][ grad_q | grad_qd | grad_qdd tiles : 64 x (n | 1) ]
+// (The gradients leave through the tiles as coalesced stores.  Written straight to the lanes' rows — 4-byte stores 4 n bytes
+// apart, which would free 18 KB of LDS at 23 DoF — the same launch took 2 005 instead of 760 us.)
 // ---------------------------------------------------------------------------------------------------
 template <int P, int L>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -301,12 +303,15 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
                                   const float *__restrict__ qd, const float *__restrict__ qdd, const float *__restrict__ gtau, int K,
                                   int cap, int n, int n_tiles, int flags, uint64_t param_mask, float *__restrict__ gq,
                                   float *__restrict__ gqd, float *__restrict__ gqdd, float *__restrict__ partials, uint32_t magic_n) {
-    constexpr int OPS = P + 4 * L, C_FLOATS = OPS * DRM_OPF_STRIDE, A_FLOATS = round4(OPS) * DRM_OPF_STRIDE;
+    constexpr int OPS = P + 4 * L, C_FLOATS = OPS * DRM_OPF_STRIDE;
     constexpr int PALM = 36 * WAVE, TILE = round4(WAVE * pad_odd(OPS));
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + A_FLOATS + PALM + 3 * TILE];
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + PALM + 3 * TILE];
     const unsigned lane = threadIdx.x;
     const int n_ops = P + K * L, NV = cap * DRM_OPF_STRIDE;
-    float *lc = smem, *lacc = lc + C_FLOATS, *lp = lacc + A_FLOATS + lane, *lt = lacc + A_FLOATS + PALM;
+    float *lc = smem, *lp = lc + C_FLOATS + lane, *lt = lc + C_FLOATS + PALM;
+    // this wavefront's row of constant-gradient sums lives in global memory (lane 63 alone adds to it, in tile order): the
+    // 1.5 KB it would take in LDS is what keeps a Panda with gripper at seven instead of eight wavefronts per CU
+    float *prow = partials + (int64_t)blockIdx.x * NV;
     const int Sq = pad_odd(n), region = round4(WAVE * Sq);
     float *lgq = lt, *lgqd = lt + region, *lgqdd = lgqd + region;
     const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
@@ -315,7 +320,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
     for (int k = 0; k < P; ++k) dof[k] = (w0[k] & 0xff) - 1;
     for (unsigned i = lane; i < (unsigned)n_ops * (DRM_OPF_STRIDE / 4); i += WAVE)
         reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
-    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = 0.0f;
+    __builtin_amdgcn_s_waitcnt(0); // (lane 63 adds to its own and the other lanes' zeros below: they must have landed)
     auto kind = [&](int op) { const int w = w0[op]; return ((w & 0xff) ? 1 : 0) | (((w >> 26) & 1) << 1); };
     const bool has_qdd = qdd != nullptr;
     const unsigned row_off = lane * (unsigned)n * 4u, trow = lane * (unsigned)Sq;
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
                 for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
                     const float total = wave_sum_lane63(g[j]);
-                    if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
+                    if (lane == 63u) prow[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
                 }
             },
             [&](int i, float x) { lp[i * WAVE] = x; }, [&](int i) { return lp[i * WAVE]; });
@@ -358,9 +364,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
             tile_store<0>(gqdd + b0 * n, WAVE, n, magic_n, lgqdd, lane, (n & 1) != 0, true);
         }
     }
-    wave_lds_sync();
-    float *prow = partials + (int64_t)blockIdx.x * NV;
-    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
 // the (P, L) this library is compiled for: those of the robots it ships (robot_data/) — Panda with gripper 7 + 2 x 1, Jaco
@@ -479,7 +482,14 @@ int64_t launch_rnea_backward_arm_hand(const drm_walk *w, const float *q, const f
                            (uintptr_t)gqdd | (uintptr_t)w->ops_f;
     if (!arm_hand_compiled(w) || !shape_of(w, P, K, L) || K > 4 || B < WAVE || B / WAVE >= 0x7fffffffLL || (ptrs & 15u) != 0) return 0;
     const int n_tiles = (int)(B / WAVE);
-    const int grid = n_tiles < BWD_MAX_WAVES ? n_tiles : BWD_MAX_WAVES;
+    // as many one-wavefront blocks as the device holds at once (a grid of 2 048 on a chip that holds 1 792 runs two rounds)
+    int resident = 0, rc = DRM_ERR_UNSUPPORTED;
+#define X(p, l) if (P == p && L == l) rc = resident_blocks((rnea_backward_arm_hand_kernel<p, l>), WAVE, 0, resident);
+    DRM_ARM_HAND_SHAPES(X)
+#undef X
+    if (rc) return 0;
+    if (resident > BWD_MAX_WAVES) resident = BWD_MAX_WAVES;
+    const int grid = n_tiles < resident ? n_tiles : resident;
 #define X(p, l)                                                                                                                  \
     if (P == p && L == l) {                                                                                                      \
         hipLaunchKernelGGL((rnea_backward_arm_hand_kernel<p, l>), dim3((unsigned)grid), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, \

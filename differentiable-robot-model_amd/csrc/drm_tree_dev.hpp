@@ -213,11 +213,11 @@ static int ensure_lds_tree(K kernel, size_t bytes) {
 template <class K>
 static int resident_blocks(K kernel, int threads, size_t lds, int &out) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, size_t>, int> cache;
+    static std::map<std::tuple<const void *, int, int, size_t>, int> cache; // (kernels of one signature share this instantiation)
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipGetDevice failed");
-    const auto key = std::make_tuple(dev, threads, lds);
+    const auto key = std::make_tuple(reinterpret_cast<const void *>(kernel), dev, threads, lds);
     auto it = cache.find(key);
     if (it == cache.end()) {
         int per_cu = 0, cus = 0;
