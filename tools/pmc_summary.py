@@ -85,7 +85,7 @@ for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two
     if line:
         with open(os.path.join(prof, tag + dst), "w") as f:
             f.write(line + "\n")
-for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt")):
+for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt")):
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 if os.path.exists(os.path.join(OUT, "overhead_under_rocprofv3.txt")):
@@ -118,12 +118,12 @@ with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
 
 acc = defaultdict(lambda: defaultdict(list))
 for r in (list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")) +
-          list(rows("prof_sq4_*/*/*_counter_collection.csv"))):
+          list(rows("prof_sq4_*/*/*_counter_collection.csv")) + list(rows("prof_sq5_*/*/*_counter_collection.csv"))):
     k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
     acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
 lines = ["# SQ counters, %s (rocprofv3 --pmc, MI355X; per wave = counter / SQ_WAVES; cycle counters are quad-cycles)" % tag,
-         "(persistent kernels — rnea_records_kernel, crba_rows_kernel, forward_dynamics_aba_kernel — run several 64-sample tiles per wave:"
+         "(persistent kernels — rnea_records_kernel, crba_rows_kernel, forward_dynamics_aba_kernel, the backward kernels — run several 64-sample tiles per wave:"
          " tiles = ceil(B / 64), waves = the grid)", "",
          "| kernel | grid threads | waves | VALU | SALU | SMEM | LDS | WAVE_CYCLES | WAIT_ANY | ACTIVE_INST_ANY |",
          "|---|---|---|---|---|---|---|---|---|---|"]

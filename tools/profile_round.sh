@@ -6,6 +6,7 @@
 #   rocprofv3 --kernel-trace --stats: bench default (graph replay), the same eagerly launched, one run per batch size,
 #                     kernel_times + probe_robots (which kernel every entry point dispatches to)
 #   rocprofv3 --pmc:  FETCH_SIZE / WRITE_SIZE (separate passes, never with API tracing), SQ counters of the hot kernels
+#                     (kernel_bench*.py: metric / dynamics / config 3 / long-segment robots / backward)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -35,6 +36,9 @@ rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- pyth
 for r in panda iiwa7_allegro; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench4.py $r 262144 > $OUT/prof_sq4_$r.log 2>&1
 done
+for r in panda_no_gripper panda allegro_left iiwa7_allegro; do
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq5_$r -- python $ROOT/tools/kernel_bench5.py $r 262144 > $OUT/prof_sq5_$r.log 2>&1
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
@@ -42,6 +46,7 @@ python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots
 python $ROOT/tools/ab_rnea.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_rnea.txt
 python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
 if [ -x $ROOT/tools/ubench/metric_lab ]; then
+  $ROOT/tools/ubench/metric_lab 1048576 floors > $OUT/io_floors_2p20.txt 2>&1
   $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
   $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_plain.txt 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_overhead -- $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_under_rocprofv3.txt 2>&1
