@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="metric config: all-gather the outputs over RCCL inside every step")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only; ~30 s)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 path: nccl (= RCCL over xGMI, the product path) or gloo "
@@ -180,6 +182,47 @@ def recorded_traffic(batch):
         except (OSError, ValueError, KeyError):
             continue
     return None, None
+
+
+def measured_traffic(args, batch):
+    """HBM bytes per launch of the metric kernel, MEASURED now: two child runs of this same script (same robot and batch, no CPU
+    legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, kernel tracing only,
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes), averaged over the dispatches of the kernel: FETCH_SIZE (KiB, x2: the
+    gfx950 correction) + WRITE_SIZE (KiB).  None (with the reason) when rocprofv3 is missing or a pass fails — the caller then
+    falls back to the recorded figure under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp", DRM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="drm_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--steps", "50", "--warmup", "5",
+               "--batch", str(batch), "--robot", args.robot]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            vals = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == counter and "fk_jacobian" in row.get("Kernel_Name", ""):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for the metric kernel in the rocprofv3 output" % counter
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
+            return None, "%s pass failed: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch, write = got["FETCH_SIZE"][0] * 1024.0 * 2.0, got["WRITE_SIZE"][0] * 1024.0
+    return {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+            "dispatches": min(got["FETCH_SIZE"][1], got["WRITE_SIZE"][1])}, None
 
 
 def sample_q(model, B, device, seed):
@@ -335,6 +378,9 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
     launch_s = dev_time / K                         # average duration of one launch, HIP events on the launch stream
     achieved = bytes_per_eval * B / launch_s / 1e9
     traffic, traffic_src = recorded_traffic(B) if args.robot == "panda_no_gripper" else (None, None)
+    measured, why_not = (None, "not requested")
+    if rank == 0 and world == 1 and not args.no_traffic and os.environ.get("DRM_BENCH_CHILD") != "1":
+        measured, why_not = measured_traffic(args, B)     # (after the timed region: the child runs own the GPU meanwhile)
     line = {
         "metric": "FK+Jacobian evals/sec, Panda 7-DoF, batch=65 536 @1/2/4/8 MI355X",
         "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -349,11 +395,17 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
                    "gather": bool(gathered is not None),
                    "gather_bytes_per_rank": B * 4 * (7 + 6 * n) if gathered is not None else 0},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured["bytes"] if measured else traffic,
                      "traffic_unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                     "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
-                     "traffic_note": "RECORDED figure: rocprofv3 --pmc passes of this same command, committed under "
-                                     "profiles/ (PMC counters cannot be read from inside the timed run)", "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                     "traffic_source": "two rocprofv3 --kernel-trace --pmc child passes of this command (FETCH_SIZE, WRITE_SIZE), "
+                                       "run right after the timed region" if measured else traffic_src,
+                     "traffic_measured_in_this_run": bool(measured),
+                     "traffic_detail": measured if measured else {"fallback_reason": why_not},
+                     "traffic_note": ("MEASURED in this run (separate counter passes, kernel tracing only)" if measured else
+                                      "RECORDED figure: rocprofv3 --pmc passes of this same command, committed under profiles/"),
+                     "traffic_over_algorithmic": (measured["bytes"] if measured else traffic) / (bytes_per_eval * B)
+                     if (measured or traffic) else None,
+                     "algorithmic_bytes_per_launch": bytes_per_eval * B,
                      "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true, 1, false>", "bytes_per_eval": bytes_per_eval,
                      "launch_us": launch_s * 1e6,
                      "note": "algorithmic bytes / average launch duration (HIP events over the timed region, includes "

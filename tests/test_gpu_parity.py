@@ -694,5 +694,13 @@ def test_bench_line_carries_the_contract_fields():
     assert abs(roof["achieved"] - 224 * 65536 / (roof["launch_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
     assert roof["launch_us"] * 1e-3 <= d["ms_per_step"] * 1.001          # a launch is not longer than a step
     assert 0.2 < roof["frac"] < 1.0 and 0.2 < roof["steady_state"]["frac"] < 1.0 and roof["steady_state"]["steps"] == 200
+    # HBM traffic of the kernel, measured by the run itself (two rocprofv3 --pmc child passes) when rocprofv3 is there: within a
+    # few percent of the algorithmic bytes (nothing is read twice); otherwise the recorded figure, and the line says which
+    assert roof["traffic"] is not None and roof["algorithmic_bytes_per_launch"] == 224 * 65536
+    if roof["traffic_measured_in_this_run"]:
+        assert 0.9 <= roof["traffic_over_algorithmic"] <= 1.2, roof["traffic_detail"]
+        assert roof["traffic_detail"]["dispatches"] >= 50
+    else:
+        assert roof["traffic_detail"]["fallback_reason"] and roof["traffic_source"].startswith("profiles/")
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "evals/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]

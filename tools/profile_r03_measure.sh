@@ -7,7 +7,7 @@ python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $O
 LAB=$ROOT/tools/ubench/metric_lab
 $LAB 65536 overhead > $OUT/overhead_plain.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_overhead -- $LAB 65536 overhead > $OUT/overhead_under_rocprofv3.txt 2>&1
-B="python $ROOT/bench.py --no-cpu-baseline --no-large"
+B="python $ROOT/bench.py --no-cpu-baseline --no-large --no-traffic"
 for batch in 65536 4194304 16777216; do
   steps=200; [ $batch -gt 65536 ] && steps=50
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$batch -- $B --batch $batch --steps $steps > $OUT/prof_stats_$batch.log 2>&1

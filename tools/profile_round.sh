@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --no-cpu-baseline"
+B="python $ROOT/bench.py --no-cpu-baseline --no-traffic"
 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
 python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
