@@ -206,7 +206,7 @@ def measured_traffic(args, batch):
                os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--steps", "50", "--warmup", "5",
                "--batch", str(batch), "--robot", args.robot]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             vals = []
             for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
