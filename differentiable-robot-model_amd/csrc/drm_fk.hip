@@ -48,6 +48,78 @@ __global__ void __launch_bounds__(WAVE)
     tile_store<0>(quat + tc.b0 * 4 * T, tc.rows, 4 * T, magic_r, lr, lane, false, tc.full && (align & AL_QUAT));
 }
 
+// The same walk for MANY targets whose slots are numbered in walk order (DRM_WALK_TARGETS_ORDERED: all links of a robot,
+// compute_forward_kinematics_all_links, robot_model.py:197-221).  Staging all T poses of a tile (64 x 28 T bytes: 50 KB at 28
+// links) leaves two wavefronts per CU; here the outputs leave a GROUP of eight consecutive slots at a time — per sample a run
+// of 96 B of positions and one of 128 B of quaternions — through two small tiles: 15 KB, and the writes of one group overlap
+// the walk to the next.  16-byte sc1 stores (nt beyond the Infinity Cache); positions fall back to 4-byte stores when 12 T is
+// not a multiple of 16.
+// LDS: [ table ][ q : 64 (n|1) ][ pos group : 64 x 25 ][ quat group : 64 x 33 ][ slots : n_slots * 12 * 64 ]
+constexpr int FK_GROUP = 8, FK_GP = 3 * FK_GROUP + 1, FK_GR = 4 * FK_GROUP + 1;
+template <bool NT>
+__global__ void __launch_bounds__(WAVE)
+    fk_tree_groups_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, int T, float *__restrict__ pos, float *__restrict__ quat,
+                          uint32_t magic_q, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileCtx tc = tile_begin(B);
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n);
+    float *lq = smem + table_lds_floats(a.n_ops);
+    float *lp = lq + round4(WAVE * Sq);
+    float *lr = lp + round4(WAVE * FK_GP);
+    float *ls = lr + round4(WAVE * FK_GR); // save slots: [slot][12][64]
+
+    const TableLds tab = stage_tree_table(a, smem);
+    tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
+    wave_lds_sync();
+    const bool live = (int)lane < tc.rows;
+    const float *qrow = lq + lane * Sq;
+    float *prow = lp + lane * FK_GP, *rrow = lr + lane * FK_GR;
+    const bool pos16 = (T & 3) == 0 && (align & AL_POS);
+    const bool quat16 = (align & AL_QUAT) != 0;
+    float *gp = pos + tc.b0 * 3 * T, *gr = quat + tc.b0 * 4 * T;
+    // the group's two tiles -> global: consecutive lanes write consecutive 16 bytes of a sample's run, then the next sample's
+    auto flush = [&](int g, int cnt) {
+        wave_lds_sync();
+        if (cnt == FK_GROUP && pos16) {
+            for (int i = (int)lane; i < tc.rows * 6; i += WAVE) {
+                const int s = i / 6, part = i - s * 6;
+                const float *src = lp + s * FK_GP + part * 4;
+                store16_wt<NT>(gp + (int64_t)s * 3 * T + g * (3 * FK_GROUP) + part * 4, make_float4(src[0], src[1], src[2], src[3]));
+            }
+        } else {
+            const int w = 3 * cnt;
+            for (int i = (int)lane; i < tc.rows * w; i += WAVE) {
+                const int s = i / w, c = i - s * w;
+                gp[(int64_t)s * 3 * T + g * (3 * FK_GROUP) + c] = lp[s * FK_GP + c];
+            }
+        }
+        if (quat16) {
+            for (int i = (int)lane; i < tc.rows * cnt; i += WAVE) {
+                const int s = i / cnt, part = i - s * cnt;
+                const float *src = lr + s * FK_GR + part * 4;
+                store16_wt<NT>(gr + (int64_t)s * 4 * T + g * (4 * FK_GROUP) + part * 4, make_float4(src[0], src[1], src[2], src[3]));
+            }
+        } else {
+            const int w = 4 * cnt;
+            for (int i = (int)lane; i < tc.rows * w; i += WAVE) {
+                const int s = i / w, c = i - s * w;
+                gr[(int64_t)s * 4 * T + g * (4 * FK_GROUP) + c] = lr[s * FK_GR + c];
+            }
+        }
+        wave_lds_sync(); // the tiles are free for the next group
+    };
+    fk_tree_walk(
+        a.n_ops, tab, [&](int k) { return tab.row(k); }, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
+        [&](int s, const PoseP &P) { lds_put_pose(ls, s, lane, P); }, [&](int s, PoseP &P) { lds_get_pose(ls, s, lane, P); },
+        [&](int t, const float *p, const float *qt) {
+            const int g = t / FK_GROUP, c = t - g * FK_GROUP;
+            prow[c * 3 + 0] = p[0]; prow[c * 3 + 1] = p[1]; prow[c * 3 + 2] = p[2];
+            rrow[c * 4 + 0] = qt[0]; rrow[c * 4 + 1] = qt[1]; rrow[c * 4 + 2] = qt[2]; rrow[c * 4 + 3] = qt[3];
+            if (c == FK_GROUP - 1 || t == T - 1) flush(g, c + 1); // (t is wave-uniform: the slots come in walk order)
+        });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fan-out FK: T <= 4 targets whose root->target chains share (almost) nothing — the fingertips of a hand that hang
 // off a common palm (Allegro, TriFinger).  The merged walk above makes ONE lane compute all T chains of a sample
@@ -185,6 +257,27 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     TreeArgs a = tree_args(w);
     a.n_segments = 1; a.prefix_end = 0;
+#ifndef DRM_NO_FK_GROUPS
+    if ((w->shape & DRM_WALK_TARGETS_ORDERED) && T > FK_GROUP) {
+        // many targets in walk order (all links of a robot): outputs leave a group of eight slots at a time
+        const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(WAVE * FK_GP) +
+                                                    round4(WAVE * FK_GR) + w->n_slots * 12 * WAVE);
+        const int64_t tiles = (B + WAVE - 1) / WAVE;
+        if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+        const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+        hipStream_t s = (hipStream_t)stream;
+        if (stream_past_llc(B * 28 * T)) {
+            rc = ensure_lds_tree(fk_tree_groups_kernel<true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_tree_groups_kernel<true>, dim3((unsigned)tiles), dim3(WAVE), lds, s, a, q, B, T, pos, quat, div_magic(n), align);
+        } else {
+            rc = ensure_lds_tree(fk_tree_groups_kernel<false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_tree_groups_kernel<false>, dim3((unsigned)tiles), dim3(WAVE), lds, s, a, q, B, T, pos, quat, div_magic(n), align);
+        }
+        return launched();
+    }
+#endif
     const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(WAVE * pad_odd(3 * T)) +
                                                 round4(WAVE * pad_odd(4 * T)) + w->n_slots * 12 * WAVE);
     rc = ensure_lds_tree(fk_tree_kernel, lds);

@@ -61,6 +61,7 @@ def opf_ti(i: int) -> int:
 SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
 SHAPE_SERIAL_CHAIN = 2               # DRM_WALK_SERIAL_CHAIN
 SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top byte, DRM_WALK_AH_PACK)
+SHAPE_TARGETS_ORDERED = 8            # DRM_WALK_TARGETS_ORDERED: output slots 0, 1, 2, ... in walk order
 
 
 def arm_hand_shape(parent_op, n_ops: int, prismatic) -> int:
@@ -151,6 +152,15 @@ class RobotSpec:
             chain.append(i)
             i = int(self.parent[i])
         return chain[::-1]
+
+    def preorder(self) -> List[int]:
+        """Links in the depth-first order build_walk visits them (the root first)."""
+        out, stack = [], [0]
+        while stack:
+            i = stack.pop()
+            out.append(i)
+            stack.extend(reversed(self.children[i]))
+        return out
 
     def perm_of(self, link: int):
         """Signed column permutation (pi, d) of the stored frame of ``link``: (M P)[:, c] = d[c] * M[:, pi[c]]
@@ -593,12 +603,16 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
               and all((row[OPI_OUT] >= 0) == (k == n_ops - 1) for k, row in enumerate(ops)))
     # bits 8..15 of shape: 1 + the largest op index that is a branch point (what per-ancestor slot records are sized by)
     branch_depth = min(255, max([k + 1 for k, row in enumerate(ops) if row[OPI_SAVE] >= 0], default=0))
+    # DRM_WALK_TARGETS_ORDERED: the ops with an output slot carry slots 0, 1, 2, ... in walk order (multi-target FK then writes
+    # its outputs a group of slots at a time)
+    ordered = [row[OPI_OUT] for row in ops if row[OPI_OUT] >= 0] == list(range(len(tlist)))
     prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
     is_leaf = [not (ops_i[k, OPI_FLAGS] & FLAG_CHILD_IS_NEXT) for k in range(n_ops)]
     seg_leaf_begin = [int(sum(is_leaf[:b])) for b in seg_begin]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
+                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0)
                        | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
 

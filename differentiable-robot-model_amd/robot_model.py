@@ -557,6 +557,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
         self._fold_masks: Dict[tuple, np.ndarray] = {}          # kept (learnable) links -> foldable_links(spec, keep)
+        self._root_pose = None                                  # the root link's identity (pos [1,3], quat [1,4]), made on first use
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
     # ------------------------------------------------------------------ constants
@@ -800,10 +801,14 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._kin_cache = {}
 
     def _all_poses(self):
+        """pos [B, L', 3], quat [B, L', 4], rot [B, L', 3, 3] of every link of the recorded state, indexed by link (the kernel's
+        outputs as they stand when the links are in walk order, else gathered once)."""
         if "poses" not in self._kin_cache:
             q = self._kin_state[0]
             with torch.no_grad():
-                pos, quat = self._fk_targets(q, list(range(len(self._bodies))))
+                cols = self._fk_links(q, list(range(len(self._bodies))))
+                pos = torch.stack([cols[i][0] for i in range(len(self._bodies))], dim=1)
+                quat = torch.stack([cols[i][1] for i in range(len(self._bodies))], dim=1)
             x, y, z, w = quat.unbind(-1)
             rot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
                                2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
@@ -832,6 +837,24 @@ class DifferentiableRobotModel(torch.nn.Module):
         return self._kin_cache[key]
 
     # ------------------------------------------------------------------ FK
+    def _fk_links(self, q: torch.Tensor, link_idxs: List[int]) -> Dict[int, Tuple[torch.Tensor, torch.Tensor]]:
+        """{link index: (pos [B,3], quat [B,4])} — column views of ONE launch whose targets are taken in WALK order (the many-target
+        kernel then writes its outputs a group of consecutive slots at a time, DRM_WALK_TARGETS_ORDERED); the root's identity
+        pose is two small tensors of its own."""
+        out = {}
+        B = q.shape[0]
+        if 0 in link_idxs:      # (read-only views of two constants: no kernel, no memory)
+            if self._root_pose is None:
+                self._root_pose = (torch.zeros(1, 3, device=self._device), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self._device))
+            out[0] = (self._root_pose[0].expand(B, 3), self._root_pose[1].expand(B, 4))
+        wanted = set(int(i) for i in link_idxs if i != 0)
+        ordered = [i for i in self._spec.preorder() if i in wanted]
+        if ordered:
+            pos, quat = self._fk_targets(q, ordered)
+            for k, i in enumerate(ordered):
+                out[i] = (pos[:, k], quat[:, k])
+        return out
+
     def _fk_targets(self, q: torch.Tensor, link_idxs: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos [B,T,3], quat [B,T,4] of the given links (root targets filled with the identity pose)."""
         self._require_device()
@@ -857,8 +880,12 @@ class DifferentiableRobotModel(torch.nn.Module):
             if len(non_root) == len(link_idxs):
                 return p, r
             cols = [k for k, i in enumerate(link_idxs) if i != 0]
-            pos[:, cols] = p
-            quat[:, cols] = r
+            if cols == list(range(cols[0], cols[0] + len(cols))):     # (a slice: no index tensor, capturable into a hipGraph)
+                pos[:, cols[0]:cols[0] + len(cols)] = p
+                quat[:, cols[0]:cols[0] + len(cols)] = r
+            else:
+                pos[:, cols] = p
+                quat[:, cols] = r
         return pos, quat
 
     @tensor_check
@@ -866,9 +893,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         """{link_name: (pos [B,3], quat_xyzw [B,4])} for every link (robot_model.py:197-221)."""
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
-        idxs = list(range(len(self._bodies)))
-        pos, quat = self._fk_targets(q, idxs)
-        return {self._bodies[i].name: (pos[:, k], quat[:, k]) for k, i in enumerate(idxs)}
+        cols = self._fk_links(q, list(range(len(self._bodies))))
+        return {self._bodies[i].name: cols[i] for i in range(len(self._bodies))}
 
     @tensor_check
     def compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False

@@ -121,6 +121,8 @@ extern "C" {
 #define DRM_WALK_AH_K(shape) ((int)(((uint32_t)(shape) >> 28) & 0x3) + 1)
 #define DRM_WALK_AH_L(shape) ((int)(((uint32_t)(shape) >> 30) & 0x3) + 1)
 #define DRM_WALK_AH_PACK(P, K, L) ((uint32_t)DRM_WALK_ARM_HAND | ((uint32_t)(P) << 24) | ((uint32_t)((K) - 1) << 28) | ((uint32_t)((L) - 1) << 30))
+#define DRM_WALK_TARGETS_ORDERED 8 /* the ops with an output slot carry slots 0, 1, 2, ... in walk order: drm_fk with more than
+                                  eight targets then writes its outputs a group of eight consecutive slots at a time */
 #define DRM_WALK_LEAVES(shape) (((shape) >> 16) & 0xff) /* number of leaf ops (ops no child follows), see DRM_OPI_CTRL */
 #define DRM_WALK_BRANCH_DEPTH(shape) (((shape) >> 8) & 0xff) /* 1 + the largest op index that is a branch
                                 point (0: none): sizes the per-ancestor slot records of drm_crba /

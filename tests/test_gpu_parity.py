@@ -560,6 +560,28 @@ def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(robot, compat):
     assert np.abs(mine - fd).max() <= 2e-3 * max(1.0, float(np.abs(fd).max())), float(np.abs(mine - fd).max())
 
 
+def test_all_links_fk_beyond_the_infinity_cache():
+    """compute_forward_kinematics_all_links of a 29-link robot at 2^19 samples: 411 MB of poses, so the many-target kernel
+    (fk_tree_groups_kernel: outputs leave eight slots at a time) takes its `nt` store path; rows from the start, the middle and
+    the ragged end against the fp64 oracle, and every row of the launch identical to the same rows launched as a small batch."""
+    m = load_model("iiwa7_allegro", "cuda")
+    B = (1 << 19) + 37
+    q, _, _ = sample_states(m, B, seed=61)
+    dq = dev(q)
+    poses = m.compute_forward_kinematics_all_links(dq)
+    rows = np.r_[0:70, 262100:262200, B - 80:B]
+    small = m.compute_forward_kinematics_all_links(dev(np.ascontiguousarray(q[rows])))
+    names = [b.name for b in m._bodies]
+    op, oq = Oracle(m._spec).fk(q[rows].astype(np.float64), list(range(len(names))), np.float64)
+    for i, name in enumerate(names):
+        p, r = poses[name]
+        assert torch.equal(p[rows], small[name][0]) and torch.equal(r[rows], small[name][1]), name
+        assert max_err(host(p[rows]), op[:, i]) <= TOL_POS["atol"], name
+        ok, _ = quat_close(host(r[rows]), oq[:, i], TOL_QUAT["atol"])
+        assert ok, name
+
+
+@pytest.mark.gpu
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
     the fp64 oracle (the oracle does 65 536 rows in well under a second)."""
