@@ -366,10 +366,25 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
 }
 
-// the (P, L) this library is compiled for: those of the robots it ships (robot_data/) — Panda with gripper 7 + 2 x 1, Jaco
-// 6 + 3 x 2, iiwa7 + Allegro 7 + 4 x 4 once the host has folded every fixed joint (flatten.foldable_links), and 9 + 2 x 1,
-// 7 + 3 x 2, 8 + 4 x 4 when learnable links keep the flange / palm an op of its own; anything else keeps the loop kernel
-#define DRM_ARM_HAND_SHAPES(X) X(7, 1) X(6, 2) X(7, 4) X(9, 1) X(7, 2) X(8, 4)
+// The (P, L) this library is compiled for: prefixes of 5 to 9 ops carrying 2 to 4 sub-chains of L = 1 .. 4 ops — 6- and 7-DoF arms
+// with or without a fixed flange, with a two-finger gripper, a three-finger hand or a four-finger hand (the robots it ships:
+// Panda with gripper 7 + 2 x 1, Jaco 6 + 3 x 2, iiwa7 + Allegro 7 + 4 x 4 once the host has folded every fixed joint, and
+// 9 + 3 x 1, 7 + 3 x 2, 8 + 4 x 4 when learnable links keep the flange / palm an op of its own); anything else keeps the loop
+// kernels.  This file is compiled once per L (-DDRM_AH_L=1 .. 4, four objects built in parallel; drm_arm_hand_dispatch.hip
+// picks the object by the walk's L): its entry points carry the suffix _l<L>.
+#ifndef DRM_AH_L
+#error "compile with -DDRM_AH_L=1 .. 4 (see the Makefile)"
+#endif
+#define DRM_ARM_HAND_SHAPES(X) X(5, DRM_AH_L) X(6, DRM_AH_L) X(7, DRM_AH_L) X(8, DRM_AH_L) X(9, DRM_AH_L)
+#define DRM_AH_CAT2(a, b) a##b
+#define DRM_AH_CAT(a, b) DRM_AH_CAT2(a, b)
+#define DRM_AH_NAME(name) DRM_AH_CAT(DRM_AH_CAT(name, _l), DRM_AH_L)
+#define arm_hand_compiled DRM_AH_NAME(arm_hand_compiled)
+#define crba_arm_hand_applies DRM_AH_NAME(crba_arm_hand_applies)
+#define launch_rnea_arm_hand DRM_AH_NAME(launch_rnea_arm_hand)
+#define launch_forward_dynamics_arm_hand DRM_AH_NAME(launch_forward_dynamics_arm_hand)
+#define launch_crba_arm_hand DRM_AH_NAME(launch_crba_arm_hand)
+#define launch_rnea_backward_arm_hand DRM_AH_NAME(launch_rnea_backward_arm_hand)
 
 static bool shape_of(const drm_walk *w, int &P, int &K, int &L) {
     if (!(w->shape & DRM_WALK_ARM_HAND)) return false;

@@ -9,6 +9,7 @@ import contextlib
 import ctypes
 import io
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -221,3 +222,117 @@ def test_gpu_random_tree_fk_and_jacobian_to_every_link_vs_oracle(tmp_path, seed)
         p2, r2 = m.compute_forward_kinematics(dq, body.name)
         assert np.abs(p2.cpu().numpy() - rp).max() <= TOL_POS["atol"] * scale and quat_close(r2.cpu().numpy(), rq, 2 * TOL_QUAT["atol"])[0]
     assert took_chain_kernel > 0
+
+
+# ------------------------------------------------------------------ arms that carry a hand nobody shipped
+def arm_hand_urdf(P: int, K: int, L: int, seed: int) -> str:
+    """An arm of P moving joints (one of them sliding when seed is odd) with a fixed flange, carrying K fingers of L joints each
+    (revolute or, every third one, prismatic) behind fixed knuckle plates and ending in fixed fingertips: after the fixed
+    joints are folded the dynamics walk is DRM_WALK_ARM_HAND (P, K, L).  Axis-aligned axes (the straight-line kernels' walks
+    hold one op per joint), random frames and inertias."""
+    rng = np.random.default_rng(91000 + 131 * seed + 17 * P + 5 * K + L)
+    out = ['<?xml version="1.0"?>', '<robot name="arm%d_%d_%d_%d">' % (P, K, L, seed), '  <link name="base"/>']
+    axes = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1"]
+    count = [0]
+
+    def link(name, mass_scale=1.0):
+        A = rng.standard_normal((3, 3)) * 0.03
+        I = (A @ A.T + np.eye(3) * 0.002) * mass_scale
+        m, c = (0.05 + rng.random() * 0.8) * mass_scale, rng.standard_normal(3) * 0.04
+        out.append('  <link name="%s"><inertial><origin xyz="%.5f %.5f %.5f" rpy="0 0 0"/><mass value="%.5f"/>'
+                   '<inertia ixx="%.6f" ixy="%.6f" ixz="%.6f" iyy="%.6f" iyz="%.6f" izz="%.6f"/></inertial></link>'
+                   % (name, c[0], c[1], c[2], m, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]))
+
+    def joint(parent, child, kind):
+        xyz, rpy = rng.standard_normal(3) * 0.08, rng.standard_normal(3) * 0.7
+        count[0] += 1
+        if kind == "fixed":
+            out.append('  <joint name="j%d" type="fixed"><parent link="%s"/><child link="%s"/>'
+                       '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/></joint>' % (count[0], parent, child, *xyz, *rpy))
+            return
+        lim = (-0.3, 0.3) if kind == "prismatic" else (-2.5, 2.5)
+        out.append('  <joint name="j%d" type="%s"><parent link="%s"/><child link="%s"/>'
+                   '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/><axis xyz="%s"/>'
+                   '<limit effort="10" lower="%.2f" upper="%.2f" velocity="3"/><dynamics damping="%.3f"/></joint>'
+                   % (count[0], kind, parent, child, *xyz, *rpy, axes[int(rng.integers(6))], lim[0], lim[1], rng.random() * 0.2))
+
+    parent = "base"
+    slide = int(rng.integers(P)) if seed % 2 else -1
+    for k in range(P):
+        link("a%d" % k)
+        joint(parent, "a%d" % k, "prismatic" if k == slide else "revolute")
+        parent = "a%d" % k
+    link("flange")
+    joint(parent, "flange", "fixed")
+    for j in range(K):
+        link("k%d" % j, 0.2)
+        joint("flange", "k%d" % j, "fixed")
+        parent = "k%d" % j
+        for i in range(L):
+            name = "f%d_%d" % (j, i)
+            link(name, 0.2)
+            joint(parent, name, "prismatic" if (j + i + seed) % 3 == 0 else "revolute")
+            parent = name
+        link("tip%d" % j, 0.05)
+        joint(parent, "tip%d" % j, "fixed")
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+ARM_HAND_SHAPES = [(P, K, L) for P in (5, 6, 7, 8, 9) for K, L in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 3), (4, 3), (3, 4), (4, 4))]
+
+
+def arm_hand_model(tmp_path, P, K, L, seed, device):
+    path = os.path.join(str(tmp_path), "arm_%d_%d_%d_%d.urdf" % (P, K, L, seed))
+    with open(path, "w") as f:
+        f.write(arm_hand_urdf(P, K, L, seed))
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return DifferentiableRobotModel(path, device=device)
+
+
+def test_generated_arms_with_hands_have_the_shape_they_are_built_for(tmp_path):
+    from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
+    for P, K, L in ARM_HAND_SHAPES:
+        m = arm_hand_model(tmp_path, P, K, L, P + K + L, "cpu")
+        sh = build_walk(m._spec, whole_tree=True, drop_folded=True).shape & 0xffffffff
+        assert sh & SHAPE_ARM_HAND and ((sh >> 24) & 0xf, ((sh >> 28) & 3) + 1, ((sh >> 30) & 3) + 1) == (P, K, L), (P, K, L)
+        assert m._n_dofs == P + K * L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,K,L", ARM_HAND_SHAPES)
+def test_gpu_generated_arm_with_hand_vs_oracle(tmp_path, P, K, L):
+    """Every compiled (P, L) of the arm + hand kernels (drm_arm_hand.hip: 5 .. 9 prefix ops, sub-chains of 1 .. 4 ops, 2 .. 4 of
+    them) on a robot generated for the shape — sliding joints in the arm and in the fingers, fixed flange / knuckles / tips
+    folded on the host: inverse dynamics, the mass matrix, forward dynamics and the gradient of a torque loss against the fp64
+    oracle (the gradient against central differences of it), full tiles + a ragged tail."""
+    seed = P + K + L
+    mc, m = arm_hand_model(tmp_path, P, K, L, seed, "cpu"), arm_hand_model(tmp_path, P, K, L, seed, "cuda")
+    from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
+    assert m._dynamics_walk().program.shape & SHAPE_ARM_HAND
+    n, B = m._n_dofs, 64 * 3 + 7
+    q, qd, qdd = sample_states(mc, B, seed=seed)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    orc = Oracle(mc._spec)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    for grav, damp in ((True, True), (False, False)):
+        tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+        assert np.allclose(tau.cpu().numpy(), orc.rnea(q64, qd64, qdd64, grav, damp, np.float64), **TOL_TAU), (P, K, L, grav)
+    H = m.compute_lagrangian_inertia_matrix(dev(q))
+    assert np.allclose(H.cpu().numpy(), orc.mass_matrix(q64, False, False, np.float64), **TOL_TAU), (P, K, L)
+    assert torch.equal(H, H.transpose(1, 2))
+    tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=True, use_damping=True)
+    acc = m.compute_forward_dynamics(dev(q), dev(qd), tau, include_gravity=True, use_damping=True)
+    ref = orc.forward_dynamics(q64, qd64, tau.cpu().numpy().astype(np.float64), True, True, np.float64)
+    assert rel(acc.cpu().numpy(), ref) < 2e-3, (P, K, L, rel(acc.cpu().numpy(), ref))
+    # reverse mode: d <g, tau> / dq along a random direction against central differences of the fp64 oracle
+    g = np.random.default_rng(seed).standard_normal((B, n)).astype(np.float32)
+    tq = dev(q).requires_grad_(True)
+    (m.compute_inverse_dynamics(tq, dev(qd), dev(qdd), include_gravity=True, use_damping=True) * dev(g)).sum().backward()
+    v = np.random.default_rng(seed + 1).standard_normal((B, n))
+    e = 1e-6
+    fd = ((orc.rnea(q64 + e * v, qd64, qdd64, True, True, np.float64) - orc.rnea(q64 - e * v, qd64, qdd64, True, True, np.float64))
+          / (2 * e) * g).sum(axis=1)
+    mine = (tq.grad.cpu().numpy().astype(np.float64) * v).sum(axis=1)
+    assert np.abs(mine - fd).max() <= 2e-3 * max(1.0, float(np.abs(fd).max())), (P, K, L, float(np.abs(mine - fd).max()))

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-echo prefetch; python tools/probe_robots.py 2>&1 | grep "n=" | grep "panda \|jaco\|allegro" | cut -c1-95
-echo no prefetch; DRM_HIP_LIBRARY=tools/variants/libdrm_nopf.so python tools/probe_robots.py 2>&1 | grep "n=" | grep "panda \|jaco\|allegro" | cut -c1-95
+timeout 1500 python -m pytest tests/test_random_trees.py -m gpu -q -k "generated_arm" 2>&1 | grep -v Warn | grep "passed\|failed\|Error\|assert" | head -30
