@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
 // kernels.  This file is compiled once per L (-DDRM_AH_L=1 .. 4, four objects built in parallel; drm_arm_hand_dispatch.hip
 // picks the object by the walk's L): its entry points carry the suffix _l<L>.
 #ifndef DRM_AH_L
-#error "compile with -DDRM_AH_L=1 .. 4 (see the Makefile)"
+#define DRM_AH_L 1 /* (a bare `hipcc -c` of this file builds the L = 1 object; the Makefile passes -DDRM_AH_L=1 .. 4) */
 #endif
 #define DRM_ARM_HAND_SHAPES(X) X(5, DRM_AH_L) X(6, DRM_AH_L) X(7, DRM_AH_L) X(8, DRM_AH_L) X(9, DRM_AH_L)
 #define DRM_AH_CAT2(a, b) a##b
