@@ -148,6 +148,95 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
     tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true); // 128 rows of NJ floats = 64 "rows" of 2 NJ
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Inverse dynamics of a HAND (DRM_WALK_FINGERS: K serial chains of L revolute ops off the root — Allegro 4 x 4, TriFinger 3 x 3 —
+// every fixed joint folded away on the host): each finger is a short arm, so it takes the arm recursion — two samples per lane,
+// every instruction a full packed op (rnea_chain2_trig<L, L, L - 1>: all body forces in registers, nothing parked).  A block of
+// K wavefronts owns 128 samples, wavefront w walks finger w: its L table rows in LDS, its L columns of q / qd / qdd read per lane
+// (one 16-byte load per sample and array when L = 4 and the rows are 16-byte multiples), its L columns of tau written the same
+// way — the K wavefronts of the block complete the rows between them.  The loop form (rnea_tree_kernel, one wavefront per
+// finger and 64 samples, generic steps unrolled) issues 905 VALU per finger and 64 samples; this one ~450.
+// ---------------------------------------------------------------------------------------------------
+#ifndef DRM_FINGERS_WAVES4
+#define DRM_FINGERS_WAVES4 2 /* waves per SIMD the L = 4 kernel is held to (L <= 3: three) */
+#endif
+#ifndef DRM_FINGERS_PARK
+#define DRM_FINGERS_PARK 0 /* body forces of that many first links parked in LDS instead of registers */
+#endif
+#define DRM_FINGERS_KEEP(L) ((L) - 1 - ((L) - 1 < DRM_FINGERS_PARK ? (L) - 1 : DRM_FINGERS_PARK))
+template <int L>
+__global__ void __launch_bounds__(WAVE * 4)
+    __attribute__((amdgpu_waves_per_eu(L <= 3 ? 3 : DRM_FINGERS_WAVES4, L <= 3 ? 3 : DRM_FINGERS_WAVES4)))
+    rnea_fingers2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                         const float *__restrict__ qdd, int n, int flags, float *__restrict__ tau, int vec) {
+    constexpr int C_FLOATS = L * DRM_OPF_STRIDE, KEEP = DRM_FINGERS_KEEP(L), PARK = (L - 1 - KEEP) * 6 * TILE2;
+    __shared__ __attribute__((aligned(16))) float smem[4 * (C_FLOATS + PARK)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * (C_FLOATS + PARK);
+    f2 *lf = reinterpret_cast<f2 *>(lc + C_FLOATS) + lane; // parked body forces (if any): [link][6][64] pairs
+    const int64_t b0 = (int64_t)blockIdx.x * TILE2;
+    if (lane < (unsigned)(L * (DRM_OPF_STRIDE / 4)))
+        reinterpret_cast<float4 *>(lc)[lane] = reinterpret_cast<const float4 *>(ops_f + (size_t)wave * C_FLOATS)[lane];
+    const int64_t ra = (b0 + lane) * n + wave * L, rb = ra + (int64_t)WAVE * n;
+    f2 qv[L], qdv[L], qddv[L], tv[L];
+    auto load = [&](const float *src, f2 (&dst)[L]) {
+        if (L == 4 && vec) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + ra), b = *reinterpret_cast<const float4 *>(src + rb);
+            dst[0] = f2_make(a.x, b.x); dst[1] = f2_make(a.y, b.y); dst[2 % L] = f2_make(a.z, b.z); dst[3 % L] = f2_make(a.w, b.w);
+        } else {
+#pragma unroll
+            for (int d = 0; d < L; ++d) dst[d] = f2_make(src[ra + d], src[rb + d]);
+        }
+    };
+    load(q, qv);
+    load(qd, qdv);
+    if (qdd) load(qdd, qddv);
+    else {
+#pragma unroll
+        for (int d = 0; d < L; ++d) qddv[d] = f2_bcast(0.0f);
+    }
+    wave_lds_sync();
+    f2 cs[L], sn[L];
+    chain_trig2<L>(qv, cs, sn);
+    rnea_chain2_trig<L, L, KEEP>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                                 flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+                                 [&](int k, const Force2 &F) {
+#pragma unroll
+                                     for (int i = 0; i < 3; ++i) { lf[(k * 6 + i) * WAVE] = F.f[i]; lf[(k * 6 + 3 + i) * WAVE] = F.n[i]; }
+                                 },
+                                 [&](int k, Force2 &F) {
+#pragma unroll
+                                     for (int i = 0; i < 3; ++i) { F.f[i] = lf[(k * 6 + i) * WAVE]; F.n[i] = lf[(k * 6 + 3 + i) * WAVE]; }
+                                 });
+    if (L == 4 && vec) {
+        *reinterpret_cast<float4 *>(tau + ra) = make_float4(tv[0][0], tv[1][0], tv[2 % L][0], tv[3 % L][0]);
+        *reinterpret_cast<float4 *>(tau + rb) = make_float4(tv[0][1], tv[1][1], tv[2 % L][1], tv[3 % L][1]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < L; ++d) { tau[ra + d] = tv[d][0]; tau[rb + d] = tv[d][1]; }
+    }
+}
+
+// rows covered (full 128-row tiles), 0 = the call does not qualify
+int64_t launch_rnea_fingers(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
+                            hipStream_t s) {
+#ifdef DRM_NO_FINGERS_KERNEL
+    return 0;
+#else
+    if (!(w->shape & DRM_WALK_FINGERS) || B < TILE2 || B / TILE2 >= 0x7fffffffLL || (((uintptr_t)w->ops_f) & 15u) != 0) return 0;
+    const int K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape), n = w->n_dofs;
+    if (K * L != w->n_ops || n != w->n_ops || K < 2 || K > 4 || L < 2 || L > 4) return 0;
+    const int n2 = (int)(B / TILE2);
+    const int vec = (n % 4 == 0) && ((((uintptr_t)q | (uintptr_t)qd | (uintptr_t)qdd | (uintptr_t)tau) & 15u) == 0);
+#define X(l)                                                                                                                     \
+    if (L == l) hipLaunchKernelGGL((rnea_fingers2_kernel<l>), dim3((unsigned)n2), dim3(WAVE * K), 0, s, w->ops_f, q, qd, qdd, n, flags, tau, vec);
+    X(2) X(3) X(4)
+#undef X
+    return (int64_t)n2 * TILE2;
+#endif
+}
+
 void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s) {
 #ifndef DRM_RNEA_ONE_SAMPLE_PER_LANE

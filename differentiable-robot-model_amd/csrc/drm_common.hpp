@@ -352,6 +352,8 @@ void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, flo
 // links the dynamics sweeps of an arm-chain walk visit: n_dofs when nothing follows the moving joints (fixed tail folded into
 // the last moving link by the host, flatten.fold_link_table), else the whole capacity
 inline int arm_links(const drm_walk *w) { return w->n_ops == w->n_dofs ? w->n_dofs : w->capacity; }
+int64_t launch_rnea_fingers(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
+                            hipStream_t s);
 void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s);
 void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,

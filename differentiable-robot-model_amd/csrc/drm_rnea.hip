@@ -220,6 +220,17 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
                         tau + done * n, scratch, stream);
     }
 #endif
+    {   // a hand (fingers off the root): full 128-row tiles through the two-samples-per-lane finger kernel
+        const int64_t done = launch_rnea_fingers(w, q, qd, qdd, B, (int)flags, tau, s);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_FINGERS;
+            return drm_rnea(&generic, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, tau + done * n,
+                            scratch, stream);
+        }
+    }
     {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel
         const int64_t done = launch_rnea_arm_hand(w, q, qd, qdd, B, (int)flags, tau, s);
         if (done > 0) {

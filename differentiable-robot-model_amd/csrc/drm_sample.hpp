@@ -1162,7 +1162,7 @@ DRM_HD void rnea2_body_force(float m, const float *mc, const float *Io, const Mo
 template <int LINKS, int NJ, int KEEP2 = DRM_RNEA2_KEEP, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)[NJ], const f2 (&sn)[NJ], const f2 (&qd)[NJ],
                              const f2 (&qdd)[NJ], f2 (&tau)[NJ], FPUT fput, FGET fget) {
-    static_assert(LINKS >= NJ && LINKS >= 2 + KEEP2, "moving joints first, then fixed links");
+    static_assert(LINKS >= NJ && LINKS >= 1 + KEEP2, "moving joints first, then fixed links"); // (KEEP2 = LINKS - 1: nothing parked)
     constexpr int PARKED = LINKS - 1 - KEEP2;
     Motion2 cur;
     Force2 tot;

@@ -62,6 +62,25 @@ SHAPE_ARM_CHAIN = 1                  # drm_walk.shape bit, see include/drm_hip.h
 SHAPE_SERIAL_CHAIN = 2               # DRM_WALK_SERIAL_CHAIN
 SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top byte, DRM_WALK_AH_PACK)
 SHAPE_TARGETS_ORDERED = 8            # DRM_WALK_TARGETS_ORDERED: output slots 0, 1, 2, ... in walk order
+SHAPE_FINGERS = 16                   # DRM_WALK_FINGERS (+ K, L in the top byte)
+
+
+def fingers_shape(ops, parent_op, n_ops: int, n_dofs: int, prismatic) -> int:
+    """DRM_WALK_FINGERS | K, L when the walk is K (2..4) serial chains of L (2..4) revolute ops each, every chain hanging off
+    the root, op k driving DoF column k — a hand whose fixed joints are folded away (Allegro 4 x 4, TriFinger 3 x 3); else 0."""
+    if n_ops != n_dofs or n_ops < 4 or any(prismatic):
+        return 0
+    heads = [k for k in range(n_ops) if parent_op[k] == -1]
+    K = len(heads)
+    if not (2 <= K <= 4) or n_ops % K or heads[0] != 0:
+        return 0
+    L = n_ops // K
+    if not (2 <= L <= 4) or heads != [j * L for j in range(K)]:
+        return 0
+    for k in range(n_ops):
+        if ops[k][OPI_DOF] != k or (k % L and parent_op[k] != k - 1) or ops[k][OPI_SAVE] >= 0:
+            return 0
+    return SHAPE_FINGERS | ((K - 1) << 28) | ((L - 1) << 30)
 
 
 def arm_hand_shape(parent_op, n_ops: int, prismatic) -> int:
@@ -613,7 +632,8 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
                        | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0)
-                       | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0),
+                       | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0)
+                       | (fingers_shape(ops, parent_op, n_ops, n, prismatic) if whole_tree else 0),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
 
 

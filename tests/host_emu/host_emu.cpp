@@ -135,6 +135,29 @@ void rnea_arm2_8_7(const drm_walk *w, const float *q, const float *qd, const flo
     }
 }
 
+// the arithmetic of rnea_fingers2_kernel<L>: finger w = ops w L .. w L + L - 1 = DoF columns of the same numbers; two samples share
+// a lane; all body forces kept (nothing parked)
+template <int L>
+void rnea_fingers2_emu(const drm_walk *w, int K, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
+    const int n = w->n_dofs;
+    for (int64_t b = 0; b < B; b += 2) {
+        const int64_t b1 = b + 1 < B ? b + 1 : b;
+        for (int f = 0; f < K; ++f) {
+            f2 qv[L], qdv[L], qddv[L], tv[L], cs[L], sn[L];
+            for (int d = 0; d < L; ++d) {
+                const int c = f * L + d;
+                qv[d] = f2_make(q[b * n + c], q[b1 * n + c]);
+                qdv[d] = f2_make(qd[b * n + c], qd[b1 * n + c]);
+                qddv[d] = qdd ? f2_make(qdd[b * n + c], qdd[b1 * n + c]) : f2_bcast(0.f);
+            }
+            chain_trig2<L>(qv, cs, sn);
+            rnea_chain2_trig<L, L, L - 1>([&](int k) { return w->ops_f + (f * L + k) * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+                                          flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv, [](int, const Force2 &) {}, [](int, Force2 &) {});
+            for (int d = 0; d < L; ++d) { tau[b * n + f * L + d] = tv[d][0]; tau[b1 * n + f * L + d] = tv[d][1]; }
+        }
+    }
+}
+
 // the arithmetic of rnea_arm_hand_kernel<P, L> (one sample per lane; K sub-chains of L ops behind a prefix of P ops)
 template <int P, int L>
 void rnea_arm_hand_emu(const drm_walk *w, int K, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau) {
@@ -523,6 +546,16 @@ int emu_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float *H) {
     if (P == 9 && L == 1) crba_arm_hand_emu<9, 1>(w, K, q, B, H);
     else if (P == 7 && L == 2) crba_arm_hand_emu<7, 2>(w, K, q, B, H);
     else if (P == 8 && L == 4) crba_arm_hand_emu<8, 4>(w, K, q, B, H);
+    else return -2;
+    return 0;
+}
+int emu_rnea_fingers(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags, float *tau) {
+    if (!(w->shape & DRM_WALK_FINGERS)) return -2;
+    const int K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (K * L != w->n_ops || w->n_ops != w->n_dofs) return -1;
+    if (L == 2) rnea_fingers2_emu<2>(w, K, q, qd, qdd, B, flags, tau);
+    else if (L == 3) rnea_fingers2_emu<3>(w, K, q, qd, qdd, B, flags, tau);
+    else if (L == 4) rnea_fingers2_emu<4>(w, K, q, qd, qdd, B, flags, tau);
     else return -2;
     return 0;
 }

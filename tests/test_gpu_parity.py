@@ -514,6 +514,31 @@ def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["allegro_left", "trifinger_edu"])
+def test_inverse_dynamics_of_a_hand_two_samples_per_lane(robot):
+    """rnea_fingers2_kernel (DRM_WALK_FINGERS: a finger per wavefront, two samples per lane, full 128-row tiles; the rest of a
+    launch through the loop kernel): every row against the fp64 oracle, all flag combinations, the non-linear effects, misaligned
+    views, and the rows of full tiles identical whether or not a tail follows."""
+    from differentiable_robot_model_amd.flatten import SHAPE_FINGERS
+    m = load_model(robot, "cuda")
+    assert m._dynamics_walk().program.shape & SHAPE_FINGERS
+    B = 128 * 7 + 77
+    q, qd, qdd = sample_states(m, B, seed=83)
+    orc = Oracle(m._spec)
+    q64, qd64, qdd64 = (a.astype(np.float64) for a in (q, qd, qdd))
+    for grav in (True, False):
+        for damp in (True, False):
+            tau = m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd), include_gravity=grav, use_damping=damp)
+            assert np.allclose(host(tau), orc.rnea(q64, qd64, qdd64, grav, damp, np.float64), **TOL_TAU), (robot, grav, damp)
+    nle = m.compute_non_linear_effects(dev(q), dev(qd))
+    assert np.allclose(host(nle), orc.rnea(q64, qd64, np.zeros_like(q64), True, True, np.float64), **TOL_TAU)
+    full = m.compute_inverse_dynamics(dev(q[:128 * 7]), dev(qd[:128 * 7]), dev(qdd[:128 * 7]))
+    assert torch.equal(full, m.compute_inverse_dynamics(dev(q), dev(qd), dev(qdd))[:128 * 7])
+    view = m.compute_inverse_dynamics(dev(q)[1:], dev(qd)[1:], dev(qdd)[1:])      # rows start 4 n bytes into the buffers
+    assert np.allclose(host(view), orc.rnea(q64[1:], qd64[1:], qdd64[1:], True, True, np.float64), **TOL_TAU)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("robot,compat", [("panda", True), ("panda", False), ("jaco", True), ("iiwa7_allegro", True)])
 def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(robot, compat):
     """rnea_backward_arm_hand_kernel (full tiles of an arm + hand walk; nothing stored per link) against the loop-structured
