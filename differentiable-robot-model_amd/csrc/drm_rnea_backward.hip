@@ -382,6 +382,85 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int a = 0; a < NACC; ++a) prow[a * WAVE + (int)lane] = acc[a];
 }
 
+// A HAND (DRM_WALK_FINGERS: K serial chains of L revolute ops off the root): every finger is a short arm, so it takes the arm
+// form of the adjoint walk (rnea_backward_chain<L, L>: nothing stored per link).  A block of K wavefronts owns a 64-sample tile
+// at a time (persistent blocks), wavefront w walks finger w: its L table rows in LDS, its L columns of q / qd / qdd / grad_tau
+// read per lane and its L columns of the three gradients written per lane (one 16-byte access per sample and array at L = 4);
+// the block's row of constant-gradient sums lives in global memory, each wavefront adding to the slice of its own ops.
+// The loop form (rnea_backward_fan_kernel + rnea_backward_walk_short) takes 436 us per 2^20 samples of the Allegro hand.
+#ifndef DRM_BWD_FINGERS_WAVES
+#define DRM_BWD_FINGERS_WAVES 3 /* 162-166 VGPRs: three wavefronts per SIMD (TriFinger: 141 -> 103 us against two) */
+#endif
+template <int L>
+__global__ void __launch_bounds__(WAVE * 4) __attribute__((amdgpu_waves_per_eu(DRM_BWD_FINGERS_WAVES, DRM_BWD_FINGERS_WAVES)))
+    rnea_backward_fingers_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                                 const float *__restrict__ qdd, const float *__restrict__ gtau, int n, int cap, int n_tiles, int flags,
+                                 uint64_t param_mask, float *__restrict__ gq, float *__restrict__ gqd, float *__restrict__ gqdd,
+                                 float *__restrict__ partials, int vec) {
+    constexpr int C_FLOATS = L * DRM_OPF_STRIDE, G_FLOATS = 3 * L * WAVE;
+    __shared__ __attribute__((aligned(16))) float smem[4 * (C_FLOATS + G_FLOATS)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * (C_FLOATS + G_FLOATS);
+    float *lg = lc + C_FLOATS + lane; // this lane's gradients until the walk is through: [array][joint][64] (each lane its own words)
+    if (lane < (unsigned)(L * (DRM_OPF_STRIDE / 4)))
+        reinterpret_cast<float4 *>(lc)[lane] = reinterpret_cast<const float4 *>(ops_f + (size_t)wave * C_FLOATS)[lane];
+    float *prow = partials + (int64_t)blockIdx.x * cap * DRM_OPF_STRIDE + wave * C_FLOATS; // this finger's slice of the block's row
+    for (int i = (int)lane; i < C_FLOATS; i += WAVE) prow[i] = 0.0f;
+    if (wave == 0) { // the rows of the table's padding ops belong to nobody: zero
+        const int K = (int)(blockDim.x >> 6);
+        float *pad = partials + (int64_t)blockIdx.x * cap * DRM_OPF_STRIDE;
+        for (int i = K * C_FLOATS + (int)lane; i < cap * DRM_OPF_STRIDE; i += WAVE) pad[i] = 0.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    wave_lds_sync();
+    const uint64_t mask = (param_mask >> (wave * L)) & ((1ull << L) - 1ull);
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t r0 = ((int64_t)tile * WAVE + lane) * n + wave * L;
+        float qv[L], qdv[L], qddv[L], gtv[L];
+        auto load = [&](const float *src, float (&dst)[L]) {
+            if (L == 4 && vec) {
+                const float4 a = *reinterpret_cast<const float4 *>(src + r0);
+                dst[0] = a.x; dst[1] = a.y; dst[2 % L] = a.z; dst[3 % L] = a.w;
+            } else {
+#pragma unroll
+                for (int d = 0; d < L; ++d) dst[d] = src[r0 + d];
+            }
+        };
+        load(q, qv); load(qd, qdv); load(gtau, gtv);
+        if (qdd) load(qdd, qddv);
+        else {
+#pragma unroll
+            for (int d = 0; d < L; ++d) qddv[d] = 0.0f;
+        }
+        rnea_backward_chain<L, L>(
+            [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, mask,
+            gq != nullptr, qv, qdv, qddv, gtv,
+            [&](int d, float a, float v, float c) { lg[d * WAVE] = a; lg[(L + d) * WAVE] = v; lg[(2 * L + d) * WAVE] = c; },
+            [&](int k, const float *g) { // wave-uniform call: only for the ops the mask selects
+#pragma unroll
+                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+                    const float total = wave_sum_lane63(g[j]);
+                    if (lane == 63u) prow[k * DRM_OPF_STRIDE + j] += total; // tiles in this block's fixed order
+                }
+            });
+        if (gq) {
+            auto store = [&](float *dst, int arr) {
+                float v[L];
+#pragma unroll
+                for (int d = 0; d < L; ++d) v[d] = lg[(arr * L + d) * WAVE];
+                if (L == 4 && vec) *reinterpret_cast<float4 *>(dst + r0) = make_float4(v[0], v[1], v[2 % L], v[3 % L]);
+                else {
+#pragma unroll
+                    for (int d = 0; d < L; ++d) dst[r0 + d] = v[d];
+                }
+            };
+            store(gq, 0); store(gqd, 1); store(gqdd, 2);
+        }
+    }
+}
+
 static size_t rnea_backward_lds_floats(int n, int n_slots, int cap, int n_ops, int n_leaves, bool park_hbm) {
     return (size_t)4 * round4(WAVE * pad_odd(n)) + (size_t)cap * DRM_OPF_STRIDE + (size_t)n_slots * SLOT_FLOATS * WAVE +
            (park_hbm ? 0 : (size_t)record_floats(n_ops, n_leaves));
@@ -485,11 +564,39 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         }
     }
 #endif
-    {   // an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through the straight-line kernel,
-        // the ragged tail (< 64 rows, one wavefront) through the loop kernel with its row of partial sums appended
+    {   // a hand (DRM_WALK_FINGERS) / an arm that carries a hand (Panda with gripper, Jaco, iiwa7 + Allegro): full tiles through
+        // the straight-line kernels, the ragged tail (< 64 rows, one wavefront) through the loop kernel with its row of partial
+        // sums appended
         int rows = 0;
-        const int64_t done = launch_rnea_backward_arm_hand(w, q, qd, qdd, grad_tau, B, (int)flags, param_mask, grad_q, grad_qd, grad_qdd,
-                                                           partials, rows, s);
+        int64_t done = 0;
+#ifndef DRM_NO_FINGERS_KERNEL
+        if ((w->shape & DRM_WALK_FINGERS) && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)w->ops_f) & 15u) == 0) {
+            const int K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+            if (K * L == w->n_ops && n == w->n_ops && K >= 2 && K <= 4 && L >= 2 && L <= 4 && cap >= w->n_ops) {
+                const int n_tiles = (int)(B / WAVE);
+                int resident = 0;
+                rc = L == 2 ? resident_blocks(rnea_backward_fingers_kernel<2>, WAVE * K, 0, resident)
+                            : L == 3 ? resident_blocks(rnea_backward_fingers_kernel<3>, WAVE * K, 0, resident)
+                                     : resident_blocks(rnea_backward_fingers_kernel<4>, WAVE * K, 0, resident);
+                if (rc) return rc;
+                if (resident > BWD_MAX_WAVES) resident = BWD_MAX_WAVES;
+                const int grid = n_tiles < resident ? n_tiles : resident;
+                const int vec = (n % 4 == 0) && ((((uintptr_t)q | (uintptr_t)qd | (uintptr_t)qdd | (uintptr_t)grad_tau | (uintptr_t)grad_q |
+                                                   (uintptr_t)grad_qd | (uintptr_t)grad_qdd) & 15u) == 0);
+#define X(l)                                                                                                                    \
+    if (L == l)                                                                                                                  \
+        hipLaunchKernelGGL((rnea_backward_fingers_kernel<l>), dim3((unsigned)grid), dim3(WAVE * K), 0, s, w->ops_f, q, qd, qdd,    \
+                           grad_tau, n, cap, n_tiles, (int)flags, param_mask, grad_q, grad_qd, grad_qdd, partials, vec);
+                X(2) X(3) X(4)
+#undef X
+                rows = grid;
+                done = (int64_t)n_tiles * WAVE;
+            }
+        }
+#endif
+        if (done == 0)
+            done = launch_rnea_backward_arm_hand(w, q, qd, qdd, grad_tau, B, (int)flags, param_mask, grad_q, grad_qd, grad_qdd,
+                                                 partials, rows, s);
         if (done > 0) {
             rc = launched();
             if (rc) return rc;

@@ -539,6 +539,50 @@ def test_inverse_dynamics_of_a_hand_two_samples_per_lane(robot):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["allegro_left", "trifinger_edu"])
+def test_inverse_dynamics_backward_of_a_hand(robot):
+    """rnea_backward_fingers_kernel (a finger per wavefront on the arm form of the adjoint walk) against the loop-structured
+    backward kernel on the same walk without its shape bit — the kernel the reference-autograd goldens hold (their batches are
+    below one tile): input gradients and the constant gradients of three ops, full tiles + ragged tail, with and without qdd,
+    aligned and misaligned; and through autograd against central differences of the fp64 oracle."""
+    import copy
+    from differentiable_robot_model_amd import backend
+    from differentiable_robot_model_amd.flatten import SHAPE_FINGERS
+    m = load_model(robot, "cuda")
+    dw = m._dynamics_walk()
+    assert dw.program.shape & SHAPE_FINGERS
+    B, n = 64 * 11 + 9, m._n_dofs
+    q, qd, qdd = (dev(a) for a in sample_states(m, B, seed=29))
+    gtau = torch.randn(B, n, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+    of = m._ops_f(dw)
+    mask = (1 << 0) | (1 << (n // 2)) | (1 << (n - 1))
+    generic = copy.copy(dw.program)
+    generic.shape = dw.program.shape & ~SHAPE_FINGERS & 0xffffff
+    for use_qdd in (True, False):
+        for grav, damp in ((True, True), (False, False)):
+            for off in (0, 1):      # off = 1: rows start 4 n bytes into the buffers (no 16-byte accesses)
+                a = [t[off:] for t in (q, qd, qdd, gtau)]
+                got = backend.rnea_backward(dw.program, of, dw.ops_i, a[0], a[1], a[2] if use_qdd else None, a[3], grav, damp, n, mask, True)
+                ref = backend.rnea_backward(generic, of, dw.ops_i, a[0], a[1], a[2] if use_qdd else None, a[3], grav, damp, n, mask, True)
+                for x, y, name in zip(got[0], ref[0], ("grad_q", "grad_qd", "grad_qdd")):
+                    scale = max(1.0, float(y.abs().max()))
+                    assert float((x - y).abs().max()) <= 5e-5 * scale, (robot, name, use_qdd, grav, off, float((x - y).abs().max()))
+                scale = max(1.0, float(ref[1].abs().max()))
+                assert float((got[1] - ref[1]).abs().max()) <= 2e-4 * scale, (robot, "grad_ops_f", float((got[1] - ref[1]).abs().max()))
+                assert float(got[1].abs().max()) > 0
+    orc = Oracle(m._spec)
+    tq = q.clone().requires_grad_(True)
+    (m.compute_inverse_dynamics(tq, qd, qdd, include_gravity=True, use_damping=True) * gtau).sum().backward()
+    v = np.random.default_rng(0).standard_normal((B, n))
+    q64, qd64, qdd64 = (host(t).astype(np.float64) for t in (q, qd, qdd))
+    e = 1e-6
+    fd = ((orc.rnea(q64 + e * v, qd64, qdd64, True, True, np.float64) - orc.rnea(q64 - e * v, qd64, qdd64, True, True, np.float64))
+          / (2 * e) * host(gtau)).sum(axis=1)
+    mine = (host(tq.grad).astype(np.float64) * v).sum(axis=1)
+    assert np.abs(mine - fd).max() <= 2e-3 * max(1.0, float(np.abs(fd).max())), float(np.abs(mine - fd).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("robot,compat", [("panda", True), ("panda", False), ("jaco", True), ("iiwa7_allegro", True)])
 def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(robot, compat):
     """rnea_backward_arm_hand_kernel (full tiles of an arm + hand walk; nothing stored per link) against the loop-structured

@@ -121,6 +121,9 @@ for B in [s for s in sizes if s <= (1 << 20)]:
     print("fwd dyn     allegro B=%8d %9.2f us  %7.1f GB/s (256 B/eval)  %6.2f Gevals/s" % (B, us, B * 256 / us / 1e3, B / us / 1e3))
     us = graph_time(lambda: backend.rnea_backward(dta.program, ofa, dta.ops_i, qa, qda, qdda, ga, True, True, 16, 0b10, True), launches=10)
     print("rnea bwd    allegro B=%8d %9.2f us  %7.1f GB/s (448 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" % (B, us, B * 448 / us / 1e3, B / us / 1e3))
+    ofz = ma._ops_f(dfa)
+    us = graph_time(lambda: backend.rnea_backward(dfa.program, ofz, dfa.ops_i, qa, qda, qdda, ga, True, True, 16, 0, True), launches=10)
+    print("rnea bwd    allegro B=%8d %9.2f us  input gradients only (the %d-op walk the API builds: every fixed joint folded)" % (B, us, dfa.program.n_ops))
 # BASELINE.json configs 2 and 3 as stated: iiwa7 FK + EE Jacobian at 65 536; Panda FK(EE) + RNEA on one GPU's shard of
 # the 2^20 batch (131 072 rows), the two calls captured back to back
 mi = load("iiwa7")
