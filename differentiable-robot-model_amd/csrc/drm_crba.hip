@@ -22,6 +22,7 @@ constexpr int CRBA_SHORT_OPS = 6; // segments of up to this many ops in a row ta
 // 256 n^2-byte tile instead allowed one block per CU for n = 16: 1 330 -> 697 us at 2^20 samples; this form: see profiles/.)
 // LDS: [ table ][ q : 64 (n|1) ][ segment map : dof -> (segment's first dof, its dof count, its block's LDS offset) ]
 //      shared, then per wavefront [ inertia slots : n_slots * 10 * 64 ][ block : 64 (cnt^2 | 1) ]
+template <bool NT>
 __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     crba_tree_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ H, uint32_t magic_q, uint32_t align) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -71,40 +72,47 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
             hout);
     }
     __syncthreads();
-    // assembly: element (r, c) of sample b is the block entry when r and c belong to the same segment, else 0
-    auto entry = [&](unsigned b, unsigned r, unsigned c) -> float {
+    // assembly: element j = (r, c) of a matrix is a block entry when r and c belong to the same segment, else 0 — where sample
+    // 0's value sits in LDS (-1: structural zero) and the per-sample stride of its block, worked out once per element
+    int *loff = lmap + 3 * n, *lstr = loff + nn;
+    for (int j = (int)threadIdx.x; j < nn; j += (int)blockDim.x) {
+        const int r = j / n, c = j - r * n;
         const int slo = lmap[r], scnt = lmap[n + r];
-        const unsigned cc = c - (unsigned)slo, rr = r - (unsigned)slo;
-        if (cc >= (unsigned)scnt) return 0.0f;
-        return smem[lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt) + rr * (unsigned)scnt + cc];
-    };
+        const unsigned cc = (unsigned)(c - slo);
+        loff[j] = cc < (unsigned)scnt ? lmap[2 * n + r] + (r - slo) * scnt + (int)cc : -1;
+        lstr[j] = pad_odd(scnt * scnt);
+    }
+    __syncthreads();
     float *g = H + tc.b0 * nn;
-    if (tc.full && !(n & 3) && (align & AL_TAU)) {
-        // one 16-byte store per thread and round, linear in the tile: thread i writes float4 i.  The (sample, row, column)
-        // of a float4 is kept incrementally (no integer divisions in the loop) and its row's segment is looked up once.
-        const unsigned per_row = (unsigned)n >> 2, per_sample = (unsigned)nn >> 2, total = WAVE * per_sample;
-        const unsigned row_magic = per_row > 1u ? 0xffffffffu / per_row + 1u : 0u; // j / per_row for j < 2^16 (per_row = 1: j)
-        unsigned b = threadIdx.x / per_sample, j = threadIdx.x - b * per_sample;
-        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
-            const unsigned r = per_row > 1u ? __umulhi(j, row_magic) : j, c = (j - r * per_row) * 4u;
-            const int slo = lmap[r], scnt = lmap[n + r];
-            const unsigned rr = r - (unsigned)slo, rbase = rr * (unsigned)scnt;
-            const float *src = smem + lmap[2 * n + r] + b * (unsigned)pad_odd(scnt * scnt);
+    if (tc.full && (align & AL_TAU)) {
+        // the tile's 64 matrices are one run of 64 n^2 floats, 16-byte aligned as a whole (a single matrix is not when n^2 is
+        // odd): 16 n^2 float4, thread i writes float4 i, i + threads, ...; the (sample, element) of its first float is kept
+        // incrementally, the other three follow with one wrap test each
+        const int total4 = 16 * nn, stride = 4 * (int)blockDim.x;
+        const int inc_b = stride / nn, inc_j = stride - inc_b * nn;
+        int b = (4 * (int)threadIdx.x) / nn, j = 4 * (int)threadIdx.x - b * nn;
+        for (int i = (int)threadIdx.x; i < total4; i += (int)blockDim.x) {
             float v[4];
 #pragma unroll
-            for (unsigned e = 0; e < 4u; ++e) {
-                const unsigned cc = c + e - (unsigned)slo;
-                v[e] = cc < (unsigned)scnt ? src[rbase + cc] : 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                const bool wrap = j + e >= nn;
+                const int jj = wrap ? j + e - nn : j + e, bb = wrap ? b + 1 : b;
+                const int o = loff[jj];
+                v[e] = o >= 0 ? smem[o + bb * lstr[jj]] : 0.0f;
             }
-            store16_wt(g + 4u * i, make_float4(v[0], v[1], v[2], v[3]));
-            j += blockDim.x;
-            while (j >= per_sample) { j -= per_sample; ++b; }
+            store16_wt<NT>(g + 4 * i, make_float4(v[0], v[1], v[2], v[3]));
+            b += inc_b; j += inc_j;
+            if (j >= nn) { j -= nn; ++b; }
         }
     } else {
-        const unsigned total = (unsigned)tc.rows * (unsigned)nn;
-        for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
-            const unsigned b = i / (unsigned)nn, j = i - b * (unsigned)nn, r = j / (unsigned)n;
-            g[i] = entry(b, r, j - r * (unsigned)n);
+        const int total = tc.rows * nn, stride = (int)blockDim.x;
+        const int inc_b = stride / nn, inc_j = stride - inc_b * nn;
+        int b = (int)threadIdx.x / nn, j = (int)threadIdx.x - b * nn;
+        for (int i = (int)threadIdx.x; i < total; i += stride) {
+            const int o = loff[j];
+            g[i] = o >= 0 ? smem[o + b * lstr[j]] : 0.0f;
+            b += inc_b; j += inc_j;
+            if (j >= nn) { j -= nn; ++b; }
         }
     }
 }
@@ -114,7 +122,7 @@ static size_t crba_short_plan(const drm_walk *w, TreeArgs &a) {
     a = tree_args(w, false);
     if (a.max_seg_ops > CRBA_SHORT_OPS) return 0;
     const int n = a.n;
-    const size_t shared = (size_t)table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n);
+    const size_t shared = (size_t)table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(3 * n + 2 * n * n);
     const size_t lds = sizeof(float) * layout_waves(a, shared, 0, a.n_slots * 10 * WAVE, [&](int sg) {
         const int c = a.seg_dof_cnt[sg];
         return round4(WAVE * pad_odd(c * c));
@@ -382,9 +390,15 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     const uint32_t align = al16(q, AL_Q) | al16(H, AL_TAU);
     TreeArgs fingers;
     if (const size_t lds = crba_short_plan(w, fingers)) {
-        rc = ensure_lds_tree(crba_tree_kernel, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(crba_tree_kernel, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, q, B, H, div_magic(n), align);
+        if (stream_past_llc(B * nn * (int64_t)sizeof(float))) { // beyond the Infinity Cache: sc1 nt stores
+            rc = ensure_lds_tree(crba_tree_kernel<true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(crba_tree_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, q, B, H, div_magic(n), align);
+        } else {
+            rc = ensure_lds_tree(crba_tree_kernel<false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(crba_tree_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * fingers.n_segments), lds, s, fingers, q, B, H, div_magic(n), align);
+        }
         return launched();
     }
     CrbaRowsPlan p;
