@@ -224,7 +224,7 @@ struct AbaPlan {
 };
 static int aba_plan(const drm_walk *w, AbaPlan &p) {
     // one wavefront per segment; all the segments through one wavefront when their save slots do not fit side by side
-    for (int single = 0; single < 2; ++single) {
+    for (int single = segments_worth_fanning_out(w) ? 0 : 1; single < 2; ++single) {
         p.a = tree_args(w, single != 0);
         const size_t shared = (size_t)table_lds_floats(p.a.n_ops) + 3 * (size_t)round4(WAVE * pad_odd(p.a.n));
         p.lds = sizeof(float) * layout_waves(p.a, shared, 0, p.a.n_slots * ABA_SLOT_FLOATS * WAVE, [](int) { return 0; });

@@ -44,6 +44,28 @@ struct TreeArgs { // by value in the kernel arguments
 
 // single = true: ignore the segments, one wavefront walks everything (what a launch falls back to when the private areas
 // of all the segments do not fit a CU's LDS side by side)
+// One wavefront per segment pays when the segments are of similar length (the fingers of a hand).  A long segment next to short
+// ones (a mobile manipulator: two wheels of one op each beside a torso + head + arm + gripper tree of twelve) leaves the short
+// segments' wavefronts idle while they hold registers and LDS: such walks run all their segments through ONE wavefront per tile
+// (twice the tiles in flight per CU for the same number of wavefronts).  Walks whose segments are all short keep the fan-out.
+// Used by the inverse- and forward-dynamics loop kernels (Fetch at 2^20: 262 -> 231 us, 715 -> 605 us); the mass-matrix and the
+// reverse-mode loop kernels are faster fanned out even then (one triangle / one set of records per segment: 662 vs 989 us,
+// 971 vs 1 106 us).
+static inline bool segments_worth_fanning_out(const drm_walk *w) {
+    if (w->n_segments < 2 || w->n_segments > DRM_MAX_SEGMENTS) return false;
+    int lo = 1 << 30, hi = 0;
+    for (int s = 0; s < w->n_segments; ++s) {
+        const int len = w->seg_begin[s + 1] - w->seg_begin[s];
+        lo = len < lo ? len : lo;
+        hi = len > hi ? len : hi;
+    }
+#ifdef DRM_ALWAYS_FAN_OUT
+    return true;
+#else
+    return hi <= 6 || 2 * lo >= hi;
+#endif
+}
+
 static inline TreeArgs tree_args(const drm_walk *w, bool single = false) {
     TreeArgs a;
     a.ops_f = w->ops_f; a.ops_i = w->ops_i;

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | grep -v Warn | tail -3
-python tools/probe_robots.py 1048576 crba 2>&1 | grep CRBA
+python tools/probe_robots.py 2>&1 | grep "n=" | grep "fetch \|trifinger"
