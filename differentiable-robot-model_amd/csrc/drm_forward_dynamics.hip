@@ -304,6 +304,86 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
 }
 
+// A HAND (DRM_WALK_FINGERS: K serial chains of L revolute ops off the root): H is block diagonal, one L x L block per finger, and
+// every finger is a short arm — so a finger takes the ARM kernel's three steps (bias torques by rnea_chain_trig with qdd = 0, its
+// block of H by crba_chain_trig on the same cos / sin, the L^T D L solve in registers) on its own wavefront: a block of K
+// wavefronts per 64-sample tile, per-lane accesses of the finger's L columns (16 bytes per sample and array at L = 4).
+// The loop form (forward_dynamics_tree_kernel) issues 1 613 VALU + 964 SALU per finger and tile.
+// LDS (static), per wavefront: [ table : L x 32 ][ parked body forces : L x 6 x 64 ]
+template <int L>
+__global__ void __launch_bounds__(WAVE * 4)
+    forward_dynamics_fingers_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                                    const float *__restrict__ f, int n, int flags, float *__restrict__ qdd, int vec) {
+    constexpr int C_FLOATS = L * DRM_OPF_STRIDE, P_FLOATS = L * 6 * WAVE; // (rnea_chain_trig parks every link's body force)
+    __shared__ __attribute__((aligned(16))) float smem[4 * (C_FLOATS + P_FLOATS)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + wave * (C_FLOATS + P_FLOATS);
+    float *park = lc + C_FLOATS + lane;
+    if (lane < (unsigned)(L * (DRM_OPF_STRIDE / 4)))
+        reinterpret_cast<float4 *>(lc)[lane] = reinterpret_cast<const float4 *>(ops_f + (size_t)wave * C_FLOATS)[lane];
+    const int64_t r0 = ((int64_t)blockIdx.x * WAVE + lane) * n + wave * L;
+    float qv[L], qdv[L], rhs[L], zero[L], nle[L];
+    auto load = [&](const float *src, float (&dst)[L]) {
+        if (L == 4 && vec) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + r0);
+            dst[0] = a.x; dst[1] = a.y; dst[2 % L] = a.z; dst[3 % L] = a.w;
+        } else {
+#pragma unroll
+            for (int d = 0; d < L; ++d) dst[d] = src[r0 + d];
+        }
+    };
+    load(q, qv); load(qd, qdv); load(f, rhs);
+#pragma unroll
+    for (int d = 0; d < L; ++d) zero[d] = 0.0f;
+    wave_lds_sync();
+    auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
+    float cs[L], sn[L];
+    chain_trig<L>(qv, cs, sn);
+    rnea_chain_trig<L, L>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, zero, nle,
+                          [&](int k, const Force &F) {
+#pragma unroll
+                              for (int i = 0; i < 3; ++i) { park[(k * 6 + i) * WAVE] = F.la[i][0]; park[(k * 6 + 3 + i) * WAVE] = F.la[i][1]; }
+                          },
+                          [&](int k, Force &F) {
+#pragma unroll
+                              for (int i = 0; i < 3; ++i) F.la[i] = f2_make(park[(k * 6 + i) * WAVE], park[(k * 6 + 3 + i) * WAVE]);
+                          });
+    float Ht[L * (L + 1) / 2];
+    crba_chain_trig<L, L>(row, cs, sn, [&](int i, int j, float v) {
+        if (i >= j) Ht[tri_index(i, j)] = v;
+    });
+#pragma unroll
+    for (int d = 0; d < L; ++d) rhs[d] -= nle[d];
+    ltdl_solve_unrolled<L>(Ht, rhs);
+    if (L == 4 && vec) *reinterpret_cast<float4 *>(qdd + r0) = make_float4(rhs[0], rhs[1], rhs[2 % L], rhs[3 % L]);
+    else {
+#pragma unroll
+        for (int d = 0; d < L; ++d) qdd[r0 + d] = rhs[d];
+    }
+}
+
+// rows covered (full tiles), 0 = the call does not qualify
+static int64_t launch_forward_dynamics_fingers(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B, int flags,
+                                               float *qdd, hipStream_t s) {
+#ifdef DRM_NO_FINGERS_KERNEL
+    return 0;
+#else
+    if (!(w->shape & DRM_WALK_FINGERS) || B < WAVE || B / WAVE >= 0x7fffffffLL || (((uintptr_t)w->ops_f) & 15u) != 0) return 0;
+    const int K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape), n = w->n_dofs;
+    if (K * L != w->n_ops || n != w->n_ops || K < 2 || K > 4 || L < 2 || L > 4) return 0;
+    const int n_tiles = (int)(B / WAVE);
+    const int vec = (n % 4 == 0) && ((((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd) & 15u) == 0);
+#define X(l)                                                                                                                     \
+    if (L == l)                                                                                                                  \
+        hipLaunchKernelGGL((forward_dynamics_fingers_kernel<l>), dim3((unsigned)n_tiles), dim3(WAVE * K), 0, s, w->ops_f, q, qd, f, n, \
+                           flags, qdd, vec);
+    X(2) X(3) X(4)
+#undef X
+    return (int64_t)n_tiles * WAVE;
+#endif
+}
+
 } // namespace drm
 
 using namespace drm;
@@ -334,6 +414,16 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs;
+    {   // a hand (fingers off the root): full tiles through the per-finger arm form
+        const int64_t done = launch_forward_dynamics_fingers(w, q, qd, f, B, (int)flags, qdd, (hipStream_t)stream);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            drm_walk generic = *w;
+            generic.shape &= ~DRM_WALK_FINGERS;
+            return drm_forward_dynamics(&generic, q + done * n, qd + done * n, f + done * n, B - done, flags, qdd + done * n, scratch, stream);
+        }
+    }
 #ifndef DRM_NO_ARM_KERNEL
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
