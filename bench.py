@@ -18,7 +18,9 @@
 Timing: W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides, max
 over ranks.  For the metric config the K launches are captured once into a hipGraph (one launch per step, same
 stream, no fusion / skipping) and replayed, so the host does not throttle a ~4 us kernel; the captured graph is
-replayed twice untimed first (uploads the executable graph, lets the clocks settle), `--no-graph` launches eagerly.
+replayed untimed first — twice to upload the executable graph, then for ~50 ms so that the clocks have left their idle
+state before a timed region of ~80 us (a cold box measured 14.6 us per step at --steps 20 without it, 5.1 us with) —
+and `--no-graph` launches eagerly.
 HIP events on the launch stream around the timed region give the average duration of a launch for the roofline
 object.
 
@@ -247,9 +249,17 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(K):
                     launch()
-            for _ in range(warm_replays):   # untimed: uploads the executable graph, lets the clocks settle
+            for _ in range(warm_replays):   # untimed: uploads the executable graph
                 graph.replay()
             torch.cuda.synchronize()
+            # untimed: ~50 ms of the same replays so that the clocks have left their idle state before a timed region that is
+            # ~80 us long at the driver's --steps 20 (measured on a box that had idled through the imports: 14.6 us per step
+            # without this, 5.1 us with the GPU warm).  Local to the rank: the graph holds no collective.
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.05:
+                for _ in range(10):
+                    graph.replay()
+                torch.cuda.synchronize()
         except Exception as err:  # pragma: no cover - depends on the runtime
             print("hipGraph capture failed (%s); launching eagerly" % err, file=sys.stderr)
             graph = None
