@@ -33,7 +33,7 @@ done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
-for r in panda iiwa7_allegro; do
+for r in panda iiwa7_allegro allegro_left; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench4.py $r 262144 > $OUT/prof_sq4_$r.log 2>&1
 done
 for r in panda_no_gripper panda allegro_left iiwa7_allegro; do
