@@ -1,15 +1,16 @@
-// drm_arm_hand.hip — K3 (inverse dynamics) of robots shaped like "an arm that carries a hand" (round 3): P serial prefix
-// ops and K serial sub-chains of L ops that all hang off the last prefix op (DRM_WALK_ARM_HAND, include/drm_hip.h).
-// Franka Panda with its gripper (P, K, L) = (9, 2, 1), Kinova Jaco (7, 3, 2), KUKA iiwa7 + Allegro hand (8, 4, 4).
+// drm_arm_hand.hip — the dynamics kernels of robots shaped like "an arm that carries a hand" (round 3): P serial prefix ops and
+// K serial sub-chains of L ops that all hang off the last prefix op (DRM_WALK_ARM_HAND, include/drm_hip.h) — K3 inverse
+// dynamics, K8 forward dynamics, K6 the mass matrix, K7 the reverse mode of K3, in that order below.
+// Franka Panda with its gripper (P, K, L) = (7, 2, 1), Kinova Jaco (6, 3, 2), KUKA iiwa7 + Allegro hand (7, 4, 4) once the host has
+// folded the fixed joints away; compiled for every P = 5 .. 9 and L = 1 .. 4 (this file once per L, see DRM_ARM_HAND_SHAPES).
 //
-// These robots are ONE dynamics segment (everything hangs off the moving arm), so the loop-structured kernel
-// (drm_rnea.hip rnea_records_kernel) walks a whole 64-sample tile with one wavefront, parks every link's body force
-// (LDS or HBM scratch) and decodes two control words per op: 183 / 256 / 437 us at 2^20 samples.  Here the walk is
-// straight-line code for the shape (drm_sample.hpp rnea_arm_hand): the prefix is the arm kernels' chain walk, every
-// sub-chain runs forward and backward while the palm's motion is in registers, so only the P - 1 prefix forces are parked
-// (LDS, 1.5 KB per link and wave) and a CU holds 9-11 wavefronts.  Which DoF column an op drives comes from the walk's
-// W0 words (scalar loads): fixed ops and arbitrary DoF numbering need no template parameters beyond (P, L); K is a
-// run-time loop count.  Full 64-row tiles only; a ragged tail goes through the loop-structured kernel.
+// These robots are ONE dynamics segment (everything hangs off the moving arm), so the loop-structured kernels walk a whole
+// 64-sample tile with one wavefront, park per-link records (LDS or HBM scratch) and decode two control words per op.  Here the
+// walks are straight-line code for the shape (drm_sample.hpp rnea_arm_hand / rnea_backward_arm_hand, drm_tree.hpp aba_arm_hand /
+// crba_arm_hand_*): the prefix is the arm kernels' chain walk, every sub-chain is swept while the palm's state is live, so what
+// is parked is a few floats per PREFIX op (or nothing).  Which DoF column an op drives comes from the walk's W0 words (scalar
+// loads): fixed ops, sliding joints and arbitrary DoF numbering need no template parameters beyond (P, L); K is a run-time
+// count.  Full 64-row tiles only; a ragged tail goes through the loop-structured kernels.
 // Build flags as drm_arm_dynamics.hip (kernel-argument preload, no SLP vectoriser).
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
