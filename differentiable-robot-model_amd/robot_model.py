@@ -741,6 +741,32 @@ class DifferentiableRobotModel(torch.nn.Module):
         ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *pieces)
         return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
 
+    def _chain_walk(self, idx: int) -> _DeviceWalk:
+        """The root -> link chain walk of the kinematics calls that do NOT run under autograd.  Without learnable parameters the
+        fixed links between the chain's moving joints are stepped over (their transforms composed into the next link's row of
+        the folded table, flatten.fold_link_table; a fixed TARGET keeps its op, with the fixed links right before it composed into
+        its row): the same pose and Jacobian from fewer ops (Panda with gripper: 10 -> 8 to a finger or to the tool frame, a
+        capacity-8 walk; TriFinger fingertip: 6 -> 4).  With learnable parameters, and under autograd, the plain walk."""
+        if idx == 0:
+            return self._get_walk(("chain", idx), targets=[])
+        if self._learnable:
+            return self._get_walk(("chain", idx), targets=[idx])
+        key = self._fold_key()
+        fold = self._fold_masks[key]
+        chain = self._spec.chain_to(idx)
+        if fold[idx] and len(chain) > 1 and fold[chain[-2]]:
+            # the target sits behind several fixed joints in a row (flange -> hand -> tool frame): it alone keeps an op, whose row
+            # carries the others' transforms — a fold mask of its own, the target un-folded
+            tkey = ("target", idx) + tuple(key)
+            if tkey not in self._fold_masks:
+                mask = fold.copy()
+                mask[idx] = False
+                self._fold_masks[tkey] = mask
+            key, fold = tkey, self._fold_masks[tkey]
+        if not any(fold[c] and not all(fold[d] for d in chain[n + 1:]) for n, c in enumerate(chain)):
+            return self._get_walk(("chain", idx), targets=[idx])      # nothing to step over
+        return self._get_walk(("chain", idx, "folded", key), targets=[idx], folded=True, fold_key=key)
+
     def _fanout_chains(self, targets, merged: _DeviceWalk):
         """Per-target chain walks for the fan-out FK kernel, or None when the merged walk is the better plan: 2..4
         targets whose chains overlap so little that walking them separately costs < 1.25x the ops of the merged
@@ -910,7 +936,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         if idx != 0 and not (torch.is_grad_enabled() and (q.requires_grad or self._learnable)):
             # the common call: one kernel, outputs allocated in their final shape (no slicing ops on the way out)
             self._require_device()
-            dw = self._get_walk(("fk", (idx,)), targets=[idx])
+            dw = self._chain_walk(idx)
             return backend.fk(dw.program, self._ops_f(dw), dw.ops_i, q, 1, self._n_dofs, squeeze=True)
         pos, quat = self._fk_targets(q, [idx])
         return pos[:, 0], quat[:, 0]
@@ -936,12 +962,15 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.shape[1] == self._n_dofs
         self._require_device()
         idx = self._name_to_idx_map[link_name]
-        dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
-        ops_f = self._ops_f(dw)
-        if idx != 0 and torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
-            self._differentiable(dw)
-            return _FkJacobian.apply(q, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
-        return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+        if idx != 0 and torch.is_grad_enabled() and (q.requires_grad or self._learnable):
+            dw = self._get_walk(("chain", idx), targets=[idx])
+            ops_f = self._ops_f(dw)
+            if q.requires_grad or ops_f.requires_grad:
+                self._differentiable(dw)
+                return _FkJacobian.apply(q, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
+            return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+        dw = self._chain_walk(idx)
+        return backend.fk_jacobian(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
 
     def plan_fk_and_jacobian(self, q: torch.Tensor, link_name: str, want_pose: bool = True
                              ) -> "backend.FkJacobianPlan":
@@ -950,7 +979,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.ndim == 2 and q.shape[1] == self._n_dofs
         assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
         idx = self._name_to_idx_map[link_name]
-        dw = self._get_walk(("chain", idx), targets=[idx] if idx != 0 else [])
+        dw = self._chain_walk(idx)
         return backend.FkJacobianPlan(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs, want_pose)
 
     def plan_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: Optional[torch.Tensor],
