@@ -777,6 +777,11 @@ class DifferentiableRobotModel(torch.nn.Module):
             if 2 <= len(targets) <= 4:
                 lengths = [len(self._spec.chain_to(t)) for t in targets]
                 if sum(lengths) <= 1.25 * merged.program.n_ops and merged.program.n_ops > 8:
+                    if not self._learnable:     # the folded chain walks (fixed links stepped over), when they share a capacity
+                        walks = [self._chain_walk(t) for t in targets]
+                        if len({w.program.capacity for w in walks}) == 1:
+                            self._fanout_plans[key] = walks
+                            return walks
                     cap = max(build_walk(self._spec, targets=[t]).capacity for t in targets)
                     plan = []
                     for t in targets:
@@ -1156,9 +1161,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable_links = None
         for dw in self._walks.values():
             dw.static_ops_f = None
-        for plan in self._fanout_plans.values():
-            for dw in plan or []:
-                dw.static_ops_f = None
+        self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
 
     def _learnable_module(self, link_name: str, parameter_name: str):
         parent_object = self._get_parent_object_of_param(link_name, parameter_name)
