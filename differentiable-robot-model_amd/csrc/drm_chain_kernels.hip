@@ -259,6 +259,71 @@ __global__ void __launch_bounds__(WAVE * 4)
     for (unsigned i = tid; i < (unsigned)(WAVE * T); i += nth) store16_wt(gr + i, reinterpret_cast<const float4 *>(lr)[i]);
 }
 
+// The same fan-out with TWO SAMPLES PER LANE (rows l and l + 64 of a 128-row tile): every op of the pose chain is a full packed
+// instruction (drm_sample.hpp fk_chain2_trig, the chain of the fused FK + RNEA kernel), so a block of T wavefronts covers 128
+// samples for ~1.1x the instructions the one-sample form spends on 64.  Revolute and fixed ops only (DRM_WALK_NO_PRISMATIC);
+// a fixed op is a joint at angle 0.  Launches of at least DRM_FAN2_MIN_TILES pairs of tiles (not BASELINE configuration 4's 65 536:
+// see the measurement at the macro).
+// LDS (static): four chain tables, then the block's [128, 3T] position and [128, 4T] quaternion tiles
+constexpr int FAN2_TILE = 2 * WAVE;
+template <int CAP, int USED>
+__global__ void __launch_bounds__(WAVE * 4)
+    fk_fan_chain2_kernel(FanChains tab, int T, int n, const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat) {
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE;
+    __shared__ __attribute__((aligned(16))) float smem[4 * C_FLOATS + FAN2_TILE * 12 + FAN2_TILE * 16];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t b0 = (int64_t)blockIdx.x * FAN2_TILE;
+    float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + FAN2_TILE * 12;
+    const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
+    const int32_t *ops_i = wave == 0 ? tab.ops_i[0] : wave == 1 ? tab.ops_i[1] : wave == 2 ? tab.ops_i[2] : tab.ops_i[3];
+    const int n_ops = wave == 0 ? tab.n_ops[0] : wave == 1 ? tab.n_ops[1] : wave == 2 ? tab.n_ops[2] : tab.n_ops[3];
+    const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
+    int dof[CAP];
+    unsigned pris;
+    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
+    chain_stage_table<CAP>(ops_f, lc, lane);
+    // this lane's two rows, one dword load per op and row at a wave-uniform column (ops that do not move: column 0, value dropped)
+    f2 qv[USED];
+    {
+        const char *qa = reinterpret_cast<const char *>(q + b0 * n), *qb = reinterpret_cast<const char *>(q + (b0 + WAVE) * n);
+        const unsigned row_off = lane * (unsigned)n * 4u;
+#pragma unroll
+        for (int k = 0; k < USED; ++k) {
+            const int c = (dof[k] < 0 ? 0 : dof[k]) * 4;
+            const float a = *reinterpret_cast<const float *>(qa + c + row_off), b = *reinterpret_cast<const float *>(qb + c + row_off);
+            qv[k] = dof[k] < 0 ? f2_bcast(0.0f) : f2_make(a, b);
+        }
+    }
+    wave_lds_sync();
+    f2 cs[USED], sn[USED];
+    chain_trig2<USED>(qv, cs, sn);
+    Pose2 ee;
+    fk_chain2_trig<USED, USED>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, cs, sn, ee);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned r = lane + (unsigned)h * WAVE;
+        float *p = lp + (r * T + wave) * 3;
+        p[0] = ee.p[0][h]; p[1] = ee.p[1][h]; p[2] = ee.p[2][h];
+        float R[9], qt[4];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = ee.R[i][h];
+        unpermute(perm, R);
+        quat_xyzw(R, qt);
+        reinterpret_cast<float4 *>(lr)[r * T + wave] = make_float4(qt[0], qt[1], qt[2], qt[3]);
+    }
+    __syncthreads();
+    const unsigned tid = threadIdx.x, nth = WAVE * (unsigned)T;
+    float4 *gp = reinterpret_cast<float4 *>(pos + b0 * 3 * T), *gr = reinterpret_cast<float4 *>(quat + b0 * 4 * T);
+    for (unsigned i = tid; i < (unsigned)(FAN2_TILE * 3 * T / 4); i += nth) store16_wt(gp + i, reinterpret_cast<const float4 *>(lp)[i]);
+    for (unsigned i = tid; i < (unsigned)(FAN2_TILE * T); i += nth) store16_wt(gr + i, reinterpret_cast<const float4 *>(lr)[i]);
+}
+// measured (Allegro, four fingertips; us per launch, one / two samples per lane): 65 536: 6.0 / 6.3, 2^18: 15.5 / 13.8, 2^20: 54.8 / 47.8
+// — half as many wavefronts hide less latency until there are enough of them: pairs of tiles from 2^18 samples on
+#ifndef DRM_FAN2_MIN_TILES
+#define DRM_FAN2_MIN_TILES 2048
+#endif
+
 // ---- launchers (called by drm_fk / drm_fk_jacobian / drm_fk_fanout); return the rows they covered (full tiles), 0 = not taken
 static bool chain_ok(const drm_walk *w) {
     return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->capacity == 4 || w->capacity == 8 || w->capacity == 12 || w->capacity == 16) &&
@@ -329,21 +394,43 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
     if (T < 2 || T > 4 || al != (AL_Q | AL_POS | AL_QUAT) || B < WAVE || B / WAVE >= 0x7fffffffLL) return 0;
     FanChains tab;
     int longest = 0;
+    const int cap = chains[0].capacity;
+    bool revolute = true;
     for (int t = 0; t < 4; ++t) {
         const drm_walk *w = chains + (t < T ? t : 0);
-        if (!chain_ok(w) || w->capacity != 8) return 0;
+        if (!chain_ok(w) || (cap != 4 && cap != 8) || w->capacity != cap) return 0;
         tab.ops_f[t] = w->ops_f; tab.ops_i[t] = w->ops_i; tab.n_ops[t] = w->n_ops; tab.perm[t] = w->target_perm;
         if (w->n_ops > longest) longest = w->n_ops;
+        revolute = revolute && (w->shape & DRM_WALK_NO_PRISMATIC);
     }
-    const int n_tiles = (int)(B / WAVE);
+    const int n = (int)chains[0].n_dofs;
+    int n_tiles = (int)(B / WAVE);
+    int64_t done = 0;
     // the instantiation that walks exactly the longest chain's ops (shorter chains of the same launch walk identity padding)
-#define FAN(U) hipLaunchKernelGGL((fk_fan_chain_kernel<8, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, (int)chains[0].n_dofs, q, pos, quat)
-    if (longest <= 5) FAN(5);
-    else if (longest == 6) FAN(6);
-    else if (longest == 7) FAN(7);
-    else FAN(8);
+#ifndef DRM_NO_FAN2_KERNEL
+    if (revolute && n_tiles / 2 >= DRM_FAN2_MIN_TILES) { // pairs of tiles: two samples per lane
+        const int n2 = n_tiles / 2;
+#define FAN2(C, U) hipLaunchKernelGGL((fk_fan_chain2_kernel<C, U>), dim3((unsigned)n2), dim3(WAVE * T), 0, s, tab, T, n, q, pos, quat)
+        if (cap == 4) FAN2(4, 4);
+        else if (longest <= 5) FAN2(8, 5);
+        else if (longest == 6) FAN2(8, 6);
+        else if (longest == 7) FAN2(8, 7);
+        else FAN2(8, 8);
+#undef FAN2
+        done = (int64_t)n2 * FAN2_TILE;
+        n_tiles -= 2 * n2;
+        if (n_tiles == 0) return done;
+        q += done * n; pos += done * 3 * T; quat += done * 4 * T;
+    }
+#endif
+#define FAN(C, U) hipLaunchKernelGGL((fk_fan_chain_kernel<C, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, n, q, pos, quat)
+    if (cap == 4) FAN(4, 4);
+    else if (longest <= 5) FAN(8, 5);
+    else if (longest == 6) FAN(8, 6);
+    else if (longest == 7) FAN(8, 7);
+    else FAN(8, 8);
 #undef FAN
-    return (int64_t)n_tiles * WAVE;
+    return done + (int64_t)n_tiles * WAVE;
 #endif
 }
 

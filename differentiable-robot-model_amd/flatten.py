@@ -63,6 +63,7 @@ SHAPE_SERIAL_CHAIN = 2               # DRM_WALK_SERIAL_CHAIN
 SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top byte, DRM_WALK_AH_PACK)
 SHAPE_TARGETS_ORDERED = 8            # DRM_WALK_TARGETS_ORDERED: output slots 0, 1, 2, ... in walk order
 SHAPE_FINGERS = 16                   # DRM_WALK_FINGERS (+ K, L in the top byte)
+SHAPE_NO_PRISMATIC = 32              # DRM_WALK_NO_PRISMATIC: no op of the walk slides
 
 
 def fingers_shape(ops, parent_op, n_ops: int, n_dofs: int, prismatic) -> int:
@@ -631,7 +632,7 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
-                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0)
+                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0) | (0 if any(prismatic) else SHAPE_NO_PRISMATIC)
                        | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0)
                        | (fingers_shape(ops, parent_op, n_ops, n, prismatic) if whole_tree else 0),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)

@@ -274,6 +274,27 @@ def test_allegro_fingertips_full_batch():
     assert len(still) == 3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,tips", [("allegro_left", ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]),
+                                        ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"])])
+def test_fanout_fk_two_samples_per_lane(robot, tips):
+    """From 2^18 samples on the fan-out FK walks pairs of tiles with two samples per lane (fk_fan_chain2_kernel), an odd tile
+    with one, a ragged tail through the loop kernel: rows from every part against the fp64 oracle, and against the same rows
+    launched as a small batch (the one-sample kernels; same poses to rounding)."""
+    m = load_model(robot, "cuda")
+    idx = [m._name_to_idx_map[t] for t in tips]
+    B = (1 << 18) + 64 * 3 + 5
+    q, _, _ = sample_states(m, B, seed=44)
+    pos, quat = m._fk_targets(dev(q), idx)
+    rows = np.r_[0:130, 70000:70130, (1 << 18) - 70:B]
+    rp, rq = Oracle(m._spec).fk(q[rows].astype(np.float64), idx, np.float64)
+    assert max_err(host(pos)[rows], rp) <= TOL_POS["atol"]
+    ok, _ = quat_close(host(quat)[rows], rq, TOL_QUAT["atol"])
+    assert ok
+    ps, qs = m._fk_targets(dev(np.ascontiguousarray(q[rows])), idx)
+    assert max_err(host(pos)[rows], host(ps)) <= 1e-6 and max_err(host(quat)[rows], host(qs)) <= 1e-6
+
+
 def test_update_kinematic_state_exposes_body_pose_and_velocity():
     """robot_model.py:139-195: after update_kinematic_state every body carries its world pose and its body-frame
     spatial velocity; here they are evaluated lazily from the recorded (q, qd)."""
