@@ -120,6 +120,48 @@ __global__ void __launch_bounds__(WAVE)
         });
 }
 
+// Many targets FANNED OUT (DRM_WALK_FK_FAN: the host found a hub — the root of a hand, a palm — behind which the walk splits
+// into sub-trees, flatten.fk_fan_partition): a block of K <= 4 wavefronts per tile, each walking the ops [0, prefix_end) every
+// sub-tree hangs off and then its own run [seg_begin[j], seg_begin[j+1]), writing its targets' columns of the [64, 3T] / [64, 4T]
+// tiles in LDS (28 T bytes per sample: 50 KB at 28 links — two blocks of four wavefronts per CU); the block stores the tiles as
+// linear 16-byte runs.  Allegro hand, all 20 links, 2^20 samples: 176 us against 285 us grouped.  (Letting every wavefront
+// flush groups of its own slots instead — four writers of short runs per sample row — was slower than the single-wavefront
+// grouped form: 397-513 us.)  The wavefronts share the save slots: they all write the same poses in the shared part, and the
+// host only fans out when no two runs write the same slot.
+// LDS: [ table ][ q : 64 (n|1) ][ slots : n_slots * 12 * 64 ][ pos : 64 (3T|1) ][ quat : 64 (4T|1) ]
+template <bool NT>
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    fk_tree_fan_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, int T, float *__restrict__ pos, float *__restrict__ quat,
+                       uint32_t magic_q, uint32_t magic_p, uint32_t magic_r, uint32_t align) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileCtx tc = tile_begin(B);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n), Sp = pad_odd(3 * T), Sr = pad_odd(4 * T);
+    float *lq = smem + table_lds_floats(a.n_ops);
+    float *ls = lq + round4(WAVE * Sq);
+    float *lp = ls + a.n_slots * 12 * WAVE;
+    float *lr = lp + round4(WAVE * Sp);
+    const TableLds tab = stage_tree_table(a, smem);
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
+    __syncthreads();
+    const bool live = (int)lane < tc.rows;
+    const float *qrow = lq + lane * Sq;
+    float *prow = lp + lane * Sp, *rrow = lr + lane * Sr;
+    const int P = a.prefix_end, first = a.seg_begin[wave], last = a.seg_begin[wave + 1];
+    fk_tree_walk_ranges(
+        P, first, last, tab, [&](int k) { return tab.row(k); }, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
+        [&](int s, const PoseP &Q) { lds_put_pose(ls, s, lane, Q); }, [&](int s, PoseP &Q) { lds_get_pose(ls, s, lane, Q); },
+        [&](int k, int t, const float *p, const float *qt) {
+            if (k < P && wave != 0) return; // the shared part's targets are wavefront 0's
+            prow[t * 3 + 0] = p[0]; prow[t * 3 + 1] = p[1]; prow[t * 3 + 2] = p[2];
+            rrow[t * 4 + 0] = qt[0]; rrow[t * 4 + 1] = qt[1]; rrow[t * 4 + 2] = qt[2]; rrow[t * 4 + 3] = qt[3];
+        });
+    __syncthreads();
+    block_tile_store<NT>(pos + tc.b0 * 3 * T, tc.rows, 3 * T, magic_p, lp, tc.full && (align & AL_POS));
+    block_tile_store<NT>(quat + tc.b0 * 4 * T, tc.rows, 4 * T, magic_r, lr, tc.full && (align & AL_QUAT));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fan-out FK: T <= 4 targets whose root->target chains share (almost) nothing — the fingertips of a hand that hang
 // off a common palm (Allegro, TriFinger).  The merged walk above makes ONE lane compute all T chains of a sample
@@ -259,6 +301,30 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
     a.n_segments = 1; a.prefix_end = 0;
 #ifndef DRM_NO_FK_GROUPS
     if ((w->shape & DRM_WALK_TARGETS_ORDERED) && T > FK_GROUP) {
+        if ((w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2 && w->n_segments <= DRM_MAX_SEGMENTS && segments_ok(w)) {
+            // fanned out over the sub-trees behind the hub, the whole tile staged — when two such blocks fit a CU
+            const size_t lds_fan = sizeof(float) * (size_t)(table_lds_floats(w->n_ops) + round4(WAVE * pad_odd(n)) + w->n_slots * 12 * WAVE +
+                                                            round4(WAVE * pad_odd(3 * T)) + round4(WAVE * pad_odd(4 * T)));
+            if (lds_fan <= (size_t)80 * 1024) {
+                const TreeArgs af = tree_args(w, false);
+                const int64_t tiles = (B + WAVE - 1) / WAVE;
+                if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+                const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+                hipStream_t s = (hipStream_t)stream;
+                if (stream_past_llc(B * 28 * T)) {
+                    rc = ensure_lds_tree(fk_tree_fan_kernel<true>, lds_fan);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(fk_tree_fan_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * af.n_segments), lds_fan, s, af, q, B, T, pos,
+                                       quat, div_magic(n), div_magic(3 * T), div_magic(4 * T), align);
+                } else {
+                    rc = ensure_lds_tree(fk_tree_fan_kernel<false>, lds_fan);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(fk_tree_fan_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * af.n_segments), lds_fan, s, af, q, B, T, pos,
+                                       quat, div_magic(n), div_magic(3 * T), div_magic(4 * T), align);
+                }
+                return launched();
+            }
+        }
         // many targets in walk order (all links of a robot): outputs leave a group of eight slots at a time
         const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + round4(WAVE * FK_GP) +
                                                     round4(WAVE * FK_GR) + w->n_slots * 12 * WAVE);

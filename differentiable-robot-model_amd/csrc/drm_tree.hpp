@@ -97,6 +97,37 @@ DRM_HD void fk_tree_walk(int n_ops, CTL ctl, ROW row, QF qf, SAVE slot_save, LOA
     }
 }
 
+// The same walk over the ops [0, P) followed by [first, last) (P <= first): a wavefront of the fanned-out many-target kernel walks
+// the part every sub-tree hangs off and then its own sub-trees.  emit(k, t, p, q) also gets the op.
+template <class CTL, class ROW, class QF, class SAVE, class LOAD, class EMIT>
+DRM_HD void fk_tree_walk_ranges(int P, int first, int last, CTL ctl, ROW row, QF qf, SAVE slot_save, LOAD slot_load, EMIT emit) {
+    PoseP cur;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { cur.A[c] = f2_make(c == 0, c == 1); cur.B[c] = f2_make(c == 2, 0.0f); }
+    const int total = P + (last - first);
+#pragma unroll 1
+    for (int i = 0; i < total; ++i) {
+        const int k = i < P ? i : first + (i - P);
+        int w0, w1;
+        ctl_words(ctl, k, w0, w1);
+        const OpCtl ct = decode_ctl(w0, w1);
+        const OpPairs o = load_pairs(row(k));
+        const float q = ct.dof >= 0 ? qf(ct.dof) : 0.0f;
+        if (ct.src >= 0) slot_load(ct.src, cur);
+        pose_step(o, ct, q, ct.src == DRM_SRC_ROOT, cur);
+        if (ct.save >= 0) slot_save(ct.save, cur);
+        if (ct.out >= 0) {
+            Pose Q;
+            pose_from_pairs(cur, Q);
+            Rot9 R;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) R.v[j] = Q.R[j];
+            const Quat4 qt = target_quaternion(R, ct.perm);
+            emit(k, ct.out, Q.p, qt.v);
+        }
+    }
+}
+
 // (A hand-pipelined form of this loop — control words two ops ahead, constants and joint value one op ahead — and a
 // straight-line form for chains of up to 8 ops with paired sin / cos both measured SLOWER than the plain loop on the
 // Allegro's four fingertips at 65 536 samples: 7.3 / 6.8 against 6.5 us.)

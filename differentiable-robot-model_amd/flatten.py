@@ -64,6 +64,63 @@ SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top b
 SHAPE_TARGETS_ORDERED = 8            # DRM_WALK_TARGETS_ORDERED: output slots 0, 1, 2, ... in walk order
 SHAPE_FINGERS = 16                   # DRM_WALK_FINGERS (+ K, L in the top byte)
 SHAPE_NO_PRISMATIC = 32              # DRM_WALK_NO_PRISMATIC: no op of the walk slides
+SHAPE_FK_FAN = 64                    # DRM_WALK_FK_FAN: a many-target FK walk split behind a hub (prefix_end / seg_begin)
+FK_FAN_WAVES = 4                     # wavefronts a fanned-out many-target FK block has at most
+
+
+def fk_fan_partition(ops, parent_op, n_ops: int):
+    """Where a many-target FK walk splits: (P, [begin_0, .., begin_K = n_ops]) such that the ops [0, P) are what every later op
+    hangs off — they end at a HUB (the root itself: P = 0; a palm; a torso) whose sub-tree reaches to the end of the walk — and
+    the hub's children's sub-trees, consecutive ones packed into K <= FK_FAN_WAVES runs, are [begin_j, begin_j+1).  Every run but
+    the first starts at an op that reads its parent's pose from a save slot or the root (a later child of the hub), so a
+    wavefront can walk [0, P) and then its run without hearing from the others.  None when no hub makes the longest wavefront
+    (P + its run) at least 1.3x shorter than the walk, when the repeats of the shared part would more than double the block's
+    work, or when two runs would write the same save slot."""
+    if n_ops < 8:
+        return None
+    end = list(range(n_ops))                      # last op of every op's sub-tree (depth-first order: a contiguous range)
+    for k in range(n_ops - 1, -1, -1):
+        if parent_op[k] >= 0:
+            end[parent_op[k]] = max(end[parent_op[k]], end[k])
+    kids = {}
+    for k in range(n_ops):
+        kids.setdefault(parent_op[k], []).append(k)
+    best = None
+    for hub, ch in kids.items():
+        if len(ch) < 2 or (hub >= 0 and end[hub] != n_ops - 1):
+            continue
+        P = hub + 1 if hub >= 0 else 0
+        if ch[0] != P or any(ops[c][OPI_SRC] == SRC_PREV for c in ch[1:]):
+            continue
+        sizes = [end[c] - c + 1 for c in ch]
+        limit = max(sizes)
+        while True:
+            begins, acc = [ch[0]], 0
+            for c, sz in zip(ch, sizes):
+                if acc and acc + sz > limit:
+                    begins.append(c)
+                    acc = 0
+                acc += sz
+            if len(begins) <= FK_FAN_WAVES:
+                break
+            limit += 1
+        if len(begins) < 2:
+            continue
+        begins.append(n_ops)
+        # the wavefronts share the save slots: a slot written inside one run must not be one another run (or the shared part)
+        # writes too — the walk reuses slots once a sub-tree is done, which is only safe in sequence
+        saves = [set(ops[k][OPI_SAVE] for k in range(a, b) if ops[k][OPI_SAVE] >= 0) for a, b in zip([0] + begins[:-1], [P] + begins[1:])]
+        if any(saves[i] & saves[j] for i in range(len(saves)) for j in range(i + 1, len(saves))):
+            continue
+        # every wavefront repeats the shared part: not when that more than doubles the work of the block
+        if len(begins[:-1]) * P + (n_ops - P) > 2 * n_ops:
+            continue
+        cost = P + max(b - a for a, b in zip(begins, begins[1:]))
+        if best is None or cost < best[0]:
+            best = (cost, P, begins)
+    if best is None or best[0] * 1.3 > n_ops:
+        return None
+    return best[1], best[2]
 
 
 def fingers_shape(ops, parent_op, n_ops: int, n_dofs: int, prismatic) -> int:
@@ -627,12 +684,19 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
     # its outputs a group of slots at a time)
     ordered = [row[OPI_OUT] for row in ops if row[OPI_OUT] >= 0] == list(range(len(tlist)))
     prefix_end, seg_begin, seg_dof = _segments(ops, parent_op, n_ops, n) if whole_tree else (0, [0, n_ops], [(0, n)])
+    fk_fan = 0
+    if not whole_tree and ordered and len(tlist) > 8 and unique:
+        part = fk_fan_partition(ops, parent_op, n_ops)
+        if part is not None:
+            prefix_end, seg_begin = part
+            seg_dof = [(0, 0)] * (len(seg_begin) - 1)
+            fk_fan = SHAPE_FK_FAN
     is_leaf = [not (ops_i[k, OPI_FLAGS] & FLAG_CHILD_IS_NEXT) for k in range(n_ops)]
     seg_leaf_begin = [int(sum(is_leaf[:b])) for b in seg_begin]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
-                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0) | (0 if any(prismatic) else SHAPE_NO_PRISMATIC)
+                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0) | (0 if any(prismatic) else SHAPE_NO_PRISMATIC) | fk_fan
                        | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0)
                        | (fingers_shape(ops, parent_op, n_ops, n, prismatic) if whole_tree else 0),
                        seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)

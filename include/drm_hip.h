@@ -125,6 +125,9 @@ extern "C" {
                               (the fingers of a hand once the fixed joints are folded: Allegro 4 x 4, TriFinger 3 x 3); K and L in
                               the top byte as for DRM_WALK_ARM_HAND (DRM_WALK_AH_K / DRM_WALK_AH_L; P = 0) */
 #define DRM_WALK_NO_PRISMATIC 32 /* no op of the walk is a prismatic joint (the two-samples-per-lane fan-out FK kernel asks for it) */
+#define DRM_WALK_FK_FAN 64 /* a many-target FK walk (DRM_WALK_TARGETS_ORDERED) that splits behind a hub: ops [0, prefix_end) are
+                              what every sub-tree hangs off, seg_begin[j] .. seg_begin[j + 1] the ops of wavefront j's sub-trees (the
+                              first op of every range but the first reads its parent's pose from a save slot or the root) */
 #define DRM_WALK_TARGETS_ORDERED 8 /* the ops with an output slot carry slots 0, 1, 2, ... in walk order: drm_fk with more than
                                   eight targets then writes its outputs a group of eight consecutive slots at a time */
 #define DRM_WALK_LEAVES(shape) (((shape) >> 16) & 0xff) /* number of leaf ops (ops no child follows), see DRM_OPI_CTRL */

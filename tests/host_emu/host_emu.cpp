@@ -7,6 +7,7 @@
 // drm_kernels.hip are NOT covered here; the `-m gpu` tests cover the real thing.
 #include <stdint.h>
 
+#include <cmath>
 #include <vector>
 
 #include "../../differentiable-robot-model_amd/csrc/drm_sample.hpp"
@@ -37,6 +38,20 @@ void fk_loop(const drm_walk *w, const float *q, int64_t B, int T, float *pos, fl
             for (int i = 0; i < 3; ++i) pos[(b * T + t) * 3 + i] = p[i];
             for (int i = 0; i < 4; ++i) quat[(b * T + t) * 4 + i] = qt[i];
         };
+        if ((w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2) {
+            // like fk_tree_fan_kernel: every wavefront walks the shared part and its own run — here with save slots of its
+            // own that start as NaN, so a run that leaned on a slot another run wrote would show
+            for (int j = 0; j < w->n_segments; ++j) {
+                for (auto &sl : slots)
+                    for (int c = 0; c < 3; ++c) { sl.A[c] = f2_make(NAN, NAN); sl.B[c] = f2_make(NAN, NAN); }
+                fk_tree_walk_ranges(w->prefix_end, w->seg_begin[j], w->seg_begin[j + 1], ctl, row, qf, save, load,
+                                    [&](int k, int t, const float *p, const float *qt) {
+                                        if (k < w->prefix_end && j != 0) return;
+                                        emit(t, p, qt);
+                                    });
+            }
+            continue;
+        }
         fk_tree_walk(w->n_ops, ctl, row, qf, save, load, emit);
     }
 }

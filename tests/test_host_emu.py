@@ -76,6 +76,31 @@ def test_fk_all_links(emu, robot):
 
 
 @pytest.mark.parametrize("robot", ALL_ROBOTS)
+def test_fk_all_links_in_walk_order_fanned_out_where_the_tree_has_a_hub(emu, robot):
+    """compute_forward_kinematics_all_links asks for the links in walk order; a hand or an arm that carries one then splits
+    behind its hub (flatten.fk_fan_partition, DRM_WALK_FK_FAN) and every wavefront walks the shared part plus its run with
+    nothing from the others — the emulation gives each run save slots of its own, poisoned with NaN."""
+    from differentiable_robot_model_amd.flatten import SHAPE_FK_FAN
+    m = load_model(robot)
+    B = 17
+    q, _, _ = sample_states(m, B, seed=2)
+    targets = [i for i in m._spec.preorder() if i != 0]
+    prog = build_walk(m._spec, targets=targets)
+    if robot in ("allegro_left", "iiwa7_allegro", "trifinger_edu"):
+        assert prog.shape & SHAPE_FK_FAN and len(prog.seg_begin) >= 3
+    if prog.shape & SHAPE_FK_FAN:
+        assert prog.seg_begin[0] == prog.prefix_end and prog.seg_begin[-1] == prog.n_ops
+        assert all(a < b for a, b in zip(prog.seg_begin, prog.seg_begin[1:]))
+    walk, keep = host_walk(m, prog)
+    pos = np.full((B, len(targets), 3), np.nan, np.float32); quat = np.full((B, len(targets), 4), np.nan, np.float32)
+    assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), len(targets), _ptr(pos), _ptr(quat)) == 0
+    op, oq = Oracle(m._spec).fk(q.astype(np.float64), targets, np.float64)
+    assert max_err(pos, op) < 1e-6
+    ok, flips = quat_close(quat, oq, 1e-6)
+    assert ok and flips == 0
+
+
+@pytest.mark.parametrize("robot", ALL_ROBOTS)
 def test_jacobian_every_link(emu, robot):
     m = load_model(robot)
     L, n, B = len(m._bodies), m._n_dofs, 17

@@ -121,6 +121,56 @@ def test_emu_random_tree_dynamics_vs_oracle(emu, tmp_path, seed):
         assert rel(acc, ref) < 1e-3, (seed, flags, rel(acc, ref))
 
 
+def fk_every_link_in_walk_order(emu, m, seed):
+    """All links' poses in walk order through the emulated many-target walk (fanned out where flatten.fk_fan_partition finds a
+    hub — each run with NaN-poisoned save slots of its own) against the oracle; returns whether the walk fanned out."""
+    from differentiable_robot_model_amd.flatten import SHAPE_FK_FAN
+    from helpers import quat_close
+    B = 7
+    q, _, _ = sample_states(m, B, seed=seed)
+    targets = [i for i in m._spec.preorder() if i != 0]
+    prog = build_walk(m._spec, targets=targets)
+    fan = bool(prog.shape & SHAPE_FK_FAN)
+    if fan:
+        P, sb = prog.prefix_end, list(prog.seg_begin)
+        assert sb[0] == P and sb[-1] == prog.n_ops and 2 <= len(sb) - 1 <= 4 and all(a < b for a, b in zip(sb, sb[1:]))
+        assert (len(sb) - 1) * P + prog.n_ops - P <= 2 * prog.n_ops
+    walk, _keep = host_walk(m, prog)
+    pos = np.full((B, len(targets), 3), np.nan, np.float32); quat = np.full((B, len(targets), 4), np.nan, np.float32)
+    assert emu.emu_fk(ctypes.byref(walk), _ptr(q), ctypes.c_int64(B), len(targets), _ptr(pos), _ptr(quat)) == 0
+    op, oq = Oracle(m._spec).fk(q.astype(np.float64), targets, np.float64)
+    assert np.abs(pos - op).max() <= 2e-6 * max(1.0, float(np.abs(op).max())), seed
+    assert quat_close(quat, oq, 2e-6)[0], seed
+    return fan
+
+
+def test_emu_every_link_in_walk_order_on_random_trees_and_generated_hands(emu, tmp_path):
+    fanned = sum(fk_every_link_in_walk_order(emu, tree_model(tmp_path, seed), seed) for seed in SEEDS)
+    for P, K, L in ARM_HAND_SHAPES[::3]:
+        fanned += fk_every_link_in_walk_order(emu, arm_hand_model(tmp_path, P, K, L, 100 * P + 10 * K + L, "cpu"), P)
+    assert fanned >= 3
+
+
+@pytest.mark.gpu
+def test_gpu_every_link_in_one_launch_on_random_trees_and_generated_hands(tmp_path):
+    """compute_forward_kinematics_all_links (one many-target launch: grouped, or fanned out behind a hub) against the oracle,
+    a ragged batch."""
+    from helpers import TOL_POS, TOL_QUAT, quat_close
+    models = [(tree_model(tmp_path, seed), tree_model(tmp_path, seed, "cuda")) for seed in SEEDS]
+    models += [(arm_hand_model(tmp_path, P, K, L, 100 * P + 10 * K + L, "cpu"), arm_hand_model(tmp_path, P, K, L, 100 * P + 10 * K + L, "cuda"))
+               for P, K, L in ARM_HAND_SHAPES[::3]]
+    for mc, m in models:
+        B = 64 * 2 + 11
+        q, _, _ = sample_states(mc, B, seed=5)
+        poses = m.compute_forward_kinematics_all_links(torch.from_numpy(q).cuda())
+        targets = list(range(1, len(mc._bodies)))
+        op, oq = Oracle(mc._spec).fk(q.astype(np.float64), targets, np.float64)
+        for k, idx in enumerate(targets):
+            pos, quat = poses[mc._bodies[idx].name]
+            assert np.abs(pos.cpu().numpy() - op[:, k]).max() <= TOL_POS["atol"] * max(1.0, float(np.abs(op).max()))
+            assert quat_close(quat.cpu().numpy(), oq[:, k], 2 * TOL_QUAT["atol"])[0]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
 def test_gpu_random_tree_dynamics_vs_oracle(tmp_path, seed):
