@@ -17,7 +17,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -30,7 +30,8 @@ class DrmWalk(ctypes.Structure):
                 ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
-                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1))]
+                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
+                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -40,7 +41,7 @@ class NativeLibraryError(RuntimeError):
 _lib = None
 _lock = threading.Lock()
 
-EXPORTS = ("drm_abi_version", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
+EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
@@ -109,6 +110,8 @@ def load_library(path: str = None):
         lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
+        if lib.drm_walk_sizeof() != ctypes.sizeof(DrmWalk):
+            raise NativeLibraryError("struct drm_walk: library %d bytes, binding %d" % (lib.drm_walk_sizeof(), ctypes.sizeof(DrmWalk)))
         _lib = lib
         return _lib
 
@@ -172,6 +175,9 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     w.prefix_end = int(prog.prefix_end)
     for i, v in enumerate(prog.seg_leaf_begin):
         w.seg_leaf_begin[i] = int(v)
+    for k, v in enumerate(prog.chain_dof1):      # (DRM_WALK_CHAIN_DOFS: what the control words say, as launch arguments)
+        w.chain_dof1[k] = int(v)
+    w.chain_prismatic = int(prog.chain_prismatic)
     return w
 
 

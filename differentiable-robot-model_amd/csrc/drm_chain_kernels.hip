@@ -26,16 +26,26 @@ namespace drm {
 
 // DoF column of every op of a serial chain (-1: fixed joint or padding), from the walk's W0 words (wave-uniform)
 //   pris: bit k set <=> op k is a prismatic joint (slides along +z of its frame by q instead of turning about it)
+// The DoF column (+1; 0 = the op does not move) of the first 16 ops and the prismatic bits, from drm_walk.chain_dof1 /
+// chain_prismatic: launch arguments, so the loads of a lane's joint angles do not wait for a read of the control words.
+struct ChainDofs {
+    uint32_t w[4];
+    uint32_t pris;
+};
+static inline ChainDofs chain_dofs_of(const drm_walk *w) {
+    ChainDofs c;
+    for (int i = 0; i < 4; ++i)
+        c.w[i] = (uint32_t)w->chain_dof1[4 * i] | ((uint32_t)w->chain_dof1[4 * i + 1] << 8) | ((uint32_t)w->chain_dof1[4 * i + 2] << 16) |
+                 ((uint32_t)w->chain_dof1[4 * i + 3] << 24);
+    c.pris = w->chain_prismatic;
+    return c;
+}
+
 template <int CAP>
-__device__ __forceinline__ void chain_dofs(const int32_t *__restrict__ ops_i, int n_ops, int (&dof)[CAP], unsigned &pris) {
-    const int32_t *w0 = ops_i + DRM_OPI_W0 * CAP; // field-major table of capacity CAP
-    pris = 0u;
+__device__ __forceinline__ void chain_dofs(const ChainDofs &c, int (&dof)[CAP], unsigned &pris) {
 #pragma unroll
-    for (int k = 0; k < CAP; ++k) {
-        const int w = w0[k];
-        dof[k] = (k < n_ops && !((w >> 25) & 1)) ? (w & 0xff) - 1 : -1;
-        if (dof[k] >= 0 && ((w >> 26) & 1)) pris |= 1u << k;
-    }
+    for (int k = 0; k < CAP; ++k) dof[k] = (int)((c.w[k >> 2] >> (8 * (k & 3))) & 0xffu) - 1;
+    pris = c.pris;
 }
 
 // cos / sin of the joint angle of every op, two ops per packed evaluation.  Ops that do not move carry the angle 0 and are
@@ -118,7 +128,7 @@ __device__ __forceinline__ void chain_walk(const float *lc, const float (&q)[CAP
 // LDS (dynamic): [ table : CAP x 32 ][ pos : 64 x 3 ][ Jacobian staging : 64 x (3n | 1), ang_jac first, then lin_jac ]
 template <int CAP, int USED, bool JAC, bool NT>
 __global__ void __launch_bounds__(WAVE)
-    chain_fk_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q, int n_ops, int n,
+    chain_fk_kernel(const float *__restrict__ ops_f, ChainDofs cd, const float *__restrict__ q, int n,
                     int target_perm, uint64_t dof_mask, float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
                     float *__restrict__ ang, uint32_t magic_j) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(WAVE)
 
     int dof[CAP];
     unsigned pris;
-    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
+    chain_dofs<CAP>(cd, dof, pris);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
     chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
@@ -207,8 +217,7 @@ __global__ void __launch_bounds__(WAVE)
 
 struct FanChains {
     const float *ops_f[4];
-    const int32_t *ops_i[4];
-    int32_t n_ops[4];
+    ChainDofs dofs[4];
     int32_t perm[4];
 };
 
@@ -224,13 +233,12 @@ __global__ void __launch_bounds__(WAVE * 4)
     float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + WAVE * 12;
     // wave-uniform choice of this wave's chain (T <= 4)
     const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
-    const int32_t *ops_i = wave == 0 ? tab.ops_i[0] : wave == 1 ? tab.ops_i[1] : wave == 2 ? tab.ops_i[2] : tab.ops_i[3];
-    const int n_ops = wave == 0 ? tab.n_ops[0] : wave == 1 ? tab.n_ops[1] : wave == 2 ? tab.n_ops[2] : tab.n_ops[3];
+    const ChainDofs &cd = wave == 0 ? tab.dofs[0] : wave == 1 ? tab.dofs[1] : wave == 2 ? tab.dofs[2] : tab.dofs[3];
     const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
 
     int dof[CAP];
     unsigned pris;
-    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
+    chain_dofs<CAP>(cd, dof, pris);
     chain_stage_table<CAP>(ops_f, lc, lane);
     float qv[CAP];
     chain_load_q<CAP, USED>(q + b0 * n, lane * (unsigned)n * 4u, dof, qv);
@@ -276,12 +284,11 @@ __global__ void __launch_bounds__(WAVE * 4)
     const int64_t b0 = (int64_t)blockIdx.x * FAN2_TILE;
     float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + FAN2_TILE * 12;
     const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
-    const int32_t *ops_i = wave == 0 ? tab.ops_i[0] : wave == 1 ? tab.ops_i[1] : wave == 2 ? tab.ops_i[2] : tab.ops_i[3];
-    const int n_ops = wave == 0 ? tab.n_ops[0] : wave == 1 ? tab.n_ops[1] : wave == 2 ? tab.n_ops[2] : tab.n_ops[3];
+    const ChainDofs &cd = wave == 0 ? tab.dofs[0] : wave == 1 ? tab.dofs[1] : wave == 2 ? tab.dofs[2] : tab.dofs[3];
     const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
     int dof[CAP];
     unsigned pris;
-    chain_dofs<CAP>(ops_i, n_ops, dof, pris);
+    chain_dofs<CAP>(cd, dof, pris);
     chain_stage_table<CAP>(ops_f, lc, lane);
     // this lane's two rows, one dword load per op and row at a wave-uniform column (ops that do not move: column 0, value dropped)
     f2 qv[USED];
@@ -326,7 +333,7 @@ __global__ void __launch_bounds__(WAVE * 4)
 
 // ---- launchers (called by drm_fk / drm_fk_jacobian / drm_fk_fanout); return the rows they covered (full tiles), 0 = not taken
 static bool chain_ok(const drm_walk *w) {
-    return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->capacity == 4 || w->capacity == 8 || w->capacity == 12 || w->capacity == 16) &&
+    return (w->shape & DRM_WALK_SERIAL_CHAIN) && (w->shape & DRM_WALK_CHAIN_DOFS) && (w->capacity == 4 || w->capacity == 8 || w->capacity == 12 || w->capacity == 16) &&
            w->n_ops >= 1 &&
            w->n_slots == 0 && (((uintptr_t)w->ops_f) & 15u) == 0 && w->target_perm >= 0 && w->target_perm <= 5;
 }
@@ -338,11 +345,11 @@ static void launch_chain_used(const drm_walk *w, const float *q, int n_tiles, fl
     const bool nt = stream_past_llc((int64_t)n_tiles * WAVE * 4 * (7 + (JAC ? 6 * n : 0)));
     if (nt) {
         ensure_lds((chain_fk_kernel<CAP, USED, JAC, true>), lds);
-        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, true>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, w->ops_i, q, w->n_ops,
+        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, true>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, chain_dofs_of(w), q,
                            n, (int)w->target_perm, w->dof_mask, pos, quat, lin, ang, div_magic(3 * n));
     } else {
         ensure_lds((chain_fk_kernel<CAP, USED, JAC, false>), lds);
-        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, false>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, w->ops_i, q, w->n_ops,
+        hipLaunchKernelGGL((chain_fk_kernel<CAP, USED, JAC, false>), dim3((unsigned)n_tiles), dim3(WAVE), lds, s, w->ops_f, chain_dofs_of(w), q,
                            n, (int)w->target_perm, w->dof_mask, pos, quat, lin, ang, div_magic(3 * n));
     }
 }
@@ -399,7 +406,7 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
     for (int t = 0; t < 4; ++t) {
         const drm_walk *w = chains + (t < T ? t : 0);
         if (!chain_ok(w) || (cap != 4 && cap != 8) || w->capacity != cap) return 0;
-        tab.ops_f[t] = w->ops_f; tab.ops_i[t] = w->ops_i; tab.n_ops[t] = w->n_ops; tab.perm[t] = w->target_perm;
+        tab.ops_f[t] = w->ops_f; tab.dofs[t] = chain_dofs_of(w); tab.perm[t] = w->target_perm;
         if (w->n_ops > longest) longest = w->n_ops;
         revolute = revolute && (w->shape & DRM_WALK_NO_PRISMATIC);
     }

@@ -173,5 +173,6 @@ int drm_link_rows_backward(const float *params, const float *grad_rows, int32_t 
     return drm::launched();
 }
 int drm_abi_version(void) { return DRM_ABI_VERSION; }
+int drm_walk_sizeof(void) { return (int)sizeof(drm_walk); }
 const char *drm_last_error(void) { return drm::last_error(); }
 }

@@ -64,6 +64,7 @@ SHAPE_ARM_HAND = 4                   # DRM_WALK_ARM_HAND (+ P, K, L in the top b
 SHAPE_TARGETS_ORDERED = 8            # DRM_WALK_TARGETS_ORDERED: output slots 0, 1, 2, ... in walk order
 SHAPE_FINGERS = 16                   # DRM_WALK_FINGERS (+ K, L in the top byte)
 SHAPE_NO_PRISMATIC = 32              # DRM_WALK_NO_PRISMATIC: no op of the walk slides
+SHAPE_CHAIN_DOFS = 128               # DRM_WALK_CHAIN_DOFS: chain_dof1 / chain_prismatic of a serial chain of <= 16 ops are filled
 SHAPE_FK_FAN = 64                    # DRM_WALK_FK_FAN: a many-target FK walk split behind a hub (prefix_end / seg_begin)
 FK_FAN_WAVES = 4                     # wavefronts a fanned-out many-target FK block has at most
 
@@ -360,6 +361,8 @@ class WalkProgram:
     op_of_link: Optional[dict] = None     # link index -> op that carries the link's TRUE frame (targets, body forces)
     prefix_end: int = 0                   # ops [0, prefix_end) are static (fixed joints off the root): every segment replays them
     seg_leaf_begin: Sequence[int] = (0, 0)  # leaf ordinals of every segment (drm_walk.seg_leaf_begin)
+    chain_dof1: Sequence[int] = (0,) * 16   # SHAPE_CHAIN_DOFS: 1 + DoF column of op k, 0 = does not move (drm_walk.chain_dof1)
+    chain_prismatic: int = 0                # SHAPE_CHAIN_DOFS: bit k <=> op k slides
 
     @property
     def n_segments(self) -> int:
@@ -691,15 +694,26 @@ def build_walk(spec: RobotSpec, targets: Optional[Sequence[int]] = None, whole_t
             prefix_end, seg_begin = part
             seg_dof = [(0, 0)] * (len(seg_begin) - 1)
             fk_fan = SHAPE_FK_FAN
+    # serial chains of up to 16 ops: the DoF columns and the prismatic bits also travel as launch arguments (what W0 says:
+    # bits 0..7 DoF + 1, bit 25 padding, bit 26 prismatic)
+    chain_dof1, chain_pris, chain_bit = [0] * 16, 0, 0
+    if serial and n_ops <= 16:
+        chain_bit = SHAPE_CHAIN_DOFS
+        for k in range(n_ops):
+            w = int(ops_i[k, OPI_W0]) & 0xffffffff
+            d1 = 0 if (w >> 25) & 1 else w & 0xff
+            chain_dof1[k] = d1
+            if d1 and (w >> 26) & 1:
+                chain_pris |= 1 << k
     is_leaf = [not (ops_i[k, OPI_FLAGS] & FLAG_CHILD_IS_NEXT) for k in range(n_ops)]
     seg_leaf_begin = [int(sum(is_leaf[:b])) for b in seg_begin]
     return WalkProgram(np.asarray(links, np.int32), ops_i, np.ascontiguousarray(ops_i.T), gather, gsign, n_ops,
                        max_used, cap, tlist, mask, unique,
                        (SHAPE_ARM_CHAIN if arm else 0) | (SHAPE_SERIAL_CHAIN if serial else 0) | (branch_depth << 8)
-                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0) | (0 if any(prismatic) else SHAPE_NO_PRISMATIC) | fk_fan
+                       | (SHAPE_TARGETS_ORDERED if ordered and tlist else 0) | (0 if any(prismatic) else SHAPE_NO_PRISMATIC) | fk_fan | chain_bit
                        | (min(n_leaves, 255) << 16) | (arm_hand_shape(parent_op, n_ops, prismatic) if whole_tree else 0)
                        | (fingers_shape(ops, parent_op, n_ops, n, prismatic) if whole_tree else 0),
-                       seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin)
+                       seg_begin, seg_dof, op_of_link, prefix_end, seg_leaf_begin, tuple(chain_dof1), chain_pris)
 
 
 def _segments(ops, parent_op, n_ops: int, n_dofs: int):

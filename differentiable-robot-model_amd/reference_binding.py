@@ -27,6 +27,7 @@ from .flatten import MAX_SEGMENTS, OPF_STRIDE, OPI_PERM, build_robot_spec, build
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
+ABI_VERSION = 8      # DRM_ABI_VERSION of include/drm_hip.h this mirror of struct drm_walk follows
 
 
 class DrmWalk(ctypes.Structure):
@@ -36,7 +37,8 @@ class DrmWalk(ctypes.Structure):
                 ("dof_mask", ctypes.c_uint64), ("target_perm", ctypes.c_int32), ("shape", ctypes.c_int32),
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
-                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1))]
+                ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
+                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 
 def link_table(body_params: Sequence[dict], device, spec=None) -> torch.Tensor:
@@ -93,6 +95,9 @@ class HipBinding(object):
         if self._lib is None:
             self._lib = ctypes.CDLL(self._library)
             self._lib.drm_last_error.restype = ctypes.c_char_p
+            if self._lib.drm_abi_version() != ABI_VERSION or self._lib.drm_walk_sizeof() != ctypes.sizeof(DrmWalk):
+                raise RuntimeError("libdrm_hip.so: ABI %d with a %d-byte drm_walk, this binding is written for ABI %d / %d bytes" % (
+                    self._lib.drm_abi_version(), self._lib.drm_walk_sizeof(), ABI_VERSION, ctypes.sizeof(DrmWalk)))
         return self._lib
 
     def _check(self, rc):
@@ -121,6 +126,9 @@ class HipBinding(object):
             w.prefix_end = int(prog.prefix_end)
             for i, v in enumerate(prog.seg_leaf_begin):
                 w.seg_leaf_begin[i] = int(v)
+            for k, v in enumerate(prog.chain_dof1):          # (serial chains: the DoF columns as launch arguments)
+                w.chain_dof1[k] = int(v)
+            w.chain_prismatic = int(prog.chain_prismatic)
             self._walks[key] = (w, ops_f, ops_i, prog)
         return self._walks[key]
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 7
+#define DRM_ABI_VERSION 8
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -125,6 +125,9 @@ extern "C" {
                               (the fingers of a hand once the fixed joints are folded: Allegro 4 x 4, TriFinger 3 x 3); K and L in
                               the top byte as for DRM_WALK_ARM_HAND (DRM_WALK_AH_K / DRM_WALK_AH_L; P = 0) */
 #define DRM_WALK_NO_PRISMATIC 32 /* no op of the walk is a prismatic joint (the two-samples-per-lane fan-out FK kernel asks for it) */
+#define DRM_WALK_CHAIN_DOFS 128 /* chain_dof1 / chain_prismatic below are filled (serial chains of <= 16 ops): the straight-line
+                                  chain kernels take the DoF columns from the launch arguments instead of reading the control words
+                                  first — one dependent memory round trip less before a wavefront's joint angles are requested */
 #define DRM_WALK_FK_FAN 64 /* a many-target FK walk (DRM_WALK_TARGETS_ORDERED) that splits behind a hub: ops [0, prefix_end) are
                               what every sub-tree hangs off, seg_begin[j] .. seg_begin[j + 1] the ops of wavefront j's sub-trees (the
                               first op of every range but the first reads its parent's pose from a save slot or the root) */
@@ -175,9 +178,14 @@ typedef struct drm_walk {
     int32_t seg_leaf_begin[DRM_MAX_SEGMENTS + 1]; /* leaf ordinals (DRM_OPI_CTRL bits 26..31) of segment s:
                              seg_leaf_begin[s] .. seg_leaf_begin[s+1]-1 (leaves are numbered in walk order, those of the
                              prefix first); read by the RNEA backward kernel when it fans the segments out over wavefronts */
+    uint8_t chain_dof1[16];   /* DRM_WALK_CHAIN_DOFS: 1 + the DoF column op k reads, 0 for an op that does not move (fixed joint,
+                                 padding) — what DRM_OPI_W0 says, for the first 16 ops of a serial chain */
+    uint32_t chain_prismatic; /* DRM_WALK_CHAIN_DOFS: bit k set <=> op k slides */
+    uint32_t reserved0;
 } drm_walk;
 
 int drm_abi_version(void);
+int drm_walk_sizeof(void); /* sizeof(struct drm_walk) as the library was compiled: a binding checks its mirror of the struct against it */
 const char *drm_last_error(void);
 
 /*
