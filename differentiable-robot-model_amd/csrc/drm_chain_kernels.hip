@@ -53,23 +53,26 @@ __device__ __forceinline__ void chain_dofs(const ChainDofs &c, int (&dof)[CAP], 
 // tried and costs more than it saves — the merges after every branch triple the register count of the 16-op kernel
 // USED: ops USED .. CAP-1 are known to be padding (the launcher picks the instantiation from n_ops)
 // and are neither evaluated nor walked
-template <int CAP, int USED>
+// TRIG < USED: the ops TRIG .. USED-1 are known NOT to move (the fixed tail of a chain: a fingertip frame) — no evaluation for them
+template <int CAP, int USED, int TRIG = USED>
 __device__ __forceinline__ void chain_trig_all(const float (&q)[CAP], float (&cs)[CAP], float (&sn)[CAP]) {
-    static_assert(USED <= CAP, "ops USED .. CAP-1 are padding");
+    static_assert(USED <= CAP && TRIG <= USED, "ops USED .. CAP-1 are padding");
+#pragma unroll
+    for (int k = TRIG; k < USED; ++k) { cs[k] = 1.0f; sn[k] = 0.0f; }
     bool big = false;
 #pragma unroll
-    for (int k = 0; k < USED; ++k) big = big || !(fabsf(q[k]) <= SINCOS_PAIR_MAX_ARG);
+    for (int k = 0; k < TRIG; ++k) big = big || !(fabsf(q[k]) <= SINCOS_PAIR_MAX_ARG);
     if (DRM_WAVE_ANY(big)) { // rare; wave-uniform
 #pragma unroll
-        for (int k = 0; k < USED; ++k) sincos_f(q[k], sn[k], cs[k]);
+        for (int k = 0; k < TRIG; ++k) sincos_f(q[k], sn[k], cs[k]);
         return;
     }
 #pragma unroll
-    for (int k = 0; k < USED; k += 2) {
+    for (int k = 0; k < TRIG; k += 2) {
         f2 s2, c2;
-        sincos_pair(f2_make(q[k], q[k + 1 < USED ? k + 1 : k]), s2, c2);
+        sincos_pair(f2_make(q[k], q[k + 1 < TRIG ? k + 1 : k]), s2, c2);
         sn[k] = s2[0]; cs[k] = c2[0];
-        if (k + 1 < USED) { sn[k + 1] = s2[1]; cs[k + 1] = c2[1]; }
+        if (k + 1 < TRIG) { sn[k + 1] = s2[1]; cs[k + 1] = c2[1]; }
     }
 }
 
@@ -103,7 +106,7 @@ __device__ __forceinline__ void chain_stage_table(const float *__restrict__ ops_
 
 // the chain itself: pose of the last op; frame(k, B) is handed the (z_k, p_k) pairs of every op's frame as soon as they exist
 // A prismatic op (wave-uniform bit of `pris`) keeps J = F and slides: t += F e_z q (drm_tree.hpp joint_transform).
-template <int CAP, int USED, bool FENCE, class FRAME>
+template <int CAP, int USED, bool FENCE, class FRAME, int TRIG = USED>
 __device__ __forceinline__ void chain_walk(const float *lc, const float (&q)[CAP], const float (&cs)[CAP], const float (&sn)[CAP],
                                            unsigned pris, PoseP &ee, FRAME frame) {
 #pragma unroll
@@ -112,7 +115,10 @@ __device__ __forceinline__ void chain_walk(const float *lc, const float (&q)[CAP
         if (FENCE) __builtin_amdgcn_sched_barrier(0);
         OpPairs o = load_pairs(lc + k * DRM_OPF_STRIDE);
         f2 J01[3];
-        if ((pris >> k) & 1u) {
+        if (k >= TRIG) { // the fixed tail: J = F
+#pragma unroll
+            for (int i = 0; i < 3; ++i) J01[i] = o.f01[i];
+        } else if ((pris >> k) & 1u) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) { J01[i] = o.f01[i]; o.f2t[i][1] += o.f2t[i][0] * q[k]; }
         } else {
@@ -215,26 +221,33 @@ __global__ void __launch_bounds__(WAVE)
     }
 }
 
+// One 32-byte record per chain, so that a wavefront picks its chain up with ONE scalar load at a wave-uniform offset (the launch's
+// other arguments sit in the preloaded kernel-argument registers ahead of the records): table pointer, DoF columns, prismatic
+// bits and target permutation arrive together, and the loads of the table and of the joint angles go out right behind them.
+struct FanChain {
+    const float *ops_f;
+    ChainDofs dofs; // 20 bytes
+    int32_t perm;
+};
+static_assert(sizeof(FanChain) == 32, "one s_load_dwordx8 per wavefront");
 struct FanChains {
-    const float *ops_f[4];
-    ChainDofs dofs[4];
-    int32_t perm[4];
+    FanChain c[4];
 };
 
 // LDS (static): four chain tables, then the block's [64, 3T] position and [64, 4T] quaternion tiles (linear images)
-template <int CAP, int USED>
+template <int CAP, int USED, int TRIG = USED>
 __global__ void __launch_bounds__(WAVE * 4)
-    fk_fan_chain_kernel(FanChains tab, int T, int n, const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat) {
+    fk_fan_chain_kernel(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat, int T, int n, FanChains tab) {
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE;
     __shared__ __attribute__((aligned(16))) float smem[4 * C_FLOATS + WAVE * 12 + WAVE * 16];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int64_t b0 = (int64_t)blockIdx.x * WAVE;
     float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + WAVE * 12;
-    // wave-uniform choice of this wave's chain (T <= 4)
-    const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
-    const ChainDofs &cd = wave == 0 ? tab.dofs[0] : wave == 1 ? tab.dofs[1] : wave == 2 ? tab.dofs[2] : tab.dofs[3];
-    const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
+        const FanChain mine = tab.c[wave]; // (wave-uniform index into the kernel arguments: one scalar load)
+    const float *ops_f = mine.ops_f;
+    const ChainDofs &cd = mine.dofs;
+    const int perm = mine.perm;
 
     int dof[CAP];
     unsigned pris;
@@ -246,9 +259,10 @@ __global__ void __launch_bounds__(WAVE * 4)
     float cs[CAP], sn[CAP], qa[CAP];
 #pragma unroll
     for (int k = 0; k < USED; ++k) qa[k] = ((pris >> k) & 1u) ? 0.0f : qv[k];
-    chain_trig_all<CAP, USED>(qa, cs, sn);
+    chain_trig_all<CAP, USED, TRIG>(qa, cs, sn);
     PoseP ee;
-    chain_walk<CAP, USED, false>(lc, qv, cs, sn, pris, ee, [](int, const f2 (&)[3]) {});
+    auto none = [](int, const f2 (&)[3]) {};
+    chain_walk<CAP, USED, false, decltype(none), TRIG>(lc, qv, cs, sn, pris, ee, none);
     {
         float *p = lp + (lane * T + wave) * 3;
         p[0] = ee.B[0][1]; p[1] = ee.B[1][1]; p[2] = ee.B[2][1];
@@ -276,16 +290,17 @@ __global__ void __launch_bounds__(WAVE * 4)
 constexpr int FAN2_TILE = 2 * WAVE;
 template <int CAP, int USED>
 __global__ void __launch_bounds__(WAVE * 4)
-    fk_fan_chain2_kernel(FanChains tab, int T, int n, const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat) {
+    fk_fan_chain2_kernel(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat, int T, int n, FanChains tab) {
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE;
     __shared__ __attribute__((aligned(16))) float smem[4 * C_FLOATS + FAN2_TILE * 12 + FAN2_TILE * 16];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const int64_t b0 = (int64_t)blockIdx.x * FAN2_TILE;
     float *lc = smem + wave * C_FLOATS, *lp = smem + 4 * C_FLOATS, *lr = lp + FAN2_TILE * 12;
-    const float *ops_f = wave == 0 ? tab.ops_f[0] : wave == 1 ? tab.ops_f[1] : wave == 2 ? tab.ops_f[2] : tab.ops_f[3];
-    const ChainDofs &cd = wave == 0 ? tab.dofs[0] : wave == 1 ? tab.dofs[1] : wave == 2 ? tab.dofs[2] : tab.dofs[3];
-    const int perm = wave == 0 ? tab.perm[0] : wave == 1 ? tab.perm[1] : wave == 2 ? tab.perm[2] : tab.perm[3];
+    const FanChain mine = tab.c[wave]; // (wave-uniform index into the kernel arguments: one scalar load)
+    const float *ops_f = mine.ops_f;
+    const ChainDofs &cd = mine.dofs;
+    const int perm = mine.perm;
     int dof[CAP];
     unsigned pris;
     chain_dofs<CAP>(cd, dof, pris);
@@ -406,7 +421,7 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
     for (int t = 0; t < 4; ++t) {
         const drm_walk *w = chains + (t < T ? t : 0);
         if (!chain_ok(w) || (cap != 4 && cap != 8) || w->capacity != cap) return 0;
-        tab.ops_f[t] = w->ops_f; tab.dofs[t] = chain_dofs_of(w); tab.perm[t] = w->target_perm;
+        tab.c[t].ops_f = w->ops_f; tab.c[t].dofs = chain_dofs_of(w); tab.c[t].perm = w->target_perm;
         if (w->n_ops > longest) longest = w->n_ops;
         revolute = revolute && (w->shape & DRM_WALK_NO_PRISMATIC);
     }
@@ -417,7 +432,7 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
 #ifndef DRM_NO_FAN2_KERNEL
     if (revolute && n_tiles / 2 >= DRM_FAN2_MIN_TILES) { // pairs of tiles: two samples per lane
         const int n2 = n_tiles / 2;
-#define FAN2(C, U) hipLaunchKernelGGL((fk_fan_chain2_kernel<C, U>), dim3((unsigned)n2), dim3(WAVE * T), 0, s, tab, T, n, q, pos, quat)
+#define FAN2(C, U) hipLaunchKernelGGL((fk_fan_chain2_kernel<C, U>), dim3((unsigned)n2), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab)
         if (cap == 4) FAN2(4, 4);
         else if (longest <= 5) FAN2(8, 5);
         else if (longest == 6) FAN2(8, 6);
@@ -430,7 +445,18 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
         q += done * n; pos += done * 3 * T; quat += done * 4 * T;
     }
 #endif
-#define FAN(C, U) hipLaunchKernelGGL((fk_fan_chain_kernel<C, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, tab, T, n, q, pos, quat)
+    // ... and, where the last walked op of every chain is fixed (a fingertip frame; identity padding of a shorter chain), the form
+    // that spends no sincos and no joint rotation on it
+#define FAN(C, U) do { if (tail_fixed(U)) hipLaunchKernelGGL((fk_fan_chain_kernel<C, U, U - 1>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab); \
+                       else hipLaunchKernelGGL((fk_fan_chain_kernel<C, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab); } while (0)
+    auto tail_fixed = [&](int used) {
+#ifdef DRM_NO_FAN_TAIL
+        return false;
+#endif
+        for (int t = 0; t < T; ++t)
+            if (chains[t].chain_dof1[used - 1]) return false;
+        return true;
+    };
     if (cap == 4) FAN(4, 4);
     else if (longest <= 5) FAN(8, 5);
     else if (longest == 6) FAN(8, 6);
