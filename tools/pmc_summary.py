@@ -85,7 +85,8 @@ for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two
     if line:
         with open(os.path.join(prof, tag + dst), "w") as f:
             f.write(line + "\n")
-for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt")):
+for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt"),
+                 ("probe_api.txt", "_probe_api.txt")):
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 if os.path.exists(os.path.join(OUT, "overhead_under_rocprofv3.txt")):
