@@ -238,8 +238,9 @@ def sample_q(model, B, device, seed):
 
 
 def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=2):
-    """EXACTLY K launches between barrier + synchronize on both sides; returns (wall seconds, device seconds from HIP
-    events on the launch stream, whether a hipGraph was used)."""
+    """EXACTLY K launches between barrier + synchronize on both sides, twice: once timed by the host's clock (wall seconds),
+    once more with HIP events on the launch stream around them (device seconds); returns (wall, device, whether a hipGraph was
+    used)."""
     import torch
     graph = None
     if use_graph:
@@ -265,21 +266,36 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
             graph = None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream); ev1.record(stream)   # untimed: an event's first record creates it (~10 us on this stack)
+
+    def k_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(K):
+                launch()
+
+    # (1) the wall-clock bracket: nothing but the K steps between the two synchronizes — recording the two events from the
+    # host inside it costs ~6 us of an ~95 us region at the driver's --steps 20 (tools/region_probe2.py: 4.95 -> 4.65 us per step)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(K):
-            launch()
-    ev1.record(stream)
-    while not ev1.query():      # poll instead of sleeping in the driver: a blocking wait adds its wake-up latency
-        pass                    # (10-20 us) to a timed region that is only ~80 us long at the driver's --steps 20
+    k_steps()
     torch.cuda.synchronize()
     t1 = time.perf_counter()    # this rank's K steps are done; the caller takes the MAX over ranks
     barrier()                   # (closing barrier of the bracket: its own latency, ~50 us over 8 GPUs, is not a step)
+    # (2) the same K steps once more, same bracket, with HIP events on the launch stream around them: the device-side duration
+    # (the roofline's launch time).  A graph launch carries ~9 us of its own on the device (4.2 us per step at --steps 20
+    # against 3.8 at 200; submitting the timed pass behind two untimed ones, so that the device never idles, does not change
+    # it — measured).  Events recorded as NODES of the graph do not bracket the kernels on this stack (0.2 us per step).
+    barrier()
+    torch.cuda.synchronize()
+    ev0.record(stream)
+    k_steps()
+    ev1.record(stream)
+    while not ev1.query():      # poll instead of sleeping in the driver
+        pass
+    torch.cuda.synchronize()
+    barrier()
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, graph is not None
 
 
@@ -418,8 +434,10 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
                      "algorithmic_bytes_per_launch": bytes_per_eval * B,
                      "kernel": "drm::fk_jacobian_arm_kernel<8, 7, true, 1, false>", "bytes_per_eval": bytes_per_eval,
                      "launch_us": launch_s * 1e6,
-                     "note": "algorithmic bytes / average launch duration (HIP events over the timed region, includes "
-                             "inter-launch gaps).  At this batch the 14.7 MB of a launch are replayed over the same buffers "
+                     "note": "algorithmic bytes / average launch duration: HIP events on the launch stream around a second pass of "
+                             "the same K steps in the same bracket (the wall-clock pass, `ms_per_step`, carries no event calls); "
+                             "includes inter-launch gaps and the ~9 us a graph launch costs on the device, i.e. 0.45 us per step "
+                             "at --steps 20.  At this batch the 14.7 MB of a launch are replayed over the same buffers "
                              "and stay in the 256 MiB Infinity Cache: `achieved` is an effective rate against the HBM peak, "
                              "bounded by launch floor (1.66 us) + write-through drain of 12.8 MB (a launch that only moves "
                              "the bytes takes 2.9 us = 0.63, profiles/r02_metric_lab.txt); genuine HBM streaming is in "
