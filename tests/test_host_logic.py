@@ -103,6 +103,23 @@ def test_walk_program_invariants(robot):
     chain = build_walk(spec, targets=[deepest])
     assert chain.links.tolist() == spec.chain_to(deepest) and chain.n_slots == 0
     assert int(chain.ops_i[chain.n_ops - 1, OPI_OUT]) == 0
+    # a serial chain of up to 16 ops also carries its DoF columns and prismatic bits as plain struct fields (DRM_WALK_CHAIN_DOFS,
+    # ABI 8: launch arguments of the chain kernels) — the same facts as the per-op columns, and they reach struct drm_walk
+    from differentiable_robot_model_amd.flatten import KIND_PRISMATIC, SHAPE_CHAIN_DOFS, SHAPE_SERIAL_CHAIN
+    for link in range(1, L):
+        c = build_walk(spec, targets=[link])
+        assert bool(c.shape & SHAPE_CHAIN_DOFS) == (bool(c.shape & SHAPE_SERIAL_CHAIN) and c.n_ops <= 16)
+        if not c.shape & SHAPE_CHAIN_DOFS:
+            assert not any(c.chain_dof1) and c.chain_prismatic == 0
+            continue
+        for k in range(16):
+            dof = int(c.ops_i[k, OPI_DOF]) if k < c.n_ops else -1
+            assert c.chain_dof1[k] == dof + 1
+            slides = dof >= 0 and int(spec.kind[int(c.links[k])]) == KIND_PRISMATIC
+            assert bool((c.chain_prismatic >> k) & 1) == slides
+        w = backend.fill_walk_struct(backend.DrmWalk, c, 0, 0, spec.n_dofs, 2)
+        assert list(w.chain_dof1) == list(c.chain_dof1) and w.chain_prismatic == c.chain_prismatic
+    assert not prog.shape & SHAPE_CHAIN_DOFS or (prog.shape & SHAPE_SERIAL_CHAIN and prog.n_ops <= 16)
 
 
 def test_axis_canonicalisation_is_a_pure_reindexing():
