@@ -19,17 +19,21 @@
 
 namespace drm {
 
-constexpr int AH_MAX_OPS = 32; // P + K L of any compiled shape (sizes the torque tile)
+constexpr int AH_MAX_OPS = 32; // P + K L of any compiled shape
+constexpr int AH_MAX_K = 4;    // sub-chains of a shape (two bits of drm_walk.shape): the LDS of a <P, L> kernel is sized for P + 4 L ops —
+                               // 11.6 instead of 17.4 KB per wavefront for a 7-joint arm with a gripper, i.e. the three wavefronts per
+                               // SIMD its registers allow instead of nine per CU
 
 // LDS (static — with a dynamic allocation the compiler's occupancy guess goes wrong and the same code needs 300 registers):
-// [ table : AH_MAX_OPS x 32 ][ torques of the sub-chain ops : 16 x 64 ][ parking : (P - 1) x 6 x 64 | tau tile : 64 x (n | 1) ]
+// [ table : (P + 4 L) x 32 ][ torques of the sub-chain ops : 4 L x 64 ][ parking : (P - 1) x 6 x 64 | tau tile : 64 x (n | 1) ]
 template <int P, int L>
 __global__ void __launch_bounds__(WAVE)
     rnea_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
                          const float *__restrict__ qd, const float *__restrict__ qdd, int K, int cap, int n, int flags,
                          float *__restrict__ tau, uint32_t magic_n) {
-    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE, H_FLOATS = 16 * WAVE;
-    constexpr int PARK = (P - 1) * 6 * WAVE, TILE = round4(WAVE * pad_odd(AH_MAX_OPS));
+    constexpr int OPS = P + AH_MAX_K * L;
+    constexpr int C_FLOATS = OPS * DRM_OPF_STRIDE, H_FLOATS = AH_MAX_K * L * WAVE;
+    constexpr int PARK = (P - 1) * 6 * WAVE, TILE = round4(WAVE * pad_odd(OPS));
     __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + H_FLOATS + (PARK > TILE ? PARK : TILE)];
     const unsigned lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * WAVE;
@@ -104,8 +108,9 @@ __global__ void __launch_bounds__(WAVE)
     forward_dynamics_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
                                      const float *__restrict__ qd, const float *__restrict__ f, int K, int cap, int n, int flags,
                                      float *__restrict__ qdd, uint32_t magic_n) {
-    constexpr int C_FLOATS = AH_MAX_OPS * DRM_OPF_STRIDE;
-    constexpr int SLOTS = P * 8 * WAVE, TILE = round4(WAVE * pad_odd(AH_MAX_OPS));
+    constexpr int OPS = P + AH_MAX_K * L;
+    constexpr int C_FLOATS = OPS * DRM_OPF_STRIDE;
+    constexpr int SLOTS = P * 8 * WAVE, TILE = round4(WAVE * pad_odd(OPS));
     __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + (SLOTS > TILE ? SLOTS : TILE)];
     const unsigned lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * WAVE;
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)
 static bool shape_of(const drm_walk *w, int &P, int &K, int &L) {
     if (!(w->shape & DRM_WALK_ARM_HAND)) return false;
     P = DRM_WALK_AH_P(w->shape); K = DRM_WALK_AH_K(w->shape); L = DRM_WALK_AH_L(w->shape);
-    if (P + K * L != w->n_ops || w->n_ops > AH_MAX_OPS || K * L > 16 || w->n_dofs > w->n_ops) return false;
+    if (P + K * L != w->n_ops || w->n_ops > AH_MAX_OPS || K > AH_MAX_K || w->n_dofs > w->n_ops) return false;
 #define X(p, l) if (P == p && L == l) return true;
     DRM_ARM_HAND_SHAPES(X)
 #undef X
