@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(WAVE)
 
 // ---------------------------------------------------------------------------------------------------
 // K8 (forward dynamics) of the same shapes: the articulated-body recursion of drm_tree.hpp aba_arm_hand — prefix records in
-// one 8-float LDS slot per op (velocities, then U, 1/D, u), sub-chains visited twice instead of stored: no scratch, 14-18 KB
+// one 8-float LDS slot per op (velocities, then U, 1/D, u), sub-chains visited twice instead of stored: no scratch, 12-20 KB
 // of LDS per wave.  The loop form (forward_dynamics_aba_kernel) needs HBM scratch and holds five wavefronts per CU.
 // LDS (static): [ table ][ slots : P x 8 x 64 | qdd tile : 64 x (n | 1) staged over them once sweep 3 of the prefix is done ]
 // ---------------------------------------------------------------------------------------------------
