@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(WAVE)
 // the walk to the next.  16-byte sc1 stores (nt beyond the Infinity Cache); positions fall back to 4-byte stores when 12 T is
 // not a multiple of 16.
 // LDS: [ table ][ q : 64 (n|1) ][ pos group : 64 x 25 ][ quat group : 64 x 33 ][ slots : n_slots * 12 * 64 ]
-constexpr int FK_GROUP = 8, FK_GP = 3 * FK_GROUP + 1, FK_GR = 4 * FK_GROUP + 1;
+#ifndef DRM_FK_GROUP
+#define DRM_FK_GROUP 8
+#endif
+constexpr int FK_GROUP = DRM_FK_GROUP, FK_GP = 3 * FK_GROUP + 1, FK_GR = 4 * FK_GROUP + 1;
 template <bool NT>
 __global__ void __launch_bounds__(WAVE)
     fk_tree_groups_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, int T, float *__restrict__ pos, float *__restrict__ quat,
@@ -82,8 +85,9 @@ __global__ void __launch_bounds__(WAVE)
     auto flush = [&](int g, int cnt) {
         wave_lds_sync();
         if (cnt == FK_GROUP && pos16) {
-            for (int i = (int)lane; i < tc.rows * 6; i += WAVE) {
-                const int s = i / 6, part = i - s * 6;
+            constexpr int PARTS = 3 * FK_GROUP / 4;
+            for (int i = (int)lane; i < tc.rows * PARTS; i += WAVE) {
+                const int s = i / PARTS, part = i - s * PARTS;
                 const float *src = lp + s * FK_GP + part * 4;
                 store16_wt<NT>(gp + (int64_t)s * 3 * T + g * (3 * FK_GROUP) + part * 4, make_float4(src[0], src[1], src[2], src[3]));
             }
@@ -300,7 +304,7 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
     TreeArgs a = tree_args(w);
     a.n_segments = 1; a.prefix_end = 0;
 #ifndef DRM_NO_FK_GROUPS
-    if ((w->shape & DRM_WALK_TARGETS_ORDERED) && T > FK_GROUP) {
+    if ((w->shape & DRM_WALK_TARGETS_ORDERED) && T > 8) {
         if ((w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2 && w->n_segments <= DRM_MAX_SEGMENTS && segments_ok(w)) {
             // fanned out over the sub-trees behind the hub, the whole tile staged — when two such blocks fit a CU
             const size_t lds_fan = sizeof(float) * (size_t)(table_lds_floats(w->n_ops) + round4(WAVE * pad_odd(n)) + w->n_slots * 12 * WAVE +
