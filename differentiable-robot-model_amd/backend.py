@@ -44,7 +44,7 @@ _lock = threading.Lock()
 EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
-           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_jacobian_backward", "drm_walk_table",
+           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats")
 
@@ -72,6 +72,8 @@ def load_library(path: str = None):
         lib.drm_last_error.argtypes = []
         lib.drm_fk.restype = ctypes.c_int
         lib.drm_fk.argtypes = [wp, vp, i64, i32, vp, vp, vp]
+        lib.drm_fk_links.restype = ctypes.c_int
+        lib.drm_fk_links.argtypes = [wp, vp, i64, i32, vp, vp, vp]
         lib.drm_fk_fanout.restype = ctypes.c_int
         lib.drm_fk_fanout.argtypes = [wp, i32, vp, i64, vp, vp, vp]
         lib.drm_fk_jacobian.restype = ctypes.c_int
@@ -203,6 +205,23 @@ def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze:
     with torch.cuda.device(q.device):
         _check(lib.drm_fk(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
                           _stream(q.device)))
+    return pos, quat
+
+
+def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
+    """pos [T, B, 3], quat [T, B, 4] of the walk's targets, LINK-major: pos[t] / quat[t] are contiguous [B, 3] / [B, 4] arrays
+    (what compute_forward_kinematics_all_links returns per link; the kernel writes a link's 64 poses of a tile as one run)."""
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    B = q.shape[0]
+    pos = torch.empty(n_targets, B, 3, device=q.device, dtype=torch.float32)
+    quat = torch.empty(n_targets, B, 4, device=q.device, dtype=torch.float32)
+    if B == 0:
+        return pos, quat
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with torch.cuda.device(q.device):
+        _check(lib.drm_fk_links(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
+                                _stream(q.device)))
     return pos, quat
 
 

@@ -166,6 +166,55 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
     block_tile_store<NT>(quat + tc.b0 * 4 * T, tc.rows, 4 * T, magic_r, lr, tc.full && (align & AL_QUAT));
 }
 
+// LINK-MAJOR outputs (drm_fk_links: pos [T, B, 3], quat [T, B, 4] — every link's poses a contiguous array, which is what
+// compute_forward_kinematics_all_links hands out per link, robot_model.py:197-221): a target's 64 poses of a tile are ONE
+// contiguous run — 768 B of positions (through a 64 x 3 LDS stage, 48 16-byte stores) and 1 KB of quaternions (a 16-byte store
+// per lane, straight from registers) — written the moment the walk reaches the target.  Nothing of a tile's outputs waits in
+// LDS: table + q tile + save slots, ~8 KB instead of the 15-50 KB of the sample-major forms above.  A walk that splits behind a
+// hub (DRM_WALK_FK_FAN) gets a wavefront per run of sub-trees; they share nothing but the table and the q tile.
+// LDS: [ table ][ q : 64 (n|1) ][ slots : n_slots * 12 * 64 ][ position stage : 64 x 3 per wavefront ]
+template <bool NT>
+__global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
+    fk_tree_links_kernel(TreeArgs a, const float *__restrict__ q, int64_t B, float *__restrict__ pos, float *__restrict__ quat,
+                         uint32_t magic_q, uint32_t align, int fan) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileCtx tc = tile_begin(B);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int n = a.n, Sq = pad_odd(n);
+    float *lq = smem + table_lds_floats(a.n_ops);
+    float *ls = lq + round4(WAVE * Sq);
+    float *lp = ls + a.n_slots * 12 * WAVE + wave * (WAVE * 3);
+    const TableLds tab = stage_tree_table(a, smem);
+    if (wave == 0) tile_load<0>(q + tc.b0 * n, tc.rows, n, magic_q, lq, lane, tc.full && (n & 1) && (align & AL_Q), tc.full && (align & AL_Q));
+    __syncthreads();
+    const bool live = (int)lane < tc.rows;
+    const float *qrow = lq + lane * Sq;
+    // a link's [B, 3] array starts 12 B t bytes in: 16-byte aligned for every t when B is a multiple of 4
+    const bool pos16 = tc.full && (align & AL_POS) && (B & 3) == 0;
+    const bool quat16 = (align & AL_QUAT) != 0;
+    const int P = fan ? a.prefix_end : 0, first = fan ? a.seg_begin[wave] : 0, last = fan ? a.seg_begin[wave + 1] : a.n_ops;
+    fk_tree_walk_ranges(
+        P, first, last, tab, [&](int k) { return tab.row(k); }, [&](int d) -> float { return live ? qrow[d] : 0.0f; },
+        [&](int s, const PoseP &Q) { lds_put_pose(ls, s, lane, Q); }, [&](int s, PoseP &Q) { lds_get_pose(ls, s, lane, Q); },
+        [&](int k, int t, const float *p, const float *qt) {
+            if (k < P && wave != 0) return; // the shared part's targets are wavefront 0's
+            float *gr = quat + ((int64_t)t * B + tc.b0) * 4, *gp = pos + ((int64_t)t * B + tc.b0) * 3;
+            if (live) {
+                if (quat16) store16_wt<NT>(gr + lane * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+                else { gr[lane * 4 + 0] = qt[0]; gr[lane * 4 + 1] = qt[1]; gr[lane * 4 + 2] = qt[2]; gr[lane * 4 + 3] = qt[3]; }
+            }
+            lp[lane * 3 + 0] = p[0]; lp[lane * 3 + 1] = p[1]; lp[lane * 3 + 2] = p[2];
+            wave_lds_sync();
+            if (pos16) {
+                if (lane < 48u) store16_wt<NT>(gp + lane * 4, reinterpret_cast<const float4 *>(lp)[lane]);
+            } else {
+                for (int i = (int)lane; i < tc.rows * 3; i += WAVE) gp[i] = lp[i];
+            }
+            wave_lds_sync(); // the stage is free for the next target
+        });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fan-out FK: T <= 4 targets whose root->target chains share (almost) nothing — the fingertips of a hand that hang
 // off a common palm (Allegro, TriFinger).  The merged walk above makes ONE lane compute all T chains of a sample
@@ -234,6 +283,36 @@ __global__ void __launch_bounds__(WAVE * 4)
 } // namespace drm
 
 using namespace drm;
+
+extern "C" int drm_fk_links(const drm_walk *w, const float *q, int64_t B, int32_t n_targets, float *pos, float *quat, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !pos || !quat) return fail(DRM_ERR_INVALID, "q / pos / quat must not be NULL");
+    if (B < 0 || n_targets < 1) return fail(DRM_ERR_INVALID, "negative batch or no targets");
+    if (n_targets > w->n_ops) return fail(DRM_ERR_INVALID, "more targets than ops in the walk");
+    if (B == 0) return DRM_OK;
+    if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
+    const int n = w->n_dofs, T = n_targets;
+    const bool fan = (w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2 && w->n_segments <= DRM_MAX_SEGMENTS && segments_ok(w);
+    TreeArgs a = tree_args(w, false);
+    if (!fan) { a.n_segments = 1; a.prefix_end = 0; }
+    const int K = fan ? a.n_segments : 1;
+    const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + w->n_slots * 12 * WAVE + K * WAVE * 3);
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+    const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+    hipStream_t s = (hipStream_t)stream;
+    if (stream_past_llc(B * 28 * T)) {
+        rc = ensure_lds_tree(fk_tree_links_kernel<true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fk_tree_links_kernel<true>, dim3((unsigned)tiles), dim3(WAVE * K), lds, s, a, q, B, pos, quat, div_magic(n), align, (int)fan);
+    } else {
+        rc = ensure_lds_tree(fk_tree_links_kernel<false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fk_tree_links_kernel<false>, dim3((unsigned)tiles), dim3(WAVE * K), lds, s, a, q, B, pos, quat, div_magic(n), align, (int)fan);
+    }
+    return launched();
+}
 
 extern "C" int drm_fk_fanout(const drm_walk *chains, int32_t n_chains, const float *q, int64_t B, float *pos, float *quat,
                              void *stream) {

@@ -881,6 +881,14 @@ class DifferentiableRobotModel(torch.nn.Module):
         wanted = set(int(i) for i in link_idxs if i != 0)
         ordered = [i for i in self._spec.preorder() if i in wanted]
         if ordered:
+            dw = self._get_walk(("fk", tuple(ordered)), targets=ordered) if len(ordered) > 4 else None
+            if dw is not None and not (torch.is_grad_enabled() and (q.requires_grad or self._ops_f(dw).requires_grad)):
+                # no graph to build and many links: link-major outputs (drm_fk_links) — every link's poses a contiguous array
+                self._require_device()
+                pos, quat = backend.fk_links(dw.program, self._ops_f(dw), dw.ops_i, q, len(ordered), self._n_dofs)
+                for k, i in enumerate(ordered):
+                    out[i] = (pos[k], quat[k])
+                return out
             pos, quat = self._fk_targets(q, ordered)
             for k, i in enumerate(ordered):
                 out[i] = (pos[:, k], quat[:, k])

@@ -203,6 +203,17 @@ int drm_fk(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets,
            float *pos, float *quat, void *stream);
 
 /*
+ * Forward kinematics of T target links with LINK-MAJOR outputs: every link's poses a contiguous array.
+ * Replaces DifferentiableRobotModel.compute_forward_kinematics_all_links (robot_model.py:197-221), which hands out one
+ * (pos [B, 3], quat [B, 4]) pair per link name.
+ *   q    [B, n]
+ *   pos  [T, B, 3]   link t's positions are pos + t * B * 3
+ *   quat [T, B, 4]   xyzw
+ * Target t is the op whose DRM_OPI_OUT == t (any order).  A walk with DRM_WALK_FK_FAN is fanned out over wavefronts.
+ */
+int drm_fk_links(const drm_walk *walk, const float *q, int64_t B, int32_t n_targets, float *pos, float *quat, void *stream);
+
+/*
  * drm_fk for 2 .. 4 targets whose root->target chains are (nearly) disjoint — the fingertips of a hand: `chains[t]`
  * is the single-target walk of target t (all with the same capacity and n_dofs, no branch points); a block of T
  * wavefronts owns 64 samples and wavefront t walks only chain t (the "per-link fan-out" of the parent-index tree).

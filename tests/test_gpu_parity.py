@@ -680,8 +680,9 @@ def test_inverse_dynamics_backward_of_an_arm_that_carries_a_hand(robot, compat):
 
 def test_all_links_fk_beyond_the_infinity_cache():
     """compute_forward_kinematics_all_links of a 29-link robot at 2^19 samples: 411 MB of poses, so the many-target kernel
-    (fk_tree_groups_kernel: outputs leave eight slots at a time) takes its `nt` store path; rows from the start, the middle and
-    the ragged end against the fp64 oracle, and every row of the launch identical to the same rows launched as a small batch."""
+    (fk_tree_links_kernel: link-major outputs, a link's 64 poses of a tile one run) takes its `nt` store path; rows from the start,
+    the middle and the ragged end against the fp64 oracle, and every row of the launch identical to the same rows launched as a
+    small batch."""
     m = load_model("iiwa7_allegro", "cuda")
     B = (1 << 19) + 37
     q, _, _ = sample_states(m, B, seed=61)
@@ -697,6 +698,29 @@ def test_all_links_fk_beyond_the_infinity_cache():
         assert max_err(host(p[rows]), op[:, i]) <= TOL_POS["atol"], name
         ok, _ = quat_close(host(r[rows]), oq[:, i], TOL_QUAT["atol"])
         assert ok, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["panda", "allegro_left", "iiwa7_allegro", "fetch", "trifinger_edu"])
+@pytest.mark.parametrize("B", [1, 63, 64 * 5, 64 * 3 + 2, 4099])
+def test_link_major_fk_is_the_sample_major_fk_transposed(robot, B):
+    """drm_fk_links (pos [T, B, 3], quat [T, B, 4]; fanned out over wavefronts where the walk splits behind a hub) against drm_fk
+    on the same walk (pos [B, T, 3]: the grouped / whole-tile kernels) — the same poses bit for bit, any batch size (B not a
+    multiple of 4 takes the 4-byte position stores), and each link's arrays contiguous."""
+    from differentiable_robot_model_amd import backend
+    m = load_model(robot, "cuda")
+    q, _, _ = sample_states(m, B, seed=B)
+    dq = dev(q)
+    idx = [i for i in m._spec.preorder() if i != 0]
+    dw = m._get_walk(("fk", tuple(idx)), targets=idx)
+    p1, r1 = backend.fk(dw.program, m._ops_f(dw), dw.ops_i, dq, len(idx), m._n_dofs)
+    p2, r2 = backend.fk_links(dw.program, m._ops_f(dw), dw.ops_i, dq, len(idx), m._n_dofs)
+    assert p2.shape == (len(idx), B, 3) and r2.shape == (len(idx), B, 4)
+    assert torch.equal(p2.permute(1, 0, 2), p1) and torch.equal(r2.permute(1, 0, 2), r1)
+    poses = m.compute_forward_kinematics_all_links(dq)
+    for k, i in enumerate(idx):
+        p, r = poses[m._bodies[i].name]
+        assert p.is_contiguous() and r.is_contiguous() and torch.equal(p, p2[k]) and torch.equal(r, r2[k])
 
 
 @pytest.mark.gpu
