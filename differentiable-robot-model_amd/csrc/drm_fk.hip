@@ -55,6 +55,9 @@ __global__ void __launch_bounds__(WAVE)
 // the walk to the next.  16-byte sc1 stores (nt beyond the Infinity Cache); positions fall back to 4-byte stores when 12 T is
 // not a multiple of 16.
 // LDS: [ table ][ q : 64 (n|1) ][ pos group : 64 x 25 ][ quat group : 64 x 33 ][ slots : n_slots * 12 * 64 ]
+#ifndef DRM_FK_LINKS_FAN_TILES
+#define DRM_FK_LINKS_FAN_TILES 4096 /* drm_fk_links: tiles up to which a walk with a shared part is fanned out over wavefronts */
+#endif
 #ifndef DRM_FK_GROUP
 #define DRM_FK_GROUP 8
 #endif
@@ -293,13 +296,18 @@ extern "C" int drm_fk_links(const drm_walk *w, const float *q, int64_t B, int32_
     if (B == 0) return DRM_OK;
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int n = w->n_dofs, T = n_targets;
-    const bool fan = (w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2 && w->n_segments <= DRM_MAX_SEGMENTS && segments_ok(w);
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
+    // A wavefront per run of sub-trees behind the hub: every wavefront repeats the ops in front of the hub, and with ~8 KB of LDS
+    // per tile the kernel is bound by instruction issue once the device is full (iiwa7 + Allegro at 2^20: 248 us fanned out,
+    // eight of a wavefront's thirteen ops repeated) — so a walk with a shared part is fanned out only while the tiles do not
+    // fill the device anyway; a hand (hub = the root, nothing repeated) always is.
+    const bool fan = (w->shape & DRM_WALK_FK_FAN) && w->n_segments >= 2 && w->n_segments <= DRM_MAX_SEGMENTS && segments_ok(w) &&
+                     (w->prefix_end == 0 || tiles <= DRM_FK_LINKS_FAN_TILES);
     TreeArgs a = tree_args(w, false);
     if (!fan) { a.n_segments = 1; a.prefix_end = 0; }
     const int K = fan ? a.n_segments : 1;
     const size_t lds = sizeof(float) * (size_t)(table_lds_floats(a.n_ops) + round4(WAVE * pad_odd(n)) + w->n_slots * 12 * WAVE + K * WAVE * 3);
-    const int64_t tiles = (B + WAVE - 1) / WAVE;
-    if (tiles > 0x7fffffffLL) return fail(DRM_ERR_UNSUPPORTED, "batch too large");
     const uint32_t align = al16(q, AL_Q) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
     hipStream_t s = (hipStream_t)stream;
     if (stream_past_llc(B * 28 * T)) {
