@@ -44,7 +44,7 @@ _lock = threading.Lock()
 EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
            "drm_fk_backward_scratch_floats", "drm_crba", "drm_rnea_backward",
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
-           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
+           "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats")
 
@@ -76,6 +76,8 @@ def load_library(path: str = None):
         lib.drm_fk_links.argtypes = [wp, vp, i64, i32, vp, vp, vp]
         lib.drm_fk_fanout.restype = ctypes.c_int
         lib.drm_fk_fanout.argtypes = [wp, i32, vp, i64, vp, vp, vp]
+        lib.drm_fk_fanout_links.restype = ctypes.c_int
+        lib.drm_fk_fanout_links.argtypes = [wp, i32, vp, i64, vp, vp, vp]
         lib.drm_fk_jacobian.restype = ctypes.c_int
         lib.drm_fk_jacobian.argtypes = [wp, vp, i64, vp, vp, vp, vp, vp]
         lib.drm_rnea.restype = ctypes.c_int
@@ -225,18 +227,20 @@ def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     return pos, quat
 
 
-def fk_fanout(chains, q, n_dofs: int):
-    """FK of 2..4 targets with (nearly) disjoint chains: ``chains`` = [(prog, ops_f, ops_i)] per target."""
+def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
+    """FK of 2..4 targets with (nearly) disjoint chains: ``chains`` = [(prog, ops_f, ops_i)] per target.  pos [B, T, 3],
+    quat [B, T, 4]; with ``link_major`` pos [T, B, 3], quat [T, B, 4] (every target's poses a contiguous array)."""
     lib = load_library()
     q = _dev_f32(q, "q", n_dofs)
     B, T = q.shape[0], len(chains)
-    pos = torch.empty(B, T, 3, device=q.device, dtype=torch.float32)
-    quat = torch.empty(B, T, 4, device=q.device, dtype=torch.float32)
+    pos = torch.empty((T, B, 3) if link_major else (B, T, 3), device=q.device, dtype=torch.float32)
+    quat = torch.empty((T, B, 4) if link_major else (B, T, 4), device=q.device, dtype=torch.float32)
     if B == 0:
         return pos, quat
     walks = (DrmWalk * T)(*[_walk_struct(p, f.detach(), i, n_dofs) for p, f, i in chains])
     with torch.cuda.device(q.device):
-        _check(lib.drm_fk_fanout(walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)))
+        _check((lib.drm_fk_fanout_links if link_major else lib.drm_fk_fanout)(
+            walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)))
     return pos, quat
 
 

@@ -235,9 +235,13 @@ struct FanChains {
 };
 
 // LDS (static): four chain tables, then the block's [64, 3T] position and [64, 4T] quaternion tiles (linear images)
-template <int CAP, int USED, int TRIG = USED>
+// LINKS: link-major outputs, pos [T, B, 3] / quat [T, B, 4] (drm_fk_fanout_links) — a wavefront writes ITS chain's 64 poses as
+// contiguous runs (the quaternion a 16-byte store per lane straight from registers, the position through its own 64 x 3 stage):
+// no tile shared by the block, no block barrier, no second pass over LDS.
+template <int CAP, int USED, int TRIG = USED, bool LINKS = false>
 __global__ void __launch_bounds__(WAVE * 4)
-    fk_fan_chain_kernel(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat, int T, int n, FanChains tab) {
+    fk_fan_chain_kernel(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat, int T, int n, int64_t B,
+                        FanChains tab) {
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE;
     __shared__ __attribute__((aligned(16))) float smem[4 * C_FLOATS + WAVE * 12 + WAVE * 16];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -263,6 +267,20 @@ __global__ void __launch_bounds__(WAVE * 4)
     PoseP ee;
     auto none = [](int, const f2 (&)[3]) {};
     chain_walk<CAP, USED, false, decltype(none), TRIG>(lc, qv, cs, sn, pris, ee, none);
+    if constexpr (LINKS) {
+        // (the launcher takes this form only for 16-byte aligned outputs and B a multiple of 4: every link's arrays are aligned)
+        float *st = lp + wave * (WAVE * 3); // 4 x 192 floats of the 28 x 64 the tiles of the other form take
+        st[lane * 3 + 0] = ee.B[0][1]; st[lane * 3 + 1] = ee.B[1][1]; st[lane * 3 + 2] = ee.B[2][1];
+        wave_lds_sync();
+        if (lane < 48u) store16_wt(reinterpret_cast<float4 *>(pos + ((int64_t)wave * B + b0) * 3) + lane, reinterpret_cast<const float4 *>(st)[lane]);
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        unpermute(perm, E.R);
+        quat_xyzw(E.R, qt);
+        store16_wt(reinterpret_cast<float4 *>(quat + ((int64_t)wave * B + b0) * 4) + lane, make_float4(qt[0], qt[1], qt[2], qt[3]));
+        return;
+    }
     {
         float *p = lp + (lane * T + wave) * 3;
         p[0] = ee.B[0][1]; p[1] = ee.B[1][1]; p[2] = ee.B[2][1];
@@ -408,7 +426,7 @@ int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos
 #endif
 }
 
-int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s) {
+int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s, bool links) {
 #ifdef DRM_NO_CHAIN_KERNEL
     return 0;
 #else
@@ -429,8 +447,10 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
     int n_tiles = (int)(B / WAVE);
     int64_t done = 0;
     // the instantiation that walks exactly the longest chain's ops (shorter chains of the same launch walk identity padding)
+    if (links && (B & 3)) return 0; // (a link's [B, 3] array starts 12 B t bytes in)
+    const int64_t Btot = B;
 #ifndef DRM_NO_FAN2_KERNEL
-    if (revolute && n_tiles / 2 >= DRM_FAN2_MIN_TILES) { // pairs of tiles: two samples per lane
+    if (!links && revolute && n_tiles / 2 >= DRM_FAN2_MIN_TILES) { // pairs of tiles: two samples per lane
         const int n2 = n_tiles / 2;
 #define FAN2(C, U) hipLaunchKernelGGL((fk_fan_chain2_kernel<C, U>), dim3((unsigned)n2), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab)
         if (cap == 4) FAN2(4, 4);
@@ -447,8 +467,9 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
 #endif
     // ... and, where the last walked op of every chain is fixed (a fingertip frame; identity padding of a shorter chain), the form
     // that spends no sincos and no joint rotation on it
-#define FAN(C, U) do { if (tail_fixed(U)) hipLaunchKernelGGL((fk_fan_chain_kernel<C, U, U - 1>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab); \
-                       else hipLaunchKernelGGL((fk_fan_chain_kernel<C, U>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, q, pos, quat, T, n, tab); } while (0)
+#define FAN_(C, U, TR, LK) hipLaunchKernelGGL((fk_fan_chain_kernel<C, U, TR, LK>), dim3((unsigned)n_tiles), dim3(WAVE * T), 0, s, q, pos, quat, T, n, Btot, tab)
+#define FAN(C, U) do { if (links) { if (tail_fixed(U)) FAN_(C, U, U - 1, true); else FAN_(C, U, U, true); }                      \
+                       else { if (tail_fixed(U)) FAN_(C, U, U - 1, false); else FAN_(C, U, U, false); } } while (0)
     auto tail_fixed = [&](int used) {
 #ifdef DRM_NO_FAN_TAIL
         return false;
@@ -463,6 +484,7 @@ int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int6
     else if (longest == 7) FAN(8, 7);
     else FAN(8, 8);
 #undef FAN
+#undef FAN_
     return done + (int64_t)n_tiles * WAVE;
 #endif
 }

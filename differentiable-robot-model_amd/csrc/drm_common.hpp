@@ -364,7 +364,7 @@ void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, co
 int64_t launch_chain_fk_jacobian(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, float *lin, float *ang,
                                  hipStream_t s);
 int64_t launch_chain_fk(const drm_walk *w, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
-int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s);
+int64_t launch_fk_fan_chains(const drm_walk *chains, int T, const float *q, int64_t B, float *pos, float *quat, hipStream_t s, bool links = false);
 
 // drm_arm_hand.hip: inverse dynamics of DRM_WALK_ARM_HAND walks whose (P, K, L) is compiled in; rows covered, 0 = not taken
 int64_t launch_rnea_arm_hand(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,

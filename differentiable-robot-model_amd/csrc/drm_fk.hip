@@ -447,3 +447,32 @@ extern "C" int drm_fk(const drm_walk *w, const float *q, int64_t B, int32_t n_ta
                        div_magic(4 * T), align);
     return launched();
 }
+
+extern "C" int drm_fk_fanout_links(const drm_walk *chains, int32_t n_chains, const float *q, int64_t B, float *pos, float *quat,
+                                   void *stream) {
+    if (!chains || n_chains < 2 || n_chains > 4) return fail(DRM_ERR_INVALID, "fan-out FK takes 2 to 4 chains");
+    if (!q || !pos || !quat) return fail(DRM_ERR_INVALID, "q / pos / quat must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    for (int t = 0; t < n_chains; ++t) {
+        int rc = check_walk(chains + t);
+        if (rc) return rc;
+        if (chains[t].capacity != chains[0].capacity || chains[t].n_dofs != chains[0].n_dofs || chains[t].n_slots != 0)
+            return fail(DRM_ERR_INVALID, "fan-out chains must share capacity and n_dofs and have no branch points");
+    }
+    if (B == 0) return DRM_OK;
+    const int n = chains[0].n_dofs;
+    // full tiles: a wavefront per chain, each writing its link's arrays; what is left (a ragged tail; everything when the fan-out
+    // kernel does not take the call): one single-target launch per chain into the same link-major arrays
+    int64_t done = launch_fk_fan_chains(chains, n_chains, q, B, pos, quat, (hipStream_t)stream, true);
+    if (done > 0) {
+        int rc = launched();
+        if (rc) return rc;
+    }
+    if (done < B)
+        for (int t = 0; t < n_chains; ++t) {
+            int rc = drm_fk(chains + t, q + done * n, B - done, 1, pos + ((int64_t)t * B + done) * 3, quat + ((int64_t)t * B + done) * 4, stream);
+            if (rc) return rc;
+        }
+    return DRM_OK;
+}
+

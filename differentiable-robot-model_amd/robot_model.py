@@ -881,11 +881,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         wanted = set(int(i) for i in link_idxs if i != 0)
         ordered = [i for i in self._spec.preorder() if i in wanted]
         if ordered:
-            dw = self._get_walk(("fk", tuple(ordered)), targets=ordered) if len(ordered) > 4 else None
+            dw = self._get_walk(("fk", tuple(ordered)), targets=ordered) if len(ordered) > 1 else None
             if dw is not None and not (torch.is_grad_enabled() and (q.requires_grad or self._ops_f(dw).requires_grad)):
-                # no graph to build and many links: link-major outputs (drm_fk_links) — every link's poses a contiguous array
+                # no graph to build: link-major outputs — every link's poses a contiguous array.  A few links at the ends of
+                # (nearly) disjoint chains, the fingertips of a hand: a wavefront per chain (drm_fk_fanout_links); else one walk
+                # over all of them (drm_fk_links)
                 self._require_device()
-                pos, quat = backend.fk_links(dw.program, self._ops_f(dw), dw.ops_i, q, len(ordered), self._n_dofs)
+                fan = self._fanout_chains(ordered, dw)
+                if fan is not None:
+                    pos, quat = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs, link_major=True)
+                else:
+                    pos, quat = backend.fk_links(dw.program, self._ops_f(dw), dw.ops_i, q, len(ordered), self._n_dofs)
                 for k, i in enumerate(ordered):
                     out[i] = (pos[k], quat[k])
                 return out
@@ -934,6 +940,16 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.shape[1] == self._n_dofs
         cols = self._fk_links(q, list(range(len(self._bodies))))
         return {self._bodies[i].name: cols[i] for i in range(len(self._bodies))}
+
+    @tensor_check
+    def compute_forward_kinematics_links(self, q: torch.Tensor, link_names: List[str]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+        """{link name: (pos [B, 3], quat xyzw [B, 4])} of the NAMED links in one launch — what calling
+        compute_forward_kinematics (robot_model.py:223-248) once per link returns, e.g. for the fingertips of a hand (BASELINE
+        configuration 4).  Not in the reference (which recomputes every link per call, robot_model.py:139-195); every tensor is
+        contiguous.  Differentiable like compute_forward_kinematics."""
+        idxs = [self._name_to_idx_map[name] for name in link_names]
+        cols = self._fk_links(q, idxs)
+        return {name: cols[i] for name, i in zip(link_names, idxs)}
 
     @tensor_check
     def compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False

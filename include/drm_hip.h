@@ -222,6 +222,12 @@ int drm_fk_links(const drm_walk *walk, const float *q, int64_t B, int32_t n_targ
 int drm_fk_fanout(const drm_walk *chains, int32_t n_chains, const float *q, int64_t B, float *pos, float *quat,
                   void *stream);
 
+/* The same with LINK-MAJOR outputs, pos [T, B, 3] / quat [T, B, 4] (chain t's poses a contiguous array, as drm_fk_links): each
+ * wavefront writes its own chain's arrays, the block shares no tile.  What a caller of compute_forward_kinematics for several
+ * fingertips wants: T (pos [B, 3], quat [B, 4]) pairs (robot_model.py:223-248 called once per link). */
+int drm_fk_fanout_links(const drm_walk *chains, int32_t n_chains, const float *q, int64_t B, float *pos, float *quat,
+                        void *stream);
+
 /*
  * FK + geometric Jacobian of ONE target link; the walk is the root->link chain
  * and its last op is the target.

@@ -724,6 +724,39 @@ def test_link_major_fk_is_the_sample_major_fk_transposed(robot, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot,tips", [("allegro_left", ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]),
+                                        ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"])])
+@pytest.mark.parametrize("B", [1, 63, 64 * 4, 64 * 3 + 2, 64 * 2 + 8, 4100])
+def test_fingertips_in_one_call_link_major(robot, tips, B):
+    """compute_forward_kinematics_links (BASELINE configuration 4 as one API call): a wavefront per fingertip chain writing its own
+    link's contiguous arrays (drm_fk_fanout_links; the ragged tail and batches that are not a multiple of 4 through single-target
+    launches into the same arrays) — equal to compute_forward_kinematics called per link (bit for bit where the same kernels run) and to the oracle."""
+    m = load_model(robot, "cuda")
+    q, _, _ = sample_states(m, B, seed=7 * B)
+    dq = dev(q)
+    got = m.compute_forward_kinematics_links(dq, tips)
+    idx = [m._name_to_idx_map[t] for t in tips]
+    rp, rq = Oracle(m._spec).fk(q.astype(np.float64), idx, np.float64)
+    for k, name in enumerate(tips):
+        p, r = got[name]
+        assert p.shape == (B, 3) and r.shape == (B, 4) and p.is_contiguous() and r.is_contiguous()
+        p1, r1 = m.compute_forward_kinematics(dq, name)
+        if B % 4 == 0:
+            assert torch.equal(p, p1) and torch.equal(r, r1), name
+        else:   # (a link's array is then not 16-byte aligned: the loop kernel writes it, same poses to rounding)
+            assert max_err(host(p), host(p1)) <= 1e-6 and max_err(host(r), host(r1)) <= 1e-6, name
+        assert max_err(host(p), rp[:, k]) <= TOL_POS["atol"]
+        assert quat_close(host(r), rq[:, k], TOL_QUAT["atol"])[0]
+    # under autograd the same call builds the graph (sample-major walk behind it)
+    tq = dq.clone().requires_grad_(True)
+    out = m.compute_forward_kinematics_links(tq, tips)
+    sum(p.sum() + r.sum() for p, r in out.values()).backward()
+    assert tq.grad is not None and torch.isfinite(tq.grad).all()
+    for name in tips:
+        assert max_err(host(out[name][0].detach()), host(got[name][0])) <= 1e-6
+
+
+@pytest.mark.gpu
 def test_config2_iiwa_fk_jacobian_full_batch_vs_oracle():
     """BASELINE configuration 2 at full size: KUKA iiwa 7-DoF, batch 65 536, FK + end-effector Jacobian — EVERY row against
     the fp64 oracle (the oracle does 65 536 rows in well under a second)."""

@@ -102,6 +102,14 @@ if fan is not None:
                                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(fan_fk)
     print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)   fan-out kernel (one wavefront per finger)" % (us, 65536 * 176 / us / 1e3))
+    pl = torch.empty(4, 65536, 3, device="cuda"); rl = torch.empty(4, 65536, 4, device="cuda")
+    def fan_fk_links():
+        backend._check(backend.load_library().drm_fk_fanout_links(walks, len(chains), qa.data_ptr(), 65536, pl.data_ptr(), rl.data_ptr(),
+                                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    us = graph_time(fan_fk_links)
+    print("fk allegro 4 tips B=   65536 %9.2f us  %7.1f GB/s (176 B/eval)   fan-out kernel, link-major outputs (drm_fk_fanout_links)" % (us, 65536 * 176 / us / 1e3))
+    us = graph_time(lambda: ma.compute_forward_kinematics_links(qa, ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]))
+    print("fk allegro 4 tips B=   65536 %9.2f us  the same through compute_forward_kinematics_links" % us)
 # whole-tree dynamics of a branching robot through the generic (table-driven) kernels: Allegro, 21 links, 16 DoF
 for B in [s for s in sizes if s <= (1 << 20)]:
     qa, qda, qdda = (t.cuda() for t in sample(ma, B))
