@@ -72,6 +72,12 @@ for d, name in (("prof_stats_eager", "_bench_eager_kernel_stats.csv"), ("prof_ov
     st = glob.glob(os.path.join(OUT, d, "*", "*_kernel_stats.csv"))
     if st:
         shutil.copy(st[0], os.path.join(prof, tag + name))
+st = glob.glob(os.path.join(OUT, "prof_api", "*", "*_kernel_stats.csv"))
+if st:
+    with open(st[0]) as f, open(os.path.join(prof, tag + "_probe_api_rocprof_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or "drm::" in line:
+                g.write(line)
 st = glob.glob(os.path.join(OUT, "prof_robots", "*", "*_kernel_stats.csv"))
 if st:
     with open(st[0]) as f, open(os.path.join(prof, tag + "_probe_robots_rocprof_stats.csv"), "w") as g:

@@ -45,6 +45,7 @@ python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
 python $ROOT/tools/ab_rnea.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_rnea.txt
 for b in 1048576 65536; do python $ROOT/tools/probe_api.py $b 2>&1 | grep "B="; done > $OUT/probe_api.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_api -- python $ROOT/tools/probe_api.py 1048576 > $OUT/prof_api.log 2>&1
 python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
 if [ -x $ROOT/tools/ubench/metric_lab ]; then
   $ROOT/tools/ubench/metric_lab 1048576 floors > $OUT/io_floors_2p20.txt 2>&1
