@@ -155,6 +155,23 @@ class HipBinding(object):
                                     self._stream()))
         return pos, quat
 
+    def fk_all_links(self, q):
+        """compute_forward_kinematics_all_links (robot_model.py:197-221): {link name: (pos [B,3], quat_xyzw [B,4])} — one
+        drm_fk_links launch; its link-major outputs make every dict entry a contiguous array."""
+        q = self._in(q)
+        B = q.shape[0]
+        order = [i for i in self.spec.preorder() if i != 0]          # targets in walk order
+        pos, quat = q.new_empty(len(order), B, 3), q.new_empty(len(order), B, 4)
+        w = self.walk(("links",), targets=order)[0]
+        self._check(self.lib.drm_fk_links(ctypes.byref(w), self._p(q), ctypes.c_int64(B), ctypes.c_int32(len(order)), self._p(pos),
+                                          self._p(quat), self._stream()))
+        root_quat = q.new_zeros(B, 4)
+        root_quat[:, 3] = 1.0
+        out = {name: (q.new_zeros(B, 3), root_quat) for name, i in self.names.items() if i == 0}
+        slot = {i: k for k, i in enumerate(order)}
+        out.update({name: (pos[slot[i]], quat[slot[i]]) for name, i in self.names.items() if i != 0})
+        return out
+
     def jacobian(self, q, link_name):
         """compute_endeffector_jacobian (robot_model.py:626-667): (lin_jac [B,3,n], ang_jac [B,3,n])."""
         idx = self.names[link_name]

@@ -71,5 +71,12 @@ def test_gpu_binding_calls_the_c_abi(robot):
     assert np.abs(pos.cpu().numpy() - rp).max() <= TOL_POS["atol"] and quat_close(quat.cpu().numpy(), rq, TOL_QUAT["atol"])[0]
     assert np.abs(lin.cpu().numpy() - rl).max() <= TOL_JAC["atol"] and np.abs(ang.cpu().numpy() - ra).max() <= TOL_JAC["atol"]
     assert np.allclose(tau.cpu().numpy(), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+    every = b.fk_all_links(dev(q))                                            # -> drm_fk_links
+    assert set(every) == {body.name for body in m._bodies}
+    ap, aq = orc.fk(q64, list(range(len(m._bodies))), np.float64)
+    for i, body in enumerate(m._bodies):
+        p, r = every[body.name]
+        assert p.is_contiguous() and np.abs(p.cpu().numpy() - ap[:, i]).max() <= TOL_POS["atol"], body.name
+        assert quat_close(r.cpu().numpy(), aq[:, i], TOL_QUAT["atol"])[0], body.name
     root_pos, root_quat = b.fk(dev(q), m._bodies[0].name)
     assert not root_pos.any() and torch.equal(root_quat[:, 3], torch.ones(193, device="cuda"))
