@@ -945,8 +945,9 @@ class DifferentiableRobotModel(torch.nn.Module):
     def compute_forward_kinematics_links(self, q: torch.Tensor, link_names: List[str]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
         """{link name: (pos [B, 3], quat xyzw [B, 4])} of the NAMED links in one launch — what calling
         compute_forward_kinematics (robot_model.py:223-248) once per link returns, e.g. for the fingertips of a hand (BASELINE
-        configuration 4).  Not in the reference (which recomputes every link per call, robot_model.py:139-195); every tensor is
-        contiguous.  Differentiable like compute_forward_kinematics."""
+        configuration 4).  Not in the reference (which recomputes every link per call, robot_model.py:139-195).  Without a graph to
+        build every tensor is a contiguous array of its own (link-major launch); under autograd they are columns of one
+        [B, T, .] result, differentiable like compute_forward_kinematics."""
         idxs = [self._name_to_idx_map[name] for name in link_names]
         cols = self._fk_links(q, idxs)
         return {name: cols[i] for name, i in zip(link_names, idxs)}
