@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="metric config: all-gather the outputs over RCCL inside every step")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` legs (BASELINE.json configurations 2-5 + eager API overhead, each with the reference "
+                         "timed beside it; N = 1 only, ~40 s)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only; ~30 s)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
@@ -205,7 +208,7 @@ def measured_traffic(args, batch):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="drm_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-               os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--steps", "50", "--warmup", "5",
+               os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--no-configs", "--steps", "50", "--warmup", "5",
                "--batch", str(batch), "--robot", args.robot]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
@@ -443,6 +446,11 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
                              "the bytes takes 2.9 us = 0.63, profiles/r02_metric_lab.txt); genuine HBM streaming is in "
                              "roofline_large"},
     }
+    if graphed and gathered is None:
+        line["fixed_overhead_us"] = {
+            "value": 9.0, "note": "one hipGraph launch carries ~9 us between its start and its first kernel on this stack; a region "
+            "of K steps pays it once: ms_per_step = kernel + gaps + 9 us / K (0.45 us per step at the driver's --steps 20, 0.045 "
+            "at 200); `roofline.steady_state` is the same launch in a region of 200"}
     if graphed and K < 200 and gathered is None:
         # a short timed region (the round driver passes --steps 20: ~80 us of kernels) carries the latency of one graph
         # launch, ~9 us between the start event and the first kernel, in its average; the same launches in a region of 200
@@ -460,8 +468,24 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         plan.launch()
         torch.cuda.synchronize()
         names = ("pos", "quat", "lin_jac", "ang_jac")
-        line["cpu_baseline"]["reference"] = reference_cpu(
+        ref = line["cpu_baseline"]["reference"] = reference_cpu(
             args.robot, link, q.cpu().numpy(), gpu_outputs={k: t.cpu().numpy() for k, t in zip(names, plan.outputs())})
+        if "one_thread" in ref:   # the CPU baseline of record: the unmodified reference's vectorised math on ONE thread (its
+            # many-thread runs are slower on [B, 3]-sized ops, and the OpenMP port above swings 10x between passes on a shared host)
+            one = ref["one_thread"]["tensor_only"]
+            line["cpu_baseline"]["of_record"] = {
+                "value": one["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "reference",
+                "sample": "compute_endeffector_jacobian of the unmodified reference on all %d rows, get_quaternion stubbed "
+                          "(tensor-only), one thread, min of %d" % (one["rows"], ref.get("reps", 3)),
+                "gpu_over_cpu": line["value"] / one["evals_per_s"]}
+    if rank == 0 and world == 1 and not args.no_configs and os.environ.get("DRM_BENCH_CHILD") != "1":
+        del plan
+        torch.cuda.empty_cache()
+        from bench_configs import run_config_legs
+        try:
+            line["configs"] = run_config_legs(device, with_reference=not args.no_cpu_baseline)
+        except Exception as err:   # the extra legs must never take the metric line down with them
+            line["configs"] = {"error": "%s: %s" % (type(err).__name__, err)}
     return line
 
 
@@ -582,7 +606,22 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     bytes_per_eval = 4 * (3 * n + n + 7)                                 # q qd qdd in; tau pos quat out = 140 B
     launch_s = dev_compute / K
     achieved = bytes_per_eval * rows / launch_s / 1e9
-    return {
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the UNMODIFIED reference on this box's host cores in this run, on a bounded sample of rank 0's shard (its RNEA runs
+        # ~5e4 evals/s on one core): compute_endeffector_jacobian / compute_inverse_dynamics timings + the HIP path's deviation
+        # from the reference's own tau / pos / quat on the first rows
+        sample = min(rows, 32768)
+        compute()
+        torch.cuda.synchronize()
+        got = {k: t[:sample].cpu().numpy() for k, t in zip(("tau", "pos", "quat"), plan.outputs())}
+        cpu = reference_cpu(args.robot, link, q[:sample].cpu().numpy(), qd[:sample].cpu().numpy(), qdd[:sample].cpu().numpy(),
+                            gpu_outputs=got, public_rows=2048)
+        if "one_thread" in cpu and "inverse_dynamics" in cpu["one_thread"]:
+            cpu = {"value": cpu["one_thread"]["inverse_dynamics"]["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "reference",
+                   "sample": "compute_inverse_dynamics of the unmodified reference on the first %d rows of rank 0's shard, one "
+                             "thread, min of 3 (FK not included: its tensor part is in `reference`)" % sample, "reference": cpu}
+    line = {
         "metric": "FK + RNEA evals/sec, Panda 7-DoF, global batch 2^20 sharded over the GPUs (BASELINE.json configuration 3)",
         "value": G * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -604,6 +643,12 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
                      "note": "the fused kernel alone (hipGraph of K launches, HIP events); RNEA sits at the vector-FP32 / HBM "
                              "ridge (2.6 kflop per 140 B), see DESIGN.md"},
     }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+        ref = cpu.get("reference", cpu)
+        if "gpu_vs_reference_max_abs" in ref:
+            line["gpu_vs_reference_max_abs"] = ref["gpu_vs_reference_max_abs"]
+    return line
 
 
 if __name__ == "__main__":

@@ -34,12 +34,13 @@ CASES = [
 ]
 
 
-def main():
+def generate(cases):
+    """The fixture dictionary for `cases` (also driven by make_golden_tiles.py with 192-row batches)."""
     rm = ref_import.import_reference()
     from differentiable_robot_model.rigid_body_params import UnconstrainedTensor
     torch.set_num_threads(1)
     out = {}
-    for name, rel, targets, learn, B in CASES:
+    for name, rel, targets, learn, B in cases:
         torch.manual_seed(0)
         np.random.seed(0)
         path = os.path.join(ref_import.reference_data_dir(), rel)
@@ -73,7 +74,11 @@ def main():
                 out["%s/init/%s/%s" % (name, link, pname)] = p.detach().numpy()
                 out["%s/grad/%s/%s" % (name, link, pname)] = p.grad.numpy()
         print("%-20s B=%3d loss=%.6f |grad_q|max=%.3e" % (name, B, loss.item(), q.grad.abs().max().item()))
-    np.savez_compressed(os.path.join(HERE, "golden_grad.npz"), **out)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "golden_grad.npz"), **generate(CASES))
 
 
 if __name__ == "__main__":

@@ -36,12 +36,13 @@ CASES = [
 ]
 
 
-def main():
+def generate(cases):
+    """The fixture dictionary for `cases` (also driven by make_golden_tiles.py with 192-row batches)."""
     rm = ref_import.import_reference()
     import differentiable_robot_model.rigid_body_params as rbp
     torch.set_num_threads(1)
     out = {}
-    for name, rel, learn, B in CASES:
+    for name, rel, learn, B in cases:
         torch.manual_seed(0)
         np.random.seed(0)
         path = os.path.join(ref_import.reference_data_dir(), rel)
@@ -76,7 +77,11 @@ def main():
                     keys.append(key)
         out[name + "/keys"] = np.array(keys)
         print("%-20s B=%3d loss=%.5g  %d parameter tensors  |grad_q|max %.3g" % (name, B, loss.item(), len(keys), np.abs(q.grad.numpy()).max()))
-    np.savez_compressed(os.path.join(HERE, "golden_grad_mass.npz"), **out)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "golden_grad_mass.npz"), **generate(CASES))
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ from make_golden import ROBOTS  # noqa: E402
 BATCH = 48
 
 
-def main():
+def generate(batch, seed_base):
     rm = ref_import.import_reference()
     torch.set_num_threads(1)
     out = {}
@@ -32,11 +32,11 @@ def main():
         lim = model.get_joint_limits()
         lo = np.asarray([j["lower"] for j in lim]); hi = np.asarray([j["upper"] for j in lim])
         n = len(lim)
-        rng = np.random.default_rng(9000 + idx)
-        q = torch.from_numpy((lo + (hi - lo) * rng.random((BATCH, n))).astype(np.float32))
-        qd = torch.from_numpy(rng.uniform(-1.0, 1.0, (BATCH, n)).astype(np.float32))
-        qdd = torch.from_numpy(rng.uniform(-2.0, 2.0, (BATCH, n)).astype(np.float32))
-        f = torch.from_numpy(rng.uniform(-1.0, 1.0, (BATCH, n)).astype(np.float32))
+        rng = np.random.default_rng(seed_base + idx)
+        q = torch.from_numpy((lo + (hi - lo) * rng.random((batch, n))).astype(np.float32))
+        qd = torch.from_numpy(rng.uniform(-1.0, 1.0, (batch, n)).astype(np.float32))
+        qdd = torch.from_numpy(rng.uniform(-2.0, 2.0, (batch, n)).astype(np.float32))
+        f = torch.from_numpy(rng.uniform(-1.0, 1.0, (batch, n)).astype(np.float32))
         for k, v in (("q", q), ("qd", qd), ("qdd", qdd), ("f", f)):
             out["%s/%s" % (name, k)] = v.numpy().copy()
         out[name + "/links"] = np.array(links)
@@ -54,7 +54,11 @@ def main():
                     q, qd, f.clone(), include_gravity=bool(g), use_damping=bool(d)).numpy()
             out[name + "/H"] = model.compute_lagrangian_inertia_matrix(q).numpy()
         print("%-40s n=%2d" % (name, n), flush=True)
-    np.savez_compressed(os.path.join(HERE, "golden_wide.npz"), **out)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "golden_wide.npz"), **generate(BATCH, 9000))
 
 
 if __name__ == "__main__":

@@ -66,7 +66,10 @@ def emu_loss_and_grads(emu, m, q, targets, wants):
 
 @pytest.mark.parametrize("case", CASES)
 def test_emu_backward_vs_reference_autograd(emu, case):
-    g = load_golden_grad()
+    check_emu_backward_vs_reference_autograd(emu, load_golden_grad(), case)
+
+
+def check_emu_backward_vs_reference_autograd(emu, g, case):
     m = learnable_model(g, case)
     targets = [str(t) for t in g[case + "/targets"]]
     q = np.ascontiguousarray(g[case + "/q"])
@@ -126,7 +129,10 @@ def _api_loss(m, q, targets, wants):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_gpu_backward_vs_reference_autograd(case):
-    g = load_golden_grad()
+    check_gpu_backward_vs_reference_autograd(load_golden_grad(), case)
+
+
+def check_gpu_backward_vs_reference_autograd(g, case):
     m = learnable_model(g, case, "cuda")
     targets = [str(t) for t in g[case + "/targets"]]
     q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)

@@ -32,6 +32,10 @@ def test_the_fixture_covers_every_golden_robot():
 @pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_oracle_vs_reference_wide(robot, links, dtype):
+    check_oracle_vs_reference(WIDE, robot, links, dtype)
+
+
+def check_oracle_vs_reference(WIDE, robot, links, dtype):
     m = load_model(robot)
     orc = Oracle(m._spec)
     q, qd, qdd, f = (WIDE["%s/%s" % (robot, k)].astype(dtype) for k in ("q", "qd", "qdd", "f"))
@@ -55,8 +59,18 @@ def test_oracle_vs_reference_wide(robot, links, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
 def test_gpu_vs_reference_wide(robot, links):
+    check_gpu_vs_reference(WIDE, robot, links)
+
+
+def check_gpu_vs_reference(WIDE, robot, links, repeat=1):
+    """`repeat` > 1: the fixture's rows tiled that many times into ONE launch (so that a 192-row fixture reaches kernels that
+    only engage beyond a launch size, e.g. the two-samples-per-lane arm kernels past 1 024 tiles); every copy must meet the
+    reference on its own."""
     m = load_model(robot, "cuda")
-    q, qd, qdd, f = (torch.from_numpy(WIDE["%s/%s" % (robot, k)].copy()).cuda() for k in ("q", "qd", "qdd", "f"))
+    q, qd, qdd, f = (torch.from_numpy(np.tile(WIDE["%s/%s" % (robot, k)], (repeat, 1))).cuda() for k in ("q", "qd", "qdd", "f"))
+    if repeat > 1:
+        WIDE = {k: (np.tile(WIDE[k], (repeat,) + (1,) * (WIDE[k].ndim - 1)) if WIDE[k].dtype == np.float32 else WIDE[k])
+                for k in WIDE.files if k.startswith(robot + "/")}
     host = lambda t: t.cpu().numpy()
     for link in links:
         pos, quat = m.compute_forward_kinematics(q, link)

@@ -131,9 +131,12 @@ def load_golden_grad_mass():
 
 @pytest.mark.parametrize("case", H_GRAD_CASES)
 def test_emu_mass_matrix_backward_vs_reference_autograd(emu, case):
+    check_emu_mass_matrix_backward_vs_reference_autograd(emu, load_golden_grad_mass(), case)
+
+
+def check_emu_mass_matrix_backward_vs_reference_autograd(emu, g, case):
     from test_forward_dynamics import grad_close, learnable_model_fd
     from test_rnea_backward import dynamic_param_mask
-    g = load_golden_grad_mass()
     m, params = learnable_model_fd(g, case)
     q = np.ascontiguousarray(g[case + "/q"])
     B, n = q.shape
@@ -170,8 +173,11 @@ def test_emu_mass_matrix_backward_vs_reference_autograd(emu, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", H_GRAD_CASES)
 def test_gpu_mass_matrix_backward_vs_reference_autograd(case):
+    check_gpu_mass_matrix_backward_vs_reference_autograd(load_golden_grad_mass(), case)
+
+
+def check_gpu_mass_matrix_backward_vs_reference_autograd(g, case):
     from test_forward_dynamics import grad_close, learnable_model_fd
-    g = load_golden_grad_mass()
     m, params = learnable_model_fd(g, case, "cuda")
     q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
     want, weight = (torch.from_numpy(g[case + "/" + k].copy()).cuda() for k in ("want", "weight"))

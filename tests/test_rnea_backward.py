@@ -97,7 +97,10 @@ def emu_loss_and_grads(emu, m, q, qd, qdd, want):
 
 @pytest.mark.parametrize("case", CASES)
 def test_emu_backward_vs_reference_autograd(emu, case):
-    g = load_golden_dyn()
+    check_emu_backward_vs_reference_autograd(emu, load_golden_dyn(), case)
+
+
+def check_emu_backward_vs_reference_autograd(emu, g, case):
     m, params = learnable_model(g, case)
     q, qd, qdd = (np.ascontiguousarray(g["%s/%s" % (case, k)]) for k in ("q", "qd", "qdd"))
     loss, tau, gq, gqd, gqdd = emu_loss_and_grads(emu, m, q, qd, qdd, g[case + "/want"])
@@ -138,7 +141,10 @@ def test_emu_arm_chain_backward_equals_generic_walk(emu, robot, flags):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_gpu_backward_vs_reference_autograd(case):
-    g = load_golden_dyn()
+    check_gpu_backward_vs_reference_autograd(load_golden_dyn(), case)
+
+
+def check_gpu_backward_vs_reference_autograd(g, case):
     m, params = learnable_model(g, case, "cuda")
     q, qd, qdd = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).cuda().requires_grad_(True) for k in ("q", "qd", "qdd"))
     want = torch.from_numpy(g[case + "/want"].copy()).cuda()
