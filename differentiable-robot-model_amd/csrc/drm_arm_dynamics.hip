@@ -18,16 +18,27 @@ namespace drm {
 // ---------------------------------------------------------------------------------------------------
 // LINKS = the links the dynamics sweeps visit: CAP, or NJ when the walk has no ops behind its moving joints (the host
 // folded the fixed tail into the last moving link, flatten.fold_link_table; the rest of the table is identity padding).
-template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LINKS < CAP ? 3 : 2, LINKS < CAP ? 3 : 2)))
+#ifdef DRM_RNEA_WAVES_FORCE /* development: tools/build_variants.sh */
+#define DRM_RNEA_WAVES(LINKS, CAP) DRM_RNEA_WAVES_FORCE
+#else
+#define DRM_RNEA_WAVES(LINKS, CAP) ((LINKS) < (CAP) ? 3 : 2)
+#endif
+// LAT ("latency form"): this kernel only ever runs launches of at most 1 024 tiles (beyond that rnea_arm2_kernel takes over),
+// i.e. ONE wave per SIMD, the whole register file to itself and nobody to hide its LDS round trips behind.  Op by op the
+// forward sweep waited three times per link for constants it had just asked for (6 cycles per instruction instead of 4,
+// tools/timeline.py: forward sweep 2.0 us for ~850 VALU).  LAT = the constants prefetched one link ahead (rnea_chain_trig's PREF)
+// and every body force kept in registers (KEEP = LINKS): the sweeps wait for no LDS read and park nothing.
+template <int CAP, int NJ, int LINKS, bool LAT = false>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : DRM_RNEA_WAVES(LINKS, CAP), LAT ? 2 : DRM_RNEA_WAVES(LINKS, CAP))))
     rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                     const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     // body-force parking area between the sweeps (tau is staged over it at the end), one [6][64] record per PARKED link:
     // LINKS - DRM_RNEA_KEEP of them (the last links' forces stay in registers, drm_sample.hpp rnea_chain_trig)
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), F_FLOATS = (LINKS - DRM_RNEA_KEEP) * 6 * WAVE;
-    static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
+    constexpr int KEEP = LAT ? LINKS : DRM_RNEA_KEEP;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ),
+                  F_FLOATS = (LINKS - KEEP) * 6 * WAVE > Q_FLOATS ? (LINKS - KEEP) * 6 * WAVE : Q_FLOATS; // (tau is staged over the parking area)
     constexpr int PER_WAVE = C_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -38,6 +49,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
     float *lq = lc + C_FLOATS;
     float *lf = lq + lane; // body forces between the sweeps: [link][6][64]
     const int64_t b0 = (int64_t)tile * WAVE;
+    DRM_STAMP(0);
 
     // constant rows -> LDS (16 bytes per lane); every lane reads its own rows of q / qd / qdd straight into registers
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
@@ -54,7 +66,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
-    rnea_chain<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+    DRM_STAMP_DRAINED(1);
+    rnea_chain<LINKS, NJ, KEEP, LAT>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
                         flags & DRM_RNEA_DAMPING, qv, qdv, qddv, tv,
                         [&](int k, const Force &F) {
 #pragma unroll
@@ -67,11 +80,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
 #pragma unroll
                             for (int i = 0; i < 3; ++i) F.la[i] = f2_make(lf[(k * 6 + i) * WAVE], lf[(k * 6 + 3 + i) * WAVE]);
                         });
+    DRM_STAMP(3);
     wave_lds_sync(); // every lane is done with the parking area before tau is staged over it
 #pragma unroll
     for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = tv[d];
     wave_lds_sync();
     tile_store<NJ>(tau + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+    DRM_STAMP(4);
+    DRM_STAMP_DRAINED(5);
 }
 
 
@@ -88,16 +104,31 @@ constexpr int TILE2 = 2 * WAVE;
 // (256 CUs x 4) and nothing is gained by halving the number of waves (65 536 samples: 5.3 us against 5.8 us, fused 6.2
 // against 7.3); beyond that the SIMDs hold several waves and the kernel with fewer instructions per sample wins
 // (131 072: 6.4 against 7.5 us, fused 7.7 against 8.5; 2^20: 32 against 38.5 us, fused 41 against 48.5; profiles/r03_ab_rnea_two_samples.txt).
-constexpr int TWO_SAMPLE_MIN_TILES = 1024;
+#ifndef DRM_TWO_SAMPLE_MIN_TILES
+#define DRM_TWO_SAMPLE_MIN_TILES 1024
+#endif
+constexpr int TWO_SAMPLE_MIN_TILES = DRM_TWO_SAMPLE_MIN_TILES;
+#ifndef DRM_LAT2_MAX_TILES
+#define DRM_LAT2_MAX_TILES 1024 /* pairs of tiles: up to one two-sample wave per SIMD */
+#endif
+constexpr int LAT2_MAX_TILES = DRM_LAT2_MAX_TILES;
+#ifdef DRM_RNEA_NO_LAT
+constexpr bool LAT1 = false;
+#else
+constexpr bool LAT1 = true; // the one-sample kernels never see more than 1 024 tiles
+#endif
 #ifndef DRM_RNEA2_WAVES
 #define DRM_RNEA2_WAVES 3
 #endif
-template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_RNEA2_WAVES, DRM_RNEA2_WAVES))) rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
+// LAT: launches of at most 1 024 pairs of tiles (131 072 rows: one wave per SIMD) — constants prefetched one link ahead, no force
+// parked (see rnea_arm_kernel)
+template <int CAP, int NJ, int LINKS, bool LAT = false>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : DRM_RNEA2_WAVES, LAT ? 2 : DRM_RNEA2_WAVES))) rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ q,
                                                          const float *__restrict__ qd, const float *__restrict__ qdd, int n_tiles,
                                                          int flags, float *__restrict__ tau) {
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - DRM_RNEA2_KEEP) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
+    constexpr int KEEP2 = LAT ? LINKS - 1 : DRM_RNEA2_KEEP;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - KEEP2) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
                   F_FLOATS = P_FLOATS > T_FLOATS ? P_FLOATS : T_FLOATS; // tau is staged over the parking area at the end
     __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + F_FLOATS];
     const int tile = (int)blockIdx.x;
@@ -122,7 +153,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
     wave_lds_sync();
     f2 cs[NJ], sn[NJ];
     chain_trig2<NJ>(qv, cs, sn);
-    rnea_chain2_trig<LINKS, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
+    rnea_chain2_trig<LINKS, NJ, KEEP2, LAT>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags & DRM_RNEA_GRAVITY,
                                 flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
                                 [&](int k, const Force2 &F) {
 #pragma unroll
@@ -243,8 +274,15 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
     // pairs of 64-sample tiles through the two-samples-per-lane kernel, an odd last tile through the one-sample kernel
     const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0;
     if (n2 > 0) {
-        if (links == 7) hipLaunchKernelGGL((rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau);
-        else hipLaunchKernelGGL((rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau);
+#define RNEA2(L, LATENCY) hipLaunchKernelGGL((rnea_arm2_kernel<8, 7, L, LATENCY>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, q, qd, qdd, n2, flags, tau)
+        if (n2 <= LAT2_MAX_TILES) { // one wave per SIMD: the latency form
+            if (links == 7) RNEA2(7, true);
+            else RNEA2(8, true);
+        } else {
+            if (links == 7) RNEA2(7, false);
+            else RNEA2(8, false);
+        }
+#undef RNEA2
     }
     if (n2 > 0) {
         if (!(n_tiles & 1)) return;
@@ -254,8 +292,9 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
     }
 #endif
     const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
-    if (links == 7) hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
-    else hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+    // (at most 1 024 tiles reach this kernel: one wave per SIMD — the latency form, see the kernel)
+    if (links == 7) hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 7, LAT1>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
+    else hipLaunchKernelGGL((rnea_arm_kernel<8, 7, 8, LAT1>), grid, block, 0, s, ops_f, q, qd, qdd, n_tiles, flags, tau);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -268,8 +307,8 @@ void launch_rnea_arm(const float *ops_f, int links, const float *q, const float 
 // (LINKS as above: the FK chain always walks all CAP ops, the dynamics sweeps the first LINKS)
 // amdgpu_waves_per_eu: the register allocator's occupancy goal follows the LDS footprint, and with the LINKS-sized parking
 // area it would settle on 170 VGPRs, two short of a third wave per SIMD; the attribute holds it to <= 168
-template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LINKS < CAP ? 3 : 2, LINKS < CAP ? 3 : 2)))
+template <int CAP, int NJ, int LINKS, bool LAT = false>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (LINKS < CAP ? 3 : 2), LAT ? 2 : (LINKS < CAP ? 3 : 2))))
     fk_rnea_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ ops_tail, const float *__restrict__ q, const float *__restrict__ qd,
                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
                        float *__restrict__ pos, float *__restrict__ quat) {
@@ -277,9 +316,9 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     // parking area sized by the links actually parked (LINKS - DRM_RNEA_KEEP), not by the table capacity: with LINKS = 7
     // a four-wave block takes 44 KB instead of 56 KB and a CU holds three of them (164 VGPR allow three waves per SIMD)
+    constexpr int KEEP = LAT ? LINKS : DRM_RNEA_KEEP; // (LAT: see rnea_arm_kernel)
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), P_FLOATS = WAVE * 3,
-                  F_FLOATS = (LINKS - DRM_RNEA_KEEP) * 6 * WAVE;
-    static_assert(Q_FLOATS <= F_FLOATS, "the tau tile fits under the parking area");
+                  F_FLOATS = (LINKS - KEEP) * 6 * WAVE > Q_FLOATS ? (LINKS - KEEP) * 6 * WAVE : Q_FLOATS; // (tau is staged over the parking area)
     constexpr int PER_WAVE = C_FLOATS + P_FLOATS + F_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -328,7 +367,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
         store16_wt(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
     }
     // inverse dynamics (robot_model.py:305-375)
-    rnea_chain_trig<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+    rnea_chain_trig<LINKS, NJ, KEEP, LAT>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
                              [&](int k, const Force &F) {
 #pragma unroll
                                  for (int i = 0; i < 3; ++i) {
@@ -349,13 +388,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK) __attribute__((amdg
 
 // The fused launch with two samples per lane: FK chain of all CAP ops first (pose out while the dynamics sweeps run), then
 // rnea_chain2_trig on the first LINKS ops; cos / sin shared.
-template <int CAP, int NJ, int LINKS>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_RNEA2_WAVES, DRM_RNEA2_WAVES)))
+template <int CAP, int NJ, int LINKS, bool LAT = false>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : DRM_RNEA2_WAVES, LAT ? 2 : DRM_RNEA2_WAVES)))
     fk_rnea_arm2_kernel(const float *__restrict__ ops_f, const float *__restrict__ ops_tail, const float *__restrict__ q, const float *__restrict__ qd,
                         const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau, float *__restrict__ pos,
                         float *__restrict__ quat) {
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - DRM_RNEA2_KEEP) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
+    constexpr int KEEP2 = LAT ? LINKS - 1 : DRM_RNEA2_KEEP;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = (LINKS - 1 - KEEP2) * 6 * TILE2, T_FLOATS = round4(TILE2 * NJ),
                   F_FLOATS = P_FLOATS > T_FLOATS ? P_FLOATS : T_FLOATS;
     static_assert(TILE2 * 3 <= F_FLOATS, "the position tile fits into the staging area");
     __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + F_FLOATS];
@@ -384,7 +424,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
     auto row = [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; };
     {   // forward kinematics of the last link (robot_model.py:223-248)
         Pose2 ee;
-        fk_chain2_trig<CAP, NJ>(row, cs, sn, ee);
+        fk_chain2_trig<CAP, NJ>(row, cs, sn, ee); // (not prefetched: with its constants in registers the compiler re-associates the pose chain and the pose is no longer bit-identical to drm_fk's)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lt[lane * 3 + c] = ee.p[c][0];
@@ -402,7 +442,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_R
         }
         wave_lds_sync(); // the position tile has left before the parking area is written
     }
-    rnea_chain2_trig<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
+    rnea_chain2_trig<LINKS, NJ, KEEP2, LAT>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
                                 [&](int k, const Force2 &F) {
 #pragma unroll
                                     for (int i = 0; i < 3; ++i) {
@@ -432,10 +472,14 @@ void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, co
 #ifndef DRM_RNEA_ONE_SAMPLE_PER_LANE
     const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0; // pairs of 64-sample tiles: two samples per lane; an odd last tile: the one-sample kernel
     if (n2 > 0) {
+#define FK_RNEA2_(L, LATENCY) hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, L, LATENCY>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat)
+#define FK_RNEA2(L) do { if (n2 <= LAT2_MAX_TILES) FK_RNEA2_(L, true); else FK_RNEA2_(L, false); } while (0)
         if (links == 7)
-            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 7>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat);
+            FK_RNEA2(7);
         else
-            hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, 8>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat);
+            FK_RNEA2(8);
+#undef FK_RNEA2
+#undef FK_RNEA2_
     }
     if (n2 > 0) {
         if (!(n_tiles & 1)) return;
@@ -446,9 +490,10 @@ void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, co
 #endif
     const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
     if (links == 7)
-        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 7, LAT1>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
     else
-        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 8>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
+        hipLaunchKernelGGL((fk_rnea_arm_kernel<8, 7, 8, LAT1>), grid, block, 0, s, ops_f, ops_tail, q, qd, qdd, n_tiles, flags, tau, pos, quat);
 }
 
 } // namespace drm
+DRM_TL_READER(dyn)

@@ -30,7 +30,14 @@ namespace drm {
 // SIMD (a 4-wave block's 54 KB of LDS stops at three) — 3.90 -> 3.85 us at 65 536 samples, 33.3 -> 31.0 us at 2^20;
 // the NT form (outputs larger than the Infinity Cache) dispatches fewer, larger blocks.
 // ---------------------------------------------------------------------------------------------------
-template <int CAP, int NJ, bool JAC, int WPB, bool NT>
+// PRE ("latency form", launches of at most two waves per SIMD — the metric's 65 536 rows are ONE wave per SIMD): the FT
+// blocks of all CAP ops are read from LDS into registers in one burst right after the table is staged (24 broadcast
+// ds_read_b128 back to back, 96 VGPRs) instead of op by op inside the walk.  A lone wave has nobody to hide its LDS round
+// trips behind: op by op, the walk waited ~8 times for a read it had issued a few instructions earlier, and the fixed tail's
+// rows could not be hoisted above the ang_jac staging stores (same LDS array: may alias).  Per-wave timeline
+// (tools/timeline.py, profiles/r04_timeline.txt): inputs landed -> first store 1.00 -> 0.8 us.  Launches that put more waves
+// on a SIMD keep the op-by-op form (106 VGPRs: occupancy is what hides latency there).
+template <int CAP, int NJ, bool JAC, int WPB, bool NT, bool PRE = false>
 __global__ void __launch_bounds__(WAVE *WPB)
     fk_jacobian_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
                            float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
@@ -50,6 +57,7 @@ __global__ void __launch_bounds__(WAVE *WPB)
     float *lc = smem + wave * PER_WAVE;
     float *lp = lc + C_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
     const int64_t b0 = (int64_t)tile * WAVE;
+    DRM_STAMP(0);
 
     // the walk's constant rows (1 KB) -> LDS: one 16-byte load per lane, in flight together with this lane's own row
     // of q, which is read straight into registers (28 contiguous bytes per lane, 1 792 per wave: the lines are shared
@@ -64,14 +72,23 @@ __global__ void __launch_bounds__(WAVE *WPB)
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     wave_lds_sync();
+    DRM_STAMP_DRAINED(1); // loads have landed
 
+    float tabr[PRE ? CAP : 1][DRM_OPF_FT_FLOATS];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < CAP; ++k)
+#pragma unroll
+            for (int i = 0; i < DRM_OPF_FT_FLOATS; ++i) tabr[k][i] = lc[k * DRM_OPF_STRIDE + i];
+        __builtin_amdgcn_sched_barrier(0); // all 24 reads are issued here, ahead of sincos and the walk
+    }
     PoseP ee;
     f2 Bk[NJ][3];
     // The outputs leave in the order they become available, so that the store drain (12.8 MB per launch, the
     // longest single item of a one-wave-per-SIMD launch) starts as early as possible: ang_jac needs only the joint
     // axes and goes out while the fixed tail of the chain is still being composed; lin_jac and pos need the end
     // position; the quaternion takes the most arithmetic and goes last.
-    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { if constexpr (PRE) return tabr[k]; else return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
         if constexpr (JAC) {
             float *arow = la + lane * SJ;
 #pragma unroll
@@ -79,9 +96,11 @@ __global__ void __launch_bounds__(WAVE *WPB)
                 arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0];
             }
             wave_lds_sync();
+            DRM_STAMP(2); // the moving joints are walked: first stores (ang_jac) go out
             tile_store<SJ, NT>(ang + b0 * SJ, WAVE, SJ, 0u, la, lane, true);
         }
     });
+    DRM_STAMP(3); // chain done
 
     const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
     if constexpr (JAC) {
@@ -118,6 +137,8 @@ __global__ void __launch_bounds__(WAVE *WPB)
         quat_xyzw(E.R, qt);
         store16_wt<NT>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
     }
+    DRM_STAMP(4);         // last store issued
+    DRM_STAMP_DRAINED(5); // ... and acknowledged
 }
 
 // FK of the single target of an arm-shaped walk through the packed chain kernel (called by drm_fk); returns the
@@ -139,12 +160,19 @@ int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, 
 }
 
 
+#ifndef DRM_PRE_MAX_TILES
+#define DRM_PRE_MAX_TILES 2048 /* 256 CUs x 4 SIMDs x 2 waves */
+#endif
+constexpr int PRE_MAX_TILES = DRM_PRE_MAX_TILES;
 void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, float *pos, float *quat, float *lin_jac,
                             float *ang_jac, hipStream_t s) {
     if (stream_past_llc((int64_t)n_tiles * WAVE * 4 * (7 + 6 * 7))) {
         constexpr int WPB = MAX_WAVES_PER_BLOCK;
         hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, WPB, true>), dim3((unsigned)((n_tiles + WPB - 1) / WPB)),
                            dim3(WAVE * WPB), 0, s, ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+    } else if (n_tiles <= PRE_MAX_TILES) { // at most two waves per SIMD: the register-resident table
+        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, 1, false, true>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, ops_f, q,
+                           n_tiles, pos, quat, lin_jac, ang_jac);
     } else {
         hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, 1, false>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, ops_f, q,
                            n_tiles, pos, quat, lin_jac, ang_jac);
@@ -153,3 +181,4 @@ void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, flo
 
 
 } // namespace drm
+DRM_TL_READER(arm)

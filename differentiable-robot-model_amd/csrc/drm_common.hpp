@@ -34,6 +34,45 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- development only (-DDRM_TIMELINE variant builds, tools/timeline.py): per-wave time stamps (the 100 MHz real-time counter,
+// the same clock on every XCD) at named points of a kernel, one record of 8 slots per wavefront, in a buffer owned by the
+// translation unit; drm_tl_read_<unit>() copies it out.  DRM_STAMP(slot) / DRM_STAMP_DRAINED(slot) compile to nothing in the
+// shipped library.
+#ifdef DRM_TIMELINE
+constexpr int TL_SLOTS = 8, TL_WAVES = 1 << 16;
+__device__ static unsigned long long tl_buf[TL_SLOTS * TL_WAVES];
+__device__ __forceinline__ void tl_stamp(int slot, bool drained) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (drained) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t = wall_clock64();
+    const unsigned w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0 && w < (unsigned)TL_WAVES) tl_buf[w * TL_SLOTS + slot] = t;
+    if (slot == 0 && (threadIdx.x & 63u) == 0 && w < (unsigned)TL_WAVES) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl_buf[w * TL_SLOTS + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define DRM_STAMP(slot) ::drm::tl_stamp(slot, false)
+#define DRM_STAMP_DRAINED(slot) ::drm::tl_stamp(slot, true)
+#define DRM_TL_READER(unit)                                                                                                      \
+    extern "C" __attribute__((visibility("default"))) int drm_tl_read_##unit(void *host, size_t bytes, int clear) {             \
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(::drm::tl_buf), bytes) != hipSuccess) return -1;                                \
+        if (clear) {                                                                                                             \
+            void *d = nullptr;                                                                                                   \
+            if (hipGetSymbolAddress(&d, HIP_SYMBOL(::drm::tl_buf)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned long long) * ::drm::TL_SLOTS * ::drm::TL_WAVES) != hipSuccess) return -2; \
+        }                                                                                                                        \
+        return 0;                                                                                                                \
+    }
+#else
+#define DRM_STAMP(slot) ((void)0)
+#define DRM_STAMP_DRAINED(slot) ((void)0)
+#define DRM_TL_READER(unit)
+#endif
+
 // keep a just-loaded value materialised HERE: stops the compiler from sinking the load into the
 // predicated block that consumes it (which would serialise load -> wait -> store per iteration)
 __device__ __forceinline__ void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }

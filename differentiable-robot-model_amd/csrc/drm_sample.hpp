@@ -868,29 +868,49 @@ DRM_HD void rnea_link_force_up(const float *J, const float *t, const Force &tot,
 #else
 #define DRM_RNEA_LINK_FENCE() ((void)0)
 #endif
-template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, class ROW, class FPUT, class FGET>
+// PREF: software prefetch of the constants, one link ahead.  The sweeps read a link's 26 constants from LDS (broadcast reads of the
+// staged table) and, op by op, waited for reads they had issued a few instructions earlier — three times per link in the
+// forward sweep — because a read cannot be hoisted over the parking stores of the link before it (same LDS array: may alias) nor
+// over the link fence.  With PREF the reads of link k + 1 (k - 1 on the way back, together with its parked force) are issued
+// BEFORE the arithmetic of link k, into a second set of registers (+26 VGPRs), so they land while link k computes.
+template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, bool PREF = false, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
                             const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget);
-template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, class ROW, class FPUT, class FGET>
+template <int CAP, int NJ, int KEEP = DRM_RNEA_KEEP, bool PREF = false, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain(ROW row, bool gravity, bool damping, const float (&q)[NJ], const float (&qd)[NJ],
                        const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
     float cs[NJ], sn[NJ];
     chain_trig<NJ>(q, cs, sn);
-    rnea_chain_trig<CAP, NJ, KEEP>(row, gravity, damping, cs, sn, qd, qdd, tau, fput, fget);
+    rnea_chain_trig<CAP, NJ, KEEP, PREF>(row, gravity, damping, cs, sn, qd, qdd, tau, fput, fget);
 }
-template <int CAP, int NJ, int KEEP, class ROW, class FPUT, class FGET>
+#ifndef DRM_STAMP
+#define DRM_STAMP(slot) ((void)0) /* (drm_common.hpp's development time stamps; this header is also compiled for the host) */
+#endif
+constexpr int RNEA_ROW_FLOATS = 28; // floats 0 .. 25 of an op row: FT block, mass, m c, I_o, damping (16-byte multiples)
+template <int N>
+DRM_HD void rnea_row_copy(const float *__restrict__ of, float (&r)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = of[i];
+}
+template <int CAP, int NJ, int KEEP, bool PREF, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&cs)[NJ], const float (&sn)[NJ],
                             const float (&qd)[NJ], const float (&qdd)[NJ], float (&tau)[NJ], FPUT fput, FGET fget) {
-    static_assert(KEEP >= 0 && KEEP < CAP, "at least one parked link");
+    static_assert(KEEP >= 0 && KEEP <= CAP, "KEEP == CAP: nothing is parked, fput / fget are never called");
     Force kept[KEEP > 0 ? KEEP : 1];
     // The joint transforms are rebuilt in the backward sweep (12 VALU ops + three broadcast LDS reads per link)
     // instead of being kept: 72 fewer live registers.
     Motion cur;
     motion_root(cur, gravity ? 9.81f : 0.0f);
+    float buf[2][PREF ? RNEA_ROW_FLOATS : 1]; // two register sets, used alternately (the loop is unrolled: no copies)
+    if constexpr (PREF) rnea_row_copy(row(0), buf[0]);
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         DRM_RNEA_LINK_FENCE();
-        const float *of = row(k);
+        if constexpr (PREF) {
+            if (k + 1 < CAP) rnea_row_copy(row(k + 1), buf[(k + 1) & 1]);
+            DRM_RNEA_LINK_FENCE(); // the reads of link k + 1 are issued here, ahead of link k's arithmetic
+        }
+        const float *of = PREF ? buf[k & 1] : row(k);
         const OpFT o = load_ft(of);
         float J[9];
         if (k < NJ) {
@@ -905,19 +925,41 @@ DRM_HD void rnea_chain_trig(ROW row, bool gravity, bool damping, const float (&c
         if (k >= CAP - KEEP) kept[k - (CAP - KEEP)] = fk;
         else fput(k, fk);
     }
+    DRM_STAMP(2); // forward sweep done
     Force tot;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tot.la[i] = f2_bcast(0.0f);
+    // the way back needs a link's FT block and damping again, and its parked force
+    constexpr int BACK_FLOATS = DRM_OPF_FT_FLOATS;
+    float back[2][PREF ? BACK_FLOATS : 1], damp2[2];
+    Force f2buf[PREF ? 2 : 1];
+    if constexpr (PREF) {
+        rnea_row_copy(row(CAP - 1), back[(CAP - 1) & 1]);
+        damp2[(CAP - 1) & 1] = row(CAP - 1)[DRM_OPF_DAMP];
+        if (CAP - 1 < CAP - KEEP) fget(CAP - 1, f2buf[(CAP - 1) & 1]);
+    }
 #pragma unroll
     for (int k = CAP - 1; k >= 0; --k) {
         DRM_RNEA_LINK_FENCE();
-        const float *of = row(k);
         Force fk;
+        if constexpr (PREF) {
+            if (k > 0) {
+                rnea_row_copy(row(k - 1), back[(k - 1) & 1]);
+                damp2[(k - 1) & 1] = row(k - 1)[DRM_OPF_DAMP];
+                if (k - 1 < CAP - KEEP) fget(k - 1, f2buf[(k - 1) & 1]);
+            }
+            DRM_RNEA_LINK_FENCE();
+            if (k < CAP - KEEP) fk = f2buf[k & 1];
+        }
+        const float *of = PREF ? back[k & 1] : row(k);
         if (k >= CAP - KEEP) fk = kept[k - (CAP - KEEP)];
-        else fget(k, fk);
+        else if constexpr (!PREF) fget(k, fk);
 #pragma unroll
         for (int i = 0; i < 3; ++i) tot.la[i] += fk.la[i];
-        if (k < NJ) tau[k] = tot.la[2][1] + (damping ? of[DRM_OPF_DAMP] * qd[k] : 0.0f);
+        if (k < NJ) {
+            if constexpr (PREF) tau[k] = tot.la[2][1] + (damping ? damp2[k & 1] * qd[k] : 0.0f);
+            else tau[k] = tot.la[2][1] + (damping ? of[DRM_OPF_DAMP] * qd[k] : 0.0f);
+        }
         if (k > 0) {
             const OpFT o = load_ft(of);
             float J[9];
@@ -1159,7 +1201,8 @@ DRM_HD void rnea2_body_force(float m, const float *mc, const float *Io, const Mo
 #else
 #define DRM_RNEA2_LINK_FENCE() ((void)0)
 #endif
-template <int LINKS, int NJ, int KEEP2 = DRM_RNEA2_KEEP, class ROW, class FPUT, class FGET>
+// PREF: the constants of the next link are read one link ahead into a second register set (see rnea_chain_trig)
+template <int LINKS, int NJ, int KEEP2 = DRM_RNEA2_KEEP, bool PREF = false, class ROW, class FPUT, class FGET>
 DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)[NJ], const f2 (&sn)[NJ], const f2 (&qd)[NJ],
                              const f2 (&qdd)[NJ], f2 (&tau)[NJ], FPUT fput, FGET fget) {
     static_assert(LINKS >= NJ && LINKS >= 1 + KEEP2, "moving joints first, then fixed links"); // (KEEP2 = LINKS - 1: nothing parked)
@@ -1167,10 +1210,16 @@ DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)
     Motion2 cur;
     Force2 tot;
     Force2 kept[KEEP2 > 0 ? KEEP2 : 1];
+    float buf[2][PREF ? RNEA_ROW_FLOATS : 1];
+    if constexpr (PREF) rnea_row_copy(row(0), buf[0]);
 #pragma unroll
     for (int k = 0; k < LINKS; ++k) {
         DRM_RNEA2_LINK_FENCE();
-        const float *of = row(k);
+        if constexpr (PREF) {
+            if (k + 1 < LINKS) rnea_row_copy(row(k + 1), buf[(k + 1) & 1]);
+            DRM_RNEA2_LINK_FENCE();
+        }
+        const float *of = PREF ? buf[k & 1] : row(k);
         const OpFT o = load_ft(of);
         Joint2 J;
         if (k < NJ) joint2_moving(o.F, cs[k], sn[k], J);
@@ -1184,18 +1233,39 @@ DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)
         else if (k < LINKS - 1) kept[k - PARKED] = fk;
         else tot = fk;
     }
+    float back[2][PREF ? DRM_OPF_FT_FLOATS : 1], damp2[2];
+    Force2 f2buf[PREF ? 2 : 1];
+    if constexpr (PREF) {
+        rnea_row_copy(row(LINKS - 1), back[(LINKS - 1) & 1]);
+        damp2[(LINKS - 1) & 1] = row(LINKS - 1)[DRM_OPF_DAMP];
+    }
 #pragma unroll
     for (int k = LINKS - 1; k >= 0; --k) {
         DRM_RNEA2_LINK_FENCE();
-        const float *of = row(k);
+        if constexpr (PREF) {
+            if (k > 0) {
+                rnea_row_copy(row(k - 1), back[(k - 1) & 1]);
+                damp2[(k - 1) & 1] = row(k - 1)[DRM_OPF_DAMP];
+                if (k - 1 < PARKED) fget(k - 1, f2buf[(k - 1) & 1]);
+            }
+            DRM_RNEA2_LINK_FENCE();
+        }
+        const float *of = PREF ? back[k & 1] : row(k);
         if (k < LINKS - 1) {
             Force2 fk;
-            if (k < PARKED) fget(k, fk);
-            else fk = kept[k - PARKED];
+            if (k < PARKED) {
+                if constexpr (PREF) fk = f2buf[k & 1];
+                else fget(k, fk);
+            } else {
+                fk = kept[k - PARKED];
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) { tot.f[i] += fk.f[i]; tot.n[i] += fk.n[i]; }
         }
-        if (k < NJ) tau[k] = damping ? tot.n[2] + f2_bcast(of[DRM_OPF_DAMP]) * qd[k] : tot.n[2];
+        if (k < NJ) {
+            if constexpr (PREF) tau[k] = damping ? tot.n[2] + f2_bcast(damp2[k & 1]) * qd[k] : tot.n[2];
+            else tau[k] = damping ? tot.n[2] + f2_bcast(of[DRM_OPF_DAMP]) * qd[k] : tot.n[2];
+        }
         if (k > 0) {
             const OpFT o = load_ft(of);
             Joint2 J;
@@ -1218,12 +1288,18 @@ DRM_HD void rnea_chain2_trig(ROW row, bool gravity, bool damping, const f2 (&cs)
 struct Pose2 {
     f2 R[9], p[3];
 };
-template <int CAP, int NJ, class ROW>
+template <int CAP, int NJ, bool PREF = false, class ROW>
 DRM_HD void fk_chain2_trig(ROW row, const f2 (&cs)[NJ], const f2 (&sn)[NJ], Pose2 &ee) {
+    float buf[2][PREF ? DRM_OPF_FT_FLOATS : 1];
+    if (PREF) rnea_row_copy(row(0), buf[0]);
 #pragma unroll
     for (int k = 0; k < CAP; ++k) {
         DRM_RNEA2_LINK_FENCE();
-        const OpFT o = load_ft(row(k));
+        if (PREF) {
+            if (k + 1 < CAP) rnea_row_copy(row(k + 1), buf[(k + 1) & 1]);
+            DRM_RNEA2_LINK_FENCE();
+        }
+        const OpFT o = load_ft(PREF ? buf[k & 1] : row(k));
         f2 J0[3], J1[3]; // columns 0 and 1 of J = F Rot_z(q) (joint_pairs: f01 c + (f1, f0) (s, -s)); column 2 is F[:, 2]
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

@@ -23,18 +23,23 @@ def graph_time(fn, launches=100, reps=5):
     return best
 
 
-m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
-tag = os.path.basename(os.environ.get("DRM_HIP_LIBRARY", "libdrm_hip.so"))
-for B in (65536, 131072, 1 << 20):
-    q, qd, qdd = (t.cuda() for t in sample(m, B))
-    p_id = m.plan_inverse_dynamics(q, qd, qdd)
-    p_fu = m.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
-    t_id = graph_time(p_id.launch, launches=100, reps=7)
-    t_fu = graph_time(p_fu.launch, launches=100, reps=7)
-    line = "%-22s B=%8d  rnea %8.2f us   fk+rnea %8.2f us" % (tag, B, t_id, t_fu)
-    if B == 1 << 20:
-        tau = p_id.tau if hasattr(p_id, "tau") else None
-        t_fd = graph_time(lambda: m.compute_forward_dynamics(q, qd, qdd), launches=20, reps=5)
-        t_h = graph_time(lambda: m.compute_lagrangian_inertia_matrix(q), launches=20, reps=5)
-        line += "   fwd dyn (API) %8.2f us   mass matrix (API) %8.2f us" % (t_fd, t_h)
-    print(line, flush=True)
+def main():
+    m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
+    tag = os.path.basename(os.environ.get("DRM_HIP_LIBRARY", "libdrm_hip.so"))
+    for B in (65536, 131072, 1 << 20):
+        q, qd, qdd = (t.cuda() for t in sample(m, B))
+        p_id = m.plan_inverse_dynamics(q, qd, qdd)
+        p_fu = m.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
+        t_id = graph_time(p_id.launch, launches=100, reps=7)
+        t_fu = graph_time(p_fu.launch, launches=100, reps=7)
+        line = "%-22s B=%8d  rnea %8.2f us   fk+rnea %8.2f us" % (tag, B, t_id, t_fu)
+        if B == 1 << 20:
+            tau = p_id.tau if hasattr(p_id, "tau") else None
+            t_fd = graph_time(lambda: m.compute_forward_dynamics(q, qd, qdd), launches=20, reps=5)
+            t_h = graph_time(lambda: m.compute_lagrangian_inertia_matrix(q), launches=20, reps=5)
+            line += "   fwd dyn (API) %8.2f us   mass matrix (API) %8.2f us" % (t_fd, t_h)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
