@@ -12,8 +12,12 @@
     rank runs its own 65 536-row shard, no data-path collective (every sample is independent).
 --config 3
     BASELINE.json configuration 3: Panda, GLOBAL batch 2^20 sharded by rows over the ranks (131 072 per GPU at N = 8),
-    one step = FK(end effector) + RNEA inverse dynamics through `drm_fk_rnea` (one fused launch) followed by ONE RCCL
-    `all_gather_into_tensor` of tau + pos + quat (56 B per row) inside the timed step.  Strong scaling.
+    one step = FK(end effector) + RNEA inverse dynamics through `drm_fk_rnea` (one fused launch) + the exchange `--gather`
+    names: none (default headline: the outputs stay sharded — the MPC / particle case, strong scaling of the compute), tau /
+    all (`all_gather_into_tensor` of the torques / of tau + pos + quat, 28 / 56 B per row), root (gather to rank 0).  Every
+    mode is timed in the same run (`gather_modes`) with the xGMI estimate beside it (`gather_model_us`): at N = 8 the shard's
+    7.3 MB take ~48 us over one 153 GB/s link against ~7.5 us of compute, so `all` is predicted SLOWER than one GPU doing the
+    whole batch (~41 us) — the number to quote for a sharded consumer is `none`.
 
 Timing: W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides, max
 over ranks.  For the metric config the K launches are captured once into a hipGraph (one launch per step, same
@@ -67,7 +71,15 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step (metric config)")
     ap.add_argument("--robot", default="panda_no_gripper", choices=sorted(EE_LINK))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--gather", action="store_true", help="metric config: all-gather the outputs over RCCL inside every step")
+    ap.add_argument("--gather", nargs="?", const="all", default=None, choices=["none", "all", "root", "tau"],
+                    help="what a step exchanges over RCCL.  metric config: `--gather` = all-gather the outputs inside every step "
+                         "(default: nothing).  --config 3: which mode the headline `value` is timed with — none (default: the "
+                         "outputs stay sharded, the MPC / particle case), all (every rank gets tau | pos | quat of every row), root "
+                         "(rank 0 only), tau (all-gather of the torques only); every mode is timed and reported under gather_modes")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="--config 3, backend nccl: capture kernel + RCCL collective of the K steps into ONE hipGraph (a step is one "
+                         "~8 us kernel and one collective: launched eagerly it pays both enqueues on the host every step).  Opt-in: "
+                         "no multi-GPU node was available to try RCCL under stream capture on this stack")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
@@ -89,6 +101,8 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.shared_gpu:
         args.backend = "gloo"
+    if args.config != "3":
+        args.gather = args.gather not in (None, "none")     # the metric config: a switch
     return args
 
 
@@ -544,8 +558,9 @@ def test_mode_fields(args, world):
 
 
 def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max, shard_bounds):
-    """BASELINE configuration 3: global batch 2^20 sharded by rows, FK(EE) + RNEA per shard (one fused launch), one RCCL
-    all-gather of tau | pos | quat per step."""
+    """BASELINE configuration 3: global batch 2^20 sharded by rows, FK(EE) + RNEA per shard (one fused launch), and what a step
+    exchanges afterwards: nothing (the outputs stay sharded: the headline), the torques, everything to rank 0, or everything to
+    every rank — all four timed in this run (gather_modes)."""
     import torch
 
     from differentiable_robot_model_amd.distributed import all_gather_flat
@@ -567,26 +582,54 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     def compute():
         plan.launch()
 
-    def exchange():
-        if world > 1:
+    from differentiable_robot_model_amd.distributed import gather_flat, gather_model_us
+    gathered_tau = torch.empty(world * rows * n, device=device) if world > 1 else None
+    headline = args.gather or "none"
+
+    def exchange(mode):
+        if world <= 1 or mode == "none":
+            return
+        if mode == "all":
             all_gather_flat(gathered, flat)               # rank r's blocks at gathered[r * rows * width:]
+        elif mode == "tau":
+            all_gather_flat(gathered_tau, flat[:rows * n])
+        else:
+            gather_flat(gathered, flat, dst=0)
 
-    def step():
-        compute()
-        exchange()
+    def step_of(mode):
+        def step():
+            compute()
+            exchange(mode)
+        return step
 
+    step = step_of(headline)
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    # the compute of a step alone (graph of K launches), then the full step with the collective (eager: RCCL)
+    # the compute of a step alone (graph of K launches), then the full step of every exchange mode: compute + collective as ONE
+    # replayed hipGraph where RCCL lets itself be captured (backend nccl), eagerly otherwise (gloo test mode; a failed capture)
     _, dev_compute, _ = timed_graph_region(compute, K, stream, barrier, use_graph=not args.no_graph)
-    wall, dev_time, _ = timed_graph_region(step, K, stream, barrier, use_graph=False)
-    wall, dev_time, dev_compute = reduce_max([wall, dev_time, dev_compute])
+    modes = {}
+    for mode in (["none"] if world == 1 else ["none", "tau", "root", "all"]):
+        fn = step_of(mode)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        capture = world > 1 and mode != "none" and args.backend == "nccl" and args.graph_collectives and not args.no_graph
+        w_, d_, graphed = timed_graph_region(fn, K, stream, barrier, use_graph=capture or (mode == "none" and not args.no_graph))
+        w_, d_ = reduce_max([w_, d_])
+        modes[mode] = {"ms_per_step": w_ / K * 1e3, "value": G * K / w_, "step_us_device": d_ / K * 1e6, "hipgraph": bool(graphed),
+                       "gather_bytes_per_rank": 0 if mode == "none" else rows * 4 * (n if mode == "tau" else width),
+                       "gather_model_us": gather_model_us(mode, rows * width * 4, rows * n * 4, world)}
+    wall, dev_time = modes[headline]["ms_per_step"] * K * 1e-3, modes[headline]["step_us_device"] * K * 1e-6
+    (dev_compute,) = reduce_max([dev_compute])
     verified = None
     if args.verify_gather and world > 1:
         # rank 0 rebuilds EVERY rank's inputs (same seeds), runs them as ONE single-rank launch over all 2^20 rows and holds
-        # the gathered buffer to it bit for bit: rank r's tau | pos | quat blocks at gathered[r * rows * width:]
-        step()
+        # the gathered buffers to it bit for bit: rank r's tau | pos | quat blocks at gathered[r * rows * width:] (all-gather,
+        # then the gather to rank 0 into the zeroed buffer), its torques at gathered_tau[r * rows * n:]
+        step_of("all")()
+        step_of("tau")()
         torch.cuda.synchronize()
         ok = 1
         if rank == 0:
@@ -596,12 +639,22 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
             whole.launch()
             torch.cuda.synchronize()
             tau_w, pos_w, quat_w = whole.outputs()
-            for r in range(world):
-                blk = gathered[r * rows * width:(r + 1) * rows * width]
-                sl = slice(r * rows, (r + 1) * rows)
-                ok &= int(torch.equal(blk[:rows * n].view(rows, n), tau_w[sl]))
-                ok &= int(torch.equal(blk[rows * n:rows * (n + 3)].view(rows, 3), pos_w[sl].reshape(rows, 3)))
-                ok &= int(torch.equal(blk[rows * (n + 3):].view(rows, 4), quat_w[sl].reshape(rows, 4)))
+            def blocks_ok():
+                good = 1
+                for r in range(world):
+                    blk = gathered[r * rows * width:(r + 1) * rows * width]
+                    sl = slice(r * rows, (r + 1) * rows)
+                    good &= int(torch.equal(blk[:rows * n].view(rows, n), tau_w[sl]))
+                    good &= int(torch.equal(blk[rows * n:rows * (n + 3)].view(rows, 3), pos_w[sl].reshape(rows, 3)))
+                    good &= int(torch.equal(blk[rows * (n + 3):].view(rows, 4), quat_w[sl].reshape(rows, 4)))
+                return good
+            ok &= blocks_ok()
+            ok &= int(torch.equal(gathered_tau.view(world * rows, n), tau_w))
+            gathered.zero_()
+        step_of("root")()                                   # (every rank takes part; only rank 0 receives)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ok &= blocks_ok()
         verified = bool(ok)
     bytes_per_eval = 4 * (3 * n + n + 7)                                 # q qd qdd in; tau pos quat out = 140 B
     launch_s = dev_compute / K
@@ -629,12 +682,18 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         "distributed": test_mode_fields(args, world),
         "config": {"workload": "Franka Panda 7-DoF, FK(panda_virtual_ee_link) + RNEA inverse dynamics (gravity, damping), "
                                "global batch %d = %d rows per GPU, q~U(limits), qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); "
-                               "one fused drm_fk_rnea launch + one all_gather_into_tensor of its output buffer (tau|pos|quat blocks) per step" % (G, rows),
+                               "one fused drm_fk_rnea launch per step; exchange mode of the headline value: %s" % (G, rows, headline),
                    "batch_per_gpu": rows, "global_batch": G, "parallelism": "batch-sharded x%d" % world,
-                   "launch": "eager step (kernel + RCCL collective)", "gather": world > 1,
-                   "gather_bytes_per_rank": rows * width * 4 if world > 1 else 0},
+                   "launch": "hipGraph of K steps" if modes[headline]["hipgraph"] else "eager steps (kernel + collective)",
+                   "gather": headline if world > 1 else "none",
+                   "gather_bytes_per_rank": modes[headline]["gather_bytes_per_rank"]},
         "compute_us_per_step": dev_compute / K * 1e6, "step_us_with_gather": dev_time / K * 1e6,
         "gather_us_per_step": max(0.0, (dev_time - dev_compute) / K * 1e6) if world > 1 else 0.0,
+        "gather_modes": modes,
+        "gather_modes_note": "the same K steps timed once per exchange mode (barrier + synchronize bracket, max over ranks): none = "
+                             "outputs stay sharded on their GPUs (the headline), tau / all = all_gather_into_tensor of the torques / of "
+                             "tau | pos | quat, root = gather to rank 0; gather_model_us = one block over one 153 GB/s xGMI link "
+                             "(distributed.gather_model_us) — what the exchange should add once it runs over RCCL",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,
                      "kernel": "drm::fk_rnea_arm2_kernel<8, 7, 7> (two samples per lane)" if rows > 1024 * 64

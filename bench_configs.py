@@ -297,6 +297,52 @@ def run_config_legs(device, with_reference=True):
         del graph
     except Exception as err:   # pragma: no cover - depends on the runtime
         leg["graph_step_error"] = repr(err)[:200]
+    # the same step with the loss as ONE node (fk_mse_loss -> drm_fk_mse: forward kinematics, MSE and the gradients in one pass)
+    try:
+        with torch.no_grad():
+            for p in ("trans", "rot_angles"):
+                getattr(body, p).param.copy_(init[p])
+        opt2 = torch.optim.Adam(learn.parameters(), lr=1e-3, capturable=True, fused=True)
+
+        def fused_step():
+            loss = learn.fk_mse_loss(q, "iiwa_link_ee", want)
+            loss.backward()
+            opt2.step()
+            return loss
+
+        us_m, _ = graph_launch_us(lambda: backend.fk_mse(dw.program, ops_f, dw.ops_i, q, want, 7, mask, False), 50)
+        leg["fk_mse_launch_us"] = us_m
+        leg["fk_mse_roofline"] = roofline(96, B, us_m, "drm_fk_mse: fk_backward_arm_kernel<8, 7, true> + fk_backward_reduce_kernel")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt2.zero_grad(set_to_none=True)
+                fused_step()
+        torch.cuda.current_stream().wait_stream(side)
+        opt2.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fused_step()
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(50):
+                graph.replay()
+            e.record()
+            torch.cuda.synchronize()
+            times.append(s.elapsed_time(e) / 50 * 1e3)
+        leg["graph_step_fused_us"] = sorted(times)[len(times) // 2]
+        leg["graph_step_fused_evals_per_s"] = B / leg["graph_step_fused_us"] * 1e6
+        leg["graph_step_fused_note"] = ("the same training step with model.fk_mse_loss (ONE node: drm_fk_mse) and fused Adam, "
+                                        "replayed from a hipGraph")
+        del graph
+    except Exception as err:   # pragma: no cover - depends on the runtime
+        leg["graph_step_fused_error"] = repr(err)[:200]
     # gradients of the loss at the initial parameters (what the reference's autograd is asked for below)
     with torch.no_grad():
         for p in ("trans", "rot_angles"):
@@ -329,7 +375,7 @@ def run_config_legs(device, with_reference=True):
             one = job["one_thread"]["tensor_only"]
             leg["cpu_baseline_of_record"] = {"evals_per_s": one["evals_per_s"], "threads": 1, "rows": one["rows"],
                                              "what": "unmodified reference, tensor-only, one thread"}
-            speed = leg.get("graph_step_evals_per_s", leg["evals_per_s"])
+            speed = leg.get("graph_step_fused_evals_per_s", leg.get("graph_step_evals_per_s", leg["evals_per_s"]))
             leg["speedup_vs_reference_one_thread"] = speed / one["evals_per_s"]
             name = by_name.get(leg["name"], leg["name"])
             if outs and name in gpu_out and leg["name"] != "config3_whole":

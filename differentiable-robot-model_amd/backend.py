@@ -8,6 +8,7 @@ runtime that is already mapped into the process.
 There is no fallback: a missing library or a non-HIP tensor raises.
 """
 import ctypes
+import math
 import os
 import threading
 
@@ -17,7 +18,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -46,7 +47,7 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
-           "drm_rnea_scratch_floats")
+           "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats")
 
 
 def load_library(path: str = None):
@@ -112,6 +113,10 @@ def load_library(path: str = None):
         lib.drm_crba_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_rnea.restype = ctypes.c_int
         lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
+        lib.drm_fk_mse.restype = ctypes.c_int
+        lib.drm_fk_mse.argtypes = [wp, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
+        lib.drm_fk_mse_scratch_floats.restype = i64
+        lib.drm_fk_mse_scratch_floats.argtypes = [i64, i32]
         if lib.drm_abi_version() != ABI_VERSION:
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         if lib.drm_walk_sizeof() != ctypes.sizeof(DrmWalk):
@@ -157,6 +162,18 @@ def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
 
 
 def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_dofs: int) -> DrmWalk:
+    """`struct drm_walk` of a walk on the device; the struct of the LAST (table, control words) pair is kept on the program
+    (a constant model launches the same pair every call: filling the ~60 fields took 4-5 us of an eager call's ~20)."""
+    key = (ops_f.data_ptr(), ops_i.data_ptr(), n_dofs, ops_f.shape[0])
+    cached = getattr(prog, "_ws_cache", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    w = _walk_struct_build(prog, ops_f, ops_i, n_dofs)
+    prog._ws_cache = (key, w)
+    return w
+
+
+def _walk_struct_build(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_dofs: int) -> DrmWalk:
     rows = prog.capacity
     assert ops_f.is_cuda and ops_f.dtype == torch.float32 and ops_f.is_contiguous() and ops_f.shape[0] == rows
     assert ops_i.is_cuda and ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[1] == rows
@@ -185,8 +202,52 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     return w
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device) -> ctypes.c_void_p:
+    """The caller's current HIP stream on `device` as a raw handle (the private accessor, when this torch has it, skips building
+    a torch.cuda.Stream object per call)."""
+    if _raw_stream is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device(object):
+    """`with torch.cuda.device(d)` only when `d` is not already the current device (the guard costs ~4 us per call)."""
+    __slots__ = ("guard",)
+
+    def __init__(self, device):
+        self.guard = None if device.index is None or torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
+def _outputs(device, *shapes):
+    """The output tensors of one call as views of ONE allocation (each starting on a 16-byte boundary): one trip through the
+    caching allocator instead of one per tensor.  (The block lives as long as any of its views does.)"""
+    sizes = [math.prod(sh) for sh in shapes]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) & ~3          # every tensor starts on a 16-byte boundary
+    flat = torch.empty(total, device=device, dtype=torch.float32)
+    return [flat.as_strided(sh, _contiguous_strides(sh), off) for sh, off in zip(shapes, offs)]
+
+
+def _contiguous_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= d
+    return tuple(reversed(st))
 
 
 def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze: bool = False):
@@ -196,15 +257,13 @@ def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze:
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     if squeeze and n_targets == 1:
-        pos = torch.empty(B, 3, device=q.device, dtype=torch.float32)
-        quat = torch.empty(B, 4, device=q.device, dtype=torch.float32)
+        pos, quat = _outputs(q.device, (B, 3), (B, 4))
     else:
-        pos = torch.empty(B, n_targets, 3, device=q.device, dtype=torch.float32)
-        quat = torch.empty(B, n_targets, 4, device=q.device, dtype=torch.float32)
+        pos, quat = _outputs(q.device, (B, n_targets, 3), (B, n_targets, 4))
     if B == 0:
         return pos, quat
-    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(q.device):
+    walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+    with _on_device(q.device):
         _check(lib.drm_fk(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
                           _stream(q.device)))
     return pos, quat
@@ -221,7 +280,7 @@ def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     if B == 0:
         return pos, quat
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _check(lib.drm_fk_links(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
                                 _stream(q.device)))
     return pos, quat
@@ -238,7 +297,7 @@ def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
     if B == 0:
         return pos, quat
     walks = (DrmWalk * T)(*[_walk_struct(p, f.detach(), i, n_dofs) for p, f, i in chains])
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _check((lib.drm_fk_fanout_links if link_major else lib.drm_fk_fanout)(
             walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)))
     return pos, quat
@@ -248,14 +307,11 @@ def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     lib = load_library()
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
-    pos = torch.empty(B, 3, device=q.device, dtype=torch.float32)
-    quat = torch.empty(B, 4, device=q.device, dtype=torch.float32)
-    lin = torch.empty(B, 3, n_dofs, device=q.device, dtype=torch.float32)
-    ang = torch.empty(B, 3, n_dofs, device=q.device, dtype=torch.float32)
+    pos, quat, lin, ang = _outputs(q.device, (B, 3), (B, 4), (B, 3, n_dofs), (B, 3, n_dofs))
     if B == 0:
         return pos, quat, lin, ang
-    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(q.device):
+    walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+    with _on_device(q.device):
         _check(lib.drm_fk_jacobian(ctypes.byref(walk), q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(),
                                    lin.data_ptr(), ang.data_ptr(), _stream(q.device)))
     return pos, quat, lin, ang
@@ -273,9 +329,9 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
     if B == 0:
         return tau
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
-    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
     scratch = _rnea_scratch(lib, walk, B, q.device)
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(),
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
                             scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
@@ -308,7 +364,7 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     ptr = lambda t: t.data_ptr() if t is not None else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(lib.drm_rnea_backward(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), ptr(qdd), B, flags,
                                      grad_tau.data_ptr(), ctypes.c_uint64(param_mask),
                                      ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
@@ -358,7 +414,7 @@ class WalkTable(torch.autograd.Function):
         params = torch.cat([p.reshape(-1).to(device=dev, dtype=torch.float32) for p in pieces])
         assert params.numel() == n_links * 20, "20 floats per learnable link"
         ops_f = torch.empty_like(base)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _check(lib.drm_walk_table(params.data_ptr(), n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
                                       base.numel(), ops_f.data_ptr(), _stream(dev)))
         ctx.save_for_backward(params, sel, gsign)
@@ -400,7 +456,7 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
     # the per-link records of the articulated-body sweeps, when the launch keeps them in HBM
     need = int(lib.drm_forward_dynamics_scratch_floats(ctypes.byref(walk), B))
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
                                         qdd.data_ptr(), scratch.data_ptr() if scratch is not None else None,
                                         _stream(q.device)))
@@ -419,7 +475,7 @@ def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     # robots with a long segment collect the lower triangle of H in scratch before its rows are written
     need = int(lib.drm_crba_scratch_floats(ctypes.byref(walk), B))
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(),
                             scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
     return H
@@ -445,12 +501,34 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
         return None, None
     scratch = torch.empty(max(1, lib.drm_fk_backward_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
                                    grad_rot.data_ptr() if grad_rot is not None else None,
                                    ctypes.c_uint64(param_mask), grad_q.data_ptr() if want_grad_q else None,
                                    grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
     return grad_q, grad_ops
+
+
+def fk_mse(prog: WalkProgram, ops_f, ops_i, q, target, n_dofs: int, param_mask: int, want_grad_q: bool):
+    """(loss [], grad_q [B, n] or None, grad_ops_f [cap, 32] or None) of loss = mean((pos(q) - target)^2) for the walk's target
+    (drm_fk_mse: forward kinematics, loss and backward in one pass).  Raises KernelUnsupported for walks / batches the fused
+    kernel does not take (the caller composes fk + mse_loss then)."""
+    lib = load_library()
+    q = _dev_f32(q, "q", n_dofs)
+    target = _dev_f32(target, "target", 3)
+    B, dev = q.shape[0], q.device
+    if target.shape[0] != B:
+        raise ValueError("q and target batch sizes differ")
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
+    grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
+    scratch = torch.empty(max(1, lib.drm_fk_mse_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
+    walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
+    with _on_device(dev):
+        _check(lib.drm_fk_mse(ctypes.byref(walk), q.data_ptr(), target.data_ptr(), B, ctypes.c_uint64(param_mask), loss.data_ptr(),
+                              grad_q.data_ptr() if want_grad_q else None, grad_ops.data_ptr() if param_mask else None,
+                              scratch.data_ptr(), _stream(dev)))
+    return loss, grad_q, grad_ops
 
 
 def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin, grad_ang, n_dofs: int,
@@ -470,7 +548,7 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
         return None, None
     scratch = torch.empty(max(1, lib.drm_fk_backward_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(lib.drm_fk_jacobian_backward(ctypes.byref(walk), q.data_ptr(), B,
                                             grad_pos.data_ptr() if grad_pos is not None else None,
                                             grad_rot.data_ptr() if grad_rot is not None else None, grad_lin.data_ptr(),

@@ -157,10 +157,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // iiwa, loss on the end-effector position): drm_sample.hpp fk_backward_chain — one packed chain FK per sample and
 // closed-form adjoints instead of stored poses and an adjoint sweep; constants staged once per wave in LDS, the
 // gradient tile staged over the dead q tile.  Same persistent-wave structure and batch reduction as the generic kernel.
-template <int CAP, int NJ>
+// MSE (drm_fk_mse): `gpos` is the TARGET position [B, 3]; the kernel forms the loss sum((p_e - target)^2) (one more column of
+// the partial rows, row pitch NV + 4) and its gradient g = g_scale (p_e - target), g_scale = 2 / (3 B), itself: forward
+// kinematics, loss and backward of the reference's kinematics-learning step (examples/learn_kinematics_of_iiwa.py:47-55) in ONE
+// pass over q — the chain is walked once, nothing per-sample is written unless grad_q is asked for.
+template <int CAP, int NJ, bool MSE = false>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
-                           int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *__restrict__ partials) {
+                           int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *__restrict__ partials, float g_scale) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
@@ -178,6 +182,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+    float loss_acc = 0.0f; // (lane 63 of the wave: the squared errors of its tiles, in tile order)
 
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
@@ -190,8 +195,18 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
 #pragma unroll
         for (int i = 0; i < 3; ++i) gv[i] = lg[lane * 3 + i];
-        fk_backward_chain<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, gv, param_mask, gqv,
-                                   [&](int d) -> float { return lq[lane * NJ + d]; },
+        fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
+                                   [&](const float (&pe)[3], float (&g)[3]) {
+                                       if constexpr (MSE) {
+                                           const float e[3] = {pe[0] - gv[0], pe[1] - gv[1], pe[2] - gv[2]};
+                                           const float sq = wave_sum_lane63(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]));
+                                           if (lane == 63u) loss_acc += sq;
+                                           g[0] = g_scale * e[0]; g[1] = g_scale * e[1]; g[2] = g_scale * e[2];
+                                       } else {
+                                           g[0] = gv[0]; g[1] = gv[1]; g[2] = gv[2];
+                                       }
+                                   },
+                                   param_mask, gqv, [&](int d) -> float { return lq[lane * NJ + d]; },
                                    [&](int k, const float *dF, const float *dt) {
 #pragma unroll
                                        for (int j = 0; j < BWD_FIELDS; ++j) {
@@ -208,17 +223,24 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         }
     }
     wave_lds_sync();
-    float *prow = partials + (int64_t)wave_id * NV;
+    float *prow = partials + (int64_t)wave_id * (MSE ? NV + 4 : NV);
     for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
+    if (MSE && lane == 63u) prow[NV] = loss_acc;
 }
 
 // grad_ops_f[k, FT field j] = sum over the partial rows of column k * 12 + j, in a fixed order (drm_common.hpp
 // column_sum); the rest of the row has no gradient here and is zeroed.
+// `pitch` = floats per partial row (NV, or NV + 4 with the loss column of drm_fk_mse: loss[0] = loss_scale x its column sum);
+// grad_ops_f may be NULL (drm_fk_mse without learnable links: only the loss is reduced)
 __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
-    fk_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f) {
+    fk_backward_reduce_kernel(const float *__restrict__ partials, int n_rows, int cap, float *__restrict__ grad_ops_f, int pitch,
+                              float *__restrict__ loss, float loss_scale) {
     __shared__ float lds[REDUCE_WAVES][WAVE];
     const int NV = cap * BWD_FIELDS, e = (int)blockIdx.x * WAVE + (int)(threadIdx.x & 63u);
-    const float total = column_sum(partials, n_rows, NV, e, e < NV, lds);
+    const bool is_loss = loss && e == NV;
+    const float total = column_sum(partials, n_rows, pitch, e, e < NV || is_loss, lds);
+    if (threadIdx.x < WAVE && is_loss) loss[0] = total * loss_scale;
+    if (!grad_ops_f) return;
     if (threadIdx.x < WAVE && e < NV) {
         const int k = e / BWD_FIELDS, j = e % BWD_FIELDS;
         const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
@@ -282,7 +304,7 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
             hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                               partials);
+                               partials, 0.0f);
             rc = launched();
             if (rc) return rc;
             rows_done = waves_a;
@@ -329,7 +351,8 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
     }
     if (grad_ops_f) {
         hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + WAVE - 1) / WAVE)),
-                           dim3(WAVE * REDUCE_WAVES), 0, s, scratch, rows_done + waves, cap, grad_ops_f);
+                           dim3(WAVE * REDUCE_WAVES), 0, s, scratch, rows_done + waves, cap, grad_ops_f, cap * BWD_FIELDS,
+                           (float *)nullptr, 0.0f);
         rc = launched();
         if (rc) return rc;
     }
@@ -347,6 +370,39 @@ extern "C" int drm_fk_backward(const drm_walk *w, const float *q, int64_t B, int
                     (long)DRM_MAX_SLOTS_BACKWARD);
     return fk_backward_launch(w, q, B, n_targets, grad_pos, grad_rot, nullptr, nullptr, param_mask, grad_q, grad_ops_f, scratch,
                               stream);
+}
+
+extern "C" int64_t drm_fk_mse_scratch_floats(int64_t B, int32_t capacity) {
+    if (B < 0 || capacity < 1 || capacity > DRM_MAX_OPS) return 0;
+    return (int64_t)(backward_waves(B, MAX_WAVES_PER_BLOCK) + MAX_WAVES_PER_BLOCK) * (capacity * BWD_FIELDS + 4);
+}
+
+// FK(end effector position) + mean squared error against `target` + the gradients of that loss, in two launches (the chain
+// kernel, the fixed-order reduction): see include/drm_hip.h
+extern "C" int drm_fk_mse(const drm_walk *w, const float *q, const float *target, int64_t B, uint64_t param_mask, float *loss,
+                          float *grad_q, float *grad_ops_f, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!q || !target || !loss || !scratch) return fail(DRM_ERR_INVALID, "q / target / loss / scratch must not be NULL");
+    if ((param_mask != 0) != (grad_ops_f != nullptr))
+        return fail(DRM_ERR_INVALID, "grad_ops_f must be given exactly when param_mask selects ops");
+    const int cap = w->capacity;
+    const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)target | (uintptr_t)grad_q | (uintptr_t)w->ops_f;
+    if (!((w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && w->n_dofs == 7 && (ptrs & 15u) == 0 && B >= WAVE && B % WAVE == 0 &&
+          B / WAVE < 0x7fffffffLL))
+        return fail(DRM_ERR_UNSUPPORTED, "drm_fk_mse takes 7-DoF arm chains (DRM_WALK_ARM_CHAIN, capacity 8), batches that are a "
+                                         "multiple of 64 rows and 16-byte aligned pointers; compose drm_fk and drm_fk_backward otherwise%s", "");
+    if (param_mask >> cap) return fail(DRM_ERR_INVALID, "param_mask selects ops beyond the walk's capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = (int)(B / WAVE);
+    const int waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
+                       0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
+    rc = launched();
+    if (rc) return rc;
+    hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + 1 + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0,
+                       s, scratch, waves, cap, grad_ops_f, cap * BWD_FIELDS + 4, loss, 1.0f / (3.0f * (float)B));
+    return launched();
 }
 
 extern "C" int drm_fk_jacobian_backward(const drm_walk *w, const float *q, int64_t B, const float *grad_pos,

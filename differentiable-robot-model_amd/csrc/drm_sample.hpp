@@ -662,13 +662,24 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 // registers: op numbers are run-time values there, angles come back through q_at).
 //   ft(k) -> FT block of op k;   gq[d] <- dL/dq_d;   q_at(d) -> q[d] for a run-time d;
 //   param_out(k, dF[9], dt[3]) for ops in param_mask (run-time k)
+//   g_of(pe, g): dL/dp_e once the end position is known — a given gradient (drm_fk_backward), or the gradient of a loss
+//   evaluated inside the kernel (drm_fk_mse: g = 2 (p_e - target) / (3 B))
+template <int CAP, int NJ, class FT, class GOF, class QAT, class PG>
+DRM_HD void fk_backward_chain_g(FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out);
 template <int CAP, int NJ, class FT, class QAT, class PG>
 DRM_HD void fk_backward_chain(FT ft, const float (&q)[NJ], const float (&g)[3], uint64_t param_mask, float (&gq)[NJ],
                               QAT q_at, PG param_out) {
+    fk_backward_chain_g<CAP, NJ>(ft, q, [&](const float (&)[3], float (&go)[3]) { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; },
+                                 param_mask, gq, q_at, param_out);
+}
+template <int CAP, int NJ, class FT, class GOF, class QAT, class PG>
+DRM_HD void fk_backward_chain_g(FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out) {
     PoseP ee;
     f2 B[NJ][3];
     fk_chain_pairs<CAP, NJ>(ft, q, ee, B, [] {});
     const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    float g[3];
+    g_of(pe, g);
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
         const float z[3] = {B[k][0][0], B[k][1][0], B[k][2][0]};

@@ -74,6 +74,32 @@ def all_gather_flat(out: torch.Tensor, local: torch.Tensor, group=None) -> None:
     out.reshape(-1).copy_(h_out, non_blocking=False)
 
 
+def gather_flat(out, local: torch.Tensor, dst: int = 0, group=None) -> None:
+    """Gather equal-sized contiguous shards on rank `dst` only (`out`: [world * local.numel()] there, ignored elsewhere): the
+    MPC / particle case in which ONE rank consumes the re-assembled batch — the other ranks only send, so the node moves
+    (N - 1) shards instead of N (N - 1).  RCCL moves device buffers; gloo stages device tensors through the host (as above)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) != "gloo" or not local.is_cuda:
+        parts = list(out.reshape(world, -1).unbind(0)) if rank == dst else None
+        dist.gather(local.reshape(-1), parts, dst=dst, group=group)
+        return
+    h_loc = local.reshape(-1).cpu()
+    parts = [torch.empty_like(h_loc) for _ in range(world)] if rank == dst else None
+    dist.gather(h_loc, parts, dst=dst, group=group)
+    if rank == dst:
+        out.reshape(world, -1).copy_(torch.stack(parts))
+
+
+def gather_model_us(mode: str, shard_bytes: int, tau_bytes: int, world: int, link_gbs: float = 153.0) -> float:
+    """What one exchange of a config-3 step should cost over xGMI (a fully connected mesh, one ~153 GB/s link per peer, all
+    links of a GPU busy in parallel): every receiving GPU takes one peer's block per link, so the time is ONE block over ONE
+    link — (N - 1) blocks arrive over (N - 1) links at once.  `all` / `root`: the whole shard (tau | pos | quat, 56 B per row),
+    `tau`: the torques only (28 B per row), `none`: the outputs stay sharded.  Collective launch latency (~10 us) not included."""
+    if world <= 1 or mode == "none":
+        return 0.0
+    return {"all": shard_bytes, "root": shard_bytes, "tau": tau_bytes}[mode] / (link_gbs * 1e3)
+
+
 def gather_outputs(outputs: Sequence[torch.Tensor], batch: int, group=None) -> List[torch.Tensor]:
     return [all_gather_rows(t, batch, group) for t in outputs]
 

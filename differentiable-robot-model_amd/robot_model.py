@@ -66,8 +66,11 @@ def tensor_check(function):
     def wrapper(self, *args, **kwargs):
         info = BatchInfo()
         p_args = [preprocess(a, self, info) for a in args]
-        p_kwargs = {k: preprocess(v, self, info) for k, v in kwargs.items()}
-        ret = function(self, *p_args, **p_kwargs)
+        if kwargs:
+            kwargs = {k: preprocess(v, self, info) for k, v in kwargs.items()}
+        ret = function(self, *p_args, **kwargs)
+        if not (info.init and len(info.shape) == 0):     # batched inputs: results pass through as they are
+            return ret
         if type(ret) is torch.Tensor:
             return postprocess(ret, info)
         if type(ret) is tuple:
@@ -290,6 +293,33 @@ class _FkPositions(torch.autograd.Function):
         if grad_q is not None:
             grad_q = grad_q.to(q.dtype).reshape(q.shape)
         return grad_q, grad_ops, None, None, None, None
+
+
+class _FkMse(torch.autograd.Function):
+    """loss = mean((pos(q) - target)^2) of a chain's end link with forward kinematics, loss AND gradients from one pass over q
+    (backend.fk_mse, csrc/drm_fk_backward.hip MSE form): the forward call already holds d loss / d q and d loss / d ops_f, the
+    backward scales them by the incoming gradient.  First order only."""
+
+    @staticmethod
+    def forward(ctx, q, target, ops_f, dw, n_dofs, param_mask):
+        want_q, want_p = q.requires_grad, ops_f.requires_grad
+        loss, grad_q, grad_ops = backend.fk_mse(dw.program, ops_f, dw.ops_i, q, target, n_dofs, param_mask if want_p else 0, want_q)
+        ctx.save_for_backward(*[g for g in (grad_q, grad_ops) if g is not None])
+        ctx.have = (grad_q is not None, grad_ops is not None)
+        ctx.q_shape, ctx.q_dtype = q.shape, q.dtype
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        saved = list(ctx.saved_tensors)
+        grad_q = saved.pop(0) if ctx.have[0] else None
+        grad_ops = saved.pop(0) if ctx.have[1] else None
+        if grad_q is not None:
+            grad_q = (grad_q * grad_loss).to(ctx.q_dtype).reshape(ctx.q_shape)
+        if grad_ops is not None:
+            grad_ops = grad_ops * grad_loss
+        return grad_q, None, grad_ops, None, None, None
 
 
 class _FkJacobian(torch.autograd.Function):
@@ -553,6 +583,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                                                                        ", ".join(sliding + skew)), stacklevel=2)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
+        self._chain_walks: Dict[int, _DeviceWalk] = {}          # link index -> _chain_walk's answer while nothing is learnable
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
@@ -751,6 +782,13 @@ class DifferentiableRobotModel(torch.nn.Module):
             return self._get_walk(("chain", idx), targets=[])
         if self._learnable:
             return self._get_walk(("chain", idx), targets=[idx])
+        hit = self._chain_walks.get(idx)      # (constant model: the walk of a link never changes; cleared when a link turns learnable)
+        if hit is not None:
+            return hit
+        dw = self._chain_walks[idx] = self._chain_walk_build(idx)
+        return dw
+
+    def _chain_walk_build(self, idx: int) -> _DeviceWalk:
         key = self._fold_key()
         fold = self._fold_masks[key]
         chain = self._spec.chain_to(idx)
@@ -971,13 +1009,37 @@ class DifferentiableRobotModel(torch.nn.Module):
         pos, quat = self._fk_targets(q, [idx])
         return pos[:, 0], quat[:, 0]
 
+    def fk_mse_loss(self, q: torch.Tensor, link_name: str, target: torch.Tensor) -> torch.Tensor:
+        """``torch.nn.functional.mse_loss(self.compute_forward_kinematics(q, link_name)[0], target)`` — the loss of the reference's
+        kinematics-learning loop (examples/learn_kinematics_of_iiwa.py:47-55) — as ONE differentiable node: for a serial 7-DoF arm
+        (the iiwa of BASELINE configuration 5, the Panda) and a batch that is a multiple of 64 rows, forward kinematics, the loss
+        and its gradients with respect to q and the learnable ``trans`` / ``rot_angles`` come from one pass over q (drm_fk_mse)
+        instead of an FK launch, the loss kernels and a backward launch; every other robot / batch takes exactly the composition
+        above.  Not in the reference."""
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs and target.shape == (q.shape[0], 3)
+        self._require_device()
+        idx = self._name_to_idx_map[link_name]
+        if idx != 0 and q.shape[0] % 64 == 0 and q.shape[0] > 0:
+            dw = self._get_walk(("fk", (idx,)), targets=[idx])
+            if dw.program.shape & 1 and dw.program.capacity == 8 and self._n_dofs == 7:    # DRM_WALK_ARM_CHAIN
+                ops_f = self._ops_f(dw)
+                try:
+                    if torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):
+                        self._differentiable(dw)
+                        return _FkMse.apply(q, target, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
+                    return backend.fk_mse(dw.program, ops_f, dw.ops_i, q, target, self._n_dofs, 0, False)[0]
+                except backend.KernelUnsupported:
+                    pass
+        pos, _ = self.compute_forward_kinematics(q, link_name)
+        return torch.nn.functional.mse_loss(pos, target)
+
     # ------------------------------------------------------------------ Jacobian
     @tensor_check
     def compute_endeffector_jacobian(self, q: torch.Tensor, link_name: str) -> Tuple[torch.Tensor, torch.Tensor]:
         """(lin_jac [B,3,n], ang_jac [B,3,n]) at the link origin, world frame (robot_model.py:626-667)."""
         assert len(q.shape) == 2
         assert q.shape[1] == self._n_dofs
-        _, _, lin, ang = self.compute_fk_and_jacobian(q, link_name)
+        _, _, lin, ang = self._fk_and_jacobian(q, link_name)
         return lin, ang
 
     @tensor_check
@@ -990,6 +1052,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         """
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
+        return self._fk_and_jacobian(q, link_name)
+
+    def _fk_and_jacobian(self, q: torch.Tensor, link_name: str):
         self._require_device()
         idx = self._name_to_idx_map[link_name]
         if idx != 0 and torch.is_grad_enabled() and (q.requires_grad or self._learnable):
@@ -1187,6 +1252,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         for dw in self._walks.values():
             dw.static_ops_f = None
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
+        self._chain_walks.clear()
 
     def _learnable_module(self, link_name: str, parameter_name: str):
         parent_object = self._get_parent_object_of_param(link_name, parameter_name)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 8
+#define DRM_ABI_VERSION 9
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
@@ -341,6 +341,24 @@ int drm_fk_backward(const drm_walk *walk, const float *q, int64_t B, int32_t n_t
 int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, const float *grad_pos, const float *grad_rot,
                              const float *grad_lin_jac, const float *grad_ang_jac, uint64_t param_mask, float *grad_q,
                              float *grad_ops_f, float *scratch, void *stream);
+
+/*
+ * One training step's worth of the reference's kinematics-learning loop in one pass over q
+ * (examples/learn_kinematics_of_iiwa.py:47-55: compute_forward_kinematics (robot_model.py:223-248) -> torch.nn.MSELoss ->
+ * backward through robot_model.py:139-195 with learnable `trans` / `rot_angles`, robot_model.py:669-713):
+ *   loss[0]     = mean over the B x 3 entries of (pos(q) - target)^2, pos = position of the walk's target (its last op)
+ *   grad_q      [B, n] or NULL   d loss / d q
+ *   grad_ops_f  [capacity, DRM_OPF_STRIDE]  d loss / d (R_fixed, trans) of the ops in param_mask (as drm_fk_backward), NULL iff
+ *               param_mask == 0
+ *   target      [B, 3];  scratch: drm_fk_mse_scratch_floats(B, capacity) floats, owned by the caller
+ * The chain is walked once per sample (the forward pose, the loss and the closed-form adjoints of drm_fk_backward's chain
+ * kernel); the batch sums are reduced in a fixed order (bit-stable from run to run).  Two launches.
+ * Takes serial 7-DoF arm chains (DRM_WALK_ARM_CHAIN, capacity 8: the iiwa of BASELINE configuration 5, the Panda), B a
+ * multiple of 64, 16-byte aligned pointers; DRM_ERR_UNSUPPORTED otherwise (compose drm_fk + the loss + drm_fk_backward).
+ */
+int64_t drm_fk_mse_scratch_floats(int64_t B, int32_t capacity);
+int drm_fk_mse(const drm_walk *walk, const float *q, const float *target, int64_t B, uint64_t param_mask, float *loss,
+               float *grad_q, float *grad_ops_f, float *scratch, void *stream);
 
 /*
  * Reverse-mode derivative of drm_rnea: what torch autograd computes in the reference when a loss on

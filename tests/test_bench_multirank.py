@@ -40,16 +40,41 @@ def test_shared_gpu_flag_selects_gloo():
     assert bench.parse_args(["--gpus", "2"]).backend == "nccl"
 
 
+def test_gather_flag_per_config():
+    import bench
+    assert bench.parse_args([]).gather is False and bench.parse_args(["--gather"]).gather is True     # metric config: a switch
+    assert bench.parse_args(["--gather", "none"]).gather is False
+    assert bench.parse_args(["--config", "3"]).gather is None                                           # config 3: a mode
+    assert bench.parse_args(["--config", "3", "--gather"]).gather == "all"
+    assert bench.parse_args(["--config", "3", "--gather", "tau"]).gather == "tau"
+    from differentiable_robot_model_amd.distributed import gather_model_us
+    shard, tau = 131072 * 56, 131072 * 28
+    assert gather_model_us("none", shard, tau, 8) == 0.0 and gather_model_us("all", shard, tau, 1) == 0.0
+    assert abs(gather_model_us("all", shard, tau, 8) - 47.97) < 0.1 and abs(gather_model_us("tau", shard, tau, 8) - 23.99) < 0.1
+    assert gather_model_us("root", shard, tau, 8) == gather_model_us("all", shard, tau, 8)
+
+
 @pytest.mark.gpu
 def test_config3_two_ranks_sharing_the_gpu_gather_equals_one_launch():
-    line = run_bench("--gpus", "2", "--config", "3", "--steps", "5", "--warmup", "2", "--shared-gpu", "--verify-gather")
+    line = run_bench("--gpus", "2", "--config", "3", "--gather", "all", "--steps", "5", "--warmup", "2", "--shared-gpu", "--verify-gather")
     rows = (1 << 20) // 2
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 5 and line["scaling"] == "strong"
-    assert line["config"]["batch_per_gpu"] == rows and line["config"]["gather"] is True
+    assert line["config"]["batch_per_gpu"] == rows and line["config"]["gather"] == "all"
     assert line["config"]["gather_bytes_per_rank"] == rows * 56
-    assert line["gather_verified"] is True
+    assert line["gather_verified"] is True          # all-gather, torques-only all-gather and gather-to-root, bit for bit vs one launch
     assert line["distributed"]["backend"] == "gloo" and line["distributed"]["shared_gpu"] is True
     assert line["value"] > 0 and line["compute_us_per_step"] > 0 and line["step_us_with_gather"] >= line["compute_us_per_step"] * 0.5
+    modes = line["gather_modes"]
+    assert set(modes) == {"none", "tau", "root", "all"} and modes["all"]["value"] == line["value"]
+    assert modes["tau"]["gather_bytes_per_rank"] == rows * 28 and modes["none"]["gather_bytes_per_rank"] == 0
+    assert modes["none"]["value"] >= modes["all"]["value"] and modes["all"]["gather_model_us"] > modes["tau"]["gather_model_us"] > 0
+
+
+@pytest.mark.gpu
+def test_config3_headline_is_the_sharded_step():
+    line = run_bench("--gpus", "2", "--config", "3", "--steps", "5", "--warmup", "2", "--shared-gpu", "--no-cpu-baseline")
+    assert line["config"]["gather"] == "none" and line["config"]["gather_bytes_per_rank"] == 0
+    assert line["value"] == line["gather_modes"]["none"]["value"] and line["gather_us_per_step"] < line["compute_us_per_step"]
 
 
 @pytest.mark.gpu

@@ -92,6 +92,48 @@ def test_gpu_fk_backward_vs_reference_autograd_tiles(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["iiwa7", "panda_no_gripper"])
+def test_gpu_fused_fk_mse_step_vs_reference_autograd_tiles(case):
+    """fk_mse_loss (drm_fk_mse: forward kinematics, MSE and gradients from ONE pass over q) against the loss and the gradients
+    torch autograd produced through the UNMODIFIED reference for compute_forward_kinematics -> MSELoss -> backward
+    (examples/learn_kinematics_of_iiwa.py:47-55), and against this package's own composition of the three."""
+    import torch
+    g = tiles("grad")
+    targets = [str(t) for t in g[case + "/targets"]]
+    assert len(targets) == 1
+    m = fkb.learnable_model(g, case, "cuda")
+    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
+    want = torch.from_numpy(g["%s/want/%s" % (case, targets[0])].copy()).cuda()
+    loss = m.fk_mse_loss(q, targets[0], want)
+    assert loss.grad_fn is not None and type(loss.grad_fn).__name__.startswith("_FkMse")     # (the fused node, not the fallback)
+    loss.backward()
+    assert abs(loss.item() - float(g[case + "/loss"])) < 1e-6
+    assert fkb.close(q.grad.cpu().numpy(), g[case + "/grad_q"])
+    grads = {}
+    for link in g[case + "/learnable"]:
+        body = m._bodies[m._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            grads[(str(link), pname)] = getattr(body, pname).param.grad.clone()
+            assert fkb.close(grads[(str(link), pname)].cpu().numpy(), g["%s/grad/%s/%s" % (case, link, pname)]), (case, link, pname)
+    # the composition it replaces: same loss and gradients to rounding
+    m2 = fkb.learnable_model(g, case, "cuda")
+    q2 = q.detach().clone().requires_grad_(True)
+    loss2 = torch.nn.functional.mse_loss(m2.compute_forward_kinematics(q2, targets[0])[0], want)
+    loss2.backward()
+    assert abs(loss2.item() - loss.item()) < 1e-7 * max(1.0, abs(loss.item())) + 1e-9
+    assert fkb.close(q.grad.cpu().numpy(), q2.grad.cpu().numpy(), 1e-5)
+    for (link, pname), got in grads.items():
+        ref = getattr(m2._bodies[m2._name_to_idx_map[link]], pname).param.grad
+        assert fkb.close(got.cpu().numpy(), ref.cpu().numpy(), 1e-4), (link, pname)
+    # no graph: the plain value; a ragged batch: the composed path, same number
+    with torch.no_grad():
+        assert abs(m.fk_mse_loss(q.detach(), targets[0], want).item() - loss.item()) < 1e-9
+        rag = m.fk_mse_loss(q.detach()[:100], targets[0], want[:100])
+        ref = torch.nn.functional.mse_loss(m.compute_forward_kinematics(q.detach()[:100], targets[0])[0], want[:100])
+        assert abs(rag.item() - ref.item()) < 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", DYN_CASES)
 def test_gpu_rnea_backward_vs_reference_autograd_tiles(case):
     rbt.check_gpu_backward_vs_reference_autograd(tiles("grad_dyn"), case)

@@ -508,7 +508,7 @@ def test_inverse_dynamics_of_an_arm_that_carries_a_hand(robot, compat):
     from differentiable_robot_model_amd import backend
     lib = backend.load_library()
     dw = m._dynamics_walk()
-    generic = backend._walk_struct(dw.program, m._ops_f(dw), dw.ops_i, m._n_dofs)
+    generic = backend._walk_struct_build(dw.program, m._ops_f(dw), dw.ops_i, m._n_dofs)   # (a private copy, not the cached struct)
     generic.shape &= ~SHAPE_ARM_HAND
     dq, dqd = dev(q), dev(qd)
     worst = 0.0

@@ -284,7 +284,7 @@ def test_gpu_scratch_of_the_persistent_kernels():
         assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
     # ... the same walk without its shape bit takes the persistent loop kernels for every row: their scratch does NOT grow with
     # the batch once the grid is full (a persistent block owns a slice)
-    generic = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
+    generic = backend._walk_struct_build(dw.program, of, dw.ops_i, m._n_dofs)   # (a private copy: _walk_struct hands out a cached struct)
     generic.shape &= ~4
     for name in SCRATCH_QUERIES:
         small, big, bigger = (int(getattr(lib, name)(ctypes.byref(generic), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Where the host time of an eager public-API call goes (cProfile over 3 000 calls per method, Panda, 65 536 rows)."""
+import cProfile, io, os, pstats, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gpu_probe import load, sample
+
+m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
+q, qd, qdd = (t.cuda() for t in sample(m, 65536))
+calls = {"compute_forward_kinematics": lambda: m.compute_forward_kinematics(q, link),
+         "compute_endeffector_jacobian": lambda: m.compute_endeffector_jacobian(q, link),
+         "compute_inverse_dynamics": lambda: m.compute_inverse_dynamics(q, qd, qdd)}
+N = 3000
+for name, fn in calls.items():
+    for _ in range(50):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(N):
+            fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / N * 1e6)
+    print("%-32s %6.2f us per eager call (wall, %d calls, one synchronize at the end)" % (name, best, N))
+if len(sys.argv) > 1 and sys.argv[1] == "profile":
+    for name, fn in calls.items():
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(N):
+            fn()
+        pr.disable()
+        torch.cuda.synchronize()
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14)
+        print("==== %s (tottime, %d calls)" % (name, N))
+        print("\n".join(l for l in s.getvalue().splitlines()[4:] if l.strip())[:3500])
