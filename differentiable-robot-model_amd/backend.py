@@ -47,7 +47,8 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_rnea_backward_scratch_floats", "drm_forward_dynamics", "drm_link_rows",
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
-           "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats")
+           "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats", "drm_rnea_scratch_floats_aligned",
+           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned")
 
 
 def load_library(path: str = None):
@@ -113,6 +114,9 @@ def load_library(path: str = None):
         lib.drm_crba_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_rnea.restype = ctypes.c_int
         lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
+        for name in ("drm_rnea_scratch_floats_aligned", "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned"):
+            getattr(lib, name).restype = i64
+            getattr(lib, name).argtypes = [wp, i64]
         lib.drm_fk_mse.restype = ctypes.c_int
         lib.drm_fk_mse.argtypes = [wp, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
         lib.drm_fk_mse_scratch_floats.restype = i64
@@ -340,7 +344,7 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
 
 def _rnea_scratch(lib, walk, B, device):
     """The body forces robots with a long segment keep between the two sweeps of drm_rnea (None: not needed)."""
-    need = int(lib.drm_rnea_scratch_floats(ctypes.byref(walk), B))
+    need = int(lib.drm_rnea_scratch_floats_aligned(ctypes.byref(walk), B))    # (_dev_f32 / _plan_input guarantee aligned pointers)
     return torch.empty(need, device=device, dtype=torch.float32) if need > 0 else None
 
 
@@ -454,7 +458,7 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
     flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     # the per-link records of the articulated-body sweeps, when the launch keeps them in HBM
-    need = int(lib.drm_forward_dynamics_scratch_floats(ctypes.byref(walk), B))
+    need = int(lib.drm_forward_dynamics_scratch_floats_aligned(ctypes.byref(walk), B))
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
     with _on_device(q.device):
         _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
@@ -473,7 +477,7 @@ def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
         return H
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     # robots with a long segment collect the lower triangle of H in scratch before its rows are written
-    need = int(lib.drm_crba_scratch_floats(ctypes.byref(walk), B))
+    need = int(lib.drm_crba_scratch_floats_aligned(ctypes.byref(walk), B))
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
     with _on_device(q.device):
         _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(),

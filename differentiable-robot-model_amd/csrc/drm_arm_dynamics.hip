@@ -194,7 +194,10 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ?
 #ifndef DRM_FINGERS_PARK
 #define DRM_FINGERS_PARK 0 /* body forces of that many first links parked in LDS instead of registers */
 #endif
-#define DRM_FINGERS_KEEP(L) ((L) - 1 - ((L) - 1 < DRM_FINGERS_PARK ? (L) - 1 : DRM_FINGERS_PARK))
+// (L = 3, TriFinger: one parked link — with all three forces in registers the kernel sat 2 VGPRs over its three-wave budget and
+// spilled them to scratch, profiles/r03_resource_usage.txt)
+#define DRM_FINGERS_PARK_OF(L) ((L) == 3 && DRM_FINGERS_PARK == 0 ? 1 : DRM_FINGERS_PARK)
+#define DRM_FINGERS_KEEP(L) ((L) - 1 - ((L) - 1 < DRM_FINGERS_PARK_OF(L) ? (L) - 1 : DRM_FINGERS_PARK_OF(L)))
 template <int L>
 __global__ void __launch_bounds__(WAVE * 4)
     __attribute__((amdgpu_waves_per_eu(L <= 3 ? 3 : DRM_FINGERS_WAVES4, L <= 3 ? 3 : DRM_FINGERS_WAVES4)))

@@ -303,8 +303,9 @@ __global__ void __launch_bounds__(WAVE *crba_max_k(L))
 // (The gradients leave through the tiles as coalesced stores.  Written straight to the lanes' rows — 4-byte stores 4 n bytes
 // apart, which would free 18 KB of LDS at 23 DoF — the same launch took 2 005 instead of 760 us.)
 // ---------------------------------------------------------------------------------------------------
+// (P = 6, L = 4 alone does not fit two waves' worth of registers — 3 VGPRs went to scratch — and takes one wave per SIMD instead)
 template <int P, int L>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((P == 6 && L == 4) ? 1 : 2, 2)))
     rnea_backward_arm_hand_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
                                   const float *__restrict__ qd, const float *__restrict__ qdd, const float *__restrict__ gtau, int K,
                                   int cap, int n, int n_tiles, int flags, uint64_t param_mask, float *__restrict__ gq,

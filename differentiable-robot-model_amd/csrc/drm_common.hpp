@@ -376,6 +376,16 @@ struct Geometry {
 // waves per block: as many as fit a 64 KiB LDS budget (<= 4); one wave per 64 samples.
 int make_geometry(int64_t B, int lds_floats_per_wave, Geometry &g);
 
+// Scratch of the walks whose FULL, ALIGNED tiles run straight-line kernels that need none (7-DoF arms, arms that carry a hand): the
+// size queries (drm_rnea / drm_crba / drm_forward_dynamics _scratch_floats) cannot see the caller's pointers, so they always size
+// for min(tiles, MISALIGNED_TILES) tiles of the loop kernels — enough for a ragged tail (one tile) and for a call whose pointers
+// are not 16-byte aligned, which runs the persistent loop kernel on at most that many blocks instead of being refused (ABI 9).
+constexpr int MISALIGNED_TILES = 64;
+static inline int64_t fast_path_scratch_tiles(int64_t B) {
+    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    return tiles < MISALIGNED_TILES ? tiles : MISALIGNED_TILES;
+}
+
 // waves of a backward launch (each strides over tiles and writes one row of partial sums), a multiple of wpb
 static inline int backward_waves(int64_t B, int wpb) {
     const int64_t tiles = (B + WAVE - 1) / WAVE;

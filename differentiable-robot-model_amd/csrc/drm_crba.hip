@@ -328,23 +328,23 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 
 using namespace drm;
 
-extern "C" int64_t drm_crba_scratch_floats(const drm_walk *w, int64_t B) {
+static int64_t drm_crba_scratch_floats_impl(const drm_walk *w, int64_t B, bool aligned) {
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
-    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
-        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
-        if (B == 0) return 0;
-    }
-    if (crba_arm_hand_applies(w)) {
-        B %= WAVE; // full tiles run the straight-line kernel (drm_arm_hand.hip, no scratch); a ragged tail a loop kernel
-        if (B == 0) return 0;
-    }
+    // (full aligned tiles of these walks run straight-line kernels without scratch: sized for the ragged tail and for a misaligned
+    // call, drm_common.hpp fast_path_scratch_tiles)
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || crba_arm_hand_applies(w);
     TreeArgs a;
     if (crba_short_plan(w, a)) return 0;
     CrbaRowsPlan p;
     if (crba_rows_plan(w, p)) return 0;
-    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    const int64_t tiles = fast ? (aligned ? (B % WAVE ? 1 : 0) : fast_path_scratch_tiles(B)) : (B + WAVE - 1) / WAVE;
     return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_segments * p.nt_max * WAVE;
 }
+extern "C" int64_t drm_crba_scratch_floats(const drm_walk *w, int64_t B) { return drm_crba_scratch_floats_impl(w, B, false); }
+// ... for a caller that GUARANTEES 16-byte aligned q / qd / qdd (f) / outputs (both Python bindings do: they clone a misaligned
+// slice): the full tiles of a 7-DoF arm / an arm with a hand then run straight-line kernels that need no scratch — only a ragged
+// tail's one tile is sized
+extern "C" int64_t drm_crba_scratch_floats_aligned(const drm_walk *w, int64_t B) { return drm_crba_scratch_floats_impl(w, B, true); }
 
 extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, float *scratch, void *stream) {
     int rc = check_walk(w);
@@ -381,8 +381,8 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
             return drm_crba(&generic, q + done * n, B - done, H + done * nn, scratch, stream);
         }
     }
-    if (B >= WAVE && crba_arm_hand_applies(w) && (((uintptr_t)q | (uintptr_t)H) & 15u) != 0)
-        return fail(DRM_ERR_INVALID, "q / H must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
+    // (a misaligned call on a walk with a straight-line kernel, or its ragged tail: the loop kernel on at most MISALIGNED_TILES blocks)
+    const bool fast_walk = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7) || crba_arm_hand_applies(w);
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;
@@ -406,7 +406,8 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (rc) return rc;
     if (!scratch || ((uintptr_t)scratch & 15u))
         return fail(DRM_ERR_INVALID, "this robot's inertia matrix is assembled through scratch: pass drm_crba_scratch_floats() floats, 16-byte aligned");
-    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    if (fast_walk && grid > MISALIGNED_TILES) grid = MISALIGNED_TILES;
     hipLaunchKernelGGL(crba_rows_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, p.nt_max, q, B, (int)tiles, H, scratch,
                        div_magic(n), align);
     return launched();

@@ -388,23 +388,23 @@ static int64_t launch_forward_dynamics_fingers(const drm_walk *w, const float *q
 
 using namespace drm;
 
-extern "C" int64_t drm_forward_dynamics_scratch_floats(const drm_walk *w, int64_t B) {
+static int64_t drm_forward_dynamics_scratch_floats_impl(const drm_walk *w, int64_t B, bool aligned) {
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
-    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
-        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
-        if (B == 0) return 0;
-    }
-    if (arm_hand_compiled(w)) {
-        B %= WAVE; // full tiles run the straight-line arm + hand kernel (drm_arm_hand.hip), which needs no scratch
-        if (B == 0) return 0;
-    }
+    // (full aligned tiles of these walks run straight-line kernels without scratch: sized for the ragged tail and for a misaligned
+    // call, drm_common.hpp fast_path_scratch_tiles)
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w);
     TreeArgs a;
     if (fd_short_plan(w, a)) return 0;
     AbaPlan p;
     if (aba_plan(w, p)) return 0;
-    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    const int64_t tiles = fast ? (aligned ? (B % WAVE ? 1 : 0) : fast_path_scratch_tiles(B)) : (B + WAVE - 1) / WAVE;
     return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_ops * ABA_REC_FLOATS * WAVE;
 }
+extern "C" int64_t drm_forward_dynamics_scratch_floats(const drm_walk *w, int64_t B) { return drm_forward_dynamics_scratch_floats_impl(w, B, false); }
+// ... for a caller that GUARANTEES 16-byte aligned q / qd / qdd (f) / outputs (both Python bindings do: they clone a misaligned
+// slice): the full tiles of a 7-DoF arm / an arm with a hand then run straight-line kernels that need no scratch — only a ragged
+// tail's one tile is sized
+extern "C" int64_t drm_forward_dynamics_scratch_floats_aligned(const drm_walk *w, int64_t B) { return drm_forward_dynamics_scratch_floats_impl(w, B, true); }
 
 extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const float *qd, const float *f, int64_t B,
                                     int32_t flags, float *qdd, float *scratch, void *stream) {
@@ -457,10 +457,9 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
                                         stream);
         }
     }
-    // (as in drm_rnea: the scratch of these walks is sized for the aligned fast path — refuse what would overrun it)
-    if (B >= WAVE && ((((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w)) &&
-        (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd) & 15u) != 0)
-        return fail(DRM_ERR_INVALID, "q / qd / f / qdd must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
+    // (as in drm_rnea: a misaligned call on a walk with a straight-line kernel, or its ragged tail, runs the loop kernel on at most
+    // MISALIGNED_TILES blocks — what its scratch is sized for)
+    const bool fast_walk = (((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w);
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;
@@ -481,7 +480,8 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if (!scratch)
         return fail(DRM_ERR_INVALID, "this robot runs the articulated-body kernel: pass drm_forward_dynamics_scratch_floats() floats of scratch");
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
-    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    if (fast_walk && grid > MISALIGNED_TILES) grid = MISALIGNED_TILES;
     hipLaunchKernelGGL(forward_dynamics_aba_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags, q, qd, f, B,
                        (int)tiles, qdd, scratch, div_magic(n), align);
     return launched();

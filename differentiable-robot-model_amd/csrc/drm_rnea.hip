@@ -176,23 +176,23 @@ static int rnea_records_plan(const drm_walk *w, RneaRecordsPlan &p) {
 
 using namespace drm;
 
-extern "C" int64_t drm_rnea_scratch_floats(const drm_walk *w, int64_t B) {
+static int64_t drm_rnea_scratch_floats_impl(const drm_walk *w, int64_t B, bool aligned) {
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
-    if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) {
-        B %= WAVE; // full tiles run the arm kernel; a ragged tail the generic one
-        if (B == 0) return 0;
-    }
-    if (arm_hand_compiled(w)) {
-        B %= WAVE; // full tiles run the straight-line arm + hand kernel (drm_arm_hand.hip)
-        if (B == 0) return 0;
-    }
+    // (7-DoF arms / arms with a hand: full aligned tiles run straight-line kernels without scratch; sized for the ragged tail and
+    // for a misaligned call, drm_common.hpp fast_path_scratch_tiles)
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w);
     TreeArgs a;
     if (rnea_short_plan(w, a)) return 0;
     RneaRecordsPlan p;
     if (rnea_records_plan(w, p)) return 0;
-    const int64_t tiles = (B + WAVE - 1) / WAVE;
+    int64_t tiles = fast ? (aligned ? (B % WAVE ? 1 : 0) : fast_path_scratch_tiles(B)) : (B + WAVE - 1) / WAVE;
     return (tiles < p.resident ? tiles : (int64_t)p.resident) * p.a.n_ops * RNEA_FORCE_FLOATS * WAVE;
 }
+extern "C" int64_t drm_rnea_scratch_floats(const drm_walk *w, int64_t B) { return drm_rnea_scratch_floats_impl(w, B, false); }
+// ... for a caller that GUARANTEES 16-byte aligned q / qd / qdd (f) / outputs (both Python bindings do: they clone a misaligned
+// slice): the full tiles of a 7-DoF arm / an arm with a hand then run straight-line kernels that need no scratch — only a ragged
+// tail's one tile is sized
+extern "C" int64_t drm_rnea_scratch_floats_aligned(const drm_walk *w, int64_t B) { return drm_rnea_scratch_floats_impl(w, B, true); }
 
 extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int32_t flags,
                         float *tau, float *scratch, void *stream) {
@@ -242,12 +242,10 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
                             scratch, stream);
         }
     }
-    // drm_rnea_scratch_floats sizes the scratch of a 7-DoF arm chain / an arm with a hand for the ragged tail only (their full
-    // tiles run kernels that need none) — which holds when the fast path is taken, i.e. for 16-byte aligned pointers.  A
-    // misaligned call would send every row through the loop kernel and overrun that scratch: refuse it.
-    if (B >= WAVE && ((((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w)) &&
-        align != (AL_Q | AL_QD | AL_TAU | (qdd ? AL_QDD : 0u)))
-        return fail(DRM_ERR_INVALID, "q / qd / qdd / tau must be 16-byte aligned for this walk (its scratch is sized for the aligned fast path)");
+    // A walk whose full tiles would have run a straight-line kernel got here because its pointers are not 16-byte aligned (or as
+    // the ragged tail of such a call): its scratch holds fast_path_scratch_tiles(B) tiles of the loop kernel — the persistent grid
+    // below is held to that many blocks.
+    const bool fast_walk = (((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7)) || arm_hand_compiled(w);
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;
@@ -265,7 +263,8 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     if (rc) return rc;
     if (!scratch)
         return fail(DRM_ERR_INVALID, "this robot's inverse dynamics keeps its per-link records in scratch: pass drm_rnea_scratch_floats() floats");
-    const int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    int64_t grid = tiles < p.resident ? tiles : (int64_t)p.resident;
+    if (fast_walk && grid > MISALIGNED_TILES) grid = MISALIGNED_TILES;
     hipLaunchKernelGGL(rnea_records_kernel, dim3((unsigned)grid), dim3(WAVE * p.a.n_segments), p.lds, s, p.a, (int)flags, q, qd, qdd, B,
                        (int)tiles, tau, scratch, div_magic(n), align);
     return launched();

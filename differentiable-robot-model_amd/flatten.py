@@ -79,6 +79,11 @@ def fk_fan_partition(ops, parent_op, n_ops: int):
     work, or when two runs would write the same save slot."""
     if n_ops < 8:
         return None
+    # the wavefronts of a block share the save slots without synchronising: every slot may be written by ONE op of the walk only
+    # (a walk that reuses a slot once a sub-tree is done is only safe in sequence) — checked here, not left to the caller
+    written = [ops[k][OPI_SAVE] for k in range(n_ops) if ops[k][OPI_SAVE] >= 0]
+    if len(written) != len(set(written)):
+        return None
     end = list(range(n_ops))                      # last op of every op's sub-tree (depth-first order: a contiguous range)
     for k in range(n_ops - 1, -1, -1):
         if parent_op[k] >= 0:

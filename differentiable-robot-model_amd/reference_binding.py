@@ -138,7 +138,10 @@ class HipBinding(object):
 
     def _in(self, t):
         assert t.device.type == "cuda" and t.ndim == 2 and t.shape[1] == self.n
-        return t.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        if t.data_ptr() & 15:    # a row slice (q[1:] of a [B, 7] tensor starts 28 bytes in): drm_rnea / drm_forward_dynamics take the
+            t = t.clone()        # aligned fast kernels of arm / arm + hand walks only on 16-byte aligned pointers (backend._dev_f32)
+        return t
 
     # -- the three methods -------------------------------------------------------------------------------------
     def fk(self, q, link_name):

@@ -29,6 +29,7 @@ from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
 
 robot_description_folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robot_data")
+_WARNED_URDFS = set()      # URDF files whose "joints modelled as the URDF says" warning has been given in this process
 
 
 def tensor_check(function):
@@ -176,12 +177,15 @@ class _GradLaunch(torch.autograd.Function):
     reference gets these from torch autograd on its tensor ops).  There is no second-order adjoint kernel: both derivatives
     of the node are DIRECTIONAL derivatives along the incoming cotangent u, taken as central differences of first-order
     launches with one Richardson step,
-        d/dc:  J(x) u          = d/de fwd(x + e u)          (four forward launches)
-        d/dx:  d/dx <g(x;c),u> = d/de bwd(x + e u; c)       (four backward launches)
-    with e = h / max|u_b| per sample and D = (4 D(h/2) - D(h)) / 3.  The outputs are trigonometric polynomials of q and at
-    most quadratic in qd / qdd, so the truncation error (h^4) is below the fp32 noise of the differences: second derivatives
-    come out to ~1e-4 relative to the gradient's scale (tests/test_second_order.py holds them to the reference's autograd
-    at 2e-3).  Third derivatives are not provided (this node's backward is once-differentiable).
+        d/dc:  J(x) u          = d/de fwd(x + e u)          (forward launches)
+        d/dx:  d/dx <g(x;c),u> = d/de bwd(x + e u; c)       (backward launches)
+    one difference quotient per input x_i (four launches for the joint angles: h = SECOND_ORDER_STEP / max|u_b| per sample with
+    D = (4 D(h/2) - D(h)) / 3; two each for qd and qdd, whose step is the input's own magnitude — the outputs are at most
+    quadratic in them, so the quotient is exact at any step).  ERROR MODEL: fp32 differences of first-order launches, i.e.
+    an ABSOLUTE error of about 1e-6 x (scale of the first-order gradient) / h per entry — ~1e-4 of the gradient's scale,
+    whatever the size of the second derivative itself: Hessian entries that are small next to the gradient are resolved only
+    to that floor (tests/test_second_order.py holds the result to the reference's autograd at 2e-3 of the largest entry, also for
+    |qd|, |qdd| ~ 50).  Third derivatives are not provided (this node's backward is once-differentiable).
 
     fwd(xs) -> tuple of outputs;  bwd(xs, cs) -> tuple of gradients, one per x;  args = xs (n_x tensors, [B, ...]) then cs."""
 
@@ -201,19 +205,39 @@ class _GradLaunch(torch.autograd.Function):
         xs, cs = args[:n_x], args[n_x:]
         us = [u.to(torch.float32) if u is not None else torch.zeros_like(x) for u, x in zip(us, xs)]
         B = xs[0].shape[0]
-        scale = torch.stack([u.reshape(B, -1).abs().amax(dim=1) for u in us]).amax(dim=0).clamp_min(1e-30)   # [B]
         bc = lambda t, like: t.reshape((B,) + (1,) * (like.ndim - 1))
-        ds = [u / bc(scale, u) for u in us]
-        at = lambda e: [x + e * d for x, d in zip(xs, ds)]
 
         def directional(f):
-            h = SECOND_ORDER_STEP
-            out = None
-            for step, weight in ((0.5 * h, 4.0 / 3.0), (h, -1.0 / 3.0)):
-                hi, lo = f(at(step)), f(at(-step))
-                part = [(a - b) * (weight / (2.0 * step)) for a, b in zip(hi, lo)]
-                out = part if out is None else [o + p for o, p in zip(out, part)]
-            return [o * bc(scale, o) for o in out]
+            """D_u f = sum_i D_{u_i} f, one difference quotient per INPUT (the directional derivative is linear in the direction)
+            so that every input gets a step of its own size: x_0 (joint angles, the outputs are trigonometric in them) the
+            absolute step h with one Richardson step; x_1, x_2 (qd, qdd: the outputs are polynomials of degree <= 2 in them,
+            for which a central difference is EXACT at any step) a step of the input's own magnitude, max(1, max|x_i|) per
+            sample — the rounding error of a difference is eps |f| / step, so a fixed small step would lose the second
+            derivatives of fast, hard-accelerating states in the noise of torques that grow like qd^2."""
+            total = None
+            for i, (x, u) in enumerate(zip(xs, us)):
+                peak = u.reshape(B, -1).abs().amax(dim=1)
+                if not bool((peak > 0).any()):
+                    continue
+                d = u / bc(peak.clamp_min(1e-30), u)
+                if i == 0:
+                    plan = ((0.5 * SECOND_ORDER_STEP, 4.0 / 3.0), (SECOND_ORDER_STEP, -1.0 / 3.0))
+                    size = torch.ones_like(peak)
+                else:
+                    plan = ((1.0, 1.0),)
+                    size = x.reshape(B, -1).abs().amax(dim=1).clamp_min(1.0)
+                part = None
+                for step, weight in plan:
+                    e = step * size
+                    shifted = lambda sgn: [xx + sgn * bc(e, xx) * d if j == i else xx for j, xx in enumerate(xs)]
+                    hi, lo = f(shifted(1.0)), f(shifted(-1.0))
+                    term = [(a - b) * bc(weight / (2.0 * e), a) for a, b in zip(hi, lo)]
+                    part = term if part is None else [o + t for o, t in zip(part, term)]
+                part = [o * bc(peak, o) for o in part]
+                total = part if total is None else [o + t for o, t in zip(total, part)]
+            if total is None:
+                total = [torch.zeros_like(t) for t in f(list(xs))]
+            return total
 
         need = ctx.needs_input_grad[3:]
         g_x = [None] * n_x
@@ -227,11 +251,21 @@ class _GradLaunch(torch.autograd.Function):
         return (None, None, None, *g_x, *g_c)
 
 
-def _refuse_second_order_in_parameters(needs_table_grad: bool):
-    if needs_table_grad:
+class _FirstOrderOnly(torch.autograd.Function):
+    """Marks a parameter gradient that was computed under create_graph=True: it is a correct FIRST-order gradient (trainers that
+    always pass create_graph=True — MAML-style inner loops, gradient penalties on the joint state — keep working on models with
+    learnable link parameters), but it is not a differentiable function of anything; differentiating THROUGH it raises instead of
+    silently contributing zero."""
+
+    @staticmethod
+    def forward(ctx, grad, anchor):
+        return grad.view_as(grad)
+
+    @staticmethod
+    def backward(ctx, _):
         raise NotImplementedError(
-            "create_graph=True with learnable link parameters: second derivatives are provided with respect to the joint-state "
-            "inputs (q, qd, qdd) and the output cotangents only — see INTEGRATION.md, 'Second derivatives'")
+            "second derivatives through the learnable link parameters: create_graph=True is provided with respect to the "
+            "joint-state inputs (q, qd, qdd) and the output cotangents only — see INTEGRATION.md, 'Second derivatives'")
 
 
 class _FkPositions(torch.autograd.Function):
@@ -259,9 +293,13 @@ class _FkPositions(torch.autograd.Function):
         if grad_pos is None:
             grad_pos = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
         if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            _refuse_second_order_in_parameters(want_p)
+            grad_ops = None
+            if want_p:                   # ... for q; the parameter gradient is first-order (see _FirstOrderOnly)
+                with torch.no_grad():
+                    grad_ops = _FkPositions._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, False, True)[1]
+                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
             if not want_q:
-                return None, None, None, None, None, None
+                return None, grad_ops, None, None, None, None
             table, T, n = ops_f.detach(), ctx.n_targets, ctx.n_dofs
             if grad_quat is None:
                 grad_quat = torch.zeros_like(quat)
@@ -280,7 +318,7 @@ class _FkPositions(torch.autograd.Function):
             with torch.enable_grad():
                 grad_u = grad_quat.to(torch.float32) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
                 (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), grad_pos.to(torch.float32), grad_u)
-            return grad_q.to(q.dtype), None, None, None, None, None
+            return grad_q.to(q.dtype), grad_ops, None, None, None, None
         with torch.no_grad():
             return _FkPositions._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, want_q, want_p)
 
@@ -345,9 +383,13 @@ class _FkJacobian(torch.autograd.Function):
         grad_lin = grad_lin if grad_lin is not None else zeros()
         grad_ang = grad_ang if grad_ang is not None else zeros()
         if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            _refuse_second_order_in_parameters(want_p)
+            grad_ops = None
+            if want_p:
+                with torch.no_grad():
+                    grad_ops = _FkJacobian._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, False, True)[1]
+                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
             if not want_q:
-                return None, None, None, None, None
+                return None, grad_ops, None, None, None
             table, n = ops_f.detach(), ctx.n_dofs
             f32 = lambda t, like: (t if t is not None else torch.zeros_like(like)).to(torch.float32)
             pos_like = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
@@ -366,7 +408,7 @@ class _FkJacobian(torch.autograd.Function):
                 grad_u = f32(grad_quat, quat) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
                 (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), f32(grad_pos, pos_like), grad_u,
                                               grad_lin.to(torch.float32), grad_ang.to(torch.float32))
-            return grad_q.to(q.dtype), None, None, None, None
+            return grad_q.to(q.dtype), grad_ops, None, None, None
         with torch.no_grad():
             return _FkJacobian._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, want_q, want_p)
 
@@ -400,9 +442,14 @@ class _InverseDynamics(torch.autograd.Function):
         want_in = any(ctx.needs_input_grad[:3])
         dw = ctx.dw
         if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            _refuse_second_order_in_parameters(ctx.needs_input_grad[3])
+            grad_ops = None
+            if ctx.needs_input_grad[3]:
+                with torch.no_grad():
+                    grad_ops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, grad_tau, ctx.flags[0], ctx.flags[1],
+                                                     ctx.n_dofs, ctx.param_mask, False)[1]
+                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
             if not want_in:
-                return (None,) * 9
+                return (None, None, None, grad_ops) + (None,) * 5
             table, n, (gravity, damping) = ops_f.detach(), ctx.n_dofs, ctx.flags
             has_qdd = ctx.has_qdd
 
@@ -420,7 +467,7 @@ class _InverseDynamics(torch.autograd.Function):
             gq = got[0].to(q.dtype) if ctx.needs_input_grad[0] else None
             gqd = got[1].to(qd.dtype) if ctx.needs_input_grad[1] else None
             gqdd = got[2].to(qdd.dtype) if (has_qdd and ctx.needs_input_grad[2]) else None
-            return gq, gqd, gqdd, None, None, None, None, None, None
+            return gq, gqd, gqdd, grad_ops, None, None, None, None, None
         with torch.no_grad():
             return _InverseDynamics._first_order(ctx, q, qd, qdd, ops_f, grad_tau, want_in)
 
@@ -573,14 +620,18 @@ class DifferentiableRobotModel(torch.nn.Module):
             from .flatten import KIND_PRISMATIC
             sliding = [b.name for i, b in enumerate(self._bodies) if self._spec.kind[i] == KIND_PRISMATIC]
             skew = [b.name for i, b in enumerate(self._bodies) if self._spec.skew[i]]
-            if sliding or skew:
+            if (sliding or skew) and os.path.abspath(urdf_path) not in _WARNED_URDFS:
+                # once per URDF file and process (models are built in loops and on every rank), pointing at the USER's call:
+                # a subclass constructor (DifferentiableFrankaPanda) adds one frame
+                _WARNED_URDFS.add(os.path.abspath(urdf_path))
                 import warnings
                 warnings.warn(
                     "%s: %s modelled as what the URDF says (prismatic joints slide, joints turn about their true axis); the "
                     "reference treats every non-fixed joint as an axis-aligned revolute joint (robot_model.py:122-126, "
                     "rigid_body.py:149-154), so FK / Jacobians / dynamics of these links differ from upstream's.  Pass "
                     "reference_compat=True for upstream's numbers." % (os.path.basename(urdf_path),
-                                                                       ", ".join(sliding + skew)), stacklevel=2)
+                                                                       ", ".join(sliding + skew)),
+                    stacklevel=2 if type(self) is DifferentiableRobotModel else 3)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._chain_walks: Dict[int, _DeviceWalk] = {}          # link index -> _chain_walk's answer while nothing is learnable

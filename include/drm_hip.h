@@ -252,6 +252,7 @@ int drm_fk_jacobian(const drm_walk *walk, const float *q, int64_t B,
  *             for hands (short independent fingers): scratch is then never touched and may be NULL
  */
 int64_t drm_rnea_scratch_floats(const drm_walk *walk, int64_t B);
+int64_t drm_rnea_scratch_floats_aligned(const drm_walk *walk, int64_t B); /* the caller guarantees 16-byte aligned pointers (see Alignment) */
 int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float *qdd, int64_t B,
              int32_t flags, float *tau, float *scratch, void *stream);
 
@@ -287,6 +288,7 @@ int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, 
  *             (short independent fingers): scratch is then never touched and may be NULL
  */
 int64_t drm_crba_scratch_floats(const drm_walk *walk, int64_t B);
+int64_t drm_crba_scratch_floats_aligned(const drm_walk *walk, int64_t B); /* the caller guarantees 16-byte aligned pointers (see Alignment) */
 int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, float *scratch, void *stream);
 
 /*
@@ -305,6 +307,7 @@ int drm_crba(const drm_walk *walk, const float *q, int64_t B, float *H, float *s
  *             MB), not by B.  0 for the arm and finger kernels: scratch is then never touched and may be NULL
  */
 int64_t drm_forward_dynamics_scratch_floats(const drm_walk *walk, int64_t B);
+int64_t drm_forward_dynamics_scratch_floats_aligned(const drm_walk *walk, int64_t B); /* the caller guarantees 16-byte aligned pointers (see Alignment) */
 int drm_forward_dynamics(const drm_walk *walk, const float *q, const float *qd, const float *f, int64_t B,
                          int32_t flags, float *qdd, float *scratch, void *stream);
 

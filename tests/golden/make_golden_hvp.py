@@ -29,6 +29,9 @@ CASES = [
     ("panda_no_gripper", "panda_description/urdf/panda_no_gripper.urdf", "panda_virtual_ee_link", 6),
     ("allegro_left", "allegro/urdf/allegro_hand_description_left.urdf", "link_15.0_tip", 5),
     ("panda", "panda_description/urdf/panda.urdf", "panda_leftfinger", 5),       # (the package's reference_compat=True)
+    # a FAST, hard-accelerating state (|qd| up to 50 rad/s, |qdd| up to 100 rad/s^2: torques ~1e4 N m): the second derivatives
+    # of inverse dynamics where a fixed small difference step would drown them in the rounding of the first-order launches
+    ("panda_no_gripper_fast", "panda_description/urdf/panda_no_gripper.urdf", "panda_virtual_ee_link", 6, 50.0),
 ]
 
 
@@ -36,7 +39,8 @@ def main():
     rm = ref_import.import_reference()
     torch.set_num_threads(1)
     out = {}
-    for name, rel, link, B in CASES:
+    for name, rel, link, B, *fast in CASES:
+        vel = fast[0] if fast else 1.0
         torch.manual_seed(0)
         np.random.seed(0)
         path = os.path.join(ref_import.reference_data_dir(), rel)
@@ -48,8 +52,8 @@ def main():
         mk = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, requires_grad=True)
         rnd = lambda *shape: np.random.uniform(-1.0, 1.0, size=shape)
         q = mk(np.random.uniform(lo, hi, size=(B, n)))
-        qd = mk(rnd(B, n))
-        qdd = mk(2.0 * rnd(B, n))
+        qd = mk(vel * rnd(B, n))
+        qdd = mk(2.0 * vel * rnd(B, n))
         vq, vqd, vqdd = (torch.tensor(rnd(B, n), dtype=torch.float32) for _ in range(3))
         out[name + "/link"] = np.array(link)
         for k, t in (("q", q), ("qd", qd), ("qdd", qdd), ("vq", vq), ("vqd", vqd), ("vqdd", vqdd)):

@@ -278,10 +278,11 @@ def test_gpu_scratch_of_the_persistent_kernels():
     walk = backend._walk_struct(dw.program, of, dw.ops_i, m._n_dofs)
     for name in SCRATCH_QUERIES:
         small, big, bigger = (int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64(B))) for B in (64, 1 << 20, 1 << 22))
-        # an arm that carries a hand: full 64-row tiles run the straight-line kernels (drm_arm_hand.hip, no scratch); only a
-        # ragged tail still goes through the persistent loop kernels
-        assert small == big == bigger == 0, (name, small, big, bigger)
-        assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) > 0
+        # an arm that carries a hand: full ALIGNED 64-row tiles run the straight-line kernels (drm_arm_hand.hip, no scratch); the
+        # query cannot see the caller's pointers, so it sizes for min(tiles, 64) tiles of the loop kernel — the ragged tail, and a
+        # call with misaligned pointers (ABI 9: served on at most 64 blocks instead of refused)
+        assert 0 < small < big == bigger == 64 * small, (name, small, big, bigger)
+        assert int(getattr(lib, name)(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7))) == big
     # ... the same walk without its shape bit takes the persistent loop kernels for every row: their scratch does NOT grow with
     # the batch once the grid is full (a persistent block owns a slice)
     generic = backend._walk_struct_build(dw.program, of, dw.ops_i, m._n_dofs)   # (a private copy: _walk_struct hands out a cached struct)
@@ -295,9 +296,16 @@ def test_gpu_scratch_of_the_persistent_kernels():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1
     assert b"scratch" in lib.drm_last_error()          # (the two rows behind the two full tiles)
-    # ... and a misaligned view is refused outright: the scratch of these walks is sized for the aligned fast path
-    assert lib.drm_rnea(ctypes.byref(walk), q[1:].data_ptr(), qd[1:].data_ptr(), qdd[1:].data_ptr(), B - 1, 3, out[1:].data_ptr(), None, st) == -1
-    assert b"aligned" in lib.drm_last_error()
+    # ... and a misaligned view (a row slice starts 4 n bytes in) is SERVED, by the loop kernel, with the scratch the query asks for:
+    # the same torques as the aligned call to rounding
+    need = int(lib.drm_rnea_scratch_floats(ctypes.byref(walk), ctypes.c_int64(B - 1)))
+    scr = torch.empty(need, device="cuda")
+    ref = m.compute_inverse_dynamics(q[1:].clone(), qd[1:].clone(), qdd[1:].clone())
+    assert q[1:].data_ptr() & 15
+    assert lib.drm_rnea(ctypes.byref(walk), q[1:].data_ptr(), qd[1:].data_ptr(), qdd[1:].data_ptr(), B - 1, 3, out[1:].data_ptr(),
+                        scr.data_ptr(), st) == 0, lib.drm_last_error()
+    torch.cuda.synchronize()
+    assert torch.allclose(out[1:], ref, rtol=2e-5, atol=2e-5)
     assert lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(), None, st) == -1
     assert b"scratch" in lib.drm_last_error()
     assert lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 3, out.data_ptr(), None, st) == -1
@@ -307,8 +315,12 @@ def test_gpu_scratch_of_the_persistent_kernels():
         r = load_model(robot, "cuda")
         rw = r._dynamics_walk()
         w = backend._walk_struct(rw.program, r._ops_f(rw), rw.ops_i, r._n_dofs)
-        for name in SCRATCH_QUERIES:
-            assert getattr(lib, name)(ctypes.byref(w), ctypes.c_int64(1 << 20)) == 0, (robot, name)
+        for name in SCRATCH_QUERIES:     # (for a caller that guarantees aligned pointers — this package's bindings do)
+            fn = getattr(lib, name + "_aligned")
+            fn.restype, fn.argtypes = ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]
+            assert fn(ctypes.byref(w), ctypes.c_int64(1 << 20)) == 0, (robot, name)
+    fn = lib.drm_rnea_scratch_floats_aligned
+    assert fn(ctypes.byref(walk), ctypes.c_int64(1 << 20)) == 0 and fn(ctypes.byref(walk), ctypes.c_int64((1 << 20) + 7)) > 0
 
 
 def test_departures_from_the_reference_are_announced():
@@ -319,6 +331,8 @@ def test_departures_from_the_reference_are_announced():
     import warnings
     from differentiable_robot_model_amd.robot_model import DifferentiableRobotModel, robot_description_folder
     path = lambda r: os.path.join(robot_description_folder, r + ".urdf")
+    from differentiable_robot_model_amd import robot_model as rm
+    rm._WARNED_URDFS.discard(os.path.abspath(path("panda")))     # (once per URDF and process: forget earlier tests' models)
     with warnings.catch_warnings(record=True) as seen, contextlib.redirect_stdout(io.StringIO()):
         warnings.simplefilter("always")
         DifferentiableRobotModel(path("panda"), device="cpu")
@@ -349,3 +363,41 @@ def test_gpu_plans_refuse_buffers_they_would_have_to_copy():
 
 def plan_out(m, q):
     return m.compute_fk_and_jacobian(q, "panda_virtual_ee_link")
+
+
+def test_fan_partition_refuses_a_walk_that_writes_a_save_slot_twice():
+    """The fan-out FK kernels share the save slots between wavefronts that never synchronise: a walk in which TWO ops write the
+    same slot (legal in sequence: a slot is reused once a sub-tree is done) must not be partitioned, wherever the two writes sit
+    — checked inside fk_fan_partition itself, not left to the caller's `slots_unique` gate."""
+    from differentiable_robot_model_amd.flatten import OPI_SAVE, fk_fan_partition
+    m = load_model("allegro_left")
+    idx = [m._name_to_idx_map[t] for t in ("link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip")]
+    prog = build_walk(m._spec, targets=idx)
+    parent_op = [int(p) for p in prog.parent_op] if hasattr(prog, "parent_op") else None
+    if parent_op is None:
+        link_to_op = {int(l): k for k, l in enumerate(prog.links[:prog.n_ops])}
+        parent_op = [link_to_op.get(int(m._spec.parent[int(l)]), -1) for l in prog.links[:prog.n_ops]]
+    ops = [list(map(int, row)) for row in prog.ops_i[:prog.n_ops]]
+    assert fk_fan_partition(ops, parent_op, prog.n_ops) is not None
+    # the same walk with one more op writing an already used slot, inside ONE run (the per-run set comparison cannot see it)
+    used = [o[OPI_SAVE] for o in ops if o[OPI_SAVE] >= 0]
+    spare = next(k for k in range(prog.n_ops) if ops[k][OPI_SAVE] < 0)
+    twice = [list(o) for o in ops]
+    twice[spare][OPI_SAVE] = used[0] if used else 0
+    if not used:
+        other = next(k for k in range(prog.n_ops) if k != spare)
+        twice[other][OPI_SAVE] = 0
+    assert fk_fan_partition(twice, parent_op, prog.n_ops) is None
+
+
+def test_joint_model_warning_is_given_once_per_urdf():
+    import warnings
+    from differentiable_robot_model_amd import robot_model as rm
+    rm._WARNED_URDFS.discard(os.path.abspath(urdf_path("panda")))
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            load_model("panda", reference_compat=False)
+        load_model("panda", reference_compat=True)
+    mine = [w for w in seen if "modelled as what the URDF says" in str(w.message)]
+    assert len(mine) == 1 and mine[0].filename.endswith("helpers.py")      # (the caller's frame, not robot_model.py)

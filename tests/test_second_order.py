@@ -5,8 +5,9 @@ autograd on the reference's CPU path): forward kinematics (robot_model.py:197-24
 (robot_model.py:626-667) and inverse dynamics (robot_model.py:305-375) — a 7-DoF arm (arm kernels), a hand (tree kernels)
 and an arm with a gripper (arm + hand kernels).
 
-Tolerance: 2e-3 of the result's scale — fp32 differences with h = 4e-2 and one Richardson step carry ~1e-4 of noise
-(robot_model._GradLaunch); the reference's own second derivatives are exact to fp32 rounding.
+Tolerance: 2e-3 of the result's scale — fp32 differences (h = 4e-2 and one Richardson step for the joint angles, a step of the
+input's own size for qd / qdd) carry ~1e-4 of the first-order gradient's scale as noise (robot_model._GradLaunch: error model);
+the reference's own second derivatives are exact to fp32 rounding.
 """
 import os
 
@@ -123,17 +124,55 @@ def test_gradient_penalty_and_a_hessian_row_by_row():
 
 
 @pytest.mark.gpu
-def test_second_order_with_learnable_parameters_is_refused_loudly():
-    """Second derivatives exist for the joint-state inputs and the output cotangents; a graph that would need them through
-    learnable link parameters raises instead of returning a gradient that silently ignores them."""
+def test_fast_hard_accelerating_states():
+    """|qd| up to 50 rad/s, |qdd| up to 100 rad/s^2 (torques ~1e4 N m; golden_hvp.npz "panda_no_gripper_fast"): every input of
+    the inverse-dynamics node is differenced with a step of its own size (robot_model._GradLaunch), so the second derivatives
+    keep the 2e-3 of the small-state cases instead of drowning in the rounding of 1e4-sized first-order launches."""
+    g = np.load(GOLDEN)
+    robot = "panda_no_gripper_fast"
+    m = load_model("panda_no_gripper", "cuda")
+    dev = lambda name: torch.from_numpy(np.ascontiguousarray(g["%s/%s" % (robot, name)])).cuda()
+    q, qd, qdd = (dev(k).requires_grad_(True) for k in ("q", "qd", "qdd"))
+    assert float(qd.abs().max()) > 30 and float(qdd.abs().max()) > 60
+    ws, g_ref, h_ref, dw_ref = case(g, robot, "id", 3, 1)
+    tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    got_g, got_h, got_dw = second((tau,), ws, (q, qd, qdd), (dev("vq"), dev("vqd"), dev("vqdd")))
+    for i, name in enumerate(("q", "qd", "qdd")):
+        close(got_g[i], g_ref[i], "gradient, " + name)
+        close(got_h[i], h_ref[i], "Hessian-vector product, " + name)
+    close(got_dw[0], dw_ref[0], "J v")
+
+
+@pytest.mark.gpu
+def test_create_graph_with_learnable_parameters_is_first_order_and_says_so():
+    """Trainers that always pass create_graph=True (MAML-style inner loops, gradient penalties on the joint state) keep working
+    on a model with learnable link parameters: the parameter gradients they get are the first-order ones; only a graph that
+    really differentiates THROUGH a parameter gradient raises (second derivatives exist for the joint-state inputs and the
+    output cotangents, INTEGRATION.md 'Second derivatives')."""
     from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
+    torch.manual_seed(0)
     m = load_model("iiwa7", "cuda")
     m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
-    q = torch.zeros(4, m._n_dofs, device="cuda", requires_grad=True)
-    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
-    with pytest.raises(NotImplementedError, match="Second derivatives"):
-        torch.autograd.grad(pos.sum(), q, create_graph=True)
-    # first order is untouched
-    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
-    pos.sum().backward()
-    assert q.grad is not None and all(p.grad is not None for p in m.parameters())
+    m.make_link_param_learnable("iiwa_link_3", "mass", UnconstrainedTensor(1, 1, init_tensor=torch.tensor([[3.0]])))
+    params = list(m.parameters())
+    q = (torch.rand(64, m._n_dofs, device="cuda") - 0.5).requires_grad_(True)
+    qd = torch.rand(64, m._n_dofs, device="cuda") - 0.5
+
+    def loss_of():
+        pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
+        lin, _ = m.compute_endeffector_jacobian(q, "iiwa_link_ee")
+        tau = m.compute_inverse_dynamics(q, qd, qd)
+        return pos.square().sum() + lin.square().sum() + 1e-2 * tau.square().sum()
+
+    plain = torch.autograd.grad(loss_of(), params + [q])
+    graph = torch.autograd.grad(loss_of(), params + [q], create_graph=True)
+    for a, b in zip(plain, graph):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+    # asking for the joint-state gradient alone (a gradient penalty) never touches the parameter path
+    (gq,) = torch.autograd.grad(loss_of(), q, create_graph=True)
+    gq.square().sum().backward()
+    assert q.grad is not None and torch.isfinite(q.grad).all()
+    # differentiating through a PARAMETER gradient is what does not exist: it raises (the table kernels' once-differentiable
+    # backward, or robot_model._FirstOrderOnly behind it) instead of contributing zero
+    with pytest.raises((NotImplementedError, RuntimeError), match="Second derivatives|differentiate twice"):
+        graph[0].sum().backward()

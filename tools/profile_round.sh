@@ -6,7 +6,7 @@
 #   rocprofv3 --kernel-trace --stats: bench default (graph replay), the same eagerly launched, one run per batch size,
 #                     kernel_times + probe_robots (which kernel every entry point dispatches to)
 #   rocprofv3 --pmc:  FETCH_SIZE / WRITE_SIZE (separate passes, never with API tracing), SQ counters of the hot kernels
-#                     (kernel_bench*.py: metric / dynamics / config 3 / long-segment robots / backward)
+#                     (kernel_bench.py hot / configs / hand / dynamics / backward)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -31,13 +31,13 @@ for batch in 65536 4194304; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
 done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
-rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py 65536 1048576 > $OUT/prof_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench3.py 65536 > $OUT/prof_sq3.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 1048576 > $OUT/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench.py hand 65536 > $OUT/prof_sq3.log 2>&1
 for r in panda iiwa7_allegro allegro_left; do
-  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench4.py $r 262144 > $OUT/prof_sq4_$r.log 2>&1
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench.py dynamics $r 262144 > $OUT/prof_sq4_$r.log 2>&1
 done
 for r in panda_no_gripper panda allegro_left iiwa7_allegro; do
-  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq5_$r -- python $ROOT/tools/kernel_bench5.py $r 262144 > $OUT/prof_sq5_$r.log 2>&1
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq5_$r -- python $ROOT/tools/kernel_bench.py backward $r 262144 > $OUT/prof_sq5_$r.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
