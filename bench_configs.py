@@ -50,6 +50,10 @@ def graph_launch_us(fn, K, reps=5):
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
+    t_warm = time.perf_counter()      # ~20 ms of the same replays first: the clocks leave their idle state (as bench.py's metric leg does)
+    while time.perf_counter() - t_warm < 0.02:
+        g.replay()
+        torch.cuda.synchronize()
     times = []
     for _ in range(reps):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -234,16 +234,23 @@ class _on_device(object):
         return False
 
 
+_output_plans = {}
+
+
 def _outputs(device, *shapes):
     """The output tensors of one call as views of ONE allocation (each starting on a 16-byte boundary): one trip through the
     caching allocator instead of one per tensor.  (The block lives as long as any of its views does.)"""
-    sizes = [math.prod(sh) for sh in shapes]
-    offs, total = [], 0
-    for n in sizes:
-        offs.append(total)
-        total += (n + 3) & ~3          # every tensor starts on a 16-byte boundary
-    flat = torch.empty(total, device=device, dtype=torch.float32)
-    return [flat.as_strided(sh, _contiguous_strides(sh), off) for sh, off in zip(shapes, offs)]
+    plan = _output_plans.get(shapes)
+    if plan is None:
+        views, total = [], 0
+        for sh in shapes:
+            views.append((sh, _contiguous_strides(sh), total))
+            total += (math.prod(sh) + 3) & ~3          # every tensor starts on a 16-byte boundary
+        if len(_output_plans) > 4096:                  # (shapes are (B, ...) tuples: bounded by the batch sizes a process uses)
+            _output_plans.clear()
+        plan = _output_plans[shapes] = (total, tuple(views))
+    flat = torch.empty(plan[0], device=device, dtype=torch.float32)
+    return [flat.as_strided(sh, st, off) for sh, st, off in plan[1]]
 
 
 def _contiguous_strides(shape):

@@ -184,18 +184,32 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
     float loss_acc = 0.0f; // (lane 63 of the wave: the squared errors of its tiles, in tile order)
 
+    // Launches of at most one wave per SIMD (BASELINE configuration 5: 16 384 rows = 256 waves) are bound by what a lone wave
+    // waits for: the FT blocks of the chain are read into registers in one burst (as in fk_jacobian_arm_kernel's PRE form), and
+    // every lane reads its own rows of q / gpos straight from memory (28 + 12 contiguous bytes) instead of through an LDS tile.
+    wave_lds_sync();
+    float tabr[CAP][DRM_OPF_FT_FLOATS];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+#pragma unroll
+        for (int i = 0; i < DRM_OPF_FT_FLOATS; ++i) tabr[k][i] = lc[k * DRM_OPF_STRIDE + i];
+    __builtin_amdgcn_sched_barrier(0);
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
-        wave_lds_sync(); // the previous tile's staged gradients have left
-        tile_load<NJ>(q + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
-        tile_load<3>(gpos + b0 * 3, WAVE, 3, 0u, lg, lane, true);
-        wave_lds_sync();
         float qv[NJ], gv[3], gqv[NJ];
+        {
+            const float *qrow = q + (b0 + lane) * NJ, *grow = gpos + (b0 + lane) * 3;
 #pragma unroll
-        for (int d = 0; d < NJ; ++d) qv[d] = lq[lane * NJ + d];
+            for (int d = 0; d < NJ; ++d) qv[d] = qrow[d];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gv[i] = lg[lane * 3 + i];
-        fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
+            for (int i = 0; i < 3; ++i) gv[i] = grow[i];
+        }
+        wave_lds_sync(); // the previous tile's staged gradients have left
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = qv[d]; // (the cold parameter loop reads an angle by run-time index)
+        wave_lds_sync();
+        fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { return tabr[k]; },
+                                   [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
                                    [&](const float (&pe)[3], float (&g)[3]) {
                                        if constexpr (MSE) {
                                            const float e[3] = {pe[0] - gv[0], pe[1] - gv[1], pe[2] - gv[2]};

@@ -110,17 +110,35 @@ __global__ void __launch_bounds__(WALK_TABLE_THREADS)
     __shared__ float grows[WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE];
     __shared__ float ge[DRM_MAX_OPS * DRM_OPF_STRIDE];   // grad * sign of every walk entry
     __shared__ int se[DRM_MAX_OPS * DRM_OPF_STRIDE];     // its row element (-1: constant)
+    __shared__ uint32_t opmask[DRM_MAX_OPS];             // per op (32 consecutive entries): bit ls set <=> it gathers from learnable row ls
     const int t = (int)threadIdx.x;
     for (int e = t; e < n_entries; e += WALK_TABLE_THREADS) {
         ge[e] = grad_ops_f[e] * gsign[e];
         se[e] = sel[e];
     }
     __syncthreads();
-    // every row element adds the walk entries gathered from it, in entry order (deterministic); the staged arrays make
-    // this a loop over LDS instead of n_entries dependent global loads per thread
+    const int n_rows_walk = (n_entries + DRM_OPF_STRIDE - 1) / DRM_OPF_STRIDE;
+    for (int k = t; k < n_rows_walk; k += WALK_TABLE_THREADS) {
+        uint32_t m = 0u;
+        for (int j = 0; j < DRM_OPF_STRIDE; ++j) {
+            const int e = k * DRM_OPF_STRIDE + j;
+            const int r = e < n_entries ? se[e] : -1;
+            if (r >= 0) m |= 1u << (r / DRM_OPF_STRIDE);
+        }
+        opmask[k] = m;
+    }
+    __syncthreads();
+    // every row element adds the walk entries gathered from it, in entry order (deterministic).  Only the ops that gather from
+    // the element's link are scanned (a learnable link is ONE op of a walk, so 32 LDS reads per element instead of all
+    // n_entries of them: this kernel took 14.5 us of a 44 us training step on the iiwa, profiles/r04_step_kernels.txt)
     for (int r = t; r < n_links * DRM_OPF_STRIDE; r += WALK_TABLE_THREADS) {
+        const uint32_t bit = 1u << (r / DRM_OPF_STRIDE);
         float s = 0.0f;
-        for (int e = 0; e < n_entries; ++e) s += se[e] == r ? ge[e] : 0.0f;
+        for (int k = 0; k < n_rows_walk; ++k) {
+            if (!(opmask[k] & bit)) continue;
+            const int e0 = k * DRM_OPF_STRIDE, e1 = e0 + DRM_OPF_STRIDE < n_entries ? e0 + DRM_OPF_STRIDE : n_entries;
+            for (int e = e0; e < e1; ++e) s += se[e] == r ? ge[e] : 0.0f;
+        }
         grows[r] = s;
     }
     __syncthreads();

@@ -664,19 +664,21 @@ DRM_HD void fk_backward_walk(const float *__restrict__ opf, const int32_t *__res
 //   param_out(k, dF[9], dt[3]) for ops in param_mask (run-time k)
 //   g_of(pe, g): dL/dp_e once the end position is known — a given gradient (drm_fk_backward), or the gradient of a loss
 //   evaluated inside the kernel (drm_fk_mse: g = 2 (p_e - target) / (3 B))
-template <int CAP, int NJ, class FT, class GOF, class QAT, class PG>
-DRM_HD void fk_backward_chain_g(FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out);
+//   ft_walk(k): the FT block of op k for the (unrolled) chain walk — k is a compile-time constant there, so a kernel may hand out
+//   registers it filled ahead of time; ft(k): the same for the cold parameter loop, where k is a run-time value (LDS)
+template <int CAP, int NJ, class FTW, class FT, class GOF, class QAT, class PG>
+DRM_HD void fk_backward_chain_g(FTW ft_walk, FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out);
 template <int CAP, int NJ, class FT, class QAT, class PG>
 DRM_HD void fk_backward_chain(FT ft, const float (&q)[NJ], const float (&g)[3], uint64_t param_mask, float (&gq)[NJ],
                               QAT q_at, PG param_out) {
-    fk_backward_chain_g<CAP, NJ>(ft, q, [&](const float (&)[3], float (&go)[3]) { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; },
+    fk_backward_chain_g<CAP, NJ>(ft, ft, q, [&](const float (&)[3], float (&go)[3]) { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; },
                                  param_mask, gq, q_at, param_out);
 }
-template <int CAP, int NJ, class FT, class GOF, class QAT, class PG>
-DRM_HD void fk_backward_chain_g(FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out) {
+template <int CAP, int NJ, class FTW, class FT, class GOF, class QAT, class PG>
+DRM_HD void fk_backward_chain_g(FTW ft_walk, FT ft, const float (&q)[NJ], GOF g_of, uint64_t param_mask, float (&gq)[NJ], QAT q_at, PG param_out) {
     PoseP ee;
     f2 B[NJ][3];
-    fk_chain_pairs<CAP, NJ>(ft, q, ee, B, [] {});
+    fk_chain_pairs<CAP, NJ>(ft_walk, q, ee, B, [] {});
     const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
     float g[3];
     g_of(pe, g);

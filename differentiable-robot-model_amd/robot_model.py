@@ -635,6 +635,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}
         self._chain_walks: Dict[int, _DeviceWalk] = {}          # link index -> _chain_walk's answer while nothing is learnable
+        self._dyn_walk: Optional[_DeviceWalk] = None            # _dynamics_walk's answer while nothing is learnable
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
@@ -761,10 +762,16 @@ class DifferentiableRobotModel(torch.nn.Module):
         same gradients from one op per DoF (Panda 8 -> 7, Panda with gripper 12 -> 9, Allegro 20 -> 16, Fetch 24 -> 14).  Links
         with learnable parameters stay ops of their own, and so does whatever would have been folded into them or would have
         had to carry a transform for them (flatten.foldable_links)."""
+        if not self._learnable and self._dyn_walk is not None:      # (constant model: the walk never changes)
+            return self._dyn_walk
         key = self._fold_key()
         if not self._fold_masks[key].any():
-            return self._get_walk(("tree",), whole_tree=True)
-        return self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
+            dw = self._get_walk(("tree",), whole_tree=True)
+        else:
+            dw = self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
+        if not self._learnable:
+            self._dyn_walk = dw
+        return dw
 
     def _static_rows(self, fold_key: Optional[tuple]) -> torch.Tensor:
         """[L + 1, OPF_STRIDE] snapshot of the constant rows, with the links of a fold mask folded into their parents."""
@@ -1304,6 +1311,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw.static_ops_f = None
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
         self._chain_walks.clear()
+        self._dyn_walk = None
 
     def _learnable_module(self, link_name: str, parameter_name: str):
         parent_object = self._get_parent_object_of_param(link_name, parameter_name)
