@@ -32,7 +32,8 @@ class DrmWalk(ctypes.Structure):
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
                 ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
-                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
+                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("special", ctypes.c_void_p * 4)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
 
 
 class NativeLibraryError(RuntimeError):
@@ -48,7 +49,7 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats", "drm_rnea_scratch_floats_aligned",
-           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned")
+           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load")
 
 
 def load_library(path: str = None):
@@ -117,6 +118,8 @@ def load_library(path: str = None):
         for name in ("drm_rnea_scratch_floats_aligned", "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [wp, i64]
+        lib.drm_special_load.restype = ctypes.c_int
+        lib.drm_special_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.drm_fk_mse.restype = ctypes.c_int
         lib.drm_fk_mse.argtypes = [wp, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
         lib.drm_fk_mse_scratch_floats.restype = i64
@@ -203,6 +206,8 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     for k, v in enumerate(prog.chain_dof1):      # (DRM_WALK_CHAIN_DOFS: what the control words say, as launch arguments)
         w.chain_dof1[k] = int(v)
     w.chain_prismatic = int(prog.chain_prismatic)
+    for kind, handle in (getattr(prog, "_special", None) or {}).items():      # (specialize.attach: kernels built for this walk)
+        w.special[kind] = handle
     return w
 
 

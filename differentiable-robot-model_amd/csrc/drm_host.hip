@@ -190,6 +190,17 @@ int drm_link_rows_backward(const float *params, const float *grad_rows, int32_t 
                        params, grad_rows, (int)n_links, grad_params);
     return drm::launched();
 }
+int drm_special_load(const char *code_object_path, const char *kernel_name, const void **function_out) {
+    if (!code_object_path || !kernel_name || !function_out) return drm::fail(DRM_ERR_INVALID, "drm_special_load: NULL argument");
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipModuleLoad(&mod, code_object_path);
+    if (e != hipSuccess) return drm::fail(DRM_ERR_LAUNCH, "hipModuleLoad(%s) failed", code_object_path);
+    e = hipModuleGetFunction(&fn, mod, kernel_name);
+    if (e != hipSuccess) return drm::fail(DRM_ERR_LAUNCH, "hipModuleGetFunction(%s) failed", kernel_name);
+    *function_out = (const void *)fn;
+    return DRM_OK;
+}
 int drm_abi_version(void) { return DRM_ABI_VERSION; }
 int drm_walk_sizeof(void) { return (int)sizeof(drm_walk); }
 const char *drm_last_error(void) { return drm::last_error(); }

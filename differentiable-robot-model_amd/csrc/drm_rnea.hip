@@ -180,7 +180,10 @@ static int64_t drm_rnea_scratch_floats_impl(const drm_walk *w, int64_t B, bool a
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
     // (7-DoF arms / arms with a hand: full aligned tiles run straight-line kernels without scratch; sized for the ragged tail and
     // for a misaligned call, drm_common.hpp fast_path_scratch_tiles)
-    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w);
+    // (a walk with its own straight-line kernel, drm_walk.special: no alignment condition at all — only the ragged tail is sized)
+    if (w->special[DRM_SPECIAL_RNEA]) aligned = true;
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w) ||
+                      w->special[DRM_SPECIAL_RNEA] != nullptr;
     TreeArgs a;
     if (rnea_short_plan(w, a)) return 0;
     RneaRecordsPlan p;
@@ -204,6 +207,20 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     const int n = w->n_dofs;
     const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(tau, AL_TAU);
     hipStream_t s = (hipStream_t)stream;
+    if (w->special[DRM_SPECIAL_RNEA] && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)w->ops_f) & 15u) == 0) {
+        // a per-robot straight-line kernel built for exactly this walk (csrc/drm_static.hpp, specialize.py): full tiles, any
+        // pointer alignment, no scratch; the ragged tail through the kernels below
+        int n_tiles = (int)(B / WAVE), fl = (int)flags;
+        uint32_t magic = div_magic(n), al = align;
+        void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&qdd, (void *)&n_tiles, (void *)&fl, (void *)&tau, (void *)&magic, (void *)&al};
+        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_static): %s", hipGetErrorString(e));
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done == B) return DRM_OK;
+        drm_walk rest = *w;
+        rest.special[DRM_SPECIAL_RNEA] = nullptr;
+        return drm_rnea(&rest, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, tau + done * n, scratch, stream);
+    }
 #ifndef DRM_NO_ARM_KERNEL
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         align == (AL_Q | AL_QD | AL_TAU | (qdd ? AL_QDD : 0u)) && (((uintptr_t)w->ops_f) & 15u) == 0) {

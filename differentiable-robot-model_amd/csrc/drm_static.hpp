@@ -1,0 +1,137 @@
+// drm_static.hpp — per-robot STRAIGHT-LINE dynamics walks for arbitrary trees (round 4): the code a robot-specific
+// translation unit instantiates (differentiable-robot-model_amd/specialize.py writes one per robot: a struct of constexpr
+// functions describing the folded whole-tree walk — parent op, DoF column and joint kind of every op — plus the kernels below
+// instantiated on it; hipcc turns it into a code object that drm_*'s C ABI launches through the walk's `special` handles).
+//
+// What the reference does with one Python loop over the links for every robot (robot_model.py:173-193, 262-301), the
+// ahead-of-time library covers with straight-line code for a few shape families (7-DoF arms, serial chains, arm + hand,
+// fingers) and with LOOP kernels for everything else: control words decoded per op, every per-op record parked in LDS or HBM.
+// Here the tree itself is a compile-time constant: every op's parent is a known register set, a branch point keeps its motion
+// alive exactly as long as it has children left (the register allocator sees the whole walk), nothing is decoded and nothing
+// is parked.  Same per-op arithmetic as the loop kernels (drm_tree.hpp: joint_transform / motion_step / rnea_body_force /
+// rnea_link_force_up), so the results agree with them to rounding.
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#ifdef __HIPCC__
+#include "drm_common.hpp"
+#endif
+#include "drm_tree.hpp"
+
+namespace drm {
+
+template <int... I, class F>
+DRM_HD void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, k>) for k = 0 .. N-1, in order; every k is a compile-time constant inside f
+template <int N, class F>
+DRM_HD void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+// Inverse dynamics of the whole tree (robot_model.py:250-375), R = the robot's walk:
+//   R::N ops in parent-before-child order, R::parent(k) (op index, -1 = the root link), R::dof(k) (column, -1 = fixed),
+//   R::prismatic(k);   row(k) -> op k's constant row;   qf(d, q, qd, qdd);   tau_out(d, tau)
+template <class R, class ROW, class QF, class TAU>
+DRM_HD void rnea_static_walk(ROW row, int flags, QF qf, TAU tau_out) {
+    constexpr int N = R::N;
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    Motion mot[N];
+    Force frc[N];
+    float cc[N], ss[N], qq[N], qdv[N];
+    static_for<N>([&](auto K) {
+        constexpr int k = K, par = R::parent(k), dof = R::dof(k);
+        constexpr bool pris = R::prismatic(k);
+        DRM_RNEA_LINK_FENCE(); // (keeps the constant reads of later ops from being hoisted over this one: register pressure)
+        const float *of = row(k);
+        float wj = 0.0f, aj = 0.0f;
+        qq[k] = 0.0f; cc[k] = 1.0f; ss[k] = 0.0f; qdv[k] = 0.0f;
+        if constexpr (dof >= 0) {
+            qf(dof, qq[k], wj, aj);
+            qdv[k] = wj;
+            if constexpr (!pris) sincos_one(qq[k], ss[k], cc[k]);
+        }
+        const OpFT o = load_ft(of);
+        float J[9], t[3];
+        joint_transform(o, dof >= 0, pris, qq[k], cc[k], ss[k], J, t);
+        Motion from;
+        if constexpr (par < 0) motion_root(from, g);
+        else from = mot[par];
+        motion_step(J, t, wj, aj, pris, from, mot[k]);
+        rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, mot[k], frc[k]);
+    });
+    static_for<N>([&](auto K) {
+        constexpr int k = N - 1 - K, par = R::parent(k), dof = R::dof(k);
+        constexpr bool pris = R::prismatic(k);
+        DRM_RNEA_LINK_FENCE();
+        const float *of = row(k);
+        if constexpr (dof >= 0) {
+            float tau = pris ? frc[k].la[2][0] : frc[k].la[2][1];
+            if (flags & DRM_RNEA_DAMPING) tau += of[DRM_OPF_DAMP] * qdv[k];
+            tau_out(dof, tau);
+        }
+        if constexpr (par >= 0) {
+            const OpFT o = load_ft(of);
+            float J[9], t[3];
+            joint_transform(o, dof >= 0, pris, qq[k], cc[k], ss[k], J, t);
+            Force up;
+            rnea_link_force_up(J, t, frc[k], up);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) frc[par].la[i] += up.la[i];
+        }
+    });
+}
+
+} // namespace drm
+
+#ifdef __HIPCC__
+namespace drm {
+
+// One wavefront per 64-row tile (full tiles; the C ABI sends a ragged tail to the loop kernels).  LDS: [ table : N x 32 ]
+// [ tau tile : 64 x (n | 1) ].  Every lane reads its own rows of q / qd / qdd straight into registers (n contiguous floats each).
+template <class R>
+__device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                                                 const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
+                                                 uint32_t magic_n, uint32_t align) {
+    constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + round4(WAVE * Sq)];
+    const unsigned lane = threadIdx.x;
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    float *lc = smem, *lt = smem + C_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    float4 cv[(C_FLOATS / 4 + WAVE - 1) / WAVE];
+#pragma unroll
+    for (int it = 0; it < (C_FLOATS / 4 + WAVE - 1) / WAVE; ++it) {
+        const int i = (int)lane + it * WAVE;
+        cv[it] = reinterpret_cast<const float4 *>(ops_f)[i < C_FLOATS / 4 ? i : C_FLOATS / 4 - 1];
+    }
+    float qv[n], qdv[n], qddv[n];
+    {
+        const int64_t row = (b0 + lane) * n;
+#pragma unroll
+        for (int d = 0; d < n; ++d) qv[d] = q[row + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qdv[d] = qd[row + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qddv[d] = qdd ? qdd[row + d] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < (C_FLOATS / 4 + WAVE - 1) / WAVE; ++it) {
+        const int i = (int)lane + it * WAVE;
+        if (i < C_FLOATS / 4) reinterpret_cast<float4 *>(lc)[i] = cv[it];
+    }
+    wave_lds_sync();
+    float *trow = lt + lane * Sq;
+    rnea_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+                        [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; },
+                        [&](int d, float v) { trow[d] = v; });
+    wave_lds_sync();
+    tile_store<0>(tau + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+}
+
+} // namespace drm
+#endif

@@ -38,7 +38,8 @@ class DrmWalk(ctypes.Structure):
                 ("n_segments", ctypes.c_int32), ("seg_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
                 ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
-                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
+                ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("special", ctypes.c_void_p * 4)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
 
 
 def link_table(body_params: Sequence[dict], device, spec=None) -> torch.Tensor:

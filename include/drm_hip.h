@@ -37,6 +37,10 @@ extern "C" {
 #define DRM_ABI_VERSION 9
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
+#define DRM_SPECIAL_KINDS 4 /* drm_walk.special[]: */
+#define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
+#define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   (reserved)           */
+#define DRM_SPECIAL_FD 2     /*   forward dynamics             (reserved)           */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
@@ -182,9 +186,19 @@ typedef struct drm_walk {
                                  padding) — what DRM_OPI_W0 says, for the first 16 ops of a serial chain */
     uint32_t chain_prismatic; /* DRM_WALK_CHAIN_DOFS: bit k set <=> op k slides */
     uint32_t reserved0;
+    /* ABI 9: per-robot STRAIGHT-LINE kernels for THIS walk (a whole-tree dynamics walk of any shape), or NULL.  Handles from
+     * drm_special_load() of a code object the host built from csrc/drm_static.hpp instantiated on this walk's tree
+     * (differentiable-robot-model_amd/specialize.py writes and compiles it: ~2 s with hipcc, cached).  When set, the full
+     * 64-row tiles of drm_rnea run it instead of the loop kernels (any pointer alignment, no scratch); a ragged tail and every
+     * walk without a handle behave as before.  The host guarantees that a handle was built for exactly this walk (n_ops,
+     * parents, DoF columns, joint kinds). */
+    const void *special[DRM_SPECIAL_KINDS];
 } drm_walk;
 
 int drm_abi_version(void);
+/* Load a code object (what `hipcc --genco --offload-arch=gfx950` writes) and look up one kernel: the handle for
+ * drm_walk.special[].  The module stays loaded for the life of the process. */
+int drm_special_load(const char *code_object_path, const char *kernel_name, const void **function_out);
 int drm_walk_sizeof(void); /* sizeof(struct drm_walk) as the library was compiled: a binding checks its mirror of the struct against it */
 const char *drm_last_error(void);
 

@@ -495,7 +495,7 @@ def test_gpu_kinematic_trajectory_optimisation_lowers_the_cost():
 # Gradients of losses that read the QUATERNION (tests/golden/golden_grad_quat.npz, made by
 # tests/golden/make_golden_grad_quat.py from torch autograd through the unmodified reference): the reference assembles the
 # quaternion from entries of R inside autograd (spatial_vector_algebra.py:108-136), so orientation losses have
-# gradients; here dL/dquat becomes dL/dR on the host (robot_model._quat_grad_to_rot) and enters the adjoint sweep.
+# gradients; here dL/dquat becomes dL/dR on the host (autograd._quat_grad_to_rot) and enters the adjoint sweep.
 # ---------------------------------------------------------------------------------------------------------------
 QUAT_CASES = [("iiwa7", "quat"), ("iiwa7", "pose"), ("allegro_left", "quat"), ("allegro_left", "pose")]
 
@@ -517,7 +517,7 @@ def learnable_model_quat(g, key, device="cpu"):
 
 @pytest.mark.parametrize("case,mode", QUAT_CASES)
 def test_emu_quaternion_backward_vs_reference_autograd(emu, case, mode):
-    from differentiable_robot_model_amd.robot_model import _quat_grad_to_rot
+    from differentiable_robot_model_amd.autograd import _quat_grad_to_rot
     g = load_golden_grad_quat()
     key = "%s/%s" % (case, mode)
     m = learnable_model_quat(g, key)

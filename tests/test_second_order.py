@@ -1,4 +1,4 @@
-"""Second derivatives (`create_graph=True`) through the hand-written backward kernels: robot_model._GradLaunch makes a
+"""Second derivatives (`create_graph=True`) through the hand-written backward kernels: autograd._GradLaunch makes a
 first-order gradient launch a differentiable node whose derivatives are directional differences of first-order launches.
 Held to the UNMODIFIED reference's own double backward (tests/golden/golden_hvp.npz, written by make_golden_hvp.py from torch
 autograd on the reference's CPU path): forward kinematics (robot_model.py:197-248), the end-effector Jacobian
@@ -6,7 +6,7 @@ autograd on the reference's CPU path): forward kinematics (robot_model.py:197-24
 and an arm with a gripper (arm + hand kernels).
 
 Tolerance: 2e-3 of the result's scale — fp32 differences (h = 4e-2 and one Richardson step for the joint angles, a step of the
-input's own size for qd / qdd) carry ~1e-4 of the first-order gradient's scale as noise (robot_model._GradLaunch: error model);
+input's own size for qd / qdd) carry ~1e-4 of the first-order gradient's scale as noise (autograd._GradLaunch: error model);
 the reference's own second derivatives are exact to fp32 rounding.
 """
 import os
@@ -126,7 +126,7 @@ def test_gradient_penalty_and_a_hessian_row_by_row():
 @pytest.mark.gpu
 def test_fast_hard_accelerating_states():
     """|qd| up to 50 rad/s, |qdd| up to 100 rad/s^2 (torques ~1e4 N m; golden_hvp.npz "panda_no_gripper_fast"): every input of
-    the inverse-dynamics node is differenced with a step of its own size (robot_model._GradLaunch), so the second derivatives
+    the inverse-dynamics node is differenced with a step of its own size (autograd._GradLaunch), so the second derivatives
     keep the 2e-3 of the small-state cases instead of drowning in the rounding of 1e4-sized first-order launches."""
     g = np.load(GOLDEN)
     robot = "panda_no_gripper_fast"
@@ -173,6 +173,6 @@ def test_create_graph_with_learnable_parameters_is_first_order_and_says_so():
     gq.square().sum().backward()
     assert q.grad is not None and torch.isfinite(q.grad).all()
     # differentiating through a PARAMETER gradient is what does not exist: it raises (the table kernels' once-differentiable
-    # backward, or robot_model._FirstOrderOnly behind it) instead of contributing zero
+    # backward, or autograd._FirstOrderOnly behind it) instead of contributing zero
     with pytest.raises((NotImplementedError, RuntimeError), match="Second derivatives|differentiate twice"):
         graph[0].sum().backward()

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Fetch (a tree with no compiled straight-line shape): inverse dynamics through the loop kernels and through the robot's own
+kernel (model.specialize(): csrc/drm_static.hpp built for its tree), hipGraph of 20 launches, best of 5."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gpu_probe import load, sample
+from ab_rnea import graph_time
+
+for robot in sys.argv[1:] or ["fetch"]:
+    loop, own = load(robot), load(robot)
+    t0 = time.perf_counter()
+    took = own.specialize()
+    print("%s: specialize() -> %s in %.2f s" % (robot, took, time.perf_counter() - t0))
+    for B in (65536, 1 << 20):
+        q, qd, qdd = (t.cuda() for t in sample(loop, B))
+        a = graph_time(lambda: loop.compute_inverse_dynamics(q, qd, qdd), launches=20, reps=5)
+        b = graph_time(lambda: own.compute_inverse_dynamics(q, qd, qdd), launches=20, reps=5)
+        n = loop._n_dofs
+        print("%-10s B=%8d  inverse dynamics: loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
+              % (robot, B, a, b, a / b, B * 16 * n / b / 1e3, 16 * n))
