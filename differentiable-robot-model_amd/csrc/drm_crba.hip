@@ -332,7 +332,8 @@ static int64_t drm_crba_scratch_floats_impl(const drm_walk *w, int64_t B, bool a
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
     // (full aligned tiles of these walks run straight-line kernels without scratch: sized for the ragged tail and for a misaligned
     // call, drm_common.hpp fast_path_scratch_tiles)
-    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || crba_arm_hand_applies(w);
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || crba_arm_hand_applies(w) ||
+                      w->special[DRM_SPECIAL_CRBA] != nullptr;
     TreeArgs a;
     if (crba_short_plan(w, a)) return 0;
     CrbaRowsPlan p;
@@ -354,6 +355,19 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs, nn = n * n;
     hipStream_t s = (hipStream_t)stream;
+    if (w->special[DRM_SPECIAL_CRBA] && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)H | (uintptr_t)w->ops_f) & 15u) == 0) {
+        // the robot's own straight-line kernel (csrc/drm_static.hpp crba_static_walk, built for exactly this walk): full tiles,
+        // no scratch; q at any alignment, H 16-byte aligned (the tile's matrices leave as 16-byte stores)
+        int n_tiles = (int)(B / WAVE);
+        void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&n_tiles, (void *)&H};
+        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_CRBA], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_crba_static): %s", hipGetErrorString(e));
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done == B) return DRM_OK;
+        drm_walk rest = *w;
+        rest.special[DRM_SPECIAL_CRBA] = nullptr;
+        return drm_crba(&rest, q + done * n, B - done, H + done * nn, scratch, stream);
+    }
 #ifndef DRM_NO_ARM_KERNEL
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         (((uintptr_t)q | (uintptr_t)H | (uintptr_t)w->ops_f) & 15u) == 0) {
@@ -382,7 +396,8 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
         }
     }
     // (a misaligned call on a walk with a straight-line kernel, or its ragged tail: the loop kernel on at most MISALIGNED_TILES blocks)
-    const bool fast_walk = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7) || crba_arm_hand_applies(w);
+    const bool fast_walk = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7) || crba_arm_hand_applies(w) ||
+                           w->special[DRM_SPECIAL_CRBA] != nullptr;
     if (!segments_ok(w)) return fail(DRM_ERR_INVALID, "walk segments are inconsistent");
     if ((((uintptr_t)w->ops_f) & 15u) != 0) return fail(DRM_ERR_INVALID, "ops_f must be 16-byte aligned");
     const int64_t tiles = (B + WAVE - 1) / WAVE;

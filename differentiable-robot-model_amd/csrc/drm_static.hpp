@@ -85,6 +85,72 @@ DRM_HD void rnea_static_walk(ROW row, int flags, QF qf, TAU tau_out) {
     });
 }
 
+// Joint-space inertia matrix of the whole tree by the composite-rigid-body algorithm (robot_model.py:402-450; drm_tree.hpp
+// crba_set_walk's organisation): ONE sweep from the leaves to the root.  When the sweep reaches op k, the forces F_c = Ic_c S_c of
+// all moving ops c of k's sub-tree are already expressed in k's frame: H[k][c] = S_k . F_c is read off, then all of them (and
+// k's own) are moved into the parent's frame by k's transform, which is built once.  The composite inertia of a sub-tree travels
+// the same way.  R::below(c, k): op c lies in the sub-tree of op k (c != k);  hout(k, c, v): entry (row op k, column op c) and
+// its mirror — the kernel maps the pair to its slot in the triangle (R::slot).
+template <class R, class ROW, class QF, class HOUT>
+DRM_HD void crba_static_walk(ROW row, QF qf, HOUT hout) {
+    constexpr int N = R::N;
+    Inertia up[N];   // a sub-tree's composite inertia in its PARENT's frame, from the step of its root until the parent's step
+    Force F[N];      // F_c of every moving op, in the frame the sweep has carried it to
+    static_for<N>([&](auto K) {
+        constexpr int k = N - 1 - K, par = R::parent(k), dof = R::dof(k);
+        constexpr bool pris = R::prismatic(k);
+        DRM_RNEA_LINK_FENCE();
+        const float *of = row(k);
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        static_for<N>([&](auto C) { // children, in walk order (the loop kernels add them in the order the sweep meets them)
+            constexpr int c = N - 1 - C;
+            if constexpr (c > k && R::parent(c) == k) inertia_add(tot, up[c]);
+        });
+        float q = 0.0f, cs = 1.0f, sn = 0.0f;
+        if constexpr (dof >= 0) {
+            q = qf(dof);
+            if constexpr (!pris) sincos_one(q, sn, cs);
+        }
+        const OpFT o = load_ft(of);
+        float J[9], t[3];
+        joint_transform(o, dof >= 0, pris, q, cs, sn, J, t);
+        if constexpr (dof >= 0) {
+            // F = Ic S_k.  revolute: f = -h x e_z, n = I e_z;  prismatic: f = m e_z, n = h x e_z  (drm_tree.hpp crba_tree_walk)
+            if constexpr (!pris) {
+                F[k].la[0] = f2_make(-tot.h[1], tot.I[2]);
+                F[k].la[1] = f2_make(tot.h[0], tot.I[4]);
+                F[k].la[2] = f2_make(0.0f, tot.I[5]);
+                hout(K, K, tot.I[5]);
+            } else {
+                F[k].la[0] = f2_make(0.0f, tot.h[1]);
+                F[k].la[1] = f2_make(0.0f, -tot.h[0]);
+                F[k].la[2] = f2_make(tot.m, 0.0f);
+                hout(K, K, tot.m);
+            }
+            static_for<N>([&](auto C) {
+                constexpr int c = C;
+                if constexpr (R::below(c, k) && R::dof(c) >= 0) hout(K, std::integral_constant<int, N - 1 - c>{}, pris ? F[c].la[2][0] : F[c].la[2][1]);
+            });
+        }
+        if constexpr (par >= 0) {
+            static_for<N>([&](auto C) {
+                constexpr int c = C;
+                if constexpr ((c == k || R::below(c, k)) && R::dof(c) >= 0) {
+                    Force moved;
+                    rnea_link_force_up(J, t, F[c], moved);
+                    F[c] = moved;
+                }
+            });
+            inertia_to_parent(J, t, tot, up[k]);
+        }
+    });
+}
+
 } // namespace drm
 
 #ifdef __HIPCC__
@@ -131,6 +197,51 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
                         [&](int d, float v) { trow[d] = v; });
     wave_lds_sync();
     tile_store<0>(tau + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+}
+
+
+// The inertia matrices of a 64-row tile: the walk leaves every entry of the related (ancestor, descendant) pairs in a slot of an
+// LDS triangle [slot][64 + 1]; the tile's 64 matrices (64 n^2 consecutive floats) then leave as 16-byte stores, every float looked
+// up by (element -> slot, sample) — R::SLOT_OF[n^2] (the zero slot for pairs on different branches), as crba_arm_hand_kernel does.
+template <class R>
+__device__ __forceinline__ void crba_static_body(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
+                                                 float *__restrict__ H, const int *__restrict__ slot_of_global) {
+    constexpr int N = R::N, n = R::NDOF, nn = n * n, C_FLOATS = N * DRM_OPF_STRIDE, TRI = WAVE + 1, ZERO = R::SLOTS;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + (R::SLOTS + 1) * TRI];
+    __shared__ int slot_of[nn];
+    const unsigned lane = threadIdx.x;
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    float *lc = smem, *tri = smem + C_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    float qv[n];
+    {
+        const int64_t row = (b0 + lane) * n;
+#pragma unroll
+        for (int d = 0; d < n; ++d) qv[d] = q[row + d];
+    }
+    for (int i = (int)lane; i < nn; i += WAVE) slot_of[i] = slot_of_global[i];
+    tri[ZERO * TRI + lane] = 0.0f;
+    if (lane == 0) tri[ZERO * TRI + WAVE] = 0.0f;
+    wave_lds_sync();
+    crba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, [&](int d) { return qv[d]; },
+                        [&](auto KR, auto CR, float v) { // (reversed op indices as types: slot(k, c) is a compile-time constant)
+                            constexpr int k = N - 1 - decltype(KR)::value, c = N - 1 - decltype(CR)::value;
+                            tri[R::slot(k, c) * TRI + lane] = v;
+                        });
+    wave_lds_sync();
+    const int n4 = 16 * nn;
+    float *g = H + b0 * nn;
+    for (int f = (int)lane; f < n4; f += WAVE) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = 4 * f + c, sm = w / nn, e = w - sm * nn;
+            v[c] = tri[slot_of[e] * TRI + sm];
+        }
+        store16_wt(g + 4 * f, make_float4(v[0], v[1], v[2], v[3]));
+    }
 }
 
 } // namespace drm

@@ -20,3 +20,7 @@ for robot in sys.argv[1:] or ["fetch"]:
         n = loop._n_dofs
         print("%-10s B=%8d  inverse dynamics: loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
               % (robot, B, a, b, a / b, B * 16 * n / b / 1e3, 16 * n))
+        a = graph_time(lambda: loop.compute_lagrangian_inertia_matrix(q), launches=10, reps=5)
+        b = graph_time(lambda: own.compute_lagrangian_inertia_matrix(q), launches=10, reps=5)
+        print("%-10s B=%8d  mass matrix:      loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
+              % (robot, B, a, b, a / b, B * 4 * (n + n * n) / b / 1e3, 4 * (n + n * n)))
