@@ -392,7 +392,9 @@ static int64_t drm_forward_dynamics_scratch_floats_impl(const drm_walk *w, int64
     if (check_walk(w) || B <= 0 || !segments_ok(w)) return 0;
     // (full aligned tiles of these walks run straight-line kernels without scratch: sized for the ragged tail and for a misaligned
     // call, drm_common.hpp fast_path_scratch_tiles)
-    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w);
+    if (w->special[DRM_SPECIAL_FD]) aligned = true;   // (the robot's own kernel takes any alignment: only a ragged tail is sized)
+    const bool fast = ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && w->n_dofs == 7) || arm_hand_compiled(w) ||
+                      w->special[DRM_SPECIAL_FD] != nullptr;
     TreeArgs a;
     if (fd_short_plan(w, a)) return 0;
     AbaPlan p;
@@ -414,6 +416,20 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
     if (B == 0) return DRM_OK;
     const int n = w->n_dofs;
+    if (w->special[DRM_SPECIAL_FD] && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)w->ops_f) & 15u) == 0) {
+        // the robot's own straight-line articulated-body kernel (csrc/drm_static.hpp aba_static_walk, built for exactly this walk):
+        // full tiles, any pointer alignment, no scratch
+        int n_tiles = (int)(B / WAVE), fl = (int)flags;
+        uint32_t magic = div_magic(n), al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
+        void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&f, (void *)&n_tiles, (void *)&fl, (void *)&qdd, (void *)&magic, (void *)&al};
+        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fd_static): %s", hipGetErrorString(e));
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done == B) return DRM_OK;
+        drm_walk rest = *w;
+        rest.special[DRM_SPECIAL_FD] = nullptr;
+        return drm_forward_dynamics(&rest, q + done * n, qd + done * n, f + done * n, B - done, flags, qdd + done * n, scratch, stream);
+    }
     {   // a hand (fingers off the root): full tiles through the per-finger arm form
         const int64_t done = launch_forward_dynamics_fingers(w, q, qd, f, B, (int)flags, qdd, (hipStream_t)stream);
         if (done > 0) {

@@ -151,6 +151,99 @@ DRM_HD void crba_static_walk(ROW row, QF qf, HOUT hout) {
     });
 }
 
+// Forward dynamics of the whole tree by the articulated-body algorithm, the reference's own (robot_model.py:487-624) — drm_tree.hpp
+// aba_tree_walk's three sweeps with the tree as a compile-time constant: the branch-point motions and the articulated bodies
+// travelling towards the root live in registers (a sub-tree's body from the step of its root to its parent's step); what every op
+// needs again in a later sweep — its velocity (6 floats, sweep 1 -> 2) and U, 1 / D, u of its joint (8 floats, sweep 2 -> 3) — is
+// parked by the caller (LDS).
+//   qf(d, q, qd)   fj(d) joint torque   out(d, qdd)   vpark / vunpark(k, Motion)   rpark / runpark(k, rec[8])
+template <class R, class ROW, class QF, class FJ, class OUT, class VPARK, class VUNPARK, class RPARK, class RUNPARK>
+DRM_HD void aba_static_walk(ROW row, int flags, QF qf, FJ fj, OUT out, VPARK vpark, VUNPARK vunpark, RPARK rpark, RUNPARK runpark) {
+    constexpr int N = R::N;
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    auto joint = [&](auto K, float *J, float *t, float &qd) {
+        constexpr int k = decltype(K)::value, dof = R::dof(k);
+        constexpr bool pris = R::prismatic(k);
+        float q = 0.0f, c = 1.0f, s = 0.0f;
+        qd = 0.0f;
+        if constexpr (dof >= 0) {
+            qf(dof, q, qd);
+            if constexpr (!pris) sincos_one(q, s, c);
+        }
+        const OpFT o = load_ft(row(k));
+        joint_transform(o, dof >= 0, pris, q, c, s, J, t);
+    };
+    // ---- sweep 1: velocities ------------------------------------------------------------------------------------------
+    {
+        Motion mot[N];
+        static_for<N>([&](auto K) {
+            constexpr int k = K, par = R::parent(k);
+            DRM_RNEA_LINK_FENCE();
+            float J[9], t[3], qd;
+            joint(K, J, t, qd);
+            Motion from;
+            if constexpr (par < 0) motion_root(from, 0.0f);
+            else from = mot[par];
+            motion_step(J, t, qd, 0.0f, R::prismatic(k), from, mot[k]);
+            vpark(k, mot[k]);
+        });
+    }
+    // ---- sweep 2: articulated inertias and bias forces, leaves -> root ------------------------------------------------------
+    {
+        ArtBody up[N];
+        static_for<N>([&](auto KR) {
+            constexpr int k = N - 1 - KR, par = R::parent(k), dof = R::dof(k);
+            DRM_RNEA_LINK_FENCE();
+            const float *of = row(k);
+            Motion vel;
+            vunpark(k, vel);      // (acceleration halves zero: the body force below is the bias force v x* (I v))
+            ArtBody tot;
+            art_from_link(of, tot.I);
+            rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, vel, tot.p);
+            static_for<N>([&](auto C) { // children, in the order the leaves -> root sweep meets them
+                constexpr int c = N - 1 - C;
+                if constexpr (c > k && R::parent(c) == k) art_add(tot, up[c]);
+            });
+            float J[9], t[3], qd;
+            joint(std::integral_constant<int, k>{}, J, t, qd);
+            float fjoint = 0.0f;
+            if constexpr (dof >= 0) {
+                fjoint = fj(dof);
+                if (flags & DRM_RNEA_DAMPING) fjoint -= of[DRM_OPF_DAMP] * qd;
+            }
+            float rec[8];
+            aba_eliminate(dof >= 0, R::prismatic(k), J, t, qd, fjoint, vel, tot, rec, par >= 0, up[k]);
+            if constexpr (dof >= 0) rpark(k, rec);
+        });
+    }
+    // ---- sweep 3: accelerations, root -> leaves --------------------------------------------------------------------------
+    {
+        Motion mot[N];
+        static_for<N>([&](auto K) {
+            constexpr int k = K, par = R::parent(k), dof = R::dof(k);
+            constexpr bool pris = R::prismatic(k);
+            DRM_RNEA_LINK_FENCE();
+            float J[9], t[3], qd;
+            joint(K, J, t, qd);
+            Motion from;
+            if constexpr (par < 0) motion_root(from, g);
+            else from = mot[par];
+            motion_step(J, t, qd, 0.0f, pris, from, mot[k]); // acceleration halves: a' = X a_parent + c
+            if constexpr (dof >= 0) {
+                float rec[8];
+                runpark(k, rec);
+                float dot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dot += rec[i] * mot[k].va[i][1] + rec[3 + i] * mot[k].wa[i][1];
+                const float qdd = (rec[7] - dot) * rec[6];
+                out(dof, qdd);
+                if constexpr (pris) mot[k].va[2][1] += qdd;
+                else mot[k].wa[2][1] += qdd;
+            }
+        });
+    }
+}
+
 } // namespace drm
 
 #ifdef __HIPCC__
@@ -242,6 +335,63 @@ __device__ __forceinline__ void crba_static_body(const float *__restrict__ ops_f
         }
         store16_wt(g + 4 * f, make_float4(v[0], v[1], v[2], v[3]));
     }
+}
+
+// Forward dynamics of a 64-row tile.  LDS: [ table ][ velocities : N x 6 x 64 ][ records : N x 8 x 64 ] — the qdd tile is staged
+// over the velocity area once sweep 2 is done with it.
+template <class R>
+__device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
+                                                const float *__restrict__ f, int n_tiles, int flags, float *__restrict__ qdd,
+                                                uint32_t magic_n, uint32_t align) {
+    constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE;
+    constexpr int V_FLOATS = N * 6 * WAVE > round4(WAVE * Sq) ? N * 6 * WAVE : round4(WAVE * Sq), R_FLOATS = N * 8 * WAVE;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + V_FLOATS + R_FLOATS];
+    const unsigned lane = threadIdx.x;
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    float *lc = smem, *lv = smem + C_FLOATS, *lr = lv + V_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    float qv[n], qdv[n], fv[n];
+    {
+        const int64_t row = (b0 + lane) * n;
+#pragma unroll
+        for (int d = 0; d < n; ++d) qv[d] = q[row + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qdv[d] = qd[row + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) fv[d] = f[row + d];
+    }
+    wave_lds_sync();
+    float acc[n];
+    aba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+                       [&](int d, float &x, float &v) { x = qv[d]; v = qdv[d]; }, [&](int d) { return fv[d]; },
+                       [&](int d, float v) { acc[d] = v; },
+                       [&](int k, const Motion &M) {
+#pragma unroll
+                           for (int i = 0; i < 3; ++i) { lv[((k * 6 + i) * WAVE) + lane] = M.wa[i][0]; lv[((k * 6 + 3 + i) * WAVE) + lane] = M.va[i][0]; }
+                       },
+                       [&](int k, Motion &M) {
+#pragma unroll
+                           for (int i = 0; i < 3; ++i) {
+                               M.wa[i] = f2_make(lv[((k * 6 + i) * WAVE) + lane], 0.0f);
+                               M.va[i] = f2_make(lv[((k * 6 + 3 + i) * WAVE) + lane], 0.0f);
+                           }
+                       },
+                       [&](int k, const float *rec) {
+#pragma unroll
+                           for (int i = 0; i < 8; ++i) lr[((k * 8 + i) * WAVE) + lane] = rec[i];
+                       },
+                       [&](int k, float *rec) {
+#pragma unroll
+                           for (int i = 0; i < 8; ++i) rec[i] = lr[((k * 8 + i) * WAVE) + lane];
+                       });
+    wave_lds_sync(); // (the velocity area is free: sweep 2 has read it all)
+    float *trow = lv + lane * Sq;
+#pragma unroll
+    for (int d = 0; d < n; ++d) trow[d] = acc[d];
+    wave_lds_sync();
+    tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, lv, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
 }
 
 } // namespace drm

@@ -278,9 +278,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         return dw
 
     def specialize(self) -> bool:
-        """Build (hipcc, ~2 s, cached) and attach this robot's OWN straight-line inverse-dynamics kernel (specialize.py,
-        csrc/drm_static.hpp): for robots whose tree is none of the shapes the library ships straight-line kernels for (a mobile
-        manipulator such as Fetch) the loop-structured kernels stop being the only choice.  Returns True when a kernel was
+        """Build (hipcc, ~3 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics, the inertia
+        matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the shapes the library ships
+        straight-line kernels for (a mobile manipulator such as Fetch) the loop-structured kernels stop being the only choice
+        (Fetch at 2^20 rows: 226 -> 125 us, 630 -> 170 us, 600 -> 331 us).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
         attached, False when the robot already runs a compiled straight-line kernel (7-DoF arms, arm + hand, hands).  Models with
         learnable link parameters specialise their full walk as well (the kernel reads the same table)."""
         from . import specialize as sp
@@ -314,6 +315,17 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw = self._get_walk(("tree",), whole_tree=True)
         else:
             dw = self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
+        if os.environ.get("DRM_SPECIALIZE") == "1" and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
+            # opt-in through the environment: every robot without a compiled straight-line shape builds its own kernels on first
+            # use (specialize.py; ~2 s once per robot and machine); a machine without hipcc keeps the loop kernels
+            dw.program._special_tried = True
+            from . import specialize as sp
+            from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
+            if not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
+                try:
+                    sp.attach(dw.program, self._spec, self._n_dofs)
+                except sp.SpecializeError:
+                    pass
         if not self._learnable:
             self._dyn_walk = dw
         return dw

@@ -40,7 +40,7 @@ extern "C" {
 #define DRM_SPECIAL_KINDS 4 /* drm_walk.special[]: */
 #define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
 #define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   kernel drm_crba_static  */
-#define DRM_SPECIAL_FD 2     /*   forward dynamics             (reserved)           */
+#define DRM_SPECIAL_FD 2     /*   forward dynamics             kernel drm_fd_static    */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
@@ -189,7 +189,7 @@ typedef struct drm_walk {
     /* ABI 9: per-robot STRAIGHT-LINE kernels for THIS walk (a whole-tree dynamics walk of any shape), or NULL.  Handles from
      * drm_special_load() of a code object the host built from csrc/drm_static.hpp instantiated on this walk's tree
      * (differentiable-robot-model_amd/specialize.py writes and compiles it: ~2 s with hipcc, cached).  When set, the full
-     * 64-row tiles of drm_rnea / drm_crba run it instead of the loop kernels (no scratch; drm_rnea at any pointer alignment); a ragged tail and every
+     * 64-row tiles of drm_rnea / drm_crba / drm_forward_dynamics run it instead of the loop kernels (no scratch; drm_rnea at any pointer alignment); a ragged tail and every
      * walk without a handle behave as before.  The host guarantees that a handle was built for exactly this walk (n_ops,
      * parents, DoF columns, joint kinds). */
     const void *special[DRM_SPECIAL_KINDS];

@@ -51,7 +51,7 @@ def test_generated_source_builds_and_is_cached(tmp_path, monkeypatch):
     monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path))
     m = load_model("fetch", reference_compat=False)
     src = sp.source(sp.walk_tree(folded_walk(m)), m._n_dofs)
-    assert "N = 14, NDOF = 14" in src and "drm_rnea_static" in src and "drm_crba_static" in src
+    assert "N = 14, NDOF = 14" in src and "drm_rnea_static" in src and "drm_crba_static" in src and "drm_fd_static" in src
     path = sp.build(src)
     assert os.path.getsize(path) > 1000 and path.startswith(str(tmp_path))
     stamp = os.path.getmtime(path)
@@ -82,6 +82,14 @@ def test_gpu_fetch_inverse_dynamics_through_its_own_kernel(compat):
         assert np.allclose(H.cpu().numpy(), Href, **TOL_TAU), B
         assert np.allclose(H.cpu().numpy(), loop.compute_lagrangian_inertia_matrix(dq).cpu().numpy(), **TOL_TAU)
         assert torch.equal(H, H.transpose(1, 2))            # (both triangles from the same slot)
+        for grav, damp in ((True, True), (False, False)):     # forward dynamics: the articulated-body recursion on torques that
+            f = loop.compute_inverse_dynamics(dq, dqd, dqdd, include_gravity=grav, use_damping=damp)   # give accelerations of order one
+            acc = own.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+            ref = orc.forward_dynamics(q.astype(np.float64), qd.astype(np.float64), f.cpu().numpy().astype(np.float64), grav, damp, np.float64)
+            err = float((np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+            other = loop.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+            err_loop = float((np.abs(other.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+            assert err < max(1e-3, 2.0 * err_loop), (B, grav, damp, err, err_loop)
         nle = own.compute_non_linear_effects(dq, dqd)      # qdd = NULL
         assert np.allclose(nle.cpu().numpy(), orc.rnea(q.astype(np.float64), qd.astype(np.float64), np.zeros_like(q, np.float64),
                                                        True, True, np.float64), **TOL_TAU)
@@ -104,7 +112,7 @@ def test_gpu_fetch_inverse_dynamics_through_its_own_kernel(compat):
 
 @pytest.mark.gpu
 @needs_hipcc
-@pytest.mark.parametrize("seed", [0, 3, 5, 8])
+@pytest.mark.parametrize("seed", __import__("test_random_trees").SEEDS)
 def test_gpu_random_trees_through_their_own_kernels(tmp_path, seed):
     mc, m = tree_model(tmp_path, seed), tree_model(tmp_path, seed, "cuda")
     try:
@@ -120,6 +128,9 @@ def test_gpu_random_trees_through_their_own_kernels(tmp_path, seed):
     assert np.allclose(tau.cpu().numpy(), ref, **TOL_TAU), seed
     H = m.compute_lagrangian_inertia_matrix(torch.from_numpy(q).cuda())
     assert np.allclose(H.cpu().numpy(), Oracle(mc._spec).mass_matrix(q.astype(np.float64), False, False, np.float64), **TOL_TAU), seed
+    acc = m.compute_forward_dynamics(*(torch.from_numpy(a).cuda() for a in (q, qd, qdd)), include_gravity=True, use_damping=True)
+    ref = Oracle(mc._spec).forward_dynamics(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), True, True, np.float64)
+    assert float((np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max()) < 1e-3, seed
 
 
 def test_robots_with_a_compiled_shape_keep_it():

@@ -22,5 +22,8 @@ for robot in sys.argv[1:] or ["fetch"]:
               % (robot, B, a, b, a / b, B * 16 * n / b / 1e3, 16 * n))
         a = graph_time(lambda: loop.compute_lagrangian_inertia_matrix(q), launches=10, reps=5)
         b = graph_time(lambda: own.compute_lagrangian_inertia_matrix(q), launches=10, reps=5)
+        fa = graph_time(lambda: loop.compute_forward_dynamics(q, qd, qdd), launches=10, reps=5)
+        fb = graph_time(lambda: own.compute_forward_dynamics(q, qd, qdd), launches=10, reps=5)
+        print("%-10s B=%8d  forward dynamics: loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx)" % (robot, B, fa, fb, fa / fb))
         print("%-10s B=%8d  mass matrix:      loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
               % (robot, B, a, b, a / b, B * 4 * (n + n * n) / b / 1e3, 4 * (n + n * n)))
