@@ -91,8 +91,12 @@ for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two
     if line:
         with open(os.path.join(prof, tag + dst), "w") as f:
             f.write(line + "\n")
-for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt"),
-                 ("probe_api.txt", "_probe_api.txt")):
+st = glob.glob(os.path.join(OUT, "prof_cfg", "*", "*_kernel_stats.csv"))
+if st:      # round 4: the kernels of BASELINE configurations 2-5 (tools/kernel_bench.py configs), eagerly launched
+    shutil.copy(st[0], os.path.join(prof, tag + "_configs_kernel_stats.csv"))
+for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea_final.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt"),
+                 ("probe_api.txt", "_probe_api.txt"), ("probe_special.txt", "_probe_special.txt"), ("api_latency.txt", "_api_latency.txt"),
+                 ("ab_fan.txt", "_ab_fan_final.txt"), ("timeline.txt", "_timeline.txt")):
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 if os.path.exists(os.path.join(OUT, "overhead_under_rocprofv3.txt")):
@@ -124,7 +128,7 @@ with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 
 acc = defaultdict(lambda: defaultdict(list))
-for r in (list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")) +
+for r in (list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")) + list(rows("prof_sq_cfg/*/*_counter_collection.csv")) +
           list(rows("prof_sq4_*/*/*_counter_collection.csv")) + list(rows("prof_sq5_*/*/*_counter_collection.csv"))):
     k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
     acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -15,8 +15,8 @@ cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-traffic"
 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
-python $ROOT/bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3.json 2> $OUT/bench_config3.err
-python $ROOT/bench.py --gpus 2 --config 3 --steps 20 --warmup 5 --shared-gpu --verify-gather > $OUT/bench_config3_two_ranks_shared_gpu.json 2> $OUT/bench_config3_two_ranks.err
+python $ROOT/bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.err
+python $ROOT/bench.py --gpus 2 --config 3 --gather all --steps 20 --warmup 5 --shared-gpu --verify-gather --no-cpu-baseline > $OUT/bench_config3_two_ranks_shared_gpu.json 2> $OUT/bench_config3_two_ranks.err
 python $ROOT/bench.py --gpus 2 --gather --steps 20 --warmup 5 --shared-gpu --verify-gather --no-large --no-cpu-baseline > $OUT/bench_metric_two_ranks_shared_gpu.json 2> $OUT/bench_metric_two_ranks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_k20 -- $B --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_k20.log 2>&1
@@ -31,7 +31,9 @@ for batch in 65536 4194304; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
 done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
-rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 1048576 > $OUT/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 131072 1048576 > $OUT/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq_cfg -- python $ROOT/tools/kernel_bench.py configs > $OUT/prof_sq_cfg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -- python $ROOT/tools/kernel_bench.py configs > $OUT/prof_cfg.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench.py hand 65536 > $OUT/prof_sq3.log 2>&1
 for r in panda iiwa7_allegro allegro_left; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq4_$r -- python $ROOT/tools/kernel_bench.py dynamics $r 262144 > $OUT/prof_sq4_$r.log 2>&1
@@ -47,6 +49,12 @@ python $ROOT/tools/ab_rnea.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_rnea.txt
 for b in 1048576 65536; do python $ROOT/tools/probe_api.py $b 2>&1 | grep "B="; done > $OUT/probe_api.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_api -- python $ROOT/tools/probe_api.py 1048576 > $OUT/prof_api.log 2>&1
 python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
+python $ROOT/tools/probe_special.py fetch 2>&1 | grep "^fetch" > $OUT/probe_special.txt
+python $ROOT/tools/api_profile.py 2>&1 | grep "us per eager call" > $OUT/api_latency.txt
+python $ROOT/tools/ab_fan.py 2>&1 | grep "B=" > $OUT/ab_fan.txt
+if [ -f $ROOT/tools/variants/libdrm_timeline.so ]; then
+  DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_timeline.so python $ROOT/tools/timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/timeline.txt
+fi
 if [ -x $ROOT/tools/ubench/metric_lab ]; then
   $ROOT/tools/ubench/metric_lab 1048576 floors > $OUT/io_floors_2p20.txt 2>&1
   $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
