@@ -111,7 +111,7 @@ for batch in (65536, 4194304):
     for name, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         vals = []
         for r in rows("prof_%s_%d/*/*_counter_collection.csv" % (name, batch)):
-            if r["Counter_Name"] == key and "fk_jacobian" in r["Kernel_Name"]:
+            if r["Counter_Name"] == key and "fk_jacobian_arm_kernel<8, 7, true" in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
                 traffic["kernel"] = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if vals:

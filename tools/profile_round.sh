@@ -13,6 +13,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-traffic"
+BM="$B --no-configs"   # the metric leg alone (counter passes, per-batch stats)
 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
 python $ROOT/bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.err
@@ -23,12 +24,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_k20 -- $
 # one stats file per batch size; 65 536 also launched eagerly (graph replays report the tracer's own period, r03_rocprof_overhead.md)
 for batch in 65536 4194304 16777216; do
   steps=200; [ $batch -gt 65536 ] && steps=50
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$batch -- $B --no-large --batch $batch --steps $steps > $OUT/prof_stats_$batch.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$batch -- $BM --no-large --batch $batch --steps $steps > $OUT/prof_stats_$batch.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_eager -- $B --no-large --no-graph > $OUT/prof_stats_eager.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_eager -- $BM --no-large --no-graph > $OUT/prof_stats_eager.log 2>&1
 for batch in 65536 4194304; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $B --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$batch -- $BM --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_fetch_$batch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $BM --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
 done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 131072 1048576 > $OUT/prof_sq.log 2>&1
