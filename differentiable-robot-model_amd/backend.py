@@ -1,11 +1,13 @@
-"""ctypes binding of the C ABI in include/drm_hip.h (csrc/libdrm_hip.so).
+"""ctypes binding of the C ABI in include/drm_hip.h: csrc/libdrm_hip.so for tensors on a HIP device, csrc/libdrm_cpu.so (the
+same entry points compiled by g++ over host pointers, csrc/drm_cpu.cpp) for tensors on the CPU — the reference's default device
+(robot_model.py:100-104).
 
-PyTorch is plumbing here: it owns the HBM buffers and the HIP stream; the
-kernels are launched on ``torch.cuda.current_stream()`` through plain pointers.
-``import torch`` must precede loading the library so that both share the HIP
-runtime that is already mapped into the process.
+PyTorch is plumbing here: it owns the buffers and the HIP stream; the kernels are launched on
+``torch.cuda.current_stream()`` through plain pointers.  ``import torch`` must precede loading the HIP library so that both share
+the HIP runtime that is already mapped into the process.
 
-There is no fallback: a missing library or a non-HIP tensor raises.
+The library is chosen by the DEVICE OF THE TENSORS and by nothing else (`library_for`): there is no fallback from one to the
+other — a HIP tensor without libdrm_hip.so raises NativeLibraryError, as does a CPU tensor without libdrm_cpu.so.
 """
 import ctypes
 import math
@@ -18,6 +20,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
+CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
 ABI_VERSION = 9
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
@@ -40,7 +43,7 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}      # "hip" / "cpu" -> the loaded library
 _lock = threading.Lock()
 
 EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "drm_fk_jacobian", "drm_rnea", "drm_fk_backward",
@@ -52,17 +55,37 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load")
 
 
-def load_library(path: str = None):
-    """Load csrc/libdrm_hip.so (once) and declare the prototypes.  Raises NativeLibraryError if absent."""
-    global _lib
+def library_for(device):
+    """The library that computes for tensors on `device`: libdrm_hip.so for a HIP device, libdrm_cpu.so for the CPU."""
+    kind = device.type
+    lib = _libs.get(kind)
+    if lib is not None:
+        return lib
+    if kind == "cuda":
+        return load_library()
+    if kind == "cpu":
+        return load_library(kind="cpu")
+    raise RuntimeError("tensors must live on a HIP device or on the CPU (got %s)" % device)
+
+
+def load_library(path: str = None, kind: str = "cuda"):
+    """Load csrc/libdrm_hip.so (kind "cuda": the library behind HIP tensors) or csrc/libdrm_cpu.so (kind "cpu": the host build of
+    the same ABI, behind CPU tensors) once and declare the prototypes.  Raises NativeLibraryError if absent."""
     with _lock:
-        if _lib is not None:
-            return _lib
-        path = path or os.environ.get("DRM_HIP_LIBRARY", LIB_PATH)
-        if not os.path.exists(path):
-            raise NativeLibraryError(
-                "native HIP library not found at %s — build it with `python __graft_entry__.py build` "
-                "(or `make -C differentiable-robot-model_amd/csrc`); there is no CPU fallback" % path)
+        if kind in _libs:
+            return _libs[kind]
+        if kind == "cuda":
+            path = path or os.environ.get("DRM_HIP_LIBRARY", LIB_PATH)
+            if not os.path.exists(path):
+                raise NativeLibraryError(
+                    "native HIP library not found at %s — build it with `python __graft_entry__.py build` "
+                    "(or `make -C differentiable-robot-model_amd/csrc`); there is no CPU fallback for tensors on a HIP device" % path)
+        else:
+            path = path or os.environ.get("DRM_CPU_LIBRARY", CPU_LIB_PATH)
+            if not os.path.exists(path):
+                raise NativeLibraryError(
+                    "host build of the library not found at %s — build it with `python __graft_entry__.py build` "
+                    "(or `make -C differentiable-robot-model_amd/csrc libdrm_cpu.so`)" % path)
         try:
             lib = ctypes.CDLL(path)
         except OSError as err:
@@ -128,19 +151,32 @@ def load_library(path: str = None):
             raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.drm_abi_version(), ABI_VERSION))
         if lib.drm_walk_sizeof() != ctypes.sizeof(DrmWalk):
             raise NativeLibraryError("struct drm_walk: library %d bytes, binding %d" % (lib.drm_walk_sizeof(), ctypes.sizeof(DrmWalk)))
-        _lib = lib
-        return _lib
+        if kind == "cpu":
+            lib.drm_cpu_set_threads.restype = None
+            lib.drm_cpu_set_threads.argtypes = [ctypes.c_int]
+            lib.drm_cpu_set_threads(torch.get_num_threads())      # (as many threads as torch's own CPU kernels use)
+        _libs[kind] = lib
+        return lib
 
 
 class KernelUnsupported(RuntimeError):
     """DRM_ERR_UNSUPPORTED: the request is valid but no compiled kernel takes it (e.g. an inertia matrix too large for LDS)."""
 
 
-def _check(rc: int):
+def _check(rc: int, lib=None):
     if rc != 0:
-        msg = load_library().drm_last_error()
+        msg = (lib if lib is not None else load_library()).drm_last_error()
         text = "drm_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?")
         raise KernelUnsupported(text) if rc == -2 else RuntimeError(text)
+
+
+def _lib_of(t, name: str, table=None):
+    """The library for the device `t` lives on (`table`: a tensor of the model, which must live there too)."""
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a tensor (got %s)" % (name, type(t)))
+    if table is not None and table.device != t.device:
+        raise RuntimeError("%s is on %s but the model's tables are on %s" % (name, t.device, table.device))
+    return library_for(t.device)
 
 
 def _plan_input(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
@@ -156,8 +192,8 @@ def _plan_input(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
 
 
 def _dev_f32(t: torch.Tensor, name: str, cols: int) -> torch.Tensor:
-    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
-        raise RuntimeError("%s must be a tensor on a HIP device (got %s)" % (name, getattr(t, "device", type(t))))
+    if not isinstance(t, torch.Tensor) or t.device.type not in ("cuda", "cpu"):
+        raise RuntimeError("%s must be a tensor on a HIP device or on the CPU (got %s)" % (name, getattr(t, "device", type(t))))
     if t.ndim != 2 or t.shape[1] != cols:
         raise ValueError("%s must be [B, %d], got %s" % (name, cols, tuple(t.shape)))
     if t.dtype != torch.float32:
@@ -182,8 +218,9 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
 
 def _walk_struct_build(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_dofs: int) -> DrmWalk:
     rows = prog.capacity
-    assert ops_f.is_cuda and ops_f.dtype == torch.float32 and ops_f.is_contiguous() and ops_f.shape[0] == rows
-    assert ops_i.is_cuda and ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[1] == rows
+    assert ops_f.device.type in ("cuda", "cpu") and ops_i.device == ops_f.device
+    assert ops_f.dtype == torch.float32 and ops_f.is_contiguous() and ops_f.shape[0] == rows
+    assert ops_i.dtype == torch.int32 and ops_i.is_contiguous() and ops_i.shape[1] == rows
     target_perm = getattr(prog, "_target_perm", None)
     if target_perm is None:   # un-permutation of the last op's frame, looked up once per walk
         target_perm = prog._target_perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM]) if prog.n_ops else 2
@@ -217,6 +254,8 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream(device) -> ctypes.c_void_p:
     """The caller's current HIP stream on `device` as a raw handle (the private accessor, when this torch has it, skips building
     a torch.cuda.Stream object per call)."""
+    if device.type == "cpu":
+        return None                                   # (libdrm_cpu.so ignores the argument: calls return when the results are written)
     if _raw_stream is not None and device.index is not None:
         return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -227,7 +266,8 @@ class _on_device(object):
     __slots__ = ("guard",)
 
     def __init__(self, device):
-        self.guard = None if device.index is None or torch.cuda.current_device() == device.index else torch.cuda.device(device)
+        self.guard = (None if device.type == "cpu" or device.index is None or torch.cuda.current_device() == device.index
+                      else torch.cuda.device(device))
 
     def __enter__(self):
         if self.guard is not None:
@@ -269,7 +309,7 @@ def _contiguous_strides(shape):
 def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze: bool = False):
     """pos [B, T, 3], quat [B, T, 4] of the walk's targets ([B, 3], [B, 4] for one target with ``squeeze``: the same
     memory without the T axis, so the single-link API returns it without a slicing op)."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     if squeeze and n_targets == 1:
@@ -281,14 +321,14 @@ def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze:
     walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
     with _on_device(q.device):
         _check(lib.drm_fk(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
-                          _stream(q.device)))
+                          _stream(q.device)), lib)
     return pos, quat
 
 
 def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     """pos [T, B, 3], quat [T, B, 4] of the walk's targets, LINK-major: pos[t] / quat[t] are contiguous [B, 3] / [B, 4] arrays
     (what compute_forward_kinematics_all_links returns per link; the kernel writes a link's 64 poses of a tile as one run)."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     pos = torch.empty(n_targets, B, 3, device=q.device, dtype=torch.float32)
@@ -298,14 +338,14 @@ def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     with _on_device(q.device):
         _check(lib.drm_fk_links(ctypes.byref(walk), q.data_ptr(), B, n_targets, pos.data_ptr(), quat.data_ptr(),
-                                _stream(q.device)))
+                                _stream(q.device)), lib)
     return pos, quat
 
 
 def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
     """FK of 2..4 targets with (nearly) disjoint chains: ``chains`` = [(prog, ops_f, ops_i)] per target.  pos [B, T, 3],
     quat [B, T, 4]; with ``link_major`` pos [T, B, 3], quat [T, B, 4] (every target's poses a contiguous array)."""
-    lib = load_library()
+    lib = _lib_of(q, "q", chains[0][1])
     q = _dev_f32(q, "q", n_dofs)
     B, T = q.shape[0], len(chains)
     pos = torch.empty((T, B, 3) if link_major else (B, T, 3), device=q.device, dtype=torch.float32)
@@ -315,12 +355,12 @@ def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
     walks = (DrmWalk * T)(*[_walk_struct(p, f.detach(), i, n_dofs) for p, f, i in chains])
     with _on_device(q.device):
         _check((lib.drm_fk_fanout_links if link_major else lib.drm_fk_fanout)(
-            walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)))
+            walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)), lib)
     return pos, quat
 
 
 def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     pos, quat, lin, ang = _outputs(q.device, (B, 3), (B, 4), (B, 3, n_dofs), (B, 3, n_dofs))
@@ -329,12 +369,12 @@ def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
     with _on_device(q.device):
         _check(lib.drm_fk_jacobian(ctypes.byref(walk), q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(),
-                                   lin.data_ptr(), ang.data_ptr(), _stream(q.device)))
+                                   lin.data_ptr(), ang.data_ptr(), _stream(q.device)), lib)
     return pos, quat, lin, ang
 
 
 def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     qd = _dev_f32(qd, "qd", n_dofs)
     qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None
@@ -350,7 +390,7 @@ def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use
     with _on_device(q.device):
         _check(lib.drm_rnea(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(),
                             qdd.data_ptr() if qdd is not None else None, B, flags, tau.data_ptr(),
-                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
+                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)), lib)
     return tau
 
 
@@ -363,7 +403,7 @@ def _rnea_scratch(lib, walk, B, device):
 def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include_gravity: bool, use_damping: bool,
                   n_dofs: int, param_mask: int, want_grad_inputs: bool):
     """((grad_q, grad_qd, grad_qdd) or None, grad_ops_f [cap,32] or None) for a loss gradient on the torques."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     if not prog.slots_unique:
         raise RuntimeError("backward RNEA needs a walk whose branch points own their save slots")
     q = _dev_f32(q, "q", n_dofs)
@@ -384,7 +424,7 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
         _check(lib.drm_rnea_backward(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), ptr(qdd), B, flags,
                                      grad_tau.data_ptr(), ctypes.c_uint64(param_mask),
                                      ptr(gin[0]) if gin else None, ptr(gin[1]) if gin else None,
-                                     ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)))
+                                     ptr(gin[2]) if gin else None, ptr(grad_ops), scratch.data_ptr(), _stream(dev)), lib)
     return gin, grad_ops
 
 
@@ -395,11 +435,11 @@ class LinkRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, params):
-        lib = load_library()
+        lib = library_for(params.device)
         params = params.contiguous().to(torch.float32)
         rows = torch.empty(params.shape[0], 32, device=params.device, dtype=torch.float32)
-        with torch.cuda.device(params.device):
-            _check(lib.drm_link_rows(params.data_ptr(), params.shape[0], rows.data_ptr(), _stream(params.device)))
+        with _on_device(params.device):
+            _check(lib.drm_link_rows(params.data_ptr(), params.shape[0], rows.data_ptr(), _stream(params.device)), lib)
         ctx.save_for_backward(params)
         return rows
 
@@ -407,12 +447,12 @@ class LinkRows(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_rows):
         (params,) = ctx.saved_tensors
-        lib = load_library()
+        lib = library_for(params.device)
         grad_rows = grad_rows.contiguous().to(torch.float32)
         grad = torch.empty_like(params)
-        with torch.cuda.device(params.device):
+        with _on_device(params.device):
             _check(lib.drm_link_rows_backward(params.data_ptr(), grad_rows.data_ptr(), params.shape[0], grad.data_ptr(),
-                                              _stream(params.device)))
+                                              _stream(params.device)), lib)
         return grad
 
 
@@ -425,14 +465,14 @@ class WalkTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, base, sel, gsign, n_links, *pieces):
-        lib = load_library()
+        lib = library_for(base.device)
         dev = base.device
         params = torch.cat([p.reshape(-1).to(device=dev, dtype=torch.float32) for p in pieces])
         assert params.numel() == n_links * 20, "20 floats per learnable link"
         ops_f = torch.empty_like(base)
         with _on_device(dev):
             _check(lib.drm_walk_table(params.data_ptr(), n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
-                                      base.numel(), ops_f.data_ptr(), _stream(dev)))
+                                      base.numel(), ops_f.data_ptr(), _stream(dev)), lib)
         ctx.save_for_backward(params, sel, gsign)
         ctx.n_links, ctx.shapes = n_links, [tuple(p.shape) for p in pieces]
         return ops_f
@@ -441,12 +481,12 @@ class WalkTable(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_ops_f):
         params, sel, gsign = ctx.saved_tensors
-        lib = load_library()
+        lib = library_for(params.device)
         g = grad_ops_f.contiguous().to(torch.float32)
         grad = torch.empty_like(params)
-        with torch.cuda.device(params.device):
+        with _on_device(params.device):
             _check(lib.drm_walk_table_backward(params.data_ptr(), ctx.n_links, g.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
-                                               g.numel(), grad.data_ptr(), _stream(params.device)))
+                                               g.numel(), grad.data_ptr(), _stream(params.device)), lib)
         out, off = [], 0
         for i, shape in enumerate(ctx.shapes):
             n = 1
@@ -459,7 +499,7 @@ class WalkTable(torch.autograd.Function):
 
 def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):
     """qdd [B, n] produced by the joint torques f in state (q, qd)."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q, qd, f = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs), _dev_f32(f, "f", n_dofs)
     B = q.shape[0]
     if qd.shape[0] != B or f.shape[0] != B:
@@ -475,13 +515,13 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
     with _on_device(q.device):
         _check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), f.data_ptr(), B, flags,
                                         qdd.data_ptr(), scratch.data_ptr() if scratch is not None else None,
-                                        _stream(q.device)))
+                                        _stream(q.device)), lib)
     return qdd
 
 
 def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     """H [B, n, n] joint-space inertia matrix."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     H = torch.empty(B, n_dofs, n_dofs, device=q.device, dtype=torch.float32)
@@ -493,7 +533,7 @@ def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     scratch = torch.empty(need, device=q.device, dtype=torch.float32) if need > 0 else None
     with _on_device(q.device):
         _check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, H.data_ptr(),
-                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)))
+                            scratch.data_ptr() if scratch is not None else None, _stream(q.device)), lib)
     return H
 
 
@@ -501,7 +541,7 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
                 want_grad_q: bool, grad_rot=None):
     """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for a loss gradient on the target positions (grad_pos
     [B,T,3]) and, optionally, on the target rotation matrices (grad_rot [B,T,3,3])."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     if not prog.slots_unique:
         raise RuntimeError("backward FK needs a walk whose branch points own their save slots (more than %d "
                            "branch points in this tree)" % prog.n_slots)
@@ -521,7 +561,7 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
         _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
                                    grad_rot.data_ptr() if grad_rot is not None else None,
                                    ctypes.c_uint64(param_mask), grad_q.data_ptr() if want_grad_q else None,
-                                   grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
+                                   grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)), lib)
     return grad_q, grad_ops
 
 
@@ -529,7 +569,7 @@ def fk_mse(prog: WalkProgram, ops_f, ops_i, q, target, n_dofs: int, param_mask: 
     """(loss [], grad_q [B, n] or None, grad_ops_f [cap, 32] or None) of loss = mean((pos(q) - target)^2) for the walk's target
     (drm_fk_mse: forward kinematics, loss and backward in one pass).  Raises KernelUnsupported for walks / batches the fused
     kernel does not take (the caller composes fk + mse_loss then)."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     target = _dev_f32(target, "target", 3)
     B, dev = q.shape[0], q.device
@@ -543,7 +583,7 @@ def fk_mse(prog: WalkProgram, ops_f, ops_i, q, target, n_dofs: int, param_mask: 
     with _on_device(dev):
         _check(lib.drm_fk_mse(ctypes.byref(walk), q.data_ptr(), target.data_ptr(), B, ctypes.c_uint64(param_mask), loss.data_ptr(),
                               grad_q.data_ptr() if want_grad_q else None, grad_ops.data_ptr() if param_mask else None,
-                              scratch.data_ptr(), _stream(dev)))
+                              scratch.data_ptr(), _stream(dev)), lib)
     return loss, grad_q, grad_ops
 
 
@@ -551,7 +591,7 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
                          param_mask: int, want_grad_q: bool, grad_rot=None):
     """(grad_q [B,n] or None, grad_ops_f [cap,32] or None) for loss gradients on the Jacobian (and, optionally, the
     target position) of the chain walk ``prog``."""
-    lib = load_library()
+    lib = _lib_of(q, "q", ops_f)
     q = _dev_f32(q, "q", n_dofs)
     B, dev = q.shape[0], q.device
     grad_lin = _dev_f32(grad_lin.reshape(B, 3 * n_dofs), "grad_lin_jac", 3 * n_dofs)
@@ -570,8 +610,14 @@ def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin,
                                             grad_rot.data_ptr() if grad_rot is not None else None, grad_lin.data_ptr(),
                                             grad_ang.data_ptr(), ctypes.c_uint64(param_mask),
                                             grad_q.data_ptr() if want_grad_q else None,
-                                            grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)))
+                                            grad_ops.data_ptr() if param_mask else None, scratch.data_ptr(), _stream(dev)), lib)
     return grad_q, grad_ops
+
+
+def _plan_stream(stream, device):
+    if device.type == "cpu":
+        return None
+    return ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream(device)).cuda_stream)
 
 
 class FkJacobianPlan(object):
@@ -582,7 +628,7 @@ class FkJacobianPlan(object):
     """
 
     def __init__(self, prog: WalkProgram, ops_f, ops_i, q, n_dofs: int, want_pose: bool = True):
-        self._lib = load_library()
+        self._lib = _lib_of(q, "q", ops_f)
         self.q = _plan_input(q, "q", n_dofs)
         B = self.q.shape[0]
         dev = self.q.device
@@ -599,10 +645,9 @@ class FkJacobianPlan(object):
         self.device = dev
 
     def launch(self, stream=None):
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self._lib.drm_fk_jacobian(*self._args, ctypes.c_void_p(s.cuda_stream))
+        rc = self._lib.drm_fk_jacobian(*self._args, _plan_stream(stream, self.device))
         if rc != 0:
-            _check(rc)
+            _check(rc, self._lib)
 
     def outputs(self):
         return self.pos, self.quat, self.lin, self.ang
@@ -616,7 +661,7 @@ class FkInverseDynamicsPlan(object):
     def __init__(self, tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int,
                  outputs=None):
         # tree / chain: (WalkProgram, ops_f, ops_i) of the whole-tree walk and of the root -> link walk
-        self._lib = load_library()
+        self._lib = _lib_of(q, "q", tree[1])
         self.q, self.qd = _plan_input(q, "q", n_dofs), _plan_input(qd, "qd", n_dofs)
         self.qdd = _plan_input(qdd, "qdd", n_dofs) if qdd is not None else None
         B, dev = self.q.shape[0], self.q.device
@@ -643,10 +688,9 @@ class FkInverseDynamicsPlan(object):
         self.batch, self.device = B, dev
 
     def launch(self, stream=None):
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self._lib.drm_fk_rnea(*self._args, ctypes.c_void_p(s.cuda_stream))
+        rc = self._lib.drm_fk_rnea(*self._args, _plan_stream(stream, self.device))
         if rc != 0:
-            _check(rc)
+            _check(rc, self._lib)
 
     def outputs(self):
         return self.tau, self.pos, self.quat
@@ -657,7 +701,7 @@ class InverseDynamicsPlan(object):
     compute_inverse_dynamics for loops that evaluate the same batch shape repeatedly (update q / qd / qdd in place)."""
 
     def __init__(self, prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
-        self._lib = load_library()
+        self._lib = _lib_of(q, "q", ops_f)
         self.q, self.qd = _plan_input(q, "q", n_dofs), _plan_input(qd, "qd", n_dofs)
         self.qdd = _plan_input(qdd, "qdd", n_dofs) if qdd is not None else None
         B, dev = self.q.shape[0], self.q.device
@@ -674,10 +718,9 @@ class InverseDynamicsPlan(object):
         self.batch, self.device = B, dev
 
     def launch(self, stream=None):
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self._lib.drm_rnea(*self._args, ctypes.c_void_p(s.cuda_stream))
+        rc = self._lib.drm_rnea(*self._args, _plan_stream(stream, self.device))
         if rc != 0:
-            _check(rc)
+            _check(rc, self._lib)
 
     def outputs(self):
         return (self.tau,)

@@ -107,8 +107,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         self.name = name
         self._reference_compat = bool(reference_compat)
         if device is None:
-            # the reference defaults to CPU (robot_model.py:100-104); this engine only computes on a HIP
-            # device, so pick it when there is one
+            # the reference defaults to CPU (robot_model.py:100-104); this engine is built for the HIP device, so pick it when
+            # there is one (a CPU model computes through the host build of the same library, csrc/drm_cpu.cpp)
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self._device = torch.device(device)
         if self._device.type == "cuda" and self._device.index is None:
@@ -285,7 +285,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         attached, False when the robot already runs a compiled straight-line kernel (7-DoF arms, arm + hand, hands).  Models with
         learnable link parameters specialise their full walk as well (the kernel reads the same table)."""
         from . import specialize as sp
-        self._require_device()
+        if self._device.type != "cuda":
+            raise RuntimeError("per-robot kernels are HIP code objects: the model must live on a HIP device (it is on %s)" % self._device)
         dw = self._dynamics_walk()
         from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
         if dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
@@ -463,10 +464,10 @@ class DifferentiableRobotModel(torch.nn.Module):
                                       "%d slots)" % (dw.program.n_ops, dw.program.n_slots))
 
     def _require_device(self):
-        if self._device.type != "cuda":
-            raise RuntimeError(
-                "differentiable-robot-model_amd has no CPU compute path: construct the model with "
-                "device='cuda' on an MI355X (model device is %s)" % self._device)
+        """The library that computes on the model's device must be there: libdrm_hip.so for a HIP device, libdrm_cpu.so (the host
+        build of the same C ABI) for the CPU, the reference's default device (robot_model.py:100-104).  One never stands in for
+        the other (backend.library_for raises NativeLibraryError)."""
+        backend.library_for(self._device)
 
     # ------------------------------------------------------------------ kinematic state (reference API)
     @tensor_check
@@ -736,7 +737,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs and qdd_des.shape[1] == self._n_dofs
         plan = self.plan_fk_and_inverse_dynamics(q.detach(), qd.detach(), qdd_des.detach(), link_name,
                                                  bool(include_gravity), bool(use_damping))
-        with torch.cuda.device(self._device):
+        with backend._on_device(self._device):
             plan.launch()
         return plan.tau, plan.pos, plan.quat
 

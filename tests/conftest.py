@@ -11,3 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cpu_library():
+    """csrc/libdrm_cpu.so — the host build of the C ABI behind device="cpu" models — built if it is missing or older than its
+    sources (g++, ~8 s), as `__graft_entry__.build()` does."""
+    import __graft_entry__ as entry
+    entry.build_cpu_library()
+    import importlib
+    return importlib.import_module("differentiable-robot-model_amd.backend").load_library(kind="cpu")

@@ -1,0 +1,148 @@
+"""Models on device="cpu" — the reference's default device (robot_model.py:100-104; its own suite constructs every model there,
+tests/test_kinematics_dynamics.py:133-137) — compute through csrc/libdrm_cpu.so, the HOST build of the C ABI of
+include/drm_hip.h (csrc/drm_cpu.cpp: the kernels' own per-sample headers compiled by g++).
+
+Same fixtures, same checks and the same bars as the kernels' tests (the bodies are shared with the -m gpu tests): forward
+outputs and torch-autograd gradients of the UNMODIFIED reference.  Plus what is particular to the host build: it exports the
+whole ABI, its batch sums do not depend on the thread count, and it is never what a HIP tensor reaches.
+"""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_ROBOTS, load_model
+import test_fk_backward as fkb
+import test_forward_dynamics as fdt
+import test_golden_tiles as tl
+import test_golden_wide as wide
+import test_mass_matrix as mmt
+import test_rnea_backward as rbt
+
+backend = importlib.import_module("differentiable-robot-model_amd.backend")
+
+
+def test_host_build_exports_the_whole_abi(cpu_library):
+    lib = ctypes.CDLL(backend.CPU_LIB_PATH)
+    for sym in backend.EXPORTS:
+        getattr(lib, sym)
+    assert lib.drm_abi_version() == backend.ABI_VERSION and lib.drm_walk_sizeof() == ctypes.sizeof(backend.DrmWalk)
+    # per-robot code objects are HIP kernels
+    out = ctypes.c_void_p()
+    assert cpu_library.drm_special_load(b"/nonexistent", b"k", ctypes.byref(out)) == -2
+    assert b"HIP" in cpu_library.drm_last_error()
+
+
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+def test_cpu_forward_vs_reference_tiles(robot, links, cpu_library):
+    wide.check_gpu_vs_reference(tl.tiles("fwd"), robot, links, device="cpu")
+
+
+@pytest.mark.parametrize("case", fkb.CASES)
+def test_cpu_fk_backward_vs_reference_autograd(case, cpu_library):
+    fkb.check_gpu_backward_vs_reference_autograd(fkb.load_golden_grad(), case, device="cpu")
+
+
+@pytest.mark.parametrize("case", rbt.CASES)
+def test_cpu_rnea_backward_vs_reference_autograd(case, cpu_library):
+    rbt.check_gpu_backward_vs_reference_autograd(rbt.load_golden_dyn(), case, device="cpu")
+
+
+@pytest.mark.parametrize("case", mmt.H_GRAD_CASES)
+def test_cpu_mass_matrix_backward_vs_reference_autograd(case, cpu_library):
+    mmt.check_gpu_mass_matrix_backward_vs_reference_autograd(mmt.load_golden_grad_mass(), case, device="cpu")
+
+
+@pytest.mark.parametrize("case", fdt.FD_GRAD_CASES)
+def test_cpu_forward_dynamics_backward_vs_reference_autograd(case, cpu_library):
+    fdt.check_gpu_forward_dynamics_backward_vs_reference_autograd(fdt.load_golden_grad_fd(), case, device="cpu")
+
+
+@pytest.mark.parametrize("case", ["iiwa7", "panda_no_gripper"])
+def test_cpu_fk_backward_full_tiles_and_fused_step(case, cpu_library):
+    """192 rows: the reference's gradients through compute_forward_kinematics, and fk_mse_loss (drm_fk_mse of the host build: any
+    batch size) against the same numbers."""
+    g = tl.tiles("grad")
+    fkb.check_gpu_backward_vs_reference_autograd(g, case, device="cpu")
+    targets = [str(t) for t in g[case + "/targets"]]
+    m = fkb.learnable_model(g, case, "cpu")
+    q = torch.from_numpy(g[case + "/q"].copy()).requires_grad_(True)
+    want = torch.from_numpy(g["%s/want/%s" % (case, targets[0])].copy())
+    loss = m.fk_mse_loss(q, targets[0], want)
+    assert type(loss.grad_fn).__name__.startswith("_FkMse")
+    loss.backward()
+    assert abs(loss.item() - float(g[case + "/loss"])) < 1e-6
+    assert fkb.close(q.grad.numpy(), g[case + "/grad_q"])
+    for link in g[case + "/learnable"]:
+        body = m._bodies[m._name_to_idx_map[str(link)]]
+        for pname in ("trans", "rot_angles"):
+            assert fkb.close(getattr(body, pname).param.grad.numpy(), g["%s/grad/%s/%s" % (case, link, pname)]), (case, link, pname)
+
+
+def test_cpu_batch_sums_do_not_depend_on_the_thread_count(cpu_library):
+    """grad_ops_f is one partial per 256 rows added in chunk order: bit-identical with 1 thread and with 7."""
+    g = tl.tiles("grad_dyn")
+    case = "panda"
+    out = []
+    for threads in (1, 7, 1):
+        cpu_library.drm_cpu_set_threads(threads)
+        m, params = rbt.learnable_model(g, case, "cpu")
+        rep = 5                                                     # 960 rows: four chunks
+        q, qd, qdd = (torch.from_numpy(np.tile(g["%s/%s" % (case, k)], (rep, 1))).requires_grad_(True) for k in ("q", "qd", "qdd"))
+        tau = m.compute_inverse_dynamics(q, qd, qdd)
+        tau.pow(2).mean().backward()
+        out.append([p.grad.clone() for p in params.values()] + [q.grad.clone(), tau.detach().clone()])
+    cpu_library.drm_cpu_set_threads(torch.get_num_threads())
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(out[0], out[2]):
+        assert torch.equal(a, b)
+
+
+def test_cpu_empty_and_single_row_batches(cpu_library):
+    m = load_model("panda", "cpu")
+    n = m._n_dofs
+    link = "panda_virtual_ee_link"
+    for B in (0, 1):
+        q = torch.zeros(B, n)
+        pos, quat = m.compute_forward_kinematics(q, link)
+        lin, ang = m.compute_endeffector_jacobian(q, link)
+        tau = m.compute_inverse_dynamics(q, q, q)
+        H = m.compute_lagrangian_inertia_matrix(q)
+        acc = m.compute_forward_dynamics(q, q, q)
+        assert pos.shape == (B, 3) and quat.shape == (B, 4) and lin.shape == (B, 3, n) and ang.shape == (B, 3, n)
+        assert tau.shape == (B, n) and H.shape == (B, n, n) and acc.shape == (B, n)
+        assert all(t.device.type == "cpu" for t in (pos, quat, lin, ang, tau, H, acc))
+
+
+def test_cpu_all_links_and_fused_call_match_the_single_calls(cpu_library):
+    m = load_model("iiwa7_allegro", "cpu")
+    g = torch.Generator().manual_seed(3)
+    q, qd, qdd = (torch.rand(300, m._n_dofs, generator=g) - 0.5 for _ in range(3))
+    poses = m.compute_forward_kinematics_all_links(q)
+    for name in list(poses)[::5]:
+        pos, quat = m.compute_forward_kinematics(q, name)
+        # (the walk of one link folds the fixed joints along its chain differently from the walk of all links: rounding)
+        assert (poses[name][0] - pos).abs().max() < 2e-6 and (poses[name][1] - quat).abs().max() < 2e-6
+    m = load_model("panda_no_gripper", "cpu")
+    q, qd, qdd = (torch.rand(300, 7, generator=g) - 0.5 for _ in range(3))
+    tau, pos, quat = m.compute_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link")
+    assert torch.equal(tau, m.compute_inverse_dynamics(q, qd, qdd))
+    p2, q2 = m.compute_forward_kinematics(q, "panda_virtual_ee_link")
+    assert torch.equal(pos, p2) and torch.equal(quat, q2)
+
+
+def test_the_library_follows_the_tensors_device(cpu_library):
+    """libdrm_cpu.so is what CPU tensors reach and nothing else: the choice is made from the tensor's device alone, and a model
+    does not take tensors from another device."""
+    assert backend.library_for(torch.device("cpu")) is cpu_library
+    with pytest.raises(RuntimeError, match="HIP device or on the CPU"):
+        backend.library_for(torch.device("meta"))
+    m = load_model("panda", "cpu")
+    prog_args = m._get_walk(("fk", (3,)), targets=[3])
+    with pytest.raises(RuntimeError, match="model's tables are on"):
+        backend.fk(prog_args.program, m._ops_f(prog_args).to("meta"), prog_args.ops_i, torch.zeros(2, m._n_dofs), 1, m._n_dofs)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.specialize()

@@ -132,11 +132,11 @@ def test_gpu_backward_vs_reference_autograd(case):
     check_gpu_backward_vs_reference_autograd(load_golden_grad(), case)
 
 
-def check_gpu_backward_vs_reference_autograd(g, case):
-    m = learnable_model(g, case, "cuda")
+def check_gpu_backward_vs_reference_autograd(g, case, device="cuda"):
+    m = learnable_model(g, case, device)
     targets = [str(t) for t in g[case + "/targets"]]
-    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
-    wants = [torch.from_numpy(g["%s/want/%s" % (case, t)].copy()).cuda() for t in targets]
+    q = torch.from_numpy(g[case + "/q"].copy()).to(device).requires_grad_(True)
+    wants = [torch.from_numpy(g["%s/want/%s" % (case, t)].copy()).to(device) for t in targets]
     # one call per target, as the reference's loop would do it
     loss = _api_loss(m, q, targets, wants)
     loss.backward()
@@ -148,7 +148,7 @@ def check_gpu_backward_vs_reference_autograd(g, case):
             assert close(getattr(body, pname).param.grad.cpu().numpy(), g["%s/grad/%s/%s" % (case, link, pname)]), \
                 (case, link, pname)
     # all targets from ONE multi-target walk (branch-point slots, adjoint slots) give the same gradients
-    m2 = learnable_model(g, case, "cuda")
+    m2 = learnable_model(g, case, device)
     q2 = q.detach().clone().requires_grad_(True)
     poses = m2.compute_forward_kinematics_all_links(q2)
     loss2 = sum(torch.nn.functional.mse_loss(poses[t][0], w) for t, w in zip(targets, wants))

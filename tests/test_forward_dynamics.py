@@ -224,10 +224,10 @@ def test_gpu_forward_dynamics_backward_vs_reference_autograd(case):
     check_gpu_forward_dynamics_backward_vs_reference_autograd(load_golden_grad_fd(), case)
 
 
-def check_gpu_forward_dynamics_backward_vs_reference_autograd(g, case):
-    m, params = learnable_model_fd(g, case, "cuda")
-    q, qd, f = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).cuda().requires_grad_(True) for k in ("q", "qd", "f"))
-    want = torch.from_numpy(g[case + "/want"].copy()).cuda()
+def check_gpu_forward_dynamics_backward_vs_reference_autograd(g, case, device="cuda"):
+    m, params = learnable_model_fd(g, case, device)
+    q, qd, f = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).to(device).requires_grad_(True) for k in ("q", "qd", "f"))
+    want = torch.from_numpy(g[case + "/want"].copy()).to(device)
     qdd = m.compute_forward_dynamics(q, qd, f, include_gravity=True, use_damping=True)
     loss = torch.nn.functional.mse_loss(qdd, want)
     loss.backward()

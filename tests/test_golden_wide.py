@@ -62,12 +62,18 @@ def test_gpu_vs_reference_wide(robot, links):
     check_gpu_vs_reference(WIDE, robot, links)
 
 
-def check_gpu_vs_reference(WIDE, robot, links, repeat=1):
+@pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
+def test_cpu_model_vs_reference_wide(robot, links, cpu_library):
+    """A model on device="cpu" (the reference's default): the host build of the C ABI (libdrm_cpu.so), same bars as the kernels."""
+    check_gpu_vs_reference(WIDE, robot, links, device="cpu")
+
+
+def check_gpu_vs_reference(WIDE, robot, links, repeat=1, device="cuda"):
     """`repeat` > 1: the fixture's rows tiled that many times into ONE launch (so that a 192-row fixture reaches kernels that
     only engage beyond a launch size, e.g. the two-samples-per-lane arm kernels past 1 024 tiles); every copy must meet the
     reference on its own."""
-    m = load_model(robot, "cuda")
-    q, qd, qdd, f = (torch.from_numpy(np.tile(WIDE["%s/%s" % (robot, k)], (repeat, 1))).cuda() for k in ("q", "qd", "qdd", "f"))
+    m = load_model(robot, device)
+    q, qd, qdd, f = (torch.from_numpy(np.tile(WIDE["%s/%s" % (robot, k)], (repeat, 1))).to(device) for k in ("q", "qd", "qdd", "f"))
     if repeat > 1:
         WIDE = {k: (np.tile(WIDE[k], (repeat,) + (1,) * (WIDE[k].ndim - 1)) if WIDE[k].dtype == np.float32 else WIDE[k])
                 for k in WIDE.files if k.startswith(robot + "/")}

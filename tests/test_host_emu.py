@@ -33,7 +33,7 @@ def emu(request):
     src = os.path.join(HERE, "host_emu", "host_emu.cpp")
     lib = os.path.join(HERE, "host_emu", "libdrm_host_emu%s.so" % ("" if cxx == "g++" else "_clang"))
     csrc = os.path.join(HERE, "..", "differentiable-robot-model_amd", "csrc")
-    deps = [src, os.path.join(csrc, "drm_sample.hpp"), os.path.join(csrc, "drm_tree.hpp"),
+    deps = [src, os.path.join(csrc, "drm_sample.hpp"), os.path.join(csrc, "drm_tree.hpp"), os.path.join(csrc, "drm_host_loops.hpp"),
             os.path.join(HERE, "..", "include", "drm_hip.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
         # -O1: the straight-line templates take minutes at -O2/-O3 and the checks here are about arithmetic and

@@ -176,11 +176,11 @@ def test_gpu_mass_matrix_backward_vs_reference_autograd(case):
     check_gpu_mass_matrix_backward_vs_reference_autograd(load_golden_grad_mass(), case)
 
 
-def check_gpu_mass_matrix_backward_vs_reference_autograd(g, case):
+def check_gpu_mass_matrix_backward_vs_reference_autograd(g, case, device="cuda"):
     from test_forward_dynamics import grad_close, learnable_model_fd
-    m, params = learnable_model_fd(g, case, "cuda")
-    q = torch.from_numpy(g[case + "/q"].copy()).cuda().requires_grad_(True)
-    want, weight = (torch.from_numpy(g[case + "/" + k].copy()).cuda() for k in ("want", "weight"))
+    m, params = learnable_model_fd(g, case, device)
+    q = torch.from_numpy(g[case + "/q"].copy()).to(device).requires_grad_(True)
+    want, weight = (torch.from_numpy(g[case + "/" + k].copy()).to(device) for k in ("want", "weight"))
     H = m.compute_lagrangian_inertia_matrix(q)
     loss = (weight * (H - want) ** 2).mean()
     loss.backward()

@@ -144,10 +144,10 @@ def test_gpu_backward_vs_reference_autograd(case):
     check_gpu_backward_vs_reference_autograd(load_golden_dyn(), case)
 
 
-def check_gpu_backward_vs_reference_autograd(g, case):
-    m, params = learnable_model(g, case, "cuda")
-    q, qd, qdd = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).cuda().requires_grad_(True) for k in ("q", "qd", "qdd"))
-    want = torch.from_numpy(g[case + "/want"].copy()).cuda()
+def check_gpu_backward_vs_reference_autograd(g, case, device="cuda"):
+    m, params = learnable_model(g, case, device)
+    q, qd, qdd = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).to(device).requires_grad_(True) for k in ("q", "qd", "qdd"))
+    want = torch.from_numpy(g[case + "/want"].copy()).to(device)
     tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
     loss = torch.nn.functional.mse_loss(tau, want)
     loss.backward()
