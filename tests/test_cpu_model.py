@@ -141,8 +141,11 @@ def test_the_library_follows_the_tensors_device(cpu_library):
     with pytest.raises(RuntimeError, match="HIP device or on the CPU"):
         backend.library_for(torch.device("meta"))
     m = load_model("panda", "cpu")
-    prog_args = m._get_walk(("fk", (3,)), targets=[3])
-    with pytest.raises(RuntimeError, match="model's tables are on"):
-        backend.fk(prog_args.program, m._ops_f(prog_args).to("meta"), prog_args.ops_i, torch.zeros(2, m._n_dofs), 1, m._n_dofs)
+
+    class TableOnHipDevice(object):      # (no HIP device on the CPU test box: what the check reads of a tensor)
+        is_cuda, device = True, torch.device("cuda", 0)
+
+    with pytest.raises(RuntimeError, match="model's tables are on cuda:0"):
+        backend._lib_of(torch.zeros(2, m._n_dofs), "q", TableOnHipDevice())
     with pytest.raises(RuntimeError, match="HIP device"):
         m.specialize()
