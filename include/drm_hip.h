@@ -24,7 +24,7 @@
  * device="cpu", the reference's default (robot_model.py:100-104): same arguments, results and error codes; `stream` is
  * ignored and a call returns when its results are written; the forward scratch queries return 0; drm_special_load is
  * DRM_ERR_UNSUPPORTED; drm_fk_mse takes any single-target walk and batch size.  One extra symbol,
- * `void drm_cpu_set_threads(int)`.  A host picks the library by where the caller's arrays live — the two never stand
+ * `drm_cpu_set_threads` (void, takes the thread count as an int).  A host picks the library by where the caller's arrays live — the two never stand
  * in for one another.
  *
  * The robot is handed over as a *walk*: the depth-first list of links a kernel
