@@ -511,6 +511,57 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
         return DRM_OK;
     }
     float *partials = scratch;
+    if (w->special[DRM_SPECIAL_RNEA_BACKWARD] && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)w->ops_f) & 15u) == 0) {
+        // a per-robot straight-line kernel built for exactly this walk (csrc/drm_static.hpp, specialize.py): full tiles on as many
+        // wavefronts as the device holds at once, any pointer alignment; the ragged tail through the loop kernel, its row of
+        // partial sums appended
+        hipFunction_t fn = (hipFunction_t)w->special[DRM_SPECIAL_RNEA_BACKWARD];
+        int n_tiles = (int)(B / WAVE), fl = (int)flags, grid = 0;
+        rc = resident_blocks_module(fn, WAVE, grid);
+        if (rc) return rc;
+        if (grid > BWD_MAX_WAVES) grid = BWD_MAX_WAVES;
+        if (grid > n_tiles) grid = n_tiles;
+        void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&qdd, (void *)&grad_tau, (void *)&n_tiles, (void *)&fl,
+                        (void *)&param_mask, (void *)&grad_q, (void *)&grad_qd, (void *)&grad_qdd, (void *)&partials};
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_backward_static): %s", hipGetErrorString(e));
+        int rows = grid;
+        const int64_t done = (int64_t)n_tiles * WAVE;
+        if (done < B) {
+            const size_t need = rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, false) * sizeof(float);
+            const bool park_tail = need > (size_t)MAX_LDS_BYTES; // (one wavefront's records behind the rows of partial sums)
+            Geometry gt;
+            rc = make_geometry(B - done, (int)rnea_backward_lds_floats(n, w->n_slots, cap, w->n_ops, n_leaves, park_tail), gt);
+            if (rc) return rc;
+            gt.grid = dim3(1);
+            gt.block = dim3(WAVE);
+            gt.lds_bytes = (size_t)gt.lds_per_wave * sizeof(float);
+            const uint32_t al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(grad_tau, AL_TAU);
+            float *park = partials + (int64_t)(rows + 1) * cap * DRM_OPF_STRIDE;
+#define DRM_LAUNCH_TAIL(HBM)                                                                                                     \
+    {                                                                                                                            \
+        rc = ensure_lds(rnea_backward_kernel<HBM>, gt.lds_bytes);                                                                \
+        if (rc) return rc;                                                                                                       \
+        hipLaunchKernelGGL((rnea_backward_kernel<HBM>), gt.grid, gt.block, gt.lds_bytes, s, w->ops_f, w->ops_i, cap, (int)w->n_ops, \
+                           n_leaves, n, (int)w->n_slots, (int)flags, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr,   \
+                           grad_tau + done * n, B - done, grad_q ? grad_q + done * n : nullptr,                                   \
+                           grad_qd ? grad_qd + done * n : nullptr, grad_qdd ? grad_qdd + done * n : nullptr, param_mask,           \
+                           partials + (int64_t)rows * cap * DRM_OPF_STRIDE, park, div_magic(n), gt.lds_per_wave,                   \
+                           al & ~(AL_POS | AL_QUAT | AL_LIN));                                                                    \
+    }
+            if (park_tail) DRM_LAUNCH_TAIL(true) else DRM_LAUNCH_TAIL(false)
+#undef DRM_LAUNCH_TAIL
+            rc = launched();
+            if (rc) return rc;
+            rows += 1;
+        }
+        if (grad_ops_f) {
+            hipLaunchKernelGGL(rnea_backward_reduce_kernel, dim3((unsigned)(cap * DRM_OPF_STRIDE / WAVE)), dim3(WAVE * REDUCE_WAVES), 0, s,
+                               partials, rows, cap, grad_ops_f);
+            rc = launched();
+        }
+        return rc;
+    }
 #ifndef DRM_NO_ARM_KERNEL
     {
         const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)qd | (uintptr_t)qdd | (uintptr_t)grad_tau | (uintptr_t)grad_q |

@@ -244,6 +244,177 @@ DRM_HD void aba_static_walk(ROW row, int flags, QF qf, FJ fj, OUT out, VPARK vpa
     }
 }
 
+// Reverse mode of the inverse dynamics of the whole tree (what torch autograd does for the reference when a loss on
+// compute_inverse_dynamics' torques is back-propagated, robot_model.py:305-375, 669-713): drm_sample.hpp rnea_backward_walk with
+// the tree as a compile-time constant — the same two sweeps (up: motions and force adjoints; down: the adjoints, every parent's
+// motion / tbar recovered from its child's, the sub-tree's total force travelling with the walk), the same per-link arithmetic
+// (rnea_link_adjoint_packed / rnea_link_adjoint / rnea_link_param_adjoint), nothing decoded.  What the loop walk parks per link
+// (cos, sin) stays in registers; what it keeps in branch-point slots (a branch point's motion and tbar on the way up, the motion
+// adjoints and forces its children hand it on the way down) are plain variables whose lifetimes the register allocator sees;
+// only the LEAVES' (motion, tbar), which must survive from one sweep to the other, go through the caller (LDS).
+//   qf(d, q, qd, qdd);  gtau(d) -> dL/dtau;  gout(d, gq, gqd, gqdd);  param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
+//   lpark / lunpark(leaf ordinal, Motion, tbar[3])
+template <class R, class ROW, class QF, class GT, class GOUT, class PG, class LPARK, class LUNPARK>
+DRM_HD void rnea_backward_static_walk(ROW row, int flags, uint64_t param_mask, bool want_gq, QF qf, GT gtau, GOUT gout, PG param_out,
+                                      LPARK lpark, LUNPARK lunpark) {
+    constexpr int N = R::N;
+    const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
+    const bool damping = flags & DRM_RNEA_DAMPING;
+    float cc[N], ss[N], qq[N];
+    // ---- up: motions and force adjoints -------------------------------------------------------------------------------------
+    {
+        Motion mot[N];
+        f2 Tb[N][3];
+        static_for<N>([&](auto K) {
+            constexpr int k = K, par = R::parent(k), dof = R::dof(k);
+            constexpr bool pris = R::prismatic(k);
+            DRM_RNEA_LINK_FENCE();
+            float wj = 0.0f, aj = 0.0f;
+            qq[k] = 0.0f; cc[k] = 1.0f; ss[k] = 0.0f;
+            if constexpr (dof >= 0) {
+                qf(dof, qq[k], wj, aj);
+                if constexpr (!pris) sincos_one(qq[k], ss[k], cc[k]);
+            }
+            const OpFT o = load_ft(row(k));
+            float J[9], t[3];
+            joint_transform(o, dof >= 0, pris, qq[k], cc[k], ss[k], J, t);
+            if constexpr (par < 0) {
+                Motion from;
+                motion_root(from, g);
+                motion_step(J, t, wj, aj, pris, from, mot[k]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) Tb[k][i] = f2_bcast(0.0f);
+            } else {
+                motion_step(J, t, wj, aj, pris, mot[par], mot[k]);
+                tbar_child(J, t, Tb[par], Tb[k]);
+            }
+            if constexpr (dof >= 0) Tb[k][2][pris ? 0 : 1] += gtau(dof); // tau = S^T f: angular z (revolute), linear z (prismatic)
+            if constexpr (R::leaf(k) >= 0) lpark(R::leaf(k), mot[k], Tb[k]);
+        });
+    }
+    // ---- down: adjoints, with the total forces formed on the way ------------------------------------------------------------
+    {
+        Motion Pm[N], pbn[N];  // op k's parent's motion as k recovered it; the motion adjoint k hands to its parent
+        f2 U[N][3];            // the parent's tbar, recovered
+        Force up[N];           // the total force of k's sub-tree in the parent's frame
+        static_for<N>([&](auto KR) {
+            constexpr int k = N - 1 - KR, par = R::parent(k), dof = R::dof(k);
+            constexpr bool pris = R::prismatic(k), has_parent = par >= 0;
+            constexpr bool chained = k + 1 < N && R::parent(k + 1 < N ? k + 1 : k) == k; // op k + 1 is a child of this link
+            DRM_RNEA_LINK_FENCE();
+            const float *of = row(k);
+            Motion M, B;
+            f2 T[3];
+            Force carry;
+            if constexpr (chained) { // continue from what the child recovered / handed up
+                M = Pm[k + 1]; B = pbn[k + 1]; carry = up[k + 1];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) T[i] = U[k + 1][i];
+            } else {                 // a leaf: its parked record, nothing below it
+                lunpark(R::leaf(k), M, T);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { B.wa[i] = B.va[i] = carry.la[i] = f2_bcast(0.0f); }
+            }
+            { // the children that do not follow this link directly, summed in the order the sweep met them (the loop walk's slot)
+                Motion sB;
+                Force sF;
+                bool any = false;
+                static_for<N>([&](auto CR) {
+                    constexpr int c = N - 1 - CR;
+                    if constexpr (c > k + 1 && R::parent(c) == k) {
+                        if (!any) {
+                            sB = pbn[c]; sF = up[c];
+                            any = true;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) { sB.wa[i] += pbn[c].wa[i]; sB.va[i] += pbn[c].va[i]; sF.la[i] += up[c].la[i]; }
+                        }
+                    }
+                });
+                if (any) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { B.wa[i] += sB.wa[i]; B.va[i] += sB.va[i]; carry.la[i] += sF.la[i]; }
+                }
+            }
+            float J[9], t[3], wj = 0.0f, aj = 0.0f, qdk = 0.0f;
+            {
+                const OpFT o = load_ft(of);
+                joint_transform(o, dof >= 0, pris, qq[k], cc[k], ss[k], J, t);
+            }
+            if constexpr (dof >= 0) { float qv; qf(dof, qv, wj, aj); qdk = wj; }
+            float gtk = 0.0f;
+            if constexpr (dof >= 0) gtk = gtau(dof);
+            if constexpr (has_parent) {
+                motion_parent(J, t, wj, aj, pris, M, Pm[k]);
+                f2 x[3] = {T[0], T[1], T[2]};
+                x[2][pris ? 0 : 1] -= gtk;
+                tbar_parent(J, t, x, U[k]);
+            } else {
+                motion_root(Pm[k], g);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) U[k][i] = f2_bcast(0.0f);
+            }
+            Force tot;
+            f2 hgl[3], hga[3];
+            rnea_body_force_hg(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, M, tot, hgl, hga);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.la[i] += carry.la[i];
+            const bool learn = (param_mask >> k) & 1u;
+            float gq, wjb, ajb;
+            auto tbar_to_floats = [](const f2 (&X)[3], float *v) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { v[i] = X[i][0]; v[3 + i] = X[i][1]; }
+            };
+            if constexpr (!pris) {
+                LinkAdjointP A;
+                rnea_link_adjoint_packed(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, M, hgl, hga, T, tot, has_parent, B, A);
+                gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+                pbn[k] = A.pb;
+                if (learn) {
+                    float gr[DRM_OPF_STRIDE], ub[6];
+                    tbar_to_floats(U[k], ub);
+                    rnea_link_param_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, cc[k], ss[k], M, Pm[k], T, ub, tot,
+                                            has_parent, B, A, gr);
+                    gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
+                    param_out(k, gr);
+                }
+            } else { // a sliding joint: the scalar form (its motion subspace differs)
+                float mo[12], mb[12], pr[12], fb[6], ub[6], tf[6];
+                motion_to_floats(M, mo); motion_to_floats(B, mb); motion_to_floats(Pm[k], pr);
+                tbar_to_floats(T, fb); tbar_to_floats(U[k], ub);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { tf[i] = tot.la[i][0]; tf[3 + i] = tot.la[i][1]; }
+                LinkAdjoint A;
+                rnea_link_adjoint(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, J, t, wj, mo, fb, pr, mb, ub, tf, has_parent, A, true, learn);
+                gq = A.gq; wjb = A.wjb; ajb = A.ajb;
+                motion_from_floats(A.pb, pbn[k]);
+                if (learn) { // J = F and t = trans + F e_z q
+                    float gr[DRM_OPF_STRIDE];
+#pragma unroll
+                    for (int i = 0; i < DRM_OPF_STRIDE; ++i) gr[i] = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        gr[DRM_OPF_FIJ(r, 0)] = A.Jb[r * 3 + 0];
+                        gr[DRM_OPF_FIJ(r, 1)] = A.Jb[r * 3 + 1];
+                        gr[DRM_OPF_FIJ(r, 2)] = A.Jb[r * 3 + 2] + A.tb[r] * qq[k];
+                        gr[DRM_OPF_TI(r)] = A.tb[r];
+                        gr[DRM_OPF_MCOM + r] = A.gmc[r];
+                    }
+                    gr[DRM_OPF_MASS] = A.gm;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) gr[DRM_OPF_IO + i] = A.gIo[i];
+                    gr[DRM_OPF_DAMP] = damping ? gtk * qdk : 0.0f;
+                    param_out(k, gr);
+                }
+            }
+            if constexpr (dof >= 0) {
+                if (want_gq) gout(dof, gq, wjb + (damping ? of[DRM_OPF_DAMP] * gtk : 0.0f), ajb);
+            }
+            if constexpr (has_parent) rnea_link_force_up(J, t, tot, up[k]); // the sub-tree's force in the parent's frame
+        });
+    }
+}
+
 } // namespace drm
 
 #ifdef __HIPCC__
@@ -392,6 +563,81 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
     for (int d = 0; d < n; ++d) trow[d] = acc[d];
     wave_lds_sync();
     tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, lv, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+}
+
+// Reverse-mode inverse dynamics of 64-row tiles: persistent wavefronts (one per block; the grid is what the device holds at
+// once), each with its own row of constant-gradient sums — tiles added in the wavefront's fixed order, the rows reduced by
+// rnea_backward_reduce_kernel afterwards, as for every backward kernel.  LDS: [ table : N x 32 ][ sums : CAP x 32 ]
+// [ leaf records : LEAVES x 18 x 64 ].  q / qd / qdd / grad_tau and the three gradients of a sample stay in its lane's registers
+// (n contiguous floats per lane and array on the way in and out, as in rnea_backward_arm_kernel).
+template <class R, int CAP>
+__device__ __forceinline__ void rnea_backward_static_body(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                          const float *__restrict__ qd, const float *__restrict__ qdd,
+                                                          const float *__restrict__ gtau, int n_tiles, int flags, uint64_t param_mask,
+                                                          float *__restrict__ gq, float *__restrict__ gqd, float *__restrict__ gqdd,
+                                                          float *__restrict__ partials) {
+    constexpr int N = R::N, n = R::NDOF, C_FLOATS = N * DRM_OPF_STRIDE, NV = CAP * DRM_OPF_STRIDE, LEAF = 18;
+    static_assert(CAP >= N, "the table's pitch covers the walk");
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + NV + R::LEAVES * LEAF * WAVE];
+    const unsigned lane = threadIdx.x;
+    float *lc = smem, *lacc = smem + C_FLOATS, *lleaf = lacc + NV + lane;
+    for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
+    wave_lds_sync();
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t r0 = ((int64_t)tile * WAVE + lane) * n;
+        float qv[n], qdv[n], qddv[n], gtv[n], gqv[n], gqdv[n], gqddv[n];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qv[d] = q[r0 + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qdv[d] = qd[r0 + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) qddv[d] = qdd ? qdd[r0 + d] : 0.0f;
+#pragma unroll
+        for (int d = 0; d < n; ++d) gtv[d] = gtau[r0 + d];
+#pragma unroll
+        for (int d = 0; d < n; ++d) gqv[d] = gqdv[d] = gqddv[d] = 0.0f;
+        rnea_backward_static_walk<R>(
+            [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags, param_mask, gq != nullptr,
+            [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; }, [&](int d) { return gtv[d]; },
+            [&](int d, float x, float v, float a) { gqv[d] = x; gqdv[d] = v; gqddv[d] = a; },
+            [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
+#pragma unroll
+                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
+                    const float total = wave_sum_lane63(g[j]);
+                    if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
+                }
+            },
+            [&](int leaf, const Motion &M, const f2 (&T)[3]) {
+                float *r = lleaf + leaf * (LEAF * WAVE);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    r[i * WAVE] = M.wa[i][0]; r[(3 + i) * WAVE] = M.wa[i][1]; r[(6 + i) * WAVE] = M.va[i][0]; r[(9 + i) * WAVE] = M.va[i][1];
+                    r[(12 + i) * WAVE] = T[i][0]; r[(15 + i) * WAVE] = T[i][1];
+                }
+            },
+            [&](int leaf, Motion &M, f2 (&T)[3]) {
+                const float *r = lleaf + leaf * (LEAF * WAVE);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    M.wa[i] = f2_make(r[i * WAVE], r[(3 + i) * WAVE]);
+                    M.va[i] = f2_make(r[(6 + i) * WAVE], r[(9 + i) * WAVE]);
+                    T[i] = f2_make(r[(12 + i) * WAVE], r[(15 + i) * WAVE]);
+                }
+            });
+        if (gq) {
+#pragma unroll
+            for (int d = 0; d < n; ++d) gq[r0 + d] = gqv[d];
+#pragma unroll
+            for (int d = 0; d < n; ++d) gqd[r0 + d] = gqdv[d];
+#pragma unroll
+            for (int d = 0; d < n; ++d) gqdd[r0 + d] = gqddv[d];
+        }
+    }
+    wave_lds_sync();
+    float *prow = partials + (int64_t)blockIdx.x * NV;
+    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
 } // namespace drm

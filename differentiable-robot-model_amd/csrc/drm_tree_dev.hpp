@@ -251,5 +251,24 @@ static int resident_blocks(K kernel, int threads, size_t lds, int &out) {
     out = it->second;
     return DRM_OK;
 }
+// the same for a kernel of a loaded code object (drm_walk.special[]: per-robot kernels, one wavefront per block, static LDS)
+static int resident_blocks_module(hipFunction_t fn, int threads, int &out) {
+    static std::mutex mu;
+    static std::map<std::tuple<const void *, int, int>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipGetDevice failed");
+    const auto key = std::make_tuple(reinterpret_cast<const void *>(fn), dev, threads);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int per_cu = 0, cus = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            return fail(DRM_ERR_LAUNCH, "occupancy query failed");
+        it = cache.emplace(key, per_cu * cus).first;
+    }
+    out = it->second;
+    return DRM_OK;
+}
 
 } // namespace drm

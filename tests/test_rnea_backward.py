@@ -144,8 +144,10 @@ def test_gpu_backward_vs_reference_autograd(case):
     check_gpu_backward_vs_reference_autograd(load_golden_dyn(), case)
 
 
-def check_gpu_backward_vs_reference_autograd(g, case, device="cuda"):
+def check_gpu_backward_vs_reference_autograd(g, case, device="cuda", prepare=None):
     m, params = learnable_model(g, case, device)
+    if prepare is not None:
+        prepare(m)
     q, qd, qdd = (torch.from_numpy(g["%s/%s" % (case, k)].copy()).to(device).requires_grad_(True) for k in ("q", "qd", "qdd"))
     want = torch.from_numpy(g[case + "/want"].copy()).to(device)
     tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)

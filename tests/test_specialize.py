@@ -16,6 +16,7 @@ from differentiable_robot_model_amd import specialize as sp
 from differentiable_robot_model_amd.flatten import build_walk
 from helpers import TOL_TAU, load_model, sample_states
 from oracle import Oracle
+from test_host_emu import emu  # noqa: F401  (fixture)
 from test_random_trees import tree_model
 
 needs_hipcc = pytest.mark.skipif(sp.hipcc() is None, reason="hipcc not on this machine")
@@ -52,11 +53,90 @@ def test_generated_source_builds_and_is_cached(tmp_path, monkeypatch):
     m = load_model("fetch", reference_compat=False)
     src = sp.source(sp.walk_tree(folded_walk(m)), m._n_dofs)
     assert "N = 14, NDOF = 14" in src and "drm_rnea_static" in src and "drm_crba_static" in src and "drm_fd_static" in src
+    assert "drm_rnea_backward_static" not in src                              # (the reverse-mode kernel needs the table's pitch)
+    assert "drm_rnea_backward_static" in sp.source(sp.walk_tree(folded_walk(m)), m._n_dofs, 16)
     path = sp.build(src)
     assert os.path.getsize(path) > 1000 and path.startswith(str(tmp_path))
     stamp = os.path.getmtime(path)
     assert sp.build(src) == path and os.path.getmtime(path) == stamp          # second call: the cache
     assert sp.build(src.replace("N = 14", "N = 14 ")) != path                  # another robot: another code object
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the walks themselves
+def host_harness(tmp_path, tree, n_dofs, cxx="g++"):
+    """The straight-line walks of csrc/drm_static.hpp instantiated on `tree` for the HOST (tests/host_emu/static_emu.hpp), from the
+    same `struct Robot` text the device code object is built from."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    cpp, lib = os.path.join(str(tmp_path), "static_host.cpp"), os.path.join(str(tmp_path), "libstatic_host.so")
+    with open(cpp, "w") as f:
+        f.write(sp.host_source(tree, n_dofs, os.path.join(here, "host_emu", "static_emu.hpp")))
+    subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-mfma", "-w", "-o", lib, cpp])
+    return ctypes.CDLL(lib)
+
+
+def _static_vs_loops(tmp_path, emu, m, seed):
+    import ctypes
+    from differentiable_robot_model_amd import backend
+    from test_host_emu import _ptr
+    dw = m._dynamics_walk()
+    prog, n = dw.program, m._n_dofs
+    tree = sp.walk_tree(prog)
+    from test_host_emu import ROCM_CLANG
+    st = host_harness(tmp_path, tree, n, ROCM_CLANG if "_clang" in emu._name else "g++")     # (the compiler the emulation was built with)
+    assert st.static_n_ops() == prog.n_ops
+    ops_f = m._ops_f(dw).detach().contiguous()
+    walk = backend._walk_struct_build(prog, ops_f, dw.ops_i, n)
+    of, B = ctypes.c_void_p(ops_f.data_ptr()), 9
+    q, qd, qdd = sample_states(m, B, seed=seed)
+    gtau = np.random.default_rng(seed).standard_normal((B, n)).astype(np.float32)
+    cb = ctypes.c_int64(B)
+    # reverse mode: the same arithmetic in the same order as the loop walk -> the same bits from g++; clang forms its fused
+    # multiply-adds per inlining context (as the device compiler does), so there the two agree to rounding
+    same_bits = "_clang" not in emu._name
+    mask = (1 << prog.n_ops) - 1 if prog.backward_ok else 0
+    if prog.backward_ok:
+        for flags, with_qdd in ((3, True), (0, True), (3, False)):
+            a = [np.full((B, n), np.nan, np.float32) for _ in range(3)] + [np.zeros((prog.capacity, 32), np.float32)]
+            b = [np.full((B, n), np.nan, np.float32) for _ in range(3)] + [np.zeros((prog.capacity, 32), np.float32)]
+            dd = _ptr(qdd) if with_qdd else None
+            assert emu.emu_rnea_backward(ctypes.byref(walk), _ptr(q), _ptr(qd), dd, cb, flags, _ptr(gtau), ctypes.c_uint64(mask),
+                                         *[_ptr(x) for x in a]) == 0
+            assert st.static_rnea_backward(of, prog.capacity, _ptr(q), _ptr(qd), dd, cb, flags, _ptr(gtau), ctypes.c_uint64(mask),
+                                           *[_ptr(x) for x in b]) == 0
+            for x, y, name in zip(a, b, ("grad_q", "grad_qd", "grad_qdd", "grad_ops_f")):
+                err = float(np.abs(x - y).max())
+                assert np.array_equal(x, y) if same_bits else err <= 2e-5 * max(1.0, float(np.abs(x).max())), (name, flags, with_qdd, err)
+            assert np.abs(a[3]).max() > 0 and np.isfinite(a[0]).all()
+    # forward walks: the loop forms to rounding
+    ta, tb = np.zeros((B, n), np.float32), np.zeros((B, n), np.float32)
+    assert emu.emu_rnea(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), cb, 3, _ptr(ta)) == 0
+    assert st.static_rnea(of, _ptr(q), _ptr(qd), _ptr(qdd), cb, 3, _ptr(tb)) == 0
+    assert np.allclose(ta, tb, **TOL_TAU)
+    Ha, Hb = np.zeros((B, n, n), np.float32), np.zeros((B, n, n), np.float32)
+    assert emu.emu_crba(ctypes.byref(walk), _ptr(q), cb, _ptr(Ha)) == 0 and st.static_crba(of, _ptr(q), cb, _ptr(Hb)) == 0
+    assert np.allclose(Ha, Hb, **TOL_TAU)
+    aa, ab = np.zeros((B, n), np.float32), np.zeros((B, n), np.float32)
+    assert emu.emu_forward_dynamics(ctypes.byref(walk), _ptr(q), _ptr(qd), _ptr(qdd), cb, 3, _ptr(aa)) == 0
+    assert st.static_fd(of, _ptr(q), _ptr(qd), _ptr(qdd), cb, 3, _ptr(ab)) == 0
+    assert float((np.abs(aa - ab) / (1.0 + np.abs(aa))).max()) < 1e-3
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_static_walks_of_fetch_on_the_host(tmp_path, emu, compat):
+    """Every straight-line walk of csrc/drm_static.hpp, instantiated on Fetch's tree and compiled for the host, against the loop
+    walks (csrc/drm_host_loops.hpp): reverse-mode inverse dynamics bit for bit (input gradients and the constant gradients of
+    every op), inverse dynamics / inertia matrix / forward dynamics to rounding."""
+    _static_vs_loops(tmp_path, emu, load_model("fetch", reference_compat=compat), 5)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 6])
+def test_static_walks_of_random_trees_on_the_host(tmp_path, emu, seed):
+    m = tree_model(tmp_path, seed)
+    if m._dynamics_walk().program.n_ops > sp.MAX_STATIC_OPS:
+        pytest.skip("more ops than the straight-line form is built for")
+    _static_vs_loops(tmp_path, emu, m, seed)
 
 
 @pytest.mark.gpu
@@ -131,6 +211,73 @@ def test_gpu_random_trees_through_their_own_kernels(tmp_path, seed):
     acc = m.compute_forward_dynamics(*(torch.from_numpy(a).cuda() for a in (q, qd, qdd)), include_gravity=True, use_damping=True)
     ref = Oracle(mc._spec).forward_dynamics(q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), True, True, np.float64)
     assert float((np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max()) < 1e-3, seed
+    # reverse mode through the tree's own kernel against the loop kernel (input gradients)
+    if m._dynamics_walk().program._special.get(sp.SPECIAL_RNEA_BACKWARD):
+        loop = tree_model(tmp_path, seed, "cuda")
+        grads = []
+        for mm in (loop, m):
+            xs = [torch.from_numpy(a).cuda().requires_grad_(True) for a in (q, qd, qdd)]
+            mm.compute_inverse_dynamics(*xs).pow(2).mean().backward()
+            grads.append([x.grad for x in xs])
+        for a, b in zip(*grads):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max())), seed
+
+
+def _specialized_backward(m):
+    assert m.specialize() is True
+    dw = m._dynamics_walk()
+    assert dw.program._special.get(sp.SPECIAL_RNEA_BACKWARD), "the walk carries its own reverse-mode kernel"
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_gpu_fetch_rnea_backward_through_its_own_kernel_vs_reference_autograd():
+    """Three full tiles of Fetch through drm_rnea_backward_static (every row by the per-robot kernel) against the gradients torch
+    autograd produced through the UNMODIFIED reference — input gradients and the gradients of the learnable link parameters
+    (tests/golden/golden_tiles_grad_dyn.npz); and the 7-19-row fixture, whose rows all take the ragged-tail path."""
+    import test_golden_tiles as tl
+    import test_rnea_backward as rbt
+    rbt.check_gpu_backward_vs_reference_autograd(tl.tiles("grad_dyn"), "fetch", prepare=_specialized_backward)
+    rbt.check_gpu_backward_vs_reference_autograd(rbt.load_golden_dyn(), "fetch", prepare=_specialized_backward)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("compat", [True, False])
+def test_gpu_fetch_rnea_backward_own_kernel_vs_loop_kernel(compat):
+    """Ragged batches, several learnable links (one of them sliding when the URDF's joint types are honoured), with and without
+    qdd / input gradients: the per-robot kernel against the loop kernel on the same walk."""
+    import test_rnea_backward as rbt
+    from differentiable_robot_model_amd import backend
+    mc = load_model("fetch", reference_compat=compat)
+    loop, own = load_model("fetch", "cuda", reference_compat=compat), load_model("fetch", "cuda", reference_compat=compat)
+    for m in (loop, own):
+        for link, pname in (("shoulder_lift_link", "mass"), ("shoulder_lift_link", "com"), ("torso_lift_link", "trans"),
+                            ("r_gripper_finger_link", "inertia_mat"), ("wrist_roll_link", "rot_angles"), ("head_tilt_link", "joint_damping")):
+            m.make_link_param_learnable(link, pname, rbt.parametrization(pname))
+    own.load_state_dict(loop.state_dict())
+    _specialized_backward(own)
+    for B in (64, 200, 2048 + 5):
+        q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(mc, B, seed=B))
+        want = torch.randn(B, own._n_dofs, device="cuda", generator=torch.Generator("cuda").manual_seed(B))
+        grads = []
+        for m in (loop, own):
+            m.zero_grad()
+            xs = [t.clone().requires_grad_(True) for t in (q, qd, qdd)]
+            torch.nn.functional.mse_loss(m.compute_inverse_dynamics(*xs), want).backward()
+            grads.append([x.grad for x in xs] + [p.grad.clone() for p in m.parameters()])
+        for a, b in zip(*grads):
+            scale = max(1e-6, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-4 * scale, (B, float((a - b).abs().max()), scale)
+    # parameter gradients only (no graph to q), and without qdd (the non-linear effects)
+    q, qd, _ = (torch.from_numpy(a).cuda() for a in sample_states(mc, 130, seed=1))
+    outs = []
+    for m in (loop, own):
+        m.zero_grad()
+        m.compute_non_linear_effects(q, qd).pow(2).mean().backward()
+        outs.append([p.grad.clone() for p in m.parameters()])
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max()))
 
 
 def test_robots_with_a_compiled_shape_keep_it():

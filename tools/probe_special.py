@@ -27,3 +27,16 @@ for robot in sys.argv[1:] or ["fetch"]:
         print("%-10s B=%8d  forward dynamics: loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx)" % (robot, B, fa, fb, fa / fb))
         print("%-10s B=%8d  mass matrix:      loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
               % (robot, B, a, b, a / b, B * 4 * (n + n * n) / b / 1e3, 4 * (n + n * n)))
+        from differentiable_robot_model_amd import backend
+        gt = torch.randn(B, n, device="cuda")
+        times = []
+        for m in (loop, own):
+            dw = m._dynamics_walk()
+            ops_f = m._ops_f(dw)
+            for mask, want_q in ((0, True), (1 << 5, True)):
+                times.append(graph_time(lambda: backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, gt, True, True, n, mask, want_q),
+                                        launches=10, reps=5))
+        print("%-10s B=%8d  inverse dynamics, reverse mode (input gradients): loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx, %.0f GB/s of %d B/eval)"
+              % (robot, B, times[0], times[2], times[0] / times[2], B * 28 * n / times[2] / 1e3, 28 * n))
+        print("%-10s B=%8d  ... + the constants of one learnable link:        loop kernels %8.2f us   own straight-line kernel %8.2f us  (%.2fx)"
+              % (robot, B, times[1], times[3], times[1] / times[3]))
