@@ -508,19 +508,20 @@ __device__ __forceinline__ void crba_static_body(const float *__restrict__ ops_f
     }
 }
 
-// Forward dynamics of a 64-row tile.  LDS: [ table ][ velocities : N x 6 x 64 ][ records : N x 8 x 64 ] — the qdd tile is staged
-// over the velocity area once sweep 2 is done with it.
+// Forward dynamics of a 64-row tile.  LDS: [ table ][ per-op slots : N x 8 x 64 ] — a slot first holds the op's velocity (6 floats,
+// sweep 1 -> 2) and, once sweep 2 has read it, the op's joint record (8 floats, sweep 2 -> 3) in its place; the qdd tile is staged
+// over the slots when sweep 3 is done with them.  (Velocities and records side by side took 52 KB for Fetch: three wavefronts per CU.)
 template <class R>
 __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                                                 const float *__restrict__ f, int n_tiles, int flags, float *__restrict__ qdd,
                                                 uint32_t magic_n, uint32_t align) {
     constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE;
-    constexpr int V_FLOATS = N * 6 * WAVE > round4(WAVE * Sq) ? N * 6 * WAVE : round4(WAVE * Sq), R_FLOATS = N * 8 * WAVE;
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + V_FLOATS + R_FLOATS];
+    constexpr int S_FLOATS = N * 8 * WAVE > round4(WAVE * Sq) ? N * 8 * WAVE : round4(WAVE * Sq);
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + S_FLOATS];
     const unsigned lane = threadIdx.x;
     const int tile = (int)blockIdx.x;
     if (tile >= n_tiles) return;
-    float *lc = smem, *lv = smem + C_FLOATS, *lr = lv + V_FLOATS;
+    float *lc = smem, *ls = smem + C_FLOATS;
     const int64_t b0 = (int64_t)tile * WAVE;
     for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
     float qv[n], qdv[n], fv[n];
@@ -540,29 +541,29 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
                        [&](int d, float v) { acc[d] = v; },
                        [&](int k, const Motion &M) {
 #pragma unroll
-                           for (int i = 0; i < 3; ++i) { lv[((k * 6 + i) * WAVE) + lane] = M.wa[i][0]; lv[((k * 6 + 3 + i) * WAVE) + lane] = M.va[i][0]; }
+                           for (int i = 0; i < 3; ++i) { ls[((k * 8 + i) * WAVE) + lane] = M.wa[i][0]; ls[((k * 8 + 3 + i) * WAVE) + lane] = M.va[i][0]; }
                        },
                        [&](int k, Motion &M) {
 #pragma unroll
                            for (int i = 0; i < 3; ++i) {
-                               M.wa[i] = f2_make(lv[((k * 6 + i) * WAVE) + lane], 0.0f);
-                               M.va[i] = f2_make(lv[((k * 6 + 3 + i) * WAVE) + lane], 0.0f);
+                               M.wa[i] = f2_make(ls[((k * 8 + i) * WAVE) + lane], 0.0f);
+                               M.va[i] = f2_make(ls[((k * 8 + 3 + i) * WAVE) + lane], 0.0f);
                            }
                        },
-                       [&](int k, const float *rec) {
+                       [&](int k, const float *rec) { // (op k's velocity has been read: sweep 2 unparks it before it eliminates the joint)
 #pragma unroll
-                           for (int i = 0; i < 8; ++i) lr[((k * 8 + i) * WAVE) + lane] = rec[i];
+                           for (int i = 0; i < 8; ++i) ls[((k * 8 + i) * WAVE) + lane] = rec[i];
                        },
                        [&](int k, float *rec) {
 #pragma unroll
-                           for (int i = 0; i < 8; ++i) rec[i] = lr[((k * 8 + i) * WAVE) + lane];
+                           for (int i = 0; i < 8; ++i) rec[i] = ls[((k * 8 + i) * WAVE) + lane];
                        });
-    wave_lds_sync(); // (the velocity area is free: sweep 2 has read it all)
-    float *trow = lv + lane * Sq;
+    wave_lds_sync(); // (the slots are free: sweep 3 has read every record)
+    float *trow = ls + lane * Sq;
 #pragma unroll
     for (int d = 0; d < n; ++d) trow[d] = acc[d];
     wave_lds_sync();
-    tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, lv, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+    tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, ls, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
 }
 
 // Reverse-mode inverse dynamics of 64-row tiles: persistent wavefronts (one per block; the grid is what the device holds at

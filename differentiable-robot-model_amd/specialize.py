@@ -141,7 +141,7 @@ def source(tree: Dict[str, list], n_dofs: int, capacity: int = 0) -> str:
     drm::rnea_backward_static_body<drm::Robot, %d>(ops_f, q, qd, qdd, gtau, n_tiles, flags, param_mask, gq, gqd, gqdd, partials);
 }
 """ % capacity
-    return """// generated by differentiable-robot-model_amd/specialize.py — one robot's whole-tree dynamics walk as compile-time constants
+    text = """// generated by differentiable-robot-model_amd/specialize.py — one robot's whole-tree dynamics walk as compile-time constants
 #include "drm_static.hpp"
 %s__device__ const int drm_slot_of[] = DRM_SLOT_OF_INIT;
 extern "C" __global__ void __launch_bounds__(64) drm_rnea_static(const float *ops_f, const float *q, const float *qd, const float *qdd,
@@ -156,6 +156,12 @@ extern "C" __global__ void __launch_bounds__(64) drm_fd_static(const float *ops_
     drm::aba_static_body<drm::Robot>(ops_f, q, qd, f, n_tiles, flags, qdd, magic_n, align);
 }
 %s""" % (robot_struct(tree, n_dofs), backward)
+    waves = os.environ.get("DRM_STATIC_WAVES")          # (experiments: force N wavefronts per SIMD on the forward kernels)
+    if waves:
+        for name in ("drm_rnea_static", "drm_fd_static"):
+            text = text.replace("__launch_bounds__(64) %s(" % name,
+                                "__launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%s, %s))) %s(" % (waves, waves, name))
+    return text
 
 
 def host_source(tree: Dict[str, list], n_dofs: int, harness: str) -> str:
