@@ -277,19 +277,29 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._walks[key] = dw
         return dw
 
-    def specialize(self) -> bool:
+    def specialize(self, force: bool = False, tune: bool = False):
         """Build (hipcc, ~3 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics, the inertia
         matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the shapes the library ships
         straight-line kernels for (a mobile manipulator such as Fetch) the loop-structured kernels stop being the only choice
         (Fetch at 2^20 rows: 226 -> 125 us, 630 -> 170 us, 600 -> 331 us).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
         attached, False when the robot already runs a compiled straight-line kernel (7-DoF arms, arm + hand, hands).  Models with
-        learnable link parameters specialise their full walk as well (the kernel reads the same table)."""
+        learnable link parameters specialise their full walk as well (the kernel reads the same table).  `force`: build the
+        robot's own kernels even when the library has a straight-line kernel for its shape (measurements, tools/probe_special.py).
+        `tune`: build them for ANY robot that is not a plain 7-DoF arm, time every entry point both ways on this device and keep the
+        faster of the two per entry point (specialize.tune; returns its report): the library's kernels for "an arm that carries a
+        hand" are generic in (P, K, L), a small robot's own walk can beat them (Panda with gripper: inertia matrix 133 -> 86 us,
+        forward dynamics 167 -> 125, inverse dynamics 70 -> 58, its reverse mode 197 -> 149 at 2^20 rows)."""
         from . import specialize as sp
         if self._device.type != "cuda":
             raise RuntimeError("per-robot kernels are HIP code objects: the model must live on a HIP device (it is on %s)" % self._device)
         dw = self._dynamics_walk()
         from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
-        if dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
+        if tune:
+            if dw.program.shape & SHAPE_ARM_CHAIN or dw.program.n_ops > sp.MAX_STATIC_OPS:
+                return {}
+            sp.attach(dw.program, self._spec, self._n_dofs)
+            return sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+        if not force and dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
             return False
         sp.attach(dw.program, self._spec, self._n_dofs)
         return True
@@ -316,17 +326,22 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw = self._get_walk(("tree",), whole_tree=True)
         else:
             dw = self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
-        if os.environ.get("DRM_SPECIALIZE") == "1" and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
+        mode = os.environ.get("DRM_SPECIALIZE")
+        if mode in ("1", "tune") and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
             # opt-in through the environment: every robot without a compiled straight-line shape builds its own kernels on first
-            # use (specialize.py; ~2 s once per robot and machine); a machine without hipcc keeps the loop kernels
+            # use (specialize.py; ~2 s once per robot and machine); a machine without hipcc keeps the loop kernels.  "tune": robots
+            # WITH a compiled shape (other than plain 7-DoF arms) build theirs too and keep, per entry point, the faster of the two
             dw.program._special_tried = True
             from . import specialize as sp
             from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
-            if not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
-                try:
+            try:
+                if not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
                     sp.attach(dw.program, self._spec, self._n_dofs)
-                except sp.SpecializeError:
-                    pass
+                elif mode == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN and dw.program.n_ops <= sp.MAX_STATIC_OPS:
+                    sp.attach(dw.program, self._spec, self._n_dofs)
+                    sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+            except sp.SpecializeError:
+                pass
         if not self._learnable:
             self._dyn_walk = dw
         return dw

@@ -230,3 +230,59 @@ def attach(prog: WalkProgram, spec, n_dofs: int) -> Dict[int, int]:
     prog._special = handles
     prog._ws_cache = None          # (the cached drm_walk predates the handles)
     return handles
+
+
+def tune(prog: WalkProgram, ops_f, ops_i, n_dofs: int, batch: int = 1 << 19, margin: float = 0.97) -> Dict[str, dict]:
+    """Keep, per entry point, whichever is FASTER on this device: the robot's own straight-line kernel (attached by `attach`) or
+    what the library would run without it (a shape-specialised kernel: an arm that carries a hand, the fingers of a hand — or
+    the loop kernels).  Each entry point is timed both ways on `batch` random rows (HIP events around 10 eager launches, best of 3;
+    the batch is large enough that a launch outlasts the ~13 us of host time an eager call costs, so the device is what is timed);
+    a handle stays when its kernel takes < `margin` of the library's time.  Returns {kernel: {"own_us", "library_us", "kept"}}.
+    Measured on an MI355X at 2^20 rows (profiles/r04_probe_special.txt): Panda with gripper keeps all four (inertia matrix 133 -> 86
+    us), Jaco the inertia matrix and the reverse mode, a hand (Allegro) and an arm carrying one (iiwa7 + Allegro) none."""
+    import torch
+    from . import backend
+    handles = dict(getattr(prog, "_special", None) or {})
+    if not handles:
+        return {}
+    dev = ops_f.device
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q, qd, x = ((torch.rand(batch, n_dofs, generator=g) - 0.5).to(dev) for _ in range(3))
+    calls = {
+        SPECIAL_RNEA: lambda: backend.rnea(prog, ops_f, ops_i, q, qd, x, True, True, n_dofs),
+        SPECIAL_CRBA: lambda: backend.crba(prog, ops_f, ops_i, q, n_dofs),
+        SPECIAL_FD: lambda: backend.forward_dynamics(prog, ops_f, ops_i, q, qd, x, True, True, n_dofs),
+        SPECIAL_RNEA_BACKWARD: lambda: backend.rnea_backward(prog, ops_f, ops_i, q, qd, x, x, True, True, n_dofs, 0, True),
+    }
+
+    def timed(fn):
+        best = float("inf")
+        fn()
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                fn()
+            b.record()
+            b.synchronize()
+            best = min(best, a.elapsed_time(b) * 100.0)      # us per launch
+        return best
+
+    def with_handles(h):
+        prog._special = h
+        prog._ws_cache = None
+
+    report, kept = {}, {}
+    try:
+        for kind, handle in handles.items():
+            with_handles({kind: handle})
+            own = timed(calls[kind])
+            with_handles({})
+            lib = timed(calls[kind])
+            keep = own < margin * lib
+            report[KERNELS[kind]] = {"own_us": round(own, 2), "library_us": round(lib, 2), "kept": bool(keep)}
+            if keep:
+                kept[kind] = handle
+    finally:
+        with_handles(kept)
+    return report

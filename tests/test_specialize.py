@@ -280,6 +280,39 @@ def test_gpu_fetch_rnea_backward_own_kernel_vs_loop_kernel(compat):
         assert float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max()))
 
 
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("robot", ["panda", "jaco"])
+def test_gpu_tuned_choice_between_shape_kernels_and_own_kernels(robot):
+    """specialize(tune=True): an arm that carries a hand builds its own kernels too and keeps, per entry point, whichever is faster
+    on this device; whatever was kept, every entry point still meets the fp64 oracle and the untuned model."""
+    mc, plain, tuned = load_model(robot), load_model(robot, "cuda"), load_model(robot, "cuda")
+    report = tuned.specialize(tune=True)
+    assert set(report) == set(sp.KERNELS.values())
+    kept = tuned._dynamics_walk().program._special
+    for kind, name in sp.KERNELS.items():
+        assert report[name]["kept"] == (kind in kept) and report[name]["own_us"] > 0 and report[name]["library_us"] > 0
+        if report[name]["kept"]:
+            assert report[name]["own_us"] < report[name]["library_us"]
+    orc = Oracle(mc._spec)
+    B = 64 * 5 + 9
+    q, qd, qdd = sample_states(mc, B, seed=11)
+    dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in (q, qd, qdd))
+    f64 = lambda a: a.astype(np.float64)
+    assert np.allclose(tuned.compute_inverse_dynamics(dq, dqd, dqdd).cpu().numpy(), orc.rnea(f64(q), f64(qd), f64(qdd), True, True, np.float64), **TOL_TAU)
+    assert np.allclose(tuned.compute_lagrangian_inertia_matrix(dq).cpu().numpy(), orc.mass_matrix(f64(q), False, False, np.float64), **TOL_TAU)
+    ref = orc.forward_dynamics(f64(q), f64(qd), f64(qdd), True, True, np.float64)
+    assert float((np.abs(tuned.compute_forward_dynamics(dq, dqd, dqdd).cpu().numpy() - ref) / (1.0 + np.abs(ref))).max()) < 1e-3
+    grads = []
+    for m in (plain, tuned):
+        xs = [t.clone().requires_grad_(True) for t in (dq, dqd, dqdd)]
+        m.compute_inverse_dynamics(*xs).pow(2).mean().backward()
+        grads.append([x.grad for x in xs])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max()))
+    assert load_model("panda_no_gripper", "cuda").specialize(tune=True) == {}       # (plain 7-DoF arms keep their kernels)
+
+
 def test_robots_with_a_compiled_shape_keep_it():
     """(CPU) specialize() is for trees the library has no straight-line kernel for; it needs a device model."""
     m = load_model("panda_no_gripper")

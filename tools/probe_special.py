@@ -8,10 +8,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gpu_probe import load, sample
 from ab_rnea import graph_time
 
-for robot in sys.argv[1:] or ["fetch"]:
+FORCE = "--force" in sys.argv       # robots with a compiled shape: their shape's kernels ("loop kernels" column) against their own
+for robot in [a for a in sys.argv[1:] if not a.startswith("--")] or ["fetch"]:
     loop, own = load(robot), load(robot)
     t0 = time.perf_counter()
-    took = own.specialize()
+    took = own.specialize(force=FORCE)
     print("%s: specialize() -> %s in %.2f s" % (robot, took, time.perf_counter() - t0))
     for B in (65536, 1 << 20):
         q, qd, qdd = (t.cuda() for t in sample(loop, B))
