@@ -213,7 +213,11 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
         int n_tiles = (int)(B / WAVE), fl = (int)flags;
         uint32_t magic = div_magic(n), al = align;
         void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&qdd, (void *)&n_tiles, (void *)&fl, (void *)&tau, (void *)&magic, (void *)&al};
-        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+        int grid = 0; // persistent wavefronts: what the device holds at once (each reads its next tile's rows while it walks one)
+        rc = resident_blocks_module((hipFunction_t)w->special[DRM_SPECIAL_RNEA], WAVE, grid);
+        if (rc) return rc;
+        if (grid > n_tiles) grid = n_tiles;
+        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA], (unsigned)grid, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_static): %s", hipGetErrorString(e));
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return DRM_OK;

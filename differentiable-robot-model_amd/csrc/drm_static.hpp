@@ -35,18 +35,27 @@ DRM_HD void static_for(F &&f) {
 // Inverse dynamics of the whole tree (robot_model.py:250-375), R = the robot's walk:
 //   R::N ops in parent-before-child order, R::parent(k) (op index, -1 = the root link), R::dof(k) (column, -1 = fixed),
 //   R::prismatic(k);   row(k) -> op k's constant row;   qf(d, q, qd, qdd);   tau_out(d, tau)
-template <class R, class ROW, class QF, class TAU>
+//   PREF: the constants of the NEXT op are read (broadcast LDS reads) into a second register set before the arithmetic of the
+//   current one, as in the arm kernels (drm_sample.hpp rnea_chain_trig): the kernels run one wavefront per SIMD, nothing else
+//   hides the reads' latency
+template <class R, bool PREF = false, class ROW, class QF, class TAU>
 DRM_HD void rnea_static_walk(ROW row, int flags, QF qf, TAU tau_out) {
     constexpr int N = R::N;
     const float g = (flags & DRM_RNEA_GRAVITY) ? 9.81f : 0.0f;
     Motion mot[N];
     Force frc[N];
     float cc[N], ss[N], qq[N], qdv[N];
+    float buf[2][PREF ? RNEA_ROW_FLOATS : 1];
+    if constexpr (PREF) rnea_row_copy(row(0), buf[0]);
     static_for<N>([&](auto K) {
         constexpr int k = K, par = R::parent(k), dof = R::dof(k);
         constexpr bool pris = R::prismatic(k);
         DRM_RNEA_LINK_FENCE(); // (keeps the constant reads of later ops from being hoisted over this one: register pressure)
-        const float *of = row(k);
+        if constexpr (PREF) {
+            if constexpr (k + 1 < N) rnea_row_copy(row(k + 1), buf[(k + 1) & 1]);
+            DRM_RNEA_LINK_FENCE();
+        }
+        const float *of = PREF ? buf[k & 1] : row(k);
         float wj = 0.0f, aj = 0.0f;
         qq[k] = 0.0f; cc[k] = 1.0f; ss[k] = 0.0f; qdv[k] = 0.0f;
         if constexpr (dof >= 0) {
@@ -63,14 +72,26 @@ DRM_HD void rnea_static_walk(ROW row, int flags, QF qf, TAU tau_out) {
         motion_step(J, t, wj, aj, pris, from, mot[k]);
         rnea_body_force(of[DRM_OPF_MASS], of + DRM_OPF_MCOM, of + DRM_OPF_IO, mot[k], frc[k]);
     });
+    float back[2][PREF ? DRM_OPF_FT_FLOATS : 1], damp2[2];
+    if constexpr (PREF) {
+        rnea_row_copy(row(N - 1), back[(N - 1) & 1]);
+        damp2[(N - 1) & 1] = row(N - 1)[DRM_OPF_DAMP];
+    }
     static_for<N>([&](auto K) {
         constexpr int k = N - 1 - K, par = R::parent(k), dof = R::dof(k);
         constexpr bool pris = R::prismatic(k);
         DRM_RNEA_LINK_FENCE();
-        const float *of = row(k);
+        if constexpr (PREF) {
+            if constexpr (k > 0) {
+                rnea_row_copy(row(k - 1), back[(k - 1) & 1]);
+                damp2[(k - 1) & 1] = row(k - 1)[DRM_OPF_DAMP];
+            }
+            DRM_RNEA_LINK_FENCE();
+        }
+        const float *of = PREF ? back[k & 1] : row(k);
         if constexpr (dof >= 0) {
             float tau = pris ? frc[k].la[2][0] : frc[k].la[2][1];
-            if (flags & DRM_RNEA_DAMPING) tau += of[DRM_OPF_DAMP] * qdv[k];
+            if (flags & DRM_RNEA_DAMPING) tau += (PREF ? damp2[k & 1] : of[DRM_OPF_DAMP]) * qdv[k];
             tau_out(dof, tau);
         }
         if constexpr (par >= 0) {
@@ -422,26 +443,48 @@ namespace drm {
 
 // One wavefront per 64-row tile (full tiles; the C ABI sends a ragged tail to the loop kernels).  LDS: [ table : N x 32 ]
 // [ tau tile : 64 x (n | 1) ].  Every lane reads its own rows of q / qd / qdd straight into registers (n contiguous floats each).
+// rows of the NEXT tile straight from global memory into LDS (global_load_lds_dword: no registers in between), element d of the
+// lanes' rows at stage[d][lane]; read back with rows_from_stage once the loads have landed (s_waitcnt vmcnt).
+// `tile_base`: the tile's first row (wave-uniform), `lane_bytes` = lane * n * 4.  Inline assembly, not
+// __builtin_amdgcn_global_load_lds: under this kernel's register pressure (256 VGPR + 256 AGPR) the compiler hands the builtin's
+// address operand an AGPR and then rejects its own instruction ("Operand has incorrect register class", ROCm 7.2).
+template <int n, int d = 0>
+__device__ __forceinline__ void rows_to_stage(const float *__restrict__ tile_base, uint32_t lane_bytes, float *stage) {
+    if constexpr (d < n) {
+        const uint32_t lds = (uint32_t)(uintptr_t)(stage + d * WAVE); // (the low half of a generic LDS pointer is the LDS address)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1 offset:%3" ::"v"(lane_bytes), "s"(tile_base), "s"(lds), "n"(d * 4)
+                     : "memory", "m0");
+        rows_to_stage<n, d + 1>(tile_base, lane_bytes, stage);
+    }
+}
+template <int n>
+__device__ __forceinline__ void rows_from_stage(const float *stage, unsigned lane, float (&v)[n]) {
+#pragma unroll
+    for (int d = 0; d < n; ++d) v[d] = stage[d * WAVE + lane];
+}
+
 template <class R>
 __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ qd,
                                                  const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
                                                  uint32_t magic_n, uint32_t align) {
-    constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE;
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + round4(WAVE * Sq)];
+    constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE, T_FLOATS = round4(WAVE * Sq);
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + T_FLOATS + 3 * n * WAVE];
     const unsigned lane = threadIdx.x;
-    const int tile = (int)blockIdx.x;
-    if (tile >= n_tiles) return;
-    float *lc = smem, *lt = smem + C_FLOATS;
-    const int64_t b0 = (int64_t)tile * WAVE;
+    if ((int)blockIdx.x >= n_tiles) return;
+    float *lc = smem, *lt = smem + C_FLOATS, *stage = lt + T_FLOATS;
     float4 cv[(C_FLOATS / 4 + WAVE - 1) / WAVE];
 #pragma unroll
     for (int it = 0; it < (C_FLOATS / 4 + WAVE - 1) / WAVE; ++it) {
         const int i = (int)lane + it * WAVE;
         cv[it] = reinterpret_cast<const float4 *>(ops_f)[i < C_FLOATS / 4 ? i : C_FLOATS / 4 - 1];
     }
+    // The grid is what the device holds at once (or one block per tile when that is fewer): a wavefront walks tiles blockIdx.x,
+    // + gridDim.x, ... and, before it walks one, starts the NEXT tile's rows on their way from global memory into an LDS staging
+    // area — with one wavefront per SIMD nothing else would overlap a tile's loads with arithmetic, and the register file
+    // (256 VGPR + up to 256 AGPR here) has no room for a second set of inputs.
     float qv[n], qdv[n], qddv[n];
     {
-        const int64_t row = (b0 + lane) * n;
+        const int64_t row = ((int64_t)blockIdx.x * WAVE + lane) * n;
 #pragma unroll
         for (int d = 0; d < n; ++d) qv[d] = q[row + d];
 #pragma unroll
@@ -454,13 +497,33 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
         const int i = (int)lane + it * WAVE;
         if (i < C_FLOATS / 4) reinterpret_cast<float4 *>(lc)[i] = cv[it];
     }
-    wave_lds_sync();
     float *trow = lt + lane * Sq;
-    rnea_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
-                        [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; },
-                        [&](int d, float v) { trow[d] = v; });
-    wave_lds_sync();
-    tile_store<0>(tau + b0 * n, WAVE, n, magic_n, lt, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+#ifndef DRM_STATIC_PREF
+#define DRM_STATIC_PREF 1
+#endif
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int next = tile + (int)gridDim.x;
+        wave_lds_sync(); // (the table is in LDS; the previous tile's staged torques and next rows have been read)
+        if (next < n_tiles) {
+            const int64_t base = (int64_t)next * WAVE * n;
+            const uint32_t off = lane * (uint32_t)(n * sizeof(float));
+            rows_to_stage<n>(q + base, off, stage);
+            rows_to_stage<n>(qd + base, off, stage + n * WAVE);
+            if (qdd) rows_to_stage<n>(qdd + base, off, stage + 2 * n * WAVE);
+        }
+        rnea_static_walk<R, DRM_STATIC_PREF != 0>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+                                                  [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; },
+                                                  [&](int d, float v) { trow[d] = v; });
+        __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago: nothing to wait for in practice)
+        wave_lds_sync();
+        if (next < n_tiles) {
+            rows_from_stage<n>(stage, lane, qv);
+            rows_from_stage<n>(stage + n * WAVE, lane, qdv);
+            if (qdd) rows_from_stage<n>(stage + 2 * n * WAVE, lane, qddv);
+        }
+        tile_store<0>(tau + (int64_t)tile * WAVE * n, WAVE, n, magic_n, lt, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+    }
 }
 
 

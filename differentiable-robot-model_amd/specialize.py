@@ -185,7 +185,8 @@ def hipcc() -> Optional[str]:
 
 def build(src: str) -> str:
     """Path of the code object of `src` (compiled once per content + header hash)."""
-    h = hashlib.sha256(src.encode())
+    extra = os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
+    h = hashlib.sha256((src + " ".join(extra)).encode())
     for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -200,7 +201,7 @@ def build(src: str) -> str:
     with open(cpp, "w") as f:
         f.write(src)
     cmd = [cc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-w",
-           "-I", CSRC, "-o", out + ".tmp", cpp]
+           "-I", CSRC, "-o", out + ".tmp", cpp] + extra
     done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     if done.returncode != 0 or not os.path.exists(out + ".tmp"):
         raise SpecializeError("hipcc failed on the robot's kernels:\n%s" % done.stderr.decode()[-2000:])
