@@ -278,10 +278,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         return dw
 
     def specialize(self, force: bool = False, tune: bool = False):
-        """Build (hipcc, ~3 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics, the inertia
-        matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the shapes the library ships
-        straight-line kernels for (a mobile manipulator such as Fetch) the loop-structured kernels stop being the only choice
-        (Fetch at 2^20 rows: 226 -> 125 us, 630 -> 170 us, 600 -> 331 us).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
+        """Build (hipcc, 3-7 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics and its
+        reverse mode, the inertia matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the
+        shapes the library ships straight-line kernels for (a mobile manipulator such as Fetch) the loop-structured kernels stop being
+        the only choice (Fetch at 2^20 rows: 226 -> 104 us, 966 -> 260 us, 650 -> 172 us, 600 -> 244 us).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
         attached, False when the robot already runs a compiled straight-line kernel (7-DoF arms, arm + hand, hands).  Models with
         learnable link parameters specialise their full walk as well (the kernel reads the same table).  `force`: build the
         robot's own kernels even when the library has a straight-line kernel for its shape (measurements, tools/probe_special.py).
