@@ -422,7 +422,11 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         int n_tiles = (int)(B / WAVE), fl = (int)flags;
         uint32_t magic = div_magic(n), al = al16(q, AL_Q) | al16(qd, AL_QD) | al16(f, AL_QDD) | al16(qdd, AL_TAU);
         void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&f, (void *)&n_tiles, (void *)&fl, (void *)&qdd, (void *)&magic, (void *)&al};
-        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+        int grid = 0; // persistent wavefronts: what the device holds at once
+        int rcg = resident_blocks_module((hipFunction_t)w->special[DRM_SPECIAL_FD], WAVE, grid);
+        if (rcg) return rcg;
+        if (grid > n_tiles) grid = n_tiles;
+        hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD], (unsigned)grid, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fd_static): %s", hipGetErrorString(e));
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return DRM_OK;

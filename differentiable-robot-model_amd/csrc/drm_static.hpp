@@ -457,6 +457,12 @@ __device__ __forceinline__ void rows_to_stage(const float *__restrict__ tile_bas
         rows_to_stage<n, d + 1>(tile_base, lane_bytes, stage);
     }
 }
+// how many of a kernel's input arrays (n floats per row) to stage for the next tile: `all` of them while four wavefronts' worth of
+// LDS (a CU's 160 KB) still holds the kernel's other `base_floats` four times, else `fewer`, else none
+constexpr int staged_arrays(int base_floats, int n, int all, int fewer) {
+    constexpr int BUDGET = 160 * 1024 / 4 / 4; // floats per wavefront at four wavefronts per CU
+    return base_floats + all * n * WAVE + 4 <= BUDGET ? all : (base_floats + fewer * n * WAVE + 4 <= BUDGET ? fewer : 0);
+}
 template <int n>
 __device__ __forceinline__ void rows_from_stage(const float *stage, unsigned lane, float (&v)[n]) {
 #pragma unroll
@@ -580,16 +586,18 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
                                                 uint32_t magic_n, uint32_t align) {
     constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE;
     constexpr int S_FLOATS = N * 8 * WAVE > round4(WAVE * Sq) ? N * 8 * WAVE : round4(WAVE * Sq);
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + S_FLOATS];
+    // arrays of the next tile that are staged in LDS: all three while four wavefronts still fit a CU's LDS, else f is read at the
+    // top of its own tile (the walk needs it in sweep 2 only), else nothing is staged
+    constexpr int STAGED = staged_arrays(C_FLOATS + S_FLOATS, n, 3, 2);
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + S_FLOATS + STAGED * n * WAVE + 4];
     const unsigned lane = threadIdx.x;
-    const int tile = (int)blockIdx.x;
-    if (tile >= n_tiles) return;
-    float *lc = smem, *ls = smem + C_FLOATS;
-    const int64_t b0 = (int64_t)tile * WAVE;
+    if ((int)blockIdx.x >= n_tiles) return;
+    float *lc = smem, *ls = smem + C_FLOATS, *stage = ls + S_FLOATS;
     for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    // persistent wavefronts, the next tile's rows staged in LDS while this one is walked (see rnea_static_body)
     float qv[n], qdv[n], fv[n];
     {
-        const int64_t row = (b0 + lane) * n;
+        const int64_t row = ((int64_t)blockIdx.x * WAVE + lane) * n;
 #pragma unroll
         for (int d = 0; d < n; ++d) qv[d] = q[row + d];
 #pragma unroll
@@ -597,36 +605,64 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
 #pragma unroll
         for (int d = 0; d < n; ++d) fv[d] = f[row + d];
     }
-    wave_lds_sync();
-    float acc[n];
-    aba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
-                       [&](int d, float &x, float &v) { x = qv[d]; v = qdv[d]; }, [&](int d) { return fv[d]; },
-                       [&](int d, float v) { acc[d] = v; },
-                       [&](int k, const Motion &M) {
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int next = tile + (int)gridDim.x;
+        wave_lds_sync(); // (the table is in LDS; the previous tile's staged accelerations and next rows have been read)
+        if (next < n_tiles && STAGED >= 2) {
+            const int64_t base = (int64_t)next * WAVE * n;
+            const uint32_t off = lane * (uint32_t)(n * sizeof(float));
+            rows_to_stage<n>(q + base, off, stage);
+            rows_to_stage<n>(qd + base, off, stage + n * WAVE);
+            if constexpr (STAGED >= 3) rows_to_stage<n>(f + base, off, stage + 2 * n * WAVE);
+        }
+        if (STAGED < 3 && tile != (int)blockIdx.x) { // (the first tile's rows were read above)
+            const int64_t row = ((int64_t)tile * WAVE + lane) * n;
+            if constexpr (STAGED < 2) {
 #pragma unroll
-                           for (int i = 0; i < 3; ++i) { ls[((k * 8 + i) * WAVE) + lane] = M.wa[i][0]; ls[((k * 8 + 3 + i) * WAVE) + lane] = M.va[i][0]; }
-                       },
-                       [&](int k, Motion &M) {
+                for (int d = 0; d < n; ++d) qv[d] = q[row + d];
 #pragma unroll
-                           for (int i = 0; i < 3; ++i) {
-                               M.wa[i] = f2_make(ls[((k * 8 + i) * WAVE) + lane], 0.0f);
-                               M.va[i] = f2_make(ls[((k * 8 + 3 + i) * WAVE) + lane], 0.0f);
-                           }
-                       },
-                       [&](int k, const float *rec) { // (op k's velocity has been read: sweep 2 unparks it before it eliminates the joint)
+                for (int d = 0; d < n; ++d) qdv[d] = qd[row + d];
+            }
 #pragma unroll
-                           for (int i = 0; i < 8; ++i) ls[((k * 8 + i) * WAVE) + lane] = rec[i];
-                       },
-                       [&](int k, float *rec) {
+            for (int d = 0; d < n; ++d) fv[d] = f[row + d];
+        }
+        float acc[n];
+        aba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+                           [&](int d, float &x, float &v) { x = qv[d]; v = qdv[d]; }, [&](int d) { return fv[d]; },
+                           [&](int d, float v) { acc[d] = v; },
+                           [&](int k, const Motion &M) {
 #pragma unroll
-                           for (int i = 0; i < 8; ++i) rec[i] = ls[((k * 8 + i) * WAVE) + lane];
-                       });
-    wave_lds_sync(); // (the slots are free: sweep 3 has read every record)
-    float *trow = ls + lane * Sq;
+                               for (int i = 0; i < 3; ++i) { ls[((k * 8 + i) * WAVE) + lane] = M.wa[i][0]; ls[((k * 8 + 3 + i) * WAVE) + lane] = M.va[i][0]; }
+                           },
+                           [&](int k, Motion &M) {
 #pragma unroll
-    for (int d = 0; d < n; ++d) trow[d] = acc[d];
-    wave_lds_sync();
-    tile_store<0>(qdd + b0 * n, WAVE, n, magic_n, ls, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+                               for (int i = 0; i < 3; ++i) {
+                                   M.wa[i] = f2_make(ls[((k * 8 + i) * WAVE) + lane], 0.0f);
+                                   M.va[i] = f2_make(ls[((k * 8 + 3 + i) * WAVE) + lane], 0.0f);
+                               }
+                           },
+                           [&](int k, const float *rec) { // (op k's velocity has been read: sweep 2 unparks it before it eliminates the joint)
+#pragma unroll
+                               for (int i = 0; i < 8; ++i) ls[((k * 8 + i) * WAVE) + lane] = rec[i];
+                           },
+                           [&](int k, float *rec) {
+#pragma unroll
+                               for (int i = 0; i < 8; ++i) rec[i] = ls[((k * 8 + i) * WAVE) + lane];
+                           });
+        __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago)
+        wave_lds_sync();               // (the slots are free: sweep 3 has read every record)
+        float *trow = ls + lane * Sq;
+#pragma unroll
+        for (int d = 0; d < n; ++d) trow[d] = acc[d];
+        if (next < n_tiles && STAGED >= 2) {
+            rows_from_stage<n>(stage, lane, qv);
+            rows_from_stage<n>(stage + n * WAVE, lane, qdv);
+            if constexpr (STAGED >= 3) rows_from_stage<n>(stage + 2 * n * WAVE, lane, fv);
+        }
+        wave_lds_sync();
+        tile_store<0>(qdd + (int64_t)tile * WAVE * n, WAVE, n, magic_n, ls, lane, (n & 1) && (align & AL_TAU), (align & AL_TAU) != 0);
+    }
 }
 
 // Reverse-mode inverse dynamics of 64-row tiles: persistent wavefronts (one per block; the grid is what the device holds at
@@ -642,16 +678,23 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
                                                           float *__restrict__ partials) {
     constexpr int N = R::N, n = R::NDOF, C_FLOATS = N * DRM_OPF_STRIDE, NV = CAP * DRM_OPF_STRIDE, LEAF = 18;
     static_assert(CAP >= N, "the table's pitch covers the walk");
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + NV + R::LEAVES * LEAF * WAVE];
+    // arrays of the next tile staged in LDS (see aba_static_body): q, qd, qdd, grad_tau — or without grad_tau — or none.
+    // NONE by default: measured on Fetch, staging made this kernel 5 % SLOWER (260 -> 273 us at 2^20 rows; 256 VGPR + 246 AGPR,
+    // the walk is 83 % of the launch already) where it gained 4-10 % on the forward kernels.  -DDRM_STATIC_STAGE_BACKWARD=1 for A/B runs.
+#ifndef DRM_STATIC_STAGE_BACKWARD
+#define DRM_STATIC_STAGE_BACKWARD 0
+#endif
+    constexpr int STAGED = DRM_STATIC_STAGE_BACKWARD ? staged_arrays(C_FLOATS + NV + R::LEAVES * LEAF * WAVE, n, 4, 3) : 0;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + NV + R::LEAVES * LEAF * WAVE + STAGED * n * WAVE + 4];
     const unsigned lane = threadIdx.x;
-    float *lc = smem, *lacc = smem + C_FLOATS, *lleaf = lacc + NV + lane;
+    float *lc = smem, *lacc = smem + C_FLOATS, *lleaf = lacc + NV + lane, *stage = lacc + NV + R::LEAVES * LEAF * WAVE;
     for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
     for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
     wave_lds_sync();
-#pragma unroll 1
-    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int64_t r0 = ((int64_t)tile * WAVE + lane) * n;
-        float qv[n], qdv[n], qddv[n], gtv[n], gqv[n], gqdv[n], gqddv[n];
+    // the next tile's rows are staged in LDS while this one is walked (see rnea_static_body)
+    float qv[n], qdv[n], qddv[n], gtv[n];
+    if (STAGED > 0 && (int)blockIdx.x < n_tiles) {
+        const int64_t r0 = ((int64_t)blockIdx.x * WAVE + lane) * n;
 #pragma unroll
         for (int d = 0; d < n; ++d) qv[d] = q[r0 + d];
 #pragma unroll
@@ -660,6 +703,33 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
         for (int d = 0; d < n; ++d) qddv[d] = qdd ? qdd[r0 + d] : 0.0f;
 #pragma unroll
         for (int d = 0; d < n; ++d) gtv[d] = gtau[r0 + d];
+    }
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int64_t r0 = ((int64_t)tile * WAVE + lane) * n;
+        const int next = tile + (int)gridDim.x;
+        if constexpr (STAGED > 0) wave_lds_sync(); // (the staged rows of this tile have been read)
+        if (next < n_tiles && STAGED >= 3) {
+            const int64_t base = (int64_t)next * WAVE * n;
+            const uint32_t off = lane * (uint32_t)(n * sizeof(float));
+            rows_to_stage<n>(q + base, off, stage);
+            rows_to_stage<n>(qd + base, off, stage + n * WAVE);
+            if (qdd) rows_to_stage<n>(qdd + base, off, stage + 2 * n * WAVE);
+            if constexpr (STAGED >= 4) rows_to_stage<n>(gtau + base, off, stage + 3 * n * WAVE);
+        }
+        if (STAGED == 0 || (STAGED < 4 && tile != (int)blockIdx.x)) { // (staging: the first tile's rows were read above)
+            if constexpr (STAGED < 3) {
+#pragma unroll
+                for (int d = 0; d < n; ++d) qv[d] = q[r0 + d];
+#pragma unroll
+                for (int d = 0; d < n; ++d) qdv[d] = qd[r0 + d];
+#pragma unroll
+                for (int d = 0; d < n; ++d) qddv[d] = qdd ? qdd[r0 + d] : 0.0f;
+            }
+#pragma unroll
+            for (int d = 0; d < n; ++d) gtv[d] = gtau[r0 + d];
+        }
+        float gqv[n], gqdv[n], gqddv[n];
 #pragma unroll
         for (int d = 0; d < n; ++d) gqv[d] = gqdv[d] = gqddv[d] = 0.0f;
         rnea_backward_static_walk<R>(
@@ -690,6 +760,16 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
                     T[i] = f2_make(r[(12 + i) * WAVE], r[(15 + i) * WAVE]);
                 }
             });
+        if constexpr (STAGED > 0) {
+            __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago)
+            wave_lds_sync();
+        }
+        if (next < n_tiles && STAGED >= 3) {
+            rows_from_stage<n>(stage, lane, qv);
+            rows_from_stage<n>(stage + n * WAVE, lane, qdv);
+            if (qdd) rows_from_stage<n>(stage + 2 * n * WAVE, lane, qddv);
+            if constexpr (STAGED >= 4) rows_from_stage<n>(stage + 3 * n * WAVE, lane, gtv);
+        }
         if (gq) {
 #pragma unroll
             for (int d = 0; d < n; ++d) gq[r0 + d] = gqv[d];

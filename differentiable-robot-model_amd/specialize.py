@@ -128,7 +128,7 @@ def backward_lds_bytes(tree: Dict[str, list], capacity: int) -> int:
     """LDS of drm_rnea_backward_static per wavefront (csrc/drm_static.hpp rnea_backward_static_body): the table, the running sums
     of the constant gradients and 18 floats per leaf and sample."""
     n = len(tree["parent"])
-    return 4 * (n * 32 + capacity * 32 + (max(leaf_ordinals(tree)) + 1) * 18 * 64)
+    return 4 * (n * 32 + capacity * 32 + (max(leaf_ordinals(tree)) + 1) * 18 * 64 + 4)
 
 
 def source(tree: Dict[str, list], n_dofs: int, capacity: int = 0) -> str:
