@@ -48,8 +48,8 @@ extern "C" {
 #define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
 #define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   kernel drm_crba_static  */
 #define DRM_SPECIAL_FD 2     /*   forward dynamics             kernel drm_fd_static    */
-#define DRM_SPECIAL_RNEA_BACKWARD 3 /* reverse-mode inverse dynamics  kernel drm_rnea_backward_static (built with the walk's capacity
-                                       as the pitch of its rows of partial sums) */
+#define DRM_SPECIAL_RNEA_BACKWARD 3 /* reverse-mode inverse dynamics  kernel drm_rnea_backward_static, built with the walk's capacity
+                                       as the pitch of its rows of partial sums */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
