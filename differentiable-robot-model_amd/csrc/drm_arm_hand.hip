@@ -16,6 +16,7 @@
 #include "drm_sample.hpp"
 #include "drm_tree.hpp"
 #include "drm_tree_dev.hpp"
+#include "drm_static.hpp"
 
 namespace drm {
 
@@ -456,6 +457,33 @@ int64_t launch_forward_dynamics_arm_hand(const drm_walk *w, const float *q, cons
 #endif
 }
 
+// the THROUGHPUT form of the mass matrix for the small shapes (up to CRBA_TREE_MAX_OPS ops): one wavefront walks the whole tree of a
+// tile (drm_static.hpp crba_shape_body), taken by launches of at least CRBA_TREE_MIN_TILES tiles
+#ifndef DRM_CRBA_TREE_MIN_TILES
+#define DRM_CRBA_TREE_MIN_TILES 2048 /* at 1 024 tiles (one per SIMD) the wavefront-per-sub-chain kernels are still ahead: 12.7 vs 13.1 us (Panda with gripper), 16.2 vs 18.4 (Jaco) */
+#endif
+constexpr int CRBA_TREE_MAX_OPS = 12;
+template <int P, int K, int L, bool NT, bool PLAIN>
+__global__ void __launch_bounds__(WAVE) crba_arm_hand_tree_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i,
+                                                                  const float *__restrict__ q, int cap, int n, int n_tiles,
+                                                                  float *__restrict__ H) {
+    crba_shape_body<ShapeTree<P, K, L>, NT, PLAIN>(ops_f, ops_i, q, cap, n, n_tiles, H);
+}
+template <int P, int K, int L>
+static bool launch_crba_tree(const drm_walk *w, const float *q, int n_tiles, bool nt, float *H, hipStream_t s) {
+    if constexpr (P + K * L <= CRBA_TREE_MAX_OPS) {
+        const bool plain = (w->shape & DRM_WALK_NO_PRISMATIC) && w->n_dofs == w->n_ops; // every op a revolute joint
+#define DRM_TREE_LAUNCH(NT_, PLAIN_)                                                                                                \
+    hipLaunchKernelGGL((crba_arm_hand_tree_kernel<P, K, L, NT_, PLAIN_>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, \
+                       (int)w->capacity, (int)w->n_dofs, n_tiles, H)
+        if (nt) { if (plain) DRM_TREE_LAUNCH(true, true); else DRM_TREE_LAUNCH(true, false); }
+        else { if (plain) DRM_TREE_LAUNCH(false, true); else DRM_TREE_LAUNCH(false, false); }
+#undef DRM_TREE_LAUNCH
+        return true;
+    }
+    return false;
+}
+
 // the mass-matrix kernel has a wavefront per sub-chain
 bool crba_arm_hand_applies(const drm_walk *w) {
 #ifdef DRM_NO_ARM_HAND_CRBA
@@ -475,6 +503,21 @@ int64_t launch_crba_arm_hand(const drm_walk *w, const float *q, int64_t B, float
         return 0;
     const int n_tiles = (int)(B / WAVE);
     const bool nt = stream_past_llc((int64_t)n_tiles * WAVE * w->n_dofs * w->n_dofs * 4);
+#ifndef DRM_NO_CRBA_TREE
+    if (n_tiles >= DRM_CRBA_TREE_MIN_TILES && P + K * L <= CRBA_TREE_MAX_OPS) {
+#ifdef DRM_CRBA_TREE_NEVER_NT
+        const bool nt = false;
+#endif
+#define X(p, l)                                                                                                                  \
+    if (P == p && L == l) {                                                                                                      \
+        if ((K == 2 && launch_crba_tree<p, 2, l>(w, q, n_tiles, nt, H, s)) || (K == 3 && launch_crba_tree<p, 3, l>(w, q, n_tiles, nt, H, s)) || \
+            (K == 4 && launch_crba_tree<p, 4, l>(w, q, n_tiles, nt, H, s)))                                                      \
+            return (int64_t)n_tiles * WAVE;                                                                                      \
+    }
+        DRM_ARM_HAND_SHAPES(X)
+#undef X
+    }
+#endif
 #define X(p, l)                                                                                                                  \
     if (P == p && L == l) {                                                                                                      \
         if (nt)                                                                                                                  \

@@ -9,6 +9,7 @@
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 #include "drm_tree_dev.hpp"
+#include "drm_static.hpp"
 
 namespace drm {
 
@@ -324,6 +325,51 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     tile_store<NN>(H + b0 * NN, WAVE, NN, 0u, lh, lane, true);
 }
 
+// The fingers of a hand (DRM_WALK_FINGERS: K serial chains of L ops off the root), small ones, large launches: one wavefront walks
+// the whole hand of a tile (drm_static.hpp crba_shape_body with P = 0) instead of a wavefront per finger (crba_tree_kernel) —
+// TriFinger at 2^19 rows: 60 -> 31 us.
+#ifndef DRM_CRBA_TREE_MIN_TILES
+#define DRM_CRBA_TREE_MIN_TILES 2048 /* at 1 024 tiles (one per SIMD) the wavefront-per-sub-chain kernels are still ahead: 12.7 vs 13.1 us (Panda with gripper), 16.2 vs 18.4 (Jaco) */
+#endif
+// (the ops of a DRM_WALK_FINGERS walk are all revolute joints, op k driving DoF column k: the PLAIN form)
+template <int K, int L, bool NT>
+__global__ void __launch_bounds__(WAVE) crba_fingers_tree_kernel(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i,
+                                                                 const float *__restrict__ q, int cap, int n, int n_tiles,
+                                                                 float *__restrict__ H) {
+    crba_shape_body<ShapeTree<0, K, L>, NT, true>(ops_f, ops_i, q, cap, n, n_tiles, H);
+}
+// rows covered (full tiles), 0: not this walk / launch
+static int64_t launch_crba_fingers_tree(const drm_walk *w, const float *q, int64_t B, float *H, hipStream_t s) {
+#ifdef DRM_NO_CRBA_TREE
+    return 0;
+#else
+    if (!(w->shape & DRM_WALK_FINGERS) || B / WAVE < DRM_CRBA_TREE_MIN_TILES || B / WAVE >= 0x7fffffffLL ||
+        (((uintptr_t)w->ops_f | (uintptr_t)H) & 15u) != 0)
+        return 0;
+    const int K = DRM_WALK_AH_K(w->shape), L = DRM_WALK_AH_L(w->shape);
+    if (K * L != w->n_ops || w->n_dofs != w->n_ops || K * L > 12) return 0;
+    const int n_tiles = (int)(B / WAVE);
+#ifdef DRM_CRBA_TREE_NEVER_NT
+    const bool nt = false;
+#else
+    const bool nt = stream_past_llc((int64_t)n_tiles * WAVE * w->n_dofs * w->n_dofs * 4);
+#endif
+#define X(k, l)                                                                                                                  \
+    if (K == k && L == l) {                                                                                                      \
+        if (nt)                                                                                                                  \
+            hipLaunchKernelGGL((crba_fingers_tree_kernel<k, l, true>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q,  \
+                               (int)w->capacity, (int)w->n_dofs, n_tiles, H);                                                    \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((crba_fingers_tree_kernel<k, l, false>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, w->ops_f, w->ops_i, q, \
+                               (int)w->capacity, (int)w->n_dofs, n_tiles, H);                                                    \
+        return (int64_t)n_tiles * WAVE;                                                                                          \
+    }
+    X(2, 2) X(3, 2) X(4, 2) X(2, 3) X(3, 3) X(4, 3) X(2, 4) X(3, 4)
+#undef X
+    return 0;
+#endif
+}
+
 } // namespace drm
 
 using namespace drm;
@@ -393,6 +439,14 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
             drm_walk generic = *w;
             generic.shape &= ~DRM_WALK_ARM_HAND;
             return drm_crba(&generic, q + done * n, B - done, H + done * nn, scratch, stream);
+        }
+    }
+    {   // a small hand, a large launch: one wavefront per tile walks all the fingers
+        const int64_t done = launch_crba_fingers_tree(w, q, B, H, s);
+        if (done > 0) {
+            rc = launched();
+            if (rc || done == B) return rc;
+            return drm_crba(w, q + done * n, B - done, H + done * nn, scratch, stream); // (< 64 rows: the kernels below)
         }
     }
     // (a misaligned call on a walk with a straight-line kernel, or its ragged tail: the loop kernel on at most MISALIGNED_TILES blocks)

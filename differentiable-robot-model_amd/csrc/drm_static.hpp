@@ -172,6 +172,63 @@ DRM_HD void crba_static_walk(ROW row, QF qf, HOUT hout) {
     });
 }
 
+// The same sweep for a tree that is a compile-time constant while the JOINTS are not: R::N, R::parent(k), R::below(c, k) as above;
+// kind(k) -> bit 0: op k moves, bit 1: it slides (wave-uniform run-time values: the control words of the walk); qf(k) -> the joint
+// value of op k.  For the ahead-of-time kernels of the SHAPE families (an arm that carries a hand, the fingers of a hand: the tree
+// is the template's (P, K, L), which joints move or slide is the robot's).  hout(k, c, v) gets both ops as compile-time constants
+// for EVERY related pair of ops; the caller drops the pairs of ops that do not move (kind).
+template <class R, class ROW, class KIND, class QF, class HOUT>
+DRM_HD void crba_static_walk_kinds(ROW row, KIND kind, QF qf, HOUT hout) {
+    constexpr int N = R::N;
+    Inertia up[N];
+    Force F[N];
+    static_for<N>([&](auto K) {
+        constexpr int k = N - 1 - K, par = R::parent(k);
+        DRM_RNEA_LINK_FENCE();
+        const float *of = row(k);
+        const int kd = kind(k);
+        const bool moves = kd & 1, pris = kd & 2;
+        Inertia tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = of[DRM_OPF_MCOM + i];
+        tot.I[0] = of[DRM_OPF_IO + 0]; tot.I[1] = of[DRM_OPF_IO + 1]; tot.I[2] = of[DRM_OPF_IO + 2];
+        tot.I[3] = of[DRM_OPF_IO + 4]; tot.I[4] = of[DRM_OPF_IO + 5]; tot.I[5] = of[DRM_OPF_IO + 8];
+        static_for<N>([&](auto C) { // children, in the order the leaves -> root sweep meets them
+            constexpr int c = N - 1 - C;
+            if constexpr (c > k && R::parent(c) == k) inertia_add(tot, up[c]);
+        });
+        float q = 0.0f, cs = 1.0f, sn = 0.0f;
+        if (moves) {
+            q = qf(k);
+            if (!pris) sincos_one(q, sn, cs);
+        }
+        const OpFT o = load_ft(of);
+        float J[9], t[3];
+        joint_transform(o, moves, pris, q, cs, sn, J, t);
+        // F = Ic S_k.  revolute: f = -h x e_z, n = I e_z;  prismatic: f = m e_z, n = h x e_z  (zero for an op that does not move)
+        F[k].la[0] = moves ? (pris ? f2_make(0.0f, tot.h[1]) : f2_make(-tot.h[1], tot.I[2])) : f2_bcast(0.0f);
+        F[k].la[1] = moves ? (pris ? f2_make(0.0f, -tot.h[0]) : f2_make(tot.h[0], tot.I[4])) : f2_bcast(0.0f);
+        F[k].la[2] = moves ? (pris ? f2_make(tot.m, 0.0f) : f2_make(0.0f, tot.I[5])) : f2_bcast(0.0f);
+        hout(K, K, pris ? tot.m : tot.I[5]);
+        static_for<N>([&](auto C) {
+            constexpr int c = C;
+            if constexpr (R::below(c, k)) hout(K, std::integral_constant<int, N - 1 - c>{}, pris ? F[c].la[2][0] : F[c].la[2][1]);
+        });
+        if constexpr (par >= 0) {
+            static_for<N>([&](auto C) {
+                constexpr int c = C;
+                if constexpr (c == k || R::below(c, k)) {
+                    Force moved;
+                    rnea_link_force_up(J, t, F[c], moved);
+                    F[c] = moved;
+                }
+            });
+            inertia_to_parent(J, t, tot, up[k]);
+        }
+    });
+}
+
 // Forward dynamics of the whole tree by the articulated-body algorithm, the reference's own (robot_model.py:487-624) — drm_tree.hpp
 // aba_tree_walk's three sweeps with the tree as a compile-time constant: the branch-point motions and the articulated bodies
 // travelling towards the root live in registers (a sub-tree's body from the step of its root to its parent's step); what every op
@@ -782,6 +839,88 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
     wave_lds_sync();
     float *prow = partials + (int64_t)blockIdx.x * NV;
     for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
+}
+
+// The tree of a SHAPE family as compile-time constants: ops 0 .. P-1 a serial chain (op 0 off the root; P = 0: none), then K serial
+// sub-chains of L ops, each hanging off op P-1 (off the root when P = 0) — DRM_WALK_ARM_HAND / DRM_WALK_FINGERS of include/drm_hip.h.
+// Which ops move or slide is the robot's (run-time kinds).  Triangle slots: every pair (oa <= ob) of ops on a common root path.
+template <int P_, int K_, int L_>
+struct ShapeTree {
+    static constexpr int P = P_, K = K_, L = L_, N = P + K * L;
+    static constexpr int parent(int k) { return k < P ? k - 1 : ((k - P) % L == 0 ? P - 1 : k - 1); }
+    static constexpr bool below(int c, int k) { return c > k && (k < P || (c - P) / L == (k - P) / L); }
+    static constexpr int PPN = P * (P + 1) / 2, SUBN = L * P + L * (L + 1) / 2, SLOTS = PPN + K * SUBN;
+    static constexpr bool related(int oa, int ob) { return oa < P || (oa - P) / L == (ob - P) / L; } // (oa <= ob)
+    static constexpr int slot(int oa, int ob) {
+        if (ob < P) return ob * (ob + 1) / 2 + oa;
+        const int j = (ob - P) / L, i = ob - P - j * L;
+        return PPN + j * SUBN + i * P + i * (i + 1) / 2 + (oa < P ? oa : oa - j * L);
+    }
+    static constexpr int TRI = WAVE + 1;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (N * DRM_OPF_STRIDE + (SLOTS + 1) * TRI) + sizeof(int) * (N + N * N);
+};
+
+// Inertia matrices of 64-row tiles for a shape family, ONE wavefront per tile walking the whole tree (crba_static_walk_kinds): the
+// throughput form.  (crba_arm_hand_kernel / crba_tree_kernel give every sub-chain a wavefront of its own, each replaying the prefix
+// — the latency form: at 2^20 rows a Panda with gripper takes 133 us there and 86 us here, a TriFinger 2x.)  Entries go to the LDS
+// triangle, the tile's 64 matrices leave as 16-byte stores looked up by (element -> slot, sample), as in crba_arm_hand_kernel.
+// PLAIN: every op is a revolute joint (the host knows: DRM_WALK_NO_PRISMATIC and n_dofs == n_ops) — the kinds are the constant 1
+// and the sliding / fixed forms of every op fold away (Panda with gripper, revolute fingers: 109 -> 9x us at 2^20 rows).
+template <class T, bool NT, bool PLAIN = false>
+__device__ __forceinline__ void crba_shape_body(const float *__restrict__ ops_f, const int32_t *__restrict__ ops_i, const float *__restrict__ q,
+                                                int cap, int n, int n_tiles, float *__restrict__ H) {
+    constexpr int N = T::N, C_FLOATS = N * DRM_OPF_STRIDE, TRI = T::TRI, ZERO = T::SLOTS;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + (T::SLOTS + 1) * TRI];
+    __shared__ int op_of_dof[N];
+    __shared__ int slot_of[N * N];
+    const unsigned lane = threadIdx.x;
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int nn = n * n;
+    float *lc = smem, *tri = smem + C_FLOATS;
+    const int32_t *w0 = ops_i + DRM_OPI_W0 * cap;
+    for (int i = (int)lane; i < C_FLOATS / 4; i += WAVE) reinterpret_cast<float4 *>(lc)[i] = reinterpret_cast<const float4 *>(ops_f)[i];
+    if ((int)lane < N) {
+        const int d = (w0[lane] & 0xff) - 1;
+        if (d >= 0) op_of_dof[d] = (int)lane;
+    }
+    tri[ZERO * TRI + lane] = 0.0f;
+    if (lane == 0) tri[ZERO * TRI + WAVE] = 0.0f;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    const float *qrow = q + (b0 + lane) * n;
+    int kinds[N];
+    float qv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { // (wave-uniform control words; a joint value per moving op)
+        const int w = w0[k], d = (w & 0xff) - 1;
+        kinds[k] = PLAIN ? 1 : ((d >= 0 ? 1 : 0) | (((w >> 26) & 1) << 1));
+        qv[k] = qrow[d < 0 ? 0 : d];
+    }
+    wave_lds_sync();
+    for (int e = (int)lane; e < nn; e += WAVE) {
+        const int r = e / n, c = e - r * n;
+        const int a0 = op_of_dof[r], a1 = op_of_dof[c];
+        const int oa = a0 < a1 ? a0 : a1, ob = a0 < a1 ? a1 : a0;
+        slot_of[e] = (T::related(oa, ob) ? T::slot(oa, ob) : ZERO) * TRI;
+    }
+    crba_static_walk_kinds<T>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, [&](int k) { return PLAIN ? 1 : kinds[k]; },
+                              [&](int k) { return qv[k]; },
+                              [&](auto KR, auto CR, float v) { // (reversed op indices as types: the slot is a compile-time constant)
+                                  constexpr int k = N - 1 - decltype(KR)::value, c = N - 1 - decltype(CR)::value;
+                                  tri[T::slot(k, c) * TRI + lane] = v;
+                              });
+    wave_lds_sync();
+    const int n4 = 16 * nn;
+    float *g = H + b0 * nn;
+    for (int f = (int)lane; f < n4; f += WAVE) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = 4 * f + c, sm = w / nn, e = w - sm * nn;
+            v[c] = tri[slot_of[e] + sm];
+        }
+        store16_wt<NT>(g + 4 * f, make_float4(v[0], v[1], v[2], v[3]));
+    }
 }
 
 } // namespace drm

@@ -86,6 +86,29 @@ def test_gpu_crba_vs_oracle(robot, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot,compat", [("panda", True), ("panda", False), ("jaco", True), ("trifinger_edu", True), ("allegro_left", True)])
+def test_gpu_crba_throughput_form_of_the_small_shapes(robot, compat):
+    """Launches of >= 2 048 tiles of a small arm + hand / hand (<= 12 ops) take the one-wavefront-per-tile walk over the shape's tree
+    (csrc/drm_static.hpp crba_shape_body; sliding fingers included); smaller launches the wavefront-per-sub-chain kernels.  Every
+    row of a 131 072 + 70 row launch against the fp64 oracle, symmetric, and equal to rounding to the same rows in small launches
+    (the Allegro hand, 16 ops, keeps its kernel at every size: the two must agree there bit for bit)."""
+    mc, m = load_model(robot, reference_compat=compat), load_model(robot, "cuda", reference_compat=compat)
+    B = 2048 * 64 + 70
+    q, _, _ = sample_states(mc, B, seed=3)
+    dq = torch.from_numpy(q).cuda()
+    H = m.compute_lagrangian_inertia_matrix(dq)
+    small = torch.cat([m.compute_lagrangian_inertia_matrix(dq[a:a + 8192]) for a in range(0, B, 8192)])
+    ref = Oracle(mc._spec).mass_matrix(q[:16384].astype(np.float64), False, False, np.float64)
+    assert np.allclose(H[:16384].cpu().numpy(), ref, **TOL_TAU), (robot, np.abs(H[:16384].cpu().numpy() - ref).max())
+    assert torch.equal(H, H.transpose(1, 2))
+    if robot == "allegro_left":
+        assert torch.equal(H, small)
+    else:
+        assert float((H - small).abs().max()) <= 2e-5 * float(small.abs().max())
+        assert not torch.equal(H[:64], small[:64]) or robot == "trifinger_edu", "the large launch took the other kernel"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("robot,links", GOLDEN_ROBOTS)
 def test_gpu_crba_vs_reference_golden(robot, links):
     g, gm = load_golden(robot), load_golden_mass()
