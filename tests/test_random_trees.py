@@ -206,6 +206,10 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
     acc = m.compute_forward_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
     from differentiable_robot_model_amd.flatten import SHAPE_ARM_HAND
     arm_hand = bool(m._dynamics_walk().program.shape & SHAPE_ARM_HAND)
+    tree_form = arm_hand and m._dynamics_walk().program.n_ops <= 12 and B // 64 >= 2048
+    if tree_form:
+        part = m.compute_lagrangian_inertia_matrix(q[64:64 + 2048 * 64])
+        assert torch.equal(H[64:64 + 2048 * 64], part)
     for lo in (0, 70000, 131072 - 65, B - 130):
         sl = slice(lo, lo + 130)
         alone = m.compute_inverse_dynamics(q[sl], qd[sl], qdd[sl], include_gravity=True, use_damping=True)
@@ -221,7 +225,9 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
         H_alone = m.compute_lagrangian_inertia_matrix(q[sl])
         if arm_hand:
             assert np.allclose(H[sl].cpu().numpy(), H_alone.cpu().numpy(), **TOL_TAU), lo
-            if lo % 64 == 0 and lo + 128 <= B - B % 64:
+            # (small shapes: launches of >= 2 048 tiles take the one-wavefront-per-tile walk, drm_static.hpp crba_shape_body — the
+            # rows of the big launch are then compared, bit for bit, with another launch of that size below)
+            if lo % 64 == 0 and lo + 128 <= B - B % 64 and not tree_form:
                 assert torch.equal(H[lo:lo + 128], H_alone[:128]), lo
         else:
             assert torch.equal(H[sl], H_alone), lo
