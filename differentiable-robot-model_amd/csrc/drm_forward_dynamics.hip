@@ -425,7 +425,7 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         int grid = 0; // persistent wavefronts: what the device holds at once
         int rcg = resident_blocks_module((hipFunction_t)w->special[DRM_SPECIAL_FD], WAVE, grid);
         if (rcg) return rcg;
-        if (grid > n_tiles) grid = n_tiles;
+        if (grid > n_tiles || w->n_ops < STATIC_LONE_OPS) grid = n_tiles; // (small robots: one tile per block, drm_common.hpp STATIC_LONE_OPS)
         hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD], (unsigned)grid, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fd_static): %s", hipGetErrorString(e));
         const int64_t done = (int64_t)n_tiles * WAVE;

@@ -216,7 +216,7 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
         int grid = 0; // persistent wavefronts: what the device holds at once (each reads its next tile's rows while it walks one)
         rc = resident_blocks_module((hipFunction_t)w->special[DRM_SPECIAL_RNEA], WAVE, grid);
         if (rc) return rc;
-        if (grid > n_tiles) grid = n_tiles;
+        if (grid > n_tiles || w->n_ops < STATIC_LONE_OPS) grid = n_tiles; // (small robots: one tile per block, drm_common.hpp STATIC_LONE_OPS)
         hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA], (unsigned)grid, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
         if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_static): %s", hipGetErrorString(e));
         const int64_t done = (int64_t)n_tiles * WAVE;

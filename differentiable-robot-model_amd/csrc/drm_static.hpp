@@ -531,7 +531,7 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
                                                  const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
                                                  uint32_t magic_n, uint32_t align) {
     constexpr int N = R::N, n = R::NDOF, Sq = pad_odd(n), C_FLOATS = N * DRM_OPF_STRIDE, T_FLOATS = round4(WAVE * Sq);
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + T_FLOATS + 3 * n * WAVE];
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + T_FLOATS + (N >= STATIC_LONE_OPS ? 3 * n * WAVE : 4)];
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x >= n_tiles) return;
     float *lc = smem, *lt = smem + C_FLOATS, *stage = lt + T_FLOATS;
@@ -564,9 +564,10 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
 #ifndef DRM_STATIC_PREF
 #define DRM_STATIC_PREF 1
 #endif
+    constexpr bool LONE = N >= STATIC_LONE_OPS; // (drm_common.hpp: the latency forms, for walks that run one wavefront per SIMD anyway)
 #pragma unroll 1
     for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int next = tile + (int)gridDim.x;
+        const int next = LONE ? tile + (int)gridDim.x : n_tiles; // (small robots: one tile per block, launched as such)
         wave_lds_sync(); // (the table is in LDS; the previous tile's staged torques and next rows have been read)
         if (next < n_tiles) {
             const int64_t base = (int64_t)next * WAVE * n;
@@ -575,10 +576,10 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
             rows_to_stage<n>(qd + base, off, stage + n * WAVE);
             if (qdd) rows_to_stage<n>(qdd + base, off, stage + 2 * n * WAVE);
         }
-        rnea_static_walk<R, DRM_STATIC_PREF != 0>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+        rnea_static_walk<R, LONE && DRM_STATIC_PREF != 0>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
                                                   [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; },
                                                   [&](int d, float v) { trow[d] = v; });
-        __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago: nothing to wait for in practice)
+        if constexpr (LONE) __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago: nothing to wait for in practice)
         wave_lds_sync();
         if (next < n_tiles) {
             rows_from_stage<n>(stage, lane, qv);
@@ -645,7 +646,7 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
     constexpr int S_FLOATS = N * 8 * WAVE > round4(WAVE * Sq) ? N * 8 * WAVE : round4(WAVE * Sq);
     // arrays of the next tile that are staged in LDS: all three while four wavefronts still fit a CU's LDS, else f is read at the
     // top of its own tile (the walk needs it in sweep 2 only), else nothing is staged
-    constexpr int STAGED = staged_arrays(C_FLOATS + S_FLOATS, n, 3, 2);
+    constexpr int STAGED = N >= STATIC_LONE_OPS ? staged_arrays(C_FLOATS + S_FLOATS, n, 3, 2) : 0; // (small robots: one tile per block)
     __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + S_FLOATS + STAGED * n * WAVE + 4];
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x >= n_tiles) return;
@@ -707,7 +708,7 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
 #pragma unroll
                                for (int i = 0; i < 8; ++i) rec[i] = ls[((k * 8 + i) * WAVE) + lane];
                            });
-        __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago)
+        if constexpr (STAGED > 0) __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago)
         wave_lds_sync();               // (the slots are free: sweep 3 has read every record)
         float *trow = ls + lane * Sq;
 #pragma unroll
