@@ -159,6 +159,48 @@ def load_library(path: str = None, kind: str = "cuda"):
         return lib
 
 
+HOSTCALL_PATH = os.path.join(_HERE, "csrc", "drm_hostcall.so")
+_hostcall = False      # False: not tried yet;  None: unavailable;  else the module
+
+
+def hostcall():
+    """csrc/drm_hostcall.so — the per-call host work of fk / fk_jacobian / rnea in C++ (a torch extension without device code,
+    built by `__graft_entry__.build()`), or None: the Python path below then does the same work, more slowly (11-14 instead of
+    ~8 us per eager call).  It holds no kernels and no arithmetic: both paths call the same entry point of the same library.
+    DRM_NO_HOSTCALL=1 switches it off (A/B runs)."""
+    global _hostcall
+    if _hostcall is False:
+        _hostcall = None
+        if os.environ.get("DRM_NO_HOSTCALL") != "1" and os.path.exists(HOSTCALL_PATH):
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("drm_hostcall", HOSTCALL_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _hostcall = mod
+            except Exception as err:      # (built against another torch: the Python path serves)
+                import warnings
+                warnings.warn("csrc/drm_hostcall.so could not be loaded (%s); eager calls take the Python host path" % err)
+    return _hostcall
+
+
+def _fn_addr(lib, name: str) -> int:
+    """Address of an entry point of `lib`, for drm_hostcall (cached on the library object)."""
+    cache = lib.__dict__.setdefault("_drm_addr", {})
+    addr = cache.get(name)
+    if addr is None:
+        addr = cache[name] = ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+    return addr
+
+
+def _stream_int(device) -> int:
+    if device.type == "cpu":
+        return 0
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 class KernelUnsupported(RuntimeError):
     """DRM_ERR_UNSUPPORTED: the request is valid but no compiled kernel takes it (e.g. an inertia matrix too large for LDS)."""
 
@@ -314,6 +356,15 @@ def fk(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int, squeeze:
     """pos [B, T, 3], quat [B, T, 4] of the walk's targets ([B, 3], [B, 4] for one target with ``squeeze``: the same
     memory without the T axis, so the single-link API returns it without a slicing op)."""
     lib = _lib_of(q, "q", ops_f)
+    fast = hostcall()
+    if fast is not None:
+        walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+        with _on_device(q.device):
+            pos, quat, rc = fast.fk(_fn_addr(lib, "drm_fk"), ctypes.addressof(walk), q, n_dofs, n_targets, squeeze, _stream_int(q.device))
+        if rc <= 0:
+            if rc:
+                _check(rc, lib)
+            return pos, quat      # (rc == NOT_CONFORMING: a tensor the kernels do not take as it is — converted below)
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     if squeeze and n_targets == 1:
@@ -365,6 +416,15 @@ def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
 
 def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     lib = _lib_of(q, "q", ops_f)
+    fast = hostcall()
+    if fast is not None:
+        walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+        with _on_device(q.device):
+            pos, quat, lin, ang, rc = fast.fk_jacobian(_fn_addr(lib, "drm_fk_jacobian"), ctypes.addressof(walk), q, n_dofs, _stream_int(q.device))
+        if rc <= 0:
+            if rc:
+                _check(rc, lib)
+            return pos, quat, lin, ang
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     pos, quat, lin, ang = _outputs(q.device, (B, 3), (B, 4), (B, 3, n_dofs), (B, 3, n_dofs))
@@ -379,6 +439,17 @@ def fk_jacobian(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
 
 def rnea(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
     lib = _lib_of(q, "q", ops_f)
+    fast = hostcall()
+    if fast is not None and isinstance(qd, torch.Tensor) and (qdd is None or isinstance(qdd, torch.Tensor)):
+        walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+        flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        with _on_device(q.device):
+            tau, rc = fast.rnea(_fn_addr(lib, "drm_rnea"), _fn_addr(lib, "drm_rnea_scratch_floats_aligned"), ctypes.addressof(walk), q, qd,
+                                qdd, n_dofs, flags, _stream_int(q.device))
+        if rc <= 0:
+            if rc:
+                _check(rc, lib)
+            return tau
     q = _dev_f32(q, "q", n_dofs)
     qd = _dev_f32(qd, "qd", n_dofs)
     qdd = _dev_f32(qdd, "qdd", n_dofs) if qdd is not None else None

@@ -1,0 +1,96 @@
+// drm_hostcall.cpp — the per-call HOST work of the three hot public methods in C++ (a torch extension, no device code): what
+// backend.fk / backend.fk_jacobian / backend.rnea do in Python for a call that builds no autograd graph — check the inputs, make
+// the outputs (one allocation, views into it), call the C ABI (include/drm_hip.h) on the caller's stream — takes ~17 us of
+// interpreter time there and ~4 us here (measured on the CPU build with a one-row batch, where the C call itself is ~1 us).
+// Replaces nothing of the kernels: the entry point is handed over as an address (the ctypes function pointer of libdrm_hip.so or,
+// for CPU tensors, libdrm_cpu.so), so this module links against neither.  An input that is not already what the kernels take
+// (fp32, contiguous, 16-byte aligned, [B, n]) is not converted here: the call returns NOT_CONFORMING and the Python path, which
+// converts, serves it.  The reference does this bookkeeping in Python too (robot_model.py:25-84, 223-248, 305-375, 626-667); the
+// point is what a drop-in caller pays per call next to a 4 us kernel.
+#include <torch/extension.h>
+
+#include <tuple>
+
+namespace {
+constexpr int64_t NOT_CONFORMING = 1; // (the C ABI's own codes are <= 0)
+
+typedef int (*fk_fn)(const void *, const float *, int64_t, int32_t, float *, float *, void *);
+typedef int (*fk_jacobian_fn)(const void *, const float *, int64_t, float *, float *, float *, float *, void *);
+typedef int (*rnea_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
+typedef int64_t (*scratch_fn)(const void *, int64_t);
+
+inline int64_t pad4(int64_t x) { return (x + 3) & ~int64_t(3); } // every output starts on a 16-byte boundary
+inline bool conforms(const at::Tensor &t, int64_t cols) {
+    return t.dim() == 2 && t.size(1) == cols && t.scalar_type() == at::kFloat && t.is_contiguous() &&
+           (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15u) == 0;
+}
+} // namespace
+
+// (pos, quat, rc): pos [B, T, 3], quat [B, T, 4] — [B, 3], [B, 4] with `squeeze` and one target
+std::tuple<at::Tensor, at::Tensor, int64_t> fk(int64_t fn, int64_t walk, const at::Tensor &q, int64_t n, int64_t n_targets, bool squeeze,
+                                               int64_t stream) {
+    if (!conforms(q, n)) return {at::Tensor(), at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0), T = n_targets, o1 = pad4(B * T * 3);
+    at::Tensor flat = at::empty({o1 + pad4(B * T * 4)}, q.options());
+    at::Tensor pos, quat;
+    if (squeeze && T == 1) {
+        pos = flat.as_strided({B, 3}, {3, 1}, 0);
+        quat = flat.as_strided({B, 4}, {4, 1}, o1);
+    } else {
+        pos = flat.as_strided({B, T, 3}, {3 * T, 3, 1}, 0);
+        quat = flat.as_strided({B, T, 4}, {4 * T, 4, 1}, o1);
+    }
+    int64_t rc = 0;
+    if (B > 0) {
+        float *base = flat.data_ptr<float>();
+        rc = reinterpret_cast<fk_fn>(fn)(reinterpret_cast<const void *>(walk), q.data_ptr<float>(), B, (int32_t)T, base, base + o1,
+                                         reinterpret_cast<void *>(stream));
+    }
+    return {pos, quat, rc};
+}
+
+// (pos [B, 3], quat [B, 4], lin_jac [B, 3, n], ang_jac [B, 3, n], rc)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t> fk_jacobian(int64_t fn, int64_t walk, const at::Tensor &q, int64_t n,
+                                                                                 int64_t stream) {
+    if (!conforms(q, n)) return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0);
+    const int64_t o1 = pad4(B * 3), o2 = o1 + pad4(B * 4), o3 = o2 + pad4(B * 3 * n), total = o3 + pad4(B * 3 * n);
+    at::Tensor flat = at::empty({total}, q.options());
+    at::Tensor pos = flat.as_strided({B, 3}, {3, 1}, 0), quat = flat.as_strided({B, 4}, {4, 1}, o1);
+    at::Tensor lin = flat.as_strided({B, 3, n}, {3 * n, n, 1}, o2), ang = flat.as_strided({B, 3, n}, {3 * n, n, 1}, o3);
+    int64_t rc = 0;
+    if (B > 0) {
+        float *base = flat.data_ptr<float>();
+        rc = reinterpret_cast<fk_jacobian_fn>(fn)(reinterpret_cast<const void *>(walk), q.data_ptr<float>(), B, base, base + o1, base + o2,
+                                                  base + o3, reinterpret_cast<void *>(stream));
+    }
+    return {pos, quat, lin, ang, rc};
+}
+
+// (tau [B, n], rc); qdd may be an undefined tensor (joint accelerations zero).  scratch: the `_aligned` query of the ABI
+std::tuple<at::Tensor, int64_t> rnea(int64_t fn, int64_t scratch_query, int64_t walk, const at::Tensor &q, const at::Tensor &qd,
+                                     const c10::optional<at::Tensor> &qdd, int64_t n, int64_t flags, int64_t stream) {
+    const bool has_qdd = qdd.has_value() && qdd->defined();
+    if (!conforms(q, n) || !conforms(qd, n) || (has_qdd && !conforms(*qdd, n))) return {at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0);
+    if (qd.size(0) != B || (has_qdd && qdd->size(0) != B) || qd.device() != q.device() || (has_qdd && qdd->device() != q.device()))
+        return {at::Tensor(), NOT_CONFORMING}; // (the Python path words the error)
+    at::Tensor tau = at::empty({B, n}, q.options());
+    int64_t rc = 0;
+    if (B > 0) {
+        const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+        at::Tensor scratch;
+        if (need > 0) scratch = at::empty({need}, q.options());
+        rc = reinterpret_cast<rnea_fn>(fn)(reinterpret_cast<const void *>(walk), q.data_ptr<float>(), qd.data_ptr<float>(),
+                                           has_qdd ? qdd->data_ptr<float>() : nullptr, B, (int32_t)flags, tau.data_ptr<float>(),
+                                           need > 0 ? scratch.data_ptr<float>() : nullptr, reinterpret_cast<void *>(stream));
+    }
+    return {tau, rc};
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.attr("NOT_CONFORMING") = NOT_CONFORMING;
+    m.def("fk", &fk);
+    m.def("fk_jacobian", &fk_jacobian);
+    m.def("rnea", &rnea);
+}

@@ -21,3 +21,17 @@ def cpu_library():
     entry.build_cpu_library()
     import importlib
     return importlib.import_module("differentiable-robot-model_amd.backend").load_library(kind="cpu")
+
+
+@pytest.fixture(scope="session")
+def hostcall_module():
+    """csrc/drm_hostcall.so — the per-call host work of the hot public methods as a torch C++ extension — built if it is missing or
+    older than its source (~30 s), as `__graft_entry__.build()` does."""
+    import __graft_entry__ as entry
+    entry.build_hostcall()
+    import importlib
+    backend = importlib.import_module("differentiable-robot-model_amd.backend")
+    backend._hostcall = False          # (a process that looked before the build cached "unavailable")
+    mod = backend.hostcall()
+    assert mod is not None
+    return mod

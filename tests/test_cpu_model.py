@@ -149,3 +149,47 @@ def test_the_library_follows_the_tensors_device(cpu_library):
         backend._lib_of(torch.zeros(2, m._n_dofs), "q", TableOnHipDevice())
     with pytest.raises(RuntimeError, match="HIP device"):
         m.specialize()
+
+
+def test_host_work_in_cxx_is_the_python_host_path(cpu_library, hostcall_module, monkeypatch):
+    """csrc/drm_hostcall.so does per call what backend.fk / fk_jacobian / rnea do in Python (checks, one output allocation, the C
+    ABI call): the same bits from both, for conforming inputs; inputs the kernels do not take as they are (float64, a column
+    slice, a misaligned row slice) come back NOT_CONFORMING from C++ and are converted by the Python path; empty batches; errors
+    of the C ABI surface as the same exceptions."""
+    m = load_model("panda", "cpu")
+    n, link = m._n_dofs, "panda_virtual_ee_link"
+    g = torch.Generator().manual_seed(5)
+    q, qd, qdd = (torch.rand(130, n, generator=g) - 0.5 for _ in range(3))
+
+    def results(*args):
+        return [m.compute_forward_kinematics(args[0], link), m.compute_endeffector_jacobian(args[0], link),
+                (m.compute_inverse_dynamics(*args),), (m.compute_non_linear_effects(args[0], args[1]),)]
+
+    fast = results(q, qd, qdd)
+    monkeypatch.setattr(backend, "_hostcall", None)
+    slow = results(q, qd, qdd)
+    monkeypatch.setattr(backend, "_hostcall", hostcall_module)
+    for a, b in zip(fast, slow):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # not conforming: served by the Python path, same numbers to rounding of the conversion
+    wide = torch.zeros(131, n + 3)
+    wide[:130, :n] = q
+    for variant in (q.double(), wide[:130, :n], torch.cat([torch.zeros(1, n), q])[1:]):
+        assert hostcall_module.fk_jacobian(0, 0, variant, n, 0)[4] == hostcall_module.NOT_CONFORMING
+        lin, ang = m.compute_endeffector_jacobian(variant, link)
+        assert torch.equal(lin, fast[1][0]) and torch.equal(ang, fast[1][1])
+        assert torch.equal(m.compute_inverse_dynamics(variant, qd, qdd), fast[2][0])
+    # empty batches and the 1-D convenience shape of tensor_check
+    e = torch.zeros(0, n)
+    assert m.compute_endeffector_jacobian(e, link)[0].shape == (0, 3, n) and m.compute_inverse_dynamics(e, e, e).shape == (0, n)
+    assert torch.equal(m.compute_forward_kinematics(q[3], link)[0], fast[0][0][3])
+    # a C-ABI error comes back as the exception the Python path raises
+    dw = m._dynamics_walk()
+    bad = backend._walk_struct_build(dw.program, m._ops_f(dw), dw.ops_i, n)
+    bad.n_dofs = 999
+    tau, rc = hostcall_module.rnea(backend._fn_addr(cpu_library, "drm_rnea"), backend._fn_addr(cpu_library, "drm_rnea_scratch_floats_aligned"),
+                                   ctypes.addressof(bad), torch.zeros(2, 999), torch.zeros(2, 999), None, 999, 3, 0)
+    assert rc == -2
+    with pytest.raises(backend.KernelUnsupported):
+        backend._check(rc, cpu_library)
