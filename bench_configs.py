@@ -131,8 +131,11 @@ def api_eager(model_panda, device, rows=65536, calls=300):
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / calls * 1e6)
         out[name] = {"us_per_call": best, "evals_per_s": rows / best * 1e6}
-    out["note"] = ("eager public-API calls (tensor_check, output allocation, ctypes, launch); the metric line replays a prepared "
-                   "launch (plan_fk_and_jacobian) from a hipGraph instead")
+    from differentiable_robot_model_amd import backend
+    out["host_path"] = "csrc/drm_hostcall.so (C++)" if backend.hostcall() is not None else "Python + ctypes"
+    out["note"] = ("eager public-API calls: tensor_check in Python, then input checks, ONE output allocation and the C-ABI call — in "
+                   "csrc/drm_hostcall.so (a torch extension without device code) when it is built, in Python + ctypes otherwise — and the "
+                   "HIP launch; the metric line replays a prepared launch (plan_fk_and_jacobian) from a hipGraph instead")
     return out
 
 
