@@ -20,7 +20,7 @@ def cpu_library():
     import __graft_entry__ as entry
     entry.build_cpu_library()
     import importlib
-    return importlib.import_module("differentiable-robot-model_amd.backend").load_library(kind="cpu")
+    return importlib.import_module("differentiable_robot_model_amd.backend").load_library(kind="cpu")
 
 
 @pytest.fixture(scope="session")
@@ -30,7 +30,7 @@ def hostcall_module():
     import __graft_entry__ as entry
     entry.build_hostcall()
     import importlib
-    backend = importlib.import_module("differentiable-robot-model_amd.backend")
+    backend = importlib.import_module("differentiable_robot_model_amd.backend")
     backend._hostcall = False          # (a process that looked before the build cached "unavailable")
     mod = backend.hostcall()
     assert mod is not None

@@ -21,7 +21,7 @@ import test_golden_wide as wide
 import test_mass_matrix as mmt
 import test_rnea_backward as rbt
 
-backend = importlib.import_module("differentiable-robot-model_amd.backend")
+backend = importlib.import_module("differentiable_robot_model_amd.backend")
 
 
 def test_host_build_exports_the_whole_abi(cpu_library):
@@ -167,6 +167,7 @@ def test_host_work_in_cxx_is_the_python_host_path(cpu_library, hostcall_module, 
 
     fast = results(q, qd, qdd)
     monkeypatch.setattr(backend, "_hostcall", None)
+    assert backend.hostcall() is None and m.compute_forward_kinematics.__module__.startswith(backend.__name__.rsplit(".", 1)[0])
     slow = results(q, qd, qdd)
     monkeypatch.setattr(backend, "_hostcall", hostcall_module)
     for a, b in zip(fast, slow):
