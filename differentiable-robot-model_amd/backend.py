@@ -575,6 +575,17 @@ class WalkTable(torch.autograd.Function):
 def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity: bool, use_damping: bool, n_dofs: int):
     """qdd [B, n] produced by the joint torques f in state (q, qd)."""
     lib = _lib_of(q, "q", ops_f)
+    fast = hostcall()
+    if fast is not None and isinstance(qd, torch.Tensor) and isinstance(f, torch.Tensor):
+        walk = _walk_struct(prog, ops_f, ops_i, n_dofs)      # (reads the table's address only)
+        flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+        with _on_device(q.device):
+            qdd, rc = fast.forward_dynamics(_fn_addr(lib, "drm_forward_dynamics"), _fn_addr(lib, "drm_forward_dynamics_scratch_floats_aligned"),
+                                            ctypes.addressof(walk), q, qd, f, n_dofs, flags, _stream_int(q.device))
+        if rc <= 0:
+            if rc:
+                _check(rc, lib)
+            return qdd
     q, qd, f = _dev_f32(q, "q", n_dofs), _dev_f32(qd, "qd", n_dofs), _dev_f32(f, "f", n_dofs)
     B = q.shape[0]
     if qd.shape[0] != B or f.shape[0] != B:
@@ -597,6 +608,16 @@ def forward_dynamics(prog: WalkProgram, ops_f, ops_i, q, qd, f, include_gravity:
 def crba(prog: WalkProgram, ops_f, ops_i, q, n_dofs: int):
     """H [B, n, n] joint-space inertia matrix."""
     lib = _lib_of(q, "q", ops_f)
+    fast = hostcall()
+    if fast is not None:
+        walk = _walk_struct(prog, ops_f, ops_i, n_dofs)
+        with _on_device(q.device):
+            H, rc = fast.crba(_fn_addr(lib, "drm_crba"), _fn_addr(lib, "drm_crba_scratch_floats_aligned"), ctypes.addressof(walk), q, n_dofs,
+                              _stream_int(q.device))
+        if rc <= 0:
+            if rc:
+                _check(rc, lib)
+            return H
     q = _dev_f32(q, "q", n_dofs)
     B = q.shape[0]
     H = torch.empty(B, n_dofs, n_dofs, device=q.device, dtype=torch.float32)

@@ -1,5 +1,5 @@
-// drm_hostcall.cpp — the per-call HOST work of the three hot public methods in C++ (a torch extension, no device code): what
-// backend.fk / backend.fk_jacobian / backend.rnea do in Python for a call that builds no autograd graph — check the inputs, make
+// drm_hostcall.cpp — the per-call HOST work of the hot public methods in C++ (a torch extension, no device code): what
+// backend.fk / fk_jacobian / rnea / crba / forward_dynamics do in Python for a call that builds no autograd graph — check the inputs, make
 // the outputs (one allocation, views into it), call the C ABI (include/drm_hip.h) on the caller's stream — takes ~17 us of
 // interpreter time there and ~4 us here (measured on the CPU build with a one-row batch, where the C call itself is ~1 us).
 // Replaces nothing of the kernels: the entry point is handed over as an address (the ctypes function pointer of libdrm_hip.so or,
@@ -18,6 +18,8 @@ typedef int (*fk_fn)(const void *, const float *, int64_t, int32_t, float *, flo
 typedef int (*fk_jacobian_fn)(const void *, const float *, int64_t, float *, float *, float *, float *, void *);
 typedef int (*rnea_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
 typedef int64_t (*scratch_fn)(const void *, int64_t);
+typedef int (*crba_fn)(const void *, const float *, int64_t, float *, float *, void *);
+typedef int (*fd_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
 
 inline int64_t pad4(int64_t x) { return (x + 3) & ~int64_t(3); } // every output starts on a 16-byte boundary
 inline bool conforms(const at::Tensor &t, int64_t cols) {
@@ -88,7 +90,44 @@ std::tuple<at::Tensor, int64_t> rnea(int64_t fn, int64_t scratch_query, int64_t 
     return {tau, rc};
 }
 
+// (H [B, n, n], rc)
+std::tuple<at::Tensor, int64_t> crba(int64_t fn, int64_t scratch_query, int64_t walk, const at::Tensor &q, int64_t n, int64_t stream) {
+    if (!conforms(q, n)) return {at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0);
+    at::Tensor H = at::empty({B, n, n}, q.options());
+    int64_t rc = 0;
+    if (B > 0) {
+        const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+        at::Tensor scratch;
+        if (need > 0) scratch = at::empty({need}, q.options());
+        rc = reinterpret_cast<crba_fn>(fn)(reinterpret_cast<const void *>(walk), q.data_ptr<float>(), B, H.data_ptr<float>(),
+                                           need > 0 ? scratch.data_ptr<float>() : nullptr, reinterpret_cast<void *>(stream));
+    }
+    return {H, rc};
+}
+
+// (qdd [B, n], rc)
+std::tuple<at::Tensor, int64_t> forward_dynamics(int64_t fn, int64_t scratch_query, int64_t walk, const at::Tensor &q, const at::Tensor &qd,
+                                                 const at::Tensor &f, int64_t n, int64_t flags, int64_t stream) {
+    if (!conforms(q, n) || !conforms(qd, n) || !conforms(f, n)) return {at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0);
+    if (qd.size(0) != B || f.size(0) != B || qd.device() != q.device() || f.device() != q.device()) return {at::Tensor(), NOT_CONFORMING};
+    at::Tensor qdd = at::empty({B, n}, q.options());
+    int64_t rc = 0;
+    if (B > 0) {
+        const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+        at::Tensor scratch;
+        if (need > 0) scratch = at::empty({need}, q.options());
+        rc = reinterpret_cast<fd_fn>(fn)(reinterpret_cast<const void *>(walk), q.data_ptr<float>(), qd.data_ptr<float>(), f.data_ptr<float>(), B,
+                                         (int32_t)flags, qdd.data_ptr<float>(), need > 0 ? scratch.data_ptr<float>() : nullptr,
+                                         reinterpret_cast<void *>(stream));
+    }
+    return {qdd, rc};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("crba", &crba);
+    m.def("forward_dynamics", &forward_dynamics);
     m.attr("NOT_CONFORMING") = NOT_CONFORMING;
     m.def("fk", &fk);
     m.def("fk_jacobian", &fk_jacobian);

@@ -163,7 +163,8 @@ def test_host_work_in_cxx_is_the_python_host_path(cpu_library, hostcall_module, 
 
     def results(*args):
         return [m.compute_forward_kinematics(args[0], link), m.compute_endeffector_jacobian(args[0], link),
-                (m.compute_inverse_dynamics(*args),), (m.compute_non_linear_effects(args[0], args[1]),)]
+                (m.compute_inverse_dynamics(*args),), (m.compute_non_linear_effects(args[0], args[1]),),
+                (m.compute_lagrangian_inertia_matrix(args[0]),), (m.compute_forward_dynamics(*args),)]
 
     fast = results(q, qd, qdd)
     monkeypatch.setattr(backend, "_hostcall", None)
