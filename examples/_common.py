@@ -34,3 +34,9 @@ def graphed(step, optimizer, warmup=3):
     with torch.cuda.graph(graph):
         loss = step()
     return lambda: (graph.replay(), loss)[1]
+
+
+def sync(device):
+    """Wait for the device's queued work (a HIP device; nothing to wait for on the CPU, where calls return when they are done)."""
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()

@@ -44,7 +44,7 @@ def run(batch=4096, epochs=300, lr=1e-3, spd=False, use_graph=False, device="cud
             opt.zero_grad(set_to_none=True)
             return step()
     history = []
-    torch.cuda.synchronize()
+    _common.sync(device)
     t0 = time.perf_counter()
     for epoch in range(epochs):
         loss = run_step()
@@ -52,7 +52,7 @@ def run(batch=4096, epochs=300, lr=1e-3, spd=False, use_graph=False, device="cud
             history.append(float(loss.detach()))
             if verbose:
                 print("epoch %5d  loss %.4e" % (epoch, history[-1]))
-    torch.cuda.synchronize()
+    _common.sync(device)
     if verbose:
         print("%.1f us per step = %.0f it/s (%s)" % ((time.perf_counter() - t0) / epochs * 1e6, epochs / (time.perf_counter() - t0),
                                                    "hipGraph" if use_graph else "eager"))

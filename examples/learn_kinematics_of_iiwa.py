@@ -40,7 +40,7 @@ def run(batch=16384, epochs=300, lr=1e-2, use_graph=False, device="cuda", verbos
             opt.zero_grad(set_to_none=True)
             return step()
     history = []
-    torch.cuda.synchronize()
+    _common.sync(device)
     t0 = time.perf_counter()
     for epoch in range(epochs):
         loss = run_step()
@@ -48,7 +48,7 @@ def run(batch=16384, epochs=300, lr=1e-2, use_graph=False, device="cuda", verbos
             history.append(float(loss.detach()))
             if verbose:
                 print("epoch %5d  loss %.3e" % (epoch, history[-1]))
-    torch.cuda.synchronize()
+    _common.sync(device)
     if verbose:
         print("%.1f us per step (%s)" % ((time.perf_counter() - t0) / epochs * 1e6, "hipGraph" if use_graph else "eager"))
         print("learned trans      ", model._bodies[model._name_to_idx_map["iiwa_link_1"]].trans().detach().cpu().numpy().ravel())

@@ -40,3 +40,14 @@ def test_learn_dynamics_example(spd, use_graph):
 def test_learn_forward_dynamics_example():
     hist = load("learn_forward_dynamics_iiwa").run(batch=1024, epochs=120, verbose=False)
     assert hist[-1] < 0.3 * hist[0]
+
+
+def test_examples_learn_on_the_cpu_device_too(cpu_library):
+    """The reference's examples run on the CPU (its default device); so do these, through libdrm_cpu.so: the same three learning
+    loops, smaller, and the losses fall."""
+    hist = load("learn_kinematics_of_iiwa").run(batch=1024, epochs=60, device="cpu", verbose=False)
+    assert hist[-1] < 0.2 * hist[0]
+    hist = load("learn_dynamics_iiwa").run(batch=256, epochs=60, lr=3e-2, device="cpu", verbose=False)
+    assert hist[-1] < 0.8 * hist[0]
+    hist = load("learn_forward_dynamics_iiwa").run(batch=256, epochs=60, device="cpu", verbose=False)
+    assert hist[-1] < 0.3 * hist[0]
