@@ -125,7 +125,23 @@ std::tuple<at::Tensor, int64_t> forward_dynamics(int64_t fn, int64_t scratch_que
     return {qdd, rc};
 }
 
+// K launches of a PREPARED drm_fk_jacobian call (backend.FkJacobianPlan: fixed buffers, raw addresses), enqueued back to back from
+// C++: what a compiled caller's loop does (a Python loop spends ~5.5 us per launch in the interpreter and ctypes, more than the
+// kernel takes).  Returns the first non-zero return code, or 0.
+int64_t repeat_fk_jacobian(int64_t fn, int64_t walk, int64_t q, int64_t B, int64_t pos, int64_t quat, int64_t lin, int64_t ang, int64_t stream,
+                           int64_t K) {
+    for (int64_t k = 0; k < K; ++k) {
+        const int rc = reinterpret_cast<fk_jacobian_fn>(fn)(reinterpret_cast<const void *>(walk), reinterpret_cast<const float *>(q), B,
+                                                            reinterpret_cast<float *>(pos), reinterpret_cast<float *>(quat),
+                                                            reinterpret_cast<float *>(lin), reinterpret_cast<float *>(ang),
+                                                            reinterpret_cast<void *>(stream));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("repeat_fk_jacobian", &repeat_fk_jacobian, pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("crba", &crba);
     m.def("forward_dynamics", &forward_dynamics);
     m.attr("NOT_CONFORMING") = NOT_CONFORMING;
