@@ -45,7 +45,6 @@ The JSON line also carries
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time

@@ -20,7 +20,6 @@ import shutil
 import subprocess
 from typing import Dict, Optional
 
-import numpy as np
 
 from .flatten import OPI_DOF, WalkProgram
 

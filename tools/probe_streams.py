@@ -2,7 +2,7 @@
 """The metric launch (Panda FK + Jacobian, 65 536 rows) as INDEPENDENT batches in flight on S streams: a hipGraph of K launches
 dealt round-robin to S captured side streams, each with its own inputs and outputs — what a caller with several independent
 batches (particle sets, parallel MPC problems) gets, against the one-after-the-other replay of bench.py (S = 1)."""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
