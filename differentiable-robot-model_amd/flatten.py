@@ -171,7 +171,7 @@ OPI_DOF, OPI_PERM, OPI_CTRL, OPI_SRC, OPI_SAVE, OPI_OUT, OPI_LINK, OPI_FLAGS, OP
 SRC_PREV, SRC_ROOT = -1, -2          # >= 0: read parent state from that save slot
 FLAG_CHILD_IS_NEXT = 1               # op k+1 is a child of op k (RNEA backward carry)
 MAX_SLOTS = 16                       # save slots available to a walk (forward kernels)
-MAX_SLOTS_BACKWARD = 4               # ... and to the backward kernels (3-bit fields of the packed control word)
+MAX_SLOTS_BACKWARD = 6               # ... and to the backward kernels (the 3-bit source field of the packed control word addresses slots 0 .. 5)
 MAX_OPS_BACKWARD = 64                # largest walk the backward kernels take (DRM_MAX_OPS)
 MAX_SEGMENTS = 8                     # independent root-level sub-walks a dynamics launch fans out over (DRM_MAX_SEGMENTS)
 MAX_DOFS = 64                        # DoF columns addressable by one walk

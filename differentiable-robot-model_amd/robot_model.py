@@ -473,9 +473,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         return mask
 
     def _differentiable(self, dw: _DeviceWalk) -> None:
-        """The backward kernels take walks of up to 64 links and 4 nested branch points (any joint model)."""
+        """The backward kernels take walks of up to 64 links and 6 branch points (any joint model)."""
         if not dw.program.backward_ok:
-            raise NotImplementedError("gradients need a walk of <= 64 links with <= 4 nested branch points (this one: %d links, "
+            raise NotImplementedError("gradients need a walk of <= 64 links with <= 6 branch points (this one: %d links, "
                                       "%d slots)" % (dw.program.n_ops, dw.program.n_slots))
 
     def _require_device(self):

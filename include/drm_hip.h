@@ -113,7 +113,7 @@ extern "C" {
 #define DRM_SRC_ROOT (-2) /* parent = the fixed root link (identity pose, zero velocity)       */
 #define DRM_FLAG_CHILD_IS_NEXT 1 /* op k+1 is a child of op k                                  */
 #define DRM_MAX_SLOTS 16  /* save slots a walk may use in the forward kernels (kept in LDS)    */
-#define DRM_MAX_SLOTS_BACKWARD 4 /* ... and in the backward kernels (3-bit fields of DRM_OPI_CTRL) */
+#define DRM_MAX_SLOTS_BACKWARD 6 /* ... and in the backward kernels (what the 3-bit source field of DRM_OPI_CTRL addresses: slots 0 .. 5) */
 #define DRM_MAX_OPS 64    /* largest walk the BACKWARD kernels and drm_walk_table take; the forward kernels are bounded
                              by the LDS their per-link records need (DRM_ERR_UNSUPPORTED beyond that, ~70 links) */
 #define DRM_MAX_SEGMENTS 8 /* independent sub-walks (sub-trees hanging off the fixed root) a dynamics launch fans out

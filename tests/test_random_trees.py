@@ -392,3 +392,50 @@ def test_gpu_generated_arm_with_hand_vs_oracle(tmp_path, P, K, L):
           / (2 * e) * g).sum(axis=1)
     mine = (tq.grad.cpu().numpy().astype(np.float64) * v).sum(axis=1)
     assert np.abs(mine - fd).max() <= 2e-3 * max(1.0, float(np.abs(fd).max())), (P, K, L, float(np.abs(mine - fd).max()))
+
+
+# ---------------------------------------------------------------------------------------------- bushy trees: five branch points
+BUSHY_SEEDS = [137, 225, 231, 292]      # (of seeds 100 .. 399: the trees whose whole-tree walk has five branch points)
+
+
+def _bushy_gradients(m, seed, device):
+    """(gradients of a weighted torque sum w.r.t. q / qd / qdd, gradient of a position sum of the last link w.r.t. q)"""
+    q, qd, qdd = (torch.from_numpy(a).to(device) for a in sample_states(m, 70, seed=seed))
+    w = torch.from_numpy(np.random.default_rng(seed).standard_normal((70, m._n_dofs)).astype(np.float32)).to(device)
+    xs = [t.clone().requires_grad_(True) for t in (q, qd, qdd)]
+    (m.compute_inverse_dynamics(*xs, include_gravity=True, use_damping=True) * w).sum().backward()
+    x = q.clone().requires_grad_(True)
+    poses = m.compute_forward_kinematics_all_links(x)
+    sum(p[0].sum() for p in poses.values()).backward()
+    return [t.grad.cpu() for t in xs] + [x.grad.cpu()], (q, qd, qdd, w)
+
+
+@pytest.mark.parametrize("seed", BUSHY_SEEDS)
+def test_cpu_reverse_mode_on_trees_with_five_branch_points(tmp_path, seed, cpu_library):
+    """The backward walks take up to six branch points (the slots the control word's source field addresses); until round 4 the
+    limit was four and these trees were refused.  Reverse-mode inverse dynamics on the CPU build against a central difference of
+    the fp64 oracle along a random direction."""
+    m = tree_model(tmp_path, seed, "cpu")
+    dw = m._dynamics_walk()
+    assert dw.program.n_slots == 5 and dw.program.backward_ok
+    grads, (q, qd, qdd, w) = _bushy_gradients(m, seed, "cpu")
+    orc = Oracle(m._spec)
+    q64, qd64, qdd64 = (t.numpy().astype(np.float64) for t in (q, qd, qdd))
+    dirs = [np.random.default_rng(seed + 1 + i).standard_normal(q64.shape) for i in range(3)]
+    f = lambda a, b, c: float((orc.rnea(a, b, c, True, True, np.float64) * w.numpy()).sum())
+    h = 1e-5
+    fd = (f(q64 + h * dirs[0], qd64 + h * dirs[1], qdd64 + h * dirs[2]) - f(q64 - h * dirs[0], qd64 - h * dirs[1], qdd64 - h * dirs[2])) / (2 * h)
+    an = sum(float((g.numpy() * d).sum()) for g, d in zip(grads[:3], dirs))
+    assert abs(an - fd) <= 2e-3 * (1 + abs(fd)), (seed, an, fd)
+    assert torch.isfinite(grads[3]).all() and float(grads[3].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", BUSHY_SEEDS[:2])
+def test_gpu_reverse_mode_on_trees_with_five_branch_points(tmp_path, seed, cpu_library):
+    """The same gradients from the kernels (rnea_backward_kernel / fk_backward_kernel with five slots in LDS) against the CPU build
+    of the same walks."""
+    host, _ = _bushy_gradients(tree_model(tmp_path, seed, "cpu"), seed, "cpu")
+    dev_, _ = _bushy_gradients(tree_model(tmp_path, seed, "cuda"), seed, "cuda")
+    for a, b in zip(dev_, host):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), seed
