@@ -195,3 +195,17 @@ def test_host_work_in_cxx_is_the_python_host_path(cpu_library, hostcall_module, 
     assert rc == -2
     with pytest.raises(backend.KernelUnsupported):
         backend._check(rc, cpu_library)
+
+
+def test_cpu_fingertips_in_one_call(cpu_library):
+    """compute_forward_kinematics_links (drm_fk_fanout_links of the host build: a chain walk per fingertip, link-major outputs) gives
+    what the per-link calls give."""
+    for robot, tips, n in (("allegro_left", ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"], 16),
+                           ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"], 9)):
+        m = load_model(robot, "cpu")
+        q = torch.rand(300, n, generator=torch.Generator().manual_seed(1)) - 0.5
+        out = m.compute_forward_kinematics_links(q, tips)
+        pairs = list(out.values()) if isinstance(out, dict) else list(out)
+        for tip, (pos, quat) in zip(tips, pairs):
+            p2, q2 = m.compute_forward_kinematics(q, tip)
+            assert torch.equal(pos, p2) and torch.equal(quat, q2), (robot, tip)
