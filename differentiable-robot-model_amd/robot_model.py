@@ -543,12 +543,20 @@ class DifferentiableRobotModel(torch.nn.Module):
         pose is two small tensors of its own."""
         out = {}
         B = q.shape[0]
-        if 0 in link_idxs:      # (read-only views of two constants: no kernel, no memory)
+        # (the walk order of a set of links is found once per set: the per-call Python work of a 13-link dictionary was ~10x the
+        # kernel's time at 65 536 rows)
+        plans = self.__dict__.setdefault("_fk_links_plans", {})
+        key = tuple(link_idxs)
+        plan = plans.get(key)
+        if plan is None:
+            wanted = set(int(i) for i in link_idxs if i != 0)
+            ordered = [i for i in self._spec.preorder() if i in wanted]
+            plan = plans[key] = (0 in link_idxs, ordered)
+        has_root, ordered = plan
+        if has_root:            # (read-only views of two constants: no kernel, no memory)
             if self._root_pose is None:
                 self._root_pose = (torch.zeros(1, 3, device=self._device), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self._device))
             out[0] = (self._root_pose[0].expand(B, 3), self._root_pose[1].expand(B, 4))
-        wanted = set(int(i) for i in link_idxs if i != 0)
-        ordered = [i for i in self._spec.preorder() if i in wanted]
         if ordered:
             dw = self._get_walk(("fk", tuple(ordered)), targets=ordered) if len(ordered) > 1 else None
             if dw is not None and not (torch.is_grad_enabled() and (q.requires_grad or self._ops_f(dw).requires_grad)):
@@ -561,12 +569,10 @@ class DifferentiableRobotModel(torch.nn.Module):
                     pos, quat = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs, link_major=True)
                 else:
                     pos, quat = backend.fk_links(dw.program, self._ops_f(dw), dw.ops_i, q, len(ordered), self._n_dofs)
-                for k, i in enumerate(ordered):
-                    out[i] = (pos[k], quat[k])
+                out.update(zip(ordered, zip(pos.unbind(0), quat.unbind(0))))      # (one unbind per array instead of an index op per link)
                 return out
             pos, quat = self._fk_targets(q, ordered)
-            for k, i in enumerate(ordered):
-                out[i] = (pos[:, k], quat[:, k])
+            out.update(zip(ordered, zip(pos.unbind(1), quat.unbind(1))))
         return out
 
     def _fk_targets(self, q: torch.Tensor, link_idxs: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -607,8 +613,12 @@ class DifferentiableRobotModel(torch.nn.Module):
         """{link_name: (pos [B,3], quat_xyzw [B,4])} for every link (robot_model.py:197-221)."""
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
-        cols = self._fk_links(q, list(range(len(self._bodies))))
-        return {self._bodies[i].name: cols[i] for i in range(len(self._bodies))}
+        names = self.__dict__.get("_body_names")
+        if names is None:       # (ModuleList indexing costs ~3 us per link and call)
+            names = self.__dict__["_body_names"] = [b.name for b in self._bodies]
+            self.__dict__["_all_link_idxs"] = list(range(len(names)))
+        cols = self._fk_links(q, self.__dict__["_all_link_idxs"])
+        return {name: cols[i] for i, name in enumerate(names)}
 
     @tensor_check
     def compute_forward_kinematics_links(self, q: torch.Tensor, link_names: List[str]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:

@@ -10,7 +10,10 @@ m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
 q, qd, qdd = (t.cuda() for t in sample(m, 65536))
 calls = {"compute_forward_kinematics": lambda: m.compute_forward_kinematics(q, link),
          "compute_endeffector_jacobian": lambda: m.compute_endeffector_jacobian(q, link),
-         "compute_inverse_dynamics": lambda: m.compute_inverse_dynamics(q, qd, qdd)}
+         "compute_inverse_dynamics": lambda: m.compute_inverse_dynamics(q, qd, qdd),
+         "compute_forward_kinematics_all_links": lambda: m.compute_forward_kinematics_all_links(q),
+         "compute_lagrangian_inertia_matrix": lambda: m.compute_lagrangian_inertia_matrix(q),
+         "compute_forward_dynamics": lambda: m.compute_forward_dynamics(q, qd, qdd)}
 N = 3000
 for name, fn in calls.items():
     for _ in range(50):
@@ -23,7 +26,7 @@ for name, fn in calls.items():
             fn()
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / N * 1e6)
-    print("%-32s %6.2f us per eager call (wall, %d calls, one synchronize at the end)" % (name, best, N))
+    print("%-38s %6.2f us per eager call (wall, %d calls, one synchronize at the end)" % (name, best, N))
 if len(sys.argv) > 1 and sys.argv[1] == "profile":
     for name, fn in calls.items():
         pr = cProfile.Profile()
