@@ -403,11 +403,18 @@ def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
     lib = _lib_of(q, "q", chains[0][1])
     q = _dev_f32(q, "q", n_dofs)
     B, T = q.shape[0], len(chains)
-    pos = torch.empty((T, B, 3) if link_major else (B, T, 3), device=q.device, dtype=torch.float32)
-    quat = torch.empty((T, B, 4) if link_major else (B, T, 4), device=q.device, dtype=torch.float32)
+    pos, quat = _outputs(q.device, (T, B, 3) if link_major else (B, T, 3), (T, B, 4) if link_major else (B, T, 4))
     if B == 0:
         return pos, quat
-    walks = (DrmWalk * T)(*[_walk_struct(p, f.detach(), i, n_dofs) for p, f, i in chains])
+    # the array of the chains' structs is kept on the first chain's program while the tables stay where they are (building it —
+    # four 248-byte structs through ctypes — took 20 us of a call whose kernel takes 4)
+    key = (n_dofs,) + tuple(f.data_ptr() for _, f, _ in chains)
+    cached = getattr(chains[0][0], "_fan_cache", None)
+    if cached is not None and cached[0] == key:
+        walks = cached[1]
+    else:
+        walks = (DrmWalk * T)(*[_walk_struct(p, f, i, n_dofs) for p, f, i in chains])
+        chains[0][0]._fan_cache = (key, walks)
     with _on_device(q.device):
         _check((lib.drm_fk_fanout_links if link_major else lib.drm_fk_fanout)(
             walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)), lib)
