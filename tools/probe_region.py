@@ -36,6 +36,17 @@ for where in ("default stream", "a created stream"):
         for _ in range(K):
             plan.launch()
     modes["hipGraph replay"] = lambda: g.replay()
+   # the same K launches as a SHORT graph followed by the rest: the doorbell rings after the first packets are written
+   for head in (1, 2, 4):
+    if head < K:
+        gh, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gh):
+            for _ in range(head):
+                plan.launch()
+        with torch.cuda.graph(gt):
+            for _ in range(K - head):
+                plan.launch()
+        modes["two graphs: %d + %d" % (head, K - head)] = (lambda a, b: (lambda: (a.replay(), b.replay())))(gh, gt)
    for name, fn_ in modes.items():
     name = name + " / " + where
     for _ in range(5):
