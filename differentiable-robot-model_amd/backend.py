@@ -756,6 +756,25 @@ class FkJacobianPlan(object):
         return self.pos, self.quat, self.lin, self.ang
 
 
+def fk_rnea(tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int):
+    """(tau [B, n], pos [B, 3], quat [B, 4]) of ONE eager drm_fk_rnea call through the C++ host path, or None when that path is not
+    there / the inputs are not what the kernels take as they are (the caller then goes through FkInverseDynamicsPlan)."""
+    fast = hostcall()
+    if fast is None or not hasattr(fast, "fk_rnea") or not isinstance(qd, torch.Tensor) or not (qdd is None or isinstance(qdd, torch.Tensor)):
+        return None
+    lib = _lib_of(q, "q", tree[1])
+    wt, wc = _walk_struct(tree[0], tree[1], tree[2], n_dofs), _walk_struct(chain[0], chain[1], chain[2], n_dofs)
+    flags = (RNEA_GRAVITY if include_gravity else 0) | (RNEA_DAMPING if use_damping else 0)
+    with _on_device(q.device):
+        tau, pos, quat, rc = fast.fk_rnea(_fn_addr(lib, "drm_fk_rnea"), _fn_addr(lib, "drm_rnea_scratch_floats_aligned"), ctypes.addressof(wt),
+                                          ctypes.addressof(wc), int(target_op), q, qd, qdd, n_dofs, flags, _stream_int(q.device))
+    if rc > 0:
+        return None
+    if rc:
+        _check(rc, lib)
+    return tau, pos, quat
+
+
 class FkInverseDynamicsPlan(object):
     """A prepared drm_fk_rnea launch on fixed buffers: q, qd, qdd -> tau and the pose (pos, quat) of one link.  For a
     serial 7-DoF arm whose last link is the target (Franka Panda, KUKA iiwa) that is ONE fused kernel; BASELINE

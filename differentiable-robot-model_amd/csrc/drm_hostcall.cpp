@@ -19,6 +19,8 @@ typedef int (*fk_jacobian_fn)(const void *, const float *, int64_t, float *, flo
 typedef int (*rnea_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
 typedef int64_t (*scratch_fn)(const void *, int64_t);
 typedef int (*crba_fn)(const void *, const float *, int64_t, float *, float *, void *);
+typedef int (*fk_rnea_fn)(const void *, const void *, int32_t, const float *, const float *, const float *, int64_t, int32_t, float *, float *,
+                          float *, float *, void *);
 typedef int (*fd_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
 
 inline int64_t pad4(int64_t x) { return (x + 3) & ~int64_t(3); } // every output starts on a 16-byte boundary
@@ -125,6 +127,32 @@ std::tuple<at::Tensor, int64_t> forward_dynamics(int64_t fn, int64_t scratch_que
     return {qdd, rc};
 }
 
+// (tau [B, n], pos [B, 3], quat [B, 4], rc): drm_fk_rnea — inverse dynamics and the pose of one link from one pass over q
+std::tuple<at::Tensor, at::Tensor, at::Tensor, int64_t> fk_rnea(int64_t fn, int64_t scratch_query, int64_t tree, int64_t chain, int64_t target_op,
+                                                               const at::Tensor &q, const at::Tensor &qd, const c10::optional<at::Tensor> &qdd,
+                                                               int64_t n, int64_t flags, int64_t stream) {
+    const bool has_qdd = qdd.has_value() && qdd->defined();
+    if (!conforms(q, n) || !conforms(qd, n) || (has_qdd && !conforms(*qdd, n))) return {at::Tensor(), at::Tensor(), at::Tensor(), NOT_CONFORMING};
+    const int64_t B = q.size(0);
+    if (qd.size(0) != B || (has_qdd && qdd->size(0) != B) || qd.device() != q.device() || (has_qdd && qdd->device() != q.device()))
+        return {at::Tensor(), at::Tensor(), at::Tensor(), NOT_CONFORMING};
+    const int64_t o1 = pad4(B * n), o2 = o1 + pad4(B * 3);
+    at::Tensor flat = at::empty({o2 + pad4(B * 4)}, q.options());
+    at::Tensor tau = flat.as_strided({B, n}, {n, 1}, 0), pos = flat.as_strided({B, 3}, {3, 1}, o1), quat = flat.as_strided({B, 4}, {4, 1}, o2);
+    int64_t rc = 0;
+    if (B > 0) {
+        const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(tree), B);
+        at::Tensor scratch;
+        if (need > 0) scratch = at::empty({need}, q.options());
+        float *base = flat.data_ptr<float>();
+        rc = reinterpret_cast<fk_rnea_fn>(fn)(reinterpret_cast<const void *>(tree), reinterpret_cast<const void *>(chain), (int32_t)target_op,
+                                              q.data_ptr<float>(), qd.data_ptr<float>(), has_qdd ? qdd->data_ptr<float>() : nullptr, B,
+                                              (int32_t)flags, base, base + o1, base + o2, need > 0 ? scratch.data_ptr<float>() : nullptr,
+                                              reinterpret_cast<void *>(stream));
+    }
+    return {tau, pos, quat, rc};
+}
+
 // K launches of a PREPARED drm_fk_jacobian call (backend.FkJacobianPlan: fixed buffers, raw addresses), enqueued back to back from
 // C++: what a compiled caller's loop does (a Python loop spends ~5.5 us per launch in the interpreter and ctypes, more than the
 // kernel takes).  Returns the first non-zero return code, or 0.
@@ -143,6 +171,7 @@ int64_t repeat_fk_jacobian(int64_t fn, int64_t walk, int64_t q, int64_t B, int64
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("repeat_fk_jacobian", &repeat_fk_jacobian, pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("crba", &crba);
+    m.def("fk_rnea", &fk_rnea);
     m.def("forward_dynamics", &forward_dynamics);
     m.attr("NOT_CONFORMING") = NOT_CONFORMING;
     m.def("fk", &fk);

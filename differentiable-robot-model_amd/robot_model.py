@@ -760,6 +760,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         a single pass over q (not differentiable; use the two separate methods under autograd)."""
         assert q.ndim == 2 and qd.ndim == 2 and qdd_des.ndim == 2
         assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs and qdd_des.shape[1] == self._n_dofs
+        idx = self._name_to_idx_map[link_name]
+        if idx != 0 and not self._learnable:      # one eager call through the C++ host path (no plan object per call)
+            self._require_device()
+            tree = self._dynamics_walk()
+            chain = self._get_walk(("chain", idx) + (("folded", tree.fold_key) if tree.folded else ()), targets=[idx],
+                                   folded=tree.folded, fold_key=tree.fold_key)
+            out = backend.fk_rnea((tree.program, self._ops_f(tree), tree.ops_i), (chain.program, self._ops_f(chain), chain.ops_i),
+                                  int(tree.program.op_of_link.get(idx, -1)), q.detach(), qd.detach(), qdd_des.detach(),
+                                  bool(include_gravity), bool(use_damping), self._n_dofs)
+            if out is not None:
+                return out
         plan = self.plan_fk_and_inverse_dynamics(q.detach(), qd.detach(), qdd_des.detach(), link_name,
                                                  bool(include_gravity), bool(use_damping))
         with backend._on_device(self._device):

@@ -13,7 +13,8 @@ calls = {"compute_forward_kinematics": lambda: m.compute_forward_kinematics(q, l
          "compute_inverse_dynamics": lambda: m.compute_inverse_dynamics(q, qd, qdd),
          "compute_forward_kinematics_all_links": lambda: m.compute_forward_kinematics_all_links(q),
          "compute_lagrangian_inertia_matrix": lambda: m.compute_lagrangian_inertia_matrix(q),
-         "compute_forward_dynamics": lambda: m.compute_forward_dynamics(q, qd, qdd)}
+         "compute_forward_dynamics": lambda: m.compute_forward_dynamics(q, qd, qdd),
+         "compute_fk_and_inverse_dynamics": lambda: m.compute_fk_and_inverse_dynamics(q, qd, qdd, link)}
 N = 3000
 for name, fn in calls.items():
     for _ in range(50):
