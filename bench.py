@@ -75,10 +75,6 @@ def parse_args(argv=None):
                          "(default: nothing).  --config 3: which mode the headline `value` is timed with — none (default: the "
                          "outputs stay sharded, the MPC / particle case), all (every rank gets tau | pos | quat of every row), root "
                          "(rank 0 only), tau (all-gather of the torques only); every mode is timed and reported under gather_modes")
-    ap.add_argument("--graph-collectives", action="store_true",
-                    help="--config 3, backend nccl: capture kernel + RCCL collective of the K steps into ONE hipGraph (a step is one "
-                         "~8 us kernel and one collective: launched eagerly it pays both enqueues on the host every step).  Opt-in: "
-                         "no multi-GPU node was available to try RCCL under stream capture on this stack")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
@@ -404,17 +400,27 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
     wall, dev_time, graphed = timed_graph_region(step, K, stream, barrier, use_graph=not args.no_graph and gathered is None)
     wall, dev_time = reduce_max([wall, dev_time])
 
-    verified = None
+    verified, vs_whole = None, None
     if args.verify_gather and gathered is not None:
         step()
         torch.cuda.synchronize()
         ok = 1
-        if rank == 0:   # every rank's q again (same seeds), ONE single-rank launch over all rows, bit-for-bit comparison
-            whole = model.plan_fk_and_jacobian(torch.cat([sample_q(model, B, device, 1234 + r)[0] for r in range(world)]), link)
+        if rank == 0:
+            # every rank's q again (same seeds).  The gather is held BIT FOR BIT to launches of the shard size (what the ranks
+            # ran: the C ABI picks a kernel form by launch size, and two forms may differ in the last bit of a row), and the
+            # same rows as ONE single-rank launch over all of them are reported beside it (bit-equal or not, max |difference|).
+            qs = [sample_q(model, B, device, 1234 + r)[0] for r in range(world)]
+            for r, qr in enumerate(qs):
+                shard = model.plan_fk_and_jacobian(qr, link)
+                shard.launch()
+                torch.cuda.synchronize()
+                for got, want in zip(gathered, shard.outputs()):
+                    ok &= int(torch.equal(got[r * B:(r + 1) * B], want))
+            whole = model.plan_fk_and_jacobian(torch.cat(qs), link)
             whole.launch()
             torch.cuda.synchronize()
-            for got, want in zip(gathered, whole.outputs()):
-                ok &= int(torch.equal(got, want))
+            vs_whole = {"bit_equal": all(torch.equal(g, w_) for g, w_ in zip(gathered, whole.outputs())),
+                        "max_abs": max(float((g - w_).abs().max()) for g, w_ in zip(gathered, whole.outputs()))}
         verified = bool(ok)
     bytes_per_eval = 4 * (n + 7 + 6 * n)            # q in; pos, quat, lin_jac, ang_jac out
     launch_s = dev_time / K                         # average duration of one launch, HIP events on the launch stream
@@ -428,7 +434,7 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         "value": world * B * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "gather_verified": verified,
-        "distributed": test_mode_fields(args, world),
+        "gather_vs_whole_launch": vs_whole, "distributed": test_mode_fields(args, world),
         "config": {"workload": "Franka Panda 7-DoF (panda_no_gripper), FK + end-effector geometric Jacobian to "
                                "panda_virtual_ee_link, batch=%d per GPU, q~U(joint limits), inputs resident in HBM"
                                % B if args.robot == "panda_no_gripper" else "%s FK+Jacobian batch=%d" % (args.robot, B),
@@ -605,8 +611,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     for _ in range(W):
         step()
     torch.cuda.synchronize()
-    # the compute of a step alone (graph of K launches), then the full step of every exchange mode: compute + collective as ONE
-    # replayed hipGraph where RCCL lets itself be captured (backend nccl), eagerly otherwise (gloo test mode; a failed capture)
+    # the compute of a step alone (graph of K launches), then the full step of every exchange mode (compute + collective)
     _, dev_compute, _ = timed_graph_region(compute, K, stream, barrier, use_graph=not args.no_graph)
     modes = {}
     for mode in (["none"] if world == 1 else ["none", "tau", "root", "all"]):
@@ -614,15 +619,16 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
-        capture = world > 1 and mode != "none" and args.backend == "nccl" and args.graph_collectives and not args.no_graph
-        w_, d_, graphed = timed_graph_region(fn, K, stream, barrier, use_graph=capture or (mode == "none" and not args.no_graph))
+        # (a step with a collective is launched eagerly: RCCL under stream capture has never run on this stack — no multi-GPU
+        # node, and RCCL refuses two ranks on one device — so there is no switch for it)
+        w_, d_, graphed = timed_graph_region(fn, K, stream, barrier, use_graph=mode == "none" and not args.no_graph)
         w_, d_ = reduce_max([w_, d_])
         modes[mode] = {"ms_per_step": w_ / K * 1e3, "value": G * K / w_, "step_us_device": d_ / K * 1e6, "hipgraph": bool(graphed),
                        "gather_bytes_per_rank": 0 if mode == "none" else rows * 4 * (n if mode == "tau" else width),
                        "gather_model_us": gather_model_us(mode, rows * width * 4, rows * n * 4, world)}
     wall, dev_time = modes[headline]["ms_per_step"] * K * 1e-3, modes[headline]["step_us_device"] * K * 1e-6
     (dev_compute,) = reduce_max([dev_compute])
-    verified = None
+    verified, vs_whole = None, None
     if args.verify_gather and world > 1:
         # rank 0 rebuilds EVERY rank's inputs (same seeds), runs them as ONE single-rank launch over all 2^20 rows and holds
         # the gathered buffers to it bit for bit: rank r's tau | pos | quat blocks at gathered[r * rows * width:] (all-gather,
@@ -632,12 +638,25 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         torch.cuda.synchronize()
         ok = 1
         if rank == 0:
+            # The gathered buffers are held BIT FOR BIT to launches of the SHARD size (what the ranks ran: the C ABI picks a kernel
+            # form by launch size — 131 072-row shards take the latency form, 2^20 rows the streaming form — and two forms may
+            # differ in the last bit of a row); the same rows as ONE launch over all of them are reported beside it.
             parts = [config3_inputs(model, rows, device, 4321 + r) for r in range(world)]
+            outs = []
+            for p_ in parts:
+                shard = model.plan_fk_and_inverse_dynamics(p_[0], p_[1], p_[2], link)
+                shard.launch()
+                torch.cuda.synchronize()
+                outs.append([t.clone() for t in shard.outputs()])
+            tau_w, pos_w, quat_w = (torch.cat([o[i] for o in outs]) for i in range(3))
             qa, qda, qdda = (torch.cat([p[i] for p in parts]) for i in range(3))
             whole = model.plan_fk_and_inverse_dynamics(qa, qda, qdda, link)
             whole.launch()
             torch.cuda.synchronize()
-            tau_w, pos_w, quat_w = whole.outputs()
+            pairs = list(zip((tau_w, pos_w, quat_w), whole.outputs()))
+            vs_whole = {"bit_equal": all(torch.equal(a, b.reshape(a.shape)) for a, b in pairs),
+                        "max_abs": max(float((a - b.reshape(a.shape)).abs().max()) for a, b in pairs),
+                        "tau_max_rel": float(((pairs[0][0] - pairs[0][1]).abs() / pairs[0][1].abs().clamp_min(1.0)).max())}
             def blocks_ok():
                 good = 1
                 for r in range(world):
@@ -678,7 +697,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         "value": G * K / wall, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "gather_verified": verified,
-        "distributed": test_mode_fields(args, world),
+        "gather_vs_whole_launch": vs_whole, "distributed": test_mode_fields(args, world),
         "config": {"workload": "Franka Panda 7-DoF, FK(panda_virtual_ee_link) + RNEA inverse dynamics (gravity, damping), "
                                "global batch %d = %d rows per GPU, q~U(limits), qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); "
                                "one fused drm_fk_rnea launch per step; exchange mode of the headline value: %s" % (G, rows, headline),

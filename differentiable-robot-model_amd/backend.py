@@ -798,6 +798,8 @@ class FkInverseDynamicsPlan(object):
             for t, cols in ((self.tau, n_dofs), (self.pos, 3), (self.quat, 4)):
                 if t.shape != (B, cols) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                     raise ValueError("outputs must be contiguous float32 [B, %d] tensors on the inputs' device" % cols)
+                if t.data_ptr() & 15:     # (the scratch below is sized by the *_aligned query, which assumes 16-byte aligned pointers)
+                    raise ValueError("outputs must start on a 16-byte boundary (slice the shared buffer at multiples of 4 floats)")
         self._keep = (tree[1], tree[2], chain[1], chain[2])
         self._tree = _walk_struct(tree[0], tree[1].detach(), tree[2], n_dofs)
         self._chain = _walk_struct(chain[0], chain[1].detach(), chain[2], n_dofs)

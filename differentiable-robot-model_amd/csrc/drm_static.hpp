@@ -509,8 +509,9 @@ template <int n, int d = 0>
 __device__ __forceinline__ void rows_to_stage(const float *__restrict__ tile_base, uint32_t lane_bytes, float *stage) {
     if constexpr (d < n) {
         const uint32_t lds = (uint32_t)(uintptr_t)(stage + d * WAVE); // (the low half of a generic LDS pointer is the LDS address)
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1 offset:%3" ::"v"(lane_bytes), "s"(tile_base), "s"(lds), "n"(d * 4)
-                     : "memory", "m0");
+        // No instruction offset: the ISA adds `offset:` to the LDS address as well as to the global one (LDS_ADDR = M0 base +
+        // inst_offset + lane * 4), so element d rides on the scalar base (tile_base + d: one s_add_u32 / s_addc_u32) instead.
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_bytes), "s"(tile_base + d), "s"(lds) : "memory", "m0");
         rows_to_stage<n, d + 1>(tile_base, lane_bytes, stage);
     }
 }

@@ -23,6 +23,7 @@
 // the forces of the mass-matrix walk).
 #pragma once
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -232,6 +233,14 @@ static int ensure_lds_tree(K kernel, size_t bytes) {
 // How many blocks of `kernel` (threads per block, dynamic LDS bytes) the current device holds at once: the grid of the
 // PERSISTENT kernels, whose blocks loop over tiles and own a slice of caller-provided scratch each.  The runtime's own
 // occupancy rule (LDS, registers) per CU times the number of CUs; cached per kernel, geometry and device.
+// DRM_MAX_RESIDENT_BLOCKS (environment, read per query): clamps the grid of every persistent kernel, so that tests reach the
+// several-tiles-per-wavefront paths (LDS staging of the next tile, partial sums carried across tiles) with small batches.
+static inline int clamp_resident(int blocks) {
+    const char *e = getenv("DRM_MAX_RESIDENT_BLOCKS");
+    if (!e || !*e) return blocks;
+    const long v = strtol(e, nullptr, 10);
+    return v >= 1 && v < blocks ? (int)v : blocks;
+}
 template <class K>
 static int resident_blocks(K kernel, int threads, size_t lds, int &out) {
     static std::mutex mu;
@@ -248,7 +257,7 @@ static int resident_blocks(K kernel, int threads, size_t lds, int &out) {
             return fail(DRM_ERR_LAUNCH, "occupancy query failed");
         it = cache.emplace(key, per_cu * cus).first;
     }
-    out = it->second;
+    out = clamp_resident(it->second);
     return DRM_OK;
 }
 // the same for a kernel of a loaded code object (drm_walk.special[]: per-robot kernels, one wavefront per block, static LDS)
@@ -267,7 +276,7 @@ static int resident_blocks_module(hipFunction_t fn, int threads, int &out) {
             return fail(DRM_ERR_LAUNCH, "occupancy query failed");
         it = cache.emplace(key, per_cu * cus).first;
     }
-    out = it->second;
+    out = clamp_resident(it->second);
     return DRM_OK;
 }
 

@@ -335,7 +335,8 @@ def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optiona
                     # (rigid_body.py:149-154, robot_model.py:356-358): there is nothing meaningful to reproduce
                     raise UnsupportedRobotError(
                         "joint of link %s has axis %s; the reference only handles +-unit x/y/z axes%s"
-                        % (names[i], a.tolist(), "" if reference_compat else " and a zero axis has no direction"))
+                        % (names[i], a.tolist(), " (pass reference_compat=False to the model for joints about their true axis)"
+                           if reference_compat and np.isfinite(norm) and norm >= 1e-6 else " and a zero axis has no direction"))
                 skew[i] = True
                 axis_rot[i] = axis_rotation(a).astype(np.float32)
                 axis_idx[i] = 2

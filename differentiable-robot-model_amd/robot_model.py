@@ -100,16 +100,17 @@ class _DeviceWalk:
 class DifferentiableRobotModel(torch.nn.Module):
     """Batched FK / geometric Jacobian / RNEA on MI355X behind the reference API."""
 
-    def __init__(self, urdf_path: str, name="", device=None, reference_compat: bool = False):
-        """``reference_compat=True`` models prismatic joints the way the reference does — as revolute joints about their
-        axis (robot_model.py:122-126) — for parity runs against it; by default they slide."""
+    def __init__(self, urdf_path: str, name="", device=None, reference_compat: bool = True):
+        """Same signature and defaults as the reference's constructor (robot_model.py:94-104): ``device=None`` is the CPU, and
+        every non-fixed joint is an axis-aligned revolute joint (robot_model.py:122-126, rigid_body.py:149-154), so a model
+        built the reference's way returns the reference's numbers for every URDF the reference accepts.
+        ``reference_compat=False`` opts into what the URDF says instead: prismatic joints slide and joints turn about their
+        true (possibly skew) axis."""
         super().__init__()
         self.name = name
         self._reference_compat = bool(reference_compat)
         if device is None:
-            # the reference defaults to CPU (robot_model.py:100-104); this engine is built for the HIP device, so pick it when
-            # there is one (a CPU model computes through the host build of the same library, csrc/drm_cpu.cpp)
-            device = "cuda" if torch.cuda.is_available() else "cpu"
+            device = "cpu"      # robot_model.py:100-104 (pass device="cuda" for the HIP kernels; nothing falls back either way)
         self._device = torch.device(device)
         if self._device.type == "cuda" and self._device.index is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
@@ -145,22 +146,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._kin_cache = {}
 
         self._spec: RobotSpec = build_robot_spec(body_params, parent_names, reference_compat=self._reference_compat)
-        if not self._reference_compat:
-            # a drop-in user should know where this engine deliberately departs from upstream's numbers
-            from .flatten import KIND_PRISMATIC
-            sliding = [b.name for i, b in enumerate(self._bodies) if self._spec.kind[i] == KIND_PRISMATIC]
-            skew = [b.name for i, b in enumerate(self._bodies) if self._spec.skew[i]]
-            if (sliding or skew) and os.path.abspath(urdf_path) not in _WARNED_URDFS:
-                # once per URDF file and process (models are built in loops and on every rank), pointing at the USER's call:
-                # a subclass constructor (DifferentiableFrankaPanda) adds one frame
+        if self._reference_compat:
+            # the reference's joint model is the default; tell a user whose URDF has a sliding joint what that means (once per
+            # URDF file and process: models are built in loops and on every rank), pointing at the USER's call
+            sliding = [b.name for i, b in enumerate(self._bodies) if body_params[i]["joint_type"] == "prismatic"]
+            if sliding and os.path.abspath(urdf_path) not in _WARNED_URDFS:
                 _WARNED_URDFS.add(os.path.abspath(urdf_path))
                 import warnings
                 warnings.warn(
-                    "%s: %s modelled as what the URDF says (prismatic joints slide, joints turn about their true axis); the "
-                    "reference treats every non-fixed joint as an axis-aligned revolute joint (robot_model.py:122-126, "
-                    "rigid_body.py:149-154), so FK / Jacobians / dynamics of these links differ from upstream's.  Pass "
-                    "reference_compat=True for upstream's numbers." % (os.path.basename(urdf_path),
-                                                                       ", ".join(sliding + skew)),
+                    "%s: prismatic joint(s) of %s modelled as REVOLUTE joints, as the reference does (robot_model.py:122-126) "
+                    "— upstream's numbers, not the mechanism's.  Pass reference_compat=False for joints that slide (and for "
+                    "joint axes that are not +-x / y / z)." % (os.path.basename(urdf_path), ", ".join(sliding)),
                     stacklevel=2 if type(self) is DifferentiableRobotModel else 3)
         self._learnable = set()          # {(link_idx, parameter_name)}
         self._walks: Dict[tuple, _DeviceWalk] = {}

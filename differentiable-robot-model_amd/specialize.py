@@ -182,30 +182,87 @@ def hipcc() -> Optional[str]:
     return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
 
 
+_CC_ID: Dict[str, str] = {}
+
+
+def compiler_id(cc: str) -> str:
+    """What identifies the compiler in the cache key: the text of `hipcc --version` (asked once per process)."""
+    if cc not in _CC_ID:
+        done = subprocess.run([cc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        _CC_ID[cc] = hashlib.sha256(done.stdout).hexdigest()[:8]
+    return _CC_ID[cc]
+
+
+def target_arch() -> str:
+    """The ISA the code objects are built for: DRM_SPECIAL_ARCH, else the current HIP device's (gfx950 on an MI355X; also the
+    answer on a machine without a device, e.g. when a cache is prepared for export)."""
+    arch = os.environ.get("DRM_SPECIAL_ARCH")
+    if arch:
+        return arch
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName.split(":")[0]
+    except Exception:       # noqa: BLE001  (no device, no torch: the product's one target)
+        pass
+    return "gfx950"
+
+
 def build(src: str) -> str:
-    """Path of the code object of `src` (compiled once per content + header hash)."""
+    """Path of the code object of `src`: drm_special_<source key>_<compiler key>.hsaco in the cache directory.  The source key
+    covers the generated text, the headers it includes, the flags and the target ISA; the compiler key `hipcc --version`.  A
+    machine WITHOUT hipcc takes any code object with the right source key (a cache exported by `export_cache` from a build
+    machine).  Several processes may build the same robot at once (the ranks of one node): each compiles to its own temporary
+    name and publishes with an atomic rename, so nobody ever loads a half-written file."""
+    import glob
+    import tempfile
     extra = os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
-    h = hashlib.sha256((src + " ".join(extra)).encode())
+    arch = target_arch()
+    h = hashlib.sha256((src + " ".join(extra) + arch).encode())
     for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     key = h.hexdigest()[:20]
-    out = os.path.join(cache_dir(), "drm_special_%s.hsaco" % key)
-    if os.path.exists(out):
-        return out
     cc = hipcc()
     if cc is None:
-        raise SpecializeError("hipcc not found: per-robot kernels need the ROCm compiler on this machine")
-    cpp = os.path.join(cache_dir(), "drm_special_%s.hip" % key)
-    with open(cpp, "w") as f:
-        f.write(src)
-    cmd = [cc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-w",
-           "-I", CSRC, "-o", out + ".tmp", cpp] + extra
-    done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    if done.returncode != 0 or not os.path.exists(out + ".tmp"):
-        raise SpecializeError("hipcc failed on the robot's kernels:\n%s" % done.stderr.decode()[-2000:])
-    os.replace(out + ".tmp", out)
+        shipped = sorted(glob.glob(os.path.join(cache_dir(), "drm_special_%s_*.hsaco" % key)))
+        if shipped:
+            return shipped[0]
+        raise SpecializeError("hipcc not found and %s holds no code object for this robot (drm_special_%s_*.hsaco): build it "
+                              "on a machine with the ROCm compiler and copy the cache (specialize.export_cache)" % (cache_dir(), key))
+    out = os.path.join(cache_dir(), "drm_special_%s_%s.hsaco" % (key, compiler_id(cc)))
+    if os.path.exists(out):
+        return out
+    fd, cpp = tempfile.mkstemp(prefix="drm_special_%s_" % key, suffix=".hip", dir=cache_dir())
+    tmp = cpp[:-4] + ".hsaco.tmp"
+    try:
+        with os.fdopen(fd, "w") as f:
+            f.write(src)
+        cmd = [cc, "--genco", "--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-w",
+               "-I", CSRC, "-o", tmp, cpp] + extra
+        done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if done.returncode != 0 or not os.path.exists(tmp):
+            raise SpecializeError("hipcc failed on the robot's kernels:\n%s" % done.stderr.decode()[-2000:])
+        os.replace(tmp, out)          # (atomic; a concurrent builder's identical file may already be there: same content)
+    finally:
+        for leftover in (cpp, tmp):
+            try:
+                os.remove(leftover)
+            except OSError:
+                pass
     return out
+
+
+def export_cache(dest: str) -> list:
+    """Copy every code object of this machine's cache into `dest` (created if missing) — for deployment machines without the ROCm
+    compiler: ship the directory and point DRM_SPECIAL_CACHE at it; `build` there finds the robots' kernels by their source key."""
+    import glob
+    os.makedirs(dest, exist_ok=True)
+    copied = []
+    for path in sorted(glob.glob(os.path.join(cache_dir(), "drm_special_*.hsaco"))):
+        shutil.copy2(path, os.path.join(dest, os.path.basename(path)))
+        copied.append(os.path.basename(path))
+    return copied
 
 
 def attach(prog: WalkProgram, spec, n_dofs: int) -> Dict[int, int]:
@@ -245,6 +302,8 @@ def tune(prog: WalkProgram, ops_f, ops_i, n_dofs: int, batch: int = 1 << 19, mar
     handles = dict(getattr(prog, "_special", None) or {})
     if not handles:
         return {}
+    import copy
+    shared, prog = prog, copy.copy(prog)     # timed on a PRIVATE copy: other threads / plans keep seeing the shared program's handles
     dev = ops_f.device
     g = torch.Generator(device="cpu").manual_seed(0)
     q, qd, x = ((torch.rand(batch, n_dofs, generator=g) - 0.5).to(dev) for _ in range(3))
@@ -284,5 +343,6 @@ def tune(prog: WalkProgram, ops_f, ops_i, n_dofs: int, batch: int = 1 << 19, mar
             if keep:
                 kept[kind] = handle
     finally:
-        with_handles(kept)
+        shared._special = kept       # one assignment at the end (plans built before it keep the struct they snapshotted)
+        shared._ws_cache = None
     return report

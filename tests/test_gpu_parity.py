@@ -406,7 +406,7 @@ def test_fk_and_inverse_dynamics_one_call(robot, link, B):
 
 def test_fk_and_inverse_dynamics_plan_under_hipgraph_config3_shard():
     """BASELINE configuration 3, one GPU's shard of 2^20 (131 072 rows) and the full 2^20: the fused plan replayed from a
-    hipGraph against the separate calls (bit-exact) and 4 096 random rows against the oracle."""
+    hipGraph against the separate calls (bit-exact) and EVERY row against the oracle."""
     m = load_model("panda_no_gripper", "cuda")
     ee = "panda_virtual_ee_link"
     orc = Oracle(m._spec)
@@ -425,12 +425,71 @@ def test_fk_and_inverse_dynamics_plan_under_hipgraph_config3_shard():
         assert torch.equal(plan.tau, m.compute_inverse_dynamics(q, qd, qdd))
         p2, r2 = m.compute_forward_kinematics(q, ee)
         assert torch.equal(plan.pos, p2) and torch.equal(plan.quat, r2)
-        sel = torch.randperm(B, generator=torch.Generator().manual_seed(2))[:4096].cuda()
-        q64, qd64, qdd64 = (host(a[sel]).astype(np.float64) for a in (q, qd, qdd))
-        rp, rq = orc.fk(q64, [8], np.float64)
-        assert max_err(host(plan.pos[sel]), rp[:, 0]) <= TOL_POS["atol"]
-        assert quat_close(host(plan.quat[sel]), rq[:, 0], TOL_QUAT["atol"])[0]
-        assert np.allclose(host(plan.tau[sel]), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+        for lo in range(0, B, 1 << 17):      # EVERY row against the fp64 oracle, 131 072 at a time
+            sl = slice(lo, lo + (1 << 17))
+            q64, qd64, qdd64 = (host(a[sl]).astype(np.float64) for a in (q, qd, qdd))
+            rp, rq = orc.fk(q64, [8], np.float64)
+            assert max_err(host(plan.pos[sl]), rp[:, 0]) <= TOL_POS["atol"]
+            assert quat_close(host(plan.quat[sl]), rq[:, 0], TOL_QUAT["atol"])[0]
+            assert np.allclose(host(plan.tau[sl]), orc.rnea(q64, qd64, qdd64, True, True, np.float64), **TOL_TAU)
+
+
+def test_eight_shards_against_one_launch():
+    """What `bench.py --verify-gather` meets on an 8-GPU node, rehearsed on one: the rows of a global batch computed as 8
+    launches of the shard size against ONE launch over all of them.  The C ABI picks a kernel form by launch size — 65 536-row
+    shards of the metric take the register-resident-table form and 524 288 rows the plain one (csrc/drm_arm_kernels.hip
+    launch_fk_jacobian_arm); 131 072-row shards of configuration 3 take the latency form of fk_rnea_arm2_kernel and 2^20 rows
+    the streaming form (csrc/drm_arm_dynamics.hip launch_fk_rnea_arm) — so this is the test that says whether the two agree bit
+    for bit.  Asserted: a shard launched twice is bit-identical (what the gather check in bench.py relies on), and shards and
+    whole agree within a few ulp (what `gather_vs_whole_launch` reports); bit-equality of the forms is printed, not required."""
+    m = load_model("panda_no_gripper", "cuda")
+    ee = "panda_virtual_ee_link"
+    # metric: 8 x 65 536 against 524 288
+    q = dev(sample_states(m, 8 * 65536, seed=11)[0])
+    whole = m.plan_fk_and_jacobian(q, ee)
+    whole.launch()
+    torch.cuda.synchronize()
+    names = ("pos", "quat", "lin_jac", "ang_jac")
+    report = {}
+    for r in range(8):
+        sl = slice(r * 65536, (r + 1) * 65536)
+        shard = m.plan_fk_and_jacobian(q[sl].contiguous(), ee)
+        shard.launch()
+        torch.cuda.synchronize()
+        first = [t.clone() for t in shard.outputs()]
+        shard.launch()
+        torch.cuda.synchronize()
+        for name, a, b, w in zip(names, first, shard.outputs(), whole.outputs()):
+            assert torch.equal(a, b), name
+            d = float((a - w[sl]).abs().max())
+            report["metric " + name] = max(report.get("metric " + name, 0.0), d)
+            if name == "quat":                      # (a last-bit difference of R on a case boundary may pick the other sign)
+                assert quat_close(host(a), host(w[sl]), 2e-6)[0], (name, r, d)
+            else:
+                assert d <= 2e-6, (name, r, d)      # (entries are O(1): a few ulp)
+    # configuration 3: 8 x 131 072 against 2^20
+    q, qd, qdd = (dev(a) for a in sample_states(m, 1 << 20, seed=12, vel=0.4, acc=0.8))
+    whole = m.plan_fk_and_inverse_dynamics(q, qd, qdd, ee)
+    whole.launch()
+    torch.cuda.synchronize()
+    for r in range(8):
+        sl = slice(r << 17, (r + 1) << 17)
+        shard = m.plan_fk_and_inverse_dynamics(q[sl].contiguous(), qd[sl].contiguous(), qdd[sl].contiguous(), ee)
+        shard.launch()
+        torch.cuda.synchronize()
+        first = [t.clone() for t in shard.outputs()]
+        shard.launch()
+        torch.cuda.synchronize()
+        for name, a, b, w in zip(("tau", "pos", "quat"), first, shard.outputs(), whole.outputs()):
+            assert torch.equal(a, b), name
+            w = w[sl].reshape(a.shape)
+            d = float(((a - w).abs() / w.abs().clamp_min(1.0)).max())
+            report["config3 " + name] = max(report.get("config3 " + name, 0.0), d)
+            if name == "quat":
+                assert quat_close(host(a), host(w), 2e-6)[0], (name, r, d)
+            else:
+                assert d <= (2e-5 if name == "tau" else 2e-6), (name, r, d)
+    print("shards vs one launch, max deviation:", {k: ("bit-equal" if v == 0.0 else "%.2e" % v) for k, v in report.items()})
 
 
 @pytest.mark.parametrize("robot,link", [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee")])
@@ -862,6 +921,14 @@ def test_fused_plan_writes_into_caller_owned_output_blocks():
     assert not torch.isnan(flat).any()
     with pytest.raises(ValueError):
         m.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link", outputs=(outs[0], outs[1], outs[2][:, :3]))
+    # blocks that do not start on a 16-byte boundary are refused (the plan's scratch is sized for aligned pointers):
+    # a ragged batch (B % 64 != 0) whose tau block starts one float into the buffer
+    Br = 4099
+    qr, qdr, qddr = (dev(a) for a in sample_states(m, Br, seed=92))
+    odd = torch.empty(Br * (n + 7) + 1, device="cuda")[1:]
+    bad = (odd[:Br * n].view(Br, n), odd[Br * n:Br * (n + 3)].view(Br, 3), odd[Br * (n + 3):].view(Br, 4))
+    with pytest.raises(ValueError, match="16-byte"):
+        m.plan_fk_and_inverse_dynamics(qr, qdr, qddr, "panda_virtual_ee_link", outputs=bad)
 
 
 # ------------------------------------------------------------------ bench.py: the JSON line the round driver reads

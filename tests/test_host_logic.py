@@ -57,9 +57,9 @@ def test_lenient_xml_and_bad_robots(tmp_path):
     skew.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="revolute"><parent link="a"/>'
                     '<child link="b"/><axis xyz="0 0.7071 0.7071"/><limit lower="-1" upper="1" effort="1" velocity="1"/>'
                     '</joint></robot>')
-    with pytest.raises(UnsupportedRobotError):      # the reference cannot model this axis (rigid_body.py:149-154) ...
-        DifferentiableRobotModel(str(skew), device="cpu", reference_compat=True)
-    ok = DifferentiableRobotModel(str(skew), device="cpu")   # ... the engine does: the joint becomes two ops
+    with pytest.raises(UnsupportedRobotError, match="reference_compat=False"):   # the reference cannot model this axis
+        DifferentiableRobotModel(str(skew), device="cpu")                          # (rigid_body.py:149-154): the default refuses ...
+    ok = DifferentiableRobotModel(str(skew), device="cpu", reference_compat=False)  # ... the opt-in models it: the joint becomes two ops
     assert ok._spec.skew.tolist() == [False, True] and build_walk(ok._spec, whole_tree=True).n_ops == 2
     floating = tmp_path / "floating.urdf"
     floating.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="floating"><parent link="a"/>'
@@ -336,8 +336,9 @@ def test_gpu_scratch_of_the_persistent_kernels():
 
 
 def test_departures_from_the_reference_are_announced():
-    """A robot whose joints this engine models differently from upstream (prismatic joints that slide) says so once at
-    construction; reference_compat=True, and robots without such joints, stay silent."""
+    """The constructor's defaults are the reference's (device CPU, every non-fixed joint an axis-aligned revolute one); a robot
+    with a prismatic joint says once at construction that it is modelled upstream's way and names the opt-in;
+    reference_compat=False, and robots without such joints, stay silent."""
     import contextlib
     import io
     import warnings
@@ -347,11 +348,12 @@ def test_departures_from_the_reference_are_announced():
     rm._WARNED_URDFS.discard(os.path.abspath(path("panda")))     # (once per URDF and process: forget earlier tests' models)
     with warnings.catch_warnings(record=True) as seen, contextlib.redirect_stdout(io.StringIO()):
         warnings.simplefilter("always")
-        DifferentiableRobotModel(path("panda"), device="cpu")
-        DifferentiableRobotModel(path("panda"), device="cpu", reference_compat=True)
+        DifferentiableRobotModel(path("panda"))                                  # (the defaults: the reference's joint model)
+        DifferentiableRobotModel(path("panda"), device="cpu", reference_compat=False)
         DifferentiableRobotModel(path("iiwa7"), device="cpu")
     texts = [str(w.message) for w in seen if "reference_compat" in str(w.message)]
     assert len(texts) == 1 and "panda_leftfinger" in texts[0] and "robot_model.py:122-126" in texts[0]
+    assert "REVOLUTE" in texts[0] and "reference_compat=False" in texts[0]
 
 
 @pytest.mark.gpu

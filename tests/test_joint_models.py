@@ -67,6 +67,7 @@ def toy_path(tmp_path_factory):
 
 
 def toy_model(path, device="cpu", **kw):
+    kw.setdefault("reference_compat", False)     # (the joint models of the URDF: the opt-in; the default is the reference's)
     with contextlib.redirect_stdout(io.StringIO()):
         return DifferentiableRobotModel(path, device=device, **kw)
 

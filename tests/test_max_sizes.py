@@ -55,7 +55,7 @@ def chain_model(tmp_path, n_joints, device="cpu"):
     with open(path, "w") as f:
         f.write(chain_urdf(n_joints))
     with contextlib.redirect_stdout(io.StringIO()):
-        return DifferentiableRobotModel(path, device=device)
+        return DifferentiableRobotModel(path, device=device, reference_compat=False)
 
 
 def test_walk_capacity_follows_the_robot(tmp_path):

@@ -77,7 +77,7 @@ def tree_model(tmp_path, seed, device="cpu"):
     with open(path, "w") as f:
         f.write(tree_urdf(seed))
     with contextlib.redirect_stdout(io.StringIO()):
-        return DifferentiableRobotModel(path, device=device)
+        return DifferentiableRobotModel(path, device=device, reference_compat=False)
 
 
 def rel(a, ref):
@@ -344,7 +344,7 @@ def arm_hand_model(tmp_path, P, K, L, seed, device):
         f.write(arm_hand_urdf(P, K, L, seed))
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return DifferentiableRobotModel(path, device=device)
+        return DifferentiableRobotModel(path, device=device, reference_compat=False)
 
 
 def test_generated_arms_with_hands_have_the_shape_they_are_built_for(tmp_path):

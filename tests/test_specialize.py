@@ -6,6 +6,7 @@ CPU (not gpu): the tree decoded from the control words, the generated translatio
 GPU (-m gpu): inverse dynamics of Fetch (both joint models) and of random trees through their OWN kernels against the fp64 oracle
 and against the loop kernels; ragged batches, misaligned slices.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -311,6 +312,95 @@ def test_gpu_tuned_choice_between_shape_kernels_and_own_kernels(robot):
     for a, b in zip(*grads):
         assert float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max()))
     assert load_model("panda_no_gripper", "cuda").specialize(tune=True) == {}       # (plain 7-DoF arms keep their kernels)
+
+
+@contextlib.contextmanager
+def resident_blocks_clamped(n):
+    """DRM_MAX_RESIDENT_BLOCKS (csrc/drm_tree_dev.hpp clamp_resident): the grid of every persistent kernel held to n blocks, so a
+    small batch walks several tiles per wavefront."""
+    before = os.environ.get("DRM_MAX_RESIDENT_BLOCKS")
+    os.environ["DRM_MAX_RESIDENT_BLOCKS"] = str(n)
+    try:
+        yield
+    finally:
+        if before is None:
+            os.environ.pop("DRM_MAX_RESIDENT_BLOCKS", None)
+        else:
+            os.environ["DRM_MAX_RESIDENT_BLOCKS"] = before
+
+
+def _fetch_pair(compat, learnable=False):
+    import test_rnea_backward as rbt
+    mc = load_model("fetch", reference_compat=compat)
+    loop, own = load_model("fetch", "cuda", reference_compat=compat), load_model("fetch", "cuda", reference_compat=compat)
+    if learnable:
+        for m in (loop, own):
+            for link, pname in (("shoulder_lift_link", "mass"), ("torso_lift_link", "trans"), ("wrist_roll_link", "rot_angles")):
+                m.make_link_param_learnable(link, pname, rbt.parametrization(pname))
+        own.load_state_dict(loop.state_dict())
+        _specialized_backward(own)
+    else:
+        assert own.specialize() is True
+    return mc, loop, own
+
+
+def _own_vs_loop_every_entry_point(mc, loop, own, B, seed, oracle_rows=512):
+    """Inverse dynamics (with and without qdd), forward dynamics and the input + parameter gradients of the per-robot kernels against
+    the loop kernels on EVERY row; the first and the last `oracle_rows` rows also against the fp64 oracle (models without learnable links)."""
+    q, qd, qdd = sample_states(mc, B, seed=seed)
+    dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in (q, qd, qdd))
+    orc = Oracle(mc._spec)
+    f64 = lambda a: a.astype(np.float64)
+    ends = np.r_[0:oracle_rows, B - oracle_rows:B]
+    tau = own.compute_inverse_dynamics(dq, dqd, dqdd)
+    ref = loop.compute_inverse_dynamics(dq, dqd, dqdd)
+    tau, ref = tau.detach(), ref.detach()
+    assert np.allclose(tau.cpu().numpy(), ref.cpu().numpy(), **TOL_TAU), B
+    if not list(own.parameters()):      # (learnable links carry freshly drawn parameters, not the URDF's the oracle was built from)
+        assert np.allclose(tau.cpu().numpy()[ends], orc.rnea(f64(q[ends]), f64(qd[ends]), f64(qdd[ends]), True, True, np.float64), **TOL_TAU)
+    nle = own.compute_non_linear_effects(dq, dqd)
+    assert np.allclose(nle.detach().cpu().numpy(), loop.compute_non_linear_effects(dq, dqd).detach().cpu().numpy(), **TOL_TAU), B
+    acc = own.compute_forward_dynamics(dq, dqd, ref, include_gravity=True, use_damping=True).detach()
+    other = loop.compute_forward_dynamics(dq, dqd, ref, include_gravity=True, use_damping=True).detach()
+    err = float(((acc - other).abs() / (1.0 + other.abs())).max())
+    err_loop = float(((other - dqdd).abs() / (1.0 + dqdd.abs())).max())          # (forward dynamics undoes inverse dynamics)
+    assert err <= max(1e-3, 2.0 * err_loop), (B, err, err_loop)
+    want = torch.randn(B, own._n_dofs, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
+    grads = []
+    for m in (loop, own):
+        m.zero_grad()
+        xs = [t.clone().requires_grad_(True) for t in (dq, dqd, dqdd)]
+        torch.nn.functional.mse_loss(m.compute_inverse_dynamics(*xs), want).backward()
+        grads.append([x.grad for x in xs] + [p.grad.clone() for p in m.parameters()])
+    assert len(grads[0]) == len(grads[1])
+    for a, b in zip(*grads):
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 3e-4 * scale, (B, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("learnable", [False, True])
+def test_gpu_own_kernels_walk_several_tiles_per_wavefront(learnable):
+    """the persistent loops of the per-robot kernels — the next tile's rows staged in LDS by global_load_lds_dword
+    (rows_to_stage / rows_from_stage), the partial parameter sums a wavefront carries across its tiles — only run when a launch
+    has more tiles than resident wavefronts (B above ~65 k rows).  Here the grid is clamped to 3 blocks, so 11 tiles + a ragged
+    tail make every wavefront walk 3-4 tiles: rnea, non-linear effects, forward dynamics and the reverse mode of Fetch against
+    the loop kernels on every row."""
+    mc, loop, own = _fetch_pair(False, learnable)
+    with resident_blocks_clamped(3):
+        _own_vs_loop_every_entry_point(mc, loop, own, 11 * 64 + 29, seed=5, oracle_rows=128)
+    with resident_blocks_clamped(1):       # one wavefront walks every tile
+        _own_vs_loop_every_entry_point(mc, loop, own, 5 * 64, seed=6, oracle_rows=64)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_gpu_own_kernels_at_a_batch_beyond_the_resident_grid():
+    """The same at the size where it happens by itself: 2^18 + 77 rows of Fetch (4 097 tiles against at most 2 048 resident
+    wavefronts), no clamp."""
+    mc, loop, own = _fetch_pair(True, learnable=True)
+    _own_vs_loop_every_entry_point(mc, loop, own, (1 << 18) + 77, seed=7)
 
 
 def test_robots_with_a_compiled_shape_keep_it():
