@@ -21,7 +21,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 
@@ -36,7 +36,7 @@ class DrmWalk(ctypes.Structure):
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
                 ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
-                ("special", ctypes.c_void_p * 4)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
+                ("special", ctypes.c_void_p * 6)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
 
 
 class NativeLibraryError(RuntimeError):

@@ -6,6 +6,7 @@
 // is 6 % shorter WITH it and stays in drm_arm_kernels.hip).
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_arm_stream.hpp"
 
 namespace drm {
 
@@ -498,134 +499,37 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ?
 // with two wavefronts per SIMD the register file has room for it (<= 256 VGPRs) and nothing is parked in LDS.
 // LDS per wavefront: table 1 KB + tau / pos staging 3.5 KB + next rows 10.5 KB = 15 KB (eight wavefronts per CU: 120 KB).
 // ---------------------------------------------------------------------------------------------------
-// one array's rows of a 128-row tile (TILE2 * NJ floats = 3.5 KB for NJ = 7) from global memory into LDS, linear image
-template <int NJ>
-__device__ __forceinline__ void tile_rows_to_lds(const float *__restrict__ src, float *dst, unsigned lane) {
-    constexpr int BYTES = TILE2 * NJ * 4, FULL = BYTES / 1024, REST = BYTES % 1024; // 16 B per lane: 1 KB per instruction
-    static_assert(REST % 16 == 0, "whole 16-byte pieces");
-    const uint32_t voff = lane * 16u;
-    const uint32_t lds = (uint32_t)(uintptr_t)dst; // (the low half of a generic LDS pointer is the LDS address)
-    unsigned keep;
-#pragma unroll
-    for (int i = 0; i < FULL; ++i)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(src + i * 256), "s"(lds + i * 1024u) : "memory");
-    if constexpr (REST > 0) {
-        if (lane < (unsigned)(REST / 16))
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(src + FULL * 256), "s"(lds + FULL * 1024u) : "memory");
-    }
-}
-template <int NJ>
-__device__ __forceinline__ void rows_from_lds(const float *st, unsigned lane, f2 (&v)[NJ]) { // rows l and l + 64 of the tile
-#pragma unroll
-    for (int d = 0; d < NJ; ++d) v[d] = f2_make(st[lane * NJ + d], st[(WAVE + lane) * NJ + d]);
-}
-template <int CAP, int NJ, int LINKS, bool FK>
-#ifndef DRM_PIPE_WAVES_MIN
-#define DRM_PIPE_WAVES_MIN DRM_PIPE_WAVES
+#ifndef DRM_PIPE_PREF
+#define DRM_PIPE_PREF true
 #endif
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_PIPE_WAVES_MIN, DRM_PIPE_WAVES)))
+template <int CAP, int NJ, int LINKS, bool FK>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(DRM_PIPE_WAVES, DRM_PIPE_WAVES)))
     arm2_stream_kernel(const float *__restrict__ ops_f, const float *__restrict__ ops_tail, const float *__restrict__ q, const float *__restrict__ qd,
                        const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau, float *__restrict__ pos,
                        float *__restrict__ quat) {
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
-    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, T_FLOATS = round4(TILE2 * NJ), ROWS = TILE2 * NJ;
-    static_assert(TILE2 * 3 <= T_FLOATS && ROWS % 4 == 0, "the position tile fits into the staging area; 16-byte aligned arrays");
-    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + T_FLOATS + 3 * ROWS];
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, T_FLOATS = round4(STREAM_TILE * NJ), ROWS_F = STREAM_TILE * NJ;
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + T_FLOATS + 3 * ROWS_F];
+    float *lc = smem;
     const unsigned lane = threadIdx.x;
-    float *lc = smem, *lt = smem + C_FLOATS, *st = lt + T_FLOATS;
-    int tile = (int)blockIdx.x;
-    if (tile >= n_tiles) return;
-    auto stage = [&](int t) {
-        const int64_t base = (int64_t)t * ROWS;
-        tile_rows_to_lds<NJ>(q + base, st, lane);
-        tile_rows_to_lds<NJ>(qd + base, st + ROWS, lane);
-        if (qdd) tile_rows_to_lds<NJ>(qdd + base, st + 2 * ROWS, lane);
-    };
-    f2 qv[NJ], qdv[NJ], qddv[NJ], tv[NJ];
-    auto unstage = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged rows have landed (LDS-DMA is invisible to the compiler's counters)
-        wave_lds_sync();
-        rows_from_lds<NJ>(st, lane, qv);
-        rows_from_lds<NJ>(st + ROWS, lane, qdv);
-        rows_from_lds<NJ>(st + 2 * ROWS, lane, qddv); // (no branch: without qdd nothing was staged there and the reads are discarded)
-#pragma unroll
-        for (int d = 0; d < NJ; ++d) qddv[d] = qdd ? qddv[d] : f2_bcast(0.0f);
-
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... and are in registers before the staging area is written again
-    };
-    stage(tile);
-    // rows 0 .. LINKS-1 from the tree walk's table, the fixed tail the pose chain still walks from the chain walk's (fk_rnea_arm_kernel)
-    float4 cv = reinterpret_cast<const float4 *>(FK && lane >= LINKS * (DRM_OPF_STRIDE / 4) ? ops_tail : ops_f)[lane];
-    pin(cv);
-    reinterpret_cast<float4 *>(lc)[lane] = cv;
-    unstage();
-#pragma unroll 1
-    for (;;) {
-        // the table's address is laundered once per tile: its rows are loop-invariant LDS reads that provably alias nothing the loop
-        // writes, so the compiler would hoist all 200 of them out of the loop (and spill them: 256 VGPRs + 180 in scratch)
-        unsigned lcw = 0; // (an OFFSET, so that the reads stay ds_reads: a laundered pointer loses its address space and reads flat)
-        asm volatile("" : "+v"(lcw));
-        auto row = [&](int k) -> const float * { return lc + lcw + k * DRM_OPF_STRIDE; };
-        const int next = tile + (int)gridDim.x;
-        const bool more = next < n_tiles;
-#ifndef DRM_EXP_NO_STAGE
-        if (more) stage(next);
-#endif
-        const int64_t b0 = (int64_t)tile * TILE2;
-        f2 cs[NJ], sn[NJ];
-        chain_trig2<NJ>(qv, cs, sn);
-        if constexpr (FK) { // forward kinematics of the last link (robot_model.py:223-248)
-            Pose2 ee;
-            fk_chain2_trig<CAP, NJ>(row, cs, sn, ee);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                lt[lane * 3 + c] = ee.p[c][0];
-                lt[(WAVE + lane) * 3 + c] = ee.p[c][1];
-            }
-            wave_lds_sync();
-            tile_store<6>(pos + b0 * 3, WAVE, 6, 0u, lt, lane, true); // 128 rows of 3 floats
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float R[9], qt[4];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) R[i] = ee.R[i][h];
-                quat_xyzw(R, qt);
-                store16_wt(quat + (b0 + h * WAVE + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
-            }
-        }
-        // inverse dynamics (robot_model.py:305-375); nothing parked: KEEP2 = LINKS - 1
-#ifndef DRM_PIPE_KEEP
-#define DRM_PIPE_KEEP (LINKS - 1)
-#endif
-#ifndef DRM_PIPE_PREF
-#define DRM_PIPE_PREF true
-#endif
-        static_assert(DRM_PIPE_KEEP == LINKS - 1, "nothing parked");
-        rnea_chain2_trig<LINKS, NJ, DRM_PIPE_KEEP, DRM_PIPE_PREF>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, qddv, tv,
-                                                    [&](int, const Force2 &) {}, [&](int, Force2 &) {});
-        // tau is staged FIRST: it pins the sweeps above the wait below.  (With the tile's last use of tv behind a branch or behind the
-        // wait, the compiler sinks the whole dynamics arithmetic after it — the table reads cannot follow, so 200 constants sit in
-        // registers across the wait, 160 of them spilled, and the wait for the next tile's rows runs BEFORE the sweeps.)
-        wave_lds_sync(); // (the position tile has been read out of lt long ago: LDS runs a wave's instructions in order)
-#pragma unroll
-        for (int d = 0; d < NJ; ++d) {
-            lt[lane * NJ + d] = tv[d][0];
-            lt[(WAVE + lane) * NJ + d] = tv[d][1];
-        }
-        unstage(); // the next tile's rows into the (now dead) input registers — after the last tile: stale rows nobody uses
-        wave_lds_sync();
-        tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true);
-#ifdef DRM_EXP_ONE_ITER
-        break;
-#endif
-        if (!more) break;
-        tile = next;
-    }
+    arm2_stream_body<CAP, NJ, LINKS, FK, DRM_PIPE_PREF>(
+        [&] { // rows 0 .. LINKS-1 from the tree walk's table, the fixed tail the pose chain still walks from the chain walk's (fk_rnea_arm_kernel)
+            float4 cv = reinterpret_cast<const float4 *>(FK && lane >= LINKS * (DRM_OPF_STRIDE / 4) ? ops_tail : ops_f)[lane];
+            pin(cv);
+            reinterpret_cast<float4 *>(lc)[lane] = cv;
+        },
+        [&] {
+            // the table's address is laundered once per tile: its rows are loop-invariant LDS reads that provably alias nothing the
+            // loop writes, so the compiler would hoist all 200 of them out of the loop (and spill them).  An OFFSET is laundered, so
+            // that the reads stay ds_reads: a laundered pointer loses its address space and reads flat.
+            unsigned lcw = 0;
+            asm volatile("" : "+v"(lcw));
+            return [lc, lcw](int k) -> const float * { return lc + lcw + k * DRM_OPF_STRIDE; };
+        },
+        smem + C_FLOATS, q, qd, qdd, n_tiles, flags, tau, pos, quat);
 }
 // the grid of the streaming form: DRM_PIPE_WAVES wavefronts per SIMD on every CU of the current device (asked once per device)
-static int stream_grid(int n_tiles) {
+int arm_stream_grid(int n_tiles) {
     static int cached[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return n_tiles < 2048 ? n_tiles : 2048;
@@ -641,7 +545,7 @@ static int stream_grid(int n_tiles) {
 
 static void launch_rnea_arm2_stream(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n2, int flags,
                                     float *tau, hipStream_t s) {
-    const dim3 grid((unsigned)stream_grid(n2)), block(WAVE);
+    const dim3 grid((unsigned)arm_stream_grid(n2)), block(WAVE);
     if (links == 7)
         hipLaunchKernelGGL((arm2_stream_kernel<8, 7, 7, false>), grid, block, 0, s, ops_f, ops_f, q, qd, qdd, n2, flags, tau, (float *)nullptr, (float *)nullptr);
     else
@@ -654,7 +558,7 @@ void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, co
     const int n2 = n_tiles > TWO_SAMPLE_MIN_TILES ? n_tiles / 2 : 0; // pairs of 64-sample tiles: two samples per lane; an odd last tile: the one-sample kernel
     if (n2 > 0) {
 #define FK_RNEA2_(L, LATENCY) hipLaunchKernelGGL((fk_rnea_arm2_kernel<8, 7, L, LATENCY>), dim3((unsigned)n2), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat)
-#define FK_RNEA2S(L) hipLaunchKernelGGL((arm2_stream_kernel<8, 7, L, true>), dim3((unsigned)stream_grid(n2)), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat)
+#define FK_RNEA2S(L) hipLaunchKernelGGL((arm2_stream_kernel<8, 7, L, true>), dim3((unsigned)arm_stream_grid(n2)), dim3(WAVE), 0, s, ops_f, ops_tail, q, qd, qdd, n2, flags, tau, pos, quat)
 #define FK_RNEA2(L) do { if (n2 >= PIPE_MIN_TILES) FK_RNEA2S(L); else if (n2 <= LAT2_MAX_TILES) FK_RNEA2_(L, true); else FK_RNEA2_(L, false); } while (0)
         if (links == 7)
             FK_RNEA2(7);

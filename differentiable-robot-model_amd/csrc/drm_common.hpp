@@ -409,6 +409,12 @@ void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, flo
 inline int arm_links(const drm_walk *w) { return w->n_ops == w->n_dofs ? w->n_dofs : w->capacity; }
 int64_t launch_rnea_fingers(const drm_walk *w, const float *q, const float *qd, const float *qdd, int64_t B, int flags, float *tau,
                             hipStream_t s);
+// the grid of the streaming two-samples-per-lane arm kernels (csrc/drm_arm_stream.hpp): two wavefronts per SIMD on every CU
+int arm_stream_grid(int n_pairs);
+// launches of at least this many 128-row pairs of tiles run a walk's constant-folded arm kernel (drm_walk.special[DRM_SPECIAL_*_ARM])
+#ifndef DRM_ARM_STATIC_MIN_PAIRS
+#define DRM_ARM_STATIC_MIN_PAIRS 1024 /* 131 072 rows: one two-sample wavefront per SIMD */
+#endif
 void launch_rnea_arm(const float *ops_f, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,
                      float *tau, hipStream_t s);
 void launch_fk_rnea_arm(const float *ops_f, const float *ops_tail, int links, const float *q, const float *qd, const float *qdd, int n_tiles, int flags,

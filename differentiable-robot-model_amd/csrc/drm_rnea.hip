@@ -229,6 +229,19 @@ extern "C" int drm_rnea(const drm_walk *w, const float *q, const float *qd, cons
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         align == (AL_Q | AL_QD | AL_TAU | (qdd ? AL_QDD : 0u)) && (((uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the packed-FP32 chain kernel, ragged tail through the generic one
+        if (w->special[DRM_SPECIAL_RNEA_ARM] && B / (2 * WAVE) >= DRM_ARM_STATIC_MIN_PAIRS) {
+            // this arm's own kernel, its constants folded into the instruction stream (csrc/drm_arm_stream.hpp, specialize.py): the
+            // 128-row pairs of tiles; an odd tile and the ragged tail through the kernels below
+            int n_pairs = (int)(B / (2 * WAVE)), fl = (int)flags;
+            void *args[] = {(void *)&q, (void *)&qd, (void *)&qdd, (void *)&n_pairs, (void *)&fl, (void *)&tau};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA_ARM], (unsigned)arm_stream_grid(n_pairs), 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_arm_static): %s", hipGetErrorString(e));
+            const int64_t done = (int64_t)n_pairs * 2 * WAVE;
+            if (done == B) return DRM_OK;
+            drm_walk rest = *w;
+            rest.special[DRM_SPECIAL_RNEA_ARM] = nullptr;
+            return drm_rnea(&rest, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, tau + done * n, scratch, stream);
+        }
         const int n_tiles = (int)(B / WAVE);
         launch_rnea_arm(w->ops_f, arm_links(w), q, qd, qdd, n_tiles, (int)flags, tau, s);
         const int64_t done = (int64_t)n_tiles * WAVE;
@@ -316,6 +329,22 @@ extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t 
         chain->target_perm == 2 && B >= WAVE && B / WAVE < 0x7fffffffLL && (((uintptr_t)tree->ops_f) & 15u) == 0 &&
         (((uintptr_t)chain->ops_f) & 15u) == 0 &&
         align == (AL_Q | AL_QD | AL_TAU | AL_POS | AL_QUAT | (qdd ? AL_QDD : 0u))) {
+        if (tree->special[DRM_SPECIAL_FK_RNEA_ARM] && tree->special[DRM_SPECIAL_FK_RNEA_ARM] == chain->special[DRM_SPECIAL_FK_RNEA_ARM] &&
+            B / (2 * WAVE) >= DRM_ARM_STATIC_MIN_PAIRS) {
+            // the constant-folded fused kernel built for exactly this (dynamics walk, target chain) pair: the same handle on both
+            int n_pairs = (int)(B / (2 * WAVE)), fl = (int)flags;
+            void *args[] = {(void *)&q, (void *)&qd, (void *)&qdd, (void *)&n_pairs, (void *)&fl, (void *)&tau, (void *)&pos, (void *)&quat};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)tree->special[DRM_SPECIAL_FK_RNEA_ARM], (unsigned)arm_stream_grid(n_pairs), 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fk_rnea_arm_static): %s", hipGetErrorString(e));
+            const int64_t done = (int64_t)n_pairs * 2 * WAVE;
+            if (done == B) return DRM_OK;
+            drm_walk t2 = *tree, c2 = *chain;
+            t2.special[DRM_SPECIAL_FK_RNEA_ARM] = nullptr;
+            t2.special[DRM_SPECIAL_RNEA_ARM] = nullptr; // (a tail of less than a pair of tiles never reaches it anyway)
+            c2.special[DRM_SPECIAL_FK_RNEA_ARM] = nullptr;
+            return drm_fk_rnea(&t2, &c2, target_op, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, tau + done * n,
+                               pos + done * 3, quat + done * 4, scratch, stream);
+        }
         const int n_tiles = (int)(B / WAVE);
         launch_fk_rnea_arm(tree->ops_f, chain->ops_f, same ? arm_links(tree) : n, q, qd, qdd, n_tiles, (int)flags, tau, pos, quat, s);
         rc = launched();

@@ -295,10 +295,43 @@ class DifferentiableRobotModel(torch.nn.Module):
                 return {}
             sp.attach(dw.program, self._spec, self._n_dofs)
             return sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+        if not force and sp.arm_qualifies(dw.program, self._n_dofs):
+            # a serial 7-DoF arm (Panda, iiwa): its OWN kernels too, of a different kind — the library's streaming walk with this
+            # robot's constants folded into the instruction stream (specialize.attach_arm, csrc/drm_arm_stream.hpp).  Inverse
+            # dynamics now; the fused FK + RNEA kernel of a target link when plan_fk_and_inverse_dynamics /
+            # compute_fk_and_inverse_dynamics first meets it.  Constant models only (the kernels do not read the table).
+            if self._learnable:
+                return False
+            self._arm_specialized = True
+            sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs)
+            return True
         if not force and dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
             return False
         sp.attach(dw.program, self._spec, self._n_dofs)
         return True
+
+    def _arm_fused_special(self, tree: "_DeviceWalk", chain: "_DeviceWalk") -> None:
+        """After specialize() (or under DRM_SPECIALIZE=1) on a serial 7-DoF arm: build and attach, once per target chain, the
+        constant-folded fused FK + RNEA kernel of this (dynamics walk, chain walk) pair."""
+        if self._learnable or self._device.type != "cuda":
+            return
+        if not (getattr(self, "_arm_specialized", False) or os.environ.get("DRM_SPECIALIZE") in ("1", "tune")):
+            return
+        from . import specialize as sp
+        have = (getattr(tree.program, "_special", None) or {}).get(sp.SPECIAL_FK_RNEA_ARM)
+        if have is not None and have == (getattr(chain.program, "_special", None) or {}).get(sp.SPECIAL_FK_RNEA_ARM):
+            return
+        if getattr(chain.program, "_arm_special_failed", False):
+            return
+        if not (sp.arm_qualifies(tree.program, self._n_dofs) and sp.arm_qualifies(chain.program, self._n_dofs) and chain.program.n_ops == 8):
+            return
+        try:
+            sp.attach_arm(tree.program, self._ops_f(tree).detach().cpu().numpy(), self._n_dofs,
+                          chain.program, self._ops_f(chain).detach().cpu().numpy())
+        except sp.SpecializeError:
+            if getattr(self, "_arm_specialized", False):
+                raise
+            chain.program._arm_special_failed = True      # (environment opt-in on a machine without hipcc: the library's kernels)
 
     def _fold_key(self) -> tuple:
         """The links that must stay ops of their own (those with learnable parameters), as the key of a fold mask."""
@@ -331,7 +364,9 @@ class DifferentiableRobotModel(torch.nn.Module):
             from . import specialize as sp
             from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
             try:
-                if not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
+                if sp.arm_qualifies(dw.program, self._n_dofs) and not self._learnable:
+                    sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs)   # (constants folded in)
+                elif not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
                     sp.attach(dw.program, self._spec, self._n_dofs)
                 elif mode == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN and dw.program.n_ops <= sp.MAX_STATIC_OPS:
                     sp.attach(dw.program, self._spec, self._n_dofs)
@@ -742,6 +777,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         tree = self._dynamics_walk()
         chain = self._get_walk(("chain", idx) + (("folded", tree.fold_key) if tree.folded else ()), targets=[idx],
                                folded=tree.folded, fold_key=tree.fold_key)
+        self._arm_fused_special(tree, chain)
         return backend.FkInverseDynamicsPlan((tree.program, self._ops_f(tree), tree.ops_i),
                                              (chain.program, self._ops_f(chain), chain.ops_i),
                                              int(tree.program.op_of_link.get(idx, -1)),
@@ -762,6 +798,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             tree = self._dynamics_walk()
             chain = self._get_walk(("chain", idx) + (("folded", tree.fold_key) if tree.folded else ()), targets=[idx],
                                    folded=tree.folded, fold_key=tree.fold_key)
+            self._arm_fused_special(tree, chain)
             out = backend.fk_rnea((tree.program, self._ops_f(tree), tree.ops_i), (chain.program, self._ops_f(chain), chain.ops_i),
                                   int(tree.program.op_of_link.get(idx, -1)), q.detach(), qd.detach(), qdd_des.detach(),
                                   bool(include_gravity), bool(use_damping), self._n_dofs)
@@ -899,6 +936,11 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable_links = None
         for dw in self._walks.values():
             dw.static_ops_f = None
+            special = getattr(dw.program, "_special", None)
+            if special and (4 in special or 5 in special):     # constant-folded arm kernels (specialize.attach_arm) bake the OLD constants
+                dw.program._special = {k: v for k, v in special.items() if k not in (4, 5)}
+                dw.program._ws_cache = None
+        self._arm_specialized = False
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
         self._chain_walks.clear()
         self._dyn_walk = None

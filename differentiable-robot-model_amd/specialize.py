@@ -28,6 +28,11 @@ CSRC = os.path.join(HERE, "csrc")
 SPECIAL_RNEA, SPECIAL_CRBA, SPECIAL_FD, SPECIAL_RNEA_BACKWARD = 0, 1, 2, 3
 KERNELS = {SPECIAL_RNEA: "drm_rnea_static", SPECIAL_CRBA: "drm_crba_static", SPECIAL_FD: "drm_fd_static",
            SPECIAL_RNEA_BACKWARD: "drm_rnea_backward_static"}
+# (ABI 10) serial 7-DoF arms with the robot's constants folded into the instruction stream (csrc/drm_arm_stream.hpp)
+SPECIAL_RNEA_ARM, SPECIAL_FK_RNEA_ARM = 4, 5
+ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "drm_fk_rnea_arm_static"}
+# what folds the constants: x * 0 -> 0 and x + 0 -> x need "no NaN / Inf / signed zero" (nothing else of -ffast-math: no reassociation)
+ARM_FLAGS = ["-fno-signed-zeros", "-ffinite-math-only"]
 MAX_STATIC_OPS = 24        # beyond this the straight-line walk no longer fits the register file (loop kernels keep serving)
 
 
@@ -208,7 +213,7 @@ def target_arch() -> str:
     return "gfx950"
 
 
-def build(src: str) -> str:
+def build(src: str, flags=()) -> str:
     """Path of the code object of `src`: drm_special_<source key>_<compiler key>.hsaco in the cache directory.  The source key
     covers the generated text, the headers it includes, the flags and the target ISA; the compiler key `hipcc --version`.  A
     machine WITHOUT hipcc takes any code object with the right source key (a cache exported by `export_cache` from a build
@@ -216,10 +221,10 @@ def build(src: str) -> str:
     name and publishes with an atomic rename, so nobody ever loads a half-written file."""
     import glob
     import tempfile
-    extra = os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
+    extra = list(flags) + os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
     arch = target_arch()
     h = hashlib.sha256((src + " ".join(extra) + arch).encode())
-    for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp"):
+    for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp", "drm_arm_stream.hpp"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     key = h.hexdigest()[:20]
@@ -263,6 +268,83 @@ def export_cache(dest: str) -> list:
         shutil.copy2(path, os.path.join(dest, os.path.basename(path)))
         copied.append(os.path.basename(path))
     return copied
+
+
+def _literal(x) -> str:
+    """A float32 as a C hex-float literal (exact round trip; zeros as the plain 0.0f the compiler folds)."""
+    import numpy as np
+    x = np.float32(x)
+    if x == 0:
+        return "0.0f"
+    return "%sf" % float(x).hex()
+
+
+def arm_source(table, links: int, fused: bool) -> str:
+    """The translation unit of one serial 7-DoF arm: `table` = the [8, 32] float32 rows its streaming walk reads (rows < `links`
+    from the dynamics walk's table, the fixed tail the pose chain still walks from the chain walk's — what
+    csrc/drm_arm_dynamics.hip arm2_stream_kernel copies into LDS), written out as a constexpr array.  `fused`: the FK + RNEA
+    kernel of this (dynamics walk, target chain) pair; else inverse dynamics alone."""
+    import numpy as np
+    table = np.asarray(table, np.float32)
+    if table.shape != (8, 32) or links not in (7, 8):
+        raise SpecializeError("arm kernels are built for walks of capacity 8 with 7 or 8 dynamics ops")
+    rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in table)
+    name = ARM_KERNELS[SPECIAL_FK_RNEA_ARM if fused else SPECIAL_RNEA_ARM]
+    tail = ", float *pos, float *quat" if fused else ""
+    return """// generated by differentiable-robot-model_amd/specialize.py — one serial arm's walk table as compile-time constants
+#include "drm_arm_stream.hpp"
+namespace drm {
+static __device__ constexpr float ROBOT_OPS[8 * DRM_OPF_STRIDE] = {
+%s};
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+%s(const float *q, const float *qd, const float *qdd, int n_tiles, int flags, float *tau%s) {
+    constexpr int NJ = 7, T_FLOATS = drm::round4(drm::STREAM_TILE * NJ), ROWS_F = drm::STREAM_TILE * NJ;
+    __shared__ __attribute__((aligned(16))) float smem[T_FLOATS + 3 * ROWS_F];
+    drm::arm2_stream_body<8, NJ, %d, %s, false>([] {}, [] { return [](int k) -> const float * { return drm::ROBOT_OPS + k * DRM_OPF_STRIDE; }; },
+                                              smem, q, qd, qdd, n_tiles, flags, tau, %s);
+}
+""" % (rows, name, tail, links, "true" if fused else "false", "pos, quat" if fused else "nullptr, nullptr")
+
+
+def _load(path: str, kernel: str) -> int:
+    from . import backend
+    lib = backend.load_library()
+    fn = ctypes.c_void_p()
+    backend._check(lib.drm_special_load(path.encode(), kernel.encode(), ctypes.byref(fn)))
+    return fn.value
+
+
+def arm_qualifies(prog: WalkProgram, n_dofs: int) -> bool:
+    from .flatten import SHAPE_ARM_CHAIN
+    return bool(prog.shape & SHAPE_ARM_CHAIN) and prog.capacity == 8 and n_dofs == 7 and prog.n_ops in (7, 8)
+
+
+def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkProgram] = None, chain_table=None) -> Dict[int, int]:
+    """Build (hipcc ~2 s each, cached) and attach the constant-folded kernels of a serial 7-DoF arm: inverse dynamics on the
+    dynamics walk `tree` (its [8, 32] table as a host array), and — given the chain walk of an FK target whose last link is the
+    arm's last link — the fused FK + RNEA kernel of the pair, the SAME handle stored on both programs (drm_fk_rnea checks that).
+    A tree program keeps the fused kernel of the LAST chain it was paired with.  Constant models only: the kernels ignore ops_f."""
+    import numpy as np
+    if not arm_qualifies(tree, n_dofs):
+        raise SpecializeError("not a serial 7-DoF arm walk of capacity 8")
+    links = tree.n_ops
+    table = np.array(tree_table, np.float32, copy=True)
+    special = dict(getattr(tree, "_special", None) or {})
+    if SPECIAL_RNEA_ARM not in special:
+        special[SPECIAL_RNEA_ARM] = _load(build(arm_source(table, links, False), ARM_FLAGS), ARM_KERNELS[SPECIAL_RNEA_ARM])
+    if chain is not None:
+        if not (arm_qualifies(chain, n_dofs) and chain.n_ops == 8):
+            raise SpecializeError("the FK target's chain is not this arm's chain of 8 ops")
+        both = table.copy()
+        both[links:] = np.asarray(chain_table, np.float32)[links:]
+        handle = _load(build(arm_source(both, links, True), ARM_FLAGS), ARM_KERNELS[SPECIAL_FK_RNEA_ARM])
+        special[SPECIAL_FK_RNEA_ARM] = handle
+        cs = dict(getattr(chain, "_special", None) or {})
+        cs[SPECIAL_FK_RNEA_ARM] = handle
+        chain._special, chain._ws_cache = cs, None
+    tree._special, tree._ws_cache = special, None
+    return special
 
 
 def attach(prog: WalkProgram, spec, n_dofs: int) -> Dict[int, int]:

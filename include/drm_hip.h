@@ -41,15 +41,22 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 9
+#define DRM_ABI_VERSION 10
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
-#define DRM_SPECIAL_KINDS 4 /* drm_walk.special[]: */
+#define DRM_SPECIAL_KINDS 6 /* drm_walk.special[]: */
 #define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
 #define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   kernel drm_crba_static  */
 #define DRM_SPECIAL_FD 2     /*   forward dynamics             kernel drm_fd_static    */
 #define DRM_SPECIAL_RNEA_BACKWARD 3 /* reverse-mode inverse dynamics  kernel drm_rnea_backward_static, built with the walk's capacity
                                        as the pitch of its rows of partial sums */
+/* ABI 10: serial 7-DoF arms (DRM_WALK_ARM_CHAIN, capacity 8) with the robot's CONSTANTS folded into the instruction stream
+ * (csrc/drm_arm_stream.hpp instantiated on a constexpr copy of the walk table: products with exact zeros and ones are gone,
+ * no table in LDS).  They cover the 128-row tile pairs of a launch of at least DRM_ARM_STATIC_MIN_PAIRS pairs and ignore
+ * ops_f: the host guarantees that the table the handle was built from is the walk's (constant models only). */
+#define DRM_SPECIAL_RNEA_ARM 4    /* drm_rnea     kernel "drm_rnea_arm_static", arguments q, qd, qdd, n_pairs, flags, tau              */
+#define DRM_SPECIAL_FK_RNEA_ARM 5 /* drm_fk_rnea  kernel "drm_fk_rnea_arm_static", arguments q, qd, qdd, n_pairs, flags, tau, pos, quat;
+                                     the SAME handle on the tree walk and on the chain walk it was built for                */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

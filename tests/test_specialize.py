@@ -403,8 +403,119 @@ def test_gpu_own_kernels_at_a_batch_beyond_the_resident_grid():
     _own_vs_loop_every_entry_point(mc, loop, own, (1 << 18) + 77, seed=7)
 
 
-def test_robots_with_a_compiled_shape_keep_it():
-    """(CPU) specialize() is for trees the library has no straight-line kernel for; it needs a device model."""
+# ------------------------------------------------------------------------------------------------ serial 7-DoF arms: constants folded
+def test_arm_source_writes_the_table_as_exact_literals():
+    """(CPU) The generated translation unit of an arm: every float of the walk table as a hex-float literal that reads back
+    bit for bit, exact zeros as the plain 0.0f the compiler folds; rows >= links from the target chain's table."""
+    import re
+    m = load_model("panda_no_gripper")
+    dw = m._dynamics_walk()
+    assert sp.arm_qualifies(dw.program, m._n_dofs) and dw.program.n_ops == 7
+    table = m._ops_f(dw).detach().numpy()
+    src = sp.arm_source(table, 7, False)
+    assert "drm_rnea_arm_static" in src and "arm2_stream_body<8, NJ, 7, false, false>" in src
+    body = src[src.index("ROBOT_OPS[8 * DRM_OPF_STRIDE] = {") + 33:src.index("};")]
+    lits = [t.strip() for t in body.replace("\n", " ").split(",") if t.strip()]
+    assert len(lits) == 256
+    back = np.array([float.fromhex(t[:-1]) if t != "0.0f" else 0.0 for t in lits], np.float32).reshape(8, 32)
+    assert np.array_equal(back.view(np.uint32) & 0x7fffffff, table.view(np.uint32) & 0x7fffffff) and np.array_equal(back, table)
+    assert (back == 0).sum() > 100                       # (Panda: most of F, half of t and of the inertia rows are exact zeros)
+    cw = m._get_walk(("chain", 8, "folded", dw.fold_key), targets=[8], folded=True, fold_key=dw.fold_key)
+    fused = sp.arm_source(np.concatenate([table[:7], m._ops_f(cw).detach().numpy()[7:]]), 7, True)
+    assert "drm_fk_rnea_arm_static" in fused and "float *pos, float *quat" in fused and "<8, NJ, 7, true, false>" in fused
+    with pytest.raises(sp.SpecializeError):
+        sp.arm_source(table[:7], 7, False)
+
+
+@needs_hipcc
+def test_arm_source_builds(tmp_path, monkeypatch):
+    """(CPU) hipcc turns the arm's translation unit into a code object with both kernels' symbols; a machine without hipcc finds
+    the same robot's code object in an exported cache by its source key."""
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path))
+    m = load_model("iiwa7")
+    dw = m._dynamics_walk()
+    src = sp.arm_source(m._ops_f(dw).detach().numpy(), dw.program.n_ops, False)
+    path = sp.build(src, sp.ARM_FLAGS)
+    blob = open(path, "rb").read()
+    assert b"drm_rnea_arm_static" in blob and os.path.getsize(path) > 10000
+    shipped = tmp_path / "shipped"
+    assert sp.export_cache(str(shipped)) == [os.path.basename(path)]
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(shipped))
+    monkeypatch.setattr(sp, "hipcc", lambda: None)
+    assert sp.build(src, sp.ARM_FLAGS) == str(shipped / os.path.basename(path))
+    with pytest.raises(sp.SpecializeError, match="export_cache"):
+        sp.build(src + " ", sp.ARM_FLAGS)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("robot,link", [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee")])
+def test_gpu_arm_kernels_with_folded_constants_every_row_vs_oracle(robot, link):
+    """model.specialize() on a serial 7-DoF arm: inverse dynamics and the fused FK + RNEA launch through the robot's own
+    constant-folded streaming kernels (csrc/drm_arm_stream.hpp, launches of >= 1 024 pairs of 64-row tiles).  B = 2 051 pairs + one
+    odd tile + 21 rows: the pairs through the robot's kernel (two waves walk a second tile: the staged-rows path), the odd tile
+    and the tail through the library's — EVERY row against the fp64 oracle; against the library's kernels (unspecialised model)
+    to a few ulp; plans under a hipGraph; without qdd; a learnable parameter drops the kernels."""
+    mc, plain, own = load_model(robot), load_model(robot, "cuda"), load_model(robot, "cuda")
+    assert own.specialize() is True
+    tree = own._dynamics_walk().program
+    assert tree._special.get(sp.SPECIAL_RNEA_ARM)
+    B, n = (2 * 1024 + 3) * 128 + 64 + 21, 7
+    q, qd, qdd = sample_states(mc, B, seed=77, vel=0.6, acc=1.2)
+    dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in (q, qd, qdd))
+    orc = Oracle(mc._spec)
+    f64 = lambda a: a.astype(np.float64)
+    ee = mc._name_to_idx_map[link]
+    rp, rq = orc.fk(f64(q), [ee], np.float64)
+    from helpers import TOL_POS, TOL_QUAT, max_err, quat_close
+    for grav, damp in ((True, True), (False, False)):
+        ref = orc.rnea(f64(q), f64(qd), f64(qdd), grav, damp, np.float64)
+        tau = own.compute_inverse_dynamics(dq, dqd, dqdd, include_gravity=grav, use_damping=damp)
+        assert np.allclose(tau.cpu().numpy(), ref, **TOL_TAU), (grav, damp)
+        lib = plain.compute_inverse_dynamics(dq, dqd, dqdd, include_gravity=grav, use_damping=damp)
+        assert float(((tau - lib).abs() / lib.abs().clamp_min(1.0)).max()) <= 2e-5
+        t2, pos, quat = own.compute_fk_and_inverse_dynamics(dq, dqd, dqdd, link, grav, damp)
+        assert tree._special.get(sp.SPECIAL_FK_RNEA_ARM)          # (built on the first fused call for this link)
+        assert np.allclose(t2.cpu().numpy(), ref, **TOL_TAU)
+        assert max_err(pos.cpu().numpy(), rp[:, 0]) <= TOL_POS["atol"] and quat_close(quat.cpu().numpy(), rq[:, 0], TOL_QUAT["atol"])[0]
+        assert float((t2 - tau).abs().max()) <= 2e-5 * float(tau.abs().max())
+    nle = own.compute_non_linear_effects(dq, dqd)
+    assert np.allclose(nle.cpu().numpy(), orc.rnea(f64(q), f64(qd), np.zeros_like(q, np.float64), True, True, np.float64), **TOL_TAU)
+    # prepared launches replayed from a hipGraph; 8 shards of 131 072 rows against one launch of 2^20 (bench.py --verify-gather)
+    Bg = 1 << 20
+    dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in sample_states(mc, Bg, seed=78, vel=0.4, acc=0.8))
+    plan = own.plan_fk_and_inverse_dynamics(dq, dqd, dqdd, link)
+    plan.launch()
+    torch.cuda.synchronize()
+    first = [t.clone() for t in plan.outputs()]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.launch()
+    for t in plan.outputs():
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(first, plan.outputs()):
+        assert torch.equal(a, b)
+    for r in range(8):
+        sl = slice(r << 17, (r + 1) << 17)
+        shard = own.plan_fk_and_inverse_dynamics(dq[sl].contiguous(), dqd[sl].contiguous(), dqdd[sl].contiguous(), link)
+        shard.launch()
+        torch.cuda.synchronize()
+        for a, b in zip(shard.outputs(), first):
+            assert torch.equal(a, b[sl].reshape(a.shape))          # (one kernel at both sizes: bit for bit)
+    sel = slice(0, 1 << 15)
+    assert np.allclose(first[0][sel].cpu().numpy(), orc.rnea(*(f64(t[sel].cpu().numpy()) for t in (dq, dqd, dqdd)), True, True, np.float64), **TOL_TAU)
+    # a learnable parameter: the constant-folded kernels no longer describe the model
+    from differentiable_robot_model_amd.rigid_body_params import PositiveScalar
+    own.make_link_param_learnable(mc.get_link_names()[3], "mass", PositiveScalar())
+    assert not any(k in (getattr(dw.program, "_special", None) or {}) for dw in own._walks.values() for k in (4, 5))
+    t3 = own.compute_inverse_dynamics(dq[:262144], dqd[:262144], dqdd[:262144])
+    assert not torch.allclose(t3, first[0][:262144])            # (another mass: other torques — through the library's kernels)
+
+
+def test_specialize_needs_a_device_model():
+    """(CPU) per-robot kernels are HIP code objects: specialize() needs a model on a HIP device."""
     m = load_model("panda_no_gripper")
     with pytest.raises(RuntimeError):
         m.specialize()
