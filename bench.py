@@ -35,12 +35,12 @@ The JSON line also carries
                     (a 20-step region carries one graph-launch latency, ~9 us, in its average)
   "roofline_large": the same kernel at batches whose per-launch traffic (0.94 GB / 3.8 GB) is far beyond the 256 MiB
                     Infinity Cache, i.e. genuine HBM streaming (N = 1 only)
-  "cpu_baseline":   the oracle's fp32 C restatement of the reference (oracle/, "port") timed on this box's host cores
-                    on a bounded sample of the same workload, and under "reference" the UNMODIFIED reference itself
-                    (oracle/_ref/, staged from /root/reference by oracle/stage_ref.py) timed on the same host cores in
-                    the same run on the same joint states: (A) its public compute_endeffector_jacobian on 4 096 rows
-                    (linear extrapolation stated), (B) tensor-only (Python quaternion loop stubbed) on all 65 536 rows,
-                    all threads and 1 thread, min of 3 — plus the HIP path's deviation from the reference's outputs.
+  "cpu_baseline":   value = the UNMODIFIED reference itself (oracle/_ref/, staged from /root/reference by oracle/stage_ref.py;
+                    kind "reference") timed on this box's host cores in this run on the same joint states: tensor-only
+                    (its Python quaternion loop stubbed) on all 65 536 rows, one thread, min of 3.  Under "reference": the
+                    same with all threads, its public compute_endeffector_jacobian on 4 096 rows (linear extrapolation
+                    stated) and the HIP path's deviation from the reference's own outputs; under "port": the oracle's fp32 C
+                    restatement of the algorithm (oracle/, OpenMP over samples, all host cores) on a bounded sample.
 """
 import argparse
 import json
@@ -75,6 +75,9 @@ def parse_args(argv=None):
                          "(default: nothing).  --config 3: which mode the headline `value` is timed with — none (default: the "
                          "outputs stay sharded, the MPC / particle case), all (every rank gets tau | pos | quat of every row), root "
                          "(rank 0 only), tau (all-gather of the torques only); every mode is timed and reported under gather_modes")
+    ap.add_argument("--library-kernels", action="store_true",
+                    help="--config 3: time the library's table-driven kernels instead of the robot's own constant-folded ones "
+                         "(model.specialize(), the default when hipcc is on the machine)")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
@@ -487,22 +490,28 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
         plan.launch()
         torch.cuda.synchronize()
         names = ("pos", "quat", "lin_jac", "ang_jac")
-        ref = line["cpu_baseline"]["reference"] = reference_cpu(
+        ref = reference_cpu(
             args.robot, link, q.cpu().numpy(), gpu_outputs={k: t.cpu().numpy() for k, t in zip(names, plan.outputs())})
-        if "one_thread" in ref:   # the CPU baseline of record: the unmodified reference's vectorised math on ONE thread (its
-            # many-thread runs are slower on [B, 3]-sized ops, and the OpenMP port above swings 10x between passes on a shared host)
+        if "one_thread" in ref:
+            # THE CPU baseline (round 5: the top-level value): the UNMODIFIED reference's vectorised math on ONE thread (its
+            # many-thread runs are slower on [B, 3]-sized ops).  The OpenMP port of the algorithm (oracle/, all host cores), which
+            # swings 10x between passes on a shared host, is reported beside it under `port`.
             one = ref["one_thread"]["tensor_only"]
-            line["cpu_baseline"]["of_record"] = {
+            port = line["cpu_baseline"]
+            line["cpu_baseline"] = {
                 "value": one["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "reference",
-                "sample": "compute_endeffector_jacobian of the unmodified reference on all %d rows, get_quaternion stubbed "
-                          "(tensor-only), one thread, min of %d" % (one["rows"], ref.get("reps", 3)),
-                "gpu_over_cpu": line["value"] / one["evals_per_s"]}
+                "sample": "compute_endeffector_jacobian of the unmodified reference (oracle/_ref, staged from /root/reference) on all "
+                          "%d rows of this run's batch, get_quaternion stubbed (tensor-only: its per-row Python loop is timed "
+                          "separately under reference.public_api), one thread, min of %d" % (one["rows"], ref.get("reps", 3)),
+                "gpu_over_cpu": line["value"] / one["evals_per_s"], "port": port, "reference": ref}
+        else:      # (the reference leg failed: the port stays the value, the error is reported)
+            line["cpu_baseline"]["reference"] = ref
     if rank == 0 and world == 1 and not args.no_configs and os.environ.get("DRM_BENCH_CHILD") != "1":
         del plan
         torch.cuda.empty_cache()
         from bench_configs import run_config_legs
         try:
-            line["configs"] = run_config_legs(device, with_reference=not args.no_cpu_baseline)
+            line["configs"] = run_config_legs(device, with_reference=not args.no_cpu_baseline, with_traffic=not args.no_traffic)
         except Exception as err:   # the extra legs must never take the metric line down with them
             line["configs"] = {"error": "%s: %s" % (type(err).__name__, err)}
     return line
@@ -574,6 +583,15 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     lo, hi = shard_bounds(G, world, rank)
     rows = hi - lo
     q, qd, qdd = config3_inputs(model, rows, device, 4321 + rank)
+    # round 5: the robot's OWN kernels (model.specialize(): the streaming walk with this arm's constants folded into the instruction
+    # stream; hipcc at run time, ~2 s, cached; the ranks of a node build the same code object and publish it atomically) — what a
+    # constant model runs at >= 131 072 rows.  A machine without hipcc keeps the library's table-driven kernels; the line says which.
+    own_kernel, own_why = False, "--library-kernels"
+    if not args.library_kernels:
+        try:
+            own_kernel, own_why = bool(model.specialize()), None
+        except Exception as err:       # noqa: BLE001
+            own_kernel, own_why = False, str(err)[:200]
     # tau | pos | quat of a shard live in ONE allocation (three contiguous blocks), so the collective sends the kernel's own
     # output buffer: no packing kernel between the launch and the all-gather
     width = n + 3 + 4                                                    # 56 B per row
@@ -705,6 +723,7 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
                    "launch": "hipGraph of K steps" if modes[headline]["hipgraph"] else "eager steps (kernel + collective)",
                    "gather": headline if world > 1 else "none",
                    "gather_bytes_per_rank": modes[headline]["gather_bytes_per_rank"]},
+        "own_kernel": own_kernel, "own_kernel_unavailable": own_why,
         "compute_us_per_step": dev_compute / K * 1e6, "step_us_with_gather": dev_time / K * 1e6,
         "gather_us_per_step": max(0.0, (dev_time - dev_compute) / K * 1e6) if world > 1 else 0.0,
         "gather_modes": modes,
@@ -714,8 +733,10 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
                              "(distributed.gather_model_us) — what the exchange should add once it runs over RCCL",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,
-                     "kernel": "drm::fk_rnea_arm2_kernel<8, 7, 7> (two samples per lane)" if rows > 1024 * 64
-                               else "drm::fk_rnea_arm_kernel<8, 7, 7>", "bytes_per_eval": bytes_per_eval,
+                     "kernel": ("drm_fk_rnea_arm_static (this robot's constants folded in, csrc/drm_arm_stream.hpp)"
+                                if own_kernel and rows >= 1024 * 128 else
+                                "drm::fk_rnea_arm2_kernel<8, 7, 7> (two samples per lane)" if rows > 1024 * 64
+                                else "drm::fk_rnea_arm_kernel<8, 7, 7>"), "bytes_per_eval": bytes_per_eval,
                      "launch_us": launch_s * 1e6,
                      "note": "the fused kernel alone (hipGraph of K launches, HIP events); RNEA sits at the vector-FP32 / HBM "
                              "ridge (2.6 kflop per 140 B), see DESIGN.md"},

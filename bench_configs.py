@@ -159,7 +159,153 @@ def run_reference(jobs, arrays, reps=2, timeout=240):
     return rec, outs
 
 
-def run_config_legs(device, with_reference=True):
+# ---------------------------------------------------------------------------------------------------- HBM traffic of every leg
+TRAFFIC_LEGS = ("config2", "config3_shard", "config3_whole", "config4", "config5", "config5_fk_mse")
+
+
+def leg_launcher(name, device):
+    """One leg's launch as a closure (the same robots, batches, seeds and entry points run_config_legs times) — what the
+    `--pmc-child NAME` mode of this file runs under rocprofv3 so that the counters of a pass belong to ONE leg."""
+    import torch
+
+    from differentiable_robot_model_amd import backend
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
+    if name == "config2":
+        iiwa = load("iiwa7", device)
+        q, _ = uniform_q(iiwa, 65536, device, 2002)
+        return iiwa.plan_fk_and_jacobian(q, "iiwa_link_ee").launch
+    if name in ("config3_shard", "config3_whole"):
+        panda = load("panda_no_gripper", device)
+        try:
+            panda.specialize()
+        except Exception:       # noqa: BLE001  (no hipcc: the library's kernels, as in run_config_legs)
+            pass
+        rows = 131072 if name == "config3_shard" else 1 << 20
+        vmax = torch.tensor([j["velocity"] for j in panda.get_joint_limits()], device=device)
+        q, gen = uniform_q(panda, rows, device, 4321)
+        qd = ((torch.rand(rows, 7, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()
+        qdd = ((torch.rand(rows, 7, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
+        return panda.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link").launch
+    if name == "config4":
+        hand = load("allegro_left", device)
+        q, _ = uniform_q(hand, 65536, device, 4004)
+        return lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
+    if name in ("config5", "config5_fk_mse"):
+        torch.manual_seed(0)
+        iiwa, learn = load("iiwa7", device), load("iiwa7", device)
+        learn.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(dim1=1, dim2=3))
+        learn.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(dim1=1, dim2=3))
+        B = 16384
+        q, _ = uniform_q(iiwa, B, device, 5005)
+        with torch.no_grad():
+            want, _ = iiwa.compute_forward_kinematics(q, "iiwa_link_ee")
+        ee = learn._name_to_idx_map["iiwa_link_ee"]
+        dw = learn._get_walk(("fk", (ee,)), targets=[ee])
+        ops_f = learn._ops_f(dw).detach()
+        gpos = torch.randn(B, 1, 3, device=device)
+        mask = learn._kinematic_param_mask(dw)
+        if name == "config5_fk_mse":
+            return lambda: backend.fk_mse(dw.program, ops_f, dw.ops_i, q, want, 7, mask, False)
+
+        def both():
+            backend.fk(dw.program, ops_f, dw.ops_i, q, 1, 7)
+            backend.fk_backward(dw.program, ops_f, dw.ops_i, q, gpos, 1, 7, mask, False)
+        return both
+    raise ValueError(name)
+
+
+PMC_CALLS = 12
+
+
+def pmc_child(name):
+    import torch
+    device = torch.device("cuda", 0)
+    fn = leg_launcher(name, device)
+    torch.cuda.synchronize()
+    print("PMC_LEG_BEGIN", flush=True)
+    with torch.no_grad():
+        for _ in range(PMC_CALLS):
+            fn()
+    torch.cuda.synchronize()
+
+
+def leg_kernel(row_name):
+    """Is a dispatch of the counter CSV one of a leg's own launches?  Everything this library launches (drm:: kernels, the robots'
+    own *_static kernels) and the runtime's fill kernel behind hipMemsetAsync (the backward scratch), minus what building a model
+    launches once (the link-row / walk-table builders)."""
+    if any(t in row_name for t in ("link_rows", "walk_table")):
+        return False
+    return any(t in row_name for t in ("drm", "_static", "fillBuffer"))
+
+
+def measured_leg_traffic(name, timeout=120):
+    """HBM bytes per launch of one leg, MEASURED: two runs of `bench_configs.py --pmc-child NAME` under `rocprofv3 --kernel-trace
+    --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, kernel tracing only, MI355X_MICROARCH.md), summed over the leg's kernels
+    (memsets and reductions of the backward included) and divided by the number of calls: FETCH_SIZE (KiB) x 2 (the gfx950
+    correction) + WRITE_SIZE (KiB)."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = dict(os.environ, TMPDIR="/tmp", DRM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    got, kernels = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="drm_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", name]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            rows_of = {}
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        kn = row.get("Kernel_Name", "")
+                        if row.get("Counter_Name") == counter and leg_kernel(kn):
+                            rows_of.setdefault(kn.split("(")[0][:80], []).append((int(row.get("Dispatch_Id", 0)), float(row["Counter_Value"])))
+            # a kernel's dispatches beyond a multiple of PMC_CALLS are the child's setup (the target of config 5's loss, a memset
+            # behind an allocation): they come first and are dropped
+            total, per = 0.0, {}
+            for kn, rows in rows_of.items():
+                rows.sort()
+                keep = rows[len(rows) % PMC_CALLS:]
+                if keep:
+                    total += sum(v for _, v in keep)
+                    per[kn] = len(keep)
+            if not per:
+                return None, "no %s rows for the leg's kernels in the rocprofv3 output" % counter
+            got[counter] = total / PMC_CALLS
+            kernels = per
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
+            return None, "%s pass failed: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch, write = got["FETCH_SIZE"] * 1024.0 * 2.0, got["WRITE_SIZE"] * 1024.0
+    return {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "calls": PMC_CALLS,
+            "dispatches_per_call": {k: v / PMC_CALLS for k, v in kernels.items()}}, None
+
+
+def fill_traffic(legs):
+    """roofline.traffic of every leg from counters collected NOW (N = 1, after the timed regions; ~8 s per leg and counter)."""
+    for leg in legs:
+        for key, child in (("roofline", leg["name"]), ("fk_mse_roofline", leg["name"] + "_fk_mse")):
+            if key not in leg or child not in TRAFFIC_LEGS:
+                continue
+            got, why = measured_leg_traffic(child)
+            r = leg[key]
+            if got is None:
+                r["traffic_unmeasured"] = why
+                continue
+            r["traffic"] = got["bytes"]
+            r["traffic_fetch_bytes"], r["traffic_write_bytes"] = got["fetch_bytes"], got["write_bytes"]
+            r["traffic_over_algorithmic"] = got["bytes"] / r["algorithmic_bytes_per_launch"]
+            r["traffic_dispatches_per_call"] = got["dispatches_per_call"]
+            r["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of bench_configs.py "
+                                   "--pmc-child %s (FETCH x 2 + WRITE, KiB), summed over the leg's kernels, per call" % child)
+
+
+def run_config_legs(device, with_reference=True, with_traffic=True):
     import numpy as np
     import torch
 
@@ -186,19 +332,33 @@ def run_config_legs(device, with_reference=True):
     # ------------------------------------------------------------------ config 3: Panda FK(EE) + RNEA, shard and whole batch
     panda = load("panda_no_gripper", device)
     link = "panda_virtual_ee_link"
+    # round 5: the robot's OWN kernels — model.specialize(): the streaming walk with Panda's constants folded into the instruction
+    # stream (hipcc at run time, ~2 s per kernel, cached) — are what a constant model runs; the library's table-driven kernels are
+    # timed beside them (and stay the path when the machine has no hipcc)
+    own = load("panda_no_gripper", device)
+    try:
+        own_ok, own_why = bool(own.specialize()), None
+    except Exception as err:       # noqa: BLE001  (no hipcc on this machine: the library's kernels are the path)
+        own_ok, own_why = False, str(err)[:200]
     vmax = torch.tensor([j["velocity"] for j in panda.get_joint_limits()], device=device)
     for rows, label, K in ((131072, "config3_shard", 100), (1 << 20, "config3_whole", 30)):
         q, gen = uniform_q(panda, rows, device, 4321)
         qd = ((torch.rand(rows, 7, device=device, generator=gen) * 2 - 1) * 0.2 * vmax).contiguous()
         qdd = ((torch.rand(rows, 7, device=device, generator=gen) * 2 - 1) * 0.4 * vmax).contiguous()
         plan = panda.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
-        us, us_min = graph_launch_us(plan.launch, K)
+        us_lib, us_lib_min = graph_launch_us(plan.launch, K)
+        us, us_min, kernel = us_lib, us_lib_min, "drm::fk_rnea_arm2_kernel<8, 7, 7> (library, table in LDS)"
+        if own_ok:
+            plan = own.plan_fk_and_inverse_dynamics(q, qd, qdd, link)
+            us, us_min = graph_launch_us(plan.launch, K)
+            kernel = "drm_fk_rnea_arm_static (this robot's constants folded in; csrc/drm_arm_stream.hpp)"
         leg = {"config": 3, "name": label, "batch": rows, "launch_us": us, "launch_us_min": us_min, "evals_per_s": rows / us * 1e6,
                "workload": "Franka Panda 7-DoF, FK(%s) + RNEA inverse dynamics (gravity, damping), %d rows%s, q~U(limits), "
                            "qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); ONE fused drm_fk_rnea launch" %
                            (link, rows, " = one GPU's shard of the 2^20 batch at N = 8" if rows == 131072 else " = the whole batch on one GPU"),
-               "roofline": roofline(140, rows, us, "drm::fk_rnea_arm2_kernel<8, 7, 7>" if rows > 65536 else "drm::fk_rnea_arm_kernel<8, 7, 7>",
-                                    flops_per_eval=2600 + 830)}
+               "own_kernel": own_ok, "own_kernel_unavailable": own_why,
+               "library_kernel_launch_us": us_lib, "library_kernel_launch_us_min": us_lib_min,
+               "roofline": roofline(140, rows, us, kernel, flops_per_eval=2600 + 830)}
         if label in IO_FLOOR_US:
             leg["io_floor_us"], leg["io_floor_source"] = IO_FLOOR_US[label]
         legs.append(leg)
@@ -389,6 +549,17 @@ def run_config_legs(device, with_reference=True):
                 tol = dict(tau_relative=True)
                 leg["gpu_vs_reference_max_abs"] = deviation(outs, name, gpu_out[name], **tol)
                 leg["gpu_vs_reference_rows"] = job["outputs_rows"]
+    if with_traffic and os.environ.get("DRM_BENCH_CHILD") != "1":
+        torch.cuda.synchronize()
+        fill_traffic(legs)
     return {"legs": legs, "api_eager_us_per_call": eager, "reference_run": ref_meta,
             "method": "launch_us: hipGraph of 30-100 launches, HIP events on the launch stream, median of 5 replays; reference: "
                       "oracle/ref_timing.py --jobs (unmodified reference, own interpreter, host cores only) in this run"}
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--pmc-child":
+        sys.path.insert(0, ROOT)
+        pmc_child(sys.argv[2])
+    else:
+        sys.exit("usage: bench_configs.py --pmc-child LEG   (a child mode of bench.py; run bench.py for the configs legs)")

@@ -31,6 +31,9 @@ KERNELS = {SPECIAL_RNEA: "drm_rnea_static", SPECIAL_CRBA: "drm_crba_static", SPE
 # (ABI 10) serial 7-DoF arms with the robot's constants folded into the instruction stream (csrc/drm_arm_stream.hpp)
 SPECIAL_RNEA_ARM, SPECIAL_FK_RNEA_ARM = 4, 5
 ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "drm_fk_rnea_arm_static"}
+ARM_KINDS = tuple(ARM_KERNELS)
+# (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
+# folds only a tenth of its instructions and the launch is bound by its loads and its store drain, profiles/r05_metric_static.txt.)
 # what folds the constants: x * 0 -> 0 and x + 0 -> x need "no NaN / Inf / signed zero" (nothing else of -ffast-math: no reassociation)
 ARM_FLAGS = ["-fno-signed-zeros", "-ffinite-math-only"]
 MAX_STATIC_OPS = 24        # beyond this the straight-line walk no longer fits the register file (loop kernels keep serving)

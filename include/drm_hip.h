@@ -44,7 +44,7 @@ extern "C" {
 #define DRM_ABI_VERSION 10
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
-#define DRM_SPECIAL_KINDS 6 /* drm_walk.special[]: */
+#define DRM_SPECIAL_KINDS 12 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
 #define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
 #define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   kernel drm_crba_static  */
 #define DRM_SPECIAL_FD 2     /*   forward dynamics             kernel drm_fd_static    */

@@ -967,5 +967,23 @@ def test_bench_line_carries_the_contract_fields():
         assert roof["traffic_detail"]["dispatches"] >= 50
     else:
         assert roof["traffic_detail"]["fallback_reason"] and roof["traffic_source"].startswith("profiles/")
+    # the CPU baseline: the UNMODIFIED reference timed in this run (one thread, tensor-only) is the value; the OpenMP port of the
+    # algorithm (oracle/) beside it; the HIP outputs against the reference's own on the same rows
     cpu = d["cpu_baseline"]
-    assert cpu["kind"] == "port" and cpu["unit"] == "evals/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["kind"] == "reference" and cpu["unit"] == "evals/s" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["port"]["kind"] == "port" and cpu["port"]["value"] > 0 and cpu["port"]["cores"] >= 1
+    dev = cpu["reference"]["gpu_vs_reference_max_abs"]
+    assert dev["pos"] <= 2e-6 and dev["lin_jac"] <= 2e-6 and dev["ang_jac"] <= 2e-6 and dev["quat_sign_flips"] == 0
+    # every BASELINE configuration beside the metric, each with its roofline (counter bytes included) and the reference beside it
+    legs = {leg["name"]: leg for leg in d["configs"]["legs"]}
+    assert set(legs) == {"config2", "config3_shard", "config3_whole", "config4", "config5"}
+    for name, leg in legs.items():
+        roof = leg["roofline"]
+        assert roof["launch_us"] > 0 and 0 < roof["frac"] < 1.0, name
+        assert roof["traffic"] is not None and 0.8 <= roof["traffic_over_algorithmic"] <= 3.0, (name, roof)
+        assert leg["reference"]["one_thread"]["tensor_only"]["evals_per_s"] > 0
+    assert legs["config5"]["fk_mse_roofline"]["traffic"] is not None
+    c3 = legs["config3_whole"]
+    assert c3["own_kernel"] is True and c3["launch_us"] < c3["library_kernel_launch_us"]      # (hipcc is on the GPU box)
+    for key, tol in (("tau", 2e-5), ("pos", 2e-6), ("quat", 2e-6)):
+        assert legs["config3_shard"]["gpu_vs_reference_max_abs"][key] <= tol

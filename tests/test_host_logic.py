@@ -236,7 +236,7 @@ def test_abi_argument_errors_need_no_gpu():
     w = backend.DrmWalk(1, 1, 8, 8, 7, 17, 0, 2, 0)  # more save slots than the kernels have
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -2
     # struct drm_walk: 48 bytes of scalars + n_segments + seg_begin[9] + seg_dof_lo[8] + seg_dof_cnt[8] + prefix_end + seg_leaf_begin[9]
-    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1 + 9) + 16 + 4 + 4 + 6 * 8    # (+ chain_dof1, chain_prismatic, reserved0: ABI 8; special[4]: ABI 9; special[6]: ABI 10)
+    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1 + 9) + 16 + 4 + 4 + 12 * 8    # (+ chain_dof1, chain_prismatic, reserved0: ABI 8; special[4]: ABI 9; special[12]: ABI 10)
 
 
 def test_rnea_backward_scratch_covers_the_fanned_out_launch():
