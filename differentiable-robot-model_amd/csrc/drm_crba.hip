@@ -418,10 +418,17 @@ extern "C" int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, 
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         (((uintptr_t)q | (uintptr_t)H | (uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the packed-FP32 chain kernel, ragged tail through the generic one
-        const int n_tiles = (int)(B / WAVE);
-        const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
-        if (arm_links(w) == 7) hipLaunchKernelGGL((crba_arm_kernel<8, 7, 7>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
-        else hipLaunchKernelGGL((crba_arm_kernel<8, 7, 8>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
+        int n_tiles = (int)(B / WAVE);
+        if (w->special[DRM_SPECIAL_CRBA_ARM]) {
+            // this arm's own kernel, its constants folded into the instruction stream (csrc/drm_arm_static.hpp, specialize.py)
+            void *args[] = {(void *)&q, (void *)&n_tiles, (void *)&H};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_CRBA_ARM], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_crba_arm_static): %s", hipGetErrorString(e));
+        } else {
+            const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
+            if (arm_links(w) == 7) hipLaunchKernelGGL((crba_arm_kernel<8, 7, 7>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
+            else hipLaunchKernelGGL((crba_arm_kernel<8, 7, 8>), grid, block, 0, s, w->ops_f, q, n_tiles, H);
+        }
         const int64_t done = (int64_t)n_tiles * WAVE;
         if (done == B) return launched();
         rc = launched();

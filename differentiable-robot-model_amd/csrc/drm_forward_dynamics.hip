@@ -448,9 +448,15 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
     if ((w->shape & DRM_WALK_ARM_CHAIN) && w->capacity == 8 && n == 7 && B >= WAVE && B / WAVE < 0x7fffffffLL &&
         (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the register-resident chain kernel, ragged tail through the generic one
-        const int n_tiles = (int)(B / WAVE);
+        int n_tiles = (int)(B / WAVE);
         const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
-        if (arm_links(w) == 7)
+        if (w->special[DRM_SPECIAL_FD_ARM]) {
+            // this arm's own kernel, its constants folded into the instruction stream (csrc/drm_arm_static.hpp, specialize.py)
+            int fl = (int)flags;
+            void *args[] = {(void *)&q, (void *)&qd, (void *)&f, (void *)&n_tiles, (void *)&fl, (void *)&qdd};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD_ARM], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fd_arm_static): %s", hipGetErrorString(e));
+        } else if (arm_links(w) == 7)
             hipLaunchKernelGGL((forward_dynamics_arm_kernel<8, 7, 7>), grid, block, 0, (hipStream_t)stream, w->ops_f, q, qd, f,
                                n_tiles, (int)flags, qdd);
         else

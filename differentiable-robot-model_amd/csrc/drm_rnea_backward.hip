@@ -570,8 +570,22 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
             B / WAVE < 0x7fffffffLL) {
             // 7-DoF arms: full tiles through the chain kernel, the ragged tail (if any) through the generic one with
             // its own rows of partial sums appended after the chain kernel's
-            const int n_tiles = (int)(B / WAVE);
+            int n_tiles = (int)(B / WAVE);
             const int64_t done = (int64_t)n_tiles * WAVE;
+            if (w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM] && param_mask == 0 && want_q) {
+                // input gradients of a constant model through this arm's own kernel, its constants folded into the instruction
+                // stream (csrc/drm_arm_static.hpp, specialize.py): nothing is summed over the batch, so no partial rows
+                int fl = (int)flags;
+                void *args[] = {(void *)&q, (void *)&qd, (void *)&qdd, (void *)&grad_tau, (void *)&n_tiles, (void *)&fl,
+                                (void *)&grad_q, (void *)&grad_qd, (void *)&grad_qdd};
+                hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM], (unsigned)n_tiles, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+                if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_backward_arm_static): %s", hipGetErrorString(e));
+                if (done == B) return DRM_OK;
+                drm_walk rest = *w;
+                rest.special[DRM_SPECIAL_RNEA_BACKWARD_ARM] = nullptr;
+                return drm_rnea_backward(&rest, q + done * n, qd + done * n, qdd ? qdd + done * n : nullptr, B - done, flags, grad_tau + done * n,
+                                         param_mask, grad_q + done * n, grad_qd + done * n, grad_qdd + done * n, grad_ops_f, scratch, stream);
+            }
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
             if (arm_links(w) == 7)
                 hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),

@@ -937,8 +937,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         for dw in self._walks.values():
             dw.static_ops_f = None
             special = getattr(dw.program, "_special", None)
-            if special and (4 in special or 5 in special):     # constant-folded arm kernels (specialize.attach_arm) bake the OLD constants
-                dw.program._special = {k: v for k, v in special.items() if k not in (4, 5)}
+            if special and any(k >= 4 for k in special):     # constant-folded arm kernels (specialize.attach_arm) bake the OLD constants
+                dw.program._special = {k: v for k, v in special.items() if k < 4}
                 dw.program._ws_cache = None
         self._arm_specialized = False
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)

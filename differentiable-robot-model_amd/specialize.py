@@ -29,8 +29,11 @@ SPECIAL_RNEA, SPECIAL_CRBA, SPECIAL_FD, SPECIAL_RNEA_BACKWARD = 0, 1, 2, 3
 KERNELS = {SPECIAL_RNEA: "drm_rnea_static", SPECIAL_CRBA: "drm_crba_static", SPECIAL_FD: "drm_fd_static",
            SPECIAL_RNEA_BACKWARD: "drm_rnea_backward_static"}
 # (ABI 10) serial 7-DoF arms with the robot's constants folded into the instruction stream (csrc/drm_arm_stream.hpp)
-SPECIAL_RNEA_ARM, SPECIAL_FK_RNEA_ARM = 4, 5
-ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "drm_fk_rnea_arm_static"}
+SPECIAL_RNEA_ARM, SPECIAL_FK_RNEA_ARM, SPECIAL_CRBA_ARM, SPECIAL_FD_ARM, SPECIAL_RNEA_BACKWARD_ARM = 4, 5, 6, 7, 8
+ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "drm_fk_rnea_arm_static",
+               SPECIAL_CRBA_ARM: "drm_crba_arm_static", SPECIAL_FD_ARM: "drm_fd_arm_static",
+               SPECIAL_RNEA_BACKWARD_ARM: "drm_rnea_backward_arm_static"}
+ARM_DYNAMICS = (SPECIAL_CRBA_ARM, SPECIAL_FD_ARM, SPECIAL_RNEA_BACKWARD_ARM)
 ARM_KINDS = tuple(ARM_KERNELS)
 # (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
 # folds only a tenth of its instructions and the launch is bound by its loads and its store drain, profiles/r05_metric_static.txt.)
@@ -227,7 +230,7 @@ def build(src: str, flags=()) -> str:
     extra = list(flags) + os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
     arch = target_arch()
     h = hashlib.sha256((src + " ".join(extra) + arch).encode())
-    for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp", "drm_arm_stream.hpp"):
+    for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp", "drm_arm_stream.hpp", "drm_arm_static.hpp"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     key = h.hexdigest()[:20]
@@ -310,6 +313,36 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
 """ % (rows, name, tail, links, "true" if fused else "false", "pos, quat" if fused else "nullptr, nullptr")
 
 
+def arm_dynamics_source(table, links: int) -> str:
+    """The inertia matrix, forward dynamics and the input gradients of inverse dynamics of one serial 7-DoF arm (the one-sample chain
+    walks, csrc/drm_arm_static.hpp) on a constexpr copy of the dynamics walk's [8, 32] table."""
+    import numpy as np
+    table = np.asarray(table, np.float32)
+    if table.shape != (8, 32) or links not in (7, 8):
+        raise SpecializeError("arm kernels are built for walks of capacity 8 with 7 or 8 dynamics ops")
+    rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in table)
+    return """// generated by differentiable-robot-model_amd/specialize.py — one serial arm's walk table as compile-time constants
+#include "drm_arm_static.hpp"
+namespace drm {
+static __device__ constexpr float ROBOT_OPS[8 * DRM_OPF_STRIDE] = {
+%s};
+struct RobotRow {
+    __device__ const float *operator()(int k) const { return ROBOT_OPS + k * DRM_OPF_STRIDE; }
+};
+}
+extern "C" __global__ void __launch_bounds__(64) drm_crba_arm_static(const float *q, int n_tiles, float *H) {
+    drm::crba_arm_static_body<7, %d>(drm::RobotRow(), q, n_tiles, H);
+}
+extern "C" __global__ void __launch_bounds__(64) drm_fd_arm_static(const float *q, const float *qd, const float *f, int n_tiles, int flags, float *qdd) {
+    drm::forward_dynamics_arm_static_body<7, %d>(drm::RobotRow(), q, qd, f, n_tiles, flags, qdd);
+}
+extern "C" __global__ void __launch_bounds__(64) drm_rnea_backward_arm_static(const float *q, const float *qd, const float *qdd, const float *gtau,
+                                                                              int n_tiles, int flags, float *gq, float *gqd, float *gqdd) {
+    drm::rnea_backward_arm_static_body<7, %d>(drm::RobotRow(), q, qd, qdd, gtau, n_tiles, flags, gq, gqd, gqdd);
+}
+""" % (rows, links, links, links)
+
+
 def _load(path: str, kernel: str) -> int:
     from . import backend
     lib = backend.load_library()
@@ -324,8 +357,9 @@ def arm_qualifies(prog: WalkProgram, n_dofs: int) -> bool:
 
 
 def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkProgram] = None, chain_table=None) -> Dict[int, int]:
-    """Build (hipcc ~2 s each, cached) and attach the constant-folded kernels of a serial 7-DoF arm: inverse dynamics on the
-    dynamics walk `tree` (its [8, 32] table as a host array), and — given the chain walk of an FK target whose last link is the
+    """Build (hipcc ~2 s each, cached) and attach the constant-folded kernels of a serial 7-DoF arm: inverse dynamics, the inertia
+    matrix, forward dynamics and the input gradients of inverse dynamics on the dynamics walk `tree` (its [8, 32] table as a host
+    array), and — given the chain walk of an FK target whose last link is the
     arm's last link — the fused FK + RNEA kernel of the pair, the SAME handle stored on both programs (drm_fk_rnea checks that).
     A tree program keeps the fused kernel of the LAST chain it was paired with.  Constant models only: the kernels ignore ops_f."""
     import numpy as np
@@ -336,6 +370,10 @@ def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkP
     special = dict(getattr(tree, "_special", None) or {})
     if SPECIAL_RNEA_ARM not in special:
         special[SPECIAL_RNEA_ARM] = _load(build(arm_source(table, links, False), ARM_FLAGS), ARM_KERNELS[SPECIAL_RNEA_ARM])
+    if SPECIAL_CRBA_ARM not in special:
+        path = build(arm_dynamics_source(table, links), ARM_FLAGS)
+        for kind in ARM_DYNAMICS:
+            special[kind] = _load(path, ARM_KERNELS[kind])
     if chain is not None:
         if not (arm_qualifies(chain, n_dofs) and chain.n_ops == 8):
             raise SpecializeError("the FK target's chain is not this arm's chain of 8 ops")

@@ -57,6 +57,11 @@ extern "C" {
 #define DRM_SPECIAL_RNEA_ARM 4    /* drm_rnea     kernel "drm_rnea_arm_static", arguments q, qd, qdd, n_pairs, flags, tau              */
 #define DRM_SPECIAL_FK_RNEA_ARM 5 /* drm_fk_rnea  kernel "drm_fk_rnea_arm_static", arguments q, qd, qdd, n_pairs, flags, tau, pos, quat;
                                      the SAME handle on the tree walk and on the chain walk it was built for                */
+/* ... and the one-sample-per-lane chain walks of the same arm (csrc/drm_arm_static.hpp), one wavefront per 64-row tile: */
+#define DRM_SPECIAL_CRBA_ARM 6    /* drm_crba              kernel "drm_crba_arm_static", arguments q, n_tiles, H                       */
+#define DRM_SPECIAL_FD_ARM 7      /* drm_forward_dynamics  kernel "drm_fd_arm_static", arguments q, qd, f, n_tiles, flags, qdd          */
+#define DRM_SPECIAL_RNEA_BACKWARD_ARM 8 /* drm_rnea_backward with param_mask == 0 (input gradients of a constant model): kernel
+                                     "drm_rnea_backward_arm_static", arguments q, qd, qdd, grad_tau, n_tiles, flags, grad_q, grad_qd, grad_qdd */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

@@ -509,9 +509,56 @@ def test_gpu_arm_kernels_with_folded_constants_every_row_vs_oracle(robot, link):
     # a learnable parameter: the constant-folded kernels no longer describe the model
     from differentiable_robot_model_amd.rigid_body_params import PositiveScalar
     own.make_link_param_learnable(mc.get_link_names()[3], "mass", PositiveScalar())
-    assert not any(k in (getattr(dw.program, "_special", None) or {}) for dw in own._walks.values() for k in (4, 5))
+    assert not any(k >= 4 for dw in own._walks.values() for k in (getattr(dw.program, "_special", None) or {}))
     t3 = own.compute_inverse_dynamics(dq[:262144], dqd[:262144], dqdd[:262144])
     assert not torch.allclose(t3, first[0][:262144])            # (another mass: other torques — through the library's kernels)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "iiwa7"])
+def test_gpu_arm_inertia_matrix_forward_dynamics_and_input_gradients_with_folded_constants(robot):
+    """model.specialize() on a serial 7-DoF arm also builds the constant-folded inertia-matrix, forward-dynamics and reverse-mode
+    (input gradients) kernels (csrc/drm_arm_static.hpp): every row against the fp64 oracle and against the library's kernels, full
+    tiles + a ragged tail; gradients against the unspecialised model's (whose kernels meet the reference's autograd elsewhere)."""
+    mc, plain, own = load_model(robot), load_model(robot, "cuda"), load_model(robot, "cuda")
+    assert own.specialize() is True
+    special = own._dynamics_walk().program._special
+    assert all(special.get(k) for k in sp.ARM_DYNAMICS)
+    orc = Oracle(mc._spec)
+    f64 = lambda a: a.astype(np.float64)
+    for B in (64, 64 * 37 + 11, 70000):
+        q, qd, qdd = sample_states(mc, B, seed=B)
+        dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in (q, qd, qdd))
+        H = own.compute_lagrangian_inertia_matrix(dq)
+        assert np.allclose(H.cpu().numpy(), orc.mass_matrix(f64(q), False, False, np.float64), **TOL_TAU), B
+        Hl = plain.compute_lagrangian_inertia_matrix(dq)
+        assert float((H - Hl).abs().max()) <= 2e-5 * float(Hl.abs().max())
+        for grav, damp in ((True, True), (False, False)):
+            f = plain.compute_inverse_dynamics(dq, dqd, dqdd, include_gravity=grav, use_damping=damp)
+            acc = own.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+            ref = orc.forward_dynamics(f64(q), f64(qd), f64(f.cpu().numpy()), grav, damp, np.float64)
+            err = float((np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+            other = plain.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+            err_lib = float((np.abs(other.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+            assert err < max(1e-3, 2.0 * err_lib), (B, grav, damp, err, err_lib)
+        want = torch.randn(B, 7, device="cuda", generator=torch.Generator("cuda").manual_seed(B))
+        grads = []
+        for m in (plain, own):
+            xs = [t.clone().requires_grad_(True) for t in (dq, dqd, dqdd)]
+            torch.nn.functional.mse_loss(m.compute_inverse_dynamics(*xs), want).backward()
+            grads.append([x.grad for x in xs])
+        for a, b in zip(*grads):
+            scale = max(1e-9, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-4 * scale, (B, float((a - b).abs().max()), scale)
+        # without qdd: the non-linear effects' gradients
+        grads = []
+        for m in (plain, own):
+            xs = [t.clone().requires_grad_(True) for t in (dq, dqd)]
+            m.compute_non_linear_effects(*xs).pow(2).mean().backward()
+            grads.append([x.grad for x in xs])
+        for a, b in zip(*grads):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1e-9, float(b.abs().max()))
 
 
 def test_specialize_needs_a_device_model():
