@@ -23,9 +23,10 @@ def test_examples_import_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_learn_kinematics_example(use_graph):
-    hist = load("learn_kinematics_of_iiwa").run(batch=2048, epochs=120, use_graph=use_graph, verbose=False)
+@pytest.mark.parametrize("use_graph,fused_loss", [(False, False), (True, False), (True, True), (False, True)])
+def test_learn_kinematics_example(use_graph, fused_loss):
+    """The reference's loop literally (eager / as a hipGraph) and the example's default (fk_mse_loss under a hipGraph)."""
+    hist = load("learn_kinematics_of_iiwa").run(batch=2048, epochs=120, use_graph=use_graph, fused_loss=fused_loss, verbose=False)
     assert hist[-1] < 0.2 * hist[0]
 
 

@@ -24,13 +24,43 @@ def graph_time(fn, launches=100, reps=5):
     return best
 
 
+# executed flops per evaluation from the ISA (tools/flop_count.py -> profiles/r05_flops.json); DRM_SPECIALIZE=1: the robot's own kernels
+import json
+try:
+    FLOPS = json.load(open(os.path.join(ROOT, "profiles", "r05_flops.json")))["kernels"]
+except OSError:
+    FLOPS = {}
+OWN = os.environ.get("DRM_SPECIALIZE") in ("1", "tune")
+
+
+def bound(what, B, us, nbytes):
+    """' | HBM x.xx  VALU y.yy (N flop/eval executed) -> bound: ...': fractions of 8 TB/s and of 157.3 TFLOP/s vector FP32; a kernel is
+    bound by whichever it uses more of (B < 131 072 rows of RNEA / FK + RNEA run the library's kernels either way)."""
+    own = OWN and not (what in ("rnea", "fk+rnea") and B < 131072) and what != "fk_jacobian"
+    if own:
+        key = {"rnea": "rnea own", "fk+rnea": "fk+rnea own", "crba": "crba own", "fwd dyn": "fwd dyn own",
+               "rnea bwd": "rnea bwd own (input gradients)"}.get(what)
+    else:
+        key = {"rnea": "rnea library (one sample per lane)" if B <= 65536 else "rnea library (two samples per lane)",
+               "fk+rnea": "fk+rnea library (two samples per lane)", "crba": "crba library", "fwd dyn": "fwd dyn library",
+               "rnea bwd": "rnea bwd library", "fk_jacobian": "fk_jacobian library"}.get(what)
+    if key not in FLOPS:
+        key = None
+    if key is None:
+        return ""
+    f = FLOPS[key]["flops_per_eval"]
+    hbm, valu = B * nbytes / us / 1e3 / 8000.0, B * f / us / 1e6 / 157.3
+    return "  | HBM %.2f  VALU %.2f (%d flop/eval executed, %s) -> bound: %s" % (
+        hbm, valu, f, "own kernel" if own else "library kernel", "HBM" if hbm >= valu else "vector FP32")
+
+
 sizes = [int(a) for a in sys.argv[1:]] or [65536, 1 << 20, 1 << 22]
 m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
 for B in sizes:
     q, qd, qdd = (t.cuda() for t in sample(m, B))
     plan = m.plan_fk_and_jacobian(q, link)
     us = graph_time(plan.launch)
-    print("fk_jacobian panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
+    print("fk_jacobian panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3) + bound("fk_jacobian", B, us, 224))
     if B > (1 << 22):   # working set >> the 256 MB Infinity Cache: the metric kernel only
         del plan
         continue
@@ -45,19 +75,19 @@ for B in sizes:
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(rnea)
     print("rnea        panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s  %5.1f TFLOP/s (2.6 kflop/eval)" %
-          (B, us, B * 112 / us / 1e3, B / us / 1e3, B * 2.6e3 / us / 1e6))
+          (B, us, B * 112 / us / 1e3, B / us / 1e3, B * 2.6e3 / us / 1e6) + bound("rnea", B, us, 112))
     Hm = torch.empty(B, 7, 7, device="cuda")
     def crba():
         backend._check(lib.drm_crba(ctypes.byref(walk), q.data_ptr(), B, Hm.data_ptr(), None,
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(crba)
-    print("crba        panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3))
+    print("crba        panda B=%8d %9.2f us  %7.1f GB/s (224 B/eval)  %6.2f Gevals/s" % (B, us, B * 224 / us / 1e3, B / us / 1e3) + bound("crba", B, us, 224))
     acc = torch.empty(B, 7, device="cuda")
     def fd():
         backend._check(lib.drm_forward_dynamics(ctypes.byref(walk), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), B, 1,
                                                 acc.data_ptr(), None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     us = graph_time(fd)
-    print("fwd dyn     panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s" % (B, us, B * 112 / us / 1e3, B / us / 1e3))
+    print("fwd dyn     panda B=%8d %9.2f us  %7.1f GB/s (112 B/eval)  %6.2f Gevals/s" % (B, us, B * 112 / us / 1e3, B / us / 1e3) + bound("fwd dyn", B, us, 112))
     gtau = torch.randn(B, 7, device="cuda")
     us = graph_time(lambda: backend.rnea_backward(dt.program, of, dt.ops_i, q, qd, qdd, gtau, True, True, 7, 0b10, True), launches=20)
     print("rnea bwd    panda B=%8d %9.2f us  %7.1f GB/s (196 B/eval)  %6.2f Gevals/s  (1 learnable link + input grads)" %
@@ -71,7 +101,7 @@ for B in sizes:
     print("rnea bwd    panda B=%8d %9.2f us  the same on the %d-op walk the API builds (fixed tail folded)" % (B, us, dl.program.n_ops))
     dfz = m._dynamics_walk()
     us = graph_time(lambda: backend.rnea_backward(dfz.program, m._ops_f(dfz), dfz.ops_i, q, qd, qdd, gtau, True, True, 7, 0, True), launches=20)
-    print("rnea bwd    panda B=%8d %9.2f us  input gradients only (%d-op walk)" % (B, us, dfz.program.n_ops))
+    print("rnea bwd    panda B=%8d %9.2f us  input gradients only (%d-op walk), 196 B/eval" % (B, us, dfz.program.n_ops) + bound("rnea bwd", B, us, 196))
     idx = m._name_to_idx_map[link]
     df = m._get_walk(("fk", (idx,)), targets=[idx]); off = m._ops_f(df)
     pos = torch.empty(B, 1, 3, device="cuda"); quat = torch.empty(B, 1, 4, device="cuda")
@@ -160,7 +190,7 @@ for Bf in (Bs, 1 << 20):
     plan_f = m.plan_fk_and_inverse_dynamics(qf, qdf, qddf, link)
     us = graph_time(plan_f.launch)
     print("config 3: fk + rnea panda B=%8d, ONE fused launch (drm_fk_rnea) %9.2f us  %7.1f GB/s (140 B/eval)  %6.2f Gevals/s"
-          % (Bf, us, Bf * 140 / us / 1e3, Bf / us / 1e3))
+          % (Bf, us, Bf * 140 / us / 1e3, Bf / us / 1e3) + bound("fk+rnea", Bf, us, 140))
     plan_r = m.plan_inverse_dynamics(qf, qdf, qddf)
     us = graph_time(plan_r.launch)
     print("          rnea alone      B=%8d %9.2f us" % (Bf, us))
