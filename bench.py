@@ -290,7 +290,7 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
                 launch()
 
     # (1) the wall-clock bracket: nothing but the K steps between the two synchronizes — recording the two events from the
-    # host inside it costs ~6 us of an ~95 us region at the driver's --steps 20 (tools/region_probe2.py: 4.95 -> 4.65 us per step)
+    # host inside it costs ~6 us of an ~95 us region at the driver's --steps 20 (tools/probe_region.py --events: 4.95 -> 4.65 us per step)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
