@@ -91,6 +91,14 @@ for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two
     if line:
         with open(os.path.join(prof, tag + dst), "w") as f:
             f.write(line + "\n")
+st = glob.glob(os.path.join(OUT, "prof_all_own", "*", "*_kernel_stats.csv"))
+if st:      # round 5: kernel_times.py under DRM_SPECIALIZE=1 — which kernels the entry points dispatch to once a robot has its own
+    with open(st[0]) as f, open(os.path.join(prof, tag + "_all_kernels_own_rocprof_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or "drm" in line:
+                g.write(line)
+if os.path.exists(os.path.join(OUT, "kernel_times_own.txt")):
+    shutil.copy(os.path.join(OUT, "kernel_times_own.txt"), os.path.join(prof, tag + "_kernel_times_own_kernels.txt"))
 st = glob.glob(os.path.join(OUT, "prof_cfg", "*", "*_kernel_stats.csv"))
 if st:      # round 4: the kernels of BASELINE configurations 2-5 (tools/kernel_bench.py configs), eagerly launched
     shutil.copy(st[0], os.path.join(prof, tag + "_configs_kernel_stats.csv"))
@@ -129,7 +137,8 @@ with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
 
 acc = defaultdict(lambda: defaultdict(list))
 for r in (list(rows("prof_sq/*/*_counter_collection.csv")) + list(rows("prof_sq3/*/*_counter_collection.csv")) + list(rows("prof_sq_cfg/*/*_counter_collection.csv")) +
-          list(rows("prof_sq4_*/*/*_counter_collection.csv")) + list(rows("prof_sq5_*/*/*_counter_collection.csv"))):
+          list(rows("prof_sq4_*/*/*_counter_collection.csv")) + list(rows("prof_sq5_*/*/*_counter_collection.csv")) +
+          list(rows("prof_sq6_*/*/*_counter_collection.csv"))):     # (sq6: the robots' own kernels, DRM_SPECIALIZE=1)
     k = r["Kernel_Name"].split("(")[0].replace("void drm::", "")
     acc[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]

@@ -42,6 +42,13 @@ done
 for r in panda_no_gripper panda allegro_left iiwa7_allegro; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq5_$r -- python $ROOT/tools/kernel_bench.py backward $r 262144 > $OUT/prof_sq5_$r.log 2>&1
 done
+# round 5: the robots' OWN kernels (model.specialize(): constants folded in; DRM_SPECIALIZE=1 attaches them on first use) — SQ counters,
+# which kernel every entry point dispatches to, and the timings beside the library's
+DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_hot -- python $ROOT/tools/kernel_bench.py hot 131072 1048576 > $OUT/prof_sq6_hot.log 2>&1
+DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_dyn -- python $ROOT/tools/kernel_bench.py dynamics panda_no_gripper 262144 > $OUT/prof_sq6_dyn.log 2>&1
+DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_bwd -- python $ROOT/tools/kernel_bench.py backward panda_no_gripper 262144 > $OUT/prof_sq6_bwd.log 2>&1
+DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all_own -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all_own.log 2>&1
+DRM_SPECIALIZE=1 python $ROOT/tools/kernel_times.py 2>&1 | grep -v amdgpu.ids > $OUT/kernel_times_own.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
@@ -65,7 +72,7 @@ fi
 cd $ROOT
 # keep what travels back small: per-dispatch counter rows of OUR kernels only
 for f in $(find gpurun_out -name "*counter_collection.csv"); do
-  head -1 $f > $f.small; grep "drm::" $f >> $f.small; mv $f.small $f
+  head -1 $f > $f.small; grep "drm" $f >> $f.small; mv $f.small $f
 done
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 du -sh gpurun_out
