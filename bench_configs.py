@@ -188,6 +188,10 @@ def leg_launcher(name, device):
         return panda.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link").launch
     if name == "config4":
         hand = load("allegro_left", device)
+        try:
+            hand.specialize()
+        except Exception:       # noqa: BLE001
+            pass
         q, _ = uniform_q(hand, 65536, device, 4004)
         return lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
     if name in ("config5", "config5_fk_mse"):
@@ -376,12 +380,30 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
     B = 65536
     q, _ = uniform_q(hand, B, device, 4004)
     with torch.no_grad():
-        us, us_min = graph_launch_us(lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS), 100)
+        us_lib, us_lib_min = graph_launch_us(lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS), 100)
+    us, us_min, kernel4, own4, own4_why = us_lib, us_lib_min, "drm::fk_fan_chain_kernel<8, 5, 4> (library, link-major outputs)", False, None
+    try:      # the hand's own fan-out kernel: every finger's constants folded in, scalar chain walk (csrc/drm_arm_static.hpp)
+        hand_own = load("allegro_left", device)
+        hand_own.specialize()
+        with torch.no_grad():
+            hand_own.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
+        from differentiable_robot_model_amd import specialize as sp
+        tips_idx = [hand_own._name_to_idx_map[t] for t in ALLEGRO_TIPS]
+        fan = hand_own._fanout_chains(tips_idx, hand_own._get_walk(("fk", tuple(tips_idx)), targets=tips_idx))
+        if fan and all((w.program._special or {}).get(sp.SPECIAL_FK_FAN_LINKS) for w in fan):
+            hand, own4 = hand_own, True
+            with torch.no_grad():
+                us, us_min = graph_launch_us(lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS), 100)
+            kernel4 = "drm_fk_fan_links_static (the hand's constants folded in; csrc/drm_arm_static.hpp)"
+    except Exception as err:       # noqa: BLE001  (no hipcc: the library's kernel is the path)
+        own4_why = str(err)[:200]
+    with torch.no_grad():
         poses = hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
     legs.append({"config": 4, "name": "config4", "workload": "Allegro hand 16-DoF (allegro_left), FK to the four fingertips through "
                  "compute_forward_kinematics_links (one launch, one wavefront per finger), batch %d, q~U(joint limits)" % B,
                  "batch": B, "launch_us": us, "launch_us_min": us_min, "evals_per_s": B / us * 1e6,
-                 "roofline": roofline(176, B, us, "drm::fk_fan_chain_kernel<8, 5, 4> (link-major outputs)"),
+                 "own_kernel": own4, "own_kernel_unavailable": own4_why, "library_kernel_launch_us": us_lib,
+                 "roofline": roofline(176, B, us, kernel4),
                  "io_floor_us": IO_FLOOR_US["config4"][0], "io_floor_source": IO_FLOOR_US["config4"][1]})
     ref_rows = 16384             # the reference walks all 21 links once per fingertip: ~4e4 evals/s on one core
     arrays["c4_q"] = host(q[:ref_rows])

@@ -104,4 +104,66 @@ __device__ __forceinline__ void rnea_backward_arm_static_body(ROW row, const flo
     tile_store<NJ>(gqdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward kinematics of 2 .. 4 disjoint serial chains (the fingertips of a hand, BASELINE configuration 4) with link-major outputs
+// (drm_fk_fanout_links: pos [T, B, 3], quat [T, B, 4]), one wavefront per chain and 64-row tile — the layout of
+// csrc/drm_chain_kernels.hip fk_fan_chain_kernel<.., LINKS = true> — with every chain's constants folded into the instruction stream.
+// The chain is walked in SCALAR form (joint_rot_z / compose of csrc/drm_sample.hpp): the library's pair-packed form multiplies PAIRS
+// of constants, of which a zero half cannot be dropped (the metric kernel folded a tenth of its instructions that way), while a
+// hand's chain tables are almost pure axis permutations (Allegro: 50 of a finger's 60 F / t entries are 0 or +-1) and a scalar
+// product with a constant 0 or 1 is no instruction at all.
+//   C (generated per chain): USED ops, DOF[k] = the DoF column op k reads or -1 (fixed), MOVING = how many move, Q4 = the moving ops
+//   read four consecutive columns starting at a multiple of four of rows of n % 4 == 0 floats (ONE 16-byte load), PERM = the target
+//   frame's un-permutation code, row(k) -> op k's constant row
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void fk_fan_links_static_wave(const float *__restrict__ q, float *__restrict__ pos, float *__restrict__ quat,
+                                                         int64_t B, int chain, float *st) {
+    constexpr int M = C::MOVING, N = C::NDOFS;
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t b0 = (int64_t)blockIdx.x * WAVE;
+    float qv[M];
+    if constexpr (C::Q4) {
+        const float4 v = *reinterpret_cast<const float4 *>(q + (b0 + lane) * N + C::FIRST);
+        qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = v.w;
+    } else {
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < C::USED; ++k)
+            if (C::dof(k) >= 0) qv[j++] = q[(b0 + lane) * N + C::dof(k)];
+    }
+    float cs[M], sn[M];
+    chain_trig<M>(qv, cs, sn);
+    Pose ee;
+    int j = 0;
+#pragma unroll
+    for (int k = 0; k < C::USED; ++k) {
+        const OpFT o = load_ft(C::row(k));
+        float J[9];
+        if (C::dof(k) >= 0) {
+            joint_rot_z(o.F, cs[j], sn[j], J);
+            ++j;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J[i] = o.F[i];
+        }
+        if (k == 0) { // the parent is the identity root: R = J, p = t exactly
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ee.R[i] = J[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ee.p[i] = o.t[i];
+        } else {
+            compose(ee, J, o.t, ee);
+        }
+    }
+    st[lane * 3 + 0] = ee.p[0]; st[lane * 3 + 1] = ee.p[1]; st[lane * 3 + 2] = ee.p[2];
+    wave_lds_sync();
+    if (lane < 48u) store16_wt(reinterpret_cast<float4 *>(pos + ((int64_t)chain * B + b0) * 3) + lane, reinterpret_cast<const float4 *>(st)[lane]);
+    float qt[4];
+    unpermute(C::PERM, ee.R);
+    quat_xyzw(ee.R, qt);
+    store16_wt(reinterpret_cast<float4 *>(quat + ((int64_t)chain * B + b0) * 4) + lane, make_float4(qt[0], qt[1], qt[2], qt[3]));
+}
+
 } // namespace drm

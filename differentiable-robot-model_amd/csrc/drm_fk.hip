@@ -463,7 +463,22 @@ extern "C" int drm_fk_fanout_links(const drm_walk *chains, int32_t n_chains, con
     const int n = chains[0].n_dofs;
     // full tiles: a wavefront per chain, each writing its link's arrays; what is left (a ragged tail; everything when the fan-out
     // kernel does not take the call): one single-target launch per chain into the same link-major arrays
-    int64_t done = launch_fk_fan_chains(chains, n_chains, q, B, pos, quat, (hipStream_t)stream, true);
+    int64_t done = 0;
+    {   // the hand's own kernel: every chain's constants folded into the instruction stream (csrc/drm_arm_static.hpp, specialize.py) —
+        // the host stored the SAME handle on every chain walk of the call it was built for
+        const void *own = chains[0].special[DRM_SPECIAL_FK_FAN_LINKS];
+        for (int t = 1; t < n_chains; ++t)
+            if (chains[t].special[DRM_SPECIAL_FK_FAN_LINKS] != own) own = nullptr;
+        if (own && B >= WAVE && !(B & 3) && B / WAVE < 0x7fffffffLL && ((((uintptr_t)q | (uintptr_t)pos | (uintptr_t)quat) & 15u) == 0)) {
+            const int64_t n_tiles = B / WAVE;
+            int64_t rows = B;
+            void *args[] = {(void *)&q, (void *)&pos, (void *)&quat, (void *)&rows};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)own, (unsigned)n_tiles, 1, 1, WAVE * (unsigned)n_chains, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fk_fan_links_static): %s", hipGetErrorString(e));
+            done = n_tiles * WAVE;
+        }
+    }
+    if (done == 0) done = launch_fk_fan_chains(chains, n_chains, q, B, pos, quat, (hipStream_t)stream, true);
     if (done > 0) {
         int rc = launched();
         if (rc) return rc;

@@ -290,6 +290,13 @@ class DifferentiableRobotModel(torch.nn.Module):
             raise RuntimeError("per-robot kernels are HIP code objects: the model must live on a HIP device (it is on %s)" % self._device)
         dw = self._dynamics_walk()
         from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
+        if not self._learnable:
+            # constant models: the kernels that bake the robot's CONSTANTS (round 5) are built where they are first needed — the fused
+            # FK + RNEA kernel of an arm's target link, the fan-out FK kernel of a set of fingertips (compute_forward_kinematics_links)
+            self._arm_specialized = True
+            for plan in self._fanout_plans.values():
+                if plan:
+                    self._fan_special(plan)
         if tune:
             if dw.program.shape & SHAPE_ARM_CHAIN or dw.program.n_ops > sp.MAX_STATIC_OPS:
                 return {}
@@ -481,6 +488,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                         walks = [self._chain_walk(t) for t in targets]
                         if len({w.program.capacity for w in walks}) == 1:
                             self._fanout_plans[key] = walks
+                            self._fan_special(walks)
                             return walks
                     cap = max(build_walk(self._spec, targets=[t]).capacity for t in targets)
                     plan = []
@@ -493,6 +501,21 @@ class DifferentiableRobotModel(torch.nn.Module):
                             gsign=torch.from_numpy(prog.gsign.reshape(-1)).to(self._device)))
             self._fanout_plans[key] = plan
         return self._fanout_plans[key]
+
+    def _fan_special(self, walks) -> None:
+        """After specialize() (or under DRM_SPECIALIZE=1) on a constant model: the fan-out FK call's own kernel — every chain's
+        constants folded into the instruction stream (specialize.attach_fan), once per set of targets."""
+        if self._learnable or self._device.type != "cuda":
+            return
+        explicit = getattr(self, "_arm_specialized", False)
+        if not (explicit or os.environ.get("DRM_SPECIALIZE") in ("1", "tune")):
+            return
+        from . import specialize as sp
+        try:
+            sp.attach_fan([w.program for w in walks], [self._ops_f(w).detach().cpu().numpy() for w in walks], self._n_dofs)
+        except sp.SpecializeError:
+            if explicit:
+                raise      # (the environment opt-in on a machine without hipcc keeps the library's kernels)
 
     def _kinematic_param_mask(self, dw: _DeviceWalk) -> int:
         """bit k set <=> op k's R_fixed / trans come from a learnable parametrisation (needs a constant gradient)."""

@@ -34,6 +34,8 @@ ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "dr
                SPECIAL_CRBA_ARM: "drm_crba_arm_static", SPECIAL_FD_ARM: "drm_fd_arm_static",
                SPECIAL_RNEA_BACKWARD_ARM: "drm_rnea_backward_arm_static"}
 ARM_DYNAMICS = (SPECIAL_CRBA_ARM, SPECIAL_FD_ARM, SPECIAL_RNEA_BACKWARD_ARM)
+SPECIAL_FK_FAN_LINKS = 9
+FAN_KERNEL = "drm_fk_fan_links_static"
 ARM_KINDS = tuple(ARM_KERNELS)
 # (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
 # folds only a tenth of its instructions and the launch is bound by its loads and its store drain, profiles/r05_metric_static.txt.)
@@ -341,6 +343,82 @@ extern "C" __global__ void __launch_bounds__(64) drm_rnea_backward_arm_static(co
     drm::rnea_backward_arm_static_body<7, %d>(drm::RobotRow(), q, qd, qdd, gtau, n_tiles, flags, gq, gqd, gqdd);
 }
 """ % (rows, links, links, links)
+
+
+def fan_chain(prog: WalkProgram, n_dofs: int) -> Optional[dict]:
+    """What the fan-out kernel needs to know about one chain walk, or None when the chain does not qualify: a serial chain of at
+    most 8 ops without branch points or sliding joints; per op the DoF column it reads (-1: fixed)."""
+    from .flatten import SHAPE_SERIAL_CHAIN
+    if not (prog.shape & SHAPE_SERIAL_CHAIN) or prog.n_slots or not 1 <= prog.n_ops <= 8 or int(prog.chain_prismatic):
+        return None
+    dof = [int(v) - 1 for v in list(prog.chain_dof1)[:prog.n_ops]]
+    moving = [d for d in dof if d >= 0]
+    if not moving or len(set(moving)) != len(moving) or max(moving) >= n_dofs:
+        return None
+    perm = getattr(prog, "_target_perm", None)
+    if perm is None:
+        from .flatten import OPI_PERM
+        perm = int(prog.ops_i[prog.n_ops - 1, OPI_PERM])
+    q4 = (len(moving) == 4 and n_dofs % 4 == 0 and moving[0] % 4 == 0 and moving == list(range(moving[0], moving[0] + 4))
+          and dof[:4] == moving)
+    return {"used": prog.n_ops, "dof": dof, "moving": len(moving), "first": moving[0], "q4": q4, "perm": int(perm)}
+
+
+def fan_source(chains, tables, n_dofs: int) -> str:
+    """The translation unit of one fan-out FK call: `chains` = fan_chain() of its 2 .. 4 chain walks, `tables` their [capacity, 32]
+    constant tables (the first `used` rows are written out)."""
+    import numpy as np
+    if not 2 <= len(chains) <= 4:
+        raise SpecializeError("fan-out FK takes 2 to 4 chains")
+    parts = []
+    for i, (c, t) in enumerate(zip(chains, tables)):
+        t = np.asarray(t, np.float32)[:c["used"]]
+        rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in t)
+        parts.append("""static __device__ constexpr float OPS%d[%d * DRM_OPF_STRIDE] = {
+%s};
+struct Chain%d {
+    static constexpr int USED = %d, MOVING = %d, NDOFS = %d, FIRST = %d, PERM = %d;
+    static constexpr bool Q4 = %s;
+    static __device__ constexpr int dof(int k) {
+        constexpr int D[%d] = {%s};
+        return D[k];
+    }
+    static __device__ const float *row(int k) { return OPS%d + k * DRM_OPF_STRIDE; }
+};
+""" % (i, c["used"], rows, i, c["used"], c["moving"], n_dofs, c["first"], c["perm"], "true" if c["q4"] else "false", c["used"],
+       ", ".join(str(d) for d in c["dof"]), i))
+    cases = "\n".join("    case %d: drm::fk_fan_links_static_wave<drm::Chain%d>(q, pos, quat, B, %d, st + %d * 3 * drm::WAVE); break;" % (i, i, i, i)
+                      for i in range(len(chains)))
+    return """// generated by differentiable-robot-model_amd/specialize.py — the chains of one fan-out FK call as compile-time constants
+#include "drm_arm_static.hpp"
+namespace drm {
+%s}
+extern "C" __global__ void __launch_bounds__(%d) %s(const float *q, float *pos, float *quat, long long B) {
+    __shared__ __attribute__((aligned(16))) float st[%d * 3 * drm::WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    switch (wave) {
+%s
+    default: break;
+    }
+}
+""" % ("".join(parts), 64 * len(chains), FAN_KERNEL, len(chains), cases)
+
+
+def attach_fan(progs, tables, n_dofs: int) -> Optional[int]:
+    """Build (cached) and attach the constant-folded fan-out FK kernel of these 2 .. 4 chain walks: the SAME handle on every program
+    (drm_fk_fanout_links checks that).  None when a chain does not qualify (the library's fan-out kernel keeps serving the call)."""
+    chains = [fan_chain(p, n_dofs) for p in progs]
+    if any(c is None for c in chains) or not 2 <= len(chains) <= 4:
+        return None
+    have = {(getattr(p, "_special", None) or {}).get(SPECIAL_FK_FAN_LINKS) for p in progs}
+    if len(have) == 1 and None not in have:
+        return have.pop()
+    handle = _load(build(fan_source(chains, tables, n_dofs), ARM_FLAGS), FAN_KERNEL)
+    for p in progs:
+        special = dict(getattr(p, "_special", None) or {})
+        special[SPECIAL_FK_FAN_LINKS] = handle
+        p._special, p._ws_cache = special, None
+    return handle
 
 
 def _load(path: str, kernel: str) -> int:

@@ -62,6 +62,9 @@ extern "C" {
 #define DRM_SPECIAL_FD_ARM 7      /* drm_forward_dynamics  kernel "drm_fd_arm_static", arguments q, qd, f, n_tiles, flags, qdd          */
 #define DRM_SPECIAL_RNEA_BACKWARD_ARM 8 /* drm_rnea_backward with param_mask == 0 (input gradients of a constant model): kernel
                                      "drm_rnea_backward_arm_static", arguments q, qd, qdd, grad_tau, n_tiles, flags, grad_q, grad_qd, grad_qdd */
+/* ... and on the 2 .. 4 CHAIN walks of a fan-out FK call (the fingertips of a hand): ONE kernel for all of them, a wavefront per
+ * chain, every chain's constants folded in (scalar chain walk, csrc/drm_arm_static.hpp); the SAME handle on every chain walk. */
+#define DRM_SPECIAL_FK_FAN_LINKS 9 /* drm_fk_fanout_links  kernel "drm_fk_fan_links_static", arguments q, pos, quat, B (int64)       */
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

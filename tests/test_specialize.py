@@ -561,6 +561,54 @@ def test_gpu_arm_inertia_matrix_forward_dynamics_and_input_gradients_with_folded
             assert float((a - b).abs().max()) <= 2e-4 * max(1e-9, float(b.abs().max()))
 
 
+def test_fan_source_describes_the_chains():
+    """(CPU) The fan-out FK call of the Allegro's four fingertips as a generated translation unit: per chain its ops' DoF columns,
+    the 16-byte load of four consecutive columns, the table rows as exact literals."""
+    h = load_model("allegro_left")
+    tips = [h._name_to_idx_map[t] for t in ("link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip")]
+    merged = h._get_walk(("fk", tuple(tips)), targets=tips)
+    fan = h._fanout_chains(tips, merged)
+    chains = [sp.fan_chain(w.program, h._n_dofs) for w in fan]
+    assert sorted(c["dof"] for c in chains) == [[0, 1, 2, 3, -1], [4, 5, 6, 7, -1], [8, 9, 10, 11, -1], [12, 13, 14, 15, -1]]
+    assert all(c["q4"] and c["moving"] == 4 and c["used"] == 5 and c["perm"] == 2 for c in chains)
+    src = sp.fan_source(chains, [h._ops_f(w).detach().numpy() for w in fan], h._n_dofs)
+    assert src.count("struct Chain") == 4 and "__launch_bounds__(256) drm_fk_fan_links_static" in src
+    assert "case 3: drm::fk_fan_links_static_wave<drm::Chain3>(q, pos, quat, B, 3, st + 3 * 3 * drm::WAVE)" in src
+    m = load_model("panda_no_gripper")                    # (an arm's chain qualifies as a chain; one chain is not a fan)
+    assert sp.fan_chain(m._chain_walk(8).program, 7)["dof"] == [0, 1, 2, 3, 4, 5, 6, -1]
+    with pytest.raises(sp.SpecializeError):
+        sp.fan_source(chains[:1], [h._ops_f(fan[0]).detach().numpy()], h._n_dofs)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("robot,links", [("allegro_left", ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]),
+                                         ("trifinger_edu", ["finger_tip_link_0", "finger_tip_link_120", "finger_tip_link_240"]),
+                                         ("iiwa7_allegro", ["link_3.0_tip", "link_15.0_tip"])])
+def test_gpu_fan_out_fk_with_folded_constants(robot, links):
+    """BASELINE configuration 4's call (compute_forward_kinematics_links of a hand's fingertips) through the hand's own fan-out
+    kernel: every row against the fp64 oracle and against the library's kernel; full tiles, a ragged tail, a batch that is not a
+    multiple of 4 (the library's path)."""
+    from helpers import TOL_POS, TOL_QUAT, max_err, quat_close
+    mc, plain, own = load_model(robot), load_model(robot, "cuda"), load_model(robot, "cuda")
+    own.specialize()
+    orc = Oracle(mc._spec)
+    idx = [mc._name_to_idx_map[n] for n in links]
+    for B in (64, 64 * 9 + 20, 65536, 1001):
+        q = sample_states(mc, B, seed=B)[0]
+        dq = torch.from_numpy(q).cuda()
+        got, lib = own.compute_forward_kinematics_links(dq, links), plain.compute_forward_kinematics_links(dq, links)
+        rp, rq = orc.fk(q.astype(np.float64), idx, np.float64)
+        for t, name in enumerate(links):
+            assert max_err(got[name][0].cpu().numpy(), rp[:, t]) <= TOL_POS["atol"], (B, name)
+            assert quat_close(got[name][1].cpu().numpy(), rq[:, t], TOL_QUAT["atol"])[0], (B, name)
+            assert float((got[name][0] - lib[name][0]).abs().max()) <= 1e-6
+    fan = own._fanout_chains(idx, own._get_walk(("fk", tuple(idx)), targets=idx))
+    if fan is not None and all(sp.fan_chain(w.program, own._n_dofs) for w in fan):
+        handles = {w.program._special.get(sp.SPECIAL_FK_FAN_LINKS) for w in fan}
+        assert len(handles) == 1 and None not in handles          # (ONE kernel, the same handle on every chain walk)
+
+
 def test_specialize_needs_a_device_model():
     """(CPU) per-robot kernels are HIP code objects: specialize() needs a model on a HIP device."""
     m = load_model("panda_no_gripper")
