@@ -17,8 +17,19 @@
 
 #ifdef __HIPCC__
 #include "drm_common.hpp"
+
 #endif
 #include "drm_tree.hpp"
+
+// The rows of the walk table, as the straight-line walks below read them.  A per-robot translation unit of a CONSTANT model (round 5,
+// specialize.source(..., table=...)) defines `struct drm::RobotTable` — the table a constexpr array — and DRM_STATIC_CONST_TABLE before
+// it includes this header: every row(k)[i] is then a compile-time constant, products with the robot's exact zeros and ones fold away
+// (built with -fno-signed-zeros -ffinite-math-only) and the LDS copy of the table is never read.  Otherwise the rows come from LDS.
+#ifdef DRM_STATIC_CONST_TABLE
+#define DRM_STATIC_ROW(lc) [](int k) -> const float * { return ::drm::RobotTable::row(k); }
+#else
+#define DRM_STATIC_ROW(lc) [&](int k) -> const float * { return (lc) + k * DRM_OPF_STRIDE; }
+#endif
 
 namespace drm {
 
@@ -577,7 +588,7 @@ __device__ __forceinline__ void rnea_static_body(const float *__restrict__ ops_f
             rows_to_stage<n>(qd + base, off, stage + n * WAVE);
             if (qdd) rows_to_stage<n>(qdd + base, off, stage + 2 * n * WAVE);
         }
-        rnea_static_walk<R, LONE && DRM_STATIC_PREF != 0>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+        rnea_static_walk<R, LONE && DRM_STATIC_PREF != 0>(DRM_STATIC_ROW(lc), flags,
                                                   [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; },
                                                   [&](int d, float v) { trow[d] = v; });
         if constexpr (LONE) __builtin_amdgcn_s_waitcnt(0); // the next rows have landed (issued a whole walk ago: nothing to wait for in practice)
@@ -617,7 +628,7 @@ __device__ __forceinline__ void crba_static_body(const float *__restrict__ ops_f
     tri[ZERO * TRI + lane] = 0.0f;
     if (lane == 0) tri[ZERO * TRI + WAVE] = 0.0f;
     wave_lds_sync();
-    crba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, [&](int d) { return qv[d]; },
+    crba_static_walk<R>(DRM_STATIC_ROW(lc), [&](int d) { return qv[d]; },
                         [&](auto KR, auto CR, float v) { // (reversed op indices as types: slot(k, c) is a compile-time constant)
                             constexpr int k = N - 1 - decltype(KR)::value, c = N - 1 - decltype(CR)::value;
                             tri[R::slot(k, c) * TRI + lane] = v;
@@ -687,7 +698,7 @@ __device__ __forceinline__ void aba_static_body(const float *__restrict__ ops_f,
             for (int d = 0; d < n; ++d) fv[d] = f[row + d];
         }
         float acc[n];
-        aba_static_walk<R>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags,
+        aba_static_walk<R>(DRM_STATIC_ROW(lc), flags,
                            [&](int d, float &x, float &v) { x = qv[d]; v = qdv[d]; }, [&](int d) { return fv[d]; },
                            [&](int d, float v) { acc[d] = v; },
                            [&](int k, const Motion &M) {
@@ -792,7 +803,7 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
 #pragma unroll
         for (int d = 0; d < n; ++d) gqv[d] = gqdv[d] = gqddv[d] = 0.0f;
         rnea_backward_static_walk<R>(
-            [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, flags, param_mask, gq != nullptr,
+            DRM_STATIC_ROW(lc), flags, param_mask, gq != nullptr,
             [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; }, [&](int d) { return gtv[d]; },
             [&](int d, float x, float v, float a) { gqv[d] = x; gqdv[d] = v; gqddv[d] = a; },
             [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
@@ -905,7 +916,7 @@ __device__ __forceinline__ void crba_shape_body(const float *__restrict__ ops_f,
         const int oa = a0 < a1 ? a0 : a1, ob = a0 < a1 ? a1 : a0;
         slot_of[e] = (T::related(oa, ob) ? T::slot(oa, ob) : ZERO) * TRI;
     }
-    crba_static_walk_kinds<T>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, [&](int k) { return PLAIN ? 1 : kinds[k]; },
+    crba_static_walk_kinds<T>(DRM_STATIC_ROW(lc), [&](int k) { return PLAIN ? 1 : kinds[k]; },
                               [&](int k) { return qv[k]; },
                               [&](auto KR, auto CR, float v) { // (reversed op indices as types: the slot is a compile-time constant)
                                   constexpr int k = N - 1 - decltype(KR)::value, c = N - 1 - decltype(CR)::value;

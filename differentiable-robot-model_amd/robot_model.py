@@ -277,7 +277,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         """Build (hipcc, 3-7 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics and its
         reverse mode, the inertia matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the
         shapes the library ships straight-line kernels for (a mobile manipulator such as Fetch) the loop-structured kernels stop being
-        the only choice (Fetch at 2^20 rows: 226 -> 104 us, 966 -> 260 us, 650 -> 172 us, 600 -> 244 us).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
+        the only choice (Fetch at 2^20 rows: 233 -> 70 us, 982 -> 206 us, 655 -> 170 us, 615 -> 150 us — round 5: a CONSTANT model's
+        kernels also carry its walk table as compile-time constants, so products with the robot's zeros and ones are gone).  DRM_SPECIALIZE=1 in the environment does it on first use.  Returns True when a kernel was
         attached, False when the robot already runs a compiled straight-line kernel (7-DoF arms, arm + hand, hands).  Models with
         learnable link parameters specialise their full walk as well (the kernel reads the same table).  `force`: build the
         robot's own kernels even when the library has a straight-line kernel for its shape (measurements, tools/probe_special.py).
@@ -300,7 +301,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         if tune:
             if dw.program.shape & SHAPE_ARM_CHAIN or dw.program.n_ops > sp.MAX_STATIC_OPS:
                 return {}
-            sp.attach(dw.program, self._spec, self._n_dofs)
+            sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
             return sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
         if not force and sp.arm_qualifies(dw.program, self._n_dofs):
             # a serial 7-DoF arm (Panda, iiwa): its OWN kernels too, of a different kind — the library's streaming walk with this
@@ -314,8 +315,15 @@ class DifferentiableRobotModel(torch.nn.Module):
             return True
         if not force and dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
             return False
-        sp.attach(dw.program, self._spec, self._n_dofs)
+        sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
         return True
+
+    def _const_table(self, dw: "_DeviceWalk"):
+        """The walk's table as a host array for kernels that carry it as compile-time constants (round 5) — None for a model with
+        learnable parameters (its kernels keep reading the table: it changes every step)."""
+        if self._learnable:
+            return None
+        return self._ops_f(dw).detach().cpu().numpy()
 
     def _arm_fused_special(self, tree: "_DeviceWalk", chain: "_DeviceWalk") -> None:
         """After specialize() (or under DRM_SPECIALIZE=1) on a serial 7-DoF arm: build and attach, once per target chain, the
@@ -374,9 +382,9 @@ class DifferentiableRobotModel(torch.nn.Module):
                 if sp.arm_qualifies(dw.program, self._n_dofs) and not self._learnable:
                     sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs)   # (constants folded in)
                 elif not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
-                    sp.attach(dw.program, self._spec, self._n_dofs)
+                    sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
                 elif mode == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN and dw.program.n_ops <= sp.MAX_STATIC_OPS:
-                    sp.attach(dw.program, self._spec, self._n_dofs)
+                    sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
                     sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
             except sp.SpecializeError:
                 pass
@@ -960,8 +968,13 @@ class DifferentiableRobotModel(torch.nn.Module):
         for dw in self._walks.values():
             dw.static_ops_f = None
             special = getattr(dw.program, "_special", None)
-            if special and any(k >= 4 for k in special):     # constant-folded arm kernels (specialize.attach_arm) bake the OLD constants
-                dw.program._special = {k: v for k, v in special.items() if k < 4}
+            if special and (any(k >= 4 for k in special) or getattr(dw.program, "_special_const", False)):
+                # kernels that carry the walk table as compile-time constants (specialize.attach_arm / attach_fan; attach(table=...))
+                # bake the OLD constants: dropped — specialize() again builds the table-reading kind
+                baked = getattr(dw.program, "_special_const", False)
+                dw.program._special = {} if baked else {k: v for k, v in special.items() if k < 4}
+                dw.program._special_const = False
+                dw.program._special_tried = False
                 dw.program._ws_cache = None
         self._arm_specialized = False
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)

@@ -143,8 +143,10 @@ def backward_lds_bytes(tree: Dict[str, list], capacity: int) -> int:
     return 4 * (n * 32 + capacity * 32 + (max(leaf_ordinals(tree)) + 1) * 18 * 64 + 4)
 
 
-def source(tree: Dict[str, list], n_dofs: int, capacity: int = 0) -> str:
-    """`capacity` (rows of the walk's table = pitch of grad_ops_f): > 0 adds the reverse-mode kernel, when its LDS fits."""
+def source(tree: Dict[str, list], n_dofs: int, capacity: int = 0, table=None) -> str:
+    """`capacity` (rows of the walk's table = pitch of grad_ops_f): > 0 adds the reverse-mode kernel, when its LDS fits.
+    `table` (round 5, constant models): the walk's [>= N, 32] float32 table, written into the translation unit as a constexpr array
+    the walks read instead of LDS (csrc/drm_static.hpp DRM_STATIC_ROW) — the robot's constants fold into the instruction stream."""
     backward = ""
     if capacity > 0 and backward_lds_bytes(tree, capacity) <= 64 * 1024:
         backward = """extern "C" __global__ void __launch_bounds__(64) drm_rnea_backward_static(
@@ -153,8 +155,26 @@ def source(tree: Dict[str, list], n_dofs: int, capacity: int = 0) -> str:
     drm::rnea_backward_static_body<drm::Robot, %d>(ops_f, q, qd, qdd, gtau, n_tiles, flags, param_mask, gq, gqd, gqdd, partials);
 }
 """ % capacity
+    const_table = ""
+    if table is not None:
+        import numpy as np
+        n = len(tree["parent"])
+        t = np.asarray(table, np.float32)
+        if t.ndim != 2 or t.shape[0] < n or t.shape[1] != 32:
+            raise SpecializeError("the walk table must be [>= %d, 32] floats" % n)
+        rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in t[:n])
+        const_table = """#include "drm_common.hpp"
+namespace drm {
+static __device__ constexpr float ROBOT_OPS[%d * DRM_OPF_STRIDE] = {
+%s};
+struct RobotTable {
+    static __device__ const float *row(int k) { return ROBOT_OPS + k * DRM_OPF_STRIDE; }
+};
+}
+#define DRM_STATIC_CONST_TABLE 1
+""" % (n, rows)
     text = """// generated by differentiable-robot-model_amd/specialize.py — one robot's whole-tree dynamics walk as compile-time constants
-#include "drm_static.hpp"
+%s#include "drm_static.hpp"
 %s__device__ const int drm_slot_of[] = DRM_SLOT_OF_INIT;
 extern "C" __global__ void __launch_bounds__(64) drm_rnea_static(const float *ops_f, const float *q, const float *qd, const float *qdd,
                                                                  int n_tiles, int flags, float *tau, uint32_t magic_n, uint32_t align) {
@@ -167,7 +187,7 @@ extern "C" __global__ void __launch_bounds__(64) drm_fd_static(const float *ops_
                                                                int n_tiles, int flags, float *qdd, uint32_t magic_n, uint32_t align) {
     drm::aba_static_body<drm::Robot>(ops_f, q, qd, f, n_tiles, flags, qdd, magic_n, align);
 }
-%s""" % (robot_struct(tree, n_dofs), backward)
+%s""" % (const_table, robot_struct(tree, n_dofs), backward)
     waves = os.environ.get("DRM_STATIC_WAVES")          # (experiments: force N wavefronts per SIMD on the forward kernels)
     if waves:
         for name in ("drm_rnea_static", "drm_fd_static"):
@@ -466,19 +486,21 @@ def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkP
     return special
 
 
-def attach(prog: WalkProgram, spec, n_dofs: int) -> Dict[int, int]:
+def attach(prog: WalkProgram, spec, n_dofs: int, table=None) -> Dict[int, int]:
     """Build (or fetch from the cache) and load the straight-line kernels of a whole-tree walk; the handles are stored on the
-    program, from where backend._walk_struct copies them into every drm_walk built for it."""
+    program, from where backend._walk_struct copies them into every drm_walk built for it.  `table` (a CONSTANT model's walk table
+    as a host array): the kernels carry it as compile-time constants (`source`) and no longer read ops_f — the host must drop them
+    when a parameter becomes learnable (`prog._special_const`)."""
     from . import backend
-    if getattr(prog, "_special", None):
+    if any(k in (getattr(prog, "_special", None) or {}) for k in KERNELS):
         return prog._special
     if prog.n_ops > MAX_STATIC_OPS:
         raise SpecializeError("walk of %d ops: the straight-line form is built for up to %d" % (prog.n_ops, MAX_STATIC_OPS))
     tree = walk_tree(prog, spec)
-    src = source(tree, n_dofs, prog.capacity if prog.backward_ok else 0)
-    path = build(src)
+    src = source(tree, n_dofs, prog.capacity if prog.backward_ok else 0, table)
+    path = build(src, ARM_FLAGS if table is not None else ())
     lib = backend.load_library()
-    handles = {}
+    handles = dict(getattr(prog, "_special", None) or {})
     for kind, kernel in KERNELS.items():
         if kernel not in src:           # (the reverse-mode kernel of a walk the backward entry points do not take / whose leaves exceed LDS)
             continue
@@ -486,6 +508,7 @@ def attach(prog: WalkProgram, spec, n_dofs: int) -> Dict[int, int]:
         backend._check(lib.drm_special_load(path.encode(), kernel.encode(), ctypes.byref(fn)))
         handles[kind] = fn.value
     prog._special = handles
+    prog._special_const = table is not None
     prog._ws_cache = None          # (the cached drm_walk predates the handles)
     return handles
 
