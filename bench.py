@@ -16,8 +16,10 @@
     names: none (default headline: the outputs stay sharded — the MPC / particle case, strong scaling of the compute), tau /
     all (`all_gather_into_tensor` of the torques / of tau + pos + quat, 28 / 56 B per row), root (gather to rank 0).  Every
     mode is timed in the same run (`gather_modes`) with the xGMI estimate beside it (`gather_model_us`): at N = 8 the shard's
-    7.3 MB take ~48 us over one 153 GB/s link against ~7.5 us of compute, so `all` is predicted SLOWER than one GPU doing the
-    whole batch (~41 us) — the number to quote for a sharded consumer is `none`.
+    7.3 MB take ~48 us over one 153 GB/s link against ~5.5 us of compute, so `all` is predicted SLOWER than one GPU doing the
+    whole batch (~30 us) — the number to quote for a sharded consumer is `none`.  The compute runs the robot's OWN kernel
+    (model.specialize(): Panda's constants folded into the instruction stream, hipcc at run time; `--library-kernels` for the
+    library's table-driven kernel: 7.1 / 42.6 us).
 
 Timing: W untimed steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides, max
 over ranks.  For the metric config the K launches are captured once into a hipGraph (one launch per step, same

@@ -985,5 +985,6 @@ def test_bench_line_carries_the_contract_fields():
     assert legs["config5"]["fk_mse_roofline"]["traffic"] is not None
     c3 = legs["config3_whole"]
     assert c3["own_kernel"] is True and c3["launch_us"] < c3["library_kernel_launch_us"]      # (hipcc is on the GPU box)
+    assert legs["config4"]["own_kernel"] is True and legs["config4"]["launch_us"] < legs["config4"]["library_kernel_launch_us"]
     for key, tol in (("tau", 2e-5), ("pos", 2e-6), ("quat", 2e-6)):
         assert legs["config3_shard"]["gpu_vs_reference_max_abs"][key] <= tol

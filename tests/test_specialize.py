@@ -447,6 +447,29 @@ def test_arm_source_builds(tmp_path, monkeypatch):
         sp.build(src + " ", sp.ARM_FLAGS)
 
 
+def _build_in_child(args):
+    cache, src = args
+    os.environ["DRM_SPECIAL_CACHE"] = cache
+    from differentiable_robot_model_amd import specialize as child_sp
+    path = child_sp.build(src, child_sp.ARM_FLAGS)
+    return path, os.path.getsize(path)
+
+
+@needs_hipcc
+def test_ranks_of_a_node_build_the_same_robot_at_once(tmp_path):
+    """(CPU) Four processes build the same translation unit into one cache at the same time — the ranks of a node under
+    DRM_SPECIALIZE=1: every one returns the same complete code object (per-process temporary names, atomic publish), and nothing but
+    that code object is left in the cache."""
+    import multiprocessing as mp
+    m = load_model("iiwa7")
+    dw = m._dynamics_walk()
+    src = sp.arm_source(m._ops_f(dw).detach().numpy(), dw.program.n_ops, False)
+    with mp.get_context("spawn").Pool(4) as pool:
+        got = pool.map(_build_in_child, [(str(tmp_path), src)] * 4)
+    assert len({p for p, _ in got}) == 1 and len({n for _, n in got}) == 1 and got[0][1] > 10000
+    assert sorted(os.listdir(str(tmp_path))) == [os.path.basename(got[0][0])]
+
+
 @pytest.mark.gpu
 @needs_hipcc
 @pytest.mark.parametrize("robot,link", [("panda_no_gripper", "panda_virtual_ee_link"), ("iiwa7", "iiwa_link_ee")])
