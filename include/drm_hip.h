@@ -215,7 +215,10 @@ typedef struct drm_walk {
      * (differentiable-robot-model_amd/specialize.py writes and compiles it: ~2 s with hipcc, cached).  When set, the full
      * 64-row tiles of drm_rnea / drm_crba / drm_forward_dynamics run it instead of the loop kernels (no scratch; drm_rnea at any pointer alignment); a ragged tail and every
      * walk without a handle behave as before.  The host guarantees that a handle was built for exactly this walk (n_ops,
-     * parents, DoF columns, joint kinds). */
+     * parents, DoF columns, joint kinds).
+     * ABI 10: 12 slots.  Kinds 4 .. 9 (DRM_SPECIAL_*_ARM, DRM_SPECIAL_FK_FAN_LINKS above) — and kinds 0 .. 3 when the host built
+     * them with the table as compile-time constants — carry the walk's CONSTANTS in their instruction stream and do not read
+     * ops_f: the host attaches them to constant models only and guarantees that the table they were built from is this walk's. */
     const void *special[DRM_SPECIAL_KINDS];
 } drm_walk;
 
