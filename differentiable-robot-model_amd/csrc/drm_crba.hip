@@ -96,8 +96,10 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool wrap = j + e >= nn;
-                const int jj = wrap ? j + e - nn : j + e, bb = wrap ? b + 1 : b;
+                // (a float4 spans up to four matrices when n = 1, nn = 1: round 5 — found by the random-tree goldens, a 1-DoF
+                // robot's rows 2 and 3 of every four came out zero; one wrap test was enough only for nn >= 4)
+                int jj = j + e, bb = b;
+                while (jj >= nn) { jj -= nn; ++bb; }
                 const int o = loff[jj];
                 v[e] = o >= 0 ? smem[o + bb * lstr[jj]] : 0.0f;
             }

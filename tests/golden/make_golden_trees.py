@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden_trees.npz: RANDOM kinematic trees — robots nobody shipped — through the UNMODIFIED reference on
+its CPU path (the random-tree tests had no reference side).  Twelve trees of 4 .. 18 links with random
+branching, sub-trees behind fixed joints at the root, fixed joints in between, revolute AND prismatic joints about +-x / y / z (what
+the reference models: every non-fixed joint an axis-aligned revolute one, robot_model.py:122-126), random frames, masses, centres of
+mass, inertias and dampings.  70 joint states per tree (one 64-row tile + a ragged tail): FK of every link, the Jacobian of the last
+link, inverse dynamics with and without gravity / damping, the joint-space inertia matrix, forward dynamics.  The URDF text travels
+in the file.  float32 in, float32 out, stored as they come.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_trees.py
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+N_TREES, BATCH = 12, 70
+AXES = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1"]
+
+
+def tree_urdf(seed):
+    """A random tree the reference accepts (links in parent-before-child order, axis-aligned joint axes)."""
+    rng = np.random.default_rng(91000 + seed)
+    n_links = int(rng.integers(4, 19))
+    chainy = rng.random()
+    fixed_root = rng.random() < 0.4
+    out = ['<?xml version="1.0"?>', '<robot name="gtree%d">' % seed, '  <link name="base"/>']
+    names, movable = ["base"], 0
+    for i in range(n_links):
+        name = "l%d" % i
+        parent = names[-1] if rng.random() < chainy else names[int(rng.integers(len(names)))]
+        if fixed_root and rng.random() < 0.3:
+            parent = "base"
+        A = rng.standard_normal((3, 3)) * 0.03
+        I = A @ A.T + np.eye(3) * 0.002
+        m, c = 0.05 + rng.random() * 0.8, rng.standard_normal(3) * 0.04
+        out.append('  <link name="%s"><inertial><origin xyz="%.5f %.5f %.5f" rpy="0 0 0"/><mass value="%.5f"/>'
+                   '<inertia ixx="%.6f" ixy="%.6f" ixz="%.6f" iyy="%.6f" iyz="%.6f" izz="%.6f"/></inertial></link>'
+                   % (name, c[0], c[1], c[2], m, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]))
+        xyz, rpy = rng.standard_normal(3) * 0.08, rng.standard_normal(3) * 0.7
+        u = rng.random()
+        last = i == n_links - 1 and movable == 0
+        kind = "fixed" if (not last and (u < 0.2 or (parent == "base" and fixed_root))) else ("prismatic" if u < 0.35 else "revolute")
+        if kind == "fixed":
+            out.append('  <joint name="j%d" type="fixed"><parent link="%s"/><child link="%s"/>'
+                       '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/></joint>' % (i, parent, name, *xyz, *rpy))
+        else:
+            movable += 1
+            out.append('  <joint name="j%d" type="%s"><parent link="%s"/><child link="%s"/>'
+                       '<origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/><axis xyz="%s"/>'
+                       '<limit effort="10" lower="-2.5" upper="2.5" velocity="3"/><dynamics damping="%.3f"/></joint>'
+                       % (i, kind, parent, name, *xyz, *rpy, AXES[int(rng.integers(6))], rng.random() * 0.2))
+        names.append(name)
+    out.append("</robot>")
+    return "\n".join(out) + "\n"
+
+
+def generate():
+    rm = ref_import.import_reference()
+    torch.set_num_threads(1)
+    out = {"n_trees": np.array(N_TREES)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for t in range(N_TREES):
+            text = tree_urdf(t)
+            path = os.path.join(tmp, "gtree%d.urdf" % t)
+            with open(path, "w") as f:
+                f.write(text)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = rm.DifferentiableRobotModel(path)
+            n = model._n_dofs
+            rng = np.random.default_rng(5000 + t)
+            q = torch.from_numpy(rng.uniform(-2.5, 2.5, (BATCH, n)).astype(np.float32))
+            qd = torch.from_numpy(rng.uniform(-1.0, 1.0, (BATCH, n)).astype(np.float32))
+            qdd = torch.from_numpy(rng.uniform(-2.0, 2.0, (BATCH, n)).astype(np.float32))
+            f = torch.from_numpy(rng.uniform(-1.0, 1.0, (BATCH, n)).astype(np.float32))
+            key = "t%d/" % t
+            out[key + "urdf"] = np.array(text)
+            for k, v in (("q", q), ("qd", qd), ("qdd", qdd), ("f", f)):
+                out[key + k] = v.numpy().copy()
+            names = model.get_link_names()
+            out[key + "links"] = np.array(names)
+            with torch.no_grad():
+                poses = model.compute_forward_kinematics_all_links(q)
+                # (the root's pose comes back as one row, robot_model.py:197-221)
+                out[key + "pos"] = np.stack([np.broadcast_to(poses[nm][0].reshape(-1, 3).numpy(), (BATCH, 3)) for nm in names], 1)
+                out[key + "quat"] = np.stack([np.broadcast_to(poses[nm][1].reshape(-1, 4).numpy(), (BATCH, 4)) for nm in names], 1)
+                lin, ang = model.compute_endeffector_jacobian(q, names[-1])
+                out[key + "lin"], out[key + "ang"] = lin.numpy(), ang.numpy()
+                for g, d in ((1, 1), (0, 0)):
+                    out[key + "tau_g%d_d%d" % (g, d)] = model.compute_inverse_dynamics(
+                        q, qd, qdd, include_gravity=bool(g), use_damping=bool(d)).numpy()
+                out[key + "acc"] = model.compute_forward_dynamics(q, qd, f.clone(), include_gravity=True, use_damping=True).numpy()
+                out[key + "H"] = model.compute_lagrangian_inertia_matrix(q).numpy()
+            print("tree %2d: %2d links, %2d DoF" % (t, len(names), n), flush=True)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "golden_trees.npz"), **generate())
+
+
+if __name__ == "__main__":
+    main()
