@@ -4,8 +4,9 @@ its CPU path (the random-tree tests had no reference side).
 branching, sub-trees behind fixed joints at the root, fixed joints in between, revolute AND prismatic joints about +-x / y / z (what
 the reference models: every non-fixed joint an axis-aligned revolute one, robot_model.py:122-126), random frames, masses, centres of
 mass, inertias and dampings.  70 joint states per tree (one 64-row tile + a ragged tail): FK of every link, the Jacobian of the last
-link, inverse dynamics with and without gravity / damping, the joint-space inertia matrix, forward dynamics.  The URDF text travels
-in the file.  float32 in, float32 out, stored as they come.
+link, inverse dynamics with and without gravity / damping, the joint-space inertia matrix, forward dynamics — and the reference's
+AUTOGRAD through five scalar losses on them (input gradients: q for FK, the Jacobian and the inertia matrix; q, qd, qdd for inverse
+dynamics; q, qd, f for forward dynamics).  The URDF text travels in the file.  float32 in, float32 out, stored as they come.
 
 Run in the build container only (needs /root/reference):   python tests/golden/make_golden_trees.py
 """
@@ -99,6 +100,27 @@ def generate():
                         q, qd, qdd, include_gravity=bool(g), use_damping=bool(d)).numpy()
                 out[key + "acc"] = model.compute_forward_dynamics(q, qd, f.clone(), include_gravity=True, use_damping=True).numpy()
                 out[key + "H"] = model.compute_lagrangian_inertia_matrix(q).numpy()
+            # the reference's autograd through the same entry points: input gradients of five scalar losses (weights w_* fixed
+            # pseudo-random tensors, so every output entry carries its own cotangent)
+            w3 = torch.from_numpy(rng.standard_normal((BATCH, 3)).astype(np.float32))
+            wj = torch.from_numpy(rng.standard_normal((BATCH, 3, n)).astype(np.float32))
+            wn = torch.from_numpy(rng.standard_normal((BATCH, n)).astype(np.float32))
+            wh = torch.from_numpy(rng.standard_normal((BATCH, n, n)).astype(np.float32))
+            for k, v in (("w3", w3), ("wj", wj), ("wn", wn), ("wh", wh)):
+                out[key + k] = v.numpy().copy()
+            def grads(fn, *xs):
+                xs = [x.clone().requires_grad_(True) for x in xs]
+                y = fn(*xs)
+                if y.requires_grad:      # (a link behind fixed joints only does not depend on q: zero gradients)
+                    y.backward()
+                return [x.grad.numpy() if x.grad is not None else np.zeros(tuple(x.shape), np.float32) for x in xs]
+            (out[key + "g_fk_q"],) = grads(lambda a: (model.compute_forward_kinematics(a, names[-1])[0] * w3).sum(), q)
+            (out[key + "g_jac_q"],) = grads(lambda a: sum((j * wj).sum() for j in model.compute_endeffector_jacobian(a, names[-1])), q)
+            out[key + "g_id_q"], out[key + "g_id_qd"], out[key + "g_id_qdd"] = grads(
+                lambda a, b, c: (model.compute_inverse_dynamics(a, b, c, include_gravity=True, use_damping=True) * wn).sum(), q, qd, qdd)
+            (out[key + "g_h_q"],) = grads(lambda a: (model.compute_lagrangian_inertia_matrix(a) * wh).sum(), q)
+            out[key + "g_fd_q"], out[key + "g_fd_qd"], out[key + "g_fd_f"] = grads(
+                lambda a, b, c: (model.compute_forward_dynamics(a, b, c.clone(), include_gravity=True, use_damping=True) * wn).sum(), q, qd, f)
             print("tree %2d: %2d links, %2d DoF" % (t, len(names), n), flush=True)
     return out
 
