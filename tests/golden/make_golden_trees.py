@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate tests/golden/golden_trees.npz: RANDOM kinematic trees — robots nobody shipped — through the UNMODIFIED reference on
-its CPU path (the random-tree tests had no reference side).  Twelve trees of 4 .. 18 links with random
+its CPU path (the random-tree tests had no reference side).  Twenty trees of 4 .. 18 links with random
 branching, sub-trees behind fixed joints at the root, fixed joints in between, revolute AND prismatic joints about +-x / y / z (what
 the reference models: every non-fixed joint an axis-aligned revolute one, robot_model.py:122-126), random frames, masses, centres of
 mass, inertias and dampings.  70 joint states per tree (one 64-row tile + a ragged tail): FK of every link, the Jacobian of the last
@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
-N_TREES, BATCH = 12, 70
+N_TREES, BATCH = 20, 70
 AXES = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1"]
 
 
