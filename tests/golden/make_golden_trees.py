@@ -64,8 +64,29 @@ def tree_urdf(seed):
     return "\n".join(out) + "\n"
 
 
+def parametrization(rbp, pname):
+    if pname == "mass":
+        return rbp.PositiveScalar()
+    if pname == "joint_damping":
+        return rbp.UnconstrainedScalar()
+    if pname == "inertia_mat":
+        return rbp.UnconstrainedTensor(dim1=3, dim2=3)
+    return rbp.UnconstrainedTensor(dim1=1, dim2=3)
+
+
+def learnable_links(model):
+    """Which parameters a tree's learnable run opens: all six of its FIRST moving link, mass / com / trans of its LAST moving link
+    (only links with a moving joint get learnable kinematic parameters: SURVEY.md Appendix B, Q2)."""
+    moving = [model._bodies[i].name for i in model._controlled_joints]
+    learn = {moving[0]: ["mass", "com", "inertia_mat", "trans", "rot_angles", "joint_damping"]}
+    if len(moving) > 1:
+        learn[moving[-1]] = ["mass", "com", "trans"]
+    return learn
+
+
 def generate():
     rm = ref_import.import_reference()
+    import differentiable_robot_model.rigid_body_params as rbp
     torch.set_num_threads(1)
     out = {"n_trees": np.array(N_TREES)}
     with tempfile.TemporaryDirectory() as tmp:
@@ -121,7 +142,47 @@ def generate():
             (out[key + "g_h_q"],) = grads(lambda a: (model.compute_lagrangian_inertia_matrix(a) * wh).sum(), q)
             out[key + "g_fd_q"], out[key + "g_fd_qd"], out[key + "g_fd_f"] = grads(
                 lambda a, b, c: (model.compute_forward_dynamics(a, b, c.clone(), include_gravity=True, use_damping=True) * wn).sum(), q, qd, f)
-            print("tree %2d: %2d links, %2d DoF" % (t, len(names), n), flush=True)
+            # ... and PARAMETER gradients: a second model of the same tree with learnable link parameters (freshly drawn under
+            # seed t), the inverse-dynamics loss of the reference's learning example against the untouched tree's torques, and an
+            # FK loss on the last link; gradients of both with respect to every parameter tensor, and the ID loss's input gradients
+            torch.manual_seed(t)
+            with contextlib.redirect_stdout(io.StringIO()):
+                learn_model = rm.DifferentiableRobotModel(path)
+            learn = learnable_links(learn_model)
+            for link, pnames in learn.items():
+                for pname in pnames:
+                    learn_model.make_link_param_learnable(link, pname, parametrization(rbp, pname))
+            ql, qdl, qddl = (x.clone().requires_grad_(True) for x in (q, qd, qdd))
+            tau_l = learn_model.compute_inverse_dynamics(ql, qdl, qddl, include_gravity=True, use_damping=True)
+            loss = torch.nn.functional.mse_loss(tau_l, torch.from_numpy(out[key + "tau_g1_d1"]))
+            loss.backward()
+            out[key + "p_loss"] = np.asarray(loss.item(), np.float64)
+            out[key + "p_tau"] = tau_l.detach().numpy()
+            out[key + "p_g_q"], out[key + "p_g_qd"], out[key + "p_g_qdd"] = ql.grad.numpy(), qdl.grad.numpy(), qddl.grad.numpy()
+            keys = []
+            for link, pnames in learn.items():
+                body = learn_model._bodies[learn_model._name_to_idx_map[link]]
+                for pname in pnames:
+                    mod = getattr(body if pname in ("trans", "rot_angles", "joint_damping") else body.inertia, pname)
+                    for k, p_ in mod.named_parameters():
+                        pk = "%s/%s/%s" % (link, pname, k)
+                        out[key + "p_init/" + pk] = p_.detach().numpy().copy()
+                        out[key + "p_grad_id/" + pk] = p_.grad.numpy().copy()
+                        keys.append(pk)
+            out[key + "p_keys"] = np.array(keys)
+            learn_model.zero_grad()
+            fk_loss = (learn_model.compute_forward_kinematics(q, names[-1])[0] * w3).sum()
+            if fk_loss.requires_grad:
+                fk_loss.backward()
+            for link, pnames in learn.items():
+                body = learn_model._bodies[learn_model._name_to_idx_map[link]]
+                for pname in pnames:
+                    if pname not in ("trans", "rot_angles"):
+                        continue
+                    for k, p_ in getattr(body, pname).named_parameters():
+                        out[key + "p_grad_fk/%s/%s/%s" % (link, pname, k)] = (p_.grad.numpy().copy() if p_.grad is not None
+                                                                           else np.zeros(tuple(p_.shape), np.float32))
+            print("tree %2d: %2d links, %2d DoF, %d learnable tensors" % (t, len(names), n, len(keys)), flush=True)
     return out
 
 
