@@ -170,7 +170,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
     # ------------------------------------------------------------------ constants
-    def _link_rows(self, link_idxs) -> torch.Tensor:
+    def _link_rows(self, link_idxs, device=None) -> torch.Tensor:
         """[len(link_idxs), OPF_STRIDE] float32 rows of per-link constants on the model device.
 
         Built with torch ops from the bodies' parameter callables, so gradients reach learnable
@@ -178,7 +178,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         R_fixed = (Rz(yaw) @ Ry(pitch)) @ Rx(roll)  (rigid_body.py:138-143, spatial_vector_algebra.py:14-53),
         mcom = com * mass, I_o = I_c + mass * S(com) S(com)^T  (spatial_vector_algebra.py:321-327).
         """
-        dev = self._device
+        dev = self._device if device is None else device
         bodies = [self._bodies[i] for i in link_idxs]
         L = len(bodies)
         cat = lambda ts, shape: torch.stack([t.reshape(shape).to(dev) for t in ts])
@@ -213,9 +213,12 @@ class DifferentiableRobotModel(torch.nn.Module):
         """
         if self._static_table is None:
             with torch.no_grad():
-                ident = torch.from_numpy(identity_table_row()).to(self._device).reshape(1, OPF_STRIDE)
-                base = torch.cat([self._link_rows(range(len(self._bodies))), ident], dim=0)
-                self._static_table = self._with_virtual_rows(base)
+                # the constant snapshot is computed on the HOST whatever the model's device (round 5): R_fixed = Rz Ry Rx through the
+                # host's cos / sin is the reference's own CPU result bit for bit (a device's differ in the last bit for general
+                # angles), the table — and with it the key of a robot's own kernels, specialize.build — is the same on every machine
+                ident = torch.from_numpy(identity_table_row()).reshape(1, OPF_STRIDE)
+                base = torch.cat([self._link_rows(range(len(self._bodies)), device=torch.device("cpu")), ident], dim=0)
+                self._static_table = self._with_virtual_rows(base).to(self._device)
         if not self._learnable:
             return self._static_table if fold_key is None else self._with_virtual_rows(self._static_rows(fold_key))
         links = sorted({link for link, _ in self._learnable})
@@ -235,10 +238,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         links, Ra = virtual_row_constants(self._spec)
         if not links:
             return base
-        Ra_t = torch.from_numpy(np.ascontiguousarray(Ra)).to(self._device)
-        rows = base[torch.tensor(links, device=self._device)]
+        Ra_t = torch.from_numpy(np.ascontiguousarray(Ra)).to(base.device)
+        rows = base[torch.tensor(links, device=base.device)]
         S = len(links)
-        zeros = lambda k: torch.zeros(S, k, device=self._device)
+        zeros = lambda k: torch.zeros(S, k, device=base.device)
         FA = (rows[:, 0:9].reshape(S, 3, 3) @ Ra_t).reshape(S, 9)
         row_a = torch.cat([FA, rows[:, 9:12], zeros(13), rows[:, 25:26], zeros(OPF_STRIDE - 26)], dim=1)
         row_b = torch.cat([Ra_t.transpose(1, 2).reshape(S, 9), zeros(3), rows[:, 12:25], zeros(OPF_STRIDE - 25)], dim=1)

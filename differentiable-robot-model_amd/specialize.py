@@ -211,6 +211,59 @@ def cache_dir() -> str:
     return d
 
 
+# code objects that ship WITH the package: `__graft_entry__.build()` pre-builds the shipped robots' own kernels here (next to
+# libdrm_hip.so; *.hsaco is git-ignored like every built artefact), so a deployment finds them without running hipcc
+SHIPPED_CACHE = os.path.join(CSRC, "special_cache")
+
+
+# (the fingertip sets whose fan-out FK kernel is pre-built: BASELINE configuration 4's)
+SHIPPED_FANS = {"allegro_left": ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]}
+
+
+def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> list:
+    """Build, into SHIPPED_CACHE, the kernels `specialize()` would build at run time for the robots of the BASELINE configurations:
+    the arms' inverse-dynamics / fused FK + RNEA (end-effector link) / inertia-matrix / forward-dynamics / input-gradient kernels and
+    the Allegro's four-fingertip fan-out kernel.  Needs hipcc and no GPU (models are built on the CPU: the tables are device-independent).
+    Returns the file names."""
+    import contextlib
+    import io
+
+    from .robot_model import DifferentiableRobotModel, robot_description_folder
+    before = os.environ.get("DRM_SPECIAL_CACHE")
+    os.environ["DRM_SPECIAL_CACHE"] = SHIPPED_CACHE
+    built = []
+    try:
+        for robot in robots:
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = DifferentiableRobotModel(os.path.join(robot_description_folder, robot + ".urdf"), device="cpu")
+            dw = m._dynamics_walk()
+            table = m._ops_f(dw).detach().numpy()
+            if arm_qualifies(dw.program, m._n_dofs):
+                links = dw.program.n_ops
+                built.append(build(arm_source(table, links, False), ARM_FLAGS))
+                built.append(build(arm_dynamics_source(table, links), ARM_FLAGS))
+                ee = len(m._bodies) - 1                                   # (the arm's last link: the FK target of configuration 3)
+                tree, chain = dw, m._get_walk(("chain", ee) + (("folded", dw.fold_key) if dw.folded else ()), targets=[ee],
+                                              folded=dw.folded, fold_key=dw.fold_key)
+                if arm_qualifies(chain.program, m._n_dofs) and chain.program.n_ops == 8:
+                    both = table.copy()
+                    both[links:] = m._ops_f(chain).detach().numpy()[links:]
+                    built.append(build(arm_source(both, links, True), ARM_FLAGS))
+            tips = sorted(m._name_to_idx_map[name] for name in SHIPPED_FANS.get(robot, []))     # (_fk_links launches in link order)
+            if 2 <= len(tips) <= 4:
+                merged = m._get_walk(("fk", tuple(tips)), targets=tips)
+                fan = m._fanout_chains(tips, merged)
+                chains = [fan_chain(w.program, m._n_dofs) for w in fan] if fan else []
+                if chains and all(chains):
+                    built.append(build(fan_source(chains, [m._ops_f(w).detach().numpy() for w in fan], m._n_dofs), ARM_FLAGS))
+    finally:
+        if before is None:
+            os.environ.pop("DRM_SPECIAL_CACHE", None)
+        else:
+            os.environ["DRM_SPECIAL_CACHE"] = before
+    return [os.path.basename(b) for b in built]
+
+
 def hipcc() -> Optional[str]:
     return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
 
@@ -258,14 +311,18 @@ def build(src: str, flags=()) -> str:
     key = h.hexdigest()[:20]
     cc = hipcc()
     if cc is None:
-        shipped = sorted(glob.glob(os.path.join(cache_dir(), "drm_special_%s_*.hsaco" % key)))
+        shipped = sorted(glob.glob(os.path.join(cache_dir(), "drm_special_%s_*.hsaco" % key)) +
+                         glob.glob(os.path.join(SHIPPED_CACHE, "drm_special_%s_*.hsaco" % key)))
         if shipped:
             return shipped[0]
         raise SpecializeError("hipcc not found and %s holds no code object for this robot (drm_special_%s_*.hsaco): build it "
                               "on a machine with the ROCm compiler and copy the cache (specialize.export_cache)" % (cache_dir(), key))
-    out = os.path.join(cache_dir(), "drm_special_%s_%s.hsaco" % (key, compiler_id(cc)))
+    name = "drm_special_%s_%s.hsaco" % (key, compiler_id(cc))
+    out = os.path.join(cache_dir(), name)
     if os.path.exists(out):
         return out
+    if os.path.exists(os.path.join(SHIPPED_CACHE, name)):      # (built with the package by __graft_entry__.build(), same compiler)
+        return os.path.join(SHIPPED_CACHE, name)
     fd, cpp = tempfile.mkstemp(prefix="drm_special_%s_" % key, suffix=".hip", dir=cache_dir())
     tmp = cpp[:-4] + ".hsaco.tmp"
     try:

@@ -632,6 +632,21 @@ def test_gpu_fan_out_fk_with_folded_constants(robot, links):
         assert len(handles) == 1 and None not in handles          # (ONE kernel, the same handle on every chain walk)
 
 
+@needs_hipcc
+def test_shipped_cache_serves_a_machine_without_hipcc(tmp_path, monkeypatch):
+    """(CPU) `__graft_entry__.build()` pre-builds the shipped robots' own kernels next to the library (csrc/special_cache/); `build`
+    finds them there — by source key — when neither the run-time cache nor hipcc has them."""
+    names = sp.prebuild_shipped(("iiwa7",))
+    assert len(names) == 3 and all(os.path.exists(os.path.join(sp.SHIPPED_CACHE, n)) for n in names)
+    m = load_model("iiwa7")
+    dw = m._dynamics_walk()
+    src = sp.arm_source(m._ops_f(dw).detach().numpy(), dw.program.n_ops, False)
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path))          # (an empty run-time cache)
+    assert sp.build(src, sp.ARM_FLAGS).startswith(sp.SHIPPED_CACHE) and os.listdir(str(tmp_path)) == []
+    monkeypatch.setattr(sp, "hipcc", lambda: None)
+    assert sp.build(src, sp.ARM_FLAGS).startswith(sp.SHIPPED_CACHE)
+
+
 def test_specialize_needs_a_device_model():
     """(CPU) per-robot kernels are HIP code objects: specialize() needs a model on a HIP device."""
     m = load_model("panda_no_gripper")
