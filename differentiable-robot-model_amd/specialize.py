@@ -216,6 +216,11 @@ def cache_dir() -> str:
 SHIPPED_CACHE = os.path.join(CSRC, "special_cache")
 
 
+def shipped_cache() -> str:
+    """SHIPPED_CACHE, or DRM_SHIPPED_CACHE from the environment (tests point it at an empty directory)."""
+    return os.environ.get("DRM_SHIPPED_CACHE") or SHIPPED_CACHE
+
+
 # (the fingertip sets whose fan-out FK kernel is pre-built: BASELINE configuration 4's)
 SHIPPED_FANS = {"allegro_left": ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]}
 
@@ -230,7 +235,7 @@ def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> li
 
     from .robot_model import DifferentiableRobotModel, robot_description_folder
     before = os.environ.get("DRM_SPECIAL_CACHE")
-    os.environ["DRM_SPECIAL_CACHE"] = SHIPPED_CACHE
+    os.environ["DRM_SPECIAL_CACHE"] = shipped_cache()
     built = []
     try:
         for robot in robots:
@@ -312,7 +317,7 @@ def build(src: str, flags=()) -> str:
     cc = hipcc()
     if cc is None:
         shipped = sorted(glob.glob(os.path.join(cache_dir(), "drm_special_%s_*.hsaco" % key)) +
-                         glob.glob(os.path.join(SHIPPED_CACHE, "drm_special_%s_*.hsaco" % key)))
+                         glob.glob(os.path.join(shipped_cache(), "drm_special_%s_*.hsaco" % key)))
         if shipped:
             return shipped[0]
         raise SpecializeError("hipcc not found and %s holds no code object for this robot (drm_special_%s_*.hsaco): build it "
@@ -321,8 +326,8 @@ def build(src: str, flags=()) -> str:
     out = os.path.join(cache_dir(), name)
     if os.path.exists(out):
         return out
-    if os.path.exists(os.path.join(SHIPPED_CACHE, name)):      # (built with the package by __graft_entry__.build(), same compiler)
-        return os.path.join(SHIPPED_CACHE, name)
+    if os.path.exists(os.path.join(shipped_cache(), name)):      # (built with the package by __graft_entry__.build(), same compiler)
+        return os.path.join(shipped_cache(), name)
     fd, cpp = tempfile.mkstemp(prefix="drm_special_%s_" % key, suffix=".hip", dir=cache_dir())
     tmp = cpp[:-4] + ".hsaco.tmp"
     try:
