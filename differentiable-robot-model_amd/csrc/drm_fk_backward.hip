@@ -161,7 +161,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 // the partial rows, row pitch NV + 4) and its gradient g = g_scale (p_e - target), g_scale = 2 / (3 B), itself: forward
 // kinematics, loss and backward of the reference's kinematics-learning step (examples/learn_kinematics_of_iiwa.py:47-55) in ONE
 // pass over q — the chain is walked once, nothing per-sample is written unless grad_q is asked for.
-template <int CAP, int NJ, bool MSE = false>
+// PRE (round 5): the register-resident table (96 VGPRs of FT blocks, 256 VGPR + AGPRs in all: ONE wavefront per SIMD) is the latency
+// form of launches that put at most one tile on a wavefront; larger launches — the persistent grid walks many tiles per wavefront —
+// read the rows from LDS op by op and fit several wavefronts per SIMD instead.
+#ifndef DRM_FK_BWD_PRE_MAX_TILES
+#define DRM_FK_BWD_PRE_MAX_TILES 1024 /* one tile per SIMD */
+#endif
+constexpr int FK_BWD_PRE_MAX_TILES = DRM_FK_BWD_PRE_MAX_TILES;
+template <int CAP, int NJ, bool MSE = false, bool PRE = true>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
                            int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *__restrict__ partials, float g_scale) {
@@ -188,12 +195,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     // waits for: the FT blocks of the chain are read into registers in one burst (as in fk_jacobian_arm_kernel's PRE form), and
     // every lane reads its own rows of q / gpos straight from memory (28 + 12 contiguous bytes) instead of through an LDS tile.
     wave_lds_sync();
-    float tabr[CAP][DRM_OPF_FT_FLOATS];
+    float tabr[PRE ? CAP : 1][DRM_OPF_FT_FLOATS];
+    if constexpr (PRE) {
 #pragma unroll
-    for (int k = 0; k < CAP; ++k)
+        for (int k = 0; k < CAP; ++k)
 #pragma unroll
-        for (int i = 0; i < DRM_OPF_FT_FLOATS; ++i) tabr[k][i] = lc[k * DRM_OPF_STRIDE + i];
-    __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < DRM_OPF_FT_FLOATS; ++i) tabr[k][i] = lc[k * DRM_OPF_STRIDE + i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
         float qv[NJ], gv[3], gqv[NJ];
@@ -208,7 +217,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 #pragma unroll
         for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = qv[d]; // (the cold parameter loop reads an angle by run-time index)
         wave_lds_sync();
-        fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { return tabr[k]; },
+        fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { if constexpr (PRE) return tabr[k]; else return lc + k * DRM_OPF_STRIDE; },
                                    [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
                                    [&](const float (&pe)[3], float (&g)[3]) {
                                        if constexpr (MSE) {
@@ -316,9 +325,14 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             const int n_tiles = (int)(B / WAVE);
             const int64_t done = (int64_t)n_tiles * WAVE;
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
-            hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
-                               dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                               partials, 0.0f);
+            if (n_tiles <= FK_BWD_PRE_MAX_TILES)
+                hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, true>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                                   dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
+                                   partials, 0.0f);
+            else
+                hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, false>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
+                                   dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
+                                   partials, 0.0f);
             rc = launched();
             if (rc) return rc;
             rows_done = waves_a;
@@ -410,8 +424,12 @@ extern "C" int drm_fk_mse(const drm_walk *w, const float *q, const float *target
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = (int)(B / WAVE);
     const int waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
-                       0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
+    if (n_tiles <= FK_BWD_PRE_MAX_TILES)
+        hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
+                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
+    else
+        hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, false>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
+                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
     rc = launched();
     if (rc) return rc;
     hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + 1 + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0,
