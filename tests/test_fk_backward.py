@@ -225,6 +225,43 @@ def test_gpu_config5_iiwa_learnable_batch_16384(emu):
 
 
 @pytest.mark.gpu
+def test_gpu_fk_backward_beyond_one_tile_per_wavefront():
+    """Launches of more than 1 024 tiles take the table-in-LDS form of fk_backward_arm_kernel (round 5; the register-resident table is
+    the latency form of smaller launches).  1 030 tiles + 9 rows of the iiwa with a learnable link offset: the whole batch in one call
+    against the same rows in chunks of at most 1 024 tiles (the other form) — per-row input gradients to a few ulp, the parameter
+    gradients (sums over the batch) to 1e-4 — for the autograd path (drm_fk_backward) and for fk_mse_loss (drm_fk_mse: full tiles)."""
+    torch.manual_seed(0)
+    m = load_model("iiwa7", "cuda")
+    m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+    m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+    gt = load_model("iiwa7", "cuda")
+    for B, fused in ((1030 * 64 + 9, False), (1030 * 64, True)):
+        q = torch.from_numpy(sample_states(m, B, seed=15)[0]).cuda()
+        with torch.no_grad():
+            want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+            want = want + 0.01
+
+        def grads(rows):
+            m.zero_grad()
+            x = q[rows].clone().requires_grad_(True)
+            if fused:
+                loss = m.fk_mse_loss(x, "iiwa_link_ee", want[rows]) * (x.shape[0] / B)
+            else:
+                loss = torch.nn.functional.mse_loss(m.compute_forward_kinematics(x, "iiwa_link_ee")[0], want[rows], reduction="sum") / (3 * B)
+            loss.backward()
+            return float(loss.detach()), x.grad, [p.grad.clone() for p in m.parameters()]
+
+        whole = grads(slice(0, B))
+        parts = [grads(slice(lo, min(B, lo + 512 * 64))) for lo in range(0, B, 512 * 64)]
+        assert abs(whole[0] - sum(p[0] for p in parts)) <= 1e-5 * abs(whole[0])
+        gq = torch.cat([p[1] for p in parts])
+        assert float((whole[1] - gq).abs().max()) <= 1e-6 * max(1e-9, float(gq.abs().max())) + 1e-12
+        for k, g in enumerate(whole[2]):
+            ref = sum(p[2][k] for p in parts)
+            assert float((g - ref).abs().max()) <= 1e-4 * max(1e-9, float(ref.abs().max())), (fused, k)
+
+
+@pytest.mark.gpu
 def test_gpu_training_step_is_hipgraph_capturable():
     """Forward + loss + backward + Adam of the kinematics-learning loop captured ONCE into a hipGraph and replayed:
     no call on the path synchronises or touches host memory, so the launch-bound loop runs without the host."""
