@@ -301,7 +301,10 @@ __device__ __forceinline__ void stage_table(const float *__restrict__ ops_f, flo
 // the latency forms cost them that (Panda with gripper, 9 ops: inverse dynamics 58 -> 73 us, forward dynamics 125 -> 172 us at 2^20
 // rows when they were applied to every robot; Jaco, 12 ops: 121 -> 108 / 247 -> 240; Fetch, 14 ops: 124 -> 104 / 330 -> 235).
 constexpr int STATIC_LONE_OPS = 12;
-constexpr int BWD_MAX_WAVES = 2048; // 256 CUs x 4 SIMDs x 2: waves of a backward launch = rows of its partial sums
+#ifndef DRM_BWD_MAX_WAVES
+#define DRM_BWD_MAX_WAVES 2048 /* 256 CUs x 4 SIMDs x 2 */
+#endif
+constexpr int BWD_MAX_WAVES = DRM_BWD_MAX_WAVES; // waves of a backward launch = rows of its partial sums
 
 // Sum of the partial-sum rows a backward launch left behind (one row of NV floats per wave), in a FIXED order so that
 // parameter gradients are bit-stable from run to run: a block of REDUCE_WAVES wavefronts owns 64 consecutive
