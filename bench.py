@@ -82,9 +82,15 @@ def parse_args(argv=None):
                          "(model.specialize(), the default when hipcc is on the machine)")
     ap.add_argument("--no-large", action="store_true", help="skip the roofline_large legs (2^22, 2^24 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true",
-                    help="skip the `configs` legs (BASELINE.json configurations 2-5 + eager API overhead, each with the reference "
-                         "timed beside it; N = 1 only, ~40 s)")
+    ap.add_argument("--configs", default="fast", choices=["off", "fast", "full"],
+                    help="the `configs` legs (BASELINE.json configurations 2-5 + eager API overhead; N = 1 only).  fast (default): the "
+                         "GPU launch times and roofline fractions only (~10 s).  full: also the unmodified reference timed beside every "
+                         "leg and two rocprofv3 --pmc passes per leg for its HBM traffic (~70 s; what tools/profile_round.sh records "
+                         "under profiles/).  off: none")
+    ap.add_argument("--no-configs", dest="configs", action="store_const", const="off", help="same as --configs off")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "profiles", "bench_last.json"),
+                    help="where rank 0 writes the FULL record of the run (every leg, note and reference timing); stdout carries "
+                         "ONE compact JSON line (< 4 KB) with the contract fields only")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only; ~30 s)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget of the cpu_baseline leg")
@@ -222,7 +228,7 @@ def measured_traffic(args, batch):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="drm_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-               os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--no-configs", "--steps", "50", "--warmup", "5",
+               os.path.abspath(__file__), "--no-cpu-baseline", "--no-large", "--no-traffic", "--configs", "off", "--detail", os.devnull, "--steps", "50", "--warmup", "5",
                "--batch", str(batch), "--robot", args.robot]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
@@ -316,6 +322,111 @@ def timed_graph_region(launch, K, stream, barrier, use_graph=True, warm_replays=
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, graph is not None
 
 
+COMPACT_LIMIT = 4096      # bytes of the stdout line (round 5's 21 KB line was not readable by the round driver)
+
+
+def _num(x, digits=6):
+    """Floats of the compact line: `digits` significant digits; non-finite values become null (strict JSON)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def compact_line(full):
+    """The ONE line stdout carries: the driver's contract fields, `roofline` and `cpu_baseline` of the dominant kernel, and one
+    flat number per BASELINE configuration — no prose, no nesting beyond one level, < COMPACT_LIMIT bytes.  Everything else of the
+    run (`full`) goes to --detail (profiles/bench_last.json) and to stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "ranks_seen")
+    out = {k: _num(full.get(k), 9) for k in keep}
+    cfg = full.get("config", {})
+    out["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "global_batch", "parallelism", "launch", "gather",
+                                             "gather_bytes_per_rank") if k in cfg}
+    roof = full.get("roofline", {})
+    out["roofline"] = {k: _num(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                      "algorithmic_bytes_per_launch", "traffic_over_algorithmic", "kernel",
+                                                      "launch_us") if k in roof}
+    out["roofline"]["traffic_measured_in_this_run"] = bool(roof.get("traffic_measured_in_this_run", False))
+    if "steady_state" in roof:          # the same launch in a region of 200 (a 20-step region carries one graph-launch latency)
+        out["roofline"]["steady_state_launch_us"] = _num(roof["steady_state"]["launch_us"])
+        out["roofline"]["steady_state_frac"] = _num(roof["steady_state"]["frac"])
+    large = [r for r in full.get("roofline_large", []) if "frac" in r]
+    if large:                           # genuine HBM streaming: per-launch traffic far beyond the Infinity Cache
+        out["roofline_large"] = {str(r["batch"]): {"launch_us": _num(r["launch_us"]), "frac": _num(r["frac"])} for r in large}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: _num(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "gpu_over_cpu") if k in cpu}
+        if len(out["cpu_baseline"].get("sample") or "") > 300:
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:297] + "..."
+        if isinstance(cpu.get("port"), dict):
+            out["cpu_baseline"]["port_value"] = _num(cpu["port"].get("value"))
+            out["cpu_baseline"]["port_cores"] = cpu["port"].get("cores")
+        ref = cpu.get("reference") if isinstance(cpu.get("reference"), dict) else {}
+        dev = ref.get("gpu_vs_reference_max_abs") or full.get("gpu_vs_reference_max_abs")
+        if dev:
+            out["gpu_vs_reference_max_abs"] = {k: _num(v, 3) for k, v in dev.items()}
+        if "error" in ref:
+            out["cpu_baseline"]["reference_error"] = str(ref["error"])[:160]
+    configs = full.get("configs")
+    if isinstance(configs, dict) and "legs" in configs:
+        short = {"config2": "c2", "config3_shard": "c3_shard", "config3_whole": "c3_whole", "config4": "c4", "config5": "c5"}
+        frac, us, own = {}, {}, {}
+        for leg in configs["legs"]:
+            key = short.get(leg["name"], leg["name"])
+            frac[key], us[key] = _num(leg["roofline"]["frac"], 4), _num(leg["roofline"]["launch_us"], 4)
+            if "own_kernel" in leg:
+                own[key] = leg.get("own_kernel_path", bool(leg["own_kernel"]))
+            if "fk_mse_roofline" in leg:
+                frac[key + "_fk_mse"] = _num(leg["fk_mse_roofline"]["frac"], 4)
+                us[key + "_fk_mse"] = _num(leg["fk_mse_roofline"]["launch_us"], 4)
+            for k_src, k_dst in (("graph_step_us", "_graph_step"), ("graph_step_fused_us", "_graph_step_fused"), ("eager_step_us", "_eager_step")):
+                if k_src in leg:
+                    us[key + k_dst] = _num(leg[k_src], 4)
+        out["configs_frac"], out["configs_launch_us"], out["configs_own_kernel"] = frac, us, own
+        eager = configs.get("api_eager_us_per_call") or {}
+        out["api_eager_us_per_call"] = {k.replace("compute_", ""): _num(v["us_per_call"], 4) for k, v in eager.items()
+                                        if isinstance(v, dict) and "us_per_call" in v}
+    elif isinstance(configs, dict) and "error" in configs:
+        out["configs_error"] = str(configs["error"])[:200]
+    for k in ("own_kernel", "compute_us_per_step", "step_us_with_gather", "gather_us_per_step", "gather_verified"):   # --config 3 / --gather
+        if full.get(k) is not None:
+            out[k] = _num(full[k])
+    if "gather_modes" in full:
+        out["gather_step_us"] = {m: _num(v["step_us_device"], 4) for m, v in full["gather_modes"].items()}
+        out["gather_model_us"] = {m: _num(v["gather_model_us"], 4) for m, v in full["gather_modes"].items()}
+    dist_ = full.get("distributed") or {}
+    if dist_.get("backend"):
+        out["distributed"] = {k: dist_[k] for k in ("backend", "shared_gpu", "devices_used") if k in dist_}
+    return out
+
+
+def emit(full, args):
+    """Rank 0: the full record to --detail and stderr, the compact line — the only thing on stdout — last."""
+    compact = compact_line(full)
+    if args.detail and args.detail != os.devnull:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, "w") as f:
+                json.dump(full, f, indent=1)
+            compact["detail"] = os.path.relpath(args.detail, ROOT) if args.detail.startswith(ROOT) else args.detail
+        except OSError as err:       # (a read-only checkout: the detail still goes to stderr)
+            compact["detail"] = "stderr (%s)" % type(err).__name__
+    print("bench.py detail: " + json.dumps(full), file=sys.stderr)
+    text = json.dumps(compact, allow_nan=False)
+    if len(text) > COMPACT_LIMIT:      # never let the line outgrow what the driver reads: drop the optional groups, largest first
+        for key in ("configs_launch_us", "api_eager_us_per_call", "gather_model_us", "roofline_large", "configs_own_kernel",
+                    "gpu_vs_reference_max_abs"):
+            compact.pop(key, None)
+            text = json.dumps(compact, allow_nan=False)
+            if len(text) <= COMPACT_LIMIT:
+                break
+    sys.stderr.flush()
+    print(text, flush=True)
+
+
 def main():
     args = parse_args()
     respawn_if_needed(args)
@@ -376,7 +487,7 @@ def main():
     else:
         line = run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -508,12 +619,15 @@ def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barri
                 "gpu_over_cpu": line["value"] / one["evals_per_s"], "port": port, "reference": ref}
         else:      # (the reference leg failed: the port stays the value, the error is reported)
             line["cpu_baseline"]["reference"] = ref
-    if rank == 0 and world == 1 and not args.no_configs and os.environ.get("DRM_BENCH_CHILD") != "1":
+    if rank == 0 and world == 1 and args.configs != "off" and os.environ.get("DRM_BENCH_CHILD") != "1":
         del plan
         torch.cuda.empty_cache()
         from bench_configs import run_config_legs
+        full = args.configs == "full"
         try:
-            line["configs"] = run_config_legs(device, with_reference=not args.no_cpu_baseline, with_traffic=not args.no_traffic)
+            line["configs"] = run_config_legs(device, with_reference=full and not args.no_cpu_baseline,
+                                              with_traffic=full and not args.no_traffic)
+            line["configs"]["mode"] = args.configs
         except Exception as err:   # the extra legs must never take the metric line down with them
             line["configs"] = {"error": "%s: %s" % (type(err).__name__, err)}
     return line
@@ -585,21 +699,30 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     lo, hi = shard_bounds(G, world, rank)
     rows = hi - lo
     q, qd, qdd = config3_inputs(model, rows, device, 4321 + rank)
-    # round 5: the robot's OWN kernels (model.specialize(): the streaming walk with this arm's constants folded into the instruction
-    # stream; hipcc at run time, ~2 s, cached; the ranks of a node build the same code object and publish it atomically) — what a
-    # constant model runs at >= 131 072 rows.  A machine without hipcc keeps the library's table-driven kernels; the line says which.
+    # round 6: a constant model runs its OWN kernels by default (the streaming walk with this arm's constants folded into the
+    # instruction stream; the code objects ship next to the library, nothing is compiled on the call path) — the model below is
+    # DifferentiableRobotModel(urdf, device) and nothing else.  --library-kernels: the library's table-driven kernels (own_kernels
+    # = "off").  A checkout without the shipped code objects compiles them now (model.specialize()); the line says which happened.
     own_kernel, own_why = False, "--library-kernels"
-    if not args.library_kernels:
-        try:
-            own_kernel, own_why = bool(model.specialize()), None
-        except Exception as err:       # noqa: BLE001
-            own_kernel, own_why = False, str(err)[:200]
+    if args.library_kernels:
+        model.own_kernels = "off"
     # tau | pos | quat of a shard live in ONE allocation (three contiguous blocks), so the collective sends the kernel's own
     # output buffer: no packing kernel between the launch and the all-gather
     width = n + 3 + 4                                                    # 56 B per row
     flat = torch.empty(rows * width, device=device)
     outs = (flat[:rows * n].view(rows, n), flat[rows * n:rows * (n + 3)].view(rows, 3), flat[rows * (n + 3):].view(rows, 4))
     plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link, outputs=outs)
+    if not args.library_kernels:
+        from differentiable_robot_model_amd import specialize as sp
+        fused = lambda: (getattr(model._dynamics_walk().program, "_special", None) or {}).get(sp.SPECIAL_FK_RNEA_ARM)
+        own_kernel, own_why = ("default", None) if fused() else (False, "no shipped code object")
+        if not own_kernel:
+            try:
+                model.specialize()
+                plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link, outputs=outs)
+                own_kernel, own_why = ("specialize()", None) if fused() else (False, "specialize() attached nothing")
+            except Exception as err:       # noqa: BLE001
+                own_kernel, own_why = False, str(err)[:200]
     gathered = torch.empty(world * rows * width, device=device) if world > 1 and G % world == 0 else None
     if world > 1 and gathered is None:
         sys.exit("bench.py --config 3: 2^20 rows do not split evenly over %d ranks" % world)

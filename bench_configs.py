@@ -175,11 +175,7 @@ def leg_launcher(name, device):
         q, _ = uniform_q(iiwa, 65536, device, 2002)
         return iiwa.plan_fk_and_jacobian(q, "iiwa_link_ee").launch
     if name in ("config3_shard", "config3_whole"):
-        panda = load("panda_no_gripper", device)
-        try:
-            panda.specialize()
-        except Exception:       # noqa: BLE001  (no hipcc: the library's kernels, as in run_config_legs)
-            pass
+        panda = load("panda_no_gripper", device)      # (its own kernels by default: the code objects ship with the library)
         rows = 131072 if name == "config3_shard" else 1 << 20
         vmax = torch.tensor([j["velocity"] for j in panda.get_joint_limits()], device=device)
         q, gen = uniform_q(panda, rows, device, 4321)
@@ -188,10 +184,6 @@ def leg_launcher(name, device):
         return panda.plan_fk_and_inverse_dynamics(q, qd, qdd, "panda_virtual_ee_link").launch
     if name == "config4":
         hand = load("allegro_left", device)
-        try:
-            hand.specialize()
-        except Exception:       # noqa: BLE001
-            pass
         q, _ = uniform_q(hand, 65536, device, 4004)
         return lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
     if name in ("config5", "config5_fk_mse"):
@@ -334,16 +326,25 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
     del plan
 
     # ------------------------------------------------------------------ config 3: Panda FK(EE) + RNEA, shard and whole batch
-    panda = load("panda_no_gripper", device)
+    from differentiable_robot_model_amd import specialize as sp
     link = "panda_virtual_ee_link"
-    # round 5: the robot's OWN kernels — model.specialize(): the streaming walk with Panda's constants folded into the instruction
-    # stream (hipcc at run time, ~2 s per kernel, cached) — are what a constant model runs; the library's table-driven kernels are
-    # timed beside them (and stay the path when the machine has no hipcc)
+    # round 6: the drop-in path IS the benchmarked path.  A constant model attaches its OWN kernels by itself on first use — Panda's
+    # constants folded into the instruction stream of the streaming walk; the code objects ship next to the library (csrc/special_cache/,
+    # built by __graft_entry__.build()), nothing is compiled here.  `panda` below is DifferentiableRobotModel(urdf, device) and
+    # nothing else.  The library's table-driven kernels (own_kernels = "off") are timed beside it.
+    panda = load("panda_no_gripper", device)
     own = load("panda_no_gripper", device)
-    try:
-        own_ok, own_why = bool(own.specialize()), None
-    except Exception as err:       # noqa: BLE001  (no hipcc on this machine: the library's kernels are the path)
-        own_ok, own_why = False, str(err)[:200]
+    panda.own_kernels = "off"
+    probe_q = torch.zeros(64, 7, device=device)
+    own.plan_fk_and_inverse_dynamics(probe_q, probe_q.clone(), probe_q.clone(), link)
+    own_ok = bool((getattr(own._dynamics_walk().program, "_special", None) or {}).get(sp.SPECIAL_FK_RNEA_ARM))
+    own_path, own_why = "default" if own_ok else None, None
+    if not own_ok:       # (a checkout whose special_cache was not built: compile now, and say so)
+        try:
+            own_ok, own_path = bool(own.specialize()), "specialize()"
+            own.plan_fk_and_inverse_dynamics(probe_q, probe_q.clone(), probe_q.clone(), link)
+        except Exception as err:       # noqa: BLE001  (no hipcc on this machine either: the library's kernels are the path)
+            own_ok, own_why = False, str(err)[:200]
     vmax = torch.tensor([j["velocity"] for j in panda.get_joint_limits()], device=device)
     for rows, label, K in ((131072, "config3_shard", 100), (1 << 20, "config3_whole", 30)):
         q, gen = uniform_q(panda, rows, device, 4321)
@@ -360,7 +361,7 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
                "workload": "Franka Panda 7-DoF, FK(%s) + RNEA inverse dynamics (gravity, damping), %d rows%s, q~U(limits), "
                            "qd~U(+-0.2 vmax), qdd~U(+-0.4 vmax); ONE fused drm_fk_rnea launch" %
                            (link, rows, " = one GPU's shard of the 2^20 batch at N = 8" if rows == 131072 else " = the whole batch on one GPU"),
-               "own_kernel": own_ok, "own_kernel_unavailable": own_why,
+               "own_kernel": own_ok, "own_kernel_path": own_path, "own_kernel_unavailable": own_why,
                "library_kernel_launch_us": us_lib, "library_kernel_launch_us_min": us_lib_min,
                "roofline": roofline(140, rows, us, kernel, flops_per_eval=2600 + 830)}
         if label in IO_FLOOR_US:
@@ -377,20 +378,23 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
 
     # ------------------------------------------------------------------ config 4: Allegro, four fingertips, 65 536 rows
     hand = load("allegro_left", device)
+    hand.own_kernels = "off"
     B = 65536
     q, _ = uniform_q(hand, B, device, 4004)
     with torch.no_grad():
         us_lib, us_lib_min = graph_launch_us(lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS), 100)
-    us, us_min, kernel4, own4, own4_why = us_lib, us_lib_min, "drm::fk_fan_chain_kernel<8, 5, 4> (library, link-major outputs)", False, None
-    try:      # the hand's own fan-out kernel: every finger's constants folded in, scalar chain walk (csrc/drm_arm_static.hpp)
+    us, us_min, kernel4, own4, own4_path, own4_why = us_lib, us_lib_min, "drm::fk_fan_chain_kernel<8, 5, 4> (library, link-major outputs)", False, None, None
+    try:      # the hand's own fan-out kernel (every finger's constants folded in, scalar chain walk; csrc/drm_arm_static.hpp): what a
+        # plain model runs by default — the code object of this set of fingertips ships with the library
         hand_own = load("allegro_left", device)
-        hand_own.specialize()
         with torch.no_grad():
             hand_own.compute_forward_kinematics_links(q, ALLEGRO_TIPS)
-        from differentiable_robot_model_amd import specialize as sp
-        tips_idx = [hand_own._name_to_idx_map[t] for t in ALLEGRO_TIPS]
-        fan = hand_own._fanout_chains(tips_idx, hand_own._get_walk(("fk", tuple(tips_idx)), targets=tips_idx))
-        if fan and all((w.program._special or {}).get(sp.SPECIAL_FK_FAN_LINKS) for w in fan):
+        tips_idx = sorted(hand_own._name_to_idx_map[t] for t in ALLEGRO_TIPS)
+        own4_path = "default" if hand_own._fan_own(tips_idx) else None
+        if own4_path is None:
+            hand_own.specialize()
+            own4_path = "specialize()" if hand_own._fan_own(tips_idx) else None
+        if own4_path:
             hand, own4 = hand_own, True
             with torch.no_grad():
                 us, us_min = graph_launch_us(lambda: hand.compute_forward_kinematics_links(q, ALLEGRO_TIPS), 100)
@@ -402,7 +406,7 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
     legs.append({"config": 4, "name": "config4", "workload": "Allegro hand 16-DoF (allegro_left), FK to the four fingertips through "
                  "compute_forward_kinematics_links (one launch, one wavefront per finger), batch %d, q~U(joint limits)" % B,
                  "batch": B, "launch_us": us, "launch_us_min": us_min, "evals_per_s": B / us * 1e6,
-                 "own_kernel": own4, "own_kernel_unavailable": own4_why, "library_kernel_launch_us": us_lib,
+                 "own_kernel": own4, "own_kernel_path": own4_path, "own_kernel_unavailable": own4_why, "library_kernel_launch_us": us_lib,
                  "roofline": roofline(176, B, us, kernel4),
                  "io_floor_us": IO_FLOOR_US["config4"][0], "io_floor_source": IO_FLOOR_US["config4"][1]})
     ref_rows = 16384             # the reference walks all 21 links once per fingertip: ~4e4 evals/s on one core

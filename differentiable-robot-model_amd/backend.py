@@ -24,6 +24,7 @@ CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
 ABI_VERSION = 10
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
+SPECIAL_FK_FAN_LINKS = 9      # index of the fan-out FK kernel in drm_walk.special[] (include/drm_hip.h DRM_SPECIAL_FK_FAN_LINKS)
 
 
 class DrmWalk(ctypes.Structure):
@@ -397,24 +398,29 @@ def fk_links(prog: WalkProgram, ops_f, ops_i, q, n_targets: int, n_dofs: int):
     return pos, quat
 
 
-def fk_fanout(chains, q, n_dofs: int, link_major: bool = False):
+def fk_fanout(chains, q, n_dofs: int, link_major: bool = False, own=None):
     """FK of 2..4 targets with (nearly) disjoint chains: ``chains`` = [(prog, ops_f, ops_i)] per target.  pos [B, T, 3],
-    quat [B, T, 4]; with ``link_major`` pos [T, B, 3], quat [T, B, 4] (every target's poses a contiguous array)."""
+    quat [B, T, 4]; with ``link_major`` pos [T, B, 3], quat [T, B, 4] (every target's poses a contiguous array).
+    ``own``: handle of the constant-folded kernel built for exactly THIS ordered set of chains (specialize.attach_fan), written
+    into the structs of this call — drm_fk_fanout_links launches it when every chain carries the same handle; None: the library's."""
     lib = _lib_of(q, "q", chains[0][1])
     q = _dev_f32(q, "q", n_dofs)
     B, T = q.shape[0], len(chains)
     pos, quat = _outputs(q.device, (T, B, 3) if link_major else (B, T, 3), (T, B, 4) if link_major else (B, T, 4))
     if B == 0:
         return pos, quat
-    # the array of the chains' structs is kept on the first chain's program while the tables stay where they are (building it —
-    # four 248-byte structs through ctypes — took 20 us of a call whose kernel takes 4)
-    key = (n_dofs,) + tuple(f.data_ptr() for _, f, _ in chains)
-    cached = getattr(chains[0][0], "_fan_cache", None)
-    if cached is not None and cached[0] == key:
-        walks = cached[1]
-    else:
-        walks = (DrmWalk * T)(*[_walk_struct(p, f, i, n_dofs) for p, f, i in chains])
-        chains[0][0]._fan_cache = (key, walks)
+    # the array of the chains' structs is kept on the first chain's program, per ordered set of chains and own-kernel handle, while
+    # the tables stay where they are (building it — four 248-byte structs through ctypes — took 20 us of a call whose kernel takes 4)
+    key = (n_dofs, own) + tuple(f.data_ptr() for _, f, _ in chains) + tuple(id(p) for p, _, _ in chains)
+    cache = chains[0][0].__dict__.setdefault("_fan_cache", {})
+    walks = cache.get(key)
+    if walks is None:
+        walks = (DrmWalk * T)(*[_walk_struct(p, f, i, n_dofs) for p, f, i in chains])      # (copies of the programs' structs)
+        for t in range(T):
+            walks[t].special[SPECIAL_FK_FAN_LINKS] = own      # (None: NULL — the fan-out kernel never comes from a shared program)
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = walks
     with _on_device(q.device):
         _check((lib.drm_fk_fanout_links if link_major else lib.drm_fk_fanout)(
             walks, T, q.data_ptr(), B, pos.data_ptr(), quat.data_ptr(), _stream(q.device)), lib)

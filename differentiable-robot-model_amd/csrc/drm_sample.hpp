@@ -84,7 +84,13 @@ DRM_HD bool ctl_prismatic(int ctl) { return (ctl >> 25) & 1; }
 // minimax polynomials on [-pi/4, pi/4] (coefficients of the classic fdlibm float
 // kernels) — max error ~1 ulp, i.e. the same class as torch.sin/cos on the CPU
 // (spatial_vector_algebra.py:14-53 evaluates them in fp32).
+// Domain (round 6): |x| <= 1e9.  Beyond it — and for +-Inf / NaN — the quadrant no longer fits an int and the reduced argument
+// is noise: sin and cos are NaN, on every path (this is where sincos_one / chain_trig send their large arguments).  The test
+// and the select are INTEGER operations on the bit patterns, so they survive -ffinite-math-only (the robots' own kernels,
+// specialize.ARM_FLAGS), which may fold a floating-point isnan / select-of-NaN away.
 DRM_HD void sincos_f(float x, float &s, float &c) {
+    const bool outside = (__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) > 0x4e6e6b28u;   // |x| > 1e9f, Inf, NaN
+    if (outside) x = 0.0f;
     const double xd = (double)x;
     const double kd = rint(xd * 0.63661977236758134308);   // 2/pi
     double rd = fma(-kd, 1.57079632679489655800e+00, xd);    // pi/2 hi
@@ -106,6 +112,8 @@ DRM_HD void sincos_f(float x, float &s, float &c) {
     const float c0 = swap ? sr : cr;
     s = (q & 2) ? -s0 : s0;
     c = ((q + 1) & 2) ? -c0 : c0;
+    s = __builtin_bit_cast(float, outside ? 0x7fc00000u : __builtin_bit_cast(uint32_t, s));
+    c = __builtin_bit_cast(float, outside ? 0x7fc00000u : __builtin_bit_cast(uint32_t, c));
 }
 
 DRM_HD float rsqrt_f(float x) {

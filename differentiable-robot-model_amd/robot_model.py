@@ -163,6 +163,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._chain_walks: Dict[int, _DeviceWalk] = {}          # link index -> _chain_walk's answer while nothing is learnable
         self._dyn_walk: Optional[_DeviceWalk] = None            # _dynamics_walk's answer while nothing is learnable
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
+        self._fan_handles: Dict[tuple, int] = {}               # fan-out plan key -> the constant-folded kernel of THAT ordered set
+        self._own_kernels: Optional[str] = None                 # None: DRM_SPECIALIZE decides (default "auto"); "off" / "auto" / "build"
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
         self._fold_masks: Dict[tuple, np.ndarray] = {}          # kept (learnable) links -> foldable_links(spec, keep)
@@ -276,6 +278,59 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._walks[key] = dw
         return dw
 
+    def _own_kernel_mode(self) -> str:
+        """How this model comes by its OWN kernels (its constants / its tree folded into the instruction stream, specialize.py):
+
+          "auto"   (default, round 6) a code object that is ALREADY built — shipped next to the library (csrc/special_cache/, the
+                   robots of the package), or in the run-time cache of an earlier `specialize()` — is attached on first use; nothing
+                   is ever compiled on a call path, and a miss keeps the library's kernels (logged once per robot at INFO);
+          "build"  compile what is missing with hipcc (2-7 s per kernel, cached): `model.specialize()`, `model.own_kernels = "build"`,
+                   DRM_SPECIALIZE=1 (or =tune) in the environment;
+          "off"    the library's kernels only: `model.own_kernels = "off"` or DRM_SPECIALIZE=0.
+        Either way the results are the same to a few ulp (tests/test_specialize.py runs both)."""
+        if self._own_kernels is not None:
+            return self._own_kernels
+        env = os.environ.get("DRM_SPECIALIZE")
+        if env == "0":
+            return "off"
+        if env in ("1", "tune") or getattr(self, "_arm_specialized", False):
+            return "build"
+        return "auto"
+
+    @property
+    def own_kernels(self) -> Optional[str]:
+        """None (DRM_SPECIALIZE decides; "auto" when unset), "off", "auto" or "build" — see _own_kernel_mode."""
+        return self._own_kernels
+
+    @own_kernels.setter
+    def own_kernels(self, mode: Optional[str]) -> None:
+        if mode not in (None, "off", "auto", "build"):
+            raise ValueError('own_kernels must be None, "off", "auto" or "build"')
+        self._own_kernels = mode
+        # whatever was attached under the previous setting goes: the next call looks again under the new one
+        for dw in list(self._walks.values()) + [w for plan in self._fanout_plans.values() if plan for w in plan]:
+            prog = dw.program
+            prog._special, prog._special_const, prog._special_tried, prog._ws_cache = {}, False, False, None
+            prog._arm_special_failed = False
+            prog.__dict__.pop("_fan_cache", None)
+        self._fan_handles.clear()
+        self._dyn_walk = None
+        self.__dict__.pop("_own_kernel_missed", None)
+        if mode in (None, "auto", "build"):
+            for key, plan in self._fanout_plans.items():
+                if plan:
+                    self._fan_special(key, plan)
+
+    def _own_kernel_miss(self, what: str, err: Exception) -> None:
+        """One INFO line per model and kind of kernel when the default (`auto`) finds nothing built."""
+        seen = self.__dict__.setdefault("_own_kernel_missed", set())
+        if what not in seen:
+            seen.add(what)
+            import logging
+            logging.getLogger("differentiable_robot_model_amd").info(
+                "%s: no pre-built own kernel for %s (%s); the library's kernels serve it — model.specialize() builds one",
+                self.name or "robot", what, str(err)[:160])
+
     def specialize(self, force: bool = False, tune: bool = False):
         """Build (hipcc, 3-7 s, cached) and attach this robot's OWN straight-line dynamics kernels — inverse dynamics and its
         reverse mode, the inertia matrix, forward dynamics (specialize.py, csrc/drm_static.hpp): for robots whose tree is none of the
@@ -298,9 +353,9 @@ class DifferentiableRobotModel(torch.nn.Module):
             # constant models: the kernels that bake the robot's CONSTANTS (round 5) are built where they are first needed — the fused
             # FK + RNEA kernel of an arm's target link, the fan-out FK kernel of a set of fingertips (compute_forward_kinematics_links)
             self._arm_specialized = True
-            for plan in self._fanout_plans.values():
+            for key, plan in self._fanout_plans.items():
                 if plan:
-                    self._fan_special(plan)
+                    self._fan_special(key, plan)
         if tune:
             if dw.program.shape & SHAPE_ARM_CHAIN or dw.program.n_ops > sp.MAX_STATIC_OPS:
                 return {}
@@ -333,7 +388,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         constant-folded fused FK + RNEA kernel of this (dynamics walk, chain walk) pair."""
         if self._learnable or self._device.type != "cuda":
             return
-        if not (getattr(self, "_arm_specialized", False) or os.environ.get("DRM_SPECIALIZE") in ("1", "tune")):
+        mode = self._own_kernel_mode()
+        if mode == "off":
             return
         from . import specialize as sp
         have = (getattr(tree.program, "_special", None) or {}).get(sp.SPECIAL_FK_RNEA_ARM)
@@ -345,7 +401,10 @@ class DifferentiableRobotModel(torch.nn.Module):
             return
         try:
             sp.attach_arm(tree.program, self._ops_f(tree).detach().cpu().numpy(), self._n_dofs,
-                          chain.program, self._ops_f(chain).detach().cpu().numpy())
+                          chain.program, self._ops_f(chain).detach().cpu().numpy(), cached_only=mode == "auto")
+            if (tree.program._special or {}).get(sp.SPECIAL_FK_RNEA_ARM) is None:      # (auto: not built yet)
+                chain.program._arm_special_failed = True
+                self._own_kernel_miss("the fused FK + inverse-dynamics launch", sp.CacheMiss("; ".join(tree.program._special_missed)))
         except sp.SpecializeError:
             if getattr(self, "_arm_specialized", False):
                 raise
@@ -373,22 +432,32 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw = self._get_walk(("tree",), whole_tree=True)
         else:
             dw = self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
-        mode = os.environ.get("DRM_SPECIALIZE")
-        if mode in ("1", "tune") and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
-            # opt-in through the environment: every robot without a compiled straight-line shape builds its own kernels on first
-            # use (specialize.py; ~2 s once per robot and machine); a machine without hipcc keeps the loop kernels.  "tune": robots
-            # WITH a compiled shape (other than plain 7-DoF arms) build theirs too and keep, per entry point, the faster of the two
+        mode = self._own_kernel_mode()
+        if mode != "off" and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
+            # the robot's OWN kernels on first use.  "auto" (the default, round 6): whatever is already built — the code objects
+            # shipped next to the library, the run-time cache of an earlier specialize() — is attached, nothing is compiled; "build"
+            # (DRM_SPECIALIZE=1, model.own_kernels = "build"): every robot without a compiled straight-line shape builds its kernels
+            # (specialize.py; ~2 s once per robot and machine; a machine without hipcc keeps the loop kernels).  DRM_SPECIALIZE=tune:
+            # robots WITH a compiled shape (other than plain 7-DoF arms) build theirs too and keep, per entry point, the faster
             dw.program._special_tried = True
             from . import specialize as sp
             from .flatten import SHAPE_ARM_CHAIN, SHAPE_ARM_HAND, SHAPE_FINGERS
+            auto = mode == "auto"
             try:
-                if sp.arm_qualifies(dw.program, self._n_dofs) and not self._learnable:
-                    sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs)   # (constants folded in)
+                if sp.arm_qualifies(dw.program, self._n_dofs):
+                    if not self._learnable:
+                        sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs, cached_only=auto)   # (constants folded in)
+                        for what in dw.program._special_missed:
+                            self._own_kernel_miss(what, sp.CacheMiss("not in the cache"))
                 elif not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
-                    sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
-                elif mode == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN and dw.program.n_ops <= sp.MAX_STATIC_OPS:
+                    if dw.program.n_ops <= sp.MAX_STATIC_OPS:
+                        sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), cached_only=auto)
+                elif (os.environ.get("DRM_SPECIALIZE") == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN
+                      and dw.program.n_ops <= sp.MAX_STATIC_OPS):
                     sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
                     sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+            except sp.CacheMiss as err:
+                self._own_kernel_miss("the dynamics walk", err)
             except sp.SpecializeError:
                 pass
         if not self._learnable:
@@ -499,7 +568,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                         walks = [self._chain_walk(t) for t in targets]
                         if len({w.program.capacity for w in walks}) == 1:
                             self._fanout_plans[key] = walks
-                            self._fan_special(walks)
+                            self._fan_special(key, walks)
                             return walks
                     cap = max(build_walk(self._spec, targets=[t]).capacity for t in targets)
                     plan = []
@@ -513,20 +582,30 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._fanout_plans[key] = plan
         return self._fanout_plans[key]
 
-    def _fan_special(self, walks) -> None:
-        """After specialize() (or under DRM_SPECIALIZE=1) on a constant model: the fan-out FK call's own kernel — every chain's
-        constants folded into the instruction stream (specialize.attach_fan), once per set of targets."""
-        if self._learnable or self._device.type != "cuda":
+    def _fan_special(self, key, walks) -> None:
+        """The fan-out FK call's own kernel — every chain's constants folded into the instruction stream (specialize.attach_fan) —
+        for THIS ordered set of targets (`key` of _fanout_plans): built already (the default) or compiled now (specialize(),
+        DRM_SPECIALIZE=1).  The handle stays with the plan (`_fan_handles`), never on the chain walks, which other sets share."""
+        if self._learnable or self._device.type != "cuda" or key in self._fan_handles:
             return
-        explicit = getattr(self, "_arm_specialized", False)
-        if not (explicit or os.environ.get("DRM_SPECIALIZE") in ("1", "tune")):
+        mode = self._own_kernel_mode()
+        if mode == "off":
             return
         from . import specialize as sp
         try:
-            sp.attach_fan([w.program for w in walks], [self._ops_f(w).detach().cpu().numpy() for w in walks], self._n_dofs)
+            handle = sp.attach_fan([w.program for w in walks], [self._ops_f(w).detach().cpu().numpy() for w in walks], self._n_dofs,
+                                   cached_only=mode == "auto")
+            if handle:
+                self._fan_handles[key] = handle
+        except sp.CacheMiss as err:
+            self._own_kernel_miss("forward kinematics of links %s" % (list(key[1]),), err)
         except sp.SpecializeError:
-            if explicit:
+            if getattr(self, "_arm_specialized", False):
                 raise      # (the environment opt-in on a machine without hipcc keeps the library's kernels)
+
+    def _fan_own(self, targets) -> Optional[int]:
+        """The handle of the own fan-out kernel of this ordered set of targets, or None."""
+        return self._fan_handles.get(("fanout", tuple(targets))) if self._own_kernel_mode() != "off" else None
 
     def _kinematic_param_mask(self, dw: _DeviceWalk) -> int:
         """bit k set <=> op k's R_fixed / trans come from a learnable parametrisation (needs a constant gradient)."""
@@ -631,7 +710,8 @@ class DifferentiableRobotModel(torch.nn.Module):
                 self._require_device()
                 fan = self._fanout_chains(ordered, dw)
                 if fan is not None:
-                    pos, quat = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs, link_major=True)
+                    pos, quat = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs, link_major=True,
+                                                  own=self._fan_own(ordered))
                 else:
                     pos, quat = backend.fk_links(dw.program, self._ops_f(dw), dw.ops_i, q, len(ordered), self._n_dofs)
                 out.update(zip(ordered, zip(pos.unbind(0), quat.unbind(0))))      # (one unbind per array instead of an index op per link)
@@ -981,6 +1061,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 dw.program._ws_cache = None
         self._arm_specialized = False
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
+        self._fan_handles.clear()       # (kernels that bake the OLD constants)
         self._chain_walks.clear()
         self._dyn_walk = None
 

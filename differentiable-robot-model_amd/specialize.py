@@ -48,6 +48,12 @@ class SpecializeError(RuntimeError):
     pass
 
 
+class CacheMiss(SpecializeError):
+    """`build(..., cached_only=True)`: no code object for this source in the run-time cache or next to the library — what a model's
+    default (round 6: own kernels whenever they are already built, never a compile on the call path) treats as "keep the library's
+    kernels"."""
+
+
 def walk_tree(prog: WalkProgram, spec=None) -> Dict[str, list]:
     """(parent op, DoF column, prismatic) of every op of a whole-tree walk, parents before children — decoded from the packed
     control words W0 / W1 (include/drm_hip.h DRM_OPI_W0 / W1), i.e. exactly what the loop kernels read for the same walk
@@ -299,27 +305,46 @@ def target_arch() -> str:
     return "gfx950"
 
 
-def build(src: str, flags=()) -> str:
+_HEADERS = ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp", "drm_arm_stream.hpp", "drm_arm_static.hpp")
+_HEADER_BYTES: Dict[tuple, bytes] = {}
+
+
+def _headers() -> bytes:
+    """The headers a generated translation unit includes, for the source key (read once per process and set of mtimes)."""
+    stamp = tuple(os.path.getmtime(os.path.join(CSRC, name)) for name in _HEADERS)
+    if stamp not in _HEADER_BYTES:
+        _HEADER_BYTES.clear()
+        parts = []
+        for name in _HEADERS:
+            with open(os.path.join(CSRC, name), "rb") as f:
+                parts.append(f.read())
+        _HEADER_BYTES[stamp] = b"".join(parts)
+    return _HEADER_BYTES[stamp]
+
+
+def build(src: str, flags=(), cached_only: bool = False) -> str:
     """Path of the code object of `src`: drm_special_<source key>_<compiler key>.hsaco in the cache directory.  The source key
     covers the generated text, the headers it includes, the flags and the target ISA; the compiler key `hipcc --version`.  A
     machine WITHOUT hipcc takes any code object with the right source key (a cache exported by `export_cache` from a build
     machine).  Several processes may build the same robot at once (the ranks of one node): each compiles to its own temporary
-    name and publishes with an atomic rename, so nobody ever loads a half-written file."""
+    name and publishes with an atomic rename, so nobody ever loads a half-written file.
+    `cached_only` (round 6, what a model does by itself on first use): never run the compiler — a code object with the right source
+    key from the run-time cache or from the shipped one, else CacheMiss."""
     import glob
     import tempfile
     extra = list(flags) + os.environ.get("DRM_SPECIAL_FLAGS", "").split()      # (experiments: e.g. -DDRM_STATIC_PREF=0)
     arch = target_arch()
     h = hashlib.sha256((src + " ".join(extra) + arch).encode())
-    for name in ("drm_static.hpp", "drm_tree.hpp", "drm_sample.hpp", "drm_common.hpp", "drm_arm_stream.hpp", "drm_arm_static.hpp"):
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
+    h.update(_headers())
     key = h.hexdigest()[:20]
-    cc = hipcc()
+    cc = None if cached_only else hipcc()
     if cc is None:
         shipped = sorted(glob.glob(os.path.join(cache_dir(), "drm_special_%s_*.hsaco" % key)) +
                          glob.glob(os.path.join(shipped_cache(), "drm_special_%s_*.hsaco" % key)))
         if shipped:
             return shipped[0]
+        if cached_only:
+            raise CacheMiss("no built code object drm_special_%s_*.hsaco in %s or %s" % (key, cache_dir(), shipped_cache()))
         raise SpecializeError("hipcc not found and %s holds no code object for this robot (drm_special_%s_*.hsaco): build it "
                               "on a machine with the ROCm compiler and copy the cache (specialize.export_cache)" % (cache_dir(), key))
     name = "drm_special_%s_%s.hsaco" % (key, compiler_id(cc))
@@ -486,29 +511,31 @@ extern "C" __global__ void __launch_bounds__(%d) %s(const float *q, float *pos, 
 """ % ("".join(parts), 64 * len(chains), FAN_KERNEL, len(chains), cases)
 
 
-def attach_fan(progs, tables, n_dofs: int) -> Optional[int]:
-    """Build (cached) and attach the constant-folded fan-out FK kernel of these 2 .. 4 chain walks: the SAME handle on every program
-    (drm_fk_fanout_links checks that).  None when a chain does not qualify (the library's fan-out kernel keeps serving the call)."""
+def attach_fan(progs, tables, n_dofs: int, cached_only: bool = False) -> Optional[int]:
+    """Build (cached) the constant-folded fan-out FK kernel of these 2 .. 4 chain walks, IN THIS ORDER, and return its handle —
+    None when a chain does not qualify (the library's fan-out kernel keeps serving the call).  The kernel belongs to the ordered
+    set of chains, not to any one of them (the chain walk of a fingertip is shared by every set of targets that names it): the
+    caller keeps the handle with its fan-out plan and hands it to backend.fk_fanout(own=...), which writes it into the structs of
+    that call only (round 5 stored it on the shared programs: a subset of a specialised set of tips launched the wrong kernel)."""
     chains = [fan_chain(p, n_dofs) for p in progs]
     if any(c is None for c in chains) or not 2 <= len(chains) <= 4:
         return None
-    have = {(getattr(p, "_special", None) or {}).get(SPECIAL_FK_FAN_LINKS) for p in progs}
-    if len(have) == 1 and None not in have:
-        return have.pop()
-    handle = _load(build(fan_source(chains, tables, n_dofs), ARM_FLAGS), FAN_KERNEL)
-    for p in progs:
-        special = dict(getattr(p, "_special", None) or {})
-        special[SPECIAL_FK_FAN_LINKS] = handle
-        p._special, p._ws_cache = special, None
-    return handle
+    return _load(build(fan_source(chains, tables, n_dofs), ARM_FLAGS, cached_only), FAN_KERNEL)
+
+
+_LOADED: Dict[tuple, int] = {}
 
 
 def _load(path: str, kernel: str) -> int:
+    """Kernel handle of a code object (one hipModuleLoad per file and process)."""
     from . import backend
-    lib = backend.load_library()
-    fn = ctypes.c_void_p()
-    backend._check(lib.drm_special_load(path.encode(), kernel.encode(), ctypes.byref(fn)))
-    return fn.value
+    key = (path, kernel)
+    if key not in _LOADED:
+        lib = backend.load_library()
+        fn = ctypes.c_void_p()
+        backend._check(lib.drm_special_load(path.encode(), kernel.encode(), ctypes.byref(fn)))
+        _LOADED[key] = fn.value
+    return _LOADED[key]
 
 
 def arm_qualifies(prog: WalkProgram, n_dofs: int) -> bool:
@@ -516,39 +543,60 @@ def arm_qualifies(prog: WalkProgram, n_dofs: int) -> bool:
     return bool(prog.shape & SHAPE_ARM_CHAIN) and prog.capacity == 8 and n_dofs == 7 and prog.n_ops in (7, 8)
 
 
-def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkProgram] = None, chain_table=None) -> Dict[int, int]:
+def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkProgram] = None, chain_table=None,
+               cached_only: bool = False) -> Dict[int, int]:
     """Build (hipcc ~2 s each, cached) and attach the constant-folded kernels of a serial 7-DoF arm: inverse dynamics, the inertia
     matrix, forward dynamics and the input gradients of inverse dynamics on the dynamics walk `tree` (its [8, 32] table as a host
     array), and — given the chain walk of an FK target whose last link is the
     arm's last link — the fused FK + RNEA kernel of the pair, the SAME handle stored on both programs (drm_fk_rnea checks that).
-    A tree program keeps the fused kernel of the LAST chain it was paired with.  Constant models only: the kernels ignore ops_f."""
+    A tree program keeps the fused kernel of the LAST chain it was paired with.  Constant models only: the kernels ignore ops_f.
+    `cached_only`: attach whichever of them is already built (the run-time cache, the code objects shipped next to the library) and
+    never compile; a piece that is missing stays with the library's kernel (`tree._special_missed` names it)."""
     import numpy as np
     if not arm_qualifies(tree, n_dofs):
         raise SpecializeError("not a serial 7-DoF arm walk of capacity 8")
     links = tree.n_ops
     table = np.array(tree_table, np.float32, copy=True)
     special = dict(getattr(tree, "_special", None) or {})
-    if SPECIAL_RNEA_ARM not in special:
-        special[SPECIAL_RNEA_ARM] = _load(build(arm_source(table, links, False), ARM_FLAGS), ARM_KERNELS[SPECIAL_RNEA_ARM])
-    if SPECIAL_CRBA_ARM not in special:
-        path = build(arm_dynamics_source(table, links), ARM_FLAGS)
+    missed = []
+
+    def piece(what, fn):
+        try:
+            fn()
+        except CacheMiss:
+            missed.append(what)
+
+    def rnea_arm():
+        special[SPECIAL_RNEA_ARM] = _load(build(arm_source(table, links, False), ARM_FLAGS, cached_only), ARM_KERNELS[SPECIAL_RNEA_ARM])
+
+    def dynamics():
+        path = build(arm_dynamics_source(table, links), ARM_FLAGS, cached_only)
         for kind in ARM_DYNAMICS:
             special[kind] = _load(path, ARM_KERNELS[kind])
-    if chain is not None:
-        if not (arm_qualifies(chain, n_dofs) and chain.n_ops == 8):
-            raise SpecializeError("the FK target's chain is not this arm's chain of 8 ops")
+
+    def fused():
         both = table.copy()
         both[links:] = np.asarray(chain_table, np.float32)[links:]
-        handle = _load(build(arm_source(both, links, True), ARM_FLAGS), ARM_KERNELS[SPECIAL_FK_RNEA_ARM])
+        handle = _load(build(arm_source(both, links, True), ARM_FLAGS, cached_only), ARM_KERNELS[SPECIAL_FK_RNEA_ARM])
         special[SPECIAL_FK_RNEA_ARM] = handle
         cs = dict(getattr(chain, "_special", None) or {})
         cs[SPECIAL_FK_RNEA_ARM] = handle
         chain._special, chain._ws_cache = cs, None
+
+    if SPECIAL_RNEA_ARM not in special:
+        piece(ARM_KERNELS[SPECIAL_RNEA_ARM], rnea_arm)
+    if SPECIAL_CRBA_ARM not in special:
+        piece("the inertia-matrix / forward-dynamics / input-gradient kernels", dynamics)
+    if chain is not None:
+        if not (arm_qualifies(chain, n_dofs) and chain.n_ops == 8):
+            raise SpecializeError("the FK target's chain is not this arm's chain of 8 ops")
+        piece(ARM_KERNELS[SPECIAL_FK_RNEA_ARM], fused)
     tree._special, tree._ws_cache = special, None
+    tree._special_missed = missed
     return special
 
 
-def attach(prog: WalkProgram, spec, n_dofs: int, table=None) -> Dict[int, int]:
+def attach(prog: WalkProgram, spec, n_dofs: int, table=None, cached_only: bool = False) -> Dict[int, int]:
     """Build (or fetch from the cache) and load the straight-line kernels of a whole-tree walk; the handles are stored on the
     program, from where backend._walk_struct copies them into every drm_walk built for it.  `table` (a CONSTANT model's walk table
     as a host array): the kernels carry it as compile-time constants (`source`) and no longer read ops_f — the host must drop them
@@ -560,15 +608,12 @@ def attach(prog: WalkProgram, spec, n_dofs: int, table=None) -> Dict[int, int]:
         raise SpecializeError("walk of %d ops: the straight-line form is built for up to %d" % (prog.n_ops, MAX_STATIC_OPS))
     tree = walk_tree(prog, spec)
     src = source(tree, n_dofs, prog.capacity if prog.backward_ok else 0, table)
-    path = build(src, ARM_FLAGS if table is not None else ())
-    lib = backend.load_library()
+    path = build(src, ARM_FLAGS if table is not None else (), cached_only)
     handles = dict(getattr(prog, "_special", None) or {})
     for kind, kernel in KERNELS.items():
         if kernel not in src:           # (the reverse-mode kernel of a walk the backward entry points do not take / whose leaves exceed LDS)
             continue
-        fn = ctypes.c_void_p()
-        backend._check(lib.drm_special_load(path.encode(), kernel.encode(), ctypes.byref(fn)))
-        handles[kind] = fn.value
+        handles[kind] = _load(path, kernel)
     prog._special = handles
     prog._special_const = table is not None
     prog._ws_cache = None          # (the cached drm_walk predates the handles)
@@ -617,9 +662,11 @@ def tune(prog: WalkProgram, ops_f, ops_i, n_dofs: int, batch: int = 1 << 19, mar
         prog._special = h
         prog._ws_cache = None
 
-    report, kept = {}, {}
+    report, kept = {}, {k: h for k, h in handles.items() if k not in calls}      # (kinds tune does not time stay as they are)
     try:
         for kind, handle in handles.items():
+            if kind not in calls:
+                continue
             with_handles({kind: handle})
             own = timed(calls[kind])
             with_handles({})

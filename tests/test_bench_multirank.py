@@ -21,16 +21,59 @@ sys.path.insert(0, ROOT)
 
 
 def run_bench(*flags, timeout=600):
+    """Run bench.py; check the stdout contract (exactly ONE compact, strict-JSON line from rank 0) and return the FULL record of the
+    run (--detail), which carries the compact line's fields and everything they were cut from."""
+    import tempfile
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):   # the spawn path, not an inherited rendezvous
         env.pop(k, None)
-    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), stdout=subprocess.PIPE,
-                          stderr=subprocess.PIPE, timeout=timeout, env=env, cwd=ROOT)
-    out = done.stdout.decode()
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert done.returncode == 0, (done.returncode, out[-2000:], done.stderr.decode()[-4000:])
-    assert len(lines) == 1, "exactly ONE JSON line, from rank 0: %r" % lines
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail", detail] + list(flags), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, timeout=timeout, env=env, cwd=ROOT)
+        out = done.stdout.decode()
+        every = [l for l in out.splitlines() if l.strip()]
+        lines = [l for l in every if l.startswith("{")]      # (gloo's C++ side prints "[Gloo] Rank r is connected ..." to stdout)
+        assert done.returncode == 0, (done.returncode, out[-2000:], done.stderr.decode()[-4000:])
+        assert len(lines) == 1 and every[-1] == lines[0], "exactly ONE JSON line, from rank 0, and it is the LAST line: %r" % every
+        assert len(lines[0]) < 4096, len(lines[0])
+        compact = json.loads(lines[0], parse_constant=lambda name: pytest.fail("non-finite %s in the bench line" % name))
+        with open(detail) as f:
+            full = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "ranks_seen"):
+        assert key in compact, key
+        if key not in ("config", "roofline"):
+            assert compact[key] == full[key] or abs(compact[key] - full[key]) <= 1e-6 * abs(full[key]), key
+    return full
+
+
+def test_compact_line_stays_small_and_strict():
+    """bench.compact_line: whatever the run collected, stdout carries < 4 KB of strict JSON with the contract fields."""
+    import bench
+    nan = float("nan")
+    prose = "x" * 3000
+    full = {"metric": "m", "value": 1.23456789012e10, "unit": "evals/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 4.6e-3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_seen": 1,
+            "config": {"workload": "w", "batch_per_gpu": 65536, "note": prose},
+            "roofline": {"bound": "hbm", "achieved": 3500.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.4375, "traffic": nan,
+                         "kernel": "k", "launch_us": 4.2, "note": prose, "steady_state": {"launch_us": 3.7, "frac": 0.49, "steps": 200}},
+            "roofline_large": [{"batch": 1 << 22, "launch_us": 140.0, "frac": 0.84, "note": prose}, {"batch": 1 << 24, "skipped": "x"}],
+            "cpu_baseline": {"value": 1.2e6, "unit": "evals/s", "cores": 1, "kind": "reference", "sample": prose,
+                             "port": {"value": 3e7, "cores": 128, "sample": prose},
+                             "reference": {"gpu_vs_reference_max_abs": {"pos": 2.4e-7, "quat_sign_flips": 0}, "blob": prose}},
+            "configs": {"legs": [{"name": n, "own_kernel": True, "own_kernel_path": "default", "workload": prose,
+                                  "roofline": {"frac": 0.5, "launch_us": float("inf")}} for n in
+                                 ("config2", "config3_shard", "config3_whole", "config4", "config5")],
+                        "api_eager_us_per_call": {"compute_forward_kinematics": {"us_per_call": 6.0}, "note": prose}}}
+    line = bench.compact_line(full)
+    text = json.dumps(line, allow_nan=False)          # raises on NaN / Infinity
+    assert len(text) < 4096 and prose not in text
+    assert line["roofline"]["traffic"] is None and line["configs_launch_us"]["c2"] is None
+    assert line["configs_frac"] == {"c2": 0.5, "c3_shard": 0.5, "c3_whole": 0.5, "c4": 0.5, "c5": 0.5}
+    assert line["configs_own_kernel"]["c4"] == "default" and line["roofline_large"] == {"4194304": {"launch_us": 140.0, "frac": 0.84}}
+    assert line["cpu_baseline"]["sample"].endswith("...") and line["cpu_baseline"]["port_cores"] == 128
+    assert line["api_eager_us_per_call"] == {"forward_kinematics": 6.0}
 
 
 def test_shared_gpu_flag_selects_gloo():
