@@ -8,6 +8,9 @@
 // converts, serves it.  The reference does this bookkeeping in Python too (robot_model.py:25-84, 223-248, 305-375, 626-667); the
 // point is what a drop-in caller pays per call next to a 4 us kernel.
 #include <torch/extension.h>
+#include <torch/csrc/autograd/python_variable.h>
+
+#include <dlfcn.h>
 
 #include <tuple>
 
@@ -168,7 +171,118 @@ int64_t repeat_fk_jacobian(int64_t fn, int64_t walk, int64_t q, int64_t B, int64
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FastCall (round 6): ONE prepared public-method call of a constant model — compute_forward_kinematics / compute_endeffector_jacobian /
+// compute_fk_and_jacobian of a link, compute_inverse_dynamics — with EVERYTHING the Python method does per call on this side of the
+// boundary: the reference's tensor_check (robot_model.py:25-84: device type, ndim 1 or 2, one batch shape, 1-D <-> [1, n] promotion),
+// the shape asserts of the method, the "does this call build an autograd graph" test, the output allocation and the C-ABI call.
+// A call it does not take AS IS — wrong device / dtype / layout, a 1-D / 2-D mix, gradients wanted, another current device —
+// returns None and the Python method (which words the reference's AssertionErrors, converts, differentiates) serves it.
+// The walk structs live in Python objects the FastCall keeps alive (`keep`); the Python side drops a FastCall whenever the walk's
+// struct is rebuilt (own kernels attached, a parameter made learnable).
+typedef int (*hip_get_device_fn)(int *);
+static hip_get_device_fn hip_get_device() {
+    static hip_get_device_fn fn = reinterpret_cast<hip_get_device_fn>(dlsym(RTLD_DEFAULT, "hipGetDevice"));
+    return fn;
+}
+
+struct FastCall {
+    int64_t fn = 0, scratch_query = 0, walk = 0, walk2 = 0, n = 0, target_op = -1;
+    bool cuda = false;
+    int64_t device_index = -1;
+    pybind11::object keep;
+
+    FastCall(int64_t fn_, int64_t scratch_query_, int64_t walk_, int64_t walk2_, int64_t n_, int64_t target_op_, bool cuda_,
+             int64_t device_index_, pybind11::object keep_)
+        : fn(fn_), scratch_query(scratch_query_), walk(walk_), walk2(walk2_), n(n_), target_op(target_op_), cuda(cuda_),
+          device_index(device_index_), keep(std::move(keep_)) {}
+
+    // the tensor behind a Python argument when it is EXACTLY a torch.Tensor (tensor_check tests `type(arg) is torch.Tensor`) that the
+    // kernels take as it stands; rows = -1 for a 1-D tensor
+    bool take(pybind11::handle h, const at::Tensor *&out, int64_t &rows) const {
+        PyObject *o = h.ptr();
+        if (!THPVariable_CheckExact(o)) return false;
+        const at::Tensor &t = THPVariable_Unpack(o);
+        const int64_t d = t.dim();
+        if (d != 1 && d != 2) return false;
+        if (t.size(d - 1) != n || t.scalar_type() != at::kFloat || !t.is_contiguous() ||
+            (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15u) != 0)
+            return false;
+        if (t.is_cuda() != cuda || (cuda && t.get_device() != device_index) || (!cuda && !t.is_cpu())) return false;
+        out = &t;
+        rows = d == 1 ? -1 : t.size(0);
+        return true;
+    }
+    bool device_is_current() const {
+        if (!cuda) return true;
+        int dev = -1;
+        hip_get_device_fn get = hip_get_device();
+        return get && get(&dev) == 0 && dev == device_index;
+    }
+    static bool graph_wanted(const at::Tensor &t) { return t.requires_grad() && at::GradMode::is_enabled(); }
+    static pybind11::object wrap(const at::Tensor &t) { return pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(t)); }
+
+    // kind 0: (pos, quat);  1: (lin_jac, ang_jac);  2: (pos, quat, lin_jac, ang_jac)
+    pybind11::object kinematics(pybind11::handle hq, int64_t kind, int64_t stream) const {
+        const at::Tensor *q;
+        int64_t rows;
+        if (!take(hq, q, rows) || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        const bool one = rows < 0;
+        const int64_t B = one ? 1 : rows;
+        const int64_t o1 = pad4(B * 3), o2 = o1 + pad4(B * 4), o3 = kind ? o2 + pad4(B * 3 * n) : o2, total = kind ? o3 + pad4(B * 3 * n) : o2;
+        at::Tensor flat = at::empty({total}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            float *base = flat.data_ptr<float>();
+            if (kind == 0)
+                rc = reinterpret_cast<fk_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), B, 1, base, base + o1,
+                                                 reinterpret_cast<void *>(stream));
+            else
+                rc = reinterpret_cast<fk_jacobian_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), B, base, base + o1, base + o2,
+                                                          base + o3, reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        auto view = [&](int64_t off, std::initializer_list<int64_t> shape2, std::initializer_list<int64_t> stride2,
+                        std::initializer_list<int64_t> shape1, std::initializer_list<int64_t> stride1) {
+            return one ? flat.as_strided(shape1, stride1, off) : flat.as_strided(shape2, stride2, off);
+        };
+        if (kind == 0) return pybind11::make_tuple(wrap(view(0, {B, 3}, {3, 1}, {3}, {1})), wrap(view(o1, {B, 4}, {4, 1}, {4}, {1})));
+        pybind11::object lin = wrap(view(o2, {B, 3, n}, {3 * n, n, 1}, {3, n}, {n, 1}));
+        pybind11::object ang = wrap(view(o3, {B, 3, n}, {3 * n, n, 1}, {3, n}, {n, 1}));
+        if (kind == 1) return pybind11::make_tuple(lin, ang);
+        return pybind11::make_tuple(wrap(view(0, {B, 3}, {3, 1}, {3}, {1})), wrap(view(o1, {B, 4}, {4, 1}, {4}, {1})), lin, ang);
+    }
+
+    // tau [B, n] ([n] for 1-D inputs); hqdd may be None (the non-linear effects)
+    pybind11::object inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) const {
+        const at::Tensor *q, *qd, *qdd = nullptr;
+        int64_t rows, rows_d, rows_dd;
+        if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || rows_d != rows) return pybind11::none();
+        if (!hqdd.is_none() && (!take(hqdd, qdd, rows_dd) || rows_dd != rows)) return pybind11::none();
+        if (graph_wanted(*q) || graph_wanted(*qd) || (qdd && graph_wanted(*qdd)) || !device_is_current()) return pybind11::none();
+        const bool one = rows < 0;
+        const int64_t B = one ? 1 : rows;
+        at::Tensor tau = one ? at::empty({n}, q->options()) : at::empty({B, n}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+            at::Tensor scratch;
+            if (need > 0) scratch = at::empty({need}, q->options());
+            rc = reinterpret_cast<rnea_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), qd->data_ptr<float>(),
+                                               qdd ? qdd->data_ptr<float>() : nullptr, B, (int32_t)flags, tau.data_ptr<float>(),
+                                               need > 0 ? scratch.data_ptr<float>() : nullptr, reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        return wrap(tau);
+    }
+};
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    pybind11::class_<FastCall>(m, "FastCall")
+        .def(pybind11::init<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, int64_t, pybind11::object>())
+        .def("kinematics", &FastCall::kinematics)
+        .def("inverse_dynamics", &FastCall::inverse_dynamics);
+
     m.def("repeat_fk_jacobian", &repeat_fk_jacobian, pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("crba", &crba);
     m.def("fk_rnea", &fk_rnea);

@@ -164,6 +164,12 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._dyn_walk: Optional[_DeviceWalk] = None            # _dynamics_walk's answer while nothing is learnable
         self._fanout_plans: Dict[tuple, Optional[list]] = {}
         self._fan_handles: Dict[tuple, int] = {}               # fan-out plan key -> the constant-folded kernel of THAT ordered set
+        # prepared eager calls of a constant model (csrc/drm_hostcall.cpp FastCall): link name -> (call, walk program, its struct cache)
+        self._fast_fk: Dict[str, tuple] = {}
+        self._fast_jac: Dict[str, tuple] = {}
+        self._fast_id: Optional[tuple] = None
+        self._stream_arg = (lambda: 0) if self._device.type != "cuda" or backend._raw_stream is None else \
+            (lambda raw=backend._raw_stream, i=self._device.index: raw(i))
         self._own_kernels: Optional[str] = None                 # None: DRM_SPECIALIZE decides (default "auto"); "off" / "auto" / "build"
         self._static_table: Optional[torch.Tensor] = None      # snapshot of all rows (constants)
         self._static_folded: Dict[tuple, torch.Tensor] = {}    # ... with the links of a fold mask folded into their parents
@@ -776,14 +782,43 @@ class DifferentiableRobotModel(torch.nn.Module):
         cols = self._fk_links(q, idxs)
         return {name: cols[i] for name, i in zip(link_names, idxs)}
 
-    @tensor_check
+    def _fast_entry(self, entry: str, scratch: Optional[str], dw: "_DeviceWalk") -> Optional[tuple]:
+        """(FastCall, walk program, the program's struct cache) of one prepared eager call of this walk through the C ABI's `entry`
+        — None when the C++ host path is not built, the model has learnable parameters (its table changes every call) or lives on
+        a device kind the path does not serve.  The call stays valid while the program's struct cache does (the identity is checked
+        per call): attaching own kernels or rebuilding the table retires it and the next call through the Python path renews it."""
+        fast = backend.hostcall()
+        if fast is None or not hasattr(fast, "FastCall") or self._learnable or self._device.type not in ("cuda", "cpu"):
+            return None
+        import ctypes
+        lib = backend.library_for(self._device)
+        ops_f = self._ops_f(dw)
+        walk = backend._walk_struct(dw.program, ops_f, dw.ops_i, self._n_dofs)
+        call = fast.FastCall(backend._fn_addr(lib, entry), backend._fn_addr(lib, scratch) if scratch else 0, ctypes.addressof(walk), 0,
+                             self._n_dofs, -1, self._device.type == "cuda", self._device.index if self._device.index is not None else -1,
+                             (walk, ops_f, dw.ops_i, lib))
+        return (call, dw.program, dw.program._ws_cache)
+
     def compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False
                                    ) -> Tuple[torch.Tensor, torch.Tensor]:
         """(pos [B,3], quat_xyzw [B,4]) of ``link_name`` (robot_model.py:223-248).
 
         ``recursive`` selects between two implementations in the reference that return the same
         pose on a fresh model; both map to the same kernel here.
+        A constant model's repeat calls go through ONE C++ call (csrc/drm_hostcall.cpp FastCall: tensor_check, the asserts below,
+        the allocation and the launch); whatever that does not take as it is — and every first call — comes here.
         """
+        ent = self._fast_fk.get(link_name)
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].kinematics(q, 0, self._stream_arg())
+            if out.__class__ is tuple:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_forward_kinematics(q, link_name, recursive)
+
+    @tensor_check
+    def _compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         idx = self._name_to_idx_map[link_name]
@@ -791,7 +826,12 @@ class DifferentiableRobotModel(torch.nn.Module):
             # the common call: one kernel, outputs allocated in their final shape (no slicing ops on the way out)
             self._require_device()
             dw = self._chain_walk(idx)
-            return backend.fk(dw.program, self._ops_f(dw), dw.ops_i, q, 1, self._n_dofs, squeeze=True)
+            out = backend.fk(dw.program, self._ops_f(dw), dw.ops_i, q, 1, self._n_dofs, squeeze=True)
+            if link_name not in self._fast_fk or self._fast_fk[link_name][1]._ws_cache is not self._fast_fk[link_name][2]:
+                ent = self._fast_entry("drm_fk", None, dw)
+                if ent is not None:
+                    self._fast_fk[link_name] = ent
+            return out
         pos, quat = self._fk_targets(q, [idx])
         return pos[:, 0], quat[:, 0]
 
@@ -820,15 +860,25 @@ class DifferentiableRobotModel(torch.nn.Module):
         return torch.nn.functional.mse_loss(pos, target)
 
     # ------------------------------------------------------------------ Jacobian
-    @tensor_check
     def compute_endeffector_jacobian(self, q: torch.Tensor, link_name: str) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(lin_jac [B,3,n], ang_jac [B,3,n]) at the link origin, world frame (robot_model.py:626-667)."""
+        """(lin_jac [B,3,n], ang_jac [B,3,n]) at the link origin, world frame (robot_model.py:626-667).  (Repeat calls of a constant
+        model: one C++ call, see compute_forward_kinematics.)"""
+        ent = self._fast_jac.get(link_name)
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].kinematics(q, 1, self._stream_arg())
+            if out.__class__ is tuple:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_endeffector_jacobian(q, link_name)
+
+    @tensor_check
+    def _compute_endeffector_jacobian(self, q: torch.Tensor, link_name: str):
         assert len(q.shape) == 2
         assert q.shape[1] == self._n_dofs
         _, _, lin, ang = self._fk_and_jacobian(q, link_name)
         return lin, ang
 
-    @tensor_check
     def compute_fk_and_jacobian(self, q: torch.Tensor, link_name: str
                                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """(pos, quat, lin_jac, ang_jac) from ONE fused kernel launch.
@@ -836,6 +886,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         The reference's ``compute_endeffector_jacobian`` runs the full FK first and throws the pose
         away (robot_model.py:641); this returns it instead.
         """
+        ent = self._fast_jac.get(link_name)
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].kinematics(q, 2, self._stream_arg())
+            if out.__class__ is tuple:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_fk_and_jacobian(q, link_name)
+
+    @tensor_check
+    def _compute_fk_and_jacobian(self, q: torch.Tensor, link_name: str):
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         return self._fk_and_jacobian(q, link_name)
@@ -851,7 +912,13 @@ class DifferentiableRobotModel(torch.nn.Module):
                 return _FkJacobian.apply(q, ops_f, dw, self._n_dofs, self._kinematic_param_mask(dw))
             return backend.fk_jacobian(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
         dw = self._chain_walk(idx)
-        return backend.fk_jacobian(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
+        out = backend.fk_jacobian(dw.program, self._ops_f(dw), dw.ops_i, q, self._n_dofs)
+        have = self._fast_jac.get(link_name)
+        if idx != 0 and (have is None or have[1]._ws_cache is not have[2]):
+            ent = self._fast_entry("drm_fk_jacobian", None, dw)
+            if ent is not None:
+                self._fast_jac[link_name] = ent
+        return out
 
     def plan_fk_and_jacobian(self, q: torch.Tensor, link_name: str, want_pose: bool = True
                              ) -> "backend.FkJacobianPlan":
@@ -925,11 +992,23 @@ class DifferentiableRobotModel(torch.nn.Module):
         return plan.tau, plan.pos, plan.quat
 
     # ------------------------------------------------------------------ inverse dynamics
-    @tensor_check
     def compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,
                                  include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
                                  ) -> torch.Tensor:
-        """tau [B,n] achieving ``qdd_des`` (RNEA, robot_model.py:305-375)."""
+        """tau [B,n] achieving ``qdd_des`` (RNEA, robot_model.py:305-375).  (Repeat calls of a constant model: one C++ call, see
+        compute_forward_kinematics.)"""
+        ent = self._fast_id
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].inverse_dynamics(q, qd, qdd_des, (1 if include_gravity else 0) | (2 if use_damping else 0), self._stream_arg())
+            if out.__class__ is torch.Tensor:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_inverse_dynamics(q, qd, qdd_des, include_gravity, use_damping)
+
+    @tensor_check
+    def _compute_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor,
+                                  include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True):
         assert q.ndim == 2
         assert qd.ndim == 2
         assert qdd_des.ndim == 2
@@ -939,10 +1018,21 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._require_device()
         return self._inverse_dynamics(q, qd, qdd_des, bool(include_gravity), bool(use_damping))
 
-    @tensor_check
     def compute_non_linear_effects(self, q: torch.Tensor, qd: torch.Tensor, include_gravity: Optional[bool] = True,
                                    use_damping: Optional[bool] = True) -> torch.Tensor:
         """Coriolis + centrifugal + gravity + damping torques = RNEA with qdd = 0 (robot_model.py:377-400)."""
+        ent = self._fast_id
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].inverse_dynamics(q, qd, None, (1 if include_gravity else 0) | (2 if use_damping else 0), self._stream_arg())
+            if out.__class__ is torch.Tensor:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_non_linear_effects(q, qd, include_gravity, use_damping)
+
+    @tensor_check
+    def _compute_non_linear_effects(self, q: torch.Tensor, qd: torch.Tensor, include_gravity: Optional[bool] = True,
+                                    use_damping: Optional[bool] = True):
         assert q.ndim == 2 and qd.ndim == 2
         assert q.shape[1] == self._n_dofs and qd.shape[1] == self._n_dofs
         self._require_device()
@@ -972,7 +1062,11 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._differentiable(dw)
             return _InverseDynamics.apply(q, qd, qdd, ops_f, dw, gravity, damping, self._n_dofs,
                                           self._learnable_op_mask(dw))
-        return backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
+        out = backend.rnea(dw.program, ops_f, dw.ops_i, q, qd, qdd, gravity, damping, self._n_dofs)
+        have = self._fast_id
+        if have is None or have[1]._ws_cache is not have[2]:
+            self._fast_id = self._fast_entry("drm_rnea", "drm_rnea_scratch_floats_aligned", dw)
+        return out
 
     @tensor_check
     def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
@@ -1060,6 +1154,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 dw.program._special_tried = False
                 dw.program._ws_cache = None
         self._arm_specialized = False
+        self._fast_fk.clear(); self._fast_jac.clear(); self._fast_id = None      # (prepared calls snapshot the constants)
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
         self._fan_handles.clear()       # (kernels that bake the OLD constants)
         self._chain_walks.clear()

@@ -197,6 +197,68 @@ def test_host_work_in_cxx_is_the_python_host_path(cpu_library, hostcall_module, 
         backend._check(rc, cpu_library)
 
 
+def test_prepared_eager_calls_are_the_python_path(cpu_library, hostcall_module, monkeypatch):
+    """Round 6: repeat calls of a constant model's hot public methods go through ONE C++ call — tensor_check
+    (robot_model.py:25-84), the asserts, the allocation and the C-ABI launch in csrc/drm_hostcall.cpp FastCall.  Same bits as the
+    Python path for 2-D and 1-D inputs; everything the prepared call does not take as it is falls back to the Python method, which
+    converts / differentiates / words the reference's errors; a learnable parameter retires the prepared calls."""
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
+    monkeypatch.setattr(backend, "_hostcall", hostcall_module)
+    m, ref = load_model("panda_no_gripper", "cpu"), load_model("panda_no_gripper", "cpu")
+    n, link = m._n_dofs, "panda_virtual_ee_link"
+    g = torch.Generator().manual_seed(7)
+    q, qd, qdd = (torch.rand(70, n, generator=g) - 0.5 for _ in range(3))
+    monkeypatch.setattr(backend, "_hostcall", None)         # `ref` never prepares a call: the Python host path, every time
+    want = [ref.compute_forward_kinematics(q, link), ref.compute_endeffector_jacobian(q, link), ref.compute_fk_and_jacobian(q, link),
+            (ref.compute_inverse_dynamics(q, qd, qdd),), (ref.compute_inverse_dynamics(q, qd, qdd, include_gravity=False, use_damping=False),),
+            (ref.compute_non_linear_effects(q, qd),)]
+    monkeypatch.setattr(backend, "_hostcall", hostcall_module)
+
+    def results(a, b, c):
+        return [m.compute_forward_kinematics(a, link), m.compute_endeffector_jacobian(a, link), m.compute_fk_and_jacobian(a, link),
+                (m.compute_inverse_dynamics(a, b, c),), (m.compute_inverse_dynamics(a, b, c, include_gravity=False, use_damping=False),),
+                (m.compute_non_linear_effects(a, b),)]
+
+    first = results(q, qd, qdd)
+    assert set(m._fast_fk) == {link} and set(m._fast_jac) == {link} and m._fast_id is not None and not ref._fast_fk
+    for rep in range(3):          # (the first call prepares, the rest run prepared)
+        for a, b in zip(results(q, qd, qdd), want):
+            assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+    # the prepared calls really serve: the Python method underneath is not reached
+    monkeypatch.setattr(type(m), "_compute_endeffector_jacobian", lambda *a, **k: pytest.fail("the prepared call should have served this"))
+    monkeypatch.setattr(type(m), "_compute_inverse_dynamics", lambda *a, **k: pytest.fail("the prepared call should have served this"))
+    assert torch.equal(m.compute_endeffector_jacobian(q, link)[0], want[1][0]) and torch.equal(m.compute_inverse_dynamics(q, qd, qdd), want[3][0])
+    one = m.compute_endeffector_jacobian(q[4], link)          # 1-D in (a 16-byte aligned row), the batch dimension stripped (tensor_check)
+    assert one[0].shape == (3, n) and torch.equal(one[0], want[1][0][4]) and torch.equal(one[1], want[1][1][4])
+    assert torch.equal(m.compute_inverse_dynamics(q[4], qd[4], qdd[4]), want[3][0][4])
+    assert m.compute_inverse_dynamics(torch.zeros(0, n), torch.zeros(0, n), torch.zeros(0, n)).shape == (0, n)
+    monkeypatch.undo()
+    monkeypatch.setattr(backend, "_hostcall", hostcall_module)
+    # not taken as it is -> the Python method: another dtype, a strided view, gradients wanted, a 1-D / 2-D mix, a wrong width
+    assert torch.equal(m.compute_endeffector_jacobian(q.double(), link)[0], want[1][0])
+    wide = torch.zeros(70, n + 1)
+    wide[:, :n] = q
+    assert torch.equal(m.compute_forward_kinematics(wide[:, :n], link)[0], want[0][0])
+    qg = q.clone().requires_grad_(True)
+    m.compute_forward_kinematics(qg, link)[0].sum().backward()
+    assert qg.grad is not None and float(qg.grad.abs().sum()) > 0
+    with torch.no_grad():
+        assert torch.equal(m.compute_forward_kinematics(qg, link)[0], want[0][0])       # (no graph wanted: prepared call, same bits)
+    with pytest.raises(AssertionError, match="Batch size mismatch"):
+        m.compute_inverse_dynamics(q, qd[0], qdd)
+    with pytest.raises(AssertionError):
+        m.compute_endeffector_jacobian(q[:, :5], link)
+    with pytest.raises(AssertionError, match="ndim of 1 or 2"):
+        m.compute_forward_kinematics(q.reshape(2, 35, n), link)
+    with pytest.raises(KeyError):
+        m.compute_forward_kinematics(q, "no_such_link")
+    # a learnable parameter: the prepared calls snapshot constants and are retired
+    m.make_link_param_learnable("panda_link2", "trans", UnconstrainedTensor(dim1=1, dim2=3))
+    assert not m._fast_fk and not m._fast_jac and m._fast_id is None
+    pos = m.compute_forward_kinematics(q, link)[0]
+    assert pos.requires_grad and not m._fast_fk
+
+
 def test_cpu_fingertips_in_one_call(cpu_library):
     """compute_forward_kinematics_links (drm_fk_fanout_links of the host build: a chain walk per fingertip, link-major outputs) gives
     what the per-link calls give."""
