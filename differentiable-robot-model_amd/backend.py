@@ -21,10 +21,11 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 SPECIAL_FK_FAN_LINKS = 9      # index of the fan-out FK kernel in drm_walk.special[] (include/drm_hip.h DRM_SPECIAL_FK_FAN_LINKS)
+WALK_TICKET = 10               # ... and of the walk's ticket word (ABI 11, DRM_WALK_TICKET): one-launch backward reductions
 
 
 class DrmWalk(ctypes.Structure):
@@ -292,7 +293,30 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     w.chain_prismatic = int(prog.chain_prismatic)
     for kind, handle in (getattr(prog, "_special", None) or {}).items():      # (specialize.attach: kernels built for this walk)
         w.special[kind] = handle
+    ticket = getattr(prog, "_ticket", None)
+    if ticket is not None and ticket.is_cuda and ops_f_ptr:
+        w.special[WALK_TICKET] = ticket.data_ptr()
     return w
+
+
+def _ticket(prog: WalkProgram, device) -> None:
+    """OPT-IN (DRM_TICKET=1): give the walk its TICKET word (ABI 11, include/drm_hip.h DRM_WALK_TICKET) before its first backward
+    launch on a HIP device: one zeroed device word per walk, with which drm_fk_mse / drm_fk_backward reduce their partial sums in the
+    block that finishes last instead of in a second launch.  Bit-identical results (tests/test_fk_backward.py) — and SLOWER on an
+    MI355X, which is why it is not the default: drm_fk_mse at 16 384 rows 7.4 us as two launches, 43 us with agent-scope fences (each
+    writes back / invalidates an XCD's whole L2), 13.2 us with write-through stores + agent-scope loads and no fence, 11.5 us with
+    every load of the last block in flight at once (profiles/r06_ticket_ab.txt): store acknowledgement -> ticket -> loads are three
+    DEPENDENT trips to memory, each dearer than the ~1.7 us kernel boundary they replace.
+    The word belongs to the walk — i.e. to the model: backward launches of ONE model must not overlap on different streams.  Not
+    created while a stream is capturing (the allocation would belong to the graph's pool)."""
+    have = getattr(prog, "_ticket", None)
+    if have is not None and have.device == device:
+        return
+    if device.type != "cuda" or os.environ.get("DRM_TICKET") != "1" or torch.cuda.is_current_stream_capturing():
+        return
+    with torch.cuda.device(device):
+        prog._ticket = torch.zeros(1, dtype=torch.int32, device=device)
+    prog._ws_cache = None
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -665,6 +689,8 @@ def fk_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, n_targets: int, n_
     if grad_q is None and grad_ops is None:
         return None, None
     scratch = torch.empty(max(1, lib.drm_fk_backward_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
+    if param_mask:
+        _ticket(prog, dev)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     with _on_device(dev):
         _check(lib.drm_fk_backward(ctypes.byref(walk), q.data_ptr(), B, n_targets, grad_pos.data_ptr(),
@@ -688,6 +714,7 @@ def fk_mse(prog: WalkProgram, ops_f, ops_i, q, target, n_dofs: int, param_mask: 
     grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
     grad_ops = torch.empty(prog.capacity, ops_f.shape[1], device=dev, dtype=torch.float32) if param_mask else None
     scratch = torch.empty(max(1, lib.drm_fk_mse_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
+    _ticket(prog, dev)
     walk = _walk_struct(prog, ops_f.detach(), ops_i, n_dofs)
     with _on_device(dev):
         _check(lib.drm_fk_mse(ctypes.byref(walk), q.data_ptr(), target.data_ptr(), B, ctypes.c_uint64(param_mask), loss.data_ptr(),

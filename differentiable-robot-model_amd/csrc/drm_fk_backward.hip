@@ -153,6 +153,92 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
 }
 
+// grad_ops_f[k, FT field j] = column k * 12 + j of the partial rows summed in column_sum's order; the rest of the row zeroed
+// (shared by fk_backward_reduce_kernel and the last-block form below)
+__device__ __forceinline__ void store_fk_gradient(float *__restrict__ grad_ops_f, int e, float total) {
+    const int k = e / BWD_FIELDS, j = e % BWD_FIELDS;
+    const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
+    grad_ops_f[k * DRM_OPF_STRIDE + at] = total;
+}
+
+// one float of a row of partial sums, written THROUGH to where every XCD reads it (an agent-scope atomic store: `sc1`)
+__device__ __forceinline__ void publish(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The tail of a backward kernel launched with a ticket word (ABI 11): every block publishes its rows of partial sums (agent-scope
+// release), takes a ticket, and the block that takes the LAST one (all rows are visible to it: agent-scope acquire) reduces them —
+// the same sums in the same order as fk_backward_reduce_kernel, whose REDUCE_WAVES wavefronts this block's waves stand in for, a
+// few each — writes grad_ops_f (and the loss), and puts the ticket word back to zero for the next launch.
+// Called by ALL threads of the block, outside divergent control flow.  `lds`: >= REDUCE_WAVES * WAVE floats of the block's LDS.
+template <int CAP>
+__device__ __forceinline__ void last_block_reduce(uint32_t *ticket, const float *partials, int n_rows, int pitch, float *grad_ops_f,
+                                                  float *loss, float loss_scale, float *lds) {
+    constexpr int NV = CAP * BWD_FIELDS;
+    __shared__ uint32_t took;
+    // No cache-wide fence on either side (an agent-scope release / acquire writes back / invalidates the whole L2 of the XCD: measured
+    // 7.5 -> 43 us for drm_fk_mse at 16 384 rows): the rows were PUBLISHED with agent-scope atomic stores (write-through, `sc1`) by
+    // publish_row() and are READ here with agent-scope atomic loads (which do not hit a line of this XCD's L2), so all the protocol
+    // needs is program order: a wave's stores are acknowledged (s_waitcnt) before its block's ticket is taken.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) took = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (took != gridDim.x - 1) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    struct Rows {
+        const float *p;
+        __device__ float operator[](int64_t i) const { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    } rows{partials};
+    // wavefront `wave` stands in for wavefronts wave, wave + wpb, ... of column_sum — all of their loads of a round in flight together
+    // (these loads go to memory: a round trip is ~0.7 us, and one wavefront after the other paid it VW times per 64 columns)
+    constexpr int VW = REDUCE_WAVES / MAX_WAVES_PER_BLOCK;
+    for (int e0 = 0; e0 < NV + (loss ? 1 : 0); e0 += WAVE) {
+        const int e = e0 + (int)lane;
+        const bool live = e < NV || (loss && e == NV);
+        const int64_t col = live ? e : 0;
+        float sum[VW][REDUCE_UNROLL];
+#pragma unroll
+        for (int j = 0; j < VW; ++j)
+#pragma unroll
+            for (int u = 0; u < REDUCE_UNROLL; ++u) sum[j][u] = 0.0f;
+        for (int r0 = 0; r0 < n_rows; r0 += REDUCE_UNROLL * REDUCE_WAVES) {
+            float v[VW][REDUCE_UNROLL];
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int u = 0; u < REDUCE_UNROLL; ++u) {
+                    const int r = r0 + wave + j * wpb + u * REDUCE_WAVES;
+                    v[j][u] = r < n_rows ? rows[(int64_t)r * pitch + col] : 0.0f;
+                }
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int u = 0; u < REDUCE_UNROLL; ++u) sum[j][u] += v[j][u];
+        }
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+#pragma unroll
+            for (int w = REDUCE_UNROLL / 2; w >= 1; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) sum[j][u] += sum[j][u + w];
+            lds[(wave + j * wpb) * WAVE + lane] = live ? sum[j][0] : 0.0f;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float total = 0.0f;
+#pragma unroll
+            for (int w = 0; w < REDUCE_WAVES; ++w) total += lds[w * WAVE + lane];
+            if (loss && e == NV) loss[0] = total * loss_scale;
+            if (grad_ops_f && e < NV) store_fk_gradient(grad_ops_f, e, total);
+        }
+        __syncthreads();
+    }
+    if (grad_ops_f)      // the FT block holds exactly the 12 differentiated constants
+        for (int i = (int)threadIdx.x; i < CAP * (DRM_OPF_STRIDE - BWD_FIELDS); i += (int)blockDim.x)
+            grad_ops_f[(i / (DRM_OPF_STRIDE - BWD_FIELDS)) * DRM_OPF_STRIDE + BWD_FIELDS + i % (DRM_OPF_STRIDE - BWD_FIELDS)] = 0.0f;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Serial-chain ("arm") specialisation for ONE target at the end of the chain, full tiles only (BASELINE config 5:
 // iiwa, loss on the end-effector position): drm_sample.hpp fk_backward_chain — one packed chain FK per sample and
 // closed-form adjoints instead of stored poses and an adjoint sweep; constants staged once per wave in LDS, the
@@ -171,7 +257,8 @@ constexpr int FK_BWD_PRE_MAX_TILES = DRM_FK_BWD_PRE_MAX_TILES;
 template <int CAP, int NJ, bool MSE = false, bool PRE = true>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
-                           int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *__restrict__ partials, float g_scale) {
+                           int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *partials, float g_scale,
+                           uint32_t *ticket, float *grad_ops_f, float *loss, float loss_scale) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
@@ -246,9 +333,14 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         }
     }
     wave_lds_sync();
-    float *prow = partials + (int64_t)wave_id * (MSE ? NV + 4 : NV);
-    for (int i = (int)lane; i < NV; i += WAVE) prow[i] = lacc[i];
-    if (MSE && lane == 63u) prow[NV] = loss_acc;
+    constexpr int PITCH = MSE ? NV + 4 : NV;
+    float *prow = partials + (int64_t)wave_id * PITCH;
+    for (int i = (int)lane; i < NV; i += WAVE) publish(prow + i, lacc[i]);
+    if (MSE && lane == 63u) publish(prow + NV, loss_acc);
+    // ABI 11 (drm_walk.special[DRM_WALK_TICKET]): ONE launch.  The block that takes the last ticket adds the rows of partial sums
+    // itself — in column_sum's order, so the totals are the two-launch form's bit for bit — instead of a second kernel behind a
+    // ~1.7 us kernel boundary (BASELINE configuration 5: 16 384 rows, where the boundary was a quarter of drm_fk_mse).
+    if (ticket) last_block_reduce<CAP>(ticket, partials, n_waves, PITCH, grad_ops_f, MSE ? loss : nullptr, loss_scale, smem);
 }
 
 // grad_ops_f[k, FT field j] = sum over the partial rows of column k * 12 + j, in a fixed order (drm_common.hpp
@@ -264,11 +356,7 @@ __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
     const float total = column_sum(partials, n_rows, pitch, e, e < NV || is_loss, lds);
     if (threadIdx.x < WAVE && is_loss) loss[0] = total * loss_scale;
     if (!grad_ops_f) return;
-    if (threadIdx.x < WAVE && e < NV) {
-        const int k = e / BWD_FIELDS, j = e % BWD_FIELDS;
-        const int at = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9); // dF row-major, then dt
-        grad_ops_f[k * DRM_OPF_STRIDE + at] = total;
-    }
+    if (threadIdx.x < WAVE && e < NV) store_fk_gradient(grad_ops_f, e, total);
     // the FT block holds exactly the 12 differentiated constants
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < cap * (DRM_OPF_STRIDE - BWD_FIELDS);
          i += (int)(gridDim.x * blockDim.x))
@@ -325,16 +413,19 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             const int n_tiles = (int)(B / WAVE);
             const int64_t done = (int64_t)n_tiles * WAVE;
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
+            // ABI 11: with a ticket word on the walk and no ragged tail, the block that finishes last reduces (one launch)
+            uint32_t *ticket = (done == B && grad_ops_f) ? (uint32_t *)w->special[DRM_WALK_TICKET] : nullptr;
             if (n_tiles <= FK_BWD_PRE_MAX_TILES)
                 hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, true>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                    dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                                   partials, 0.0f);
+                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f);
             else
                 hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, false>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                    dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                                   partials, 0.0f);
+                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f);
             rc = launched();
             if (rc) return rc;
+            if (ticket) return DRM_OK;
             rows_done = waves_a;
             partials += (int64_t)waves_a * cap * BWD_FIELDS;
             q += done * n; grad_pos += done * 3;   // (grad_rot is NULL on this path)
@@ -424,14 +515,19 @@ extern "C" int drm_fk_mse(const drm_walk *w, const float *q, const float *target
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = (int)(B / WAVE);
     const int waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
+    uint32_t *ticket = (uint32_t *)w->special[DRM_WALK_TICKET];      // ABI 11: ONE launch, the last block reduces
+    const float loss_scale = 1.0f / (3.0f * (float)B);
     if (n_tiles <= FK_BWD_PRE_MAX_TILES)
         hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
-                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
+                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B), ticket, grad_ops_f, loss,
+                           loss_scale);
     else
         hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, false>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
-                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B));
+                           0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B), ticket, grad_ops_f, loss,
+                           loss_scale);
     rc = launched();
     if (rc) return rc;
+    if (ticket) return DRM_OK;
     hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + 1 + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0,
                        s, scratch, waves, cap, grad_ops_f, cap * BWD_FIELDS + 4, loss, 1.0f / (3.0f * (float)B));
     return launched();

@@ -275,13 +275,86 @@ struct FastCall {
         if (rc) return pybind11::int_(rc);
         return wrap(tau);
     }
+
+    // H [B, n, n] ([n, n] for a 1-D q): drm_crba
+    pybind11::object inertia_matrix(pybind11::handle hq, int64_t stream) const {
+        const at::Tensor *q;
+        int64_t rows;
+        if (!take(hq, q, rows) || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        const bool one = rows < 0;
+        const int64_t B = one ? 1 : rows;
+        at::Tensor H = one ? at::empty({n, n}, q->options()) : at::empty({B, n, n}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+            at::Tensor scratch;
+            if (need > 0) scratch = at::empty({need}, q->options());
+            rc = reinterpret_cast<crba_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), B, H.data_ptr<float>(),
+                                               need > 0 ? scratch.data_ptr<float>() : nullptr, reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        return wrap(H);
+    }
+
+    // qdd [B, n]: drm_forward_dynamics
+    pybind11::object forward_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hf, int64_t flags, int64_t stream) const {
+        const at::Tensor *q, *qd, *f;
+        int64_t rows, rows_d, rows_f;
+        if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || !take(hf, f, rows_f) || rows_d != rows || rows_f != rows) return pybind11::none();
+        if (graph_wanted(*q) || graph_wanted(*qd) || graph_wanted(*f) || !device_is_current()) return pybind11::none();
+        const bool one = rows < 0;
+        const int64_t B = one ? 1 : rows;
+        at::Tensor qdd = one ? at::empty({n}, q->options()) : at::empty({B, n}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+            at::Tensor scratch;
+            if (need > 0) scratch = at::empty({need}, q->options());
+            rc = reinterpret_cast<fd_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), qd->data_ptr<float>(), f->data_ptr<float>(),
+                                             B, (int32_t)flags, qdd.data_ptr<float>(), need > 0 ? scratch.data_ptr<float>() : nullptr,
+                                             reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        return wrap(qdd);
+    }
+
+    // (tau [B, n], pos [B, 3], quat [B, 4]): drm_fk_rnea on (walk = the dynamics walk, walk2 = the target's chain walk)
+    pybind11::object fk_inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) const {
+        const at::Tensor *q, *qd, *qdd;
+        int64_t rows, rows_d, rows_dd;
+        if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || !take(hqdd, qdd, rows_dd) || rows_d != rows || rows_dd != rows) return pybind11::none();
+        if (!device_is_current()) return pybind11::none();      // (this entry point is not differentiable: no graph test)
+        const bool one = rows < 0;
+        const int64_t B = one ? 1 : rows;
+        const int64_t o1 = pad4(B * n), o2 = o1 + pad4(B * 3);
+        at::Tensor flat = at::empty({o2 + pad4(B * 4)}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            const int64_t need = reinterpret_cast<scratch_fn>(scratch_query)(reinterpret_cast<const void *>(walk), B);
+            at::Tensor scratch;
+            if (need > 0) scratch = at::empty({need}, flat.options());
+            float *base = flat.data_ptr<float>();
+            rc = reinterpret_cast<fk_rnea_fn>(fn)(reinterpret_cast<const void *>(walk), reinterpret_cast<const void *>(walk2), (int32_t)target_op,
+                                                  q->data_ptr<float>(), qd->data_ptr<float>(), qdd->data_ptr<float>(), B, (int32_t)flags, base,
+                                                  base + o1, base + o2, need > 0 ? scratch.data_ptr<float>() : nullptr,
+                                                  reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        if (one)
+            return pybind11::make_tuple(wrap(flat.as_strided({n}, {1}, 0)), wrap(flat.as_strided({3}, {1}, o1)), wrap(flat.as_strided({4}, {1}, o2)));
+        return pybind11::make_tuple(wrap(flat.as_strided({B, n}, {n, 1}, 0)), wrap(flat.as_strided({B, 3}, {3, 1}, o1)),
+                                    wrap(flat.as_strided({B, 4}, {4, 1}, o2)));
+    }
 };
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     pybind11::class_<FastCall>(m, "FastCall")
         .def(pybind11::init<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, int64_t, pybind11::object>())
         .def("kinematics", &FastCall::kinematics)
-        .def("inverse_dynamics", &FastCall::inverse_dynamics);
+        .def("inverse_dynamics", &FastCall::inverse_dynamics)
+        .def("inertia_matrix", &FastCall::inertia_matrix)
+        .def("forward_dynamics", &FastCall::forward_dynamics)
+        .def("fk_inverse_dynamics", &FastCall::fk_inverse_dynamics);
 
     m.def("repeat_fk_jacobian", &repeat_fk_jacobian, pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("crba", &crba);

@@ -168,6 +168,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._fast_fk: Dict[str, tuple] = {}
         self._fast_jac: Dict[str, tuple] = {}
         self._fast_id: Optional[tuple] = None
+        self._fast_crba: Optional[tuple] = None
+        self._fast_fd: Optional[tuple] = None
+        self._fast_fkid: Dict[str, tuple] = {}                  # link name -> (call, dynamics walk program, its cache, chain program, its cache)
         self._stream_arg = (lambda: 0) if self._device.type != "cuda" or backend._raw_stream is None else \
             (lambda raw=backend._raw_stream, i=self._device.index: raw(i))
         self._own_kernels: Optional[str] = None                 # None: DRM_SPECIALIZE decides (default "auto"); "off" / "auto" / "build"
@@ -782,7 +785,8 @@ class DifferentiableRobotModel(torch.nn.Module):
         cols = self._fk_links(q, idxs)
         return {name: cols[i] for name, i in zip(link_names, idxs)}
 
-    def _fast_entry(self, entry: str, scratch: Optional[str], dw: "_DeviceWalk") -> Optional[tuple]:
+    def _fast_entry(self, entry: str, scratch: Optional[str], dw: "_DeviceWalk", chain: Optional["_DeviceWalk"] = None,
+                    target_op: int = -1) -> Optional[tuple]:
         """(FastCall, walk program, the program's struct cache) of one prepared eager call of this walk through the C ABI's `entry`
         — None when the C++ host path is not built, the model has learnable parameters (its table changes every call) or lives on
         a device kind the path does not serve.  The call stays valid while the program's struct cache does (the identity is checked
@@ -794,9 +798,17 @@ class DifferentiableRobotModel(torch.nn.Module):
         lib = backend.library_for(self._device)
         ops_f = self._ops_f(dw)
         walk = backend._walk_struct(dw.program, ops_f, dw.ops_i, self._n_dofs)
-        call = fast.FastCall(backend._fn_addr(lib, entry), backend._fn_addr(lib, scratch) if scratch else 0, ctypes.addressof(walk), 0,
-                             self._n_dofs, -1, self._device.type == "cuda", self._device.index if self._device.index is not None else -1,
-                             (walk, ops_f, dw.ops_i, lib))
+        keep, walk2 = [walk, ops_f, dw.ops_i, lib], 0
+        if chain is not None:      # (drm_fk_rnea: the dynamics walk and the target's chain walk)
+            cf = self._ops_f(chain)
+            w2 = backend._walk_struct(chain.program, cf, chain.ops_i, self._n_dofs)
+            keep += [w2, cf, chain.ops_i]
+            walk2 = ctypes.addressof(w2)
+        call = fast.FastCall(backend._fn_addr(lib, entry), backend._fn_addr(lib, scratch) if scratch else 0, ctypes.addressof(walk), walk2,
+                             self._n_dofs, target_op, self._device.type == "cuda",
+                             self._device.index if self._device.index is not None else -1, tuple(keep))
+        if chain is not None:
+            return (call, dw.program, dw.program._ws_cache, chain.program, chain.program._ws_cache)
         return (call, dw.program, dw.program._ws_cache)
 
     def compute_forward_kinematics(self, q: torch.Tensor, link_name: str, recursive: bool = False
@@ -965,10 +977,24 @@ class DifferentiableRobotModel(torch.nn.Module):
                                              q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs,
                                              outputs=outputs)
 
-    @tensor_check
     def compute_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor, link_name: str,
                                         include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
                                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(tau [B,n], pos [B,3], quat [B,4]) from one pass over q — see _compute_fk_and_inverse_dynamics; repeat calls of a constant
+        model go through one prepared C++ call (csrc/drm_hostcall.cpp FastCall)."""
+        ent = self._fast_fkid.get(link_name)
+        if ent is not None and ent[1]._ws_cache is ent[2] and ent[3]._ws_cache is ent[4]:
+            out = ent[0].fk_inverse_dynamics(q, qd, qdd_des, (1 if include_gravity else 0) | (2 if use_damping else 0), self._stream_arg())
+            if out.__class__ is tuple:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_fk_and_inverse_dynamics(q, qd, qdd_des, link_name, include_gravity, use_damping)
+
+    @tensor_check
+    def _compute_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor, link_name: str,
+                                         include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
+                                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """(tau [B,n], pos [B,3], quat [B,4]): compute_inverse_dynamics and compute_forward_kinematics of one link from
         a single pass over q (not differentiable; use the two separate methods under autograd)."""
         assert q.ndim == 2 and qd.ndim == 2 and qdd_des.ndim == 2
@@ -984,6 +1010,12 @@ class DifferentiableRobotModel(torch.nn.Module):
                                   int(tree.program.op_of_link.get(idx, -1)), q.detach(), qd.detach(), qdd_des.detach(),
                                   bool(include_gravity), bool(use_damping), self._n_dofs)
             if out is not None:
+                have = self._fast_fkid.get(link_name)
+                if have is None or have[1]._ws_cache is not have[2] or have[3]._ws_cache is not have[4]:
+                    ent = self._fast_entry("drm_fk_rnea", "drm_rnea_scratch_floats_aligned", tree, chain,
+                                           int(tree.program.op_of_link.get(idx, -1)))
+                    if ent is not None:
+                        self._fast_fkid[link_name] = ent
                 return out
         plan = self.plan_fk_and_inverse_dynamics(q.detach(), qd.detach(), qdd_des.detach(), link_name,
                                                  bool(include_gravity), bool(use_damping))
@@ -1068,9 +1100,22 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._fast_id = self._fast_entry("drm_rnea", "drm_rnea_scratch_floats_aligned", dw)
         return out
 
-    @tensor_check
     def compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
                                           use_damping: Optional[bool] = True) -> torch.Tensor:
+        """H(q) [B, n, n] (robot_model.py:402-450) — see _compute_lagrangian_inertia_matrix; repeat calls of a constant model go
+        through one prepared C++ call (csrc/drm_hostcall.cpp FastCall)."""
+        ent = self._fast_crba
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].inertia_matrix(q, self._stream_arg())
+            if out.__class__ is torch.Tensor:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_lagrangian_inertia_matrix(q, include_gravity, use_damping)
+
+    @tensor_check
+    def _compute_lagrangian_inertia_matrix(self, q: torch.Tensor, include_gravity: Optional[bool] = True,
+                                           use_damping: Optional[bool] = True) -> torch.Tensor:
         """Joint-space inertia matrix H(q) [B, n, n] (robot_model.py:402-450).
 
         The reference assembles H from n + 1 inverse-dynamics passes, column j = ID(q, 0, e_j) - ID(q, 0, 0);
@@ -1087,12 +1132,30 @@ class DifferentiableRobotModel(torch.nn.Module):
         if torch.is_grad_enabled() and (ops_f.requires_grad or q.requires_grad):
             self._differentiable(dw)
             return _MassMatrix.apply(q, ops_f, dw, self._n_dofs, self._learnable_op_mask(dw))
-        return backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+        out = backend.crba(dw.program, ops_f, dw.ops_i, q, self._n_dofs)
+        have = self._fast_crba
+        if have is None or have[1]._ws_cache is not have[2]:
+            self._fast_crba = self._fast_entry("drm_crba", "drm_crba_scratch_floats_aligned", dw)
+        return out
 
-    @tensor_check
     def compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
                                  include_gravity: Optional[bool] = True, use_damping: Optional[bool] = False
                                  ) -> torch.Tensor:
+        """qdd [B, n] (robot_model.py:487-624) — see _compute_forward_dynamics; repeat calls of a constant model go through one
+        prepared C++ call (csrc/drm_hostcall.cpp FastCall)."""
+        ent = self._fast_fd
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            out = ent[0].forward_dynamics(q, qd, f, (1 if include_gravity else 0) | (2 if use_damping else 0), self._stream_arg())
+            if out.__class__ is torch.Tensor:
+                return out
+            if out is not None:
+                backend._check(out, backend.library_for(self._device))
+        return self._compute_forward_dynamics(q, qd, f, include_gravity, use_damping)
+
+    @tensor_check
+    def _compute_forward_dynamics(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
+                                  include_gravity: Optional[bool] = True, use_damping: Optional[bool] = False
+                                  ) -> torch.Tensor:
         """qdd [B,n] that the joint torques ``f`` produce in state (q, qd) (robot_model.py:487-624).
 
         One kernel launch: Featherstone's articulated-body recursion, as in the reference, for robots with a long
@@ -1114,8 +1177,12 @@ class DifferentiableRobotModel(torch.nn.Module):
             self._differentiable(dw)
             return _ForwardDynamics.apply(q, qd, f, ops_f, dw, bool(include_gravity), bool(use_damping), self._n_dofs,
                                           self._learnable_op_mask(dw))
-        return backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
-                                        bool(use_damping), self._n_dofs)
+        out = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, bool(include_gravity),
+                                       bool(use_damping), self._n_dofs)
+        have = self._fast_fd
+        if have is None or have[1]._ws_cache is not have[2]:
+            self._fast_fd = self._fast_entry("drm_forward_dynamics", "drm_forward_dynamics_scratch_floats_aligned", dw)
+        return out
 
     def compute_forward_dynamics_old(self, q: torch.Tensor, qd: torch.Tensor, f: torch.Tensor,
                                      include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True
@@ -1154,7 +1221,8 @@ class DifferentiableRobotModel(torch.nn.Module):
                 dw.program._special_tried = False
                 dw.program._ws_cache = None
         self._arm_specialized = False
-        self._fast_fk.clear(); self._fast_jac.clear(); self._fast_id = None      # (prepared calls snapshot the constants)
+        self._fast_fk.clear(); self._fast_jac.clear(); self._fast_fkid.clear()    # (prepared calls snapshot the constants)
+        self._fast_id = self._fast_crba = self._fast_fd = None
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
         self._fan_handles.clear()       # (kernels that bake the OLD constants)
         self._chain_walks.clear()

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 10
+#define DRM_ABI_VERSION 11
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_SPECIAL_KINDS 12 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
@@ -65,6 +65,14 @@ extern "C" {
 /* ... and on the 2 .. 4 CHAIN walks of a fan-out FK call (the fingertips of a hand): ONE kernel for all of them, a wavefront per
  * chain, every chain's constants folded in (scalar chain walk, csrc/drm_arm_static.hpp); the SAME handle on every chain walk. */
 #define DRM_SPECIAL_FK_FAN_LINKS 9 /* drm_fk_fanout_links  kernel "drm_fk_fan_links_static", arguments q, pos, quat, B (int64)       */
+/* ABI 11: NOT a kernel — a device `uint32_t` TICKET word owned by the host, one per walk: zero when a call is enqueued and zero again
+ * when it has completed (allocate it zeroed once; calls that use it must not overlap on different streams).  With it the backward
+ * entry points that end in a fixed-order reduction of per-wavefront partial sums (drm_fk_mse; drm_fk_backward of a 7-DoF arm
+ * chain at a multiple of 64 rows) run as ONE launch: every block publishes its rows and takes a ticket, the block that takes
+ * the last one adds the rows — same order, same bits as the separate reduction kernel — and resets the word.  NULL: two
+ * launches, as before (the reference's counterpart is autograd's accumulation, robot_model.py:669-713 + examples/
+ * learn_kinematics_of_iiwa.py:47-55). */
+#define DRM_WALK_TICKET 10
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

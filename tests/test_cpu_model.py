@@ -211,22 +211,30 @@ def test_prepared_eager_calls_are_the_python_path(cpu_library, hostcall_module, 
     monkeypatch.setattr(backend, "_hostcall", None)         # `ref` never prepares a call: the Python host path, every time
     want = [ref.compute_forward_kinematics(q, link), ref.compute_endeffector_jacobian(q, link), ref.compute_fk_and_jacobian(q, link),
             (ref.compute_inverse_dynamics(q, qd, qdd),), (ref.compute_inverse_dynamics(q, qd, qdd, include_gravity=False, use_damping=False),),
-            (ref.compute_non_linear_effects(q, qd),)]
+            (ref.compute_non_linear_effects(q, qd),), (ref.compute_lagrangian_inertia_matrix(q),),
+            (ref.compute_forward_dynamics(q, qd, qdd, use_damping=True),), ref.compute_fk_and_inverse_dynamics(q, qd, qdd, link)]
     monkeypatch.setattr(backend, "_hostcall", hostcall_module)
 
     def results(a, b, c):
         return [m.compute_forward_kinematics(a, link), m.compute_endeffector_jacobian(a, link), m.compute_fk_and_jacobian(a, link),
                 (m.compute_inverse_dynamics(a, b, c),), (m.compute_inverse_dynamics(a, b, c, include_gravity=False, use_damping=False),),
-                (m.compute_non_linear_effects(a, b),)]
+                (m.compute_non_linear_effects(a, b),), (m.compute_lagrangian_inertia_matrix(a),),
+                (m.compute_forward_dynamics(a, b, c, use_damping=True),), m.compute_fk_and_inverse_dynamics(a, b, c, link)]
 
     first = results(q, qd, qdd)
     assert set(m._fast_fk) == {link} and set(m._fast_jac) == {link} and m._fast_id is not None and not ref._fast_fk
+    assert m._fast_crba is not None and m._fast_fd is not None and set(m._fast_fkid) == {link}
     for rep in range(3):          # (the first call prepares, the rest run prepared)
         for a, b in zip(results(q, qd, qdd), want):
             assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
     # the prepared calls really serve: the Python method underneath is not reached
     monkeypatch.setattr(type(m), "_compute_endeffector_jacobian", lambda *a, **k: pytest.fail("the prepared call should have served this"))
     monkeypatch.setattr(type(m), "_compute_inverse_dynamics", lambda *a, **k: pytest.fail("the prepared call should have served this"))
+    for name in ("_compute_lagrangian_inertia_matrix", "_compute_forward_dynamics", "_compute_fk_and_inverse_dynamics"):
+        monkeypatch.setattr(type(m), name, lambda *a, **k: pytest.fail("the prepared call should have served this"))
+    assert torch.equal(m.compute_lagrangian_inertia_matrix(q), want[6][0]) and torch.equal(m.compute_forward_dynamics(q, qd, qdd, use_damping=True), want[7][0])
+    assert all(torch.equal(x, y) for x, y in zip(m.compute_fk_and_inverse_dynamics(q, qd, qdd, link), want[8]))
+    assert m.compute_lagrangian_inertia_matrix(q[4]).shape == (n, n) and torch.equal(m.compute_fk_and_inverse_dynamics(q[4], qd[4], qdd[4], link)[1], want[8][1][4])
     assert torch.equal(m.compute_endeffector_jacobian(q, link)[0], want[1][0]) and torch.equal(m.compute_inverse_dynamics(q, qd, qdd), want[3][0])
     one = m.compute_endeffector_jacobian(q[4], link)          # 1-D in (a 16-byte aligned row), the batch dimension stripped (tensor_check)
     assert one[0].shape == (3, n) and torch.equal(one[0], want[1][0][4]) and torch.equal(one[1], want[1][1][4])
@@ -254,7 +262,7 @@ def test_prepared_eager_calls_are_the_python_path(cpu_library, hostcall_module, 
         m.compute_forward_kinematics(q, "no_such_link")
     # a learnable parameter: the prepared calls snapshot constants and are retired
     m.make_link_param_learnable("panda_link2", "trans", UnconstrainedTensor(dim1=1, dim2=3))
-    assert not m._fast_fk and not m._fast_jac and m._fast_id is None
+    assert not m._fast_fk and not m._fast_jac and m._fast_id is None and m._fast_crba is None and m._fast_fd is None and not m._fast_fkid
     pos = m.compute_forward_kinematics(q, link)[0]
     assert pos.requires_grad and not m._fast_fk
 

@@ -262,6 +262,65 @@ def test_gpu_fk_backward_beyond_one_tile_per_wavefront():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [64, 16384, 1030 * 64, 2500 * 64])
+def test_gpu_one_launch_backward_reduction_equals_the_two_launch_form(B, monkeypatch):
+    """ABI 11 (drm_walk.special[DRM_WALK_TICKET]): drm_fk_mse and drm_fk_backward of a 7-DoF arm chain reduce their per-wavefront
+    partial sums in the block that finishes LAST instead of in a second launch — opt-in (DRM_TICKET=1): correct, bit-identical, and
+    slower than the kernel boundary it removes (backend._ticket has the numbers).  Same sums in the same order: loss and parameter
+    gradients BIT FOR BIT the two-launch form's,
+    launch after launch (the ticket word resets itself), eagerly and replayed from a hipGraph; sizes on both sides of the
+    register-table / LDS-table switch (1 024 tiles) and of the cap on the launch's wavefronts (2 048)."""
+    from differentiable_robot_model_amd import backend
+    torch.manual_seed(0)
+    models = []
+    for ticket in ("0", "1"):
+        monkeypatch.setenv("DRM_TICKET", ticket)
+        m = load_model("iiwa7", "cuda")
+        torch.manual_seed(1)
+        m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+        m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+        models.append(m)
+    two, one = models
+    q = torch.from_numpy(sample_states(one, B, seed=B)[0]).cuda()
+    with torch.no_grad():
+        want = load_model("iiwa7", "cuda").compute_forward_kinematics(q, "iiwa_link_ee")[0] + 0.02
+
+    def step(m, fused, ticket):
+        monkeypatch.setenv("DRM_TICKET", ticket)
+        m.zero_grad()
+        x = q.clone().requires_grad_(True)
+        loss = m.fk_mse_loss(x, "iiwa_link_ee", want) if fused else torch.nn.functional.mse_loss(m.compute_forward_kinematics(x, "iiwa_link_ee")[0], want)
+        loss.backward()
+        return [loss.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    for fused in (True, False):
+        ref = step(two, fused, "0")
+        for rep in range(3):
+            got = step(one, fused, "1")
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), (fused, rep)
+    ee = one._name_to_idx_map["iiwa_link_ee"]
+    prog = one._get_walk(("fk", (ee,)), targets=[ee]).program
+    assert getattr(prog, "_ticket", None) is not None and int(prog._ticket.item()) == 0          # (back to zero after every launch)
+    assert getattr(two._get_walk(("fk", (ee,)), targets=[ee]).program, "_ticket", None) is None
+    # replayed from a hipGraph
+    monkeypatch.setenv("DRM_TICKET", "1")
+    dw = one._get_walk(("fk", (ee,)), targets=[ee])
+    ops_f, mask = one._ops_f(dw).detach(), one._kinematic_param_mask(dw)
+    eager = backend.fk_mse(dw.program, ops_f, dw.ops_i, q, want, 7, mask, True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = backend.fk_mse(dw.program, ops_f, dw.ops_i, q, want, 7, mask, True)
+    for _ in range(3):
+        for t in out:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, eager))
+    assert int(prog._ticket.item()) == 0
+
+
+@pytest.mark.gpu
 def test_gpu_training_step_is_hipgraph_capturable():
     """Forward + loss + backward + Adam of the kinematics-learning loop captured ONCE into a hipGraph and replayed:
     no call on the path synchronises or touches host memory, so the launch-bound loop runs without the host."""
