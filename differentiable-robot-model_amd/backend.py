@@ -293,6 +293,8 @@ def fill_walk_struct(cls, prog: WalkProgram, ops_f_ptr: int, ops_i_ptr: int, n_d
     w.chain_prismatic = int(prog.chain_prismatic)
     for kind, handle in (getattr(prog, "_special", None) or {}).items():      # (specialize.attach: kernels built for this walk)
         w.special[kind] = handle
+    if (getattr(prog, "_special", None) or {}).get(11):      # (specialize.attach_arm_param: the set of learnable blocks it was built for)
+        w.reserved0 = int(getattr(prog, "_special_mask", 0))
     ticket = getattr(prog, "_ticket", None)
     if ticket is not None and ticket.is_cuda and ops_f_ptr:
         w.special[WALK_TICKET] = ticket.data_ptr()

@@ -106,6 +106,124 @@ __device__ __forceinline__ void rnea_backward_arm_static_body(ROW row, const flo
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Reverse-mode inverse dynamics of a serial arm WITH learnable link parameters (round 6; the learn-dynamics workload, reference
+// robot_model.py:305-375 under autograd with rigid_body_params.py parametrisations, examples/learn_dynamics_iiwa.py): the gradient
+// of a loss on the torques with respect to the learnable entries of the walk table (+ the input gradients, when asked for).
+// A model's table changes every optimiser step — but only in the blocks a learnable parameter feeds: KIN = F / t of a link whose
+// `trans` / `rot_angles` are learnable, DYN = mass / mcom / I_o / damping of a link whose `mass` / `com` / `inertia_mat` /
+// `joint_damping` are.  Every other block is a constant of the robot and is folded into the instruction stream here (MIXED::ft(k) /
+// MIXED::operator()(k) return the constexpr table or this launch's LDS copy, per op and block, decided at compile time); the adjoint
+// code of constant blocks is dead and gone.  The sums over the batch of the live gradient entries are kept PER LANE in registers
+// across the tiles of a (persistent) wavefront and reduced across the wavefront once at the end (the library kernel does that for
+// ONE learnable link and pays 26 DPP reductions per tile and link otherwise); the per-wavefront rows of partial sums have the
+// library's layout ([waves, CAP * 32], reduced by rnea_backward_reduce_kernel in a fixed order).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int LINKS, uint32_t MASK_KIN, uint32_t MASK_DYN>
+struct ParamSlots {      // where op k's live entries sit in the per-lane sums: KIN entries [0, 12) first, then DYN entries [12, 26)
+    static constexpr int KIN = DRM_OPF_FT_FLOATS, DYN = DRM_OPF_DAMP + 1 - DRM_OPF_FT_FLOATS;
+    static constexpr int base(int k) {
+        int b = 0;
+        for (int i = 0; i < k; ++i) b += (((MASK_KIN >> i) & 1u) ? KIN : 0) + (((MASK_DYN >> i) & 1u) ? DYN : 0);
+        return b;
+    }
+    static constexpr int COUNT = base(LINKS);
+};
+
+template <int NJ, int LINKS, uint32_t MASK_KIN, uint32_t MASK_DYN, class MIXED>
+__device__ __forceinline__ void rnea_backward_arm_param_static_body(const float *__restrict__ ops_f, const float *__restrict__ q,
+                                                                    const float *__restrict__ qd, const float *__restrict__ qdd,
+                                                                    const float *__restrict__ gtau, int n_tiles, int flags,
+                                                                    float *__restrict__ gq, float *__restrict__ gqd,
+                                                                    float *__restrict__ gqdd, float *__restrict__ partials) {
+    static_assert(NJ & 1, "odd row width (linear LDS image)");
+    constexpr int CAP = 8, C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), PER_WAVE = C_FLOATS + 3 * Q_FLOATS;
+    constexpr int NV = CAP * DRM_OPF_STRIDE;
+    using Slots = ParamSlots<LINKS, MASK_KIN, MASK_DYN>;
+    constexpr int NSUM = Slots::COUNT;
+    static_assert(NSUM > 0 && NSUM <= 8 * 26, "at least one learnable block");
+    __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave_id = (int)blockIdx.x * MAX_WAVES_PER_BLOCK + wave, n_waves = (int)gridDim.x * MAX_WAVES_PER_BLOCK;
+    float *lc = smem + wave * PER_WAVE;
+    float *lq = lc + C_FLOATS, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS;
+    {
+        float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];      // this launch's table: only the live blocks are read back
+        pin(cv);
+        reinterpret_cast<float4 *>(lc)[lane] = cv;
+    }
+    wave_lds_sync();
+    float psum[NSUM];
+#pragma unroll
+    for (int j = 0; j < NSUM; ++j) psum[j] = 0.0f;
+    const MIXED row{lc};
+    constexpr uint64_t MASK = (uint64_t)(MASK_KIN | MASK_DYN);
+
+    for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        float qv[NJ], qdv[NJ], qddv[NJ], gtv[NJ];
+        lane_row<NJ>(q, b0 + lane, qv);
+        lane_row<NJ>(qd, b0 + lane, qdv);
+        if (qdd) lane_row<NJ>(qdd, b0 + lane, qddv);
+        else {
+#pragma unroll
+            for (int d = 0; d < NJ; ++d) qddv[d] = 0.0f;
+        }
+        lane_row<NJ>(gtau, b0 + lane, gtv);
+        wave_lds_sync(); // the previous tile's staged gradients have left the LDS tiles
+        rnea_backward_chain<LINKS, NJ>(
+            row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, MASK, gq != nullptr, qv, qdv, qddv, gtv,
+            [&](int d, float a, float v, float c) {
+                lq[lane * NJ + d] = a; lqd[lane * NJ + d] = v; lqdd[lane * NJ + d] = c;
+            },
+            [&](int k, const float *g) {      // (k is a constant of the unrolled walk: every index below folds)
+                int at = Slots::base(k);
+                if ((MASK_KIN >> k) & 1u) {
+#pragma unroll
+                    for (int j = 0; j < Slots::KIN; ++j) psum[at + j] += g[j];
+                    at += Slots::KIN;
+                }
+                if ((MASK_DYN >> k) & 1u) {
+#pragma unroll
+                    for (int j = 0; j < Slots::DYN; ++j) psum[at + j] += g[DRM_OPF_FT_FLOATS + j];
+                }
+            });
+        if (gq) {
+            wave_lds_sync();
+            tile_store<NJ>(gq + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
+            tile_store<NJ>(gqd + b0 * NJ, WAVE, NJ, 0u, lqd, lane, true);
+            tile_store<NJ>(gqdd + b0 * NJ, WAVE, NJ, 0u, lqdd, lane, true);
+        }
+    }
+    // this wavefront's row of partial sums: zeros, the live entries summed over its 64 lanes — assembled in LDS (over the table,
+    // which is dead now), written as one coalesced row
+    wave_lds_sync();
+    reinterpret_cast<float4 *>(lc)[lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < LINKS; ++k) {
+        int at = Slots::base(k);
+        if ((MASK_KIN >> k) & 1u) {
+#pragma unroll
+            for (int j = 0; j < Slots::KIN; ++j) {
+                const float total = wave_sum_lane63(psum[at + j]);
+                if (lane == 63u) lc[k * DRM_OPF_STRIDE + j] = total;
+            }
+            at += Slots::KIN;
+        }
+        if ((MASK_DYN >> k) & 1u) {
+#pragma unroll
+            for (int j = 0; j < Slots::DYN; ++j) {
+                const float total = wave_sum_lane63(psum[at + j]);
+                if (lane == 63u) lc[k * DRM_OPF_STRIDE + DRM_OPF_FT_FLOATS + j] = total;
+            }
+        }
+    }
+    wave_lds_sync();
+    reinterpret_cast<float4 *>(partials + (int64_t)wave_id * NV)[lane] = reinterpret_cast<const float4 *>(lc)[lane];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Forward kinematics of 2 .. 4 disjoint serial chains (the fingertips of a hand, BASELINE configuration 4) with link-major outputs
 // (drm_fk_fanout_links: pos [T, B, 3], quat [T, B, 4]), one wavefront per chain and 64-row tile — the layout of
 // csrc/drm_chain_kernels.hip fk_fan_chain_kernel<.., LINKS = true> — with every chain's constants folded into the instruction stream.

@@ -587,7 +587,17 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
                                          param_mask, grad_q + done * n, grad_qd + done * n, grad_qdd + done * n, grad_ops_f, scratch, stream);
             }
             const int waves_a = backward_waves(done, MAX_WAVES_PER_BLOCK);
-            if (arm_links(w) == 7)
+            if (w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM_PARAM] && param_mask != 0 && param_mask == (uint64_t)w->reserved0) {
+                // ABI 11: this arm's own reverse-mode kernel for exactly this set of learnable blocks (csrc/drm_arm_static.hpp
+                // rnea_backward_arm_param_static_body, specialize.py): the constant blocks of the table folded into the instruction
+                // stream, the learnable ones read from ops_f; same rows of partial sums, same reduction below
+                int fl = (int)flags;
+                void *args[] = {(void *)&w->ops_f, (void *)&q, (void *)&qd, (void *)&qdd, (void *)&grad_tau, (void *)&n_tiles, (void *)&fl,
+                                (void *)&grad_q, (void *)&grad_qd, (void *)&grad_qdd, (void *)&partials};
+                hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM_PARAM],
+                                                     (unsigned)(waves_a / MAX_WAVES_PER_BLOCK), 1, 1, WAVE * MAX_WAVES_PER_BLOCK, 1, 1, 0, s, args, nullptr);
+                if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_backward_arm_param_static): %s", hipGetErrorString(e));
+            } else if (arm_links(w) == 7)
                 hipLaunchKernelGGL((rnea_backward_arm_kernel<8, 7, 7>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                    dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, qd, qdd, grad_tau, n_tiles, (int)flags,
                                    param_mask, grad_q, grad_qd, grad_qdd, partials);

@@ -2069,6 +2069,13 @@ DRM_HD bool rnea_backward_walk_short(const float *__restrict__ opf, const int32_
 // kernel runs at two or three waves per SIMD instead of one (the earlier form kept tot[CAP][6] and tbar[CAP][6] in registers:
 // 256 VGPR + 180 AGPR).
 //   row(k) -> op k's constant row;   gout(d, gq, gqd, gqdd);   param_out(k, g[DRM_OPF_STRIDE]) for ops in param_mask
+// op k's F / t block: `row.ft(k)` when the row source tells kinematic constants from dynamic ones (the per-robot kernels of a model
+// with learnable DYNAMIC parameters, csrc/drm_arm_static.hpp: F / t stay compile-time constants while mass / mcom / I_o come from
+// this launch's table), else the start of `row(k)`
+template <class ROW> DRM_HD auto row_ft_of(ROW &row, int k, int) -> decltype(row.ft(k)) { return row.ft(k); }
+template <class ROW> DRM_HD const float *row_ft_of(ROW &row, int k, long) { return row(k); }
+template <class ROW> DRM_HD const float *row_ft(ROW &row, int k) { return row_ft_of(row, k, 0); }
+
 template <int CAP, int NJ, class ROW, class GOUT, class PG>
 DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint64_t param_mask, bool want_gq,
                                 const float (&q)[NJ], const float (&qd)[NJ], const float (&qdd)[NJ],
@@ -2077,7 +2084,7 @@ DRM_HD void rnea_backward_chain(ROW row, bool gravity, bool damping, uint64_t pa
     chain_trig<NJ>(q, cs, sn);
     const float g = gravity ? 9.81f : 0.0f;
     auto joint = [&](int k, float *J, float *t) {
-        const OpFT o = load_ft(row(k));
+        const OpFT o = load_ft(row_ft(row, k));
         if (k < NJ) {
             joint_rot_z(o.F, cs[k], sn[k], J);
         } else {

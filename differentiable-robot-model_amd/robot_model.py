@@ -375,8 +375,10 @@ class DifferentiableRobotModel(torch.nn.Module):
             # robot's constants folded into the instruction stream (specialize.attach_arm, csrc/drm_arm_stream.hpp).  Inverse
             # dynamics now; the fused FK + RNEA kernel of a target link when plan_fk_and_inverse_dynamics /
             # compute_fk_and_inverse_dynamics first meets it.  Constant models only (the kernels do not read the table).
-            if self._learnable:
-                return False
+            if self._learnable:      # the reverse-mode kernel of this set of learnable blocks (the constant blocks folded in)
+                kin, dyn = self._learnable_block_masks(dw)
+                sp.attach_arm_param(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs, kin, dyn)
+                return True
             self._arm_specialized = True
             sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs)
             return True
@@ -458,6 +460,11 @@ class DifferentiableRobotModel(torch.nn.Module):
                         sp.attach_arm(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs, cached_only=auto)   # (constants folded in)
                         for what in dw.program._special_missed:
                             self._own_kernel_miss(what, sp.CacheMiss("not in the cache"))
+                    else:
+                        # learnable link parameters: the reverse-mode kernel of THIS set of learnable blocks — every other block of
+                        # the table is still a constant of the robot and folds into the instruction stream (round 6)
+                        kin, dyn = self._learnable_block_masks(dw)
+                        sp.attach_arm_param(dw.program, self._ops_f(dw).detach().cpu().numpy(), self._n_dofs, kin, dyn, cached_only=auto)
                 elif not dw.program.shape & (SHAPE_ARM_CHAIN | SHAPE_ARM_HAND | SHAPE_FINGERS):
                     if dw.program.n_ops <= sp.MAX_STATIC_OPS:
                         sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), cached_only=auto)
@@ -1076,6 +1083,19 @@ class DifferentiableRobotModel(torch.nn.Module):
         raise NotImplementedError("iterative_newton_euler is an internal step of the reference's per-link recursion; "
                                   "call compute_inverse_dynamics / compute_non_linear_effects")
 
+    def _learnable_block_masks(self, dw) -> Tuple[int, int]:
+        """(kinematic, dynamic): bit k set <=> op k's F / t block (`trans`, `rot_angles`) / its mass - mcom - I_o - damping block
+        (`mass`, `com`, `inertia_mat`, `joint_damping`) comes from a learnable parametrisation."""
+        kin_links = {link for link, pname in self._learnable if pname in ("trans", "rot_angles")}
+        dyn_links = {link for link, pname in self._learnable if pname not in ("trans", "rot_angles")}
+        kin = dyn = 0
+        for k, link in enumerate(dw.program.links):
+            if int(link) in kin_links:
+                kin |= 1 << k
+            if int(link) in dyn_links:
+                dyn |= 1 << k
+        return kin, dyn
+
     def _learnable_op_mask(self, dw) -> int:
         """Bit k set <=> op k of the walk belongs to a link with a learnable parameter (param_mask of the backward kernels)."""
         links = {link for link, _ in self._learnable}
@@ -1211,15 +1231,15 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable_links = None
         for dw in self._walks.values():
             dw.static_ops_f = None
-            special = getattr(dw.program, "_special", None)
-            if special and (any(k >= 4 for k in special) or getattr(dw.program, "_special_const", False)):
-                # kernels that carry the walk table as compile-time constants (specialize.attach_arm / attach_fan; attach(table=...))
-                # bake the OLD constants: dropped — specialize() again builds the table-reading kind
-                baked = getattr(dw.program, "_special_const", False)
-                dw.program._special = {} if baked else {k: v for k, v in special.items() if k < 4}
-                dw.program._special_const = False
-                dw.program._special_tried = False
-                dw.program._ws_cache = None
+            special = getattr(dw.program, "_special", None) or {}
+            # kernels that carry the walk table as compile-time constants (specialize.attach_arm / attach_fan / attach_arm_param;
+            # attach(table=...)) bake the OLD constants or the OLD set of learnable blocks: dropped — the next call looks again
+            baked = getattr(dw.program, "_special_const", False)
+            dw.program._special = {} if baked else {k: v for k, v in special.items() if k < 4}
+            dw.program._special_const = False
+            dw.program._special_tried = False
+            dw.program._special_mask = 0
+            dw.program._ws_cache = None
         self._arm_specialized = False
         self._fast_fk.clear(); self._fast_jac.clear(); self._fast_fkid.clear()    # (prepared calls snapshot the constants)
         self._fast_id = self._fast_crba = self._fast_fd = None

@@ -36,6 +36,10 @@ ARM_KERNELS = {SPECIAL_RNEA_ARM: "drm_rnea_arm_static", SPECIAL_FK_RNEA_ARM: "dr
 ARM_DYNAMICS = (SPECIAL_CRBA_ARM, SPECIAL_FD_ARM, SPECIAL_RNEA_BACKWARD_ARM)
 SPECIAL_FK_FAN_LINKS = 9
 FAN_KERNEL = "drm_fk_fan_links_static"
+# (ABI 11) reverse-mode inverse dynamics of a serial arm WITH learnable link parameters: the constant blocks of the table folded in
+SPECIAL_RNEA_BACKWARD_ARM_PARAM = 11
+ARM_PARAM_KERNEL = "drm_rnea_backward_arm_param_static"
+FT_FLOATS, DAMP_INDEX = 12, 25        # include/drm_hip.h DRM_OPF_FT_FLOATS, DRM_OPF_DAMP: [0, 12) = F / t, [12, 26) = mass, mcom, I_o, damping
 ARM_KINDS = tuple(ARM_KERNELS)
 # (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
 # folds only a tenth of its instructions and the launch is bound by its loads and its store drain, profiles/r05_metric_static.txt.)
@@ -260,6 +264,12 @@ def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> li
                     both = table.copy()
                     both[links:] = m._ops_f(chain).detach().numpy()[links:]
                     built.append(build(arm_source(both, links, True), ARM_FLAGS))
+            if arm_qualifies(dw.program, m._n_dofs):
+                # ... and the reverse-mode kernels of the arm WITH learnable dynamic parameters (round 6): mass, com and inertia_mat of
+                # all moving links (examples/learn_dynamics_iiwa.py) and of every single one of them (identification of one link / a payload)
+                moving = [m._bodies[i].name for i in m._controlled_joints]
+                for names in [moving] + [[name] for name in moving]:
+                    built.append(build(learnable_arm_source(robot, names, ("mass", "com", "inertia_mat")), ARM_FLAGS))
             tips = sorted(m._name_to_idx_map[name] for name in SHIPPED_FANS.get(robot, []))     # (_fk_links launches in link order)
             if 2 <= len(tips) <= 4:
                 merged = m._get_walk(("fk", tuple(tips)), targets=tips)
@@ -273,6 +283,29 @@ def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> li
         else:
             os.environ["DRM_SPECIAL_CACHE"] = before
     return [os.path.basename(b) for b in built]
+
+
+def learnable_arm_source(robot: str, link_names, parameter_names) -> str:
+    """The reverse-mode translation unit `model.specialize()` / the default look-up would ask for when the named parameters of the
+    named links of a shipped arm are learnable: a host model with those parameters learnable, its dynamics walk, its block masks."""
+    import contextlib
+    import io
+
+    import torch
+
+    from .rigid_body_params import UnconstrainedTensor
+    from .robot_model import DifferentiableRobotModel, robot_description_folder
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DifferentiableRobotModel(os.path.join(robot_description_folder, robot + ".urdf"), device="cpu")
+    shapes = {"mass": (1, 1), "com": (1, 3), "inertia_mat": (3, 3), "trans": (1, 3), "rot_angles": (1, 3), "joint_damping": (1, 1)}
+    for link in link_names:
+        for pname in parameter_names:
+            m.make_link_param_learnable(link, pname, UnconstrainedTensor(dim1=shapes[pname][0], dim2=shapes[pname][1]))
+    dw = m._dynamics_walk()
+    kin, dyn = m._learnable_block_masks(dw)
+    with torch.no_grad():
+        table = m._ops_f(dw).detach().numpy()
+    return arm_param_backward_source(table, dw.program.n_ops, kin, dyn)
 
 
 def hipcc() -> Optional[str]:
@@ -450,6 +483,57 @@ extern "C" __global__ void __launch_bounds__(64) drm_rnea_backward_arm_static(co
     drm::rnea_backward_arm_static_body<7, %d>(drm::RobotRow(), q, qd, qdd, gtau, n_tiles, flags, gq, gqd, gqdd);
 }
 """ % (rows, links, links, links)
+
+
+def arm_param_backward_source(table, links: int, mask_kin: int, mask_dyn: int) -> str:
+    """The translation unit of one serial 7-DoF arm's reverse-mode inverse dynamics for ONE set of learnable blocks: `table` = the
+    [8, 32] walk table of the model (the learnable blocks are written as zeros — their values come from the launch's ops_f, and a
+    parameter update must not change the source key), bit k of `mask_kin` / `mask_dyn`: op k's F / t block / its mass, mcom, I_o,
+    damping block is learnable (csrc/drm_arm_static.hpp rnea_backward_arm_param_static_body)."""
+    import numpy as np
+    table = np.array(table, np.float32, copy=True)
+    if table.shape != (8, 32) or links not in (7, 8):
+        raise SpecializeError("arm kernels are built for walks of capacity 8 with 7 or 8 dynamics ops")
+    if not (mask_kin | mask_dyn) or (mask_kin | mask_dyn) >> links:
+        raise SpecializeError("the learnable blocks must belong to the walk's %d ops" % links)
+    for k in range(8):
+        if (mask_kin >> k) & 1:
+            table[k, :FT_FLOATS] = 0.0
+        if (mask_dyn >> k) & 1:
+            table[k, FT_FLOATS:DAMP_INDEX + 1] = 0.0
+    rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in table)
+    return """// generated by differentiable-robot-model_amd/specialize.py — a serial arm with learnable link parameters: the constant blocks of its walk
+// table as compile-time constants, the learnable ones (kinematic 0x%x, dynamic 0x%x) read from the launch's table
+#include "drm_arm_static.hpp"
+namespace drm {
+static __device__ constexpr float ROBOT_OPS[8 * DRM_OPF_STRIDE] = {
+%s};
+struct RobotRowMixed {
+    const float *live;      // this launch's table (LDS)
+    static constexpr uint32_t KIN = 0x%xu, DYN = 0x%xu;
+    __device__ const float *operator()(int k) const { return ((DYN >> k) & 1u) ? live + k * DRM_OPF_STRIDE : ROBOT_OPS + k * DRM_OPF_STRIDE; }
+    __device__ const float *ft(int k) const { return ((KIN >> k) & 1u) ? live + k * DRM_OPF_STRIDE : ROBOT_OPS + k * DRM_OPF_STRIDE; }
+};
+}
+extern "C" __global__ void __launch_bounds__(256) %s(
+    const float *ops_f, const float *q, const float *qd, const float *qdd, const float *gtau, int n_tiles, int flags, float *gq, float *gqd,
+    float *gqdd, float *partials) {
+    drm::rnea_backward_arm_param_static_body<7, %d, drm::RobotRowMixed::KIN, drm::RobotRowMixed::DYN, drm::RobotRowMixed>(
+        ops_f, q, qd, qdd, gtau, n_tiles, flags, gq, gqd, gqdd, partials);
+}
+""" % (mask_kin, mask_dyn, rows, mask_kin, mask_dyn, ARM_PARAM_KERNEL, links)
+
+
+def attach_arm_param(tree: WalkProgram, tree_table, n_dofs: int, mask_kin: int, mask_dyn: int, cached_only: bool = False) -> int:
+    """Build (cached) and attach the reverse-mode kernel of a serial 7-DoF arm with THIS set of learnable blocks; the C ABI runs it
+    when a call's param_mask equals `mask_kin | mask_dyn` (stored in drm_walk.reserved0).  Returns the handle."""
+    if not arm_qualifies(tree, n_dofs):
+        raise SpecializeError("not a serial 7-DoF arm walk of capacity 8")
+    handle = _load(build(arm_param_backward_source(tree_table, tree.n_ops, mask_kin, mask_dyn), ARM_FLAGS, cached_only), ARM_PARAM_KERNEL)
+    special = dict(getattr(tree, "_special", None) or {})
+    special[SPECIAL_RNEA_BACKWARD_ARM_PARAM] = handle
+    tree._special, tree._special_mask, tree._ws_cache = special, mask_kin | mask_dyn, None
+    return handle
 
 
 def fan_chain(prog: WalkProgram, n_dofs: int) -> Optional[dict]:

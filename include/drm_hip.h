@@ -73,6 +73,13 @@ extern "C" {
  * launches, as before (the reference's counterpart is autograd's accumulation, robot_model.py:669-713 + examples/
  * learn_kinematics_of_iiwa.py:47-55). */
 #define DRM_WALK_TICKET 10
+/* ABI 11: a serial 7-DoF arm WITH learnable link parameters (the learn-dynamics workload): drm_rnea_backward's kernel for exactly
+ * the set of learnable blocks `drm_walk.reserved0` names (bit k: op k has a learnable parameter; the host built the kernel for
+ * that set and for the split into kinematic / dynamic blocks its model has) — the constant blocks of the table are compile-time
+ * constants of the kernel, the learnable ones are read from ops_f.  Kernel "drm_rnea_backward_arm_param_static", arguments ops_f,
+ * q, qd, qdd, grad_tau, n_tiles, flags, grad_q, grad_qd, grad_qdd, partials; launched with 256-thread blocks, the library's rows of
+ * partial sums.  Used when the call's param_mask equals reserved0. */
+#define DRM_SPECIAL_RNEA_BACKWARD_ARM_PARAM 11
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
@@ -217,7 +224,7 @@ typedef struct drm_walk {
     uint8_t chain_dof1[16];   /* DRM_WALK_CHAIN_DOFS: 1 + the DoF column op k reads, 0 for an op that does not move (fixed joint,
                                  padding) — what DRM_OPI_W0 says, for the first 16 ops of a serial chain */
     uint32_t chain_prismatic; /* DRM_WALK_CHAIN_DOFS: bit k set <=> op k slides */
-    uint32_t reserved0;
+    uint32_t reserved0;       /* ABI 11: the param_mask special[DRM_SPECIAL_RNEA_BACKWARD_ARM_PARAM] was built for (else 0) */
     /* ABI 9: per-robot STRAIGHT-LINE kernels for THIS walk (a whole-tree dynamics walk of any shape), or NULL.  Handles from
      * drm_special_load() of a code object the host built from csrc/drm_static.hpp instantiated on this walk's tree
      * (differentiable-robot-model_amd/specialize.py writes and compiles it: ~2 s with hipcc, cached).  When set, the full
