@@ -72,11 +72,13 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step (metric config)")
     ap.add_argument("--robot", default="panda_no_gripper", choices=sorted(EE_LINK))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--gather", nargs="?", const="all", default=None, choices=["none", "all", "root", "tau"],
+    ap.add_argument("--gather", nargs="?", const="all", default=None, choices=["none", "all", "root", "tau", "p2p"],
                     help="what a step exchanges over RCCL.  metric config: `--gather` = all-gather the outputs inside every step "
                          "(default: nothing).  --config 3: which mode the headline `value` is timed with — none (default: the "
                          "outputs stay sharded, the MPC / particle case), all (every rank gets tau | pos | quat of every row), root "
-                         "(rank 0 only), tau (all-gather of the torques only); every mode is timed and reported under gather_modes")
+                         "(rank 0 only), tau (all-gather of the torques only), p2p (as all, ONE-SIDED: the fused kernel's epilogue writes "
+                         "every tile into the peers' gathered arrays over xGMI while the walk runs — drm_fk_rnea_put, "
+                         "distributed.PeerGather; no collective launch, no second pass); every mode is timed and reported under gather_modes")
     ap.add_argument("--library-kernels", action="store_true",
                     help="--config 3: time the library's table-driven kernels instead of the robot's own constant-folded ones "
                          "(model.specialize(), the default when hipcc is on the machine)")
@@ -734,6 +736,19 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     gathered_tau = torch.empty(world * rows * n, device=device) if world > 1 else None
     headline = args.gather or "none"
 
+    # the one-sided gather (round 6): every rank owns the gathered arrays of the whole batch, the handles are exchanged ONCE, and
+    # the launch itself writes this rank's rows into its own arrays and into the peers' (drm_fk_rnea_put)
+    peer, plan_put = None, None
+    if world > 1:
+        from differentiable_robot_model_amd.distributed import PeerGather
+        try:
+            peer = PeerGather(G, n, device, mode="all")
+            assert (peer.lo, peer.hi) == (lo, hi)
+            plan_put = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link, outputs=peer.outputs(), put=peer.put())
+        except Exception as err:       # noqa: BLE001  (no IPC on this stack: the collective modes stay)
+            peer, plan_put, p2p_why = None, None, "%s: %s" % (type(err).__name__, str(err)[:160])
+            print("bench.py: one-sided gather unavailable (%s)" % p2p_why, file=sys.stderr)
+
     def exchange(mode):
         if world <= 1 or mode == "none":
             return
@@ -745,6 +760,9 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
             gather_flat(gathered, flat, dst=0)
 
     def step_of(mode):
+        if mode == "p2p":
+            return plan_put.launch          # (compute and exchange are ONE launch)
+
         def step():
             compute()
             exchange(mode)
@@ -757,18 +775,22 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
     # the compute of a step alone (graph of K launches), then the full step of every exchange mode (compute + collective)
     _, dev_compute, _ = timed_graph_region(compute, K, stream, barrier, use_graph=not args.no_graph)
     modes = {}
-    for mode in (["none"] if world == 1 else ["none", "tau", "root", "all"]):
+    if headline == "p2p" and plan_put is None:
+        sys.exit("bench.py --gather p2p: the one-sided gather needs IPC-mapped peer buffers (%s)" % ("one rank" if world == 1 else "see stderr"))
+    for mode in (["none"] if world == 1 else ["none", "tau", "root", "all"] + (["p2p"] if plan_put is not None else [])):
         fn = step_of(mode)
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
         # (a step with a collective is launched eagerly: RCCL under stream capture has never run on this stack — no multi-GPU
         # node, and RCCL refuses two ranks on one device — so there is no switch for it)
-        w_, d_, graphed = timed_graph_region(fn, K, stream, barrier, use_graph=mode == "none" and not args.no_graph)
+        w_, d_, graphed = timed_graph_region(fn, K, stream, barrier, use_graph=mode in ("none", "p2p") and not args.no_graph)
         w_, d_ = reduce_max([w_, d_])
         modes[mode] = {"ms_per_step": w_ / K * 1e3, "value": G * K / w_, "step_us_device": d_ / K * 1e6, "hipgraph": bool(graphed),
                        "gather_bytes_per_rank": 0 if mode == "none" else rows * 4 * (n if mode == "tau" else width),
                        "gather_model_us": gather_model_us(mode, rows * width * 4, rows * n * 4, world)}
+        if mode == "p2p":      # the puts ride on the walk: a step should take max(compute, one block over one link), not their sum
+            modes[mode]["one_sided"] = True
     wall, dev_time = modes[headline]["ms_per_step"] * K * 1e-3, modes[headline]["step_us_device"] * K * 1e-6
     (dev_compute,) = reduce_max([dev_compute])
     verified, vs_whole = None, None
@@ -816,6 +838,18 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
         torch.cuda.synchronize()
         if rank == 0:
             ok &= blocks_ok()
+        if plan_put is not None:
+            # the one-sided gather: every rank's arrays hold ALL rows after its peers' launches have completed (synchronize + barrier)
+            for t in peer.gathered():
+                t.zero_()
+            torch.cuda.synchronize()
+            barrier()
+            plan_put.launch()
+            torch.cuda.synchronize()
+            barrier()
+            if rank == 0:
+                for got, want in zip(peer.gathered(), (tau_w, pos_w, quat_w)):
+                    ok &= int(torch.equal(got, want.reshape(got.shape)))
         verified = bool(ok)
     bytes_per_eval = 4 * (3 * n + n + 7)                                 # q qd qdd in; tau pos quat out = 140 B
     launch_s = dev_compute / K
@@ -866,6 +900,12 @@ def run_config3(args, model, link, device, world, rank, ranks_seen, stream, barr
                      "note": "the fused kernel alone (hipGraph of K launches, HIP events); RNEA sits at the vector-FP32 / HBM "
                              "ridge (2.6 kflop per 140 B), see DESIGN.md"},
     }
+    if peer is not None:
+        line["one_sided_gather"] = {"in_kernel": bool(own_kernel) and rows >= 1024 * 128,
+                                    "note": "drm_fk_rnea_put: the arm's own fused kernel stores every tile to the peers' gathered arrays "
+                                            "(IPC-mapped) from its epilogue; launches below 131 072 rows / walks without that kernel "
+                                            "compute first and copy on the stream"}
+        peer.close()
     if cpu is not None:
         line["cpu_baseline"] = cpu
         ref = cpu.get("reference", cpu)

@@ -38,7 +38,16 @@ class DrmWalk(ctypes.Structure):
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
                 ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
-                ("special", ctypes.c_void_p * 12)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
+                ("special", ctypes.c_void_p * 16)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
+
+
+MAX_PEERS = 8
+
+
+class DrmPut(ctypes.Structure):
+    """Mirror of ``struct drm_put`` (include/drm_hip.h, ABI 11): the destination sets of drm_fk_rnea_put's one-sided gather."""
+    _fields_ = [("n_peers", ctypes.c_int32), ("reserved", ctypes.c_int32), ("row_offset", ctypes.c_int64),
+                ("tau", ctypes.c_void_p * MAX_PEERS), ("pos", ctypes.c_void_p * MAX_PEERS), ("quat", ctypes.c_void_p * MAX_PEERS)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -54,7 +63,7 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats", "drm_rnea_scratch_floats_aligned",
-           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load")
+           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load", "drm_fk_rnea_put")
 
 
 def library_for(device):
@@ -140,6 +149,8 @@ def load_library(path: str = None, kind: str = "cuda"):
         lib.drm_crba_scratch_floats.argtypes = [wp, i64]
         lib.drm_fk_rnea.restype = ctypes.c_int
         lib.drm_fk_rnea.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp]
+        lib.drm_fk_rnea_put.restype = ctypes.c_int
+        lib.drm_fk_rnea_put.argtypes = [wp, wp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, ctypes.POINTER(DrmPut), vp]
         for name in ("drm_rnea_scratch_floats_aligned", "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned"):
             getattr(lib, name).restype = i64
             getattr(lib, name).argtypes = [wp, i64]
@@ -816,8 +827,10 @@ class FkInverseDynamicsPlan(object):
     configuration 3 (bench.py --config 3) runs it on every GPU's shard."""
 
     def __init__(self, tree, chain, target_op: int, q, qd, qdd, include_gravity: bool, use_damping: bool, n_dofs: int,
-                 outputs=None):
+                 outputs=None, put=None):
         # tree / chain: (WalkProgram, ops_f, ops_i) of the whole-tree walk and of the root -> link walk
+        # put: a DrmPut (distributed.PeerGather.put()) — every launch also writes its rows into the peers' gathered arrays
+        # (drm_fk_rnea_put: the one-sided gather of a batch sharded over the GPUs of a node)
         self._lib = _lib_of(q, "q", tree[1])
         self.q, self.qd = _plan_input(q, "q", n_dofs), _plan_input(qd, "qd", n_dofs)
         self.qdd = _plan_input(qdd, "qdd", n_dofs) if qdd is not None else None
@@ -845,9 +858,13 @@ class FkInverseDynamicsPlan(object):
                       self.tau.data_ptr(), self.pos.data_ptr(), self.quat.data_ptr(),
                       self._scratch.data_ptr() if self._scratch is not None else None)
         self.batch, self.device = B, dev
+        self._put = put
 
     def launch(self, stream=None):
-        rc = self._lib.drm_fk_rnea(*self._args, _plan_stream(stream, self.device))
+        if self._put is not None:
+            rc = self._lib.drm_fk_rnea_put(*self._args, ctypes.byref(self._put), _plan_stream(stream, self.device))
+        else:
+            rc = self._lib.drm_fk_rnea(*self._args, _plan_stream(stream, self.device))
         if rc != 0:
             _check(rc, self._lib)
 

@@ -37,10 +37,13 @@ __device__ __forceinline__ void rows_from_lds(const float *st, unsigned lane, f2
 // ROWS: rows() is called once per tile and returns row(k) -> const float * (op k's constant row).
 // smem: [ tau / pos staging : round4(STREAM_TILE * NJ) ][ next rows : 3 * STREAM_TILE * NJ ] floats of LDS, 16-byte aligned.
 //   table(): run once, after the first tile's loads have been issued.
-template <int CAP, int NJ, int LINKS, bool FK, bool PREF, class TABLE, class ROWS>
+// PUT (ABI 11, drm_fk_rnea_put): every output tile is ALSO stored to the destination sets of `put` at row put->row_offset + b0 — the
+// gathered arrays of the other GPUs of the node (peer memory over xGMI), as the tile leaves the wavefront: the one-sided gather of
+// a sharded batch rides on the walk instead of following it as a collective.
+template <int CAP, int NJ, int LINKS, bool FK, bool PREF, bool PUT = false, class TABLE, class ROWS>
 __device__ __forceinline__ void arm2_stream_body(TABLE table, ROWS rows, float *smem, const float *__restrict__ q, const float *__restrict__ qd,
                                                  const float *__restrict__ qdd, int n_tiles, int flags, float *__restrict__ tau,
-                                                 float *__restrict__ pos, float *__restrict__ quat) {
+                                                 float *__restrict__ pos, float *__restrict__ quat, const drm_put *put = nullptr) {
     constexpr int T_FLOATS = round4(STREAM_TILE * NJ), ROWS_F = STREAM_TILE * NJ;
     static_assert(STREAM_TILE * 3 <= T_FLOATS && ROWS_F % 4 == 0, "the position tile fits into the staging area; 16-byte aligned arrays");
     const unsigned lane = threadIdx.x;
@@ -87,13 +90,22 @@ __device__ __forceinline__ void arm2_stream_body(TABLE table, ROWS rows, float *
             }
             wave_lds_sync();
             tile_store<6>(pos + b0 * 3, WAVE, 6, 0u, lt, lane, true); // 128 rows of 3 floats
+            if constexpr (PUT) {
+                for (int p = 0; p < put->n_peers; ++p)
+                    if (put->pos[p]) tile_store<6>(put->pos[p] + (put->row_offset + b0) * 3, WAVE, 6, 0u, lt, lane, true);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float R[9], qt[4];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) R[i] = ee.R[i][h];
                 quat_xyzw(R, qt);
-                store16_wt(quat + (b0 + h * WAVE + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+                const float4 qv4 = make_float4(qt[0], qt[1], qt[2], qt[3]);
+                store16_wt(quat + (b0 + h * WAVE + lane) * 4, qv4);
+                if constexpr (PUT) {
+                    for (int p = 0; p < put->n_peers; ++p)
+                        if (put->quat[p]) store16_wt(put->quat[p] + (put->row_offset + b0 + h * WAVE + lane) * 4, qv4);
+                }
             }
         }
         // inverse dynamics (robot_model.py:305-375); nothing parked: KEEP2 = LINKS - 1
@@ -111,6 +123,10 @@ __device__ __forceinline__ void arm2_stream_body(TABLE table, ROWS rows, float *
         unstage(); // the next tile's rows into the (now dead) input registers — after the last tile: stale rows nobody uses
         wave_lds_sync();
         tile_store<2 * NJ>(tau + b0 * NJ, WAVE, 2 * NJ, 0u, lt, lane, true);
+        if constexpr (PUT) {
+            for (int p = 0; p < put->n_peers; ++p)
+                if (put->tau[p]) tile_store<2 * NJ>(put->tau[p] + (put->row_offset + b0) * NJ, WAVE, 2 * NJ, 0u, lt, lane, true);
+        }
         if (!more) break;
         tile = next;
     }

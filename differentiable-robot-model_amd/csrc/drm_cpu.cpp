@@ -199,6 +199,22 @@ int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t, const floa
     return DRM_OK;
 }
 
+// ABI 11: the host build of the one-sided gather — the destinations are host arrays (e.g. shared-memory tensors of the other ranks)
+int drm_fk_rnea_put(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd, const float *qdd,
+                    int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch, const drm_put *put, void *stream) {
+    if (put && (put->n_peers < 0 || put->n_peers > DRM_MAX_PEERS || put->row_offset < 0))
+        return fail(DRM_ERR_INVALID, "drm_put: n_peers must be 0 .. DRM_MAX_PEERS and row_offset >= 0");
+    if (int rc = drm_fk_rnea(tree, chain, target_op, q, qd, qdd, B, flags, tau, pos, quat, scratch, stream)) return rc;
+    if (!put || B == 0) return DRM_OK;
+    const int n = tree->n_dofs;
+    for (int p = 0; p < put->n_peers; ++p) {
+        if (put->tau[p]) memcpy(put->tau[p] + put->row_offset * n, tau, sizeof(float) * (size_t)B * n);
+        if (put->pos[p]) memcpy(put->pos[p] + put->row_offset * 3, pos, sizeof(float) * (size_t)B * 3);
+        if (put->quat[p]) memcpy(put->quat[p] + put->row_offset * 4, quat, sizeof(float) * (size_t)B * 4);
+    }
+    return DRM_OK;
+}
+
 int drm_crba(const drm_walk *w, const float *q, int64_t B, float *H, float *, void *) {
     if (int rc = check_walk(w)) return rc;
     if (B < 0 || !q || !H) return fail(DRM_ERR_INVALID, "bad batch or NULL q / H");

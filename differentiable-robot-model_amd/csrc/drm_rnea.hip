@@ -359,3 +359,61 @@ extern "C" int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t 
     if (rc) return rc;
     return drm_rnea(tree, q, qd, qdd, B, flags, tau, scratch, stream);
 }
+
+// ABI 11: drm_fk_rnea with a one-sided gather of its outputs (include/drm_hip.h drm_put).  The in-kernel form: the arm's own fused
+// kernel with the destinations in its argument block (csrc/drm_arm_stream.hpp PUT) covers the 128-row tile pairs of a launch of at
+// least DRM_ARM_STATIC_MIN_PAIRS pairs; everything else is computed by drm_fk_rnea and copied on the stream.
+extern "C" int drm_fk_rnea_put(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
+                               const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch,
+                               const drm_put *put, void *stream) {
+    if (!put || put->n_peers == 0) return drm_fk_rnea(tree, chain, target_op, q, qd, qdd, B, flags, tau, pos, quat, scratch, stream);
+    if (put->n_peers < 0 || put->n_peers > DRM_MAX_PEERS || put->row_offset < 0)
+        return fail(DRM_ERR_INVALID, "drm_put: n_peers must be 0 .. DRM_MAX_PEERS and row_offset >= 0");
+    int rc = check_walk(tree);
+    if (rc) return rc;
+    rc = check_walk(chain);
+    if (rc) return rc;
+    if (!q || !qd || !tau || !pos || !quat) return fail(DRM_ERR_INVALID, "q / qd / tau / pos / quat must not be NULL");
+    if (B < 0) return fail(DRM_ERR_INVALID, "negative batch");
+    if (tree->n_dofs != chain->n_dofs) return fail(DRM_ERR_INVALID, "the two walks belong to different robots");
+    if (B == 0) return DRM_OK;
+    const int n = tree->n_dofs;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t done = 0;
+#ifndef DRM_NO_ARM_KERNEL
+    {
+        uintptr_t dst = 0;
+        for (int p = 0; p < put->n_peers; ++p) dst |= (uintptr_t)put->tau[p] | (uintptr_t)put->pos[p] | (uintptr_t)put->quat[p];
+        const uint32_t align = al16(q, AL_Q) | al16(qd, AL_QD) | al16(qdd, AL_QDD) | al16(tau, AL_TAU) | al16(pos, AL_POS) | al16(quat, AL_QUAT);
+        const bool same = target_op == tree->n_ops - 1 && tree->n_ops == chain->n_ops;
+        const bool folded = tree->n_ops == n && chain->n_ops > n && (chain->shape & DRM_WALK_ARM_CHAIN) && chain->capacity == 8;
+        const void *own = tree->special[DRM_SPECIAL_FK_RNEA_ARM_PUT];
+        if (own && own == chain->special[DRM_SPECIAL_FK_RNEA_ARM_PUT] && (tree->shape & DRM_WALK_ARM_CHAIN) && tree->capacity == 8 && n == 7 &&
+            (same || folded) && chain->target_perm == 2 && B / (2 * WAVE) >= DRM_ARM_STATIC_MIN_PAIRS && B / WAVE < 0x7fffffffLL &&
+            align == (AL_Q | AL_QD | AL_TAU | AL_POS | AL_QUAT | (qdd ? AL_QDD : 0u)) && (dst & 15u) == 0 && (put->row_offset & 3) == 0) {
+            int n_pairs = (int)(B / (2 * WAVE)), fl = (int)flags;
+            drm_put dsts = *put;
+            void *args[] = {(void *)&q, (void *)&qd, (void *)&qdd, (void *)&n_pairs, (void *)&fl, (void *)&tau, (void *)&pos, (void *)&quat, (void *)&dsts};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)own, (unsigned)arm_stream_grid(n_pairs), 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fk_rnea_arm_put_static): %s", hipGetErrorString(e));
+            done = (int64_t)n_pairs * 2 * WAVE;
+            if (done == B) return DRM_OK;
+        }
+    }
+#endif
+    // what is left (everything, for walks without the in-kernel form): compute, then one copy per destination and array
+    const float *rq = q + done * n, *rqd = qd + done * n, *rqdd = qdd ? qdd + done * n : nullptr;
+    float *rtau = tau + done * n, *rpos = pos + done * 3, *rquat = quat + done * 4;
+    const int64_t rest = B - done, at = put->row_offset + done;
+    drm_walk t2 = *tree, c2 = *chain;
+    rc = drm_fk_rnea(&t2, &c2, target_op, rq, rqd, rqdd, rest, flags, rtau, rpos, rquat, scratch, stream);
+    if (rc) return rc;
+    for (int p = 0; p < put->n_peers; ++p) {
+        hipError_t e = hipSuccess;
+        if (put->tau[p]) e = hipMemcpyAsync(put->tau[p] + at * n, rtau, sizeof(float) * (size_t)rest * n, hipMemcpyDefault, s);
+        if (e == hipSuccess && put->pos[p]) e = hipMemcpyAsync(put->pos[p] + at * 3, rpos, sizeof(float) * (size_t)rest * 3, hipMemcpyDefault, s);
+        if (e == hipSuccess && put->quat[p]) e = hipMemcpyAsync(put->quat[p] + at * 4, rquat, sizeof(float) * (size_t)rest * 4, hipMemcpyDefault, s);
+        if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipMemcpyAsync to a gather destination: %s", hipGetErrorString(e));
+    }
+    return DRM_OK;
+}

@@ -90,6 +90,103 @@ def gather_flat(out, local: torch.Tensor, dst: int = 0, group=None) -> None:
         out.reshape(world, -1).copy_(torch.stack(parts))
 
 
+class PeerGather:
+    """One-sided gather of the fused FK + inverse-dynamics launch's outputs over the GPUs of one node ("direct peer
+    writes"): every rank owns ONE buffer holding the gathered arrays tau [G, n] | pos [G, 3] | quat [G, 4] of
+    the global batch; the ranks exchange the buffers' IPC handles ONCE (hipIpcGetMemHandle / OpenMemHandle behind torch's CUDA-tensor
+    sharing; HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack) and every rank's launch then writes its own rows into its own buffer AND
+    into the peers' (drm_fk_rnea_put: for a 7-DoF arm with its own fused kernel the stores leave from the kernel's epilogue, tile
+    by tile, while the walk runs — no collective launch, no second pass over the data).
+
+        pg = PeerGather(batch, n_dofs, device, mode="all")              # collective: every rank of the group calls it
+        plan = model.plan_fk_and_inverse_dynamics(q, qd, qdd, link, outputs=pg.outputs(), put=pg.put())
+        plan.launch(); torch.cuda.synchronize(); dist.barrier()         # one-sided: the consumer synchronises with the writers
+        tau, pos, quat = pg.gathered()                                  # all G rows
+
+    mode: "all" every rank receives tau | pos | quat of every row; "tau": the torques only; "root": rank 0 receives everything,
+    the others only keep their own rows.  CPU tensors (the gloo tests): the buffers are shared-memory tensors and the host build of
+    the ABI copies into them.  At most backend.MAX_PEERS + 1 = 9 ranks."""
+
+    def __init__(self, batch: int, n_dofs: int, device, mode: str = "all", group=None):
+        import pickle
+
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        from . import backend
+        if mode not in ("all", "tau", "root"):
+            raise ValueError("mode must be all, tau or root")
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world - 1 > backend.MAX_PEERS:
+            raise ValueError("PeerGather serves up to %d ranks" % (backend.MAX_PEERS + 1))
+        self.batch, self.n, self.mode, self.group = int(batch), int(n_dofs), mode, group
+        self.lo, self.hi = self.bounds(self.batch, self.world, self.rank)
+        device = torch.device(device)
+        self.flat = torch.zeros(self._off(3), dtype=torch.float32, device=device)
+        if device.type == "cpu":
+            torch.multiprocessing.set_sharing_strategy("file_system")      # (handles that travel as plain data, not as file descriptors)
+            self.flat.share_memory_()
+        # torch's own tensor-sharing reducers (what torch.multiprocessing sends over its queues): an IPC handle for device memory, the
+        # name of the shared-memory file for a host tensor — as bytes, so that they can travel through all_gather_object
+        from multiprocessing.reduction import ForkingPickler
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(ForkingPickler.dumps(reduce_tensor(self.flat))), group=group)
+        self._peers = {}
+        for r, blob in enumerate(handles):
+            if r != self.rank and self._sends_to(r):
+                fn_r, args_r = pickle.loads(blob)
+                self._peers[r] = fn_r(*args_r)          # the peer's buffer, mapped into this process (kept alive here)
+        dist.barrier(group=group)                       # every handle is open before anybody writes
+
+    @staticmethod
+    def bounds(batch: int, world: int, rank: int) -> Tuple[int, int]:
+        """Rows [lo, hi) of `rank`: contiguous shards whose first row is a multiple of 4, so that every shard's slice of every
+        gathered array starts on a 16-byte boundary (what the kernels' 16-byte stores and the plans' output checks ask for); the
+        last ranks of a ragged batch get fewer rows (shard_bounds, which balances to one row, does not align)."""
+        per = ((int(batch) + world - 1) // world + 3) & ~3
+        lo = min(int(batch), rank * per)
+        return lo, min(int(batch), lo + per)
+
+    def _off(self, k: int) -> int:
+        """Start (in floats) of array k of the buffer: 0 tau, 1 pos, 2 quat, 3 = the end; every array on a 16-byte boundary."""
+        sizes = (self.batch * self.n, self.batch * 3, self.batch * 4)
+        return sum((x + 3) & ~3 for x in sizes[:k])
+
+    def _sends_to(self, r: int) -> bool:
+        return r == 0 if self.mode == "root" else True
+
+    def _arrays(self, flat):
+        G, n = self.batch, self.n
+        return (flat[self._off(0):self._off(0) + G * n].view(G, n), flat[self._off(1):self._off(1) + G * 3].view(G, 3),
+                flat[self._off(2):self._off(2) + G * 4].view(G, 4))
+
+    def gathered(self):
+        """(tau [G, n], pos [G, 3], quat [G, 4]) of this rank's buffer (complete once every writer has synchronised)."""
+        return self._arrays(self.flat)
+
+    def outputs(self):
+        """This rank's own rows inside its buffer: what the launch writes locally (no copy of the own shard afterwards)."""
+        return tuple(a[self.lo:self.hi] for a in self._arrays(self.flat))
+
+    def put(self):
+        """The DrmPut of this rank's launches: the peers' arrays (tau only in mode "tau") and this shard's first row."""
+        from . import backend
+        put = backend.DrmPut()
+        put.row_offset = self.lo
+        for k, (r, flat) in enumerate(sorted(self._peers.items())):
+            tau, pos, quat = self._arrays(flat)
+            put.tau[k] = tau.data_ptr()
+            if self.mode != "tau":
+                put.pos[k], put.quat[k] = pos.data_ptr(), quat.data_ptr()
+        put.n_peers = len(self._peers)
+        return put
+
+    def close(self):
+        """Unmap the peers' buffers (collective: the owners must outlive the mappings)."""
+        dist.barrier(group=self.group)
+        self._peers.clear()
+        dist.barrier(group=self.group)
+
+
 def gather_model_us(mode: str, shard_bytes: int, tau_bytes: int, world: int, link_gbs: float = 153.0) -> float:
     """What one exchange of a config-3 step should cost over xGMI (a fully connected mesh, one ~153 GB/s link per peer, all
     links of a GPU busy in parallel): every receiving GPU takes one peer's block per link, so the time is ONE block over ONE
@@ -97,7 +194,7 @@ def gather_model_us(mode: str, shard_bytes: int, tau_bytes: int, world: int, lin
     `tau`: the torques only (28 B per row), `none`: the outputs stay sharded.  Collective launch latency (~10 us) not included."""
     if world <= 1 or mode == "none":
         return 0.0
-    return {"all": shard_bytes, "root": shard_bytes, "tau": tau_bytes}[mode] / (link_gbs * 1e3)
+    return {"all": shard_bytes, "root": shard_bytes, "tau": tau_bytes, "p2p": shard_bytes, "p2p_tau": tau_bytes}[mode] / (link_gbs * 1e3)
 
 
 def gather_outputs(outputs: Sequence[torch.Tensor], batch: int, group=None) -> List[torch.Tensor]:

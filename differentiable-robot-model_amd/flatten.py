@@ -316,9 +316,11 @@ def build_robot_spec(body_params: Sequence[dict], parent_names: Sequence[Optiona
         mass[i] = f32(bp["mass"], 1)[0]; com[i] = f32(bp["com"], 3); inertia[i] = f32(bp["inertia_mat"], 9)
         jtype = bp["joint_type"]
         if jtype != "fixed":
-            if jtype not in ("revolute", "continuous", "prismatic"):
-                raise UnsupportedRobotError("joint of link %s has type %r; supported: fixed, revolute, continuous, "
-                                            "prismatic" % (names[i], jtype))
+            if jtype not in ("revolute", "continuous", "prismatic") and not reference_compat:
+                # (under reference_compat EVERY joint that is not `fixed` — floating and planar ones included — is one revolute DoF
+                # about its <axis>, as upstream counts and moves them, robot_model.py:122-126, rigid_body.py:130-157)
+                raise UnsupportedRobotError("joint of link %s has type %r; with reference_compat=False the supported types are "
+                                            "fixed, revolute, continuous, prismatic" % (names[i], jtype))
             dof[i] = len(controlled)
             controlled.append(i)
             kind[i] = KIND_PRISMATIC if (jtype == "prismatic" and not reference_compat) else KIND_REVOLUTE

@@ -39,7 +39,7 @@ class DrmWalk(ctypes.Structure):
                 ("seg_dof_lo", ctypes.c_int32 * MAX_SEGMENTS), ("seg_dof_cnt", ctypes.c_int32 * MAX_SEGMENTS),
                 ("prefix_end", ctypes.c_int32), ("seg_leaf_begin", ctypes.c_int32 * (MAX_SEGMENTS + 1)),
                 ("chain_dof1", ctypes.c_uint8 * 16), ("chain_prismatic", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
-                ("special", ctypes.c_void_p * 12)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
+                ("special", ctypes.c_void_p * 16)]      # per-robot straight-line kernels of this walk (specialize.py), or NULL
 
 
 def link_table(body_params: Sequence[dict], device, spec=None) -> torch.Tensor:

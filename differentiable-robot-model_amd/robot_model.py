@@ -962,12 +962,13 @@ class DifferentiableRobotModel(torch.nn.Module):
 
     def plan_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: Optional[torch.Tensor],
                                      link_name: str, include_gravity: bool = True, use_damping: bool = True,
-                                     outputs=None) -> "backend.FkInverseDynamicsPlan":
+                                     outputs=None, put=None) -> "backend.FkInverseDynamicsPlan":
         """Prepared launch of inverse dynamics + the pose of ``link_name`` on fixed buffers (drm_fk_rnea): what the
         reference computes with compute_inverse_dynamics (robot_model.py:305-375) followed by
         compute_forward_kinematics (robot_model.py:223-248) on the same q.  One fused kernel for a serial 7-DoF arm
         whose last link is the target, the two walks back to back otherwise.  ``outputs``: caller-owned (tau [B,n], pos [B,3],
-        quat [B,4]) buffers to write into."""
+        quat [B,4]) buffers to write into.  ``put``: the destinations of a one-sided gather (distributed.PeerGather.put(): every
+        launch also writes its rows into the other ranks' gathered arrays, drm_fk_rnea_put)."""
         self._require_device()
         assert q.ndim == 2 and q.shape[1] == self._n_dofs
         assert not self._learnable, "plans snapshot the constants; not available with learnable parameters"
@@ -982,7 +983,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                                              (chain.program, self._ops_f(chain), chain.ops_i),
                                              int(tree.program.op_of_link.get(idx, -1)),
                                              q, qd, qdd_des, bool(include_gravity), bool(use_damping), self._n_dofs,
-                                             outputs=outputs)
+                                             outputs=outputs, put=put)
 
     def compute_fk_and_inverse_dynamics(self, q: torch.Tensor, qd: torch.Tensor, qdd_des: torch.Tensor, link_name: str,
                                         include_gravity: Optional[bool] = True, use_damping: Optional[bool] = True

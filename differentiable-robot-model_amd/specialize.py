@@ -39,6 +39,8 @@ FAN_KERNEL = "drm_fk_fan_links_static"
 # (ABI 11) reverse-mode inverse dynamics of a serial arm WITH learnable link parameters: the constant blocks of the table folded in
 SPECIAL_RNEA_BACKWARD_ARM_PARAM = 11
 ARM_PARAM_KERNEL = "drm_rnea_backward_arm_param_static"
+SPECIAL_FK_RNEA_ARM_PUT = 12          # (ABI 11) the fused FK + RNEA kernel with a one-sided gather of its outputs (drm_fk_rnea_put)
+ARM_PUT_KERNEL = "drm_fk_rnea_arm_put_static"
 FT_FLOATS, DAMP_INDEX = 12, 25        # include/drm_hip.h DRM_OPF_FT_FLOATS, DRM_OPF_DAMP: [0, 12) = F / t, [12, 26) = mass, mcom, I_o, damping
 ARM_KINDS = tuple(ARM_KERNELS)
 # (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
@@ -439,7 +441,7 @@ def arm_source(table, links: int, fused: bool) -> str:
     rows = ",\n".join("    " + ", ".join(_literal(v) for v in r) for r in table)
     name = ARM_KERNELS[SPECIAL_FK_RNEA_ARM if fused else SPECIAL_RNEA_ARM]
     tail = ", float *pos, float *quat" if fused else ""
-    return """// generated by differentiable-robot-model_amd/specialize.py — one serial arm's walk table as compile-time constants
+    text = """// generated by differentiable-robot-model_amd/specialize.py — one serial arm's walk table as compile-time constants
 #include "drm_arm_stream.hpp"
 namespace drm {
 static __device__ constexpr float ROBOT_OPS[8 * DRM_OPF_STRIDE] = {
@@ -453,6 +455,16 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                                               smem, q, qd, qdd, n_tiles, flags, tau, %s);
 }
 """ % (rows, name, tail, links, "true" if fused else "false", "pos, quat" if fused else "nullptr, nullptr")
+    if fused:      # (ABI 11) the same launch with a one-sided gather of its outputs (drm_fk_rnea_put): every tile also to the peers' arrays
+        text += """extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+%s(const float *q, const float *qd, const float *qdd, int n_tiles, int flags, float *tau, float *pos, float *quat, drm_put put) {
+    constexpr int NJ = 7, T_FLOATS = drm::round4(drm::STREAM_TILE * NJ), ROWS_F = drm::STREAM_TILE * NJ;
+    __shared__ __attribute__((aligned(16))) float smem[T_FLOATS + 3 * ROWS_F];
+    drm::arm2_stream_body<8, NJ, %d, true, false, true>([] {}, [] { return [](int k) -> const float * { return drm::ROBOT_OPS + k * DRM_OPF_STRIDE; }; },
+                                                      smem, q, qd, qdd, n_tiles, flags, tau, pos, quat, &put);
+}
+""" % (ARM_PUT_KERNEL, links)
+    return text
 
 
 def arm_dynamics_source(table, links: int) -> str:
@@ -661,10 +673,11 @@ def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkP
     def fused():
         both = table.copy()
         both[links:] = np.asarray(chain_table, np.float32)[links:]
-        handle = _load(build(arm_source(both, links, True), ARM_FLAGS, cached_only), ARM_KERNELS[SPECIAL_FK_RNEA_ARM])
-        special[SPECIAL_FK_RNEA_ARM] = handle
+        path = build(arm_source(both, links, True), ARM_FLAGS, cached_only)
+        handle, put = _load(path, ARM_KERNELS[SPECIAL_FK_RNEA_ARM]), _load(path, ARM_PUT_KERNEL)
+        special[SPECIAL_FK_RNEA_ARM], special[SPECIAL_FK_RNEA_ARM_PUT] = handle, put
         cs = dict(getattr(chain, "_special", None) or {})
-        cs[SPECIAL_FK_RNEA_ARM] = handle
+        cs[SPECIAL_FK_RNEA_ARM], cs[SPECIAL_FK_RNEA_ARM_PUT] = handle, put
         chain._special, chain._ws_cache = cs, None
 
     if SPECIAL_RNEA_ARM not in special:

@@ -44,7 +44,7 @@ extern "C" {
 #define DRM_ABI_VERSION 11
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
-#define DRM_SPECIAL_KINDS 12 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
+#define DRM_SPECIAL_KINDS 16 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
 #define DRM_SPECIAL_RNEA 0   /*   inverse dynamics          kernel drm_rnea_static  */
 #define DRM_SPECIAL_CRBA 1   /*   joint-space inertia matrix   kernel drm_crba_static  */
 #define DRM_SPECIAL_FD 2     /*   forward dynamics             kernel drm_fd_static    */
@@ -80,6 +80,9 @@ extern "C" {
  * q, qd, qdd, grad_tau, n_tiles, flags, grad_q, grad_qd, grad_qdd, partials; launched with 256-thread blocks, the library's rows of
  * partial sums.  Used when the call's param_mask equals reserved0. */
 #define DRM_SPECIAL_RNEA_BACKWARD_ARM_PARAM 11
+/* ABI 11: drm_fk_rnea_put's form of DRM_SPECIAL_FK_RNEA_ARM (same code object, same pair of walks): kernel
+ * "drm_fk_rnea_arm_put_static", arguments q, qd, qdd, n_pairs, flags, tau, pos, quat and the drm_put struct by value */
+#define DRM_SPECIAL_FK_RNEA_ARM_PUT 12
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:
@@ -331,6 +334,31 @@ int drm_rnea(const drm_walk *walk, const float *q, const float *qd, const float 
  */
 int drm_fk_rnea(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd,
                 const float *qdd, int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch, void *stream);
+
+/*
+ * ABI 11: drm_fk_rnea with a ONE-SIDED GATHER of its outputs — the exchange step of a batch sharded over the GPUs of a node
+ * (BASELINE configuration 3; SURVEY.md §8e asked for direct peer writes instead of a collective after the kernel).  Besides its own
+ * tau / pos / quat the call writes the same rows into up to DRM_MAX_PEERS destination sets at row `row_offset`: the gathered arrays
+ * of the peers (their device memory, mapped into this process once by hipIpcOpenMemHandle — differentiable-robot-model_amd/
+ * distributed.py PeerGather does the exchange), or of rank 0 only.  For a serial 7-DoF arm with its own fused kernel attached
+ * (drm_walk.special[DRM_SPECIAL_FK_RNEA_ARM_PUT]) the kernel's epilogue stores every tile to all destinations as it leaves the
+ * wavefront — the xGMI links are busy while the walk runs, no collective launch, no second pass over the data; every other walk,
+ * and ragged tails, are computed by drm_fk_rnea and copied (hipMemcpyAsync on `stream`, one copy per destination and array).
+ * A destination pointer may be NULL (that array is not wanted there, e.g. torques only).  Completion: stream order on THIS GPU —
+ * a consumer on another GPU needs its own synchronisation with this rank (a barrier, a flag), as after any one-sided put.
+ * The reference has no counterpart (one process, one device: robot_model.py:87-137); the rows are bit-identical to drm_fk_rnea's.
+ */
+#define DRM_MAX_PEERS 8
+typedef struct drm_put {
+    int32_t n_peers;             /* 0 .. DRM_MAX_PEERS destination sets                                              */
+    int32_t reserved;
+    int64_t row_offset;          /* this call's first row in the destinations' arrays (a multiple of 4 for the in-kernel form) */
+    float *tau[DRM_MAX_PEERS];   /* [>= row_offset + B, n] each, or NULL                                              */
+    float *pos[DRM_MAX_PEERS];   /* [>= row_offset + B, 3]                                                            */
+    float *quat[DRM_MAX_PEERS];  /* [>= row_offset + B, 4]                                                            */
+} drm_put;
+int drm_fk_rnea_put(const drm_walk *tree, const drm_walk *chain, int32_t target_op, const float *q, const float *qd, const float *qdd,
+                    int64_t B, int32_t flags, float *tau, float *pos, float *quat, float *scratch, const drm_put *put, void *stream);
 
 /*
  * Joint-space inertia matrix over the whole tree (composite-rigid-body algorithm).

@@ -86,6 +86,52 @@ def test_shard_and_gather_world_size_2(tmp_path, batch):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _peer_worker(rank, world, port, batch, mode, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from differentiable_robot_model_amd.distributed import PeerGather
+        from helpers import load_model, sample_states
+        torch.set_num_threads(1)
+        m = load_model("panda_no_gripper", "cpu")          # (libdrm_cpu.so: the host build of drm_fk_rnea_put copies into the peers' arrays)
+        link = "panda_virtual_ee_link"
+        q, qd, qdd = (torch.from_numpy(a) for a in sample_states(m, batch, seed=9))      # every rank builds the same global batch
+        pg = PeerGather(batch, m._n_dofs, "cpu", mode=mode)
+        lo, hi = pg.lo, pg.hi
+        spans = [PeerGather.bounds(batch, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == batch and all(a[1] == b[0] and b[0] % 4 == 0 for a, b in zip(spans, spans[1:]))
+        assert pg.put().n_peers == (world - 1 if mode != "root" else (0 if rank == 0 else 1)) and pg.put().row_offset == lo
+        plan = m.plan_fk_and_inverse_dynamics(q[lo:hi].clone(), qd[lo:hi].clone(), qdd[lo:hi].clone(), link, outputs=pg.outputs(), put=pg.put())
+        for _ in range(2):          # (a second launch overwrites the same rows: nothing accumulates)
+            plan.launch()
+        dist.barrier()              # one-sided puts: the consumer synchronises with the writers
+        tau, pos, quat = pg.gathered()
+        want = m.compute_fk_and_inverse_dynamics(q, qd, qdd, link)
+        rows = slice(0, batch) if (mode != "root" or rank == 0) else slice(lo, hi)       # (root: the others keep their own rows only)
+        assert torch.equal(tau[rows], want[0][rows])
+        if mode == "tau" :
+            assert torch.equal(pos[lo:hi], want[1][lo:hi]) and torch.equal(quat[lo:hi], want[2][lo:hi])
+            other = [r for r in range(world) if r != rank][0]
+            olo, ohi = PeerGather.bounds(batch, world, other)
+            assert ohi == olo or float(pos[olo:ohi].abs().sum()) == 0.0                   # (the peers sent their torques only)
+        else:
+            assert torch.equal(pos[rows], want[1][rows]) and torch.equal(quat[rows], want[2][rows])
+        pg.close()
+        open(os.path.join(result_dir, "ok%d" % rank), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch,mode", [(2, 256, "all"), (3, 130, "all"), (2, 131, "tau"), (3, 64, "root")])
+def test_one_sided_gather_world_size_n(tmp_path, cpu_library, world, batch, mode):
+    """distributed.PeerGather + drm_fk_rnea_put (ABI 11) with world_size-N gloo processes on the CPU: every rank's launch writes its
+    rows into its own gathered buffer and into the peers' (shared-memory tensors here, IPC-mapped device memory on a GPU node);
+    after one barrier every receiving rank holds all rows, bit for bit what ONE process computes for the whole batch."""
+    mp.spawn(_peer_worker, args=(world, _free_port(), batch, mode, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok%d" % r for r in range(world)]
+
+
 def test_torchrun_spawn_path(tmp_path):
     """`python bench.py --gpus N` without a rendezvous re-executes itself through distributed.torchrun_command; the same
     line must bring up N ranks that see each other (gloo here, RCCL on the GPU node)."""

@@ -1,6 +1,8 @@
 """Host-side logic (not gpu): URDF ingest, constant tables, walk programs, tensor_check, learnable-parameter
 plumbing, error behaviour, and the C-ABI library's exported symbols."""
+import contextlib
 import ctypes
+import io
 import os
 import re
 
@@ -64,8 +66,27 @@ def test_lenient_xml_and_bad_robots(tmp_path):
     floating = tmp_path / "floating.urdf"
     floating.write_text('<robot name="r"><link name="a"/><link name="b"/><joint name="j" type="floating"><parent link="a"/>'
                         '<child link="b"/><limit lower="-1" upper="1" effort="1" velocity="1"/></joint></robot>')
-    with pytest.raises(UnsupportedRobotError):
-        DifferentiableRobotModel(str(floating), device="cpu")
+    # upstream counts EVERY joint that is not `fixed` as one revolute DoF about its <axis> (robot_model.py:122-126, rigid_body.py:
+    # 130-157), `floating` and `planar` ones included: the default (reference_compat=True) mirrors that — the same numbers as the
+    # same URDF with type="revolute" — and reference_compat=False, which models joints as the URDF says, refuses what it cannot model
+    with pytest.raises(UnsupportedRobotError, match="reference_compat=False"):
+        DifferentiableRobotModel(str(floating), device="cpu", reference_compat=False)
+    body = ('<robot name="r"><link name="a"/><link name="b"/><link name="c"/>'
+            '<joint name="j" type="%s"><parent link="a"/><child link="b"/><origin xyz="0.1 0 0.2" rpy="0.3 0 0"/><axis xyz="0 1 0"/>'
+            '<limit lower="-1" upper="1" effort="1" velocity="1"/></joint>'
+            '<joint name="k" type="%s"><parent link="b"/><child link="c"/><origin xyz="0 0.3 0"/><axis xyz="0 0 -1"/>'
+            '<limit lower="-1" upper="1" effort="1" velocity="1"/></joint></robot>')
+    models = []
+    for n, kinds in enumerate((("floating", "planar"), ("revolute", "revolute"))):
+        path = tmp_path / ("exotic%d.urdf" % n)
+        path.write_text(body % kinds)
+        with contextlib.redirect_stdout(io.StringIO()):
+            models.append(DifferentiableRobotModel(str(path), device="cpu"))
+    assert models[0]._n_dofs == 2 and models[0]._controlled_joints == models[1]._controlled_joints
+    q, qd, qdd = (torch.rand(9, 2, generator=torch.Generator().manual_seed(k)) - 0.5 for k in range(3))
+    for a, b in zip(models[0].compute_forward_kinematics(q, "c"), models[1].compute_forward_kinematics(q, "c")):
+        assert torch.equal(a, b)
+    assert torch.equal(models[0].compute_inverse_dynamics(q, qd, qdd), models[1].compute_inverse_dynamics(q, qd, qdd))
     order = tmp_path / "order.urdf"
     order.write_text('<robot name="r"><link name="a"/><link name="c"/><link name="b"/>'
                      '<joint name="j1" type="fixed"><parent link="a"/><child link="b"/></joint>'
@@ -236,7 +257,7 @@ def test_abi_argument_errors_need_no_gpu():
     w = backend.DrmWalk(1, 1, 8, 8, 7, 17, 0, 2, 0)  # more save slots than the kernels have
     assert lib.drm_fk(ctypes.byref(w), None, 1, 1, None, None, None) == -2
     # struct drm_walk: 48 bytes of scalars + n_segments + seg_begin[9] + seg_dof_lo[8] + seg_dof_cnt[8] + prefix_end + seg_leaf_begin[9]
-    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1 + 9) + 16 + 4 + 4 + 12 * 8    # (+ chain_dof1, chain_prismatic, reserved0: ABI 8; special[4]: ABI 9; special[12]: ABI 10)
+    assert ctypes.sizeof(backend.DrmWalk) == 48 + 4 * (1 + 9 + 8 + 8 + 1 + 9) + 16 + 4 + 4 + 16 * 8    # (+ chain_dof1, chain_prismatic, reserved0: ABI 8; special[4]: ABI 9; special[12]: ABI 10; special[16]: ABI 11)
 
 
 def test_rnea_backward_scratch_covers_the_fanned_out_launch():

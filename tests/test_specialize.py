@@ -723,7 +723,8 @@ def test_gpu_models_attach_built_kernels_by_default_and_only_those(tmp_path, mon
     learn = load_model("panda_no_gripper", "cuda")
     learn.make_link_param_learnable("panda_link3", "mass", PositiveScalar())
     learn.compute_inverse_dynamics(q[:4096], qd[:4096], qdd[:4096])
-    assert special(learn) == {}
+    # ... only the reverse-mode kernel of THIS set of learnable blocks, which reads them from the table (shipped for single links)
+    assert set(special(learn)) <= {sp.SPECIAL_RNEA_BACKWARD_ARM_PARAM}
 
 
 # ------------------------------------------------------------------ arms WITH learnable link parameters (round 6)
