@@ -9,8 +9,8 @@ here one node per public method:
     _InverseDynamics  compute_inverse_dynamics / compute_non_linear_effects           drm_rnea / drm_rnea_backward
     _MassMatrix       compute_lagrangian_inertia_matrix                               drm_crba / drm_rnea_backward per column
     _ForwardDynamics  compute_forward_dynamics (implicit differentiation)             drm_forward_dynamics / drm_rnea_backward
-    _GradLaunch       a first-order gradient launch as a differentiable node (create_graph=True: second derivatives in q / qd / qdd)
-    _FirstOrderOnly   marks parameter gradients computed under create_graph=True
+    _GradLaunch       a first-order gradient launch as a differentiable node (create_graph=True: second derivatives with respect to
+                      q / qd / qdd / f, the output cotangents and — round 6 — the walk's table, i.e. the learnable link parameters)
 
 plus the host-side maps between quaternion gradients and rotation-matrix adjoints (the reference's quaternion is assembled from
 the entries of R by a per-sample case rule, spatial_vector_algebra.py:108-136).  robot_model.py holds the model class only.
@@ -112,13 +112,22 @@ class _GradLaunch(torch.autograd.Function):
     to that floor (tests/test_second_order.py holds the result to the reference's autograd at 2e-3 of the largest entry, also for
     |qd|, |qdd| ~ 50).  Third derivatives are not provided (this node's backward is once-differentiable).
 
-    fwd(xs) -> tuple of outputs;  bwd(xs, cs) -> tuple of gradients, one per x;  args = xs (n_x tensors, [B, ...]) then cs."""
+    Round 6: one of the inputs may be the walk's constant TABLE ([cap, 32], not per-sample: `table_at` = its index among xs, -1 for
+    none) — second derivatives with respect to learnable link parameters (the reference gets them from autograd on its per-link
+    tensor ops, robot_model.py:669-713).  The table is differenced along the incoming cotangent of its gradient (which is non-zero
+    only in the blocks a learnable parameter feeds) with ONE step for the whole table, `table_step` x the largest |entry| of the
+    direction, and one Richardson step: the outputs are polynomials in the table entries of inverse dynamics / the inertia matrix /
+    forward kinematics (exact for the dynamic blocks, which enter linearly), rational for forward dynamics (which passes a smaller
+    step: a table whose inertias went indefinite has no accelerations).
+
+    fwd(xs) -> tuple of outputs;  bwd(xs, cs) -> tuple of gradients, one per x;  args = xs (n_x tensors: [B, ...], the table
+    [cap, 32]) then cs."""
 
     @staticmethod
-    def forward(ctx, fwd, bwd, n_x, *args):
+    def forward(ctx, fwd, bwd, n_x, table_at, table_step, *args):
         xs, cs = args[:n_x], args[n_x:]
         grads = bwd(xs, cs)
-        ctx.fwd, ctx.bwd, ctx.n_x = fwd, bwd, n_x
+        ctx.fwd, ctx.bwd, ctx.n_x, ctx.table_at, ctx.table_step = fwd, bwd, n_x, table_at, table_step
         ctx.save_for_backward(*args)
         return tuple(grads)
 
@@ -131,16 +140,38 @@ class _GradLaunch(torch.autograd.Function):
         us = [u.to(torch.float32) if u is not None else torch.zeros_like(x) for u, x in zip(us, xs)]
         B = xs[0].shape[0]
         bc = lambda t, like: t.reshape((B,) + (1,) * (like.ndim - 1))
+        table_at = ctx.table_at
 
-        def directional(f):
+        def directional(f, summed=None):
             """D_u f = sum_i D_{u_i} f, one difference quotient per INPUT (the directional derivative is linear in the direction)
             so that every input gets a step of its own size: x_0 (joint angles, the outputs are trigonometric in them) the
             absolute step h with one Richardson step; x_1, x_2 (qd, qdd: the outputs are polynomials of degree <= 2 in them,
             for which a central difference is EXACT at any step) a step of the input's own magnitude, max(1, max|x_i|) per
             sample — the rounding error of a difference is eps |f| / step, so a fixed small step would lose the second
-            derivatives of fast, hard-accelerating states in the noise of torques that grow like qd^2."""
+            derivatives of fast, hard-accelerating states in the noise of torques that grow like qd^2.
+            `summed`: the index of an output that is a SUM over the batch (the table's gradient): per-sample steps cannot be
+            undone behind a sum, so that output is differenced once more with ONE step factor for the whole batch (every sample
+            moves by eta u_b)."""
             total = None
             for i, (x, u) in enumerate(zip(xs, us)):
+                if i == table_at:      # the constant table: one direction, one step for all of it, one Richardson step
+                    top = u.abs().max()
+                    if not bool(top > 0):
+                        continue
+                    d = u / top
+                    # the step is RELATIVE to the entries the direction moves (their |d|-weighted mean size): a hand's inertias are
+                    # 1e-6 kg m^2, an arm's 1e-2, a rotation's entries 1 — an absolute step fits none of them at once
+                    size = float(((d.abs() * x.abs()).sum() / d.abs().sum()).clamp_min(1e-12))
+                    part = None
+                    for rel, weight in ((0.5 * ctx.table_step, 4.0 / 3.0), (ctx.table_step, -1.0 / 3.0)):
+                        step = rel * size
+                        shifted = lambda sgn: [xx + sgn * step * d if j == i else xx for j, xx in enumerate(xs)]
+                        hi, lo = f(shifted(1.0)), f(shifted(-1.0))
+                        term = [(a - b) * (weight / (2.0 * step)) for a, b in zip(hi, lo)]
+                        part = term if part is None else [o + t for o, t in zip(part, term)]
+                    part = [o * top for o in part]
+                    total = part if total is None else [o + t for o, t in zip(total, part)]
+                    continue
                 peak = u.reshape(B, -1).abs().amax(dim=1)
                 if not bool((peak > 0).any()):
                     continue
@@ -156,41 +187,34 @@ class _GradLaunch(torch.autograd.Function):
                     e = step * size
                     shifted = lambda sgn: [xx + sgn * bc(e, xx) * d if j == i else xx for j, xx in enumerate(xs)]
                     hi, lo = f(shifted(1.0)), f(shifted(-1.0))
-                    term = [(a - b) * bc(weight / (2.0 * e), a) for a, b in zip(hi, lo)]
-                    part = term if part is None else [o + t for o, t in zip(part, term)]
-                part = [o * bc(peak, o) for o in part]
+                    term = [None if k == summed else (a - b) * bc(weight / (2.0 * e), a) for k, (a, b) in enumerate(zip(hi, lo))]
+                    part = term if part is None else [None if o is None else o + t for o, t in zip(part, term)]
+                part = [None if o is None else o * bc(peak, o) for o in part]
+                if summed is not None:
+                    top = peak.max()
+                    scale = 1.0 if i == 0 else float(size.max())
+                    acc = None
+                    for step, weight in plan:
+                        eta = step * scale / top
+                        shifted = lambda sgn: [xx + sgn * eta * u if j == i else xx for j, xx in enumerate(xs)]
+                        term = (f(shifted(1.0))[summed] - f(shifted(-1.0))[summed]) * (weight / (2.0 * eta))
+                        acc = term if acc is None else acc + term
+                    part[summed] = acc
                 total = part if total is None else [o + t for o, t in zip(total, part)]
             if total is None:
                 total = [torch.zeros_like(t) for t in f(list(xs))]
             return total
 
-        need = ctx.needs_input_grad[3:]
+        need = ctx.needs_input_grad[5:]
         g_x = [None] * n_x
         g_c = [None] * len(cs)
         if any(need[:n_x]):
-            got = directional(lambda X: ctx.bwd(X, cs))
+            got = directional(lambda X: ctx.bwd(X, cs), summed=table_at if table_at >= 0 else None)
             g_x = [g if need[i] else None for i, g in enumerate(got)]
         if any(need[n_x:]):
             got = directional(lambda X: ctx.fwd(X))
             g_c = [g if need[n_x + j] else None for j, g in enumerate(got)]
-        return (None, None, None, *g_x, *g_c)
-
-
-class _FirstOrderOnly(torch.autograd.Function):
-    """Marks a parameter gradient that was computed under create_graph=True: it is a correct FIRST-order gradient (trainers that
-    always pass create_graph=True — MAML-style inner loops, gradient penalties on the joint state — keep working on models with
-    learnable link parameters), but it is not a differentiable function of anything; differentiating THROUGH it raises instead of
-    silently contributing zero."""
-
-    @staticmethod
-    def forward(ctx, grad, anchor):
-        return grad.view_as(grad)
-
-    @staticmethod
-    def backward(ctx, _):
-        raise NotImplementedError(
-            "second derivatives through the learnable link parameters: create_graph=True is provided with respect to the "
-            "joint-state inputs (q, qd, qdd) and the output cotangents only — see INTEGRATION.md, 'Second derivatives'")
+        return (None, None, None, None, None, *g_x, *g_c)
 
 
 class _FkPositions(torch.autograd.Function):
@@ -217,15 +241,11 @@ class _FkPositions(torch.autograd.Function):
         dw = ctx.dw
         if grad_pos is None:
             grad_pos = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
-        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            grad_ops = None
-            if want_p:                   # ... for q; the parameter gradient is first-order (see _FirstOrderOnly)
-                with torch.no_grad():
-                    grad_ops = _FkPositions._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, False, True)[1]
-                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
-            if not want_q:
-                return None, grad_ops, None, None, None, None
-            table, T, n = ops_f.detach(), ctx.n_targets, ctx.n_dofs
+        if torch.is_grad_enabled():      # create_graph=True: the gradients are themselves a differentiable node (_GradLaunch)
+            if not (want_q or want_p):
+                return None, None, None, None, None, None
+            T, n = ctx.n_targets, ctx.n_dofs
+            const, mask = ops_f.detach(), (ctx.param_mask if want_p else 0)
             if grad_quat is None:
                 grad_quat = torch.zeros_like(quat)
 
@@ -233,17 +253,19 @@ class _FkPositions(torch.autograd.Function):
             masks, t = _quat_cases(_rot_from_quat(quat.detach()))
 
             def fwd(X):
-                pos, qt = backend.fk(dw.program, table, dw.ops_i, X[0], T, n)
+                pos, qt = backend.fk(dw.program, X[1] if want_p else const, dw.ops_i, X[0], T, n)
                 return pos, _u_from_rot(_rot_from_quat(qt), masks)
 
             def bwd(X, C):
-                return (backend.fk_backward(dw.program, table, dw.ops_i, X[0], C[0], T, n, 0, True,
-                                            _u_grad_to_rot(masks, C[1]))[0].reshape(X[0].shape),)
+                gq, gops = backend.fk_backward(dw.program, X[1] if want_p else const, dw.ops_i, X[0], C[0], T, n, mask, True,
+                                               _u_grad_to_rot(masks, C[1]))
+                return (gq.reshape(X[0].shape),) + ((gops,) if want_p else ())
 
+            xs = [q.to(torch.float32)] + ([ops_f.to(torch.float32)] if want_p else [])
             with torch.enable_grad():
                 grad_u = grad_quat.to(torch.float32) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
-                (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), grad_pos.to(torch.float32), grad_u)
-            return grad_q.to(q.dtype), grad_ops, None, None, None, None
+                got = _GradLaunch.apply(fwd, bwd, len(xs), 1 if want_p else -1, SECOND_ORDER_STEP, *xs, grad_pos.to(torch.float32), grad_u)
+            return (got[0].to(q.dtype) if want_q else None), (got[1] if want_p else None), None, None, None, None
         with torch.no_grad():
             return _FkPositions._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, want_q, want_p)
 
@@ -307,33 +329,31 @@ class _FkJacobian(torch.autograd.Function):
         zeros = lambda: torch.zeros(q.shape[0], 3, ctx.n_dofs, device=q.device, dtype=torch.float32)
         grad_lin = grad_lin if grad_lin is not None else zeros()
         grad_ang = grad_ang if grad_ang is not None else zeros()
-        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            grad_ops = None
-            if want_p:
-                with torch.no_grad():
-                    grad_ops = _FkJacobian._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, False, True)[1]
-                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
-            if not want_q:
-                return None, grad_ops, None, None, None
-            table, n = ops_f.detach(), ctx.n_dofs
+        if torch.is_grad_enabled():      # create_graph=True: the gradients are themselves a differentiable node (_GradLaunch)
+            if not (want_q or want_p):
+                return None, None, None, None, None
+            n = ctx.n_dofs
+            const, mask = ops_f.detach(), (ctx.param_mask if want_p else 0)
             f32 = lambda t, like: (t if t is not None else torch.zeros_like(like)).to(torch.float32)
             pos_like = torch.zeros(quat.shape[:-1] + (3,), device=quat.device, dtype=torch.float32)
 
             masks, t = _quat_cases(_rot_from_quat(quat.detach()))     # (constants of the reference's graph, as in _FkPositions)
 
             def fwd(X):
-                pos, qt, lin, ang = backend.fk_jacobian(dw.program, table, dw.ops_i, X[0], n)
+                pos, qt, lin, ang = backend.fk_jacobian(dw.program, X[1] if want_p else const, dw.ops_i, X[0], n)
                 return pos, _u_from_rot(_rot_from_quat(qt), masks), lin, ang
 
             def bwd(X, C):
-                return (backend.fk_jacobian_backward(dw.program, table, dw.ops_i, X[0], C[0], C[2], C[3], n, 0, True,
-                                                     _u_grad_to_rot(masks, C[1]))[0].reshape(X[0].shape),)
+                gq, gops = backend.fk_jacobian_backward(dw.program, X[1] if want_p else const, dw.ops_i, X[0], C[0], C[2], C[3], n, mask,
+                                                        True, _u_grad_to_rot(masks, C[1]))
+                return (gq.reshape(X[0].shape),) + ((gops,) if want_p else ())
 
+            xs = [q.to(torch.float32)] + ([ops_f.to(torch.float32)] if want_p else [])
             with torch.enable_grad():
                 grad_u = f32(grad_quat, quat) * (0.5 * torch.rsqrt(t)).unsqueeze(-1)
-                (grad_q,) = _GradLaunch.apply(fwd, bwd, 1, q.to(torch.float32), f32(grad_pos, pos_like), grad_u,
-                                              grad_lin.to(torch.float32), grad_ang.to(torch.float32))
-            return grad_q.to(q.dtype), grad_ops, None, None, None
+                got = _GradLaunch.apply(fwd, bwd, len(xs), 1 if want_p else -1, SECOND_ORDER_STEP, *xs, f32(grad_pos, pos_like), grad_u,
+                                        grad_lin.to(torch.float32), grad_ang.to(torch.float32))
+            return (got[0].to(q.dtype) if want_q else None), (got[1] if want_p else None), None, None, None
         with torch.no_grad():
             return _FkJacobian._first_order(ctx, q, ops_f, quat, grad_pos, grad_quat, grad_lin, grad_ang, want_q, want_p)
 
@@ -366,33 +386,31 @@ class _InverseDynamics(torch.autograd.Function):
         qdd = qdd if ctx.has_qdd else None
         want_in = any(ctx.needs_input_grad[:3])
         dw = ctx.dw
-        if torch.is_grad_enabled():      # create_graph=True: the gradient is itself a differentiable node (_GradLaunch)
-            grad_ops = None
-            if ctx.needs_input_grad[3]:
-                with torch.no_grad():
-                    grad_ops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, grad_tau, ctx.flags[0], ctx.flags[1],
-                                                     ctx.n_dofs, ctx.param_mask, False)[1]
-                grad_ops = _FirstOrderOnly.apply(grad_ops, ops_f)
-            if not want_in:
-                return (None, None, None, grad_ops) + (None,) * 5
-            table, n, (gravity, damping) = ops_f.detach(), ctx.n_dofs, ctx.flags
-            has_qdd = ctx.has_qdd
+        if torch.is_grad_enabled():      # create_graph=True: the gradients are themselves a differentiable node (_GradLaunch)
+            want_p = bool(ctx.needs_input_grad[3]) and ctx.param_mask != 0
+            if not (want_in or want_p):
+                return (None,) * 9
+            const, n, (gravity, damping) = ops_f.detach(), ctx.n_dofs, ctx.flags
+            has_qdd, mask = ctx.has_qdd, (ctx.param_mask if want_p else 0)
+            n_in = 3 if has_qdd else 2
 
             def fwd(X):
-                return (backend.rnea(dw.program, table, dw.ops_i, X[0], X[1], X[2] if has_qdd else None, gravity, damping, n),)
+                return (backend.rnea(dw.program, X[n_in] if want_p else const, dw.ops_i, X[0], X[1], X[2] if has_qdd else None, gravity,
+                                     damping, n),)
 
             def bwd(X, C):
-                gin, _ = backend.rnea_backward(dw.program, table, dw.ops_i, X[0], X[1], X[2] if has_qdd else None, C[0],
-                                               gravity, damping, n, 0, True)
-                return tuple(g.reshape(X[0].shape) for g in gin[:3 if has_qdd else 2])
+                gin, gops = backend.rnea_backward(dw.program, X[n_in] if want_p else const, dw.ops_i, X[0], X[1],
+                                                  X[2] if has_qdd else None, C[0], gravity, damping, n, mask, True)
+                return tuple(g.reshape(X[0].shape) for g in gin[:n_in]) + ((gops,) if want_p else ())
 
-            xs = [q.to(torch.float32), qd.to(torch.float32)] + ([qdd.to(torch.float32)] if has_qdd else [])
+            xs = [q.to(torch.float32), qd.to(torch.float32)] + ([qdd.to(torch.float32)] if has_qdd else []) + \
+                ([ops_f.to(torch.float32)] if want_p else [])
             with torch.enable_grad():
-                got = _GradLaunch.apply(fwd, bwd, len(xs), *xs, grad_tau.to(torch.float32))
+                got = _GradLaunch.apply(fwd, bwd, len(xs), n_in if want_p else -1, SECOND_ORDER_STEP, *xs, grad_tau.to(torch.float32))
             gq = got[0].to(q.dtype) if ctx.needs_input_grad[0] else None
             gqd = got[1].to(qd.dtype) if ctx.needs_input_grad[1] else None
             gqdd = got[2].to(qdd.dtype) if (has_qdd and ctx.needs_input_grad[2]) else None
-            return gq, gqd, gqdd, grad_ops, None, None, None, None, None
+            return gq, gqd, gqdd, (got[n_in] if want_p else None), None, None, None, None, None
         with torch.no_grad():
             return _InverseDynamics._first_order(ctx, q, qd, qdd, ops_f, grad_tau, want_in)
 
@@ -415,7 +433,8 @@ class _MassMatrix(torch.autograd.Function):
     (robot_model.py:402-450): column j is the inverse dynamics of a unit acceleration of joint j at rest without
     gravity, H[:, :, j] = ID(q, 0, e_j), so for a loss gradient G on H the gradients with respect to q and to the
     learnable link parameters are those of the RNEA with qdd = e_j and grad_tau = G[:, :, j], summed over j — one launch of
-    the RNEA backward kernel over the batch stacked n times."""
+    the RNEA backward kernel over the batch stacked n times.  Under create_graph=True that gradient is a differentiable node
+    (_GradLaunch: second derivatives with respect to q, the learnable parameters and the incoming cotangent)."""
 
     @staticmethod
     def forward(ctx, q, ops_f, dw, n_dofs, param_mask):
@@ -425,14 +444,8 @@ class _MassMatrix(torch.autograd.Function):
         return H
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_H):
-        q, ops_f = ctx.saved_tensors
-        dw, n = ctx.dw, ctx.n_dofs
-        want_q = ctx.needs_input_grad[0]
-        mask = ctx.param_mask if ctx.needs_input_grad[1] else 0
-        G = grad_H.to(torch.float32)
-        qf = q.to(torch.float32)
+    def _first_order(dw, n, qf, table, G, want_q, mask):
+        """(grad_q [B, n] or None, grad_ops_f [cap, 32] or None) for the loss gradient G [B, n, n] on H(q; table)."""
         B = qf.shape[0]
         # all columns in ONE launch of the RNEA backward kernel: the batch is stacked n times (rows j B .. (j + 1) B - 1 carry
         # qdd = e_j and grad_tau = G[:, :, j]); the kernel's fixed-order reduction sums the parameter gradients over all of
@@ -445,14 +458,53 @@ class _MassMatrix(torch.autograd.Function):
             qs = qf.repeat(cols, 1)
             unit = eye[j0:j0 + cols].repeat_interleave(B, dim=0)
             gt = G[:, :, j0:j0 + cols].permute(2, 0, 1).reshape(cols * B, n).contiguous()
-            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, qs, torch.zeros_like(qs), unit, gt, False, False, n,
+            gin, gops = backend.rnea_backward(dw.program, table, dw.ops_i, qs, torch.zeros_like(qs), unit, gt, False, False, n,
                                               mask, want_q)
             if gin is not None:
                 part = gin[0].reshape(cols, B, n).sum(dim=0)
                 gq = part if gq is None else gq + part
             if gops is not None:
                 grad_ops = gops if grad_ops is None else grad_ops + gops
+        return gq, grad_ops
+
+    @staticmethod
+    def backward(ctx, grad_H):
+        q, ops_f = ctx.saved_tensors
+        dw, n = ctx.dw, ctx.n_dofs
+        want_q = ctx.needs_input_grad[0]
+        want_p = bool(ctx.needs_input_grad[1]) and ctx.param_mask != 0
+        if not (want_q or want_p):
+            return None, None, None, None, None
+        if torch.is_grad_enabled():      # create_graph=True
+            const, mask = ops_f.detach(), (ctx.param_mask if want_p else 0)
+
+            def fwd(X):
+                # H by the reference's own definition, column j = ID(q, 0, e_j) without gravity (robot_model.py:402-450) — the function
+                # the backward above differentiates.  (The composite-rigid-body kernel reads an inertia matrix as the symmetric matrix
+                # it physically is; a table moved along an unsymmetric direction — an UnconstrainedTensor(3, 3) parametrisation —
+                # is still the reference's function only through the RNEA.)
+                x, table = X[0], (X[1] if want_p else const)
+                Bx = x.shape[0]
+                unit = torch.eye(n, device=x.device, dtype=torch.float32).repeat_interleave(Bx, dim=0)
+                xs_ = x.repeat(n, 1)
+                tau = backend.rnea(dw.program, table, dw.ops_i, xs_, torch.zeros_like(xs_), unit, False, False, n)
+                return (tau.reshape(n, Bx, n).permute(1, 2, 0).contiguous(),)
+
+            def bwd(X, C):
+                gq, gops = _MassMatrix._first_order(dw, n, X[0], X[1] if want_p else const, C[0], True, mask)
+                return (gq.reshape(X[0].shape),) + ((gops,) if want_p else ())
+
+            xs = [q.to(torch.float32)] + ([ops_f.to(torch.float32)] if want_p else [])
+            with torch.enable_grad():
+                got = _GradLaunch.apply(fwd, bwd, len(xs), 1 if want_p else -1, SECOND_ORDER_STEP, *xs, grad_H.to(torch.float32))
+            return (got[0].to(q.dtype) if want_q else None), (got[1] if want_p else None), None, None, None
+        with torch.no_grad():
+            gq, grad_ops = _MassMatrix._first_order(dw, n, q.to(torch.float32), ops_f, grad_H.to(torch.float32), want_q,
+                                                    ctx.param_mask if want_p else 0)
         return (gq.to(q.dtype).reshape(q.shape) if gq is not None else None), grad_ops, None, None, None
+
+
+FD_TABLE_STEP = 5e-2       # (relative, as SECOND_ORDER_STEP) forward dynamics is RATIONAL in the table (H^-1): the inertias stay positive definite
 
 
 class _ForwardDynamics(torch.autograd.Function):
@@ -462,31 +514,54 @@ class _ForwardDynamics(torch.autograd.Function):
         dL/df = lambda,    dL/d(q, qd, theta) = -lambda^T dID/d(q, qd, theta) at (q, qd, qdd),
 
     which is exactly the RNEA backward kernel fed with grad_tau = lambda (what torch autograd gets by differentiating
-    through the reference's articulated-body recursion, robot_model.py:487-624; examples/learn_forward_dynamics_iiwa.py)."""
+    through the reference's articulated-body recursion, robot_model.py:487-624; examples/learn_forward_dynamics_iiwa.py).
+    Under create_graph=True that gradient is a differentiable node (_GradLaunch)."""
 
     @staticmethod
     def forward(ctx, q, qd, f, ops_f, dw, gravity, damping, n_dofs, param_mask):
         qdd = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, qd, f, gravity, damping, n_dofs)
-        ctx.save_for_backward(q, qd, qdd, ops_f)
+        ctx.save_for_backward(q, qd, f, qdd, ops_f)
         ctx.dw, ctx.flags, ctx.n_dofs, ctx.param_mask = dw, (gravity, damping), n_dofs, param_mask
         return qdd
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_qdd):
-        q, qd, qdd, ops_f = ctx.saved_tensors
-        dw, n = ctx.dw, ctx.n_dofs
-        lam = backend.forward_dynamics(dw.program, ops_f, dw.ops_i, q, torch.zeros_like(qd),
-                                       grad_qdd.to(torch.float32).contiguous(), False, False, n)
-        want_in = any(ctx.needs_input_grad[:2])
-        want_ops = ctx.needs_input_grad[3] and ctx.param_mask != 0
+    def _first_order(dw, n, flags, q, qd, qdd, table, grad_qdd, want_in, mask):
+        """(grad_q, grad_qd, grad_f, grad_ops_f) of a loss gradient on qdd = FD(q, qd, f; table) at the given solution qdd."""
+        lam = backend.forward_dynamics(dw.program, table, dw.ops_i, q, torch.zeros_like(qd), grad_qdd.contiguous(), False, False, n)
         gq = gqd = grad_ops = None
-        if want_in or want_ops:
-            gin, gops = backend.rnea_backward(dw.program, ops_f, dw.ops_i, q, qd, qdd, lam, ctx.flags[0], ctx.flags[1], n,
-                                              ctx.param_mask if want_ops else 0, want_in)
+        if want_in or mask:
+            gin, gops = backend.rnea_backward(dw.program, table, dw.ops_i, q, qd, qdd, lam, flags[0], flags[1], n, mask, want_in)
             if gin is not None:
-                gq = -gin[0].reshape(q.shape) if ctx.needs_input_grad[0] else None
-                gqd = -gin[1].reshape(qd.shape) if ctx.needs_input_grad[1] else None
+                gq, gqd = -gin[0].reshape(q.shape), -gin[1].reshape(qd.shape)
             grad_ops = -gops if gops is not None else None
-        gf = lam.reshape(grad_qdd.shape) if ctx.needs_input_grad[2] else None
-        return gq, gqd, gf, grad_ops, None, None, None, None, None, None
+        return gq, gqd, lam.reshape(grad_qdd.shape), grad_ops
+
+    @staticmethod
+    def backward(ctx, grad_qdd):
+        q, qd, f, qdd, ops_f = ctx.saved_tensors
+        dw, n = ctx.dw, ctx.n_dofs
+        want_p = bool(ctx.needs_input_grad[3]) and ctx.param_mask != 0
+        if torch.is_grad_enabled():      # create_graph=True
+            const, mask, flags = ops_f.detach(), (ctx.param_mask if want_p else 0), ctx.flags
+
+            def table_of(X):
+                return X[3] if want_p else const
+
+            def fwd(X):
+                return (backend.forward_dynamics(dw.program, table_of(X), dw.ops_i, X[0], X[1], X[2], flags[0], flags[1], n),)
+
+            def bwd(X, C):
+                acc = backend.forward_dynamics(dw.program, table_of(X), dw.ops_i, X[0], X[1], X[2], flags[0], flags[1], n)
+                gq, gqd, gf, gops = _ForwardDynamics._first_order(dw, n, flags, X[0], X[1], acc, table_of(X), C[0], True, mask)
+                return (gq, gqd, gf) + ((gops,) if want_p else ())
+
+            xs = [t.to(torch.float32) for t in (q, qd, f)] + ([ops_f.to(torch.float32)] if want_p else [])
+            with torch.enable_grad():
+                got = _GradLaunch.apply(fwd, bwd, len(xs), 3 if want_p else -1, FD_TABLE_STEP, *xs, grad_qdd.to(torch.float32))
+            pick = lambda i, like: got[i].to(like.dtype) if ctx.needs_input_grad[i] else None
+            return pick(0, q), pick(1, qd), pick(2, f), (got[3] if want_p else None), None, None, None, None, None, None
+        with torch.no_grad():
+            gq, gqd, gf, grad_ops = _ForwardDynamics._first_order(dw, n, ctx.flags, q, qd, qdd, ops_f, grad_qdd.to(torch.float32),
+                                                                  any(ctx.needs_input_grad[:2]), ctx.param_mask if want_p else 0)
+        return (gq if ctx.needs_input_grad[0] else None), (gqd if ctx.needs_input_grad[1] else None), \
+            (gf if ctx.needs_input_grad[2] else None), grad_ops, None, None, None, None, None, None

@@ -553,6 +553,29 @@ def rnea_backward(prog: WalkProgram, ops_f, ops_i, q, qd, qdd, grad_tau, include
     return gin, grad_ops
 
 
+def link_rows_torch(params: torch.Tensor) -> torch.Tensor:
+    """[L, 20] URDF-level link parameters (rpy, trans, mass, com, inertia_mat, damping) -> [L, 32] link-table rows with plain
+    torch ops: the arithmetic of csrc/drm_sample.hpp link_row (= the reference's: R_fixed = (Rz(yaw) Ry(pitch)) Rx(roll),
+    rigid_body.py:138-143, spatial_vector_algebra.py:14-53; mcom = com * mass, I_o = I_c + mass * S(com) S(com)^T,
+    spatial_vector_algebra.py:321-327).  Differentiable any number of times: the constant snapshot of a model is built with it
+    (on the host), and the one-kernel maps below fall back to it when a graph is being created THROUGH their backward
+    (create_graph=True: second derivatives with respect to learnable link parameters)."""
+    L, dev = params.shape[0], params.device
+    rpy, trans, mass, com = params[:, 0:3], params[:, 3:6], params[:, 6:7], params[:, 7:10]
+    inertia, damping = params[:, 10:19].reshape(L, 3, 3), params[:, 19:20]
+    c, s = torch.cos(rpy), torch.sin(rpy)
+    one, zero = torch.ones(L, device=dev, dtype=params.dtype), torch.zeros(L, device=dev, dtype=params.dtype)
+    mat = lambda rows: torch.stack([torch.stack(r, dim=-1) for r in rows], dim=-2)
+    Rx = mat([[one, zero, zero], [zero, c[:, 0], -s[:, 0]], [zero, s[:, 0], c[:, 0]]])
+    Ry = mat([[c[:, 1], zero, s[:, 1]], [zero, one, zero], [-s[:, 1], zero, c[:, 1]]])
+    Rz = mat([[c[:, 2], -s[:, 2], zero], [s[:, 2], c[:, 2], zero], [zero, zero, one]])
+    F = (Rz @ Ry) @ Rx
+    S = mat([[zero, -com[:, 2], com[:, 1]], [com[:, 2], zero, -com[:, 0]], [-com[:, 1], com[:, 0], zero]])
+    Io = inertia + mass.reshape(L, 1, 1) * (S @ S.transpose(-2, -1))
+    return torch.cat([F.reshape(L, 9), trans, mass, com * mass, Io.reshape(L, 9), damping,
+                      torch.zeros(L, 32 - 26, device=dev, dtype=params.dtype)], dim=1)
+
+
 class LinkRows(torch.autograd.Function):
     """[n, 20] URDF-level link parameters -> [n, 32] link-table rows, with a hand-written backward: two tiny
     kernels instead of ~150 eager torch kernels per training step (the reference rebuilds these quantities with one
@@ -569,9 +592,12 @@ class LinkRows(torch.autograd.Function):
         return rows
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_rows):
         (params,) = ctx.saved_tensors
+        if torch.is_grad_enabled():      # create_graph=True: the same map through torch ops, differentiable again (link_rows_torch)
+            with torch.enable_grad():
+                (grad,) = torch.autograd.grad(link_rows_torch(params), params, grad_rows, create_graph=True)
+            return grad
         lib = library_for(params.device)
         grad_rows = grad_rows.contiguous().to(torch.float32)
         grad = torch.empty_like(params)
@@ -598,14 +624,30 @@ class WalkTable(torch.autograd.Function):
         with _on_device(dev):
             _check(lib.drm_walk_table(params.data_ptr(), n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
                                       base.numel(), ops_f.data_ptr(), _stream(dev)), lib)
-        ctx.save_for_backward(params, sel, gsign)
+        ctx.save_for_backward(params, sel, gsign, base, *pieces)
         ctx.n_links, ctx.shapes = n_links, [tuple(p.shape) for p in pieces]
         return ops_f
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_ops_f):
-        params, sel, gsign = ctx.saved_tensors
+        params, sel, gsign, base = ctx.saved_tensors[:4]
+        if torch.is_grad_enabled():
+            # create_graph=True: the gradient has to be a differentiable function of the parameters and of grad_ops_f (second
+            # derivatives with respect to learnable link parameters).  The same map, pieces -> link rows -> walk order, through
+            # torch ops (link_rows_torch) and torch's own double backward; first-order training never comes here.
+            pieces = ctx.saved_tensors[4:]
+            with torch.enable_grad():
+                packed = torch.cat([p.reshape(-1).to(device=base.device, dtype=torch.float32) for p in pieces]).reshape(ctx.n_links, 20)
+                rows = link_rows_torch(packed).reshape(-1)
+                live = sel >= 0
+                table = torch.where(live, rows[sel.clamp_min(0).long()] * gsign, base)
+                wanted = [i for i in range(len(pieces)) if ctx.needs_input_grad[4 + i]]
+                got = torch.autograd.grad(table, [pieces[i] for i in wanted], grad_ops_f.reshape(table.shape), create_graph=True,
+                                          allow_unused=True)
+            out = [None] * len(pieces)
+            for i, g in zip(wanted, got):
+                out[i] = g if g is not None else torch.zeros_like(pieces[i])
+            return (None, None, None, None) + tuple(out)
         lib = library_for(params.device)
         g = grad_ops_f.contiguous().to(torch.float32)
         grad = torch.empty_like(params)

@@ -190,30 +190,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         mcom = com * mass, I_o = I_c + mass * S(com) S(com)^T  (spatial_vector_algebra.py:321-327).
         """
         dev = self._device if device is None else device
-        bodies = [self._bodies[i] for i in link_idxs]
-        L = len(bodies)
-        cat = lambda ts, shape: torch.stack([t.reshape(shape).to(dev) for t in ts])
-        rpy = cat([b.rot_angles() for b in bodies], (3,))
-        trans = cat([b.trans() for b in bodies], (3,))
-        mass = cat([b.inertia.mass() for b in bodies], (1,))
-        com = cat([b.inertia.com() for b in bodies], (3,))
-        inertia = cat([b.inertia.inertia_mat() for b in bodies], (3, 3))
-        zero1 = torch.zeros(1, device=dev)
-        damping = cat([b.joint_damping() if b.joint_damping() is not None else zero1 for b in bodies], (1,))
-
-        c, s = torch.cos(rpy), torch.sin(rpy)
-        one, zero = torch.ones(L, device=dev), torch.zeros(L, device=dev)
-        mat = lambda rows: torch.stack([torch.stack(r, dim=-1) for r in rows], dim=-2)
-        Rx = mat([[one, zero, zero], [zero, c[:, 0], -s[:, 0]], [zero, s[:, 0], c[:, 0]]])
-        Ry = mat([[c[:, 1], zero, s[:, 1]], [zero, one, zero], [-s[:, 1], zero, c[:, 1]]])
-        Rz = mat([[c[:, 2], -s[:, 2], zero], [s[:, 2], c[:, 2], zero], [zero, zero, one]])
-        F = (Rz @ Ry) @ Rx
-        S = mat([[zero, -com[:, 2], com[:, 1]], [com[:, 2], zero, -com[:, 0]], [-com[:, 1], com[:, 0], zero]])
-        Io = inertia + mass.reshape(L, 1, 1) * (S @ S.transpose(-2, -1))
-        mcom = com * mass
-        table = torch.cat([F.reshape(L, 9), trans, mass, mcom, Io.reshape(L, 9), damping,
-                           torch.zeros(L, OPF_STRIDE - 26, device=dev)], dim=1)
-        return table.to(torch.float32)
+        rows = backend.link_rows_torch(self._link_params(link_idxs, device=dev).to(torch.float32))
+        if OPF_STRIDE != rows.shape[1]:
+            rows = torch.cat([rows, torch.zeros(rows.shape[0], OPF_STRIDE - rows.shape[1], device=dev)], dim=1)
+        return rows.to(torch.float32)
 
     def _link_table(self, fold_key: Optional[tuple] = None) -> torch.Tensor:
         """[L + 1, OPF_STRIDE] table of per-link constants (row L = the identity op used to pad walks); ``fold_key``: with
@@ -258,10 +238,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         row_b = torch.cat([Ra_t.transpose(1, 2).reshape(S, 9), zeros(3), rows[:, 12:25], zeros(OPF_STRIDE - 25)], dim=1)
         return torch.cat([base, torch.stack([row_a, row_b], dim=1).reshape(2 * S, OPF_STRIDE)], dim=0)
 
-    def _link_params(self, link_idxs) -> torch.Tensor:
+    def _link_params(self, link_idxs, device=None) -> torch.Tensor:
         """[len(link_idxs), 20] rpy, trans, mass, com, inertia_mat, damping of the given links (include/drm_hip.h
         drm_link_rows), read from the bodies' parameter callables so that gradients reach learnable modules."""
-        dev = self._device
+        dev = self._device if device is None else device
         zero1 = torch.zeros(1, device=dev)
         rows = []
         for i in link_idxs:
