@@ -9,6 +9,7 @@ here one node per public method:
     _InverseDynamics  compute_inverse_dynamics / compute_non_linear_effects           drm_rnea / drm_rnea_backward
     _MassMatrix       compute_lagrangian_inertia_matrix                               drm_crba / drm_rnea_backward per column
     _ForwardDynamics  compute_forward_dynamics (implicit differentiation)             drm_forward_dynamics / drm_rnea_backward
+    _FirstOrderOnly   marks the gradients of _FkMse computed under create_graph=True (differentiating through them raises)
     _GradLaunch       a first-order gradient launch as a differentiable node (create_graph=True: second derivatives with respect to
                       q / qd / qdd / f, the output cotangents and — round 6 — the walk's table, i.e. the learnable link parameters)
 
@@ -280,6 +281,23 @@ class _FkPositions(torch.autograd.Function):
         return grad_q, grad_ops, None, None, None, None
 
 
+class _FirstOrderOnly(torch.autograd.Function):
+    """Marks a gradient that was computed under create_graph=True by a node that has no second derivatives (the fused loss node
+    _FkMse): it is a correct FIRST-order gradient — trainers that always pass create_graph=True keep working — but differentiating
+    THROUGH it raises instead of silently contributing a part of the answer."""
+
+    @staticmethod
+    def forward(ctx, grad):
+        return grad.view_as(grad)
+
+    @staticmethod
+    def backward(ctx, _):
+        raise NotImplementedError(
+            "fk_mse_loss is a first-order node (forward kinematics, loss and gradients in one launch): for second derivatives "
+            "compose torch.nn.functional.mse_loss(model.compute_forward_kinematics(q, link)[0], target), which is differentiable "
+            "twice with respect to q and the learnable link parameters — see INTEGRATION.md, 'Second derivatives'")
+
+
 class _FkMse(torch.autograd.Function):
     """loss = mean((pos(q) - target)^2) of a chain's end link with forward kinematics, loss AND gradients from one pass over q
     (backend.fk_mse, csrc/drm_fk_backward.hip MSE form): the forward call already holds d loss / d q and d loss / d ops_f, the
@@ -295,15 +313,20 @@ class _FkMse(torch.autograd.Function):
         return loss
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
         saved = list(ctx.saved_tensors)
         grad_q = saved.pop(0) if ctx.have[0] else None
         grad_ops = saved.pop(0) if ctx.have[1] else None
-        if grad_q is not None:
-            grad_q = (grad_q * grad_loss).to(ctx.q_dtype).reshape(ctx.q_shape)
-        if grad_ops is not None:
-            grad_ops = grad_ops * grad_loss
+        second = torch.is_grad_enabled()          # create_graph=True: first-order gradients that say so when differentiated again
+        with torch.no_grad():
+            if grad_q is not None:
+                grad_q = (grad_q * grad_loss).to(ctx.q_dtype).reshape(ctx.q_shape)
+            if grad_ops is not None:
+                grad_ops = grad_ops * grad_loss
+        if second:
+            with torch.enable_grad():
+                grad_q = _FirstOrderOnly.apply(grad_q.requires_grad_(True)) if grad_q is not None else None
+                grad_ops = _FirstOrderOnly.apply(grad_ops.requires_grad_(True)) if grad_ops is not None else None
         return grad_q, None, grad_ops, None, None, None
 
 
