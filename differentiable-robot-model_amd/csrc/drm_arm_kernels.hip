@@ -160,6 +160,10 @@ int64_t launch_fk_arm(const drm_walk *w, const float *q, int64_t B, float *pos, 
 }
 
 
+#ifndef DRM_STREAM_CHUNK_TILES
+#define DRM_STREAM_CHUNK_TILES (1 << 15) /* 2^21 rows = 470 MB of outputs per launch */
+#endif
+constexpr int STREAM_CHUNK_TILES = DRM_STREAM_CHUNK_TILES;
 #ifndef DRM_PRE_MAX_TILES
 #define DRM_PRE_MAX_TILES 2048 /* 256 CUs x 4 SIMDs x 2 waves */
 #endif
@@ -167,9 +171,18 @@ constexpr int PRE_MAX_TILES = DRM_PRE_MAX_TILES;
 void launch_fk_jacobian_arm(const float *ops_f, const float *q, int n_tiles, float *pos, float *quat, float *lin_jac,
                             float *ang_jac, hipStream_t s) {
     if (stream_past_llc((int64_t)n_tiles * WAVE * 4 * (7 + 6 * 7))) {
+        // outputs streamed past the Infinity Cache.  Launches of more than STREAM_CHUNK_TILES tiles go as back-to-back launches of that
+        // many over slices of the same arrays (round 6): one launch over 2^24 rows (3.8 GB) streamed at 0.67 of the HBM peak, the same
+        // rows as eight launches of 2^21 at 0.78 (profiles/r06_probe_chunks.txt: the wavefronts of a launch then work inside a 0.5 GB
+        // window instead of all over the allocation); a kernel boundary costs ~2 us of a ~75 us chunk
         constexpr int WPB = MAX_WAVES_PER_BLOCK;
-        hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, WPB, true>), dim3((unsigned)((n_tiles + WPB - 1) / WPB)),
-                           dim3(WAVE * WPB), 0, s, ops_f, q, n_tiles, pos, quat, lin_jac, ang_jac);
+        for (int t0 = 0; t0 < n_tiles; t0 += STREAM_CHUNK_TILES) {
+            const int nt = n_tiles - t0 < STREAM_CHUNK_TILES + STREAM_CHUNK_TILES / 2 ? n_tiles - t0 : STREAM_CHUNK_TILES;   // (no short last chunk)
+            const int64_t r0 = (int64_t)t0 * WAVE;
+            hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, WPB, true>), dim3((unsigned)((nt + WPB - 1) / WPB)), dim3(WAVE * WPB), 0, s,
+                               ops_f, q + r0 * 7, nt, pos + r0 * 3, quat + r0 * 4, lin_jac + r0 * 21, ang_jac + r0 * 21);
+            if (nt != STREAM_CHUNK_TILES) break;
+        }
     } else if (n_tiles <= PRE_MAX_TILES) { // at most two waves per SIMD: the register-resident table
         hipLaunchKernelGGL((fk_jacobian_arm_kernel<8, 7, true, 1, false, true>), dim3((unsigned)n_tiles), dim3(WAVE), 0, s, ops_f, q,
                            n_tiles, pos, quat, lin_jac, ang_jac);

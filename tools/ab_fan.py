@@ -14,7 +14,9 @@ idx = [h._name_to_idx_map[t] for t in TIPS]
 tag = os.path.basename(os.environ.get("DRM_HIP_LIBRARY", "libdrm_hip.so"))
 for B in (65536, 1 << 18):
     q = sample(h, B)[0].cuda()
-    with torch.no_grad():
-        t_links = graph_time(lambda: h.compute_forward_kinematics_links(q, TIPS), launches=100, reps=7)
-        t_rows = graph_time(lambda: h._fk_targets(q, idx), launches=100, reps=7)
-    print("%-22s B=%8d  fk 4 tips link-major %7.2f us   sample-major %7.2f us" % (tag, B, t_links, t_rows), flush=True)
+    for mode, what in (("off", "library kernels"), (None, "default (own kernel)")):      # round 6: a model runs its own kernels by default
+        h.own_kernels = mode
+        with torch.no_grad():
+            t_links = graph_time(lambda: h.compute_forward_kinematics_links(q, TIPS), launches=100, reps=7)
+            t_rows = graph_time(lambda: h._fk_targets(q, idx), launches=100, reps=7)
+        print("%-22s B=%8d  %-22s fk 4 tips link-major %7.2f us   sample-major %7.2f us" % (tag, B, what, t_links, t_rows), flush=True)

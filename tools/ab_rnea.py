@@ -26,7 +26,9 @@ def graph_time(fn, launches=100, reps=5):
 def main():
     m = load("panda_no_gripper"); link = "panda_virtual_ee_link"
     tag = os.path.basename(os.environ.get("DRM_HIP_LIBRARY", "libdrm_hip.so"))
-    for B in (65536, 131072, 1 << 20):
+    for B, mode in ((65536, "off"), (65536, None), (131072, "off"), (131072, None), (1 << 20, "off"), (1 << 20, None)):
+        m.own_kernels = mode          # round 6: "off" = the library's kernels, None = the default (the arm's own kernels)
+        tag = "library" if mode == "off" else "default (own kernels)"
         q, qd, qdd = (t.cuda() for t in sample(m, B))
         p_id = m.plan_inverse_dynamics(q, qd, qdd)
         p_fu = m.plan_fk_and_inverse_dynamics(q, qd, qdd, link)

@@ -24,13 +24,13 @@ def graph_time(fn, launches=100, reps=5):
     return best
 
 
-# executed flops per evaluation from the ISA (tools/flop_count.py -> profiles/r05_flops.json); DRM_SPECIALIZE=1: the robot's own kernels
+# executed flops per evaluation from the ISA (tools/flop_count.py -> profiles/r05_flops.json); the robot's own kernels by default (round 6), DRM_SPECIALIZE=0: the library's
 import json
 try:
     FLOPS = json.load(open(os.path.join(ROOT, "profiles", "r05_flops.json")))["kernels"]
 except OSError:
     FLOPS = {}
-OWN = os.environ.get("DRM_SPECIALIZE") in ("1", "tune")
+OWN = os.environ.get("DRM_SPECIALIZE") != "0"      # (round 6: the robots' own kernels are the default; DRM_SPECIALIZE=0: the library's)
 
 
 def bound(what, B, us, nbytes):

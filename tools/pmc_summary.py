@@ -104,7 +104,15 @@ if st:      # round 4: the kernels of BASELINE configurations 2-5 (tools/kernel_
     shutil.copy(st[0], os.path.join(prof, tag + "_configs_kernel_stats.csv"))
 for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", "_ab_rnea_final.txt"), ("io_floors_2p20.txt", "_io_floors_2p20.txt"),
                  ("probe_api.txt", "_probe_api.txt"), ("probe_special.txt", "_probe_special.txt"), ("api_latency.txt", "_api_latency.txt"),
-                 ("ab_fan.txt", "_ab_fan_final.txt"), ("timeline.txt", "_timeline.txt")):
+                 ("ab_fan.txt", "_ab_fan_final.txt"), ("timeline.txt", "_timeline.txt"),
+                 ("ab_learnable_arm.txt", "_ab_learnable_arm.txt"), ("probe_chunks.txt", "_probe_chunks.txt"),
+                 ("probe_nonfinite.txt", "_probe_nonfinite.txt"),
+                 # round 6: bench.py's stdout is the compact line; the full records of the runs
+                 ("bench_default_detail.json", "_bench_default_detail.json"), ("bench_k20_detail.json", "_bench_k20_detail.json"),
+                 ("bench_config3_detail.json", "_bench_config3_detail.json"),
+                 ("bench_config3_p2p_two_ranks_shared_gpu_detail.json", "_bench_config3_p2p_two_ranks_shared_gpu_detail.json"),
+                 ("bench_config3_two_ranks_shared_gpu_detail.json", "_bench_config3_two_ranks_shared_gpu_detail.json"),
+                 ("bench_metric_two_ranks_shared_gpu_detail.json", "_bench_metric_two_ranks_shared_gpu_detail.json")):
     if os.path.exists(os.path.join(OUT, src)):
         shutil.copy(os.path.join(OUT, src), os.path.join(prof, tag + dst))
 if os.path.exists(os.path.join(OUT, "overhead_under_rocprofv3.txt")):

@@ -12,13 +12,16 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-traffic"
+B="python $ROOT/bench.py --no-cpu-baseline --no-traffic --detail /dev/null"
 BM="$B --no-configs"   # the metric leg alone (counter passes, per-batch stats)
-python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
-python $ROOT/bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.err
-python $ROOT/bench.py --gpus 2 --config 3 --gather all --steps 20 --warmup 5 --shared-gpu --verify-gather --no-cpu-baseline > $OUT/bench_config3_two_ranks_shared_gpu.json 2> $OUT/bench_config3_two_ranks.err
-python $ROOT/bench.py --gpus 2 --gather --steps 20 --warmup 5 --shared-gpu --verify-gather --no-large --no-cpu-baseline > $OUT/bench_metric_two_ranks_shared_gpu.json 2> $OUT/bench_metric_two_ranks.err
+# round 6: stdout of bench.py is ONE compact line (< 4 KB); the full record goes to --detail.  The default run here is the FULL one
+# (--configs full: the reference beside every leg, counter traffic per leg); the driver's own form (k20) runs the fast legs
+( time python $ROOT/bench.py --configs full --detail $OUT/bench_default_detail.json ) > $OUT/bench_default.json 2> $OUT/bench_default.err
+( time python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --detail $OUT/bench_k20_detail.json ) > $OUT/bench_k20.json 2> $OUT/bench_k20.err
+python $ROOT/bench.py --config 3 --detail $OUT/bench_config3_detail.json > $OUT/bench_config3.json 2> $OUT/bench_config3.err
+python $ROOT/bench.py --gpus 2 --config 3 --gather all --steps 20 --warmup 5 --shared-gpu --verify-gather --no-cpu-baseline --detail $OUT/bench_config3_two_ranks_shared_gpu_detail.json > $OUT/bench_config3_two_ranks_shared_gpu.json 2> $OUT/bench_config3_two_ranks.err
+python $ROOT/bench.py --gpus 2 --config 3 --gather p2p --steps 20 --warmup 5 --shared-gpu --verify-gather --no-cpu-baseline --detail $OUT/bench_config3_p2p_two_ranks_shared_gpu_detail.json > $OUT/bench_config3_p2p_two_ranks_shared_gpu.json 2> $OUT/bench_config3_p2p_two_ranks.err
+python $ROOT/bench.py --gpus 2 --gather --steps 20 --warmup 5 --shared-gpu --verify-gather --no-large --no-cpu-baseline --detail $OUT/bench_metric_two_ranks_shared_gpu_detail.json > $OUT/bench_metric_two_ranks_shared_gpu.json 2> $OUT/bench_metric_two_ranks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $B > $OUT/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_k20 -- $B --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_k20.log 2>&1
 # one stats file per batch size; 65 536 also launched eagerly (graph replays report the tracer's own period, r03_rocprof_overhead.md)
@@ -32,7 +35,7 @@ for batch in 65536 4194304; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$batch -- $BM --no-large --steps 50 --warmup 5 --batch $batch > $OUT/prof_write_$batch.log 2>&1
 done
 PMC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
-rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 131072 1048576 > $OUT/prof_sq.log 2>&1
+DRM_SPECIALIZE=0 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq -- python $ROOT/tools/kernel_bench.py hot 65536 131072 1048576 > $OUT/prof_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq_cfg -- python $ROOT/tools/kernel_bench.py configs > $OUT/prof_sq_cfg.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -- python $ROOT/tools/kernel_bench.py configs > $OUT/prof_cfg.log 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq3 -- python $ROOT/tools/kernel_bench.py hand 65536 > $OUT/prof_sq3.log 2>&1
@@ -42,16 +45,19 @@ done
 for r in panda_no_gripper panda allegro_left iiwa7_allegro; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq5_$r -- python $ROOT/tools/kernel_bench.py backward $r 262144 > $OUT/prof_sq5_$r.log 2>&1
 done
-# round 5: the robots' OWN kernels (model.specialize(): constants folded in; DRM_SPECIALIZE=1 attaches them on first use) — SQ counters,
-# which kernel every entry point dispatches to, and the timings beside the library's
-DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_hot -- python $ROOT/tools/kernel_bench.py hot 131072 1048576 > $OUT/prof_sq6_hot.log 2>&1
-DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_dyn -- python $ROOT/tools/kernel_bench.py dynamics panda_no_gripper 262144 > $OUT/prof_sq6_dyn.log 2>&1
-DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_bwd -- python $ROOT/tools/kernel_bench.py backward panda_no_gripper 262144 > $OUT/prof_sq6_bwd.log 2>&1
-DRM_SPECIALIZE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all_own -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all_own.log 2>&1
-DRM_SPECIALIZE=1 python $ROOT/tools/kernel_times.py 2>&1 | grep -v amdgpu.ids > $OUT/kernel_times_own.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
+# the robots' OWN kernels (constants folded in; round 6: what a plain model runs by default, DRM_SPECIALIZE=0 switches them off) — SQ
+# counters, which kernel every entry point dispatches to, and the timings beside the library's
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_hot -- python $ROOT/tools/kernel_bench.py hot 131072 1048576 > $OUT/prof_sq6_hot.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_dyn -- python $ROOT/tools/kernel_bench.py dynamics panda_no_gripper 262144 > $OUT/prof_sq6_dyn.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/prof_sq6_bwd -- python $ROOT/tools/kernel_bench.py backward panda_no_gripper 262144 > $OUT/prof_sq6_bwd.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all_own -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all_own.log 2>&1
+python $ROOT/tools/kernel_times.py 2>&1 | grep -v amdgpu.ids > $OUT/kernel_times_own.txt
+DRM_SPECIALIZE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_all -- python $ROOT/tools/kernel_times.py 65536 1048576 > $OUT/prof_all.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
-python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
+DRM_SPECIALIZE=0 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
+for r in iiwa7 panda_no_gripper; do python $ROOT/tools/ab_learnable_arm.py $r 2>&1 | grep -v amdgpu.ids; done > $OUT/ab_learnable_arm.txt
+python $ROOT/tools/probe_chunks.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_chunks.txt
+python $ROOT/tools/probe_nonfinite.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|return Diff" > $OUT/probe_nonfinite.txt
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
 python $ROOT/tools/ab_rnea.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_rnea.txt
 for b in 1048576 65536; do python $ROOT/tools/probe_api.py $b 2>&1 | grep "B="; done > $OUT/probe_api.txt

@@ -166,6 +166,129 @@ __global__ void __launch_bounds__(64 * WPB) fkj_lane_kernel(const float *__restr
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// round 6: the two forms of the lone-wave regime that had not been tried
+//   rows<ROWS>  ROWS-row tiles (32 / 16): 64 / ROWS times as many wavefronts, each with ROWS live lanes — two / four
+//               part-populated wavefronts per SIMD overlapping each other's waits (a wave64 instruction takes four
+//               cycles whatever its EXEC mask, so the issue work of the launch grows by 64 / ROWS)
+//   split       a block of TWO wavefronts per 64-row tile: both walk the chain (redundantly: the issue slots of a lone
+//               wave are 78 % idle), wave 0 stores ang_jac and the quaternion, wave 1 lin_jac and the position — each
+//               wave's post-chain tail and store burst are half as long
+// ---------------------------------------------------------------------------------------------------------------
+template <int FL, int ROWS>
+__global__ void __launch_bounds__(64) fkj_rows_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
+                                                      float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
+                                                      float *__restrict__ ang) {
+    constexpr int CAP = 8, NJ = 7, SJ = 3 * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, P_FLOATS = round4(WAVE * 3), J_FLOATS = round4(WAVE * SJ);
+    __shared__ __attribute__((aligned(16))) float smem[C_FLOATS + P_FLOATS + 2 * J_FLOATS];
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned row = lane < (unsigned)ROWS ? lane : (unsigned)ROWS - 1u;      // idle lanes shadow the last live row (no stores)
+    float *lc = smem, *lp = lc + C_FLOATS, *ll = lp + P_FLOATS, *la = ll + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float qv[NJ];
+    {
+        const float *qr = q + (b0 + row) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = qr[d];
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    PoseP ee;
+    f2 Bk[NJ][3];
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+        float *arow = la + lane * SJ;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) { arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0]; }
+        wave_lds_sync();
+        image_store<FL, ROWS * SJ / 4>(ang + b0 * SJ, la, lane);
+    });
+    const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+    float *lrow = ll + lane * SJ;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+        const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+        float c[3];
+        cross3(z, dp, c);
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+    }
+    lp[lane * 3 + 0] = pe[0]; lp[lane * 3 + 1] = pe[1]; lp[lane * 3 + 2] = pe[2];
+    wave_lds_sync();
+    image_store<FL, ROWS * SJ / 4>(lin + b0 * SJ, ll, lane);
+    image_store<FL, ROWS * 3 / 4>(pos + b0 * 3, lp, lane);
+    Pose E;
+    float qt[4];
+    pose_from_pairs(ee, E);
+    quat_xyzw(E.R, qt);
+    if (lane < (unsigned)ROWS) store16<FL>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+}
+
+template <int FL>
+__global__ void __launch_bounds__(128) fkj_split_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, int n_tiles,
+                                                        float *__restrict__ pos, float *__restrict__ quat, float *__restrict__ lin,
+                                                        float *__restrict__ ang) {
+    constexpr int CAP = 8, NJ = 7, SJ = 3 * NJ;
+    constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, J_FLOATS = round4(WAVE * SJ), P_FLOATS = round4(WAVE * 3);
+    constexpr int PER_WAVE = C_FLOATS + J_FLOATS + P_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * PER_WAVE];
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0: ang_jac + quat, 1: lin_jac + pos
+    const int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    const unsigned lane = threadIdx.x & 63u;
+    float *lc = smem + role * PER_WAVE, *lj = lc + C_FLOATS, *lp = lj + J_FLOATS;
+    const int64_t b0 = (int64_t)tile * WAVE;
+    float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float qv[NJ];
+    {
+        const float *qr = q + (b0 + lane) * NJ;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = qr[d];
+    }
+    pin(cv);
+    reinterpret_cast<float4 *>(lc)[lane] = cv;
+    wave_lds_sync();
+    PoseP ee;
+    f2 Bk[NJ][3];
+    fk_chain_pairs<CAP, NJ>([&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv, ee, Bk, [&]() {
+        if (role == 0) {
+            float *arow = lj + lane * SJ;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) { arow[k] = Bk[k][0][0]; arow[NJ + k] = Bk[k][1][0]; arow[2 * NJ + k] = Bk[k][2][0]; }
+            wave_lds_sync();
+            image_store<FL, 16 * SJ>(ang + b0 * SJ, lj, lane);
+        }
+    });
+    if (role == 0) {
+        Pose E;
+        float qt[4];
+        pose_from_pairs(ee, E);
+        quat_xyzw(E.R, qt);
+        store16<FL>(quat + (b0 + lane) * 4, make_float4(qt[0], qt[1], qt[2], qt[3]));
+    } else {
+        const float pe[3] = {ee.B[0][1], ee.B[1][1], ee.B[2][1]};
+        float *lrow = lj + lane * SJ;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const float z[3] = {Bk[k][0][0], Bk[k][1][0], Bk[k][2][0]};
+            const float dp[3] = {pe[0] - Bk[k][0][1], pe[1] - Bk[k][1][1], pe[2] - Bk[k][2][1]};
+            float c[3];
+            cross3(z, dp, c);
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+            lrow[k] = c[0]; lrow[NJ + k] = c[1]; lrow[2 * NJ + k] = c[2];
+        }
+        lp[lane * 3 + 0] = pe[0]; lp[lane * 3 + 1] = pe[1]; lp[lane * 3 + 2] = pe[2];
+        wave_lds_sync();
+        image_store<FL, 16 * SJ>(lin + b0 * SJ, lj, lane);
+        image_store<FL, 48>(pos + b0 * 3, lp, lane);
+    }
+}
+
 // lane kernel v2: the end position first (B pairs of the trailing fixed link), Jacobians staged together and stored
 // back to back, the end ORIENTATION (only the quaternion needs it) afterwards
 template <int FL, int WPB>
@@ -681,6 +804,22 @@ int main(int argc, char **argv) {
     LANE2(ST_SC1NT, 4, "lane2 sc1nt wpb4")
     LANE2(ST_SC1NT, 1, "lane2 sc1nt wpb1")
     LANE2(ST_PLAIN, 4, "lane2 plain wpb4")
+#define ROWSK(ROWS, NAME)                                                                                                \
+    {                                                                                                                    \
+        auto l = [&] { hipLaunchKernelGGL((fkj_rows_kernel<ST_SC1, ROWS>), dim3(n_tiles * (64 / ROWS)), dim3(64), 0, s, b.ops_f, b.q,        \
+                                          n_tiles * (64 / ROWS), b.pos, b.quat, b.lin, b.ang); };                                        \
+        clear(b); l(); CK(hipStreamSynchronize(s)); check(NAME, ref, fetch(b));                                          \
+        time_graph(NAME, l, s);                                                                                          \
+    }
+    ROWSK(64, "rows 64 (the lane kernel, 1 wave per tile)")
+    ROWSK(32, "rows 32: two half-populated waves per SIMD")
+    ROWSK(16, "rows 16: four quarter-populated waves per SIMD")
+    {
+        auto l = [&] { hipLaunchKernelGGL((fkj_split_kernel<ST_SC1>), dim3(n_tiles), dim3(128), 0, s, b.ops_f, b.q, n_tiles, b.pos, b.quat,
+                                          b.lin, b.ang); };
+        clear(b); l(); CK(hipStreamSynchronize(s)); check("split: 2 waves per tile", ref, fetch(b));
+        time_graph("split: 2 waves per tile (ang+quat | lin+pos)", l, s);
+    }
 #define IO(FL, RD, WR, NAME) time_graph(NAME, [&] { hipLaunchKernelGGL((k_io<FL, RD, WR>), dim3((n_tiles + 3) / 4), dim3(256), 0, s, b.q, n_tiles, b.pos, b.quat, b.lin, b.ang); }, s);
     IO(ST_PLAIN, true, true, "io plain rd+wr")
     IO(ST_SC1, true, true, "io sc1 rd+wr")
