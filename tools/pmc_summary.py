@@ -137,8 +137,12 @@ for batch in (65536, 4194304):
         alg = 224 * batch
         fetch = rec["FETCH_SIZE_KiB_mean"] * 1024 * 2   # gfx950 correction
         write = rec["WRITE_SIZE_KiB_mean"] * 1024
-        rec.update(fetch_bytes_corrected=fetch, write_bytes=write, traffic_bytes_per_launch=fetch + write,
-                   algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(fetch + write) / alg)
+        # round 6: a launch whose outputs exceed the Infinity Cache goes as chunks of 2^21 rows (csrc/drm_arm_kernels.hip
+        # STREAM_CHUNK_TILES): the counters are per dispatch, a "launch" of the API is `chunks` of them
+        chunks = batch // (1 << 21) if batch * 196 > 256 * 1024 * 1024 and batch > (1 << 21) else 1
+        rec.update(fetch_bytes_corrected=fetch * chunks, write_bytes=write * chunks, traffic_bytes_per_launch=(fetch + write) * chunks,
+                   dispatches_per_launch=chunks, algorithmic_bytes_per_launch=alg,
+                   traffic_over_algorithmic=(fetch + write) * chunks / alg)
         traffic["per_batch"][str(batch)] = rec
 with open(os.path.join(prof, tag + "_pmc_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
