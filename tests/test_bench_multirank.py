@@ -112,7 +112,9 @@ def test_config3_two_ranks_sharing_the_gpu_gather_equals_one_launch():
     # round 6: the one-sided gather (drm_fk_rnea_put + distributed.PeerGather: IPC-mapped peer buffers, the stores leave from the
     # fused kernel's epilogue) — verified bit for bit with the collectives above (gather_verified), one launch per step, and far
     # cheaper than a host-staged collective even with both ranks on one device
-    assert modes["p2p"]["one_sided"] is True and modes["p2p"]["hipgraph"] is True and line["one_sided_gather"]["in_kernel"] is True
+    assert modes["p2p"]["one_sided"] is True and modes["p2p"]["hipgraph"] is True
+    assert line["one_sided_gather"]["in_kernel"] is bool(line["own_kernel"])      # (the arm's own fused kernel stores to the peers itself;
+    assert line["own_kernel"] == "default" or os.environ.get("DRM_SPECIALIZE") == "0"   # under DRM_SPECIALIZE=0: compute, then copies)
     assert modes["p2p"]["step_us_device"] < 0.2 * modes["all"]["step_us_device"]
     assert modes["tau"]["gather_bytes_per_rank"] == rows * 28 and modes["none"]["gather_bytes_per_rank"] == 0
     assert modes["none"]["value"] >= modes["all"]["value"] and modes["all"]["gather_model_us"] > modes["tau"]["gather_model_us"] > 0
