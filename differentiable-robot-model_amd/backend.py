@@ -840,6 +840,21 @@ class FkJacobianPlan(object):
         if rc != 0:
             _check(rc, self._lib)
 
+    def launch_many(self, k: int, stream=None):
+        """k back-to-back launches enqueued from C++ (csrc/drm_hostcall.cpp repeat_fk_jacobian: ~2 us of host time per launch, less
+        than the kernel takes, so the device never waits for the host) — what a compiled caller's loop does; the Python loop over
+        `launch` when the host-call module is not built."""
+        fast = hostcall()
+        if fast is None or self.pos is None:
+            for _ in range(k):
+                self.launch(stream)
+            return
+        st = 0 if self.device.type == "cpu" else (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        rc = fast.repeat_fk_jacobian(_fn_addr(self._lib, "drm_fk_jacobian"), ctypes.addressof(self._walk), self.q.data_ptr(), self.batch,
+                                     self.pos.data_ptr(), self.quat.data_ptr(), self.lin.data_ptr(), self.ang.data_ptr(), st, int(k))
+        if rc != 0:
+            _check(rc, self._lib)
+
     def outputs(self):
         return self.pos, self.quat, self.lin, self.ang
 

@@ -71,6 +71,49 @@ __device__ __forceinline__ void forward_dynamics_arm_static_body(ROW row, const 
     tile_store<NJ>(qdd + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
 }
 
+// forward dynamics, TWO SAMPLES PER LANE (round 6): one wavefront per 128-row pair of tiles, rows l and l + 64 in the two halves of
+// every register pair — bias torques (rnea_chain2_trig, qdd = 0), H (crba_chain2_trig), L^T D L solve, all on pairs
+template <int NJ, int LINKS, class ROW>
+__device__ __forceinline__ void forward_dynamics_arm2_static_body(ROW row, const float *__restrict__ q, const float *__restrict__ qd,
+                                                                  const float *__restrict__ f, int n_pairs, int flags,
+                                                                  float *__restrict__ qdd) {
+    static_assert(NJ & 1, "odd row width (linear LDS image)");
+    __shared__ __attribute__((aligned(16))) float lq[round4(STREAM_TILE * NJ)];
+    const int pair = (int)blockIdx.x;
+    if (pair >= n_pairs) return;
+    const unsigned lane = threadIdx.x;
+    const int64_t b0 = (int64_t)pair * STREAM_TILE;
+    f2 qv[NJ], qdv[NJ], rhs[NJ], zero[NJ], nle[NJ];
+    {
+        float a[NJ], b[NJ];
+        lane_row<NJ>(q, b0 + lane, a); lane_row<NJ>(q, b0 + WAVE + lane, b);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = f2_make(a[d], b[d]);
+        lane_row<NJ>(qd, b0 + lane, a); lane_row<NJ>(qd, b0 + WAVE + lane, b);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qdv[d] = f2_make(a[d], b[d]);
+        lane_row<NJ>(f, b0 + lane, a); lane_row<NJ>(f, b0 + WAVE + lane, b);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) { rhs[d] = f2_make(a[d], b[d]); zero[d] = f2_bcast(0.0f); }
+    }
+    f2 cs[NJ], sn[NJ];
+    chain_trig2<NJ>(qv, cs, sn);
+    rnea_chain2_trig<LINKS, NJ, LINKS - 1, false>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, cs, sn, qdv, zero, nle,
+                                                 [](int, const Force2 &) {}, [](int, Force2 &) {});
+    f2 Ht[NJ * (NJ + 1) / 2];
+    crba_chain2_trig<LINKS, NJ>(row, cs, sn, [&](int i, int j, f2 v) { Ht[tri_index(i, j)] = v; });
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) rhs[d] -= nle[d];
+    ltdl_solve_unrolled<NJ, f2>(Ht, rhs);
+#pragma unroll
+    for (int d = 0; d < NJ; ++d) {
+        lq[lane * NJ + d] = rhs[d][0];
+        lq[(WAVE + lane) * NJ + d] = rhs[d][1];
+    }
+    wave_lds_sync();
+    tile_store<2 * NJ>(qdd + b0 * NJ, WAVE, 2 * NJ, 0u, lq, lane, true);
+}
+
 template <int NJ, int LINKS, class ROW>
 __device__ __forceinline__ void rnea_backward_arm_static_body(ROW row, const float *__restrict__ q, const float *__restrict__ qd,
                                                               const float *__restrict__ qdd, const float *__restrict__ gtau,

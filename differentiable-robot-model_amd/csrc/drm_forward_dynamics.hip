@@ -449,6 +449,21 @@ extern "C" int drm_forward_dynamics(const drm_walk *w, const float *q, const flo
         (((uintptr_t)q | (uintptr_t)qd | (uintptr_t)f | (uintptr_t)qdd | (uintptr_t)w->ops_f) & 15u) == 0) {
         // 7-DoF arms: full tiles through the register-resident chain kernel, ragged tail through the generic one
         int n_tiles = (int)(B / WAVE);
+        if (w->special[DRM_SPECIAL_FD_ARM2] && w->special[DRM_SPECIAL_FD_ARM] && n_tiles / 2 >= DRM_ARM_STATIC_MIN_PAIRS) {
+            // ABI 11: two samples per lane for the pairs of tiles of a large launch (issue-bound: a third fewer instructions per
+            // sample); an odd last tile and the ragged tail follow through the forms below
+            int n_pairs = n_tiles / 2, fl = (int)flags;
+            void *args[] = {(void *)&q, (void *)&qd, (void *)&f, (void *)&n_pairs, (void *)&fl, (void *)&qdd};
+            hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_FD_ARM2], (unsigned)n_pairs, 1, 1, WAVE, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+            if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_fd_arm2_static): %s", hipGetErrorString(e));
+            const int64_t done2 = (int64_t)n_pairs * 2 * WAVE;
+            if (done2 == B) return launched();
+            rc = launched();
+            if (rc) return rc;
+            drm_walk rest = *w;
+            rest.special[DRM_SPECIAL_FD_ARM2] = nullptr;
+            return drm_forward_dynamics(&rest, q + done2 * n, qd + done2 * n, f + done2 * n, B - done2, flags, qdd + done2 * n, scratch, stream);
+        }
         const dim3 grid((unsigned)((n_tiles + MAX_WAVES_PER_BLOCK - 1) / MAX_WAVES_PER_BLOCK)), block(WAVE * MAX_WAVES_PER_BLOCK);
         if (w->special[DRM_SPECIAL_FD_ARM]) {
             // this arm's own kernel, its constants folded into the instruction stream (csrc/drm_arm_static.hpp, specialize.py)

@@ -2679,16 +2679,17 @@ DRM_HD void ltdl_solve(int n, float *H, float *b) {
 
 // The same factorisation and solves for a compile-time size, fully unrolled: H (packed lower triangle) and b live
 // in registers (the arm kernels: n = 7, 28 + 7 floats).
-template <int N>
-DRM_HD void ltdl_solve_unrolled(float (&H)[N * (N + 1) / 2], float (&b)[N]) {
+DRM_HD f2 recip_f(f2 x) { return f2_make(recip_f(x[0]), recip_f(x[1])); }      // (two samples per lane)
+template <int N, class T = float>
+DRM_HD void ltdl_solve_unrolled(T (&H)[N * (N + 1) / 2], T (&b)[N]) {
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
-        const float inv = recip_f(H[tri_index(k, k)]);
+        const T inv = recip_f(H[tri_index(k, k)]);
         H[tri_index(k, k)] = inv;
 #pragma unroll
         for (int i = 0; i < k; ++i) {
-            const float hki = H[tri_index(k, i)];
-            const float a = hki * inv;
+            const T hki = H[tri_index(k, i)];
+            const T a = hki * inv;
 #pragma unroll
             for (int j = 0; j < i; ++j) H[tri_index(i, j)] -= hki * H[tri_index(k, j)];
             H[tri_index(i, i)] -= hki * a;
@@ -2702,10 +2703,103 @@ DRM_HD void ltdl_solve_unrolled(float (&H)[N * (N + 1) / 2], float (&b)[N]) {
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        float t = b[i] * H[tri_index(i, i)];
+        T t = b[i] * H[tri_index(i, i)];
 #pragma unroll
         for (int j = 0; j < i; ++j) t -= H[tri_index(i, j)] * b[j];
         b[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Joint-space inertia matrix of a serial chain, TWO SAMPLES PER LANE (round 6): crba_chain_trig on sample pairs — a pair is the
+// same quantity of rows b and b + 64 of a 128-row tile, the link constants enter as broadcast operands, every instruction of the
+// per-sample walk is a full v_pk_*_f32 (the form that took inverse dynamics from 1 126 to 780 VALU per 64 rows; forward dynamics =
+// this + rnea_chain2_trig + the L^T D L solve on pairs).  Same formulas, same association order as the one-sample walk.
+//   row(k) -> op k's constant row;   cs / sn: [d] = (sample A, sample B);   hout(i, j, f2) for i >= j (the lower triangle)
+// ---------------------------------------------------------------------------
+struct Inertia2 {
+    float m;     // the sub-tree's mass: a constant of the robot, the same for both samples
+    f2 h[3];     // first moment
+    f2 I[6];     // xx xy xz yy yz zz about the link origin
+};
+// inertia_to_parent on sample pairs: x_p = J x_c + t with J = (c0 | c1 | F[:, 2])
+DRM_HD void inertia2_to_parent(const Joint2 &J, const float *F, const float *t, const Inertia2 &c, Inertia2 &out) {
+    f2 g[3], M[9], w[3];
+    joint2_N(J, F, c.h, g);
+    const f2 If[9] = {c.I[0], c.I[1], c.I[2], c.I[1], c.I[3], c.I[4], c.I[2], c.I[4], c.I[5]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[r * 3 + k] = J.c0[r] * If[0 * 3 + k] + J.c1[r] * If[1 * 3 + k] + f2_bcast(F[r * 3 + 2]) * If[2 * 3 + k];
+    auto R = [&](int r, int k) { return M[r * 3 + 0] * J.c0[k] + M[r * 3 + 1] * J.c1[k] + M[r * 3 + 2] * f2_bcast(F[k * 3 + 2]); };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = g[i] + f2_bcast(0.5f * c.m * t[i]);
+    const f2 wt2 = f2_bcast(2.0f) * (w[0] * f2_bcast(t[0]) + w[1] * f2_bcast(t[1]) + w[2] * f2_bcast(t[2]));
+    out.I[0] = R(0, 0) + (wt2 - f2_bcast(2.0f * t[0]) * w[0]);
+    out.I[1] = R(0, 1) - (w[0] * f2_bcast(t[1]) + f2_bcast(t[0]) * w[1]);
+    out.I[2] = R(0, 2) - (w[0] * f2_bcast(t[2]) + f2_bcast(t[0]) * w[2]);
+    out.I[3] = R(1, 1) + (wt2 - f2_bcast(2.0f * t[1]) * w[1]);
+    out.I[4] = R(1, 2) - (w[1] * f2_bcast(t[2]) + f2_bcast(t[1]) * w[2]);
+    out.I[5] = R(2, 2) + (wt2 - f2_bcast(2.0f * t[2]) * w[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.h[i] = g[i] + f2_bcast(c.m * t[i]);
+    out.m = c.m;
+}
+template <int CAP, int NJ, class ROW, class HOUT>
+DRM_HD void crba_chain2_trig(ROW row, const f2 (&cs)[NJ], const f2 (&sn)[NJ], HOUT hout) {
+    Joint2 J[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const OpFT o = load_ft(row(k));
+        if (k < NJ) joint2_moving(o.F, cs[k], sn[k], J[k]);
+        else joint2_fixed(o.F, J[k]);
+    }
+    Inertia2 carry;
+    carry.m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) carry.h[i] = f2_bcast(0.0f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) carry.I[i] = f2_bcast(0.0f);
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = row(k);
+        Inertia2 tot;
+        tot.m = of[DRM_OPF_MASS];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot.h[i] = f2_bcast(of[DRM_OPF_MCOM + i]);
+        const int at[6] = {0, 1, 2, 4, 5, 8};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tot.I[i] = f2_bcast(of[DRM_OPF_IO + at[i]]);
+        if (k < CAP - 1) {
+            tot.m += carry.m;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.h[i] += carry.h[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tot.I[i] += carry.I[i];
+        }
+        if (k < NJ) {      // F = Ic S_k with S_k = (ang e_z, lin 0):  f = (-h_y, h_x, 0),  n = I e_z
+            Force2 F;
+            F.f[0] = f2_bcast(0.0f) - tot.h[1]; F.f[1] = tot.h[0]; F.f[2] = f2_bcast(0.0f);
+            F.n[0] = tot.I[2]; F.n[1] = tot.I[4]; F.n[2] = tot.I[5];
+            hout(k, k, tot.I[5]);
+#pragma unroll
+            for (int j = k - 1; j >= 0; --j) {
+                const OpFT oc = load_ft(row(j + 1));
+                Force2 up;
+                joint2_N(J[j + 1], oc.F, F.f, up.f);
+                joint2_N(J[j + 1], oc.F, F.n, up.n);
+                f2 x[3];
+                cross2_cv(oc.t, up.f, x);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) up.n[i] += x[i];
+                F = up;
+                hout(k, j, F.n[2]);
+            }
+        }
+        if (k > 0) {
+            const OpFT o = load_ft(of);
+            inertia2_to_parent(J[k], o.F, o.t, tot, carry);
+        }
     }
 }
 

@@ -83,6 +83,10 @@ extern "C" {
 /* ABI 11: drm_fk_rnea_put's form of DRM_SPECIAL_FK_RNEA_ARM (same code object, same pair of walks): kernel
  * "drm_fk_rnea_arm_put_static", arguments q, qd, qdd, n_pairs, flags, tau, pos, quat and the drm_put struct by value */
 #define DRM_SPECIAL_FK_RNEA_ARM_PUT 12
+/* ABI 11: DRM_SPECIAL_FD_ARM with TWO samples per lane (csrc/drm_arm_static.hpp forward_dynamics_arm2_static_body): covers the
+ * 128-row tile pairs of a launch of at least DRM_ARM_STATIC_MIN_PAIRS pairs; kernel "drm_fd_arm2_static", arguments q, qd, f,
+ * n_pairs, flags, qdd */
+#define DRM_SPECIAL_FD_ARM2 13
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

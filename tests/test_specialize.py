@@ -592,6 +592,22 @@ def test_gpu_arm_inertia_matrix_forward_dynamics_and_input_gradients_with_folded
             grads.append([x.grad for x in xs])
         for a, b in zip(*grads):
             assert float((a - b).abs().max()) <= 2e-4 * max(1e-9, float(b.abs().max()))
+    # round 6: launches of >= 1 024 pairs of tiles run forward dynamics TWO samples per lane (drm_fd_arm2_static): 1 027 pairs + an
+    # odd tile + a ragged tail — the pairs through that kernel, the odd tile through the one-sample own kernel, the tail through the
+    # library's — every row against the fp64 oracle and the library's kernel
+    assert special.get(sp.SPECIAL_FD_ARM2)
+    B = 1027 * 128 + 64 + 9
+    q, qd, qdd = sample_states(mc, B, seed=41)
+    dq, dqd, dqdd = (torch.from_numpy(a).cuda() for a in (q, qd, qdd))
+    for grav, damp in ((True, True), (False, False)):
+        f = plain.compute_inverse_dynamics(dq, dqd, dqdd, include_gravity=grav, use_damping=damp)
+        acc = own.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+        ref = orc.forward_dynamics(f64(q), f64(qd), f64(f.cpu().numpy()), grav, damp, np.float64)
+        err = float((np.abs(acc.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+        other = plain.compute_forward_dynamics(dq, dqd, f, include_gravity=grav, use_damping=damp)
+        err_lib = float((np.abs(other.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
+        assert err < max(1e-3, 2.0 * err_lib), (B, grav, damp, err, err_lib)
+        assert float(((acc - other).abs() / (1.0 + other.abs())).max()) < 2e-3
 
 
 def test_fan_source_describes_the_chains():
