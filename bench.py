@@ -488,11 +488,11 @@ def main():
         line = run_config3(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max, shard_bounds)
     else:
         line = run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max)
-    if rank == 0:
-        emit(line, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:          # LAST: nothing of this process follows the compact line on stdout (the process group is already down)
+        emit(line, args)
 
 
 def run_metric(args, model, link, device, world, rank, ranks_seen, stream, barrier, reduce_max):
