@@ -148,6 +148,48 @@ __device__ __forceinline__ void rnea_backward_arm_static_body(ROW row, const flo
 }
 
 
+// input gradients of inverse dynamics, TWO SAMPLES PER LANE (round 6): one wavefront per 128-row pair of tiles
+template <int NJ, int LINKS, class ROW>
+__device__ __forceinline__ void rnea_backward_arm2_static_body(ROW row, const float *__restrict__ q, const float *__restrict__ qd,
+                                                               const float *__restrict__ qdd, const float *__restrict__ gtau,
+                                                               int n_pairs, int flags, float *__restrict__ gq, float *__restrict__ gqd,
+                                                               float *__restrict__ gqdd) {
+    static_assert(NJ & 1, "odd row width (linear LDS image)");
+    constexpr int Q_FLOATS = round4(STREAM_TILE * NJ);
+    __shared__ __attribute__((aligned(16))) float lg[3 * Q_FLOATS];
+    const int pair = (int)blockIdx.x;
+    if (pair >= n_pairs) return;
+    const unsigned lane = threadIdx.x;
+    const int64_t b0 = (int64_t)pair * STREAM_TILE;
+    float *lq = lg, *lqd = lq + Q_FLOATS, *lqdd = lqd + Q_FLOATS;
+    f2 qv[NJ], qdv[NJ], qddv[NJ], gtv[NJ];
+    auto rows2 = [&](const float *src, f2 (&v)[NJ]) {
+        float a[NJ], b[NJ];
+        lane_row<NJ>(src, b0 + lane, a);
+        lane_row<NJ>(src, b0 + WAVE + lane, b);
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) v[d] = f2_make(a[d], b[d]);
+    };
+    rows2(q, qv);
+    rows2(qd, qdv);
+    if (qdd) rows2(qdd, qddv);
+    else {
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qddv[d] = f2_bcast(0.0f);
+    }
+    rows2(gtau, gtv);
+    rnea_backward_chain2<LINKS, NJ>(row, flags & DRM_RNEA_GRAVITY, flags & DRM_RNEA_DAMPING, qv, qdv, qddv, gtv,
+                                    [&](int d, f2 a, f2 v, f2 c) {
+                                        lq[lane * NJ + d] = a[0]; lq[(WAVE + lane) * NJ + d] = a[1];
+                                        lqd[lane * NJ + d] = v[0]; lqd[(WAVE + lane) * NJ + d] = v[1];
+                                        lqdd[lane * NJ + d] = c[0]; lqdd[(WAVE + lane) * NJ + d] = c[1];
+                                    });
+    wave_lds_sync();
+    tile_store<2 * NJ>(gq + b0 * NJ, WAVE, 2 * NJ, 0u, lq, lane, true);
+    tile_store<2 * NJ>(gqd + b0 * NJ, WAVE, 2 * NJ, 0u, lqd, lane, true);
+    tile_store<2 * NJ>(gqdd + b0 * NJ, WAVE, 2 * NJ, 0u, lqdd, lane, true);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Reverse-mode inverse dynamics of a serial arm WITH learnable link parameters (round 6; the learn-dynamics workload, reference
 // robot_model.py:305-375 under autograd with rigid_body_params.py parametrisations, examples/learn_dynamics_iiwa.py): the gradient

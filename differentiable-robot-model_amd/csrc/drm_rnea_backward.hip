@@ -572,6 +572,21 @@ extern "C" int drm_rnea_backward(const drm_walk *w, const float *q, const float 
             // its own rows of partial sums appended after the chain kernel's
             int n_tiles = (int)(B / WAVE);
             const int64_t done = (int64_t)n_tiles * WAVE;
+            if (w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM2] && w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM] && param_mask == 0 && want_q &&
+                n_tiles / 2 >= DRM_ARM_STATIC_MIN_PAIRS) {
+                // ABI 11: two samples per lane for the pairs of tiles of a large launch; an odd tile and the tail follow below
+                int n_pairs = n_tiles / 2, fl = (int)flags;
+                void *args[] = {(void *)&q, (void *)&qd, (void *)&qdd, (void *)&grad_tau, (void *)&n_pairs, (void *)&fl,
+                                (void *)&grad_q, (void *)&grad_qd, (void *)&grad_qdd};
+                hipError_t e = hipModuleLaunchKernel((hipFunction_t)w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM2], (unsigned)n_pairs, 1, 1, WAVE, 1, 1, 0, s, args, nullptr);
+                if (e != hipSuccess) return fail(DRM_ERR_LAUNCH, "hipModuleLaunchKernel(drm_rnea_backward_arm2_static): %s", hipGetErrorString(e));
+                const int64_t done2 = (int64_t)n_pairs * 2 * WAVE;
+                if (done2 == B) return DRM_OK;
+                drm_walk rest = *w;
+                rest.special[DRM_SPECIAL_RNEA_BACKWARD_ARM2] = nullptr;
+                return drm_rnea_backward(&rest, q + done2 * n, qd + done2 * n, qdd ? qdd + done2 * n : nullptr, B - done2, flags, grad_tau + done2 * n,
+                                         param_mask, grad_q + done2 * n, grad_qd + done2 * n, grad_qdd + done2 * n, grad_ops_f, scratch, stream);
+            }
             if (w->special[DRM_SPECIAL_RNEA_BACKWARD_ARM] && param_mask == 0 && want_q) {
                 // input gradients of a constant model through this arm's own kernel, its constants folded into the instruction
                 // stream (csrc/drm_arm_static.hpp, specialize.py): nothing is summed over the batch, so no partial rows

@@ -2803,4 +2803,188 @@ DRM_HD void crba_chain2_trig(ROW row, const f2 (&cs)[NJ], const f2 (&sn)[NJ], HO
     }
 }
 
+// ---------------------------------------------------------------------------
+// Reverse-mode inverse dynamics of a serial chain, INPUT gradients, TWO SAMPLES PER LANE (round 6): rnea_backward_chain's three
+// sweeps (A motions up, C force adjoints up, D back to the root with B folded in; nothing stored per link, every parent's motion and
+// force adjoint recovered from its child's) with a pair = the same quantity of rows b and b + 64, on the helpers of the two-sample
+// RNEA (Joint2, Motion2, Force2).  The one-sample form packs (w, al) / (v, a) of ONE sample and leaves its scalar third — crosses of
+// two per-sample vectors, the joint rotations, the closed-form dL/dq terms — on half-empty instructions; here every instruction is
+// a full v_pk_*_f32.  The link adjoint is rnea_link_adjoint's (revolute joint about +z, no parameter gradients) written out on pairs.
+//   gout(d, gq, gqd, gqdd): f2 each
+// ---------------------------------------------------------------------------
+DRM_HD void acc2_cross_vv(f2 *acc, const f2 *a, const f2 *b) { // acc += a x b
+    acc[0] += a[1] * b[2] - a[2] * b[1];
+    acc[1] += a[2] * b[0] - a[0] * b[2];
+    acc[2] += a[0] * b[1] - a[1] * b[0];
+}
+DRM_HD void acc2_cross_vc(f2 *acc, const f2 *a, const float *b, float sign) { // acc += sign (a x b), b a constant of the robot
+    acc[0] += f2_bcast(sign) * (a[1] * f2_bcast(b[2]) - a[2] * f2_bcast(b[1]));
+    acc[1] += f2_bcast(sign) * (a[2] * f2_bcast(b[0]) - a[0] * f2_bcast(b[2]));
+    acc[2] += f2_bcast(sign) * (a[0] * f2_bcast(b[1]) - a[1] * f2_bcast(b[0]));
+}
+DRM_HD void acc2_matT_c(f2 *acc, const float *M, const f2 *x) { // acc += M^T x, M a constant 3x3 (row-major)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += f2_bcast(M[0 * 3 + c]) * x[0] + f2_bcast(M[1 * 3 + c]) * x[1] + f2_bcast(M[2 * 3 + c]) * x[2];
+}
+template <int CAP, int NJ, class ROW, class GOUT>
+DRM_HD void rnea_backward_chain2(ROW row, bool gravity, bool damping, const f2 (&q)[NJ], const f2 (&qd)[NJ], const f2 (&qdd)[NJ],
+                                 const f2 (&gtau)[NJ], GOUT gout) {
+    f2 cs[NJ], sn[NJ];
+    chain_trig2<NJ>(q, cs, sn);
+    const float g = gravity ? 9.81f : 0.0f;
+    const f2 zero = f2_bcast(0.0f);
+    auto joint = [&](int k, Joint2 &J) {
+        const OpFT o = load_ft(row_ft(row, k));
+        if (k < NJ) joint2_moving(o.F, cs[k], sn[k], J);
+        else joint2_fixed(o.F, J);
+    };
+    // ---- A: motions up the chain (only the tip's is kept);  C: adjoints of the total forces (tbar), likewise ------------
+    Motion2 M;
+    f2 Tl[3] = {zero, zero, zero}, Ta[3] = {zero, zero, zero};
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        const OpFT o = load_ft(row_ft(row, k));
+        Joint2 J;
+        joint(k, J);
+        const f2 wj = k < NJ ? qd[k] : zero, aj = k < NJ ? qdd[k] : zero;
+        if (k == 0) rnea2_first_motion(J, o.F, g, wj, aj, M);
+        else rnea2_link_motion(J, o.F, o.t, wj, aj, M, M);
+        if (k > 0) { // tbar_k = (J^T (ubar.lin + ubar.ang x t), J^T ubar.ang), ubar = tbar_(k-1)
+            f2 x[3], y[3];
+            cross2_vc(Ta, o.t, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[i] += Tl[i];
+            joint2_T(J, o.F, x, y);
+            joint2_T(J, o.F, Ta, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Tl[i] = y[i]; Ta[i] = x[i]; }
+        }
+        if (k < NJ) Ta[2] += gtau[k];
+    }
+    // ---- D (with B): back to the root ----------------------------------------------------------------------------
+    f2 wb[3] = {zero, zero, zero}, vb[3] = {zero, zero, zero}, alb[3] = {zero, zero, zero}, ab[3] = {zero, zero, zero};
+    Force2 carry;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { carry.f[i] = zero; carry.n[i] = zero; }
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; --k) {
+        const float *of = row(k);
+        const OpFT o = load_ft(row_ft(row, k));
+        const float m = of[DRM_OPF_MASS], *mc = of + DRM_OPF_MCOM, *Io = of + DRM_OPF_IO;
+        Joint2 J;
+        joint(k, J);
+        const f2 wj = k < NJ ? qd[k] : zero, aj = k < NJ ? qdd[k] : zero;
+        // parent's motion and force adjoint from this link's (inverses of rnea2_link_motion / of sweep C; J is orthogonal)
+        Motion2 P;
+        f2 Ul[3], Ua[3];
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { P.w[i] = zero; P.al[i] = zero; P.v[i] = zero; P.a[i] = zero; Ul[i] = zero; Ua[i] = zero; }
+            P.a[2] = f2_bcast(g);
+        } else {
+            f2 x[3], y[3], c[3];
+            x[0] = M.w[0]; x[1] = M.w[1]; x[2] = M.w[2] - wj;
+            joint2_N(J, o.F, x, P.w);
+            x[0] = M.al[0] - M.w[1] * wj; x[1] = M.al[1] + M.w[0] * wj; x[2] = M.al[2] - aj;
+            joint2_N(J, o.F, x, P.al);
+            joint2_N(J, o.F, M.v, y);
+            cross2_vc(P.w, o.t, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.v[i] = y[i] - c[i];
+            x[0] = M.a[0] - M.v[1] * wj; x[1] = M.a[1] + M.v[0] * wj; x[2] = M.a[2];
+            joint2_N(J, o.F, x, y);
+            cross2_vc(P.al, o.t, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.a[i] = y[i] - c[i];
+            x[0] = Ta[0]; x[1] = Ta[1]; x[2] = k < NJ ? Ta[2] - gtau[k < NJ ? k : 0] : Ta[2];
+            joint2_N(J, o.F, Tl, Ul);
+            joint2_N(J, o.F, x, Ua);
+            cross2_vc(Ua, o.t, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Ul[i] -= c[i];            // ubar.lin = J tbar.lin - ubar.ang x t
+        }
+        // body force of the link from the recovered motion (+ what came up): hl = m v - mc x w, ha = Io w + mc x v, likewise (gl, ga)
+        f2 hl[3], ha[3], x[3], y[3];
+        Force2 tot;
+        cross2_cv(mc, M.w, x);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hl[i] = f2_bcast(m) * M.v[i] - x[i];
+        cross2_cv(mc, M.v, x);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            ha[r] = f2_bcast(Io[r * 3 + 0]) * M.w[0] + f2_bcast(Io[r * 3 + 1]) * M.w[1] + f2_bcast(Io[r * 3 + 2]) * M.w[2] + x[r];
+        {
+            f2 gl[3], ga[3];
+            cross2_cv(mc, M.al, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gl[i] = f2_bcast(m) * M.a[i] - x[i];
+            cross2_cv(mc, M.a, x);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                ga[r] = f2_bcast(Io[r * 3 + 0]) * M.al[0] + f2_bcast(Io[r * 3 + 1]) * M.al[1] + f2_bcast(Io[r * 3 + 2]) * M.al[2] + x[r];
+            cross2_vv(M.w, hl, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.f[i] = gl[i] + x[i] + carry.f[i];
+            cross2_vv(M.w, ha, x);
+            cross2_vv(M.v, hl, y);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tot.n[i] = ga[i] + (x[i] + y[i]) + carry.n[i];
+        }
+        // the link's adjoint (rnea_link_adjoint: fl = tbar.lin, fa = tbar.ang; wb / vb / alb / ab arrive from the child)
+        f2 hlb[3] = {zero, zero, zero}, hab[3] = {zero, zero, zero};
+        acc2_cross_vv(hlb, Tl, M.w); acc2_cross_vv(hlb, Ta, M.v);
+        acc2_cross_vv(hab, Ta, M.w);
+        acc2_cross_vv(wb, hl, Tl); acc2_cross_vv(wb, ha, Ta);
+        acc2_cross_vv(vb, hl, Ta);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vb[i] += f2_bcast(m) * hlb[i];
+        acc2_cross_vc(wb, hlb, mc, -1.0f);
+        acc2_matT_c(wb, Io, hab);
+        acc2_cross_vc(vb, hab, mc, 1.0f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ab[i] += f2_bcast(m) * Tl[i];
+        acc2_cross_vc(alb, Tl, mc, -1.0f);
+        acc2_matT_c(alb, Io, Ta);
+        acc2_cross_vc(ab, Ta, mc, 1.0f);
+        // the link's motion from its parent's (revolute joint about +z): adjoint
+        f2 Pwb[3], Pvb[3], Palb[3], Pab[3];
+        f2 gq = ab[0] * (M.a[1] + M.v[0] * wj) - ab[1] * (M.a[0] - M.v[1] * wj);
+        f2 wjb = ab[0] * M.v[1] - ab[1] * M.v[0];
+        joint2_N(J, o.F, ab, Pab);
+        vb[1] += ab[0] * wj; vb[0] -= ab[1] * wj;
+        cross2_cv(o.t, Pab, Palb);
+        joint2_N(J, o.F, alb, x);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Palb[i] += x[i];
+        gq += alb[0] * (M.al[1] + M.w[0] * wj) - alb[1] * (M.al[0] - M.w[1] * wj);
+        const f2 ajb = alb[2];
+        wb[1] += alb[0] * wj; wb[0] -= alb[1] * wj;
+        wjb += alb[0] * M.w[1] - alb[1] * M.w[0];
+        joint2_N(J, o.F, vb, Pvb);
+        gq += vb[0] * M.v[1] - vb[1] * M.v[0];
+        cross2_cv(o.t, Pvb, Pwb);
+        joint2_N(J, o.F, wb, x);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Pwb[i] += x[i];
+        gq += wb[0] * M.w[1] - wb[1] * M.w[0];
+        wjb += wb[2];
+        if (k > 0) gq += tot.f[0] * Tl[1] - tot.f[1] * Tl[0] + tot.n[0] * Ta[1] - tot.n[1] * Ta[0];
+        if (k < NJ) gout(k, gq, damping ? wjb + f2_bcast(of[DRM_OPF_DAMP]) * gtau[k < NJ ? k : 0] : wjb, ajb);
+        if (k > 0) { // the sub-tree's force in the parent's frame
+            Force2 up;
+            joint2_N(J, o.F, tot.f, up.f);
+            joint2_N(J, o.F, tot.n, up.n);
+            cross2_cv(o.t, up.f, x);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { carry.f[i] = up.f[i]; carry.n[i] = up.n[i] + x[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wb[i] = Pwb[i]; vb[i] = Pvb[i]; alb[i] = Palb[i]; ab[i] = Pab[i];
+            Tl[i] = Ul[i]; Ta[i] = Ua[i];
+        }
+        M = P;
+    }
+}
+
 } // namespace drm

@@ -43,6 +43,8 @@ SPECIAL_FK_RNEA_ARM_PUT = 12          # (ABI 11) the fused FK + RNEA kernel with
 ARM_PUT_KERNEL = "drm_fk_rnea_arm_put_static"
 SPECIAL_FD_ARM2 = 13                  # (ABI 11) forward dynamics of the arm, two samples per lane (launches of >= 1 024 tile pairs)
 ARM_FD2_KERNEL = "drm_fd_arm2_static"
+SPECIAL_RNEA_BACKWARD_ARM2 = 14       # (ABI 11) input gradients of inverse dynamics, two samples per lane
+ARM_BWD2_KERNEL = "drm_rnea_backward_arm2_static"
 FT_FLOATS, DAMP_INDEX = 12, 25        # include/drm_hip.h DRM_OPF_FT_FLOATS, DRM_OPF_DAMP: [0, 12) = F / t, [12, 26) = mass, mcom, I_o, damping
 ARM_KINDS = tuple(ARM_KERNELS)
 # (The FK + Jacobian metric kernel was built this way too and measured: 3.75 us either way at 65 536 rows — its pair-packed chain
@@ -496,11 +498,16 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
 drm_fd_arm2_static(const float *q, const float *qd, const float *f, int n_pairs, int flags, float *qdd) {
     drm::forward_dynamics_arm2_static_body<7, %d>(drm::RobotRow(), q, qd, f, n_pairs, flags, qdd);
 }
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+drm_rnea_backward_arm2_static(const float *q, const float *qd, const float *qdd, const float *gtau, int n_pairs, int flags, float *gq, float *gqd,
+                              float *gqdd) {
+    drm::rnea_backward_arm2_static_body<7, %d>(drm::RobotRow(), q, qd, qdd, gtau, n_pairs, flags, gq, gqd, gqdd);
+}
 extern "C" __global__ void __launch_bounds__(64) drm_rnea_backward_arm_static(const float *q, const float *qd, const float *qdd, const float *gtau,
                                                                               int n_tiles, int flags, float *gq, float *gqd, float *gqdd) {
     drm::rnea_backward_arm_static_body<7, %d>(drm::RobotRow(), q, qd, qdd, gtau, n_tiles, flags, gq, gqd, gqdd);
 }
-""" % (rows, links, links, links, links)
+""" % (rows, links, links, links, links, links)
 
 
 def arm_param_backward_source(table, links: int, mask_kin: int, mask_dyn: int) -> str:
@@ -676,6 +683,7 @@ def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkP
         for kind in ARM_DYNAMICS:
             special[kind] = _load(path, ARM_KERNELS[kind])
         special[SPECIAL_FD_ARM2] = _load(path, ARM_FD2_KERNEL)
+        special[SPECIAL_RNEA_BACKWARD_ARM2] = _load(path, ARM_BWD2_KERNEL)
 
     def fused():
         both = table.copy()

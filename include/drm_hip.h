@@ -87,6 +87,9 @@ extern "C" {
  * 128-row tile pairs of a launch of at least DRM_ARM_STATIC_MIN_PAIRS pairs; kernel "drm_fd_arm2_static", arguments q, qd, f,
  * n_pairs, flags, qdd */
 #define DRM_SPECIAL_FD_ARM2 13
+/* ... and DRM_SPECIAL_RNEA_BACKWARD_ARM (input gradients, param_mask == 0) with two samples per lane: kernel
+ * "drm_rnea_backward_arm2_static", arguments q, qd, qdd, grad_tau, n_pairs, flags, grad_q, grad_qd, grad_qdd */
+#define DRM_SPECIAL_RNEA_BACKWARD_ARM2 14
 #define DRM_OPF_STRIDE 32 /* floats per op in ops_f                                            */
 /* [0..11] "FT block": R_fixed = Rz(yaw)Ry(pitch)Rx(roll) (rigid_body.py:138-143) and the joint origin xyz
  * ("trans", rigid_body.py:48) interleaved as the 8-byte pairs the packed-FP32 chain kernel multiplies with:

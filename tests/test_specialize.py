@@ -608,6 +608,20 @@ def test_gpu_arm_inertia_matrix_forward_dynamics_and_input_gradients_with_folded
         err_lib = float((np.abs(other.cpu().numpy() - ref) / (1.0 + np.abs(ref))).max())
         assert err < max(1e-3, 2.0 * err_lib), (B, grav, damp, err, err_lib)
         assert float(((acc - other).abs() / (1.0 + other.abs())).max()) < 2e-3
+    # ... and the input gradients of inverse dynamics (drm_rnea_backward_arm2_static), with and without qdd, both flag settings
+    assert special.get(sp.SPECIAL_RNEA_BACKWARD_ARM2)
+    want = torch.randn(B, 7, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
+    for grav, damp, with_qdd in ((True, True, True), (False, False, True), (True, True, False)):
+        grads = []
+        for m in (plain, own):
+            xs = [t.clone().requires_grad_(True) for t in ((dq, dqd, dqdd) if with_qdd else (dq, dqd))]
+            tau = m.compute_inverse_dynamics(*xs, include_gravity=grav, use_damping=damp) if with_qdd else \
+                m.compute_non_linear_effects(*xs, include_gravity=grav, use_damping=damp)
+            (tau * want).sum().backward()
+            grads.append([x.grad for x in xs])
+        for a, b in zip(*grads):
+            scale = max(1e-9, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-4 * scale, (grav, damp, with_qdd, float((a - b).abs().max()), scale)
 
 
 def test_fan_source_describes_the_chains():
