@@ -330,6 +330,43 @@ class _FkMse(torch.autograd.Function):
         return grad_q, None, grad_ops, None, None, None
 
 
+class _FkMseLinks(torch.autograd.Function):
+    """_FkMse for a model WITH learnable links, from the links' parameter tensors to their gradients (backend.fk_mse_links,
+    drm_fk_mse_links): the walk table is built inside the first launch and the gradient is taken back through that map inside the
+    second, so a training step's forward + loss + backward is two launches and this ONE autograd node — instead of WalkTable (a cat and
+    a launch), _FkMse (two launches) and WalkTable's backward (a launch).  ``pieces``: six tensors per learnable link, as for
+    backend.WalkTable.  First order only."""
+
+    @staticmethod
+    def forward(ctx, q, target, base, sel, gsign, dw, n_dofs, param_mask, *pieces):
+        want_q = q.requires_grad
+        loss, grad_q, grad_params = backend.fk_mse_links(dw.program, base, dw.ops_i, sel, gsign, pieces, q, target, n_dofs, param_mask, want_q)
+        ctx.save_for_backward(grad_params, *([grad_q] if want_q else []))
+        ctx.want_q, ctx.q_shape, ctx.q_dtype = want_q, q.shape, q.dtype
+        ctx.shapes = [tuple(p.shape) for p in pieces]
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        saved = ctx.saved_tensors
+        second = torch.is_grad_enabled()
+        with torch.no_grad():
+            flat = (saved[0] * grad_loss).reshape(-1)      # ONE kernel for every parameter's gradient; the pieces are views of it
+            grad_q = (saved[1] * grad_loss).to(ctx.q_dtype).reshape(ctx.q_shape) if ctx.want_q else None
+        if second:      # create_graph=True: first-order gradients that say so when differentiated again (as _FkMse's)
+            with torch.enable_grad():
+                flat = _FirstOrderOnly.apply(flat.requires_grad_(True))
+                grad_q = _FirstOrderOnly.apply(grad_q.requires_grad_(True)) if grad_q is not None else None
+        out, off = [], 0
+        for i, shape in enumerate(ctx.shapes):
+            n = 1
+            for d in shape:
+                n *= d
+            out.append(flat[off:off + n].reshape(shape) if ctx.needs_input_grad[8 + i] else None)
+            off += n
+        return (grad_q, None, None, None, None, None, None, None) + tuple(out)
+
+
 class _FkJacobian(torch.autograd.Function):
     """Fused FK + geometric Jacobian with a hand-written backward (csrc/drm_fk_backward.hip, JAC form): position and
     both Jacobians are differentiable with respect to q and to the walk's constant table (learnable ``trans`` /

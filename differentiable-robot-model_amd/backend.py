@@ -21,7 +21,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 SPECIAL_FK_FAN_LINKS = 9      # index of the fan-out FK kernel in drm_walk.special[] (include/drm_hip.h DRM_SPECIAL_FK_FAN_LINKS)
@@ -50,6 +50,14 @@ class DrmPut(ctypes.Structure):
                 ("tau", ctypes.c_void_p * MAX_PEERS), ("pos", ctypes.c_void_p * MAX_PEERS), ("quat", ctypes.c_void_p * MAX_PEERS)]
 
 
+FK_MSE_MAX_LINKS = 8
+
+
+class DrmLinkPieces(ctypes.Structure):
+    """Mirror of ``struct drm_link_pieces`` (include/drm_hip.h, ABI 12): where the outputs of one learnable link's parameter modules lie."""
+    _fields_ = [(name, ctypes.c_void_p) for name in ("rot_angles", "trans", "mass", "com", "inertia_mat", "damping")]
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -63,7 +71,8 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_link_rows_backward", "drm_fk_fanout", "drm_fk_fanout_links", "drm_fk_links", "drm_fk_jacobian_backward", "drm_walk_table",
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats", "drm_rnea_scratch_floats_aligned",
-           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load", "drm_fk_rnea_put")
+           "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load", "drm_fk_rnea_put",
+           "drm_fk_mse_links")
 
 
 def library_for(device):
@@ -158,6 +167,8 @@ def load_library(path: str = None, kind: str = "cuda"):
         lib.drm_special_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.drm_fk_mse.restype = ctypes.c_int
         lib.drm_fk_mse.argtypes = [wp, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
+        lib.drm_fk_mse_links.restype = ctypes.c_int
+        lib.drm_fk_mse_links.argtypes = [wp, vp, vp, ctypes.POINTER(DrmLinkPieces), i32, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
         lib.drm_fk_mse_scratch_floats.restype = i64
         lib.drm_fk_mse_scratch_floats.argtypes = [i64, i32]
         if lib.drm_abi_version() != ABI_VERSION:
@@ -776,6 +787,50 @@ def fk_mse(prog: WalkProgram, ops_f, ops_i, q, target, n_dofs: int, param_mask: 
                               grad_q.data_ptr() if want_grad_q else None, grad_ops.data_ptr() if param_mask else None,
                               scratch.data_ptr(), _stream(dev)), lib)
     return loss, grad_q, grad_ops
+
+
+def fk_mse_links(prog: WalkProgram, base, ops_i, sel, gsign, pieces, q, target, n_dofs: int, param_mask: int, want_grad_q: bool):
+    """(loss [], grad_q [B, n] or None, grad_params [n_links, 20]) of loss = mean((pos(q) - target)^2) for a walk WITH learnable
+    links, from the links' parameters to the gradients with respect to them (drm_fk_mse_links, ABI 12): ``base`` is the table of the
+    constant links in walk order, ``sel`` / ``gsign`` as for WalkTable, ``pieces`` the six parameter tensors per learnable link
+    (rot_angles, trans, mass, com, inertia_mat, damping) where they lie.  Two launches for what WalkTable -> fk_mse -> WalkTable's
+    backward do in five (plus a cat).  Raises KernelUnsupported as fk_mse does."""
+    lib = _lib_of(q, "q", base)
+    q = _dev_f32(q, "q", n_dofs)
+    target = _dev_f32(target, "target", 3)
+    B, dev = q.shape[0], q.device
+    if target.shape[0] != B:
+        raise ValueError("q and target batch sizes differ")
+    n_links, rest = divmod(len(pieces), 6)
+    if rest or not 1 <= n_links <= FK_MSE_MAX_LINKS:
+        raise KernelUnsupported("drm_fk_mse_links takes 1 .. %d learnable links" % FK_MSE_MAX_LINKS)
+    links = (DrmLinkPieces * n_links)()
+    keep = []
+    for l in range(n_links):
+        for j, (name, size) in enumerate((("rot_angles", 3), ("trans", 3), ("mass", 1), ("com", 3), ("inertia_mat", 9), ("damping", 1))):
+            t = pieces[l * 6 + j]
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != size:
+                t = t.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if t.numel() != size:
+                    raise ValueError("%s of a learnable link has %d elements, not %d" % (name, t.numel(), size))
+            keep.append(t)
+            setattr(links[l], name, t.data_ptr())
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad_q = torch.empty(B, n_dofs, device=dev, dtype=torch.float32) if want_grad_q else None
+    grad_params = torch.empty(n_links, 20, device=dev, dtype=torch.float32)
+    scratch = torch.empty(max(1, lib.drm_fk_mse_scratch_floats(B, prog.capacity)), device=dev, dtype=torch.float32)
+    table = base.detach().reshape(prog.capacity, -1)
+    key = (table.data_ptr(), ops_i.data_ptr(), n_dofs)
+    cached = getattr(prog, "_ws_links", None)      # (its own slot: _walk_struct keeps the struct of the LIVE table of this program)
+    if cached is None or cached[0] != key:
+        cached = prog._ws_links = (key, _walk_struct_build(prog, table, ops_i, n_dofs))
+    walk = cached[1]
+    with _on_device(dev):
+        _check(lib.drm_fk_mse_links(ctypes.byref(walk), sel.data_ptr(), gsign.data_ptr(), links, n_links, q.data_ptr(), target.data_ptr(), B,
+                                    ctypes.c_uint64(param_mask), loss.data_ptr(), grad_q.data_ptr() if want_grad_q else None,
+                                    grad_params.data_ptr(), scratch.data_ptr(), _stream(dev)), lib)
+    del keep
+    return loss, grad_q, grad_params
 
 
 def fk_jacobian_backward(prog: WalkProgram, ops_f, ops_i, q, grad_pos, grad_lin, grad_ang, n_dofs: int,

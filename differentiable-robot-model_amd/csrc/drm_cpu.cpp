@@ -372,4 +372,35 @@ int drm_walk_table_backward(const float *params, int32_t n_links, const float *g
         link_row_backward(params + i * LINK_PARAM_FLOATS, grows + i * DRM_OPF_STRIDE, grad_params + i * LINK_PARAM_FLOATS);
     return DRM_OK;
 }
+
+// ABI 12: the composition itself (the host build has no launches to save): table from the links' parameters, drm_fk_mse, and the
+// gradient back through the table's map
+int drm_fk_mse_links(const drm_walk *w, const int32_t *sel, const float *gsign, const drm_link_pieces *links, int32_t n_links, const float *q,
+                     const float *target, int64_t B, uint64_t mask, float *loss, float *gq, float *grad_params, float *scratch, void *) {
+    if (int rc = check_backward_walk(w, mask)) return rc;
+    if (!sel || !gsign || !links || !grad_params) return fail(DRM_ERR_INVALID, "NULL sel / gsign / links / grad_params");
+    if (n_links < 1 || n_links > DRM_FK_MSE_MAX_LINKS)
+        return fail(DRM_ERR_UNSUPPORTED, "drm_fk_mse_links takes 1 .. %ld learnable links (%ld)", DRM_FK_MSE_MAX_LINKS, n_links);
+    if (!mask) return fail(DRM_ERR_INVALID, "param_mask must select the ops of the learnable links");
+    const int entries = w->capacity * DRM_OPF_STRIDE;
+    float params[DRM_FK_MSE_MAX_LINKS * LINK_PARAM_FLOATS] = {0.0f};
+    for (int l = 0; l < n_links; ++l) {
+        if (!links[l].rot_angles || !links[l].trans) return fail(DRM_ERR_INVALID, "rot_angles / trans of a link are NULL");
+        for (int i = 0; i < 3; ++i) {
+            params[l * LINK_PARAM_FLOATS + i] = links[l].rot_angles[i];
+            params[l * LINK_PARAM_FLOATS + 3 + i] = links[l].trans[i];
+        }
+    }
+    std::vector<float> table(entries), gops(entries);
+    if (int rc = drm_walk_table(params, n_links, w->ops_f, sel, gsign, entries, table.data(), nullptr)) return rc;
+    drm_walk live = *w;
+    live.ops_f = table.data();
+    if (int rc = drm_fk_mse(&live, q, target, B, mask, loss, gq, gops.data(), scratch, nullptr)) return rc;
+    for (int e = 0; e < entries; ++e)       // forward kinematics reads the FT block of a row only
+        if ((e % DRM_OPF_STRIDE) >= DRM_OPF_FT_FLOATS) gops[e] = 0.0f;
+    if (int rc = drm_walk_table_backward(params, n_links, gops.data(), sel, gsign, entries, grad_params, nullptr)) return rc;
+    for (int l = 0; l < n_links; ++l)
+        for (int i = 6; i < LINK_PARAM_FLOATS; ++i) grad_params[l * LINK_PARAM_FLOATS + i] = 0.0f;
+    return DRM_OK;
+}
 } // extern "C"

@@ -254,11 +254,40 @@ __device__ __forceinline__ void last_block_reduce(uint32_t *ticket, const float 
 #define DRM_FK_BWD_PRE_MAX_TILES 1024 /* one tile per SIMD */
 #endif
 constexpr int FK_BWD_PRE_MAX_TILES = DRM_FK_BWD_PRE_MAX_TILES;
-template <int CAP, int NJ, bool MSE = false, bool PRE = true>
+#ifndef DRM_LINKS_VARIANT
+#define DRM_LINKS_VARIANT 0 /* development A/B of the in-kernel table build (tools/ab_fk_mse_links.py); 0 = the product */
+#endif
+// LINKS (drm_fk_mse_links): the walk table is built INSIDE the launch.  `ops_f` is the table of the constant links gathered into walk
+// order; the entries that come from a learnable link (sel[e] = slot * 32 + element of its link row, -1 otherwise) are rebuilt by every
+// wavefront from that link's rot_angles / trans — drm_walk_table's arithmetic (link_row, then x gsign), without its launch.
+struct LinkArgs {
+    const float *rpy[DRM_FK_MSE_MAX_LINKS], *trans[DRM_FK_MSE_MAX_LINKS];
+    const int32_t *sel;
+    const float *gsign;
+    int n_links;
+};
+// rot_angles (3) + trans (3) of every learnable link: lane i < 6 of the calling wavefront holds element i of link l in pv[l] (the
+// loads are ISSUED here and waited for where pv is first used: callers put their other loads in between)
+__device__ __forceinline__ void link_args_load(const LinkArgs &la, unsigned lane, float (&pv)[DRM_FK_MSE_MAX_LINKS]) {
+#pragma unroll
+    for (int l = 0; l < DRM_FK_MSE_MAX_LINKS; ++l) {      // (unrolled: every pointer is a scalar at a fixed offset of the argument block)
+        pv[l] = 0.0f;
+        if (l < la.n_links && lane < 6u) {
+            const float *src = lane < 3u ? la.rpy[l] + lane : la.trans[l] + (lane - 3u);
+            pv[l] = *src;
+        }
+    }
+}
+__device__ __forceinline__ void link_args_to_lds(const LinkArgs &la, unsigned lane, const float (&pv)[DRM_FK_MSE_MAX_LINKS], float *params) {
+#pragma unroll
+    for (int l = 0; l < DRM_FK_MSE_MAX_LINKS; ++l)
+        if (l < la.n_links && lane < 6u) params[l * 6 + (int)lane] = pv[l];
+}
+template <int CAP, int NJ, bool MSE = false, bool PRE = true, bool LINKS = false>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     fk_backward_arm_kernel(const float *__restrict__ ops_f, const float *__restrict__ q, const float *__restrict__ gpos,
                            int n_tiles, uint64_t param_mask, float *__restrict__ gq, float *partials, float g_scale,
-                           uint32_t *ticket, float *grad_ops_f, float *loss, float loss_scale) {
+                           uint32_t *ticket, float *grad_ops_f, float *loss, float loss_scale, LinkArgs la) {
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
@@ -272,7 +301,70 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *lq = lc + C_FLOATS, *lg = lq + Q_FLOATS;
     float *lacc = lg + G_FLOATS; // this wave's running sums of the constant gradients
 
+    // LINKS: everything the table build waits for is requested first, then the first tile's rows (a lone wavefront would otherwise pay
+    // the two round trips one after the other)
+#if defined(DRM_TIMELINE) && DRM_TL_WHICH == 2
+#define ARM_STAMP(slot) do { if constexpr (LINKS) DRM_STAMP(slot); } while (0)
+#define ARM_STAMP_DRAINED(slot) do { if constexpr (LINKS) DRM_STAMP_DRAINED(slot); } while (0)
+#else
+#define ARM_STAMP(slot) ((void)0)
+#define ARM_STAMP_DRAINED(slot) ((void)0)
+#endif
+    ARM_STAMP(0);
+    float pv[DRM_FK_MSE_MAX_LINKS];
+    int4 sel4;
+    float4 sg4;
+    if constexpr (LINKS) {
+#if DRM_LINKS_VARIANT == 3
+        for (int l = 0; l < DRM_FK_MSE_MAX_LINKS; ++l) pv[l] = 0.01f * (float)(lane + l);
+#else
+        link_args_load(la, lane, pv);
+#endif
+        sel4 = reinterpret_cast<const int4 *>(la.sel)[lane];
+        sg4 = reinterpret_cast<const float4 *>(la.gsign)[lane];
+    }
     float4 cv = reinterpret_cast<const float4 *>(ops_f)[lane];
+    float qv[NJ], gv[3];
+    auto load_rows = [&](int tile) {
+        const int64_t b0 = (int64_t)tile * WAVE;
+        const float *qrow = q + (b0 + lane) * NJ, *grow = gpos + (b0 + lane) * 3;
+#pragma unroll
+        for (int d = 0; d < NJ; ++d) qv[d] = qrow[d];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gv[i] = grow[i];
+    };
+    if constexpr (LINKS) {
+#if DRM_LINKS_VARIANT != 1
+        if (wave_id < n_tiles) load_rows(wave_id);
+#endif
+        static_assert(DRM_FK_MSE_MAX_LINKS * 12 <= Q_FLOATS && DRM_FK_MSE_MAX_LINKS * 6 <= G_FLOATS, "scratch of the table build");
+        float *lrows = lq, *lpar = lg;          // (both tiles are written per tile further down)
+        link_args_to_lds(la, lane, pv, lpar);
+        wave_lds_sync();
+        ARM_STAMP(1);
+        if ((int)lane < la.n_links) {
+            float p[LINK_PARAM_FLOATS], row[DRM_OPF_STRIDE];
+#pragma unroll
+            for (int i = 0; i < LINK_PARAM_FLOATS; ++i) p[i] = i < 6 ? lpar[lane * 6 + i] : 0.0f;
+#if DRM_LINKS_VARIANT == 2
+            for (int i = 0; i < 12; ++i) row[i] = p[i % 6];
+#else
+            link_row(p, row);                   // (only F and t are live: forward kinematics reads nothing else of a row)
+#endif
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lrows[lane * 12 + i] = row[i];
+        }
+        wave_lds_sync();
+        auto entry = [&](int r, float sign, float constant) {
+            const bool live = r >= 0 && (r & (DRM_OPF_STRIDE - 1)) < 12;
+            const float v = lrows[live ? (r >> 5) * 12 + (r & (DRM_OPF_STRIDE - 1)) : 0];
+            return live ? v * sign : constant;
+        };
+        cv.x = entry(sel4.x, sg4.x, cv.x); cv.y = entry(sel4.y, sg4.y, cv.y);
+        cv.z = entry(sel4.z, sg4.z, cv.z); cv.w = entry(sel4.w, sg4.w, cv.w);
+        wave_lds_sync();
+        ARM_STAMP(2);
+    }
     pin(cv);
     reinterpret_cast<float4 *>(lc)[lane] = cv;
     for (int i = (int)lane; i < NV; i += WAVE) lacc[i] = 0.0f;
@@ -292,14 +384,12 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     }
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
-        float qv[NJ], gv[3], gqv[NJ];
-        {
-            const float *qrow = q + (b0 + lane) * NJ, *grow = gpos + (b0 + lane) * 3;
-#pragma unroll
-            for (int d = 0; d < NJ; ++d) qv[d] = qrow[d];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) gv[i] = grow[i];
-        }
+        float gqv[NJ];
+#if DRM_LINKS_VARIANT == 1
+        load_rows(tile);
+#else
+        if (!LINKS || tile != wave_id) load_rows(tile);
+#endif
         wave_lds_sync(); // the previous tile's staged gradients have left
 #pragma unroll
         for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = qv[d]; // (the cold parameter loop reads an angle by run-time index)
@@ -324,6 +414,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                                            if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in a fixed order
                                        }
                                    });
+        ARM_STAMP(3);
         if (gq) {
             wave_lds_sync(); // every lane is done with its q row
 #pragma unroll
@@ -337,6 +428,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     float *prow = partials + (int64_t)wave_id * PITCH;
     for (int i = (int)lane; i < NV; i += WAVE) publish(prow + i, lacc[i]);
     if (MSE && lane == 63u) publish(prow + NV, loss_acc);
+    ARM_STAMP_DRAINED(5);
     // ABI 11 (drm_walk.special[DRM_WALK_TICKET]): ONE launch.  The block that takes the last ticket adds the rows of partial sums
     // itself — in column_sum's order, so the totals are the two-launch form's bit for bit — instead of a second kernel behind a
     // ~1.7 us kernel boundary (BASELINE configuration 5: 16 384 rows, where the boundary was a quarter of drm_fk_mse).
@@ -361,6 +453,171 @@ __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < cap * (DRM_OPF_STRIDE - BWD_FIELDS);
          i += (int)(gridDim.x * blockDim.x))
         grad_ops_f[(i / (DRM_OPF_STRIDE - BWD_FIELDS)) * DRM_OPF_STRIDE + BWD_FIELDS + i % (DRM_OPF_STRIDE - BWD_FIELDS)] = 0.0f;
+}
+
+// The second launch of drm_fk_mse_links: the rows of partial sums -> d loss / d (F, t) of every op (fk_backward_reduce_kernel's sums,
+// in its order) -> d loss / d (rot_angles, trans) of the learnable links (drm_walk_table_backward's sums, in its order, and
+// link_row_backward), and the loss.  One block; capacity-8 walks.
+// Latency-bound (one block, ~25 KB read): everything that does not depend on the sums — the gather map of the 96 differentiated
+// entries, the links' parameters, d F / d rpy of every learnable link — is requested / computed while the rows are in flight, both
+// halves of the 97 columns are summed in ONE pass, and after the block's only barrier wavefront 0 finishes alone.
+#ifndef DRM_FIN_WAVES
+#define DRM_FIN_WAVES 8
+#endif
+#if defined(DRM_TIMELINE) && DRM_TL_WHICH == 1 /* development: stamps of the finish kernel (tools/timeline_links.py) */
+#define FIN_STAMP(slot) DRM_STAMP(slot)
+#define FIN_STAMP_DRAINED(slot) DRM_STAMP_DRAINED(slot)
+#else
+#define FIN_STAMP(slot) ((void)0)
+#define FIN_STAMP_DRAINED(slot) ((void)0)
+#endif
+// (FIN_WAVES wavefronts stand in for column_sum's REDUCE_WAVES, VW each: 16 x 64 threads would cap a wavefront at 128 VGPRs, which the
+// 32 rows in flight per column pair + the trigonometry under them do not fit)
+constexpr int FIN_WAVES = DRM_FIN_WAVES, FIN_VW = REDUCE_WAVES / FIN_WAVES;
+// One more wavefront than the FIN_WAVES that sum: it only turns the links' rot_angles into d F / d (roll, pitch, yaw) — 1.1 us of
+// dependent arithmetic that ends with the sums instead of after them.
+__global__ void __launch_bounds__(WAVE *(FIN_WAVES + 1))
+    fk_mse_links_finish_kernel(const float *__restrict__ partials, int n_rows, LinkArgs la, float *__restrict__ grad_params,
+                               float *__restrict__ loss, float loss_scale) {
+    constexpr int CAP = 8, NV = CAP * BWD_FIELDS, PITCH = NV + 4, FT = 12, NT = DRM_FK_MSE_MAX_LINKS * FT;
+    static_assert(REDUCE_WAVES % FIN_WAVES == 0, "whole virtual wavefronts per wavefront");
+    __shared__ float lds[2][REDUCE_WAVES][WAVE];
+    __shared__ float ge[CAP * FT], grows[NT], lpar[DRM_FK_MSE_MAX_LINKS * 6], dmat[DRM_FK_MSE_MAX_LINKS][27];
+    __shared__ int se[CAP * FT];
+    __shared__ unsigned owner[NT], count[NT];      // per element of a learnable link's (F, t): the first walk entry gathered from it, how many
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u);
+    FIN_STAMP(0);
+    if (wave == FIN_WAVES) {      // the trigonometry wavefront
+        float pv[DRM_FK_MSE_MAX_LINKS];
+        link_args_load(la, (unsigned)lane, pv);
+        for (int i = lane; i < NT; i += WAVE) { owner[i] = 0xffffffffu; count[i] = 0u; }
+        link_args_to_lds(la, (unsigned)lane, pv, lpar);
+        wave_lds_sync();
+        if (lane < la.n_links) {
+            float rpy[3], D[27];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rpy[i] = lpar[lane * 6 + i];
+            rpy_jacobian(rpy, D, D + 9, D + 18);
+#pragma unroll
+            for (int i = 0; i < 27; ++i) dmat[lane][i] = D[i];
+        }
+        FIN_STAMP_DRAINED(3);
+        __syncthreads();
+        return;
+    }
+    // column e = op k, field j of (dF row-major, dt) -> entry `at` of the op's row (store_fk_gradient).  A lane holds columns 2 lane and
+    // 2 lane + 1: ONE 8-byte load per lane and row (a row is 100 floats: 50 lanes), half the load instructions of one column per lane
+    // — the block's 25 KB all go through one CU's address path, which is what this phase waits for.
+    int at[2], sel[2] = {-1, -1};
+    float sign[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = 2 * lane + h, k = e / BWD_FIELDS, j = e % BWD_FIELDS;
+        const int a = j < 9 ? DRM_OPF_FIJ(j / 3, j % 3) : DRM_OPF_TI(j - 9);
+        at[h] = k * FT + a;
+        if (wave == 0 && e < NV) { sel[h] = la.sel[k * DRM_OPF_STRIDE + a]; sign[h] = la.gsign[k * DRM_OPF_STRIDE + a]; }
+    }
+    // column_sum's order for both columns; virtual wavefront vw = wave + j * FIN_WAVES adds rows vw, vw + 16, ...
+    // (32-bit byte offsets from the scalar base: the load's own addressing mode, one add per load)
+    const bool live0 = 2 * lane <= NV, live1 = 2 * lane + 1 <= NV;      // (column NV is the loss; NV + 1 .. NV + 3 pad the row)
+    const unsigned c0 = (unsigned)(wave * PITCH + (live0 ? 2 * lane : 0));
+    auto at_float2 = [&](unsigned index) -> float2 {
+        return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(partials) + index * 4u);
+    };
+    float s0[FIN_VW][REDUCE_UNROLL], s1[FIN_VW][REDUCE_UNROLL];
+#pragma unroll
+    for (int j = 0; j < FIN_VW; ++j)
+#pragma unroll
+        for (int u = 0; u < REDUCE_UNROLL; ++u) s0[j][u] = s1[j][u] = 0.0f;
+    int r = 0;
+    for (; r + (REDUCE_WAVES - 1) + (REDUCE_UNROLL - 1) * REDUCE_WAVES < n_rows; r += REDUCE_UNROLL * REDUCE_WAVES) {
+        float2 v[FIN_VW][REDUCE_UNROLL];
+#pragma unroll
+        for (int j = 0; j < FIN_VW; ++j)
+#pragma unroll
+            for (int u = 0; u < REDUCE_UNROLL; ++u) v[j][u] = at_float2((unsigned)(r + j * FIN_WAVES + u * REDUCE_WAVES) * PITCH + c0);
+        FIN_STAMP(1);
+#pragma unroll
+        for (int j = 0; j < FIN_VW; ++j)
+#pragma unroll
+            for (int u = 0; u < REDUCE_UNROLL; ++u) { s0[j][u] += v[j][u].x; s1[j][u] += v[j][u].y; }
+    }
+    if (r < n_rows)      // (uniform; 256 rows — BASELINE configuration 5 — are exactly one full round)
+#pragma unroll
+    for (int j = 0; j < FIN_VW; ++j)
+#pragma unroll
+        for (int u = 0; u < REDUCE_UNROLL; ++u) { // the last, partial round: same slots, rows past the end add nothing
+            const int row = r + wave + j * FIN_WAVES + u * REDUCE_WAVES;
+            const bool in = row < n_rows;
+            const float2 a = at_float2((unsigned)(in ? r + j * FIN_WAVES + u * REDUCE_WAVES : 0) * PITCH + c0);
+            s0[j][u] += in ? a.x : 0.0f;
+            s1[j][u] += in ? a.y : 0.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < FIN_VW; ++j) {
+#pragma unroll
+        for (int w = REDUCE_UNROLL / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) { s0[j][u] += s0[j][u + w]; s1[j][u] += s1[j][u + w]; }
+        lds[0][wave + j * FIN_WAVES][lane] = live0 ? s0[j][0] : 0.0f;
+        lds[1][wave + j * FIN_WAVES][lane] = live1 ? s1[j][0] : 0.0f;
+    }
+    FIN_STAMP_DRAINED(3);
+    __syncthreads();
+    FIN_STAMP(4);
+    if (wave != 0) return;
+    float total[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int w = 0; w < REDUCE_WAVES; ++w) { total[0] += lds[0][w][lane]; total[1] += lds[1][w][lane]; }
+    if (2 * lane == NV) loss[0] = total[0] * loss_scale;
+    // d loss / d (element of a learnable link's row) = the walk entries gathered from it, added in entry order
+    // (drm_walk_table_backward).  A link is one op of a walk, so nearly always ONE entry per element: every entry names itself at its
+    // element (the lowest index wins) and is counted; an element with one entry takes it, one with several scans them in order.
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = 2 * lane + h;
+        if (e < NV) {
+            ge[at[h]] = total[h] * sign[h];
+            se[at[h]] = sel[h];
+            const int col = sel[h] & (DRM_OPF_STRIDE - 1), slot = sel[h] >> 5;
+            if (sel[h] >= 0 && col < FT && slot < la.n_links) {
+                atomicMin(&owner[slot * FT + col], (unsigned)at[h]);
+                atomicAdd(&count[slot * FT + col], 1u);
+            }
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = h * WAVE + lane;
+        if (t < la.n_links * FT) {
+            const unsigned n = count[t];
+            float s = 0.0f;
+            if (n == 1u) {
+                s += ge[owner[t]];
+            } else if (n > 1u) {
+                const int want = (t / FT) * DRM_OPF_STRIDE + t % FT;
+                for (int e = 0; e < CAP * FT; ++e) s += se[e] == want ? ge[e] : 0.0f;
+            }
+            grows[t] = s;
+        }
+    }
+    wave_lds_sync();
+    FIN_STAMP_DRAINED(5);
+    if (lane < la.n_links) {           // link_row_backward for the (F, t) block: its first six outputs; the other 14 are zeros
+        float g[FT];
+#pragma unroll
+        for (int i = 0; i < FT; ++i) g[i] = grows[lane * FT + i];
+        float *out = grad_params + lane * LINK_PARAM_FLOATS;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[a] = dot9(&dmat[lane][a * 9], g);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[3 + i] = g[9 + i];
+#pragma unroll
+        for (int i = 6; i < LINK_PARAM_FLOATS; ++i) out[i] = 0.0f;
+    }
+    FIN_STAMP_DRAINED(6);
 }
 
 } // namespace drm
@@ -418,11 +675,11 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             if (n_tiles <= FK_BWD_PRE_MAX_TILES)
                 hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, true>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                    dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f);
+                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f, LinkArgs{});
             else
                 hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, false, false>), dim3((unsigned)(waves_a / MAX_WAVES_PER_BLOCK)),
                                    dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, grad_pos, n_tiles, param_mask, grad_q,
-                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f);
+                                   partials, 0.0f, ticket, grad_ops_f, (float *)nullptr, 0.0f, LinkArgs{});
             rc = launched();
             if (rc) return rc;
             if (ticket) return DRM_OK;
@@ -520,16 +777,61 @@ extern "C" int drm_fk_mse(const drm_walk *w, const float *q, const float *target
     if (n_tiles <= FK_BWD_PRE_MAX_TILES)
         hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
                            0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B), ticket, grad_ops_f, loss,
-                           loss_scale);
+                           loss_scale, LinkArgs{});
     else
         hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, false>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)), dim3(WAVE * MAX_WAVES_PER_BLOCK),
                            0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, 2.0f / (3.0f * (float)B), ticket, grad_ops_f, loss,
-                           loss_scale);
+                           loss_scale, LinkArgs{});
     rc = launched();
     if (rc) return rc;
     if (ticket) return DRM_OK;
     hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + 1 + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0,
                        s, scratch, waves, cap, grad_ops_f, cap * BWD_FIELDS + 4, loss, 1.0f / (3.0f * (float)B));
+    return launched();
+}
+
+// drm_fk_mse with the walk table built from the learnable links' parameters inside the first launch and the gradient taken back to
+// them inside the second: see include/drm_hip.h
+extern "C" int drm_fk_mse_links(const drm_walk *w, const int32_t *sel, const float *gsign, const drm_link_pieces *links, int32_t n_links,
+                                const float *q, const float *target, int64_t B, uint64_t param_mask, float *loss, float *grad_q,
+                                float *grad_params, float *scratch, void *stream) {
+    int rc = check_walk(w);
+    if (rc) return rc;
+    if (!sel || !gsign || !links || !q || !target || !loss || !grad_params || !scratch)
+        return fail(DRM_ERR_INVALID, "drm_fk_mse_links: sel / gsign / links / q / target / loss / grad_params / scratch must not be NULL");
+    if (n_links < 1 || n_links > DRM_FK_MSE_MAX_LINKS)
+        return fail(DRM_ERR_UNSUPPORTED, "drm_fk_mse_links takes 1 .. %s%ld learnable links (%ld): compose drm_walk_table, drm_fk_mse, "
+                                         "drm_walk_table_backward otherwise", "", (long)DRM_FK_MSE_MAX_LINKS, (long)n_links);
+    const int cap = w->capacity;
+    const uintptr_t ptrs = (uintptr_t)q | (uintptr_t)target | (uintptr_t)grad_q | (uintptr_t)w->ops_f | (uintptr_t)sel | (uintptr_t)gsign;
+    if (!((w->shape & DRM_WALK_ARM_CHAIN) && cap == 8 && w->n_dofs == 7 && (ptrs & 15u) == 0 && B >= WAVE && B % WAVE == 0 &&
+          B / WAVE < 0x7fffffffLL))
+        return fail(DRM_ERR_UNSUPPORTED, "drm_fk_mse_links takes what drm_fk_mse takes: 7-DoF arm chains (capacity 8), batches that are a "
+                                         "multiple of 64 rows, 16-byte aligned pointers%s", "");
+    if (!param_mask || (param_mask >> cap)) return fail(DRM_ERR_INVALID, "param_mask must select ops of the walk (those of the learnable links)");
+    LinkArgs la{};
+    for (int l = 0; l < n_links; ++l) {
+        if (!links[l].rot_angles || !links[l].trans) return fail(DRM_ERR_INVALID, "drm_fk_mse_links: rot_angles / trans of a link are NULL");
+        la.rpy[l] = links[l].rot_angles;
+        la.trans[l] = links[l].trans;
+    }
+    la.sel = sel; la.gsign = gsign; la.n_links = n_links;
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = (int)(B / WAVE);
+    const int waves = backward_waves(B, MAX_WAVES_PER_BLOCK);
+    const float loss_scale = 1.0f / (3.0f * (float)B), g_scale = 2.0f / (3.0f * (float)B);
+    if (n_tiles <= FK_BWD_PRE_MAX_TILES)
+        hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, true, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)),
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, g_scale,
+                           (uint32_t *)nullptr, (float *)nullptr, loss, loss_scale, la);
+    else
+        hipLaunchKernelGGL((fk_backward_arm_kernel<8, 7, true, false, true>), dim3((unsigned)(waves / MAX_WAVES_PER_BLOCK)),
+                           dim3(WAVE * MAX_WAVES_PER_BLOCK), 0, s, w->ops_f, q, target, n_tiles, param_mask, grad_q, scratch, g_scale,
+                           (uint32_t *)nullptr, (float *)nullptr, loss, loss_scale, la);
+    rc = launched();
+    if (rc) return rc;
+    hipLaunchKernelGGL(fk_mse_links_finish_kernel, dim3(1), dim3(WAVE * (FIN_WAVES + 1)), 0, s, scratch, waves, la, grad_params, loss,
+                       loss_scale);
     return launched();
 }
 
@@ -544,3 +846,4 @@ extern "C" int drm_fk_jacobian_backward(const drm_walk *w, const float *q, int64
     return fk_backward_launch(w, q, B, 1, grad_pos, grad_rot, grad_lin_jac, grad_ang_jac, param_mask, grad_q, grad_ops_f, scratch,
                               stream);
 }
+DRM_TL_READER(fkb)

@@ -2447,28 +2447,32 @@ DRM_HD void link_row(const float *p, float *row) {
 #pragma unroll
     for (int i = 26; i < DRM_OPF_STRIDE; ++i) row[i] = 0.0f;
 }
-DRM_HD void link_row_backward(const float *p, const float *g, float *gp) {
-    float Rx[9], Ry[9], Rz[9], cs[6], T[9], D[9], E[9];
-    rpy_factors(p, Rx, Ry, Rz, cs);
+// d F / d (roll, pitch, yaw) of F = (Rz Ry) Rx, each a 3 x 3 matrix (row-major)
+DRM_HD void rpy_jacobian(const float *rpy, float *D0, float *D1, float *D2) {
+    float Rx[9], Ry[9], Rz[9], cs[6], T[9], E[9];
+    rpy_factors(rpy, Rx, Ry, Rz, cs);
     const float sr = cs[0], cr = cs[1], sp = cs[2], cp = cs[3], sy = cs[4], cy = cs[5];
-    auto dot9 = [&](const float *A) {
-        float a = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) a += A[i] * g[i];
-        return a;
-    };
-    // F = (Rz Ry) Rx: derivative factors
     const float dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp},
                 dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
     mat3_mul(Rz, Ry, T);
-    mat3_mul(T, dRx, D);
-    gp[0] = dot9(D);
+    mat3_mul(T, dRx, D0);
     mat3_mul(Rz, dRy, E);
-    mat3_mul(E, Rx, D);
-    gp[1] = dot9(D);
+    mat3_mul(E, Rx, D1);
     mat3_mul(dRz, Ry, E);
-    mat3_mul(E, Rx, D);
-    gp[2] = dot9(D);
+    mat3_mul(E, Rx, D2);
+}
+DRM_HD float dot9(const float *A, const float *g) {
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a += A[i] * g[i];
+    return a;
+}
+DRM_HD void link_row_backward(const float *p, const float *g, float *gp) {
+    float D0[9], D1[9], D2[9];
+    rpy_jacobian(p, D0, D1, D2);
+    gp[0] = dot9(D0, g);
+    gp[1] = dot9(D1, g);
+    gp[2] = dot9(D2, g);
     const float m = p[6];
     const float *c = p + 7;
     const float *gI = g + 16;

@@ -25,7 +25,7 @@ import torch
 from . import backend
 from .flatten import (OPF_STRIDE, RobotSpec, WalkProgram, build_robot_spec, build_walk, fold_link_table,
                       foldable_links, identity_table_row, virtual_row_constants)
-from .autograd import (_FkJacobian, _FkMse, _FkPositions, _ForwardDynamics, _InverseDynamics, _MassMatrix,  # noqa: F401
+from .autograd import (_FkJacobian, _FkMse, _FkMseLinks, _FkPositions, _ForwardDynamics, _InverseDynamics, _MassMatrix,  # noqa: F401
                        _quat_grad_to_rot)
 from .rigid_body import DifferentiableRigidBody, LinkPose, LinkVelocity
 from .urdf_utils import URDFRobotModel
@@ -142,6 +142,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             body.set_parent(parent)
             parent.add_child(body)
         self._zero1 = torch.zeros(1, device=self._device)
+        self._fk_mse_links = os.environ.get("DRM_FK_MSE_LINKS", "1") != "0"      # (0: fk_mse_loss composes WalkTable + drm_fk_mse; A/B switch)
         self._kin_state = None   # (q, qd) of the last update_kinematic_state
         self._kin_cache = {}
 
@@ -491,6 +492,13 @@ class DifferentiableRobotModel(torch.nn.Module):
         """The walk table with learnable links through ONE fused kernel (backend.WalkTable): the constant entries come
         from a cached gather of the constant link table, the entries of the learnable links are rebuilt from their
         parameter callables inside the kernel, and the autograd graph holds a single node."""
+        links, base, sel = self._learnable_plan(dw)
+        ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *self._learnable_pieces(links))
+        return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
+
+    def _learnable_plan(self, dw: _DeviceWalk):
+        """(learnable links, base, sel) of a walk: the table of the CONSTANT links gathered into walk order, and for every entry of
+        the table the element of a learnable link's row it comes from (slot * 32 + column; -1: constant).  Cached per set of links."""
         links = sorted({link for link, _ in self._learnable})
         key = tuple(links)
         plan = dw.learnable_plan
@@ -506,7 +514,10 @@ class DifferentiableRobotModel(torch.nn.Module):
                 if link in row_of:
                     sel[e] = row_of[link] * OPF_STRIDE + col
             plan = dw.learnable_plan = (key, base, torch.from_numpy(sel).to(self._device))
-        _, base, sel = plan
+        return links, plan[1], plan[2]
+
+    def _learnable_pieces(self, links) -> list:
+        """The outputs of the parameter callables of the given links, six per link (backend.WalkTable's ``pieces``)."""
         zero1 = self._zero1
         pieces = []
         for i in links:
@@ -514,8 +525,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             damping = b.joint_damping()
             pieces += [b.rot_angles(), b.trans(), b.inertia.mass(), b.inertia.com(), b.inertia.inertia_mat(),
                        damping if damping is not None else zero1]
-        ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *pieces)
-        return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
+        return pieces
 
     def _chain_walk(self, idx: int) -> _DeviceWalk:
         """The root -> link chain walk of the kinematics calls that do NOT run under autograd.  Without learnable parameters the
@@ -847,6 +857,19 @@ class DifferentiableRobotModel(torch.nn.Module):
         if idx != 0 and q.shape[0] % 64 == 0 and q.shape[0] > 0:
             dw = self._get_walk(("fk", (idx,)), targets=[idx])
             if dw.program.shape & 1 and dw.program.capacity == 8 and self._n_dofs == 7:    # DRM_WALK_ARM_CHAIN
+                if (self._learnable and torch.is_grad_enabled() and self._device.type == "cuda" and not self._spec.skew.any()
+                        and len({link for link, _ in self._learnable}) <= backend.FK_MSE_MAX_LINKS and self._fk_mse_links):
+                    # learnable links: from their parameter tensors to the gradients with respect to them in TWO launches and one
+                    # autograd node (drm_fk_mse_links, ABI 12) — no table pass before, no table backward pass after
+                    links, base, sel = self._learnable_plan(dw)
+                    pieces = self._learnable_pieces(links)
+                    mask = self._kinematic_param_mask(dw)
+                    if mask and all(p.is_cuda for p in pieces):
+                        try:
+                            self._differentiable(dw)
+                            return _FkMseLinks.apply(q, target, base, sel, dw.gsign, dw, self._n_dofs, mask, *pieces)
+                        except backend.KernelUnsupported:
+                            pass
                 ops_f = self._ops_f(dw)
                 try:
                     if torch.is_grad_enabled() and (q.requires_grad or ops_f.requires_grad):

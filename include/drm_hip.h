@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 11
+#define DRM_ABI_VERSION 12
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_SPECIAL_KINDS 16 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
@@ -453,6 +453,32 @@ int drm_fk_jacobian_backward(const drm_walk *walk, const float *q, int64_t B, co
 int64_t drm_fk_mse_scratch_floats(int64_t B, int32_t capacity);
 int drm_fk_mse(const drm_walk *walk, const float *q, const float *target, int64_t B, uint64_t param_mask, float *loss,
                float *grad_q, float *grad_ops_f, float *scratch, void *stream);
+
+/*
+ * ABI 12: drm_fk_mse for a walk WITH learnable links, from their URDF-level parameters to the gradients with respect to them —
+ * what drm_walk_table -> drm_fk_mse -> drm_walk_table_backward compute (the whole forward + loss + backward of
+ * examples/learn_kinematics_of_iiwa.py:47-55 with the parameter modules of rigid_body_params.py in the loop), in TWO launches
+ * instead of five: every wavefront of the first launch rebuilds the rows of the learnable links itself (R_fixed = (Rz Ry) Rx of
+ * rot_angles, rigid_body.py:138-143; trans), the second adds the rows of partial sums AND takes the result back through that map.
+ *   walk->ops_f   the table of the CONSTANT links gathered into walk order (`base` of drm_walk_table)
+ *   sel, gsign    [capacity * DRM_OPF_STRIDE] as for drm_walk_table: entry e of the table is element sel[e] % 32 of the link row of
+ *                 learnable link sel[e] / 32, times gsign[e] (+-1: the axis canonicalisation), or the constant (sel[e] < 0)
+ *   links         HOST array of n_links (1 .. DRM_FK_MSE_MAX_LINKS) structs of DEVICE pointers, one per learnable link: the outputs
+ *                 of its parameter modules where they lie (no packing pass).  Forward kinematics reads rot_angles[3] and trans[3];
+ *                 the other four may be NULL.
+ *   grad_params   [n_links, 20] d loss / d (rot_angles, trans, mass, com, inertia_mat, damping) in drm_walk_table's layout (the last
+ *                 14 of a link are zeros: forward kinematics does not depend on them)
+ *   loss, grad_q, target, param_mask (!= 0: the ops of the learnable links), scratch (drm_fk_mse_scratch_floats): as for drm_fk_mse,
+ *   and the same walks / batches / alignment; DRM_ERR_UNSUPPORTED otherwise (compose the three calls).  Sums in drm_fk_mse's and
+ *   drm_walk_table_backward's order: the same bits as the composition.
+ */
+#define DRM_FK_MSE_MAX_LINKS 8
+struct drm_link_pieces {
+    const float *rot_angles, *trans, *mass, *com, *inertia_mat, *damping; /* 3, 3, 1, 3, 9, 1 floats */
+};
+int drm_fk_mse_links(const drm_walk *walk, const int32_t *sel, const float *gsign, const struct drm_link_pieces *links,
+                     int32_t n_links, const float *q, const float *target, int64_t B, uint64_t param_mask, float *loss,
+                     float *grad_q, float *grad_params, float *scratch, void *stream);
 
 /*
  * Reverse-mode derivative of drm_rnea: what torch autograd computes in the reference when a loss on

@@ -279,6 +279,7 @@ def test_gpu_one_launch_backward_reduction_equals_the_two_launch_form(B, monkeyp
         torch.manual_seed(1)
         m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
         m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+        m._fk_mse_links = False      # (the composition WalkTable + drm_fk_mse: drm_fk_mse_links has no ticket form)
         models.append(m)
     two, one = models
     q = torch.from_numpy(sample_states(one, B, seed=B)[0]).cuda()
@@ -717,3 +718,148 @@ def test_gpu_config5_full_size_vs_reference_autograd():
     for pname in ("trans", "rot_angles"):
         assert close(getattr(body, pname).param.grad.cpu().numpy(), g["config5/grad/" + pname]), pname
     assert abs(float(q.grad.double().abs().sum()) - float(g["config5/grad_q_abs_sum"])) < 1e-3 * float(g["config5/grad_q_abs_sum"])
+
+
+LINK_SETS = {
+    "link1": [("iiwa_link_1", "trans"), ("iiwa_link_1", "rot_angles")],
+    "rot_only": [("iiwa_link_3", "rot_angles")],
+    "every_arm_link": [("iiwa_link_%d" % i, p) for i in range(1, 8) for p in ("trans", "rot_angles")],
+    "with_dynamics": [("iiwa_link_2", "trans"), ("iiwa_link_5", "mass"), ("iiwa_link_5", "rot_angles"), ("iiwa_link_6", "com")],
+}
+
+
+def _learnable_pair(device, what, seed=3):
+    """Two models with the same learnable parameters: fk_mse_loss through drm_fk_mse_links, and through the composition."""
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor as UT
+    out = []
+    for links_path in (True, False):
+        m = load_model("iiwa7", device)
+        torch.manual_seed(seed)
+        for link, pname in LINK_SETS[what]:
+            m.make_link_param_learnable(link, pname, UT(1, 1) if pname == "mass" else UT(1, 3))
+        m._fk_mse_links = links_path
+        out.append(m)
+    return out
+
+
+def test_fk_mse_links_of_the_host_build_is_the_composition():
+    """ABI 12, libdrm_cpu.so: drm_fk_mse_links (table from the links' parameter tensors, loss, gradients back to the parameters) against
+    drm_walk_table -> drm_fk_mse -> drm_walk_table_backward called one by one."""
+    from differentiable_robot_model_amd import backend
+    for what in LINK_SETS:
+        m = _learnable_pair("cpu", what)[0]
+        ee = m._name_to_idx_map["iiwa_link_ee"]
+        dw = m._get_walk(("fk", (ee,)), targets=[ee])
+        links, base, sel = m._learnable_plan(dw)
+        pieces = [p.detach() for p in m._learnable_pieces(links)]
+        mask = m._kinematic_param_mask(dw)
+        B = 192
+        q = torch.from_numpy(sample_states(m, B, seed=2)[0])
+        want = torch.randn(B, 3, generator=torch.Generator().manual_seed(1)) * 0.3
+        loss, gq, gp = backend.fk_mse_links(dw.program, base, dw.ops_i, sel, dw.gsign, pieces, q, want, 7, mask, True)
+        table = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *pieces).reshape(dw.program.capacity, -1)
+        loss2, gq2, gops = backend.fk_mse(dw.program, table, dw.ops_i, q, want, 7, mask, True)
+        lib = backend.library_for(torch.device("cpu"))
+        params = torch.cat([p.reshape(-1) for p in pieces]).contiguous()
+        gp2 = torch.empty(len(links), 20)
+        assert lib.drm_walk_table_backward(params.data_ptr(), len(links), gops.data_ptr(), sel.data_ptr(), dw.gsign.data_ptr(), gops.numel(),
+                                           gp2.data_ptr(), None) == 0
+        assert torch.equal(loss, loss2) and torch.equal(gq, gq2), what
+        assert torch.equal(gp[:, :6], gp2[:, :6]) and not gp[:, 6:].any(), what
+        assert float(gp[:, :6].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", sorted(LINK_SETS))
+@pytest.mark.parametrize("B", [64, 16384, 1030 * 64])
+def test_gpu_fk_mse_links_is_the_composition_in_two_launches(what, B):
+    """ABI 12 (drm_fk_mse_links): fk_mse_loss of a model with learnable links builds the walk table inside the chain kernel and takes
+    the gradient back to the links' parameters inside the reduction kernel.  Loss, d loss / d q and every parameter's gradient BIT FOR
+    BIT those of WalkTable -> drm_fk_mse -> WalkTable's backward (the same sums in the same order), for learnable sets of one link,
+    rotation only, all seven arm links, and links that are learnable in their dynamics only; batch sizes on both sides of the
+    register-table / LDS-table switch; with and without input gradients."""
+    fused, composed = _learnable_pair("cuda", what)
+    q = torch.from_numpy(sample_states(fused, B, seed=B)[0]).cuda()
+    with torch.no_grad():
+        want = load_model("iiwa7", "cuda").compute_forward_kinematics(q, "iiwa_link_ee")[0] + 0.02
+    for want_q, scale in ((True, 1.0), (False, 1.0), (True, -1.7)):
+        got = []
+        for m in (fused, composed):
+            m.zero_grad()
+            x = q.clone().requires_grad_(want_q)
+            loss = m.fk_mse_loss(x, "iiwa_link_ee", want)
+            assert (loss.grad_fn.name().startswith("_FkMseLinks")) == (m is fused)
+            (loss * scale).backward()
+            got.append([loss.detach()] + ([x.grad] if want_q else []) + [p.grad for p in m.parameters()])
+        assert len(got[0]) == len(got[1]) and len(got[0]) >= 2
+        for k, (a, b) in enumerate(zip(*got)):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            if scale == 1.0:
+                assert torch.equal(a, b), (what, B, want_q, k, float((a - b).abs().max()))
+            else:       # (the incoming gradient multiplies the sums here, their terms there: the last bits differ)
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (what, B, k)
+
+
+@pytest.mark.gpu
+def test_gpu_fk_mse_links_training_step_from_a_hip_graph(monkeypatch):
+    """The training step of the reference's kinematics-learning loop (examples/learn_kinematics_of_iiwa.py:47-55) through fk_mse_loss's
+    links form, captured into a hipGraph with fused Adam: the replayed steps follow the eager ones, and more learnable links than the
+    kernel takes (nine: every link of the chain) fall back to the composition."""
+    fused, composed = _learnable_pair("cuda", "link1")
+    B = 16384
+    q = torch.from_numpy(sample_states(fused, B, seed=4)[0]).cuda()
+    with torch.no_grad():
+        want = load_model("iiwa7", "cuda").compute_forward_kinematics(q, "iiwa_link_ee")[0]
+    losses = []
+    for m in (fused, composed):
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True, fused=True)
+
+        def step():
+            loss = m.fk_mse_loss(q, "iiwa_link_ee", want)
+            loss.backward()
+            opt.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()
+        seen = []
+        for _ in range(30):
+            graph.replay()
+            seen.append(float(loss.detach()))
+        losses.append(seen)
+    assert losses[0][-1] < 0.5 * losses[0][0]
+    assert np.allclose(losses[0], losses[1], rtol=1e-5, atol=1e-9)
+    # the kernel's maximum (eight learnable links: every link of the iiwa below its base) still goes through it, one more falls back
+    from differentiable_robot_model_amd import backend
+    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor as UT
+    pair = []
+    for links_path in (True, False):
+        many = load_model("iiwa7", "cuda")
+        torch.manual_seed(5)
+        for body in many._bodies[1:]:
+            many.make_link_param_learnable(body.name, "trans", UT(1, 3))
+        many._fk_mse_links = links_path
+        pair.append(many)
+    assert len({link for link, _ in pair[0]._learnable}) == backend.FK_MSE_MAX_LINKS == 8
+    got = []
+    for many in pair:
+        loss = many.fk_mse_loss(q, "iiwa_link_ee", want)
+        assert loss.grad_fn.name().startswith("_FkMseLinks") == (many is pair[0])
+        loss.backward()
+        got.append([loss.detach()] + [p.grad for p in many.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*got))
+    monkeypatch.setattr(backend, "FK_MSE_MAX_LINKS", 7)
+    loss = pair[0].fk_mse_loss(q, "iiwa_link_ee", want)
+    assert loss.grad_fn.name().startswith("_FkMse") and not loss.grad_fn.name().startswith("_FkMseLinks")
+    assert torch.equal(loss.detach(), got[0][0])
