@@ -103,41 +103,69 @@ __global__ void __launch_bounds__(WALK_TABLE_THREADS)
         ops_f[e] = r >= 0 ? rows[r] * gsign[e] : base[e];
     }
 }
+// Latency-bound (one block, a few KB): the last wavefront only turns every link's rot_angles into d F / d (roll, pitch, yaw)
+// (rpy_jacobian: ~1.1 us of dependent arithmetic) while the others sort the walk entries to the row elements they were gathered from.
+// A link is one op of a walk, so nearly always ONE entry per element: every entry names itself at its element (LDS atomicMin: the
+// lowest index) and is counted; an element with one entry takes it, one with several adds them in entry order (deterministic, the
+// host build's order) — instead of every element scanning the ops of the walk (round 4: 14.5 -> 6 us; now ~3).
 __global__ void __launch_bounds__(WALK_TABLE_THREADS)
     walk_table_backward_kernel(const float *__restrict__ params, int n_links, const float *__restrict__ grad_ops_f,
                                const int32_t *__restrict__ sel, const float *__restrict__ gsign, int n_entries,
                                float *__restrict__ grad_params) {
-    __shared__ float grows[WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE];
-    __shared__ float ge[DRM_MAX_OPS * DRM_OPF_STRIDE];   // grad * sign of every walk entry
-    __shared__ int se[DRM_MAX_OPS * DRM_OPF_STRIDE];     // its row element (-1: constant)
-    __shared__ uint32_t opmask[DRM_MAX_OPS];             // per op (32 consecutive entries): bit ls set <=> it gathers from learnable row ls
+    constexpr int NE = DRM_MAX_OPS * DRM_OPF_STRIDE, NR = WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE, WAVES = WALK_TABLE_THREADS / WAVE;
+    __shared__ float grows[NR], ge[NE], dmat[WALK_TABLE_MAX_LINKS][27];
+    __shared__ int se[NE];
+    __shared__ unsigned owner[NR], count[NR];
     const int t = (int)threadIdx.x;
-    for (int e = t; e < n_entries; e += WALK_TABLE_THREADS) {
-        ge[e] = grad_ops_f[e] * gsign[e];
-        se[e] = sel[e];
-    }
-    __syncthreads();
-    const int n_rows_walk = (n_entries + DRM_OPF_STRIDE - 1) / DRM_OPF_STRIDE;
-    for (int k = t; k < n_rows_walk; k += WALK_TABLE_THREADS) {
-        uint32_t m = 0u;
-        for (int j = 0; j < DRM_OPF_STRIDE; ++j) {
-            const int e = k * DRM_OPF_STRIDE + j;
-            const int r = e < n_entries ? se[e] : -1;
-            if (r >= 0) m |= 1u << (r / DRM_OPF_STRIDE);
+    const bool trig_wave = t >= (WAVES - 1) * WAVE;
+    const int n_rows = n_links * DRM_OPF_STRIDE;
+    // (requested first: the entries this thread sorts below)
+    constexpr int PER = NE / ((WAVES - 1) * WAVE) + 1;
+    float g_mine[PER];
+    int r_mine[PER];
+    if (!trig_wave) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = t + i * (WAVES - 1) * WAVE;
+            const bool in = e < n_entries;
+            r_mine[i] = in ? sel[e] : -1;
+            g_mine[i] = in ? grad_ops_f[e] * gsign[e] : 0.0f;
         }
-        opmask[k] = m;
+    }
+    for (int r = t; r < n_rows; r += WALK_TABLE_THREADS) { owner[r] = 0xffffffffu; count[r] = 0u; }
+    __syncthreads();
+    if (trig_wave) {
+        const int l = t - (WAVES - 1) * WAVE;
+        if (l < n_links) {
+            float rpy[3], D[27];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rpy[i] = params[l * LINK_PARAM_FLOATS + i];
+            rpy_jacobian(rpy, D, D + 9, D + 18);
+#pragma unroll
+            for (int i = 0; i < 27; ++i) dmat[l][i] = D[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = t + i * (WAVES - 1) * WAVE;
+            if (e < n_entries) {
+                ge[e] = g_mine[i];
+                se[e] = r_mine[i];
+                if (r_mine[i] >= 0 && r_mine[i] < n_rows) {
+                    atomicMin(&owner[r_mine[i]], (unsigned)e);
+                    atomicAdd(&count[r_mine[i]], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
-    // every row element adds the walk entries gathered from it, in entry order (deterministic).  Only the ops that gather from
-    // the element's link are scanned (a learnable link is ONE op of a walk, so 32 LDS reads per element instead of all
-    // n_entries of them: this kernel took 14.5 us of a 44 us training step on the iiwa, profiles/r04_step_kernels.txt)
-    for (int r = t; r < n_links * DRM_OPF_STRIDE; r += WALK_TABLE_THREADS) {
-        const uint32_t bit = 1u << (r / DRM_OPF_STRIDE);
+    for (int r = t; r < n_rows; r += WALK_TABLE_THREADS) {
+        const unsigned n = count[r];
         float s = 0.0f;
-        for (int k = 0; k < n_rows_walk; ++k) {
-            if (!(opmask[k] & bit)) continue;
-            const int e0 = k * DRM_OPF_STRIDE, e1 = e0 + DRM_OPF_STRIDE < n_entries ? e0 + DRM_OPF_STRIDE : n_entries;
-            for (int e = e0; e < e1; ++e) s += se[e] == r ? ge[e] : 0.0f;
+        if (n == 1u) {
+            s += ge[owner[r]];
+        } else if (n > 1u) {
+            for (int e = 0; e < n_entries; ++e) s += se[e] == r ? ge[e] : 0.0f;
         }
         grows[r] = s;
     }
@@ -148,7 +176,9 @@ __global__ void __launch_bounds__(WALK_TABLE_THREADS)
         for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[t * LINK_PARAM_FLOATS + k];
 #pragma unroll
         for (int k = 0; k < DRM_OPF_STRIDE; ++k) g[k] = grows[t * DRM_OPF_STRIDE + k];
-        link_row_backward(p, g, gp);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gp[a] = dot9(&dmat[t][a * 9], g);
+        link_row_backward_rest(p, g, gp);
 #pragma unroll
         for (int k = 0; k < LINK_PARAM_FLOATS; ++k) grad_params[t * LINK_PARAM_FLOATS + k] = gp[k];
     }

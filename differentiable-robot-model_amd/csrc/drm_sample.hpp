@@ -2467,12 +2467,17 @@ DRM_HD float dot9(const float *A, const float *g) {
     for (int i = 0; i < 9; ++i) a += A[i] * g[i];
     return a;
 }
+DRM_HD void link_row_backward_rest(const float *p, const float *g, float *gp);
 DRM_HD void link_row_backward(const float *p, const float *g, float *gp) {
     float D0[9], D1[9], D2[9];
     rpy_jacobian(p, D0, D1, D2);
     gp[0] = dot9(D0, g);
     gp[1] = dot9(D1, g);
     gp[2] = dot9(D2, g);
+    link_row_backward_rest(p, g, gp);
+}
+// gp[3 .. 19]: everything but the three angles (trans, mass, com, inertia_mat, damping)
+DRM_HD void link_row_backward_rest(const float *p, const float *g, float *gp) {
     const float m = p[6];
     const float *c = p + 7;
     const float *gI = g + 16;

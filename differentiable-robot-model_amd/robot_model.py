@@ -479,8 +479,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if (self._learnable and self._device.type == "cuda" and len({link for link, _ in self._learnable}) <= 32
-                and not self._spec.skew.any()):
+        if self._learnable and len({link for link, _ in self._learnable}) <= 32 and not self._spec.skew.any():
             return self._ops_f_learnable(dw)      # (more learnable links than the fused kernel takes: the torch path below)
         table = self._link_table(dw.fold_key)
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
@@ -857,14 +856,14 @@ class DifferentiableRobotModel(torch.nn.Module):
         if idx != 0 and q.shape[0] % 64 == 0 and q.shape[0] > 0:
             dw = self._get_walk(("fk", (idx,)), targets=[idx])
             if dw.program.shape & 1 and dw.program.capacity == 8 and self._n_dofs == 7:    # DRM_WALK_ARM_CHAIN
-                if (self._learnable and torch.is_grad_enabled() and self._device.type == "cuda" and not self._spec.skew.any()
+                if (self._learnable and torch.is_grad_enabled() and not self._spec.skew.any()
                         and len({link for link, _ in self._learnable}) <= backend.FK_MSE_MAX_LINKS and self._fk_mse_links):
                     # learnable links: from their parameter tensors to the gradients with respect to them in TWO launches and one
                     # autograd node (drm_fk_mse_links, ABI 12) — no table pass before, no table backward pass after
                     links, base, sel = self._learnable_plan(dw)
                     pieces = self._learnable_pieces(links)
                     mask = self._kinematic_param_mask(dw)
-                    if mask and all(p.is_cuda for p in pieces):
+                    if mask and all(p.device == self._device for p in pieces):
                         try:
                             self._differentiable(dw)
                             return _FkMseLinks.apply(q, target, base, sel, dw.gsign, dw, self._n_dofs, mask, *pieces)

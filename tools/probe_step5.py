@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configuration 5, the whole training step: WHICH kernels does one step launch?
 
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step5 -- python tools/probe_step5.py
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step5 -- python tools/probe_step5.py [dyn] [B]
   python tools/probe_step5.py --read gpurun_out/prof_step5        (lists the kernels of the last steps, in order, with durations)
 
 The step is the one bench_configs.py times: model.fk_mse_loss (ONE node) + loss.backward() + fused Adam, eagerly launched here so that
@@ -45,19 +45,34 @@ def main():
         return read(sys.argv[2])
     import torch
     from gpu_probe import load, sample
-    from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, UnconstrainedTensor
+    dyn = len(sys.argv) > 1 and sys.argv[1] == "dyn"      # the learn-dynamics step (examples/learn_dynamics_iiwa.py) instead
+    args = [a for a in sys.argv[1:] if a != "dyn"]
+    B = int(args[0]) if args else 16384
     torch.manual_seed(0)
     m, gt = load("iiwa7"), load("iiwa7")
-    m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
-    m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
-    q = sample(m, B)[0].cuda()
-    with torch.no_grad():
-        want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+    if dyn:
+        for k in range(1, 8):
+            link = "iiwa_link_%d" % k
+            m.make_link_param_learnable(link, "mass", PositiveScalar())
+            m.make_link_param_learnable(link, "com", UnconstrainedTensor(1, 3))
+            m.make_link_param_learnable(link, "inertia_mat", UnconstrainedTensor(3, 3))
+        q, qd, qdd = (t.cuda() for t in sample(m, B))
+        with torch.no_grad():
+            want = gt.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    else:
+        m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+        m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+        q = sample(m, B)[0].cuda()
+        with torch.no_grad():
+            want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
     for _ in range(12):
         opt.zero_grad(set_to_none=True)
-        loss = m.fk_mse_loss(q, "iiwa_link_ee", want)
+        if dyn:
+            loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True), want)
+        else:
+            loss = m.fk_mse_loss(q, "iiwa_link_ee", want)
         loss.backward()
         opt.step()
         torch.cuda.synchronize()
