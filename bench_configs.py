@@ -505,6 +505,11 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
 
         us_m, _ = graph_launch_us(lambda: backend.fk_mse(dw.program, ops_f, dw.ops_i, q, want, 7, mask, False), 50)
         leg["fk_mse_launch_us"] = us_m
+        # ABI 12: the same from the links' parameter tensors to their gradients (table build + table backward inside the two launches)
+        links, base, sel = learn._learnable_plan(dw)
+        pieces = [p.detach() for p in learn._learnable_pieces(links)]
+        leg["fk_mse_links_launch_us"], _ = graph_launch_us(
+            lambda: backend.fk_mse_links(dw.program, base, dw.ops_i, sel, dw.gsign, pieces, q, want, 7, mask, False), 50)
         leg["fk_mse_roofline"] = roofline(96, B, us_m, "drm_fk_mse: fk_backward_arm_kernel<8, 7, true> + fk_backward_reduce_kernel")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -531,7 +536,7 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
             times.append(s.elapsed_time(e) / 50 * 1e3)
         leg["graph_step_fused_us"] = sorted(times)[len(times) // 2]
         leg["graph_step_fused_evals_per_s"] = B / leg["graph_step_fused_us"] * 1e6
-        leg["graph_step_fused_note"] = ("the same training step with model.fk_mse_loss (ONE node: drm_fk_mse) and fused Adam, "
+        leg["graph_step_fused_note"] = ("the same training step with model.fk_mse_loss (ONE node: drm_fk_mse_links, two launches) and fused Adam, "
                                         "replayed from a hipGraph")
         del graph
     except Exception as err:   # pragma: no cover - depends on the runtime

@@ -106,7 +106,9 @@ for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", 
                  ("probe_api.txt", "_probe_api.txt"), ("probe_special.txt", "_probe_special.txt"), ("api_latency.txt", "_api_latency.txt"),
                  ("ab_fan.txt", "_ab_fan_final.txt"), ("timeline.txt", "_timeline.txt"),
                  ("ab_learnable_arm.txt", "_ab_learnable_arm.txt"), ("probe_chunks.txt", "_probe_chunks.txt"),
-                 ("probe_nonfinite.txt", "_probe_nonfinite.txt"),
+                 ("probe_nonfinite.txt", "_probe_nonfinite.txt"), ("step5_kernels.txt", "_step5_kernels.txt"),
+                 ("step_dyn_kernels.txt", "_step_dyn_kernels.txt"), ("ab_fk_mse_links.txt", "_ab_fk_mse_links.txt"),
+                 ("timeline_links.txt", "_timeline_links.txt"), ("learn_dynamics.txt", "_learn_dynamics.txt"),
                  # round 6: bench.py's stdout is the compact line; the full records of the runs
                  ("bench_default_detail.json", "_bench_default_detail.json"), ("bench_k20_detail.json", "_bench_k20_detail.json"),
                  ("bench_config3_detail.json", "_bench_config3_detail.json"),

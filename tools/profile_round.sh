@@ -56,6 +56,20 @@ DRM_SPECIALIZE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pr
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_robots -- python $ROOT/tools/probe_robots.py > $OUT/prof_robots.log 2>&1
 DRM_SPECIALIZE=0 python $ROOT/tools/kernel_times.py > $OUT/kernel_times.txt 2>&1
 for r in iiwa7 panda_no_gripper; do python $ROOT/tools/ab_learnable_arm.py $r 2>&1 | grep -v amdgpu.ids; done > $OUT/ab_learnable_arm.txt
+# round 6: which kernels one training step launches (configuration 5 through fk_mse_loss with and without drm_fk_mse_links; the
+# learn-dynamics example), the A/B of drm_fk_mse_links against the launches it replaces, its kernels' per-wavefront time stamps
+for mode in 1 0; do
+  DRM_FK_MSE_LINKS=$mode rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_step5_$mode -- python $ROOT/tools/probe_step5.py > $OUT/step5_$mode.log 2>&1
+  echo "== DRM_FK_MSE_LINKS=$mode"; python $ROOT/tools/probe_step5.py --read $OUT/prof_step5_$mode 2>&1 | tail -12
+done > $OUT/step5_kernels.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stepdyn -- python $ROOT/tools/probe_step5.py dyn 256 > $OUT/stepdyn.log 2>&1
+python $ROOT/tools/probe_step5.py --read $OUT/prof_stepdyn > $OUT/step_dyn_kernels.txt 2>&1
+python $ROOT/tools/ab_fk_mse_links.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_fk_mse_links.txt
+python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable" > $OUT/learn_dynamics.txt
+if [ -f $ROOT/tools/variants/libdrm_tl_fin.so ]; then
+  DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_tl_fin.so python $ROOT/tools/timeline_links.py fin 2>&1 | grep -v amdgpu.ids | sed 's/-[0-9.]*e+1[12]/      --/g' > $OUT/timeline_links.txt
+  DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_tl_arm.so python $ROOT/tools/timeline_links.py arm 2>&1 | grep -v amdgpu.ids >> $OUT/timeline_links.txt
+fi
 python $ROOT/tools/probe_chunks.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_chunks.txt
 python $ROOT/tools/probe_nonfinite.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|return Diff" > $OUT/probe_nonfinite.txt
 python $ROOT/tools/probe_robots.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_robots.txt
