@@ -85,6 +85,7 @@ if st:
             if i == 0 or "drm::" in line:
                 g.write(line)
 for src, dst in (("bench_config3_two_ranks_shared_gpu.json", "_bench_config3_two_ranks_shared_gpu.json"),
+                 ("bench_config3_p2p_two_ranks_shared_gpu.json", "_bench_config3_p2p_two_ranks_shared_gpu.json"),
                  ("bench_metric_two_ranks_shared_gpu.json", "_bench_metric_two_ranks_shared_gpu.json"),
                  ("prof_stats_eager.log", "_bench_eager_under_rocprofv3.json")):
     line = last_json_line(os.path.join(OUT, src))
