@@ -254,9 +254,6 @@ __device__ __forceinline__ void last_block_reduce(uint32_t *ticket, const float 
 #define DRM_FK_BWD_PRE_MAX_TILES 1024 /* one tile per SIMD */
 #endif
 constexpr int FK_BWD_PRE_MAX_TILES = DRM_FK_BWD_PRE_MAX_TILES;
-#ifndef DRM_LINKS_VARIANT
-#define DRM_LINKS_VARIANT 0 /* development A/B of the in-kernel table build (tools/ab_fk_mse_links.py); 0 = the product */
-#endif
 // LINKS (drm_fk_mse_links): the walk table is built INSIDE the launch.  `ops_f` is the table of the constant links gathered into walk
 // order; the entries that come from a learnable link (sel[e] = slot * 32 + element of its link row, -1 otherwise) are rebuilt by every
 // wavefront from that link's rot_angles / trans — drm_walk_table's arithmetic (link_row, then x gsign), without its launch.
@@ -315,11 +312,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     int4 sel4;
     float4 sg4;
     if constexpr (LINKS) {
-#if DRM_LINKS_VARIANT == 3
-        for (int l = 0; l < DRM_FK_MSE_MAX_LINKS; ++l) pv[l] = 0.01f * (float)(lane + l);
-#else
         link_args_load(la, lane, pv);
-#endif
         sel4 = reinterpret_cast<const int4 *>(la.sel)[lane];
         sg4 = reinterpret_cast<const float4 *>(la.gsign)[lane];
     }
@@ -334,9 +327,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         for (int i = 0; i < 3; ++i) gv[i] = grow[i];
     };
     if constexpr (LINKS) {
-#if DRM_LINKS_VARIANT != 1
         if (wave_id < n_tiles) load_rows(wave_id);
-#endif
         static_assert(DRM_FK_MSE_MAX_LINKS * 12 <= Q_FLOATS && DRM_FK_MSE_MAX_LINKS * 6 <= G_FLOATS, "scratch of the table build");
         float *lrows = lq, *lpar = lg;          // (both tiles are written per tile further down)
         link_args_to_lds(la, lane, pv, lpar);
@@ -346,11 +337,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             float p[LINK_PARAM_FLOATS], row[DRM_OPF_STRIDE];
 #pragma unroll
             for (int i = 0; i < LINK_PARAM_FLOATS; ++i) p[i] = i < 6 ? lpar[lane * 6 + i] : 0.0f;
-#if DRM_LINKS_VARIANT == 2
-            for (int i = 0; i < 12; ++i) row[i] = p[i % 6];
-#else
             link_row(p, row);                   // (only F and t are live: forward kinematics reads nothing else of a row)
-#endif
 #pragma unroll
             for (int i = 0; i < 12; ++i) lrows[lane * 12 + i] = row[i];
         }
@@ -385,11 +372,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     for (int tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t b0 = (int64_t)tile * WAVE;
         float gqv[NJ];
-#if DRM_LINKS_VARIANT == 1
-        load_rows(tile);
-#else
         if (!LINKS || tile != wave_id) load_rows(tile);
-#endif
         wave_lds_sync(); // the previous tile's staged gradients have left
 #pragma unroll
         for (int d = 0; d < NJ; ++d) lq[lane * NJ + d] = qv[d]; // (the cold parameter loop reads an angle by run-time index)
