@@ -988,7 +988,8 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     assert set(d["configs_frac"]) == {"c2", "c3_shard", "c3_whole", "c4", "c5", "c5_fk_mse"}
     assert all(0 < v < 1.0 for v in d["configs_frac"].values())
     # round 6: the drop-in path IS the benchmarked path — a constant model picks its own (shipped) kernels up by itself
-    assert d["configs_own_kernel"] == {"c3_shard": "default", "c3_whole": "default", "c4": "default"}, d["configs_own_kernel"]
+    own_off = os.environ.get("DRM_SPECIALIZE") == "0"      # (the suite run on the library's kernels: nothing is attached)
+    assert own_off or d["configs_own_kernel"] == {"c3_shard": "default", "c3_whole": "default", "c4": "default"}, d["configs_own_kernel"]
     assert set(d["api_eager_us_per_call"]) == {"forward_kinematics", "endeffector_jacobian", "inverse_dynamics"}
 
     # ---- the full record (--detail): what the compact line was cut from
@@ -1012,5 +1013,5 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
         roof = leg["roofline"]
         assert roof["launch_us"] > 0 and 0 < roof["frac"] < 1.0, name
     c3 = legs["config3_whole"]
-    assert c3["own_kernel"] is True and c3["launch_us"] < c3["library_kernel_launch_us"]
-    assert legs["config4"]["own_kernel"] is True and legs["config4"]["launch_us"] < legs["config4"]["library_kernel_launch_us"]
+    assert own_off or (c3["own_kernel"] is True and c3["launch_us"] < c3["library_kernel_launch_us"])
+    assert own_off or (legs["config4"]["own_kernel"] is True and legs["config4"]["launch_us"] < legs["config4"]["library_kernel_launch_us"])

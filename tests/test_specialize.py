@@ -23,6 +23,13 @@ from test_random_trees import tree_model
 needs_hipcc = pytest.mark.skipif(sp.hipcc() is None, reason="hipcc not on this machine")
 
 
+@pytest.fixture(autouse=True)
+def _own_kernels_as_shipped(monkeypatch):
+    """This file tests the own-kernel machinery itself: DRM_SPECIALIZE in the caller's environment (e.g. =0 to run every OTHER suite on
+    the library's kernels) does not reach it; the tests of that switch set it themselves."""
+    monkeypatch.delenv("DRM_SPECIALIZE", raising=False)
+
+
 def library_only(m):
     """A model that keeps to the library's kernels (round 6: by default a model attaches whatever own kernel is already built —
     shipped, or left in the run-time cache by an earlier test): the other side of every own-vs-library comparison below."""
