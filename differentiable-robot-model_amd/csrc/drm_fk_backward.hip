@@ -11,10 +11,13 @@
 // Per sample: in q[n], grad_pos[T,3]; out grad_q[n] (optional).                 n = 7, T = 1: 28 + 12 + 28 = 68 B
 // Per launch: out grad_ops_f[cap, 32] (dL/dF and dL/dt in the FT block of every op selected by param_mask, zeros
 //             elsewhere), reduced DETERMINISTICALLY: each wave strides over tiles and keeps one running sum per
-//             (op, field), writes one row of `partials`, and a second tiny kernel adds the rows in a fixed order.
+//             (op, field), writes one row of `partials` (the arm kernel: one row per BLOCK, its wavefronts' sums added in
+//             wavefront order through LDS), and a second tiny kernel adds the rows in a fixed order.
 // LDS per wave: [ q : 64 (n|1) ][ grad_pos : 64 (3T|1) ][ grad_q : 64 (n|1) ][ constant-gradient sums : cap*12 ]
 //               [ pose slots : n_slots*12*64 ][ adjoint slots : n_slots*12*64 ][ JAC: 2 x 64 (3n|1) ]
 //               [ parked poses : cap*12*64 unless PARK_HBM ]
+#include <type_traits>
+
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
 
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
     static_assert(NJ & 1, "odd row widths only (linear LDS image)");
     static_assert(CAP * DRM_OPF_STRIDE == 4 * WAVE, "one float4 per lane copies the constant table");
     constexpr int C_FLOATS = CAP * DRM_OPF_STRIDE, Q_FLOATS = round4(WAVE * NJ), G_FLOATS = round4(WAVE * 3);
-    constexpr int NV = CAP * BWD_FIELDS, A_FLOATS = round4(NV);
+    constexpr int NV = CAP * BWD_FIELDS, A_FLOATS = round4(NV + 1);      // (+ the loss column of the MSE form)
     constexpr int PER_WAVE = C_FLOATS + Q_FLOATS + G_FLOATS + A_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[MAX_WAVES_PER_BLOCK * PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -406,16 +409,23 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
             tile_store<NJ>(gq + b0 * NJ, WAVE, NJ, 0u, lq, lane, true);
         }
     }
-    wave_lds_sync();
-    constexpr int PITCH = MSE ? NV + 4 : NV;
-    float *prow = partials + (int64_t)wave_id * PITCH;
-    for (int i = (int)lane; i < NV; i += WAVE) publish(prow + i, lacc[i]);
-    if (MSE && lane == 63u) publish(prow + NV, loss_acc);
+    // ONE row of partial sums per BLOCK (round 6): the wavefronts' running sums are added in wavefront order through LDS before they
+    // leave the CU.  The reduction launch then reads an eighth of the rows — at 16 384 rows 12.8 KB instead of 100 KB, which one CU
+    // (drm_fk_mse_links' finish kernel) spent 0.8 us just pulling through its L1.
+    constexpr int PITCH = MSE ? NV + 4 : NV, COLS = MSE ? NV + 1 : NV;
+    if (MSE && lane == 63u) lacc[NV] = loss_acc;
+    __syncthreads();
+    if ((int)threadIdx.x < COLS) {
+        float total = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MAX_WAVES_PER_BLOCK; ++w) total += smem[w * PER_WAVE + (C_FLOATS + Q_FLOATS + G_FLOATS) + (int)threadIdx.x];
+        publish(partials + (int64_t)blockIdx.x * PITCH + (int)threadIdx.x, total);
+    }
     ARM_STAMP_DRAINED(5);
     // ABI 11 (drm_walk.special[DRM_WALK_TICKET]): ONE launch.  The block that takes the last ticket adds the rows of partial sums
     // itself — in column_sum's order, so the totals are the two-launch form's bit for bit — instead of a second kernel behind a
     // ~1.7 us kernel boundary (BASELINE configuration 5: 16 384 rows, where the boundary was a quarter of drm_fk_mse).
-    if (ticket) last_block_reduce<CAP>(ticket, partials, n_waves, PITCH, grad_ops_f, MSE ? loss : nullptr, loss_scale, smem);
+    if (ticket) last_block_reduce<CAP>(ticket, partials, (int)gridDim.x, PITCH, grad_ops_f, MSE ? loss : nullptr, loss_scale, smem);
 }
 
 // grad_ops_f[k, FT field j] = sum over the partial rows of column k * 12 + j, in a fixed order (drm_common.hpp
@@ -526,17 +536,36 @@ __global__ void __launch_bounds__(WAVE *(FIN_WAVES + 1))
 #pragma unroll
             for (int u = 0; u < REDUCE_UNROLL; ++u) { s0[j][u] += v[j][u].x; s1[j][u] += v[j][u].y; }
     }
-    if (r < n_rows)      // (uniform; 256 rows — BASELINE configuration 5 — are exactly one full round)
+    if (r < n_rows) {    // (uniform) the last, partial round: same slots, rows past the end add nothing.  BASELINE configuration 5:
+        // 32 rows (one per block of the chain kernel), two per virtual wavefront.  Every load of the round is requested before the first
+        // is added (clamped addresses instead of branches), for as many slots as have a row left: 2, 8 or all 16.
+        auto round = [&](auto slots) {
+            constexpr int U = decltype(slots)::value;
+            float2 a[FIN_VW][U];
 #pragma unroll
-    for (int j = 0; j < FIN_VW; ++j)
+            for (int j = 0; j < FIN_VW; ++j)
 #pragma unroll
-        for (int u = 0; u < REDUCE_UNROLL; ++u) { // the last, partial round: same slots, rows past the end add nothing
-            const int row = r + wave + j * FIN_WAVES + u * REDUCE_WAVES;
-            const bool in = row < n_rows;
-            const float2 a = at_float2((unsigned)(in ? r + j * FIN_WAVES + u * REDUCE_WAVES : 0) * PITCH + c0);
-            s0[j][u] += in ? a.x : 0.0f;
-            s1[j][u] += in ? a.y : 0.0f;
-        }
+                for (int u = 0; u < U; ++u) {
+                    const bool in = r + wave + j * FIN_WAVES + u * REDUCE_WAVES < n_rows;
+                    a[j][u] = at_float2((unsigned)(in ? r + j * FIN_WAVES + u * REDUCE_WAVES : 0) * PITCH + c0);
+                }
+#pragma unroll
+            for (int j = 0; j < FIN_VW; ++j)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = r + wave + j * FIN_WAVES + u * REDUCE_WAVES < n_rows;
+                    s0[j][u] += in ? a[j][u].x : 0.0f;
+                    s1[j][u] += in ? a[j][u].y : 0.0f;
+                }
+        };
+        const int u_live = (n_rows - r + REDUCE_WAVES - 1) / REDUCE_WAVES;      // slots with any row left (uniform)
+        if (u_live <= 2)
+            round(std::integral_constant<int, 2>());
+        else if (u_live <= 8)
+            round(std::integral_constant<int, 8>());
+        else
+            round(std::integral_constant<int, REDUCE_UNROLL>());
+    }
 #pragma unroll
     for (int j = 0; j < FIN_VW; ++j) {
 #pragma unroll
@@ -666,8 +695,8 @@ static int fk_backward_launch(const drm_walk *w, const float *q, int64_t B, int3
             rc = launched();
             if (rc) return rc;
             if (ticket) return DRM_OK;
-            rows_done = waves_a;
-            partials += (int64_t)waves_a * cap * BWD_FIELDS;
+            rows_done = waves_a / MAX_WAVES_PER_BLOCK;      // (one row per block)
+            partials += (int64_t)rows_done * cap * BWD_FIELDS;
             q += done * n; grad_pos += done * 3;   // (grad_rot is NULL on this path)
             if (grad_q) grad_q += done * n;
             B -= done;
@@ -769,7 +798,7 @@ extern "C" int drm_fk_mse(const drm_walk *w, const float *q, const float *target
     if (rc) return rc;
     if (ticket) return DRM_OK;
     hipLaunchKernelGGL(fk_backward_reduce_kernel, dim3((unsigned)((cap * BWD_FIELDS + 1 + WAVE - 1) / WAVE)), dim3(WAVE * REDUCE_WAVES), 0,
-                       s, scratch, waves, cap, grad_ops_f, cap * BWD_FIELDS + 4, loss, 1.0f / (3.0f * (float)B));
+                       s, scratch, waves / MAX_WAVES_PER_BLOCK, cap, grad_ops_f, cap * BWD_FIELDS + 4, loss, 1.0f / (3.0f * (float)B));
     return launched();
 }
 
@@ -813,7 +842,7 @@ extern "C" int drm_fk_mse_links(const drm_walk *w, const int32_t *sel, const flo
                            (uint32_t *)nullptr, (float *)nullptr, loss, loss_scale, la);
     rc = launched();
     if (rc) return rc;
-    hipLaunchKernelGGL(fk_mse_links_finish_kernel, dim3(1), dim3(WAVE * (FIN_WAVES + 1)), 0, s, scratch, waves, la, grad_params, loss,
+    hipLaunchKernelGGL(fk_mse_links_finish_kernel, dim3(1), dim3(WAVE * (FIN_WAVES + 1)), 0, s, scratch, waves / MAX_WAVES_PER_BLOCK, la, grad_params, loss,
                        loss_scale);
     return launched();
 }
