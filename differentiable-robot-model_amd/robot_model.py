@@ -349,8 +349,9 @@ class DifferentiableRobotModel(torch.nn.Module):
         if tune:
             if dw.program.shape & SHAPE_ARM_CHAIN or dw.program.n_ops > sp.MAX_STATIC_OPS:
                 return {}
-            sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
-            return sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+            dw.program._special = {k: h for k, h in (getattr(dw.program, "_special", None) or {}).items() if k not in sp.KERNELS}
+            sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), ignore_tuned=True)
+            return sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)      # (remembered: specialize.tuned_kinds)
         if not force and sp.arm_qualifies(dw.program, self._n_dofs):
             # a serial 7-DoF arm (Panda, iiwa): its OWN kernels too, of a different kind — the library's streaming walk with this
             # robot's constants folded into the instruction stream (specialize.attach_arm, csrc/drm_arm_stream.hpp).  Inverse
@@ -451,8 +452,16 @@ class DifferentiableRobotModel(torch.nn.Module):
                         sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), cached_only=auto)
                 elif (os.environ.get("DRM_SPECIALIZE") == "tune" and not dw.program.shape & SHAPE_ARM_CHAIN
                       and dw.program.n_ops <= sp.MAX_STATIC_OPS):
-                    sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw))
+                    sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), ignore_tuned=True)
                     sp.tune(dw.program, self._ops_f(dw).detach(), dw.ops_i, self._n_dofs)
+                elif auto and not dw.program.shape & SHAPE_ARM_CHAIN and dw.program.n_ops <= sp.MAX_STATIC_OPS and not self._learnable:
+                    # a robot WITH a compiled shape in the library (an arm that carries a hand, a hand): its own kernels where a
+                    # tuning record — this machine's `specialize(tune=True)`, or the one shipped with the package — says they are
+                    # the faster ones, and only those entry points; silently none without a record
+                    try:
+                        sp.attach(dw.program, self._spec, self._n_dofs, self._const_table(dw), cached_only=True, tuned_only=True)
+                    except sp.CacheMiss:
+                        pass
             except sp.CacheMiss as err:
                 self._own_kernel_miss("the dynamics walk", err)
             except sp.SpecializeError:

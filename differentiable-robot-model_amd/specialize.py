@@ -241,11 +241,16 @@ def shipped_cache() -> str:
 SHIPPED_FANS = {"allegro_left": ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip", "link_15.0_tip"]}
 
 
-def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> list:
+SHIPPED_TREES = ("fetch", "panda", "jaco")      # robots whose whole-tree dynamics kernels ship (entry points per *.tuned.json)
+
+
+def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left"), trees=()) -> list:
     """Build, into SHIPPED_CACHE, the kernels `specialize()` would build at run time for the robots of the BASELINE configurations:
     the arms' inverse-dynamics / fused FK + RNEA (end-effector link) / inertia-matrix / forward-dynamics / input-gradient kernels and
-    the Allegro's four-fingertip fan-out kernel.  Needs hipcc and no GPU (models are built on the CPU: the tables are device-independent).
-    Returns the file names."""
+    the Allegro's four-fingertip fan-out kernel; `trees`: the whole-tree straight-line dynamics kernels (`attach`) of robots that are
+    not plain arms — a mobile manipulator (Fetch: no compiled shape in the library, every entry point 2-3.6x faster), arms with a
+    gripper (Panda, Jaco: the entry points their shipped tuning record keeps).  Needs hipcc and no GPU (models are built on the CPU:
+    the tables are device-independent).  Returns the file names."""
     import contextlib
     import io
 
@@ -283,6 +288,14 @@ def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left")) -> li
                 chains = [fan_chain(w.program, m._n_dofs) for w in fan] if fan else []
                 if chains and all(chains):
                     built.append(build(fan_source(chains, [m._ops_f(w).detach().numpy() for w in fan], m._n_dofs), ARM_FLAGS))
+        for robot in trees:
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = DifferentiableRobotModel(os.path.join(robot_description_folder, robot + ".urdf"), device="cpu")
+            dw = m._dynamics_walk()
+            if arm_qualifies(dw.program, m._n_dofs) or dw.program.n_ops > MAX_STATIC_OPS:
+                continue
+            src = source(walk_tree(dw.program, m._spec), m._n_dofs, dw.program.capacity if dw.program.backward_ok else 0, m._const_table(dw))
+            built.append(build(src, ARM_FLAGS))
     finally:
         if before is None:
             os.environ.pop("DRM_SPECIAL_CACHE", None)
@@ -708,11 +721,35 @@ def attach_arm(tree: WalkProgram, tree_table, n_dofs: int, chain: Optional[WalkP
     return special
 
 
-def attach(prog: WalkProgram, spec, n_dofs: int, table=None, cached_only: bool = False) -> Dict[int, int]:
+def _tuned_name(path: str) -> str:
+    """drm_special_<source key>.tuned.json of a code object drm_special_<source key>_<compiler key>.hsaco (the choice belongs to the
+    kernels' source, not to the compiler build that produced them)."""
+    stem = os.path.basename(path)
+    return "_".join(stem.split("_")[:3]) + ".tuned.json"
+
+
+def tuned_kinds(path: str):
+    """The entry points `tune` kept for this code object — on this machine (the run-time cache) or, failing that, as shipped with the
+    package (csrc/special_cache/*.tuned.json, measured on an MI355X by tools/tune_shipped.py) — or None when it was never tuned."""
+    import json
+    for folder in (cache_dir(), shipped_cache()):
+        try:
+            with open(os.path.join(folder, _tuned_name(path))) as f:
+                return set(int(k) for k in json.load(f)["kept"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def attach(prog: WalkProgram, spec, n_dofs: int, table=None, cached_only: bool = False, tuned_only: bool = False,
+           ignore_tuned: bool = False) -> Dict[int, int]:
     """Build (or fetch from the cache) and load the straight-line kernels of a whole-tree walk; the handles are stored on the
     program, from where backend._walk_struct copies them into every drm_walk built for it.  `table` (a CONSTANT model's walk table
     as a host array): the kernels carry it as compile-time constants (`source`) and no longer read ops_f — the host must drop them
-    when a parameter becomes learnable (`prog._special_const`)."""
+    when a parameter becomes learnable (`prog._special_const`).
+    A tuning record of this code object (`tuned_kinds`: written by `tune`, or shipped) limits the handles to the entry points it kept;
+    `tuned_only`: attach nothing without one (robots with a compiled shape in the library: their own kernels win some entry points
+    and lose others, only a measurement says which); `ignore_tuned`: every entry point (what `tune` itself starts from)."""
     from . import backend
     if any(k in (getattr(prog, "_special", None) or {}) for k in KERNELS):
         return prog._special
@@ -721,12 +758,18 @@ def attach(prog: WalkProgram, spec, n_dofs: int, table=None, cached_only: bool =
     tree = walk_tree(prog, spec)
     src = source(tree, n_dofs, prog.capacity if prog.backward_ok else 0, table)
     path = build(src, ARM_FLAGS if table is not None else (), cached_only)
+    kept = None if ignore_tuned else tuned_kinds(path)
+    if tuned_only and kept is None:
+        raise CacheMiss("%s was never tuned" % os.path.basename(path))
     handles = dict(getattr(prog, "_special", None) or {})
     for kind, kernel in KERNELS.items():
         if kernel not in src:           # (the reverse-mode kernel of a walk the backward entry points do not take / whose leaves exceed LDS)
             continue
+        if kept is not None and kind not in kept:
+            continue
         handles[kind] = _load(path, kernel)
     prog._special = handles
+    prog._special_path = path
     prog._special_const = table is not None
     prog._ws_cache = None          # (the cached drm_walk predates the handles)
     return handles
@@ -790,4 +833,12 @@ def tune(prog: WalkProgram, ops_f, ops_i, n_dofs: int, batch: int = 1 << 19, mar
     finally:
         shared._special = kept       # one assignment at the end (plans built before it keep the struct they snapshotted)
         shared._ws_cache = None
+    path = getattr(shared, "_special_path", None)
+    if path and report:      # remembered: a later process attaches exactly the kept entry points without measuring again
+        import json
+        try:
+            with open(os.path.join(cache_dir(), _tuned_name(path)), "w") as f:
+                json.dump({"kept": sorted(k for k in kept if k in calls), "batch": batch, "arch": target_arch(), "report": report}, f, indent=1)
+        except OSError:
+            pass
     return report

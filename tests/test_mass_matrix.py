@@ -93,6 +93,7 @@ def test_gpu_crba_throughput_form_of_the_small_shapes(robot, compat):
     row of a 131 072 + 70 row launch against the fp64 oracle, symmetric, and equal to rounding to the same rows in small launches
     (the Allegro hand, 16 ops, keeps its kernel at every size: the two must agree there bit for bit)."""
     mc, m = load_model(robot, reference_compat=compat), load_model(robot, "cuda", reference_compat=compat)
+    m.own_kernels = "off"       # (the library's two forms; the Panda and the Jaco ship their own inertia-matrix kernel, round 6)
     B = 2048 * 64 + 70
     q, _, _ = sample_states(mc, B, seed=3)
     dq = torch.from_numpy(q).cuda()

@@ -199,6 +199,7 @@ def test_gpu_persistent_kernels_walk_every_tile_of_a_large_batch(robot):
     own (a sample's arithmetic does not depend on its tile), and a few of them are checked against the fp64 oracle."""
     from helpers import load_model
     mc, m = load_model(robot), load_model(robot, "cuda")
+    m.own_kernels = "off"       # (the library's persistent kernels are what this test walks; Fetch and the Panda ship their own, round 6)
     B, n = 150001, m._n_dofs
     q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(mc, B, seed=5))
     tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)

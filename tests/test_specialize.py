@@ -990,3 +990,61 @@ def test_specialize_needs_a_device_model():
     m = load_model("panda_no_gripper")
     with pytest.raises(RuntimeError):
         m.specialize()
+
+
+def test_tuning_records_limit_what_a_model_attaches(tmp_path, monkeypatch):
+    """(CPU) `specialize.tune` leaves drm_special_<source key>.tuned.json next to the code object it measured; `tuned_kinds` reads the
+    run-time cache's record before the shipped one; the records shipped with the package name code objects that `prebuild_shipped`
+    builds from the current sources (a stale record would silently switch the robot's own kernels off)."""
+    import json
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path / "runtime"))
+    monkeypatch.setenv("DRM_SHIPPED_CACHE", str(tmp_path / "shipped"))
+    os.makedirs(sp.shipped_cache(), exist_ok=True)
+    path = os.path.join(sp.cache_dir(), "drm_special_0123456789abcdef0123_deadbeef.hsaco")
+    assert sp._tuned_name(path) == "drm_special_0123456789abcdef0123.tuned.json" and sp.tuned_kinds(path) is None
+    with open(os.path.join(sp.shipped_cache(), sp._tuned_name(path)), "w") as f:
+        json.dump({"kept": [1, 3]}, f)
+    assert sp.tuned_kinds(path) == {1, 3}
+    with open(os.path.join(sp.cache_dir(), sp._tuned_name(path)), "w") as f:
+        json.dump({"kept": []}, f)
+    assert sp.tuned_kinds(path) == set()                 # (this machine's own measurement wins)
+    monkeypatch.delenv("DRM_SHIPPED_CACHE")
+    monkeypatch.delenv("DRM_SPECIAL_CACHE")
+    records = [f for f in os.listdir(sp.SHIPPED_CACHE) if f.endswith(".tuned.json")]
+    assert len(records) == len(sp.SHIPPED_TREES)
+    if sp.hipcc() is not None:       # every shipped record belongs to a code object the current sources generate
+        monkeypatch.setenv("DRM_SHIPPED_CACHE", str(tmp_path / "rebuilt"))
+        built = sp.prebuild_shipped(robots=(), trees=sp.SHIPPED_TREES)
+        assert sorted(sp._tuned_name(b) for b in built) == sorted(records)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["fetch", "panda", "jaco"])
+def test_gpu_shipped_tree_robots_run_their_tuned_entry_points_by_default(robot):
+    """Robots that are not plain arms (round 6): the whole-tree kernels of Fetch, the Panda with its gripper and the Jaco ship with the
+    package together with a tuning record measured on an MI355X (tools/tune_shipped.py, profiles/r06_tune_shipped.txt); a plain
+    DifferentiableRobotModel(urdf, device="cuda") attaches exactly the entry points the record keeps — and the four entry points agree
+    with the library's kernels."""
+    import json
+    own, plain = load_model(robot, "cuda"), library_only(load_model(robot, "cuda"))
+    special = own._dynamics_walk().program._special
+    path = own._dynamics_walk().program._special_path
+    assert path.startswith(sp.shipped_cache()) or path.startswith(sp.cache_dir())
+    with open(os.path.join(sp.SHIPPED_CACHE, sp._tuned_name(path))) as f:
+        kept = set(json.load(f)["kept"])
+    assert kept and {k for k in special if k in sp.KERNELS} == kept
+    assert not (getattr(plain._dynamics_walk().program, "_special", None) or {})
+    B = 64 * 9 + 5
+    q, qd, qdd = (torch.from_numpy(a).cuda() for a in sample_states(own, B, seed=3))
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-4 * max(1e-6, float(b.abs().max()))
+    tau = plain.compute_inverse_dynamics(q, qd, qdd)
+    assert close(own.compute_inverse_dynamics(q, qd, qdd), tau)
+    assert close(own.compute_lagrangian_inertia_matrix(q), plain.compute_lagrangian_inertia_matrix(q))
+    a, b = own.compute_forward_dynamics(q, qd, tau), plain.compute_forward_dynamics(q, qd, tau)
+    assert float(((a - b).abs() / (1.0 + b.abs())).max()) < 2e-3        # (the solve amplifies rounding: as the other FD comparisons)
+    grads = []
+    for m in (own, plain):
+        x = q.clone().requires_grad_(True)
+        m.compute_inverse_dynamics(x, qd, qdd).pow(2).mean().backward()
+        grads.append(x.grad)
+    assert close(*grads)
