@@ -244,7 +244,11 @@ SHIPPED_FANS = {"allegro_left": ["link_3.0_tip", "link_7.0_tip", "link_11.0_tip"
 SHIPPED_TREES = ("fetch", "panda", "jaco")      # robots whose whole-tree dynamics kernels ship (entry points per *.tuned.json)
 
 
-def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left"), trees=()) -> list:
+SHIPPED_ROBOTS = ("panda_no_gripper", "iiwa7", "allegro_left", "fetch_arm_no_gripper")
+SHIPPED_LEARNABLE = ("panda_no_gripper", "iiwa7")      # arms whose learnable-parameter kernels ship (the examples' sets)
+
+
+def prebuild_shipped(robots=SHIPPED_ROBOTS, trees=()) -> list:
     """Build, into SHIPPED_CACHE, the kernels `specialize()` would build at run time for the robots of the BASELINE configurations:
     the arms' inverse-dynamics / fused FK + RNEA (end-effector link) / inertia-matrix / forward-dynamics / input-gradient kernels and
     the Allegro's four-fingertip fan-out kernel; `trees`: the whole-tree straight-line dynamics kernels (`attach`) of robots that are
@@ -275,7 +279,7 @@ def prebuild_shipped(robots=("panda_no_gripper", "iiwa7", "allegro_left"), trees
                     both = table.copy()
                     both[links:] = m._ops_f(chain).detach().numpy()[links:]
                     built.append(build(arm_source(both, links, True), ARM_FLAGS))
-            if arm_qualifies(dw.program, m._n_dofs):
+            if arm_qualifies(dw.program, m._n_dofs) and robot in SHIPPED_LEARNABLE:
                 # ... and the reverse-mode kernels of the arm WITH learnable dynamic parameters (round 6): mass, com and inertia_mat of
                 # all moving links (examples/learn_dynamics_iiwa.py) and of every single one of them (identification of one link / a payload)
                 moving = [m._bodies[i].name for i in m._controlled_joints]
