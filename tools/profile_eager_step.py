@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Host-side profile (cProfile) of the literal drop-in training step of BASELINE configuration 5, eagerly launched:
+compute_forward_kinematics + torch.nn.functional.mse_loss + backward + Adam (the reference's examples/learn_kinematics_of_iiwa.py loop)."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gpu_probe import load, sample  # noqa: E402
+from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor  # noqa: E402
+
+dev = "cuda" if torch.cuda.is_available() else "cpu"
+B = 16384
+torch.manual_seed(0)
+m, gt = load("iiwa7", dev), load("iiwa7", dev)
+m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+q = sample(m, B)[0].to(dev)
+with torch.no_grad():
+    want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+sync = torch.cuda.synchronize if dev == "cuda" else (lambda: None)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
+    loss = torch.nn.functional.mse_loss(pos, want)
+    loss.backward()
+    opt.step()
+
+
+def parts():
+    t = [time.perf_counter()]
+    opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee"); t.append(time.perf_counter())
+    loss = torch.nn.functional.mse_loss(pos, want); t.append(time.perf_counter())
+    loss.backward(); t.append(time.perf_counter())
+    opt.step(); t.append(time.perf_counter())
+    return [b - a for a, b in zip(t, t[1:])]
+
+
+for _ in range(50):
+    step()
+sync()
+t0 = time.perf_counter()
+for _ in range(300):
+    step()
+sync()
+print("eager step %.1f us" % ((time.perf_counter() - t0) / 300 * 1e6))
+acc = [0.0] * 5
+for _ in range(300):
+    for i, d in enumerate(parts()):
+        acc[i] += d
+sync()
+print("host time per part (us): zero_grad %.1f  forward %.1f  loss %.1f  backward %.1f  Adam %.1f" % tuple(a / 300 * 1e6 for a in acc))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(300):
+    step()
+pr.disable()
+sync()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
