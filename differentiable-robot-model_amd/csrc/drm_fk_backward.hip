@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         }
     }
     // ONE row of partial sums per BLOCK (round 6): the wavefronts' running sums are added in wavefront order through LDS before they
-    // leave the CU.  The reduction launch then reads an eighth of the rows — at 16 384 rows 12.8 KB instead of 100 KB, which one CU
+    // leave the CU.  The reduction launch then reads a quarter of the rows — at 16 384 rows 25.6 KB instead of 100 KB, which one CU
     // (drm_fk_mse_links' finish kernel) spent 0.8 us just pulling through its L1.
     constexpr int PITCH = MSE ? NV + 4 : NV, COLS = MSE ? NV + 1 : NV;
     if (MSE && lane == 63u) lacc[NV] = loss_acc;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(WAVE *REDUCE_WAVES)
 // The second launch of drm_fk_mse_links: the rows of partial sums -> d loss / d (F, t) of every op (fk_backward_reduce_kernel's sums,
 // in its order) -> d loss / d (rot_angles, trans) of the learnable links (drm_walk_table_backward's sums, in its order, and
 // link_row_backward), and the loss.  One block; capacity-8 walks.
-// Latency-bound (one block, ~25 KB read): everything that does not depend on the sums — the gather map of the 96 differentiated
+// Latency-bound (one block, 25.6 KB read at 16 384 rows): everything that does not depend on the sums — the gather map of the 96 differentiated
 // entries, the links' parameters, d F / d rpy of every learnable link — is requested / computed while the rows are in flight, both
 // halves of the 97 columns are summed in ONE pass, and after the block's only barrier wavefront 0 finishes alone.
 #ifndef DRM_FIN_WAVES
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(WAVE *(FIN_WAVES + 1))
             for (int u = 0; u < REDUCE_UNROLL; ++u) { s0[j][u] += v[j][u].x; s1[j][u] += v[j][u].y; }
     }
     if (r < n_rows) {    // (uniform) the last, partial round: same slots, rows past the end add nothing.  BASELINE configuration 5:
-        // 32 rows (one per block of the chain kernel), two per virtual wavefront.  Every load of the round is requested before the first
+        // 64 rows (one per block of the chain kernel), four per virtual wavefront.  Every load of the round is requested before the first
         // is added (clamped addresses instead of branches), for as many slots as have a row left: 2, 8 or all 16.
         auto round = [&](auto slots) {
             constexpr int U = decltype(slots)::value;
