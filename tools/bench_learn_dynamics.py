@@ -28,7 +28,7 @@ def timeit(fn, iters=200, warm=20):
 
 
 for constrained in (False, True):
-    for B in (256, 16384):
+    for B in (256, 16384) + (() if constrained else (1 << 20,)):
         torch.manual_seed(0)
         gt, m = load("iiwa7"), load("iiwa7")
         for k in range(1, 8):

@@ -65,7 +65,8 @@ done > $OUT/step5_kernels.txt
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stepdyn -- python $ROOT/tools/probe_step5.py dyn 256 > $OUT/stepdyn.log 2>&1
 python $ROOT/tools/probe_step5.py --read $OUT/prof_stepdyn > $OUT/step_dyn_kernels.txt 2>&1
 python $ROOT/tools/ab_fk_mse_links.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_fk_mse_links.txt
-python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable" > $OUT/learn_dynamics.txt
+( echo "== default: the arm's own kernel for this set of learnable blocks (shipped)"; python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable"
+  echo "== DRM_SPECIALIZE=0: the library's kernels (the round-5 path)"; DRM_SPECIALIZE=0 python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable" ) > $OUT/learn_dynamics.txt
 if [ -f $ROOT/tools/variants/libdrm_tl_fin.so ]; then
   DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_tl_fin.so python $ROOT/tools/timeline_links.py fin 2>&1 | grep -v amdgpu.ids | sed 's/-[0-9.]*e+1[12]/      --/g' > $OUT/timeline_links.txt
   DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_tl_arm.so python $ROOT/tools/timeline_links.py arm 2>&1 | grep -v amdgpu.ids >> $OUT/timeline_links.txt
