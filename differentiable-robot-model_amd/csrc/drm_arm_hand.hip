@@ -358,11 +358,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((P ==
                 lgq[trow + d] = a; lgqd[trow + d] = v; lgqdd[trow + d] = acc;
             },
             [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
-#pragma unroll
-                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
-                    const float total = wave_sum_lane63(g[j]);
-                    if (lane == 63u) prow[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
-                }
+                wave_sums_lane63<DRM_OPF_DAMP + 1>(lane, [&](int j) { return g[j]; },
+                                                   [&](int j, float total) { prow[k * DRM_OPF_STRIDE + j] += total; }); // tiles in this wavefront's fixed order
             },
             [&](int i, float x) { lp[i * WAVE] = x; }, [&](int i) { return lp[i * WAVE]; });
         if (gq) {

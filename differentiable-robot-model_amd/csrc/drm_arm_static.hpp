@@ -289,19 +289,12 @@ __device__ __forceinline__ void rnea_backward_arm_param_static_body(const float 
     for (int k = 0; k < LINKS; ++k) {
         int at = Slots::base(k);
         if ((MASK_KIN >> k) & 1u) {
-#pragma unroll
-            for (int j = 0; j < Slots::KIN; ++j) {
-                const float total = wave_sum_lane63(psum[at + j]);
-                if (lane == 63u) lc[k * DRM_OPF_STRIDE + j] = total;
-            }
+            wave_sums_lane63<Slots::KIN>(lane, [&](int j) { return psum[at + j]; }, [&](int j, float total) { lc[k * DRM_OPF_STRIDE + j] = total; });
             at += Slots::KIN;
         }
         if ((MASK_DYN >> k) & 1u) {
-#pragma unroll
-            for (int j = 0; j < Slots::DYN; ++j) {
-                const float total = wave_sum_lane63(psum[at + j]);
-                if (lane == 63u) lc[k * DRM_OPF_STRIDE + DRM_OPF_FT_FLOATS + j] = total;
-            }
+            wave_sums_lane63<Slots::DYN>(lane, [&](int j) { return psum[at + j]; },
+                                         [&](int j, float total) { lc[k * DRM_OPF_STRIDE + DRM_OPF_FT_FLOATS + j] = total; });
         }
     }
     wave_lds_sync();

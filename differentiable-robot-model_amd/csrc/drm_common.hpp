@@ -265,6 +265,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 #undef DRM_DPP_ADD
+// N cross-lane sums, G at a time: the DPP steps of a group interleave — a branch or an LDS update after every single sum serialised
+// them: 1.4 us of a 5 us wavefront in drm_fk_mse at 16 384 rows, profiles/r06_timeline_links.txt — while only G totals are live at once
+// (a whole row's 26 cost a streaming kernel its occupancy).  value(j): this lane's addend of sum j; sink(j, total): runs on lane 63.
+template <int N, int G = 4, typename V, typename S>
+__device__ __forceinline__ void wave_sums_lane63(unsigned lane, V &&value, S &&sink) {
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += G) {
+        float t[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (j0 + u < N) t[u] = wave_sum_lane63(value(j0 + u));
+        if (lane == 63u) {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                if (j0 + u < N) sink(j0 + u, t[u]);
+        }
+    }
+}
 
 // The walk's constant rows (CAP x 32 floats, 0.5 - 4 KB) -> wave-private LDS, once per wave: every later read of
 // a link constant is a broadcast LDS read (in-order returns, so the compiler can wait per link) instead of a scalar

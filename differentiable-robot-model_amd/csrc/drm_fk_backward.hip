@@ -128,12 +128,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         };
         auto gq_out = [&](int d, float v) { gqrow[d] = v; };
         auto param_out = [&](int k, const float *dF, const float *dt) { // wave-uniform: only for ops in param_mask
-#pragma unroll
-            for (int j = 0; j < BWD_FIELDS; ++j) {
-                const float mine = live ? (j < 9 ? dF[j] : dt[j - 9]) : 0.0f; // lanes past a partial tile hold garbage
-                const float total = wave_sum_lane63(mine);
-                if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in this wave's fixed order
-            }
+            wave_sums_lane63<BWD_FIELDS>(lane, [&](int j) { return live ? (j < 9 ? dF[j] : dt[j - 9]) : 0.0f; }, // lanes past a partial tile hold garbage
+                                         [&](int j, float total) { lacc[k * BWD_FIELDS + j] += total; }); // tiles in this wave's fixed order
         };
         // dL/dR of a target (the loss reads its quaternion): 9 floats per (sample, target), read straight from HBM
         const float *rrow = grot ? grot + (b0 + (live ? lane : 0u)) * (int64_t)(9 * T) : nullptr;
@@ -383,6 +379,7 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         fk_backward_chain_g<CAP, NJ>([&](int k) -> const float * { if constexpr (PRE) return tabr[k]; else return lc + k * DRM_OPF_STRIDE; },
                                    [&](int k) -> const float * { return lc + k * DRM_OPF_STRIDE; }, qv,
                                    [&](const float (&pe)[3], float (&g)[3]) {
+                                       ARM_STAMP(4);      // (the forward sweep is done)
                                        if constexpr (MSE) {
                                            const float e[3] = {pe[0] - gv[0], pe[1] - gv[1], pe[2] - gv[2]};
                                            const float sq = wave_sum_lane63(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]));
@@ -394,11 +391,17 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
                                    },
                                    param_mask, gqv, [&](int d) -> float { return lq[lane * NJ + d]; },
                                    [&](int k, const float *dF, const float *dt) {
-#pragma unroll
-                                       for (int j = 0; j < BWD_FIELDS; ++j) {
-                                           const float total = wave_sum_lane63(j < 9 ? dF[j] : dt[j - 9]);
-                                           if (lane == 63u) lacc[k * BWD_FIELDS + j] += total; // tiles in a fixed order
-                                       }
+                                       ARM_STAMP(6);      // (the adjoint sweep has reached a learnable op)
+                                       // (PRE: one wavefront per SIMD, at most one tile per wavefront — all twelve sums at once, and
+                                       // nothing to add to; the streaming form four at a time)
+                                       wave_sums_lane63<BWD_FIELDS, PRE ? BWD_FIELDS : 4>(
+                                           lane, [&](int j) { return j < 9 ? dF[j] : dt[j - 9]; },
+                                           [&](int j, float total) {
+                                               if constexpr (PRE)
+                                                   lacc[k * BWD_FIELDS + j] = total;
+                                               else
+                                                   lacc[k * BWD_FIELDS + j] += total; // tiles in a fixed order
+                                           });
                                    });
         ARM_STAMP(3);
         if (gq) {

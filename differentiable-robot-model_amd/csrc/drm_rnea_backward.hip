@@ -125,12 +125,8 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
         };
         auto gout = [&](int d, float a, float v, float c) { lgq[row + d] = a; lgqd[row + d] = v; lgqdd[row + d] = c; };
         auto param_out = [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
-#pragma unroll
-            for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) { // the last constant of a row is the damping
-                const float mine = live ? g[j] : 0.0f; // lanes past a partial tile hold garbage
-                const float total = wave_sum_lane63(mine);
-                if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wave's fixed order
-            }
+            wave_sums_lane63<DRM_OPF_DAMP + 1>(lane, [&](int j) { return live ? g[j] : 0.0f; }, // lanes past a partial tile hold garbage
+                                               [&](int j, float total) { lacc[k * DRM_OPF_STRIDE + j] += total; }); // tiles in this wavefront's fixed order
         };
         rnea_backward_walk(ops_f, ctl, 0, 0, n_ops, flags, param_mask, gq != nullptr, qf, gt, park, unpark, slot_put, slot_get,
                            slot_add, slot_take, gout, param_out);
@@ -246,12 +242,8 @@ __global__ void __launch_bounds__(WAVE *DRM_MAX_SEGMENTS)
         };
         auto gout = [&](int d, float x, float v, float c) { lq[row + d] = x; lqd[row + d] = v; lqdd[row + d] = c; };
         auto param_out = [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
-#pragma unroll
-            for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
-                const float mine = live ? g[j] : 0.0f;
-                const float total = wave_sum_lane63(mine);
-                if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
-            }
+            wave_sums_lane63<DRM_OPF_DAMP + 1>(lane, [&](int j) { return live ? g[j] : 0.0f; }, // lanes past a partial tile hold garbage
+                                               [&](int j, float total) { lacc[k * DRM_OPF_STRIDE + j] += total; }); // tiles in this wavefront's fixed order
         };
         // a short serial segment (a finger): the unrolled walk that parks nothing; anything else: the loops
         if (!rnea_backward_walk_short<BWD_SHORT_OPS>(ops_f, ctl, fa.p_end, a, b, flags, param_mask, gq != nullptr, qf, gt, slot_put,
@@ -439,11 +431,8 @@ __global__ void __launch_bounds__(WAVE * 4) __attribute__((amdgpu_waves_per_eu(D
             gq != nullptr, qv, qdv, qddv, gtv,
             [&](int d, float a, float v, float c) { lg[d * WAVE] = a; lg[(L + d) * WAVE] = v; lg[(2 * L + d) * WAVE] = c; },
             [&](int k, const float *g) { // wave-uniform call: only for the ops the mask selects
-#pragma unroll
-                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
-                    const float total = wave_sum_lane63(g[j]);
-                    if (lane == 63u) prow[k * DRM_OPF_STRIDE + j] += total; // tiles in this block's fixed order
-                }
+                wave_sums_lane63<DRM_OPF_DAMP + 1>(lane, [&](int j) { return g[j]; },
+                                                   [&](int j, float total) { prow[k * DRM_OPF_STRIDE + j] += total; }); // tiles in this block's fixed order
             });
         if (gq) {
             auto store = [&](float *dst, int arr) {

@@ -807,11 +807,8 @@ __device__ __forceinline__ void rnea_backward_static_body(const float *__restric
             [&](int d, float &x, float &v, float &a) { x = qv[d]; v = qdv[d]; a = qddv[d]; }, [&](int d) { return gtv[d]; },
             [&](int d, float x, float v, float a) { gqv[d] = x; gqdv[d] = v; gqddv[d] = a; },
             [&](int k, const float *g) { // wave-uniform call: only for the ops param_mask selects
-#pragma unroll
-                for (int j = 0; j < DRM_OPF_DAMP + 1; ++j) {
-                    const float total = wave_sum_lane63(g[j]);
-                    if (lane == 63u) lacc[k * DRM_OPF_STRIDE + j] += total; // tiles in this wavefront's fixed order
-                }
+                wave_sums_lane63<DRM_OPF_DAMP + 1>(lane, [&](int j) { return g[j]; },
+                                                   [&](int j, float total) { lacc[k * DRM_OPF_STRIDE + j] += total; }); // tiles in this wavefront's fixed order
             },
             [&](int leaf, const Motion &M, const f2 (&T)[3]) {
                 float *r = lleaf + leaf * (LEAF * WAVE);

@@ -65,7 +65,8 @@ if which == "fin":
 else:
     print("chain kernel (LINKS), %d wavefronts, us after the first start; slots: 0 start, 1 parameters in LDS, 2 table built, "
           "3 chain + adjoints done, 5 partial sums published (drained)" % n)
-    cols = [0, 1, 2, 3, 5]
+    cols = [0, 1, 2, 4, 6, 3, 5]
+    print("(slots in time order: 0 start, 1 parameters in LDS, 2 table built, 4 forward sweep done, 6 adjoint sweep at the learnable op, 3 chain done, 5 published)")
     print("median", np.median(rel[:, cols], axis=0))
     print("min   ", rel[:, cols].min(axis=0))
     print("max   ", rel[:, cols].max(axis=0))
