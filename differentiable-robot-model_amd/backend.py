@@ -21,7 +21,7 @@ from .flatten import MAX_SEGMENTS, OPI_PERM, WalkProgram
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 CPU_LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_cpu.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
 SPECIAL_FK_FAN_LINKS = 9      # index of the fan-out FK kernel in drm_walk.special[] (include/drm_hip.h DRM_SPECIAL_FK_FAN_LINKS)
@@ -58,6 +58,15 @@ class DrmLinkPieces(ctypes.Structure):
     _fields_ = [(name, ctypes.c_void_p) for name in ("rot_angles", "trans", "mass", "com", "inertia_mat", "damping")]
 
 
+FORM_PLAIN, FORM_SQUARE_PLUS, FORM_SYMM, FORM_SPD, FORM_COV = 0, 1, 2, 3, 4      # DRM_FORM_* of include/drm_hip.h (ABI 13)
+
+
+class DrmLinkForms(ctypes.Structure):
+    """Mirror of ``struct drm_link_forms`` (include/drm_hip.h, ABI 13): the form mass / inertia_mat / damping of a learnable link are stored in."""
+    _fields_ = [("mass", ctypes.c_int32), ("inertia_mat", ctypes.c_int32), ("damping", ctypes.c_int32),
+                ("mass_c", ctypes.c_float), ("inertia_mat_c", ctypes.c_float), ("damping_c", ctypes.c_float)]
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -72,7 +81,7 @@ EXPORTS = ("drm_abi_version", "drm_walk_sizeof", "drm_last_error", "drm_fk", "dr
            "drm_walk_table_backward", "drm_fk_rnea", "drm_forward_dynamics_scratch_floats", "drm_crba_scratch_floats",
            "drm_rnea_scratch_floats", "drm_fk_mse", "drm_fk_mse_scratch_floats", "drm_rnea_scratch_floats_aligned",
            "drm_crba_scratch_floats_aligned", "drm_forward_dynamics_scratch_floats_aligned", "drm_special_load", "drm_fk_rnea_put",
-           "drm_fk_mse_links")
+           "drm_fk_mse_links", "drm_walk_table_links", "drm_walk_table_links_backward")
 
 
 def library_for(device):
@@ -167,6 +176,10 @@ def load_library(path: str = None, kind: str = "cuda"):
         lib.drm_special_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.drm_fk_mse.restype = ctypes.c_int
         lib.drm_fk_mse.argtypes = [wp, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
+        lib.drm_walk_table_links.restype = ctypes.c_int
+        lib.drm_walk_table_links.argtypes = [ctypes.POINTER(DrmLinkPieces), ctypes.POINTER(DrmLinkForms), i32, vp, vp, vp, i32, vp, vp]
+        lib.drm_walk_table_links_backward.restype = ctypes.c_int
+        lib.drm_walk_table_links_backward.argtypes = [ctypes.POINTER(DrmLinkPieces), ctypes.POINTER(DrmLinkForms), i32, vp, vp, vp, i32, vp, vp]
         lib.drm_fk_mse_links.restype = ctypes.c_int
         lib.drm_fk_mse_links.argtypes = [wp, vp, vp, ctypes.POINTER(DrmLinkPieces), i32, vp, vp, i64, ctypes.c_uint64, vp, vp, vp, vp, vp]
         lib.drm_fk_mse_scratch_floats.restype = i64
@@ -672,6 +685,113 @@ class WalkTable(torch.autograd.Function):
                 n *= d
             out.append(grad[off:off + n].reshape(shape) if ctx.needs_input_grad[4 + i] else None)
             off += n
+        return (None, None, None, None) + tuple(out)
+
+
+PIECE_NAMES = ("rot_angles", "trans", "mass", "com", "inertia_mat", "damping")
+PIECE_SIZES = (3, 3, 1, 3, 9, 1)
+PIECE_OFFSETS = (0, 3, 6, 7, 10, 19)
+
+
+class LinkSourcePlan(object):
+    """What WalkTableLinks needs to know about the learnable links of a model besides their tensors: per link and piece the FORM the
+    tensor is stored in (FORM_*), the form's constant and — for a form other than plain — the module whose raw parameter the tensor
+    is (its torch arithmetic is what second derivatives go through)."""
+
+    def __init__(self, entries):
+        self.entries = entries                      # [n_links][6] of (form, constant, module or None)
+        self.n_links = len(entries)
+        self.forms = (DrmLinkForms * self.n_links)()
+        for l, link in enumerate(entries):
+            for j, name in ((2, "mass"), (4, "inertia_mat"), (5, "damping")):
+                setattr(self.forms[l], name, link[j][0])
+                setattr(self.forms[l], name + "_c", float(link[j][1]))
+        self.sizes = [6 if (j == 4 and link[j][0] != FORM_PLAIN) else PIECE_SIZES[j] for link in entries for j in range(6)]
+        self._links, self._key = None, None
+
+    def pieces(self, sources):
+        """The drm_link_pieces array of these tensors (cached while they stay where they are)."""
+        key = tuple(t.data_ptr() for t in sources)
+        if key != self._key:
+            links = (DrmLinkPieces * self.n_links)()
+            for i, ptr in enumerate(key):
+                setattr(links[i // 6], PIECE_NAMES[i % 6], ptr)
+            self._links, self._key = links, key
+        return self._links
+
+    def torch_pieces(self, sources):
+        """The pieces as differentiable functions of the sources (the modules' own arithmetic on the given raw tensors)."""
+        out = []
+        for i, t in enumerate(sources):
+            form, _, module = self.entries[i // 6][i % 6]
+            if form == FORM_PLAIN:
+                out.append(t)
+            else:
+                out.append(torch.func.functional_call(module, {"l": t}, ()))
+        return out
+
+
+class WalkTableLinks(torch.autograd.Function):
+    """The walk table of a robot with learnable links straight from the links' parameter tensors WHERE THEY LIE and in the form their
+    modules store them (drm_walk_table_links, ABI 13), and its derivative back to those tensors: one launch each, no cat of the 6 x
+    n_links pieces, no torch kernels for the modules the kernels know (PositiveScalar and the l[6] inertia-matrix modules of
+    rigid_body_params).  ``sources``: six tensors per learnable link (rot_angles, trans, mass, com, inertia_mat, damping) — the raw
+    parameter for a piece whose form is not plain, the module's output otherwise."""
+
+    @staticmethod
+    def forward(ctx, base, sel, gsign, plan, *sources):
+        lib = library_for(base.device)
+        dev = base.device
+        held = []
+        for t, size in zip(sources, plan.sizes):
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if t.numel() != size:
+                raise ValueError("a piece of a learnable link has %d elements, not %d" % (t.numel(), size))
+            held.append(t)
+        ops_f = torch.empty_like(base)
+        with _on_device(dev):
+            _check(lib.drm_walk_table_links(plan.pieces(held), plan.forms, plan.n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
+                                            base.numel(), ops_f.data_ptr(), _stream(dev)), lib)
+        ctx.save_for_backward(sel, gsign, base, *sources)
+        ctx.plan = plan
+        return ops_f
+
+    @staticmethod
+    def backward(ctx, grad_ops_f):
+        sel, gsign, base = ctx.saved_tensors[:3]
+        sources, plan = ctx.saved_tensors[3:], ctx.plan
+        if torch.is_grad_enabled():
+            # create_graph=True: sources -> pieces -> link rows -> walk order through torch ops (WalkTable.backward's twin)
+            with torch.enable_grad():
+                pieces = plan.torch_pieces(sources)
+                packed = torch.cat([p.reshape(-1).to(device=base.device, dtype=torch.float32) for p in pieces]).reshape(plan.n_links, 20)
+                rows = link_rows_torch(packed).reshape(-1)
+                table = torch.where(sel >= 0, rows[sel.clamp_min(0).long()] * gsign, base)
+                wanted = [i for i in range(len(sources)) if ctx.needs_input_grad[4 + i]]
+                got = torch.autograd.grad(table, [sources[i] for i in wanted], grad_ops_f.reshape(table.shape), create_graph=True,
+                                          allow_unused=True)
+            out = [None] * len(sources)
+            for i, g in zip(wanted, got):
+                out[i] = g if g is not None else torch.zeros_like(sources[i])
+            return (None, None, None, None) + tuple(out)
+        dev = base.device
+        lib = library_for(dev)
+        held = [t if (t.device == dev and t.dtype == torch.float32 and t.is_contiguous()) else
+                t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in sources]
+        g = grad_ops_f.contiguous().to(torch.float32)
+        grad = torch.empty(plan.n_links, 20, device=dev, dtype=torch.float32)
+        with _on_device(dev):
+            _check(lib.drm_walk_table_links_backward(plan.pieces(held), plan.forms, plan.n_links, g.data_ptr(), sel.data_ptr(),
+                                                     gsign.data_ptr(), g.numel(), grad.data_ptr(), _stream(dev)), lib)
+        out = []
+        for i, (t, size) in enumerate(zip(sources, plan.sizes)):
+            if not ctx.needs_input_grad[4 + i]:
+                out.append(None)
+                continue
+            l, j = divmod(i, 6)
+            piece = grad[l, PIECE_OFFSETS[j]:PIECE_OFFSETS[j] + size].reshape(t.shape)
+            out.append(piece if t.device == dev and t.dtype == torch.float32 else piece.to(device=t.device, dtype=t.dtype))
         return (None, None, None, None) + tuple(out)
 
 

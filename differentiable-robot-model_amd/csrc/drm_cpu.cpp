@@ -373,6 +373,51 @@ int drm_walk_table_backward(const float *params, int32_t n_links, const float *g
     return DRM_OK;
 }
 
+// ABI 13: the table from the links' parameter tensors where they lie, in the forms their modules store them, and the gradient back
+// to those tensors (include/drm_hip.h)
+static int links_raw(const char *, const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, int32_t n_entries,
+                     float *raw, int32_t (*form)[3], float (*c)[3]) {
+    if (!links) return fail(DRM_ERR_INVALID, "drm_walk_table_links: links must not be NULL");
+    if (n_links < 1 || n_links > 32 || n_entries < 1 || n_entries > DRM_MAX_OPS * DRM_OPF_STRIDE)
+        return fail(DRM_ERR_INVALID, "drm_walk_table_links: 1..32 learnable links and at most 32 x 32 walk entries (%ld, %ld)", n_links, n_entries);
+    for (int l = 0; l < n_links; ++l) {
+        const float *at[6] = {links[l].rot_angles, links[l].trans, links[l].mass, links[l].com, links[l].inertia_mat, links[l].damping};
+        for (int j = 0; j < 6; ++j)
+            if (!at[j]) return fail(DRM_ERR_INVALID, "drm_walk_table_links: a piece of link %ld is NULL", l);
+        const drm_link_forms f = forms ? forms[l] : drm_link_forms{};
+        const bool ok = (f.mass == DRM_FORM_PLAIN || f.mass == DRM_FORM_SQUARE_PLUS) &&
+                        (f.damping == DRM_FORM_PLAIN || f.damping == DRM_FORM_SQUARE_PLUS) &&
+                        (f.inertia_mat == DRM_FORM_PLAIN || (f.inertia_mat >= DRM_FORM_SYMM && f.inertia_mat <= DRM_FORM_COV));
+        if (!ok) return fail(DRM_ERR_INVALID, "drm_walk_table_links: unknown form of a piece of link %ld", l);
+        form[l][0] = f.mass; form[l][1] = f.inertia_mat; form[l][2] = f.damping;
+        c[l][0] = f.mass_c; c[l][1] = f.inertia_mat_c; c[l][2] = f.damping_c;
+        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) {
+            const int piece = link_piece_of(k), off = link_piece_offset(k);
+            const bool there = piece != 4 || f.inertia_mat == DRM_FORM_PLAIN || off < 6;
+            raw[l * LINK_PARAM_FLOATS + k] = there ? at[piece][off] : 0.0f;
+        }
+    }
+    return DRM_OK;
+}
+int drm_walk_table_links(const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, const float *base, const int32_t *sel,
+                         const float *gsign, int32_t n_entries, float *ops_f, void *) {
+    float raw[32 * LINK_PARAM_FLOATS], params[32 * LINK_PARAM_FLOATS], c[32][3];
+    int32_t form[32][3];
+    if (int rc = links_raw("drm_walk_table_links", links, forms, n_links, n_entries, raw, form, c)) return rc;
+    for (int l = 0; l < n_links; ++l) link_forms_apply(form[l], c[l], raw + l * LINK_PARAM_FLOATS, params + l * LINK_PARAM_FLOATS);
+    return drm_walk_table(params, n_links, base, sel, gsign, n_entries, ops_f, nullptr);
+}
+int drm_walk_table_links_backward(const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, const float *grad_ops_f,
+                                  const int32_t *sel, const float *gsign, int32_t n_entries, float *grad_params, void *) {
+    float raw[32 * LINK_PARAM_FLOATS], params[32 * LINK_PARAM_FLOATS], c[32][3];
+    int32_t form[32][3];
+    if (int rc = links_raw("drm_walk_table_links_backward", links, forms, n_links, n_entries, raw, form, c)) return rc;
+    for (int l = 0; l < n_links; ++l) link_forms_apply(form[l], c[l], raw + l * LINK_PARAM_FLOATS, params + l * LINK_PARAM_FLOATS);
+    if (int rc = drm_walk_table_backward(params, n_links, grad_ops_f, sel, gsign, n_entries, grad_params, nullptr)) return rc;
+    for (int l = 0; l < n_links; ++l) link_forms_grad(form[l], raw + l * LINK_PARAM_FLOATS, grad_params + l * LINK_PARAM_FLOATS);
+    return DRM_OK;
+}
+
 // ABI 12: the composition itself (the host build has no launches to save): table from the links' parameters, drm_fk_mse, and the
 // gradient back through the table's map
 int drm_fk_mse_links(const drm_walk *w, const int32_t *sel, const float *gsign, const drm_link_pieces *links, int32_t n_links, const float *q,

@@ -83,6 +83,57 @@ __global__ void link_rows_backward_kernel(const float *__restrict__ params, cons
 // links from their URDF-level parameters, gathered into walk order (with the exact +-1 factors of the axis
 // canonicalisation) over the table of the constant links.  One block; everything is < 8 KB.
 constexpr int WALK_TABLE_THREADS = 256, WALK_TABLE_MAX_LINKS = 32;
+// ABI 13: where the pieces of the learnable links lie and the forms they are stored in — passed by value (2.3 KB of kernel arguments)
+struct LinkSources {
+    const float *at[WALK_TABLE_MAX_LINKS][6];      // rot_angles, trans, mass, com, inertia_mat, damping
+    int32_t form[WALK_TABLE_MAX_LINKS][3];         // of mass, inertia_mat, damping
+    float c[WALK_TABLE_MAX_LINKS][3];
+};
+// raw[l * 20 + k]: what lies at the addresses, in drm_link_rows' layout (an inertia matrix in a six-number form: zeros behind them).
+// One element per thread and pass; the caller's next barrier publishes it.
+__device__ __forceinline__ void link_sources_load(const LinkSources &src, int n_links, int t, float *raw) {
+    for (int i = t; i < n_links * LINK_PARAM_FLOATS; i += WALK_TABLE_THREADS) {
+        const int l = i / LINK_PARAM_FLOATS, k = i - l * LINK_PARAM_FLOATS;
+        const int piece = link_piece_of(k), off = link_piece_offset(k);
+        const bool there = piece != 4 || src.form[l][1] == DRM_FORM_PLAIN || off < 6;
+        raw[i] = there ? src.at[l][piece][off] : 0.0f;
+    }
+}
+__global__ void __launch_bounds__(WALK_TABLE_THREADS)
+    walk_table_links_kernel(LinkSources src, int n_links, const float *__restrict__ base, const int32_t *__restrict__ sel,
+                            const float *__restrict__ gsign, int n_entries, float *__restrict__ ops_f) {
+    __shared__ float rows[WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE], raw[WALK_TABLE_MAX_LINKS * LINK_PARAM_FLOATS];
+    const int t = (int)threadIdx.x;
+    // (requested before the parameters are waited for)
+    constexpr int PER = DRM_MAX_OPS * DRM_OPF_STRIDE / WALK_TABLE_THREADS;
+    int r_mine[PER];
+    float s_mine[PER], b_mine[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = t + i * WALK_TABLE_THREADS;
+        const bool in = e < n_entries;
+        r_mine[i] = in ? sel[e] : -1;
+        s_mine[i] = in ? gsign[e] : 0.0f;
+        b_mine[i] = in ? base[e] : 0.0f;
+    }
+    link_sources_load(src, n_links, t, raw);
+    __syncthreads();
+    if (t < n_links) {
+        float pr[LINK_PARAM_FLOATS], p[LINK_PARAM_FLOATS], row[DRM_OPF_STRIDE];
+#pragma unroll
+        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) pr[k] = raw[t * LINK_PARAM_FLOATS + k];
+        link_forms_apply(src.form[t], src.c[t], pr, p);
+        link_row(p, row);
+#pragma unroll
+        for (int k = 0; k < DRM_OPF_STRIDE; ++k) rows[t * DRM_OPF_STRIDE + k] = row[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = t + i * WALK_TABLE_THREADS;
+        if (e < n_entries) ops_f[e] = r_mine[i] >= 0 ? rows[r_mine[i]] * s_mine[i] : b_mine[i];
+    }
+}
 __global__ void __launch_bounds__(WALK_TABLE_THREADS)
     walk_table_kernel(const float *__restrict__ params, int n_links, const float *__restrict__ base,
                       const int32_t *__restrict__ sel, const float *__restrict__ gsign, int n_entries,
@@ -108,15 +159,23 @@ __global__ void __launch_bounds__(WALK_TABLE_THREADS)
 // A link is one op of a walk, so nearly always ONE entry per element: every entry names itself at its element (LDS atomicMin: the
 // lowest index) and is counted; an element with one entry takes it, one with several adds them in entry order (deterministic, the
 // host build's order) — instead of every element scanning the ops of the walk (round 4: 14.5 -> 6 us; now ~3).
+// LINKS (ABI 13, drm_walk_table_links_backward): the parameters are read where the links' tensors lie, in their forms (LinkSources),
+// and the gradient goes back to the raw parameters.
+template <bool LINKS>
 __global__ void __launch_bounds__(WALK_TABLE_THREADS)
     walk_table_backward_kernel(const float *__restrict__ params, int n_links, const float *__restrict__ grad_ops_f,
                                const int32_t *__restrict__ sel, const float *__restrict__ gsign, int n_entries,
-                               float *__restrict__ grad_params) {
+                               float *__restrict__ grad_params, LinkSources src) {
     constexpr int NE = DRM_MAX_OPS * DRM_OPF_STRIDE, NR = WALK_TABLE_MAX_LINKS * DRM_OPF_STRIDE, WAVES = WALK_TABLE_THREADS / WAVE;
     __shared__ float grows[NR], ge[NE], dmat[WALK_TABLE_MAX_LINKS][27];
+    __shared__ float raw[LINKS ? WALK_TABLE_MAX_LINKS * LINK_PARAM_FLOATS : 1];
     __shared__ int se[NE];
     __shared__ unsigned owner[NR], count[NR];
     const int t = (int)threadIdx.x;
+    if constexpr (LINKS) {
+        link_sources_load(src, n_links, t, raw);
+        params = raw;      // (the three angles are plain in every form: the trigonometry wavefront reads them from here)
+    }
     const bool trig_wave = t >= (WAVES - 1) * WAVE;
     const int n_rows = n_links * DRM_OPF_STRIDE;
     // (requested first: the entries this thread sorts below)
@@ -171,14 +230,21 @@ __global__ void __launch_bounds__(WALK_TABLE_THREADS)
     }
     __syncthreads();
     if (t < n_links) {
-        float p[LINK_PARAM_FLOATS], g[DRM_OPF_STRIDE], gp[LINK_PARAM_FLOATS];
+        float p[LINK_PARAM_FLOATS], g[DRM_OPF_STRIDE], gp[LINK_PARAM_FLOATS], pr[LINKS ? LINK_PARAM_FLOATS : 1];
+        if constexpr (LINKS) {
 #pragma unroll
-        for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[t * LINK_PARAM_FLOATS + k];
+            for (int k = 0; k < LINK_PARAM_FLOATS; ++k) pr[k] = raw[t * LINK_PARAM_FLOATS + k];
+            link_forms_apply(src.form[t], src.c[t], pr, p);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LINK_PARAM_FLOATS; ++k) p[k] = params[t * LINK_PARAM_FLOATS + k];
+        }
 #pragma unroll
         for (int k = 0; k < DRM_OPF_STRIDE; ++k) g[k] = grows[t * DRM_OPF_STRIDE + k];
 #pragma unroll
         for (int a = 0; a < 3; ++a) gp[a] = dot9(&dmat[t][a * 9], g);
         link_row_backward_rest(p, g, gp);
+        if constexpr (LINKS) link_forms_grad(src.form[t], pr, gp);
 #pragma unroll
         for (int k = 0; k < LINK_PARAM_FLOATS; ++k) grad_params[t * LINK_PARAM_FLOATS + k] = gp[k];
     }
@@ -201,8 +267,47 @@ int drm_walk_table_backward(const float *params, int32_t n_links, const float *g
         return drm::fail(DRM_ERR_INVALID, "drm_walk_table_backward: NULL argument");
     if (n_links < 1 || n_links > drm::WALK_TABLE_MAX_LINKS || n_entries < 1 || n_entries > DRM_MAX_OPS * DRM_OPF_STRIDE)
         return drm::fail(DRM_ERR_INVALID, "drm_walk_table_backward: 1..32 learnable links and at most 32 x 32 walk entries");
-    hipLaunchKernelGGL(drm::walk_table_backward_kernel, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream,
-                       params, (int)n_links, grad_ops_f, sel, gsign, (int)n_entries, grad_params);
+    hipLaunchKernelGGL(drm::walk_table_backward_kernel<false>, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream,
+                       params, (int)n_links, grad_ops_f, sel, gsign, (int)n_entries, grad_params, drm::LinkSources{});
+    return drm::launched();
+}
+static int link_sources(const char *who, const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, int32_t n_entries,
+                        drm::LinkSources &src) {
+    if (!links) return drm::fail(DRM_ERR_INVALID, "%s: links must not be NULL", who);
+    if (n_links < 1 || n_links > drm::WALK_TABLE_MAX_LINKS || n_entries < 1 || n_entries > DRM_MAX_OPS * DRM_OPF_STRIDE)
+        return drm::fail(DRM_ERR_INVALID, "%s: 1..32 learnable links and at most 32 x 32 walk entries", who);
+    for (int l = 0; l < n_links; ++l) {
+        const float *at[6] = {links[l].rot_angles, links[l].trans, links[l].mass, links[l].com, links[l].inertia_mat, links[l].damping};
+        for (int j = 0; j < 6; ++j) {
+            if (!at[j]) return drm::fail(DRM_ERR_INVALID, "%s: a piece of a link is NULL", who);
+            src.at[l][j] = at[j];
+        }
+        const drm_link_forms f = forms ? forms[l] : drm_link_forms{};
+        const bool ok = (f.mass == DRM_FORM_PLAIN || f.mass == DRM_FORM_SQUARE_PLUS) &&
+                        (f.damping == DRM_FORM_PLAIN || f.damping == DRM_FORM_SQUARE_PLUS) &&
+                        (f.inertia_mat == DRM_FORM_PLAIN || (f.inertia_mat >= DRM_FORM_SYMM && f.inertia_mat <= DRM_FORM_COV));
+        if (!ok) return drm::fail(DRM_ERR_INVALID, "%s: unknown form of a piece", who);
+        src.form[l][0] = f.mass; src.form[l][1] = f.inertia_mat; src.form[l][2] = f.damping;
+        src.c[l][0] = f.mass_c; src.c[l][1] = f.inertia_mat_c; src.c[l][2] = f.damping_c;
+    }
+    return DRM_OK;
+}
+int drm_walk_table_links(const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, const float *base, const int32_t *sel,
+                         const float *gsign, int32_t n_entries, float *ops_f, void *stream) {
+    if (!base || !sel || !gsign || !ops_f) return drm::fail(DRM_ERR_INVALID, "drm_walk_table_links: NULL argument");
+    drm::LinkSources src{};
+    if (int rc = link_sources("drm_walk_table_links", links, forms, n_links, n_entries, src)) return rc;
+    hipLaunchKernelGGL(drm::walk_table_links_kernel, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream, src, (int)n_links,
+                       base, sel, gsign, (int)n_entries, ops_f);
+    return drm::launched();
+}
+int drm_walk_table_links_backward(const drm_link_pieces *links, const drm_link_forms *forms, int32_t n_links, const float *grad_ops_f,
+                                  const int32_t *sel, const float *gsign, int32_t n_entries, float *grad_params, void *stream) {
+    if (!grad_ops_f || !sel || !gsign || !grad_params) return drm::fail(DRM_ERR_INVALID, "drm_walk_table_links_backward: NULL argument");
+    drm::LinkSources src{};
+    if (int rc = link_sources("drm_walk_table_links_backward", links, forms, n_links, n_entries, src)) return rc;
+    hipLaunchKernelGGL(drm::walk_table_backward_kernel<true>, dim3(1), dim3(drm::WALK_TABLE_THREADS), 0, (hipStream_t)stream,
+                       (const float *)nullptr, (int)n_links, grad_ops_f, sel, gsign, (int)n_entries, grad_params, src);
     return drm::launched();
 }
 int drm_link_rows(const float *params, int32_t n_links, float *rows, void *stream) {

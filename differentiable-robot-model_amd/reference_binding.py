@@ -27,7 +27,7 @@ from .flatten import MAX_SEGMENTS, OPF_STRIDE, OPI_PERM, build_robot_spec, build
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "csrc", "libdrm_hip.so")
 RNEA_GRAVITY, RNEA_DAMPING = 1, 2
-ABI_VERSION = 12      # DRM_ABI_VERSION of include/drm_hip.h this mirror of struct drm_walk follows
+ABI_VERSION = 13      # DRM_ABI_VERSION of include/drm_hip.h this mirror of struct drm_walk follows
 
 
 class DrmWalk(ctypes.Structure):

@@ -142,6 +142,8 @@ class DifferentiableRobotModel(torch.nn.Module):
             body.set_parent(parent)
             parent.add_child(body)
         self._zero1 = torch.zeros(1, device=self._device)
+        self._table_links = os.environ.get("DRM_TABLE_LINKS", "1") != "0"        # (0: the table of a learnable model through a cat of the modules' outputs + drm_walk_table; A/B switch)
+        self._source_plan = None
         self._fk_mse_links = os.environ.get("DRM_FK_MSE_LINKS", "1") != "0"      # (0: fk_mse_loss composes WalkTable + drm_fk_mse; A/B switch)
         self._kin_state = None   # (q, qd) of the last update_kinematic_state
         self._kin_cache = {}
@@ -501,8 +503,45 @@ class DifferentiableRobotModel(torch.nn.Module):
         from a cached gather of the constant link table, the entries of the learnable links are rebuilt from their
         parameter callables inside the kernel, and the autograd graph holds a single node."""
         links, base, sel = self._learnable_plan(dw)
-        ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *self._learnable_pieces(links))
+        if self._table_links:
+            # ABI 13: from the parameter tensors where they lie, the known modules' arithmetic inside the kernel (backend.WalkTableLinks)
+            plan, sources = self._learnable_sources(links)
+            ops_f = backend.WalkTableLinks.apply(base, sel, dw.gsign, plan, *sources)
+        else:
+            ops_f = backend.WalkTable.apply(base, sel, dw.gsign, len(links), *self._learnable_pieces(links))
         return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
+
+    def _learnable_sources(self, links):
+        """(backend.LinkSourcePlan, tensors) of the given learnable links: six tensors per link; a piece whose module the kernels know
+        (exactly PositiveScalar for mass / damping, exactly one of the l[6] inertia-matrix modules for inertia_mat) hands over its RAW
+        parameter and its form, every other piece the output of its callable.  The plan is cached per set of links and modules."""
+        from . import rigid_body_params as rbp
+        key = tuple(links)
+        cached = self._source_plan
+        getters = cached[2] if cached is not None and cached[0] == key else None
+        if getters is None:
+            entries, getters = [], []
+            zero1 = self._zero1
+            for i in links:
+                b = self._bodies[i]
+                damping = b.joint_damping if isinstance(b.joint_damping, torch.nn.Module) or b.joint_damping() is not None else (lambda: zero1)
+                link = []
+                for name, fn in (("rot_angles", b.rot_angles), ("trans", b.trans), ("mass", b.inertia.mass), ("com", b.inertia.com),
+                                 ("inertia_mat", b.inertia.inertia_mat), ("damping", damping)):
+                    form, const = backend.FORM_PLAIN, 0.0
+                    if name in ("mass", "damping") and type(fn) is rbp.PositiveScalar:
+                        form, const = backend.FORM_SQUARE_PLUS, fn._min_val
+                    elif name == "inertia_mat" and type(fn) is rbp.Symm3DInertiaMatrixNet:
+                        form = backend.FORM_SYMM
+                    elif name == "inertia_mat" and type(fn) is rbp.SymmPosDef3DInertiaMatrixNet:
+                        form, const = backend.FORM_SPD, fn.spd_3d_inertia_mat_diag_bias
+                    elif name == "inertia_mat" and type(fn) is rbp.CovParameterized3DInertiaMatrixNet:
+                        form, const = backend.FORM_COV, fn.spd_3d_cov_inertia_mat_diag_bias
+                    link.append((form, const, fn if form != backend.FORM_PLAIN else None))
+                    getters.append(fn if form == backend.FORM_PLAIN else (lambda m=fn: m.l))
+                entries.append(link)
+            cached = self._source_plan = (key, backend.LinkSourcePlan(entries), getters)
+        return cached[1], [g() for g in getters]
 
     def _learnable_plan(self, dw: _DeviceWalk):
         """(learnable links, base, sel) of a walk: the table of the CONSTANT links gathered into walk order, and for every entry of
@@ -1241,6 +1280,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         parent_object.add_module(parameter_name, parametrization.to(self._device))
         self._learnable.add((self._name_to_idx_map[link_name], parameter_name))
         self._learnable_links = None
+        self._source_plan = None
         for dw in self._walks.values():
             dw.static_ops_f = None
             special = getattr(dw.program, "_special", None) or {}

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 12
+#define DRM_ABI_VERSION 13
 
 /* ---- layout of one op (= one link) of a walk ---------------------------- */
 #define DRM_SPECIAL_KINDS 16 /* drm_walk.special[] (the kinds not named below are reserved and must be NULL): */
@@ -526,6 +526,37 @@ int drm_walk_table(const float *params, int32_t n_links, const float *base, cons
                    int32_t n_entries, float *ops_f, void *stream);
 int drm_walk_table_backward(const float *params, int32_t n_links, const float *grad_ops_f, const int32_t *sel,
                             const float *gsign, int32_t n_entries, float *grad_params, void *stream);
+
+/*
+ * ABI 13: the walk table straight from the learnable links' parameter TENSORS, where they lie and in the form their modules store
+ * them, and the derivative of that map back to those tensors — one launch each.  What the reference does by calling the parameter
+ * modules inside every per-link op (rigid_body.py:138-143; rigid_body_params.py:26-43 PositiveScalar, :252-404 the inertia-matrix
+ * modules) and differentiating through them with one autograd node per tiny op: a learn-dynamics step
+ * (examples/learn_dynamics_iiwa.py:49-96) spends 14 + 1 + 21 launches there (l * l + min per link, the cat of 42 pieces, the
+ * backward of the squares) around drm_walk_table's two.
+ *   links  [n_links]   where rot_angles, trans, mass, com, inertia_mat, damping of a learnable link lie (device addresses; constant
+ *                      pieces point at the constants).  A piece in a form other than DRM_FORM_PLAIN points at the module's RAW parameter:
+ *                      one float for the scalars, l[6] = (diagonal entries, then (1,0), (2,0), (2,1)) for inertia_mat
+ *   forms  [n_links]   the form of mass / inertia_mat / damping and its constant (min_val, bias); NULL = everything plain
+ *   base, sel, gsign, n_entries, ops_f   as for drm_walk_table
+ * drm_walk_table_links_backward: grad_ops_f [n_entries] -> grad_params [n_links, 20] in drm_link_rows' layout, with respect to what lies
+ * AT THE ADDRESSES (the raw parameters; inertia_mat in a six-number form fills the first six of its nine places, zeros behind).
+ * Sums in drm_walk_table_backward's order.  At most 32 links.
+ */
+#define DRM_FORM_PLAIN 0
+#define DRM_FORM_SQUARE_PLUS 1 /* mass, damping: l * l + c */
+#define DRM_FORM_SYMM 2        /* inertia_mat: symmetric from l[6] */
+#define DRM_FORM_SPD 3         /* inertia_mat: L L^T + c E */
+#define DRM_FORM_COV 4         /* inertia_mat: tr(S) E - S, S = L L^T + c E */
+struct drm_link_forms {
+    int32_t mass, inertia_mat, damping;
+    float mass_c, inertia_mat_c, damping_c;
+};
+int drm_walk_table_links(const struct drm_link_pieces *links, const struct drm_link_forms *forms, int32_t n_links, const float *base,
+                         const int32_t *sel, const float *gsign, int32_t n_entries, float *ops_f, void *stream);
+int drm_walk_table_links_backward(const struct drm_link_pieces *links, const struct drm_link_forms *forms, int32_t n_links,
+                                  const float *grad_ops_f, const int32_t *sel, const float *gsign, int32_t n_entries,
+                                  float *grad_params, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,263 @@
+"""ABI 13: the walk table of a model with learnable links straight from the links' parameter tensors, in the form their modules store
+them (drm_walk_table_links / drm_walk_table_links_backward, backend.WalkTableLinks) — against the composition it replaces: the
+modules' own torch arithmetic (the reference's, rigid_body_params.py:26-43, 252-404), a cat of their outputs, drm_walk_table and
+torch autograd back through the modules.  Tolerances: 2e-6 relative to the largest entry (fp32; the kernel contracts l * l + c into
+one fused multiply-add, torch rounds twice)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from differentiable_robot_model_amd import DifferentiableKUKAiiwa, DifferentiableFrankaPanda, backend
+from differentiable_robot_model_amd.rigid_body_params import (CovParameterized3DInertiaMatrixNet, PositiveScalar, Symm3DInertiaMatrixNet,
+                                                              SymmPosDef3DInertiaMatrixNet, TriangParam3DInertiaMatrixNet,
+                                                              UnconstrainedScalar, UnconstrainedTensor)
+
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+INERTIA = {
+    "plain": lambda: UnconstrainedTensor(3, 3),
+    "symm": lambda: Symm3DInertiaMatrixNet(init_param_std=0.1),
+    "spd": lambda: SymmPosDef3DInertiaMatrixNet(bias=1e-3, init_param_std=0.3),
+    "cov": lambda: CovParameterized3DInertiaMatrixNet(bias=1e-3, init_param_std=0.3),
+    "triang": lambda: TriangParam3DInertiaMatrixNet(bias=1e-3),      # (a module the kernels do not know: its output is the piece)
+}
+RTOL = 2e-6      # of the largest entry; parameter gradients (sums with cancellation over the batch, fed by a mass that differs in its last bit): 5e-5
+
+
+def learnable_iiwa(device, inertia, table_links, seed=0):
+    torch.manual_seed(seed)
+    m = DifferentiableKUKAiiwa(device=device)
+    m._table_links = table_links
+    for k in range(1, 8):
+        link = "iiwa_link_%d" % k
+        m.make_link_param_learnable(link, "mass", PositiveScalar(min_val=0.01))
+        m.make_link_param_learnable(link, "com", UnconstrainedTensor(1, 3))
+        m.make_link_param_learnable(link, "inertia_mat", INERTIA[inertia]())
+        if k % 2:
+            m.make_link_param_learnable(link, "trans", UnconstrainedTensor(1, 3))
+        if k == 3:
+            m.make_link_param_learnable(link, "joint_damping", PositiveScalar())
+        if k == 4:
+            m.make_link_param_learnable(link, "rot_angles", UnconstrainedTensor(1, 3))
+        if k == 5:
+            m.make_link_param_learnable(link, "joint_damping", UnconstrainedScalar())
+    return m
+
+
+def states(device, B=192, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return tuple((torch.rand(B, 7, generator=g) - 0.5).to(device) for _ in range(3))
+
+
+def close(a, b, rtol=RTOL, floor=0.0):
+    """max |a - b| <= rtol * max |b| (+ floor: for the gradient of ONE parameter tensor — a scalar that is a sum with cancellation over
+    the batch — the noise scales with the largest gradient of the model, not with the scalar)."""
+    scale = max(float(b.abs().max()), 1e-6)
+    return float((a - b).abs().max()) <= rtol * scale + floor
+
+
+def grad_floor(grads, rel=2e-6):
+    return rel * max(float(g.abs().max()) for g in grads if g is not None)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("inertia", list(INERTIA))
+def test_torques_and_parameter_gradients_equal_the_composition(device, inertia):
+    got = []
+    for table_links in (False, True):
+        m = learnable_iiwa(device, inertia, table_links)
+        q, qd, qdd = states(device)
+        tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+        (tau.pow(2).mean() + m.compute_forward_kinematics(q, "iiwa_link_ee")[0].pow(2).mean()).backward()
+        got.append((tau.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    (tau0, g0), (tau1, g1) = got
+    assert close(tau1, tau0)
+    assert g0.keys() == g1.keys() and len(g0) >= 26
+    floor = grad_floor(g0.values())
+    for name in g0:
+        assert g1[name].shape == g0[name].shape and close(g1[name], g0[name], 5e-5, floor), name
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_one_autograd_node_and_no_module_kernels(device):
+    """The table of the learnable model hangs on the raw parameters through ONE node: the modules' forward() is not called for the
+    forms the kernel knows."""
+    m = learnable_iiwa(device, "spd", True)
+    m._ops_f(m._dynamics_walk())      # (the snapshot of the constant rows evaluates every module once)
+    called = []
+    for mod in m.modules():
+        if type(mod) in (PositiveScalar, SymmPosDef3DInertiaMatrixNet):
+            mod.register_forward_hook(lambda *a: called.append(1))
+    dw = m._dynamics_walk()
+    table = m._ops_f(dw)
+    assert table.grad_fn.name().startswith("WalkTableLinks") or table.grad_fn.next_functions[0][0].name().startswith("WalkTableLinks")
+    assert not called
+    plan, sources = m._learnable_sources(sorted({l for l, _ in m._learnable}))
+    forms = [plan.entries[l][j][0] for l in range(plan.n_links) for j in range(6)]
+    assert forms.count(backend.FORM_SQUARE_PLUS) == 8 and forms.count(backend.FORM_SPD) == 7
+    assert all(s.numel() == n for s, n in zip(sources, plan.sizes))
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_frozen_and_shared_parameters(device):
+    m0, m1 = learnable_iiwa(device, "cov", False), learnable_iiwa(device, "cov", True)
+    for m in (m0, m1):
+        m.freeze_learnable_link_param("iiwa_link_2", "mass")
+        m.freeze_learnable_link_param("iiwa_link_6", "inertia_mat")
+        q, qd, qdd = states(device, 64)
+        m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True).pow(2).sum().backward()
+    floor = grad_floor([p.grad for p in m0.parameters()])
+    for (n0, p0), (n1, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert n0 == n1 and (p0.grad is None) == (p1.grad is None), n0
+        if p0.grad is not None:
+            assert close(p1.grad, p0.grad, 5e-5, floor), n0
+    assert sum(p.grad is None for p in m1.parameters()) == 2
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_second_derivatives_go_through_the_modules(device):
+    """create_graph=True: the backward of the table is the torch twin (the modules' arithmetic on the raw tensors), differentiable
+    again — Hessian-vector products equal the composition's."""
+    hv = []
+    for table_links in (False, True):
+        m = learnable_iiwa(device, "spd", table_links)
+        q, qd, qdd = states(device, 64)
+        params = [p for p in m.parameters()]
+        loss = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True).pow(2).mean()
+        grads = torch.autograd.grad(loss, params, create_graph=True)
+        dot = sum((g * torch.ones_like(g)).sum() for g in grads)
+        hv.append(torch.autograd.grad(dot, params, allow_unused=True))
+    floor = grad_floor(hv[0], 2e-5)
+    for a, b in zip(*hv):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert close(b, a, 2e-4, floor)
+
+
+def test_abi_errors_need_no_gpu(cpu_library):
+    lib = cpu_library
+    links = (backend.DrmLinkPieces * 1)()
+    forms = (backend.DrmLinkForms * 1)()
+    buf = np.zeros(64, np.float32)
+    sel = np.full(32, -1, np.int32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.drm_walk_table_links(links, forms, 1, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) != 0      # NULL pieces
+    assert b"NULL" in lib.drm_last_error()
+    for name in backend.PIECE_NAMES:
+        setattr(links[0], name, buf.ctypes.data)
+    assert lib.drm_walk_table_links(links, forms, 1, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) == 0
+    forms[0].inertia_mat = 9
+    assert lib.drm_walk_table_links(links, forms, 1, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) != 0
+    assert b"form" in lib.drm_last_error()
+    forms[0].inertia_mat = backend.FORM_SQUARE_PLUS      # a scalar form on the matrix
+    assert lib.drm_walk_table_links_backward(links, forms, 1, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) != 0
+    assert lib.drm_walk_table_links(links, None, 0, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) != 0
+    assert lib.drm_walk_table_links(links, None, 33, ptr(buf), ptr(sel), ptr(buf), 32, ptr(buf), None) != 0
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_raw_gradient_layout_against_torch(device):
+    """drm_walk_table_links_backward by itself: a random cotangent on the table, every form on one link — against torch autograd
+    through the modules and link_rows_torch."""
+    torch.manual_seed(3)
+    lib = backend.library_for(torch.device(device))
+    mods = [PositiveScalar(min_val=0.2), SymmPosDef3DInertiaMatrixNet(bias=1e-2, init_param_std=0.5), PositiveScalar(),
+            CovParameterized3DInertiaMatrixNet(bias=1e-2, init_param_std=0.5), Symm3DInertiaMatrixNet(init_param_std=0.5)]
+    mods = [m.to(device) for m in mods]
+    entries, sources = [], []
+    P, F = backend.FORM_PLAIN, backend
+    rnd = lambda *s: torch.randn(*s, device=device).requires_grad_(True)
+    for mass, inertia, form in ((mods[0], mods[1], F.FORM_SPD), (mods[2], mods[3], F.FORM_COV), (None, mods[4], F.FORM_SYMM)):
+        link = [(P, 0.0, None), (P, 0.0, None)]
+        srcs = [rnd(1, 3), rnd(1, 3)]
+        if mass is None:
+            link.append((P, 0.0, None)); srcs.append(rnd(1))
+        else:
+            link.append((F.FORM_SQUARE_PLUS, mass._min_val, mass)); srcs.append(mass.l)
+        link.append((P, 0.0, None)); srcs.append(rnd(1, 3))
+        bias = getattr(inertia, "spd_3d_inertia_mat_diag_bias", getattr(inertia, "spd_3d_cov_inertia_mat_diag_bias", 0.0))
+        link.append((form, bias, inertia)); srcs.append(inertia.l)
+        link.append((P, 0.0, None)); srcs.append(rnd(1))
+        entries.append(link); sources += srcs
+    plan = backend.LinkSourcePlan(entries)
+    n_entries = 8 * 32
+    base = torch.randn(n_entries, device=device)
+    sel = torch.full((n_entries,), -1, dtype=torch.int32)
+    sel[32:64] = torch.arange(32, dtype=torch.int32)
+    sel[96:128] = torch.arange(32, 64, dtype=torch.int32)
+    sel[160:192] = torch.arange(64, 96, dtype=torch.int32)
+    sel[200:232] = torch.arange(32, dtype=torch.int32)          # (a link that two ops of the walk read)
+    sel = sel.to(device)
+    gsign = torch.where(torch.rand(n_entries, device=device) < 0.5, -1.0, 1.0)
+    table = backend.WalkTableLinks.apply(base, sel, gsign, plan, *sources)
+    cot = torch.randn(n_entries, device=device)
+    got = torch.autograd.grad(table, sources, cot)
+    pieces = plan.torch_pieces(sources)
+    packed = torch.cat([p.reshape(-1) for p in pieces]).reshape(3, 20)
+    rows = backend.link_rows_torch(packed).reshape(-1)
+    want_table = torch.where(sel >= 0, rows[sel.clamp_min(0).long()] * gsign, base)
+    want = torch.autograd.grad(want_table, sources, cot)
+    assert close(table.detach(), want_table.detach())
+    for g, w, s in zip(got, want, sources):
+        assert g.shape == s.shape and close(g, w, 5e-6)
+
+
+@pytest.mark.gpu
+def test_learn_dynamics_step_under_a_hip_graph_has_no_module_kernels():
+    """The reference's learn-dynamics step (examples/learn_dynamics_iiwa.py:49-96: PositiveScalar masses, free centres of mass and
+    inertia matrices, Adam) captured into a hipGraph: replays equal the eager steps, and the parameters move."""
+    def run(graph):
+        torch.manual_seed(0)
+        truth = DifferentiableKUKAiiwa(device="cuda")
+        m = learnable_iiwa("cuda", "plain", True)
+        q, qd, qdd = states("cuda", 256)
+        with torch.no_grad():
+            target = truth.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True), target)
+            loss.backward()
+            opt.step()
+            return loss
+        losses = []
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    losses.append(float(step()))
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = step()
+            for _ in range(7):
+                g.replay()
+                losses.append(float(out))
+        else:
+            for _ in range(10):
+                losses.append(float(step()))
+        return losses
+    eager, graphed = run(False), run(True)
+    assert eager[-1] < eager[0]
+    np.testing.assert_allclose(graphed, eager, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_panda_learnable_arm_kernel_reads_the_links_table():
+    """The arm's own kernel for a set of learnable blocks (specialize.attach_arm_param) takes the table WalkTableLinks built."""
+    got = []
+    for table_links in (False, True):
+        torch.manual_seed(0)
+        m = DifferentiableFrankaPanda(device="cuda")
+        m._table_links = table_links
+        m.make_link_param_learnable("panda_link4", "mass", PositiveScalar(min_val=0.01))
+        m.make_link_param_learnable("panda_link4", "inertia_mat", SymmPosDef3DInertiaMatrixNet(bias=1e-3, init_param_std=0.3))
+        q, qd, qdd = states("cuda", 65536)
+        qg = q.clone().requires_grad_(True)
+        m.compute_inverse_dynamics(qg, qd, qdd, include_gravity=True).pow(2).mean().backward()
+        got.append([qg.grad] + [p.grad for p in m.parameters()])
+    for a, b in zip(*got):
+        assert close(b, a, 2e-5)

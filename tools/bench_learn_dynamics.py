@@ -40,34 +40,41 @@ for constrained in (False, True):
         q, qd, qdd = (t.cuda() for t in sample(m, B))
         with torch.no_grad():
             want = gt.compute_inverse_dynamics(q, qd, qdd)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+        params0 = [p.detach().clone() for p in m.parameters()]
+        res = {}
+        for fused in (False, True):      # torch's default (foreach) Adam as in the reference's example, and its fused one
+            with torch.no_grad():
+                for p, p0 in zip(m.parameters(), params0):
+                    p.copy_(p0)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=fused)
 
-        def train_step():
-            loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd), want)
-            loss.backward()
-            opt.step()
-            return loss
+            def train_step():
+                loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd), want)
+                loss.backward()
+                opt.step()
+                return loss
 
-        def eager():
-            opt.zero_grad(set_to_none=True)
-            train_step()
-
-        eager_us = timeit(eager, iters=100)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
+            def eager():
                 opt.zero_grad(set_to_none=True)
                 train_step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            static_loss = train_step()
-        graph.replay(); torch.cuda.synchronize()
-        l0 = static_loss.item()
-        graph_us = timeit(graph.replay)
+
+            eager_us = timeit(eager, iters=100)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    opt.zero_grad(set_to_none=True)
+                    train_step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = train_step()
+            graph.replay(); torch.cuda.synchronize()
+            l0 = static_loss.item()
+            res[fused] = (eager_us, timeit(graph.replay), l0, static_loss.item())
+        (eager_us, graph_us, l0, l1), (eager_f, graph_f, _, _) = res[False], res[True]
         print("learnable-RNEA train step, iiwa7, 21 parameter tensors (%s inertia), batch %6d:  eager %8.1f us = %7.0f it/s   "
-              "hipGraph %7.1f us = %7.0f it/s   loss %.4g -> %.4g"
-              % ("SPD" if constrained else "unconstrained", B, eager_us, 1e6 / eager_us, graph_us, 1e6 / graph_us, l0,
-                 static_loss.item()))
+              "hipGraph %7.1f us = %7.0f it/s   loss %.4g -> %.4g   | fused Adam: eager %7.1f us   hipGraph %6.1f us = %7.0f it/s"
+              % ("SPD" if constrained else "unconstrained", B, eager_us, 1e6 / eager_us, graph_us, 1e6 / graph_us, l0, l1,
+                 eager_f, graph_f, 1e6 / graph_f))

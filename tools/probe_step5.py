@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configuration 5, the whole training step: WHICH kernels does one step launch?
 
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step5 -- python tools/probe_step5.py [dyn] [B]
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_step5 -- python tools/probe_step5.py [dyn] [graph] [B]
   python tools/probe_step5.py --read gpurun_out/prof_step5        (lists the kernels of the last steps, in order, with durations)
 
 The step is the one bench_configs.py times: model.fk_mse_loss (ONE node) + loss.backward() + fused Adam, eagerly launched here so that
@@ -46,8 +46,9 @@ def main():
     import torch
     from gpu_probe import load, sample
     from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, UnconstrainedTensor
-    dyn = len(sys.argv) > 1 and sys.argv[1] == "dyn"      # the learn-dynamics step (examples/learn_dynamics_iiwa.py) instead
-    args = [a for a in sys.argv[1:] if a != "dyn"]
+    dyn = "dyn" in sys.argv[1:]        # the learn-dynamics step (examples/learn_dynamics_iiwa.py) instead
+    graph = "graph" in sys.argv[1:]    # ... and ten replays of the step captured into a hipGraph behind the eager steps
+    args = [a for a in sys.argv[1:] if a not in ("dyn", "graph")]
     B = int(args[0]) if args else 16384
     torch.manual_seed(0)
     m, gt = load("iiwa7"), load("iiwa7")
@@ -67,7 +68,7 @@ def main():
         with torch.no_grad():
             want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True)
-    for _ in range(12):
+    def step():
         opt.zero_grad(set_to_none=True)
         if dyn:
             loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True), want)
@@ -75,7 +76,19 @@ def main():
             loss = m.fk_mse_loss(q, "iiwa_link_ee", want)
         loss.backward()
         opt.step()
-        torch.cuda.synchronize()
+        return loss
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            loss = step()
+            torch.cuda.synchronize()
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                loss = step()
+            for _ in range(10):
+                g.replay()
+                torch.cuda.synchronize()
     print("loss %.6f" % float(loss))
 
 
