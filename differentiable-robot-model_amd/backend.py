@@ -694,11 +694,13 @@ PIECE_OFFSETS = (0, 3, 6, 7, 10, 19)
 
 
 class LinkSourcePlan(object):
-    """What WalkTableLinks needs to know about the learnable links of a model besides their tensors: per link and piece the FORM the
-    tensor is stored in (FORM_*), the form's constant and — for a form other than plain — the module whose raw parameter the tensor
-    is (its torch arithmetic is what second derivatives go through)."""
+    """What WalkTableLinks needs to know about the learnable links of a model besides the tensors that change: per link and piece the
+    FORM it is stored in (FORM_*), the form's constant and — for a form other than plain — the module whose raw parameter the tensor
+    is (its torch arithmetic is what second derivatives go through); ``fixed``: the tensor of every piece that is a CONSTANT of the
+    model (six per link; None where a parameter module supplies the piece on every call — the LIVE pieces, in this order the
+    ``sources`` of WalkTableLinks)."""
 
-    def __init__(self, entries):
+    def __init__(self, entries, fixed=None):
         self.entries = entries                      # [n_links][6] of (form, constant, module or None)
         self.n_links = len(entries)
         self.forms = (DrmLinkForms * self.n_links)()
@@ -706,28 +708,33 @@ class LinkSourcePlan(object):
             for j, name in ((2, "mass"), (4, "inertia_mat"), (5, "damping")):
                 setattr(self.forms[l], name, link[j][0])
                 setattr(self.forms[l], name + "_c", float(link[j][1]))
-        self.sizes = [6 if (j == 4 and link[j][0] != FORM_PLAIN) else PIECE_SIZES[j] for link in entries for j in range(6)]
-        self._links, self._key = None, None
+        sizes = [6 if (j == 4 and link[j][0] != FORM_PLAIN) else PIECE_SIZES[j] for link in entries for j in range(6)]
+        self.fixed = list(fixed) if fixed is not None else [None] * (6 * self.n_links)
+        self.live = [i for i, t in enumerate(self.fixed) if t is None]
+        self.sizes = [sizes[i] for i in self.live]
+        self._links = (DrmLinkPieces * self.n_links)()
+        for i, t in enumerate(self.fixed):
+            if t is not None:
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != sizes[i]:
+                    raise ValueError("constant piece %d of a learnable link: %d float32 values expected" % (i, sizes[i]))
+                setattr(self._links[i // 6], PIECE_NAMES[i % 6], t.data_ptr())
+        self._key = None
 
     def pieces(self, sources):
-        """The drm_link_pieces array of these tensors (cached while they stay where they are)."""
-        key = tuple(t.data_ptr() for t in sources)
+        """The drm_link_pieces array with the live pieces at these tensors (rewritten only when one of them has moved)."""
+        key = tuple([t.data_ptr() for t in sources])
         if key != self._key:
-            links = (DrmLinkPieces * self.n_links)()
-            for i, ptr in enumerate(key):
-                setattr(links[i // 6], PIECE_NAMES[i % 6], ptr)
-            self._links, self._key = links, key
+            for i, ptr in zip(self.live, key):
+                setattr(self._links[i // 6], PIECE_NAMES[i % 6], ptr)
+            self._key = key
         return self._links
 
     def torch_pieces(self, sources):
-        """The pieces as differentiable functions of the sources (the modules' own arithmetic on the given raw tensors)."""
-        out = []
-        for i, t in enumerate(sources):
+        """All 6 x n_links pieces as differentiable functions of the live sources (the modules' own arithmetic on the raw tensors)."""
+        out = list(self.fixed)
+        for i, t in zip(self.live, sources):
             form, _, module = self.entries[i // 6][i % 6]
-            if form == FORM_PLAIN:
-                out.append(t)
-            else:
-                out.append(torch.func.functional_call(module, {"l": t}, ()))
+            out[i] = t if form == FORM_PLAIN else torch.func.functional_call(module, {"l": t}, ())
         return out
 
 
@@ -735,8 +742,8 @@ class WalkTableLinks(torch.autograd.Function):
     """The walk table of a robot with learnable links straight from the links' parameter tensors WHERE THEY LIE and in the form their
     modules store them (drm_walk_table_links, ABI 13), and its derivative back to those tensors: one launch each, no cat of the 6 x
     n_links pieces, no torch kernels for the modules the kernels know (PositiveScalar and the l[6] inertia-matrix modules of
-    rigid_body_params).  ``sources``: six tensors per learnable link (rot_angles, trans, mass, com, inertia_mat, damping) — the raw
-    parameter for a piece whose form is not plain, the module's output otherwise."""
+    rigid_body_params).  ``sources``: the LIVE pieces of ``plan`` (LinkSourcePlan) — the raw parameter for a piece whose form is not
+    plain, the module's output otherwise; the constant pieces of the learnable links are part of the plan."""
 
     @staticmethod
     def forward(ctx, base, sel, gsign, plan, *sources):
@@ -780,17 +787,18 @@ class WalkTableLinks(torch.autograd.Function):
         held = [t if (t.device == dev and t.dtype == torch.float32 and t.is_contiguous()) else
                 t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in sources]
         g = grad_ops_f.contiguous().to(torch.float32)
-        grad = torch.empty(plan.n_links, 20, device=dev, dtype=torch.float32)
+        grad = torch.empty(plan.n_links * 20, device=dev, dtype=torch.float32)
         with _on_device(dev):
             _check(lib.drm_walk_table_links_backward(plan.pieces(held), plan.forms, plan.n_links, g.data_ptr(), sel.data_ptr(),
                                                      gsign.data_ptr(), g.numel(), grad.data_ptr(), _stream(dev)), lib)
         out = []
-        for i, (t, size) in enumerate(zip(sources, plan.sizes)):
-            if not ctx.needs_input_grad[4 + i]:
+        needs = ctx.needs_input_grad
+        for k, (i, t, size) in enumerate(zip(plan.live, sources, plan.sizes)):
+            if not needs[4 + k]:
                 out.append(None)
                 continue
-            l, j = divmod(i, 6)
-            piece = grad[l, PIECE_OFFSETS[j]:PIECE_OFFSETS[j] + size].reshape(t.shape)
+            at = (i // 6) * 20 + PIECE_OFFSETS[i % 6]
+            piece = grad[at:at + size].view(t.shape)
             out.append(piece if t.device == dev and t.dtype == torch.float32 else piece.to(device=t.device, dtype=t.dtype))
         return (None, None, None, None) + tuple(out)
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "drm_host_loops.hpp"
+#include "drm_link_forms.hpp"
 
 namespace {
 using namespace drm_host;

@@ -3,6 +3,7 @@
 
 #include "drm_common.hpp"
 #include "drm_sample.hpp"
+#include "drm_link_forms.hpp"
 
 namespace drm {
 

@@ -512,36 +512,48 @@ class DifferentiableRobotModel(torch.nn.Module):
         return ops_f.reshape(dw.program.capacity, OPF_STRIDE)
 
     def _learnable_sources(self, links):
-        """(backend.LinkSourcePlan, tensors) of the given learnable links: six tensors per link; a piece whose module the kernels know
-        (exactly PositiveScalar for mass / damping, exactly one of the l[6] inertia-matrix modules for inertia_mat) hands over its RAW
-        parameter and its form, every other piece the output of its callable.  The plan is cached per set of links and modules."""
+        """(backend.LinkSourcePlan, live tensors) of the given learnable links.  A piece that is a constant of the model is part of
+        the plan; a piece supplied by a parameter module is LIVE: the module's RAW parameter and its form where the kernels know the
+        module (exactly PositiveScalar for mass / damping, exactly one of the l[6] inertia-matrix modules for inertia_mat; exactly
+        UnconstrainedTensor / UnconstrainedScalar: the parameter itself), the output of the module's call otherwise.  Cached per set
+        of links and modules."""
         from . import rigid_body_params as rbp
         key = tuple(links)
         cached = self._source_plan
-        getters = cached[2] if cached is not None and cached[0] == key else None
-        if getters is None:
-            entries, getters = [], []
-            zero1 = self._zero1
+        if cached is None or cached[0] != key:
+            entries, fixed, getters = [], [], []
             for i in links:
                 b = self._bodies[i]
-                damping = b.joint_damping if isinstance(b.joint_damping, torch.nn.Module) or b.joint_damping() is not None else (lambda: zero1)
                 link = []
                 for name, fn in (("rot_angles", b.rot_angles), ("trans", b.trans), ("mass", b.inertia.mass), ("com", b.inertia.com),
-                                 ("inertia_mat", b.inertia.inertia_mat), ("damping", damping)):
+                                 ("inertia_mat", b.inertia.inertia_mat), ("damping", b.joint_damping)):
                     form, const = backend.FORM_PLAIN, 0.0
-                    if name in ("mass", "damping") and type(fn) is rbp.PositiveScalar:
+                    if not isinstance(fn, torch.nn.Module):
+                        value = fn()
+                        value = self._zero1 if value is None else value
+                        fixed.append(value.detach().to(device=self._device, dtype=torch.float32).reshape(-1).contiguous())
+                        link.append((form, const, None))
+                        continue
+                    fixed.append(None)
+                    kind = type(fn)
+                    if name in ("mass", "damping") and kind is rbp.PositiveScalar:
                         form, const = backend.FORM_SQUARE_PLUS, fn._min_val
-                    elif name == "inertia_mat" and type(fn) is rbp.Symm3DInertiaMatrixNet:
+                    elif name == "inertia_mat" and kind is rbp.Symm3DInertiaMatrixNet:
                         form = backend.FORM_SYMM
-                    elif name == "inertia_mat" and type(fn) is rbp.SymmPosDef3DInertiaMatrixNet:
+                    elif name == "inertia_mat" and kind is rbp.SymmPosDef3DInertiaMatrixNet:
                         form, const = backend.FORM_SPD, fn.spd_3d_inertia_mat_diag_bias
-                    elif name == "inertia_mat" and type(fn) is rbp.CovParameterized3DInertiaMatrixNet:
+                    elif name == "inertia_mat" and kind is rbp.CovParameterized3DInertiaMatrixNet:
                         form, const = backend.FORM_COV, fn.spd_3d_cov_inertia_mat_diag_bias
                     link.append((form, const, fn if form != backend.FORM_PLAIN else None))
-                    getters.append(fn if form == backend.FORM_PLAIN else (lambda m=fn: m.l))
+                    if form != backend.FORM_PLAIN:
+                        getters.append(lambda m=fn: m.l)
+                    elif kind in (rbp.UnconstrainedTensor, rbp.UnconstrainedScalar):
+                        getters.append(lambda m=fn: m.param)
+                    else:
+                        getters.append(fn)
                 entries.append(link)
-            cached = self._source_plan = (key, backend.LinkSourcePlan(entries), getters)
-        return cached[1], [g() for g in getters]
+            cached = self._source_plan = (key, backend.LinkSourcePlan(entries, fixed), getters)
+        return cached[1], [g() for g in cached[2]]
 
     def _learnable_plan(self, dw: _DeviceWalk):
         """(learnable links, base, sel) of a walk: the table of the CONSTANT links gathered into walk order, and for every entry of

@@ -96,7 +96,9 @@ def test_one_autograd_node_and_no_module_kernels(device):
     plan, sources = m._learnable_sources(sorted({l for l, _ in m._learnable}))
     forms = [plan.entries[l][j][0] for l in range(plan.n_links) for j in range(6)]
     assert forms.count(backend.FORM_SQUARE_PLUS) == 8 and forms.count(backend.FORM_SPD) == 7
-    assert all(s.numel() == n for s, n in zip(sources, plan.sizes))
+    assert len(sources) == len(plan.live) == len(list(m.parameters())) and all(s.numel() == n for s, n in zip(sources, plan.sizes))
+    assert all(any(s is p for p in m.parameters()) for s in sources)       # (the parameters themselves, where they lie)
+    assert sum(t is not None for t in plan.fixed) == 6 * 7 - len(sources)
 
 
 @pytest.mark.parametrize("device", DEVICES)

@@ -46,7 +46,7 @@ for constrained in (False, True):
             with torch.no_grad():
                 for p, p0 in zip(m.parameters(), params0):
                     p.copy_(p0)
-            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=fused)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=True if fused else None)
 
             def train_step():
                 loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd), want)

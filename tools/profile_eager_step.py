@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Host-side profile (cProfile) of the literal drop-in training step of BASELINE configuration 5, eagerly launched:
-compute_forward_kinematics + torch.nn.functional.mse_loss + backward + Adam (the reference's examples/learn_kinematics_of_iiwa.py loop)."""
+compute_forward_kinematics + torch.nn.functional.mse_loss + backward + Adam (the reference's examples/learn_kinematics_of_iiwa.py loop);
+with `dyn`: the learn-dynamics step (examples/learn_dynamics_iiwa.py: PositiveScalar masses, free centres of mass and inertia matrices of
+the seven links, compute_inverse_dynamics, batch 256)."""
 import cProfile
 import os
 import pstats
@@ -13,24 +15,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gpu_probe import load, sample  # noqa: E402
-from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor  # noqa: E402
+from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, UnconstrainedTensor  # noqa: E402
 
 dev = "cuda" if torch.cuda.is_available() else "cpu"
-B = 16384
+DYN = "dyn" in sys.argv[1:]
+B = 256 if DYN else 16384
 torch.manual_seed(0)
 m, gt = load("iiwa7", dev), load("iiwa7", dev)
-m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
-m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
-q = sample(m, B)[0].to(dev)
-with torch.no_grad():
-    want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+if DYN:
+    for k in range(1, 8):
+        m.make_link_param_learnable("iiwa_link_%d" % k, "mass", PositiveScalar())
+        m.make_link_param_learnable("iiwa_link_%d" % k, "com", UnconstrainedTensor(1, 3))
+        m.make_link_param_learnable("iiwa_link_%d" % k, "inertia_mat", UnconstrainedTensor(3, 3))
+    q, qd, qdd = (t.to(dev) for t in sample(m, B))
+    with torch.no_grad():
+        want = gt.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    forward = lambda: m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+else:
+    m.make_link_param_learnable("iiwa_link_1", "trans", UnconstrainedTensor(1, 3))
+    m.make_link_param_learnable("iiwa_link_1", "rot_angles", UnconstrainedTensor(1, 3))
+    q = sample(m, B)[0].to(dev)
+    with torch.no_grad():
+        want, _ = gt.compute_forward_kinematics(q, "iiwa_link_ee")
+    forward = lambda: m.compute_forward_kinematics(q, "iiwa_link_ee")[0]
 opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 sync = torch.cuda.synchronize if dev == "cuda" else (lambda: None)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
-    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee")
+    pos = forward()
     loss = torch.nn.functional.mse_loss(pos, want)
     loss.backward()
     opt.step()
@@ -39,7 +53,7 @@ def step():
 def parts():
     t = [time.perf_counter()]
     opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
-    pos, _ = m.compute_forward_kinematics(q, "iiwa_link_ee"); t.append(time.perf_counter())
+    pos = forward(); t.append(time.perf_counter())
     loss = torch.nn.functional.mse_loss(pos, want); t.append(time.perf_counter())
     loss.backward(); t.append(time.perf_counter())
     opt.step(); t.append(time.perf_counter())
