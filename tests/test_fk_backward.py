@@ -738,7 +738,8 @@ def _learnable_pair(device, what, seed=3):
         for link, pname in LINK_SETS[what]:
             m.make_link_param_learnable(link, pname, UT(1, 1) if pname == "mass" else UT(1, 3))
         m._fk_mse_links = links_path
-        out.append(m)
+        m._table_links = False      # (the composition these tests hold drm_fk_mse_links to: cat + drm_walk_table + ... + drm_walk_table_backward;
+        out.append(m)               #  ABI 13's drm_walk_table_links agrees with it to the last bits, tests/test_table_links.py)
     return out
 
 
