@@ -292,8 +292,17 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
     (a constant model launches the same pair every call: filling the ~60 fields took 4-5 us of an eager call's ~20)."""
     key = (ops_f.data_ptr(), ops_i.data_ptr(), n_dofs, ops_f.shape[0])
     cached = getattr(prog, "_ws_cache", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
+    if cached is not None:
+        if cached[0] == key:
+            return cached[1]
+        if cached[0][1:] == key[1:] and key[0] and cached[0][0]:
+            # a model with learnable links: a NEW table on every call, everything else as before — the struct is read by the C side
+            # while the call is made, so the one of the last call takes the new address (a new cache entry: prepared calls that hold
+            # the old one by identity look again)
+            w = cached[1]
+            w.ops_f = key[0]
+            prog._ws_cache = (key, w)
+            return w
     w = _walk_struct_build(prog, ops_f, ops_i, n_dofs)
     prog._ws_cache = (key, w)
     return w
@@ -719,6 +728,8 @@ class LinkSourcePlan(object):
                     raise ValueError("constant piece %d of a learnable link: %d float32 values expected" % (i, sizes[i]))
                 setattr(self._links[i // 6], PIECE_NAMES[i % 6], t.data_ptr())
         self._key = None
+        self.checked = None        # data_ptr()s of the live sources WalkTableLinks last found on `device`, float32, contiguous, of the right sizes
+        self.device = next((t.device for t in self.fixed if t is not None), None)
 
     def pieces(self, sources):
         """The drm_link_pieces array with the live pieces at these tensors (rewritten only when one of them has moved)."""
@@ -749,13 +760,17 @@ class WalkTableLinks(torch.autograd.Function):
     def forward(ctx, base, sel, gsign, plan, *sources):
         lib = library_for(base.device)
         dev = base.device
-        held = []
-        for t, size in zip(sources, plan.sizes):
-            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
-                t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
-            if t.numel() != size:
-                raise ValueError("a piece of a learnable link has %d elements, not %d" % (t.numel(), size))
-            held.append(t)
+        if tuple([t.data_ptr() for t in sources]) == plan.checked:      # (the tensors of the last call, where they were: checked then)
+            held = sources
+        else:
+            held, as_given = [], True
+            for t, size in zip(sources, plan.sizes):
+                if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                    t, as_given = t.detach().to(device=dev, dtype=torch.float32).contiguous(), False
+                if t.numel() != size:
+                    raise ValueError("a piece of a learnable link has %d elements, not %d" % (t.numel(), size))
+                held.append(t)
+            plan.checked = tuple([t.data_ptr() for t in sources]) if as_given and dev == plan.device else None
         ops_f = torch.empty_like(base)
         with _on_device(dev):
             _check(lib.drm_walk_table_links(plan.pieces(held), plan.forms, plan.n_links, base.data_ptr(), sel.data_ptr(), gsign.data_ptr(),
@@ -784,8 +799,9 @@ class WalkTableLinks(torch.autograd.Function):
             return (None, None, None, None) + tuple(out)
         dev = base.device
         lib = library_for(dev)
-        held = [t if (t.device == dev and t.dtype == torch.float32 and t.is_contiguous()) else
-                t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in sources]
+        plain = tuple([t.data_ptr() for t in sources]) == plan.checked
+        held = sources if plain else [t if (t.device == dev and t.dtype == torch.float32 and t.is_contiguous()) else
+                                      t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in sources]
         g = grad_ops_f.contiguous().to(torch.float32)
         grad = torch.empty(plan.n_links * 20, device=dev, dtype=torch.float32)
         with _on_device(dev):
@@ -799,7 +815,7 @@ class WalkTableLinks(torch.autograd.Function):
                 continue
             at = (i // 6) * 20 + PIECE_OFFSETS[i % 6]
             piece = grad[at:at + size].view(t.shape)
-            out.append(piece if t.device == dev and t.dtype == torch.float32 else piece.to(device=t.device, dtype=t.dtype))
+            out.append(piece if plain or (t.device == dev and t.dtype == torch.float32) else piece.to(device=t.device, dtype=t.dtype))
         return (None, None, None, None) + tuple(out)
 
 

@@ -144,6 +144,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._zero1 = torch.zeros(1, device=self._device)
         self._table_links = os.environ.get("DRM_TABLE_LINKS", "1") != "0"        # (0: the table of a learnable model through a cat of the modules' outputs + drm_walk_table; A/B switch)
         self._source_plan = None
+        self._learnable_version = 0                 # counts make_link_param_learnable: what is cached per set of learnable parameters looks at it
         self._fk_mse_links = os.environ.get("DRM_FK_MSE_LINKS", "1") != "0"      # (0: fk_mse_loss composes WalkTable + drm_fk_mse; A/B switch)
         self._kin_state = None   # (q, qd) of the last update_kinematic_state
         self._kin_cache = {}
@@ -422,12 +423,16 @@ class DifferentiableRobotModel(torch.nn.Module):
         had to carry a transform for them (flatten.foldable_links)."""
         if not self._learnable and self._dyn_walk is not None:      # (constant model: the walk never changes)
             return self._dyn_walk
+        mode = self._own_kernel_mode()
+        have = self.__dict__.get("_dyn_walk_learnable")     # (a model with learnable links asks on every call)
+        if have is not None and have[0] == (self._learnable_version, mode) and (
+                mode == "off" or self._device.type != "cuda" or getattr(have[1].program, "_special_tried", False)):
+            return have[1]
         key = self._fold_key()
         if not self._fold_masks[key].any():
             dw = self._get_walk(("tree",), whole_tree=True)
         else:
             dw = self._get_walk(("tree", "folded", key), whole_tree=True, folded=True, fold_key=key)
-        mode = self._own_kernel_mode()
         if mode != "off" and self._device.type == "cuda" and not getattr(dw.program, "_special_tried", False):
             # the robot's OWN kernels on first use.  "auto" (the default, round 6): whatever is already built — the code objects
             # shipped next to the library, the run-time cache of an earlier specialize() — is attached, nothing is compiled; "build"
@@ -470,6 +475,8 @@ class DifferentiableRobotModel(torch.nn.Module):
                 pass
         if not self._learnable:
             self._dyn_walk = dw
+        else:
+            self.__dict__["_dyn_walk_learnable"] = ((self._learnable_version, mode), dw)
         return dw
 
     def _static_rows(self, fold_key: Optional[tuple]) -> torch.Tensor:
@@ -490,13 +497,26 @@ class DifferentiableRobotModel(torch.nn.Module):
         gather (+ exact sign flips) from the link table, cached while nothing is learnable."""
         if not self._learnable and dw.static_ops_f is not None:
             return dw.static_ops_f
-        if self._learnable and len({link for link, _ in self._learnable}) <= 32 and not self._spec.skew.any():
+        if self._learnable and len(self._learnable_link_list()) <= 32 and not self._has_skew():
             return self._ops_f_learnable(dw)      # (more learnable links than the fused kernel takes: the torch path below)
         table = self._link_table(dw.fold_key)
         ops_f = (table.reshape(-1).index_select(0, dw.gather) * dw.gsign).reshape(dw.program.capacity, OPF_STRIDE)
         if not self._learnable:
             dw.static_ops_f = ops_f
         return ops_f
+
+    def _learnable_link_list(self) -> list:
+        """The links with a learnable parameter, ascending (cached per set of learnable parameters)."""
+        have = self.__dict__.get("_learnable_sorted")
+        if have is None or have[0] != self._learnable_version:
+            have = self.__dict__["_learnable_sorted"] = (self._learnable_version, sorted({link for link, _ in self._learnable}))
+        return have[1]
+
+    def _has_skew(self) -> bool:
+        have = self.__dict__.get("_skew_any")
+        if have is None:
+            have = self.__dict__["_skew_any"] = bool(self._spec.skew.any())
+        return have
 
     def _ops_f_learnable(self, dw: _DeviceWalk) -> torch.Tensor:
         """The walk table with learnable links through ONE fused kernel (backend.WalkTable): the constant entries come
@@ -545,10 +565,10 @@ class DifferentiableRobotModel(torch.nn.Module):
                     elif name == "inertia_mat" and kind is rbp.CovParameterized3DInertiaMatrixNet:
                         form, const = backend.FORM_COV, fn.spd_3d_cov_inertia_mat_diag_bias
                     link.append((form, const, fn if form != backend.FORM_PLAIN else None))
-                    if form != backend.FORM_PLAIN:
-                        getters.append(lambda m=fn: m.l)
+                    if form != backend.FORM_PLAIN:           # (the module's own dictionary: nn.Module.__getattr__ is three times slower)
+                        getters.append(lambda d=fn._parameters: d["l"])
                     elif kind in (rbp.UnconstrainedTensor, rbp.UnconstrainedScalar):
-                        getters.append(lambda m=fn: m.param)
+                        getters.append(lambda d=fn._parameters: d["param"])
                     else:
                         getters.append(fn)
                 entries.append(link)
@@ -558,7 +578,7 @@ class DifferentiableRobotModel(torch.nn.Module):
     def _learnable_plan(self, dw: _DeviceWalk):
         """(learnable links, base, sel) of a walk: the table of the CONSTANT links gathered into walk order, and for every entry of
         the table the element of a learnable link's row it comes from (slot * 32 + column; -1: constant).  Cached per set of links."""
-        links = sorted({link for link, _ in self._learnable})
+        links = self._learnable_link_list()
         key = tuple(links)
         plan = dw.learnable_plan
         if plan is None or plan[0] != key:
@@ -674,11 +694,15 @@ class DifferentiableRobotModel(torch.nn.Module):
 
     def _kinematic_param_mask(self, dw: _DeviceWalk) -> int:
         """bit k set <=> op k's R_fixed / trans come from a learnable parametrisation (needs a constant gradient)."""
+        have = dw.__dict__.get("_kin_mask")
+        if have is not None and have[0] == self._learnable_version:
+            return have[1]
         links = {link for link, pname in self._learnable if pname in ("trans", "rot_angles")}
         mask = 0
         for k, link in enumerate(dw.program.links):
             if int(link) in links:
                 mask |= 1 << k
+        dw.__dict__["_kin_mask"] = (self._learnable_version, mask)
         return mask
 
     def _differentiable(self, dw: _DeviceWalk) -> None:
@@ -1161,11 +1185,15 @@ class DifferentiableRobotModel(torch.nn.Module):
 
     def _learnable_op_mask(self, dw) -> int:
         """Bit k set <=> op k of the walk belongs to a link with a learnable parameter (param_mask of the backward kernels)."""
+        have = dw.__dict__.get("_op_mask")
+        if have is not None and have[0] == self._learnable_version:
+            return have[1]
         links = {link for link, _ in self._learnable}
         mask = 0
         for k, link in enumerate(dw.program.links):
             if int(link) in links:
                 mask |= 1 << k
+        dw.__dict__["_op_mask"] = (self._learnable_version, mask)
         return mask
 
     def _inverse_dynamics(self, q, qd, qdd, gravity: bool, damping: bool) -> torch.Tensor:
@@ -1293,6 +1321,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._learnable.add((self._name_to_idx_map[link_name], parameter_name))
         self._learnable_links = None
         self._source_plan = None
+        self._learnable_version += 1
         for dw in self._walks.values():
             dw.static_ops_f = None
             special = getattr(dw.program, "_special", None) or {}
