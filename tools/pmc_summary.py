@@ -110,6 +110,8 @@ for src, dst in (("overhead_plain.txt", "_overhead_plain.txt"), ("ab_rnea.txt", 
                  ("probe_nonfinite.txt", "_probe_nonfinite.txt"), ("step5_kernels.txt", "_step5_kernels.txt"),
                  ("step_dyn_kernels.txt", "_step_dyn_kernels.txt"), ("ab_fk_mse_links.txt", "_ab_fk_mse_links.txt"),
                  ("timeline_links.txt", "_timeline_links.txt"), ("learn_dynamics.txt", "_learn_dynamics.txt"),
+                 ("learn_dynamics_links.txt", "_learn_dynamics_links.txt"), ("step_dyn_kernels_links.txt", "_step_dyn_kernels_links.txt"),
+                 ("io_floors_c3_shard.txt", "_io_floors_c3_shard.txt"),
                  # round 6: bench.py's stdout is the compact line; the full records of the runs
                  ("bench_default_detail.json", "_bench_default_detail.json"), ("bench_k20_detail.json", "_bench_k20_detail.json"),
                  ("bench_config3_detail.json", "_bench_config3_detail.json"),

@@ -64,6 +64,8 @@ for mode in 1 0; do
 done > $OUT/step5_kernels.txt
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stepdyn -- python $ROOT/tools/probe_step5.py dyn 256 > $OUT/stepdyn.log 2>&1
 python $ROOT/tools/probe_step5.py --read $OUT/prof_stepdyn > $OUT/step_dyn_kernels.txt 2>&1
+# ABI 13 (drm_walk_table_links): the learn-dynamics step with and without it — step times, the kernels of a replayed step, host time
+bash $ROOT/tools/run_links_round.sh > $OUT/links_round.log 2>&1
 python $ROOT/tools/ab_fk_mse_links.py 2>&1 | grep -v amdgpu.ids > $OUT/ab_fk_mse_links.txt
 ( echo "== default: the arm's own kernel for this set of learnable blocks (shipped)"; python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable"
   echo "== DRM_SPECIALIZE=0: the library's kernels (the round-5 path)"; DRM_SPECIALIZE=0 python $ROOT/tools/bench_learn_dynamics.py 2>&1 | grep "^learnable" ) > $OUT/learn_dynamics.txt
@@ -86,6 +88,7 @@ if [ -f $ROOT/tools/variants/libdrm_timeline.so ]; then
 fi
 if [ -x $ROOT/tools/ubench/metric_lab ]; then
   $ROOT/tools/ubench/metric_lab 1048576 floors > $OUT/io_floors_2p20.txt 2>&1
+  $ROOT/tools/ubench/metric_lab 131072 floors 2>&1 | grep "^device\|config 3\|inverse dynamics, 7 DoF" > $OUT/io_floors_c3_shard.txt
   $ROOT/tools/ubench/metric_lab > $OUT/metric_lab.txt 2>&1
   $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_plain.txt 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_overhead -- $ROOT/tools/ubench/metric_lab 65536 overhead > $OUT/overhead_under_rocprofv3.txt 2>&1

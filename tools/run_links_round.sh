@@ -2,7 +2,7 @@
 # gpurun -- bash tools/run_links_round.sh : ABI 13 (drm_walk_table_links) on the GPU — the GPU tests of the new path, the learn-dynamics
 # step with and without it (torch's default and fused Adam), the kernels of one eager and one replayed step, the host profile of the
 # eager steps
-ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; rm -rf $OUT/prof_stepdyn_links_*
 cd /tmp && export TMPDIR=/tmp
 python -m pytest $ROOT/tests/test_table_links.py -q -m gpu -p no:cacheprovider 2>&1 | tail -15 > $OUT/test_table_links.log
 ( echo "== default: drm_walk_table_links (ABI 13: the table from the parameter tensors where they lie, the modules' forms inside the kernel)"

@@ -15,8 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import load_model, sample_states  # noqa: E402
-from differentiable_robot_model_amd.rigid_body_params import UnconstrainedTensor  # noqa: E402
+from differentiable_robot_model_amd.rigid_body_params import (CovParameterized3DInertiaMatrixNet, PositiveScalar,  # noqa: E402
+                                                               Symm3DInertiaMatrixNet, SymmPosDef3DInertiaMatrixNet, UnconstrainedTensor)
 
+GPU = "cuda" if torch.cuda.is_available() else "cpu"      # (without a device the same checks run host against host: a dry run of the tool)
 ROBOTS = ["panda_no_gripper", "iiwa7", "allegro_left", "panda", "fetch", "jaco", "trifinger_edu", "2link_robot"]
 SHAPES = {"trans": (1, 3), "rot_angles": (1, 3), "mass": (1, 1), "com": (1, 3), "inertia_mat": (3, 3), "joint_damping": (1, 1)}
 SIZES = [1, 63, 64, 65, 128, 192, 1000, 4096, 4160]
@@ -31,17 +33,30 @@ while time.time() - t0 < budget:
     picks = [(link, p) for link in chosen for p in SHAPES if rng.random() < 0.4] or [(chosen[0], "trans")]
     seed = int(rng.integers(1 << 30))
     models = []
-    for dev, own in (("cpu", None), ("cuda", None), ("cuda", "off")):
+    # the module of every learnable piece (round 6, ABI 13: the kernels know PositiveScalar and the l[6] inertia-matrix modules; the
+    # reference model evaluates them with torch ops and packs their outputs: DRM_TABLE_LINKS=0's path on the host)
+    kinds = {(link, p): int(rng.integers(4)) for link, p in picks}
+    def module(link, p):
+        k = kinds[(link, p)]
+        if p in ("mass", "joint_damping") and k >= 2:
+            return PositiveScalar(min_val=0.05 * k)
+        if p == "inertia_mat" and k >= 1:
+            return (Symm3DInertiaMatrixNet(init_param_std=0.05), SymmPosDef3DInertiaMatrixNet(bias=1e-3, init_param_std=0.1),
+                    CovParameterized3DInertiaMatrixNet(bias=1e-3, init_param_std=0.1))[k - 1]
+        return UnconstrainedTensor(*SHAPES[p])
+    for dev, own, links_path in (("cpu", None, False), (GPU, None, True), (GPU, "off", True), ("cpu", None, True)):
         m = load_model(robot, dev)
+        m._table_links = links_path
         torch.manual_seed(seed)
         for link, p in picks:
-            m.make_link_param_learnable(link, p, UnconstrainedTensor(*SHAPES[p]))
+            m.make_link_param_learnable(link, p, module(link, p))
         if own:
             m.own_kernels = own
         models.append(m)
-    with torch.no_grad():       # the same parameter values everywhere; inertia matrices near the URDF's (keeps the dynamics well posed)
-        for pc, pg, pl in zip(*(m.parameters() for m in models)):
-            pg.copy_(pc.cuda()); pl.copy_(pc.cuda())
+    with torch.no_grad():       # the same parameter values everywhere
+        for ps in zip(*(m.parameters() for m in models)):
+            for other in ps[1:]:
+                other.copy_(ps[0].to(other.device))
     n_models += 1
     cpu = models[0]
     link = list(cpu._name_to_idx_map)[int(rng.integers(1, len(cpu._name_to_idx_map)))]
@@ -52,7 +67,7 @@ while time.time() - t0 < budget:
         arm = cpu._n_dofs == 7 and B % 64 == 0 and len(cpu._bodies) <= 10
         results = []
         for m in models:
-            dev = "cuda" if m._device.type == "cuda" else "cpu"
+            dev = m._device.type
             x = q.to(dev).clone().requires_grad_(True)
             m.zero_grad()
             pos, _ = m.compute_forward_kinematics(x, link)
@@ -66,7 +81,7 @@ while time.time() - t0 < budget:
             results.append([loss.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu() for p in m.parameters()])
         ref = results[0]
         pnames = [n.replace("_bodies.", "").replace(".param", "") for n, _ in cpu.named_parameters()]
-        for tag, got in (("own", results[1]), ("lib", results[2])):
+        for tag, got in (("own", results[1]), ("lib", results[2]), ("host links", results[3])):
             for k, (a, b) in enumerate(zip(got, ref)):
                 what = ("loss", "grad q")[k] if k < 2 else "grad " + pnames[k - 2].split(".")[-1]
                 # (a gradient that cancels analytically — a rotation-invariant loss term with respect to a frame's angles, a mass at a
