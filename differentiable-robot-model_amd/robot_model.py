@@ -184,6 +184,33 @@ class DifferentiableRobotModel(torch.nn.Module):
         self._root_pose = None                                  # the root link's identity (pos [1,3], quat [1,4]), made on first use
         self._learnable_links: Optional[torch.Tensor] = None   # link indices whose rows are rebuilt per call
 
+    # ------------------------------------------------------------------ copies
+    # copy.deepcopy(model) works as it does for the reference's plain nn.Module (a ground-truth copy, a target network): parameters,
+    # constants and the set of learnable parameters are copied; everything DERIVED — walks with their launch structs and kernel handles,
+    # prepared calls, the source plan of the learnable links — is left behind and rebuilt by the copy on first use.
+    _DERIVED = {"_walks": dict, "_chain_walks": dict, "_dyn_walk": lambda: None, "_fanout_plans": dict, "_fan_handles": dict,
+                "_fast_fk": dict, "_fast_jac": dict, "_fast_id": lambda: None, "_fast_crba": lambda: None, "_fast_fd": lambda: None,
+                "_fast_fkid": dict, "_source_plan": lambda: None, "_kin_cache": dict, "_kin_state": lambda: None,
+                "_stream_arg": lambda: None, "_arm_specialized": lambda: False}
+    _DERIVED_LAZY = ("_learnable_sorted", "_skew_any", "_dyn_walk_learnable", "_body_names", "_all_link_idxs")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for name, make in self._DERIVED.items():
+            if name in state:
+                state[name] = make()
+        for name in self._DERIVED_LAZY:
+            state.pop(name, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._stream_arg = (lambda: 0) if self._device.type != "cuda" or backend._raw_stream is None else \
+            (lambda raw=backend._raw_stream, i=self._device.index: raw(i))
+        self._learnable_version = self.__dict__.get("_learnable_version", 0) + 1
+        for i, body in enumerate(self._bodies):
+            body._attach(self, i)       # (a body's pose / vel ask ITS model)
+
     # ------------------------------------------------------------------ constants
     def _link_rows(self, link_idxs, device=None) -> torch.Tensor:
         """[len(link_idxs), OPF_STRIDE] float32 rows of per-link constants on the model device.

@@ -263,3 +263,35 @@ def test_panda_learnable_arm_kernel_reads_the_links_table():
         got.append([qg.grad] + [p.grad for p in m.parameters()])
     for a, b in zip(*got):
         assert close(b, a, 2e-5)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_deepcopy_gives_an_independent_model(device):
+    """copy.deepcopy(model), as users of the reference's plain nn.Module do (a ground-truth copy, a target network): parameters and
+    constants are copied, everything derived (walks, launch structs, prepared calls, the source plan of the learnable links) is
+    rebuilt by the copy; the two models then learn independently and a body's pose asks its own model."""
+    import copy
+    m = learnable_iiwa(device, "spd", True)
+    q, qd, qdd = states(device, 64)
+    tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True).detach()
+    pos = m.compute_forward_kinematics(q, "iiwa_link_ee")[0].detach()
+    twin = copy.deepcopy(m)
+    assert [n for n, _ in twin.named_parameters()] == [n for n, _ in m.named_parameters()]
+    assert all(a is not b and torch.equal(a, b) for a, b in zip(twin.parameters(), m.parameters()))
+    assert torch.equal(twin.compute_inverse_dynamics(q, qd, qdd, include_gravity=True).detach(), tau)
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.add_(0.05)
+    assert torch.equal(m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True).detach(), tau)       # (the original is untouched)
+    assert torch.equal(m.compute_forward_kinematics(q, "iiwa_link_ee")[0].detach(), pos)
+    moved = twin.compute_inverse_dynamics(q, qd, qdd, include_gravity=True)
+    assert not torch.equal(moved.detach(), tau)
+    moved.pow(2).mean().backward()
+    assert all(p.grad is not None for p in twin.parameters()) and all(p.grad is None for p in m.parameters())
+    twin.update_kinematic_state(q, qd)
+    m.update_kinematic_state(q, qd)
+    assert not torch.equal(twin._bodies[-1].pose.translation(), m._bodies[-1].pose.translation())
+    plain = DifferentiableKUKAiiwa(device=device)       # a constant model: prepared calls and walks are the copy's own
+    want = plain.compute_endeffector_jacobian(q, "iiwa_link_ee")
+    got = copy.deepcopy(plain).compute_endeffector_jacobian(q, "iiwa_link_ee")
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
