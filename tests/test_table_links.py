@@ -295,3 +295,60 @@ def test_deepcopy_gives_an_independent_model(device):
     want = plain.compute_endeffector_jacobian(q, "iiwa_link_ee")
     got = copy.deepcopy(plain).compute_endeffector_jacobian(q, "iiwa_link_ee")
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+FORM_CASES = ["iiwa7_spd", "iiwa7_cov", "panda_symm", "allegro_mixed"]
+FORM_ROBOT = {"iiwa7_spd": "iiwa7", "iiwa7_cov": "iiwa7", "panda_symm": "panda_no_gripper", "allegro_mixed": "allegro_left"}
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("case", FORM_CASES)
+def test_forms_against_the_references_own_modules(case, device):
+    """tests/golden/golden_forms.npz (make_golden_forms.py): the UNMODIFIED reference with ITS parameter modules in the loop —
+    PositiveScalar masses / dampings, symmetric / SPD / covariance inertia matrices, free tensors — torques, end-link positions and the
+    gradient of a random linear functional of both with respect to every RAW parameter and the joint state, from torch autograd through
+    the reference.  Here: the same raw values in this package's modules, the table built and differentiated inside the kernels (ABI 13).
+    Tolerances as for the other reference-autograd fixtures: 2e-5 (outputs), 2e-4 (gradients), of the largest entry."""
+    import os
+    from helpers import load_model
+    from differentiable_robot_model_amd import rigid_body_params as rbp
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_forms.npz"))
+    m = load_model(FORM_ROBOT[case], device)
+    assert m._table_links
+    raws = []
+    for key, kind, const in zip(G[case + "/keys"], G[case + "/kinds"], G[case + "/consts"]):
+        lname, pname = str(key).split("/")
+        raw = torch.from_numpy(G["%s/raw/%s" % (case, key)])
+        if kind == "PositiveScalar":
+            module = rbp.PositiveScalar(min_val=float(const))
+        elif kind == "UnconstrainedTensor":
+            module = rbp.UnconstrainedTensor(dim1=raw.shape[0], dim2=raw.shape[1])
+        else:
+            module = getattr(rbp, str(kind))(bias=float(const)) if kind != "Symm3DInertiaMatrixNet" else rbp.Symm3DInertiaMatrixNet()
+        (param,) = list(module.parameters())
+        with torch.no_grad():
+            param.copy_(raw.reshape(param.shape))
+        m.make_link_param_learnable(lname, pname, module)
+        (param,) = list(module.parameters())        # (moved to the model's device)
+        raws.append(param)
+        holder = m._bodies[m._name_to_idx_map[lname]]
+        holder = holder if pname in ("trans", "rot_angles", "joint_damping") else holder.inertia
+        value = getattr(holder, pname)().detach().cpu().numpy()
+        want = G["%s/value/%s" % (case, key)]
+        assert np.abs(value.reshape(-1) - want.reshape(-1)).max() <= 1e-6 * max(1.0, np.abs(want).max()), key      # (the module's own forward)
+    plan, _ = m._learnable_sources(m._learnable_link_list())
+    kernel_forms = sum(e[0] != backend.FORM_PLAIN for link in plan.entries for e in link)
+    assert kernel_forms == sum(str(k) != "UnconstrainedTensor" for k in G[case + "/kinds"])       # (every known module is a kernel form)
+    t = lambda tag, grad=False: torch.from_numpy(G["%s/%s" % (case, tag)]).to(device).requires_grad_(grad)
+    q, qd, qdd = t("q", True), t("qd", True), t("qdd", True)
+    tau = m.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
+    pos, _ = m.compute_forward_kinematics(q, str(G[case + "/link"]))
+    rel = lambda got, want: float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-6)
+    assert rel(tau.detach().cpu().numpy(), G[case + "/tau"]) <= 2e-5 and rel(pos.detach().cpu().numpy(), G[case + "/pos"]) <= 2e-5
+    L = (t("w_tau") * tau).sum() + (t("w_pos") * pos).sum()
+    grads = torch.autograd.grad(L, raws + [q, qd, qdd], allow_unused=True)
+    wants = [G["%s/grad/%s" % (case, key)] for key in G[case + "/keys"]] + [G[case + "/gq"], G[case + "/gqd"], G[case + "/gqdd"]]
+    floor = 2e-5 * max(float(np.abs(w).max()) for w in wants[:len(raws)])
+    for key, g, want in zip(list(G[case + "/keys"]) + ["q", "qd", "qdd"], grads, wants):
+        got = np.zeros_like(want) if g is None else g.detach().cpu().numpy().reshape(want.shape)
+        assert float(np.abs(got - want).max()) <= 2e-4 * float(np.abs(want).max()) + floor, (case, key)
