@@ -4,7 +4,10 @@ examples/learn_dynamics_iiwa.py and of its L4DC notebook): mass, centre of mass 
 links are learnable, the loss is the MSE of the predicted joint torques against a ground-truth model.  Forward through
 drm_rnea, backward through drm_rnea_backward (hand-written adjoint sweeps, deterministic batch reduction).
 
-    python examples/learn_dynamics_iiwa.py [--batch 4096] [--epochs 300] [--spd] [--graph]
+    python examples/learn_dynamics_iiwa.py [--batch 4096] [--epochs 300] [--spd] [--graph] [--fused-adam]
+
+The parameter modules (PositiveScalar, the inertia-matrix modules) are evaluated and differentiated inside the table kernels (ABI 13,
+drm_walk_table_links): a step is 12 kernels, five of them this package's; --graph --fused-adam replays it in ~45 us at batch 256.
 """
 import argparse
 import time
@@ -16,7 +19,7 @@ from differentiable_robot_model_amd import DifferentiableKUKAiiwa
 from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, SymmPosDef3DInertiaMatrixNet, UnconstrainedTensor
 
 
-def run(batch=4096, epochs=300, lr=1e-3, spd=False, use_graph=False, device="cuda", verbose=True):
+def run(batch=4096, epochs=300, lr=1e-3, spd=False, use_graph=False, device="cuda", verbose=True, fused_adam=False):
     torch.manual_seed(0)
     truth = DifferentiableKUKAiiwa(device=device)
     model = DifferentiableKUKAiiwa(device=device)
@@ -28,7 +31,7 @@ def run(batch=4096, epochs=300, lr=1e-3, spd=False, use_graph=False, device="cud
     q, qd, qdd = _common.sample_states(truth, batch, seed=2)
     with torch.no_grad():
         target = truth.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=use_graph)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=use_graph, fused=True if fused_adam else None)
 
     def step():
         tau = model.compute_inverse_dynamics(q, qd, qdd, include_gravity=True, use_damping=True)
@@ -65,5 +68,6 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=300)
     ap.add_argument("--spd", action="store_true", help="symmetric positive definite inertia parametrisation")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true", help="torch's fused Adam (two kernels) instead of its default foreach implementation")
     a = ap.parse_args()
-    run(a.batch, a.epochs, spd=a.spd, use_graph=a.graph)
+    run(a.batch, a.epochs, spd=a.spd, use_graph=a.graph, fused_adam=a.fused_adam)

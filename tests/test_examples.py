@@ -31,9 +31,9 @@ def test_learn_kinematics_example(use_graph, fused_loss):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spd,use_graph", [(False, False), (True, True)])
-def test_learn_dynamics_example(spd, use_graph):
-    hist = load("learn_dynamics_iiwa").run(batch=1024, epochs=150, lr=3e-2, spd=spd, use_graph=use_graph, verbose=False)
+@pytest.mark.parametrize("spd,use_graph,fused_adam", [(False, False, False), (True, True, False), (False, True, True)])
+def test_learn_dynamics_example(spd, use_graph, fused_adam):
+    hist = load("learn_dynamics_iiwa").run(batch=1024, epochs=150, lr=3e-2, spd=spd, use_graph=use_graph, verbose=False, fused_adam=fused_adam)
     assert hist[-1] < 0.5 * hist[0]
 
 
