@@ -853,6 +853,11 @@ class DifferentiableRobotModel(torch.nn.Module):
             fan = None if needs_grad else self._fanout_chains(non_root, dw)
             if fan is not None:
                 p, r = backend.fk_fanout([(c.program, self._ops_f(c), c.ops_i) for c in fan], q, self._n_dofs)
+            elif needs_grad and len(non_root) > 1 and not dw.program.backward_ok:
+                # a many-target walk the backward kernels do not take (more than 6 branch points open at once, > 64 ops): the targets'
+                # root -> link chains one by one — a chain has no branch point — as the reference's per-link autograd graph would
+                parts = [self._fk_targets(q, [i]) for i in non_root]
+                p, r = torch.cat([a for a, _ in parts], dim=1), torch.cat([b for _, b in parts], dim=1)
             elif needs_grad:
                 self._differentiable(dw)
                 p, r = _FkPositions.apply(q, ops_f, dw, len(non_root), self._n_dofs, self._kinematic_param_mask(dw))

@@ -314,3 +314,66 @@ def test_emu_learnable_op_beyond_32_gets_its_own_gradient(emu, tmp_path):
     assert np.abs(gops[k]).max() > 1e-3 and np.abs(gops[k - 32]).max() == 0.0
     rows = [r for r in range(prog.capacity) if r != k]
     assert np.abs(gops[rows]).max() == 0.0
+
+
+def comb_urdf(n_teeth: int) -> str:
+    """A spine of n_teeth revolute joints, every spine link carrying a two-joint side branch: n_teeth branch points, all of them open
+    while the deepest tooth is walked."""
+    rng = np.random.default_rng(77)
+    axes = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1"]
+    out = ['<?xml version="1.0"?>', '<robot name="comb%d">' % n_teeth, '  <link name="base"/>']
+
+    def link(name):
+        out.append('  <link name="%s"><inertial><origin xyz="0.01 0.0 0.02" rpy="0 0 0"/><mass value="0.3"/>'
+                   '<inertia ixx="0.003" ixy="0" ixz="0" iyy="0.003" iyz="0" izz="0.002"/></inertial></link>' % name)
+
+    def joint(name, parent, child):
+        xyz, rpy = rng.standard_normal(3) * 0.05 + np.array([0, 0, 0.08]), rng.standard_normal(3) * 0.5
+        out.append('  <joint name="%s" type="revolute"><parent link="%s"/><child link="%s"/><origin xyz="%.5f %.5f %.5f" rpy="%.5f %.5f %.5f"/>'
+                   '<axis xyz="%s"/><limit effort="10" lower="-2" upper="2" velocity="3"/></joint>'
+                   % (name, parent, child, xyz[0], xyz[1], xyz[2], rpy[0], rpy[1], rpy[2], axes[int(rng.integers(6))]))
+    parent = "base"
+    for i in range(n_teeth):
+        link("spine%d" % i); joint("js%d" % i, parent, "spine%d" % i)
+        link("tooth%da" % i); joint("jt%da" % i, "spine%d" % i, "tooth%da" % i)
+        link("tooth%db" % i); joint("jt%db" % i, "tooth%da" % i, "tooth%db" % i)
+        parent = "spine%d" % i
+    link("tip"); joint("jtip", parent, "tip")
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_gradients_of_every_links_pose_on_a_tree_with_more_branch_points_than_the_backward_walk_takes(tmp_path, device):
+    """The backward kernels walk trees with up to 6 branch points open at once (the packed control word addresses six save slots); a
+    many-target FK call that needs gradients on a wider tree goes target by target over root -> link chains instead of refusing —
+    same poses as the one-launch forward, gradients against central differences of it."""
+    path = os.path.join(str(tmp_path), "comb.urdf")
+    with open(path, "w") as f:
+        f.write(comb_urdf(9))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DifferentiableRobotModel(path, device=device)
+    n = m._n_dofs
+    assert n == 28
+    g = torch.Generator().manual_seed(3)
+    q = ((torch.rand(5, n, generator=g) - 0.5) * 2.0).to(device)
+    with torch.no_grad():
+        want = m.compute_forward_kinematics_all_links(q)
+    leaves = [i for i, b in enumerate(m._bodies) if b.name.endswith("b") or b.name == "tip"]
+    walk = m._get_walk(("fk", tuple(sorted(leaves))), targets=sorted(leaves))
+    assert not walk.program.backward_ok and walk.program.n_slots > 6       # (the case this test is about)
+    x = q.clone().requires_grad_(True)
+    got = m.compute_forward_kinematics_all_links(x)
+    w = {name: torch.randn(5, 3, generator=g).to(device) for name in got}
+    for name in got:
+        assert torch.allclose(got[name][0].detach(), want[name][0], atol=2e-6) and torch.allclose(got[name][1].detach(), want[name][1], atol=2e-6)
+    loss = sum((w[name] * got[name][0]).sum() for name in got)
+    (grad,) = torch.autograd.grad(loss, x)
+    h = 2e-3
+    with torch.no_grad():
+        num = torch.zeros_like(q)
+        for d in range(n):
+            e = torch.zeros(n, device=device); e[d] = h
+            hi, lo = m.compute_forward_kinematics_all_links(q + e), m.compute_forward_kinematics_all_links(q - e)
+            num[:, d] = sum((w[name] * (hi[name][0] - lo[name][0])).sum(dim=1) for name in got) / (2 * h)
+    assert float((grad - num).abs().max()) <= 5e-3 * max(1.0, float(num.abs().max()))
