@@ -387,6 +387,11 @@ def compact_line(full):
             for k_src, k_dst in (("graph_step_us", "_graph_step"), ("graph_step_fused_us", "_graph_step_fused"), ("eager_step_us", "_eager_step")):
                 if k_src in leg:
                     us[key + k_dst] = _num(leg[k_src], 4)
+        dyn = configs.get("learn_dynamics_step") or {}
+        for k_src, k_dst in (("graph_step_us", "dyn_graph_step"), ("graph_step_fused_adam_us", "dyn_graph_step_fused_adam"),
+                             ("without_table_links_us", "dyn_graph_step_fused_adam_no_abi13")):
+            if k_src in dyn:
+                us[k_dst] = _num(dyn[k_src], 4)
         out["configs_frac"], out["configs_launch_us"], out["configs_own_kernel"] = frac, us, own
         eager = configs.get("api_eager_us_per_call") or {}
         out["api_eager_us_per_call"] = {k.replace("compute_", ""): _num(v["us_per_call"], 4) for k, v in eager.items()

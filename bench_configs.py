@@ -139,6 +139,66 @@ def api_eager(model_panda, device, rows=65536, calls=300):
     return out
 
 
+def learn_dynamics_step(device, B=256):
+    """Not a BASELINE configuration; the reference's other learning workload (examples/learn_dynamics_iiwa.py:49-96, the L4DC notebook's
+    batch): iiwa, PositiveScalar masses, free centres of mass and inertia matrices of the seven links, MSE on the torques, Adam — the
+    whole step replayed from a hipGraph, with torch's default Adam and with its fused one (us per step, HIP events).  ABI 13's table
+    kernels (drm_walk_table_links) evaluate the parameter modules; `without_table_links_us`: the modules' torch kernels + cat instead."""
+    import torch
+    from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, UnconstrainedTensor
+    out = {"workload": "iiwa7, 21 parameter tensors (mass / com / inertia_mat of seven links), batch %d, forward + MSE + backward + Adam, "
+                       "replayed from a hipGraph" % B, "batch": B}
+    try:
+        for key, links_path, fused in (("graph_step_us", True, None), ("graph_step_fused_adam_us", True, True),
+                                       ("without_table_links_us", False, True)):
+            torch.manual_seed(0)
+            truth, m = load("iiwa7", device), load("iiwa7", device)
+            m._table_links = links_path
+            for k in range(1, 8):
+                m.make_link_param_learnable("iiwa_link_%d" % k, "mass", PositiveScalar())
+                m.make_link_param_learnable("iiwa_link_%d" % k, "com", UnconstrainedTensor(1, 3))
+                m.make_link_param_learnable("iiwa_link_%d" % k, "inertia_mat", UnconstrainedTensor(3, 3))
+            q, _ = uniform_q(m, B, device, 11)
+            qd, qdd = torch.rand(B, 7, device=device) - 0.5, torch.rand(B, 7, device=device) - 0.5
+            with torch.no_grad():
+                want = truth.compute_inverse_dynamics(q, qd, qdd)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True, fused=fused)
+
+            def step():
+                loss = torch.nn.functional.mse_loss(m.compute_inverse_dynamics(q, qd, qdd), want)
+                loss.backward()
+                opt.step()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    opt.zero_grad(set_to_none=True)
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            for _ in range(5):
+                graph.replay()
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(5):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(50):
+                    graph.replay()
+                e.record()
+                torch.cuda.synchronize()
+                times.append(s.elapsed_time(e) / 50 * 1e3)
+            out[key] = sorted(times)[len(times) // 2]
+            del graph
+        out["steps_per_s_fused_adam"] = 1e6 / out["graph_step_fused_adam_us"]
+    except Exception as err:   # pragma: no cover - depends on the runtime
+        out["error"] = repr(err)[:200]
+    return out
+
+
 def run_reference(jobs, arrays, reps=2, timeout=240):
     """oracle/ref_timing.py --jobs in its own interpreter on the host cores only; returns (record, outputs npz dict)."""
     import numpy as np
@@ -558,6 +618,7 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
 
     # ------------------------------------------------------------------ eager public-API overhead
     eager = api_eager(panda, device)
+    learn_dyn = learn_dynamics_step(device)
 
     # ------------------------------------------------------------------ the reference beside every leg (one subprocess)
     ref_meta = None
@@ -583,7 +644,7 @@ def run_config_legs(device, with_reference=True, with_traffic=True):
     if with_traffic and os.environ.get("DRM_BENCH_CHILD") != "1":
         torch.cuda.synchronize()
         fill_traffic(legs)
-    return {"legs": legs, "api_eager_us_per_call": eager, "reference_run": ref_meta,
+    return {"legs": legs, "api_eager_us_per_call": eager, "learn_dynamics_step": learn_dyn, "reference_run": ref_meta,
             "method": "launch_us: hipGraph of 30-100 launches, HIP events on the launch stream, median of 5 replays; reference: "
                       "oracle/ref_timing.py --jobs (unmodified reference, own interpreter, host cores only) in this run"}
 

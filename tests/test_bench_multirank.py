@@ -65,11 +65,14 @@ def test_compact_line_stays_small_and_strict():
             "configs": {"legs": [{"name": n, "own_kernel": True, "own_kernel_path": "default", "workload": prose,
                                   "roofline": {"frac": 0.5, "launch_us": float("inf")}} for n in
                                  ("config2", "config3_shard", "config3_whole", "config4", "config5")],
+                        "learn_dynamics_step": {"workload": prose, "graph_step_us": 131.0, "graph_step_fused_adam_us": 44.2,
+                                                "without_table_links_us": 101.0},
                         "api_eager_us_per_call": {"compute_forward_kinematics": {"us_per_call": 6.0}, "note": prose}}}
     line = bench.compact_line(full)
     text = json.dumps(line, allow_nan=False)          # raises on NaN / Infinity
     assert len(text) < 4096 and prose not in text
     assert line["roofline"]["traffic"] is None and line["configs_launch_us"]["c2"] is None
+    assert line["configs_launch_us"]["dyn_graph_step_fused_adam"] == 44.2 and line["configs_launch_us"]["dyn_graph_step_fused_adam_no_abi13"] == 101.0
     assert line["configs_frac"] == {"c2": 0.5, "c3_shard": 0.5, "c3_whole": 0.5, "c4": 0.5, "c5": 0.5}
     assert line["configs_own_kernel"]["c4"] == "default" and line["roofline_large"] == {"4194304": {"launch_us": 140.0, "frac": 0.84}}
     assert line["cpu_baseline"]["sample"].endswith("...") and line["cpu_baseline"]["port_cores"] == 128
