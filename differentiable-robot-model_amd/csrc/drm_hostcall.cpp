@@ -253,6 +253,28 @@ struct FastCall {
         return pybind11::make_tuple(wrap(view(0, {B, 3}, {3, 1}, {3}, {1})), wrap(view(o1, {B, 4}, {4, 1}, {4}, {1})), lin, ang);
     }
 
+    // compute_forward_kinematics_all_links (robot_model.py:197-221): the T targets of the walk through drm_fk_links' LINK-MAJOR outputs,
+    // handed back as a list of T (pos [B, 3], quat [B, 4]) pairs — contiguous views of ONE allocation, in the walk's target order.
+    // Batched q only (a 1-D q keeps the Python path, whose dictionary passes through tensor_check unsqueezed, as upstream's does).
+    pybind11::object links(pybind11::handle hq, int64_t T, int64_t stream) const {
+        const at::Tensor *q;
+        int64_t rows;
+        if (!take(hq, q, rows) || rows < 0 || T < 1 || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        const int64_t B = rows, o1 = pad4(T * B * 3), total = o1 + pad4(T * B * 4);
+        at::Tensor flat = at::empty({total}, q->options());
+        int64_t rc = 0;
+        if (B > 0) {
+            float *base = flat.data_ptr<float>();
+            rc = reinterpret_cast<fk_fn>(fn)(reinterpret_cast<const void *>(walk), q->data_ptr<float>(), B, (int32_t)T, base, base + o1,
+                                             reinterpret_cast<void *>(stream));
+        }
+        if (rc) return pybind11::int_(rc);
+        pybind11::list out(T);
+        for (int64_t t = 0; t < T; ++t)
+            out[t] = pybind11::make_tuple(wrap(flat.as_strided({B, 3}, {3, 1}, t * B * 3)), wrap(flat.as_strided({B, 4}, {4, 1}, o1 + t * B * 4)));
+        return out;
+    }
+
     // tau [B, n] ([n] for 1-D inputs); hqdd may be None (the non-linear effects)
     pybind11::object inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) const {
         const at::Tensor *q, *qd, *qdd = nullptr;
@@ -351,6 +373,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     pybind11::class_<FastCall>(m, "FastCall")
         .def(pybind11::init<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, int64_t, pybind11::object>())
         .def("kinematics", &FastCall::kinematics)
+        .def("links", &FastCall::links)
         .def("inverse_dynamics", &FastCall::inverse_dynamics)
         .def("inertia_matrix", &FastCall::inertia_matrix)
         .def("forward_dynamics", &FastCall::forward_dynamics)

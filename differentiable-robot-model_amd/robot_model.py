@@ -192,7 +192,7 @@ class DifferentiableRobotModel(torch.nn.Module):
                 "_fast_fk": dict, "_fast_jac": dict, "_fast_id": lambda: None, "_fast_crba": lambda: None, "_fast_fd": lambda: None,
                 "_fast_fkid": dict, "_source_plan": lambda: None, "_kin_cache": dict, "_kin_state": lambda: None,
                 "_stream_arg": lambda: None, "_arm_specialized": lambda: False}
-    _DERIVED_LAZY = ("_learnable_sorted", "_skew_any", "_dyn_walk_learnable", "_body_names", "_all_link_idxs")
+    _DERIVED_LAZY = ("_learnable_sorted", "_skew_any", "_dyn_walk_learnable", "_body_names", "_all_link_idxs", "_fast_links", "_fk_links_plans")
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -874,17 +874,49 @@ class DifferentiableRobotModel(torch.nn.Module):
                 quat[:, cols] = r
         return pos, quat
 
-    @tensor_check
     def compute_forward_kinematics_all_links(self, q: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
-        """{link_name: (pos [B,3], quat_xyzw [B,4])} for every link (robot_model.py:197-221)."""
+        """{link_name: (pos [B,3], quat_xyzw [B,4])} for every link (robot_model.py:197-221).  (Repeat calls of a constant model with a
+        batched q: one C++ call over drm_fk_links' link-major outputs, see compute_forward_kinematics.)"""
+        ent = self.__dict__.get("_fast_links")
+        if ent is not None and ent[1]._ws_cache is ent[2]:
+            pairs = ent[0].links(q, len(ent[3]), self._stream_arg())
+            if pairs.__class__ is list:
+                names, B = self.__dict__["_body_names"], q.shape[0]
+                out = dict.fromkeys(names)
+                out[names[0]] = (self._root_pose[0].expand(B, 3), self._root_pose[1].expand(B, 4))
+                for i, pair in zip(ent[3], pairs):
+                    out[names[i]] = pair
+                return out
+            if pairs is not None:
+                backend._check(pairs, backend.library_for(self._device))
+        return self._compute_forward_kinematics_all_links(q)
+
+    @tensor_check
+    def _compute_forward_kinematics_all_links(self, q: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
         assert q.ndim == 2
         assert q.shape[1] == self._n_dofs
         names = self.__dict__.get("_body_names")
         if names is None:       # (ModuleList indexing costs ~3 us per link and call)
             names = self.__dict__["_body_names"] = [b.name for b in self._bodies]
             self.__dict__["_all_link_idxs"] = list(range(len(names)))
+        ent = self.__dict__.get("_fast_links")
         cols = self._fk_links(q, self.__dict__["_all_link_idxs"])
+        if ent is None or ent[1]._ws_cache is not ent[2]:
+            self.__dict__["_fast_links"] = self._fast_links_entry()
         return {name: cols[i] for i, name in enumerate(names)}
+
+    def _fast_links_entry(self) -> Optional[tuple]:
+        """(FastCall of drm_fk_links over every non-root link, its walk program, the program's struct cache, the links in the walk's
+        target order) — None for models the prepared call does not serve (learnable parameters, a robot of one link, no C++ host path)."""
+        plan = self.__dict__.get("_fk_links_plans", {}).get(tuple(self.__dict__["_all_link_idxs"]))
+        if plan is None or not plan[0] or len(plan[1]) < 2 or self._root_pose is None:
+            return None
+        ordered = plan[1]
+        dw = self._get_walk(("fk", tuple(ordered)), targets=ordered)
+        if self._fanout_chains(ordered, dw) is not None:
+            return None
+        ent = self._fast_entry("drm_fk_links", None, dw)
+        return None if ent is None else ent + (list(ordered),)
 
     @tensor_check
     def compute_forward_kinematics_links(self, q: torch.Tensor, link_names: List[str]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
@@ -1367,6 +1399,7 @@ class DifferentiableRobotModel(torch.nn.Module):
             dw.program._ws_cache = None
         self._arm_specialized = False
         self._fast_fk.clear(); self._fast_jac.clear(); self._fast_fkid.clear()    # (prepared calls snapshot the constants)
+        self.__dict__.pop("_fast_links", None)
         self._fast_id = self._fast_crba = self._fast_fd = None
         self._fanout_plans.clear()      # (they may hold folded chain walks, which are for models without learnable parameters)
         self._fan_handles.clear()       # (kernels that bake the OLD constants)

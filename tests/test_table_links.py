@@ -352,3 +352,36 @@ def test_forms_against_the_references_own_modules(case, device):
     for key, g, want in zip(list(G[case + "/keys"]) + ["q", "qd", "qdd"], grads, wants):
         got = np.zeros_like(want) if g is None else g.detach().cpu().numpy().reshape(want.shape)
         assert float(np.abs(got - want).max()) <= 2e-4 * float(np.abs(want).max()) + floor, (case, key)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("robot", ["panda_no_gripper", "allegro_left", "fetch"])
+def test_repeat_all_links_calls_take_the_prepared_call(device, robot, hostcall_module):
+    """compute_forward_kinematics_all_links of a constant model, second call on: ONE C++ call over drm_fk_links' link-major outputs
+    (FastCall.links) — the same dictionary, bit for bit, as the first call through the Python path; another batch size, a 1-D q
+    (Python path), gradients wanted (Python path) and a parameter made learnable afterwards (the prepared call is dropped)."""
+    from helpers import load_model
+    m = load_model(robot, device)
+    n = m._n_dofs
+    g = torch.Generator().manual_seed(5)
+    q = (torch.rand(130, n, generator=g) - 0.5).to(device)
+    first = m.compute_forward_kinematics_all_links(q)
+    assert m.__dict__.get("_fast_links") is not None
+    again = m.compute_forward_kinematics_all_links(q)
+    assert list(first) == list(again) == [b.name for b in m._bodies]
+    for name in first:
+        assert torch.equal(first[name][0], again[name][0]) and torch.equal(first[name][1], again[name][1]), name
+        assert again[name][0].shape == (130, 3) and again[name][1].shape == (130, 4)
+    other = m.compute_forward_kinematics_all_links(q[:7])
+    assert all(torch.equal(other[k][0], first[k][0][:7]) for k in first)
+    one = m.compute_forward_kinematics_all_links(q[3])
+    assert all(torch.equal(one[k][0][0], first[k][0][3]) for k in first)
+    x = q.clone().requires_grad_(True)
+    diff = m.compute_forward_kinematics_all_links(x)
+    last = list(diff)[-1]
+    assert diff[last][0].requires_grad and torch.allclose(diff[last][0].detach(), first[last][0], atol=1e-6)
+    link = m._bodies[-1].name
+    m.make_link_param_learnable(link, "trans", UnconstrainedTensor(1, 3))
+    assert m.__dict__.get("_fast_links") is None
+    moved = m.compute_forward_kinematics_all_links(q)
+    assert not torch.equal(moved[link][0], first[link][0]) and m.__dict__.get("_fast_links") is None
