@@ -297,14 +297,13 @@ def _walk_struct(prog: WalkProgram, ops_f: torch.Tensor, ops_i: torch.Tensor, n_
             return cached[1]
         if cached[0][1:] == key[1:] and key[0] and cached[0][0]:
             # a model with learnable links: a NEW table on every call, everything else as before — the struct is read by the C side
-            # while the call is made, so the one of the last call takes the new address (a new cache entry: prepared calls that hold
-            # the old one by identity look again)
+            # while the call is made, so the one of the last call takes the new address
             w = cached[1]
             w.ops_f = key[0]
-            prog._ws_cache = (key, w)
+            cached[0] = key      # (the SAME cache entry: prepared calls of a learnable model — which own a copy of the struct — stay valid)
             return w
     w = _walk_struct_build(prog, ops_f, ops_i, n_dofs)
-    prog._ws_cache = (key, w)
+    prog._ws_cache = [key, w]
     return w
 
 

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <tuple>
+#include <vector>
 
 namespace {
 constexpr int64_t NOT_CONFORMING = 1; // (the C ABI's own codes are <= 0)
@@ -25,6 +26,7 @@ typedef int (*crba_fn)(const void *, const float *, int64_t, float *, float *, v
 typedef int (*fk_rnea_fn)(const void *, const void *, int32_t, const float *, const float *, const float *, int64_t, int32_t, float *, float *,
                           float *, float *, void *);
 typedef int (*fd_fn)(const void *, const float *, const float *, const float *, int64_t, int32_t, float *, float *, void *);
+typedef int (*table_links_fn)(const void *, const void *, int32_t, const float *, const int32_t *, const float *, int32_t, float *, void *);
 
 inline int64_t pad4(int64_t x) { return (x + 3) & ~int64_t(3); } // every output starts on a 16-byte boundary
 inline bool conforms(const at::Tensor &t, int64_t cols) {
@@ -197,6 +199,57 @@ struct FastCall {
         : fn(fn_), scratch_query(scratch_query_), walk(walk_), walk2(walk2_), n(n_), target_op(target_op_), cuda(cuda_),
           device_index(device_index_), keep(std::move(keep_)) {}
 
+    // ---- a model WITH learnable link parameters (round 6, ABI 13): its walk table is rebuilt from the parameter tensors in front of
+    // every call (drm_walk_table_links: one small launch on the same stream) — when the call builds no autograd graph, i.e. under
+    // torch.no_grad() or with every parameter frozen: a learned model in a control loop.  Every live piece is looked up in its
+    // module's own parameter dictionary on every call (a parameter that was moved, replaced or re-typed is seen; one the kernels
+    // cannot read as it lies sends the call to the Python path).  `walk` is then this call's OWN copy of the struct: its table
+    // pointer is rewritten per call.
+    int64_t table_fn = 0, forms = 0, n_links = 0, base = 0, sel = 0, gsign = 0, n_entries = 0;
+    std::vector<const float *> pieces;                  // n_links x 6 (struct drm_link_pieces)
+    std::vector<int64_t> live_slot, live_size;          // the slots of `pieces` that parameter modules supply, and their element counts
+    std::vector<pybind11::object> live_dict, live_key;  // module._parameters, the parameter's name
+    at::Tensor base_tensor;
+
+    void set_table(int64_t table_fn_, int64_t links_, int64_t forms_, int64_t n_links_, const at::Tensor &base_, int64_t sel_, int64_t gsign_,
+                   std::vector<int64_t> slots, std::vector<int64_t> sizes, std::vector<pybind11::object> dicts, std::vector<pybind11::object> keys) {
+        TORCH_CHECK(slots.size() == sizes.size() && slots.size() == dicts.size() && slots.size() == keys.size(), "set_table: ragged lists");
+        table_fn = table_fn_; forms = forms_; n_links = n_links_; sel = sel_; gsign = gsign_;
+        base_tensor = base_; base = reinterpret_cast<int64_t>(base_.data_ptr()); n_entries = base_.numel();
+        const float *const *src = reinterpret_cast<const float *const *>(links_);
+        pieces.assign(src, src + n_links_ * 6);
+        live_slot = std::move(slots); live_size = std::move(sizes); live_dict = std::move(dicts); live_key = std::move(keys);
+    }
+    // 1: the table is built (held keeps it alive until the launches are enqueued), 0: not servable here (the Python path), < 0: an error code
+    int64_t table(int64_t stream, at::Tensor &held) {
+        const bool grad = at::GradMode::is_enabled();
+        for (size_t i = 0; i < live_slot.size(); ++i) {
+            PyObject *o = PyDict_GetItemWithError(live_dict[i].ptr(), live_key[i].ptr());     // (borrowed)
+            if (!o) { PyErr_Clear(); return 0; }
+            if (!THPVariable_Check(o)) return 0;
+            const at::Tensor &t = THPVariable_Unpack(o);
+            if ((grad && t.requires_grad()) || t.scalar_type() != at::kFloat || !t.is_contiguous() || t.numel() != live_size[i] ||
+                t.is_cuda() != cuda || (cuda && t.get_device() != device_index))
+                return 0;
+            pieces[(size_t)live_slot[i]] = t.data_ptr<float>();
+        }
+        held = at::empty_like(base_tensor);
+        const int rc = reinterpret_cast<table_links_fn>(table_fn)(pieces.data(), reinterpret_cast<const void *>(forms), (int32_t)n_links,
+                                                                   reinterpret_cast<const float *>(base), reinterpret_cast<const int32_t *>(sel),
+                                                                   reinterpret_cast<const float *>(gsign), (int32_t)n_entries,
+                                                                   held.data_ptr<float>(), reinterpret_cast<void *>(stream));
+        if (rc) return rc;
+        *reinterpret_cast<void **>(walk) = held.data_ptr();      // (drm_walk.ops_f is the struct's first member)
+        return 1;
+    }
+#define DRM_FAST_TABLE(stream)                                                  \
+    at::Tensor table_held;                                                      \
+    if (table_fn) {                                                             \
+        const int64_t trc = table(stream, table_held);                          \
+        if (trc == 0) return pybind11::none();                                  \
+        if (trc < 0) return pybind11::int_(trc);                                \
+    }
+
     // the tensor behind a Python argument when it is EXACTLY a torch.Tensor (tensor_check tests `type(arg) is torch.Tensor`) that the
     // kernels take as it stands; rows = -1 for a 1-D tensor
     bool take(pybind11::handle h, const at::Tensor *&out, int64_t &rows) const {
@@ -223,10 +276,11 @@ struct FastCall {
     static pybind11::object wrap(const at::Tensor &t) { return pybind11::reinterpret_steal<pybind11::object>(THPVariable_Wrap(t)); }
 
     // kind 0: (pos, quat);  1: (lin_jac, ang_jac);  2: (pos, quat, lin_jac, ang_jac)
-    pybind11::object kinematics(pybind11::handle hq, int64_t kind, int64_t stream) const {
+    pybind11::object kinematics(pybind11::handle hq, int64_t kind, int64_t stream) {
         const at::Tensor *q;
         int64_t rows;
         if (!take(hq, q, rows) || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        DRM_FAST_TABLE(stream)
         const bool one = rows < 0;
         const int64_t B = one ? 1 : rows;
         const int64_t o1 = pad4(B * 3), o2 = o1 + pad4(B * 4), o3 = kind ? o2 + pad4(B * 3 * n) : o2, total = kind ? o3 + pad4(B * 3 * n) : o2;
@@ -256,10 +310,11 @@ struct FastCall {
     // compute_forward_kinematics_all_links (robot_model.py:197-221): the T targets of the walk through drm_fk_links' LINK-MAJOR outputs,
     // handed back as a list of T (pos [B, 3], quat [B, 4]) pairs — contiguous views of ONE allocation, in the walk's target order.
     // Batched q only (a 1-D q keeps the Python path, whose dictionary passes through tensor_check unsqueezed, as upstream's does).
-    pybind11::object links(pybind11::handle hq, int64_t T, int64_t stream) const {
+    pybind11::object links(pybind11::handle hq, int64_t T, int64_t stream) {
         const at::Tensor *q;
         int64_t rows;
         if (!take(hq, q, rows) || rows < 0 || T < 1 || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        DRM_FAST_TABLE(stream)
         const int64_t B = rows, o1 = pad4(T * B * 3), total = o1 + pad4(T * B * 4);
         at::Tensor flat = at::empty({total}, q->options());
         int64_t rc = 0;
@@ -276,12 +331,13 @@ struct FastCall {
     }
 
     // tau [B, n] ([n] for 1-D inputs); hqdd may be None (the non-linear effects)
-    pybind11::object inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) const {
+    pybind11::object inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) {
         const at::Tensor *q, *qd, *qdd = nullptr;
         int64_t rows, rows_d, rows_dd;
         if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || rows_d != rows) return pybind11::none();
         if (!hqdd.is_none() && (!take(hqdd, qdd, rows_dd) || rows_dd != rows)) return pybind11::none();
         if (graph_wanted(*q) || graph_wanted(*qd) || (qdd && graph_wanted(*qdd)) || !device_is_current()) return pybind11::none();
+        DRM_FAST_TABLE(stream)
         const bool one = rows < 0;
         const int64_t B = one ? 1 : rows;
         at::Tensor tau = one ? at::empty({n}, q->options()) : at::empty({B, n}, q->options());
@@ -299,10 +355,11 @@ struct FastCall {
     }
 
     // H [B, n, n] ([n, n] for a 1-D q): drm_crba
-    pybind11::object inertia_matrix(pybind11::handle hq, int64_t stream) const {
+    pybind11::object inertia_matrix(pybind11::handle hq, int64_t stream) {
         const at::Tensor *q;
         int64_t rows;
         if (!take(hq, q, rows) || graph_wanted(*q) || !device_is_current()) return pybind11::none();
+        DRM_FAST_TABLE(stream)
         const bool one = rows < 0;
         const int64_t B = one ? 1 : rows;
         at::Tensor H = one ? at::empty({n, n}, q->options()) : at::empty({B, n, n}, q->options());
@@ -319,11 +376,12 @@ struct FastCall {
     }
 
     // qdd [B, n]: drm_forward_dynamics
-    pybind11::object forward_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hf, int64_t flags, int64_t stream) const {
+    pybind11::object forward_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hf, int64_t flags, int64_t stream) {
         const at::Tensor *q, *qd, *f;
         int64_t rows, rows_d, rows_f;
         if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || !take(hf, f, rows_f) || rows_d != rows || rows_f != rows) return pybind11::none();
         if (graph_wanted(*q) || graph_wanted(*qd) || graph_wanted(*f) || !device_is_current()) return pybind11::none();
+        DRM_FAST_TABLE(stream)
         const bool one = rows < 0;
         const int64_t B = one ? 1 : rows;
         at::Tensor qdd = one ? at::empty({n}, q->options()) : at::empty({B, n}, q->options());
@@ -343,6 +401,7 @@ struct FastCall {
     // (tau [B, n], pos [B, 3], quat [B, 4]): drm_fk_rnea on (walk = the dynamics walk, walk2 = the target's chain walk)
     pybind11::object fk_inverse_dynamics(pybind11::handle hq, pybind11::handle hqd, pybind11::handle hqdd, int64_t flags, int64_t stream) const {
         const at::Tensor *q, *qd, *qdd;
+        if (table_fn) return pybind11::none();      // (two walks, two tables: the Python path)
         int64_t rows, rows_d, rows_dd;
         if (!take(hq, q, rows) || !take(hqd, qd, rows_d) || !take(hqdd, qdd, rows_dd) || rows_d != rows || rows_dd != rows) return pybind11::none();
         if (!device_is_current()) return pybind11::none();      // (this entry point is not differentiable: no graph test)
@@ -372,6 +431,7 @@ struct FastCall {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     pybind11::class_<FastCall>(m, "FastCall")
         .def(pybind11::init<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, int64_t, pybind11::object>())
+        .def("set_table", &FastCall::set_table)
         .def("kinematics", &FastCall::kinematics)
         .def("links", &FastCall::links)
         .def("inverse_dynamics", &FastCall::inverse_dynamics)

@@ -568,7 +568,7 @@ class DifferentiableRobotModel(torch.nn.Module):
         key = tuple(links)
         cached = self._source_plan
         if cached is None or cached[0] != key:
-            entries, fixed, getters = [], [], []
+            entries, fixed, getters, refs = [], [], [], []      # refs: (module._parameters, name) of a live piece, None for a module's call
             for i in links:
                 b = self._bodies[i]
                 link = []
@@ -594,12 +594,15 @@ class DifferentiableRobotModel(torch.nn.Module):
                     link.append((form, const, fn if form != backend.FORM_PLAIN else None))
                     if form != backend.FORM_PLAIN:           # (the module's own dictionary: nn.Module.__getattr__ is three times slower)
                         getters.append(lambda d=fn._parameters: d["l"])
+                        refs.append((fn._parameters, "l"))
                     elif kind in (rbp.UnconstrainedTensor, rbp.UnconstrainedScalar):
                         getters.append(lambda d=fn._parameters: d["param"])
+                        refs.append((fn._parameters, "param"))
                     else:
                         getters.append(fn)
+                        refs.append(None)
                 entries.append(link)
-            cached = self._source_plan = (key, backend.LinkSourcePlan(entries, fixed), getters)
+            cached = self._source_plan = (key, backend.LinkSourcePlan(entries, fixed), getters, refs)
         return cached[1], [g() for g in cached[2]]
 
     def _learnable_plan(self, dw: _DeviceWalk):
@@ -836,6 +839,36 @@ class DifferentiableRobotModel(torch.nn.Module):
             out.update(zip(ordered, zip(pos.unbind(1), quat.unbind(1))))
         return out
 
+    def _fast_entry_learnable(self, fast, entry: str, scratch: Optional[str], dw: "_DeviceWalk", chain, target_op: int) -> Optional[tuple]:
+        """The prepared call of a model WITH learnable link parameters (round 6): the C++ side rebuilds the walk table from the parameter
+        tensors in front of every call (drm_walk_table_links, looked up in the modules' own parameter dictionaries each time) whenever
+        the call builds no autograd graph — torch.no_grad(), or every parameter frozen: a learned model in a control loop costs what a
+        constant one does plus one small launch.  None where the table does not come from the links path, a live piece is the output of
+        a module the kernels do not know, or the call needs two walks."""
+        import ctypes
+        if (chain is not None or not hasattr(fast.FastCall, "set_table") or not self._table_links or self._has_skew()
+                or len(self._learnable_link_list()) > 32):
+            return None
+        links, base, sel = self._learnable_plan(dw)
+        plan, sources = self._learnable_sources(links)
+        refs = self._source_plan[3]
+        if any(r is None for r in refs) or any(t.device != self._device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n
+                                              for t, n in zip(sources, plan.sizes)):
+            return None
+        lib = backend.library_for(self._device)
+        with torch.no_grad():
+            ops_f = self._ops_f(dw)
+        shared = backend._walk_struct(dw.program, ops_f.detach(), dw.ops_i, self._n_dofs)
+        walk = backend.DrmWalk.from_buffer_copy(shared)      # (this call's own struct: the C++ side rewrites its table pointer per call)
+        pieces = plan.pieces(sources)
+        keep = [walk, dw.ops_i, lib, plan, base, sel, dw.gsign]
+        call = fast.FastCall(backend._fn_addr(lib, entry), backend._fn_addr(lib, scratch) if scratch else 0, ctypes.addressof(walk), 0,
+                             self._n_dofs, target_op, self._device.type == "cuda",
+                             self._device.index if self._device.index is not None else -1, tuple(keep))
+        call.set_table(backend._fn_addr(lib, "drm_walk_table_links"), ctypes.addressof(pieces), ctypes.addressof(plan.forms), plan.n_links,
+                       base, sel.data_ptr(), dw.gsign.data_ptr(), list(plan.live), list(plan.sizes), [r[0] for r in refs], [r[1] for r in refs])
+        return (call, dw.program, dw.program._ws_cache)
+
     def _fk_targets(self, q: torch.Tensor, link_idxs: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
         """pos [B,T,3], quat [B,T,4] of the given links (root targets filled with the identity pose)."""
         self._require_device()
@@ -936,8 +969,10 @@ class DifferentiableRobotModel(torch.nn.Module):
         a device kind the path does not serve.  The call stays valid while the program's struct cache does (the identity is checked
         per call): attaching own kernels or rebuilding the table retires it and the next call through the Python path renews it."""
         fast = backend.hostcall()
-        if fast is None or not hasattr(fast, "FastCall") or self._learnable or self._device.type not in ("cuda", "cpu"):
+        if fast is None or not hasattr(fast, "FastCall") or self._device.type not in ("cuda", "cpu"):
             return None
+        if self._learnable:
+            return self._fast_entry_learnable(fast, entry, scratch, dw, chain, target_op)
         import ctypes
         lib = backend.library_for(self._device)
         ops_f = self._ops_f(dw)
