@@ -131,6 +131,28 @@ def api_eager(model_panda, device, rows=65536, calls=300):
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / calls * 1e6)
         out[name] = {"us_per_call": best, "evals_per_s": rows / best * 1e6}
+    # a LEARNED model (the Panda's link 4 with a PositiveScalar mass and an SPD inertia matrix) where no graph is built: the prepared
+    # call rebuilds the walk table from the parameter tensors in front of the launch (two launches per call)
+    try:
+        from differentiable_robot_model_amd.rigid_body_params import PositiveScalar, SymmPosDef3DInertiaMatrixNet
+        learned = load("panda_no_gripper", device)
+        learned.make_link_param_learnable("panda_link4", "mass", PositiveScalar())
+        learned.make_link_param_learnable("panda_link4", "inertia_mat", SymmPosDef3DInertiaMatrixNet())
+        with torch.no_grad():
+            fn = lambda: learned.compute_inverse_dynamics(q, qd, qdd)
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    fn()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / calls * 1e6)
+        out["learned_model_inverse_dynamics"] = {"us_per_call": best, "evals_per_s": rows / best * 1e6}
+    except Exception as err:   # pragma: no cover - depends on the runtime
+        out["learned_model_error"] = repr(err)[:160]
     from differentiable_robot_model_amd import backend
     out["host_path"] = "csrc/drm_hostcall.so (C++)" if backend.hostcall() is not None else "Python + ctypes"
     out["note"] = ("eager public-API calls: tensor_check in Python, then input checks, ONE output allocation and the C-ABI call — in "

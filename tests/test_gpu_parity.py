@@ -990,7 +990,7 @@ def test_bench_line_carries_the_contract_fields(tmp_path):
     # round 6: the drop-in path IS the benchmarked path — a constant model picks its own (shipped) kernels up by itself
     own_off = os.environ.get("DRM_SPECIALIZE") == "0"      # (the suite run on the library's kernels: nothing is attached)
     assert own_off or d["configs_own_kernel"] == {"c3_shard": "default", "c3_whole": "default", "c4": "default"}, d["configs_own_kernel"]
-    assert set(d["api_eager_us_per_call"]) == {"forward_kinematics", "endeffector_jacobian", "inverse_dynamics"}
+    assert set(d["api_eager_us_per_call"]) == {"forward_kinematics", "endeffector_jacobian", "inverse_dynamics", "learned_model_inverse_dynamics"}
 
     # ---- the full record (--detail): what the compact line was cut from
     with open(detail) as f:
