@@ -27,6 +27,8 @@ def cpu_library():
 def hostcall_module():
     """csrc/drm_hostcall.so — the per-call host work of the hot public methods as a torch C++ extension — built if it is missing or
     older than its source (~30 s), as `__graft_entry__.build()` does."""
+    if os.environ.get("DRM_NO_HOSTCALL") == "1":
+        pytest.skip("DRM_NO_HOSTCALL=1: this run exercises the Python host path")
     import __graft_entry__ as entry
     entry.build_hostcall()
     import importlib

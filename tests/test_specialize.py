@@ -298,9 +298,12 @@ def test_gpu_fetch_rnea_backward_own_kernel_vs_loop_kernel(compat):
 @pytest.mark.gpu
 @needs_hipcc
 @pytest.mark.parametrize("robot", ["panda", "jaco"])
-def test_gpu_tuned_choice_between_shape_kernels_and_own_kernels(robot):
+def test_gpu_tuned_choice_between_shape_kernels_and_own_kernels(robot, tmp_path, monkeypatch):
     """specialize(tune=True): an arm that carries a hand builds its own kernels too and keeps, per entry point, whichever is faster
-    on this device; whatever was kept, every entry point still meets the fp64 oracle and the untuned model."""
+    on this device; whatever was kept, every entry point still meets the fp64 oracle and the untuned model.  (Its own run-time cache:
+    the record this machine's measurement leaves must not decide what LATER tests' models attach — a kernel that wins by a few per cent
+    in the shipped record may lose here.)"""
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path / "runtime"))
     mc, plain, tuned = load_model(robot), library_only(load_model(robot, "cuda")), load_model(robot, "cuda")
     report = tuned.specialize(tune=True)
     assert set(report) == set(sp.KERNELS.values())
@@ -1020,12 +1023,13 @@ def test_tuning_records_limit_what_a_model_attaches(tmp_path, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot", ["fetch", "panda", "jaco"])
-def test_gpu_shipped_tree_robots_run_their_tuned_entry_points_by_default(robot):
+def test_gpu_shipped_tree_robots_run_their_tuned_entry_points_by_default(robot, tmp_path, monkeypatch):
     """Robots that are not plain arms (round 6): the whole-tree kernels of Fetch, the Panda with its gripper and the Jaco ship with the
     package together with a tuning record measured on an MI355X (tools/tune_shipped.py, profiles/r06_tune_shipped.txt); a plain
     DifferentiableRobotModel(urdf, device="cuda") attaches exactly the entry points the record keeps — and the four entry points agree
     with the library's kernels."""
     import json
+    monkeypatch.setenv("DRM_SPECIAL_CACHE", str(tmp_path / "runtime"))     # (an empty run-time cache: the SHIPPED record decides)
     own, plain = load_model(robot, "cuda"), library_only(load_model(robot, "cuda"))
     special = own._dynamics_walk().program._special
     path = own._dynamics_walk().program._special_path
