@@ -82,6 +82,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_api -- python 
 python $ROOT/tools/bench_config5.py 2>&1 | grep '^config5\|^  kernels' > $OUT/config5.txt
 python $ROOT/tools/probe_special.py fetch 2>&1 | grep "^fetch" > $OUT/probe_special.txt
 python $ROOT/tools/api_profile.py 2>&1 | grep "us per eager call" > $OUT/api_latency.txt
+DRM_NO_HOSTCALL=1 python $ROOT/tools/api_profile.py 2>&1 | grep "learned model" | sed "s/^/(DRM_NO_HOSTCALL=1: the Python path) /" >> $OUT/api_latency.txt
 python $ROOT/tools/ab_fan.py 2>&1 | grep "B=" > $OUT/ab_fan.txt
 if [ -f $ROOT/tools/variants/libdrm_timeline.so ]; then
   DRM_HIP_LIBRARY=$ROOT/tools/variants/libdrm_timeline.so python $ROOT/tools/timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/timeline.txt
